@@ -1,0 +1,105 @@
+"""CPU tests of the oracle itself: the checker must be right before it checks
+anything.  (1) known-answer vectors recorded from the reference;
+(2) brute-force definition checker on random tiny inputs, all modes;
+(3) SA/LCP/BWT stream against a naive sort."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from bruteforce import bruteforce_lines
+from mumemto_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_known_answer_vectors():
+    spec = json.load(open(os.path.join(HERE, "golden", "toy_vectors.json")))
+    for v in spec["vectors"]:
+        docs = [[r.encode() for r in d] for d in v["docs"]]
+        r = O.run(docs, min_len=v["min_len"], revcomp=v["revcomp"], max_doc_freq=v["max_doc_freq"])
+        assert r.text() == v["expect"].encode(), v
+
+
+def test_stream_against_naive_sort():
+    rng = np.random.default_rng(5)
+    for trial in range(30):
+        n = int(rng.integers(1, 200))
+        text = rng.choice(np.frombuffer(b"$ACGTN", np.uint8), size=n).astype(np.uint8)
+        sa, lcp, bwt = O.build_stream(text)
+        t = text.tobytes()
+        order = sorted(range(n), key=lambda i: t[i:])
+        assert sa[0] == n and list(sa[1:]) == order
+        assert lcp[0] == 0 and lcp[1] == 0
+        for j in range(2, n + 1):
+            a, b = t[sa[j - 1]:], t[sa[j]:]
+            k = 0
+            while k < min(len(a), len(b)) and a[k] == b[k]:
+                k += 1
+            assert lcp[j] == k
+        for j in range(n + 1):
+            assert bwt[j] == (t[sa[j] - 1] if sa[j] > 0 else 0)
+
+
+def _random_docs(rng, n_docs):
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(25, 60))).astype(np.uint8)
+    docs = []
+    for _ in range(n_docs):
+        s = base.copy()
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, len(s)))] = rng.choice(np.frombuffer(b"ACGTN", np.uint8))
+        if rng.random() < 0.3:  # reverse-complement a doc so '-' strand rows appear
+            comp = {65: 84, 67: 71, 71: 67, 84: 65, 78: 78}
+            s = np.array([comp[c] for c in s[::-1]], np.uint8)
+        if rng.random() < 0.3:
+            s = np.concatenate([s, s[: int(rng.integers(5, 20))]])
+        docs.append([s.tobytes()])
+    return docs
+
+
+@pytest.mark.parametrize("mode", ["mum", "partial", "mem", "mem_capped", "mem_unlimited"])
+def test_scan_against_bruteforce(mode):
+    rng = np.random.default_rng({"mum": 1, "partial": 2, "mem": 3, "mem_capped": 4, "mem_unlimited": 6}[mode])
+    for trial in range(25):
+        n_docs = int(rng.integers(2, 5))
+        docs = _random_docs(rng, n_docs)
+        revcomp = bool(rng.integers(0, 2))
+        min_len = int(rng.integers(3, 9))
+        nd, f, F = {"mum": (n_docs, 1, 0), "partial": (max(2, n_docs - 1), 1, 0), "mem": (n_docs, 2, 0),
+                    "mem_capped": (2, 3, n_docs + 1), "mem_unlimited": (2, 0, 0)}[mode]
+        text, doc_start = O.build_text(docs, revcomp)
+        sa, lcp, bwt = O.build_stream(text)
+        got = O.scan(sa, lcp, bwt, doc_start, min_len=min_len, num_distinct=nd, max_doc_freq=f,
+                     max_total_freq=F, revcomp=revcomp).text()
+        want = bruteforce_lines(text, list(doc_start), min_len, nd, f, F, revcomp)
+        assert got == want, (mode, trial, docs, revcomp, min_len)
+
+
+def test_cli_param_normalisation():
+    # include/pfp_mum.hpp:149-198
+    assert O.cli_params(16) == (16, 1, 16)
+    assert O.cli_params(94, k=-1, f=3) == (93, 3, 282)
+    assert O.cli_params(5, k=1) == (2, 1, 5)
+    assert O.cli_params(5, k=9) == (5, 1, 5)
+    assert O.cli_params(5, k=-9) == (2, 1, 5)
+    assert O.cli_params(5, f=0, k=2, F=100) == (2, 0, 100)
+    assert O.cli_params(5, f=2, F=100) == (5, 2, 10)
+    assert O.cli_params(5, f=2, F=-1) == (5, 2, 4)
+    assert O.cli_params(5, f=0, F=1) == (5, 0, 0)
+
+
+def test_thresholds_and_accepted_lists():
+    docs = synth.pangenome(4, 3000, 0.02, seed=11, inversion=(2, 500, 900))
+    r = O.run(docs, merge=True)
+    th = r.thresh()
+    assert len(th) == 2 * (3000 + 1)
+    acc, iv = r.accepted(), r.intervals()
+    assert len(acc) >= len(iv) > 0
+    # every emitted interval is also an accepted candidate, same order
+    keys = {tuple(x) for x in acc.tolist()}
+    assert all(tuple(x) in keys for x in iv.tolist())
+    # emitted intervals come out in (closing j asc, length desc) order
+    k = [(x[3], -x[2]) for x in iv.tolist()]
+    assert k == sorted(k)

@@ -1,0 +1,130 @@
+/* mumemto_gpu.h -- device-resident entry points of libmumemto (MI355X).
+ *
+ * The drop-in ABI (mumemto.h) takes host strings, like the reference.  These
+ * entry points expose the same hot path with inputs already in HBM, stage by
+ * stage, for bench.py, the parity tests and multi-GPU drivers.  Plain C ABI:
+ * pointers and sizes only.  Every call returns 0 on success; on failure the
+ * message is in mmt_last_error() (thread-local) and nothing falls back to a
+ * CPU path.
+ *
+ * Reference interfaces replaced (file:line under the reference tree):
+ *   text layout           RefBuilder::build_input_file   src/ref_builder.cpp:211-314, :330-384
+ *   SA/LCP/BWT stream     gsacak_lcp / pfp_lcp::process  include/direct_gsacak.hpp:50-116,
+ *                                                        include/pfp_lcp_mum.hpp:115-231
+ *   match scan            mem_finder::update             include/mem_finder.hpp:161-170, :304-355
+ *   writers               write_mum / write_mem / close  include/mem_finder.hpp:104-158, :210-263, :357-428
+ *   partition merge       merge_partitions               src/merge_candidates.cpp:97-157
+ */
+#ifndef MUMEMTO_GPU_H
+#define MUMEMTO_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__) || defined(__clang__)
+#define MMT_API __attribute__((visibility("default")))
+#else
+#define MMT_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmt_engine mmt_engine;
+
+/* Scan predicates, named as in mem_finder's constructor (mem_finder.hpp:53).
+ * CLI flag normalisation (pfp_mum.hpp:149-198) is the caller's job.          */
+typedef struct mmt_params {
+    uint32_t min_match_len;   /* -l, default 20                               */
+    uint64_t num_distinct;    /* matches must occur in >= this many docs; 0 = all */
+    int64_t  max_doc_freq;    /* 1 = multi-MUM mode; 0 = unlimited            */
+    int64_t  max_total_freq;  /* 0 = no cap                                   */
+    uint8_t  use_revcomp;     /* text holds F$ R$ per document                */
+    uint8_t  merge_metadata;  /* record candidate thresholds (-M / -n)        */
+} mmt_params;
+
+MMT_API const char* mmt_last_error(void);
+
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or
+ * NULL for a stream owned by the engine.                                      */
+MMT_API int  mmt_engine_create(int device, void* hip_stream, mmt_engine** out);
+MMT_API void mmt_engine_destroy(mmt_engine* e);
+
+/* Input = concatenated raw forward bases of all documents (records of one
+ * document concatenated, no separators; any case) + per-document lengths.
+ * _device: d_bases is HBM memory borrowed until the next set_input/destroy.   */
+MMT_API int mmt_engine_set_input_device(mmt_engine* e, const uint8_t* d_bases,
+                                        const uint64_t* doc_len, size_t n_docs);
+MMT_API int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases,
+                                      const uint64_t* doc_len, size_t n_docs);
+
+/* One pass of the hot path: text -> SA/LCP/BWT -> scan -> rows (+ thresholds). */
+MMT_API int mmt_engine_run(mmt_engine* e, const mmt_params* p);
+
+/* ---- results of the last run (host memory owned by the engine) ------------ */
+MMT_API size_t mmt_num_rows(const mmt_engine* e);
+MMT_API size_t mmt_num_docs(const mmt_engine* e);
+/* MUM mode: length[n_rows], offsets[n_rows*n_docs] (-1 absent), strands (1 '+') */
+MMT_API int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands);
+/* MEM mode: occ_start[n_rows+1]; flat offsets / doc ids / strands              */
+MMT_API size_t mmt_num_occ(const mmt_engine* e);
+MMT_API int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start,
+                         int64_t* offsets, uint64_t* seq_ids, uint8_t* strands);
+/* PREFIX.mums / PREFIX.mems bytes exactly as the CLI writes them.              */
+MMT_API const char* mmt_output_text(mmt_engine* e, size_t* len);
+/* PREFIX.bumbl bytes (MUM mode).                                               */
+MMT_API const uint8_t* mmt_output_bumbl(mmt_engine* e, size_t* len);
+/* candidate_thresh (u16, 2*(L_0+1) entries) when merge_metadata was set.       */
+MMT_API size_t mmt_thresh_len(const mmt_engine* e);
+MMT_API int mmt_copy_thresh(const mmt_engine* e, uint16_t* out);
+/* Device pointers of the last run's thresholds / anchor ISA (for the merge).   */
+MMT_API const uint16_t* mmt_thresh_device(const mmt_engine* e);
+
+/* ---- stage introspection (parity tests, bench roofline) ------------------- */
+MMT_API uint64_t mmt_text_length(const mmt_engine* e);
+MMT_API int mmt_copy_text(const mmt_engine* e, uint8_t* out);   /* n bytes    */
+MMT_API int mmt_copy_sa(const mmt_engine* e, uint32_t* out);    /* n entries, real suffixes only */
+MMT_API int mmt_copy_lcp(const mmt_engine* e, uint32_t* out);   /* lcp[0] = 0 */
+MMT_API int mmt_copy_bwt(const mmt_engine* e, uint8_t* out);
+/* Candidate lists of the last run, each entry {start, end, length, flags}
+ * in real-suffix index space (= reference stream index - 1).                  */
+MMT_API size_t mmt_num_candidates(const mmt_engine* e);
+MMT_API int mmt_copy_candidates(const mmt_engine* e, uint32_t* out);
+/* HIP-event times (ms) of the last run:
+ * [0] text build  [1] suffix sort  [2] LCP+BWT  [3] scan kernel (roofline kernel)
+ * [4] candidate verification + thresholds  [5] row gather + D2H  [6] host rows/format
+ * [7] whole run (host clock).                                                  */
+MMT_API int mmt_stage_ms(const mmt_engine* e, float out[8]);
+/* Bytes of the SA / LCP / BWT columns as stored (for the roofline model).     */
+MMT_API int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]);
+
+/* ---- anchor partition merge (src/merge_candidates.cpp:97-157) -------------- */
+typedef struct mmt_partition {
+    uint64_t n_rows, n_docs;
+    const uint32_t* length;   /* host */
+    const int64_t*  offsets;  /* host, n_rows * n_docs, column 0 = anchor      */
+    const uint8_t*  strands;  /* host, 1 = '+'                                 */
+    const uint16_t* thresh;   /* host or device (see thresh_on_device), L_0+1 entries */
+    uint64_t thresh_len;
+    uint8_t thresh_on_device;
+} mmt_partition;
+typedef struct mmt_merged mmt_merged;
+/* Left fold over parts[0..k) exactly as anchor_merge does; the per-position
+ * work of every fold step runs on the GPU of `e`.                              */
+MMT_API int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out);
+MMT_API size_t mmt_merged_rows(const mmt_merged* m);
+MMT_API size_t mmt_merged_docs(const mmt_merged* m);
+MMT_API int mmt_merged_get(const mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands,
+                           uint16_t* thresh);
+/* Re-order merged rows into the order of a direct run (lexicographic by match
+ * string) using the anchor suffix ranks of the engine's last run, whose
+ * document 0 must be the anchor.                              */
+MMT_API int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m);
+MMT_API const char* mmt_merged_text(mmt_merged* m, size_t* len);
+MMT_API void mmt_merged_free(mmt_merged* m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUMEMTO_GPU_H */

@@ -1,0 +1,358 @@
+"""ctypes binding of libmumemto.so (include/mumemto.h + include/mumemto_gpu.h)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libmumemto.so")
+_lib = None
+
+
+class MumemtoError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _LIB
+
+
+class DocView(C.Structure):
+    _fields_ = [("records", C.POINTER(C.c_char_p)), ("num_records", C.c_size_t)]
+
+
+class MumView(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("offsets", C.POINTER(C.c_int64)), ("strands", C.POINTER(C.c_uint8))]
+
+
+class MemView(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("occurrences", C.c_size_t), ("offsets", C.POINTER(C.c_int64)),
+                ("seq_ids", C.POINTER(C.c_size_t)), ("strands", C.POINTER(C.c_uint8))]
+
+
+class Params(C.Structure):
+    """mmt_params (include/mumemto_gpu.h)."""
+    _fields_ = [("min_match_len", C.c_uint32), ("num_distinct", C.c_uint64), ("max_doc_freq", C.c_int64),
+                ("max_total_freq", C.c_int64), ("use_revcomp", C.c_uint8), ("merge_metadata", C.c_uint8)]
+
+
+class Partition(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_docs", C.c_uint64), ("length", C.c_void_p), ("offsets", C.c_void_p),
+                ("strands", C.c_void_p), ("thresh", C.c_void_p), ("thresh_len", C.c_uint64),
+                ("thresh_on_device", C.c_uint8)]
+
+
+C_ABI_SYMBOLS = [
+    "mumemto_last_error", "mumemto_mum", "mumemto_mem", "num_docs", "doc_record_offsets", "record_lengths",
+    "num_mums", "mum_at", "mum_free", "num_docs_mem", "doc_record_offsets_mem", "record_lengths_mem", "num_mems",
+    "mem_at", "mem_free",
+]
+GPU_ABI_SYMBOLS = [
+    "mmt_last_error", "mmt_engine_create", "mmt_engine_destroy", "mmt_engine_set_input_device",
+    "mmt_engine_set_input_host", "mmt_engine_run", "mmt_num_rows", "mmt_num_docs", "mmt_rows_mum", "mmt_num_occ",
+    "mmt_rows_mem", "mmt_output_text", "mmt_output_bumbl", "mmt_thresh_len", "mmt_copy_thresh", "mmt_thresh_device",
+    "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
+    "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
+    "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
+]
+
+
+def load_library():
+    """Loads libmumemto.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise MumemtoError("libmumemto.so is not built (%s): run `python -m mumemto_amd.build`; "
+                           "mumemto_amd has no CPU fallback" % _LIB)
+    if "torch" in sys.modules or os.environ.get("MUMEMTO_IMPORT_TORCH_FIRST"):
+        # torch ships its own libamdhip64 under the same soname: it must be the one already
+        # loaded when both live in one process, so that device pointers are shared.
+        import torch  # noqa: F401
+    L = C.CDLL(_LIB)
+    L.mumemto_last_error.restype = C.c_char_p
+    L.mmt_last_error.restype = C.c_char_p
+    L.mumemto_mum.argtypes = [C.POINTER(DocView), C.c_size_t, C.c_uint32, C.c_uint8, C.c_size_t, C.c_uint8,
+                              C.POINTER(C.c_void_p)]
+    L.mumemto_mem.argtypes = [C.POINTER(DocView), C.c_size_t, C.c_uint32, C.c_uint8, C.c_size_t, C.c_size_t,
+                              C.c_size_t, C.c_uint8, C.POINTER(C.c_void_p)]
+    for f in ("num_docs", "num_mums", "num_docs_mem", "num_mems"):
+        getattr(L, f).restype = C.c_size_t
+        getattr(L, f).argtypes = [C.c_void_p]
+    for f in ("doc_record_offsets", "record_lengths", "doc_record_offsets_mem", "record_lengths_mem"):
+        getattr(L, f).restype = C.POINTER(C.c_size_t)
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.mum_at.restype = MumView
+    L.mum_at.argtypes = [C.c_void_p, C.c_size_t]
+    L.mem_at.restype = MemView
+    L.mem_at.argtypes = [C.c_void_p, C.c_size_t]
+    L.mum_free.argtypes = [C.c_void_p]
+    L.mem_free.argtypes = [C.c_void_p]
+
+    L.mmt_engine_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mmt_engine_destroy.argtypes = [C.c_void_p]
+    L.mmt_engine_set_input_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mmt_engine_set_input_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mmt_engine_run.argtypes = [C.c_void_p, C.POINTER(Params)]
+    for f in ("mmt_num_rows", "mmt_num_docs", "mmt_num_occ", "mmt_thresh_len", "mmt_num_candidates",
+              "mmt_merged_rows", "mmt_merged_docs"):
+        getattr(L, f).restype = C.c_size_t
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.mmt_text_length.restype = C.c_uint64
+    L.mmt_text_length.argtypes = [C.c_void_p]
+    L.mmt_rows_mum.argtypes = [C.c_void_p] * 4
+    L.mmt_rows_mem.argtypes = [C.c_void_p] * 6
+    L.mmt_output_text.restype = C.c_void_p
+    L.mmt_output_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.mmt_output_bumbl.restype = C.c_void_p
+    L.mmt_output_bumbl.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.mmt_copy_thresh.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_thresh_device.restype = C.c_void_p
+    L.mmt_thresh_device.argtypes = [C.c_void_p]
+    for f in ("mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_copy_candidates"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.mmt_column_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mmt_anchor_merge.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mmt_merged_get.argtypes = [C.c_void_p] * 5
+    L.mmt_merged_sort_like_direct.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_merged_text.restype = C.c_void_p
+    L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.mmt_merged_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc, gpu=True):
+    if rc != 0:
+        L = load_library()
+        msg = (L.mmt_last_error() if gpu else L.mumemto_last_error()) or b""
+        raise MumemtoError("libmumemto rc=%d: %s" % (rc, msg.decode(errors="replace")))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _doc_views(sequences):
+    views = (DocView * max(len(sequences), 1))()
+    keep = []
+    for i, doc in enumerate(sequences):
+        recs = [r if isinstance(r, bytes) else r.encode() for r in doc]
+        arr = (C.c_char_p * max(len(recs), 1))(*recs)
+        keep.append(arr)
+        views[i].records = arr
+        views[i].num_records = len(recs)
+    return views, keep
+
+
+# ---- drop-in API (mirror of mumemto_library/mumemto_api.hpp:29-57) --------------
+def mumemto_mum(sequences, min_match_len=20, use_revcomp=True, num_distinct=0, use_gsacak=False):
+    """Multi-MUMs of `sequences` (list of docs, each a list of record strings).
+    Returns dict(lengths=u32[n], offsets=i64[n,N] (-1 absent), strands=u8[n,N] (1='+'),
+    record_lengths=list of per-doc record lengths) -- through the C ABI of mumemto.h."""
+    L = load_library()
+    views, keep = _doc_views(sequences)
+    out = C.c_void_p()
+    rc = L.mumemto_mum(views, len(sequences), min_match_len, int(bool(use_revcomp)), num_distinct,
+                       int(bool(use_gsacak)), C.byref(out))
+    _check(rc, gpu=False)
+    try:
+        n, N = L.num_mums(out), L.num_docs(out)
+        lengths = np.zeros(n, np.uint32)
+        offsets = np.zeros((n, N), np.int64)
+        strands = np.zeros((n, N), np.uint8)
+        for i in range(n):
+            v = L.mum_at(out, i)
+            lengths[i] = v.length
+            offsets[i] = np.ctypeslib.as_array(v.offsets, shape=(N,))
+            strands[i] = np.ctypeslib.as_array(v.strands, shape=(N,))
+        dro = L.doc_record_offsets(out)
+        rl = L.record_lengths(out)
+        rec = [[rl[k] for k in range(dro[d], dro[d + 1])] for d in range(N)]
+        return dict(lengths=lengths, offsets=offsets, strands=strands, record_lengths=rec)
+    finally:
+        L.mum_free(out)
+
+
+def mumemto_mem(sequences, min_match_len=20, use_revcomp=True, num_distinct=0, max_total_freq=0, max_doc_freq=2,
+                use_gsacak=False):
+    """Multi-MEMs; returns a list of dict(length, offsets, seq_ids, strands) + record_lengths."""
+    L = load_library()
+    views, keep = _doc_views(sequences)
+    out = C.c_void_p()
+    rc = L.mumemto_mem(views, len(sequences), min_match_len, int(bool(use_revcomp)), num_distinct, max_total_freq,
+                       max_doc_freq, int(bool(use_gsacak)), C.byref(out))
+    _check(rc, gpu=False)
+    try:
+        n, N = L.num_mems(out), L.num_docs_mem(out)
+        mems = []
+        for i in range(n):
+            v = L.mem_at(out, i)
+            k = v.occurrences
+            mems.append(dict(length=int(v.length),
+                             offsets=np.ctypeslib.as_array(v.offsets, shape=(k,)).copy(),
+                             seq_ids=np.ctypeslib.as_array(v.seq_ids, shape=(k,)).astype(np.int64),
+                             strands=np.ctypeslib.as_array(v.strands, shape=(k,)).copy()))
+        dro = L.doc_record_offsets_mem(out)
+        rl = L.record_lengths_mem(out)
+        rec = [[rl[k] for k in range(dro[d], dro[d + 1])] for d in range(N)]
+        return dict(mems=mems, record_lengths=rec)
+    finally:
+        L.mem_free(out)
+
+
+# ---- device-resident engine ----------------------------------------------------------
+class Engine:
+    """One GPU's hot path (include/mumemto_gpu.h)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.mmt_engine_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mmt_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_docs(self, docs):
+        """docs: list of docs, each a list of record bytes (host memory)."""
+        lens = np.array([sum(len(r) for r in d) for d in docs], dtype=np.uint64)
+        flat = b"".join(b"".join(d) for d in docs)
+        bases = np.frombuffer(flat, dtype=np.uint8) if flat else np.zeros(1, np.uint8)
+        _check(self.L.mmt_engine_set_input_host(self.h, _p(bases), _p(lens), len(docs)))
+
+    def set_input_device(self, dev_ptr, doc_len, keepalive=None):
+        """dev_ptr: address of the concatenated bases in HBM (e.g. tensor.data_ptr())."""
+        lens = np.ascontiguousarray(doc_len, dtype=np.uint64)
+        self._keep = keepalive
+        _check(self.L.mmt_engine_set_input_device(self.h, C.c_void_p(dev_ptr), _p(lens), len(lens)))
+
+    def run(self, min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, use_revcomp=True,
+            merge_metadata=False):
+        p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
+        _check(self.L.mmt_engine_run(self.h, C.byref(p)))
+
+    # results
+    def output_text(self):
+        n = C.c_size_t()
+        ptr = self.L.mmt_output_text(self.h, C.byref(n))
+        return C.string_at(ptr, n.value) if n.value else b""
+
+    def output_bumbl(self):
+        n = C.c_size_t()
+        ptr = self.L.mmt_output_bumbl(self.h, C.byref(n))
+        return C.string_at(ptr, n.value) if n.value else b""
+
+    def rows_mum(self):
+        n, N = self.L.mmt_num_rows(self.h), self.L.mmt_num_docs(self.h)
+        length = np.zeros(max(n, 1), np.uint32)
+        off = np.zeros((max(n, 1), N), np.int64)
+        st = np.zeros((max(n, 1), N), np.uint8)
+        _check(self.L.mmt_rows_mum(self.h, _p(length), _p(off), _p(st)))
+        return length[:n], off[:n], st[:n]
+
+    def rows_mem(self):
+        n, t = self.L.mmt_num_rows(self.h), self.L.mmt_num_occ(self.h)
+        length = np.zeros(max(n, 1), np.uint32)
+        occ = np.zeros(n + 1, np.uint64)
+        off = np.zeros(max(t, 1), np.int64)
+        ids = np.zeros(max(t, 1), np.uint64)
+        st = np.zeros(max(t, 1), np.uint8)
+        _check(self.L.mmt_rows_mem(self.h, _p(length), _p(occ), _p(off), _p(ids), _p(st)))
+        return length[:n], occ, off[:t], ids[:t], st[:t]
+
+    def thresholds(self):
+        n = self.L.mmt_thresh_len(self.h)
+        out = np.zeros(max(n, 1), np.uint16)
+        if n:
+            _check(self.L.mmt_copy_thresh(self.h, _p(out)))
+        return out[:n]
+
+    def thresh_device_ptr(self):
+        return self.L.mmt_thresh_device(self.h)
+
+    # stage introspection
+    def text_length(self):
+        return int(self.L.mmt_text_length(self.h))
+
+    def _copy(self, fn, dtype):
+        n = self.text_length()
+        out = np.zeros(max(n, 1), dtype)
+        _check(fn(self.h, _p(out)))
+        return out[:n]
+
+    def text(self):
+        return self._copy(self.L.mmt_copy_text, np.uint8)
+
+    def sa(self):
+        return self._copy(self.L.mmt_copy_sa, np.uint32)
+
+    def lcp(self):
+        return self._copy(self.L.mmt_copy_lcp, np.uint32)
+
+    def bwt(self):
+        return self._copy(self.L.mmt_copy_bwt, np.uint8)
+
+    def candidates(self):
+        n = self.L.mmt_num_candidates(self.h)
+        out = np.zeros((max(n, 1), 4), np.uint32)
+        if n:
+            _check(self.L.mmt_copy_candidates(self.h, _p(out)))
+        return out[:n]
+
+    def stage_ms(self):
+        out = (C.c_float * 8)()
+        _check(self.L.mmt_stage_ms(self.h, out))
+        return list(out)
+
+    def column_bytes(self):
+        out = (C.c_uint32 * 3)()
+        _check(self.L.mmt_column_bytes(self.h, out))
+        return list(out)
+
+    # anchor merge
+    def anchor_merge(self, parts, sort_like_direct=False):
+        """parts: list of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh) where thresh is a
+        numpy u16 array (host) or an int device address paired as (ptr, length)."""
+        arr = (Partition * len(parts))()
+        keep = []
+        for i, (length, off, st, th) in enumerate(parts):
+            length = np.ascontiguousarray(length, np.uint32)
+            off = np.ascontiguousarray(off, np.int64).reshape(len(length), -1)
+            st = np.ascontiguousarray(st, np.uint8).reshape(len(length), -1)
+            if isinstance(th, tuple):
+                tptr, tlen, on_dev = th[0], th[1], 1
+            else:
+                th = np.ascontiguousarray(th, np.uint16)
+                tptr, tlen, on_dev = _p(th).value, len(th), 0
+            keep += [length, off, st, th]
+            arr[i] = Partition(len(length), off.shape[1], _p(length).value, _p(off).value, _p(st).value, tptr, tlen,
+                               on_dev)
+        m = C.c_void_p()
+        _check(self.L.mmt_anchor_merge(self.h, arr, len(parts), C.byref(m)))
+        try:
+            if sort_like_direct:
+                _check(self.L.mmt_merged_sort_like_direct(self.h, m))
+            n, nd = self.L.mmt_merged_rows(m), self.L.mmt_merged_docs(m)
+            length = np.zeros(max(n, 1), np.uint32)
+            off = np.zeros((max(n, 1), nd), np.int64)
+            st = np.zeros((max(n, 1), nd), np.uint8)
+            th = np.zeros(int(arr[0].thresh_len), np.uint16)
+            _check(self.L.mmt_merged_get(m, _p(length), _p(off), _p(st), _p(th)))
+            k = C.c_size_t()
+            ptr = self.L.mmt_merged_text(m, C.byref(k))
+            text = C.string_at(ptr, k.value) if k.value else b""
+            return dict(lengths=length[:n], offsets=off[:n], strands=st[:n], thresh=th, text=text)
+        finally:
+            self.L.mmt_merged_free(m)

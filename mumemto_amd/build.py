@@ -1,0 +1,84 @@
+"""In-tree build of libmumemto.so (hipcc, gfx950 only) and the CLI tools.
+
+`python -m mumemto_amd.build` or `mumemto_amd.build.build()`.  Objects go to
+mumemto_amd/csrc/_build/, products to mumemto_amd/lib/ and mumemto_amd/bin/
+(git-ignored; they travel to the GPU box with the snapshot).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(SRC, "_build")
+LIB_DIR = os.path.join(HERE, "lib")
+BIN_DIR = os.path.join(HERE, "bin")
+LIB = os.path.join(LIB_DIR, "libmumemto.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
+            "--offload-arch=" + ARCH]
+
+LIB_SOURCES = ["kernels.hip", "prims.hip", "pfp_kernels.hip", "engine.cpp", "pfp.cpp", "merge.cpp", "api.cpp",
+               "cxx_api.cpp", "fasta.cpp", "options.cpp"]
+TOOLS = {"mumemto_exec": ["cli_main.cpp"], "anchor_merge": ["merge_main.cpp"]}
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _headers():
+    hs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".hpp", ".h"))]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hs += [os.path.join(inc, f) for f in os.listdir(inc)]
+    return hs
+
+
+def _compile(src):
+    path = os.path.join(SRC, src)
+    obj = os.path.join(OBJ, src + ".o")
+    if not os.path.exists(path):
+        return None
+    if _newer(obj, [path] + _headers()):
+        cmd = [HIPCC] + CXXFLAGS + ["-c", path, "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-6000:]))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(verbose=False):
+    for d in (OBJ, LIB_DIR, BIN_DIR):
+        os.makedirs(d, exist_ok=True)
+    tool_sources = [s for v in TOOLS.values() for s in v]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(_compile, LIB_SOURCES + tool_sources))
+    lib_objs = [o for o in objs[: len(LIB_SOURCES)] if o]
+    if _newer(LIB, lib_objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + lib_objs + ["-Wl,-soname,libmumemto.so", "-lz"]
+        subprocess.check_call(cmd)
+    for tool, srcs in TOOLS.items():
+        tobjs = [os.path.join(OBJ, s + ".o") for s in srcs if os.path.exists(os.path.join(OBJ, s + ".o"))]
+        if not tobjs:
+            continue
+        out = os.path.join(BIN_DIR, tool)
+        if _newer(out, tobjs + [LIB]):
+            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-o", out] + tobjs +
+                                  ["-L" + LIB_DIR, "-lmumemto", "-Wl,-rpath,$ORIGIN/../lib", "-lz"])
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(verbose=True)

@@ -1,0 +1,344 @@
+// api.cpp -- the C ABI of libmumemto: the drop-in symbols of include/mumemto.h
+// (reference: mumemto_library/mumemto_api.cpp:489-644) and the device-resident
+// entry points of include/mumemto_gpu.h.
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mumemto.h"
+#include "../../include/mumemto_gpu.h"
+#include "engine.hpp"
+#include "merge.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;   // mumemto_api.cpp:440-448
+
+int fail(int rc, const std::string& msg) { g_last_error = msg; return rc; }
+
+// One engine per process for the host-string ABI; calls are serialised
+// (SURVEY.md 8(b) "Threading": device use must be serialised or stream-safe).
+std::mutex g_engine_mu;
+std::unique_ptr<mmt::Engine> g_engine;
+
+mmt::Engine& shared_engine() {
+    if (!g_engine) {
+        int dev = 0;
+        if (const char* s = std::getenv("MUMEMTO_DEVICE")) dev = std::atoi(s);
+        g_engine.reset(new mmt::Engine(dev, nullptr));
+    }
+    return *g_engine;
+}
+
+struct DocInput {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> doc_len;
+    std::vector<size_t> doc_record_offsets, record_lengths;
+};
+
+// build_sequences_from_docs + compute_record_lengths + flatten_lengths
+// (mumemto_api.cpp:315-330, :450-485): records of a document are concatenated,
+// a NULL record is the empty string, lengths are the raw record byte lengths.
+DocInput gather_docs(const mumemto_doc_view* docs, size_t n) {
+    DocInput in;
+    in.doc_record_offsets.push_back(0);
+    for (size_t d = 0; d < n; d++) {
+        uint64_t total = 0;
+        for (size_t r = 0; r < docs[d].num_records; r++) {
+            const char* s = docs[d].records ? docs[d].records[r] : nullptr;
+            size_t len = s ? std::strlen(s) : 0;
+            in.record_lengths.push_back(len);
+            if (len) in.bases.insert(in.bases.end(), reinterpret_cast<const uint8_t*>(s),
+                                     reinterpret_cast<const uint8_t*>(s) + len);
+            total += len;
+        }
+        in.doc_len.push_back(total);
+        in.doc_record_offsets.push_back(in.record_lengths.size());
+    }
+    return in;
+}
+
+}  // namespace
+
+struct mumemto_mum_result {
+    size_t num_docs = 0;
+    std::vector<size_t> doc_record_offsets, record_lengths;
+    std::vector<uint32_t> length;
+    std::vector<int64_t> offsets;
+    std::vector<uint8_t> strands;
+};
+struct mumemto_mem_result {
+    size_t num_docs = 0;
+    std::vector<size_t> doc_record_offsets, record_lengths;
+    std::vector<uint32_t> length;
+    std::vector<uint64_t> occ_start;
+    std::vector<int64_t> offsets;
+    std::vector<size_t> seq_ids;
+    std::vector<uint8_t> strands;
+};
+struct mmt_engine {
+    std::unique_ptr<mmt::Engine> e;
+};
+struct mmt_merged {
+    mmt::MergedRows rows;
+    std::string text;
+};
+
+extern "C" {
+
+const char* mumemto_last_error(void) { return g_last_error.c_str(); }
+const char* mmt_last_error(void) { return g_last_error.c_str(); }
+
+int mumemto_mum(const mumemto_doc_view* docs, size_t n_docs, uint32_t min_match_len, uint8_t use_revcomp,
+                size_t num_distinct, uint8_t /*use_gsacak*/, mumemto_mum_result** out_result) {
+    if (!out_result) return fail(1, "out_result must be non-null");
+    *out_result = nullptr;
+    try {
+        if (!docs && n_docs != 0) return fail(2, "docs must be non-null when num_docs != 0");
+        DocInput in = gather_docs(docs, n_docs);
+        std::unique_ptr<mumemto_mum_result> r(new mumemto_mum_result());
+        r->num_docs = n_docs;
+        r->doc_record_offsets = std::move(in.doc_record_offsets);
+        r->record_lengths = std::move(in.record_lengths);
+        if (n_docs) {
+            std::lock_guard<std::mutex> lock(g_engine_mu);
+            mmt::Engine& e = shared_engine();
+            e.set_input_host(in.bases.data(), in.doc_len.data(), n_docs);
+            mmt_params p{};
+            p.min_match_len = min_match_len; p.num_distinct = num_distinct;
+            p.max_doc_freq = 1; p.max_total_freq = 0;                 // mumemto_api.cpp:353
+            p.use_revcomp = use_revcomp ? 1 : 0; p.merge_metadata = 0;
+            e.run(p);
+            const mmt::HostRows& R = e.rows();
+            r->length = R.length; r->offsets = R.mum_offsets; r->strands = R.mum_strands;
+        }
+        *out_result = r.release();
+        return 0;
+    } catch (const std::exception& ex) {
+        return fail(3, ex.what());
+    } catch (...) {
+        return fail(4, "unknown exception");
+    }
+}
+
+int mumemto_mem(const mumemto_doc_view* docs, size_t n_docs, uint32_t min_match_len, uint8_t use_revcomp,
+                size_t num_distinct, size_t max_total_freq, size_t max_doc_freq, uint8_t /*use_gsacak*/,
+                mumemto_mem_result** out_result) {
+    if (!out_result) return fail(1, "out_result must be non-null");
+    *out_result = nullptr;
+    try {
+        if (!docs && n_docs != 0) return fail(2, "docs must be non-null when num_docs != 0");
+        DocInput in = gather_docs(docs, n_docs);
+        std::unique_ptr<mumemto_mem_result> r(new mumemto_mem_result());
+        r->num_docs = n_docs;
+        r->doc_record_offsets = std::move(in.doc_record_offsets);
+        r->record_lengths = std::move(in.record_lengths);
+        if (n_docs) {
+            if (max_doc_freq <= 1)                                     // mumemto_api.cpp:381-383
+                throw std::invalid_argument("per-sequence MEM frequency f must be > 1 (use mumemto_mum instead)");
+            std::lock_guard<std::mutex> lock(g_engine_mu);
+            mmt::Engine& e = shared_engine();
+            e.set_input_host(in.bases.data(), in.doc_len.data(), n_docs);
+            mmt_params p{};
+            p.min_match_len = min_match_len; p.num_distinct = num_distinct;
+            p.max_doc_freq = (int64_t)max_doc_freq; p.max_total_freq = (int64_t)max_total_freq;
+            p.use_revcomp = use_revcomp ? 1 : 0; p.merge_metadata = 0;
+            e.run(p);
+            const mmt::HostRows& R = e.rows();
+            r->length = R.length; r->occ_start = R.occ_start; r->offsets = R.mem_offsets;
+            r->seq_ids.assign(R.mem_docs.begin(), R.mem_docs.end()); r->strands = R.mem_strands;
+        }
+        if (r->occ_start.empty()) r->occ_start.push_back(0);
+        *out_result = r.release();
+        return 0;
+    } catch (const std::exception& ex) {
+        return fail(3, ex.what());
+    } catch (...) {
+        return fail(4, "unknown exception");
+    }
+}
+
+size_t num_docs(const mumemto_mum_result* r) { return r ? r->num_docs : 0; }
+const size_t* doc_record_offsets(const mumemto_mum_result* r) { return r ? r->doc_record_offsets.data() : nullptr; }
+const size_t* record_lengths(const mumemto_mum_result* r) { return r ? r->record_lengths.data() : nullptr; }
+size_t num_mums(const mumemto_mum_result* r) { return r ? r->length.size() : 0; }
+mumemto_mum_match_view mum_at(const mumemto_mum_result* r, size_t idx) {
+    mumemto_mum_match_view v{};
+    if (!r || idx >= r->length.size()) return v;
+    v.length = r->length[idx];
+    v.offsets = r->offsets.data() + idx * r->num_docs;
+    v.strands = r->strands.data() + idx * r->num_docs;
+    return v;
+}
+void mum_free(mumemto_mum_result* r) { delete r; }
+
+size_t num_docs_mem(const mumemto_mem_result* r) { return r ? r->num_docs : 0; }
+const size_t* doc_record_offsets_mem(const mumemto_mem_result* r) { return r ? r->doc_record_offsets.data() : nullptr; }
+const size_t* record_lengths_mem(const mumemto_mem_result* r) { return r ? r->record_lengths.data() : nullptr; }
+size_t num_mems(const mumemto_mem_result* r) { return r ? r->length.size() : 0; }
+mumemto_mem_match_view mem_at(const mumemto_mem_result* r, size_t idx) {
+    mumemto_mem_match_view v{};
+    if (!r || idx >= r->length.size()) return v;
+    v.length = r->length[idx];
+    v.occurrences = (size_t)(r->occ_start[idx + 1] - r->occ_start[idx]);
+    v.offsets = r->offsets.data() + r->occ_start[idx];
+    v.seq_ids = r->seq_ids.data() + r->occ_start[idx];
+    v.strands = r->strands.data() + r->occ_start[idx];
+    return v;
+}
+void mem_free(mumemto_mem_result* r) { delete r; }
+
+// ---------------------------------------------------------------------------------
+// device-resident entry points
+// ---------------------------------------------------------------------------------
+#define MMT_TRY try {
+#define MMT_CATCH                                                           \
+    return 0;                                                                \
+    } catch (const std::exception& ex) { return fail(3, ex.what()); }        \
+    catch (...) { return fail(4, "unknown exception"); }
+
+int mmt_engine_create(int device, void* hip_stream, mmt_engine** out) {
+    if (!out) return fail(1, "out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    std::unique_ptr<mmt_engine> h(new mmt_engine());
+    h->e.reset(new mmt::Engine(device, reinterpret_cast<hipStream_t>(hip_stream)));
+    *out = h.release();
+    MMT_CATCH
+}
+void mmt_engine_destroy(mmt_engine* e) { delete e; }
+
+int mmt_engine_set_input_device(mmt_engine* e, const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs) {
+    if (!e) return fail(1, "engine must be non-null");
+    MMT_TRY
+    e->e->set_input_device(d_bases, doc_len, n_docs);
+    MMT_CATCH
+}
+int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs) {
+    if (!e) return fail(1, "engine must be non-null");
+    MMT_TRY
+    e->e->set_input_host(h_bases, doc_len, n_docs);
+    MMT_CATCH
+}
+int mmt_engine_run(mmt_engine* e, const mmt_params* p) {
+    if (!e || !p) return fail(1, "engine and params must be non-null");
+    MMT_TRY
+    e->e->run(*p);
+    MMT_CATCH
+}
+
+size_t mmt_num_rows(const mmt_engine* e) { return e ? e->e->rows().n_rows() : 0; }
+size_t mmt_num_docs(const mmt_engine* e) { return e ? e->e->n_docs() : 0; }
+int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands) {
+    if (!e) return fail(1, "engine must be non-null");
+    const mmt::HostRows& R = e->e->rows();
+    if (!R.mum_mode) return fail(3, "last run was not in MUM mode");
+    if (R.n_rows()) {
+        std::memcpy(length, R.length.data(), R.length.size() * 4);
+        std::memcpy(offsets, R.mum_offsets.data(), R.mum_offsets.size() * 8);
+        std::memcpy(strands, R.mum_strands.data(), R.mum_strands.size());
+    }
+    return 0;
+}
+size_t mmt_num_occ(const mmt_engine* e) { return e ? e->e->rows().mem_offsets.size() : 0; }
+int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start, int64_t* offsets, uint64_t* seq_ids,
+                 uint8_t* strands) {
+    if (!e) return fail(1, "engine must be non-null");
+    const mmt::HostRows& R = e->e->rows();
+    if (R.mum_mode) return fail(3, "last run was in MUM mode");
+    occ_start[0] = 0;
+    if (R.n_rows()) {
+        std::memcpy(length, R.length.data(), R.length.size() * 4);
+        std::memcpy(occ_start, R.occ_start.data(), R.occ_start.size() * 8);
+        std::memcpy(offsets, R.mem_offsets.data(), R.mem_offsets.size() * 8);
+        std::memcpy(seq_ids, R.mem_docs.data(), R.mem_docs.size() * 8);
+        std::memcpy(strands, R.mem_strands.data(), R.mem_strands.size());
+    }
+    return 0;
+}
+const char* mmt_output_text(mmt_engine* e, size_t* len) {
+    if (!e) { if (len) *len = 0; return nullptr; }
+    const std::string& t = e->e->rows().text;
+    if (len) *len = t.size();
+    return t.data();
+}
+const uint8_t* mmt_output_bumbl(mmt_engine* e, size_t* len) {
+    if (!e) { if (len) *len = 0; return nullptr; }
+    const std::string& t = e->e->bumbl();
+    if (len) *len = t.size();
+    return reinterpret_cast<const uint8_t*>(t.data());
+}
+size_t mmt_thresh_len(const mmt_engine* e) { return e ? e->e->thresh_len() : 0; }
+int mmt_copy_thresh(const mmt_engine* e, uint16_t* out) {
+    if (!e) return fail(1, "engine must be non-null");
+    MMT_TRY
+    e->e->copy_thresh(out);
+    MMT_CATCH
+}
+const uint16_t* mmt_thresh_device(const mmt_engine* e) { return e ? e->e->thresh_device() : nullptr; }
+
+uint64_t mmt_text_length(const mmt_engine* e) { return e ? e->e->text_length() : 0; }
+int mmt_copy_text(const mmt_engine* e, uint8_t* out) { if (!e) return fail(1, "null"); MMT_TRY e->e->copy_text(out); MMT_CATCH }
+int mmt_copy_sa(const mmt_engine* e, uint32_t* out) { if (!e) return fail(1, "null"); MMT_TRY e->e->copy_sa(out); MMT_CATCH }
+int mmt_copy_lcp(const mmt_engine* e, uint32_t* out) { if (!e) return fail(1, "null"); MMT_TRY e->e->copy_lcp(out); MMT_CATCH }
+int mmt_copy_bwt(const mmt_engine* e, uint8_t* out) { if (!e) return fail(1, "null"); MMT_TRY e->e->copy_bwt(out); MMT_CATCH }
+size_t mmt_num_candidates(const mmt_engine* e) { return e ? e->e->n_candidates() : 0; }
+int mmt_copy_candidates(const mmt_engine* e, uint32_t* out) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    e->e->copy_candidates(out);
+    MMT_CATCH
+}
+int mmt_stage_ms(const mmt_engine* e, float out[8]) {
+    if (!e) return fail(1, "null");
+    std::memcpy(out, e->e->stage_ms(), 8 * sizeof(float));
+    return 0;
+}
+int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]) {
+    if (!e) return fail(1, "null");
+    out[0] = 4; out[1] = 4; out[2] = 1;   // SA u32, LCP u32, BWT u8 as stored by this build
+    return 0;
+}
+
+// ---- anchor merge --------------------------------------------------------------------
+int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out) {
+    if (!e || !parts || !out) return fail(1, "engine, parts and out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    if (k < 2) throw std::invalid_argument("anchor merge requires at least two partitions");
+    std::unique_ptr<mmt_merged> m(new mmt_merged());
+    m->rows = mmt::anchor_merge(*e->e, parts, k);
+    *out = m.release();
+    MMT_CATCH
+}
+size_t mmt_merged_rows(const mmt_merged* m) { return m ? m->rows.length.size() : 0; }
+size_t mmt_merged_docs(const mmt_merged* m) { return m ? m->rows.n_docs : 0; }
+int mmt_merged_get(const mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands, uint16_t* thresh) {
+    if (!m) return fail(1, "null");
+    const mmt::MergedRows& R = m->rows;
+    if (!R.length.empty()) {
+        std::memcpy(length, R.length.data(), R.length.size() * 4);
+        std::memcpy(offsets, R.offsets.data(), R.offsets.size() * 8);
+        std::memcpy(strands, R.strands.data(), R.strands.size());
+    }
+    if (thresh && !R.thresh.empty()) std::memcpy(thresh, R.thresh.data(), R.thresh.size() * 2);
+    return 0;
+}
+int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m) {
+    if (!e || !m) return fail(1, "null");
+    MMT_TRY
+    mmt::sort_like_direct(*e->e, m->rows);
+    m->text.clear();
+    MMT_CATCH
+}
+const char* mmt_merged_text(mmt_merged* m, size_t* len) {
+    if (!m) { if (len) *len = 0; return nullptr; }
+    if (m->text.empty()) m->text = mmt::format_merged(m->rows);
+    if (len) *len = m->text.size();
+    return m->text.data();
+}
+void mmt_merged_free(mmt_merged* m) { delete m; }
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// device_utils.hpp -- HIP error handling, owned device buffers, event timers.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mmt {
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e != hipSuccess) {
+        throw HipError(std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" +
+                       std::to_string(line));
+    }
+}
+#define MMT_HIP(x) ::mmt::hip_check((x), #x, __FILE__, __LINE__)
+
+// Device allocation that only grows (steps of the hot path are re-run by the
+// bench with the same sizes; re-allocating per run would time hipMalloc).
+template <typename T>
+class DevBuf {
+public:
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void ensure(size_t n) {
+        if (n <= cap_) { n_ = n; return; }
+        release();
+        size_t want = n + n / 16 + 64;
+        MMT_HIP(hipMalloc(reinterpret_cast<void**>(&p_), want * sizeof(T)));
+        cap_ = want; n_ = n;
+    }
+    void release() {
+        if (p_) { (void)hipFree(p_); p_ = nullptr; }
+        cap_ = n_ = 0;
+    }
+    T* get() const { return p_; }
+    size_t size() const { return n_; }
+    size_t bytes() const { return n_ * sizeof(T); }
+    void swap(DevBuf& o) { std::swap(p_, o.p_); std::swap(cap_, o.cap_); std::swap(n_, o.n_); }
+
+private:
+    T* p_ = nullptr;
+    size_t cap_ = 0, n_ = 0;
+};
+
+class EventPair {
+public:
+    EventPair() { MMT_HIP(hipEventCreate(&a_)); MMT_HIP(hipEventCreate(&b_)); }
+    ~EventPair() { (void)hipEventDestroy(a_); (void)hipEventDestroy(b_); }
+    EventPair(const EventPair&) = delete;
+    void start(hipStream_t s) { MMT_HIP(hipEventRecord(a_, s)); used_ = true; }
+    void stop(hipStream_t s) { MMT_HIP(hipEventRecord(b_, s)); }
+    float ms() {
+        if (!used_) return 0.f;
+        float t = 0.f;
+        MMT_HIP(hipEventSynchronize(b_));
+        MMT_HIP(hipEventElapsedTime(&t, a_, b_));
+        return t;
+    }
+    void reset() { used_ = false; }
+
+private:
+    hipEvent_t a_{}, b_{};
+    bool used_ = false;
+};
+
+template <typename T>
+inline void d2h(std::vector<T>& dst, const T* src, size_t n, hipStream_t s) {
+    dst.resize(n);
+    if (n) MMT_HIP(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+}
+
+}  // namespace mmt

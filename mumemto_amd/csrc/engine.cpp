@@ -1,0 +1,361 @@
+// engine.cpp -- orchestration of the hot path on one GPU (no kernels here).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "prims.hpp"
+
+namespace mmt {
+
+static int bit_width_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+Engine::Engine(int device, hipStream_t stream) : device_(device), stream_(stream) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        throw HipError("no usable HIP device (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) +
+                       "); libmumemto has no CPU fallback");
+    if (device < 0 || device >= count) throw HipError("device index out of range");
+    MMT_HIP(hipSetDevice(device_));
+    if (!stream_) { MMT_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking)); own_stream_ = true; }
+    for (auto& ev : ev_) ev.reset(new EventPair());
+}
+
+Engine::~Engine() {
+    if (own_stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs) {
+    MMT_HIP(hipSetDevice(device_));
+    d_bases_ = d_bases;
+    doc_len_.assign(doc_len, doc_len + n_docs);
+    doc_base_.assign(n_docs + 1, 0);
+    for (size_t d = 0; d < n_docs; d++) doc_base_[d + 1] = doc_base_[d] + doc_len_[d];
+}
+
+void Engine::set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs) {
+    MMT_HIP(hipSetDevice(device_));
+    uint64_t total = 0;
+    for (size_t d = 0; d < n_docs; d++) total += doc_len[d];
+    d_bases_own_.ensure(total + 16);
+    if (total) MMT_HIP(hipMemcpyAsync(d_bases_own_.get(), h_bases, total, hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    set_input_device(d_bases_own_.get(), doc_len, n_docs);
+}
+
+// ---- A1 ----------------------------------------------------------------------
+void Engine::build_text(bool revcomp) {
+    const size_t N = doc_len_.size();
+    revcomp_ = revcomp;
+    doc_start_.assign(N + 1, 0);
+    for (size_t d = 0; d < N; d++) doc_start_[d + 1] = doc_start_[d] + (revcomp ? 2 : 1) * (doc_len_[d] + 1);
+    n_ = doc_start_[N];
+    if (n_ >= 0xffffff00ull)
+        throw std::runtime_error("text of " + std::to_string(n_) +
+                                 " characters exceeds the 32-bit suffix-array build of this version");
+    d_doc_base_.ensure(N + 1);
+    d_doc_start_.ensure(N + 1);
+    MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipMemcpyAsync(d_doc_start_.get(), doc_start_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
+    d_text_.ensure(n_ + 64);
+    d_hist_.ensure(256);
+    MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 4, stream_));
+    MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~3ull), 0, 64 + (n_ & 3ull), stream_));
+    k::build_text(d_bases_, d_doc_base_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, d_text_.get(), n_,
+                  d_hist_.get(), stream_);
+}
+
+// ---- A8: suffix array by prefix doubling ---------------------------------------
+void Engine::suffix_sort() {
+    const uint32_t n = (uint32_t)n_;
+    // symbol codes: dense ranks of the bytes that occur, 0 reserved for "past the end"
+    std::vector<uint32_t> hist;
+    d2h(hist, d_hist_.get(), 256, stream_);
+    uint8_t code[256];
+    int sigma = 0;
+    for (int c = 0; c < 256; c++) code[c] = hist[c] ? (uint8_t)(++sigma) : 0;
+    int bits = std::max(1, bit_width_u64((uint64_t)sigma));
+    int chars = std::min(64 / bits, 64);
+    d_code_.ensure(256);
+    MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, stream_));
+
+    d_keys_a_.ensure(n); d_keys_b_.ensure(n);
+    d_sac_a_.ensure(n); d_sac_b_.ensure(n); d_pos_a_.ensure(n); d_pos_b_.ensure(n); d_headc_.ensure(n);
+    d_sa_.ensure(n); d_rank_.ensure(n); d_headval_.ensure(n); d_head_.ensure(n); d_idx_.ensure(n);
+    d_flags_.ensure(n); d_count_.ensure(4);
+
+    k::pack_keys(d_text_.get(), n, d_code_.get(), bits, chars, d_keys_a_.get(), d_sac_a_.get(), stream_);
+    prims::sort_pairs_u64_u32(d_temp_, d_keys_a_.get(), d_keys_b_.get(), d_sac_a_.get(), d_sa_.get(), n, 0,
+                              std::min(64, bits * chars), stream_);
+    k::mark_heads(d_keys_b_.get(), n, d_headval_.get(), stream_);
+    prims::inclusive_max_u32(d_temp_, d_headval_.get(), d_head_.get(), n, stream_);
+    k::scatter_rank(d_sa_.get(), d_head_.get(), n, d_rank_.get(), stream_);
+    k::flag_unsorted(d_head_.get(), n, d_flags_.get(), stream_);
+    prims::select_indices(d_temp_, d_flags_.get(), d_idx_.get(), d_count_.get(), n, stream_);
+    uint32_t m = 0;
+    MMT_HIP(hipMemcpyAsync(&m, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    if (m) k::gather_active(d_idx_.get(), m, d_sa_.get(), d_head_.get(), d_pos_a_.get(), d_sac_a_.get(),
+                            d_headc_.get(), stream_);
+
+    const int shift = bit_width_u64(n);            // second key component holds values 0..n
+    uint64_t h = (uint64_t)chars;
+    int rounds = 0;
+    while (m) {
+        if (++rounds > 64) throw std::runtime_error("suffix sort did not converge");
+        uint32_t hh = h > 0xffffffffull ? 0xffffffffu : (uint32_t)h;
+        k::make_round_keys(d_sac_a_.get(), d_headc_.get(), m, d_rank_.get(), n, hh, shift, d_keys_a_.get(), stream_);
+        prims::sort_pairs_u64_u32(d_temp_, d_keys_a_.get(), d_keys_b_.get(), d_sac_a_.get(), d_sac_b_.get(), m, 0,
+                                  std::min(64, 2 * shift), stream_);
+        k::mark_subheads(d_keys_b_.get(), d_pos_a_.get(), m, d_headval_.get(), stream_);
+        prims::inclusive_max_u32(d_temp_, d_headval_.get(), d_head_.get(), m, stream_);
+        k::apply_round(d_sac_b_.get(), d_head_.get(), d_pos_a_.get(), m, d_sa_.get(), d_rank_.get(), d_flags_.get(),
+                       stream_);
+        prims::select_indices(d_temp_, d_flags_.get(), d_idx_.get(), d_count_.get(), m, stream_);
+        uint32_t m2 = 0;
+        MMT_HIP(hipMemcpyAsync(&m2, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+        if (m2) {
+            k::compact_round(d_idx_.get(), m2, d_pos_a_.get(), d_sac_b_.get(), d_head_.get(), d_pos_b_.get(),
+                             d_sac_a_.get(), d_headc_.get(), stream_);
+            d_pos_a_.swap(d_pos_b_);
+        }
+        m = m2;
+        h *= 2;
+    }
+}
+
+void Engine::lcp_bwt() {
+    const uint32_t n = (uint32_t)n_;
+    d_lcp_.ensure(n + 1);
+    d_bwt_.ensure(n + 16);
+    k::lcp_from_isa(d_text_.get(), n, d_sa_.get(), d_rank_.get(), d_lcp_.get(), stream_);
+    k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
+}
+
+// ---- A5 ------------------------------------------------------------------------
+void Engine::scan(const mmt_params& p) {
+    const uint32_t n = (uint32_t)n_;
+    const size_t N = doc_len_.size();
+    num_distinct_eff_ = p.num_distinct ? p.num_distinct : N;     // mumemto_api.cpp:344-346
+    // interval size cap: explicit total cap, else docs * per-doc cap (every accepted interval obeys it)
+    uint64_t cap = 0;
+    if (p.max_total_freq > 0) cap = (uint64_t)p.max_total_freq;
+    if (p.max_doc_freq > 0) {
+        uint64_t c2 = (uint64_t)p.max_doc_freq * N;
+        cap = cap ? std::min(cap, c2) : c2;
+    }
+    if (cap > 0xfffffff0ull) cap = 0;
+    if (N > 32768 && !(p.max_doc_freq == 1 && N <= 64))
+        throw std::runtime_error("more than 32768 documents are not supported by the candidate verifier");
+
+    k::ScanArgs a;
+    a.lcp = d_lcp_.get(); a.bwt = d_bwt_.get(); a.n = n;
+    a.min_len = p.min_match_len;
+    a.num_distinct = (uint32_t)std::min<uint64_t>(num_distinct_eff_, 0xffffffffu);
+    a.cap = (uint32_t)cap;
+    a.emit_all = p.merge_metadata ? 1 : 0;
+    a.d_count = d_count_.get();
+    size_t capacity = std::max<size_t>(1u << 20, p.merge_metadata ? n / 6 : n / 32);
+    uint32_t found = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        d_cand_.ensure(capacity);
+        a.out = d_cand_.get(); a.capacity = (uint32_t)capacity;
+        MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 16, stream_));
+        ev_[3]->start(stream_);
+        k::scan_intervals(a, stream_);
+        ev_[3]->stop(stream_);
+        MMT_HIP(hipMemcpyAsync(&found, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+        if (found <= capacity) break;
+        capacity = (size_t)found + 1024;       // rare: re-run with the exact size
+    }
+    n_cand_ = found;
+
+    // verification + thresholds
+    ev_[4]->start(stream_);
+    thresh_len_ = 0;
+    if (p.merge_metadata && N > 0) {
+        thresh_len_ = 2 * (doc_len_[0] + 1);
+        d_thresh_.ensure(thresh_len_);
+        MMT_HIP(hipMemsetAsync(d_thresh_.get(), 0, thresh_len_ * 2, stream_));
+    }
+    d_rows_.ensure(std::max<size_t>(n_cand_, 1));
+    MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, stream_));
+    k::VerifyArgs v;
+    v.cand = d_cand_.get(); v.n_cand = (uint32_t)n_cand_; v.sa = d_sa_.get(); v.lcp = d_lcp_.get();
+    v.d_doc_start = d_doc_start_.get(); v.n_docs = (uint32_t)N;
+    v.num_distinct = a.num_distinct;
+    v.max_doc_freq = p.max_doc_freq > 0 ? (uint32_t)std::min<int64_t>(p.max_doc_freq, 0x7fffffff) : 0u;
+    v.merge = p.merge_metadata ? 1 : 0; v.thresh = d_thresh_.get();
+    v.rows = d_rows_.get(); v.d_row_count = d_count_.get() + 1;
+    k::verify_candidates(v, stream_);
+    ev_[4]->stop(stream_);
+}
+
+// ---- A6: rows -> coordinates -> text ---------------------------------------------
+void append_uint(std::string& s, uint64_t v) {
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) s.push_back(tmp[--k]);
+}
+
+void Engine::make_rows(const mmt_params& p) {
+    const size_t N = doc_len_.size();
+    ev_[5]->start(stream_);
+    uint32_t n_rows = 0;
+    MMT_HIP(hipMemcpyAsync(&n_rows, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    d2h(h_rows_, d_rows_.get(), n_rows, stream_);
+    // pop order of the reference's stack: closing position ascending, longer first
+    std::sort(h_rows_.begin(), h_rows_.end(), [](const k::Cand& x, const k::Cand& y) {
+        return x.end != y.end ? x.end < y.end : x.len > y.len;
+    });
+    h_off_.assign((size_t)n_rows + 1, 0);
+    for (uint32_t r = 0; r < n_rows; r++) h_off_[r + 1] = h_off_[r] + (h_rows_[r].end - h_rows_[r].start + 1);
+    const uint64_t total = h_off_[n_rows];
+    if (n_rows) {
+        d_off_.ensure((size_t)n_rows + 1);
+        d_occ_.ensure(total);
+        MMT_HIP(hipMemcpyAsync(d_rows_.get(), h_rows_.data(), (size_t)n_rows * sizeof(k::Cand), hipMemcpyHostToDevice,
+                               stream_));
+        MMT_HIP(hipMemcpyAsync(d_off_.get(), h_off_.data(), ((size_t)n_rows + 1) * 8, hipMemcpyHostToDevice, stream_));
+        k::gather_occurrences(d_rows_.get(), d_off_.get(), n_rows, d_sa_.get(), d_occ_.get(), stream_);
+    }
+    d2h(h_occ_, d_occ_.get(), total, stream_);
+    ev_[5]->stop(stream_);
+
+    auto t0 = std::chrono::steady_clock::now();
+    HostRows& R = rows_;
+    R = HostRows();
+    R.mum_mode = p.max_doc_freq == 1;                 // mem_finder.hpp:85
+    R.n_docs = N;
+    std::vector<uint64_t> half(N);
+    for (size_t d = 0; d < N; d++) half[d] = doc_len_[d] + 1;
+    auto doc_of = [&](uint64_t sa) {
+        return (size_t)(std::upper_bound(doc_start_.begin(), doc_start_.end(), sa) - doc_start_.begin()) - 1;
+    };
+    std::string& T = R.text;
+    T.reserve((size_t)n_rows * (R.mum_mode ? 12 * N + 16 : 64));
+    if (R.mum_mode) {
+        std::vector<int64_t> off(N);
+        std::vector<uint8_t> st(N);   // 0 absent, '+', '-'
+        for (uint32_t r = 0; r < n_rows; r++) {
+            const uint64_t len = h_rows_[r].len;
+            std::fill(off.begin(), off.end(), -1);
+            std::fill(st.begin(), st.end(), 0);
+            bool keep = true;
+            for (uint64_t o = h_off_[r]; o < h_off_[r + 1]; o++) {        // write_mum, mem_finder.hpp:365-380
+                const uint64_t sa = h_occ_[o];
+                const size_t d = doc_of(sa);
+                uint64_t pos = sa - doc_start_[d];
+                uint8_t strand = '+';
+                if (revcomp_ && pos >= half[d]) {
+                    strand = '-';
+                    if (pos + len >= 2 * half[d]) { keep = false; break; }
+                    pos = 2 * half[d] - pos - len - 1;
+                }
+                off[d] = (int64_t)pos; st[d] = strand;
+            }
+            if (!keep) continue;
+            size_t i = 0;                                                  // :382-391
+            while (i + 1 < N && st[i] == 0) i++;
+            if (st[i] == '-') continue;
+            R.length.push_back((uint32_t)len);
+            for (size_t d = 0; d < N; d++) {
+                R.mum_offsets.push_back(off[d]);
+                R.mum_strands.push_back(st[d] == '+' ? 1 : 0);
+            }
+            append_uint(T, len); T.push_back('\t');                        // :406-426
+            for (size_t d = 0; d + 1 < N; d++) { if (off[d] >= 0) append_uint(T, (uint64_t)off[d]); T.push_back(','); }
+            if (off[N - 1] >= 0) append_uint(T, (uint64_t)off[N - 1]);
+            T.push_back('\t');
+            for (size_t d = 0; d + 1 < N; d++) { if (off[d] >= 0) T.push_back((char)st[d]); T.push_back(','); }
+            if (off[N - 1] >= 0) T.push_back((char)st[N - 1]);
+            T.push_back('\n');
+        }
+    } else {
+        R.occ_start.push_back(0);
+        std::string docs_s, strand_s;
+        for (uint32_t r = 0; r < n_rows; r++) {                            // write_mem, :210-263
+            const uint64_t len = h_rows_[r].len;
+            R.length.push_back((uint32_t)len);
+            append_uint(T, len); T.push_back('\t');
+            docs_s.clear(); strand_s.clear();
+            for (uint64_t o = h_off_[r]; o < h_off_[r + 1]; o++) {
+                const bool last = o + 1 == h_off_[r + 1];
+                const uint64_t sa = h_occ_[o];
+                const size_t d = doc_of(sa);
+                uint64_t pos = sa - doc_start_[d];
+                bool minus = false;
+                if (revcomp_ && pos >= half[d]) {
+                    minus = true;
+                    pos = 2 * half[d] - pos - len - (last ? 0 : 1);       // size_t arithmetic, may wrap (:229,:248)
+                }
+                R.mem_offsets.push_back((int64_t)pos);
+                R.mem_docs.push_back(d);
+                R.mem_strands.push_back(minus ? 0 : 1);
+                append_uint(T, pos); append_uint(docs_s, d); strand_s.push_back(minus ? '-' : '+');
+                if (!last) { T.push_back(','); docs_s.push_back(','); strand_s.push_back(','); }
+            }
+            R.occ_start.push_back(R.mem_offsets.size());
+            T.push_back('\t'); T += docs_s; T.push_back('\t'); T += strand_s; T.push_back('\n');
+        }
+    }
+    bumbl_.clear();
+    stage_ms_[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+const std::string& Engine::bumbl() {
+    // mem_finder.hpp:451-503: u16 flags | u64 n_seqs | u64 n_mums | u32 len[] | i64 starts | strand bits
+    if (!bumbl_.empty() || !rows_.mum_mode) return bumbl_;
+    const HostRows& R = rows_;
+    const uint64_t nm = R.n_rows(), ns = R.n_docs, nbits = nm * ns;
+    uint16_t flags = (uint16_t)(1u << 15);
+    if (num_distinct_eff_ < ns) flags |= (uint16_t)(1u << 13);
+    bumbl_.assign(2 + 16 + 4 * nm + 8 * nbits + (nbits + 7) / 8, '\0');
+    char* p = &bumbl_[0];
+    std::memcpy(p, &flags, 2); p += 2;
+    std::memcpy(p, &ns, 8); p += 8;
+    std::memcpy(p, &nm, 8); p += 8;
+    if (nm) { std::memcpy(p, R.length.data(), 4 * nm); p += 4 * nm; std::memcpy(p, R.mum_offsets.data(), 8 * nbits); p += 8 * nbits; }
+    for (uint64_t i = 0; i < nbits; i++)
+        if (R.mum_strands[i]) p[i / 8] |= (char)(1u << (7 - (i % 8)));
+    return bumbl_;
+}
+
+void Engine::run(const mmt_params& p) {
+    MMT_HIP(hipSetDevice(device_));
+    auto t0 = std::chrono::steady_clock::now();
+    for (auto& ev : ev_) ev->reset();
+    for (float& f : stage_ms_) f = 0.f;
+    rows_ = HostRows();
+    rows_.mum_mode = p.max_doc_freq == 1;
+    rows_.n_docs = doc_len_.size();
+    n_cand_ = 0; thresh_len_ = 0; bumbl_.clear();
+    if (doc_len_.empty()) return;                       // mumemto_api.cpp:338-340
+    ev_[0]->start(stream_); build_text(p.use_revcomp != 0); ev_[0]->stop(stream_);
+    ev_[1]->start(stream_); suffix_sort(); ev_[1]->stop(stream_);
+    ev_[2]->start(stream_); lcp_bwt(); ev_[2]->stop(stream_);
+    scan(p);
+    make_rows(p);
+    for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
+    stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::copy_text(uint8_t* out) const {
+    MMT_HIP(hipMemcpy(out, d_text_.get(), n_, hipMemcpyDeviceToHost));
+}
+void Engine::copy_sa(uint32_t* out) const { MMT_HIP(hipMemcpy(out, d_sa_.get(), n_ * 4, hipMemcpyDeviceToHost)); }
+void Engine::copy_lcp(uint32_t* out) const { MMT_HIP(hipMemcpy(out, d_lcp_.get(), n_ * 4, hipMemcpyDeviceToHost)); }
+void Engine::copy_bwt(uint8_t* out) const { MMT_HIP(hipMemcpy(out, d_bwt_.get(), n_, hipMemcpyDeviceToHost)); }
+void Engine::copy_candidates(uint32_t* out) const {
+    if (n_cand_) MMT_HIP(hipMemcpy(out, d_cand_.get(), n_cand_ * sizeof(k::Cand), hipMemcpyDeviceToHost));
+}
+void Engine::copy_thresh(uint16_t* out) const {
+    if (thresh_len_) MMT_HIP(hipMemcpy(out, d_thresh_.get(), thresh_len_ * 2, hipMemcpyDeviceToHost));
+}
+
+}  // namespace mmt

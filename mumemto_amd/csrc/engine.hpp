@@ -1,0 +1,108 @@
+// engine.hpp -- the hot path as one object: text -> SA/LCP/BWT -> scan -> rows.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mumemto_gpu.h"
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace mmt {
+
+// Host-side result of one run, in the shapes the reference's collectors use
+// (mumemto_library/mumemto_api.cpp:137-166 MEM, :241-286 MUM).
+struct HostRows {
+    bool mum_mode = true;
+    size_t n_docs = 0;
+    std::vector<uint32_t> length;
+    // MUM mode: n_rows * n_docs
+    std::vector<int64_t> mum_offsets;
+    std::vector<uint8_t> mum_strands;
+    // MEM mode: flat occurrences
+    std::vector<uint64_t> occ_start;   // n_rows + 1
+    std::vector<int64_t> mem_offsets;
+    std::vector<uint64_t> mem_docs;
+    std::vector<uint8_t> mem_strands;
+    std::string text;                  // PREFIX.mums / PREFIX.mems bytes
+    size_t n_rows() const { return length.size(); }
+};
+
+class Engine {
+public:
+    Engine(int device, hipStream_t stream);
+    ~Engine();
+    Engine(const Engine&) = delete;
+
+    void set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs);
+    void set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs);
+    void run(const mmt_params& p);
+
+    const HostRows& rows() const { return rows_; }
+    const std::string& bumbl();
+    uint64_t text_length() const { return n_; }
+    size_t n_docs() const { return doc_len_.size(); }
+    const std::vector<uint64_t>& doc_len() const { return doc_len_; }
+    hipStream_t stream() const { return stream_; }
+    int device() const { return device_; }
+
+    // stage introspection
+    void copy_text(uint8_t* out) const;
+    void copy_sa(uint32_t* out) const;
+    void copy_lcp(uint32_t* out) const;
+    void copy_bwt(uint8_t* out) const;
+    size_t n_candidates() const { return n_cand_; }
+    void copy_candidates(uint32_t* out) const;
+    size_t thresh_len() const { return thresh_len_; }
+    void copy_thresh(uint16_t* out) const;
+    const uint16_t* thresh_device() const { return d_thresh_.get(); }
+    const uint32_t* isa_device() const { return d_rank_.get(); }
+    const float* stage_ms() const { return stage_ms_; }
+    DevBuf<uint8_t>& scratch() { return d_temp_; }
+
+private:
+    void build_text(bool revcomp);
+    void suffix_sort();
+    void lcp_bwt();
+    void scan(const mmt_params& p);
+    void make_rows(const mmt_params& p);
+
+    int device_;
+    hipStream_t stream_;
+    bool own_stream_ = false;
+
+    // input
+    const uint8_t* d_bases_ = nullptr;    // borrowed or = d_bases_own_
+    DevBuf<uint8_t> d_bases_own_;
+    std::vector<uint64_t> doc_len_, doc_base_, doc_start_;
+    DevBuf<uint64_t> d_doc_base_, d_doc_start_;
+    bool revcomp_ = true;
+    uint64_t n_ = 0;
+
+    // columns
+    DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_;
+    DevBuf<uint32_t> d_hist_, d_sa_, d_rank_, d_lcp_, d_headval_, d_head_, d_idx_, d_count_;
+    DevBuf<uint32_t> d_pos_a_, d_pos_b_, d_sac_a_, d_sac_b_, d_headc_;
+    DevBuf<uint64_t> d_keys_a_, d_keys_b_;
+    // scan
+    DevBuf<k::Cand> d_cand_, d_rows_;
+    DevBuf<uint16_t> d_thresh_;
+    DevBuf<uint64_t> d_off_;
+    DevBuf<uint32_t> d_occ_;
+    size_t n_cand_ = 0, thresh_len_ = 0;
+    std::vector<k::Cand> h_rows_;
+    std::vector<uint32_t> h_occ_;
+    std::vector<uint64_t> h_off_;
+
+    HostRows rows_;
+    std::string bumbl_;
+    uint64_t num_distinct_eff_ = 0;
+    float stage_ms_[8] = {0};
+    std::unique_ptr<EventPair> ev_[6];
+};
+
+// Row formatting shared with the merge output (host side of A6).
+void append_uint(std::string& s, uint64_t v);
+
+}  // namespace mmt

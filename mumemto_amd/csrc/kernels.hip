@@ -1,0 +1,578 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the hot path.
+//
+// Everything here is integer / byte work bounded by HBM bandwidth: loads are
+// coalesced and, where a tile is re-read (keys, scan), staged through LDS.
+// Reference behaviour restated by each kernel is cited at its definition.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace mmt { namespace k {
+
+static inline unsigned grid_for(uint64_t items, unsigned per_block) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    return (unsigned)(g ? g : 1);
+}
+
+// ============================================================================
+// A1  text layout -- RefBuilder::build_input_file (src/ref_builder.cpp:211-314)
+//     and build_input_file_lib (:330-384): per document
+//     UPPER(F) '$' [ revcomp(UPPER(F)) '$' ]; complement = the IUPAC table the
+//     reference embeds (:29-38), letters only.
+// ============================================================================
+__device__ __forceinline__ uint8_t dev_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+__device__ __forceinline__ uint8_t dev_complement(uint8_t c) {
+    switch (c) {
+        case 'A': return 'T'; case 'B': return 'V'; case 'C': return 'G'; case 'D': return 'H';
+        case 'G': return 'C'; case 'H': return 'D'; case 'K': return 'M'; case 'M': return 'K';
+        case 'R': return 'Y'; case 'T': return 'A'; case 'U': return 'A'; case 'V': return 'B';
+        case 'Y': return 'R'; default: return c;   // S W N and non-IUPAC bytes map to themselves
+    }
+}
+
+// largest d in [0, n_docs] with start[d] <= p
+__device__ __forceinline__ uint32_t doc_lookup(const uint64_t* __restrict__ start, uint32_t n_docs, uint64_t p) {
+    uint32_t lo = 0, hi = n_docs;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict__ raw,
+                                                       const uint64_t* __restrict__ doc_base,
+                                                       const uint64_t* __restrict__ doc_start, uint32_t n_docs,
+                                                       int revcomp, uint8_t* __restrict__ text, uint64_t n,
+                                                       uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_hist[256];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) s_hist[i] = 0;
+    __syncthreads();
+    const uint64_t p0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 4;   // 4 output bytes per thread
+    if (p0 < n) {
+        uint32_t d = doc_lookup(doc_start, n_docs, p0);
+        uint32_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint64_t p = p0 + b;
+            uint8_t c = 0;
+            if (p < n) {
+                while (p >= doc_start[d + 1]) d++;
+                uint64_t L = doc_base[d + 1] - doc_base[d];
+                uint64_t local = p - doc_start[d];
+                if (local < L) c = dev_upper(raw[doc_base[d] + local]);
+                else if (local == L) c = '$';
+                else if (local <= 2 * L) c = dev_complement(dev_upper(raw[doc_base[d] + (2 * L - local)]));
+                else c = '$';
+                atomicAdd(&s_hist[c], 1u);
+            }
+            word |= (uint32_t)c << (8 * b);
+        }
+        *reinterpret_cast<uint32_t*>(text + p0) = word;   // buffer is padded past n
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += BLOCK)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+    (void)revcomp;
+}
+
+void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
+                bool revcomp, uint8_t* text, uint64_t n, uint32_t* hist, hipStream_t s) {
+    constexpr int B = 256;
+    hipLaunchKernelGGL(k_build_text<B>, dim3(grid_for((n + 3) / 4, B)), dim3(B), 0, s, raw, d_doc_base, d_doc_start,
+                       n_docs, (int)revcomp, text, n, hist);
+    MMT_HIP(hipGetLastError());
+}
+
+// ============================================================================
+// A8  direct suffix sort: prefix doubling over a radix sort.
+//     Replaces gsacak(text) of include/direct_gsacak.hpp:62 (suffix array of
+//     the whole text; the end of the text is smaller than every symbol).
+// ============================================================================
+// Tile of the text is converted to `bits`-wide symbol codes in LDS once; each
+// thread then builds 4 consecutive keys with a rolling shift.
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__ text, uint32_t n,
+                                                     const uint8_t* __restrict__ code, int bits, int chars,
+                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    constexpr int TILE = BLOCK * PER;
+    __shared__ uint8_t s_code[256];
+    __shared__ uint8_t s_sym[TILE + 64];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = code[i];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    for (int i = threadIdx.x; i < TILE + 64; i += BLOCK) {
+        uint64_t p = base + i;
+        s_sym[i] = p < n ? s_code[text[p]] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * PER;
+    const uint64_t mask = (bits * chars >= 64) ? ~0ull : ((1ull << (bits * chars)) - 1);
+    uint64_t key = 0;
+    for (int c = 0; c < chars; c++) key = (key << bits) | s_sym[t0 + c];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        uint64_t p = base + t0 + q;
+        if (p < n) { keys[p] = key & mask; vals[p] = (uint32_t)p; }
+        key = ((key << bits) | s_sym[t0 + q + chars]) & mask;
+    }
+}
+void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint64_t* keys,
+               uint32_t* vals, hipStream_t s) {
+    constexpr int B = 256, PER = 4;
+    hipLaunchKernelGGL((k_pack_keys<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, d_code, bits, chars,
+                       keys, vals);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_mark_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ headval) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    headval[j] = (j == 0 || keys[j] != keys[j - 1]) ? j : 0u;
+}
+void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_heads, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, n, headval);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_scatter_rank(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ head, uint32_t n,
+                               uint32_t* __restrict__ rank) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) rank[sa[j]] = head[j];
+}
+void scatter_rank(const uint32_t* sa, const uint32_t* head, uint32_t n, uint32_t* rank, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_rank, dim3(grid_for(n, 256)), dim3(256), 0, s, sa, head, n, rank);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_flag_unsorted(const uint32_t* __restrict__ head, uint32_t n, uint8_t* __restrict__ flags) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    bool single = head[j] == j && (j + 1 == n || head[j + 1] == j + 1);
+    flags[j] = single ? 0 : 1;
+}
+void flag_unsorted(const uint32_t* head, uint32_t n, uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_unsorted, dim3(grid_for(n, 256)), dim3(256), 0, s, head, n, flags);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_gather_active(const uint32_t* __restrict__ idx, uint32_t m, const uint32_t* __restrict__ sa,
+                                const uint32_t* __restrict__ head, uint32_t* __restrict__ out_pos,
+                                uint32_t* __restrict__ out_sa, uint32_t* __restrict__ out_head) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    uint32_t j = idx[c];
+    out_pos[c] = j; out_sa[c] = sa[j]; out_head[c] = head[j];
+}
+void gather_active(const uint32_t* idx, uint32_t m, const uint32_t* sa, const uint32_t* head, uint32_t* out_pos,
+                   uint32_t* out_sa, uint32_t* out_head, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_active, dim3(grid_for(m, 256)), dim3(256), 0, s, idx, m, sa, head, out_pos, out_sa,
+                       out_head);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_make_round_keys(const uint32_t* __restrict__ sa_c, const uint32_t* __restrict__ head_c, uint32_t m,
+                                  const uint32_t* __restrict__ rank, uint32_t n, uint32_t h, int shift,
+                                  uint64_t* __restrict__ keys) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    uint64_t i = (uint64_t)sa_c[c] + h;
+    uint64_t second = i < n ? (uint64_t)rank[i] + 1 : 0;   // past the end sorts first
+    keys[c] = ((uint64_t)head_c[c] << shift) | second;
+}
+void make_round_keys(const uint32_t* sa_c, const uint32_t* head_c, uint32_t m, const uint32_t* rank, uint32_t n,
+                     uint32_t h, int shift, uint64_t* keys, hipStream_t s) {
+    hipLaunchKernelGGL(k_make_round_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_c, head_c, m, rank, n, h, shift,
+                       keys);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_mark_subheads(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, uint32_t m,
+                                uint32_t* __restrict__ headval) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    headval[c] = (c == 0 || keys[c] != keys[c - 1]) ? pos[c] : 0u;
+}
+void mark_subheads(const uint64_t* keys, const uint32_t* pos, uint32_t m, uint32_t* headval, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_subheads, dim3(grid_for(m, 256)), dim3(256), 0, s, keys, pos, m, headval);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_apply_round(const uint32_t* __restrict__ sa_sorted, const uint32_t* __restrict__ newhead,
+                              const uint32_t* __restrict__ pos, uint32_t m, uint32_t* __restrict__ sa,
+                              uint32_t* __restrict__ rank, uint8_t* __restrict__ flags) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    uint32_t p = pos[c], i = sa_sorted[c], hd = newhead[c];
+    sa[p] = i;
+    rank[i] = hd;
+    bool single = hd == p && (c + 1 == m || newhead[c + 1] == pos[c + 1]);
+    flags[c] = single ? 0 : 1;
+}
+void apply_round(const uint32_t* sa_sorted, const uint32_t* newhead, const uint32_t* pos, uint32_t m, uint32_t* sa,
+                 uint32_t* rank, uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_apply_round, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_sorted, newhead, pos, m, sa, rank,
+                       flags);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_compact_round(const uint32_t* __restrict__ idx, uint32_t m2, const uint32_t* __restrict__ pos,
+                                const uint32_t* __restrict__ sa_sorted, const uint32_t* __restrict__ newhead,
+                                uint32_t* __restrict__ out_pos, uint32_t* __restrict__ out_sa,
+                                uint32_t* __restrict__ out_head) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m2) return;
+    uint32_t o = idx[c];
+    out_pos[c] = pos[o]; out_sa[c] = sa_sorted[o]; out_head[c] = newhead[o];
+}
+void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const uint32_t* sa_sorted,
+                   const uint32_t* newhead, uint32_t* out_pos, uint32_t* out_sa, uint32_t* out_head, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_round, dim3(grid_for(m2, 256)), dim3(256), 0, s, idx, m2, pos, sa_sorted, newhead,
+                       out_pos, out_sa, out_head);
+    MMT_HIP(hipGetLastError());
+}
+
+// ============================================================================
+// LCP column: lcp[j] = LCP(suffix sa[j-1], suffix sa[j]), lcp[0] = 0 -- the
+// array gsacak returns (direct_gsacak.hpp:62) / pfp_lcp emits
+// (pfp_lcp_mum.hpp:197).  Text-order sweep (Kasai et al.) cut into chunks, one
+// chunk per lane; matches are extended 8 bytes at a time.
+// ============================================================================
+__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);   // gfx950 + amdhsa: one unaligned global_load_dwordx2
+    return v;
+}
+
+template <int CHUNK>
+__global__ void k_lcp_from_isa(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ sa,
+                               const uint32_t* __restrict__ isa, uint32_t* __restrict__ lcp) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i0 = t * CHUNK;
+    if (i0 >= n) return;
+    uint64_t i1 = i0 + CHUNK < n ? i0 + CHUNK : n;
+    uint32_t h = 0;
+    for (uint64_t i = i0; i < i1; i++) {
+        uint32_t r = isa[i];
+        if (r == 0) { lcp[0] = 0; h = 0; continue; }
+        uint32_t p = sa[r - 1];
+        uint32_t limit = n - (uint32_t)(i > p ? i : p);   // the shorter suffix ends first
+        while (h < limit) {
+            uint64_t x = load_u64(text + i + h), y = load_u64(text + p + h);
+            if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); break; }
+            h += 8;
+        }
+        if (h > limit) h = limit;
+        lcp[r] = h;
+        if (h > 0) h--;
+    }
+}
+void lcp_from_isa(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
+                  hipStream_t s) {
+    constexpr int CHUNK = 64;
+    uint64_t threads = ((uint64_t)n + CHUNK - 1) / CHUNK;
+    hipLaunchKernelGGL(k_lcp_from_isa<CHUNK>, dim3(grid_for(threads, 64)), dim3(64), 0, s, text, n, sa, isa, lcp);
+    MMT_HIP(hipGetLastError());
+}
+
+// bwt[j] = text[sa[j]-1], 0 for sa[j] = 0 (pfp_lcp_mum.hpp:268, direct_gsacak.hpp:66)
+__global__ void k_bwt_from_sa(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ sa,
+                              uint8_t* __restrict__ bwt) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t p = sa[j];
+    bwt[j] = p ? text[p - 1] : (uint8_t)0;
+}
+void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s) {
+    hipLaunchKernelGGL(k_bwt_from_sa, dim3(grid_for(n, 256)), dim3(256), 0, s, text, n, sa, bwt);
+    MMT_HIP(hipGetLastError());
+}
+
+// ============================================================================
+// A5  match scan -- mem_finder::update / update_mems (include/mem_finder.hpp:
+//     161-170, 304-355), order-independent form:
+//     position j closes every LCP interval [s, j-1] whose value
+//     l = min(lcp[s+1..j-1]) satisfies lcp[s] < l and lcp[j] < l.  The thread of
+//     j walks left from j-1 keeping the running minimum; every time the minimum
+//     drops it has found one interval, longest first -- the pop order of the
+//     reference's stack.  Intervals with l < min_len are never produced
+//     (:350-353); an interval is produced only if some later entry closes it
+//     (no flush, pfp_lcp_mum.hpp:223-230) which holds by construction as j <= n-1.
+//     Left-maximality (check_bwt_range, :189-192) = some t in (s, j-1] with
+//     bwt[t] != bwt[t-1], accumulated during the same walk.
+//     LCP and BWT tiles (+ left halo of `cap` entries) are staged in LDS; the
+//     positions with a falling edge are first compacted into an LDS work queue
+//     so that every lane of a wave walks a real candidate.
+// ============================================================================
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo) {
+    constexpr int TILE = BLOCK * PER;
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                   // halo + TILE
+    uint8_t* s_bwt = smem + (size_t)(halo + TILE) * 4;                      // halo + TILE
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_bwt + ((halo + TILE + 15) & ~15u));  // TILE
+    __shared__ uint32_t s_qn;
+
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    const uint64_t lds_lo = tile0 >= halo ? tile0 - halo : 0;              // first staged index
+    const uint32_t shift = (uint32_t)(tile0 - lds_lo);                      // LDS index of tile0
+    const uint64_t hi = tile0 + TILE < a.n ? tile0 + TILE : a.n;           // one past last staged index
+    const uint32_t staged = (uint32_t)(hi - lds_lo);
+    if (threadIdx.x == 0) s_qn = 0;
+    for (uint32_t i = threadIdx.x; i < staged; i += BLOCK) {
+        s_lcp[i] = a.lcp[lds_lo + i];
+        s_bwt[i] = a.bwt[lds_lo + i];
+    }
+    __syncthreads();
+
+    // phase 1: falling edges with a long enough value go to the work queue
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        uint32_t o = threadIdx.x + q * BLOCK;                               // offset in tile
+        uint64_t j = tile0 + o;
+        if (j >= 1 && j < a.n) {
+            uint32_t prev = s_lcp[shift + o - 1], cur = s_lcp[shift + o];
+            if (cur < prev && prev >= a.min_len) s_queue[atomicAdd(&s_qn, 1u)] = (uint16_t)o;
+        }
+    }
+    __syncthreads();
+    const uint32_t qn = s_qn;
+
+    // phase 2: walk
+    for (uint32_t w = threadIdx.x; w < qn; w += BLOCK) {
+        const uint32_t o = s_queue[w];
+        const uint64_t j = tile0 + o;
+        const uint32_t closing = s_lcp[shift + o];
+        uint64_t kpos = j - 1;                                              // current k
+        uint32_t m = s_lcp[shift + o - 1];
+        bool chg = false;
+        while (true) {
+            // candidate start s = kpos - 1
+            if (kpos == 0) break;
+            uint32_t v; uint8_t b1, b0;
+            if (kpos - 1 >= lds_lo) {
+                uint32_t li = (uint32_t)(kpos - lds_lo);
+                v = s_lcp[li - 1]; b1 = s_bwt[li]; b0 = s_bwt[li - 1];
+            } else {                                                        // uncapped modes only
+                v = a.lcp[kpos - 1]; b1 = a.bwt[kpos]; b0 = a.bwt[kpos - 1];
+            }
+            chg |= (b1 != b0);
+            if (v < m) {
+                uint64_t cnt = j - (kpos - 1);
+                if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
+                    uint32_t slot = atomicAdd(a.d_count, 1u);
+                    if (slot < a.capacity) {
+                        Cand c; c.start = (uint32_t)(kpos - 1); c.end = (uint32_t)(j - 1); c.len = m;
+                        c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
+                        a.out[slot] = c;
+                    }
+                }
+                m = v;
+                if (m <= closing || m < a.min_len) break;
+            }
+            kpos--;
+            if (a.cap && j - (kpos - 1) > a.cap) break;                     // every further interval is too big
+        }
+    }
+}
+
+void scan_intervals(const ScanArgs& a, hipStream_t s) {
+    constexpr int B = 256, PER = 8, TILE = B * PER;
+    uint32_t halo = a.cap ? a.cap + 1 : 256;
+    halo = (halo + 3) & ~3u;
+    if (halo > 8192) halo = 8192;   // beyond this the walk reads the cached global columns
+    size_t lds = (size_t)(halo + TILE) * 4 + ((halo + TILE + 15) & ~15u) + (size_t)TILE * 2;
+    hipLaunchKernelGGL((k_scan<B, PER>), dim3(grid_for(a.n, TILE)), dim3(B), lds, s, a, halo);
+    MMT_HIP(hipGetLastError());
+}
+
+// ============================================================================
+// Candidate verification -- check_doc_range (mem_finder.hpp:265-289), the
+// threshold record of update_mems (:326-336) and the row decision (:338-343).
+// One wave per candidate; document ids are derived from SA by binary search
+// over the document starts (rank of doc_ends, pfp_lcp_mum.hpp:194).
+// ============================================================================
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { uint32_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_counters) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(smem) + (size_t)(threadIdx.x >> 6) * a.n_docs;
+    const uint32_t lane = threadIdx.x & 63;
+    if (use_counters) {
+        for (uint32_t i = lane; i < a.n_docs; i += 64) ctr[i] = 0;
+    }
+    const uint64_t wave = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES;
+    for (uint64_t ci = wave; ci < a.n_cand; ci += n_waves) {
+        const Cand c = a.cand[ci];
+        const uint32_t cnt = c.end - c.start + 1;
+        bool ok;
+        uint32_t first0 = 0xffffffffu;
+        if (!use_counters) {
+            // <= 64 documents, at most one occurrence each, interval fits one wave
+            uint64_t bit = 0;
+            if (lane < cnt) {
+                uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[c.start + lane]);
+                bit = 1ull << d;
+                if (d == 0) first0 = c.start + lane;
+            }
+            uint64_t mask = wave_or64(bit);
+            ok = (uint32_t)__popcll(mask) == cnt && cnt >= a.num_distinct;
+        } else {
+            uint32_t uniq = 0, fail = 0;
+            for (uint32_t base = 0; base < cnt; base += 64) {
+                if (base + lane < cnt) {
+                    uint32_t kk = c.start + base + lane;
+                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[kk]);
+                    if (d >= a.n_docs) { fail = 1; }
+                    else {
+                        uint32_t old = atomicAdd(&ctr[d], 1u);
+                        if (old == 0) uniq++;
+                        if (a.max_doc_freq && old + 1 > a.max_doc_freq) fail = 1;
+                        if (d == 0 && kk < first0) first0 = kk;
+                    }
+                }
+            }
+            uniq = wave_sum32(uniq);
+            fail = wave_sum32(fail);
+            for (uint32_t base = 0; base < cnt; base += 64) {               // undo the counters
+                if (base + lane < cnt) {
+                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[c.start + base + lane]);
+                    if (d < a.n_docs) ctr[d] = 0;
+                }
+            }
+            ok = fail == 0 && uniq >= a.num_distinct;
+        }
+        if (!ok) continue;
+        if (a.merge) {
+            first0 = wave_min32(first0);
+            if (lane == 0 && first0 != 0xffffffffu) {
+                uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
+                uint32_t nb = before > after ? before : after;
+                if (nb > 65535u) nb = 65535u;
+                a.thresh[(uint64_t)a.sa[first0] - a.d_doc_start[0]] = (uint16_t)nb;
+            }
+        }
+        if (lane == 0 && (c.flags & CAND_LEFT_MAXIMAL)) a.rows[atomicAdd(a.d_row_count, 1u)] = c;
+    }
+}
+
+void verify_candidates(const VerifyArgs& a, hipStream_t s) {
+    if (a.n_cand == 0) return;
+    // every candidate interval has <= cap entries; the single-wave bitmap path needs
+    // MUM mode, <= 64 documents (then an accepted interval has <= 64 entries)
+    bool fast = a.max_doc_freq == 1 && a.n_docs <= 64;
+    uint64_t waves_needed = a.n_cand;
+    if (fast) {
+        // intervals longer than 64 cannot be all-distinct with <= 64 docs, but the fast path
+        // reads only 64 entries; they are rejected by the popcount == cnt test because cnt > 64
+        constexpr int W = 4;
+        unsigned grid = (unsigned)std::min<uint64_t>((waves_needed + W - 1) / W, 256u * 16u);
+        hipLaunchKernelGGL(k_verify<W>, dim3(grid), dim3(W * 64), 0, s, a, 0);
+    } else {
+        size_t per_wave = (size_t)a.n_docs * 4;
+        int W = per_wave * 4 <= 144 * 1024 ? 4 : (per_wave * 2 <= 144 * 1024 ? 2 : 1);
+        unsigned grid = (unsigned)std::min<uint64_t>((waves_needed + W - 1) / W, 256u * 8u);
+        size_t lds = per_wave * W;
+        if (W == 4) hipLaunchKernelGGL(k_verify<4>, dim3(grid), dim3(256), lds, s, a, 1);
+        else if (W == 2) hipLaunchKernelGGL(k_verify<2>, dim3(grid), dim3(128), lds, s, a, 1);
+        else hipLaunchKernelGGL(k_verify<1>, dim3(grid), dim3(64), lds, s, a, 1);
+    }
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_gather_occ(const Cand* __restrict__ rows, const uint64_t* __restrict__ off, uint32_t n_rows,
+                             const uint32_t* __restrict__ sa, uint32_t* __restrict__ occ) {
+    // one wave per row
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n_rows) return;
+    const Cand c = rows[r];
+    const uint32_t cnt = c.end - c.start + 1;
+    for (uint32_t k2 = lane; k2 < cnt; k2 += 64) occ[off[r] + k2] = sa[c.start + k2];
+}
+void gather_occurrences(const Cand* rows, const uint64_t* off, uint32_t n_rows, const uint32_t* sa, uint32_t* occ,
+                        hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_gather_occ, dim3(grid_for((uint64_t)n_rows * 64, 256)), dim3(256), 0, s, rows, off, n_rows,
+                       sa, occ);
+    MMT_HIP(hipGetLastError());
+}
+
+// ============================================================================
+// A9  anchor merge, one fold step -- merge_partitions
+//     (src/merge_candidates.cpp:106-157), one thread per anchor position.
+//     The reference walks i = 0..L_0 keeping "the last MUM that started at or
+//     before i" per side; that is row (#starts in [0,i]) - 1, a prefix count.
+// ============================================================================
+__global__ void k_mark_starts(const uint64_t* __restrict__ starts, uint32_t n_rows, uint8_t* __restrict__ bv,
+                              uint32_t* __restrict__ ones) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    bv[starts[r]] = 1;
+    ones[starts[r]] = 1;
+}
+void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, uint32_t* ones, hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, starts, n_rows, bv, ones);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_fold_step(FoldArgs a) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.len) return;
+    const uint16_t na = a.nb_a[i], nb = a.nb_b[i];
+    const bool both = na > 0 && nb > 0;
+    const uint16_t nbo = both ? (na > nb ? na : nb) : (uint16_t)0;        // :121-123
+    a.nb_out[i] = nbo;
+    const bool sa_ = a.bv_a[i] != 0, sb_ = a.bv_b[i] != 0;
+    if (!(sa_ || sb_) || !both) return;                                    // :132
+    // exclusive counts + own flag = number of starts in [0, i]
+    const uint32_t ca = a.rank_a[i] + (sa_ ? 1u : 0u), cb = a.rank_b[i] + (sb_ ? 1u : 0u);
+    if (ca == 0 || cb == 0) return;                                        // cur_mum1 && cur_mum2
+    const uint32_t ra = ca - 1, rb = cb - 1;
+    const uint64_t d1 = i - a.start_a[ra], d2 = i - a.start_b[rb];
+    if (d1 > a.len_a[ra] || d2 > a.len_b[rb]) return;                      // :135
+    const uint32_t s1 = (uint32_t)(a.len_a[ra] - d1), s2 = (uint32_t)(a.len_b[rb] - d2);
+    const uint32_t nl = s1 < s2 ? s1 : s2;
+    if (nl > nbo && nl >= 20) {                                            // :139-141
+        uint32_t slot = atomicAdd(a.d_count, 1u);
+        if (slot < a.capacity) { a.out_pos[slot] = i; a.out_ra[slot] = ra; a.out_rb[slot] = rb; a.out_len[slot] = nl; }
+    }
+}
+void fold_step(const FoldArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_step, dim3(grid_for(a.len, 256)), dim3(256), 0, s, a);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint64_t* __restrict__ idx, uint32_t n,
+                             uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+void gather_u32(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, n, out);
+    MMT_HIP(hipGetLastError());
+}
+
+}}  // namespace mmt::k

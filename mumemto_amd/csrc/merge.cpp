@@ -1,0 +1,204 @@
+// merge.cpp -- see merge.hpp.  Host side keeps the row tables (rows x docs);
+// the device does everything that is proportional to the anchor length.
+#include "merge.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <stdexcept>
+
+#include "prims.hpp"
+
+namespace mmt {
+namespace {
+
+struct Side {
+    size_t n_docs = 0;
+    std::vector<uint32_t> length;
+    std::vector<int64_t> offsets;
+    std::vector<uint8_t> strands;
+    size_t n_rows() const { return length.size(); }
+};
+
+// parse_candidate(): rows sorted by their anchor offset (merge_candidates.cpp:89-92)
+Side load_side(const mmt_partition& p) {
+    Side s;
+    s.n_docs = p.n_docs;
+    std::vector<size_t> order(p.n_rows);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(),
+              [&](size_t a, size_t b) { return p.offsets[a * p.n_docs] < p.offsets[b * p.n_docs]; });
+    s.length.resize(p.n_rows); s.offsets.resize(p.n_rows * p.n_docs); s.strands.resize(p.n_rows * p.n_docs);
+    for (size_t i = 0; i < p.n_rows; i++) {
+        size_t r = order[i];
+        s.length[i] = p.length[r];
+        for (size_t c = 0; c < p.n_docs; c++) {
+            s.offsets[i * p.n_docs + c] = p.offsets[r * p.n_docs + c];
+            s.strands[i * p.n_docs + c] = p.strands[r * p.n_docs + c];
+        }
+    }
+    return s;
+}
+
+struct DeviceSide {
+    DevBuf<uint64_t> start;
+    DevBuf<uint32_t> len, ones, rank;
+    DevBuf<uint8_t> bv;
+    void upload(const Side& s, uint64_t L, DevBuf<uint8_t>& temp, hipStream_t st) {
+        const size_t n = s.n_rows();
+        std::vector<uint64_t> h_start(n);
+        for (size_t r = 0; r < n; r++) {
+            int64_t o = s.offsets[r * s.n_docs];
+            if (o < 0 || (uint64_t)o >= L) throw std::runtime_error("anchor offset outside the threshold array");
+            h_start[r] = (uint64_t)o;
+        }
+        start.ensure(n + 1); len.ensure(n + 1); bv.ensure(L); ones.ensure(L); rank.ensure(L);
+        if (n) {
+            MMT_HIP(hipMemcpyAsync(start.get(), h_start.data(), n * 8, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipMemcpyAsync(len.get(), s.length.data(), n * 4, hipMemcpyHostToDevice, st));
+        }
+        MMT_HIP(hipMemsetAsync(bv.get(), 0, L, st));
+        MMT_HIP(hipMemsetAsync(ones.get(), 0, L * 4, st));
+        k::mark_starts(start.get(), (uint32_t)n, bv.get(), ones.get(), st);
+        prims::exclusive_sum_u32(temp, ones.get(), rank.get(), L, st);
+        MMT_HIP(hipStreamSynchronize(st));   // h_start goes out of scope
+    }
+};
+
+}  // namespace
+
+MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
+    hipStream_t st = e.stream();
+    MMT_HIP(hipSetDevice(e.device()));
+    const uint64_t L = parts[0].thresh_len;
+    for (size_t i = 0; i < k; i++) {
+        if (parts[i].thresh_len != L) throw std::runtime_error("partitions disagree on the anchor length");
+        if (parts[i].n_rows >= 0xffffffffull) throw std::runtime_error("too many rows in a partition");
+    }
+    DevBuf<uint16_t> nb_left, nb_right, nb_out;
+    auto load_thresh = [&](const mmt_partition& p, DevBuf<uint16_t>& dst) {
+        dst.ensure(L);
+        MMT_HIP(hipMemcpyAsync(dst.get(), p.thresh, L * 2,
+                               p.thresh_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    };
+    Side left = load_side(parts[0]);
+    load_thresh(parts[0], nb_left);
+    DeviceSide da, db;
+    DevBuf<uint64_t> d_pos; DevBuf<uint32_t> d_ra, d_rb, d_len, d_count;
+    d_count.ensure(4);
+    for (size_t pi = 1; pi < k; pi++) {
+        Side right = load_side(parts[pi]);
+        load_thresh(parts[pi], nb_right);
+        nb_out.ensure(L);
+        da.upload(left, L, e.scratch(), st);
+        db.upload(right, L, e.scratch(), st);
+        const size_t capacity = left.n_rows() + right.n_rows() + 1;
+        d_pos.ensure(capacity); d_ra.ensure(capacity); d_rb.ensure(capacity); d_len.ensure(capacity);
+        MMT_HIP(hipMemsetAsync(d_count.get(), 0, 16, st));
+        k::FoldArgs a;
+        a.len = L; a.nb_a = nb_left.get(); a.nb_b = nb_right.get(); a.nb_out = nb_out.get();
+        a.rank_a = da.rank.get(); a.rank_b = db.rank.get();
+        a.start_a = da.start.get(); a.start_b = db.start.get();
+        a.len_a = da.len.get(); a.len_b = db.len.get();
+        a.bv_a = da.bv.get(); a.bv_b = db.bv.get();
+        a.out_pos = d_pos.get(); a.out_ra = d_ra.get(); a.out_rb = d_rb.get(); a.out_len = d_len.get();
+        a.capacity = (uint32_t)capacity; a.d_count = d_count.get();
+        k::fold_step(a, st);
+        uint32_t found = 0;
+        MMT_HIP(hipMemcpyAsync(&found, d_count.get(), 4, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        if (found > capacity) throw std::runtime_error("anchor merge produced more rows than MUM starts");
+        std::vector<uint64_t> h_pos; std::vector<uint32_t> h_ra, h_rb, h_len;
+        d2h(h_pos, d_pos.get(), found, st); d2h(h_ra, d_ra.get(), found, st);
+        d2h(h_rb, d_rb.get(), found, st); d2h(h_len, d_len.get(), found, st);
+        std::vector<uint32_t> order(found);
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_pos[x] < h_pos[y]; });
+        // new rows: fix_neg_strand (merge_candidates.cpp:97-104) + column concatenation (:142-151)
+        Side out;
+        out.n_docs = left.n_docs + right.n_docs - 1;
+        out.length.resize(found); out.offsets.resize((size_t)found * out.n_docs);
+        out.strands.resize((size_t)found * out.n_docs);
+        for (uint32_t q = 0; q < found; q++) {
+            const uint32_t t = order[q], ra = h_ra[t], rb = h_rb[t], nl = h_len[t];
+            const int64_t i = (int64_t)h_pos[t];
+            const int64_t d1 = i - left.offsets[(size_t)ra * left.n_docs], d2 = i - right.offsets[(size_t)rb * right.n_docs];
+            const int64_t s1 = (int64_t)left.length[ra] - d1, s2 = (int64_t)right.length[rb] - d2;
+            int64_t* ro = &out.offsets[(size_t)q * out.n_docs];
+            uint8_t* rs = &out.strands[(size_t)q * out.n_docs];
+            for (size_t c = 0; c < left.n_docs; c++) {
+                uint8_t sd = left.strands[(size_t)ra * left.n_docs + c];
+                ro[c] = left.offsets[(size_t)ra * left.n_docs + c] + (sd ? d1 : s1 - (int64_t)nl);
+                rs[c] = sd;
+            }
+            for (size_t c = 1; c < right.n_docs; c++) {
+                uint8_t sd = right.strands[(size_t)rb * right.n_docs + c];
+                ro[left.n_docs + c - 1] = right.offsets[(size_t)rb * right.n_docs + c] + (sd ? d2 : s2 - (int64_t)nl);
+                rs[left.n_docs + c - 1] = sd;
+            }
+            out.length[q] = nl;
+        }
+        left = std::move(out);
+        nb_left.swap(nb_out);
+    }
+    MergedRows m;
+    m.n_docs = left.n_docs;
+    m.length = std::move(left.length); m.offsets = std::move(left.offsets); m.strands = std::move(left.strands);
+    d2h(m.thresh, nb_left.get(), L, st);
+    return m;
+}
+
+void sort_like_direct(Engine& e, MergedRows& m) {
+    const size_t n = m.length.size();
+    if (!n) return;
+    if (e.text_length() == 0) throw std::runtime_error("engine holds no suffix ranks: run it on a partition first");
+    hipStream_t st = e.stream();
+    MMT_HIP(hipSetDevice(e.device()));
+    // anchor = document 0 of the engine's text, '+' strand starts at text offset 0
+    std::vector<uint64_t> h_idx(n);
+    for (size_t r = 0; r < n; r++) {
+        int64_t o = m.offsets[r * m.n_docs];
+        if (o < 0 || (uint64_t)o >= e.doc_len()[0]) throw std::runtime_error("anchor offset outside the anchor");
+        h_idx[r] = (uint64_t)o;
+    }
+    DevBuf<uint64_t> d_idx; DevBuf<uint32_t> d_key;
+    d_idx.ensure(n); d_key.ensure(n);
+    MMT_HIP(hipMemcpyAsync(d_idx.get(), h_idx.data(), n * 8, hipMemcpyHostToDevice, st));
+    k::gather_u32(e.isa_device(), d_idx.get(), (uint32_t)n, d_key.get(), st);
+    std::vector<uint32_t> key;
+    d2h(key, d_key.get(), n, st);
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+    MergedRows o;
+    o.n_docs = m.n_docs; o.thresh = std::move(m.thresh);
+    o.length.resize(n); o.offsets.resize(n * m.n_docs); o.strands.resize(n * m.n_docs);
+    for (size_t i = 0; i < n; i++) {
+        size_t r = order[i];
+        o.length[i] = m.length[r];
+        std::copy_n(&m.offsets[r * m.n_docs], m.n_docs, &o.offsets[i * m.n_docs]);
+        std::copy_n(&m.strands[r * m.n_docs], m.n_docs, &o.strands[i * m.n_docs]);
+    }
+    m = std::move(o);
+}
+
+std::string format_merged(const MergedRows& m) {
+    std::string t;
+    const size_t n = m.length.size();
+    for (size_t r = 0; r < n; r++) {
+        append_uint(t, m.length[r]); t.push_back('\t');
+        for (size_t c = 0; c < m.n_docs; c++) {
+            int64_t o = m.offsets[r * m.n_docs + c];
+            if (o < 0) { t.push_back('-'); append_uint(t, (uint64_t)(-o)); } else append_uint(t, (uint64_t)o);
+            if (c + 1 < m.n_docs) t.push_back(',');
+        }
+        t.push_back('\t');
+        for (size_t c = 0; c < m.n_docs; c++) {
+            t.push_back(m.strands[r * m.n_docs + c] ? '+' : '-');
+            if (c + 1 < m.n_docs) t.push_back(',');
+        }
+        t.push_back('\n');
+    }
+    return t;
+}
+
+}  // namespace mmt

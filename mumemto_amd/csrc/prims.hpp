@@ -1,0 +1,25 @@
+// prims.hpp -- device-wide library primitives (rocPRIM) used as building blocks:
+// LSD radix sort of (u64 key, u32 value) pairs, prefix max / sum, flagged
+// select.  Everything domain-specific is hand-written in kernels.hip.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "device_utils.hpp"
+
+namespace mmt { namespace prims {
+
+void sort_pairs_u64_u32(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                        uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
+void sort_pairs_u64_u64(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,
+                        uint64_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
+void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                        uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
+void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
+void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
+void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out, size_t n, hipStream_t s);
+// out[k] = index i of the k-th set flag; *d_count = number of set flags
+void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
+                    hipStream_t s);
+
+}}  // namespace mmt::prims

@@ -1,0 +1,228 @@
+"""GPU parity tests: the HIP path (through the C ABI of libmumemto.so) against
+the oracle, bit-exact, on the same seeded inputs -- stage by stage (text, SA,
+LCP, BWT) and end to end (.mums/.mems bytes, row arrays, thresholds)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from mumemto_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import mumemto_amd
+    e = mumemto_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def check_stream(engine, docs, revcomp):
+    text, doc_start = O.build_text(docs, revcomp)
+    sa, lcp, bwt = O.build_stream(text)
+    assert engine.text_length() == len(text)
+    assert np.array_equal(engine.text(), text)
+    assert np.array_equal(engine.sa().astype(np.int64), sa[1:])
+    assert np.array_equal(engine.lcp().astype(np.int64), lcp[1:])
+    assert np.array_equal(engine.bwt(), bwt[1:])
+    return sa, lcp, bwt, doc_start
+
+
+CASES = {
+    "snp": dict(n_haps=5, length=20000, divergence=0.01, seed=1),
+    "indel_inv": dict(n_haps=6, length=30000, divergence=0.01, seed=2, indel_rate=0.002, inversion=(2, 4000, 8000)),
+    "tandem": dict(n_haps=4, length=15000, divergence=0.005, seed=3, tandem=(1, 3000, 3400, 5)),
+    "n_run_lower": dict(n_haps=4, length=12000, divergence=0.02, seed=4, n_run=(0, 2000, 2600), lowercase_frac=0.1),
+    "identical": dict(n_haps=3, length=5000, divergence=0.0, seed=5),
+}
+MODES = {
+    "mum": dict(num_distinct=0, max_doc_freq=1, max_total_freq=0),
+    "partial": dict(num_distinct=-1, max_doc_freq=1, max_total_freq=0),
+    "mem_f2": dict(num_distinct=0, max_doc_freq=2, max_total_freq=0),
+    "mem_k-1_f3": dict(num_distinct=-1, max_doc_freq=3, max_total_freq=0),
+    "mem_unlimited": dict(num_distinct=2, max_doc_freq=0, max_total_freq=0),
+    "mem_capped": dict(num_distinct=2, max_doc_freq=0, max_total_freq=7),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("revcomp", [True, False])
+def test_stream_columns(engine, case, revcomp):
+    docs = synth.pangenome(**CASES[case])
+    engine.set_docs(docs)
+    engine.run(use_revcomp=revcomp)
+    check_stream(engine, docs, revcomp)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("revcomp", [True, False])
+def test_output_bytes(engine, case, mode, revcomp):
+    docs = synth.pangenome(**CASES[case])
+    m = dict(MODES[mode])
+    if m["num_distinct"] < 0:
+        m["num_distinct"] = len(docs) + m["num_distinct"]
+    engine.set_docs(docs)
+    engine.run(min_match_len=20, use_revcomp=revcomp, **m)
+    want = O.run(docs, min_len=20, revcomp=revcomp, **m)
+    assert engine.output_text() == want.text()
+    if m["max_doc_freq"] == 1:
+        L, off, st = engine.rows_mum()
+        wl, wo, ws = want.mum_rows()
+        assert np.array_equal(L, wl) and np.array_equal(off, wo) and np.array_equal(st, ws)
+        assert engine.output_bumbl() == want.bumbl()
+    else:
+        L, occ, off, ids, st = engine.rows_mem()
+        wl, wocc, wo, wd, ws = want.mem_rows()
+        assert np.array_equal(L, wl) and np.array_equal(occ.astype(np.int64), wocc)
+        assert np.array_equal(off, wo) and np.array_equal(ids.astype(np.int64), wd) and np.array_equal(st, ws)
+
+
+@pytest.mark.parametrize("case", ["snp", "indel_inv", "tandem"])
+def test_merge_thresholds(engine, case):
+    docs = synth.pangenome(**CASES[case])
+    engine.set_docs(docs)
+    engine.run(merge_metadata=True)
+    want = O.run(docs, merge=True)
+    assert engine.output_text() == want.text()
+    assert np.array_equal(engine.thresholds(), want.thresh())
+
+
+def test_known_answer_vectors_through_c_abi():
+    import mumemto_amd
+    from mumsfile import parse_mums
+    spec = json.load(open(os.path.join(HERE, "golden", "toy_vectors.json")))
+    for v in spec["vectors"]:
+        docs = [[r.encode() for r in d] for d in v["docs"]]
+        want = O.run(docs, min_len=v["min_len"], revcomp=v["revcomp"], max_doc_freq=v["max_doc_freq"])
+        assert want.text() == v["expect"].encode()
+        if v["max_doc_freq"] == 1:
+            got = mumemto_amd.mumemto_mum(docs, v["min_len"], v["revcomp"])
+            wl, wo, ws = want.mum_rows()
+            assert np.array_equal(got["lengths"], wl)
+            assert np.array_equal(got["offsets"].reshape(wo.shape), wo)
+            assert np.array_equal(got["strands"].reshape(ws.shape), ws)
+            if len(wl):
+                pl, po, ps = parse_mums(v["expect"].encode())
+                assert np.array_equal(got["lengths"], pl) and np.array_equal(got["offsets"], po)
+        else:
+            got = mumemto_amd.mumemto_mem(docs, v["min_len"], v["revcomp"], max_doc_freq=v["max_doc_freq"])
+            wl, wocc, wo, wd, ws = want.mem_rows()
+            assert [m["length"] for m in got["mems"]] == list(wl)
+            flat = np.concatenate([m["offsets"] for m in got["mems"]]) if got["mems"] else np.zeros(0, np.int64)
+            assert np.array_equal(flat, wo)
+        assert got["record_lengths"] == [[len(r) for r in d] for d in docs]
+
+
+def test_c_abi_error_codes_and_edge_inputs():
+    import ctypes as C
+    import mumemto_amd
+    L = mumemto_amd.load_library()
+    out = C.c_void_p()
+    assert L.mumemto_mum(None, 0, 20, 1, 0, 0, None) == 1           # out_result == NULL
+    assert L.mumemto_mum(None, 2, 20, 1, 0, 0, C.byref(out)) == 2   # docs == NULL && num_docs != 0
+    assert out.value is None
+    assert L.mumemto_mum(None, 0, 20, 1, 0, 0, C.byref(out)) == 0   # empty -> empty result
+    assert L.num_mums(out) == 0 and L.num_docs(out) == 0
+    L.mum_free(out)
+    with pytest.raises(mumemto_amd.MumemtoError):                    # f <= 1 in MEM mode -> rc 3
+        mumemto_amd.mumemto_mem([[b"ACGT"], [b"ACGT"]], max_doc_freq=1)
+    assert b"must be > 1" in L.mumemto_last_error()
+    assert L.num_mums(None) == 0 and L.mum_at(None, 3).length == 0
+    # multi-record docs, an empty record and a doc without any base
+    docs = [[b"ACGTTGCATTGACCAGTAGGCTA", b"", b"GGATCCATTGACCAGTAGGCTAAC"], [b"TTGACCAGTAGGCTAAGG"], [b""]]
+    got = mumemto_amd.mumemto_mum(docs, 5, True, num_distinct=2)
+    want = O.run(docs, min_len=5, revcomp=True, num_distinct=2)
+    wl, wo, ws = want.mum_rows()
+    assert np.array_equal(got["lengths"], wl) and np.array_equal(got["offsets"].reshape(wo.shape), wo)
+    assert got["record_lengths"] == [[23, 0, 24], [18], [0]]
+
+
+def test_many_documents_counter_path(engine):
+    # > 64 documents: the verifier uses LDS counters instead of the one-wave bitmap
+    docs = synth.pangenome(70, 1500, 0.01, seed=8)
+    for m in (dict(num_distinct=0, max_doc_freq=1), dict(num_distinct=60, max_doc_freq=1),
+              dict(num_distinct=65, max_doc_freq=2)):
+        engine.set_docs(docs)
+        engine.run(**m)
+        assert engine.output_text() == O.run(docs, **m).text()
+
+
+def test_tiny_and_degenerate_texts(engine):
+    for docs in ([[b"A"], [b"A"]], [[b""], [b""]], [[b"ACGT" * 30], [b"ACGT" * 30]], [[b"A" * 200], [b"A" * 150]],
+                 [[b"N" * 50 + b"ACGTGGA" * 5], [b"ACGTGGA" * 5 + b"N" * 40]]):
+        for revcomp in (True, False):
+            for m in (dict(max_doc_freq=1), dict(max_doc_freq=3), dict(max_doc_freq=0, num_distinct=2)):
+                engine.set_docs(docs)
+                engine.run(min_match_len=4, use_revcomp=revcomp, **m)
+                check_stream(engine, docs, revcomp)
+                assert engine.output_text() == O.run(docs, min_len=4, revcomp=revcomp, **m).text(), (docs, revcomp, m)
+
+
+def test_anchor_merge_against_reference_binary(engine):
+    import glob
+    from mumsfile import parse_mums
+    G = os.path.join(HERE, "golden", "anchor_merge")
+    for case in sorted(os.listdir(G)):
+        parts = []
+        for p in sorted(glob.glob(os.path.join(G, case, "p*.mums"))):
+            L, off, st = parse_mums(open(p, "rb").read())
+            parts.append((L, off, st, np.fromfile(p[:-5] + ".athresh", np.uint16)))
+        got = engine.anchor_merge(parts)
+        assert got["text"] == open(os.path.join(G, case, "merged.mums"), "rb").read()
+        assert got["thresh"].tobytes() == open(os.path.join(G, case, "merged.athresh"), "rb").read()
+
+
+def test_partition_merge_equals_direct_run(engine):
+    # partitions sharing doc 0 -> fold -> re-sort == direct run, byte for byte
+    docs = synth.pangenome(7, 20000, 0.01, seed=21, indel_rate=0.001, inversion=(4, 3000, 5000))
+    groups = [[0, 1, 2], [0, 3, 4], [0, 5, 6]]
+    parts = []
+    for g in groups:
+        engine.set_docs([docs[i] for i in g])
+        engine.run(merge_metadata=True)
+        L, off, st = engine.rows_mum()
+        parts.append((L, off, st, engine.thresholds()[: len(docs[0][0]) + 1].copy()))
+    merged = engine.anchor_merge(parts, sort_like_direct=True)   # engine's last run holds the anchor ranks
+    direct = O.run(docs, merge=True)
+    assert merged["text"] == direct.text()
+    assert np.array_equal(merged["thresh"], direct.thresh()[: len(docs[0][0]) + 1])
+
+
+def test_full_size_properties(engine):
+    # larger than the oracle comfortably checks in CI time: size-independent properties
+    docs = synth.pangenome(8, 400000, 0.005, seed=33)
+    engine.set_docs(docs)
+    engine.run()
+    sa = engine.sa().astype(np.int64)
+    n = engine.text_length()
+    assert n == 8 * 2 * (400000 + 1)
+    assert np.array_equal(np.sort(sa), np.arange(n))                 # a permutation
+    text = engine.text()
+    lcp = engine.lcp().astype(np.int64)
+    idx = np.random.default_rng(0).integers(1, n, size=20000)
+    for j in idx[:2000]:                                             # sortedness + exact lcp on a sample
+        a, b, l = sa[j - 1], sa[j], lcp[j]
+        assert np.array_equal(text[a:a + l], text[b:b + l])
+        ca = text[a + l] if a + l < n else -1
+        cb = text[b + l] if b + l < n else -1
+        assert ca < cb
+    L, off, st = engine.rows_mum()
+    assert len(L) > 100
+    for r in np.random.default_rng(1).integers(0, len(L), size=200):  # every reported occurrence is a real match
+        seqs = []
+        for d in range(8):
+            s = docs[d][0][off[r, d]: off[r, d] + L[r]]
+            if not st[r, d]:
+                s = s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+            seqs.append(s)
+        assert len(set(seqs)) == 1 and len(seqs[0]) == L[r]
+    # idempotence: same input, same bytes
+    first = engine.output_text()
+    engine.run()
+    assert engine.output_text() == first

@@ -51,6 +51,22 @@ def pangenome(n_haps, length, divergence, seed, indel_rate=0.0, inversion=None, 
     return docs
 
 
+def pangenome_subset(n_haps, length, divergence, seed, which):
+    """Same haplotypes as pangenome(...)[i] for i in `which`, generated alone
+    (per-haplotype RNG streams are independent): SNP-only model."""
+    rng = np.random.default_rng(seed)
+    anc = rng.integers(0, 4, size=length, dtype=np.uint8)
+    docs = []
+    for h in which:
+        hrng = np.random.default_rng([seed, h + 1])
+        seq = anc.copy()
+        if divergence > 0:
+            mut = hrng.random(length) < divergence
+            seq[mut] = (seq[mut] + hrng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+        docs.append([_ACGT[seq].tobytes()])
+    return docs
+
+
 def write_fasta(path, records, names=None, width=80):
     with open(path, "wb") as f:
         for i, rec in enumerate(records):

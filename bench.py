@@ -156,7 +156,8 @@ def main():
                                % (n_total_haps, a.length, a.divergence, a.seed),
                    "haplotypes": n_total_haps, "bases_per_haplotype": a.length, "text_chars_per_gpu": int(n_text),
                    "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL all-gather + GPU fold" % world,
-                   "output_bytes": len(out), "output_rows": out.count(b"\n")},
+                   "output_bytes": len(out), "output_rows": out.count(b"\n"),
+                   "scan_candidates": int(eng.L.mmt_num_candidates(eng.h))},
         "roofline": {"bound": "hbm", "kernel": "k_scan (LCP-interval match scan)", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,

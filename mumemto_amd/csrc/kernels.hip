@@ -308,85 +308,211 @@ void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* b
 //     positions with a falling edge are first compacted into an LDS work queue
 //     so that every lane of a wave walks a real candidate.
 // ============================================================================
-template <int BLOCK, int PER>
-__global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo) {
+//
+// Two ideas keep the kernel off the instruction-issue and atomic limits:
+//  * every reportable interval has >= num_distinct entries, so the first
+//    w = num_distinct - 1 steps of the walk are replaced by one range-min /
+//    range-or query on sparse tables T_k[i] = min(lcp[i .. i+2^k-1]) (and the
+//    same with OR over the "BWT changes here" bits), built per tile in LDS by
+//    k = floor(log2 w) doubling passes.  A position whose window minimum is not
+//    above its own LCP closes nothing and is dropped without any walk; for
+//    strict multi-MUMs (cap == num_distinct) the walk is a single step.
+//  * candidates are collected in an LDS buffer per workgroup and flushed with
+//    ONE global atomic per flush: a single counter word saturates at ~90
+//    returning atomics per microsecond on MI355X, which bounded the first
+//    version of this kernel (profiles/round1_a).
+template <int BLOCK, int PER, int OUT_CAP>
+__global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint32_t n_tiles, uint32_t w,
+                                                uint32_t klev) {
     constexpr int TILE = BLOCK * PER;
+    constexpr int MAXR = PER + 4;                       // register slots per thread for one table pass
+    constexpr uint32_t FLUSH_AT = OUT_CAP / 2;
+    const uint32_t span = halo + TILE;
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                   // halo + TILE
-    uint8_t* s_bwt = smem + (size_t)(halo + TILE) * 4;                      // halo + TILE
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_bwt + ((halo + TILE + 15) & ~15u));  // TILE
-    __shared__ uint32_t s_qn;
+    uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                    // span
+    uint32_t* s_T = s_lcp + span;                                           // span: range-min table
+    uint8_t* s_c = reinterpret_cast<uint8_t*>(s_T + span);                  // span: bwt[i] != bwt[i-1]
+    uint8_t* s_Tc = s_c + span;                                             // span: range-or table
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_Tc + span);           // TILE
+    Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
+    __shared__ uint32_t s_qn, s_on, s_base;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wstep = 1u << klev;
+    if (threadIdx.x == 0) { s_on = 0; }
 
-    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
-    const uint64_t lds_lo = tile0 >= halo ? tile0 - halo : 0;              // first staged index
-    const uint32_t shift = (uint32_t)(tile0 - lds_lo);                      // LDS index of tile0
-    const uint64_t hi = tile0 + TILE < a.n ? tile0 + TILE : a.n;           // one past last staged index
-    const uint32_t staged = (uint32_t)(hi - lds_lo);
-    if (threadIdx.x == 0) s_qn = 0;
-    for (uint32_t i = threadIdx.x; i < staged; i += BLOCK) {
-        s_lcp[i] = a.lcp[lds_lo + i];
-        s_bwt[i] = a.bwt[lds_lo + i];
-    }
-    __syncthreads();
-
-    // phase 1: falling edges with a long enough value go to the work queue
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t tile0 = (uint64_t)tile * TILE;
+        const uint64_t lds_lo = tile0 >= halo ? tile0 - halo : 0;          // first staged index
+        const uint32_t shift = (uint32_t)(tile0 - lds_lo);                  // LDS index of tile0
+        const uint64_t hi = tile0 + TILE < a.n ? tile0 + TILE : a.n;       // one past last staged index
+        const uint32_t staged = (uint32_t)(hi - lds_lo);
+        if (threadIdx.x == 0) s_qn = 0;
+        // ---- stage the columns (range starts 16-element aligned: 16-byte loads) ----
+        {
+            const uint32_t vec4 = staged >> 2;
+            const uint4* g4 = reinterpret_cast<const uint4*>(a.lcp + lds_lo);
+            uint4* l4 = reinterpret_cast<uint4*>(s_lcp);
+            uint4* t4 = reinterpret_cast<uint4*>(s_T);
+            for (uint32_t i = threadIdx.x; i < vec4; i += BLOCK) { uint4 v = g4[i]; l4[i] = v; t4[i] = v; }
+            for (uint32_t i = (vec4 << 2) + threadIdx.x; i < staged; i += BLOCK) {
+                uint32_t v = a.lcp[lds_lo + i]; s_lcp[i] = v; s_T[i] = v;
+            }
+            const uint32_t vec16 = staged >> 4;
+            const uint4* b4 = reinterpret_cast<const uint4*>(a.bwt + lds_lo);
+            uint4* lb4 = reinterpret_cast<uint4*>(s_Tc);                    // raw BWT bytes, replaced below
+            for (uint32_t i = threadIdx.x; i < vec16; i += BLOCK) lb4[i] = b4[i];
+            for (uint32_t i = (vec16 << 4) + threadIdx.x; i < staged; i += BLOCK) s_Tc[i] = a.bwt[lds_lo + i];
+        }
+        __syncthreads();
+        {   // change bits
+            uint8_t r[MAXR];
 #pragma unroll
-    for (int q = 0; q < PER; q++) {
-        uint32_t o = threadIdx.x + q * BLOCK;                               // offset in tile
-        uint64_t j = tile0 + o;
-        if (j >= 1 && j < a.n) {
-            uint32_t prev = s_lcp[shift + o - 1], cur = s_lcp[shift + o];
-            if (cur < prev && prev >= a.min_len) s_queue[atomicAdd(&s_qn, 1u)] = (uint16_t)o;
-        }
-    }
-    __syncthreads();
-    const uint32_t qn = s_qn;
-
-    // phase 2: walk
-    for (uint32_t w = threadIdx.x; w < qn; w += BLOCK) {
-        const uint32_t o = s_queue[w];
-        const uint64_t j = tile0 + o;
-        const uint32_t closing = s_lcp[shift + o];
-        uint64_t kpos = j - 1;                                              // current k
-        uint32_t m = s_lcp[shift + o - 1];
-        bool chg = false;
-        while (true) {
-            // candidate start s = kpos - 1
-            if (kpos == 0) break;
-            uint32_t v; uint8_t b1, b0;
-            if (kpos - 1 >= lds_lo) {
-                uint32_t li = (uint32_t)(kpos - lds_lo);
-                v = s_lcp[li - 1]; b1 = s_bwt[li]; b0 = s_bwt[li - 1];
-            } else {                                                        // uncapped modes only
-                v = a.lcp[kpos - 1]; b1 = a.bwt[kpos]; b0 = a.bwt[kpos - 1];
-            }
-            chg |= (b1 != b0);
-            if (v < m) {
-                uint64_t cnt = j - (kpos - 1);
-                if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
-                    uint32_t slot = atomicAdd(a.d_count, 1u);
-                    if (slot < a.capacity) {
-                        Cand c; c.start = (uint32_t)(kpos - 1); c.end = (uint32_t)(j - 1); c.len = m;
-                        c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
-                        a.out[slot] = c;
-                    }
+            for (int q = 0; q < MAXR; q++) {
+                uint32_t i = threadIdx.x + q * BLOCK;
+                if (i < staged) {
+                    uint8_t prevb = i ? s_Tc[i - 1] : (lds_lo ? a.bwt[lds_lo - 1] : (uint8_t)0);
+                    r[q] = s_Tc[i] != prevb ? 1 : 0;
                 }
-                m = v;
-                if (m <= closing || m < a.min_len) break;
             }
-            kpos--;
-            if (a.cap && j - (kpos - 1) > a.cap) break;                     // every further interval is too big
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MAXR; q++) {
+                uint32_t i = threadIdx.x + q * BLOCK;
+                if (i < staged) { s_c[i] = r[q]; s_Tc[i] = r[q]; }
+            }
         }
+        __syncthreads();
+        // ---- sparse-table levels: T <- min(T[i], T[i+step]), Tc <- Tc[i] | Tc[i+step] ----
+        for (uint32_t lev = 0; lev < klev; lev++) {
+            const uint32_t step = 1u << lev;
+            uint32_t rt[MAXR]; uint8_t rc[MAXR];
+#pragma unroll
+            for (int q = 0; q < MAXR; q++) {
+                uint32_t i = threadIdx.x + q * BLOCK;
+                if (i < staged) {
+                    uint32_t i2 = i + step < staged ? i + step : staged - 1;
+                    uint32_t x = s_T[i], y = s_T[i2];
+                    rt[q] = x < y ? x : y;
+                    rc[q] = s_Tc[i] | s_Tc[i2];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MAXR; q++) {
+                uint32_t i = threadIdx.x + q * BLOCK;
+                if (i < staged) { s_T[i] = rt[q]; s_Tc[i] = rc[q]; }
+            }
+            __syncthreads();
+        }
+
+        // ---- phase 1: positions whose w-window minimum exceeds their own LCP close something ----
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t o = threadIdx.x + q * BLOCK;                     // offset in tile
+            const uint64_t j = tile0 + o;
+            const uint32_t lj = shift + o;                                  // LDS index of j
+            bool take = false;
+            if (j >= 1 && j < a.n && lj >= w) {
+                const uint32_t closing = s_lcp[lj];
+                const uint32_t x = s_T[lj - w], y = s_T[lj - wstep];
+                const uint32_t M = x < y ? x : y;                           // min(lcp[j-w .. j-1])
+                take = M > closing && M >= a.min_len;
+            }
+            const uint64_t mask = __ballot(take);
+            uint32_t base = 0;
+            if (lane == 0 && mask) base = atomicAdd(&s_qn, (uint32_t)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (take) s_queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)o;
+        }
+        __syncthreads();
+        const uint32_t qn = s_qn;
+
+        // ---- phase 2: finish the walk from s = j - w - 1 leftwards ----
+        for (uint32_t wi = threadIdx.x; wi < qn; wi += BLOCK) {
+            const uint32_t o = s_queue[wi];
+            const uint32_t lj = shift + o;
+            const uint32_t closing = s_lcp[lj];
+            uint32_t m; bool chg;
+            {
+                const uint32_t x = s_T[lj - w], y = s_T[lj - wstep];
+                m = x < y ? x : y;
+                chg = (s_Tc[lj - w] | s_Tc[lj - wstep]) != 0;
+            }
+            uint32_t lk = lj - w;                                           // LDS index of k; candidate start s = k - 1
+            bool done = false;
+            while (lk > 0) {
+                const uint32_t v = s_lcp[lk - 1];
+                chg |= s_c[lk] != 0;
+                if (v < m) {
+                    const uint32_t cnt = lj - lk + 1;
+                    if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
+                        Cand c; c.start = (uint32_t)(lds_lo + lk - 1); c.end = (uint32_t)(lds_lo + lj - 1); c.len = m;
+                        c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
+                        uint32_t slot = atomicAdd(&s_on, 1u);
+                        if (slot < OUT_CAP) s_out[slot] = c;
+                        else { uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
+                    }
+                    m = v;
+                    if (m <= closing || m < a.min_len) { done = true; break; }
+                }
+                lk--;
+                if (a.cap && lj - lk + 1 > a.cap) { done = true; break; }  // every further interval is too big
+            }
+            if (!done && lds_lo > 0) {
+                // left the staged halo (uncapped modes / very large caps): continue in the global columns
+                const uint64_t j = lds_lo + lj;
+                uint64_t kpos = lds_lo;                                     // k = lds_lo, candidate start k - 1
+                while (kpos > 0) {
+                    const uint32_t v = a.lcp[kpos - 1];
+                    chg |= a.bwt[kpos] != a.bwt[kpos - 1];
+                    if (v < m) {
+                        const uint64_t cnt = j - (kpos - 1);
+                        if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
+                            Cand c; c.start = (uint32_t)(kpos - 1); c.end = (uint32_t)(j - 1); c.len = m;
+                            c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
+                            uint32_t g = atomicAdd(a.d_count, 1u);
+                            if (g < a.capacity) a.out[g] = c;
+                        }
+                        m = v;
+                        if (m <= closing || m < a.min_len) break;
+                    }
+                    kpos--;
+                    if (a.cap && j - (kpos - 1) > a.cap) break;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t filled = s_on < OUT_CAP ? s_on : OUT_CAP;
+        const bool last = tile + gridDim.x >= n_tiles;
+        if (filled >= FLUSH_AT || (last && filled)) {
+            if (threadIdx.x == 0) s_base = atomicAdd(a.d_count, filled);
+            __syncthreads();
+            const uint32_t base = s_base;
+            for (uint32_t i = threadIdx.x; i < filled; i += BLOCK)
+                if (base + i < a.capacity) a.out[base + i] = s_out[i];
+            __syncthreads();
+            if (threadIdx.x == 0) s_on = 0;
+        }
+        __syncthreads();
     }
 }
 
 void scan_intervals(const ScanArgs& a, hipStream_t s) {
-    constexpr int B = 256, PER = 8, TILE = B * PER;
+    constexpr int B = 256, PER = 8, TILE = B * PER, OUT_CAP = 512;
+    if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
+    uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
+    uint32_t w = nd - 1;
+    if (w > 1000) w = 1;                                   // window tables need w <= halo <= 4 * BLOCK
+    uint32_t klev = 0;
+    while ((2u << klev) <= w) klev++;                      // floor(log2(w))
     uint32_t halo = a.cap ? a.cap + 1 : 256;
-    halo = (halo + 3) & ~3u;
-    if (halo > 8192) halo = 8192;   // beyond this the walk reads the cached global columns
-    size_t lds = (size_t)(halo + TILE) * 4 + ((halo + TILE + 15) & ~15u) + (size_t)TILE * 2;
-    hipLaunchKernelGGL((k_scan<B, PER>), dim3(grid_for(a.n, TILE)), dim3(B), lds, s, a, halo);
+    if (halo < w + 1) halo = w + 1;
+    halo = (halo + 15) & ~15u;
+    if (halo > 4 * B) halo = 4 * B;                        // beyond this the walk reads the cached global columns
+    size_t lds = (size_t)(halo + TILE) * 10 + (size_t)TILE * 2 + (size_t)OUT_CAP * sizeof(Cand);
+    uint32_t n_tiles = grid_for(a.n, TILE);
+    unsigned grid = n_tiles < 256u * 8u ? n_tiles : 256u * 8u;
+    hipLaunchKernelGGL((k_scan<B, PER, OUT_CAP>), dim3(grid), dim3(B), lds, s, a, halo, n_tiles, w, klev);
     MMT_HIP(hipGetLastError());
 }
 
@@ -416,6 +542,9 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_counters) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* ctr = reinterpret_cast<uint32_t*>(smem) + (size_t)(threadIdx.x >> 6) * a.n_docs;
+    __shared__ Cand s_rows[WAVES][64];       // accepted rows of this wave, flushed 64 at a time
+    Cand* my_rows = s_rows[threadIdx.x >> 6];
+    uint32_t n_my = 0;                        // wave-uniform
     const uint32_t lane = threadIdx.x & 63;
     if (use_counters) {
         for (uint32_t i = lane; i < a.n_docs; i += 64) ctr[i] = 0;
@@ -472,7 +601,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
                 a.thresh[(uint64_t)a.sa[first0] - a.d_doc_start[0]] = (uint16_t)nb;
             }
         }
-        if (lane == 0 && (c.flags & CAND_LEFT_MAXIMAL)) a.rows[atomicAdd(a.d_row_count, 1u)] = c;
+        if (c.flags & CAND_LEFT_MAXIMAL) {
+            if (lane == 0) my_rows[n_my] = c;
+            n_my++;
+            if (n_my == 64) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.d_row_count, 64u);
+                base = __shfl(base, 0, 64);
+                a.rows[base + lane] = my_rows[lane];
+                n_my = 0;
+            }
+        }
+    }
+    if (n_my) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.d_row_count, n_my);
+        base = __shfl(base, 0, 64);
+        if (lane < n_my) a.rows[base + lane] = my_rows[lane];
     }
 }
 

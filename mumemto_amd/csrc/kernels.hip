@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "device_utils.hpp"
 #include "kernels.hpp"
@@ -331,9 +332,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                    // span
     uint32_t* s_T = s_lcp + span;                                           // span: range-min table
-    uint8_t* s_c = reinterpret_cast<uint8_t*>(s_T + span);                  // span: bwt[i] != bwt[i-1]
-    uint8_t* s_Tc = s_c + span;                                             // span: range-or table
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_Tc + span);           // TILE
+    uint8_t* s_bwt = reinterpret_cast<uint8_t*>(s_T + span);                // span + 16: BWT bytes, [0] = bwt[lds_lo-1]
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_bwt + span + 16);     // TILE
     Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
     __shared__ uint32_t s_qn, s_on, s_base;
     const uint32_t lane = threadIdx.x & 63;
@@ -359,33 +359,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             }
             const uint32_t vec16 = staged >> 4;
             const uint4* b4 = reinterpret_cast<const uint4*>(a.bwt + lds_lo);
-            uint4* lb4 = reinterpret_cast<uint4*>(s_Tc);                    // raw BWT bytes, replaced below
+            uint4* lb4 = reinterpret_cast<uint4*>(s_bwt + 16);              // s_bwt[16 + i] = bwt[lds_lo + i]
             for (uint32_t i = threadIdx.x; i < vec16; i += BLOCK) lb4[i] = b4[i];
-            for (uint32_t i = (vec16 << 4) + threadIdx.x; i < staged; i += BLOCK) s_Tc[i] = a.bwt[lds_lo + i];
+            for (uint32_t i = (vec16 << 4) + threadIdx.x; i < staged; i += BLOCK) s_bwt[16 + i] = a.bwt[lds_lo + i];
+            if (threadIdx.x == 0) s_bwt[15] = lds_lo ? a.bwt[lds_lo - 1] : (uint8_t)0;
         }
         __syncthreads();
-        {   // change bits
-            uint8_t r[MAXR];
-#pragma unroll
-            for (int q = 0; q < MAXR; q++) {
-                uint32_t i = threadIdx.x + q * BLOCK;
-                if (i < staged) {
-                    uint8_t prevb = i ? s_Tc[i - 1] : (lds_lo ? a.bwt[lds_lo - 1] : (uint8_t)0);
-                    r[q] = s_Tc[i] != prevb ? 1 : 0;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < MAXR; q++) {
-                uint32_t i = threadIdx.x + q * BLOCK;
-                if (i < staged) { s_c[i] = r[q]; s_Tc[i] = r[q]; }
-            }
-        }
-        __syncthreads();
-        // ---- sparse-table levels: T <- min(T[i], T[i+step]), Tc <- Tc[i] | Tc[i+step] ----
+        // ---- sparse-table levels: T <- min(T[i], T[i+step]) ----
         for (uint32_t lev = 0; lev < klev; lev++) {
             const uint32_t step = 1u << lev;
-            uint32_t rt[MAXR]; uint8_t rc[MAXR];
+            uint32_t rt[MAXR];
 #pragma unroll
             for (int q = 0; q < MAXR; q++) {
                 uint32_t i = threadIdx.x + q * BLOCK;
@@ -393,14 +376,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                     uint32_t i2 = i + step < staged ? i + step : staged - 1;
                     uint32_t x = s_T[i], y = s_T[i2];
                     rt[q] = x < y ? x : y;
-                    rc[q] = s_Tc[i] | s_Tc[i2];
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < MAXR; q++) {
                 uint32_t i = threadIdx.x + q * BLOCK;
-                if (i < staged) { s_T[i] = rt[q]; s_Tc[i] = rc[q]; }
+                if (i < staged) s_T[i] = rt[q];
             }
             __syncthreads();
         }
@@ -432,17 +414,20 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             const uint32_t o = s_queue[wi];
             const uint32_t lj = shift + o;
             const uint32_t closing = s_lcp[lj];
-            uint32_t m; bool chg;
+            uint32_t m; bool chg = false;
             {
                 const uint32_t x = s_T[lj - w], y = s_T[lj - wstep];
                 m = x < y ? x : y;
-                chg = (s_Tc[lj - w] | s_Tc[lj - wstep]) != 0;
             }
             uint32_t lk = lj - w;                                           // LDS index of k; candidate start s = k - 1
+            {   // BWT bytes of [k, j-1] not all equal?  (s_bwt is offset by 16)
+                const uint8_t b0 = s_bwt[16 + lj - 1];
+                for (uint32_t t = lk; t + 1 < lj; t++) chg |= s_bwt[16 + t] != b0;
+            }
             bool done = false;
             while (lk > 0) {
                 const uint32_t v = s_lcp[lk - 1];
-                chg |= s_c[lk] != 0;
+                chg |= s_bwt[16 + lk] != s_bwt[16 + lk - 1];
                 if (v < m) {
                     const uint32_t cnt = lj - lk + 1;
                     if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
@@ -497,9 +482,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     }
 }
 
-void scan_intervals(const ScanArgs& a, hipStream_t s) {
-    constexpr int B = 256, PER = 8, TILE = B * PER, OUT_CAP = 512;
-    if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
+template <int B, int PER, int OUT_CAP>
+static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu) {
+    constexpr int TILE = B * PER;
     uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
     uint32_t w = nd - 1;
     if (w > 1000) w = 1;                                   // window tables need w <= halo <= 4 * BLOCK
@@ -509,11 +494,28 @@ void scan_intervals(const ScanArgs& a, hipStream_t s) {
     if (halo < w + 1) halo = w + 1;
     halo = (halo + 15) & ~15u;
     if (halo > 4 * B) halo = 4 * B;                        // beyond this the walk reads the cached global columns
-    size_t lds = (size_t)(halo + TILE) * 10 + (size_t)TILE * 2 + (size_t)OUT_CAP * sizeof(Cand);
+    size_t lds = (size_t)(halo + TILE) * 9 + 16 + (size_t)TILE * 2 + (size_t)OUT_CAP * sizeof(Cand);
     uint32_t n_tiles = grid_for(a.n, TILE);
-    unsigned grid = n_tiles < 256u * 8u ? n_tiles : 256u * 8u;
+    unsigned grid = n_tiles < 256u * blocks_per_cu ? n_tiles : 256u * blocks_per_cu;
     hipLaunchKernelGGL((k_scan<B, PER, OUT_CAP>), dim3(grid), dim3(B), lds, s, a, halo, n_tiles, w, klev);
     MMT_HIP(hipGetLastError());
+}
+
+void scan_intervals(const ScanArgs& a, hipStream_t s) {
+    if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
+    static int variant = -1, bpc = 8;
+    if (variant < 0) {
+        const char* v = getenv("MMT_SCAN_VARIANT"); variant = v ? atoi(v) : 0;
+        const char* g = getenv("MMT_SCAN_BPC"); if (g) bpc = atoi(g);
+    }
+    switch (variant) {
+        case 1: launch_scan<256, 4, 256>(a, s, bpc); break;
+        case 2: launch_scan<256, 16, 512>(a, s, bpc); break;
+        case 3: launch_scan<512, 4, 512>(a, s, bpc); break;
+        case 4: launch_scan<512, 8, 512>(a, s, bpc); break;
+        case 5: launch_scan<128, 8, 256>(a, s, bpc); break;
+        default: launch_scan<256, 8, 512>(a, s, bpc); break;
+    }
 }
 
 // ============================================================================

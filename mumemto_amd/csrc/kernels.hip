@@ -322,22 +322,42 @@ void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* b
 //    ONE global atomic per flush: a single counter word saturates at ~90
 //    returning atomics per microsecond on MI355X, which bounded the first
 //    version of this kernel (profiles/round1_a).
-template <int BLOCK, int PER, int OUT_CAP>
+//  * all table work is done on groups of 4 consecutive entries (16-byte LDS
+//    accesses, conflict-free for consecutive lanes); the first min(k,3) levels
+//    are fused into one register pass over 12 staged values.
+__device__ __forceinline__ uint32_t umin32(uint32_t x, uint32_t y) { return x < y ? x : y; }
+__device__ __forceinline__ uint4 umin4(uint4 x, uint4 y) {
+    return make_uint4(umin32(x.x, y.x), umin32(x.y, y.y), umin32(x.z, y.z), umin32(x.w, y.w));
+}
+// entries r..r+3 of the 8 values {lo, hi}; r is uniform over the kernel
+__device__ __forceinline__ uint4 shift4(uint4 lo, uint4 hi, uint32_t r) {
+    switch (r) {
+        case 0: return lo;
+        case 1: return make_uint4(lo.y, lo.z, lo.w, hi.x);
+        case 2: return make_uint4(lo.z, lo.w, hi.x, hi.y);
+        default: return make_uint4(lo.w, hi.x, hi.y, hi.z);
+    }
+}
+
+// K0 = min(klev, 3): number of levels fused into the first pass.
+template <int BLOCK, int VG, int K0, int OUT_CAP>
 __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint32_t n_tiles, uint32_t w,
                                                 uint32_t klev) {
-    constexpr int TILE = BLOCK * PER;
-    constexpr int MAXR = PER + 4;                       // register slots per thread for one table pass
+    constexpr int TILE = BLOCK * VG * 4;
+    constexpr int MAXG = VG + 1;                        // groups of 4 per thread incl. halo (halo <= 4 * BLOCK)
     constexpr uint32_t FLUSH_AT = OUT_CAP / 2;
     const uint32_t span = halo + TILE;
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                    // span
-    uint32_t* s_T = s_lcp + span;                                           // span: range-min table
-    uint8_t* s_bwt = reinterpret_cast<uint8_t*>(s_T + span);                // span + 16: BWT bytes, [0] = bwt[lds_lo-1]
+    uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                    // span + 16
+    uint32_t* s_T = s_lcp + span + 16;                                      // span + 16: T_k[i] = min(lcp[i..i+2^k-1])
+    uint8_t* s_bwt = reinterpret_cast<uint8_t*>(s_T + span + 16);           // 16 + span: [16 + i] = bwt[lds_lo + i]
     uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_bwt + span + 16);     // TILE
     Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
     __shared__ uint32_t s_qn, s_on, s_base;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wstep = 1u << klev;
+    const uint32_t rl = (0u - w) & 3u, rr = (0u - wstep) & 3u;              // misalignment of the two query windows
+    const uint32_t* tbl = K0 == 0 ? s_lcp : s_T;                            // level-0 table is the column itself
     if (threadIdx.x == 0) { s_on = 0; }
 
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -346,65 +366,118 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         const uint32_t shift = (uint32_t)(tile0 - lds_lo);                  // LDS index of tile0
         const uint64_t hi = tile0 + TILE < a.n ? tile0 + TILE : a.n;       // one past last staged index
         const uint32_t staged = (uint32_t)(hi - lds_lo);
+        const uint32_t groups = (staged + 3) >> 2;
         if (threadIdx.x == 0) s_qn = 0;
         // ---- stage the columns (range starts 16-element aligned: 16-byte loads) ----
         {
             const uint32_t vec4 = staged >> 2;
             const uint4* g4 = reinterpret_cast<const uint4*>(a.lcp + lds_lo);
             uint4* l4 = reinterpret_cast<uint4*>(s_lcp);
-            uint4* t4 = reinterpret_cast<uint4*>(s_T);
-            for (uint32_t i = threadIdx.x; i < vec4; i += BLOCK) { uint4 v = g4[i]; l4[i] = v; t4[i] = v; }
-            for (uint32_t i = (vec4 << 2) + threadIdx.x; i < staged; i += BLOCK) {
-                uint32_t v = a.lcp[lds_lo + i]; s_lcp[i] = v; s_T[i] = v;
-            }
+            for (uint32_t i = threadIdx.x; i < vec4; i += BLOCK) l4[i] = g4[i];
+            for (uint32_t i = (vec4 << 2) + threadIdx.x; i < staged; i += BLOCK) s_lcp[i] = a.lcp[lds_lo + i];
             const uint32_t vec16 = staged >> 4;
             const uint4* b4 = reinterpret_cast<const uint4*>(a.bwt + lds_lo);
-            uint4* lb4 = reinterpret_cast<uint4*>(s_bwt + 16);              // s_bwt[16 + i] = bwt[lds_lo + i]
+            uint4* lb4 = reinterpret_cast<uint4*>(s_bwt + 16);
             for (uint32_t i = threadIdx.x; i < vec16; i += BLOCK) lb4[i] = b4[i];
             for (uint32_t i = (vec16 << 4) + threadIdx.x; i < staged; i += BLOCK) s_bwt[16 + i] = a.bwt[lds_lo + i];
             if (threadIdx.x == 0) s_bwt[15] = lds_lo ? a.bwt[lds_lo - 1] : (uint8_t)0;
         }
         __syncthreads();
-        // ---- sparse-table levels: T <- min(T[i], T[i+step]) ----
-        for (uint32_t lev = 0; lev < klev; lev++) {
-            const uint32_t step = 1u << lev;
-            uint32_t rt[MAXR];
+        // ---- fused levels 0..K0-1: T[i] = min(lcp[i .. i+W0-1]) from 12 staged values per group ----
+        if (K0 > 0) {
+            const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
+            uint4* t4 = reinterpret_cast<uint4*>(s_T);
 #pragma unroll
-            for (int q = 0; q < MAXR; q++) {
-                uint32_t i = threadIdx.x + q * BLOCK;
-                if (i < staged) {
-                    uint32_t i2 = i + step < staged ? i + step : staged - 1;
-                    uint32_t x = s_T[i], y = s_T[i2];
-                    rt[q] = x < y ? x : y;
+            for (int q = 0; q < MAXG; q++) {
+                const uint32_t g = threadIdx.x + q * BLOCK;
+                if (g < groups) {
+                    const uint4 A = l4[g], B = l4[g + 1], C = l4[g + 2];     // entries i..i+11 (tail is padding)
+                    uint4 r;
+                    if (K0 == 1) {
+                        r = make_uint4(umin32(A.x, A.y), umin32(A.y, A.z), umin32(A.z, A.w), umin32(A.w, B.x));
+                    } else if (K0 == 2) {
+                        const uint32_t m12 = umin32(A.y, A.z), m23 = umin32(A.z, A.w), m01b = umin32(B.x, B.y);
+                        r = make_uint4(umin32(umin32(A.x, m12), A.w), umin32(umin32(m12, A.w), B.x),
+                                       umin32(m23, m01b), umin32(umin32(A.w, m01b), B.z));
+                    } else {
+                        const uint32_t mid = umin32(umin32(A.w, B.x), umin32(umin32(B.y, B.z), B.w));  // i+3..i+7
+                        const uint32_t a12 = umin32(A.y, A.z), c01 = umin32(C.x, C.y);
+                        r = make_uint4(umin32(umin32(A.x, a12), mid), umin32(umin32(a12, mid), C.x),
+                                       umin32(umin32(A.z, mid), c01), umin32(umin32(mid, c01), C.z));
+                    }
+                    t4[g] = r;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- remaining levels (step >= 8): T[i..i+3] = min(T[i..i+3], T[i+step..i+step+3]) ----
+        for (uint32_t lev = K0; lev < klev; lev++) {
+            const uint32_t gstep = (1u << lev) >> 2;
+            uint4* t4 = reinterpret_cast<uint4*>(s_T);
+            uint4 rt[MAXG];
+#pragma unroll
+            for (int q = 0; q < MAXG; q++) {
+                const uint32_t g = threadIdx.x + q * BLOCK;
+                if (g < groups) {
+                    const uint32_t g2 = g + gstep < groups ? g + gstep : groups - 1;
+                    rt[q] = umin4(t4[g], t4[g2]);
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < MAXR; q++) {
-                uint32_t i = threadIdx.x + q * BLOCK;
-                if (i < staged) s_T[i] = rt[q];
+            for (int q = 0; q < MAXG; q++) {
+                const uint32_t g = threadIdx.x + q * BLOCK;
+                if (g < groups) t4[g] = rt[q];
             }
             __syncthreads();
         }
 
         // ---- phase 1: positions whose w-window minimum exceeds their own LCP close something ----
+        {
+            const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
+            const uint4* t4 = reinterpret_cast<const uint4*>(tbl);
 #pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const uint32_t o = threadIdx.x + q * BLOCK;                     // offset in tile
-            const uint64_t j = tile0 + o;
-            const uint32_t lj = shift + o;                                  // LDS index of j
-            bool take = false;
-            if (j >= 1 && j < a.n && lj >= w) {
-                const uint32_t closing = s_lcp[lj];
-                const uint32_t x = s_T[lj - w], y = s_T[lj - wstep];
-                const uint32_t M = x < y ? x : y;                           // min(lcp[j-w .. j-1])
-                take = M > closing && M >= a.min_len;
+            for (int q = 0; q < VG; q++) {
+                const uint32_t o = (threadIdx.x + q * BLOCK) * 4;               // offset in tile of 4 positions
+                const uint32_t lj = shift + o;                                  // LDS index, multiple of 4
+                uint32_t takes = 0;
+                if (tile0 + o < a.n && lj + 3 >= w) {
+                    const uint4 closing = l4[lj >> 2];
+                    // windows start at lj - w + t (left) and lj - wstep + t (right), t = 0..3
+                    uint4 L, R;
+                    {
+                        // floor((lj - w) / 4) without going negative: lj + 3 >= w guarantees lj - w >= -3
+                        const int32_t s0 = (int32_t)lj - (int32_t)w;
+                        const int32_t g0 = s0 >= 0 ? (s0 >> 2) : -1;
+                        const uint4 lo = g0 >= 0 ? t4[g0] : make_uint4(0, 0, 0, 0);
+                        const uint4 hi4 = t4[g0 + 1];
+                        L = shift4(lo, hi4, rl);
+                        const int32_t s1 = (int32_t)lj - (int32_t)wstep;
+                        const int32_t g1 = s1 >= 0 ? (s1 >> 2) : -1;
+                        const uint4 lo1 = g1 >= 0 ? t4[g1] : make_uint4(0, 0, 0, 0);
+                        const uint4 hi1 = t4[g1 + 1];
+                        R = shift4(lo1, hi1, rr);
+                    }
+                    const uint4 M = umin4(L, R);
+                    const uint64_t j0 = tile0 + o;
+                    const uint32_t mv[4] = {M.x, M.y, M.z, M.w}, cv[4] = {closing.x, closing.y, closing.z, closing.w};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const uint64_t j = j0 + t;
+                        const bool ok = j >= 1 && j < a.n && lj + t >= w && mv[t] > cv[t] && mv[t] >= a.min_len;
+                        takes |= ok ? (1u << t) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool take = (takes >> t) & 1u;
+                    const uint64_t mask = __ballot(take);
+                    uint32_t base = 0;
+                    if (lane == 0 && mask) base = atomicAdd(&s_qn, (uint32_t)__popcll(mask));
+                    base = __shfl(base, 0, 64);
+                    if (take) s_queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)(o + t);
+                }
             }
-            const uint64_t mask = __ballot(take);
-            uint32_t base = 0;
-            if (lane == 0 && mask) base = atomicAdd(&s_qn, (uint32_t)__popcll(mask));
-            base = __shfl(base, 0, 64);
-            if (take) s_queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)o;
         }
         __syncthreads();
         const uint32_t qn = s_qn;
@@ -414,11 +487,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             const uint32_t o = s_queue[wi];
             const uint32_t lj = shift + o;
             const uint32_t closing = s_lcp[lj];
-            uint32_t m; bool chg = false;
-            {
-                const uint32_t x = s_T[lj - w], y = s_T[lj - wstep];
-                m = x < y ? x : y;
-            }
+            uint32_t m = umin32(tbl[lj - w], tbl[lj - wstep]);
+            bool chg = false;
             uint32_t lk = lj - w;                                           // LDS index of k; candidate start s = k - 1
             {   // BWT bytes of [k, j-1] not all equal?  (s_bwt is offset by 16)
                 const uint8_t b0 = s_bwt[16 + lj - 1];
@@ -482,9 +552,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     }
 }
 
-template <int B, int PER, int OUT_CAP>
+template <int B, int VG, int OUT_CAP>
 static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu) {
-    constexpr int TILE = B * PER;
+    constexpr int TILE = B * VG * 4;
     uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
     uint32_t w = nd - 1;
     if (w > 1000) w = 1;                                   // window tables need w <= halo <= 4 * BLOCK
@@ -494,27 +564,36 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     if (halo < w + 1) halo = w + 1;
     halo = (halo + 15) & ~15u;
     if (halo > 4 * B) halo = 4 * B;                        // beyond this the walk reads the cached global columns
-    size_t lds = (size_t)(halo + TILE) * 9 + 16 + (size_t)TILE * 2 + (size_t)OUT_CAP * sizeof(Cand);
+    size_t lds = (size_t)(halo + TILE + 16) * 9 + 16 + (size_t)TILE * 2 + (size_t)OUT_CAP * sizeof(Cand);
     uint32_t n_tiles = grid_for(a.n, TILE);
     unsigned grid = n_tiles < 256u * blocks_per_cu ? n_tiles : 256u * blocks_per_cu;
-    hipLaunchKernelGGL((k_scan<B, PER, OUT_CAP>), dim3(grid), dim3(B), lds, s, a, halo, n_tiles, w, klev);
+    dim3 g(grid), b(B);
+    switch (klev < 3 ? klev : 3) {
+        case 0: hipLaunchKernelGGL((k_scan<B, VG, 0, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
+        case 1: hipLaunchKernelGGL((k_scan<B, VG, 1, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
+        case 2: hipLaunchKernelGGL((k_scan<B, VG, 2, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
+        default: hipLaunchKernelGGL((k_scan<B, VG, 3, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
+    }
     MMT_HIP(hipGetLastError());
 }
 
 void scan_intervals(const ScanArgs& a, hipStream_t s) {
     if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
+    // measured on MI355X (profiles/round1_b): 512 threads x 8 positions per thread is best for small
+    // windows (16 docs: 0.88 ms / 387 M suffixes), 512 x 12 for wide ones (94 docs: 0.92 ms / 376 M)
     static int variant = -1, bpc = 8;
     if (variant < 0) {
         const char* v = getenv("MMT_SCAN_VARIANT"); variant = v ? atoi(v) : 0;
         const char* g = getenv("MMT_SCAN_BPC"); if (g) bpc = atoi(g);
     }
     switch (variant) {
-        case 1: launch_scan<256, 4, 256>(a, s, bpc); break;
-        case 2: launch_scan<256, 16, 512>(a, s, bpc); break;
-        case 3: launch_scan<512, 4, 512>(a, s, bpc); break;
-        case 4: launch_scan<512, 8, 512>(a, s, bpc); break;
-        case 5: launch_scan<128, 8, 256>(a, s, bpc); break;
-        default: launch_scan<256, 8, 512>(a, s, bpc); break;
+        case 1: launch_scan<256, 2, 512>(a, s, bpc); break;
+        case 2: launch_scan<512, 2, 512>(a, s, bpc); break;
+        case 3: launch_scan<512, 3, 512>(a, s, bpc); break;
+        default:
+            if (a.num_distinct > 32) launch_scan<512, 3, 512>(a, s, bpc);
+            else launch_scan<512, 2, 512>(a, s, bpc);
+            break;
     }
 }
 

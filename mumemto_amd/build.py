@@ -72,9 +72,9 @@ def build(verbose=False):
         if not tobjs:
             continue
         out = os.path.join(BIN_DIR, tool)
-        if _newer(out, tobjs + [LIB]):
-            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-o", out] + tobjs +
-                                  ["-L" + LIB_DIR, "-lmumemto", "-Wl,-rpath,$ORIGIN/../lib", "-lz"])
+        if _newer(out, tobjs + lib_objs):
+            # the tools use the engine classes directly (hidden symbols of the .so): link the objects in
+            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-o", out] + tobjs + lib_objs + ["-lz"])
     if verbose:
         print("built", LIB)
     return LIB

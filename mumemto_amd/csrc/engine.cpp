@@ -326,6 +326,31 @@ const std::string& Engine::bumbl() {
     return bumbl_;
 }
 
+void Engine::thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev) const {
+    // thresholds re-indexed by position inside each written MUM, MUMs in anchor order, 0-terminated
+    const HostRows& R = rows_;
+    if (!R.mum_mode || !thresh_len_) throw std::runtime_error("thresholds need a multi-MUM run with merge metadata");
+    std::vector<uint16_t> th(thresh_len_);
+    copy_thresh(th.data());
+    const size_t nr = R.n_rows(), N = R.n_docs;
+    std::vector<std::pair<uint64_t, uint64_t>> mp(nr);     // (offset in doc 0, length), mem_finder.hpp:394-397
+    uint64_t total = 0;
+    for (size_t r = 0; r < nr; r++) { mp[r] = {(uint64_t)R.mum_offsets[r * N], R.length[r]}; total += R.length[r] + 1; }
+    std::sort(mp.begin(), mp.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    fwd.assign(total, 0); rev.assign(total, 0);
+    const uint64_t half0 = doc_len_[0] + 1;
+    uint64_t off = 0;
+    for (size_t r = 0; r < nr; r++) {
+        const uint64_t first = mp[r].first, len = mp[r].second;
+        const uint64_t revpos = 2 * half0 - first - len - 1;
+        for (uint64_t j = 0; j < len; j++, off++) {
+            if (first + j < th.size() && th[first + j] < len - j) fwd[off] = th[first + j];
+            if (revpos + j < th.size() && th[revpos + j] < len - j) rev[off] = th[revpos + j];
+        }
+        off++;   // terminator stays 0
+    }
+}
+
 void Engine::run(const mmt_params& p) {
     MMT_HIP(hipSetDevice(device_));
     auto t0 = std::chrono::steady_clock::now();

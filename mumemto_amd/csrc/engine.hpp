@@ -41,6 +41,8 @@ public:
 
     const HostRows& rows() const { return rows_; }
     const std::string& bumbl();
+    // PREFIX.thresh / PREFIX.thresh_rev contents (mem_finder.hpp:116-157); needs a merge_metadata MUM run
+    void thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev) const;
     uint64_t text_length() const { return n_; }
     size_t n_docs() const { return doc_len_.size(); }
     const std::vector<uint64_t>& doc_len() const { return doc_len_; }

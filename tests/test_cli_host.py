@@ -1,0 +1,100 @@
+"""CPU tests of the CLI's host logic (no GPU): option normalisation
+(include/pfp_mum.hpp:80-198), input checks (src/ref_builder.cpp:52-138), FASTA
+parsing (kseq semantics) and the .lengths writer (src/ref_builder.cpp:193-209).
+MUMEMTO_DRY_RUN=1 makes mumemto_exec stop before touching the device."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import pyoracle as O
+from mumemto_amd import build, synth
+
+EXE = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build()
+
+
+def run(args, cwd):
+    env = dict(os.environ, MUMEMTO_DRY_RUN="1")
+    return subprocess.run([EXE] + args, cwd=cwd, env=env, capture_output=True, text=True)
+
+
+def fields(stdout):
+    return dict(kv.split("=") for kv in stdout.split())
+
+
+def make_inputs(tmp_path, n=5):
+    docs = synth.pangenome(n, 500, 0.02, seed=1)
+    paths = []
+    for i, d in enumerate(docs):
+        p = tmp_path / ("g%d.fa" % i)
+        synth.write_fasta(str(p), d, width=60)
+        paths.append(str(p))
+    return docs, paths
+
+
+def test_parameter_normalisation_matches_reference_rules(tmp_path):
+    docs, paths = make_inputs(tmp_path)
+    for k, f, F in [(0, 1, 0), (-1, 3, 0), (1, 1, 0), (9, 1, 0), (-9, 1, 0), (2, 0, 100), (0, 2, 100), (0, 2, -1), (0, 0, 1)]:
+        r = run(["-o", str(tmp_path / "o"), "-k", str(k), "-f", str(f), "-F", str(F)] + paths, tmp_path)
+        assert r.returncode == 0, r.stderr
+        nd, mf, mt = O.cli_params(len(paths), k, f, F)
+        got = fields(r.stdout)
+        assert (int(got["num_distinct"]), int(got["max_doc_freq"]), int(got["max_total_freq"])) == (nd, mf, mt)
+
+
+def test_flags_and_errors(tmp_path):
+    docs, paths = make_inputs(tmp_path)
+    got = fields(run(["-o", str(tmp_path / "o"), "-r", "-n", "-b", "-l", "33"] + paths, tmp_path).stdout)
+    assert got["revcomp"] == "0" and got["merge"] == "1" and got["anchor"] == "1" and got["binary"] == "1"
+    assert got["min_len"] == "33"
+    # binary is dropped for multi-MEMs, merging refuses partial / MEM modes
+    assert fields(run(["-o", str(tmp_path / "o"), "-b", "-f", "2"] + paths, tmp_path).stdout)["binary"] == "0"
+    assert run(["-o", str(tmp_path / "o"), "-M", "-k", "-1"] + paths, tmp_path).returncode == 1
+    assert run(["-o", str(tmp_path / "o"), "-M", "-f", "2"] + paths, tmp_path).returncode == 1
+    assert run(["-o", str(tmp_path / "o"), paths[0]], tmp_path).returncode == 1          # one input only
+    assert run(["-o", str(tmp_path / "o"), paths[0], paths[0]], tmp_path).returncode == 1  # duplicates collapse
+    bad = tmp_path / "x.txt"
+    bad.write_text(">a\nACGT\n")
+    assert run(["-o", str(tmp_path / "o"), paths[0], str(bad)], tmp_path).returncode == 1   # not a FASTA suffix
+    empty = tmp_path / "e.fa"
+    empty.write_text("")
+    r = run(["-o", str(tmp_path / "o"), paths[0], str(empty)], tmp_path)
+    assert r.returncode == 1 and "Empty input file" in r.stderr
+    assert run(["-o", str(tmp_path / "o"), "-f", "-2"] + paths, tmp_path).returncode == 1
+
+
+def test_fasta_parsing_and_lengths_file(tmp_path):
+    # multi-record, lowercase, CRLF, blank lines, gzip and a FASTQ record
+    a = tmp_path / "a.fa"
+    a.write_bytes(b">chr1 some comment\nACGTacgt\r\nNNAC\n\n>chr2\nGG\nTTA\n")
+    b = tmp_path / "b.fasta.gz"
+    with gzip.open(b, "wb") as f:
+        f.write(b">only\nACGTTGCA\nACG\n")
+    c = tmp_path / "c.fna"
+    c.write_bytes(b"@read1 x\nACGTAC\n+\nIIIIII\n@read2\nTTGA\n+read2\nIIII\n")
+    r = run(["-o", str(tmp_path / "out")] + [str(a), str(b), str(c)], tmp_path)
+    assert r.returncode == 0, r.stderr
+    got = fields(r.stdout)
+    want = b"ACGTacgtNNAC" + b"GGTTA" + b"ACGTTGCAACG" + b"ACGTAC" + b"TTGA"
+    h = 1469598103934665603
+    for ch in want:
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert int(got["bases"]) == len(want) and got["fnv1a"] == "%016x" % h
+    lengths = (tmp_path / "out.lengths").read_text().splitlines()
+    ra, rb, rc = (os.path.realpath(str(p)) for p in (a, b, c))
+    assert lengths == [ra + " * 17", ra + " chr1 12", ra + " chr2 5", rb + " * 11", rb + " only 11",
+                       rc + " * 10", rc + " read1 6", rc + " read2 4"]
+
+
+def test_filelist_input(tmp_path):
+    docs, paths = make_inputs(tmp_path, 3)
+    fl = tmp_path / "list.txt"
+    fl.write_text("\n".join(p + " 1" for p in paths) + "\n\n")
+    got = fields(run(["-i", str(fl), "-o", str(tmp_path / "o")], tmp_path).stdout)
+    assert got["docs"] == "3"

@@ -1,0 +1,121 @@
+"""GPU tests of the CLI contract: FASTA files in, PREFIX.{mums,mems,bumbl,lengths,
+athresh,thresh,thresh_rev,sa,lcp,bwt} out, byte-compared with the oracle's writers;
+anchor_merge tool against the real reference binary's golden output."""
+import glob
+import gzip
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from mumemto_amd import build, synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(build.LIB), "..", "bin")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def write_inputs(tmp_path, docs):
+    paths = []
+    for i, d in enumerate(docs):
+        if i == 1:   # two records + lowercase + 60 columns
+            rec = d[0]
+            recs = [rec[: len(rec) // 3].lower(), rec[len(rec) // 3:]]
+            p = tmp_path / ("g%d.fasta" % i)
+            synth.write_fasta(str(p), recs, names=["a", "b"], width=60)
+        elif i == 2:
+            p = tmp_path / ("g%d.fa.gz" % i)
+            raw = tmp_path / "tmp.fa"
+            synth.write_fasta(str(raw), d)
+            with gzip.open(p, "wb") as f:
+                f.write(raw.read_bytes())
+        else:
+            p = tmp_path / ("g%d.fa" % i)
+            synth.write_fasta(str(p), d)
+        paths.append(str(p))
+    return paths
+
+
+def cli(args, cwd):
+    r = subprocess.run([os.path.join(BIN, "mumemto_exec")] + args, cwd=cwd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("cli")
+    docs = synth.pangenome(6, 30000, 0.01, seed=12, indel_rate=0.002, inversion=(3, 5000, 9000))
+    return tmp, docs, write_inputs(tmp, docs)
+
+
+def test_default_partial_mem_and_norevcomp(inputs):
+    tmp, docs, paths = inputs
+    N = len(docs)
+    for name, args, kw, ext in [
+        ("def", [], dict(), "mums"),
+        ("k1", ["-k", "-1"], dict(num_distinct=N - 1), "mums"),
+        ("mem", ["-k", "-1", "-f", "3"], dict(num_distinct=N - 1, max_doc_freq=3, max_total_freq=3 * N), "mems"),
+        ("nor", ["-r"], dict(revcomp=False), "mums"),
+        ("F", ["-f", "0", "-k", "2", "-F", "9", "-l", "25"], dict(num_distinct=2, max_doc_freq=0, max_total_freq=9,
+                                                                 min_len=25), "mems"),
+        ("g", ["-g", "-w", "12", "-m", "50"], dict(), "mums"),
+    ]:
+        cli(["-o", str(tmp / name)] + args + paths, tmp)
+        if "num_distinct" not in kw and "max_doc_freq" not in kw:
+            kw = dict(kw, max_total_freq=N)
+        elif kw.get("max_doc_freq", 1) == 1 and "max_total_freq" not in kw:
+            kw = dict(kw, max_total_freq=N)
+        want = O.run(docs, **kw)
+        assert (tmp / (name + "." + ext)).read_bytes() == want.text(), name
+
+
+def test_binary_and_merge_metadata_outputs(inputs):
+    tmp, docs, paths = inputs
+    cli(["-o", str(tmp / "b"), "-b"] + paths, tmp)
+    want = O.run(docs, max_total_freq=len(docs), merge=True)
+    assert (tmp / "b.bumbl").read_bytes() == want.bumbl()
+    cli(["-o", str(tmp / "an"), "-n"] + paths, tmp)
+    assert (tmp / "an.mums").read_bytes() == want.text()
+    L0 = len(docs[0][0])
+    assert (tmp / "an.athresh").read_bytes() == want.thresh()[: L0 + 1].tobytes()
+    cli(["-o", str(tmp / "st"), "-M"] + paths, tmp)
+    assert (tmp / "st.thresh").read_bytes() == want.thresh_file(False).tobytes()
+    assert (tmp / "st.thresh_rev").read_bytes() == want.thresh_file(True).tobytes()
+
+
+def test_arrays_out(inputs):
+    tmp, docs, paths = inputs
+    cli(["-o", str(tmp / "arr"), "-A"] + paths, tmp)
+    text, _ = O.build_text(docs, True)
+    sa, lcp, bwt = O.build_stream(text)
+    n1 = len(sa)
+
+    def u40(path):
+        raw = np.fromfile(path, np.uint8).reshape(-1, 5).astype(np.uint64)
+        return sum(raw[:, k] << np.uint64(8 * k) for k in range(5))
+    assert np.array_equal(u40(tmp / "arr.sa"), sa.astype(np.uint64)) and len(sa) == n1
+    assert np.array_equal(u40(tmp / "arr.lcp"), lcp.astype(np.uint64))
+    got_bwt = np.fromfile(tmp / "arr.bwt", np.uint8)
+    assert np.array_equal(got_bwt[1:], bwt[1:]) and got_bwt[0] == text[-1]
+
+
+def test_anchor_merge_tool_matches_reference_binary(tmp_path):
+    G = os.path.join(HERE, "golden", "anchor_merge")
+    for case in sorted(os.listdir(G)):
+        work = tmp_path / case
+        shutil.copytree(os.path.join(G, case), work)
+        parts = sorted(glob.glob(str(work / "p*.mums")))
+        r = subprocess.run([os.path.join(BIN, "anchor_merge")] + parts + ["-o", str(work / "out")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert (work / "out.mums").read_bytes() == (work / "merged.mums").read_bytes()
+        assert (work / "out.athresh").read_bytes() == (work / "merged.athresh").read_bytes()
+        # .bumbl in, .bumbl out
+        r = subprocess.run([os.path.join(BIN, "anchor_merge")] + parts + ["-o", str(work / "outb.bumbl")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert os.path.getsize(work / "outb.bumbl") > 18

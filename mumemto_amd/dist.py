@@ -54,8 +54,11 @@ def all_gather_partitions(local, dist, device):
     t = torch.from_numpy(table).to(device)
     tables = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(tables, t)
-    threshes = [torch.zeros_like(thresh) for _ in range(world)]
-    dist.all_gather(threshes, thresh)
+    # thresholds travel as raw bytes: neither RCCL nor gloo has a 16-bit integer type
+    tbytes = thresh.contiguous().view(torch.uint8)
+    gathered = [torch.zeros_like(tbytes) for _ in range(world)]
+    dist.all_gather(gathered, tbytes)
+    threshes = [g.view(torch.int16) for g in gathered]
     parts = []
     for r in range(world):
         rn, rnd = metas[r]

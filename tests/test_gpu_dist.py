@@ -1,0 +1,54 @@
+"""GPU: the multi-GPU step's device plumbing on one MI355X -- thresholds wrapped
+zero-copy as a torch tensor, RCCL all-gather (world_size 1), fold on the GPU with
+device-resident thresholds, re-sort to direct-run order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from mumemto_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_exchange_and_device_fold():
+    import torch
+    import torch.distributed as dist
+    import mumemto_amd
+    from mumemto_amd import dist as mdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        device = torch.device("cuda", 0)
+        docs = synth.pangenome(7, 40000, 0.01, seed=17)
+        groups = [[0, 1, 2, 3], [0, 4, 5, 6]]
+        L0 = len(docs[0][0])
+        eng = mumemto_amd.Engine(0, torch.cuda.current_stream(device).cuda_stream)
+        parts = []
+        for g in reversed(groups):      # the last run must hold the anchor ranks; any partition does
+            eng.set_docs([docs[i] for i in g])
+            eng.run(merge_metadata=True)
+            length, off, st = eng.rows_mum()
+            th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
+            torch.cuda.synchronize()
+            gathered = mdist.all_gather_partitions((length, off, st, th), dist, device)
+            assert len(gathered) == 1
+            p = gathered[0]
+            assert np.array_equal(p[0], length) and np.array_equal(p[1], off) and np.array_equal(p[2], st)
+            parts.append((p[0], p[1], p[2], p[3].clone()))
+        parts.reverse()
+        merged = eng.anchor_merge([(p[0], p[1], p[2], (p[3].data_ptr(), L0 + 1)) for p in parts],
+                                  sort_like_direct=True)
+        order = mdist.merged_column_order(groups)
+        direct = O.run([docs[i] for i in order], merge=True)
+        assert merged["text"] == direct.text()
+        assert np.array_equal(merged["thresh"], direct.thresh()[: L0 + 1])
+        eng.close()
+    finally:
+        dist.destroy_process_group()

@@ -59,6 +59,13 @@ MMT_API int mmt_engine_set_input_device(mmt_engine* e, const uint8_t* d_bases,
 MMT_API int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases,
                                       const uint64_t* doc_len, size_t n_docs);
 
+/* Producer of the SA/LCP/BWT stream for the next runs:
+ *   0 automatic | 1 direct suffix sort of the whole text (the reference's -g path, direct_gsacak.hpp)
+ *   2 prefix-free parsing (the reference's default: newscan.hpp + pfp.hpp + pfp_lcp_mum.hpp);
+ * w / p = PFP window and modulus (0 = the reference defaults 10 / 100).  Both give the same stream. */
+MMT_API int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p);
+MMT_API int mmt_producer_used(const mmt_engine* e);
+
 /* One pass of the hot path: text -> SA/LCP/BWT -> scan -> rows (+ thresholds). */
 MMT_API int mmt_engine_run(mmt_engine* e, const mmt_params* p);
 
@@ -98,6 +105,20 @@ MMT_API int mmt_copy_candidates(const mmt_engine* e, uint32_t* out);
 MMT_API int mmt_stage_ms(const mmt_engine* e, float out[8]);
 /* Bytes of the SA / LCP / BWT columns as stored (for the roofline model).     */
 MMT_API int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]);
+
+/* ---- PFP stage checkpoints (the reference's -P / -K: PREFIX.dict, PREFIX.parse) ------------ */
+/* Text layout + prefix-free parse only (newscan.hpp pfparser: process_string ... finish_parse).  */
+MMT_API int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p);
+/* out[0] #phrases of the parse, [1] #distinct phrases, [2] dictionary bytes, [3] #groups of equal
+ * proper phrase suffixes, [4] doubling rounds on the dictionary, [5] on the parse                */
+MMT_API int mmt_pfp_counts(const mmt_engine* e, uint64_t out[6]);
+/* PREFIX.dict bytes (sorted phrases, 0x01 after each, 0x00 at the end; out holds counts[2] bytes)  */
+MMT_API int mmt_pfp_copy_dict(mmt_engine* e, uint8_t* out);
+/* PREFIX.parse entries (1-based phrase ranks, u32; out holds counts[0] entries)                    */
+MMT_API int mmt_pfp_copy_parse(mmt_engine* e, uint32_t* out);
+/* ms: [0] triggers+phrases [1] distinct phrases [2] dictionary text [3] dictionary SA
+ * [4] dictionary LCP + groups + ranks [5] parse SA [6] text keys + sort [7] total (host clock)    */
+MMT_API int mmt_pfp_stage_ms(const mmt_engine* e, float out[8]);
 
 /* ---- anchor partition merge (src/merge_candidates.cpp:97-157) -------------- */
 typedef struct mmt_partition {

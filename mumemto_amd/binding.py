@@ -55,6 +55,8 @@ GPU_ABI_SYMBOLS = [
     "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
+    "mmt_engine_set_producer", "mmt_producer_used", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
+    "mmt_pfp_copy_parse", "mmt_pfp_stage_ms",
 ]
 
 
@@ -114,6 +116,13 @@ def load_library():
         getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mmt_column_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mmt_engine_set_producer.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
+    L.mmt_producer_used.argtypes = [C.c_void_p]
+    L.mmt_engine_parse_only.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint32]
+    L.mmt_pfp_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_pfp_copy_parse.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_pfp_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mmt_anchor_merge.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.POINTER(C.c_void_p)]
     L.mmt_merged_get.argtypes = [C.c_void_p] * 5
     L.mmt_merged_sort_like_direct.argtypes = [C.c_void_p, C.c_void_p]
@@ -242,6 +251,33 @@ class Engine:
             merge_metadata=False):
         p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
         _check(self.L.mmt_engine_run(self.h, C.byref(p)))
+
+    def set_producer(self, kind="auto", w=0, p=0):
+        """kind: 'auto' | 'direct' (reference -g path) | 'pfp' (reference default path)."""
+        _check(self.L.mmt_engine_set_producer(self.h, {"auto": 0, "direct": 1, "pfp": 2}[kind], w, p))
+
+    def producer_used(self):
+        return {1: "direct", 2: "pfp"}.get(self.L.mmt_producer_used(self.h), "?")
+
+    def parse_only(self, use_revcomp=True, w=10, p=100):
+        """Text layout + prefix-free parse; returns (dict bytes, parse u32[]) as the reference's -P writes them."""
+        _check(self.L.mmt_engine_parse_only(self.h, int(use_revcomp), w, p))
+        c = self.pfp_counts()
+        d = np.zeros(max(c["dict_len"], 1), np.uint8)
+        q = np.zeros(max(c["phrases"], 1), np.uint32)
+        _check(self.L.mmt_pfp_copy_dict(self.h, _p(d)))
+        _check(self.L.mmt_pfp_copy_parse(self.h, _p(q)))
+        return d[: c["dict_len"]].tobytes(), q[: c["phrases"]]
+
+    def pfp_counts(self):
+        out = (C.c_uint64 * 6)()
+        _check(self.L.mmt_pfp_counts(self.h, out))
+        return dict(zip(["phrases", "distinct", "dict_len", "groups", "rounds_dict", "rounds_parse"], map(int, out)))
+
+    def pfp_stage_ms(self):
+        out = (C.c_float * 8)()
+        _check(self.L.mmt_pfp_stage_ms(self.h, out))
+        return list(out)
 
     # results
     def output_text(self):

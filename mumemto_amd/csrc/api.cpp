@@ -302,6 +302,48 @@ int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]) {
     return 0;
 }
 
+int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p) {
+    if (!e) return fail(1, "null");
+    if (kind < 0 || kind > 2) return fail(3, "producer must be 0 (auto), 1 (direct) or 2 (pfp)");
+    e->e->set_producer(kind, w, p);
+    return 0;
+}
+int mmt_producer_used(const mmt_engine* e) { return e ? e->e->producer_used() : 0; }
+int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    e->e->parse_only(use_revcomp != 0, w ? w : 10, p ? p : 100);
+    MMT_CATCH
+}
+int mmt_pfp_counts(const mmt_engine* e, uint64_t out[6]) {
+    if (!e) return fail(1, "null");
+    const mmt::PfpState& S = e->e->pfp_state();
+    out[0] = S.n_phrases; out[1] = S.n_distinct; out[2] = S.dict_len; out[3] = S.n_groups;
+    out[4] = (uint64_t)S.rounds_dict; out[5] = (uint64_t)S.rounds_parse;
+    return 0;
+}
+int mmt_pfp_copy_dict(mmt_engine* e, uint8_t* out) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    std::vector<uint8_t> v;
+    e->e->pfp_copy_dict(v);
+    std::memcpy(out, v.data(), v.size());
+    MMT_CATCH
+}
+int mmt_pfp_copy_parse(mmt_engine* e, uint32_t* out) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    std::vector<uint32_t> v;
+    e->e->pfp_copy_parse(v);
+    std::memcpy(out, v.data(), v.size() * 4);
+    MMT_CATCH
+}
+int mmt_pfp_stage_ms(const mmt_engine* e, float out[8]) {
+    if (!e) return fail(1, "null");
+    std::memcpy(out, e->e->pfp_state().ms, 8 * sizeof(float));
+    return 0;
+}
+
 // ---- anchor merge --------------------------------------------------------------------
 int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out) {
     if (!e || !parts || !out) return fail(1, "engine, parts and out must be non-null");

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "prims.hpp"
@@ -81,50 +82,10 @@ void Engine::suffix_sort() {
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, stream_));
 
-    d_keys_a_.ensure(n); d_keys_b_.ensure(n);
-    d_sac_a_.ensure(n); d_sac_b_.ensure(n); d_pos_a_.ensure(n); d_pos_b_.ensure(n); d_headc_.ensure(n);
-    d_sa_.ensure(n); d_rank_.ensure(n); d_headval_.ensure(n); d_head_.ensure(n); d_idx_.ensure(n);
-    d_flags_.ensure(n); d_count_.ensure(4);
-
-    k::pack_keys(d_text_.get(), n, d_code_.get(), bits, chars, d_keys_a_.get(), d_sac_a_.get(), stream_);
-    prims::sort_pairs_u64_u32(d_temp_, d_keys_a_.get(), d_keys_b_.get(), d_sac_a_.get(), d_sa_.get(), n, 0,
-                              std::min(64, bits * chars), stream_);
-    k::mark_heads(d_keys_b_.get(), n, d_headval_.get(), stream_);
-    prims::inclusive_max_u32(d_temp_, d_headval_.get(), d_head_.get(), n, stream_);
-    k::scatter_rank(d_sa_.get(), d_head_.get(), n, d_rank_.get(), stream_);
-    k::flag_unsorted(d_head_.get(), n, d_flags_.get(), stream_);
-    prims::select_indices(d_temp_, d_flags_.get(), d_idx_.get(), d_count_.get(), n, stream_);
-    uint32_t m = 0;
-    MMT_HIP(hipMemcpyAsync(&m, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));
-    MMT_HIP(hipStreamSynchronize(stream_));
-    if (m) k::gather_active(d_idx_.get(), m, d_sa_.get(), d_head_.get(), d_pos_a_.get(), d_sac_a_.get(),
-                            d_headc_.get(), stream_);
-
-    const int shift = bit_width_u64(n);            // second key component holds values 0..n
-    uint64_t h = (uint64_t)chars;
-    int rounds = 0;
-    while (m) {
-        if (++rounds > 64) throw std::runtime_error("suffix sort did not converge");
-        uint32_t hh = h > 0xffffffffull ? 0xffffffffu : (uint32_t)h;
-        k::make_round_keys(d_sac_a_.get(), d_headc_.get(), m, d_rank_.get(), n, hh, shift, d_keys_a_.get(), stream_);
-        prims::sort_pairs_u64_u32(d_temp_, d_keys_a_.get(), d_keys_b_.get(), d_sac_a_.get(), d_sac_b_.get(), m, 0,
-                                  std::min(64, 2 * shift), stream_);
-        k::mark_subheads(d_keys_b_.get(), d_pos_a_.get(), m, d_headval_.get(), stream_);
-        prims::inclusive_max_u32(d_temp_, d_headval_.get(), d_head_.get(), m, stream_);
-        k::apply_round(d_sac_b_.get(), d_head_.get(), d_pos_a_.get(), m, d_sa_.get(), d_rank_.get(), d_flags_.get(),
-                       stream_);
-        prims::select_indices(d_temp_, d_flags_.get(), d_idx_.get(), d_count_.get(), m, stream_);
-        uint32_t m2 = 0;
-        MMT_HIP(hipMemcpyAsync(&m2, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));
-        MMT_HIP(hipStreamSynchronize(stream_));
-        if (m2) {
-            k::compact_round(d_idx_.get(), m2, d_pos_a_.get(), d_sac_b_.get(), d_head_.get(), d_pos_b_.get(),
-                             d_sac_a_.get(), d_headc_.get(), stream_);
-            d_pos_a_.swap(d_pos_b_);
-        }
-        m = m2;
-        h *= 2;
-    }
+    d_sa_.ensure(n); d_rank_.ensure(n);
+    sorter_.reserve(n);
+    k::pack_keys(d_text_.get(), n, d_code_.get(), bits, chars, sorter_.keys_in(), sorter_.vals_in(), stream_);
+    sort_rounds_ = sorter_.sort(n, bits * chars, (uint64_t)chars, d_sa_.get(), d_rank_.get(), d_temp_, stream_);
 }
 
 void Engine::lcp_bwt() {
@@ -139,6 +100,7 @@ void Engine::lcp_bwt() {
 void Engine::scan(const mmt_params& p) {
     const uint32_t n = (uint32_t)n_;
     const size_t N = doc_len_.size();
+    d_count_.ensure(4);
     num_distinct_eff_ = p.num_distinct ? p.num_distinct : N;     // mumemto_api.cpp:344-346
     // interval size cap: explicit total cap, else docs * per-doc cap (every accepted interval obeys it)
     uint64_t cap = 0;
@@ -362,12 +324,29 @@ void Engine::run(const mmt_params& p) {
     n_cand_ = 0; thresh_len_ = 0; bumbl_.clear();
     if (doc_len_.empty()) return;                       // mumemto_api.cpp:338-340
     ev_[0]->start(stream_); build_text(p.use_revcomp != 0); ev_[0]->stop(stream_);
-    ev_[1]->start(stream_); suffix_sort(); ev_[1]->stop(stream_);
+    ev_[1]->start(stream_);
+    {
+        int kind = producer_;
+        if (kind == 0) {
+            const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp"
+            kind = (env && std::string(env) == "pfp") ? 2 : 1;
+        }
+        if (kind == 2) suffix_sort_pfp(pfp_w_, pfp_p_); else suffix_sort();
+        producer_used_ = kind;
+    }
+    ev_[1]->stop(stream_);
     ev_[2]->start(stream_); lcp_bwt(); ev_[2]->stop(stream_);
     scan(p);
     make_rows(p);
     for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
     stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::parse_only(bool revcomp, uint32_t w, uint32_t p) {
+    MMT_HIP(hipSetDevice(device_));
+    if (doc_len_.empty()) throw std::runtime_error("no input");
+    build_text(revcomp);
+    pfp_parse(w, p);
 }
 
 void Engine::copy_text(uint8_t* out) const {

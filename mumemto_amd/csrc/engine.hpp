@@ -8,6 +8,8 @@
 #include "../../include/mumemto_gpu.h"
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "pfp.hpp"
+#include "sorter.hpp"
 
 namespace mmt {
 
@@ -38,6 +40,14 @@ public:
     void set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs);
     void set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs);
     void run(const mmt_params& p);
+    // SA/LCP/BWT producer: 0 = automatic, 1 = direct suffix sort of the text (A8), 2 = prefix-free parsing (A2-A4)
+    void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w ? w : 10; pfp_p_ = p ? p : 100; }
+    int producer_used() const { return producer_used_; }
+    // A2 alone (after build_text): phrases, dictionary, parse.  Used by -P / -K and the parity tests.
+    void parse_only(bool revcomp, uint32_t w, uint32_t p);
+    void pfp_copy_dict(std::vector<uint8_t>& out);
+    void pfp_copy_parse(std::vector<uint32_t>& out);
+    const PfpState& pfp_state() const { return pfp_; }
 
     const HostRows& rows() const { return rows_; }
     const std::string& bumbl();
@@ -66,6 +76,8 @@ public:
 private:
     void build_text(bool revcomp);
     void suffix_sort();
+    void pfp_parse(uint32_t w, uint32_t p);
+    void suffix_sort_pfp(uint32_t w, uint32_t p);
     void lcp_bwt();
     void scan(const mmt_params& p);
     void make_rows(const mmt_params& p);
@@ -84,9 +96,12 @@ private:
 
     // columns
     DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_;
-    DevBuf<uint32_t> d_hist_, d_sa_, d_rank_, d_lcp_, d_headval_, d_head_, d_idx_, d_count_;
-    DevBuf<uint32_t> d_pos_a_, d_pos_b_, d_sac_a_, d_sac_b_, d_headc_;
-    DevBuf<uint64_t> d_keys_a_, d_keys_b_;
+    DevBuf<uint32_t> d_hist_, d_sa_, d_rank_, d_lcp_, d_count_;
+    DoublingSorter sorter_;
+    int sort_rounds_ = 0;
+    PfpState pfp_;
+    int producer_ = 0, producer_used_ = 1;
+    uint32_t pfp_w_ = 10, pfp_p_ = 100;
     // scan
     DevBuf<k::Cand> d_cand_, d_rows_;
     DevBuf<uint16_t> d_thresh_;

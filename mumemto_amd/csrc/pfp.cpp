@@ -1,0 +1,174 @@
+// pfp.cpp -- Engine methods of the PFP producer: parse (A2), dictionary / parse
+// structures (A3) and the suffix array of the text from them (A4).
+#include <algorithm>
+#include <chrono>
+#include <stdexcept>
+
+#include "engine.hpp"
+#include "pfp_kernels.hpp"
+#include "prims.hpp"
+
+namespace mmt {
+
+static int bit_width_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+static uint32_t read_u32(const uint32_t* d, hipStream_t s) {
+    uint32_t v = 0;
+    MMT_HIP(hipMemcpyAsync(&v, d, 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    return v;
+}
+
+// A2 + the dictionary half of A3: phrases, distinct phrases, dictionary text with its suffix
+// array / LCP, phrase ranks, parse.  Requires build_text() to have run.
+void Engine::pfp_parse(uint32_t w, uint32_t p) {
+    PfpState& S = pfp_;
+    const uint32_t n = (uint32_t)n_;
+    if (w < 1 || w > 32 || p < 1) throw std::runtime_error("PFP window must be in [1, 32] and the modulus positive");
+    std::vector<uint32_t> hist;
+    d2h(hist, d_hist_.get(), 256, stream_);
+    if (hist[0] || hist[1] || hist[2])          // newscan.hpp:318: characters <= Dollar are not allowed
+        throw std::runtime_error("input contains bytes <= 0x02, which the prefix-free parse reserves");
+    S.w = w; S.p = p; S.have_parse = false;
+    hipStream_t st = stream_;
+    EventPair e0, e1, e2, e3, e4;
+
+    // -- triggers, phrase boundaries
+    e0.start(st);
+    const uint32_t vlen = n + 1 + w;
+    S.vtext.ensure((size_t)vlen + 64);
+    pk::make_vtext(d_text_.get(), n, w, S.vtext.get(), vlen + 64, st);
+    S.flags.ensure(n);
+    pk::trigger_flags(d_text_.get(), n, w, p, S.flags.get(), st);
+    S.cuts.ensure(n); S.err.ensure(4);
+    prims::select_indices(d_temp_, S.flags.get(), S.cuts.get(), S.err.get(), n, st);
+    S.n_cuts = read_u32(S.err.get(), st);
+    const uint32_t m = S.n_phrases = S.n_cuts + 1;
+    S.pstart.ensure(m); S.plen.ensure(m);
+    pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), st);
+    e0.stop(st);
+
+    // -- distinct phrases: fingerprints, sort, verified grouping
+    e1.start(st);
+    S.h1.ensure(m); S.h2.ensure(m); S.hk_a.ensure(m); S.hk_b.ensure(m);
+    S.iota.ensure(m); S.ord_a.ensure(m); S.order.ensure(m);
+    pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.h2.get(), st);
+    pk::iota(S.iota.get(), m, st);
+    prims::sort_pairs_u64_u32(d_temp_, S.h2.get(), S.hk_a.get(), S.iota.get(), S.ord_a.get(), m, 0, 64, st);
+    pk::gather_u64(S.h1.get(), S.ord_a.get(), m, S.hk_a.get(), st);
+    prims::sort_pairs_u64_u32(d_temp_, S.hk_a.get(), S.hk_b.get(), S.ord_a.get(), S.order.get(), m, 0, 64, st);
+    S.dflags.ensure(m); S.scan.ensure(m);
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
+    pk::mark_distinct(S.order.get(), S.h1.get(), S.h2.get(), S.pstart.get(), S.plen.get(), S.vtext.get(), m,
+                      S.dflags.get(), S.err.get(), st);
+    prims::inclusive_sum_u32(d_temp_, S.dflags.get(), S.scan.get(), m, st);
+    if (read_u32(S.err.get(), st))
+        throw std::runtime_error("phrase fingerprint collision (128-bit); refusing to merge different phrases");
+    const uint32_t D = S.n_distinct = read_u32(S.scan.get() + (m - 1), st);
+    S.pid.ensure(m); S.rep.ensure(D); S.dlen.ensure(D); S.dstart.ensure(D);
+    pk::assign_distinct(S.order.get(), S.scan.get(), S.dflags.get(), S.plen.get(), m, S.pid.get(), S.rep.get(),
+                        S.dlen.get(), st);
+    e1.stop(st);
+
+    // -- dictionary text (distinct phrases in fingerprint order; ranks come from its suffix array)
+    e2.start(st);
+    prims::exclusive_sum_u32(d_temp_, S.dlen.get(), S.dstart.get(), D, st);
+    const uint64_t dict_len64 = (uint64_t)read_u32(S.dstart.get() + (D - 1), st) + read_u32(S.dlen.get() + (D - 1), st) + 1;
+    if (dict_len64 >= 0xffffff00ull) throw std::runtime_error("PFP dictionary exceeds the 32-bit build");
+    const uint32_t nd = S.dict_len = (uint32_t)dict_len64;
+    S.dict.ensure((size_t)nd + 64); S.dsuf.ensure(nd);
+    MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
+    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
+                  S.dsuf.get(), nd, st);
+    e2.stop(st);
+
+    // -- suffix array of the dictionary (dictionary.hpp:133) ...
+    e3.start(st);
+    uint8_t code[256];
+    int sigma = 0;
+    for (int c = 0; c < 256; c++) code[c] = (hist[c] || c <= 2) ? (uint8_t)(++sigma) : 0;
+    const int bits = std::max(1, bit_width_u64((uint64_t)sigma));
+    const int chars = std::min(64 / bits, 64);
+    d_code_.ensure(256);
+    MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
+    S.sa_d.ensure(nd); S.rank_d.ensure(nd); S.lcp_d.ensure(nd + 1);
+    sorter_.reserve(std::max(nd, n + 1));
+    k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, sorter_.keys_in(), sorter_.vals_in(), st);
+    S.rounds_dict = sorter_.sort(nd, bits * chars, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st);
+    e3.stop(st);
+    // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
+    e4.start(st);
+    k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), st);
+    S.gflag.ensure(nd); S.pflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd); S.gpos.ensure(nd);
+    S.prank.ensure(D); S.parse.ensure(m);
+    pk::group_flags(S.sa_d.get(), S.lcp_d.get(), S.dsuf.get(), nd, w, S.gflag.get(), S.pflag.get(), st);
+    prims::inclusive_sum_u32(d_temp_, S.gflag.get(), S.gscan.get(), nd, st);
+    prims::inclusive_sum_u32(d_temp_, S.pflag.get(), S.pscan.get(), nd, st);
+    pk::scatter_groups(S.sa_d.get(), S.gscan.get(), S.pscan.get(), S.dsuf.get(), S.dstart.get(), D, nd, w,
+                       S.gpos.get(), S.prank.get(), st);
+    pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
+    S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
+    e4.stop(st);
+    S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms(); S.ms[3] = e3.ms(); S.ms[4] = e4.ms();
+    S.have_parse = true;
+}
+
+// A3 (parse half) + A4: suffix array of the text = positions sorted by
+// (group of the phrase suffix, rank of the following parse suffix).
+void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
+    PfpState& S = pfp_;
+    const uint32_t n = (uint32_t)n_;
+    auto t0 = std::chrono::steady_clock::now();
+    pfp_parse(w, p);
+    hipStream_t st = stream_;
+    const uint32_t m = S.n_phrases, D = S.n_distinct;
+    EventPair e5, e6;
+    e5.start(st);
+    S.sa_p.ensure(m); S.isa_p.ensure(m);
+    const int pbits = std::max(1, bit_width_u64((uint64_t)D));
+    const int pchars = std::max(1, 64 / pbits);
+    pk::pack_keys_u32(S.parse.get(), m, pbits, pchars, sorter_.keys_in(), sorter_.vals_in(), st);
+    S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
+    e5.stop(st);
+
+    e6.start(st);
+    const int shift = bit_width_u64((uint64_t)m + 1);
+    const int gbits = bit_width_u64((uint64_t)S.n_groups);
+    if (shift + gbits > 64) throw std::runtime_error("PFP key does not fit 64 bits");
+    S.sa_x.ensure((size_t)n + 1);
+    d_sa_.ensure(n); d_rank_.ensure(n);
+    pk::text_keys(S.pstart.get(), m, n, S.pid.get(), S.dstart.get(), S.gpos.get(), S.isa_p.get(), shift,
+                  sorter_.keys_in(), sorter_.vals_in(), st);
+    prims::sort_pairs_u64_u32(d_temp_, sorter_.keys_in(), sorter_.keys_b().get(), sorter_.vals_in(), S.sa_x.get(),
+                              (size_t)n + 1, 0, shift + gbits, st);
+    // entry 0 is the end sentinel (its phrase suffix is the Dollar padding, smaller than every text byte)
+    if (read_u32(S.sa_x.get(), st) != n) throw std::runtime_error("PFP order: the end sentinel is not first");
+    MMT_HIP(hipMemcpyAsync(d_sa_.get(), S.sa_x.get() + 1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    pk::invert_sa(d_sa_.get(), n, d_rank_.get(), st);
+    e6.stop(st);
+    S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
+    S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    sort_rounds_ = S.rounds_dict;
+}
+
+// PREFIX.dict bytes: phrases in lexicographic order, 0x01 after each, final 0x00 (newscan.hpp:386-397)
+void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
+    PfpState& S = pfp_;
+    if (!S.have_parse) throw std::runtime_error("no parse available");
+    const uint32_t D = S.n_distinct, nd = S.dict_len;
+    DevBuf<uint32_t> which, slen, sstart;
+    DevBuf<uint8_t> sorted;
+    which.ensure(D); slen.ensure(D); sstart.ensure(D); sorted.ensure(nd);
+    pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
+    prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
+    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
+                  stream_);
+    d2h(out, sorted.get(), nd, stream_);
+}
+
+void Engine::pfp_copy_parse(std::vector<uint32_t>& out) {
+    if (!pfp_.have_parse) throw std::runtime_error("no parse available");
+    d2h(out, pfp_.parse.get(), pfp_.n_phrases, stream_);
+}
+
+}  // namespace mmt

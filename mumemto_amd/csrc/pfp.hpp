@@ -1,0 +1,21 @@
+// pfp.hpp -- device state of the prefix-free-parsing producer (rows A2-A4).
+#pragma once
+#include <cstdint>
+
+#include "device_utils.hpp"
+
+namespace mmt {
+
+struct PfpState {
+    uint32_t w = 0, p = 0;
+    uint32_t n_cuts = 0, n_phrases = 0, n_distinct = 0, dict_len = 0, n_groups = 0;
+    bool have_parse = false;
+    int rounds_dict = 0, rounds_parse = 0;
+    float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, text keys + sort, total
+    DevBuf<uint8_t> vtext, flags, dict;
+    DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, dsuf;
+    DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, gpos, prank, parse, sa_p, isa_p, sa_x, err;
+    DevBuf<uint64_t> h1, h2, hk_a, hk_b;
+};
+
+}  // namespace mmt

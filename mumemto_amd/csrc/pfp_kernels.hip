@@ -1,0 +1,393 @@
+// pfp_kernels.hip -- prefix-free parsing on the GPU (rows A2-A4).
+//
+// A2  newscan.hpp: KR_window::addchar (:106-114), trigger test (:321),
+//     save_update_word (:265-307), finish_parse (:357-423).
+// A3  dictionary.hpp:103-157 (SA + LCP of the dictionary), parse.hpp:77-146
+//     (SA / ISA of the parse), pfp.hpp:171-244.
+// A4  pfp_lcp_mum.hpp:115-231: order of the text suffixes = (rank of the proper
+//     phrase suffix of length >= w, rank of the parse suffix that follows).
+//
+// All kernels address the virtual text V = Dollar . T . Dollar^w (V[i+1] = T[i]),
+// exactly the string the reference parser consumes (newscan.hpp:248, :359).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_utils.hpp"
+#include "pfp_kernels.hpp"
+
+namespace mmt { namespace pk {
+
+static inline unsigned grid_for(uint64_t items, unsigned per_block) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    return (unsigned)(g ? g : 1);
+}
+
+// V from T: V[0] = Dollar, V[1..n] = T, V[n+1..n+w] = Dollar, zero padding after.
+__global__ void k_make_vtext(const uint8_t* __restrict__ text, uint32_t n, uint32_t w, uint8_t* __restrict__ v,
+                             uint32_t vlen_padded) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= vlen_padded) return;
+    uint8_t c;
+    if (i == 0) c = 2;
+    else if (i <= n) c = text[i - 1];
+    else if (i <= (uint64_t)n + w) c = 2;
+    else c = 0;
+    v[i] = c;
+}
+void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_t vlen_padded, hipStream_t s) {
+    hipLaunchKernelGGL(k_make_vtext, dim3(grid_for(vlen_padded, 256)), dim3(256), 0, s, text, n, w, v, vlen_padded);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- A2: trigger positions ---------------------------------------------------------
+// hash_i = sum_{k<w} T[i-k] * 256^k mod prime (T[<0] = 0): the value KR_window holds after
+// addchar(T[i]) when its window starts zero-filled and is never reset (newscan.hpp:96-114).
+// A phrase ends at i iff hash_i % p == 0 and the accumulated word is longer than w
+// (newscan.hpp:266), which holds for every trigger with i >= w - 1.
+template <int PER>
+__global__ void k_trigger_flags(const uint8_t* __restrict__ text, uint32_t n, uint32_t w, uint32_t p, uint64_t prime,
+                                uint64_t pot, uint8_t* __restrict__ flags) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * PER;
+    if (i0 >= n) return;
+    uint64_t h = 0;
+    for (uint32_t k = 0; k < w; k++) {                 // window ending at i0
+        int64_t pos = (int64_t)i0 - (int64_t)w + 1 + k;
+        uint64_t c = pos >= 0 ? text[pos] : 0;
+        h = (h * 256 + c) % prime;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint64_t i = i0 + q;
+        if (i >= n) break;
+        flags[i] = (i + 1 >= w && h % p == 0) ? 1 : 0;
+        // roll to i + 1: drop T[i-w+1], add T[i+1]
+        const int64_t drop = (int64_t)i - (int64_t)w + 1;
+        const uint64_t out = drop >= 0 ? text[drop] : 0;
+        const uint64_t in = i + 1 < n ? text[i + 1] : 0;
+        h = (h + prime - (out * pot) % prime) % prime;
+        h = (h * 256 + in) % prime;
+    }
+}
+void trigger_flags(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint8_t* flags, hipStream_t s) {
+    const uint64_t prime = 1999999973ull;              // newscan.hpp:86
+    uint64_t pot = 1;
+    for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % prime;
+    constexpr int PER = 16;
+    hipLaunchKernelGGL(k_trigger_flags<PER>, dim3(grid_for(((uint64_t)n + PER - 1) / PER, 256)), dim3(256), 0, s, text,
+                       n, w, p, prime, pot, flags);
+    MMT_HIP(hipGetLastError());
+}
+
+// phrase k occupies V[a_k .. a_k + len_k - 1]; consecutive phrases overlap by w characters
+__global__ void k_phrase_bounds(const uint32_t* __restrict__ cuts, uint32_t n_cuts, uint32_t n, uint32_t w,
+                                uint32_t* __restrict__ start, uint32_t* __restrict__ len) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > n_cuts) return;
+    const uint32_t a = k == 0 ? 0u : cuts[k - 1] - w + 2;          // V index of T[cut - w + 1]
+    const uint32_t b = k < n_cuts ? cuts[k] + 1 : n + w;            // V index of the last character
+    start[k] = a;
+    len[k] = b - a + 1;
+}
+void phrase_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t n, uint32_t w, uint32_t* start, uint32_t* len,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_phrase_bounds, dim3(grid_for((uint64_t)n_cuts + 1, 256)), dim3(256), 0, s, cuts, n_cuts, n, w,
+                       start, len);
+    MMT_HIP(hipGetLastError());
+}
+
+// Two independent 64-bit polynomial fingerprints per phrase (the reference keys its std::map by
+// one 55-bit KR hash with probing, newscan.hpp:133-142, 269-282; fingerprints only group equal
+// phrases here and every merge is verified byte by byte in k_mark_distinct).
+#define MMT_B1 0x9E3779B97F4A7C15ull
+#define MMT_B2 0xC2B2AE3D27D4EB4Full
+__device__ __forceinline__ void hash_range(const uint8_t* __restrict__ v, uint64_t lo, uint64_t hi, uint64_t& h1,
+                                           uint64_t& h2, uint64_t& p1, uint64_t& p2) {
+    h1 = 0; h2 = 0; p1 = 1; p2 = 1;
+    for (uint64_t i = lo; i < hi; i++) {
+        const uint64_t c = (uint64_t)v[i] + 1;
+        h1 = h1 * MMT_B1 + c; h2 = h2 * MMT_B2 + c;
+        p1 *= MMT_B1; p2 *= MMT_B2;
+    }
+}
+__global__ void k_phrase_hash(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
+                              const uint32_t* __restrict__ len, uint32_t m, uint64_t* __restrict__ o1,
+                              uint64_t* __restrict__ o2) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool have = k < m;
+    const uint32_t a = have ? start[k] : 0, l = have ? len[k] : 0;
+    const bool is_long = l > 2048;
+    uint64_t h1 = 0, h2 = 0, p1, p2;
+    if (have && !is_long) hash_range(v, a, (uint64_t)a + l, h1, h2, p1, p2);
+    // long phrases (no trigger inside a low-complexity run): the whole wave hashes one phrase
+    uint64_t todo = __ballot(have && is_long);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint64_t A = __shfl(a, src, 64), L = __shfl(l, src, 64);
+        const uint64_t chunk = (L + 63) / 64;
+        const uint64_t lo = A + (uint64_t)lane * chunk < A + L ? A + (uint64_t)lane * chunk : A + L;
+        const uint64_t hi = lo + chunk < A + L ? lo + chunk : A + L;
+        uint64_t c1, c2, q1, q2;
+        hash_range(v, lo, hi, c1, c2, q1, q2);
+        uint64_t t1 = 0, t2 = 0;
+        for (int s = 0; s < 64; s++) {                 // left-to-right combine, identical on every lane
+            const uint64_t x1 = __shfl(c1, s, 64), x2 = __shfl(c2, s, 64);
+            const uint64_t y1 = __shfl(q1, s, 64), y2 = __shfl(q2, s, 64);
+            t1 = t1 * y1 + x1; t2 = t2 * y2 + x2;
+        }
+        if ((int)lane == src) { h1 = t1; h2 = t2; }
+    }
+    if (have) {
+        o1[k] = h1 ^ ((uint64_t)l * 0xD6E8FEB86659FD93ull);
+        o2[k] = h2 + ((uint64_t)l << 32);
+    }
+}
+void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, uint64_t* h2,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(k_phrase_hash, dim3(grid_for(m, 256)), dim3(256), 0, s, v, start, len, m, h1, h2);
+    MMT_HIP(hipGetLastError());
+}
+
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+
+// order[] lists the phrases sorted by (h1, h2); flags[k] = 1 where a new distinct phrase starts.
+// Equal fingerprints + equal length are confirmed by comparing the bytes; a mismatch there
+// (a 128-bit collision) raises *err instead of silently merging two different phrases.
+__global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64_t* __restrict__ h1,
+                                const uint64_t* __restrict__ h2, const uint32_t* __restrict__ start,
+                                const uint32_t* __restrict__ len, const uint8_t* __restrict__ v, uint32_t m,
+                                uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    if (k == 0) { flags[0] = 1; return; }
+    const uint32_t x = order[k], y = order[k - 1];
+    bool same = h1[x] == h1[y] && h2[x] == h2[y] && len[x] == len[y];
+    if (same) {
+        const uint8_t* px = v + start[x]; const uint8_t* py = v + start[y];
+        const uint32_t l = len[x];
+        uint32_t i = 0;
+        for (; i + 8 <= l; i += 8) if (ld64(px + i) != ld64(py + i)) { same = false; break; }
+        if (same) for (; i < l; i++) if (px[i] != py[i]) { same = false; break; }
+        if (!same) atomicAdd(err, 1u);
+    }
+    flags[k] = same ? 0u : 1u;
+}
+void mark_distinct(const uint32_t* order, const uint64_t* h1, const uint64_t* h2, const uint32_t* start,
+                   const uint32_t* len, const uint8_t* v, uint32_t m, uint32_t* flags, uint32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, order, h1, h2, start, len, v, m, flags,
+                       err);
+    MMT_HIP(hipGetLastError());
+}
+
+// scan[k] = inclusive sum of flags: distinct id of order[k] is scan[k] - 1
+__global__ void k_assign_distinct(const uint32_t* __restrict__ order, const uint32_t* __restrict__ scan,
+                                  const uint32_t* __restrict__ flags, const uint32_t* __restrict__ len, uint32_t m,
+                                  uint32_t* __restrict__ pid, uint32_t* __restrict__ rep, uint32_t* __restrict__ dlen) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t d = scan[k] - 1;
+    pid[order[k]] = d;
+    if (flags[k]) { rep[d] = order[k]; dlen[d] = len[order[k]] + 1; }   // + EndOfWord
+}
+void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
+                     uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s) {
+    hipLaunchKernelGGL(k_assign_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, order, scan, flags, len, m, pid, rep,
+                       dlen);
+    MMT_HIP(hipGetLastError());
+}
+
+// dictionary text: phrase bytes, EndOfWord (1) after every phrase, EndOfDict (0) at the very end
+// (dictionary file layout of newscan.hpp:386-397).  dsuf[pos] = length of the phrase suffix that
+// starts at pos (0 on separators), bit 31 set on the first byte of a phrase.  One wave per phrase.
+__global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
+                            const uint32_t* __restrict__ len, const uint32_t* __restrict__ which,
+                            const uint32_t* __restrict__ dstart, uint32_t n_phr, uint8_t* __restrict__ dict,
+                            uint32_t* __restrict__ dsuf, uint32_t dict_len) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (wave >= n_phr) return;
+    const uint32_t ph = which[wave], a = start[ph], l = len[ph], o = dstart[wave];
+    for (uint32_t i = lane; i < l; i += 64) {
+        dict[o + i] = v[a + i];
+        if (dsuf) dsuf[o + i] = (l - i) | (i == 0 ? 0x80000000u : 0u);
+    }
+    if (lane == 0) {
+        dict[o + l] = 1;
+        if (dsuf) dsuf[o + l] = 0;
+        if (wave + 1 == n_phr) { dict[dict_len - 1] = 0; if (dsuf) dsuf[dict_len - 1] = 0; }
+    }
+}
+void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
+               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t dict_len, hipStream_t s) {
+    hipLaunchKernelGGL(k_copy_dict, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v, start, len, which,
+                       dstart, n_phr, dict, dsuf, dict_len);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- A3/A4: groups of equal proper phrase suffixes, in dictionary suffix-array order -----------
+// Valid = proper suffix (not the whole phrase) of length >= w (pfp_lcp_mum.hpp:272-282).  Two
+// neighbours of the dictionary SA spell the same string iff they have the same length and their LCP
+// reaches it (:141-154 collects them as `same_suffix`).
+__global__ void k_group_flags(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ lcp_d,
+                              const uint32_t* __restrict__ dsuf, uint32_t nd, uint32_t w,
+                              uint32_t* __restrict__ gflag, uint32_t* __restrict__ pflag) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t e = dsuf[sa_d[r]];
+    const uint32_t sl = e & 0x7fffffffu;
+    const bool is_start = e >> 31;
+    const bool valid = !is_start && sl >= w;
+    bool fresh = valid;
+    if (valid && r > 0) {
+        const uint32_t pe = dsuf[sa_d[r - 1]];
+        const bool pvalid = !(pe >> 31) && (pe & 0x7fffffffu) >= w;
+        if (pvalid && (pe & 0x7fffffffu) == sl && lcp_d[r] >= sl) fresh = false;
+    }
+    gflag[r] = fresh ? 1u : 0u;
+    pflag[r] = is_start ? 1u : 0u;
+}
+void group_flags(const uint32_t* sa_d, const uint32_t* lcp_d, const uint32_t* dsuf, uint32_t nd, uint32_t w,
+                 uint32_t* gflag, uint32_t* pflag, hipStream_t s) {
+    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, lcp_d, dsuf, nd, w, gflag, pflag);
+    MMT_HIP(hipGetLastError());
+}
+
+// gpos[dict position] = group id (1-based, 0 = not a valid suffix); prank[distinct phrase] = 1-based
+// lexicographic rank of the phrase (position of its first byte among the phrase starts of the SA).
+__global__ void k_scatter_groups(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ gscan,
+                                 const uint32_t* __restrict__ pscan, const uint32_t* __restrict__ dsuf,
+                                 const uint32_t* __restrict__ dstart, uint32_t n_distinct, uint32_t nd, uint32_t w,
+                                 uint32_t* __restrict__ gpos, uint32_t* __restrict__ prank) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t pos = sa_d[r];
+    const uint32_t e = dsuf[pos];
+    const bool is_start = e >> 31;
+    const bool valid = !is_start && (e & 0x7fffffffu) >= w;
+    gpos[pos] = valid ? gscan[r] : 0u;
+    if (is_start) {                                     // which phrase starts here?
+        uint32_t lo = 0, hi = n_distinct - 1;
+        while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (dstart[mid] <= pos) lo = mid; else hi = mid - 1; }
+        prank[lo] = pscan[r];
+    }
+}
+void scatter_groups(const uint32_t* sa_d, const uint32_t* gscan, const uint32_t* pscan, const uint32_t* dsuf,
+                    const uint32_t* dstart, uint32_t n_distinct, uint32_t nd, uint32_t w, uint32_t* gpos,
+                    uint32_t* prank, hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_groups, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, gscan, pscan, dsuf, dstart,
+                       n_distinct, nd, w, gpos, prank);
+    MMT_HIP(hipGetLastError());
+}
+
+// parse[q] = 1-based rank of the q-th phrase (the reference's .parse, newscan.hpp:399-404);
+// byrank[rank-1] = distinct id (for writing the sorted dictionary)
+__global__ void k_parse_ranks(const uint32_t* __restrict__ pid, const uint32_t* __restrict__ prank, uint32_t m,
+                              uint32_t* __restrict__ parse) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < m) parse[q] = prank[pid[q]];
+}
+void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s) {
+    hipLaunchKernelGGL(k_parse_ranks, dim3(grid_for(m, 256)), dim3(256), 0, s, pid, prank, m, parse);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_invert_ranks(const uint32_t* __restrict__ prank, const uint32_t* __restrict__ rep,
+                               const uint32_t* __restrict__ dlen, uint32_t n_distinct, uint32_t* __restrict__ which,
+                               uint32_t* __restrict__ slen) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    which[prank[d] - 1] = rep[d];
+    slen[prank[d] - 1] = dlen[d];
+}
+void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
+                  uint32_t* which, uint32_t* slen, hipStream_t s) {
+    hipLaunchKernelGGL(k_invert_ranks, dim3(grid_for(n_distinct, 256)), dim3(256), 0, s, prank, rep, dlen, n_distinct,
+                       which, slen);
+    MMT_HIP(hipGetLastError());
+}
+
+// keys for the parse suffix sort: `chars` consecutive ranks of `bits` bits each (0 past the end)
+__global__ void k_pack_keys_u32(const uint32_t* __restrict__ parse, uint32_t m, int bits, int chars,
+                                uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    uint64_t key = 0;
+    for (int c = 0; c < chars; c++) {
+        const uint64_t x = (uint64_t)q + c < m ? parse[q + c] : 0;
+        key = (key << bits) | x;
+    }
+    keys[q] = key;
+    vals[q] = q;
+}
+void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint64_t* keys, uint32_t* vals,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_keys_u32, dim3(grid_for(m, 256)), dim3(256), 0, s, parse, m, bits, chars, keys, vals);
+    MMT_HIP(hipGetLastError());
+}
+
+// One key per text position i in [0, n] (i = n is the end sentinel): (group of its phrase suffix,
+// rank of the parse suffix that follows) -- the two-level order of pfp_lcp_mum.hpp:123-212.
+template <int PER>
+__global__ void k_text_keys(const uint32_t* __restrict__ pstart, uint32_t m, uint32_t n,
+                            const uint32_t* __restrict__ pid, const uint32_t* __restrict__ dstart,
+                            const uint32_t* __restrict__ gpos, const uint32_t* __restrict__ isa_p, int shift,
+                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * PER;
+    if (i0 > n) return;
+    // phrase of V position v = i + 1: the last phrase with start < v
+    uint32_t lo = 0, hi = m - 1;
+    const uint32_t v0 = (uint32_t)i0 + 1;
+    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (pstart[mid] < v0) lo = mid; else hi = mid - 1; }
+    uint32_t q = lo;
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+        const uint64_t i = i0 + t;
+        if (i > n) break;
+        const uint32_t v = (uint32_t)i + 1;
+        while (q + 1 < m && pstart[q + 1] < v) q++;
+        const uint32_t off = v - pstart[q];
+        const uint64_t g = gpos[dstart[pid[q]] + off];
+        const uint64_t nxt = q + 1 < m ? (uint64_t)isa_p[q + 1] + 1 : 0;
+        keys[i] = (g << shift) | nxt;
+        vals[i] = (uint32_t)i;
+    }
+}
+void text_keys(const uint32_t* pstart, uint32_t m, uint32_t n, const uint32_t* pid, const uint32_t* dstart,
+               const uint32_t* gpos, const uint32_t* isa_p, int shift, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+    constexpr int PER = 16;
+    hipLaunchKernelGGL(k_text_keys<PER>, dim3(grid_for(((uint64_t)n + 1 + PER - 1) / PER, 256)), dim3(256), 0, s, pstart,
+                       m, n, pid, dstart, gpos, isa_p, shift, keys, vals);
+    MMT_HIP(hipGetLastError());
+}
+
+// rank[sa[j]] = j
+__global__ void k_invert_sa(const uint32_t* __restrict__ sa, uint32_t n, uint32_t* __restrict__ rank) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) rank[sa[j]] = j;
+}
+void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s) {
+    hipLaunchKernelGGL(k_invert_sa, dim3(grid_for(n, 256)), dim3(256), 0, s, sa, n, rank);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_iota(uint32_t* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+void iota(uint32_t* out, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, s, out, n);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_gather_u64(const uint64_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n,
+                             uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_u64, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, n, out);
+    MMT_HIP(hipGetLastError());
+}
+
+}}  // namespace mmt::pk

@@ -1,0 +1,37 @@
+// pfp_kernels.hpp -- launch wrappers of pfp_kernels.hip (rows A2-A4).
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime_api.h>
+
+namespace mmt { namespace pk {
+
+void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_t vlen_padded, hipStream_t s);
+void trigger_flags(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint8_t* flags, hipStream_t s);
+void phrase_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t n, uint32_t w, uint32_t* start, uint32_t* len,
+                   hipStream_t s);
+void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, uint64_t* h2,
+                 hipStream_t s);
+void mark_distinct(const uint32_t* order, const uint64_t* h1, const uint64_t* h2, const uint32_t* start,
+                   const uint32_t* len, const uint8_t* v, uint32_t m, uint32_t* flags, uint32_t* err, hipStream_t s);
+void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
+                     uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
+void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
+               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t dict_len, hipStream_t s);
+void group_flags(const uint32_t* sa_d, const uint32_t* lcp_d, const uint32_t* dsuf, uint32_t nd, uint32_t w,
+                 uint32_t* gflag, uint32_t* pflag, hipStream_t s);
+void scatter_groups(const uint32_t* sa_d, const uint32_t* gscan, const uint32_t* pscan, const uint32_t* dsuf,
+                    const uint32_t* dstart, uint32_t n_distinct, uint32_t nd, uint32_t w, uint32_t* gpos,
+                    uint32_t* prank, hipStream_t s);
+void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s);
+void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
+                  uint32_t* which, uint32_t* slen, hipStream_t s);
+void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint64_t* keys, uint32_t* vals,
+                   hipStream_t s);
+void text_keys(const uint32_t* pstart, uint32_t m, uint32_t n, const uint32_t* pid, const uint32_t* dstart,
+               const uint32_t* gpos, const uint32_t* isa_p, int shift, uint64_t* keys, uint32_t* vals, hipStream_t s);
+void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
+void iota(uint32_t* out, uint32_t n, hipStream_t s);
+void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);
+
+}}  // namespace mmt::pk

@@ -44,6 +44,11 @@ void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out,
         return rocprim::exclusive_scan(t, b, in, out, uint32_t(0), n, rocprim::plus<uint32_t>(), s);
     });
 }
+void inclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
+    with_temp(temp, [&](void* t, size_t& b) {
+        return rocprim::inclusive_scan(t, b, in, out, n, rocprim::plus<uint32_t>(), s);
+    });
+}
 void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out, size_t n, hipStream_t s) {
     with_temp(temp, [&](void* t, size_t& b) {
         return rocprim::exclusive_scan(t, b, in, out, uint64_t(0), n, rocprim::plus<uint64_t>(), s);

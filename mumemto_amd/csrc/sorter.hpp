@@ -1,0 +1,35 @@
+// sorter.hpp -- suffix sorting by prefix doubling (Manber-Myers / Larsson-Sadakane
+// scheme) on top of a device radix sort.  Used for the whole text (A8, replaces
+// gsacak(text), include/direct_gsacak.hpp:62), for the PFP dictionary (replaces
+// gsacak(d), include/dictionary.hpp:133) and for the parse (replaces sacak_int,
+// include/parse.hpp:85).
+#pragma once
+#include <cstdint>
+
+#include "device_utils.hpp"
+
+namespace mmt {
+
+class DoublingSorter {
+public:
+    // The caller fills keys_in() / vals_in() for n suffixes: keys = first h0 symbols of every
+    // suffix packed big-endian into `key_bits` bits (past-the-end = 0 = smallest), vals = 0..n-1.
+    void reserve(uint32_t n);
+    uint64_t* keys_in() { return keys_a_.get(); }
+    uint32_t* vals_in() { return sac_a_.get(); }
+    // Sorts; sa_out[j] = j-th smallest suffix, rank_out = its inverse.  Returns #doubling rounds.
+    int sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa_out, uint32_t* rank_out, DevBuf<uint8_t>& temp,
+             hipStream_t s);
+    // scratch columns, reusable by the caller between sorts (each holds >= n entries)
+    DevBuf<uint64_t>& keys_a() { return keys_a_; }
+    DevBuf<uint64_t>& keys_b() { return keys_b_; }
+    DevBuf<uint32_t>& u32_a() { return sac_a_; }
+    DevBuf<uint32_t>& u32_b() { return sac_b_; }
+
+private:
+    DevBuf<uint64_t> keys_a_, keys_b_;
+    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, headval_, head_, idx_, count_;
+    DevBuf<uint8_t> flags_;
+};
+
+}  // namespace mmt

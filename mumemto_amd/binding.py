@@ -68,10 +68,14 @@ def load_library():
     if not os.path.exists(_LIB):
         raise MumemtoError("libmumemto.so is not built (%s): run `python -m mumemto_amd.build`; "
                            "mumemto_amd has no CPU fallback" % _LIB)
-    if "torch" in sys.modules or os.environ.get("MUMEMTO_IMPORT_TORCH_FIRST"):
-        # torch ships its own libamdhip64 under the same soname: it must be the one already
-        # loaded when both live in one process, so that device pointers are shared.
-        import torch  # noqa: F401
+    if not os.environ.get("MUMEMTO_NO_TORCH"):
+        # PyTorch-ROCm ships its own libamdhip64 under the same soname.  If torch is (or will be)
+        # in this process it must be loaded first, so that both share ONE HIP runtime and device
+        # pointers / streams can be exchanged; loading ours first leaves torch without devices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(_LIB)
     L.mumemto_last_error.restype = C.c_char_p
     L.mmt_last_error.restype = C.c_char_p

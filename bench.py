@@ -101,7 +101,7 @@ def main():
         eng.run(min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, use_revcomp=True,
                 merge_metadata=merge_mode)
         if not merge_mode:
-            return eng.output_text()
+            return eng.output_size()      # the .mums bytes are in (page-locked) host memory at this point
         length, off, st = eng.rows_mum()
         th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
         parts = mdist.all_gather_partitions((length, off, st, th), dist, device)
@@ -133,6 +133,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if not merge_mode:
+        out = eng.output_text()
 
     total_bp = a.length * n_total_haps          # every distinct input base once
     n_text = eng.text_length()
@@ -167,6 +169,11 @@ def main():
             ["text", "suffix_sort", "lcp_bwt", "scan_kernel", "verify", "rows_gather_d2h", "host_rows_format",
              "engine_total"], stage_acc)},
     }
+    result["config"]["stream_producer"] = eng.producer_used()
+    if eng.producer_used() == "pfp":
+        result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(
+            ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_lcp_groups",
+             "parse_sa", "text_keys_sort", "total_host_clock"], [round(x, 3) for x in eng.pfp_stage_ms()]))}
     if rank == 0:
         if world == 1 and a.cpu_sample_bp > 0:
             cb, cpu_out, sample = cpu_baseline(docs, min(a.cpu_sample_bp, a.length))

@@ -289,6 +289,12 @@ class Engine:
         ptr = self.L.mmt_output_text(self.h, C.byref(n))
         return C.string_at(ptr, n.value) if n.value else b""
 
+    def output_size(self):
+        """Bytes of the last run's .mums / .mems output (already in host memory; no copy)."""
+        n = C.c_size_t()
+        self.L.mmt_output_text(self.h, C.byref(n))
+        return n.value
+
     def output_bumbl(self):
         n = C.c_size_t()
         ptr = self.L.mmt_output_bumbl(self.h, C.byref(n))

@@ -112,7 +112,9 @@ int mumemto_mum(const mumemto_doc_view* docs, size_t n_docs, uint32_t min_match_
             p.use_revcomp = use_revcomp ? 1 : 0; p.merge_metadata = 0;
             e.run(p);
             const mmt::HostRows& R = e.rows();
-            r->length = R.length; r->offsets = R.mum_offsets; r->strands = R.mum_strands;
+            r->length.assign(R.length, R.length + R.n_rows);
+            r->offsets.assign(R.mum_offsets, R.mum_offsets + R.n_rows * n_docs);
+            r->strands.assign(R.mum_strands, R.mum_strands + R.n_rows * n_docs);
         }
         *out_result = r.release();
         return 0;
@@ -147,8 +149,11 @@ int mumemto_mem(const mumemto_doc_view* docs, size_t n_docs, uint32_t min_match_
             p.use_revcomp = use_revcomp ? 1 : 0; p.merge_metadata = 0;
             e.run(p);
             const mmt::HostRows& R = e.rows();
-            r->length = R.length; r->occ_start = R.occ_start; r->offsets = R.mem_offsets;
-            r->seq_ids.assign(R.mem_docs.begin(), R.mem_docs.end()); r->strands = R.mem_strands;
+            r->length.assign(R.length, R.length + R.n_rows);
+            r->occ_start.assign(R.occ_start, R.occ_start + R.n_rows + 1);
+            r->offsets.assign(R.mem_offsets, R.mem_offsets + R.n_occ);
+            r->seq_ids.assign(R.mem_docs, R.mem_docs + R.n_occ);
+            r->strands.assign(R.mem_strands, R.mem_strands + R.n_occ);
         }
         if (r->occ_start.empty()) r->occ_start.push_back(0);
         *out_result = r.release();
@@ -229,40 +234,40 @@ int mmt_engine_run(mmt_engine* e, const mmt_params* p) {
     MMT_CATCH
 }
 
-size_t mmt_num_rows(const mmt_engine* e) { return e ? e->e->rows().n_rows() : 0; }
+size_t mmt_num_rows(const mmt_engine* e) { return e ? e->e->rows().n_rows : 0; }
 size_t mmt_num_docs(const mmt_engine* e) { return e ? e->e->n_docs() : 0; }
 int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands) {
     if (!e) return fail(1, "engine must be non-null");
     const mmt::HostRows& R = e->e->rows();
     if (!R.mum_mode) return fail(3, "last run was not in MUM mode");
-    if (R.n_rows()) {
-        std::memcpy(length, R.length.data(), R.length.size() * 4);
-        std::memcpy(offsets, R.mum_offsets.data(), R.mum_offsets.size() * 8);
-        std::memcpy(strands, R.mum_strands.data(), R.mum_strands.size());
+    if (R.n_rows) {
+        std::memcpy(length, R.length, R.n_rows * 4);
+        std::memcpy(offsets, R.mum_offsets, R.n_rows * R.n_docs * 8);
+        std::memcpy(strands, R.mum_strands, R.n_rows * R.n_docs);
     }
     return 0;
 }
-size_t mmt_num_occ(const mmt_engine* e) { return e ? e->e->rows().mem_offsets.size() : 0; }
+size_t mmt_num_occ(const mmt_engine* e) { return e ? e->e->rows().n_occ : 0; }
 int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start, int64_t* offsets, uint64_t* seq_ids,
                  uint8_t* strands) {
     if (!e) return fail(1, "engine must be non-null");
     const mmt::HostRows& R = e->e->rows();
     if (R.mum_mode) return fail(3, "last run was in MUM mode");
     occ_start[0] = 0;
-    if (R.n_rows()) {
-        std::memcpy(length, R.length.data(), R.length.size() * 4);
-        std::memcpy(occ_start, R.occ_start.data(), R.occ_start.size() * 8);
-        std::memcpy(offsets, R.mem_offsets.data(), R.mem_offsets.size() * 8);
-        std::memcpy(seq_ids, R.mem_docs.data(), R.mem_docs.size() * 8);
-        std::memcpy(strands, R.mem_strands.data(), R.mem_strands.size());
+    if (R.n_rows) {
+        std::memcpy(length, R.length, R.n_rows * 4);
+        std::memcpy(occ_start, R.occ_start, (R.n_rows + 1) * 8);
+        std::memcpy(offsets, R.mem_offsets, R.n_occ * 8);
+        std::memcpy(seq_ids, R.mem_docs, R.n_occ * 8);
+        std::memcpy(strands, R.mem_strands, R.n_occ);
     }
     return 0;
 }
 const char* mmt_output_text(mmt_engine* e, size_t* len) {
     if (!e) { if (len) *len = 0; return nullptr; }
-    const std::string& t = e->e->rows().text;
-    if (len) *len = t.size();
-    return t.data();
+    const mmt::HostRows& R = e->e->rows();
+    if (len) *len = R.text_len;
+    return R.text;
 }
 const uint8_t* mmt_output_bumbl(mmt_engine* e, size_t* len) {
     if (!e) { if (len) *len = 0; return nullptr; }

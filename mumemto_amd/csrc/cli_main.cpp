@@ -96,9 +96,9 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n",
                      mum_mode ? "MUM" : "MEM", secs_since(t0));
 
-        if (!mum_mode) write_file(o.output_prefix + ".mems", R.text.data(), R.text.size());
+        if (!mum_mode) write_file(o.output_prefix + ".mems", R.text, R.text_len);
         else if (o.binary) { const std::string& b = eng.bumbl(); write_file(o.output_prefix + ".bumbl", b.data(), b.size()); }
-        else write_file(o.output_prefix + ".mums", R.text.data(), R.text.size());
+        else write_file(o.output_prefix + ".mums", R.text, R.text_len);
 
         if (o.anchor_merge) {                       // mem_finder.hpp:110-115
             std::vector<uint16_t> th(eng.thresh_len());
@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
             write_file(o.output_prefix + ".lcp", flcp.data(), flcp.size());
             write_file(o.output_prefix + ".bwt", fbwt.data(), fbwt.size());
         }
-        log_line("build_main", "Found " + std::to_string(R.n_rows()) + " matches!");
+        log_line("build_main", "Found " + std::to_string(R.n_rows) + " matches!");
         const float* ms = eng.stage_ms();
         std::fprintf(stderr, "GPU stages (ms): text %.2f | suffix sort %.2f | lcp+bwt %.2f | scan %.2f | verify %.2f | rows %.2f | format %.2f\n\n",
                      ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]);

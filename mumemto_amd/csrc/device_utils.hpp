@@ -52,6 +52,28 @@ private:
     size_t cap_ = 0, n_ = 0;
 };
 
+// Page-locked host memory that only grows: D2H targets of the result rows / output bytes.
+template <typename T>
+class PinnedBuf {
+public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p_) (void)hipHostFree(p_); }
+    void ensure(size_t n) {
+        if (n <= cap_) return;
+        if (p_) { (void)hipHostFree(p_); p_ = nullptr; }
+        size_t want = n + n / 8 + 64;
+        MMT_HIP(hipHostMalloc(reinterpret_cast<void**>(&p_), want * sizeof(T), hipHostMallocDefault));
+        cap_ = want;
+    }
+    T* get() const { return p_; }
+
+private:
+    T* p_ = nullptr;
+    size_t cap_ = 0;
+};
+
 class EventPair {
 public:
     EventPair() { MMT_HIP(hipEventCreate(&a_)); MMT_HIP(hipEventCreate(&b_)); }

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "prims.hpp"
+#include "rows_kernels.hpp"
 
 namespace mmt {
 
@@ -165,116 +166,107 @@ void append_uint(std::string& s, uint64_t v) {
 }
 
 void Engine::make_rows(const mmt_params& p) {
+    // Rows stay on the device: sort into pop order, measure, place, write (rows_kernels.hip), then
+    // one D2H of the library arrays and of the .mums / .mems bytes into page-locked host memory.
     const size_t N = doc_len_.size();
-    ev_[5]->start(stream_);
-    uint32_t n_rows = 0;
-    MMT_HIP(hipMemcpyAsync(&n_rows, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, stream_));
-    MMT_HIP(hipStreamSynchronize(stream_));
-    d2h(h_rows_, d_rows_.get(), n_rows, stream_);
-    // pop order of the reference's stack: closing position ascending, longer first
-    std::sort(h_rows_.begin(), h_rows_.end(), [](const k::Cand& x, const k::Cand& y) {
-        return x.end != y.end ? x.end < y.end : x.len > y.len;
-    });
-    h_off_.assign((size_t)n_rows + 1, 0);
-    for (uint32_t r = 0; r < n_rows; r++) h_off_[r + 1] = h_off_[r] + (h_rows_[r].end - h_rows_[r].start + 1);
-    const uint64_t total = h_off_[n_rows];
-    if (n_rows) {
-        d_off_.ensure((size_t)n_rows + 1);
-        d_occ_.ensure(total);
-        MMT_HIP(hipMemcpyAsync(d_rows_.get(), h_rows_.data(), (size_t)n_rows * sizeof(k::Cand), hipMemcpyHostToDevice,
-                               stream_));
-        MMT_HIP(hipMemcpyAsync(d_off_.get(), h_off_.data(), ((size_t)n_rows + 1) * 8, hipMemcpyHostToDevice, stream_));
-        k::gather_occurrences(d_rows_.get(), d_off_.get(), n_rows, d_sa_.get(), d_occ_.get(), stream_);
-    }
-    d2h(h_occ_, d_occ_.get(), total, stream_);
-    ev_[5]->stop(stream_);
-
-    auto t0 = std::chrono::steady_clock::now();
+    hipStream_t st = stream_;
+    ev_[5]->start(st);
     HostRows& R = rows_;
     R = HostRows();
     R.mum_mode = p.max_doc_freq == 1;                 // mem_finder.hpp:85
     R.n_docs = N;
-    std::vector<uint64_t> half(N);
-    for (size_t d = 0; d < N; d++) half[d] = doc_len_[d] + 1;
-    auto doc_of = [&](uint64_t sa) {
-        return (size_t)(std::upper_bound(doc_start_.begin(), doc_start_.end(), sa) - doc_start_.begin()) - 1;
-    };
-    std::string& T = R.text;
-    T.reserve((size_t)n_rows * (R.mum_mode ? 12 * N + 16 : 64));
-    if (R.mum_mode) {
-        std::vector<int64_t> off(N);
-        std::vector<uint8_t> st(N);   // 0 absent, '+', '-'
-        for (uint32_t r = 0; r < n_rows; r++) {
-            const uint64_t len = h_rows_[r].len;
-            std::fill(off.begin(), off.end(), -1);
-            std::fill(st.begin(), st.end(), 0);
-            bool keep = true;
-            for (uint64_t o = h_off_[r]; o < h_off_[r + 1]; o++) {        // write_mum, mem_finder.hpp:365-380
-                const uint64_t sa = h_occ_[o];
-                const size_t d = doc_of(sa);
-                uint64_t pos = sa - doc_start_[d];
-                uint8_t strand = '+';
-                if (revcomp_ && pos >= half[d]) {
-                    strand = '-';
-                    if (pos + len >= 2 * half[d]) { keep = false; break; }
-                    pos = 2 * half[d] - pos - len - 1;
-                }
-                off[d] = (int64_t)pos; st[d] = strand;
-            }
-            if (!keep) continue;
-            size_t i = 0;                                                  // :382-391
-            while (i + 1 < N && st[i] == 0) i++;
-            if (st[i] == '-') continue;
-            R.length.push_back((uint32_t)len);
-            for (size_t d = 0; d < N; d++) {
-                R.mum_offsets.push_back(off[d]);
-                R.mum_strands.push_back(st[d] == '+' ? 1 : 0);
-            }
-            append_uint(T, len); T.push_back('\t');                        // :406-426
-            for (size_t d = 0; d + 1 < N; d++) { if (off[d] >= 0) append_uint(T, (uint64_t)off[d]); T.push_back(','); }
-            if (off[N - 1] >= 0) append_uint(T, (uint64_t)off[N - 1]);
-            T.push_back('\t');
-            for (size_t d = 0; d + 1 < N; d++) { if (off[d] >= 0) T.push_back((char)st[d]); T.push_back(','); }
-            if (off[N - 1] >= 0) T.push_back((char)st[N - 1]);
-            T.push_back('\n');
-        }
-    } else {
-        R.occ_start.push_back(0);
-        std::string docs_s, strand_s;
-        for (uint32_t r = 0; r < n_rows; r++) {                            // write_mem, :210-263
-            const uint64_t len = h_rows_[r].len;
-            R.length.push_back((uint32_t)len);
-            append_uint(T, len); T.push_back('\t');
-            docs_s.clear(); strand_s.clear();
-            for (uint64_t o = h_off_[r]; o < h_off_[r + 1]; o++) {
-                const bool last = o + 1 == h_off_[r + 1];
-                const uint64_t sa = h_occ_[o];
-                const size_t d = doc_of(sa);
-                uint64_t pos = sa - doc_start_[d];
-                bool minus = false;
-                if (revcomp_ && pos >= half[d]) {
-                    minus = true;
-                    pos = 2 * half[d] - pos - len - (last ? 0 : 1);       // size_t arithmetic, may wrap (:229,:248)
-                }
-                R.mem_offsets.push_back((int64_t)pos);
-                R.mem_docs.push_back(d);
-                R.mem_strands.push_back(minus ? 0 : 1);
-                append_uint(T, pos); append_uint(docs_s, d); strand_s.push_back(minus ? '-' : '+');
-                if (!last) { T.push_back(','); docs_s.push_back(','); strand_s.push_back(','); }
-            }
-            R.occ_start.push_back(R.mem_offsets.size());
-            T.push_back('\t'); T += docs_s; T.push_back('\t'); T += strand_s; T.push_back('\n');
-        }
-    }
     bumbl_.clear();
-    stage_ms_[6] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const uint32_t n_rows = [&] {
+        uint32_t v = 0;
+        MMT_HIP(hipMemcpyAsync(&v, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        return v;
+    }();
+    h_occ_start_.ensure(2);
+    h_occ_start_.get()[0] = 0;
+    R.occ_start = h_occ_start_.get();
+    if (n_rows == 0) { ev_[5]->stop(st); return; }
+
+    // pop order of the reference's stack: closing position ascending, longer first
+    d_rkeys_a_.ensure(n_rows); d_rkeys_b_.ensure(n_rows); d_rvals_a_.ensure(n_rows); d_order_.ensure(n_rows);
+    rk::row_keys(d_rows_.get(), n_rows, d_rkeys_a_.get(), d_rvals_a_.get(), st);
+    prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_a_.get(), d_order_.get(), n_rows, 0,
+                              64, st);
+    d_doc_len_.ensure(N);
+    MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, st));
+    rk::RowArgs a;
+    a.rows = d_rows_.get(); a.order = d_order_.get(); a.n_rows = n_rows; a.sa = d_sa_.get();
+    a.doc_start = d_doc_start_.get(); a.doc_len = d_doc_len_.get(); a.n_docs = (uint32_t)N; a.revcomp = revcomp_ ? 1 : 0;
+    d_tlen_.ensure(n_rows); d_tlen64_.ensure(n_rows); d_toff_.ensure(n_rows);
+    auto last_u32 = [&](const uint32_t* d) {
+        uint32_t v = 0; MMT_HIP(hipMemcpyAsync(&v, d + (n_rows - 1), 4, hipMemcpyDeviceToHost, st)); return v; };
+    auto last_u64 = [&](const uint64_t* d) {
+        uint64_t v = 0; MMT_HIP(hipMemcpyAsync(&v, d + (n_rows - 1), 8, hipMemcpyDeviceToHost, st)); return v; };
+
+    if (R.mum_mode) {
+        const size_t slots = (size_t)n_rows * N;
+        d_slot_off_.ensure(slots); d_slot_st_.ensure(slots); d_keep_.ensure(n_rows); d_ridx_.ensure(n_rows);
+        MMT_HIP(hipMemsetAsync(d_slot_off_.get(), 0xFF, slots * 8, st));     // -1 = document absent
+        MMT_HIP(hipMemsetAsync(d_slot_st_.get(), 0, slots, st));
+        rk::mum_measure(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_tlen_.get(), st);
+        prims::exclusive_sum_u32(d_temp_, d_keep_.get(), d_ridx_.get(), n_rows, st);
+        rk::widen(d_tlen_.get(), n_rows, d_tlen64_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_tlen64_.get(), d_toff_.get(), n_rows, st);
+        const uint32_t k0 = last_u32(d_ridx_.get()), k1 = last_u32(d_keep_.get());
+        const uint64_t t0 = last_u64(d_toff_.get()), t1 = last_u64(d_tlen64_.get());
+        MMT_HIP(hipStreamSynchronize(st));
+        const size_t kept = (size_t)k0 + k1, tbytes = (size_t)(t0 + t1);
+        d_olen_.ensure(kept + 1); d_ooffs_.ensure(kept * N + 1); d_ost_.ensure(kept * N + 1); d_otext_.ensure(tbytes + 1);
+        rk::mum_write(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_ridx_.get(), d_toff_.get(),
+                      d_olen_.get(), d_ooffs_.get(), d_ost_.get(), d_otext_.get(), st);
+        h_len_.ensure(kept + 1); h_offs_.ensure(kept * N + 1); h_st_.ensure(kept * N + 1); h_text_.ensure(tbytes + 1);
+        if (kept) {
+            MMT_HIP(hipMemcpyAsync(h_len_.get(), d_olen_.get(), kept * 4, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_offs_.get(), d_ooffs_.get(), kept * N * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_st_.get(), d_ost_.get(), kept * N, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_text_.get(), d_otext_.get(), tbytes, hipMemcpyDeviceToHost, st));
+        }
+        MMT_HIP(hipStreamSynchronize(st));
+        R.n_rows = kept; R.length = h_len_.get(); R.mum_offsets = h_offs_.get(); R.mum_strands = h_st_.get();
+        R.text = h_text_.get(); R.text_len = tbytes;
+    } else {
+        d_keep_.ensure(n_rows); d_wpos_.ensure(n_rows); d_wdoc_.ensure(n_rows); d_occ64_.ensure(n_rows);
+        d_ooff_.ensure(n_rows);
+        rk::mem_measure(a, d_keep_.get() /* occurrences per row */, d_tlen_.get(), d_wpos_.get(), d_wdoc_.get(), st);
+        rk::widen(d_keep_.get(), n_rows, d_occ64_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_occ64_.get(), d_ooff_.get(), n_rows, st);
+        rk::widen(d_tlen_.get(), n_rows, d_tlen64_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_tlen64_.get(), d_toff_.get(), n_rows, st);
+        const uint64_t o0 = last_u64(d_ooff_.get()), o1 = last_u64(d_occ64_.get());
+        const uint64_t t0 = last_u64(d_toff_.get()), t1 = last_u64(d_tlen64_.get());
+        MMT_HIP(hipStreamSynchronize(st));
+        const size_t occ = (size_t)(o0 + o1), tbytes = (size_t)(t0 + t1);
+        d_olen_.ensure(n_rows); d_ooffs_.ensure(occ + 1); d_omdoc_.ensure(occ + 1); d_ost_.ensure(occ + 1);
+        d_otext_.ensure(tbytes + 1);
+        rk::mem_write(a, d_ooff_.get(), d_toff_.get(), d_wpos_.get(), d_wdoc_.get(), d_olen_.get(), d_ooffs_.get(),
+                      d_omdoc_.get(), d_ost_.get(), d_otext_.get(), st);
+        h_len_.ensure(n_rows); h_offs_.ensure(occ + 1); h_mdoc_.ensure(occ + 1); h_st_.ensure(occ + 1);
+        h_text_.ensure(tbytes + 1); h_occ_start_.ensure((size_t)n_rows + 2);
+        MMT_HIP(hipMemcpyAsync(h_len_.get(), d_olen_.get(), (size_t)n_rows * 4, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(h_occ_start_.get(), d_ooff_.get(), (size_t)n_rows * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(h_offs_.get(), d_ooffs_.get(), occ * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(h_mdoc_.get(), d_omdoc_.get(), occ * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(h_st_.get(), d_ost_.get(), occ, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(h_text_.get(), d_otext_.get(), tbytes, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        h_occ_start_.get()[n_rows] = occ;
+        R.n_rows = n_rows; R.n_occ = occ; R.length = h_len_.get(); R.occ_start = h_occ_start_.get();
+        R.mem_offsets = h_offs_.get(); R.mem_docs = h_mdoc_.get(); R.mem_strands = h_st_.get();
+        R.text = h_text_.get(); R.text_len = tbytes;
+    }
+    ev_[5]->stop(st);
 }
 
 const std::string& Engine::bumbl() {
     // mem_finder.hpp:451-503: u16 flags | u64 n_seqs | u64 n_mums | u32 len[] | i64 starts | strand bits
     if (!bumbl_.empty() || !rows_.mum_mode) return bumbl_;
     const HostRows& R = rows_;
-    const uint64_t nm = R.n_rows(), ns = R.n_docs, nbits = nm * ns;
+    const uint64_t nm = R.n_rows, ns = R.n_docs, nbits = nm * ns;
     uint16_t flags = (uint16_t)(1u << 15);
     if (num_distinct_eff_ < ns) flags |= (uint16_t)(1u << 13);
     bumbl_.assign(2 + 16 + 4 * nm + 8 * nbits + (nbits + 7) / 8, '\0');
@@ -282,7 +274,7 @@ const std::string& Engine::bumbl() {
     std::memcpy(p, &flags, 2); p += 2;
     std::memcpy(p, &ns, 8); p += 8;
     std::memcpy(p, &nm, 8); p += 8;
-    if (nm) { std::memcpy(p, R.length.data(), 4 * nm); p += 4 * nm; std::memcpy(p, R.mum_offsets.data(), 8 * nbits); p += 8 * nbits; }
+    if (nm) { std::memcpy(p, R.length, 4 * nm); p += 4 * nm; std::memcpy(p, R.mum_offsets, 8 * nbits); p += 8 * nbits; }
     for (uint64_t i = 0; i < nbits; i++)
         if (R.mum_strands[i]) p[i / 8] |= (char)(1u << (7 - (i % 8)));
     return bumbl_;
@@ -294,7 +286,7 @@ void Engine::thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev
     if (!R.mum_mode || !thresh_len_) throw std::runtime_error("thresholds need a multi-MUM run with merge metadata");
     std::vector<uint16_t> th(thresh_len_);
     copy_thresh(th.data());
-    const size_t nr = R.n_rows(), N = R.n_docs;
+    const size_t nr = R.n_rows, N = R.n_docs;
     std::vector<std::pair<uint64_t, uint64_t>> mp(nr);     // (offset in doc 0, length), mem_finder.hpp:394-397
     uint64_t total = 0;
     for (size_t r = 0; r < nr; r++) { mp[r] = {(uint64_t)R.mum_offsets[r * N], R.length[r]}; total += R.length[r] + 1; }
@@ -328,8 +320,13 @@ void Engine::run(const mmt_params& p) {
     {
         int kind = producer_;
         if (kind == 0) {
-            const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp"
-            kind = (env && std::string(env) == "pfp") ? 2 : 1;
+            // automatic: prefix-free parsing (never slower than the direct sort in profiles/round1, 3x
+            // faster at 0.1 % divergence) unless the text holds bytes the parse reserves (<= 0x02)
+            const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp" override
+            std::vector<uint32_t> hist;
+            d2h(hist, d_hist_.get(), 256, stream_);
+            const bool reserved = hist[0] || hist[1] || hist[2];
+            kind = (env && std::string(env) == "direct") || reserved ? 1 : 2;
         }
         if (kind == 2) suffix_sort_pfp(pfp_w_, pfp_p_); else suffix_sort();
         producer_used_ = kind;

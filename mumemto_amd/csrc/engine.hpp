@@ -17,18 +17,18 @@ namespace mmt {
 // (mumemto_library/mumemto_api.cpp:137-166 MEM, :241-286 MUM).
 struct HostRows {
     bool mum_mode = true;
-    size_t n_docs = 0;
-    std::vector<uint32_t> length;
-    // MUM mode: n_rows * n_docs
-    std::vector<int64_t> mum_offsets;
-    std::vector<uint8_t> mum_strands;
-    // MEM mode: flat occurrences
-    std::vector<uint64_t> occ_start;   // n_rows + 1
-    std::vector<int64_t> mem_offsets;
-    std::vector<uint64_t> mem_docs;
-    std::vector<uint8_t> mem_strands;
-    std::string text;                  // PREFIX.mums / PREFIX.mems bytes
-    size_t n_rows() const { return length.size(); }
+    size_t n_docs = 0, n_rows = 0, n_occ = 0;
+    const uint32_t* length = nullptr;
+    // MUM mode: n_rows * n_docs, -1 = document absent; strands 1 = '+'
+    const int64_t* mum_offsets = nullptr;
+    const uint8_t* mum_strands = nullptr;
+    // MEM mode: occ_start[n_rows + 1], flat occurrences in suffix-array order
+    const uint64_t* occ_start = nullptr;
+    const int64_t* mem_offsets = nullptr;
+    const uint64_t* mem_docs = nullptr;
+    const uint8_t* mem_strands = nullptr;
+    const char* text = nullptr;        // PREFIX.mums / PREFIX.mems bytes (page-locked host memory)
+    size_t text_len = 0;
 };
 
 class Engine {
@@ -105,12 +105,18 @@ private:
     // scan
     DevBuf<k::Cand> d_cand_, d_rows_;
     DevBuf<uint16_t> d_thresh_;
-    DevBuf<uint64_t> d_off_;
-    DevBuf<uint32_t> d_occ_;
     size_t n_cand_ = 0, thresh_len_ = 0;
-    std::vector<k::Cand> h_rows_;
-    std::vector<uint32_t> h_occ_;
-    std::vector<uint64_t> h_off_;
+    // A6 on the device
+    DevBuf<uint64_t> d_doc_len_, d_rkeys_a_, d_rkeys_b_, d_tlen64_, d_toff_, d_occ64_, d_ooff_, d_omdoc_;
+    DevBuf<uint32_t> d_rvals_a_, d_order_, d_keep_, d_tlen_, d_ridx_, d_wpos_, d_wdoc_, d_olen_;
+    DevBuf<int64_t> d_slot_off_, d_ooffs_;
+    DevBuf<uint8_t> d_slot_st_, d_ost_;
+    DevBuf<char> d_otext_;
+    PinnedBuf<uint32_t> h_len_;
+    PinnedBuf<int64_t> h_offs_;
+    PinnedBuf<uint8_t> h_st_;
+    PinnedBuf<uint64_t> h_occ_start_, h_mdoc_;
+    PinnedBuf<char> h_text_;
 
     HostRows rows_;
     std::string bumbl_;
@@ -119,7 +125,7 @@ private:
     std::unique_ptr<EventPair> ev_[6];
 };
 
-// Row formatting shared with the merge output (host side of A6).
+// decimal formatting shared with the merge output
 void append_uint(std::string& s, uint64_t v);
 
 }  // namespace mmt

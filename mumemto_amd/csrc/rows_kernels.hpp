@@ -1,0 +1,35 @@
+// rows_kernels.hpp -- launch wrappers of rows_kernels.hip (A6 on the device).
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime_api.h>
+
+#include "kernels.hpp"
+
+namespace mmt { namespace rk {
+
+struct RowArgs {
+    const k::Cand* rows;        // accepted, left-maximal intervals (any order)
+    const uint32_t* order;      // order[r] = index into rows of the r-th row in pop order
+    uint32_t n_rows;
+    const uint32_t* sa;
+    const uint64_t* doc_start;  // N + 1
+    const uint64_t* doc_len;    // N (bases per document)
+    uint32_t n_docs;
+    int revcomp;
+};
+
+void row_keys(const k::Cand* rows, uint32_t n_rows, uint64_t* keys, uint32_t* vals, hipStream_t s);
+void mum_measure(const RowArgs& a, int64_t* slot_off, uint8_t* slot_st, uint32_t* keep, uint32_t* text_len,
+                 hipStream_t s);
+void mum_write(const RowArgs& a, const int64_t* slot_off, const uint8_t* slot_st, const uint32_t* keep,
+               const uint32_t* row_idx, const uint64_t* text_off, uint32_t* out_len, int64_t* out_off, uint8_t* out_st,
+               char* text, hipStream_t s);
+void mem_measure(const RowArgs& a, uint32_t* occ_cnt, uint32_t* text_len, uint32_t* w_pos, uint32_t* w_doc,
+                 hipStream_t s);
+void mem_write(const RowArgs& a, const uint64_t* occ_off, const uint64_t* text_off, const uint32_t* w_pos,
+               const uint32_t* w_doc, uint32_t* out_len, int64_t* out_off, uint64_t* out_doc, uint8_t* out_st,
+               char* text, hipStream_t s);
+void widen(const uint32_t* in, uint32_t n, uint64_t* out, hipStream_t s);
+
+}}  // namespace mmt::rk

@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample-bp", type=int, default=3_000_000,
                     help="bases per haplotype given to the 1-core CPU baseline (0 = skip)")
+    ap.add_argument("--producer", default="auto", choices=["auto", "direct", "pfp"])
+    ap.add_argument("--pfp-w", type=int, default=0)
+    ap.add_argument("--pfp-p", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
     return ap.parse_args()
 
@@ -94,6 +97,7 @@ def main():
     stream = torch.cuda.current_stream(device)
     eng = mumemto_amd.Engine(local_rank, stream.cuda_stream)
     eng.set_input_device(d_bases.data_ptr(), doc_len, keepalive=d_bases)
+    eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
     merge_mode = world > 1
     L0 = int(doc_len[0])
 

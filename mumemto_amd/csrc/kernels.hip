@@ -801,4 +801,15 @@ void gather_u32(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* 
     MMT_HIP(hipGetLastError());
 }
 
+__global__ void k_gather_u32_idx32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n,
+                                   uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+void gather_u32_idx32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gather_u32_idx32, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, n, out);
+    MMT_HIP(hipGetLastError());
+}
+
 }}  // namespace mmt::k

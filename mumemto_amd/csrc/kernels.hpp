@@ -103,4 +103,6 @@ void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, uint32_t*
 // out[i] = src[idx[i]]
 void gather_u32(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* out, hipStream_t s);
 
+void gather_u32_idx32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s);
+
 }}  // namespace mmt::k

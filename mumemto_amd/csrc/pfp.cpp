@@ -78,8 +78,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     const uint32_t nd = S.dict_len = (uint32_t)dict_len64;
     S.dict.ensure((size_t)nd + 64); S.dsuf.ensure(nd);
     MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
+    S.dphr.ensure(nd);
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
-                  S.dsuf.get(), nd, st);
+                  S.dsuf.get(), S.dphr.get(), nd, st);
     e2.stop(st);
 
     // -- suffix array of the dictionary (dictionary.hpp:133) ...
@@ -133,14 +134,40 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
 
     e6.start(st);
     const int shift = bit_width_u64((uint64_t)m + 1);
-    const int gbits = bit_width_u64((uint64_t)S.n_groups);
-    if (shift + gbits > 64) throw std::runtime_error("PFP key does not fit 64 bits");
+    const uint32_t nd = S.dict_len;
     S.sa_x.ensure((size_t)n + 1);
     d_sa_.ensure(n); d_rank_.ensure(n);
-    pk::text_keys(S.pstart.get(), m, n, S.pid.get(), S.dstart.get(), S.gpos.get(), S.isa_p.get(), shift,
-                  sorter_.keys_in(), sorter_.vals_in(), st);
-    prims::sort_pairs_u64_u32(d_temp_, sorter_.keys_in(), sorter_.keys_b().get(), sorter_.vals_in(), S.sa_x.get(),
-                              (size_t)n + 1, 0, shift + gbits, st);
+    // inverted list: parse positions ordered by (phrase, rank of the following parse suffix)
+    S.occ_cnt.ensure(D); S.occ_start.ensure(D); S.occ_sorted.ensure(m);
+    MMT_HIP(hipMemsetAsync(S.occ_cnt.get(), 0, (size_t)D * 4, st));
+    pk::occ_keys(S.pid.get(), S.isa_p.get(), m, shift, sorter_.keys_in(), sorter_.vals_in(), S.occ_cnt.get(), st);
+    prims::sort_pairs_u64_u32(d_temp_, sorter_.keys_in(), sorter_.keys_b().get(), sorter_.vals_in(), S.occ_sorted.get(),
+                              m, 0, std::min(64, shift + bit_width_u64(D)), st);
+    prims::exclusive_sum_u32(d_temp_, S.occ_cnt.get(), S.occ_start.get(), D, st);
+    // every valid dictionary suffix, in dictionary suffix-array order, contributes its phrase's list
+    S.ecnt.ensure(nd); S.eoff.ensure(nd); S.segb.ensure((size_t)S.n_groups + 2);
+    pk::entry_counts(S.sa_d.get(), S.dsuf.get(), S.dphr.get(), S.occ_cnt.get(), nd, w, S.ecnt.get(), st);
+    prims::exclusive_sum_u32(d_temp_, S.ecnt.get(), S.eoff.get(), nd, st);
+    {
+        const uint64_t total = (uint64_t)read_u32(S.eoff.get() + (nd - 1), st) + read_u32(S.ecnt.get() + (nd - 1), st);
+        if (total != (uint64_t)n + 1) throw std::runtime_error("PFP expansion does not cover the text exactly once");
+    }
+    // plen of the representative of every distinct phrase (offset inside the phrase = plen - suffix length)
+    S.plen_rep.ensure(D);
+    k::gather_u32_idx32(S.plen.get(), S.rep.get(), D, S.plen_rep.get(), st);
+    S.xk_a.ensure((size_t)n + 1); S.xk_b.ensure((size_t)n + 1); S.xv_a.ensure((size_t)n + 1);
+    pk::expand(S.sa_d.get(), S.dsuf.get(), S.dphr.get(), S.plen_rep.get(), S.occ_start.get(), S.occ_sorted.get(),
+               S.ecnt.get(), S.eoff.get(), S.pstart.get(), S.isa_p.get(), m, nd, S.xk_a.get(), S.xv_a.get(), st);
+    // segments = groups of equal phrase suffixes; merge their lists by the parse-suffix rank
+    prims::select_values_u32(d_temp_, S.eoff.get(), S.gflag.get(), S.segb.get(), S.err.get(), nd, st);
+    if (read_u32(S.err.get(), st) != S.n_groups) throw std::runtime_error("PFP group count mismatch");
+    {
+        const uint32_t endv = n + 1;
+        MMT_HIP(hipMemcpyAsync(S.segb.get() + S.n_groups, &endv, 4, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipStreamSynchronize(st));
+    }
+    prims::segmented_sort_pairs_u32(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.sa_x.get(), n + 1,
+                                    S.n_groups, S.segb.get(), shift, st);
     // entry 0 is the end sentinel (its phrase suffix is the Dollar padding, smaller than every text byte)
     if (read_u32(S.sa_x.get(), st) != n) throw std::runtime_error("PFP order: the end sentinel is not first");
     MMT_HIP(hipMemcpyAsync(d_sa_.get(), S.sa_x.get() + 1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
@@ -161,8 +188,8 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     which.ensure(D); slen.ensure(D); sstart.ensure(D); sorted.ensure(nd);
     pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
     prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
-    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
-                  stream_);
+    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr,
+                  nullptr, nd, stream_);
     d2h(out, sorted.get(), nd, stream_);
 }
 

@@ -16,6 +16,7 @@ struct PfpState {
     DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, dsuf;
     DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, gpos, prank, parse, sa_p, isa_p, sa_x, err;
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
+    DevBuf<uint32_t> dphr, plen_rep, occ_cnt, occ_start, occ_sorted, ecnt, eoff, segb, xk_a, xk_b, xv_a;
 };
 
 }  // namespace mmt

@@ -204,7 +204,7 @@ void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t
 __global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
                             const uint32_t* __restrict__ len, const uint32_t* __restrict__ which,
                             const uint32_t* __restrict__ dstart, uint32_t n_phr, uint8_t* __restrict__ dict,
-                            uint32_t* __restrict__ dsuf, uint32_t dict_len) {
+                            uint32_t* __restrict__ dsuf, uint32_t* __restrict__ dphr, uint32_t dict_len) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (wave >= n_phr) return;
@@ -212,6 +212,7 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __res
     for (uint32_t i = lane; i < l; i += 64) {
         dict[o + i] = v[a + i];
         if (dsuf) dsuf[o + i] = (l - i) | (i == 0 ? 0x80000000u : 0u);
+        if (dphr) dphr[o + i] = (uint32_t)wave;
     }
     if (lane == 0) {
         dict[o + l] = 1;
@@ -220,9 +221,10 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __res
     }
 }
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
-               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t dict_len, hipStream_t s) {
+               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t* dphr, uint32_t dict_len,
+               hipStream_t s) {
     hipLaunchKernelGGL(k_copy_dict, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v, start, len, which,
-                       dstart, n_phr, dict, dsuf, dict_len);
+                       dstart, n_phr, dict, dsuf, dphr, dict_len);
     MMT_HIP(hipGetLastError());
 }
 
@@ -358,6 +360,92 @@ void text_keys(const uint32_t* pstart, uint32_t m, uint32_t n, const uint32_t* p
     constexpr int PER = 16;
     hipLaunchKernelGGL(k_text_keys<PER>, dim3(grid_for(((uint64_t)n + 1 + PER - 1) / PER, 256)), dim3(256), 0, s, pstart,
                        m, n, pid, dstart, gpos, isa_p, shift, keys, vals);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- A4 without a global sort -----------------------------------------------------------
+// The occurrences of every distinct phrase, ordered by the rank of the parse suffix that follows
+// them, are the reference's inverted list (parse.hpp:106-134 compute_ilist).  Walking the
+// dictionary suffix array and copying, for every valid phrase suffix, its phrase's list yields the
+// text suffixes grouped by phrase suffix; only suffixes that spell the same string in several
+// phrases still have to be merged -- a segmented sort of small segments instead of the
+// reference's priority queue (pfp_lcp_mum.hpp:151-212).
+__global__ void k_occ_keys(const uint32_t* __restrict__ pid, const uint32_t* __restrict__ isa_p, uint32_t m,
+                           int shift, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                           uint32_t* __restrict__ occ_cnt) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
+    const uint64_t nxt = q + 1 < m ? (uint64_t)isa_p[q + 1] + 1 : 0;
+    keys[q] = ((uint64_t)pid[q] << shift) | nxt;
+    vals[q] = q;
+    atomicAdd(&occ_cnt[pid[q]], 1u);
+}
+void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift, uint64_t* keys, uint32_t* vals,
+              uint32_t* occ_cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_occ_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, pid, isa_p, m, shift, keys, vals, occ_cnt);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_entry_counts(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf,
+                               const uint32_t* __restrict__ dphr, const uint32_t* __restrict__ occ_cnt, uint32_t nd,
+                               uint32_t w, uint32_t* __restrict__ cnt) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t pos = sa_d[r], e = dsuf[pos];
+    const bool valid = !(e >> 31) && (e & 0x7fffffffu) >= w;
+    cnt[r] = valid ? occ_cnt[dphr[pos]] : 0u;
+}
+void entry_counts(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* occ_cnt,
+                  uint32_t nd, uint32_t w, uint32_t* cnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_entry_counts, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, dphr, occ_cnt, nd, w, cnt);
+    MMT_HIP(hipGetLastError());
+}
+
+// keys[eoff[r] + k] = rank of the parse suffix after the k-th occurrence, vals = text position
+__global__ void k_expand(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf,
+                         const uint32_t* __restrict__ dphr, const uint32_t* __restrict__ plen_rep,
+                         const uint32_t* __restrict__ occ_start, const uint32_t* __restrict__ occ_sorted,
+                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ eoff,
+                         const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ isa_p, uint32_t m,
+                         uint32_t nd, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t c = 0, base = 0, first = 0, off = 0;
+    if (r < nd) {
+        c = cnt[r];
+        if (c) {
+            const uint32_t pos = sa_d[r], d = dphr[pos];
+            off = plen_rep[d] - (dsuf[pos] & 0x7fffffffu);     // offset of the suffix inside its phrase
+            base = eoff[r]; first = occ_start[d];
+        }
+    }
+    const bool big = c > 128;
+    if (c && !big) {
+        for (uint32_t k = 0; k < c; k++) {
+            const uint32_t q = occ_sorted[first + k];
+            keys[base + k] = q + 1 < m ? isa_p[q + 1] + 1 : 0u;
+            vals[base + k] = pstart[q] + off - 1;
+        }
+    }
+    uint64_t todo = __ballot(big);                              // frequent phrases: the wave shares the copy
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t C = __shfl(c, src, 64), B = __shfl(base, src, 64), F = __shfl(first, src, 64),
+                       O = __shfl(off, src, 64);
+        for (uint32_t k = lane; k < C; k += 64) {
+            const uint32_t q = occ_sorted[F + k];
+            keys[B + k] = q + 1 < m ? isa_p[q + 1] + 1 : 0u;
+            vals[B + k] = pstart[q] + O - 1;
+        }
+    }
+}
+void expand(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* plen_rep,
+            const uint32_t* occ_start, const uint32_t* occ_sorted, const uint32_t* cnt, const uint32_t* eoff,
+            const uint32_t* pstart, const uint32_t* isa_p, uint32_t m, uint32_t nd, uint32_t* keys, uint32_t* vals,
+            hipStream_t s) {
+    hipLaunchKernelGGL(k_expand, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, dphr, plen_rep, occ_start,
+                       occ_sorted, cnt, eoff, pstart, isa_p, m, nd, keys, vals);
     MMT_HIP(hipGetLastError());
 }
 

@@ -17,7 +17,8 @@ void mark_distinct(const uint32_t* order, const uint64_t* h1, const uint64_t* h2
 void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
                      uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
-               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t dict_len, hipStream_t s);
+               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t* dphr, uint32_t dict_len,
+               hipStream_t s);
 void group_flags(const uint32_t* sa_d, const uint32_t* lcp_d, const uint32_t* dsuf, uint32_t nd, uint32_t w,
                  uint32_t* gflag, uint32_t* pflag, hipStream_t s);
 void scatter_groups(const uint32_t* sa_d, const uint32_t* gscan, const uint32_t* pscan, const uint32_t* dsuf,
@@ -30,6 +31,14 @@ void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint6
                    hipStream_t s);
 void text_keys(const uint32_t* pstart, uint32_t m, uint32_t n, const uint32_t* pid, const uint32_t* dstart,
                const uint32_t* gpos, const uint32_t* isa_p, int shift, uint64_t* keys, uint32_t* vals, hipStream_t s);
+void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift, uint64_t* keys, uint32_t* vals,
+              uint32_t* occ_cnt, hipStream_t s);
+void entry_counts(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* occ_cnt,
+                  uint32_t nd, uint32_t w, uint32_t* cnt, hipStream_t s);
+void expand(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* plen_rep,
+            const uint32_t* occ_start, const uint32_t* occ_sorted, const uint32_t* cnt, const uint32_t* eoff,
+            const uint32_t* pstart, const uint32_t* isa_p, uint32_t m, uint32_t nd, uint32_t* keys, uint32_t* vals,
+            hipStream_t s);
 void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

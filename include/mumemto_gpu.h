@@ -110,8 +110,9 @@ MMT_API int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]);
 /* Text layout + prefix-free parse only (newscan.hpp pfparser: process_string ... finish_parse).  */
 MMT_API int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p);
 /* out[0] #phrases of the parse, [1] #distinct phrases, [2] dictionary bytes, [3] #groups of equal
- * proper phrase suffixes, [4] doubling rounds on the dictionary, [5] on the parse                */
-MMT_API int mmt_pfp_counts(const mmt_engine* e, uint64_t out[6]);
+ * proper phrase suffixes, [4] doubling rounds on the dictionary, [5] on the parse, [6] #valid
+ * dictionary suffixes, [7] #groups too large for an LDS tile (sorted by the segmented fallback)   */
+MMT_API int mmt_pfp_counts(const mmt_engine* e, uint64_t out[8]);
 /* PREFIX.dict bytes (sorted phrases, 0x01 after each, 0x00 at the end; out holds counts[2] bytes)  */
 MMT_API int mmt_pfp_copy_dict(mmt_engine* e, uint8_t* out);
 /* PREFIX.parse entries (1-based phrase ranks, u32; out holds counts[0] entries)                    */

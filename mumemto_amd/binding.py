@@ -274,9 +274,10 @@ class Engine:
         return d[: c["dict_len"]].tobytes(), q[: c["phrases"]]
 
     def pfp_counts(self):
-        out = (C.c_uint64 * 6)()
+        out = (C.c_uint64 * 8)()
         _check(self.L.mmt_pfp_counts(self.h, out))
-        return dict(zip(["phrases", "distinct", "dict_len", "groups", "rounds_dict", "rounds_parse"], map(int, out)))
+        return dict(zip(["phrases", "distinct", "dict_len", "groups", "rounds_dict", "rounds_parse", "entries",
+                         "oversized_groups"], map(int, out)))
 
     def pfp_stage_ms(self):
         out = (C.c_float * 8)()

@@ -320,11 +320,11 @@ int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32
     e->e->parse_only(use_revcomp != 0, w ? w : 10, p ? p : 100);
     MMT_CATCH
 }
-int mmt_pfp_counts(const mmt_engine* e, uint64_t out[6]) {
+int mmt_pfp_counts(const mmt_engine* e, uint64_t out[8]) {
     if (!e) return fail(1, "null");
     const mmt::PfpState& S = e->e->pfp_state();
     out[0] = S.n_phrases; out[1] = S.n_distinct; out[2] = S.dict_len; out[3] = S.n_groups;
-    out[4] = (uint64_t)S.rounds_dict; out[5] = (uint64_t)S.rounds_parse;
+    out[4] = (uint64_t)S.rounds_dict; out[5] = (uint64_t)S.rounds_parse; out[6] = S.n_entries; out[7] = S.n_fallback;
     return 0;
 }
 int mmt_pfp_copy_dict(mmt_engine* e, uint8_t* out) {

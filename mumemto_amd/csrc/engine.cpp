@@ -54,7 +54,7 @@ void Engine::build_text(bool revcomp) {
     doc_start_.assign(N + 1, 0);
     for (size_t d = 0; d < N; d++) doc_start_[d + 1] = doc_start_[d] + (revcomp ? 2 : 1) * (doc_len_[d] + 1);
     n_ = doc_start_[N];
-    if (n_ >= 0xffffff00ull)
+    if (n_ >= 0xfffff000ull)
         throw std::runtime_error("text of " + std::to_string(n_) +
                                  " characters exceeds the 32-bit suffix-array build of this version");
     d_doc_base_.ensure(N + 1);
@@ -94,7 +94,10 @@ void Engine::lcp_bwt() {
     d_lcp_.ensure(n + 1);
     d_bwt_.ensure(n + 16);
     k::lcp_from_isa(d_text_.get(), n, d_sa_.get(), d_rank_.get(), d_lcp_.get(), stream_);
-    k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
+    if (producer_used_ == 2 && pfp_.bwt_ready)      // the PFP emitter already produced the BWT column
+        MMT_HIP(hipMemcpyAsync(d_bwt_.get(), pfp_.bwt_x.get() + 1, n, hipMemcpyDeviceToDevice, stream_));
+    else
+        k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
 }
 
 // ---- A5 ------------------------------------------------------------------------

@@ -29,7 +29,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     d2h(hist, d_hist_.get(), 256, stream_);
     if (hist[0] || hist[1] || hist[2])          // newscan.hpp:318: characters <= Dollar are not allowed
         throw std::runtime_error("input contains bytes <= 0x02, which the prefix-free parse reserves");
-    S.w = w; S.p = p; S.have_parse = false;
+    S.w = w; S.p = p; S.have_parse = false; S.bwt_ready = false;
     hipStream_t st = stream_;
     EventPair e0, e1, e2, e3, e4;
 
@@ -137,37 +137,66 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const uint32_t nd = S.dict_len;
     S.sa_x.ensure((size_t)n + 1);
     d_sa_.ensure(n); d_rank_.ensure(n);
-    // inverted list: parse positions ordered by (phrase, rank of the following parse suffix)
-    S.occ_cnt.ensure(D); S.occ_start.ensure(D); S.occ_sorted.ensure(m);
+    // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
+    S.occ_cnt.ensure(D); S.occ_start.ensure(D); S.occ_sorted.ensure(m); S.occ_pos.ensure(m); S.occ_key.ensure(m);
     MMT_HIP(hipMemsetAsync(S.occ_cnt.get(), 0, (size_t)D * 4, st));
     pk::occ_keys(S.pid.get(), S.isa_p.get(), m, shift, sorter_.keys_in(), sorter_.vals_in(), S.occ_cnt.get(), st);
     prims::sort_pairs_u64_u32(d_temp_, sorter_.keys_in(), sorter_.keys_b().get(), sorter_.vals_in(), S.occ_sorted.get(),
                               m, 0, std::min(64, shift + bit_width_u64(D)), st);
     prims::exclusive_sum_u32(d_temp_, S.occ_cnt.get(), S.occ_start.get(), D, st);
-    // every valid dictionary suffix, in dictionary suffix-array order, contributes its phrase's list
-    S.ecnt.ensure(nd); S.eoff.ensure(nd); S.segb.ensure((size_t)S.n_groups + 2);
-    pk::entry_counts(S.sa_d.get(), S.dsuf.get(), S.dphr.get(), S.occ_cnt.get(), nd, w, S.ecnt.get(), st);
-    prims::exclusive_sum_u32(d_temp_, S.ecnt.get(), S.eoff.get(), nd, st);
+    pk::occ_payload(S.occ_sorted.get(), S.pstart.get(), S.isa_p.get(), m, S.occ_pos.get(), S.occ_key.get(), st);
+    // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
+    S.vflag.ensure(nd); S.vscan.ensure(nd); S.plen_rep.ensure(D);
+    pk::valid_flags(S.sa_d.get(), S.dsuf.get(), nd, w, S.vflag.get(), st);
+    prims::exclusive_sum_u32(d_temp_, S.vflag.get(), S.vscan.get(), nd, st);
+    const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
+    k::gather_u32_idx32(S.plen.get(), S.rep.get(), D, S.plen_rep.get(), st);
+    S.ce_cnt.ensure(E); S.ce_eoff.ensure(E); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
+    S.ce_bwt.ensure(E);
+    pk::entry_compact(S.sa_d.get(), S.dsuf.get(), S.dphr.get(), S.dict.get(), S.gflag.get(), S.vscan.get(),
+                      S.plen_rep.get(), S.occ_cnt.get(), S.occ_start.get(), nd, w, S.ce_cnt.get(), S.ce_first.get(),
+                      S.ce_offm1.get(), S.ce_bwt.get(), S.ce_gs.get(), st);
+    prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.get(), E, st);
     {
-        const uint64_t total = (uint64_t)read_u32(S.eoff.get() + (nd - 1), st) + read_u32(S.ecnt.get() + (nd - 1), st);
+        const uint64_t total = (uint64_t)read_u32(S.ce_eoff.get() + (E - 1), st) + read_u32(S.ce_cnt.get() + (E - 1), st);
         if (total != (uint64_t)n + 1) throw std::runtime_error("PFP expansion does not cover the text exactly once");
     }
-    // plen of the representative of every distinct phrase (offset inside the phrase = plen - suffix length)
-    S.plen_rep.ensure(D);
-    k::gather_u32_idx32(S.plen.get(), S.rep.get(), D, S.plen_rep.get(), st);
-    S.xk_a.ensure((size_t)n + 1); S.xk_b.ensure((size_t)n + 1); S.xv_a.ensure((size_t)n + 1);
-    pk::expand(S.sa_d.get(), S.dsuf.get(), S.dphr.get(), S.plen_rep.get(), S.occ_start.get(), S.occ_sorted.get(),
-               S.ecnt.get(), S.eoff.get(), S.pstart.get(), S.isa_p.get(), m, nd, S.xk_a.get(), S.xv_a.get(), st);
-    // segments = groups of equal phrase suffixes; merge their lists by the parse-suffix rank
-    prims::select_values_u32(d_temp_, S.eoff.get(), S.gflag.get(), S.segb.get(), S.err.get(), nd, st);
-    if (read_u32(S.err.get(), st) != S.n_groups) throw std::runtime_error("PFP group count mismatch");
+    // groups of equal phrase suffixes: first entry and first output position of each
+    const uint32_t G = S.n_groups;
+    S.sege.ensure((size_t)G + 2); S.segb.ensure((size_t)G + 2);
+    prims::select_indices_u32flags(d_temp_, S.ce_gs.get(), S.sege.get(), S.err.get(), E, st);
+    if (read_u32(S.err.get(), st) != G) throw std::runtime_error("PFP group count mismatch");
+    k::gather_u32_idx32(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), st);
     {
-        const uint32_t endv = n + 1;
-        MMT_HIP(hipMemcpyAsync(S.segb.get() + S.n_groups, &endv, 4, hipMemcpyHostToDevice, st));
+        const uint32_t endv[2] = {E, n + 1};
+        MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &endv[0], 4, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemcpyAsync(S.segb.get() + G, &endv[1], 4, hipMemcpyHostToDevice, st));
         MMT_HIP(hipStreamSynchronize(st));
     }
-    prims::segmented_sort_pairs_u32(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.sa_x.get(), n + 1,
-                                    S.n_groups, S.segb.get(), shift, st);
+    // the emitter
+    const uint32_t fb_cap = 1u << 20;
+    S.bwt_x.ensure((size_t)n + 17); S.xk_a.ensure((size_t)n + 1); S.xv_a.ensure((size_t)n + 1);
+    S.fb_begin.ensure(fb_cap); S.fb_end.ensure(fb_cap);
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
+    pk::EmitArgs ea;
+    ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
+    ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
+    ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
+    ea.occ_pos = S.occ_pos.get(); ea.occ_key = S.occ_key.get();
+    ea.sa_x = S.sa_x.get(); ea.bwt_x = S.bwt_x.get();
+    ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.fb_begin = S.fb_begin.get(); ea.fb_end = S.fb_end.get();
+    ea.fb_count = S.err.get(); ea.fb_capacity = fb_cap;
+    pk::emit(ea, n + 1, st);
+    S.n_fallback = read_u32(S.err.get(), st);
+    if (S.n_fallback > fb_cap) throw std::runtime_error("too many oversized suffix groups for the PFP emitter");
+    if (S.n_fallback) {      // groups larger than an LDS tile: one segmented radix sort over just those ranges
+        S.xk_b.ensure((size_t)n + 1); S.xv_b.ensure((size_t)n + 1);
+        prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(), n + 1,
+                                               S.n_fallback, S.fb_begin.get(), S.fb_end.get(), shift, st);
+        pk::fallback_finish(S.fb_begin.get(), S.fb_end.get(), S.n_fallback, S.xv_b.get(), d_text_.get(), S.sa_x.get(),
+                            S.bwt_x.get(), st);
+    }
+    S.bwt_ready = true;
     // entry 0 is the end sentinel (its phrase suffix is the Dollar padding, smaller than every text byte)
     if (read_u32(S.sa_x.get(), st) != n) throw std::runtime_error("PFP order: the end sentinel is not first");
     MMT_HIP(hipMemcpyAsync(d_sa_.get(), S.sa_x.get() + 1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));

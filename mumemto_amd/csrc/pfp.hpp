@@ -16,7 +16,11 @@ struct PfpState {
     DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, dsuf;
     DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, gpos, prank, parse, sa_p, isa_p, sa_x, err;
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
-    DevBuf<uint32_t> dphr, plen_rep, occ_cnt, occ_start, occ_sorted, ecnt, eoff, segb, xk_a, xk_b, xv_a;
+    DevBuf<uint32_t> dphr, plen_rep, occ_cnt, occ_start, occ_sorted, occ_pos, occ_key, vflag, vscan;
+    DevBuf<uint32_t> ce_cnt, ce_eoff, ce_first, ce_offm1, ce_gs, segb, sege, xk_a, xk_b, xv_a, xv_b, fb_begin, fb_end;
+    DevBuf<uint8_t> ce_bwt, bwt_x;
+    uint32_t n_entries = 0, n_fallback = 0;
+    bool bwt_ready = false;
 };
 
 }  // namespace mmt

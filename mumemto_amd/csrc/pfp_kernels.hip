@@ -449,6 +449,270 @@ void expand(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, co
     MMT_HIP(hipGetLastError());
 }
 
+// ---- A4 emitter: tile kernel ------------------------------------------------------------------
+// Valid dictionary suffixes ("entries", in dictionary suffix-array order) are first compacted with
+// everything the emitter needs; the inverted lists carry (phrase start, following parse rank).
+__global__ void k_occ_payload(const uint32_t* __restrict__ occ_sorted, const uint32_t* __restrict__ pstart,
+                              const uint32_t* __restrict__ isa_p, uint32_t m, uint32_t* __restrict__ occ_pos,
+                              uint32_t* __restrict__ occ_key) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t q = occ_sorted[k];
+    occ_pos[k] = pstart[q];
+    occ_key[k] = q + 1 < m ? isa_p[q + 1] + 1 : 0u;
+}
+void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
+                 uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s) {
+    hipLaunchKernelGGL(k_occ_payload, dim3(grid_for(m, 256)), dim3(256), 0, s, occ_sorted, pstart, isa_p, m, occ_pos,
+                       occ_key);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_entry_compact(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf,
+                                const uint32_t* __restrict__ dphr, const uint8_t* __restrict__ dict,
+                                const uint32_t* __restrict__ gflag, const uint32_t* __restrict__ vscan,
+                                const uint32_t* __restrict__ plen_rep, const uint32_t* __restrict__ occ_cnt,
+                                const uint32_t* __restrict__ occ_start, uint32_t nd, uint32_t w,
+                                uint32_t* __restrict__ ce_cnt, uint32_t* __restrict__ ce_first,
+                                uint32_t* __restrict__ ce_offm1, uint8_t* __restrict__ ce_bwt,
+                                uint32_t* __restrict__ ce_gs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t pos = sa_d[r], e = dsuf[pos];
+    const bool valid = !(e >> 31) && (e & 0x7fffffffu) >= w;
+    if (!valid) return;
+    const uint32_t c = vscan[r], d = dphr[pos];
+    ce_cnt[c] = occ_cnt[d];
+    ce_first[c] = occ_start[d];
+    ce_offm1[c] = plen_rep[d] - (e & 0x7fffffffu) - 1;      // offset inside the phrase, minus one
+    const uint8_t prev = dict[pos - 1];                      // valid suffixes never start a phrase
+    ce_bwt[c] = prev == 2 ? (uint8_t)0 : prev;               // Dollar before text position 0 -> bwt 0
+    ce_gs[c] = gflag[r];
+}
+void entry_compact(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint8_t* dict,
+                   const uint32_t* gflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
+                   const uint32_t* occ_start, uint32_t nd, uint32_t w, uint32_t* ce_cnt, uint32_t* ce_first,
+                   uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s) {
+    hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, dphr, dict, gflag, vscan,
+                       plen_rep, occ_cnt, occ_start, nd, w, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs);
+    MMT_HIP(hipGetLastError());
+}
+
+// valid flag per dictionary SA rank (same rule as k_group_flags)
+__global__ void k_valid_flags(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf, uint32_t nd,
+                              uint32_t w, uint32_t* __restrict__ vflag) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t e = dsuf[sa_d[r]];
+    vflag[r] = (!(e >> 31) && (e & 0x7fffffffu) >= w) ? 1u : 0u;
+}
+void valid_flags(const uint32_t* sa_d, const uint32_t* dsuf, uint32_t nd, uint32_t w, uint32_t* vflag, hipStream_t s) {
+    hipLaunchKernelGGL(k_valid_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, nd, w, vflag);
+    MMT_HIP(hipGetLastError());
+}
+
+// first index i in [0, n] with a[i] >= x (a non-decreasing), all lanes of the calling wave cooperate
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict__ a, uint32_t n, uint32_t x) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t lo = 0, hi = n;                                 // answer in [lo, hi]
+    while (hi - lo > 64) {
+        const uint32_t step = (hi - lo + 63) / 64;
+        const uint32_t probe = lo + (lane + 1) * step;       // probes lo+step .. lo+64*step
+        const bool ge = probe >= hi ? true : a[probe] >= x;
+        const uint64_t m = __ballot(ge);
+        const uint32_t first = (uint32_t)__builtin_ctzll(m); // always at least the last lane
+        const uint32_t nhi = lo + (first + 1) * step;
+        lo = lo + first * step;
+        hi = nhi < hi ? nhi : hi;
+    }
+    const uint32_t i = lo + lane;
+    const bool ge = i >= hi ? true : a[i] >= x;
+    const uint64_t m = __ballot(ge);
+    return m ? lo + (uint32_t)__builtin_ctzll(m) : hi;
+}
+
+// One workgroup per tile of TILE output positions: takes the groups (of equal phrase suffixes) that
+// START inside its tile, expands their entries' inverted lists into LDS and places every element at
+// (group begin + number of group elements with a smaller following-parse-suffix rank) -- the k-way
+// merge of pfp_lcp_mum.hpp:151-212 done by counting, since the lists of one group are sorted runs.
+// Groups that do not fit CAP elements are expanded unsorted and queued for a segmented sort.
+template <int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
+    __shared__ uint32_t s_key[CAP];
+    __shared__ uint32_t s_estart[CAP + 1];
+    __shared__ uint32_t s_efirst[CAP];
+    __shared__ uint32_t s_eoffm1[CAP];
+    __shared__ uint32_t s_egfirst[CAP];       // first entry of the entry's group
+    __shared__ uint16_t s_owner[CAP];
+    __shared__ uint8_t s_ebwt[CAP], s_egs[CAP];
+    __shared__ uint32_t s_bound[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // groups whose begin offset lies in [b*tile, (b+1)*tile)
+    if (wave == 0) {
+        const uint64_t x0 = (uint64_t)blockIdx.x * tile, x1 = x0 + tile;
+        const uint32_t g0 = wave_lower_bound(a.segb, a.n_groups, x0 > 0xffffffffull ? 0xffffffffu : (uint32_t)x0);
+        const uint32_t g1 = wave_lower_bound(a.segb, a.n_groups, x1 > 0xffffffffull ? 0xffffffffu : (uint32_t)x1);
+        if (lane == 0) { s_bound[0] = g0; s_bound[1] = g1; }
+    }
+    __syncthreads();
+    uint32_t g = s_bound[0];
+    const uint32_t g_end = s_bound[1];
+    while (g < g_end) {
+        // chunk = maximal run of whole groups [g, g2) with at most CAP elements
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t lo = a.segb[g];
+            const uint32_t lim = lo + CAP;                   // n + 1 < 2^32 - CAP is checked on the host
+            // first group index in (g, g_end] whose begin exceeds lim, minus one
+            uint32_t cnt = wave_lower_bound(a.segb + g, g_end - g + 1, lim + 1);   // segb[g + cnt] > lim
+            uint32_t g2 = g + cnt - 1;                       // segb[g2] <= lim
+            if (g2 > g_end) g2 = g_end;
+            if (lane == 0) { s_bound[2] = g2; }
+        }
+        __syncthreads();
+        uint32_t g2 = s_bound[2];
+        if (g2 == g) {
+            // a single group larger than CAP: expand unsorted, sort later
+            const uint32_t clo = a.segb[g], chi = a.segb[g + 1];
+            const uint32_t e0 = a.sege[g], e1 = a.sege[g + 1];
+            for (uint32_t e = e0; e < e1; e++) {
+                const uint32_t cntE = a.ce_cnt[e], base = a.ce_eoff[e], first = a.ce_first[e], om1 = a.ce_offm1[e];
+                for (uint32_t k = tid; k < cntE; k += BLOCK) {
+                    a.fb_keys[base + k] = a.occ_key[first + k];
+                    a.fb_vals[base + k] = a.occ_pos[first + k] + om1;
+                }
+            }
+            if (tid == 0) {
+                const uint32_t slot = atomicAdd(a.fb_count, 1u);
+                if (slot < a.fb_capacity) { a.fb_begin[slot] = clo; a.fb_end[slot] = chi; }
+            }
+            g = g + 1;
+            continue;
+        }
+        const uint32_t clo = a.segb[g], chi = a.segb[g2];
+        const uint32_t L = chi - clo;
+        const uint32_t e0 = a.sege[g], e1 = a.sege[g2];
+        const uint32_t E = e1 - e0;                          // <= L <= CAP
+        for (uint32_t i = tid; i < L; i += BLOCK) s_owner[i] = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < E; e += BLOCK) {
+            const uint32_t st = a.ce_eoff[e0 + e] - clo;
+            s_estart[e] = st;
+            s_efirst[e] = a.ce_first[e0 + e];
+            s_eoffm1[e] = a.ce_offm1[e0 + e];
+            s_ebwt[e] = a.ce_bwt[e0 + e];
+            s_egs[e] = (uint8_t)a.ce_gs[e0 + e];
+            s_owner[st] = (uint16_t)e;
+        }
+        if (tid == 0) s_estart[E] = L;
+        __syncthreads();
+        // owner[i] = last entry starting at or before i; egfirst[e] = last group-start entry at or before e
+        // (running maxima over <= CAP items: each thread scans a contiguous slice, then slices are stitched)
+        {
+            constexpr int PER = CAP / BLOCK;
+            const uint32_t b0 = tid * PER;
+            uint32_t run = 0, grun = 0;
+            uint32_t loc[PER], gloc[PER];
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t i = b0 + q;
+                if (i < L) { const uint32_t o = s_owner[i]; run = o > run ? o : run; }
+                loc[q] = run;
+                if (i < E) { if (s_egs[i]) grun = i; }
+                gloc[q] = grun;
+            }
+            // exclusive running max across threads via wave shuffles + LDS across waves
+            __shared__ uint32_t s_wmax[BLOCK / 64], s_gwmax[BLOCK / 64];
+            uint32_t inc = run, ginc = grun;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t y = __shfl_up(inc, o, 64), gy = __shfl_up(ginc, o, 64);
+                if (lane >= (uint32_t)o) { inc = y > inc ? y : inc; ginc = gy > ginc ? gy : ginc; }
+            }
+            if (lane == 63) { s_wmax[wave] = inc; s_gwmax[wave] = ginc; }
+            __syncthreads();
+            uint32_t pre = __shfl_up(inc, 1, 64), gpre = __shfl_up(ginc, 1, 64);
+            if (lane == 0) { pre = 0; gpre = 0; }
+            for (uint32_t wv = 0; wv < wave; wv++) {
+                pre = s_wmax[wv] > pre ? s_wmax[wv] : pre;
+                gpre = s_gwmax[wv] > gpre ? s_gwmax[wv] : gpre;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t i = b0 + q;
+                if (i < L) s_owner[i] = (uint16_t)(loc[q] > pre ? loc[q] : pre);
+                if (i < E) s_egfirst[i] = gloc[q] > gpre ? gloc[q] : gpre;
+            }
+        }
+        __syncthreads();
+        // expand keys into LDS (positions stay in registers)
+        constexpr int PERX = CAP / BLOCK;
+        uint32_t my_pos[PERX];
+#pragma unroll
+        for (int q = 0; q < PERX; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            if (i < L) {
+                const uint32_t e = s_owner[i], k = i - s_estart[e];
+                s_key[i] = a.occ_key[s_efirst[e] + k];
+                my_pos[q] = a.occ_pos[s_efirst[e] + k] + s_eoffm1[e];
+            }
+        }
+        __syncthreads();
+        // place
+#pragma unroll
+        for (int q = 0; q < PERX; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            if (i < L) {
+                const uint32_t e = s_owner[i], key = s_key[i];
+                const uint32_t gf = s_egfirst[e];
+                uint32_t rank = 0, e2 = gf;
+                do {
+                    const uint32_t lo = s_estart[e2], hi = s_estart[e2 + 1];
+                    if (e2 == e) rank += i - lo;
+                    else {                                   // #keys of run e2 smaller than key
+                        uint32_t x = lo, y = hi;
+                        while (x < y) { const uint32_t mid = (x + y) >> 1; if (s_key[mid] < key) x = mid + 1; else y = mid; }
+                        rank += x - lo;
+                    }
+                    e2++;
+                } while (e2 < E && !s_egs[e2]);
+                const uint32_t out = clo + s_estart[gf] + rank;
+                a.sa_x[out] = my_pos[q];
+                a.bwt_x[out] = s_ebwt[e];
+            }
+        }
+        g = g2;
+    }
+}
+
+void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s) {
+    constexpr int BLOCK = 256, CAP = 2048, TILE = 1024;
+    const uint32_t tiles = (uint32_t)(((uint64_t)n_out + TILE - 1) / TILE);
+    hipLaunchKernelGGL((k_emit<BLOCK, CAP>), dim3(tiles), dim3(BLOCK), 0, s, a, (uint32_t)TILE);
+    MMT_HIP(hipGetLastError());
+}
+
+// fallback ranges after their segmented sort: sa_x / bwt_x from the sorted values
+__global__ void k_fallback_finish(const uint32_t* __restrict__ begin, const uint32_t* __restrict__ end, uint32_t n_ranges,
+                                  const uint32_t* __restrict__ sorted_vals, const uint8_t* __restrict__ text,
+                                  uint32_t* __restrict__ sa_x, uint8_t* __restrict__ bwt_x) {
+    const uint32_t rg = blockIdx.x;
+    if (rg >= n_ranges) return;
+    for (uint32_t i = begin[rg] + threadIdx.x; i < end[rg]; i += blockDim.x) {
+        const uint32_t p = sorted_vals[i];
+        sa_x[i] = p;
+        bwt_x[i] = p ? text[p - 1] : (uint8_t)0;
+    }
+}
+void fallback_finish(const uint32_t* begin, const uint32_t* end, uint32_t n_ranges, const uint32_t* sorted_vals,
+                     const uint8_t* text, uint32_t* sa_x, uint8_t* bwt_x, hipStream_t s) {
+    if (!n_ranges) return;
+    hipLaunchKernelGGL(k_fallback_finish, dim3(n_ranges), dim3(256), 0, s, begin, end, n_ranges, sorted_vals, text, sa_x,
+                       bwt_x);
+    MMT_HIP(hipGetLastError());
+}
+
 // rank[sa[j]] = j
 __global__ void k_invert_sa(const uint32_t* __restrict__ sa, uint32_t n, uint32_t* __restrict__ rank) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

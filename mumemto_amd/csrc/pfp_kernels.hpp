@@ -39,6 +39,27 @@ void expand(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, co
             const uint32_t* occ_start, const uint32_t* occ_sorted, const uint32_t* cnt, const uint32_t* eoff,
             const uint32_t* pstart, const uint32_t* isa_p, uint32_t m, uint32_t nd, uint32_t* keys, uint32_t* vals,
             hipStream_t s);
+void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
+                 uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
+void valid_flags(const uint32_t* sa_d, const uint32_t* dsuf, uint32_t nd, uint32_t w, uint32_t* vflag, hipStream_t s);
+void entry_compact(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint8_t* dict,
+                   const uint32_t* gflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
+                   const uint32_t* occ_start, uint32_t nd, uint32_t w, uint32_t* ce_cnt, uint32_t* ce_first,
+                   uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
+struct EmitArgs {
+    const uint32_t* segb;       // n_groups + 1 group begin offsets in the output (last = n + 1)
+    const uint32_t* sege;       // n_groups + 1 compact entry index of every group's first entry
+    uint32_t n_groups;
+    const uint32_t* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
+    const uint8_t* ce_bwt; const uint32_t* ce_gs;
+    const uint32_t* occ_pos; const uint32_t* occ_key;
+    uint32_t* sa_x; uint8_t* bwt_x;
+    uint32_t* fb_keys; uint32_t* fb_vals; uint32_t* fb_begin; uint32_t* fb_end; uint32_t* fb_count;
+    uint32_t fb_capacity;
+};
+void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s);
+void fallback_finish(const uint32_t* begin, const uint32_t* end, uint32_t n_ranges, const uint32_t* sorted_vals,
+                     const uint8_t* text, uint32_t* sa_x, uint8_t* bwt_x, hipStream_t s);
 void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

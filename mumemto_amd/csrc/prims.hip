@@ -73,4 +73,18 @@ void segmented_sort_pairs_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32
     });
 }
 
+void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
+                             hipStream_t s) {
+    rocprim::counting_iterator<uint32_t> idx(0);
+    with_temp(temp, [&](void* t, size_t& b) { return rocprim::select(t, b, idx, flags, out, d_count, n, s); });
+}
+void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                                     uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                     const uint32_t* end, int end_bit, hipStream_t s) {
+    with_temp(temp, [&](void* t, size_t& b) {
+        return rocprim::segmented_radix_sort_pairs(t, b, kin, kout, vin, vout, n, segments, begin, end, 0u,
+                                                   (unsigned)end_bit, s);
+    });
+}
+
 }}  // namespace mmt::prims

@@ -31,4 +31,10 @@ void segmented_sort_pairs_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32
                               uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* offsets, int end_bit,
                               hipStream_t s);
 
+void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
+                             hipStream_t s);
+void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                                     uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                     const uint32_t* end, int end_bit, hipStream_t s);
+
 }}  // namespace mmt::prims

@@ -89,6 +89,25 @@ def test_degenerate_inputs_through_the_parse(engine):
     engine.set_producer("auto")
 
 
+def test_oversized_groups_take_the_segmented_fallback(engine):
+    # long tandem repeats: some phrase suffix occurs more often than an LDS tile holds
+    unit = b"ACGTTGCATTAGCCAGT"
+    docs = [[unit * 900 + b"TTGACCA"], [b"GGA" + unit * 700]]
+    saw_fallback = False
+    for wp in [(10, 100), (6, 20), (4, 11)]:
+        engine.set_producer("pfp", *wp)
+        engine.set_docs(docs)
+        engine.run(min_match_len=20, max_doc_freq=0, num_distinct=2, max_total_freq=50)
+        saw_fallback |= engine.pfp_counts()["oversized_groups"] > 0
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        assert np.array_equal(engine.sa().astype(np.int64), sa[1:])
+        assert np.array_equal(engine.bwt(), bwt[1:])
+        assert engine.output_text() == O.run(docs, min_len=20, max_doc_freq=0, num_distinct=2, max_total_freq=50).text()
+    assert saw_fallback
+    engine.set_producer("auto")
+
+
 def test_parse_is_the_same_as_a_cpu_restatement_on_bigger_input(engine):
     # independent check of trigger positions: plain-python Karp-Rabin of newscan.hpp:106-114
     docs = synth.pangenome(3, 40000, 0.01, seed=9)

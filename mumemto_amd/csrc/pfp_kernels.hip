@@ -537,152 +537,186 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict_
 // merge of pfp_lcp_mum.hpp:151-212 done by counting, since the lists of one group are sorted runs.
 // Groups that do not fit CAP elements are expanded unsorted and queued for a segmented sort.
 template <int BLOCK, int CAP>
+struct EmitShared {
+    uint32_t key[CAP];
+    uint32_t estart[CAP + 1];
+    uint32_t efirst[CAP];
+    uint32_t eoffm1[CAP];
+    uint32_t egfirst[CAP];       // first entry of the entry's group
+    uint16_t owner[CAP];
+    uint8_t ebwt[CAP], egs[CAP];
+    uint32_t wmax[BLOCK / 64], gwmax[BLOCK / 64];
+    uint32_t bound[4];
+};
+
+// Expands entries [e0, e1) (<= CAP entries, L <= CAP elements starting at output offset clo) through
+// LDS.  sorted = true: entries form whole groups; every element goes to its merged position in
+// sa_x / bwt_x.  sorted = false: part of an oversized group; (key, position) go to the fallback arrays.
+template <int BLOCK, int CAP>
+__device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
+                                           uint32_t clo, uint32_t L, bool sorted) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t E = e1 - e0;
+    __syncthreads();
+    for (uint32_t i = tid; i < L; i += BLOCK) sh.owner[i] = 0;
+    __syncthreads();
+    for (uint32_t e = tid; e < E; e += BLOCK) {
+        const uint32_t st = a.ce_eoff[e0 + e] - clo;
+        sh.estart[e] = st;
+        sh.efirst[e] = a.ce_first[e0 + e];
+        sh.eoffm1[e] = a.ce_offm1[e0 + e];
+        sh.ebwt[e] = a.ce_bwt[e0 + e];
+        sh.egs[e] = (uint8_t)a.ce_gs[e0 + e];
+        sh.owner[st] = (uint16_t)e;
+    }
+    if (tid == 0) sh.estart[E] = L;
+    __syncthreads();
+    // owner[i] = last entry starting at or before i; egfirst[e] = last group-start entry at or before e
+    // (running maxima over <= CAP items: each thread scans a contiguous slice, slices are stitched)
+    {
+        constexpr int PER = CAP / BLOCK;
+        const uint32_t b0 = tid * PER;
+        uint32_t run = 0, grun = 0;
+        uint32_t loc[PER], gloc[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = b0 + q;
+            if (i < L) { const uint32_t o = sh.owner[i]; run = o > run ? o : run; }
+            loc[q] = run;
+            if (i < E) { if (sh.egs[i]) grun = i; }
+            gloc[q] = grun;
+        }
+        uint32_t inc = run, ginc = grun;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(inc, o, 64), gy = __shfl_up(ginc, o, 64);
+            if (lane >= (uint32_t)o) { inc = y > inc ? y : inc; ginc = gy > ginc ? gy : ginc; }
+        }
+        if (lane == 63) { sh.wmax[wave] = inc; sh.gwmax[wave] = ginc; }
+        __syncthreads();
+        uint32_t pre = __shfl_up(inc, 1, 64), gpre = __shfl_up(ginc, 1, 64);
+        if (lane == 0) { pre = 0; gpre = 0; }
+        for (uint32_t wv = 0; wv < wave; wv++) {
+            pre = sh.wmax[wv] > pre ? sh.wmax[wv] : pre;
+            gpre = sh.gwmax[wv] > gpre ? sh.gwmax[wv] : gpre;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = b0 + q;
+            if (i < L) sh.owner[i] = (uint16_t)(loc[q] > pre ? loc[q] : pre);
+            if (i < E) sh.egfirst[i] = gloc[q] > gpre ? gloc[q] : gpre;
+        }
+    }
+    __syncthreads();
+    constexpr int PERX = CAP / BLOCK;
+    uint32_t my_pos[PERX];
+#pragma unroll
+    for (int q = 0; q < PERX; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        if (i < L) {
+            const uint32_t e = sh.owner[i], k = i - sh.estart[e];
+            const uint32_t key = a.occ_key[sh.efirst[e] + k];
+            my_pos[q] = a.occ_pos[sh.efirst[e] + k] + sh.eoffm1[e];
+            if (sorted) sh.key[i] = key;
+            else { a.fb_keys[clo + i] = key; a.fb_vals[clo + i] = my_pos[q]; }
+        }
+    }
+    if (!sorted) return;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERX; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        if (i < L) {
+            const uint32_t e = sh.owner[i], key = sh.key[i];
+            const uint32_t gf = sh.egfirst[e];
+            uint32_t rank = 0, e2 = gf;
+            do {
+                const uint32_t lo = sh.estart[e2], hi = sh.estart[e2 + 1];
+                if (e2 == e) rank += i - lo;
+                else {                                   // #keys of run e2 smaller than key
+                    uint32_t x = lo, y = hi;
+                    while (x < y) { const uint32_t mid = (x + y) >> 1; if (sh.key[mid] < key) x = mid + 1; else y = mid; }
+                    rank += x - lo;
+                }
+                e2++;
+            } while (e2 < E && !sh.egs[e2]);
+            const uint32_t out = clo + sh.estart[gf] + rank;
+            a.sa_x[out] = my_pos[q];
+            a.bwt_x[out] = sh.ebwt[e];
+        }
+    }
+}
+
+template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
-    __shared__ uint32_t s_key[CAP];
-    __shared__ uint32_t s_estart[CAP + 1];
-    __shared__ uint32_t s_efirst[CAP];
-    __shared__ uint32_t s_eoffm1[CAP];
-    __shared__ uint32_t s_egfirst[CAP];       // first entry of the entry's group
-    __shared__ uint16_t s_owner[CAP];
-    __shared__ uint8_t s_ebwt[CAP], s_egs[CAP];
-    __shared__ uint32_t s_bound[4];
+    __shared__ EmitShared<BLOCK, CAP> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // groups whose begin offset lies in [b*tile, (b+1)*tile)
     if (wave == 0) {
         const uint64_t x0 = (uint64_t)blockIdx.x * tile, x1 = x0 + tile;
         const uint32_t g0 = wave_lower_bound(a.segb, a.n_groups, x0 > 0xffffffffull ? 0xffffffffu : (uint32_t)x0);
         const uint32_t g1 = wave_lower_bound(a.segb, a.n_groups, x1 > 0xffffffffull ? 0xffffffffu : (uint32_t)x1);
-        if (lane == 0) { s_bound[0] = g0; s_bound[1] = g1; }
+        if (lane == 0) { sh.bound[0] = g0; sh.bound[1] = g1; }
     }
     __syncthreads();
-    uint32_t g = s_bound[0];
-    const uint32_t g_end = s_bound[1];
+    uint32_t g = sh.bound[0];
+    const uint32_t g_end = sh.bound[1];
     while (g < g_end) {
         // chunk = maximal run of whole groups [g, g2) with at most CAP elements
         __syncthreads();
         if (wave == 0) {
-            const uint32_t lo = a.segb[g];
-            const uint32_t lim = lo + CAP;                   // n + 1 < 2^32 - CAP is checked on the host
-            // first group index in (g, g_end] whose begin exceeds lim, minus one
-            uint32_t cnt = wave_lower_bound(a.segb + g, g_end - g + 1, lim + 1);   // segb[g + cnt] > lim
+            const uint32_t lim = a.segb[g] + CAP;           // n + 1 + CAP < 2^32 is checked on the host
+            const uint32_t cnt = wave_lower_bound(a.segb + g, g_end - g + 1, lim + 1);   // segb[g + cnt] > lim
             uint32_t g2 = g + cnt - 1;                       // segb[g2] <= lim
             if (g2 > g_end) g2 = g_end;
-            if (lane == 0) { s_bound[2] = g2; }
+            if (lane == 0) sh.bound[2] = g2;
         }
         __syncthreads();
-        uint32_t g2 = s_bound[2];
-        if (g2 == g) {
-            // a single group larger than CAP: expand unsorted, sort later
-            const uint32_t clo = a.segb[g], chi = a.segb[g + 1];
-            const uint32_t e0 = a.sege[g], e1 = a.sege[g + 1];
-            for (uint32_t e = e0; e < e1; e++) {
-                const uint32_t cntE = a.ce_cnt[e], base = a.ce_eoff[e], first = a.ce_first[e], om1 = a.ce_offm1[e];
-                for (uint32_t k = tid; k < cntE; k += BLOCK) {
+        const uint32_t g2 = sh.bound[2];
+        if (g2 > g) {
+            const uint32_t clo = a.segb[g];
+            emit_piece<BLOCK, CAP>(a, sh, a.sege[g], a.sege[g2], clo, a.segb[g2] - clo, true);
+            g = g2;
+            continue;
+        }
+        // a single group larger than CAP: expand it piecewise, unsorted, and queue it for the segmented sort
+        const uint32_t e_end = a.sege[g + 1];
+        uint32_t e = a.sege[g];
+        while (e < e_end) {
+            __syncthreads();
+            const uint32_t base = a.ce_eoff[e], c = a.ce_cnt[e];
+            if (c > CAP / 2) {                               // one frequent phrase: plain strided copy
+                const uint32_t first = a.ce_first[e], om1 = a.ce_offm1[e];
+                for (uint32_t k = tid; k < c; k += BLOCK) {
                     a.fb_keys[base + k] = a.occ_key[first + k];
                     a.fb_vals[base + k] = a.occ_pos[first + k] + om1;
                 }
+                e++;
+                continue;
             }
-            if (tid == 0) {
-                const uint32_t slot = atomicAdd(a.fb_count, 1u);
-                if (slot < a.fb_capacity) { a.fb_begin[slot] = clo; a.fb_end[slot] = chi; }
-            }
-            g = g + 1;
-            continue;
-        }
-        const uint32_t clo = a.segb[g], chi = a.segb[g2];
-        const uint32_t L = chi - clo;
-        const uint32_t e0 = a.sege[g], e1 = a.sege[g2];
-        const uint32_t E = e1 - e0;                          // <= L <= CAP
-        for (uint32_t i = tid; i < L; i += BLOCK) s_owner[i] = 0;
-        __syncthreads();
-        for (uint32_t e = tid; e < E; e += BLOCK) {
-            const uint32_t st = a.ce_eoff[e0 + e] - clo;
-            s_estart[e] = st;
-            s_efirst[e] = a.ce_first[e0 + e];
-            s_eoffm1[e] = a.ce_offm1[e0 + e];
-            s_ebwt[e] = a.ce_bwt[e0 + e];
-            s_egs[e] = (uint8_t)a.ce_gs[e0 + e];
-            s_owner[st] = (uint16_t)e;
-        }
-        if (tid == 0) s_estart[E] = L;
-        __syncthreads();
-        // owner[i] = last entry starting at or before i; egfirst[e] = last group-start entry at or before e
-        // (running maxima over <= CAP items: each thread scans a contiguous slice, then slices are stitched)
-        {
-            constexpr int PER = CAP / BLOCK;
-            const uint32_t b0 = tid * PER;
-            uint32_t run = 0, grun = 0;
-            uint32_t loc[PER], gloc[PER];
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const uint32_t i = b0 + q;
-                if (i < L) { const uint32_t o = s_owner[i]; run = o > run ? o : run; }
-                loc[q] = run;
-                if (i < E) { if (s_egs[i]) grun = i; }
-                gloc[q] = grun;
-            }
-            // exclusive running max across threads via wave shuffles + LDS across waves
-            __shared__ uint32_t s_wmax[BLOCK / 64], s_gwmax[BLOCK / 64];
-            uint32_t inc = run, ginc = grun;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t y = __shfl_up(inc, o, 64), gy = __shfl_up(ginc, o, 64);
-                if (lane >= (uint32_t)o) { inc = y > inc ? y : inc; ginc = gy > ginc ? gy : ginc; }
-            }
-            if (lane == 63) { s_wmax[wave] = inc; s_gwmax[wave] = ginc; }
-            __syncthreads();
-            uint32_t pre = __shfl_up(inc, 1, 64), gpre = __shfl_up(ginc, 1, 64);
-            if (lane == 0) { pre = 0; gpre = 0; }
-            for (uint32_t wv = 0; wv < wave; wv++) {
-                pre = s_wmax[wv] > pre ? s_wmax[wv] : pre;
-                gpre = s_gwmax[wv] > gpre ? s_gwmax[wv] : gpre;
+            if (wave == 0) {
+                // entries [e, e2) with at most CAP elements and at most CAP entries
+                const uint32_t room = e_end - e < (uint32_t)CAP ? e_end - e : (uint32_t)CAP;
+                const uint32_t cntE = wave_lower_bound(a.ce_eoff + e, room, base + CAP + 1);  // first entry starting > base+CAP
+                uint32_t e2 = e + cntE;                      // entries before it start <= base + CAP
+                // the last of them may end beyond base + CAP: drop it unless it is the only one
+                if (lane == 0) {
+                    while (e2 > e + 1 && a.ce_eoff[e2 - 1] + a.ce_cnt[e2 - 1] > base + CAP) e2--;
+                    sh.bound[3] = e2;
+                }
             }
             __syncthreads();
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const uint32_t i = b0 + q;
-                if (i < L) s_owner[i] = (uint16_t)(loc[q] > pre ? loc[q] : pre);
-                if (i < E) s_egfirst[i] = gloc[q] > gpre ? gloc[q] : gpre;
-            }
+            const uint32_t e2 = sh.bound[3];
+            const uint32_t endoff = e2 < e_end ? a.ce_eoff[e2] : a.segb[g + 1];
+            emit_piece<BLOCK, CAP>(a, sh, e, e2, base, endoff - base, false);
+            e = e2;
         }
-        __syncthreads();
-        // expand keys into LDS (positions stay in registers)
-        constexpr int PERX = CAP / BLOCK;
-        uint32_t my_pos[PERX];
-#pragma unroll
-        for (int q = 0; q < PERX; q++) {
-            const uint32_t i = tid + q * BLOCK;
-            if (i < L) {
-                const uint32_t e = s_owner[i], k = i - s_estart[e];
-                s_key[i] = a.occ_key[s_efirst[e] + k];
-                my_pos[q] = a.occ_pos[s_efirst[e] + k] + s_eoffm1[e];
-            }
+        if (tid == 0) {
+            const uint32_t slot = atomicAdd(a.fb_count, 1u);
+            if (slot < a.fb_capacity) { a.fb_begin[slot] = a.segb[g]; a.fb_end[slot] = a.segb[g + 1]; }
         }
-        __syncthreads();
-        // place
-#pragma unroll
-        for (int q = 0; q < PERX; q++) {
-            const uint32_t i = tid + q * BLOCK;
-            if (i < L) {
-                const uint32_t e = s_owner[i], key = s_key[i];
-                const uint32_t gf = s_egfirst[e];
-                uint32_t rank = 0, e2 = gf;
-                do {
-                    const uint32_t lo = s_estart[e2], hi = s_estart[e2 + 1];
-                    if (e2 == e) rank += i - lo;
-                    else {                                   // #keys of run e2 smaller than key
-                        uint32_t x = lo, y = hi;
-                        while (x < y) { const uint32_t mid = (x + y) >> 1; if (s_key[mid] < key) x = mid + 1; else y = mid; }
-                        rank += x - lo;
-                    }
-                    e2++;
-                } while (e2 < E && !s_egs[e2]);
-                const uint32_t out = clo + s_estart[gf] + rank;
-                a.sa_x[out] = my_pos[q];
-                a.bwt_x[out] = s_ebwt[e];
-            }
-        }
-        g = g2;
+        g = g + 1;
     }
 }
 

@@ -92,9 +92,16 @@ def test_degenerate_inputs_through_the_parse(engine):
 def test_oversized_groups_take_the_segmented_fallback(engine):
     # long tandem repeats: some phrase suffix occurs more often than an LDS tile holds
     unit = b"ACGTTGCATTAGCCAGT"
-    docs = [[unit * 900 + b"TTGACCA"], [b"GGA" + unit * 700]]
+    rnd = synth.pangenome(2, 250000, 0.3, seed=77)       # many distinct phrases sharing short trigger windows
+    for docs, wps in (([[unit * 3000 + b"TTGACCA"], [b"GGA" + unit * 2500]], [(10, 100), (6, 20), (4, 11)]),
+                      (rnd, [(4, 11), (3, 7)])):
+        _check_fallback(engine, docs, wps)
+    engine.set_producer("auto")
+
+
+def _check_fallback(engine, docs, wps):
     saw_fallback = False
-    for wp in [(10, 100), (6, 20), (4, 11)]:
+    for wp in wps:
         engine.set_producer("pfp", *wp)
         engine.set_docs(docs)
         engine.run(min_match_len=20, max_doc_freq=0, num_distinct=2, max_total_freq=50)
@@ -105,7 +112,6 @@ def test_oversized_groups_take_the_segmented_fallback(engine):
         assert np.array_equal(engine.bwt(), bwt[1:])
         assert engine.output_text() == O.run(docs, min_len=20, max_doc_freq=0, num_distinct=2, max_total_freq=50).text()
     assert saw_fallback
-    engine.set_producer("auto")
 
 
 def test_parse_is_the_same_as_a_cpu_restatement_on_bigger_input(engine):

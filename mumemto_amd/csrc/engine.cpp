@@ -94,9 +94,7 @@ void Engine::lcp_bwt() {
     d_lcp_.ensure(n + 1);
     d_bwt_.ensure(n + 16);
     k::lcp_from_isa(d_text_.get(), n, d_sa_.get(), d_rank_.get(), d_lcp_.get(), stream_);
-    if (producer_used_ == 2 && pfp_.bwt_ready)      // the PFP emitter already produced the BWT column
-        MMT_HIP(hipMemcpyAsync(d_bwt_.get(), pfp_.bwt_x.get() + 1, n, hipMemcpyDeviceToDevice, stream_));
-    else
+    if (!(producer_used_ == 2 && pfp_.bwt_ready))   // the PFP emitter writes the BWT column itself
         k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
 }
 

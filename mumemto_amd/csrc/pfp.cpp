@@ -135,8 +135,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     e6.start(st);
     const int shift = bit_width_u64((uint64_t)m + 1);
     const uint32_t nd = S.dict_len;
-    S.sa_x.ensure((size_t)n + 1);
-    d_sa_.ensure(n); d_rank_.ensure(n);
+    d_sa_.ensure(n); d_rank_.ensure(n); d_bwt_.ensure((size_t)n + 16);
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
     S.occ_cnt.ensure(D); S.occ_start.ensure(D); S.occ_sorted.ensure(m); S.occ_pos.ensure(m); S.occ_key.ensure(m);
     MMT_HIP(hipMemsetAsync(S.occ_cnt.get(), 0, (size_t)D * 4, st));
@@ -175,7 +174,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     }
     // the emitter
     const uint32_t fb_cap = 1u << 20;
-    S.bwt_x.ensure((size_t)n + 17); S.xk_a.ensure((size_t)n + 1); S.xv_a.ensure((size_t)n + 1);
+    S.xk_a.ensure((size_t)n + 1); S.xv_a.ensure((size_t)n + 1);
     S.fb_begin.ensure(fb_cap); S.fb_end.ensure(fb_cap);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
     pk::EmitArgs ea;
@@ -183,7 +182,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
     ea.occ_pos = S.occ_pos.get(); ea.occ_key = S.occ_key.get();
-    ea.sa_x = S.sa_x.get(); ea.bwt_x = S.bwt_x.get();
+    ea.n = n; ea.sa = d_sa_.get(); ea.rank = d_rank_.get(); ea.bwt = d_bwt_.get();
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.fb_begin = S.fb_begin.get(); ea.fb_end = S.fb_end.get();
     ea.fb_count = S.err.get(); ea.fb_capacity = fb_cap;
     pk::emit(ea, n + 1, st);
@@ -193,14 +192,11 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         S.xk_b.ensure((size_t)n + 1); S.xv_b.ensure((size_t)n + 1);
         prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(), n + 1,
                                                S.n_fallback, S.fb_begin.get(), S.fb_end.get(), shift, st);
-        pk::fallback_finish(S.fb_begin.get(), S.fb_end.get(), S.n_fallback, S.xv_b.get(), d_text_.get(), S.sa_x.get(),
-                            S.bwt_x.get(), st);
+        pk::fallback_finish(S.fb_begin.get(), S.fb_end.get(), S.n_fallback, S.xv_b.get(), d_text_.get(), n,
+                            d_sa_.get(), d_rank_.get(), d_bwt_.get(), S.err.get() + 1, st);
     }
+    if (read_u32(S.err.get() + 1, st)) throw std::runtime_error("PFP order: the end sentinel is not first");
     S.bwt_ready = true;
-    // entry 0 is the end sentinel (its phrase suffix is the Dollar padding, smaller than every text byte)
-    if (read_u32(S.sa_x.get(), st) != n) throw std::runtime_error("PFP order: the end sentinel is not first");
-    MMT_HIP(hipMemcpyAsync(d_sa_.get(), S.sa_x.get() + 1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-    pk::invert_sa(d_sa_.get(), n, d_rank_.get(), st);
     e6.stop(st);
     S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
     S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -641,9 +641,11 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
                 }
                 e2++;
             } while (e2 < E && !sh.egs[e2]);
-            const uint32_t out = clo + sh.estart[gf] + rank;
-            a.sa_x[out] = my_pos[q];
-            a.bwt_x[out] = sh.ebwt[e];
+            const uint32_t out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
+            const uint32_t pos = my_pos[q];
+            if (out == 0) { if (pos != a.n) atomicAdd(a.fb_count + 1, 1u); }   // entry 0 must be the end sentinel
+            else if (pos < a.n) { a.sa[out - 1] = pos; a.rank[pos] = out - 1; a.bwt[out - 1] = sh.ebwt[e]; }
+            else atomicAdd(a.fb_count + 1, 1u);
         }
     }
 }
@@ -730,20 +732,23 @@ void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s) {
 // fallback ranges after their segmented sort: sa_x / bwt_x from the sorted values
 __global__ void k_fallback_finish(const uint32_t* __restrict__ begin, const uint32_t* __restrict__ end, uint32_t n_ranges,
                                   const uint32_t* __restrict__ sorted_vals, const uint8_t* __restrict__ text,
-                                  uint32_t* __restrict__ sa_x, uint8_t* __restrict__ bwt_x) {
+                                  uint32_t n, uint32_t* __restrict__ sa, uint32_t* __restrict__ rank,
+                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
     const uint32_t rg = blockIdx.x;
     if (rg >= n_ranges) return;
     for (uint32_t i = begin[rg] + threadIdx.x; i < end[rg]; i += blockDim.x) {
         const uint32_t p = sorted_vals[i];
-        sa_x[i] = p;
-        bwt_x[i] = p ? text[p - 1] : (uint8_t)0;
+        if (i == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
+        sa[i - 1] = p; rank[p] = i - 1;
+        bwt[i - 1] = p ? text[p - 1] : (uint8_t)0;
     }
 }
 void fallback_finish(const uint32_t* begin, const uint32_t* end, uint32_t n_ranges, const uint32_t* sorted_vals,
-                     const uint8_t* text, uint32_t* sa_x, uint8_t* bwt_x, hipStream_t s) {
+                     const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank, uint8_t* bwt, uint32_t* err,
+                     hipStream_t s) {
     if (!n_ranges) return;
-    hipLaunchKernelGGL(k_fallback_finish, dim3(n_ranges), dim3(256), 0, s, begin, end, n_ranges, sorted_vals, text, sa_x,
-                       bwt_x);
+    hipLaunchKernelGGL(k_fallback_finish, dim3(n_ranges), dim3(256), 0, s, begin, end, n_ranges, sorted_vals, text, n,
+                       sa, rank, bwt, err);
     MMT_HIP(hipGetLastError());
 }
 

@@ -53,13 +53,16 @@ struct EmitArgs {
     const uint32_t* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
     const uint32_t* occ_pos; const uint32_t* occ_key;
-    uint32_t* sa_x; uint8_t* bwt_x;
-    uint32_t* fb_keys; uint32_t* fb_vals; uint32_t* fb_begin; uint32_t* fb_end; uint32_t* fb_count;
+    uint32_t n;                 // text length; output stream has n + 1 entries, entry 0 = end sentinel
+    uint32_t* sa; uint32_t* rank; uint8_t* bwt;   // n entries each (the sentinel entry is not stored)
+    uint32_t* fb_keys; uint32_t* fb_vals; uint32_t* fb_begin; uint32_t* fb_end;
+    uint32_t* fb_count;         // [0] #oversized groups, [1] consistency errors
     uint32_t fb_capacity;
 };
 void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s);
 void fallback_finish(const uint32_t* begin, const uint32_t* end, uint32_t n_ranges, const uint32_t* sorted_vals,
-                     const uint8_t* text, uint32_t* sa_x, uint8_t* bwt_x, hipStream_t s);
+                     const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank, uint8_t* bwt, uint32_t* err,
+                     hipStream_t s);
 void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--producer", default="auto", choices=["auto", "direct", "pfp"])
     ap.add_argument("--pfp-w", type=int, default=0)
     ap.add_argument("--pfp-p", type=int, default=0)
+    ap.add_argument("--merge-metadata", action="store_true", help="record anchor thresholds also on 1 GPU")
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
     return ap.parse_args()
 
@@ -99,11 +100,12 @@ def main():
     eng.set_input_device(d_bases.data_ptr(), doc_len, keepalive=d_bases)
     eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
     merge_mode = world > 1
+    want_thresh = merge_mode or a.merge_metadata
     L0 = int(doc_len[0])
 
     def step():
         eng.run(min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, use_revcomp=True,
-                merge_metadata=merge_mode)
+                merge_metadata=want_thresh)
         if not merge_mode:
             return eng.output_size()      # the .mums bytes are in (page-locked) host memory at this point
         length, off, st = eng.rows_mum()

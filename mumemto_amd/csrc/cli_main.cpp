@@ -50,8 +50,8 @@ int main(int argc, char** argv) {
         o.parse(argc, argv);
         if (o.help) { std::fputs(usage_text().c_str(), stderr); return 0; }
         const bool mum_mode = o.validate();
-        if (o.from_parse_flag || o.arrays_in_flag || o.only_parse)
-            throw CliError{"-p/--from-parse, -a/--arrays-in and -P/--only-parse are not available in this build", 1};
+        if (o.from_parse_flag || o.arrays_in_flag)
+            throw CliError{"-p/--from-parse and -a/--arrays-in are not available in this build", 1};
         const std::vector<std::string> inputs = resolve_inputs(o);
         o.set_parameters(inputs.size(), mum_mode);
         for (const auto& n : o.notes) log_line("build_main", n);
@@ -84,6 +84,18 @@ int main(int argc, char** argv) {
         t0 = std::chrono::steady_clock::now();
         Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
         eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
+        auto write_pfp_files = [&]() {              // PREFIX.dict / PREFIX.parse as newscan.hpp:406-419 writes them
+            eng.parse_only(o.use_rcomp, (uint32_t)o.pfp_w, (uint32_t)o.hash_mod);
+            std::vector<uint8_t> dict; std::vector<uint32_t> parse;
+            eng.pfp_copy_dict(dict); eng.pfp_copy_parse(parse);
+            write_file(o.output_prefix + ".dict", dict.data(), dict.size());
+            write_file(o.output_prefix + ".parse", parse.data(), parse.size() * 4);
+        };
+        if (o.only_parse) {                         // -P: pfp_mum.cpp:125-127
+            write_pfp_files();
+            log_line("build_main", "wrote the prefix-free parse (.dict, .parse)");
+            return 0;
+        }
         mmt_params p{};
         p.min_match_len = (uint32_t)o.min_match_len;
         p.num_distinct = (uint64_t)o.num_distinct_docs;
@@ -123,6 +135,7 @@ int main(int argc, char** argv) {
             write_file(o.output_prefix + ".bwt", fbwt.data(), fbwt.size());
         }
         log_line("build_main", "Found " + std::to_string(R.n_rows) + " matches!");
+        if (o.keep_temp) write_pfp_files();         // -K: keep PREFIX.dict / PREFIX.parse
         const float* ms = eng.stage_ms();
         std::fprintf(stderr, "GPU stages (ms): text %.2f | suffix sort %.2f | lcp+bwt %.2f | scan %.2f | verify %.2f | rows %.2f | format %.2f\n\n",
                      ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]);

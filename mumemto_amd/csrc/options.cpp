@@ -168,8 +168,13 @@ std::string usage_text() {
            "\t-f, --rare            [INT]     maximum number of occurences per sequence (0 = no limit; default 1)\n"
            "\t-F, --max-freq        [INT]     maximum number of total occurences (negative: relative to N)\n"
            "Accepted for compatibility (the GPU pipeline has no use for them):\n"
-           "\t-w, --window [INT]  -m, --modulus [INT]  -g, --use-gsacak  -K, --keep-temp-files  -s\n"
-           "Not available in this build: -p/--from-parse, -a/--arrays-in, -P/--only-parse\n";
+           "\t-g, --use-gsacak  -s, --no-overlap\n"
+           "PFP options:\n"
+           "\t-w, --window          [INT]     window size of the PFP files written by -P / -K (default: 10)\n"
+           "\t-m, --modulus         [INT]     hash modulus of the PFP files written by -P / -K (default: 100)\n"
+           "\t-P, --only-parse                only compute the prefix-free parse (PREFIX.dict, PREFIX.parse)\n"
+           "\t-K, --keep-temp-files           also write PREFIX.dict and PREFIX.parse\n"
+           "Not available in this build: -p/--from-parse, -a/--arrays-in\n";
 }
 
 }  // namespace mmt

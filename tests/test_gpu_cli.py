@@ -103,6 +103,31 @@ def test_arrays_out(inputs):
     assert np.array_equal(got_bwt[1:], bwt[1:]) and got_bwt[0] == text[-1]
 
 
+def test_only_parse_writes_reference_compatible_files(tmp_path):
+    # -P with the reference's default w/p: same bytes as the real reference parser (golden fixture)
+    G = os.path.join(HERE, "golden", "newscan", "three_docs_w10_p100")
+    docs, cur = [], []
+    for line in open(os.path.join(G, "input.txt"), "rb").read().split(b"\n"):
+        if line.startswith(b"F $"):
+            if cur:
+                docs.append(cur)
+                cur = []
+        elif line.startswith(b"F "):
+            cur.append(line[2:])
+    paths = []
+    for i, d in enumerate(docs):
+        p = tmp_path / ("d%d.fa" % i)
+        synth.write_fasta(str(p), d)
+        paths.append(str(p))
+    cli(["-o", str(tmp_path / "pp"), "-P"] + paths, tmp_path)
+    assert (tmp_path / "pp.dict").read_bytes() == open(os.path.join(G, "out.dict"), "rb").read()
+    assert (tmp_path / "pp.parse").read_bytes() == open(os.path.join(G, "out.parse"), "rb").read()
+    assert not (tmp_path / "pp.mums").exists()
+    cli(["-o", str(tmp_path / "kk"), "-K"] + paths, tmp_path)
+    assert (tmp_path / "kk.dict").read_bytes() == open(os.path.join(G, "out.dict"), "rb").read()
+    assert (tmp_path / "kk.mums").exists()
+
+
 def test_anchor_merge_tool_matches_reference_binary(tmp_path):
     G = os.path.join(HERE, "golden", "anchor_merge")
     for case in sorted(os.listdir(G)):

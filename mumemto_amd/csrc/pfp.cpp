@@ -100,13 +100,13 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
     k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), st);
-    S.gflag.ensure(nd); S.pflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd); S.gpos.ensure(nd);
+    S.gflag.ensure(nd); S.pflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
     pk::group_flags(S.sa_d.get(), S.lcp_d.get(), S.dsuf.get(), nd, w, S.gflag.get(), S.pflag.get(), st);
     prims::inclusive_sum_u32(d_temp_, S.gflag.get(), S.gscan.get(), nd, st);
     prims::inclusive_sum_u32(d_temp_, S.pflag.get(), S.pscan.get(), nd, st);
     pk::scatter_groups(S.sa_d.get(), S.gscan.get(), S.pscan.get(), S.dsuf.get(), S.dstart.get(), D, nd, w,
-                       S.gpos.get(), S.prank.get(), st);
+                       nullptr, S.prank.get(), st);
     pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
     e4.stop(st);

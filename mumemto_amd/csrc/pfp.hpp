@@ -11,14 +11,14 @@ struct PfpState {
     uint32_t n_cuts = 0, n_phrases = 0, n_distinct = 0, dict_len = 0, n_groups = 0;
     bool have_parse = false;
     int rounds_dict = 0, rounds_parse = 0;
-    float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, text keys + sort, total
+    float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
     DevBuf<uint8_t> vtext, flags, dict;
     DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, dsuf;
-    DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, gpos, prank, parse, sa_p, isa_p, sa_x, err;
+    DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, prank, parse, sa_p, isa_p, err;
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
     DevBuf<uint32_t> dphr, plen_rep, occ_cnt, occ_start, occ_sorted, occ_pos, occ_key, vflag, vscan;
     DevBuf<uint32_t> ce_cnt, ce_eoff, ce_first, ce_offm1, ce_gs, segb, sege, xk_a, xk_b, xv_a, xv_b, fb_begin, fb_end;
-    DevBuf<uint8_t> ce_bwt, bwt_x;
+    DevBuf<uint8_t> ce_bwt;
     uint32_t n_entries = 0, n_fallback = 0;
     bool bwt_ready = false;
 };

@@ -268,7 +268,7 @@ __global__ void k_scatter_groups(const uint32_t* __restrict__ sa_d, const uint32
     const uint32_t e = dsuf[pos];
     const bool is_start = e >> 31;
     const bool valid = !is_start && (e & 0x7fffffffu) >= w;
-    gpos[pos] = valid ? gscan[r] : 0u;
+    if (gpos) gpos[pos] = valid ? gscan[r] : 0u;
     if (is_start) {                                     // which phrase starts here?
         uint32_t lo = 0, hi = n_distinct - 1;
         while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (dstart[mid] <= pos) lo = mid; else hi = mid - 1; }
@@ -328,41 +328,6 @@ void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint6
     MMT_HIP(hipGetLastError());
 }
 
-// One key per text position i in [0, n] (i = n is the end sentinel): (group of its phrase suffix,
-// rank of the parse suffix that follows) -- the two-level order of pfp_lcp_mum.hpp:123-212.
-template <int PER>
-__global__ void k_text_keys(const uint32_t* __restrict__ pstart, uint32_t m, uint32_t n,
-                            const uint32_t* __restrict__ pid, const uint32_t* __restrict__ dstart,
-                            const uint32_t* __restrict__ gpos, const uint32_t* __restrict__ isa_p, int shift,
-                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * PER;
-    if (i0 > n) return;
-    // phrase of V position v = i + 1: the last phrase with start < v
-    uint32_t lo = 0, hi = m - 1;
-    const uint32_t v0 = (uint32_t)i0 + 1;
-    while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (pstart[mid] < v0) lo = mid; else hi = mid - 1; }
-    uint32_t q = lo;
-#pragma unroll
-    for (int t = 0; t < PER; t++) {
-        const uint64_t i = i0 + t;
-        if (i > n) break;
-        const uint32_t v = (uint32_t)i + 1;
-        while (q + 1 < m && pstart[q + 1] < v) q++;
-        const uint32_t off = v - pstart[q];
-        const uint64_t g = gpos[dstart[pid[q]] + off];
-        const uint64_t nxt = q + 1 < m ? (uint64_t)isa_p[q + 1] + 1 : 0;
-        keys[i] = (g << shift) | nxt;
-        vals[i] = (uint32_t)i;
-    }
-}
-void text_keys(const uint32_t* pstart, uint32_t m, uint32_t n, const uint32_t* pid, const uint32_t* dstart,
-               const uint32_t* gpos, const uint32_t* isa_p, int shift, uint64_t* keys, uint32_t* vals, hipStream_t s) {
-    constexpr int PER = 16;
-    hipLaunchKernelGGL(k_text_keys<PER>, dim3(grid_for(((uint64_t)n + 1 + PER - 1) / PER, 256)), dim3(256), 0, s, pstart,
-                       m, n, pid, dstart, gpos, isa_p, shift, keys, vals);
-    MMT_HIP(hipGetLastError());
-}
-
 // ---- A4 without a global sort -----------------------------------------------------------
 // The occurrences of every distinct phrase, ordered by the rank of the parse suffix that follows
 // them, are the reference's inverted list (parse.hpp:106-134 compute_ilist).  Walking the
@@ -383,69 +348,6 @@ __global__ void k_occ_keys(const uint32_t* __restrict__ pid, const uint32_t* __r
 void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift, uint64_t* keys, uint32_t* vals,
               uint32_t* occ_cnt, hipStream_t s) {
     hipLaunchKernelGGL(k_occ_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, pid, isa_p, m, shift, keys, vals, occ_cnt);
-    MMT_HIP(hipGetLastError());
-}
-
-__global__ void k_entry_counts(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf,
-                               const uint32_t* __restrict__ dphr, const uint32_t* __restrict__ occ_cnt, uint32_t nd,
-                               uint32_t w, uint32_t* __restrict__ cnt) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nd) return;
-    const uint32_t pos = sa_d[r], e = dsuf[pos];
-    const bool valid = !(e >> 31) && (e & 0x7fffffffu) >= w;
-    cnt[r] = valid ? occ_cnt[dphr[pos]] : 0u;
-}
-void entry_counts(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* occ_cnt,
-                  uint32_t nd, uint32_t w, uint32_t* cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_entry_counts, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, dphr, occ_cnt, nd, w, cnt);
-    MMT_HIP(hipGetLastError());
-}
-
-// keys[eoff[r] + k] = rank of the parse suffix after the k-th occurrence, vals = text position
-__global__ void k_expand(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf,
-                         const uint32_t* __restrict__ dphr, const uint32_t* __restrict__ plen_rep,
-                         const uint32_t* __restrict__ occ_start, const uint32_t* __restrict__ occ_sorted,
-                         const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ eoff,
-                         const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ isa_p, uint32_t m,
-                         uint32_t nd, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t c = 0, base = 0, first = 0, off = 0;
-    if (r < nd) {
-        c = cnt[r];
-        if (c) {
-            const uint32_t pos = sa_d[r], d = dphr[pos];
-            off = plen_rep[d] - (dsuf[pos] & 0x7fffffffu);     // offset of the suffix inside its phrase
-            base = eoff[r]; first = occ_start[d];
-        }
-    }
-    const bool big = c > 128;
-    if (c && !big) {
-        for (uint32_t k = 0; k < c; k++) {
-            const uint32_t q = occ_sorted[first + k];
-            keys[base + k] = q + 1 < m ? isa_p[q + 1] + 1 : 0u;
-            vals[base + k] = pstart[q] + off - 1;
-        }
-    }
-    uint64_t todo = __ballot(big);                              // frequent phrases: the wave shares the copy
-    while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint32_t C = __shfl(c, src, 64), B = __shfl(base, src, 64), F = __shfl(first, src, 64),
-                       O = __shfl(off, src, 64);
-        for (uint32_t k = lane; k < C; k += 64) {
-            const uint32_t q = occ_sorted[F + k];
-            keys[B + k] = q + 1 < m ? isa_p[q + 1] + 1 : 0u;
-            vals[B + k] = pstart[q] + O - 1;
-        }
-    }
-}
-void expand(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* plen_rep,
-            const uint32_t* occ_start, const uint32_t* occ_sorted, const uint32_t* cnt, const uint32_t* eoff,
-            const uint32_t* pstart, const uint32_t* isa_p, uint32_t m, uint32_t nd, uint32_t* keys, uint32_t* vals,
-            hipStream_t s) {
-    hipLaunchKernelGGL(k_expand, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, dphr, plen_rep, occ_start,
-                       occ_sorted, cnt, eoff, pstart, isa_p, m, nd, keys, vals);
     MMT_HIP(hipGetLastError());
 }
 

@@ -29,16 +29,8 @@ void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dl
                   uint32_t* which, uint32_t* slen, hipStream_t s);
 void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint64_t* keys, uint32_t* vals,
                    hipStream_t s);
-void text_keys(const uint32_t* pstart, uint32_t m, uint32_t n, const uint32_t* pid, const uint32_t* dstart,
-               const uint32_t* gpos, const uint32_t* isa_p, int shift, uint64_t* keys, uint32_t* vals, hipStream_t s);
 void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift, uint64_t* keys, uint32_t* vals,
               uint32_t* occ_cnt, hipStream_t s);
-void entry_counts(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* occ_cnt,
-                  uint32_t nd, uint32_t w, uint32_t* cnt, hipStream_t s);
-void expand(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint32_t* plen_rep,
-            const uint32_t* occ_start, const uint32_t* occ_sorted, const uint32_t* cnt, const uint32_t* eoff,
-            const uint32_t* pstart, const uint32_t* isa_p, uint32_t m, uint32_t nd, uint32_t* keys, uint32_t* vals,
-            hipStream_t s);
 void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
                  uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
 void valid_flags(const uint32_t* sa_d, const uint32_t* dsuf, uint32_t nd, uint32_t w, uint32_t* vflag, hipStream_t s);

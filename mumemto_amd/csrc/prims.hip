@@ -60,18 +60,6 @@ void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, 
     with_temp(temp, [&](void* t, size_t& b) { return rocprim::select(t, b, idx, flags, out, d_count, n, s); });
 }
 
-void select_values_u32(DevBuf<uint8_t>& temp, const uint32_t* values, const uint32_t* flags, uint32_t* out,
-                       uint32_t* d_count, size_t n, hipStream_t s) {
-    with_temp(temp, [&](void* t, size_t& b) { return rocprim::select(t, b, values, flags, out, d_count, n, s); });
-}
-void segmented_sort_pairs_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                              uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* offsets, int end_bit,
-                              hipStream_t s) {
-    with_temp(temp, [&](void* t, size_t& b) {
-        return rocprim::segmented_radix_sort_pairs(t, b, kin, kout, vin, vout, n, segments, offsets, offsets + 1, 0u,
-                                                   (unsigned)end_bit, s);
-    });
-}
 
 void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                              hipStream_t s) {

@@ -23,13 +23,6 @@ void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out,
 void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                     hipStream_t s);
 
-// out[k] = values[i] of the k-th non-zero flag
-void select_values_u32(DevBuf<uint8_t>& temp, const uint32_t* values, const uint32_t* flags, uint32_t* out,
-                       uint32_t* d_count, size_t n, hipStream_t s);
-// sorts (key, value) pairs inside every segment [offsets[g], offsets[g+1])
-void segmented_sort_pairs_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                              uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* offsets, int end_bit,
-                              hipStream_t s);
 
 void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                              hipStream_t s);

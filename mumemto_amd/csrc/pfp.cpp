@@ -76,11 +76,10 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     const uint64_t dict_len64 = (uint64_t)read_u32(S.dstart.get() + (D - 1), st) + read_u32(S.dlen.get() + (D - 1), st) + 1;
     if (dict_len64 >= 0xffffff00ull) throw std::runtime_error("PFP dictionary exceeds the 32-bit build");
     const uint32_t nd = S.dict_len = (uint32_t)dict_len64;
-    S.dict.ensure((size_t)nd + 64); S.dsuf.ensure(nd);
+    S.dict.ensure((size_t)nd + 64); S.dinfo.ensure(nd);
     MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
-    S.dphr.ensure(nd);
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
-                  S.dsuf.get(), S.dphr.get(), nd, st);
+                  S.dinfo.get(), nd, st);
     e2.stop(st);
 
     // -- suffix array of the dictionary (dictionary.hpp:133) ...
@@ -100,13 +99,14 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
     k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), st);
-    S.gflag.ensure(nd); S.pflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
+    S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
+    pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
+    S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
-    pk::group_flags(S.sa_d.get(), S.lcp_d.get(), S.dsuf.get(), nd, w, S.gflag.get(), S.pflag.get(), st);
+    pk::group_flags(S.esuf.get(), S.lcp_d.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);
     prims::inclusive_sum_u32(d_temp_, S.gflag.get(), S.gscan.get(), nd, st);
     prims::inclusive_sum_u32(d_temp_, S.pflag.get(), S.pscan.get(), nd, st);
-    pk::scatter_groups(S.sa_d.get(), S.gscan.get(), S.pscan.get(), S.dsuf.get(), S.dstart.get(), D, nd, w,
-                       nullptr, S.prank.get(), st);
+    pk::phrase_ranks(S.esuf.get(), S.ephr.get(), S.pscan.get(), nd, S.prank.get(), st);
     pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
     e4.stop(st);
@@ -145,15 +145,14 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     prims::exclusive_sum_u32(d_temp_, S.occ_cnt.get(), S.occ_start.get(), D, st);
     pk::occ_payload(S.occ_sorted.get(), S.pstart.get(), S.isa_p.get(), m, S.occ_pos.get(), S.occ_key.get(), st);
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
-    S.vflag.ensure(nd); S.vscan.ensure(nd); S.plen_rep.ensure(D);
-    pk::valid_flags(S.sa_d.get(), S.dsuf.get(), nd, w, S.vflag.get(), st);
+    S.vscan.ensure(nd); S.plen_rep.ensure(D);
     prims::exclusive_sum_u32(d_temp_, S.vflag.get(), S.vscan.get(), nd, st);
     const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
     k::gather_u32_idx32(S.plen.get(), S.rep.get(), D, S.plen_rep.get(), st);
     S.ce_cnt.ensure(E); S.ce_eoff.ensure(E); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
     S.ce_bwt.ensure(E);
-    pk::entry_compact(S.sa_d.get(), S.dsuf.get(), S.dphr.get(), S.dict.get(), S.gflag.get(), S.vscan.get(),
-                      S.plen_rep.get(), S.occ_cnt.get(), S.occ_start.get(), nd, w, S.ce_cnt.get(), S.ce_first.get(),
+    pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.vflag.get(), S.vscan.get(),
+                      S.plen_rep.get(), S.occ_cnt.get(), S.occ_start.get(), nd, S.ce_cnt.get(), S.ce_first.get(),
                       S.ce_offm1.get(), S.ce_bwt.get(), S.ce_gs.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.get(), E, st);
     {
@@ -213,8 +212,8 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     which.ensure(D); slen.ensure(D); sstart.ensure(D); sorted.ensure(nd);
     pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
     prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
-    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr,
-                  nullptr, nd, stream_);
+    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
+                  stream_);
     d2h(out, sorted.get(), nd, stream_);
 }
 

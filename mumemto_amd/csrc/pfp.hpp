@@ -13,10 +13,12 @@ struct PfpState {
     int rounds_dict = 0, rounds_parse = 0;
     float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
     DevBuf<uint8_t> vtext, flags, dict;
-    DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, dsuf;
+    DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, esuf, ephr;
+    DevBuf<uint64_t> dinfo;
+    DevBuf<uint8_t> ebw;
     DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, prank, parse, sa_p, isa_p, err;
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
-    DevBuf<uint32_t> dphr, plen_rep, occ_cnt, occ_start, occ_sorted, occ_pos, occ_key, vflag, vscan;
+    DevBuf<uint32_t> plen_rep, occ_cnt, occ_start, occ_sorted, occ_pos, occ_key, vflag, vscan;
     DevBuf<uint32_t> ce_cnt, ce_eoff, ce_first, ce_offm1, ce_gs, segb, sege, xk_a, xk_b, xv_a, xv_b, fb_begin, fb_end;
     DevBuf<uint8_t> ce_bwt;
     uint32_t n_entries = 0, n_fallback = 0;

@@ -199,87 +199,96 @@ void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t
 }
 
 // dictionary text: phrase bytes, EndOfWord (1) after every phrase, EndOfDict (0) at the very end
-// (dictionary file layout of newscan.hpp:386-397).  dsuf[pos] = length of the phrase suffix that
-// starts at pos (0 on separators), bit 31 set on the first byte of a phrase.  One wave per phrase.
+// (dictionary file layout of newscan.hpp:386-397).  dinfo[pos] = (distinct phrase id << 32) | suffix
+// word: length of the phrase suffix that starts at pos (0 on separators), bit 31 set on the first
+// byte of a phrase.  One wave per phrase.
 __global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
                             const uint32_t* __restrict__ len, const uint32_t* __restrict__ which,
                             const uint32_t* __restrict__ dstart, uint32_t n_phr, uint8_t* __restrict__ dict,
-                            uint32_t* __restrict__ dsuf, uint32_t* __restrict__ dphr, uint32_t dict_len) {
+                            uint64_t* __restrict__ dinfo, uint32_t dict_len) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (wave >= n_phr) return;
     const uint32_t ph = which[wave], a = start[ph], l = len[ph], o = dstart[wave];
     for (uint32_t i = lane; i < l; i += 64) {
         dict[o + i] = v[a + i];
-        if (dsuf) dsuf[o + i] = (l - i) | (i == 0 ? 0x80000000u : 0u);
-        if (dphr) dphr[o + i] = (uint32_t)wave;
+        if (dinfo) dinfo[o + i] = ((uint64_t)wave << 32) | (uint64_t)((l - i) | (i == 0 ? 0x80000000u : 0u));
     }
     if (lane == 0) {
         dict[o + l] = 1;
-        if (dsuf) dsuf[o + l] = 0;
-        if (wave + 1 == n_phr) { dict[dict_len - 1] = 0; if (dsuf) dsuf[dict_len - 1] = 0; }
+        if (dinfo) dinfo[o + l] = (uint64_t)wave << 32;
+        if (wave + 1 == n_phr) { dict[dict_len - 1] = 0; if (dinfo) dinfo[dict_len - 1] = (uint64_t)wave << 32; }
     }
 }
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
-               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t* dphr, uint32_t dict_len,
+               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
                hipStream_t s) {
     hipLaunchKernelGGL(k_copy_dict, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v, start, len, which,
-                       dstart, n_phr, dict, dsuf, dphr, dict_len);
+                       dstart, n_phr, dict, dinfo, dict_len);
     MMT_HIP(hipGetLastError());
 }
 
 // ---- A3/A4: groups of equal proper phrase suffixes, in dictionary suffix-array order -----------
-// Valid = proper suffix (not the whole phrase) of length >= w (pfp_lcp_mum.hpp:272-282).  Two
-// neighbours of the dictionary SA spell the same string iff they have the same length and their LCP
-// reaches it (:141-154 collects them as `same_suffix`).
-__global__ void k_group_flags(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ lcp_d,
-                              const uint32_t* __restrict__ dsuf, uint32_t nd, uint32_t w,
-                              uint32_t* __restrict__ gflag, uint32_t* __restrict__ pflag) {
+// One random pass brings everything that is known per dictionary position into suffix-array order;
+// all later kernels read these columns coalesced.
+__global__ void k_entry_info(const uint32_t* __restrict__ sa_d, const uint64_t* __restrict__ dinfo,
+                             const uint8_t* __restrict__ dict, uint32_t nd, uint32_t* __restrict__ esuf,
+                             uint32_t* __restrict__ ephr, uint8_t* __restrict__ ebw) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd) return;
-    const uint32_t e = dsuf[sa_d[r]];
+    const uint32_t pos = sa_d[r];
+    const uint64_t e = dinfo[pos];
+    esuf[r] = (uint32_t)e;
+    ephr[r] = (uint32_t)(e >> 32);
+    const uint8_t prev = pos ? dict[pos - 1] : (uint8_t)0;
+    ebw[r] = prev == 2 ? (uint8_t)0 : prev;                 // Dollar before text position 0 -> bwt 0
+}
+void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, uint32_t* esuf,
+                uint32_t* ephr, uint8_t* ebw, hipStream_t s) {
+    hipLaunchKernelGGL(k_entry_info, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dinfo, dict, nd, esuf, ephr, ebw);
+    MMT_HIP(hipGetLastError());
+}
+
+// Valid = proper suffix (not the whole phrase) of length >= w (pfp_lcp_mum.hpp:272-282).  Two
+// neighbours of the dictionary SA spell the same string iff they have the same length and their LCP
+// reaches it (:141-154 collects them as `same_suffix`).  vflag = valid, gflag = first of its group,
+// pflag = first byte of a phrase (their order gives the lexicographic phrase ranks).
+__global__ void k_group_flags(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ lcp_d, uint32_t nd,
+                              uint32_t w, uint32_t* __restrict__ gflag, uint32_t* __restrict__ pflag,
+                              uint32_t* __restrict__ vflag) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t e = esuf[r];
     const uint32_t sl = e & 0x7fffffffu;
     const bool is_start = e >> 31;
     const bool valid = !is_start && sl >= w;
     bool fresh = valid;
     if (valid && r > 0) {
-        const uint32_t pe = dsuf[sa_d[r - 1]];
+        const uint32_t pe = esuf[r - 1];
         const bool pvalid = !(pe >> 31) && (pe & 0x7fffffffu) >= w;
         if (pvalid && (pe & 0x7fffffffu) == sl && lcp_d[r] >= sl) fresh = false;
     }
     gflag[r] = fresh ? 1u : 0u;
     pflag[r] = is_start ? 1u : 0u;
+    vflag[r] = valid ? 1u : 0u;
 }
-void group_flags(const uint32_t* sa_d, const uint32_t* lcp_d, const uint32_t* dsuf, uint32_t nd, uint32_t w,
-                 uint32_t* gflag, uint32_t* pflag, hipStream_t s) {
-    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, lcp_d, dsuf, nd, w, gflag, pflag);
+void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag,
+                 uint32_t* pflag, uint32_t* vflag, hipStream_t s) {
+    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, lcp_d, nd, w, gflag, pflag, vflag);
     MMT_HIP(hipGetLastError());
 }
 
-// gpos[dict position] = group id (1-based, 0 = not a valid suffix); prank[distinct phrase] = 1-based
-// lexicographic rank of the phrase (position of its first byte among the phrase starts of the SA).
-__global__ void k_scatter_groups(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ gscan,
-                                 const uint32_t* __restrict__ pscan, const uint32_t* __restrict__ dsuf,
-                                 const uint32_t* __restrict__ dstart, uint32_t n_distinct, uint32_t nd, uint32_t w,
-                                 uint32_t* __restrict__ gpos, uint32_t* __restrict__ prank) {
+// prank[distinct phrase] = 1-based lexicographic rank = position of its first byte among the phrase
+// starts of the dictionary suffix array
+__global__ void k_phrase_ranks(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ ephr,
+                               const uint32_t* __restrict__ pscan, uint32_t nd, uint32_t* __restrict__ prank) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd) return;
-    const uint32_t pos = sa_d[r];
-    const uint32_t e = dsuf[pos];
-    const bool is_start = e >> 31;
-    const bool valid = !is_start && (e & 0x7fffffffu) >= w;
-    if (gpos) gpos[pos] = valid ? gscan[r] : 0u;
-    if (is_start) {                                     // which phrase starts here?
-        uint32_t lo = 0, hi = n_distinct - 1;
-        while (lo < hi) { uint32_t mid = (lo + hi + 1) >> 1; if (dstart[mid] <= pos) lo = mid; else hi = mid - 1; }
-        prank[lo] = pscan[r];
-    }
+    if (esuf[r] >> 31) prank[ephr[r]] = pscan[r];
 }
-void scatter_groups(const uint32_t* sa_d, const uint32_t* gscan, const uint32_t* pscan, const uint32_t* dsuf,
-                    const uint32_t* dstart, uint32_t n_distinct, uint32_t nd, uint32_t w, uint32_t* gpos,
-                    uint32_t* prank, hipStream_t s) {
-    hipLaunchKernelGGL(k_scatter_groups, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, gscan, pscan, dsuf, dstart,
-                       n_distinct, nd, w, gpos, prank);
+void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_phrase_ranks, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, ephr, pscan, nd, prank);
     MMT_HIP(hipGetLastError());
 }
 
@@ -370,46 +379,29 @@ void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint3
     MMT_HIP(hipGetLastError());
 }
 
-__global__ void k_entry_compact(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf,
-                                const uint32_t* __restrict__ dphr, const uint8_t* __restrict__ dict,
-                                const uint32_t* __restrict__ gflag, const uint32_t* __restrict__ vscan,
+__global__ void k_entry_compact(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ ephr,
+                                const uint8_t* __restrict__ ebw, const uint32_t* __restrict__ gflag,
+                                const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vscan,
                                 const uint32_t* __restrict__ plen_rep, const uint32_t* __restrict__ occ_cnt,
-                                const uint32_t* __restrict__ occ_start, uint32_t nd, uint32_t w,
+                                const uint32_t* __restrict__ occ_start, uint32_t nd,
                                 uint32_t* __restrict__ ce_cnt, uint32_t* __restrict__ ce_first,
                                 uint32_t* __restrict__ ce_offm1, uint8_t* __restrict__ ce_bwt,
                                 uint32_t* __restrict__ ce_gs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nd) return;
-    const uint32_t pos = sa_d[r], e = dsuf[pos];
-    const bool valid = !(e >> 31) && (e & 0x7fffffffu) >= w;
-    if (!valid) return;
-    const uint32_t c = vscan[r], d = dphr[pos];
+    if (r >= nd || !vflag[r]) return;
+    const uint32_t c = vscan[r], d = ephr[r];
     ce_cnt[c] = occ_cnt[d];
     ce_first[c] = occ_start[d];
-    ce_offm1[c] = plen_rep[d] - (e & 0x7fffffffu) - 1;      // offset inside the phrase, minus one
-    const uint8_t prev = dict[pos - 1];                      // valid suffixes never start a phrase
-    ce_bwt[c] = prev == 2 ? (uint8_t)0 : prev;               // Dollar before text position 0 -> bwt 0
+    ce_offm1[c] = plen_rep[d] - (esuf[r] & 0x7fffffffu) - 1;   // offset inside the phrase, minus one
+    ce_bwt[c] = ebw[r];
     ce_gs[c] = gflag[r];
 }
-void entry_compact(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint8_t* dict,
-                   const uint32_t* gflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
-                   const uint32_t* occ_start, uint32_t nd, uint32_t w, uint32_t* ce_cnt, uint32_t* ce_first,
-                   uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s) {
-    hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, dphr, dict, gflag, vscan,
-                       plen_rep, occ_cnt, occ_start, nd, w, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs);
-    MMT_HIP(hipGetLastError());
-}
-
-// valid flag per dictionary SA rank (same rule as k_group_flags)
-__global__ void k_valid_flags(const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ dsuf, uint32_t nd,
-                              uint32_t w, uint32_t* __restrict__ vflag) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nd) return;
-    const uint32_t e = dsuf[sa_d[r]];
-    vflag[r] = (!(e >> 31) && (e & 0x7fffffffu) >= w) ? 1u : 0u;
-}
-void valid_flags(const uint32_t* sa_d, const uint32_t* dsuf, uint32_t nd, uint32_t w, uint32_t* vflag, hipStream_t s) {
-    hipLaunchKernelGGL(k_valid_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dsuf, nd, w, vflag);
+void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
+                   const uint32_t* vflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
+                   const uint32_t* occ_start, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
+                   uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s) {
+    hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, ephr, ebw, gflag, vflag, vscan,
+                       plen_rep, occ_cnt, occ_start, nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs);
     MMT_HIP(hipGetLastError());
 }
 

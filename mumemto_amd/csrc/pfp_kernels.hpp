@@ -17,13 +17,18 @@ void mark_distinct(const uint32_t* order, const uint64_t* h1, const uint64_t* h2
 void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
                      uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
-               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint32_t* dsuf, uint32_t* dphr, uint32_t dict_len,
+               const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
                hipStream_t s);
-void group_flags(const uint32_t* sa_d, const uint32_t* lcp_d, const uint32_t* dsuf, uint32_t nd, uint32_t w,
-                 uint32_t* gflag, uint32_t* pflag, hipStream_t s);
-void scatter_groups(const uint32_t* sa_d, const uint32_t* gscan, const uint32_t* pscan, const uint32_t* dsuf,
-                    const uint32_t* dstart, uint32_t n_distinct, uint32_t nd, uint32_t w, uint32_t* gpos,
-                    uint32_t* prank, hipStream_t s);
+void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, uint32_t* esuf,
+                uint32_t* ephr, uint8_t* ebw, hipStream_t s);
+void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag,
+                 uint32_t* pflag, uint32_t* vflag, hipStream_t s);
+void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,
+                  hipStream_t s);
+void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
+                   const uint32_t* vflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
+                   const uint32_t* occ_start, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
+                   uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
 void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s);
 void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
                   uint32_t* which, uint32_t* slen, hipStream_t s);
@@ -33,11 +38,6 @@ void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift,
               uint32_t* occ_cnt, hipStream_t s);
 void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
                  uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
-void valid_flags(const uint32_t* sa_d, const uint32_t* dsuf, uint32_t nd, uint32_t w, uint32_t* vflag, hipStream_t s);
-void entry_compact(const uint32_t* sa_d, const uint32_t* dsuf, const uint32_t* dphr, const uint8_t* dict,
-                   const uint32_t* gflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
-                   const uint32_t* occ_start, uint32_t nd, uint32_t w, uint32_t* ce_cnt, uint32_t* ce_first,
-                   uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
 struct EmitArgs {
     const uint32_t* segb;       // n_groups + 1 group begin offsets in the output (last = n + 1)
     const uint32_t* sege;       // n_groups + 1 compact entry index of every group's first entry

@@ -581,7 +581,7 @@ void scan_intervals(const ScanArgs& a, hipStream_t s) {
     if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
     // measured on MI355X (profiles/round1_b): 512 threads x 8 positions per thread is best for small
     // windows (16 docs: 0.88 ms / 387 M suffixes), 512 x 12 for wide ones (94 docs: 0.92 ms / 376 M)
-    static int variant = -1, bpc = 8;
+    static int variant = -1, bpc = 6;     // 1536 workgroups: 61.5 tiles each on the bench workload (sweep6)
     if (variant < 0) {
         const char* v = getenv("MMT_SCAN_VARIANT"); variant = v ? atoi(v) : 0;
         const char* g = getenv("MMT_SCAN_BPC"); if (g) bpc = atoi(g);

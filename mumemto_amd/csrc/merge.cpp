@@ -11,31 +11,33 @@
 namespace mmt {
 namespace {
 
+// Rows of one side of a fold step, viewed in anchor order: `order[i]` = index of the i-th row by
+// offsets[0] in the backing arrays (parse_candidate sorts them, merge_candidates.cpp:89-92).
 struct Side {
     size_t n_docs = 0;
-    std::vector<uint32_t> length;
-    std::vector<int64_t> offsets;
-    std::vector<uint8_t> strands;
-    size_t n_rows() const { return length.size(); }
+    const uint32_t* length = nullptr;
+    const int64_t* offsets = nullptr;
+    const uint8_t* strands = nullptr;
+    std::vector<uint32_t> order;
+    // backing storage when the side is the result of a previous fold step
+    std::vector<uint32_t> own_length;
+    std::vector<int64_t> own_offsets;
+    std::vector<uint8_t> own_strands;
+    size_t n_rows() const { return order.size(); }
+    int64_t start(size_t i) const { return offsets[(size_t)order[i] * n_docs]; }
 };
 
-// parse_candidate(): rows sorted by their anchor offset (merge_candidates.cpp:89-92)
-Side load_side(const mmt_partition& p) {
+Side view_side(const mmt_partition& p) {
     Side s;
-    s.n_docs = p.n_docs;
-    std::vector<size_t> order(p.n_rows);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(),
-              [&](size_t a, size_t b) { return p.offsets[a * p.n_docs] < p.offsets[b * p.n_docs]; });
-    s.length.resize(p.n_rows); s.offsets.resize(p.n_rows * p.n_docs); s.strands.resize(p.n_rows * p.n_docs);
-    for (size_t i = 0; i < p.n_rows; i++) {
-        size_t r = order[i];
-        s.length[i] = p.length[r];
-        for (size_t c = 0; c < p.n_docs; c++) {
-            s.offsets[i * p.n_docs + c] = p.offsets[r * p.n_docs + c];
-            s.strands[i * p.n_docs + c] = p.strands[r * p.n_docs + c];
-        }
-    }
+    s.n_docs = p.n_docs; s.length = p.length; s.offsets = p.offsets; s.strands = p.strands;
+    s.order.resize(p.n_rows);
+    std::iota(s.order.begin(), s.order.end(), 0u);
+    bool sorted = true;
+    for (size_t i = 1; i < p.n_rows && sorted; i++) sorted = p.offsets[(i - 1) * p.n_docs] <= p.offsets[i * p.n_docs];
+    if (!sorted)
+        std::sort(s.order.begin(), s.order.end(), [&](uint32_t a, uint32_t b) {
+            return p.offsets[(size_t)a * p.n_docs] < p.offsets[(size_t)b * p.n_docs];
+        });
     return s;
 }
 
@@ -43,26 +45,40 @@ struct DeviceSide {
     DevBuf<uint64_t> start;
     DevBuf<uint32_t> len, ones, rank;
     DevBuf<uint8_t> bv;
+    std::vector<uint64_t> h_start;
+    std::vector<uint32_t> h_len;
     void upload(const Side& s, uint64_t L, DevBuf<uint8_t>& temp, hipStream_t st) {
         const size_t n = s.n_rows();
-        std::vector<uint64_t> h_start(n);
+        h_start.resize(n); h_len.resize(n);
         for (size_t r = 0; r < n; r++) {
-            int64_t o = s.offsets[r * s.n_docs];
+            const int64_t o = s.start(r);
             if (o < 0 || (uint64_t)o >= L) throw std::runtime_error("anchor offset outside the threshold array");
             h_start[r] = (uint64_t)o;
+            h_len[r] = s.length[s.order[r]];
         }
         start.ensure(n + 1); len.ensure(n + 1); bv.ensure(L); ones.ensure(L); rank.ensure(L);
         if (n) {
             MMT_HIP(hipMemcpyAsync(start.get(), h_start.data(), n * 8, hipMemcpyHostToDevice, st));
-            MMT_HIP(hipMemcpyAsync(len.get(), s.length.data(), n * 4, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipMemcpyAsync(len.get(), h_len.data(), n * 4, hipMemcpyHostToDevice, st));
         }
         MMT_HIP(hipMemsetAsync(bv.get(), 0, L, st));
         MMT_HIP(hipMemsetAsync(ones.get(), 0, L * 4, st));
         k::mark_starts(start.get(), (uint32_t)n, bv.get(), ones.get(), st);
         prims::exclusive_sum_u32(temp, ones.get(), rank.get(), L, st);
-        MMT_HIP(hipStreamSynchronize(st));   // h_start goes out of scope
     }
 };
+
+// device scratch of the fold, kept between calls (one merge per bench step on rank 0)
+struct MergeScratch {
+    DevBuf<uint16_t> nb_left, nb_right, nb_out;
+    DeviceSide da, db;
+    DevBuf<uint64_t> d_pos;
+    DevBuf<uint32_t> d_ra, d_rb, d_len, d_count;
+};
+MergeScratch& scratch() {
+    static thread_local MergeScratch s;
+    return s;
+}
 
 }  // namespace
 
@@ -74,76 +90,86 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
         if (parts[i].thresh_len != L) throw std::runtime_error("partitions disagree on the anchor length");
         if (parts[i].n_rows >= 0xffffffffull) throw std::runtime_error("too many rows in a partition");
     }
-    DevBuf<uint16_t> nb_left, nb_right, nb_out;
+    MergeScratch& M = scratch();
     auto load_thresh = [&](const mmt_partition& p, DevBuf<uint16_t>& dst) {
         dst.ensure(L);
         MMT_HIP(hipMemcpyAsync(dst.get(), p.thresh, L * 2,
                                p.thresh_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     };
-    Side left = load_side(parts[0]);
-    load_thresh(parts[0], nb_left);
-    DeviceSide da, db;
-    DevBuf<uint64_t> d_pos; DevBuf<uint32_t> d_ra, d_rb, d_len, d_count;
-    d_count.ensure(4);
+    Side left = view_side(parts[0]);
+    load_thresh(parts[0], M.nb_left);
+    M.d_count.ensure(4);
     for (size_t pi = 1; pi < k; pi++) {
-        Side right = load_side(parts[pi]);
-        load_thresh(parts[pi], nb_right);
-        nb_out.ensure(L);
-        da.upload(left, L, e.scratch(), st);
-        db.upload(right, L, e.scratch(), st);
+        Side right = view_side(parts[pi]);
+        load_thresh(parts[pi], M.nb_right);
+        M.nb_out.ensure(L);
+        M.da.upload(left, L, e.scratch(), st);
+        M.db.upload(right, L, e.scratch(), st);
         const size_t capacity = left.n_rows() + right.n_rows() + 1;
-        d_pos.ensure(capacity); d_ra.ensure(capacity); d_rb.ensure(capacity); d_len.ensure(capacity);
-        MMT_HIP(hipMemsetAsync(d_count.get(), 0, 16, st));
+        M.d_pos.ensure(capacity); M.d_ra.ensure(capacity); M.d_rb.ensure(capacity); M.d_len.ensure(capacity);
+        MMT_HIP(hipMemsetAsync(M.d_count.get(), 0, 16, st));
         k::FoldArgs a;
-        a.len = L; a.nb_a = nb_left.get(); a.nb_b = nb_right.get(); a.nb_out = nb_out.get();
-        a.rank_a = da.rank.get(); a.rank_b = db.rank.get();
-        a.start_a = da.start.get(); a.start_b = db.start.get();
-        a.len_a = da.len.get(); a.len_b = db.len.get();
-        a.bv_a = da.bv.get(); a.bv_b = db.bv.get();
-        a.out_pos = d_pos.get(); a.out_ra = d_ra.get(); a.out_rb = d_rb.get(); a.out_len = d_len.get();
-        a.capacity = (uint32_t)capacity; a.d_count = d_count.get();
+        a.len = L; a.nb_a = M.nb_left.get(); a.nb_b = M.nb_right.get(); a.nb_out = M.nb_out.get();
+        a.rank_a = M.da.rank.get(); a.rank_b = M.db.rank.get();
+        a.start_a = M.da.start.get(); a.start_b = M.db.start.get();
+        a.len_a = M.da.len.get(); a.len_b = M.db.len.get();
+        a.bv_a = M.da.bv.get(); a.bv_b = M.db.bv.get();
+        a.out_pos = M.d_pos.get(); a.out_ra = M.d_ra.get(); a.out_rb = M.d_rb.get(); a.out_len = M.d_len.get();
+        a.capacity = (uint32_t)capacity; a.d_count = M.d_count.get();
         k::fold_step(a, st);
         uint32_t found = 0;
-        MMT_HIP(hipMemcpyAsync(&found, d_count.get(), 4, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&found, M.d_count.get(), 4, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipStreamSynchronize(st));
         if (found > capacity) throw std::runtime_error("anchor merge produced more rows than MUM starts");
         std::vector<uint64_t> h_pos; std::vector<uint32_t> h_ra, h_rb, h_len;
-        d2h(h_pos, d_pos.get(), found, st); d2h(h_ra, d_ra.get(), found, st);
-        d2h(h_rb, d_rb.get(), found, st); d2h(h_len, d_len.get(), found, st);
+        d2h(h_pos, M.d_pos.get(), found, st); d2h(h_ra, M.d_ra.get(), found, st);
+        d2h(h_rb, M.d_rb.get(), found, st); d2h(h_len, M.d_len.get(), found, st);
         std::vector<uint32_t> order(found);
         std::iota(order.begin(), order.end(), 0u);
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_pos[x] < h_pos[y]; });
         // new rows: fix_neg_strand (merge_candidates.cpp:97-104) + column concatenation (:142-151)
         Side out;
         out.n_docs = left.n_docs + right.n_docs - 1;
-        out.length.resize(found); out.offsets.resize((size_t)found * out.n_docs);
-        out.strands.resize((size_t)found * out.n_docs);
+        out.own_length.resize(found); out.own_offsets.resize((size_t)found * out.n_docs);
+        out.own_strands.resize((size_t)found * out.n_docs);
         for (uint32_t q = 0; q < found; q++) {
-            const uint32_t t = order[q], ra = h_ra[t], rb = h_rb[t], nl = h_len[t];
+            const uint32_t t = order[q], nl = h_len[t];
+            const size_t ra = left.order[h_ra[t]], rb = right.order[h_rb[t]];     // rows in the backing arrays
             const int64_t i = (int64_t)h_pos[t];
-            const int64_t d1 = i - left.offsets[(size_t)ra * left.n_docs], d2 = i - right.offsets[(size_t)rb * right.n_docs];
+            const int64_t d1 = i - left.offsets[ra * left.n_docs], d2 = i - right.offsets[rb * right.n_docs];
             const int64_t s1 = (int64_t)left.length[ra] - d1, s2 = (int64_t)right.length[rb] - d2;
-            int64_t* ro = &out.offsets[(size_t)q * out.n_docs];
-            uint8_t* rs = &out.strands[(size_t)q * out.n_docs];
+            int64_t* ro = &out.own_offsets[(size_t)q * out.n_docs];
+            uint8_t* rs = &out.own_strands[(size_t)q * out.n_docs];
             for (size_t c = 0; c < left.n_docs; c++) {
-                uint8_t sd = left.strands[(size_t)ra * left.n_docs + c];
-                ro[c] = left.offsets[(size_t)ra * left.n_docs + c] + (sd ? d1 : s1 - (int64_t)nl);
+                const uint8_t sd = left.strands[ra * left.n_docs + c];
+                ro[c] = left.offsets[ra * left.n_docs + c] + (sd ? d1 : s1 - (int64_t)nl);
                 rs[c] = sd;
             }
             for (size_t c = 1; c < right.n_docs; c++) {
-                uint8_t sd = right.strands[(size_t)rb * right.n_docs + c];
-                ro[left.n_docs + c - 1] = right.offsets[(size_t)rb * right.n_docs + c] + (sd ? d2 : s2 - (int64_t)nl);
+                const uint8_t sd = right.strands[rb * right.n_docs + c];
+                ro[left.n_docs + c - 1] = right.offsets[rb * right.n_docs + c] + (sd ? d2 : s2 - (int64_t)nl);
                 rs[left.n_docs + c - 1] = sd;
             }
-            out.length[q] = nl;
+            out.own_length[q] = nl;
         }
+        out.length = out.own_length.data(); out.offsets = out.own_offsets.data(); out.strands = out.own_strands.data();
+        out.order.resize(found);
+        std::iota(out.order.begin(), out.order.end(), 0u);   // emitted in anchor order
         left = std::move(out);
-        nb_left.swap(nb_out);
+        left.length = left.own_length.data(); left.offsets = left.own_offsets.data(); left.strands = left.own_strands.data();
+        M.nb_left.swap(M.nb_out);
     }
     MergedRows m;
     m.n_docs = left.n_docs;
-    m.length = std::move(left.length); m.offsets = std::move(left.offsets); m.strands = std::move(left.strands);
-    d2h(m.thresh, nb_left.get(), L, st);
+    const size_t n = left.n_rows();
+    m.length.resize(n); m.offsets.resize(n * m.n_docs); m.strands.resize(n * m.n_docs);
+    for (size_t i = 0; i < n; i++) {
+        const size_t r = left.order[i];
+        m.length[i] = left.length[r];
+        std::copy_n(left.offsets + r * m.n_docs, m.n_docs, &m.offsets[i * m.n_docs]);
+        std::copy_n(left.strands + r * m.n_docs, m.n_docs, &m.strands[i * m.n_docs]);
+    }
+    d2h(m.thresh, M.nb_left.get(), L, st);
     return m;
 }
 

@@ -109,6 +109,8 @@ def main():
         if not merge_mode:
             return eng.output_size()      # the .mums bytes are in (page-locked) host memory at this point
         length, off, st = eng.rows_mum()
+        order = np.argsort(off[:, 0], kind="stable")      # anchor order, so that rank 0's fold need not sort
+        length, off, st = length[order], off[order], st[order]
         th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
         parts = mdist.all_gather_partitions((length, off, st, th), dist, device)
         if rank != 0:

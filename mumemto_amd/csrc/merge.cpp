@@ -3,6 +3,9 @@
 #include "merge.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -83,6 +86,14 @@ MergeScratch& scratch() {
 }  // namespace
 
 MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
+    const bool dbg = std::getenv("MMT_MERGE_DEBUG") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[merge] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+        T0 = t;
+    };
     hipStream_t st = e.stream();
     MMT_HIP(hipSetDevice(e.device()));
     const uint64_t L = parts[0].thresh_len;
@@ -98,13 +109,16 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
     };
     Side left = view_side(parts[0]);
     load_thresh(parts[0], M.nb_left);
+    lap("view part 0");
     M.d_count.ensure(4);
     for (size_t pi = 1; pi < k; pi++) {
         Side right = view_side(parts[pi]);
         load_thresh(parts[pi], M.nb_right);
+        lap("view right");
         M.nb_out.ensure(L);
         M.da.upload(left, L, e.scratch(), st);
         M.db.upload(right, L, e.scratch(), st);
+        lap("upload sides");
         const size_t capacity = left.n_rows() + right.n_rows() + 1;
         M.d_pos.ensure(capacity); M.d_ra.ensure(capacity); M.d_rb.ensure(capacity); M.d_len.ensure(capacity);
         MMT_HIP(hipMemsetAsync(M.d_count.get(), 0, 16, st));
@@ -121,6 +135,7 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
         MMT_HIP(hipMemcpyAsync(&found, M.d_count.get(), 4, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipStreamSynchronize(st));
         if (found > capacity) throw std::runtime_error("anchor merge produced more rows than MUM starts");
+        lap("fold kernel");
         std::vector<uint64_t> h_pos; std::vector<uint32_t> h_ra, h_rb, h_len;
         d2h(h_pos, M.d_pos.get(), found, st); d2h(h_ra, M.d_ra.get(), found, st);
         d2h(h_rb, M.d_rb.get(), found, st); d2h(h_len, M.d_len.get(), found, st);
@@ -158,6 +173,7 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
         left = std::move(out);
         left.length = left.own_length.data(); left.offsets = left.own_offsets.data(); left.strands = left.own_strands.data();
         M.nb_left.swap(M.nb_out);
+        lap("host rows");
     }
     MergedRows m;
     m.n_docs = left.n_docs;
@@ -170,6 +186,7 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
         std::copy_n(left.strands + r * m.n_docs, m.n_docs, &m.strands[i * m.n_docs]);
     }
     d2h(m.thresh, M.nb_left.get(), L, st);
+    lap("final copy");
     return m;
 }
 

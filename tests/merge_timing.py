@@ -17,9 +17,11 @@ for r in reversed(range(G)):
     eng.set_docs(docs)
     t = time.perf_counter(); eng.run(merge_metadata=True); dt = time.perf_counter() - t
     length, off, st = eng.rows_mum()
+    o = np.argsort(off[:, 0], kind='stable'); length, off, st = length[o], off[o], st[o]
     parts.append((length, off, st, eng.thresholds()[: L + 1].copy()))
     print("rank", r, "run %.1f ms rows %d" % (dt * 1e3, len(length)), flush=True)
 parts.reverse()
+os.environ['MMT_MERGE_DEBUG']='1'
 for rep in range(2):
     t = time.perf_counter()
     m = eng.anchor_merge(parts, sort_like_direct=True)

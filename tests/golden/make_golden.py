@@ -64,6 +64,26 @@ def newscan_case(name, lines, w=10, p=100):
     open(os.path.join(d, "params.txt"), "w").write("%d %d\n" % (w, p))
 
 
+def bumbl_case(name, docs, **kw):
+    """<case>/in.mums + in.bumbl: written by the oracle; ref.bumbl / ref.mums: the same rows written
+    by the REFERENCE's Python (mumemto/utils.py MUMdata.write_bums / write_mums after parsing in.mums);
+    ref_from_bumbl.npz: arrays the reference parses out of in.bumbl."""
+    sys.path.insert(0, "/root/reference/mumemto")
+    import importlib
+    utils = importlib.import_module("utils")
+    d = os.path.join(OUT, "bumbl", name)
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    r = O.run(docs, **kw)
+    open(os.path.join(d, "in.mums"), "wb").write(r.text())
+    open(os.path.join(d, "in.bumbl"), "wb").write(r.bumbl())
+    m = utils.MUMdata(os.path.join(d, "in.mums"), sort=False)
+    m.write_bums(os.path.join(d, "ref.bumbl"))
+    m.write_mums(os.path.join(d, "ref.mums"))
+    b = utils.MUMdata(os.path.join(d, "in.bumbl"), sort=False)
+    np.savez(os.path.join(d, "ref_from_bumbl.npz"), lengths=b.lengths, starts=b.starts, strands=b.strands)
+
+
 def main():
     docs = synth.pangenome(6, 4000, 0.01, seed=7, indel_rate=0.002, inversion=(3, 1000, 1400))
     anchor_case("two_way", docs, [[0, 1, 2], [0, 3, 4, 5]])
@@ -84,6 +104,8 @@ def main():
         lines.append(b"F $")
     newscan_case("three_docs_w10_p100", lines)
     newscan_case("three_docs_w4_p11", lines, w=4, p=11)
+    bumbl_case("strict", synth.pangenome(5, 3000, 0.01, seed=21, inversion=(2, 500, 900)))
+    bumbl_case("partial", synth.pangenome(5, 3000, 0.02, seed=22, inversion=(1, 200, 700)), num_distinct=3)
     newscan_case("tiny", [b"F ACGTACGTTTGACCA", b"F $", b"R ACGTACGTTTGACCA", b"F $"], w=3, p=5)
 
 

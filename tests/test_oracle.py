@@ -103,3 +103,21 @@ def test_thresholds_and_accepted_lists():
     # emitted intervals come out in (closing j asc, length desc) order
     k = [(x[3], -x[2]) for x in iv.tolist()]
     assert k == sorted(k)
+
+
+def test_bumbl_bytes_match_the_reference_python_writer():
+    # fixtures by tests/golden/make_golden.py: the same rows written by the REFERENCE's
+    # mumemto/utils.py (MUMdata.write_bums) and parsed back by it
+    G = os.path.join(HERE, "golden", "bumbl")
+    cases = {"strict": (dict(n_haps=5, length=3000, divergence=0.01, seed=21, inversion=(2, 500, 900)), {}),
+             "partial": (dict(n_haps=5, length=3000, divergence=0.02, seed=22, inversion=(1, 200, 700)),
+                         dict(num_distinct=3))}
+    for name, (gen, kw) in cases.items():
+        r = O.run(synth.pangenome(**gen), **kw)
+        assert r.text() == open(os.path.join(G, name, "in.mums"), "rb").read()
+        assert r.bumbl() == open(os.path.join(G, name, "ref.bumbl"), "rb").read()
+        ref = np.load(os.path.join(G, name, "ref_from_bumbl.npz"))
+        L, off, st = r.mum_rows()
+        assert np.array_equal(ref["lengths"], L) and np.array_equal(ref["starts"], off)
+        present = off >= 0
+        assert np.array_equal(np.asarray(ref["strands"], bool)[present], st.astype(bool)[present])

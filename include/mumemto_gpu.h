@@ -69,6 +69,16 @@ MMT_API int mmt_producer_used(const mmt_engine* e);
 /* One pass of the hot path: text -> SA/LCP/BWT -> scan -> rows (+ thresholds). */
 MMT_API int mmt_engine_run(mmt_engine* e, const mmt_params* p);
 
+/* The same job for host-resident input of any size.  When the text would exceed max_text_chars
+ * (0 = the limit of one suffix array in this build, 2^32 - 4097 characters) the documents are
+ * processed as partitions that share document 0 and merged like `anchor_merge` does
+ * (README.md:124-141 of the reference); strict multi-MUMs only, byte-identical to a direct run.   */
+MMT_API int mmt_engine_run_partitioned(mmt_engine* e, const uint8_t* h_bases, const uint64_t* doc_len,
+                                       size_t n_docs, const mmt_params* p, uint64_t max_text_chars);
+MMT_API size_t mmt_partitions_used(const mmt_engine* e);
+/* merged PREFIX.athresh (L_0 + 1 entries) after a partitioned run                                  */
+MMT_API int mmt_copy_merged_thresh(const mmt_engine* e, uint16_t* out);
+
 /* ---- results of the last run (host memory owned by the engine) ------------ */
 MMT_API size_t mmt_num_rows(const mmt_engine* e);
 MMT_API size_t mmt_num_docs(const mmt_engine* e);

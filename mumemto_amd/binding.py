@@ -56,7 +56,8 @@ GPU_ABI_SYMBOLS = [
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
     "mmt_engine_set_producer", "mmt_producer_used", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
-    "mmt_pfp_copy_parse", "mmt_pfp_stage_ms",
+    "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
+    "mmt_copy_merged_thresh",
 ]
 
 
@@ -127,6 +128,11 @@ def load_library():
     L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_pfp_copy_parse.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_pfp_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.mmt_engine_run_partitioned.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Params),
+                                             C.c_uint64]
+    L.mmt_partitions_used.restype = C.c_size_t
+    L.mmt_partitions_used.argtypes = [C.c_void_p]
+    L.mmt_copy_merged_thresh.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_anchor_merge.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.POINTER(C.c_void_p)]
     L.mmt_merged_get.argtypes = [C.c_void_p] * 5
     L.mmt_merged_sort_like_direct.argtypes = [C.c_void_p, C.c_void_p]
@@ -255,6 +261,20 @@ class Engine:
             merge_metadata=False):
         p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
         _check(self.L.mmt_engine_run(self.h, C.byref(p)))
+
+    def run_partitioned(self, docs, max_text_chars=0, min_match_len=20, use_revcomp=True):
+        """Strict multi-MUMs of host-resident docs of any size (anchor partitions + merge when needed)."""
+        lens = np.array([sum(len(r) for r in d) for d in docs], dtype=np.uint64)
+        flat = b"".join(b"".join(d) for d in docs)
+        bases = np.frombuffer(flat, dtype=np.uint8) if flat else np.zeros(1, np.uint8)
+        p = Params(min_match_len, 0, 1, 0, int(use_revcomp), 0)
+        _check(self.L.mmt_engine_run_partitioned(self.h, _p(bases), _p(lens), len(docs), C.byref(p), max_text_chars))
+        return int(self.L.mmt_partitions_used(self.h))
+
+    def merged_thresholds(self, anchor_len):
+        out = np.zeros(anchor_len + 1, np.uint16)
+        _check(self.L.mmt_copy_merged_thresh(self.h, _p(out)))
+        return out
 
     def set_producer(self, kind="auto", w=0, p=0):
         """kind: 'auto' | 'direct' (reference -g path) | 'pfp' (reference default path)."""

@@ -234,6 +234,22 @@ int mmt_engine_run(mmt_engine* e, const mmt_params* p) {
     MMT_CATCH
 }
 
+int mmt_engine_run_partitioned(mmt_engine* e, const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs,
+                               const mmt_params* p, uint64_t max_text_chars) {
+    if (!e || !p || (!doc_len && n_docs)) return fail(1, "engine, params and doc_len must be non-null");
+    MMT_TRY
+    e->e->run_partitioned_host(h_bases, doc_len, n_docs, *p, max_text_chars);
+    MMT_CATCH
+}
+size_t mmt_partitions_used(const mmt_engine* e) { return e ? e->e->partitions_used() : 0; }
+int mmt_copy_merged_thresh(const mmt_engine* e, uint16_t* out) {
+    if (!e) return fail(1, "null");
+    if (!e->e->last_run_partitioned()) return fail(3, "the last run was not partitioned");
+    const std::vector<uint16_t>& t = e->e->merged_thresh();
+    std::memcpy(out, t.data(), t.size() * 2);
+    return 0;
+}
+
 size_t mmt_num_rows(const mmt_engine* e) { return e ? e->e->rows().n_rows : 0; }
 size_t mmt_num_docs(const mmt_engine* e) { return e ? e->e->n_docs() : 0; }
 int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands) {

@@ -83,7 +83,12 @@ int main(int argc, char** argv) {
         }
         t0 = std::chrono::steady_clock::now();
         Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
-        eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
+        uint64_t text_chars = 0;
+        for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
+        const uint64_t max_text = std::getenv("MUMEMTO_MAX_TEXT") ? std::strtoull(std::getenv("MUMEMTO_MAX_TEXT"), nullptr, 10)
+                                                                  : 0xfffff000ull - 1;
+        const bool partitioned = text_chars > max_text;
+        if (!partitioned) eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
         auto write_pfp_files = [&]() {              // PREFIX.dict / PREFIX.parse as newscan.hpp:406-419 writes them
             eng.parse_only(o.use_rcomp, (uint32_t)o.pfp_w, (uint32_t)o.hash_mod);
             std::vector<uint8_t> dict; std::vector<uint32_t> parse;
@@ -91,6 +96,7 @@ int main(int argc, char** argv) {
             write_file(o.output_prefix + ".dict", dict.data(), dict.size());
             write_file(o.output_prefix + ".parse", parse.data(), parse.size() * 4);
         };
+        if (o.only_parse && partitioned) throw CliError{"-P is not available for inputs larger than one suffix array", 1};
         if (o.only_parse) {                         // -P: pfp_mum.cpp:125-127
             write_pfp_files();
             log_line("build_main", "wrote the prefix-free parse (.dict, .parse)");
@@ -103,7 +109,15 @@ int main(int argc, char** argv) {
         p.max_total_freq = o.max_mem_freq;
         p.use_revcomp = o.use_rcomp ? 1 : 0;
         p.merge_metadata = o.merge ? 1 : 0;
-        eng.run(p);
+        if (partitioned) {      // larger than one suffix array: anchor partitions + merge on this GPU
+            if (o.keep_temp || o.arrays_out || (o.merge && !o.anchor_merge))
+                throw CliError{"-K, -A and -M (without -n) are not available for inputs larger than one suffix array", 1};
+            eng.run_partitioned_host(bases.data(), doc_len.data(), doc_len.size(), p, max_text);
+            log_line("build_main", "text of " + std::to_string(text_chars) + " characters processed as " +
+                                       std::to_string(eng.partitions_used()) + " anchor partitions");
+        } else {
+            eng.run(p);
+        }
         const HostRows& R = eng.rows();
         std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n",
                      mum_mode ? "MUM" : "MEM", secs_since(t0));
@@ -112,7 +126,9 @@ int main(int argc, char** argv) {
         else if (o.binary) { const std::string& b = eng.bumbl(); write_file(o.output_prefix + ".bumbl", b.data(), b.size()); }
         else write_file(o.output_prefix + ".mums", R.text, R.text_len);
 
-        if (o.anchor_merge) {                       // mem_finder.hpp:110-115
+        if (o.anchor_merge && partitioned) {
+            write_file(o.output_prefix + ".athresh", eng.merged_thresh().data(), (doc_len[0] + 1) * sizeof(uint16_t));
+        } else if (o.anchor_merge) {                // mem_finder.hpp:110-115
             std::vector<uint16_t> th(eng.thresh_len());
             eng.copy_thresh(th.data());
             write_file(o.output_prefix + ".athresh", th.data(), (doc_len[0] + 1) * sizeof(uint16_t));

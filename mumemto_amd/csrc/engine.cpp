@@ -311,6 +311,7 @@ void Engine::run(const mmt_params& p) {
     auto t0 = std::chrono::steady_clock::now();
     for (auto& ev : ev_) ev->reset();
     for (float& f : stage_ms_) f = 0.f;
+    merged_thresh_valid_ = false;
     rows_ = HostRows();
     rows_.mum_mode = p.max_doc_freq == 1;
     rows_.n_docs = doc_len_.size();

@@ -8,6 +8,7 @@
 #include "../../include/mumemto_gpu.h"
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "merge_types.hpp"
 #include "pfp.hpp"
 #include "sorter.hpp"
 
@@ -40,6 +41,15 @@ public:
     void set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs);
     void set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs);
     void run(const mmt_params& p);
+    // Same job for host-resident input of any size: if the text exceeds max_text characters (0 = the
+    // 32-bit suffix-array limit) the documents are processed as anchor partitions and merged
+    // (strict multi-MUMs only, like the reference's merge).
+    void run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
+                              uint64_t max_text);
+    size_t partitions_used() const { return partitions_used_; }
+    // merged .athresh (L_0 + 1 entries) of the last partitioned run, empty otherwise
+    const std::vector<uint16_t>& merged_thresh() const { return merged_.thresh; }
+    bool last_run_partitioned() const { return merged_thresh_valid_; }
     // SA/LCP/BWT producer: 0 = automatic, 1 = direct suffix sort of the text (A8), 2 = prefix-free parsing (A2-A4)
     void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w ? w : 10; pfp_p_ = p ? p : 100; }
     int producer_used() const { return producer_used_; }
@@ -119,6 +129,10 @@ private:
     PinnedBuf<char> h_text_;
 
     HostRows rows_;
+    MergedRows merged_;
+    std::string merged_text_;
+    size_t partitions_used_ = 1;
+    bool merged_thresh_valid_ = false;
     std::string bumbl_;
     uint64_t num_distinct_eff_ = 0;
     float stage_ms_[8] = {0};

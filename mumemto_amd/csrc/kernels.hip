@@ -780,7 +780,7 @@ __global__ void k_fold_step(FoldArgs a) {
     if (d1 > a.len_a[ra] || d2 > a.len_b[rb]) return;                      // :135
     const uint32_t s1 = (uint32_t)(a.len_a[ra] - d1), s2 = (uint32_t)(a.len_b[rb] - d2);
     const uint32_t nl = s1 < s2 ? s1 : s2;
-    if (nl > nbo && nl >= 20) {                                            // :139-141
+    if (nl > nbo && nl >= a.min_len) {                                            // :139-141
         uint32_t slot = atomicAdd(a.d_count, 1u);
         if (slot < a.capacity) { a.out_pos[slot] = i; a.out_ra[slot] = ra; a.out_rb[slot] = rb; a.out_len[slot] = nl; }
     }

@@ -96,6 +96,7 @@ struct FoldArgs {
     const uint8_t* bv_a; const uint8_t* bv_b;         // MUM start flags per position
     uint64_t* out_pos; uint32_t* out_ra; uint32_t* out_rb; uint32_t* out_len;
     uint32_t capacity; uint32_t* d_count;
+    uint32_t min_len;                   // 20 in the reference (merge_candidates.cpp:141)
 };
 void fold_step(const FoldArgs& a, hipStream_t s);
 void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, uint32_t* ones, hipStream_t s);

@@ -85,7 +85,7 @@ MergeScratch& scratch() {
 
 }  // namespace
 
-MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
+MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len) {
     const bool dbg = std::getenv("MMT_MERGE_DEBUG") != nullptr;
     auto T0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -129,7 +129,7 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k) {
         a.len_a = M.da.len.get(); a.len_b = M.db.len.get();
         a.bv_a = M.da.bv.get(); a.bv_b = M.db.bv.get();
         a.out_pos = M.d_pos.get(); a.out_ra = M.d_ra.get(); a.out_rb = M.d_rb.get(); a.out_len = M.d_len.get();
-        a.capacity = (uint32_t)capacity; a.d_count = M.d_count.get();
+        a.capacity = (uint32_t)capacity; a.d_count = M.d_count.get(); a.min_len = min_len;
         k::fold_step(a, st);
         uint32_t found = 0;
         MMT_HIP(hipMemcpyAsync(&found, M.d_count.get(), 4, hipMemcpyDeviceToHost, st));

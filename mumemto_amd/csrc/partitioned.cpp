@@ -1,0 +1,107 @@
+// partitioned.cpp -- collections whose text does not fit one suffix array.
+//
+// The reference scales the same way (README.md:124-141): split the documents into
+// partitions that share document 0 (the anchor), run each partition with merge metadata
+// (-M -n), fold the partitions (anchor_merge, src/merge_candidates.cpp).  Here the
+// partitions run back to back on one GPU, the fold and the re-sort into direct-run order
+//  run on the same GPU, and the result is byte-identical to a direct run.
+// Like the reference's merge (include/pfp_mum.hpp:178-183) this is defined for strict
+// multi-MUMs only.
+#include <algorithm>
+#include <chrono>
+#include <stdexcept>
+
+#include "engine.hpp"
+#include "merge.hpp"
+
+namespace mmt {
+
+void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
+                                  uint64_t max_text) {
+    MMT_HIP(hipSetDevice(device_));
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t mult = p.use_revcomp ? 2 : 1;
+    std::vector<uint64_t> base(n_docs + 1, 0);
+    uint64_t total = 0;
+    for (size_t d = 0; d < n_docs; d++) { base[d + 1] = base[d] + doc_len[d]; total += mult * (doc_len[d] + 1); }
+    if (max_text == 0) max_text = 0xfffff000ull - 1;
+    partitions_used_ = 1;
+    if (total <= max_text || n_docs < 3) {
+        set_input_host(h_bases, doc_len, n_docs);
+        run(p);
+        return;
+    }
+    const bool strict = p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == n_docs) &&
+                        (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
+    if (!strict)
+        throw std::runtime_error("the text (" + std::to_string(total) + " characters) exceeds one suffix array and only "
+                                 "strict multi-MUMs can be computed by partition + anchor merge");
+    // contiguous groups of documents 1..N-1, each together with the anchor within max_text
+    const uint64_t anchor_chars = mult * (doc_len[0] + 1);
+    std::vector<std::pair<size_t, size_t>> groups;      // [first, last) document indices
+    for (size_t d = 1; d < n_docs;) {
+        uint64_t chars = anchor_chars;
+        size_t e = d;
+        while (e < n_docs && chars + mult * (doc_len[e] + 1) <= max_text) { chars += mult * (doc_len[e] + 1); e++; }
+        if (e == d) throw std::runtime_error("document " + std::to_string(d) + " does not fit next to the anchor");
+        groups.emplace_back(d, e);
+        d = e;
+    }
+    const size_t G = groups.size();
+    const uint64_t L = doc_len[0] + 1;
+    struct Part {
+        std::vector<uint32_t> length; std::vector<int64_t> offsets; std::vector<uint8_t> strands;
+        DevBuf<uint16_t> thresh; size_t n_docs;
+    };
+    std::vector<Part> parts(G);
+    std::vector<uint8_t> sub;
+    std::vector<uint64_t> sub_len;
+    float acc[8] = {0};
+    mmt_params q = p;
+    q.merge_metadata = 1; q.num_distinct = 0; q.max_total_freq = 0;
+    for (size_t g = 0; g < G; g++) {
+        const size_t a = groups[g].first, b = groups[g].second;
+        sub.assign(h_bases, h_bases + doc_len[0]);
+        sub.insert(sub.end(), h_bases + base[a], h_bases + base[b]);
+        sub_len.assign(1, doc_len[0]);
+        sub_len.insert(sub_len.end(), doc_len + a, doc_len + b);
+        set_input_host(sub.data(), sub_len.data(), sub_len.size());
+        run(q);
+        const HostRows& R = rows_;
+        Part& P = parts[g];
+        P.n_docs = sub_len.size();
+        P.length.assign(R.length, R.length + R.n_rows);
+        P.offsets.assign(R.mum_offsets, R.mum_offsets + R.n_rows * P.n_docs);
+        P.strands.assign(R.mum_strands, R.mum_strands + R.n_rows * P.n_docs);
+        P.thresh.ensure(L);
+        MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+        for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
+    }
+    std::vector<mmt_partition> mp(G);
+    for (size_t g = 0; g < G; g++) {
+        mp[g].n_rows = parts[g].length.size(); mp[g].n_docs = parts[g].n_docs;
+        mp[g].length = parts[g].length.data(); mp[g].offsets = parts[g].offsets.data();
+        mp[g].strands = parts[g].strands.data(); mp[g].thresh = parts[g].thresh.get();
+        mp[g].thresh_len = L; mp[g].thresh_on_device = 1;
+    }
+    merged_ = anchor_merge(*this, mp.data(), G, p.min_match_len);
+    sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions
+    merged_text_ = format_merged(merged_);
+    // publish as the result of this "run"
+    doc_len_.assign(doc_len, doc_len + n_docs);
+    HostRows& R = rows_;
+    R = HostRows();
+    R.mum_mode = true; R.n_docs = n_docs; R.n_rows = merged_.length.size();
+    R.length = merged_.length.data(); R.mum_offsets = merged_.offsets.data(); R.mum_strands = merged_.strands.data();
+    h_occ_start_.ensure(2); h_occ_start_.get()[0] = 0; R.occ_start = h_occ_start_.get();
+    R.text = merged_text_.data(); R.text_len = merged_text_.size();
+    bumbl_.clear();
+    num_distinct_eff_ = n_docs;
+    partitions_used_ = G;
+    merged_thresh_valid_ = true;
+    for (int i = 0; i < 7; i++) stage_ms_[i] = acc[i];
+    stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace mmt

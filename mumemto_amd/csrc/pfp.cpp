@@ -40,9 +40,10 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     pk::make_vtext(d_text_.get(), n, w, S.vtext.get(), vlen + 64, st);
     S.flags.ensure(n);
     pk::trigger_flags(d_text_.get(), n, w, p, S.flags.get(), st);
-    S.cuts.ensure(n); S.err.ensure(4);
+    S.err.ensure(4);
+    S.n_cuts = prims::count_nonzero_u8(d_temp_, S.flags.get(), n, S.err.get(), st);   // size the cut list exactly
+    S.cuts.ensure((size_t)S.n_cuts + 1);
     prims::select_indices(d_temp_, S.flags.get(), S.cuts.get(), S.err.get(), n, st);
-    S.n_cuts = read_u32(S.err.get(), st);
     const uint32_t m = S.n_phrases = S.n_cuts + 1;
     S.pstart.ensure(m); S.plen.ensure(m);
     pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), st);
@@ -92,7 +93,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     S.sa_d.ensure(nd); S.rank_d.ensure(nd); S.lcp_d.ensure(nd + 1);
-    sorter_.reserve(std::max(nd, n + 1));
+    sorter_.reserve(std::max(nd, m));
     k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_dict = sorter_.sort(nd, bits * chars, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st);
     e3.stop(st);

@@ -75,4 +75,15 @@ void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin,
     });
 }
 
+uint32_t count_nonzero_u8(DevBuf<uint8_t>& temp, const uint8_t* flags, size_t n, uint32_t* d_scratch, hipStream_t s) {
+    auto as_u32 = rocprim::make_transform_iterator(flags, [] __device__(uint8_t f) -> uint32_t { return f ? 1u : 0u; });
+    with_temp(temp, [&](void* t, size_t& b) {
+        return rocprim::reduce(t, b, as_u32, d_scratch, uint32_t(0), n, rocprim::plus<uint32_t>(), s);
+    });
+    uint32_t v = 0;
+    MMT_HIP(hipMemcpyAsync(&v, d_scratch, 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    return v;
+}
+
 }}  // namespace mmt::prims

@@ -30,4 +30,7 @@ void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s);
 
+// number of non-zero bytes (d_scratch: one u32 on the device); synchronises the stream
+uint32_t count_nonzero_u8(DevBuf<uint8_t>& temp, const uint8_t* flags, size_t n, uint32_t* d_scratch, hipStream_t s);
+
 }}  // namespace mmt::prims

@@ -1,0 +1,71 @@
+"""GPU: collections larger than one suffix array -> anchor partitions on one GPU +
+fold + re-sort == direct run, byte for byte (here the limit is lowered artificially so that
+the oracle can check the result)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from mumemto_amd import build, synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(os.path.dirname(build.LIB), "..", "bin")
+
+
+@pytest.mark.parametrize("min_len", [12, 20, 33])
+@pytest.mark.parametrize("revcomp", [True, False])
+def test_partitioned_equals_direct(min_len, revcomp):
+    import mumemto_amd
+    docs = synth.pangenome(9, 20000, 0.01, seed=51, indel_rate=0.001, inversion=(5, 3000, 6000))
+    eng = mumemto_amd.Engine(0)
+    per_doc = (2 if revcomp else 1) * 20100
+    parts = eng.run_partitioned(docs, max_text_chars=4 * per_doc, min_match_len=min_len, use_revcomp=revcomp)
+    assert parts >= 3
+    direct = O.run(docs, min_len=min_len, revcomp=revcomp, merge=True)
+    assert eng.output_text() == direct.text()
+    L, off, st = eng.rows_mum()
+    wl, wo, ws = direct.mum_rows()
+    assert np.array_equal(L, wl) and np.array_equal(off, wo) and np.array_equal(st, ws)
+    L0 = len(docs[0][0])
+    assert np.array_equal(eng.merged_thresholds(L0), direct.thresh()[: L0 + 1])
+    assert eng.output_bumbl() == direct.bumbl()
+    # below the limit the same call is a plain run
+    assert eng.run_partitioned(docs, max_text_chars=0, min_match_len=min_len, use_revcomp=revcomp) == 1
+    assert eng.output_text() == direct.text()
+    eng.close()
+
+
+def test_partitioned_refuses_non_strict_modes():
+    import ctypes as C
+    import mumemto_amd
+    from mumemto_amd.binding import Params, _p
+    docs = synth.pangenome(5, 3000, 0.01, seed=52)
+    eng = mumemto_amd.Engine(0)
+    lens = np.array([len(d[0]) for d in docs], np.uint64)
+    bases = np.frombuffer(b"".join(d[0] for d in docs), np.uint8)
+    p = Params(20, 4, 1, 0, 1, 0)      # partial multi-MUMs
+    rc = eng.L.mmt_engine_run_partitioned(eng.h, _p(bases), _p(lens), 5, C.byref(p), 10000)
+    assert rc == 3 and b"strict multi-MUMs" in eng.L.mmt_last_error()
+    eng.close()
+
+
+def test_cli_partitions_when_the_text_is_too_large(tmp_path):
+    docs = synth.pangenome(7, 15000, 0.01, seed=53)
+    paths = []
+    for i, d in enumerate(docs):
+        p = tmp_path / ("h%d.fa" % i)
+        synth.write_fasta(str(p), d)
+        paths.append(str(p))
+    env = dict(os.environ, MUMEMTO_MAX_TEXT=str(3 * 2 * 15001 + 10))
+    r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "-o", str(tmp_path / "big"), "-n"] + paths,
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "anchor partitions" in r.stderr
+    direct = O.run(docs, max_total_freq=7, merge=True)
+    assert (tmp_path / "big.mums").read_bytes() == direct.text()
+    assert (tmp_path / "big.athresh").read_bytes() == direct.thresh()[: 15001].tobytes()
+    r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "-o", str(tmp_path / "bad"), "-k", "-1"] + paths,
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "strict multi-MUMs" in r.stderr

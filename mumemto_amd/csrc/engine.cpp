@@ -330,9 +330,12 @@ void Engine::run(const mmt_params& p) {
             const bool reserved = hist[0] || hist[1] || hist[2];
             kind = (env && std::string(env) == "direct") || reserved ? 1 : 2;
         }
-        // the stream does not depend on (w, p): the automatic producer uses short phrases (w 6, p 20),
-        // which shrink the dictionary 2.2x on the bench workload (profiles/round1, pfp sweep)
-        if (kind == 2) suffix_sort_pfp(producer_ == 0 ? 6 : pfp_w_, producer_ == 0 ? 20 : pfp_p_); else suffix_sort();
+        // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
+        // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of
+        // short phrase suffixes (all occurrences of a trigger window) small (gpurun sweeps)
+        const uint32_t auto_w = n_ < (1ull << 30) ? 6 : 10, auto_p = n_ < (1ull << 30) ? 20 : 30;
+        if (kind == 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
+        else suffix_sort();
         producer_used_ = kind;
     }
     ev_[1]->stop(stream_);

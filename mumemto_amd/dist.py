@@ -30,41 +30,53 @@ def merged_column_order(groups):
     return groups[0] + [d for g in groups[1:] for d in g[1:]]
 
 
-def all_gather_partitions(local, dist, device):
+def all_gather_partitions(local, dist, device, host_on_rank=0):
     """local = (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh) where thresh is a
     1-D int16 torch tensor on `device` (the anchor thresholds, L_0+1 entries).
-    Returns the list of every rank's tuple (thresh as torch tensor on `device`).
-    One all_gather for the sizes, one for the padded rows, one for the thresholds."""
+    Four collectives per step (sizes, offsets+lengths, strands, thresholds), each an RCCL
+    all-gather of padded, exactly typed buffers.  Only rank `host_on_rank` (None = every rank)
+    copies the gathered rows back to host numpy arrays -- the other ranks get thresholds only.
+    Returns the list of every rank's tuple (thresh as torch tensor on `device`)."""
     import torch
     length, off, st, thresh = local
     world = dist.get_world_size()
+    rank = dist.get_rank()
     n, nd = off.shape if off.ndim == 2 else (0, 0)
     meta = torch.tensor([n, nd], dtype=torch.int64, device=device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta)
     metas = [m.cpu().tolist() for m in metas]
-    max_n = max(m[0] for m in metas)
-    max_nd = max(m[1] for m in metas)
-    # one padded i64 table per rank: [length | offsets... | strands...]
-    table = np.zeros((max(max_n, 1), 1 + 2 * max(max_nd, 1)), np.int64)
+    max_n = max(max(m[0] for m in metas), 1)
+    max_nd = max(max(m[1] for m in metas), 1)
+    # i64 table [length | offsets...] and u8 table [strands...], padded to the largest partition
+    tab = np.zeros((max_n, 1 + max_nd), np.int64)
+    stt = np.zeros((max_n, max_nd), np.uint8)
     if n:
-        table[:n, 0] = length
-        table[:n, 1:1 + nd] = off
-        table[:n, 1 + max_nd:1 + max_nd + nd] = st
-    t = torch.from_numpy(table).to(device)
-    tables = [torch.zeros_like(t) for _ in range(world)]
+        tab[:n, 0] = length
+        tab[:n, 1:1 + nd] = off
+        stt[:n, :nd] = st
+    t = torch.from_numpy(tab).to(device)
+    u = torch.from_numpy(stt).to(device)
+    tables = [torch.empty_like(t) for _ in range(world)]
+    stables = [torch.empty_like(u) for _ in range(world)]
     dist.all_gather(tables, t)
+    dist.all_gather(stables, u)
     # thresholds travel as raw bytes: neither RCCL nor gloo has a 16-bit integer type
     tbytes = thresh.contiguous().view(torch.uint8)
-    gathered = [torch.zeros_like(tbytes) for _ in range(world)]
+    gathered = [torch.empty_like(tbytes) for _ in range(world)]
     dist.all_gather(gathered, tbytes)
     threshes = [g.view(torch.int16) for g in gathered]
+    want_host = host_on_rank is None or rank == host_on_rank
     parts = []
     for r in range(world):
         rn, rnd = metas[r]
-        tb = tables[r].cpu().numpy()
-        parts.append((tb[:rn, 0].astype(np.uint32), tb[:rn, 1:1 + rnd].copy(),
-                      tb[:rn, 1 + max_nd:1 + max_nd + rnd].astype(np.uint8), threshes[r]))
+        if want_host:
+            tb = tables[r][:rn].cpu().numpy()
+            sb = stables[r][:rn].cpu().numpy()
+            parts.append((tb[:, 0].astype(np.uint32), np.ascontiguousarray(tb[:, 1:1 + rnd]),
+                          np.ascontiguousarray(sb[:, :rnd]), threshes[r]))
+        else:
+            parts.append((None, None, None, threshes[r]))
     return parts
 
 

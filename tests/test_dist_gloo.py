@@ -29,6 +29,8 @@ def _worker(rank, world, port, q):
     L, off, st = r.mum_rows()
     th = torch.from_numpy(r.thresh()[: length + 1].astype(np.int16))
     parts = mdist.all_gather_partitions((L, off, st, th), dist, torch.device("cpu"))
+    if rank != 0:
+        assert all(p[0] is None for p in parts) and len(parts) == world
     if rank == 0:
         host_parts = [(p[0], p[1], p[2], p[3].numpy().view(np.uint16)) for p in parts]
         ml, mo, ms, mth = O.anchor_merge(host_parts)

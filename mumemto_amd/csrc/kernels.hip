@@ -719,9 +719,15 @@ void verify_candidates(const VerifyArgs& a, hipStream_t s) {
         int W = per_wave * 4 <= 144 * 1024 ? 4 : (per_wave * 2 <= 144 * 1024 ? 2 : 1);
         unsigned grid = (unsigned)std::min<uint64_t>((waves_needed + W - 1) / W, 256u * 8u);
         size_t lds = per_wave * W;
-        if (W == 4) hipLaunchKernelGGL(k_verify<4>, dim3(grid), dim3(256), lds, s, a, 1);
-        else if (W == 2) hipLaunchKernelGGL(k_verify<2>, dim3(grid), dim3(128), lds, s, a, 1);
-        else hipLaunchKernelGGL(k_verify<1>, dim3(grid), dim3(64), lds, s, a, 1);
+        auto launch = [&](auto kernel, int threads) {
+            if (lds > 48 * 1024)      // more dynamic LDS than the default launch limit: opt in (160 KiB per CU on gfx950)
+                MMT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, a, 1);
+        };
+        if (W == 4) launch(k_verify<4>, 256);
+        else if (W == 2) launch(k_verify<2>, 128);
+        else launch(k_verify<1>, 64);
     }
     MMT_HIP(hipGetLastError());
 }

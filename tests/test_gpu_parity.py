@@ -153,6 +153,20 @@ def test_many_documents_counter_path(engine):
         assert engine.output_text() == O.run(docs, **m).text()
 
 
+def test_thousands_of_documents(engine):
+    # per-wave LDS counters of 4 bytes per document: 6000 documents need 96 KiB of dynamic LDS per workgroup
+    rng = np.random.default_rng(3)
+    core = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=28))
+    docs = []
+    for d in range(6000):
+        flank = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(3, 9))))
+        docs.append([flank + (core if d % 7 else core[:20] + b"A") + flank[::-1]])
+    for m in (dict(num_distinct=4000, max_doc_freq=2, max_total_freq=0), dict(num_distinct=3000, max_doc_freq=1)):
+        engine.set_docs(docs)
+        engine.run(min_match_len=12, **m)
+        assert engine.output_text() == O.run(docs, min_len=12, **m).text()
+
+
 def test_tiny_and_degenerate_texts(engine):
     for docs in ([[b"A"], [b"A"]], [[b""], [b""]], [[b"ACGT" * 30], [b"ACGT" * 30]], [[b"A" * 200], [b"A" * 150]],
                  [[b"N" * 50 + b"ACGTGGA" * 5], [b"ACGTGGA" * 5 + b"N" * 40]]):

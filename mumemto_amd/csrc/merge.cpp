@@ -14,33 +14,39 @@
 namespace mmt {
 namespace {
 
-// Rows of one side of a fold step, viewed in anchor order: `order[i]` = index of the i-th row by
-// offsets[0] in the backing arrays (parse_candidate sorts them, merge_candidates.cpp:89-92).
+// One side of a fold step, in anchor order.  Rows are kept lazily: a merged row is (anchor start,
+// length) plus, for every source partition g folded so far, the source row and the accumulated
+// shifts of its '+' and '-' columns (fix_neg_strand, merge_candidates.cpp:97-104, applied once per
+// fold step: '+' offsets move by the trim at the front, '-' offsets by the trim at the back).
+// The columns themselves are materialised once, for the rows that survive every fold.
 struct Side {
-    size_t n_docs = 0;
-    const uint32_t* length = nullptr;
-    const int64_t* offsets = nullptr;
-    const uint8_t* strands = nullptr;
-    std::vector<uint32_t> order;
-    // backing storage when the side is the result of a previous fold step
-    std::vector<uint32_t> own_length;
-    std::vector<int64_t> own_offsets;
-    std::vector<uint8_t> own_strands;
-    size_t n_rows() const { return order.size(); }
-    int64_t start(size_t i) const { return offsets[(size_t)order[i] * n_docs]; }
+    size_t n_parts = 0;                 // partitions folded into this side
+    std::vector<uint64_t> start;        // anchor offset of row i
+    std::vector<uint32_t> len;
+    std::vector<uint32_t> src;          // n_rows * n_parts: row index inside partition g
+    std::vector<int64_t> plus, minus;   // n_rows * n_parts accumulated shifts
+    size_t n_rows() const { return start.size(); }
 };
 
-Side view_side(const mmt_partition& p) {
+// parse_candidate(): rows in anchor order (merge_candidates.cpp:89-92)
+Side leaf_side(const mmt_partition& p, uint64_t L) {
     Side s;
-    s.n_docs = p.n_docs; s.length = p.length; s.offsets = p.offsets; s.strands = p.strands;
-    s.order.resize(p.n_rows);
-    std::iota(s.order.begin(), s.order.end(), 0u);
+    s.n_parts = 1;
+    const size_t n = p.n_rows;
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
     bool sorted = true;
-    for (size_t i = 1; i < p.n_rows && sorted; i++) sorted = p.offsets[(i - 1) * p.n_docs] <= p.offsets[i * p.n_docs];
+    for (size_t i = 1; i < n && sorted; i++) sorted = p.offsets[(i - 1) * p.n_docs] <= p.offsets[i * p.n_docs];
     if (!sorted)
-        std::sort(s.order.begin(), s.order.end(), [&](uint32_t a, uint32_t b) {
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
             return p.offsets[(size_t)a * p.n_docs] < p.offsets[(size_t)b * p.n_docs];
         });
+    s.start.resize(n); s.len.resize(n); s.src.resize(n); s.plus.assign(n, 0); s.minus.assign(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const int64_t o = p.offsets[(size_t)order[i] * p.n_docs];
+        if (o < 0 || (uint64_t)o >= L) throw std::runtime_error("anchor offset outside the threshold array");
+        s.start[i] = (uint64_t)o; s.len[i] = p.length[order[i]]; s.src[i] = order[i];
+    }
     return s;
 }
 
@@ -48,21 +54,12 @@ struct DeviceSide {
     DevBuf<uint64_t> start;
     DevBuf<uint32_t> len, ones, rank;
     DevBuf<uint8_t> bv;
-    std::vector<uint64_t> h_start;
-    std::vector<uint32_t> h_len;
     void upload(const Side& s, uint64_t L, DevBuf<uint8_t>& temp, hipStream_t st) {
         const size_t n = s.n_rows();
-        h_start.resize(n); h_len.resize(n);
-        for (size_t r = 0; r < n; r++) {
-            const int64_t o = s.start(r);
-            if (o < 0 || (uint64_t)o >= L) throw std::runtime_error("anchor offset outside the threshold array");
-            h_start[r] = (uint64_t)o;
-            h_len[r] = s.length[s.order[r]];
-        }
         start.ensure(n + 1); len.ensure(n + 1); bv.ensure(L); ones.ensure(L); rank.ensure(L);
         if (n) {
-            MMT_HIP(hipMemcpyAsync(start.get(), h_start.data(), n * 8, hipMemcpyHostToDevice, st));
-            MMT_HIP(hipMemcpyAsync(len.get(), h_len.data(), n * 4, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipMemcpyAsync(start.get(), s.start.data(), n * 8, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipMemcpyAsync(len.get(), s.len.data(), n * 4, hipMemcpyHostToDevice, st));
         }
         MMT_HIP(hipMemsetAsync(bv.get(), 0, L, st));
         MMT_HIP(hipMemsetAsync(ones.get(), 0, L * 4, st));
@@ -107,12 +104,12 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
         MMT_HIP(hipMemcpyAsync(dst.get(), p.thresh, L * 2,
                                p.thresh_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     };
-    Side left = view_side(parts[0]);
+    Side left = leaf_side(parts[0], L);
     load_thresh(parts[0], M.nb_left);
-    lap("view part 0");
     M.d_count.ensure(4);
+    lap("view part 0");
     for (size_t pi = 1; pi < k; pi++) {
-        Side right = view_side(parts[pi]);
+        Side right = leaf_side(parts[pi], L);
         load_thresh(parts[pi], M.nb_right);
         lap("view right");
         M.nb_out.ensure(L);
@@ -142,48 +139,50 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
         std::vector<uint32_t> order(found);
         std::iota(order.begin(), order.end(), 0u);
         std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return h_pos[x] < h_pos[y]; });
-        // new rows: fix_neg_strand (merge_candidates.cpp:97-104) + column concatenation (:142-151)
+        // new rows, lazily: trims of this step added to the shifts of every source partition (:97-104, :142-151)
         Side out;
-        out.n_docs = left.n_docs + right.n_docs - 1;
-        out.own_length.resize(found); out.own_offsets.resize((size_t)found * out.n_docs);
-        out.own_strands.resize((size_t)found * out.n_docs);
+        const size_t np = left.n_parts + 1;
+        out.n_parts = np;
+        out.start.resize(found); out.len.resize(found);
+        out.src.resize((size_t)found * np); out.plus.resize((size_t)found * np); out.minus.resize((size_t)found * np);
         for (uint32_t q = 0; q < found; q++) {
-            const uint32_t t = order[q], nl = h_len[t];
-            const size_t ra = left.order[h_ra[t]], rb = right.order[h_rb[t]];     // rows in the backing arrays
+            const uint32_t t = order[q], nl = h_len[t], ra = h_ra[t], rb = h_rb[t];
             const int64_t i = (int64_t)h_pos[t];
-            const int64_t d1 = i - left.offsets[ra * left.n_docs], d2 = i - right.offsets[rb * right.n_docs];
-            const int64_t s1 = (int64_t)left.length[ra] - d1, s2 = (int64_t)right.length[rb] - d2;
-            int64_t* ro = &out.own_offsets[(size_t)q * out.n_docs];
-            uint8_t* rs = &out.own_strands[(size_t)q * out.n_docs];
-            for (size_t c = 0; c < left.n_docs; c++) {
-                const uint8_t sd = left.strands[ra * left.n_docs + c];
-                ro[c] = left.offsets[ra * left.n_docs + c] + (sd ? d1 : s1 - (int64_t)nl);
-                rs[c] = sd;
+            const int64_t d1 = i - (int64_t)left.start[ra], d2 = i - (int64_t)right.start[rb];
+            const int64_t s1 = (int64_t)left.len[ra] - d1, s2 = (int64_t)right.len[rb] - d2;
+            out.start[q] = (uint64_t)i; out.len[q] = nl;
+            for (size_t g = 0; g < left.n_parts; g++) {
+                out.src[q * np + g] = left.src[ra * left.n_parts + g];
+                out.plus[q * np + g] = left.plus[ra * left.n_parts + g] + d1;
+                out.minus[q * np + g] = left.minus[ra * left.n_parts + g] + (s1 - (int64_t)nl);
             }
-            for (size_t c = 1; c < right.n_docs; c++) {
-                const uint8_t sd = right.strands[rb * right.n_docs + c];
-                ro[left.n_docs + c - 1] = right.offsets[rb * right.n_docs + c] + (sd ? d2 : s2 - (int64_t)nl);
-                rs[left.n_docs + c - 1] = sd;
-            }
-            out.own_length[q] = nl;
+            out.src[q * np + np - 1] = right.src[rb];
+            out.plus[q * np + np - 1] = d2;
+            out.minus[q * np + np - 1] = s2 - (int64_t)nl;
         }
-        out.length = out.own_length.data(); out.offsets = out.own_offsets.data(); out.strands = out.own_strands.data();
-        out.order.resize(found);
-        std::iota(out.order.begin(), out.order.end(), 0u);   // emitted in anchor order
         left = std::move(out);
-        left.length = left.own_length.data(); left.offsets = left.own_offsets.data(); left.strands = left.own_strands.data();
         M.nb_left.swap(M.nb_out);
         lap("host rows");
     }
+    // materialise the surviving rows: partition 0's columns, then every other partition's without its anchor
     MergedRows m;
-    m.n_docs = left.n_docs;
+    m.n_docs = 0;
+    for (size_t g = 0; g < k; g++) m.n_docs += parts[g].n_docs - (g ? 1 : 0);
     const size_t n = left.n_rows();
     m.length.resize(n); m.offsets.resize(n * m.n_docs); m.strands.resize(n * m.n_docs);
     for (size_t i = 0; i < n; i++) {
-        const size_t r = left.order[i];
-        m.length[i] = left.length[r];
-        std::copy_n(left.offsets + r * m.n_docs, m.n_docs, &m.offsets[i * m.n_docs]);
-        std::copy_n(left.strands + r * m.n_docs, m.n_docs, &m.strands[i * m.n_docs]);
+        m.length[i] = left.len[i];
+        size_t col = 0;
+        for (size_t g = 0; g < left.n_parts; g++) {
+            const mmt_partition& P = parts[g];
+            const size_t r = left.src[i * left.n_parts + g];
+            const int64_t ps = left.plus[i * left.n_parts + g], ms = left.minus[i * left.n_parts + g];
+            for (size_t c = g ? 1 : 0; c < P.n_docs; c++, col++) {
+                const uint8_t sd = P.strands[r * P.n_docs + c];
+                m.offsets[i * m.n_docs + col] = P.offsets[r * P.n_docs + c] + (sd ? ps : ms);
+                m.strands[i * m.n_docs + col] = sd;
+            }
+        }
     }
     d2h(m.thresh, M.nb_left.get(), L, st);
     lap("final copy");

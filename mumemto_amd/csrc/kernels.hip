@@ -272,11 +272,26 @@ __global__ void k_lcp_from_isa(const uint8_t* __restrict__ text, uint32_t n, con
         if (h > 0) h--;
     }
 }
+template <int CHUNK>
+static void launch_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
+                       int block, hipStream_t s) {
+    uint64_t threads = ((uint64_t)n + CHUNK - 1) / CHUNK;
+    hipLaunchKernelGGL(k_lcp_from_isa<CHUNK>, dim3(grid_for(threads, block)), dim3(block), 0, s, text, n, sa, isa, lcp);
+}
 void lcp_from_isa(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
                   hipStream_t s) {
-    constexpr int CHUNK = 64;
-    uint64_t threads = ((uint64_t)n + CHUNK - 1) / CHUNK;
-    hipLaunchKernelGGL(k_lcp_from_isa<CHUNK>, dim3(grid_for(threads, 64)), dim3(64), 0, s, text, n, sa, isa, lcp);
+    static int chunk = -1, block = 64;
+    if (chunk < 0) {
+        const char* c = getenv("MMT_LCP_CHUNK"); chunk = c ? atoi(c) : 64;
+        const char* b = getenv("MMT_LCP_BLOCK"); if (b) block = atoi(b);
+    }
+    switch (chunk) {
+        case 16: launch_lcp<16>(text, n, sa, isa, lcp, block, s); break;
+        case 32: launch_lcp<32>(text, n, sa, isa, lcp, block, s); break;
+        case 128: launch_lcp<128>(text, n, sa, isa, lcp, block, s); break;
+        case 256: launch_lcp<256>(text, n, sa, isa, lcp, block, s); break;
+        default: launch_lcp<64>(text, n, sa, isa, lcp, block, s); break;
+    }
     MMT_HIP(hipGetLastError());
 }
 

@@ -172,10 +172,22 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         MMT_HIP(hipMemcpyAsync(S.segb.get() + G, &endv[1], 4, hipMemcpyHostToDevice, st));
         MMT_HIP(hipStreamSynchronize(st));
     }
+    // groups larger than one LDS tile of the emitter get compact slots in the fallback arrays
+    uint32_t* osize = S.gscan.get();                       // scratch of >= G entries (G <= dictionary length)
+    pk::oversize(S.segb.get(), G, osize, st);
+    S.fb_group.ensure((size_t)G + 1);
+    prims::select_indices_u32flags(d_temp_, osize, S.fb_group.get(), S.err.get(), G, st);
+    const uint32_t F = S.n_fallback = read_u32(S.err.get(), st);
+    S.fb_size.ensure((size_t)F + 2); S.fb_off.ensure((size_t)F + 2);
+    uint32_t fb_total = 0;
+    if (F) {
+        k::gather_u32_idx32(osize, S.fb_group.get(), F, S.fb_size.get(), st);
+        MMT_HIP(hipMemsetAsync(S.fb_size.get() + F, 0, 4, st));
+        prims::exclusive_sum_u32(d_temp_, S.fb_size.get(), S.fb_off.get(), (size_t)F + 1, st);
+        fb_total = read_u32(S.fb_off.get() + F, st);
+    }
+    S.xk_a.ensure((size_t)fb_total + 1); S.xv_a.ensure((size_t)fb_total + 1);
     // the emitter
-    const uint32_t fb_cap = 1u << 20;
-    S.xk_a.ensure((size_t)n + 1); S.xv_a.ensure((size_t)n + 1);
-    S.fb_begin.ensure(fb_cap); S.fb_end.ensure(fb_cap);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
     pk::EmitArgs ea;
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
@@ -183,19 +195,17 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
     ea.occ_pos = S.occ_pos.get(); ea.occ_key = S.occ_key.get();
     ea.n = n; ea.sa = d_sa_.get(); ea.rank = d_rank_.get(); ea.bwt = d_bwt_.get();
-    ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.fb_begin = S.fb_begin.get(); ea.fb_end = S.fb_end.get();
-    ea.fb_count = S.err.get(); ea.fb_capacity = fb_cap;
+    ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F;
+    ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
     pk::emit(ea, n + 1, st);
-    S.n_fallback = read_u32(S.err.get(), st);
-    if (S.n_fallback > fb_cap) throw std::runtime_error("too many oversized suffix groups for the PFP emitter");
-    if (S.n_fallback) {      // groups larger than an LDS tile: one segmented radix sort over just those ranges
-        S.xk_b.ensure((size_t)n + 1); S.xv_b.ensure((size_t)n + 1);
-        prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(), n + 1,
-                                               S.n_fallback, S.fb_begin.get(), S.fb_end.get(), shift, st);
-        pk::fallback_finish(S.fb_begin.get(), S.fb_end.get(), S.n_fallback, S.xv_b.get(), d_text_.get(), n,
-                            d_sa_.get(), d_rank_.get(), d_bwt_.get(), S.err.get() + 1, st);
+    if (F) {      // one segmented radix sort over just the oversized groups
+        S.xk_b.ensure((size_t)fb_total + 1); S.xv_b.ensure((size_t)fb_total + 1);
+        prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(),
+                                               fb_total, F, S.fb_off.get(), S.fb_off.get() + 1, shift, st);
+        pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), F, S.segb.get(), S.xv_b.get(), d_text_.get(), n,
+                            d_sa_.get(), d_rank_.get(), d_bwt_.get(), S.err.get(), st);
     }
-    if (read_u32(S.err.get() + 1, st)) throw std::runtime_error("PFP order: the end sentinel is not first");
+    if (read_u32(S.err.get(), st)) throw std::runtime_error("PFP order: the end sentinel is not first");
     S.bwt_ready = true;
     e6.stop(st);
     S.ms[5] = e5.ms(); S.ms[6] = e6.ms();

@@ -448,7 +448,7 @@ struct EmitShared {
 // sa_x / bwt_x.  sorted = false: part of an oversized group; (key, position) go to the fallback arrays.
 template <int BLOCK, int CAP>
 __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
-                                           uint32_t clo, uint32_t L, bool sorted) {
+                                           uint32_t clo, uint32_t L, bool sorted, uint32_t fb_shift) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t E = e1 - e0;
     __syncthreads();
@@ -513,7 +513,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
             const uint32_t key = a.occ_key[sh.efirst[e] + k];
             my_pos[q] = a.occ_pos[sh.efirst[e] + k] + sh.eoffm1[e];
             if (sorted) sh.key[i] = key;
-            else { a.fb_keys[clo + i] = key; a.fb_vals[clo + i] = my_pos[q]; }
+            else { a.fb_keys[clo - fb_shift + i] = key; a.fb_vals[clo - fb_shift + i] = my_pos[q]; }
         }
     }
     if (!sorted) return;
@@ -537,9 +537,9 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
             } while (e2 < E && !sh.egs[e2]);
             const uint32_t out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
             const uint32_t pos = my_pos[q];
-            if (out == 0) { if (pos != a.n) atomicAdd(a.fb_count + 1, 1u); }   // entry 0 must be the end sentinel
+            if (out == 0) { if (pos != a.n) atomicAdd(a.err, 1u); }   // entry 0 must be the end sentinel
             else if (pos < a.n) { a.sa[out - 1] = pos; a.rank[pos] = out - 1; a.bwt[out - 1] = sh.ebwt[e]; }
-            else atomicAdd(a.fb_count + 1, 1u);
+            else atomicAdd(a.err, 1u);
         }
     }
 }
@@ -572,11 +572,18 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
         const uint32_t g2 = sh.bound[2];
         if (g2 > g) {
             const uint32_t clo = a.segb[g];
-            emit_piece<BLOCK, CAP>(a, sh, a.sege[g], a.sege[g2], clo, a.segb[g2] - clo, true);
+            emit_piece<BLOCK, CAP>(a, sh, a.sege[g], a.sege[g2], clo, a.segb[g2] - clo, true, 0u);
             g = g2;
             continue;
         }
-        // a single group larger than CAP: expand it piecewise, unsorted, and queue it for the segmented sort
+        // a single group larger than CAP: expand it piecewise, unsorted, into the compact fallback arrays
+        // (its slot there was assigned by the host-side prefix sum over the oversized groups)
+        if (wave == 0) {
+            const uint32_t f = wave_lower_bound(a.fb_group, a.n_fb, g);      // fb_group[f] == g
+            if (lane == 0) sh.bound[3] = a.segb[g] - a.fb_off[f];            // output offset -> fallback offset
+        }
+        __syncthreads();
+        const uint32_t fb_shift = sh.bound[3];
         const uint32_t e_end = a.sege[g + 1];
         uint32_t e = a.sege[g];
         while (e < e_end) {
@@ -585,8 +592,8 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
             if (c > CAP / 2) {                               // one frequent phrase: plain strided copy
                 const uint32_t first = a.ce_first[e], om1 = a.ce_offm1[e];
                 for (uint32_t k = tid; k < c; k += BLOCK) {
-                    a.fb_keys[base + k] = a.occ_key[first + k];
-                    a.fb_vals[base + k] = a.occ_pos[first + k] + om1;
+                    a.fb_keys[base - fb_shift + k] = a.occ_key[first + k];
+                    a.fb_vals[base - fb_shift + k] = a.occ_pos[first + k] + om1;
                 }
                 e++;
                 continue;
@@ -599,50 +606,61 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
                 // the last of them may end beyond base + CAP: drop it unless it is the only one
                 if (lane == 0) {
                     while (e2 > e + 1 && a.ce_eoff[e2 - 1] + a.ce_cnt[e2 - 1] > base + CAP) e2--;
-                    sh.bound[3] = e2;
+                    sh.bound[2] = e2;
                 }
             }
             __syncthreads();
-            const uint32_t e2 = sh.bound[3];
+            const uint32_t e2 = sh.bound[2];
             const uint32_t endoff = e2 < e_end ? a.ce_eoff[e2] : a.segb[g + 1];
-            emit_piece<BLOCK, CAP>(a, sh, e, e2, base, endoff - base, false);
+            emit_piece<BLOCK, CAP>(a, sh, e, e2, base, endoff - base, false, fb_shift);
             e = e2;
-        }
-        if (tid == 0) {
-            const uint32_t slot = atomicAdd(a.fb_count, 1u);
-            if (slot < a.fb_capacity) { a.fb_begin[slot] = a.segb[g]; a.fb_end[slot] = a.segb[g + 1]; }
         }
         g = g + 1;
     }
 }
 
 void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s) {
-    constexpr int BLOCK = 256, CAP = 2048, TILE = 1024;
+    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP, TILE = 1024;
     const uint32_t tiles = (uint32_t)(((uint64_t)n_out + TILE - 1) / TILE);
     hipLaunchKernelGGL((k_emit<BLOCK, CAP>), dim3(tiles), dim3(BLOCK), 0, s, a, (uint32_t)TILE);
     MMT_HIP(hipGetLastError());
 }
 
-// fallback ranges after their segmented sort: sa_x / bwt_x from the sorted values
-__global__ void k_fallback_finish(const uint32_t* __restrict__ begin, const uint32_t* __restrict__ end, uint32_t n_ranges,
+// osize[g] = size of group g if it exceeds the emitter's LDS tile, else 0
+__global__ void k_oversize(const uint32_t* __restrict__ segb, uint32_t n_groups, uint32_t cap,
+                           uint32_t* __restrict__ osize) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t sz = segb[g + 1] - segb[g];
+    osize[g] = sz > cap ? sz : 0u;
+}
+void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStream_t s) {
+    hipLaunchKernelGGL(k_oversize, dim3(grid_for(n_groups, 256)), dim3(256), 0, s, segb, n_groups, EMIT_CAP, osize);
+    MMT_HIP(hipGetLastError());
+}
+
+// oversized groups after their segmented sort: sa / rank / bwt from the sorted values
+__global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const uint32_t* __restrict__ fb_off,
+                                  uint32_t n_fb, const uint32_t* __restrict__ segb,
                                   const uint32_t* __restrict__ sorted_vals, const uint8_t* __restrict__ text,
                                   uint32_t n, uint32_t* __restrict__ sa, uint32_t* __restrict__ rank,
                                   uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
-    const uint32_t rg = blockIdx.x;
-    if (rg >= n_ranges) return;
-    for (uint32_t i = begin[rg] + threadIdx.x; i < end[rg]; i += blockDim.x) {
-        const uint32_t p = sorted_vals[i];
-        if (i == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
-        sa[i - 1] = p; rank[p] = i - 1;
-        bwt[i - 1] = p ? text[p - 1] : (uint8_t)0;
+    const uint32_t f = blockIdx.x;
+    if (f >= n_fb) return;
+    const uint32_t lo = fb_off[f], hi = fb_off[f + 1], out0 = segb[fb_group[f]];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const uint32_t p = sorted_vals[i], out = out0 + (i - lo);
+        if (out == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
+        sa[out - 1] = p; rank[p] = out - 1;
+        bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;
     }
 }
-void fallback_finish(const uint32_t* begin, const uint32_t* end, uint32_t n_ranges, const uint32_t* sorted_vals,
-                     const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank, uint8_t* bwt, uint32_t* err,
-                     hipStream_t s) {
-    if (!n_ranges) return;
-    hipLaunchKernelGGL(k_fallback_finish, dim3(n_ranges), dim3(256), 0, s, begin, end, n_ranges, sorted_vals, text, n,
-                       sa, rank, bwt, err);
+void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
+                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank,
+                     uint8_t* bwt, uint32_t* err, hipStream_t s) {
+    if (!n_fb) return;
+    hipLaunchKernelGGL(k_fallback_finish, dim3(n_fb), dim3(256), 0, s, fb_group, fb_off, n_fb, segb, sorted_vals, text,
+                       n, sa, rank, bwt, err);
     MMT_HIP(hipGetLastError());
 }
 

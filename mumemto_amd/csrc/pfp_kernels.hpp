@@ -38,6 +38,7 @@ void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift,
               uint32_t* occ_cnt, hipStream_t s);
 void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
                  uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
+static const uint32_t EMIT_CAP = 2048;   // elements of one LDS tile of the emitter
 struct EmitArgs {
     const uint32_t* segb;       // n_groups + 1 group begin offsets in the output (last = n + 1)
     const uint32_t* sege;       // n_groups + 1 compact entry index of every group's first entry
@@ -47,14 +48,16 @@ struct EmitArgs {
     const uint32_t* occ_pos; const uint32_t* occ_key;
     uint32_t n;                 // text length; output stream has n + 1 entries, entry 0 = end sentinel
     uint32_t* sa; uint32_t* rank; uint8_t* bwt;   // n entries each (the sentinel entry is not stored)
-    uint32_t* fb_keys; uint32_t* fb_vals; uint32_t* fb_begin; uint32_t* fb_end;
-    uint32_t* fb_count;         // [0] #oversized groups, [1] consistency errors
-    uint32_t fb_capacity;
+    // oversized groups (more than EMIT_CAP suffixes): ids ascending, compact offsets (n_fb + 1 entries)
+    const uint32_t* fb_group; const uint32_t* fb_off; uint32_t n_fb;
+    uint32_t* fb_keys; uint32_t* fb_vals;     // compact fallback arrays, fb_off[n_fb] entries
+    uint32_t* err;                            // consistency errors
 };
 void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s);
-void fallback_finish(const uint32_t* begin, const uint32_t* end, uint32_t n_ranges, const uint32_t* sorted_vals,
-                     const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank, uint8_t* bwt, uint32_t* err,
-                     hipStream_t s);
+void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStream_t s);
+void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
+                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank,
+                     uint8_t* bwt, uint32_t* err, hipStream_t s);
 void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

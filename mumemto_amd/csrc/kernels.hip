@@ -54,9 +54,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
     for (int i = threadIdx.x; i < 256; i += BLOCK) s_hist[i] = 0;
     __syncthreads();
     const uint64_t p0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 4;   // 4 output bytes per thread
+    uint32_t word = 0, valid = 0;
     if (p0 < n) {
         uint32_t d = doc_lookup(doc_start, n_docs, p0);
-        uint32_t word = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             uint64_t p = p0 + b;
@@ -69,11 +69,26 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
                 else if (local == L) c = '$';
                 else if (local <= 2 * L) c = dev_complement(dev_upper(raw[doc_base[d] + (2 * L - local)]));
                 else c = '$';
-                atomicAdd(&s_hist[c], 1u);
+                valid |= 1u << b;
             }
             word |= (uint32_t)c << (8 * b);
         }
         *reinterpret_cast<uint32_t*>(text + p0) = word;   // buffer is padded past n
+    }
+    // alphabet histogram: a wave holds a handful of distinct bytes, so count per distinct value with
+    // ballots (one LDS atomic per value and byte slot) instead of 64 colliding atomics
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const uint32_t c = (word >> (8 * b)) & 0xffu;
+        uint64_t todo = __ballot((valid >> b) & 1u);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const uint32_t cv = __shfl(c, first, 64);
+            const uint64_t same = __ballot(((valid >> b) & 1u) && c == cv);
+            if ((int)lane == first) atomicAdd(&s_hist[cv], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += BLOCK)

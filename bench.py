@@ -108,15 +108,13 @@ def main():
                 merge_metadata=want_thresh)
         if not merge_mode:
             return eng.output_size()      # the .mums bytes are in (page-locked) host memory at this point
-        length, off, st = eng.rows_mum()
-        order = np.argsort(off[:, 0], kind="stable")      # anchor order, so that rank 0's fold need not sort
-        length, off, st = length[order], off[order], st[order]
+        # rows and thresholds go from this rank's HBM straight into the all-gather; rank 0 folds them in HBM
+        len_t, off_t, st_t = mdist.engine_rows_as_tensors(eng, device)
         th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
-        parts = mdist.all_gather_partitions((length, off, st, th), dist, device)
+        parts = mdist.all_gather_partitions_device((len_t, off_t, st_t, th), dist)
         if rank != 0:
             return b""
-        merged = eng.anchor_merge([(p[0], p[1], p[2], (p[3].data_ptr(), L0 + 1)) for p in parts],
-                                  sort_like_direct=True)
+        merged = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False)
         return merged["text"]
 
     def fence():

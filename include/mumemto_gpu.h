@@ -84,6 +84,10 @@ MMT_API size_t mmt_num_rows(const mmt_engine* e);
 MMT_API size_t mmt_num_docs(const mmt_engine* e);
 /* MUM mode: length[n_rows], offsets[n_rows*n_docs] (-1 absent), strands (1 '+') */
 MMT_API int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands);
+/* the same three tables where the run left them in HBM (valid until the next run): what a
+ * multi-GPU exchange hands to RCCL without a host round trip                    */
+MMT_API int mmt_rows_mum_device(const mmt_engine* e, const uint32_t** length, const int64_t** offsets,
+                                const uint8_t** strands);
 /* MEM mode: occ_start[n_rows+1]; flat offsets / doc ids / strands              */
 MMT_API size_t mmt_num_occ(const mmt_engine* e);
 MMT_API int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start,
@@ -134,21 +138,26 @@ MMT_API int mmt_pfp_stage_ms(const mmt_engine* e, float out[8]);
 /* ---- anchor partition merge (src/merge_candidates.cpp:97-157) -------------- */
 typedef struct mmt_partition {
     uint64_t n_rows, n_docs;
-    const uint32_t* length;   /* host */
-    const int64_t*  offsets;  /* host, n_rows * n_docs, column 0 = anchor      */
-    const uint8_t*  strands;  /* host, 1 = '+'                                 */
+    const uint32_t* length;   /* host or device (see rows_on_device)           */
+    const int64_t*  offsets;  /* n_rows * n_docs, column 0 = anchor            */
+    const uint8_t*  strands;  /* 1 = '+'                                       */
     const uint16_t* thresh;   /* host or device (see thresh_on_device), L_0+1 entries */
     uint64_t thresh_len;
     uint8_t thresh_on_device;
+    uint8_t rows_on_device;   /* length / offsets / strands are HBM pointers   */
 } mmt_partition;
 typedef struct mmt_merged mmt_merged;
 /* Left fold over parts[0..k) exactly as anchor_merge does; the per-position
- * work of every fold step runs on the GPU of `e`.                              */
+ * whole fold runs on the GPU of `e` and the merged rows stay in its HBM until
+ * mmt_merged_get / mmt_merged_text copy them out.                              */
 MMT_API int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out);
 MMT_API size_t mmt_merged_rows(const mmt_merged* m);
 MMT_API size_t mmt_merged_docs(const mmt_merged* m);
-MMT_API int mmt_merged_get(const mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands,
+MMT_API int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands,
                            uint16_t* thresh);
+/* the merged tables in HBM (owned by m)                                        */
+MMT_API int mmt_merged_device(const mmt_merged* m, const uint32_t** length, const int64_t** offsets,
+                              const uint8_t** strands, const uint16_t** thresh);
 /* Re-order merged rows into the order of a direct run (lexicographic by match
  * string) using the anchor suffix ranks of the engine's last run, whose
  * document 0 must be the anchor.                              */

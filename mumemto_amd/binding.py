@@ -40,7 +40,19 @@ class Params(C.Structure):
 class Partition(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("n_docs", C.c_uint64), ("length", C.c_void_p), ("offsets", C.c_void_p),
                 ("strands", C.c_void_p), ("thresh", C.c_void_p), ("thresh_len", C.c_uint64),
-                ("thresh_on_device", C.c_uint8)]
+                ("thresh_on_device", C.c_uint8), ("rows_on_device", C.c_uint8)]
+
+
+class DevicePartition:
+    """One partition's MUM rows and anchor thresholds as HBM addresses (what the multi-GPU exchange
+    produces): length u32[n_rows], offsets i64[n_rows, n_docs], strands u8[n_rows, n_docs],
+    thresh i16/u16[thresh_len].  `keepalive` holds whatever owns the memory."""
+
+    def __init__(self, n_rows, n_docs, length_ptr, offsets_ptr, strands_ptr, thresh_ptr, thresh_len, keepalive=None):
+        self.n_rows, self.n_docs = int(n_rows), int(n_docs)
+        self.length_ptr, self.offsets_ptr, self.strands_ptr = int(length_ptr), int(offsets_ptr), int(strands_ptr)
+        self.thresh_ptr, self.thresh_len = int(thresh_ptr), int(thresh_len)
+        self.keepalive = keepalive
 
 
 C_ABI_SYMBOLS = [
@@ -57,7 +69,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
     "mmt_engine_set_producer", "mmt_producer_used", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
-    "mmt_copy_merged_thresh",
+    "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device",
 ]
 
 
@@ -135,6 +147,8 @@ def load_library():
     L.mmt_copy_merged_thresh.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_anchor_merge.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.POINTER(C.c_void_p)]
     L.mmt_merged_get.argtypes = [C.c_void_p] * 5
+    L.mmt_merged_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
+    L.mmt_rows_mum_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
     L.mmt_merged_sort_like_direct.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_merged_text.restype = C.c_void_p
     L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
@@ -329,6 +343,13 @@ class Engine:
         _check(self.L.mmt_rows_mum(self.h, _p(length), _p(off), _p(st)))
         return length[:n], off[:n], st[:n]
 
+    def rows_mum_device(self):
+        """(n_rows, n_docs, length_ptr, offsets_ptr, strands_ptr): the MUM rows of the last run in HBM,
+        valid until the next run."""
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(self.L.mmt_rows_mum_device(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return (self.L.mmt_num_rows(self.h), self.L.mmt_num_docs(self.h), a.value or 0, b.value or 0, c.value or 0)
+
     def rows_mem(self):
         n, t = self.L.mmt_num_rows(self.h), self.L.mmt_num_occ(self.h)
         length = np.zeros(max(n, 1), np.uint32)
@@ -389,12 +410,19 @@ class Engine:
         return list(out)
 
     # anchor merge
-    def anchor_merge(self, parts, sort_like_direct=False):
-        """parts: list of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh) where thresh is a
-        numpy u16 array (host) or an int device address paired as (ptr, length)."""
+    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True):
+        """parts: list of DevicePartition, or of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh)
+        where thresh is a numpy u16 array (host) or a device address paired as (ptr, length).
+        want_rows=False returns only the PREFIX.mums bytes (no D2H of the tables)."""
         arr = (Partition * len(parts))()
         keep = []
-        for i, (length, off, st, th) in enumerate(parts):
+        for i, part in enumerate(parts):
+            if isinstance(part, DevicePartition):
+                arr[i] = Partition(part.n_rows, part.n_docs, part.length_ptr, part.offsets_ptr, part.strands_ptr,
+                                   part.thresh_ptr, part.thresh_len, 1, 1)
+                keep.append(part)
+                continue
+            length, off, st, th = part
             length = np.ascontiguousarray(length, np.uint32)
             off = np.ascontiguousarray(off, np.int64).reshape(len(length), -1)
             st = np.ascontiguousarray(st, np.uint8).reshape(len(length), -1)
@@ -405,21 +433,25 @@ class Engine:
                 tptr, tlen, on_dev = _p(th).value, len(th), 0
             keep += [length, off, st, th]
             arr[i] = Partition(len(length), off.shape[1], _p(length).value, _p(off).value, _p(st).value, tptr, tlen,
-                               on_dev)
+                               on_dev, 0)
         m = C.c_void_p()
         _check(self.L.mmt_anchor_merge(self.h, arr, len(parts), C.byref(m)))
         try:
             if sort_like_direct:
                 _check(self.L.mmt_merged_sort_like_direct(self.h, m))
             n, nd = self.L.mmt_merged_rows(m), self.L.mmt_merged_docs(m)
+            k = C.c_size_t()
+            ptr = self.L.mmt_merged_text(m, C.byref(k))
+            if not ptr and n:
+                raise MumemtoError(self.L.mmt_last_error().decode())
+            text = C.string_at(ptr, k.value) if k.value else b""
+            if not want_rows:
+                return dict(text=text, n_rows=n, n_docs=nd)
             length = np.zeros(max(n, 1), np.uint32)
             off = np.zeros((max(n, 1), nd), np.int64)
             st = np.zeros((max(n, 1), nd), np.uint8)
             th = np.zeros(int(arr[0].thresh_len), np.uint16)
             _check(self.L.mmt_merged_get(m, _p(length), _p(off), _p(st), _p(th)))
-            k = C.c_size_t()
-            ptr = self.L.mmt_merged_text(m, C.byref(k))
-            text = C.string_at(ptr, k.value) if k.value else b""
             return dict(lengths=length[:n], offsets=off[:n], strands=st[:n], thresh=th, text=text)
         finally:
             self.L.mmt_merged_free(m)

@@ -84,6 +84,8 @@ struct mmt_engine {
 struct mmt_merged {
     mmt::MergedRows rows;
     std::string text;
+    mmt::Engine* engine = nullptr;     // the engine whose device and stream the rows live on
+    bool text_valid = false;
 };
 
 extern "C" {
@@ -263,6 +265,13 @@ int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_
     }
     return 0;
 }
+int mmt_rows_mum_device(const mmt_engine* e, const uint32_t** length, const int64_t** offsets,
+                        const uint8_t** strands) {
+    if (!e || !length || !offsets || !strands) return fail(1, "engine and outputs must be non-null");
+    if (!e->e->rows().mum_mode) return fail(3, "last run was not in MUM mode");
+    e->e->rows_mum_device(length, offsets, strands);
+    return 0;
+}
 size_t mmt_num_occ(const mmt_engine* e) { return e ? e->e->rows().n_occ : 0; }
 int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start, int64_t* offsets, uint64_t* seq_ids,
                  uint8_t* strands) {
@@ -373,13 +382,16 @@ int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_me
     if (k < 2) throw std::invalid_argument("anchor merge requires at least two partitions");
     std::unique_ptr<mmt_merged> m(new mmt_merged());
     m->rows = mmt::anchor_merge(*e->e, parts, k);
+    m->engine = e->e.get();
     *out = m.release();
     MMT_CATCH
 }
-size_t mmt_merged_rows(const mmt_merged* m) { return m ? m->rows.length.size() : 0; }
+size_t mmt_merged_rows(const mmt_merged* m) { return m ? m->rows.n_rows : 0; }
 size_t mmt_merged_docs(const mmt_merged* m) { return m ? m->rows.n_docs : 0; }
-int mmt_merged_get(const mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands, uint16_t* thresh) {
+int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands, uint16_t* thresh) {
     if (!m) return fail(1, "null");
+    MMT_TRY
+    mmt::download_merged(*m->engine, m->rows);
     const mmt::MergedRows& R = m->rows;
     if (!R.length.empty()) {
         std::memcpy(length, R.length.data(), R.length.size() * 4);
@@ -387,18 +399,30 @@ int mmt_merged_get(const mmt_merged* m, uint32_t* length, int64_t* offsets, uint
         std::memcpy(strands, R.strands.data(), R.strands.size());
     }
     if (thresh && !R.thresh.empty()) std::memcpy(thresh, R.thresh.data(), R.thresh.size() * 2);
+    MMT_CATCH
+}
+int mmt_merged_device(const mmt_merged* m, const uint32_t** length, const int64_t** offsets, const uint8_t** strands,
+                      const uint16_t** thresh) {
+    if (!m) return fail(1, "null");
+    if (length) *length = m->rows.d_length.get();
+    if (offsets) *offsets = m->rows.d_offsets.get();
+    if (strands) *strands = m->rows.d_strands.get();
+    if (thresh) *thresh = m->rows.d_thresh.get();
     return 0;
 }
 int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m) {
     if (!e || !m) return fail(1, "null");
     MMT_TRY
     mmt::sort_like_direct(*e->e, m->rows);
-    m->text.clear();
+    m->text.clear(); m->text_valid = false;
     MMT_CATCH
 }
 const char* mmt_merged_text(mmt_merged* m, size_t* len) {
     if (!m) { if (len) *len = 0; return nullptr; }
-    if (m->text.empty()) m->text = mmt::format_merged(m->rows);
+    if (!m->text_valid) {
+        try { m->text = mmt::format_merged(*m->engine, m->rows); m->text_valid = true; }
+        catch (const std::exception& ex) { fail(2, ex.what()); if (len) *len = 0; return nullptr; }
+    }
     if (len) *len = m->text.size();
     return m->text.data();
 }

@@ -49,6 +49,11 @@ public:
     size_t partitions_used() const { return partitions_used_; }
     // merged .athresh (L_0 + 1 entries) of the last partitioned run, empty otherwise
     const std::vector<uint16_t>& merged_thresh() const { return merged_.thresh; }
+    // the MUM-mode rows of the last run as they sit in HBM (valid until the next run)
+    void rows_mum_device(const uint32_t** len, const int64_t** off, const uint8_t** st) const {
+        if (merged_thresh_valid_) { *len = merged_.d_length.get(); *off = merged_.d_offsets.get(); *st = merged_.d_strands.get(); }
+        else { *len = d_olen_.get(); *off = d_ooffs_.get(); *st = d_ost_.get(); }
+    }
     bool last_run_partitioned() const { return merged_thresh_valid_; }
     // SA/LCP/BWT producer: 0 = automatic, 1 = direct suffix sort of the text (A8), 2 = prefix-free parsing (A2-A4)
     void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w ? w : 10; pfp_p_ = p ? p : 100; }

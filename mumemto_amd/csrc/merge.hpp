@@ -10,12 +10,15 @@
 namespace mmt {
 
 // Left fold parts[0] (+) parts[1] (+) ... exactly like anchor_merge's main()
-// (merge_candidates.cpp:208-219); each step's O(L_0) walk is one kernel launch.
-// min_len: minimum length of a merged MUM; the reference hard-codes 20 (its default -l).
+// (merge_candidates.cpp:208-219).  Partitions may hand their rows over in host memory or in HBM
+// (mmt_partition.rows_on_device); everything after the upload runs on the device and the merged
+// rows stay there.  min_len: minimum length of a merged MUM; the reference hard-codes 20.
 MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len = 20);
 // Direct-run order: sort by the suffix rank of the anchor occurrence.
 void sort_like_direct(Engine& e, MergedRows& m);
-// mumsio::write_mums / serialize_mum (include/mumsio.hpp:281-294, :311-320)
-std::string format_merged(const MergedRows& m);
+// mumsio::write_mums / serialize_mum (include/mumsio.hpp:281-294, :311-320), formatted on the device
+std::string format_merged(Engine& e, const MergedRows& m);
+// host copies of the rows and thresholds (m.length / m.offsets / m.strands / m.thresh)
+void download_merged(Engine& e, MergedRows& m);
 
 }  // namespace mmt

@@ -71,10 +71,11 @@ int main(int argc, char** argv) {
             mp[i].n_rows = parts[i].length.size(); mp[i].n_docs = parts[i].n_docs;
             mp[i].length = parts[i].length.data(); mp[i].offsets = parts[i].offsets.data();
             mp[i].strands = parts[i].strands.data(); mp[i].thresh = parts[i].thresh.data();
-            mp[i].thresh_len = parts[i].thresh.size(); mp[i].thresh_on_device = 0;
+            mp[i].thresh_len = parts[i].thresh.size(); mp[i].thresh_on_device = 0; mp[i].rows_on_device = 0;
         }
         mmt::Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
         mmt::MergedRows m = mmt::anchor_merge(eng, mp.data(), mp.size());
+        mmt::download_merged(eng, m);
         bool out_bumbl = ends_with(output, ".bumbl"), out_mums = ends_with(output, ".mums");
         std::string out_path = output;
         if (!out_bumbl && !out_mums) { out_path += ".mums"; out_mums = true; }
@@ -88,7 +89,7 @@ int main(int argc, char** argv) {
             }
             mumsio::write_bumbl(rows, out_path);
         } else {
-            std::string text = mmt::format_merged(m);
+            std::string text = mmt::format_merged(eng, m);
             std::ofstream f(out_path, std::ios::binary);
             f.write(text.data(), (std::streamsize)text.size());
         }

@@ -83,11 +83,12 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
         mp[g].n_rows = parts[g].length.size(); mp[g].n_docs = parts[g].n_docs;
         mp[g].length = parts[g].length.data(); mp[g].offsets = parts[g].offsets.data();
         mp[g].strands = parts[g].strands.data(); mp[g].thresh = parts[g].thresh.get();
-        mp[g].thresh_len = L; mp[g].thresh_on_device = 1;
+        mp[g].thresh_len = L; mp[g].thresh_on_device = 1; mp[g].rows_on_device = 0;
     }
     merged_ = anchor_merge(*this, mp.data(), G, p.min_match_len);
     sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions
-    merged_text_ = format_merged(merged_);
+    merged_text_ = format_merged(*this, merged_);
+    download_merged(*this, merged_);
     // publish as the result of this "run"
     doc_len_.assign(doc_len, doc_len + n_docs);
     HostRows& R = rows_;

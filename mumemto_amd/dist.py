@@ -80,9 +80,71 @@ def all_gather_partitions(local, dist, device, host_on_rank=0):
     return parts
 
 
+def all_gather_partitions_device(local, dist):
+    """The same exchange without leaving the device the tensors live on.
+    local = (length int32[n], offsets int64[n,nd], strands uint8[n,nd], thresh int16[L_0+1]) as torch
+    tensors (HBM under RCCL; CPU tensors under gloo).  Returns, for every rank, a tuple
+    (length, offsets, strands, thresh) of contiguous tensors on that same device."""
+    import torch
+    length, off, st, thresh = local
+    world = dist.get_world_size()
+    device = off.device
+    n, nd = (int(off.shape[0]), int(off.shape[1])) if off.ndim == 2 else (0, 0)
+    meta = torch.tensor([n, nd], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    metas = [m.cpu().tolist() for m in metas]
+    max_n = max(max(m[0] for m in metas), 1)
+    max_nd = max(max(m[1] for m in metas), 1)
+    # padded to the largest partition; one typed collective per table
+    tl = torch.zeros(max_n, dtype=torch.int32, device=device)
+    to = torch.zeros((max_n, max_nd), dtype=torch.int64, device=device)
+    ts = torch.zeros((max_n, max_nd), dtype=torch.uint8, device=device)
+    if n:
+        tl[:n] = length.view(torch.int32)
+        to[:n, :nd] = off
+        ts[:n, :nd] = st
+    gl = [torch.empty_like(tl) for _ in range(world)]
+    go = [torch.empty_like(to) for _ in range(world)]
+    gs = [torch.empty_like(ts) for _ in range(world)]
+    dist.all_gather(gl, tl)
+    dist.all_gather(go, to)
+    dist.all_gather(gs, ts)
+    tbytes = thresh.contiguous().view(torch.uint8)
+    gt = [torch.empty_like(tbytes) for _ in range(world)]
+    dist.all_gather(gt, tbytes)
+    parts = []
+    for r in range(world):
+        rn, rnd = metas[r]
+        parts.append((gl[r][:rn].contiguous(), go[r][:rn, :rnd].contiguous(), gs[r][:rn, :rnd].contiguous(),
+                      gt[r].view(torch.int16)))
+    return parts
+
+
+def device_partitions(parts):
+    """binding.DevicePartition objects over the tensors all_gather_partitions_device returned."""
+    from .binding import DevicePartition
+    return [DevicePartition(p[1].shape[0], p[1].shape[1], p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(),
+                            p[3].data_ptr(), p[3].numel(), keepalive=p) for p in parts]
+
+
 class DevicePointerView:
     """Exposes a raw HBM pointer through __cuda_array_interface__ so that torch can
-    wrap the engine's threshold buffer without a copy."""
+    wrap the engine's buffers (thresholds, row tables) without a copy."""
 
-    def __init__(self, ptr, n, typestr="<i2"):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, shape, typestr="<i2"):
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def engine_rows_as_tensors(eng, device):
+    """(length int32[n], offsets int64[n,nd], strands uint8[n,nd]) torch views of the engine's last MUM rows
+    in HBM -- no copy; valid until the engine's next run."""
+    import torch
+    n, nd, lp, op, sp = eng.rows_mum_device()
+    if n == 0:
+        return (torch.empty(0, dtype=torch.int32, device=device), torch.empty((0, nd), dtype=torch.int64, device=device),
+                torch.empty((0, nd), dtype=torch.uint8, device=device))
+    return (torch.as_tensor(DevicePointerView(lp, (n,), "<i4"), device=device),
+            torch.as_tensor(DevicePointerView(op, (n, nd), "<i8"), device=device),
+            torch.as_tensor(DevicePointerView(sp, (n, nd), "|u1"), device=device))

@@ -16,13 +16,21 @@ for r in reversed(range(G)):
     docs = synth.pangenome_subset(haps, L, 0.005, 2, groups[r])
     eng.set_docs(docs)
     t = time.perf_counter(); eng.run(merge_metadata=True); dt = time.perf_counter() - t
-    length, off, st = eng.rows_mum()
-    o = np.argsort(off[:, 0], kind='stable'); length, off, st = length[o], off[o], st[o]
-    parts.append((length, off, st, eng.thresholds()[: L + 1].copy()))
-    print("rank", r, "run %.1f ms rows %d" % (dt * 1e3, len(length)), flush=True)
+    dev = torch.device("cuda", 0)
+    t = time.perf_counter()
+    lt, ot, stt = mdist.engine_rows_as_tensors(eng, dev)
+    th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L + 1), device=dev)
+    parts.append((lt.clone(), ot.clone(), stt.clone(), th.clone()))
+    torch.cuda.synchronize()
+    print("rank", r, "run %.1f ms rows %d, views+clones %.2f ms" % (dt * 1e3, len(lt), (time.perf_counter() - t) * 1e3), flush=True)
 parts.reverse()
 os.environ['MMT_MERGE_DEBUG']='1'
 for rep in range(2):
     t = time.perf_counter()
-    m = eng.anchor_merge(parts, sort_like_direct=True)
-    print("merge of %d partitions: %.1f ms, %d rows x %d docs, %d bytes" % (G, (time.perf_counter() - t) * 1e3, len(m["lengths"]), m["offsets"].shape[1], len(m["text"])))
+    m = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False)
+    print("merge of %d partitions: %.1f ms, %d rows x %d docs, %d bytes" % (G, (time.perf_counter() - t) * 1e3, m["n_rows"], m["n_docs"], len(m["text"])))
+os.environ.pop('MMT_MERGE_DEBUG')
+for rep in range(3):
+    t = time.perf_counter()
+    m = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False)
+    print("  without debug syncs: %.1f ms" % ((time.perf_counter() - t) * 1e3))

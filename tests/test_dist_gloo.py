@@ -31,6 +31,15 @@ def _worker(rank, world, port, q):
     parts = mdist.all_gather_partitions((L, off, st, th), dist, torch.device("cpu"))
     if rank != 0:
         assert all(p[0] is None for p in parts) and len(parts) == world
+    # the tensor-resident variant (what the GPU ranks use) must hand over the very same partitions
+    tparts = mdist.all_gather_partitions_device(
+        (torch.from_numpy(L.astype(np.int32)), torch.from_numpy(off), torch.from_numpy(st), th), dist)
+    ref = mdist.all_gather_partitions((L, off, st, th), dist, torch.device("cpu"), host_on_rank=None)
+    assert len(tparts) == world
+    for a, b in zip(tparts, ref):
+        assert np.array_equal(a[0].numpy().view(np.uint32), b[0]) and np.array_equal(a[1].numpy(), b[1])
+        assert np.array_equal(a[2].numpy(), b[2]) and torch.equal(a[3], b[3])
+        assert a[1].is_contiguous() and a[2].is_contiguous()
     if rank == 0:
         host_parts = [(p[0], p[1], p[2], p[3].numpy().view(np.uint16)) for p in parts]
         ml, mo, ms, mth = O.anchor_merge(host_parts)

@@ -52,3 +52,57 @@ def test_rccl_exchange_and_device_fold():
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_device_resident_exchange_and_fold():
+    """The bench's N > 1 step: rows and thresholds never leave HBM between the per-partition run, the
+    RCCL all-gather and the fold; only the merged .mums bytes come back."""
+    import torch
+    import torch.distributed as dist
+    import mumemto_amd
+    from mumemto_amd import dist as mdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        device = torch.device("cuda", 0)
+        docs = synth.pangenome(10, 30000, 0.01, seed=23)
+        groups = [[0, 1, 2, 3], [0, 4, 5], [0, 6, 7, 8, 9]]
+        L0 = len(docs[0][0])
+        eng = mumemto_amd.Engine(0, torch.cuda.current_stream(device).cuda_stream)
+        parts = []
+        for g in reversed(groups):
+            eng.set_docs([docs[i] for i in g])
+            eng.run(merge_metadata=True)
+            len_t, off_t, st_t = mdist.engine_rows_as_tensors(eng, device)
+            hl, ho, hs = eng.rows_mum()
+            assert np.array_equal(len_t.cpu().numpy().view(np.uint32), hl)
+            assert np.array_equal(off_t.cpu().numpy(), ho) and np.array_equal(st_t.cpu().numpy(), hs)
+            th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
+            gathered = mdist.all_gather_partitions_device((len_t, off_t, st_t, th), dist)
+            assert len(gathered) == 1 and all(t.is_cuda for t in gathered[0])
+            parts.append(tuple(t.clone() for t in gathered[0]))     # the engine's buffers are reused by the next run
+        parts.reverse()
+        dparts = mdist.device_partitions(parts)
+        merged = eng.anchor_merge(dparts, sort_like_direct=True, want_rows=False)
+        order = mdist.merged_column_order(groups)
+        direct = O.run([docs[i] for i in order], merge=True)
+        assert merged["text"] == direct.text()
+        full = eng.anchor_merge(dparts, sort_like_direct=True)
+        assert full["text"] == direct.text()
+        assert np.array_equal(full["thresh"], direct.thresh()[: L0 + 1])
+        dl, do, ds = direct.mum_rows()
+        assert np.array_equal(full["lengths"], dl) and np.array_equal(full["offsets"], do)
+        assert np.array_equal(full["strands"], ds)
+        # host partitions and device partitions give the same fold
+        host = eng.anchor_merge([(p[0].cpu().numpy().view(np.uint32), p[1].cpu().numpy(), p[2].cpu().numpy(),
+                                  p[3].cpu().numpy().view(np.uint16)) for p in parts])
+        dev = eng.anchor_merge(dparts)
+        for k in ("lengths", "offsets", "strands", "thresh", "text"):
+            assert np.array_equal(host[k], dev[k]) if k != "text" else host[k] == dev[k]
+        eng.close()
+    finally:
+        dist.destroy_process_group()

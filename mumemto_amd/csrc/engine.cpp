@@ -64,7 +64,7 @@ void Engine::build_text(bool revcomp) {
     d_text_.ensure(n_ + 64);
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 4, stream_));
-    MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~3ull), 0, 64 + (n_ & 3ull), stream_));
+    MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~15ull), 0, 64 + (n_ & 15ull), stream_));
     k::build_text(d_bases_, d_doc_base_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, d_text_.get(), n_,
                   d_hist_.get(), stream_);
 }

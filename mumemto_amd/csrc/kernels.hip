@@ -44,63 +44,110 @@ __device__ __forceinline__ uint32_t doc_lookup(const uint64_t* __restrict__ star
     return lo;
 }
 
-template <int BLOCK>
+// 16 output bytes per thread.  A thread whose 16 bytes lie inside one strand of one document (all
+// but a handful per document) does two 8-byte loads, a table lookup per byte (upper-case, or
+// complement of upper-case in reverse order) and one 16-byte store; the others go byte by byte.
+// Alphabet histogram: A C G T N $ are counted in packed registers and reduced across the wave,
+// anything else (rare) goes to the LDS histogram directly.
+__device__ __forceinline__ uint64_t load_u64_raw(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+template <int BLOCK, int MAXD>
 __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict__ raw,
                                                        const uint64_t* __restrict__ doc_base,
                                                        const uint64_t* __restrict__ doc_start, uint32_t n_docs,
-                                                       int revcomp, uint8_t* __restrict__ text, uint64_t n,
+                                                       uint8_t* __restrict__ text, uint64_t n,
                                                        uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_hist[256];
-    for (int i = threadIdx.x; i < 256; i += BLOCK) s_hist[i] = 0;
-    __syncthreads();
-    const uint64_t p0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 4;   // 4 output bytes per thread
-    uint32_t word = 0, valid = 0;
-    if (p0 < n) {
-        uint32_t d = doc_lookup(doc_start, n_docs, p0);
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            uint64_t p = p0 + b;
-            uint8_t c = 0;
-            if (p < n) {
-                while (p >= doc_start[d + 1]) d++;
-                uint64_t L = doc_base[d + 1] - doc_base[d];
-                uint64_t local = p - doc_start[d];
-                if (local < L) c = dev_upper(raw[doc_base[d] + local]);
-                else if (local == L) c = '$';
-                else if (local <= 2 * L) c = dev_complement(dev_upper(raw[doc_base[d] + (2 * L - local)]));
-                else c = '$';
-                valid |= 1u << b;
-            }
-            word |= (uint32_t)c << (8 * b);
-        }
-        *reinterpret_cast<uint32_t*>(text + p0) = word;   // buffer is padded past n
+    __shared__ uint8_t s_up[256], s_rc[256], s_slot[256];
+    __shared__ uint64_t s_start[MAXD + 1], s_base[MAXD + 1];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) {
+        s_hist[i] = 0;
+        const uint8_t u = dev_upper((uint8_t)i);
+        s_up[i] = u; s_rc[i] = dev_complement(u);
+        s_slot[i] = i == 'A' ? 0 : i == 'C' ? 1 : i == 'G' ? 2 : i == 'T' ? 3 : i == 'N' ? 4 : i == '$' ? 5 : 7;
     }
-    // alphabet histogram: a wave holds a handful of distinct bytes, so count per distinct value with
-    // ballots (one LDS atomic per value and byte slot) instead of 64 colliding atomics
-    const uint32_t lane = threadIdx.x & 63;
+    const bool in_lds = n_docs <= (uint32_t)MAXD;
+    if (in_lds)
+        for (uint32_t i = threadIdx.x; i <= n_docs; i += BLOCK) { s_start[i] = doc_start[i]; s_base[i] = doc_base[i]; }
+    __syncthreads();
+    const uint64_t* st = in_lds ? s_start : doc_start;
+    const uint64_t* bs = in_lds ? s_base : doc_base;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
+    uint8_t out[16];
+    uint32_t valid = 0;
+    if (p0 < n) {
+        uint32_t d = doc_lookup(st, n_docs, p0);
+        const uint64_t L = bs[d + 1] - bs[d], local = p0 - st[d];
+        if (local + 16 <= L) {                                              // forward strand
+            const uint8_t* src = raw + bs[d] + local;
+            const uint64_t x = load_u64_raw(src), y = load_u64_raw(src + 8);
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const uint32_t c = (word >> (8 * b)) & 0xffu;
-        uint64_t todo = __ballot((valid >> b) & 1u);
-        while (todo) {
-            const int first = __builtin_ctzll(todo);
-            const uint32_t cv = __shfl(c, first, 64);
-            const uint64_t same = __ballot(((valid >> b) & 1u) && c == cv);
-            if ((int)lane == first) atomicAdd(&s_hist[cv], (uint32_t)__popcll(same));
-            todo &= ~same;
+            for (int b = 0; b < 8; b++) { out[b] = s_up[(x >> (8 * b)) & 0xff]; out[8 + b] = s_up[(y >> (8 * b)) & 0xff]; }
+            valid = 0xffffu;
+        } else if (local > L && local + 15 <= 2 * L) {                      // reverse strand
+            const uint8_t* src = raw + bs[d] + (2 * L - local - 15);
+            const uint64_t x = load_u64_raw(src), y = load_u64_raw(src + 8);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                out[15 - b] = s_rc[(x >> (8 * b)) & 0xff]; out[7 - b] = s_rc[(y >> (8 * b)) & 0xff];
+            }
+            valid = 0xffffu;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint64_t p = p0 + b;
+                uint8_t c = 0;
+                if (p < n) {
+                    while (p >= st[d + 1]) d++;
+                    const uint64_t Ld = bs[d + 1] - bs[d], lo = p - st[d];
+                    if (lo < Ld) c = s_up[raw[bs[d] + lo]];
+                    else if (lo == Ld) c = '$';
+                    else if (lo <= 2 * Ld) c = s_rc[raw[bs[d] + (2 * Ld - lo)]];
+                    else c = '$';
+                    valid |= 1u << b;
+                }
+                out[b] = c;
+            }
         }
+        uint4 w;
+        uint32_t* wp = reinterpret_cast<uint32_t*>(&w);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            wp[q] = (uint32_t)out[4 * q] | ((uint32_t)out[4 * q + 1] << 8) | ((uint32_t)out[4 * q + 2] << 16) |
+                    ((uint32_t)out[4 * q + 3] << 24);
+        *reinterpret_cast<uint4*>(text + p0) = w;                           // buffer is padded past n
+    }
+    uint64_t pa = 0, pb = 0;      // 16-bit counters: pa = A C G T, pb = N $
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        if (!((valid >> b) & 1u)) continue;
+        const uint32_t sl = s_slot[out[b]];
+        const uint64_t inc = 1ull << ((sl & 3u) * 16);
+        if (sl < 4) pa += inc; else if (sl < 6) pb += inc; else atomicAdd(&s_hist[out[b]], 1u);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { pa += __shfl_xor(pa, o, 64); pb += __shfl_xor(pb, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (pa & 0xffffull) atomicAdd(&s_hist['A'], (uint32_t)(pa & 0xffff));
+        if ((pa >> 16) & 0xffffull) atomicAdd(&s_hist['C'], (uint32_t)((pa >> 16) & 0xffff));
+        if ((pa >> 32) & 0xffffull) atomicAdd(&s_hist['G'], (uint32_t)((pa >> 32) & 0xffff));
+        if (pa >> 48) atomicAdd(&s_hist['T'], (uint32_t)(pa >> 48));
+        if (pb & 0xffffull) atomicAdd(&s_hist['N'], (uint32_t)(pb & 0xffff));
+        if ((pb >> 16) & 0xffffull) atomicAdd(&s_hist['$'], (uint32_t)((pb >> 16) & 0xffff));
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += BLOCK)
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
-    (void)revcomp;
 }
 
 void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
-                bool revcomp, uint8_t* text, uint64_t n, uint32_t* hist, hipStream_t s) {
+                bool /*revcomp*/, uint8_t* text, uint64_t n, uint32_t* hist, hipStream_t s) {
     constexpr int B = 256;
-    hipLaunchKernelGGL(k_build_text<B>, dim3(grid_for((n + 3) / 4, B)), dim3(B), 0, s, raw, d_doc_base, d_doc_start,
-                       n_docs, (int)revcomp, text, n, hist);
+    hipLaunchKernelGGL((k_build_text<B, 1023>), dim3(grid_for((n + 15) / 16, B)), dim3(B), 0, s, raw, d_doc_base,
+                       d_doc_start, n_docs, text, n, hist);
     MMT_HIP(hipGetLastError());
 }
 

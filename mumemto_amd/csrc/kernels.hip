@@ -5,6 +5,8 @@
 // Reference behaviour restated by each kernel is cited at its definition.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 #include <cstdlib>
 
@@ -416,8 +418,34 @@ __device__ __forceinline__ uint4 shift4(uint4 lo, uint4 hi, uint32_t r) {
     }
 }
 
+// bytes r..r+3 of the 8 bytes {lo, hi}; r is uniform over the kernel
+__device__ __forceinline__ uint32_t shift4b(uint32_t lo, uint32_t hi, uint32_t r) {
+    return r ? (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * r)) : lo;
+}
+// the byte before each byte of `cur`, given the word before it
+__device__ __forceinline__ uint32_t prev_bytes(uint32_t cur, uint32_t before) { return (cur << 8) | (before >> 24); }
+
 // K0 = min(klev, 3): number of levels fused into the first pass.
-template <int BLOCK, int VG, int K0, int OUT_CAP>
+// EXACT: cap == num_distinct and the BWT test applies (strict multi-MUMs, every -k run without merge
+// metadata).  An interval then has exactly w + 1 entries, so "the BWT bytes are not all equal" is a second
+// window query -- on a sparse OR-table C over the change bytes bwt[t] ^ bwt[t-1], built next to T with the
+// same levels -- and the walk disappears: a queued position is a candidate as soon as lcp[s] < l.
+// LDS byte address of a pointer into shared memory (what M0 / ds instructions take)
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// 64 lanes x 16 bytes from per-lane global addresses to LDS at (wave-uniform) dst + lane * 16.  hipcc does not
+// count this load: it is retired by the explicit vmcnt(0) at the top of the tile that consumes the buffer.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// Workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also drains vmcnt, i.e. the DMA).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT>
 __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint32_t n_tiles, uint32_t w,
                                                 uint32_t klev) {
     constexpr int TILE = BLOCK * VG * 4;
@@ -425,148 +453,241 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     constexpr uint32_t FLUSH_AT = OUT_CAP / 2;
     const uint32_t span = halo + TILE;
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_lcp = reinterpret_cast<uint32_t*>(smem);                    // span + 16
-    uint32_t* s_T = s_lcp + span + 16;                                      // span + 16: T_k[i] = min(lcp[i..i+2^k-1])
-    uint8_t* s_bwt = reinterpret_cast<uint8_t*>(s_T + span + 16);           // 16 + span: [16 + i] = bwt[lds_lo + i]
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(s_bwt + span + 16);     // TILE
+    // two column buffers: while one tile is processed the next one of this workgroup lands in the other by LDS-DMA
+    uint32_t* const lcp_buf = reinterpret_cast<uint32_t*>(smem);           // 2 x (span + 16)
+    uint32_t* const s_T = lcp_buf + 2 * (span + 16);                        // span + 16: T_k[i] = min(lcp[i..i+2^k-1])
+    uint8_t* const bwt_buf = reinterpret_cast<uint8_t*>(s_T + span + 16);   // 2 x (16 + span + 16): [16 + i] = bwt[lds_lo + i]
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(bwt_buf + 2 * (span + 32));   // TILE
+    uint32_t* s_lcp = lcp_buf;
+    uint8_t* s_bwt = bwt_buf;
     Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
-    __shared__ uint32_t s_qn, s_on, s_base;
+    uint32_t* s_C = reinterpret_cast<uint32_t*>(s_out + OUT_CAP);           // EXACT: span / 4 + 8 words of 4 change bytes
+    __shared__ uint32_t s_on, s_base;
     const uint32_t lane = threadIdx.x & 63;
+    uint16_t* my_queue = s_queue + (threadIdx.x >> 6) * (VG * 256);       // VG passes x 64 lanes x 4 positions
     const uint32_t wstep = 1u << klev;
-    const uint32_t rl = (0u - w) & 3u, rr = (0u - wstep) & 3u;              // misalignment of the two query windows
-    const uint32_t* tbl = K0 == 0 ? s_lcp : s_T;                            // level-0 table is the column itself
+    // misalignment of the two query windows; the right one is aligned as soon as its step is a multiple of 4
+    const uint32_t rl = (0u - w) & 3u, rr = K0 >= 2 ? 0u : (0u - wstep) & 3u;
+    const uint32_t* tbl = s_T;
     if (threadIdx.x == 0) { s_on = 0; }
+    bool by_dma = false;
+    uint32_t cur = 0;
+    const uint32_t wave = threadIdx.x >> 6;
 
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // T (and C) of one group of 4 entries from 12 staged values: fused levels 0..K0-1
+    auto fuse_group = [&](uint32_t g) {
+        if (K0 > 0) {
+            const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
+            const uint4 A = l4[g], B = l4[g + 1], C = l4[g + 2];             // entries i..i+11 (tail is padding)
+            uint4 r;
+            if (K0 == 1) {
+                r = make_uint4(umin32(A.x, A.y), umin32(A.y, A.z), umin32(A.z, A.w), umin32(A.w, B.x));
+            } else if (K0 == 2) {
+                const uint32_t m12 = umin32(A.y, A.z), m23 = umin32(A.z, A.w), m01b = umin32(B.x, B.y);
+                r = make_uint4(umin32(umin32(A.x, m12), A.w), umin32(umin32(m12, A.w), B.x),
+                               umin32(m23, m01b), umin32(umin32(A.w, m01b), B.z));
+            } else {
+                const uint32_t mid = umin32(umin32(A.w, B.x), umin32(umin32(B.y, B.z), B.w));  // i+3..i+7
+                const uint32_t a12 = umin32(A.y, A.z), c01 = umin32(C.x, C.y);
+                r = make_uint4(umin32(umin32(A.x, a12), mid), umin32(umin32(a12, mid), C.x),
+                               umin32(umin32(A.z, mid), c01), umin32(umin32(mid, c01), C.z));
+            }
+            reinterpret_cast<uint4*>(s_T)[g] = r;
+        }
+        if (EXACT) {
+            // change bytes x[t] = bwt[t] ^ bwt[t-1] of entries i..i+11, then OR over windows of 2^K0 bytes
+            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(s_bwt + 12) + g;   // word before the group
+            const uint32_t wm = b32[0], w0 = b32[1], w1 = b32[2], w2 = b32[3];
+            const uint32_t x0 = w0 ^ prev_bytes(w0, wm), x1 = w1 ^ prev_bytes(w1, w0), x2 = w2 ^ prev_bytes(w2, w1);
+            uint32_t c;
+            if (K0 == 0) c = x0;
+            else {
+                const uint32_t y0 = x0 | shift4b(x0, x1, 1), y1 = x1 | shift4b(x1, x2, 1);
+                if (K0 == 1) c = y0;
+                else {
+                    const uint32_t z0 = y0 | shift4b(y0, y1, 2);
+                    if (K0 == 2) c = z0;
+                    else {
+                        const uint32_t y2 = x2 | (x2 >> 8);
+                        const uint32_t z1 = y1 | shift4b(y1, y2, 2);
+                        c = z0 | z1;
+                    }
+                }
+            }
+            s_C[g] = c;
+        }
+    };
+
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1u) {
+        s_lcp = lcp_buf + cur * (span + 16);
+        s_bwt = bwt_buf + cur * (span + 32);
+        tbl = K0 == 0 ? s_lcp : s_T;                                        // level-0 table is the column itself
         const uint64_t tile0 = (uint64_t)tile * TILE;
         const uint64_t lds_lo = tile0 >= halo ? tile0 - halo : 0;          // first staged index
         const uint32_t shift = (uint32_t)(tile0 - lds_lo);                  // LDS index of tile0
         const uint64_t hi = tile0 + TILE < a.n ? tile0 + TILE : a.n;       // one past last staged index
+        // interior tiles (full halo, full length: all but the first and the last few) need no bounds checks
+        const bool interior = tile0 >= halo && tile0 + TILE <= a.n;
         const uint32_t staged = (uint32_t)(hi - lds_lo);
         const uint32_t groups = (staged + 3) >> 2;
-        if (threadIdx.x == 0) s_qn = 0;
-        // ---- stage the columns (range starts 16-element aligned: 16-byte loads) ----
-        {
-            const uint32_t vec4 = staged >> 2;
-            const uint4* g4 = reinterpret_cast<const uint4*>(a.lcp + lds_lo);
-            uint4* l4 = reinterpret_cast<uint4*>(s_lcp);
-            for (uint32_t i = threadIdx.x; i < vec4; i += BLOCK) l4[i] = g4[i];
-            for (uint32_t i = (vec4 << 2) + threadIdx.x; i < staged; i += BLOCK) s_lcp[i] = a.lcp[lds_lo + i];
-            const uint32_t vec16 = staged >> 4;
-            const uint4* b4 = reinterpret_cast<const uint4*>(a.bwt + lds_lo);
-            uint4* lb4 = reinterpret_cast<uint4*>(s_bwt + 16);
-            for (uint32_t i = threadIdx.x; i < vec16; i += BLOCK) lb4[i] = b4[i];
-            for (uint32_t i = (vec16 << 4) + threadIdx.x; i < staged; i += BLOCK) s_bwt[16 + i] = a.bwt[lds_lo + i];
-            if (threadIdx.x == 0) s_bwt[15] = lds_lo ? a.bwt[lds_lo - 1] : (uint8_t)0;
-        }
-        __syncthreads();
-        // ---- fused levels 0..K0-1: T[i] = min(lcp[i .. i+W0-1]) from 12 staged values per group ----
-        if (K0 > 0) {
-            const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
-            uint4* t4 = reinterpret_cast<uint4*>(s_T);
-#pragma unroll
-            for (int q = 0; q < MAXG; q++) {
-                const uint32_t g = threadIdx.x + q * BLOCK;
-                if (g < groups) {
-                    const uint4 A = l4[g], B = l4[g + 1], C = l4[g + 2];     // entries i..i+11 (tail is padding)
-                    uint4 r;
-                    if (K0 == 1) {
-                        r = make_uint4(umin32(A.x, A.y), umin32(A.y, A.z), umin32(A.z, A.w), umin32(A.w, B.x));
-                    } else if (K0 == 2) {
-                        const uint32_t m12 = umin32(A.y, A.z), m23 = umin32(A.z, A.w), m01b = umin32(B.x, B.y);
-                        r = make_uint4(umin32(umin32(A.x, m12), A.w), umin32(umin32(m12, A.w), B.x),
-                                       umin32(m23, m01b), umin32(umin32(A.w, m01b), B.z));
-                    } else {
-                        const uint32_t mid = umin32(umin32(A.w, B.x), umin32(umin32(B.y, B.z), B.w));  // i+3..i+7
-                        const uint32_t a12 = umin32(A.y, A.z), c01 = umin32(C.x, C.y);
-                        r = make_uint4(umin32(umin32(A.x, a12), mid), umin32(umin32(a12, mid), C.x),
-                                       umin32(umin32(A.z, mid), c01), umin32(umin32(mid, c01), C.z));
-                    }
-                    t4[g] = r;
-                }
-            }
-            __syncthreads();
-        }
-        // ---- remaining levels (step >= 8): T[i..i+3] = min(T[i..i+3], T[i+step..i+step+3]) ----
-        for (uint32_t lev = K0; lev < klev; lev++) {
-            const uint32_t gstep = (1u << lev) >> 2;
-            uint4* t4 = reinterpret_cast<uint4*>(s_T);
-            uint4 rt[MAXG];
-#pragma unroll
-            for (int q = 0; q < MAXG; q++) {
-                const uint32_t g = threadIdx.x + q * BLOCK;
-                if (g < groups) {
-                    const uint32_t g2 = g + gstep < groups ? g + gstep : groups - 1;
-                    rt[q] = umin4(t4[g], t4[g2]);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < MAXG; q++) {
-                const uint32_t g = threadIdx.x + q * BLOCK;
-                if (g < groups) t4[g] = rt[q];
-            }
-            __syncthreads();
-        }
+        uint32_t qn = 0;                                                    // entries in this wave's queue
 
-        // ---- phase 1: positions whose w-window minimum exceeds their own LCP close something ----
-        {
-            const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
-            const uint4* t4 = reinterpret_cast<const uint4*>(tbl);
+        auto tile_body = [&](auto interior_tag) {
+            constexpr bool INT = decltype(interior_tag)::value;
+            // ---- stage the columns (range starts 16-element aligned: 16-byte loads) ----
+            if (INT && by_dma) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the DMA has landed
+            } else {
+                const uint4* g4 = reinterpret_cast<const uint4*>(a.lcp + lds_lo);
+                uint4* l4 = reinterpret_cast<uint4*>(s_lcp);
+                const uint4* b4 = reinterpret_cast<const uint4*>(a.bwt + lds_lo);
+                uint4* lb4 = reinterpret_cast<uint4*>(s_bwt + 16);
+                if (INT) {
 #pragma unroll
-            for (int q = 0; q < VG; q++) {
-                const uint32_t o = (threadIdx.x + q * BLOCK) * 4;               // offset in tile of 4 positions
-                const uint32_t lj = shift + o;                                  // LDS index, multiple of 4
-                uint32_t takes = 0;
-                if (tile0 + o < a.n && lj + 3 >= w) {
-                    const uint4 closing = l4[lj >> 2];
-                    // windows start at lj - w + t (left) and lj - wstep + t (right), t = 0..3
-                    uint4 L, R;
-                    {
+                    for (int q = 0; q < VG; q++) l4[threadIdx.x + q * BLOCK] = g4[threadIdx.x + q * BLOCK];
+                    if (threadIdx.x < (halo >> 2)) l4[VG * BLOCK + threadIdx.x] = g4[VG * BLOCK + threadIdx.x];
+                    for (uint32_t i = threadIdx.x; i < (span >> 4); i += BLOCK) lb4[i] = b4[i];
+                } else {
+                    const uint32_t vec4 = staged >> 2;
+                    for (uint32_t i = threadIdx.x; i < vec4; i += BLOCK) l4[i] = g4[i];
+                    for (uint32_t i = (vec4 << 2) + threadIdx.x; i < staged; i += BLOCK) s_lcp[i] = a.lcp[lds_lo + i];
+                    const uint32_t vec16 = staged >> 4;
+                    for (uint32_t i = threadIdx.x; i < vec16; i += BLOCK) lb4[i] = b4[i];
+                    for (uint32_t i = (vec16 << 4) + threadIdx.x; i < staged; i += BLOCK) s_bwt[16 + i] = a.bwt[lds_lo + i];
+                }
+                if (threadIdx.x == 0) s_bwt[15] = lds_lo ? a.bwt[lds_lo - 1] : (uint8_t)0;
+            }
+            lds_barrier();
+            {   // send the next tile of this workgroup to the other buffer (interior tiles only)
+                const uint32_t nt = tile + gridDim.x;
+                const uint64_t nt0 = (uint64_t)nt * TILE;
+                by_dma = nt < n_tiles && nt0 >= (uint64_t)halo + 16 && nt0 + TILE <= a.n;
+                if (by_dma) {
+                    const uint64_t nlo = nt0 - halo;
+                    const uint32_t other = cur ^ 1u;
+                    const uint8_t* gl = reinterpret_cast<const uint8_t*>(a.lcp + nlo);
+                    const uint32_t l_dst = lds_offset(lcp_buf + other * (span + 16));
+                    const uint32_t l_bytes = span * 4;
+                    for (uint32_t off = wave * 1024; off < l_bytes; off += (BLOCK / 64) * 1024)
+                        if (off + lane * 16 < l_bytes) glds16(gl + off + lane * 16, l_dst + off);
+                    const uint8_t* gb = a.bwt + nlo - 16;                   // [15] = the byte before the staged range
+                    const uint32_t b_dst = lds_offset(bwt_buf + other * (span + 32));
+                    const uint32_t b_bytes = span + 16;
+                    for (uint32_t off = wave * 1024; off < b_bytes; off += (BLOCK / 64) * 1024)
+                        if (off + lane * 16 < b_bytes) glds16(gb + off + lane * 16, b_dst + off);
+                }
+            }
+            // ---- fused levels 0..K0-1 ----
+            if (K0 > 0 || EXACT) {
+                if (INT) {
+#pragma unroll
+                    for (int q = 0; q < VG; q++) fuse_group(threadIdx.x + q * BLOCK);
+                    if (threadIdx.x < (halo >> 2)) fuse_group(VG * BLOCK + threadIdx.x);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < MAXG; q++) {
+                        const uint32_t g = threadIdx.x + q * BLOCK;
+                        if (g < groups) fuse_group(g);
+                    }
+                }
+                lds_barrier();
+            }
+            // ---- remaining levels (step >= 8): T[i..i+3] = min(T[i..i+3], T[i+step..i+step+3]) ----
+            for (uint32_t lev = K0; lev < klev; lev++) {
+                const uint32_t gstep = (1u << lev) >> 2;
+                uint4* t4 = reinterpret_cast<uint4*>(s_T);
+                uint4 rt[MAXG];
+                uint32_t rc[MAXG];
+#pragma unroll
+                for (int q = 0; q < MAXG; q++) {
+                    const uint32_t g = threadIdx.x + q * BLOCK;
+                    if (g < groups) {
+                        const uint32_t g2 = g + gstep < groups ? g + gstep : groups - 1;
+                        rt[q] = umin4(t4[g], t4[g2]);
+                        if (EXACT) rc[q] = s_C[g] | s_C[g2];
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < MAXG; q++) {
+                    const uint32_t g = threadIdx.x + q * BLOCK;
+                    if (g < groups) { t4[g] = rt[q]; if (EXACT) s_C[g] = rc[q]; }
+                }
+                lds_barrier();
+            }
+
+            // ---- phase 1: positions whose w-window minimum exceeds their own LCP close something ----
+            {
+                const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
+                const uint4* t4 = reinterpret_cast<const uint4*>(tbl);
+#pragma unroll
+                for (int q = 0; q < VG; q++) {
+                    const uint32_t o = (threadIdx.x + q * BLOCK) * 4;               // offset in tile of 4 positions
+                    const uint32_t lj = shift + o;                                  // LDS index, multiple of 4
+                    uint32_t takes = 0;
+                    if (INT || (tile0 + o < a.n && lj + 3 >= w)) {
+                        const uint4 closing = l4[lj >> 2];
+                        // windows start at lj - w + t (left) and lj - wstep + t (right), t = 0..3;
                         // floor((lj - w) / 4) without going negative: lj + 3 >= w guarantees lj - w >= -3
-                        const int32_t s0 = (int32_t)lj - (int32_t)w;
-                        const int32_t g0 = s0 >= 0 ? (s0 >> 2) : -1;
-                        const uint4 lo = g0 >= 0 ? t4[g0] : make_uint4(0, 0, 0, 0);
-                        const uint4 hi4 = t4[g0 + 1];
-                        L = shift4(lo, hi4, rl);
-                        const int32_t s1 = (int32_t)lj - (int32_t)wstep;
-                        const int32_t g1 = s1 >= 0 ? (s1 >> 2) : -1;
-                        const uint4 lo1 = g1 >= 0 ? t4[g1] : make_uint4(0, 0, 0, 0);
-                        const uint4 hi1 = t4[g1 + 1];
-                        R = shift4(lo1, hi1, rr);
-                    }
-                    const uint4 M = umin4(L, R);
-                    const uint64_t j0 = tile0 + o;
-                    const uint32_t mv[4] = {M.x, M.y, M.z, M.w}, cv[4] = {closing.x, closing.y, closing.z, closing.w};
+                        const int32_t s0 = (int32_t)lj - (int32_t)w, s1 = (int32_t)lj - (int32_t)wstep;
+                        const int32_t g0 = (INT || s0 >= 0) ? (s0 >> 2) : -1, g1 = (INT || s1 >= 0) ? (s1 >> 2) : -1;
+                        const uint4 lo = (INT || g0 >= 0) ? t4[g0] : make_uint4(0, 0, 0, 0);
+                        const uint4 lo1 = (INT || g1 >= 0) ? t4[g1] : make_uint4(0, 0, 0, 0);
+                        const uint4 M = umin4(shift4(lo, t4[g0 + 1], rl), K0 >= 2 ? lo1 : shift4(lo1, t4[g1 + 1], rr));
+                        const uint32_t mv[4] = {M.x, M.y, M.z, M.w}, cv[4] = {closing.x, closing.y, closing.z, closing.w};
+                        uint32_t chg4 = 0xffffffffu;
+                        if (EXACT) {
+                            const uint32_t cl = (INT || g0 >= 0) ? s_C[g0] : 0u, cr = (INT || g1 >= 0) ? s_C[g1] : 0u;
+                            chg4 = shift4b(cl, s_C[g0 + 1], rl) | (K0 >= 2 ? cr : shift4b(cr, s_C[g1 + 1], rr));
+                        }
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const uint64_t j = j0 + t;
-                        const bool ok = j >= 1 && j < a.n && lj + t >= w && mv[t] > cv[t] && mv[t] >= a.min_len;
-                        takes |= ok ? (1u << t) : 0u;
+                        for (int t = 0; t < 4; t++) {
+                            bool ok = mv[t] > cv[t] && mv[t] >= a.min_len;
+                            if (!INT) ok = ok && tile0 + o + t >= 1 && tile0 + o + t < a.n && lj + t >= w;
+                            if (EXACT) ok = ok && ((chg4 >> (8 * t)) & 0xffu);
+                            takes |= ok ? (1u << t) : 0u;
+                        }
                     }
-                }
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const bool take = (takes >> t) & 1u;
-                    const uint64_t mask = __ballot(take);
-                    uint32_t base = 0;
-                    if (lane == 0 && mask) base = atomicAdd(&s_qn, (uint32_t)__popcll(mask));
-                    base = __shfl(base, 0, 64);
-                    if (take) s_queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = (uint16_t)(o + t);
+                    if (__ballot(takes) == 0) continue;                             // nothing to queue in this wave
+                    // compaction into this wave's queue: four ballots, the chained mbcnt of all four gives the
+                    // number of taken positions in lower lanes; no LDS atomic, no cross-wave traffic
+                    const uint64_t m0 = __ballot(takes & 1u), m1 = __ballot(takes & 2u), m2 = __ballot(takes & 4u),
+                                   m3 = __ballot(takes & 8u);
+                    uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, qn));
+                    at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, at));
+                    at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, at));
+                    at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, at));
+                    if (takes & 1u) my_queue[at++] = (uint16_t)o;
+                    if (takes & 2u) my_queue[at++] = (uint16_t)(o + 1);
+                    if (takes & 4u) my_queue[at++] = (uint16_t)(o + 2);
+                    if (takes & 8u) my_queue[at] = (uint16_t)(o + 3);
+                    qn += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
                 }
             }
-        }
-        __syncthreads();
-        const uint32_t qn = s_qn;
+        };
+        if (interior) tile_body(std::true_type{}); else tile_body(std::false_type{});
+        __builtin_amdgcn_wave_barrier();     // the queue is private to the wave: LDS keeps its writes and reads in order
 
-        // ---- phase 2: finish the walk from s = j - w - 1 leftwards ----
-        for (uint32_t wi = threadIdx.x; wi < qn; wi += BLOCK) {
-            const uint32_t o = s_queue[wi];
+        // ---- phase 2: every wave drains its own queue ----
+        for (uint32_t wi = lane; wi < qn; wi += 64) {
+            const uint32_t o = my_queue[wi];
             const uint32_t lj = shift + o;
             const uint32_t closing = s_lcp[lj];
             uint32_t m = umin32(tbl[lj - w], tbl[lj - wstep]);
-            bool chg = false;
             uint32_t lk = lj - w;                                           // LDS index of k; candidate start s = k - 1
+            if (EXACT) {
+                // the only interval this position can close has w + 1 entries and its BWT bytes differ
+                if (lk > 0 && s_lcp[lk - 1] < m) {
+                    Cand c; c.start = (uint32_t)(lds_lo + lk - 1); c.end = (uint32_t)(lds_lo + lj - 1); c.len = m;
+                    c.flags = CAND_LEFT_MAXIMAL;
+                    uint32_t slot = atomicAdd(&s_on, 1u);
+                    if (slot < OUT_CAP) s_out[slot] = c;
+                    else { uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
+                }
+                continue;
+            }
+            // general case: finish the walk from s = j - w - 1 leftwards
+            bool chg = false;
             {   // BWT bytes of [k, j-1] not all equal?  (s_bwt is offset by 16)
                 const uint8_t b0 = s_bwt[16 + lj - 1];
                 for (uint32_t t = lk; t + 1 < lj; t++) chg |= s_bwt[16 + t] != b0;
@@ -613,19 +734,19 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         const uint32_t filled = s_on < OUT_CAP ? s_on : OUT_CAP;
         const bool last = tile + gridDim.x >= n_tiles;
         if (filled >= FLUSH_AT || (last && filled)) {
             if (threadIdx.x == 0) s_base = atomicAdd(a.d_count, filled);
-            __syncthreads();
+            lds_barrier();
             const uint32_t base = s_base;
             for (uint32_t i = threadIdx.x; i < filled; i += BLOCK)
                 if (base + i < a.capacity) a.out[base + i] = s_out[i];
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0) s_on = 0;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -634,43 +755,58 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     constexpr int TILE = B * VG * 4;
     uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
     uint32_t w = nd - 1;
-    if (w > 1000) w = 1;                                   // window tables need w <= halo <= 4 * BLOCK
+    bool exact = a.cap != 0 && a.cap == nd && !a.emit_all && nd == a.num_distinct;
+    if (w > 1000) { w = 1; exact = false; }                // window tables need w <= halo <= 4 * BLOCK
     uint32_t klev = 0;
     while ((2u << klev) <= w) klev++;                      // floor(log2(w))
     uint32_t halo = a.cap ? a.cap + 1 : 256;
     if (halo < w + 1) halo = w + 1;
     halo = (halo + 15) & ~15u;
     if (halo > 4 * B) halo = 4 * B;                        // beyond this the walk reads the cached global columns
-    size_t lds = (size_t)(halo + TILE + 16) * 9 + 16 + (size_t)TILE * 2 + (size_t)OUT_CAP * sizeof(Cand);
+    if (halo < w + 1) exact = false;
+    size_t lds = (size_t)(halo + TILE + 16) * 12 + (size_t)(halo + TILE + 32) * 2 + (size_t)TILE * 2 +
+                 (size_t)OUT_CAP * sizeof(Cand) + (exact ? (size_t)(halo + TILE + 32) : 0);
     uint32_t n_tiles = grid_for(a.n, TILE);
     unsigned grid = n_tiles < 256u * blocks_per_cu ? n_tiles : 256u * blocks_per_cu;
     dim3 g(grid), b(B);
-    switch (klev < 3 ? klev : 3) {
-        case 0: hipLaunchKernelGGL((k_scan<B, VG, 0, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
-        case 1: hipLaunchKernelGGL((k_scan<B, VG, 1, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
-        case 2: hipLaunchKernelGGL((k_scan<B, VG, 2, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
-        default: hipLaunchKernelGGL((k_scan<B, VG, 3, OUT_CAP>), g, b, lds, s, a, halo, n_tiles, w, klev); break;
+    auto go = [&](auto kernel) {
+        MMT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+        hipLaunchKernelGGL(kernel, g, b, lds, s, a, halo, n_tiles, w, klev);
+    };
+    const uint32_t k0 = klev < 3 ? klev : 3;
+    if (exact) {
+        switch (k0) {
+            case 0: go(k_scan<B, VG, 0, OUT_CAP, true>); break;
+            case 1: go(k_scan<B, VG, 1, OUT_CAP, true>); break;
+            case 2: go(k_scan<B, VG, 2, OUT_CAP, true>); break;
+            default: go(k_scan<B, VG, 3, OUT_CAP, true>); break;
+        }
+    } else {
+        switch (k0) {
+            case 0: go(k_scan<B, VG, 0, OUT_CAP, false>); break;
+            case 1: go(k_scan<B, VG, 1, OUT_CAP, false>); break;
+            case 2: go(k_scan<B, VG, 2, OUT_CAP, false>); break;
+            default: go(k_scan<B, VG, 3, OUT_CAP, false>); break;
+        }
     }
     MMT_HIP(hipGetLastError());
 }
 
 void scan_intervals(const ScanArgs& a, hipStream_t s) {
     if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
-    // measured on MI355X (profiles/round1_b): 512 threads x 8 positions per thread is best for small
-    // windows (16 docs: 0.88 ms / 387 M suffixes), 512 x 12 for wide ones (94 docs: 0.92 ms / 376 M)
-    static int variant = -1, bpc = 6;     // 1536 workgroups: 61.5 tiles each on the bench workload (sweep6)
+    // measured on MI355X (tests/scan_sweep.sh, profiles/): workgroups of 256 threads x 8 positions (39.7 KB of LDS
+    // with both column buffers: four resident workgroups per CU) and a grid of 16 per CU are best for 16 and for
+    // 94 documents alike; 512 x 8 is 5 % slower, 512 x 12 leaves one workgroup per CU.
+    static int variant = -1, bpc = 16;
     if (variant < 0) {
         const char* v = getenv("MMT_SCAN_VARIANT"); variant = v ? atoi(v) : 0;
         const char* g = getenv("MMT_SCAN_BPC"); if (g) bpc = atoi(g);
     }
     switch (variant) {
-        case 1: launch_scan<256, 2, 512>(a, s, bpc); break;
-        case 2: launch_scan<512, 2, 512>(a, s, bpc); break;
-        case 3: launch_scan<512, 3, 512>(a, s, bpc); break;
-        default:
-            if (a.num_distinct > 32) launch_scan<512, 3, 512>(a, s, bpc);
-            else launch_scan<512, 2, 512>(a, s, bpc);
-            break;
+        case 1: launch_scan<512, 1, 256>(a, s, bpc); break;
+        case 2: launch_scan<512, 2, 256>(a, s, bpc); break;
+        default: launch_scan<256, 2, 256>(a, s, bpc); break;
     }
 }
 

@@ -1,0 +1,35 @@
+"""GPU box helper (run in a subprocess with MMT_SCAN_VARIANT / MMT_SCAN_BPC set): a text long enough that
+every workgroup of k_scan processes several tiles -- i.e. takes the LDS-DMA double-buffered path -- checked
+against the oracle in the strict (exact-window) mode, with merge metadata, and in partial / MEM modes."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE]
+import pyoracle as O                       # noqa: E402
+import mumemto_amd                         # noqa: E402
+from mumemto_amd import synth              # noqa: E402
+
+n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+length = int(sys.argv[2]) if len(sys.argv) > 2 else 120_000
+docs = synth.pangenome(n_docs, length, 0.01, seed=31)
+eng = mumemto_amd.Engine(0)
+eng.set_docs(docs)
+cases = [
+    dict(min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, merge_metadata=False),
+    dict(min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, merge_metadata=True),
+    dict(min_match_len=12, num_distinct=n_docs - 1, max_doc_freq=1, max_total_freq=0, merge_metadata=False),
+    dict(min_match_len=25, num_distinct=2, max_doc_freq=3, max_total_freq=0, merge_metadata=False),
+    dict(min_match_len=30, num_distinct=2, max_doc_freq=0, max_total_freq=7, merge_metadata=False),
+]
+for c in cases:
+    eng.run(use_revcomp=True, **c)
+    ref = O.run(docs, min_len=c["min_match_len"], num_distinct=c["num_distinct"], max_doc_freq=c["max_doc_freq"],
+                max_total_freq=c["max_total_freq"], revcomp=True, merge=c["merge_metadata"])
+    got = eng.output_text()
+    assert got == ref.text(), ("output differs", c, len(got), len(ref.text()))
+    assert got.count(b"\n") > 0, c
+    if c["merge_metadata"]:
+        import numpy as np
+        assert np.array_equal(eng.thresholds(), ref.thresh())
+print("scan shapes ok: text of %d characters, %d cases" % (eng.text_length(), len(cases)))

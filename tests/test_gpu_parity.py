@@ -240,3 +240,18 @@ def test_full_size_properties(engine):
     first = engine.output_text()
     engine.run()
     assert engine.output_text() == first
+
+
+@pytest.mark.parametrize("variant,bpc", [(0, 1), (0, 16), (1, 1), (2, 2)])
+def test_scan_kernel_shapes_and_double_buffering(variant, bpc):
+    """k_scan's workgroup shape and grid size are tuning knobs (MMT_SCAN_VARIANT / MMT_SCAN_BPC, read once per
+    process).  With one workgroup per CU every workgroup walks several tiles of a 1.4 M-character text, so the
+    LDS-DMA double buffering, the interior fast path and the boundary tiles all run; outputs must not change."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MMT_SCAN_VARIANT=str(variant), MMT_SCAN_BPC=str(bpc))
+    r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "scan shapes ok" in r.stdout

@@ -67,6 +67,13 @@ MMT_API int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_
 MMT_API int mmt_producer_used(const mmt_engine* e);
 
 /* One pass of the hot path: text -> SA/LCP/BWT -> scan -> rows (+ thresholds). */
+/* Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): hand over the text T itself
+ * (UPPER(F) '$' [revcomp(F) '$'] per document, n characters) or the stream of the real suffixes (sentinel entry
+ * dropped; may be a prefix of the full stream).  mmt_engine_run then skips the stages that would have made them.  */
+MMT_API int mmt_engine_set_text_host(mmt_engine* e, const uint8_t* text, uint64_t n, const uint64_t* doc_len,
+                                     size_t n_docs, int use_revcomp);
+MMT_API int mmt_engine_set_stream_host(mmt_engine* e, const uint32_t* sa, const uint32_t* lcp, const uint8_t* bwt,
+                                       uint64_t entries, const uint64_t* doc_len, size_t n_docs, int use_revcomp);
 MMT_API int mmt_engine_run(mmt_engine* e, const mmt_params* p);
 
 /* The same job for host-resident input of any size.  When the text would exceed max_text_chars

@@ -69,7 +69,8 @@ GPU_ABI_SYMBOLS = [
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
     "mmt_engine_set_producer", "mmt_producer_used", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
-    "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device",
+    "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
+    "mmt_engine_set_stream_host",
 ]
 
 
@@ -113,6 +114,9 @@ def load_library():
     L.mmt_engine_destroy.argtypes = [C.c_void_p]
     L.mmt_engine_set_input_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.mmt_engine_set_input_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mmt_engine_set_text_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]
+    L.mmt_engine_set_stream_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.c_size_t, C.c_int]
     L.mmt_engine_run.argtypes = [C.c_void_p, C.POINTER(Params)]
     for f in ("mmt_num_rows", "mmt_num_docs", "mmt_num_occ", "mmt_thresh_len", "mmt_num_candidates",
               "mmt_merged_rows", "mmt_merged_docs"):
@@ -270,6 +274,19 @@ class Engine:
         lens = np.ascontiguousarray(doc_len, dtype=np.uint64)
         self._keep = keepalive
         _check(self.L.mmt_engine_set_input_device(self.h, C.c_void_p(dev_ptr), _p(lens), len(lens)))
+
+    def set_text(self, text, doc_len, use_revcomp=True):
+        """Hand over the text T itself (bytes; UPPER(F) '$' [revcomp '$'] per document): the `-p` checkpoint."""
+        t = np.frombuffer(bytes(text), np.uint8) if len(text) else np.zeros(1, np.uint8)
+        lens = np.ascontiguousarray(doc_len, np.uint64)
+        _check(self.L.mmt_engine_set_text_host(self.h, _p(t), C.c_uint64(len(text)), _p(lens), len(lens), int(use_revcomp)))
+
+    def set_stream(self, sa, lcp, bwt, doc_len, use_revcomp=True):
+        """Hand over SA / LCP / BWT of the real suffixes (possibly a prefix of the stream): the `-a` checkpoint."""
+        sa = np.ascontiguousarray(sa, np.uint32); lcp = np.ascontiguousarray(lcp, np.uint32)
+        bwt = np.ascontiguousarray(bwt, np.uint8); lens = np.ascontiguousarray(doc_len, np.uint64)
+        _check(self.L.mmt_engine_set_stream_host(self.h, _p(sa), _p(lcp), _p(bwt), C.c_uint64(len(sa)), _p(lens), len(lens),
+                                                 int(use_revcomp)))
 
     def run(self, min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, use_revcomp=True,
             merge_metadata=False):

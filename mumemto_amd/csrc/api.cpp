@@ -229,6 +229,21 @@ int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases, const uint6
     e->e->set_input_host(h_bases, doc_len, n_docs);
     MMT_CATCH
 }
+int mmt_engine_set_text_host(mmt_engine* e, const uint8_t* text, uint64_t n, const uint64_t* doc_len, size_t n_docs,
+                             int use_revcomp) {
+    if (!e || (!text && n) || (!doc_len && n_docs)) return fail(1, "engine, text and doc_len must be non-null");
+    MMT_TRY
+    e->e->set_text_host(text, n, doc_len, n_docs, use_revcomp != 0);
+    MMT_CATCH
+}
+int mmt_engine_set_stream_host(mmt_engine* e, const uint32_t* sa, const uint32_t* lcp, const uint8_t* bwt,
+                               uint64_t entries, const uint64_t* doc_len, size_t n_docs, int use_revcomp) {
+    if (!e || ((!sa || !lcp || !bwt) && entries) || (!doc_len && n_docs))
+        return fail(1, "engine, columns and doc_len must be non-null");
+    MMT_TRY
+    e->e->set_stream_host(sa, lcp, bwt, entries, doc_len, n_docs, use_revcomp != 0);
+    MMT_CATCH
+}
 int mmt_engine_run(mmt_engine* e, const mmt_params* p) {
     if (!e || !p) return fail(1, "engine and params must be non-null");
     MMT_TRY

@@ -38,6 +38,90 @@ static void write_lengths(const std::string& prefix, const std::vector<FastaDoc>
     }
 }
 
+// RefBuilder(prefix, use_rcomp) (src/ref_builder.cpp:140-169): document lengths from PREFIX.lengths --
+// "path * total" lines (or the two-word "path total" form); per-record lines are skipped
+static std::vector<uint64_t> read_lengths_file(const std::string& prefix) {
+    const std::string name = prefix + ".lengths";
+    std::ifstream in(name);
+    if (!in) throw CliError{"Lengths file required for using intermediate files. File should match output prefix: " + name, 1};
+    std::vector<uint64_t> lens;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::vector<std::string> words;
+        size_t a = 0;
+        while (a <= line.size()) {
+            size_t b = line.find(' ', a);
+            if (b == std::string::npos) b = line.size();
+            if (b > a) words.push_back(line.substr(a, b - a));
+            a = b + 1;
+        }
+        if (words.size() == 2) lens.push_back(std::stoull(words[1]));
+        else if (words.size() == 3 && words[1] == "*") lens.push_back(std::stoull(words[2]));
+    }
+    if (lens.empty()) throw CliError{"no document lengths in " + name, 1};
+    return lens;
+}
+static std::vector<uint8_t> read_whole_file(const std::string& path, const char* what) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw CliError{std::string("Error: opening ") + what + " file " + path, 1};
+    std::vector<uint8_t> data((size_t)f.tellg());
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(data.data()), (std::streamsize)data.size());
+    return data;
+}
+// -a PREFIX (src/pfp_mum.cpp:97-111, include/read_arrays.hpp:86-122): 40-bit little-endian SA / LCP, one BWT byte
+// per entry.  The reference feeds the first |T| entries of the |T|+1 the writer produced to the match finder, i.e.
+// the sentinel entry and all real suffixes but the last; the engine takes exactly those real suffixes.
+static void load_stream_files(const std::string& prefix, uint64_t text_chars, std::vector<uint32_t>& sa,
+                              std::vector<uint32_t>& lcp, std::vector<uint8_t>& bwt) {
+    const std::vector<uint8_t> fsa = read_whole_file(prefix + ".sa", "SA"), flcp = read_whole_file(prefix + ".lcp", "LCP"),
+                               fbwt = read_whole_file(prefix + ".bwt", "BWT");
+    if (fsa.size() < text_chars * 5 || flcp.size() < text_chars * 5 || fbwt.size() < text_chars)
+        throw CliError{"the arrays under " + prefix + " hold fewer than the " + std::to_string(text_chars) +
+                       " entries the lengths file announces", 1};
+    auto get40 = [](const std::vector<uint8_t>& b, uint64_t j) {
+        uint64_t v = 0;
+        for (int k = 4; k >= 0; k--) v = (v << 8) | b[j * 5 + k];
+        return v;
+    };
+    const uint64_t entries = text_chars ? text_chars - 1 : 0;      // stream entries 1 .. |T|-1
+    sa.resize(entries); lcp.resize(entries); bwt.resize(entries);
+    for (uint64_t j = 0; j < entries; j++) {
+        const uint64_t s = get40(fsa, j + 1), l = get40(flcp, j + 1);
+        if (s > 0xffffffffull || l > 0xffffffffull) throw CliError{"array entry beyond 32 bits", 1};
+        sa[j] = (uint32_t)s; lcp[j] = (uint32_t)l; bwt[j] = fbwt[j + 1];
+    }
+}
+// -p PREFIX (src/pfp_mum.cpp:122-124, include/pfp.hpp:105-129): PREFIX.dict = sorted phrases, each closed by 0x01,
+// the file by 0x00; PREFIX.parse = 1-based u32 ranks.  Consecutive phrases overlap by w characters; the parsed
+// string is 0x02 T 0x02^w (include/newscan.hpp:357-423), so T falls out by concatenation.
+static std::vector<uint8_t> text_from_parse(const std::string& prefix, size_t w) {
+    const std::vector<uint8_t> dict = read_whole_file(prefix + ".dict", "dictionary"),
+                               parse = read_whole_file(prefix + ".parse", "parse");
+    std::vector<std::pair<size_t, size_t>> phrase;              // (offset, length) in dict
+    size_t a = 0;
+    for (size_t i = 0; i < dict.size(); i++) {
+        if (dict[i] == 0x01) { phrase.emplace_back(a, i - a); a = i + 1; }
+        else if (dict[i] == 0x00) break;
+    }
+    if (phrase.empty() || parse.size() % 4) throw CliError{"malformed " + prefix + ".dict / .parse", 1};
+    std::vector<uint8_t> full;
+    const size_t m = parse.size() / 4;
+    for (size_t i = 0; i < m; i++) {
+        uint32_t r;
+        std::memcpy(&r, parse.data() + 4 * i, 4);
+        if (r == 0 || r > phrase.size()) throw CliError{"parse rank outside the dictionary", 1};
+        const auto& ph = phrase[r - 1];
+        const size_t skip = i ? w : 0;
+        if (ph.second < skip) throw CliError{"phrase shorter than the window: is -w the value the parse was made with?", 1};
+        full.insert(full.end(), dict.begin() + ph.first + skip, dict.begin() + ph.first + ph.second);
+    }
+    if (full.size() < w + 1 || full[0] != 0x02) throw CliError{"the parse does not start with the padding symbol", 1};
+    for (size_t i = 0; i < w; i++)
+        if (full[full.size() - 1 - i] != 0x02) throw CliError{"the parse does not end with w padding symbols: is -w right?", 1};
+    return std::vector<uint8_t>(full.begin() + 1, full.end() - w);
+}
+
 static void put40(std::vector<uint8_t>& b, uint64_t v) {
     for (int k = 0; k < 5; k++) b.push_back((uint8_t)(v >> (8 * k)));
 }
@@ -50,16 +134,16 @@ int main(int argc, char** argv) {
         o.parse(argc, argv);
         if (o.help) { std::fputs(usage_text().c_str(), stderr); return 0; }
         const bool mum_mode = o.validate();
-        if (o.from_parse_flag || o.arrays_in_flag)
-            throw CliError{"-p/--from-parse and -a/--arrays-in are not available in this build", 1};
-        const std::vector<std::string> inputs = resolve_inputs(o);
-        o.set_parameters(inputs.size(), mum_mode);
+        const bool checkpoint = o.from_parse_flag || o.arrays_in_flag;
+        std::vector<uint64_t> doc_len;
+        if (checkpoint) doc_len = read_lengths_file(o.from_parse_flag ? o.parse_prefix : o.arrays_in);
+        const std::vector<std::string> inputs = checkpoint ? std::vector<std::string>() : resolve_inputs(o);
+        o.set_parameters(checkpoint ? doc_len.size() : inputs.size(), mum_mode);
         for (const auto& n : o.notes) log_line("build_main", n);
 
         auto t0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> bases;
         std::vector<FastaDoc> docs;
-        std::vector<uint64_t> doc_len;
         for (const auto& f : inputs) {
             docs.push_back(read_fasta(f, bases));
             if (docs.back().total == 0) {           // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
@@ -68,27 +152,56 @@ int main(int argc, char** argv) {
             }
             doc_len.push_back(docs.back().total);
         }
-        write_lengths(o.output_prefix, docs);
-        std::fprintf(stderr, "\033[32m[build_main] \033[0mread %zu files, %zu bases ... done.  (%.3f sec)\n", docs.size(),
-                     bases.size(), secs_since(t0));
+        uint64_t text_chars = 0;
+        for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
+        // stage checkpoints: the text (from PREFIX.parse/.dict) or the stream (PREFIX.sa/.lcp/.bwt) comes from files
+        std::vector<uint8_t> ck_text, ck_bwt;
+        std::vector<uint32_t> ck_sa, ck_lcp;
+        if (o.from_parse_flag) {
+            ck_text = text_from_parse(o.parse_prefix, o.pfp_w);
+            if (ck_text.size() != text_chars)
+                throw CliError{"the parse expands to " + std::to_string(ck_text.size()) + " characters, " + o.parse_prefix +
+                               ".lengths announces " + std::to_string(text_chars) + " (is -r set as it was for the parse?)", 1};
+            log_line("build_main", "text of " + std::to_string(text_chars) + " characters rebuilt from " + o.parse_prefix +
+                                       ".parse / .dict");
+        } else if (o.arrays_in_flag) {
+            load_stream_files(o.arrays_in, text_chars, ck_sa, ck_lcp, ck_bwt);
+            log_line("build_main", "Using pre-computed LCP/BWT/SA arrays from files with prefix: " + o.arrays_in);
+        } else {
+            write_lengths(o.output_prefix, docs);
+            std::fprintf(stderr, "\033[32m[build_main] \033[0mread %zu files, %zu bases ... done.  (%.3f sec)\n", docs.size(),
+                         bases.size(), secs_since(t0));
+        }
 
         if (std::getenv("MUMEMTO_DRY_RUN")) {     // host-side checks only (tests on machines without a GPU)
             uint64_t h = 1469598103934665603ull;
             for (uint8_t b : bases) { h ^= b; h *= 1099511628211ull; }
+            for (uint8_t b : ck_text) { h ^= b; h *= 1099511628211ull; }
+            for (uint32_t v : ck_sa) { h ^= v; h *= 1099511628211ull; }
+            for (uint32_t v : ck_lcp) { h ^= v; h *= 1099511628211ull; }
+            for (uint8_t b : ck_bwt) { h ^= b; h *= 1099511628211ull; }
+            if (checkpoint)
+                std::printf("checkpoint=%s text_chars=%llu entries=%zu ", o.from_parse_flag ? "parse" : "arrays",
+                            (unsigned long long)text_chars, o.from_parse_flag ? ck_text.size() : ck_sa.size());
             std::printf("docs=%zu bases=%zu fnv1a=%016llx num_distinct=%d max_doc_freq=%d max_total_freq=%d revcomp=%d "
-                        "merge=%d anchor=%d binary=%d min_len=%zu\n", docs.size(), bases.size(), (unsigned long long)h,
+                        "merge=%d anchor=%d binary=%d min_len=%zu\n", doc_len.size(), bases.size(), (unsigned long long)h,
                         o.num_distinct_docs, o.rare_freq, o.max_mem_freq, (int)o.use_rcomp, (int)o.merge,
                         (int)o.anchor_merge, (int)o.binary, o.min_match_len);
             return 0;
         }
         t0 = std::chrono::steady_clock::now();
         Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
-        uint64_t text_chars = 0;
-        for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
         const uint64_t max_text = std::getenv("MUMEMTO_MAX_TEXT") ? std::strtoull(std::getenv("MUMEMTO_MAX_TEXT"), nullptr, 10)
                                                                   : 0xfffff000ull - 1;
         const bool partitioned = text_chars > max_text;
-        if (!partitioned) eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
+        if (checkpoint && partitioned) throw CliError{"-p / -a are not available for inputs larger than one suffix array", 1};
+        if (checkpoint && (o.keep_temp || o.arrays_out))
+            throw CliError{"-K and -A write what -p / -a read: run them without a checkpoint", 1};
+        if (o.from_parse_flag) eng.set_text_host(ck_text.data(), ck_text.size(), doc_len.data(), doc_len.size(), o.use_rcomp);
+        else if (o.arrays_in_flag)
+            eng.set_stream_host(ck_sa.data(), ck_lcp.data(), ck_bwt.data(), ck_sa.size(), doc_len.data(), doc_len.size(),
+                                o.use_rcomp);
+        else if (!partitioned) eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
         auto write_pfp_files = [&]() {              // PREFIX.dict / PREFIX.parse as newscan.hpp:406-419 writes them
             eng.parse_only(o.use_rcomp, (uint32_t)o.pfp_w, (uint32_t)o.hash_mod);
             std::vector<uint8_t> dict; std::vector<uint32_t> parse;

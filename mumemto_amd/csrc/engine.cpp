@@ -32,6 +32,7 @@ Engine::~Engine() {
 void Engine::set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs) {
     MMT_HIP(hipSetDevice(device_));
     d_bases_ = d_bases;
+    preset_ = 0;
     doc_len_.assign(doc_len, doc_len + n_docs);
     doc_base_.assign(n_docs + 1, 0);
     for (size_t d = 0; d < n_docs; d++) doc_base_[d + 1] = doc_base_[d] + doc_len_[d];
@@ -47,8 +48,8 @@ void Engine::set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, siz
     set_input_device(d_bases_own_.get(), doc_len, n_docs);
 }
 
-// ---- A1 ----------------------------------------------------------------------
-void Engine::build_text(bool revcomp) {
+// document layout of the text: starts of the documents, total length, device copy of the starts
+void Engine::layout_docs(bool revcomp) {
     const size_t N = doc_len_.size();
     revcomp_ = revcomp;
     doc_start_.assign(N + 1, 0);
@@ -57,10 +58,57 @@ void Engine::build_text(bool revcomp) {
     if (n_ >= 0xfffff000ull)
         throw std::runtime_error("text of " + std::to_string(n_) +
                                  " characters exceeds the 32-bit suffix-array build of this version");
-    d_doc_base_.ensure(N + 1);
     d_doc_start_.ensure(N + 1);
-    MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
     MMT_HIP(hipMemcpyAsync(d_doc_start_.get(), doc_start_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
+}
+
+void Engine::set_text_host(const uint8_t* text, uint64_t n, const uint64_t* doc_len, size_t n_docs, bool revcomp) {
+    MMT_HIP(hipSetDevice(device_));
+    d_bases_ = nullptr;
+    doc_len_.assign(doc_len, doc_len + n_docs);
+    doc_base_.assign(n_docs + 1, 0);
+    layout_docs(revcomp);
+    if (n != n_) throw std::runtime_error("the text has " + std::to_string(n) + " characters, the document lengths add "
+                                          "up to " + std::to_string(n_));
+    d_text_.ensure(n_ + 64);
+    MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~15ull), 0, 64 + (n_ & 15ull), stream_));
+    if (n_) MMT_HIP(hipMemcpyAsync(d_text_.get(), text, n_, hipMemcpyHostToDevice, stream_));
+    std::vector<uint32_t> hist(256, 0);
+    for (uint64_t i = 0; i < n_; i++) hist[text[i]]++;
+    d_hist_.ensure(256);
+    MMT_HIP(hipMemcpyAsync(d_hist_.get(), hist.data(), 256 * 4, hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    preset_ = 1;
+}
+
+void Engine::set_stream_host(const uint32_t* sa, const uint32_t* lcp, const uint8_t* bwt, uint64_t entries,
+                             const uint64_t* doc_len, size_t n_docs, bool revcomp) {
+    MMT_HIP(hipSetDevice(device_));
+    d_bases_ = nullptr;
+    doc_len_.assign(doc_len, doc_len + n_docs);
+    doc_base_.assign(n_docs + 1, 0);
+    layout_docs(revcomp);
+    if (entries > n_) throw std::runtime_error("more stream entries than text characters");
+    const uint64_t text_chars = n_;
+    for (uint64_t j = 0; j < entries; j++)
+        if (sa[j] >= text_chars) throw std::runtime_error("suffix array entry outside the text");
+    n_ = entries;                                      // what the scan walks (a truncated stream is legal, see -a)
+    d_sa_.ensure(n_ + 1); d_lcp_.ensure(n_ + 1); d_bwt_.ensure(n_ + 16);
+    if (n_) {
+        MMT_HIP(hipMemcpyAsync(d_sa_.get(), sa, n_ * 4, hipMemcpyHostToDevice, stream_));
+        MMT_HIP(hipMemcpyAsync(d_lcp_.get(), lcp, n_ * 4, hipMemcpyHostToDevice, stream_));
+        MMT_HIP(hipMemcpyAsync(d_bwt_.get(), bwt, n_, hipMemcpyHostToDevice, stream_));
+    }
+    MMT_HIP(hipStreamSynchronize(stream_));
+    preset_ = 2;
+}
+
+// ---- A1 ----------------------------------------------------------------------
+void Engine::build_text(bool revcomp) {
+    const size_t N = doc_len_.size();
+    layout_docs(revcomp);
+    d_doc_base_.ensure(N + 1);
+    MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
     d_text_.ensure(n_ + 64);
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 4, stream_));
@@ -317,7 +365,19 @@ void Engine::run(const mmt_params& p) {
     rows_.n_docs = doc_len_.size();
     n_cand_ = 0; thresh_len_ = 0; bumbl_.clear();
     if (doc_len_.empty()) return;                       // mumemto_api.cpp:338-340
-    ev_[0]->start(stream_); build_text(p.use_revcomp != 0); ev_[0]->stop(stream_);
+    if (preset_ && (p.use_revcomp != 0) != revcomp_)
+        throw std::runtime_error("the text / stream handed over was laid out with the other strand setting");
+    if (preset_ == 2) {                                 // stream handed over: scan it as it is
+        producer_used_ = 0;
+        scan(p);
+        make_rows(p);
+        for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
+        stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return;
+    }
+    ev_[0]->start(stream_);
+    if (preset_ == 0) build_text(p.use_revcomp != 0);
+    ev_[0]->stop(stream_);
     ev_[1]->start(stream_);
     {
         int kind = producer_;

@@ -40,6 +40,13 @@ public:
 
     void set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs);
     void set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs);
+    // Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): the caller hands over
+    // the text T itself (UPPER(F) '$' [revcomp '$'] per document, e.g. rebuilt from PREFIX.parse/.dict) or the
+    // whole stream (SA / LCP / BWT of the real suffixes, sentinel entry dropped); run() then skips the stages
+    // that would have produced them.  `revcomp` says how the documents are laid out in that text.
+    void set_text_host(const uint8_t* text, uint64_t n, const uint64_t* doc_len, size_t n_docs, bool revcomp);
+    void set_stream_host(const uint32_t* sa, const uint32_t* lcp, const uint8_t* bwt, uint64_t entries,
+                         const uint64_t* doc_len, size_t n_docs, bool revcomp);
     void run(const mmt_params& p);
     // Same job for host-resident input of any size: if the text exceeds max_text characters (0 = the
     // 32-bit suffix-array limit) the documents are processed as anchor partitions and merged
@@ -89,6 +96,7 @@ public:
     DevBuf<uint8_t>& scratch() { return d_temp_; }
 
 private:
+    void layout_docs(bool revcomp);
     void build_text(bool revcomp);
     void suffix_sort();
     void pfp_parse(uint32_t w, uint32_t p);
@@ -108,6 +116,7 @@ private:
     DevBuf<uint64_t> d_doc_base_, d_doc_start_;
     bool revcomp_ = true;
     uint64_t n_ = 0;
+    int preset_ = 0;                      // 0: build everything, 1: text handed over, 2: stream handed over
 
     // columns
     DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_;

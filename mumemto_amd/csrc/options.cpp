@@ -174,7 +174,9 @@ std::string usage_text() {
            "\t-m, --modulus         [INT]     hash modulus of the PFP files written by -P / -K (default: 100)\n"
            "\t-P, --only-parse                only compute the prefix-free parse (PREFIX.dict, PREFIX.parse)\n"
            "\t-K, --keep-temp-files           also write PREFIX.dict and PREFIX.parse\n"
-           "Not available in this build: -p/--from-parse, -a/--arrays-in\n";
+           "Stage checkpoints (need PREFIX.lengths next to the files):\n"
+           "\t-p, --from-parse     [PREFIX]  start from PREFIX.parse and PREFIX.dict (made with the same -w and -r)\n"
+           "\t-a, --arrays-in      [PREFIX]  start from PREFIX.sa, PREFIX.lcp and PREFIX.bwt as -A writes them\n";
 }
 
 }  // namespace mmt

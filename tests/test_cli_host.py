@@ -98,3 +98,80 @@ def test_filelist_input(tmp_path):
     fl.write_text("\n".join(p + " 1" for p in paths) + "\n\n")
     got = fields(run(["-i", str(fl), "-o", str(tmp_path / "o")], tmp_path).stdout)
     assert got["docs"] == "3"
+
+
+def _fnv1a(chunks):
+    h = 1469598103934665603
+    for values in chunks:
+        for v in values:
+            h = ((h ^ int(v)) * 1099511628211) % (1 << 64)
+    return h
+
+
+def _fixture_docs(case):
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "newscan", case)
+    docs, cur = [], []
+    for line in open(os.path.join(g, "input.txt"), "rb").read().split(b"\n"):
+        if line.startswith(b"F $"):
+            if cur:
+                docs.append(cur)
+                cur = []
+        elif line.startswith(b"F "):
+            cur.append(line[2:])
+    w, p = open(os.path.join(g, "params.txt")).read().split()
+    return g, docs, int(w), int(p)
+
+
+@pytest.mark.parametrize("case", ["tiny", "three_docs_w4_p11", "three_docs_w10_p100"])
+def test_from_parse_checkpoint_rebuilds_the_text(tmp_path, case):
+    """-p PREFIX: PREFIX.dict / PREFIX.parse written by the REAL reference parser (golden fixture) expand to exactly
+    the text the FASTA path builds (src/pfp_mum.cpp:122-124, include/pfp.hpp:105-129)."""
+    import shutil
+    g, docs, w, p = _fixture_docs(case)
+    shutil.copy(os.path.join(g, "out.dict"), tmp_path / "ck.dict")
+    shutil.copy(os.path.join(g, "out.parse"), tmp_path / "ck.parse")
+    with open(tmp_path / "ck.lengths", "w") as f:
+        for i, d in enumerate(docs):
+            f.write("/data/d%d.fa * %d\n" % (i, sum(len(r) for r in d)))
+            for j, r in enumerate(d):
+                f.write("/data/d%d.fa rec%d %d\n" % (i, j, len(r)))
+    r = run(["-p", str(tmp_path / "ck"), "-w", str(w), "-o", str(tmp_path / "out")], tmp_path)
+    assert r.returncode == 0, r.stderr
+    f = fields(r.stdout)
+    text, _ = O.build_text(docs, True)
+    assert f["checkpoint"] == "parse" and int(f["text_chars"]) == len(text) == int(f["entries"])
+    assert int(f["docs"]) == len(docs) and int(f["num_distinct"]) == len(docs)
+    assert int(f["fnv1a"], 16) == _fnv1a([text])
+    # a wrong window, a wrong strand setting and a missing lengths file are refused
+    assert run(["-p", str(tmp_path / "ck"), "-w", str(w + 1), "-o", str(tmp_path / "out")], tmp_path).returncode == 1
+    assert run(["-p", str(tmp_path / "ck"), "-w", str(w), "-r", "-o", str(tmp_path / "out")], tmp_path).returncode == 1
+    os.remove(tmp_path / "ck.lengths")
+    assert run(["-p", str(tmp_path / "ck"), "-w", str(w), "-o", str(tmp_path / "out")], tmp_path).returncode == 1
+
+
+def test_arrays_in_checkpoint_reads_the_streams_first_entries(tmp_path):
+    """-a PREFIX: 40-bit SA / LCP + BWT files; like the reference (include/read_arrays.hpp:86-104) only the first |T|
+    of the |T|+1 entries are used, i.e. every real suffix but the last."""
+    import numpy as np
+    docs = synth.pangenome(4, 300, 0.02, seed=3)
+    text, _ = O.build_text(docs, True)
+    sa, lcp, bwt = O.build_stream(text)
+
+    def put40(a):
+        a = np.asarray(a, np.uint64)
+        return np.stack([(a >> np.uint64(8 * k)) & np.uint64(255) for k in range(5)], axis=1).astype(np.uint8).tobytes()
+    (tmp_path / "arr.sa").write_bytes(put40(sa))
+    (tmp_path / "arr.lcp").write_bytes(put40(lcp))
+    (tmp_path / "arr.bwt").write_bytes(np.asarray(bwt, np.uint8).tobytes())
+    with open(tmp_path / "arr.lengths", "w") as f:
+        for i, d in enumerate(docs):
+            f.write("/data/d%d.fa * %d\n" % (i, len(d[0])))
+    r = run(["-a", str(tmp_path / "arr"), "-o", str(tmp_path / "out")], tmp_path)
+    assert r.returncode == 0, r.stderr
+    f = fields(r.stdout)
+    n = len(text)
+    assert f["checkpoint"] == "arrays" and int(f["text_chars"]) == n and int(f["entries"]) == n - 1
+    assert int(f["fnv1a"], 16) == _fnv1a([sa[1:n], lcp[1:n], bwt[1:n]])
+    (tmp_path / "arr.bwt").write_bytes(np.asarray(bwt, np.uint8).tobytes()[: n - 5])      # truncated file
+    assert run(["-a", str(tmp_path / "arr"), "-o", str(tmp_path / "out")], tmp_path).returncode == 1
+    assert run(["-a", str(tmp_path / "arr"), "-p", str(tmp_path / "arr"), "-o", str(tmp_path / "o")], tmp_path).returncode == 1

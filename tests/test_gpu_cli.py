@@ -144,3 +144,56 @@ def test_anchor_merge_tool_matches_reference_binary(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert os.path.getsize(work / "outb.bumbl") > 18
+
+
+def test_checkpoints_from_parse_and_arrays_in(inputs, tmp_path):
+    """-K / -A write the stage checkpoints, -p / -a start from them (src/pfp_mum.cpp:97-111, :122-124).  -p must
+    reproduce the direct run byte for byte; -a scans the first |T| stream entries only, exactly like the reference's
+    file reader (include/read_arrays.hpp:86-104), so it is compared with the oracle's scan of that truncated stream."""
+    tmp, docs, paths = inputs
+    cli(["-o", str(tmp_path / "ck"), "-K", "-A", "-w", "8", "-m", "40"] + paths, tmp_path)
+    direct = (tmp_path / "ck.mums").read_bytes()
+    assert direct == O.run(docs).text()
+    for extra, want in ([], None), (["-k", "-1", "-f", "3"], None):
+        cli(["-o", str(tmp_path / "fromp"), "-p", str(tmp_path / "ck"), "-w", "8"] + extra, tmp_path)
+        out = (tmp_path / ("fromp.mums" if not extra else "fromp.mems")).read_bytes()
+        nd, f, F = O.cli_params(len(docs), *([0, 1, 0] if not extra else [-1, 3, 0]))
+        assert out == O.run(docs, num_distinct=nd, max_doc_freq=f, max_total_freq=F).text()
+    assert not (tmp_path / "fromp.lengths").exists()          # the checkpoint runs only read PREFIX.lengths
+    text, doc_start = O.build_text(docs, True)
+    sa, lcp, bwt = O.build_stream(text)
+    n = len(text)
+    cli(["-o", str(tmp_path / "froma"), "-a", str(tmp_path / "ck")], tmp_path)
+    want = O.scan(sa[:n], lcp[:n], bwt[:n], doc_start)
+    assert (tmp_path / "froma.mums").read_bytes() == want.text()
+    cli(["-o", str(tmp_path / "fromam"), "-a", str(tmp_path / "ck"), "-M", "-n"], tmp_path)
+    wantm = O.scan(sa[:n], lcp[:n], bwt[:n], doc_start, merge=True)
+    assert (tmp_path / "fromam.mums").read_bytes() == wantm.text()
+    L0 = len(b"".join(docs[0]))
+    assert (tmp_path / "fromam.athresh").read_bytes() == wantm.thresh()[: L0 + 1].tobytes()
+
+
+def test_engine_accepts_text_and_stream():
+    """The same checkpoints through the device-resident ABI (mmt_engine_set_text_host / _set_stream_host)."""
+    import mumemto_amd
+    docs = synth.pangenome(5, 20000, 0.01, seed=41, inversion=(2, 3000, 6000))
+    lens = [len(b"".join(d)) for d in docs]
+    for revcomp in (True, False):
+        text, doc_start = O.build_text(docs, revcomp)
+        sa, lcp, bwt = O.build_stream(text)
+        want = O.run(docs, revcomp=revcomp)
+        eng = mumemto_amd.Engine(0)
+        eng.set_text(bytes(text), lens, use_revcomp=revcomp)
+        eng.run(use_revcomp=revcomp)
+        assert eng.output_text() == want.text()
+        eng.set_stream(sa[1:], lcp[1:], bwt[1:], lens, use_revcomp=revcomp)
+        eng.run(use_revcomp=revcomp)
+        assert eng.output_text() == want.text()
+        eng.run(use_revcomp=revcomp, num_distinct=3, max_doc_freq=2)
+        assert eng.output_text() == O.run(docs, revcomp=revcomp, num_distinct=3, max_doc_freq=2).text()
+        with pytest.raises(mumemto_amd.MumemtoError):
+            eng.run(use_revcomp=not revcomp)
+        eng.set_docs(docs)                                   # back to the normal path
+        eng.run(use_revcomp=revcomp)
+        assert eng.output_text() == want.text()
+        eng.close()

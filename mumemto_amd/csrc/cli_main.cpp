@@ -7,7 +7,9 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <atomic>
 #include <iostream>
+#include <thread>
 
 #include "engine.hpp"
 #include "fasta.hpp"
@@ -143,14 +145,37 @@ int main(int argc, char** argv) {
 
         auto t0 = std::chrono::steady_clock::now();
         std::vector<uint8_t> bases;
-        std::vector<FastaDoc> docs;
-        for (const auto& f : inputs) {
-            docs.push_back(read_fasta(f, bases));
-            if (docs.back().total == 0) {           // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
-                std::cerr << std::endl << "Empty input file found: " << f << std::endl;
-                throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
+        std::vector<FastaDoc> docs(inputs.size());
+        {   // the files are independent: inflate and parse them on as many host threads as the machine offers
+            std::vector<std::vector<uint8_t>> part(inputs.size());
+            std::vector<std::string> err(inputs.size());
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (size_t i = next++; i < inputs.size(); i = next++) {
+                    try { docs[i] = read_fasta(inputs[i], part[i]); }
+                    catch (const std::exception& e) { err[i] = e.what(); }
+                }
+            };
+            const size_t n_thr = std::min<size_t>(inputs.size(), std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+            size_t total = 0;
+            for (size_t i = 0; i < inputs.size(); i++) {
+                if (!err[i].empty()) throw std::runtime_error(err[i]);
+                if (docs[i].total == 0) {           // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
+                    std::cerr << std::endl << "Empty input file found: " << inputs[i] << std::endl;
+                    throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
+                }
+                total += part[i].size();
             }
-            doc_len.push_back(docs.back().total);
+            bases.reserve(total);
+            for (size_t i = 0; i < inputs.size(); i++) {
+                bases.insert(bases.end(), part[i].begin(), part[i].end());
+                std::vector<uint8_t>().swap(part[i]);
+                doc_len.push_back(docs[i].total);
+            }
         }
         uint64_t text_chars = 0;
         for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);

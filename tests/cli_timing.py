@@ -1,0 +1,19 @@
+"""GPU box helper: wall-clock of the command line on the bench workload (FASTA in page cache -> PREFIX.mums)."""
+import os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mumemto_amd import synth, build
+haps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 12_100_000
+d = "/tmp/cli_timing"; os.makedirs(d, exist_ok=True)
+docs = synth.pangenome(haps, L, 0.005, 2)
+paths = []
+for i, doc in enumerate(docs):
+    p = os.path.join(d, "h%02d.fa" % i); synth.write_fasta(p, doc, width=80); paths.append(p)
+exe = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
+for rep in range(3):
+    t = time.perf_counter()
+    r = subprocess.run([exe, "-o", os.path.join(d, "out")] + paths, capture_output=True, text=True)
+    dt = time.perf_counter() - t
+    print("run %d: %.3f s wall, rc %d, %.3f Gbp/s" % (rep, dt, r.returncode, haps * L / dt / 1e9))
+    print("\n".join(l for l in r.stderr.split("\n") if "sec" in l or "stages" in l))
+print(os.path.getsize(os.path.join(d, "out.mums")), "bytes of .mums")

@@ -141,9 +141,12 @@ void Engine::lcp_bwt() {
     const uint32_t n = (uint32_t)n_;
     d_lcp_.ensure(n + 1);
     d_bwt_.ensure(n + 16);
-    k::lcp_from_isa(d_text_.get(), n, d_sa_.get(), d_rank_.get(), d_lcp_.get(), stream_);
     if (!(producer_used_ == 2 && pfp_.bwt_ready))   // the PFP emitter writes the BWT column itself
         k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
+    // the BWT column tells which text positions are irreducible; the LCP sweep touches SA and text only there
+    d_irr_.ensure(((size_t)n + 31) / 32 + 1);
+    k::mark_irreducible(d_sa_.get(), d_bwt_.get(), n, d_irr_.get(), stream_);
+    k::lcp_from_isa(d_text_.get(), n, d_sa_.get(), d_rank_.get(), d_lcp_.get(), d_irr_.get(), stream_);
 }
 
 // ---- A5 ------------------------------------------------------------------------

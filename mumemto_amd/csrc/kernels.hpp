@@ -45,8 +45,12 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
 
 // ---- LCP / BWT columns of the stream ----------------------------------------
 // text must be readable (zero padded) up to n + 16.  isa = inverse of sa.
+// irr: optional bitmap of irreducible text positions (mark_irreducible) -- every other position costs no
+// suffix-array or text access.
 void lcp_from_isa(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
-                  hipStream_t s);
+                  const uint32_t* irr, hipStream_t s);
+// bits: (n + 31) / 32 words, cleared here; bit p set iff the BWT byte of suffix p differs from its predecessor's
+void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32_t* bits, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
 
 // ---- A5 match scan -----------------------------------------------------------

@@ -99,7 +99,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     e3.stop(st);
     // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
-    k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), st);
+    k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), nullptr, st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
     pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
     S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);

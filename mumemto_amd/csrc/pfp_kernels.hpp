@@ -38,7 +38,7 @@ void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift,
               uint32_t* occ_cnt, hipStream_t s);
 void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
                  uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
-static const uint32_t EMIT_CAP = 2048;   // elements of one LDS tile of the emitter
+static const uint32_t EMIT_CAP = 1024;   // elements of one LDS tile of the emitter
 struct EmitArgs {
     const uint32_t* segb;       // n_groups + 1 group begin offsets in the output (last = n + 1)
     const uint32_t* sege;       // n_groups + 1 compact entry index of every group's first entry

@@ -197,7 +197,8 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.n = n; ea.sa = d_sa_.get(); ea.rank = d_rank_.get(); ea.bwt = d_bwt_.get();
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
-    pk::emit(ea, n + 1, st);
+    S.tile_first.ensure(((size_t)n + 1) / pk::EMIT_TILE + 4);
+    pk::emit(ea, n + 1, S.tile_first.get(), st);
     if (F) {      // one segmented radix sort over just the oversized groups
         S.xk_b.ensure((size_t)fb_total + 1); S.xv_b.ensure((size_t)fb_total + 1);
         prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(),

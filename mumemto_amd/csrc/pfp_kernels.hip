@@ -544,35 +544,54 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
     }
 }
 
-template <int BLOCK, int CAP>
-__global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
+// tile_first[t] = first group whose begin offset is >= t * TILE (t = 0 .. tiles; n_groups past the end): one
+// pass over the groups instead of a global binary search per workgroup of the emitter
+__global__ void k_tile_first(const uint32_t* __restrict__ segb, uint32_t n_groups, uint32_t tile, uint32_t tiles,
+                             uint32_t* __restrict__ tile_first) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    // group g is the first one at or after t * tile for every t with begin(g-1) < t * tile <= begin(g);
+    // the thread of g == n_groups closes the table for the tiles behind the last group
+    const uint64_t lo = g ? (uint64_t)segb[g - 1] / tile + 1 : 0;
+    const uint64_t hi = g < n_groups ? (uint64_t)segb[g] / tile : tiles;
+    for (uint64_t t = lo; t <= hi && t <= tiles; t++) tile_first[t] = g;
+}
+void tile_first(const uint32_t* segb, uint32_t n_groups, uint32_t tile, uint32_t tiles, uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_first, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s, segb, n_groups, tile,
+                       tiles, out);
+    MMT_HIP(hipGetLastError());
+}
+
+template <int BLOCK, int CAP, int TILE>
+__global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __restrict__ tile_first) {
     __shared__ EmitShared<BLOCK, CAP> sh;
+    __shared__ uint32_t s_gb[TILE + 2];          // begin offsets of the groups that start in this tile (+ the next one)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // groups whose begin offset lies in [b*tile, (b+1)*tile)
-    if (wave == 0) {
-        const uint64_t x0 = (uint64_t)blockIdx.x * tile, x1 = x0 + tile;
-        const uint32_t g0 = wave_lower_bound(a.segb, a.n_groups, x0 > 0xffffffffull ? 0xffffffffu : (uint32_t)x0);
-        const uint32_t g1 = wave_lower_bound(a.segb, a.n_groups, x1 > 0xffffffffull ? 0xffffffffu : (uint32_t)x1);
-        if (lane == 0) { sh.bound[0] = g0; sh.bound[1] = g1; }
-    }
+    // groups whose begin offset lies in [b*TILE, (b+1)*TILE): at most TILE of them, every group has an element
+    const uint32_t g0 = tile_first[blockIdx.x], g_end = tile_first[blockIdx.x + 1];
+    const uint32_t ng = g_end - g0;
+    for (uint32_t i = tid; i <= ng; i += BLOCK) s_gb[i] = a.segb[g0 + i];
     __syncthreads();
-    uint32_t g = sh.bound[0];
-    const uint32_t g_end = sh.bound[1];
+    uint32_t g = g0;
     while (g < g_end) {
         // chunk = maximal run of whole groups [g, g2) with at most CAP elements
         __syncthreads();
         if (wave == 0) {
-            const uint32_t lim = a.segb[g] + CAP;           // n + 1 + CAP < 2^32 is checked on the host
-            const uint32_t cnt = wave_lower_bound(a.segb + g, g_end - g + 1, lim + 1);   // segb[g + cnt] > lim
-            uint32_t g2 = g + cnt - 1;                       // segb[g2] <= lim
-            if (g2 > g_end) g2 = g_end;
-            if (lane == 0) sh.bound[2] = g2;
+            const uint32_t lim = s_gb[g - g0] + CAP;         // n + 1 + CAP < 2^32 is checked on the host
+            uint32_t c = 0;                                  // groups after g that still begin at or before lim
+            for (uint32_t base = g - g0 + 1; base <= ng; base += 64) {
+                const uint32_t idx = base + lane;
+                const uint64_t m = __ballot(idx <= ng && s_gb[idx] <= lim);
+                c += (uint32_t)__popcll(m);
+                if (m != ~0ull) break;
+            }
+            if (lane == 0) sh.bound[2] = g + c;              // segb[g2] <= lim < segb[g2 + 1]
         }
         __syncthreads();
         const uint32_t g2 = sh.bound[2];
         if (g2 > g) {
-            const uint32_t clo = a.segb[g];
-            emit_piece<BLOCK, CAP>(a, sh, a.sege[g], a.sege[g2], clo, a.segb[g2] - clo, true, 0u);
+            const uint32_t clo = s_gb[g - g0];
+            emit_piece<BLOCK, CAP>(a, sh, a.sege[g], a.sege[g2], clo, s_gb[g2 - g0] - clo, true, 0u);
             g = g2;
             continue;
         }
@@ -619,10 +638,11 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, uint32_t tile) {
     }
 }
 
-void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s) {
-    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP, TILE = 1024;
+void emit(const EmitArgs& a, uint32_t n_out, uint32_t* tile_first_buf, hipStream_t s) {
+    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP, TILE = (int)EMIT_TILE;
     const uint32_t tiles = (uint32_t)(((uint64_t)n_out + TILE - 1) / TILE);
-    hipLaunchKernelGGL((k_emit<BLOCK, CAP>), dim3(tiles), dim3(BLOCK), 0, s, a, (uint32_t)TILE);
+    tile_first(a.segb, a.n_groups, (uint32_t)TILE, tiles, tile_first_buf, s);
+    hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE>), dim3(tiles), dim3(BLOCK), 0, s, a, tile_first_buf);
     MMT_HIP(hipGetLastError());
 }
 

@@ -39,6 +39,7 @@ void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift,
 void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
                  uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
 static const uint32_t EMIT_CAP = 1024;   // elements of one LDS tile of the emitter
+static const uint32_t EMIT_TILE = 1024;  // output positions per workgroup of the emitter
 struct EmitArgs {
     const uint32_t* segb;       // n_groups + 1 group begin offsets in the output (last = n + 1)
     const uint32_t* sege;       // n_groups + 1 compact entry index of every group's first entry
@@ -53,7 +54,8 @@ struct EmitArgs {
     uint32_t* fb_keys; uint32_t* fb_vals;     // compact fallback arrays, fb_off[n_fb] entries
     uint32_t* err;                            // consistency errors
 };
-void emit(const EmitArgs& a, uint32_t n_out, hipStream_t s);
+// tile_first_buf: scratch of n_out / EMIT_TILE + 2 entries
+void emit(const EmitArgs& a, uint32_t n_out, uint32_t* tile_first_buf, hipStream_t s);
 void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStream_t s);
 void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
                      const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank,

@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box helper: SQ counter passes for k_scan (separate rocprofv3 runs, counters only).
+# GPU box helper: SQ counter passes for one kernel (separate rocprofv3 runs, counters only).
+# usage: pmc_scan.sh [kernel-name-substring, default mmt::k::k_scan]
+export KERNEL=${1:-mmt::k::k_scan}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_sq
@@ -10,14 +12,15 @@ run() {
      python $R/bench.py --steps 2 --warmup 1 --cpu-sample-bp 0 > $OUT/$name.log 2>&1
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
-import csv, sys, collections
+import csv, sys, collections, os
+KERNEL = os.environ['KERNEL']
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "k_scan" not in k: continue
-    acc["k_scan"][r["Counter_Name"]] += float(r["Counter_Value"])
+    if KERNEL not in k: continue
+    acc[KERNEL][r["Counter_Name"]] += float(r["Counter_Value"])
     cnt[r["Counter_Name"]] += 1
-for c, v in acc["k_scan"].items():
+for c, v in acc[KERNEL].items():
     print("%-28s %16.0f per launch (%d launches)" % (c, v / cnt[c], cnt[c]))
 PY
 }

@@ -381,7 +381,8 @@ __global__ void k_mark_irreducible(const uint32_t* __restrict__ sa, const uint8_
                                    uint32_t* __restrict__ bits) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    if (j == 0 || bwt[j] != bwt[j - 1]) { const uint32_t p = sa[j]; atomicOr(&bits[p >> 5], 1u << (p & 31)); }
+    const uint8_t b = bwt[j];       // 0 = "no byte before" (or a padding byte of the dictionary): never reducible
+    if (j == 0 || b == 0 || b != bwt[j - 1]) { const uint32_t p = sa[j]; atomicOr(&bits[p >> 5], 1u << (p & 31)); }
 }
 void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32_t* bits, hipStream_t s) {
     MMT_HIP(hipMemsetAsync(bits, 0, ((size_t)n + 31) / 32 * 4, s));

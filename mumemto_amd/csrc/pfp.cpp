@@ -99,9 +99,13 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     e3.stop(st);
     // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
-    k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), nullptr, st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
     pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
+    // ebw is the BWT column of the dictionary (0 where the byte before is padding): the LCP sweep reads the
+    // dictionary and its suffix array only at the irreducible positions
+    d_irr_.ensure(((size_t)nd + 31) / 32 + 1);
+    k::mark_irreducible(S.sa_d.get(), S.ebw.get(), nd, d_irr_.get(), st);
+    k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), d_irr_.get(), st);
     S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
     pk::group_flags(S.esuf.get(), S.lcp_d.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);

@@ -390,6 +390,131 @@ void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32
     MMT_HIP(hipGetLastError());
 }
 
+// ============================================================================
+// LCP column WITHOUT the inverse suffix array (PFP producer: the emitter then
+// has no 4-byte random store per suffix, and the sweep no random store either).
+//   1. k_irr_lcp: in suffix-array order, the entries whose BWT byte differs from
+//      the entry before are the irreducible ones; their LCP is computed by plain
+//      comparison of the two suffixes (their sum is O(n log n), Karkkainen et
+//      al.) and K[sa[j]] = LCP + sa[j] is stored at the text position.  Entries
+//      are compacted per workgroup first so that every lane compares; matches
+//      longer than IRR_STEPS * 8 characters go to a list for k_long_lcp.
+//   2. K is non-decreasing along the text where it is defined and
+//      PLCP[i] = PLCP[i-1] - 1 at every reducible position: an inclusive
+//      max-scan of K (zero elsewhere) gives PLCP[i] + i for all i.
+//   3. k_lcp_gather: lcp[j] = K'[sa[j]] - sa[j].
+// Also records the suffix ranks of the anchor document (positions < anchor_len),
+// which the multi-GPU re-sort needs.
+// ============================================================================
+struct LongLcp { uint32_t p, q, h; };
+constexpr int IRR_STEPS = 24;
+
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ text, uint32_t n,
+                                                   const uint32_t* __restrict__ sa, const uint8_t* __restrict__ bwt,
+                                                   uint32_t* __restrict__ K, uint32_t* __restrict__ anchor_rank,
+                                                   uint32_t anchor_len, LongLcp* __restrict__ longs,
+                                                   uint32_t* __restrict__ long_count, uint32_t long_cap) {
+    constexpr int TILE = BLOCK * PER;
+    __shared__ uint32_t s_q[TILE];
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint64_t j = base + (uint64_t)q * BLOCK + threadIdx.x;
+        bool irr = false;
+        if (j < n) {
+            const uint8_t b = bwt[j];
+            irr = j == 0 || b == 0 || b != bwt[j - 1];
+            if (anchor_rank) { const uint32_t p = sa[j]; if (p < anchor_len) anchor_rank[p] = (uint32_t)j; }
+        }
+        const uint64_t m = __ballot(irr);
+        uint32_t at = 0;
+        if (lane == 0 && m) at = atomicAdd(&s_n, (uint32_t)__popcll(m));
+        at = __shfl(at, 0, 64);
+        if (irr) s_q[at + __popcll(m & ((1ull << lane) - 1))] = (uint32_t)(j - base);
+    }
+    __syncthreads();
+    const uint32_t cnt = s_n;
+    for (uint32_t wi = threadIdx.x; wi < cnt; wi += BLOCK) {
+        const uint64_t j = base + s_q[wi];
+        const uint32_t p = sa[j];
+        if (j == 0) { K[p] = p; continue; }                      // no predecessor: LCP 0
+        const uint32_t qq = sa[j - 1];
+        const uint32_t limit = n - (p > qq ? p : qq);           // the shorter suffix ends first
+        uint32_t h = 0;
+        bool done = false;
+        for (int step = 0; step < IRR_STEPS && h < limit; step++) {
+            const uint64_t x = load_u64(text + p + h), y = load_u64(text + qq + h);
+            if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
+            h += 8;
+        }
+        if (h >= limit) { h = limit; done = true; }
+        if (done) K[p] = h + p;
+        else {
+            const uint32_t slot = atomicAdd(long_count, 1u);
+            if (slot < long_cap) { longs[slot].p = p; longs[slot].q = qq; longs[slot].h = h; }
+        }
+    }
+}
+
+// one wave per long match: 512 characters per step
+__global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, const LongLcp* __restrict__ longs,
+                           uint32_t count, uint32_t* __restrict__ K) {
+    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (w >= count) return;
+    const uint32_t p = longs[w].p, q = longs[w].q;
+    uint32_t h = longs[w].h;
+    const uint32_t limit = n - (p > q ? p : q);
+    while (h < limit) {
+        const uint32_t o = h + lane * 8;
+        uint64_t x = 0, y = 0;
+        if (o < limit) { x = load_u64(text + p + o); y = load_u64(text + q + o); }   // text is zero padded by 64 bytes
+        const uint64_t m = __ballot(x != y);
+        if (m) {
+            const int first = __builtin_ctzll(m);
+            const uint64_t dx = __shfl(x ^ y, first, 64);
+            h += (uint32_t)first * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3);
+            break;
+        }
+        h += 512;
+    }
+    if (h > limit) h = limit;
+    if (lane == 0) K[p] = h + p;
+}
+
+__global__ void k_lcp_gather(const uint32_t* __restrict__ Ks, const uint32_t* __restrict__ sa, uint32_t n,
+                             uint32_t* __restrict__ lcp) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t p = sa[j];
+    lcp[j] = Ks[p] - p;
+}
+
+void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
+                     uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
+                     uint32_t long_cap, hipStream_t s) {
+    constexpr int B = 256, PER = 8;
+    MMT_HIP(hipMemsetAsync(K, 0, (size_t)n * 4, s));
+    MMT_HIP(hipMemsetAsync(long_count, 0, 4, s));
+    hipLaunchKernelGGL((k_irr_lcp<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, sa, bwt, K, anchor_rank,
+                       anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap);
+    MMT_HIP(hipGetLastError());
+}
+void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_long_lcp, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, n,
+                       static_cast<const LongLcp*>(long_list), count, K);
+    MMT_HIP(hipGetLastError());
+}
+void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s) {
+    hipLaunchKernelGGL(k_lcp_gather, dim3(grid_for(n, 256)), dim3(256), 0, s, Ks, sa, n, lcp);
+    MMT_HIP(hipGetLastError());
+}
+
 // bwt[j] = text[sa[j]-1], 0 for sa[j] = 0 (pfp_lcp_mum.hpp:268, direct_gsacak.hpp:66)
 __global__ void k_bwt_from_sa(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ sa,
                               uint8_t* __restrict__ bwt) {

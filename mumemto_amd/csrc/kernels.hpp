@@ -51,6 +51,15 @@ void lcp_from_isa(const uint8_t* text, uint32_t n, const uint32_t* sa, const uin
                   const uint32_t* irr, hipStream_t s);
 // bits: (n + 31) / 32 words, cleared here; bit p set iff the BWT byte of suffix p differs from its predecessor's
 void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32_t* bits, hipStream_t s);
+// ISA-free LCP construction (see kernels.hip): K (n entries, cleared here) receives LCP + position at the
+// irreducible suffixes; matches longer than 192 characters are queued (12-byte records, long_cap of them) for
+// long_lcp; after an inclusive max-scan Ks of K, lcp_gather writes the column.  anchor_rank (optional) receives the
+// suffix ranks of the text positions below anchor_len.
+void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
+                     uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
+                     uint32_t long_cap, hipStream_t s);
+void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s);
+void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
 
 // ---- A5 match scan -----------------------------------------------------------

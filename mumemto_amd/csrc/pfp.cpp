@@ -140,7 +140,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     e6.start(st);
     const int shift = bit_width_u64((uint64_t)m + 1);
     const uint32_t nd = S.dict_len;
-    d_sa_.ensure(n); d_rank_.ensure(n); d_bwt_.ensure((size_t)n + 16);
+    d_sa_.ensure(n); d_bwt_.ensure((size_t)n + 16);     // no inverse suffix array on this path (see Engine::lcp_bwt)
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
     S.occ_cnt.ensure(D); S.occ_start.ensure(D); S.occ_sorted.ensure(m); S.occ_pos.ensure(m); S.occ_key.ensure(m);
     MMT_HIP(hipMemsetAsync(S.occ_cnt.get(), 0, (size_t)D * 4, st));
@@ -198,7 +198,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
     ea.occ_pos = S.occ_pos.get(); ea.occ_key = S.occ_key.get();
-    ea.n = n; ea.sa = d_sa_.get(); ea.rank = d_rank_.get(); ea.bwt = d_bwt_.get();
+    ea.n = n; ea.sa = d_sa_.get(); ea.bwt = d_bwt_.get();
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
     S.tile_first.ensure(((size_t)n + 1) / pk::EMIT_TILE + 4);
@@ -208,7 +208,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(),
                                                fb_total, F, S.fb_off.get(), S.fb_off.get() + 1, shift, st);
         pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), F, S.segb.get(), S.xv_b.get(), d_text_.get(), n,
-                            d_sa_.get(), d_rank_.get(), d_bwt_.get(), S.err.get(), st);
+                            d_sa_.get(), d_bwt_.get(), S.err.get(), st);
     }
     if (read_u32(S.err.get(), st)) throw std::runtime_error("PFP order: the end sentinel is not first");
     S.bwt_ready = true;

@@ -538,7 +538,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
             const uint32_t out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
             const uint32_t pos = my_pos[q];
             if (out == 0) { if (pos != a.n) atomicAdd(a.err, 1u); }   // entry 0 must be the end sentinel
-            else if (pos < a.n) { a.sa[out - 1] = pos; a.rank[pos] = out - 1; a.bwt[out - 1] = sh.ebwt[e]; }
+            else if (pos < a.n) { a.sa[out - 1] = pos; a.bwt[out - 1] = sh.ebwt[e]; }
             else atomicAdd(a.err, 1u);
         }
     }
@@ -663,24 +663,24 @@ void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStrea
 __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const uint32_t* __restrict__ fb_off,
                                   uint32_t n_fb, const uint32_t* __restrict__ segb,
                                   const uint32_t* __restrict__ sorted_vals, const uint8_t* __restrict__ text,
-                                  uint32_t n, uint32_t* __restrict__ sa, uint32_t* __restrict__ rank,
-                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
+                                  uint32_t n, uint32_t* __restrict__ sa, uint8_t* __restrict__ bwt,
+                                  uint32_t* __restrict__ err) {
     const uint32_t f = blockIdx.x;
     if (f >= n_fb) return;
     const uint32_t lo = fb_off[f], hi = fb_off[f + 1], out0 = segb[fb_group[f]];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t p = sorted_vals[i], out = out0 + (i - lo);
         if (out == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
-        sa[out - 1] = p; rank[p] = out - 1;
+        sa[out - 1] = p;
         bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;
     }
 }
 void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
-                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank,
-                     uint8_t* bwt, uint32_t* err, hipStream_t s) {
+                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt,
+                     uint32_t* err, hipStream_t s) {
     if (!n_fb) return;
     hipLaunchKernelGGL(k_fallback_finish, dim3(n_fb), dim3(256), 0, s, fb_group, fb_off, n_fb, segb, sorted_vals, text,
-                       n, sa, rank, bwt, err);
+                       n, sa, bwt, err);
     MMT_HIP(hipGetLastError());
 }
 

@@ -48,7 +48,7 @@ struct EmitArgs {
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
     const uint32_t* occ_pos; const uint32_t* occ_key;
     uint32_t n;                 // text length; output stream has n + 1 entries, entry 0 = end sentinel
-    uint32_t* sa; uint32_t* rank; uint8_t* bwt;   // n entries each (the sentinel entry is not stored)
+    uint32_t* sa; uint8_t* bwt;                   // n entries each (the sentinel entry is not stored)
     // oversized groups (more than EMIT_CAP suffixes): ids ascending, compact offsets (n_fb + 1 entries)
     const uint32_t* fb_group; const uint32_t* fb_off; uint32_t n_fb;
     uint32_t* fb_keys; uint32_t* fb_vals;     // compact fallback arrays, fb_off[n_fb] entries
@@ -58,8 +58,8 @@ struct EmitArgs {
 void emit(const EmitArgs& a, uint32_t n_out, uint32_t* tile_first_buf, hipStream_t s);
 void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStream_t s);
 void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
-                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint32_t* rank,
-                     uint8_t* bwt, uint32_t* err, hipStream_t s);
+                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt,
+                     uint32_t* err, hipStream_t s);
 void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

@@ -101,11 +101,23 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     e4.start(st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
     pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
-    // ebw is the BWT column of the dictionary (0 where the byte before is padding): the LCP sweep reads the
-    // dictionary and its suffix array only at the irreducible positions
-    d_irr_.ensure(((size_t)nd + 31) / 32 + 1);
-    k::mark_irreducible(S.sa_d.get(), S.ebw.get(), nd, d_irr_.get(), st);
-    k::lcp_from_isa(S.dict.get(), nd, S.sa_d.get(), S.rank_d.get(), S.lcp_d.get(), d_irr_.get(), st);
+    // ebw is the BWT column of the dictionary (0 where the byte before is padding): its LCP array comes from the
+    // irreducible suffixes alone, like the text's (kernels.hip, "LCP column WITHOUT the inverse suffix array")
+    {
+        d_plcp_a_.ensure(nd); d_plcp_b_.ensure(nd); d_count_.ensure(4);
+        uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)nd / 256 + 4096);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            d_long_.ensure((size_t)cap * 12);
+            k::irreducible_lcp(S.dict.get(), nd, S.sa_d.get(), S.ebw.get(), d_plcp_a_.get(), nullptr, 0, d_long_.get(),
+                               d_count_.get() + 2, cap, st);
+            const uint32_t found = read_u32(d_count_.get() + 2, st);
+            if (found <= cap) { k::long_lcp(S.dict.get(), nd, d_long_.get(), found, d_plcp_a_.get(), st); break; }
+            if (attempt) throw std::runtime_error("long-match list overflow in the dictionary LCP construction");
+            cap = found + 1024;
+        }
+        prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_b_.get(), nd, st);
+        k::lcp_gather(d_plcp_b_.get(), S.sa_d.get(), nd, S.lcp_d.get(), st);
+    }
     S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
     pk::group_flags(S.esuf.get(), S.lcp_d.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);

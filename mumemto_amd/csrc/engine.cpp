@@ -133,7 +133,7 @@ void Engine::suffix_sort() {
 
     d_sa_.ensure(n); d_rank_.ensure(n);
     sorter_.reserve(n);
-    k::pack_keys(d_text_.get(), n, d_code_.get(), bits, chars, sorter_.keys_in(), sorter_.vals_in(), stream_);
+    k::pack_keys(d_text_.get(), n, d_code_.get(), bits, chars, 0u, sorter_.keys_in(), sorter_.vals_in(), stream_);
     sort_rounds_ = sorter_.sort(n, bits * chars, (uint64_t)chars, d_sa_.get(), d_rank_.get(), d_temp_, stream_);
 }
 
@@ -151,11 +151,11 @@ void Engine::lcp_bwt() {
         for (int attempt = 0; attempt < 2; attempt++) {
             d_long_.ensure((size_t)cap * 12);
             k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), d_rank_.get(), anchor,
-                               d_long_.get(), d_count_.get() + 2, cap, stream_);
+                               d_long_.get(), d_count_.get() + 2, cap, 0u, stream_);
             uint32_t found = 0;
             MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
             MMT_HIP(hipStreamSynchronize(stream_));
-            if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), stream_); break; }
+            if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), 0u, stream_); break; }
             if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
             cap = found + 1024;                        // rare: rerun with the exact size
         }

@@ -160,10 +160,16 @@ void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* 
 // ============================================================================
 // Tile of the text is converted to `bits`-wide symbol codes in LDS once; each
 // thread then builds 4 consecutive keys with a rolling shift.
+// sep_code != 0 (PFP dictionary): every occurrence of that symbol is a UNIQUE terminator, ordered by position --
+// the strings between terminators are what matters there, and a suffix is fully ordered as soon as its window
+// reaches its terminator.  The key then is (symbols up to and including the first terminator, rest zeroed) << 1
+// | 1; without a terminator in the window (symbols) << 1.  Equal keys with the low bit set stay in position
+// order (stable radix sort), and k_mark_heads makes each of them its own bucket.
 template <int BLOCK, int PER>
 __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__ text, uint32_t n,
                                                      const uint8_t* __restrict__ code, int bits, int chars,
-                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                     uint32_t sep_code, uint64_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals) {
     constexpr int TILE = BLOCK * PER;
     __shared__ uint8_t s_code[256];
     __shared__ uint8_t s_sym[TILE + 64];
@@ -177,30 +183,48 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__
     __syncthreads();
     const int t0 = threadIdx.x * PER;
     const uint64_t mask = (bits * chars >= 64) ? ~0ull : ((1ull << (bits * chars)) - 1);
+    int next_sep[PER];                                   // offset of the first terminator in window q, or >= chars
+    if (sep_code) {
+        int nx = 1 << 20;
+        for (int idx = t0 + PER - 1 + chars - 1; idx >= t0; idx--) {
+            if (s_sym[idx] == sep_code) nx = idx;
+            if (idx < t0 + PER) next_sep[idx - t0] = nx - idx;
+        }
+    }
     uint64_t key = 0;
     for (int c = 0; c < chars; c++) key = (key << bits) | s_sym[t0 + c];
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         uint64_t p = base + t0 + q;
-        if (p < n) { keys[p] = key & mask; vals[p] = (uint32_t)p; }
+        if (p < n) {
+            uint64_t kq = key & mask;
+            if (sep_code) {
+                const int d = next_sep[q];
+                if (d < chars) kq = ((kq >> (bits * (chars - 1 - d))) << (bits * (chars - 1 - d)) << 1) | 1ull;
+                else kq <<= 1;
+            }
+            keys[p] = kq; vals[p] = (uint32_t)p;
+        }
         key = ((key << bits) | s_sym[t0 + q + chars]) & mask;
     }
 }
-void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint64_t* keys,
-               uint32_t* vals, hipStream_t s) {
+void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint32_t sep_code,
+               uint64_t* keys, uint32_t* vals, hipStream_t s) {
     constexpr int B = 256, PER = 4;
     hipLaunchKernelGGL((k_pack_keys<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, d_code, bits, chars,
-                       keys, vals);
+                       sep_code, keys, vals);
     MMT_HIP(hipGetLastError());
 }
 
-__global__ void k_mark_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ headval) {
+__global__ void k_mark_heads(const uint64_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ headval,
+                             int lsb_unique) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    headval[j] = (j == 0 || keys[j] != keys[j - 1]) ? j : 0u;
+    const uint64_t k = keys[j];
+    headval[j] = (j == 0 || k != keys[j - 1] || (lsb_unique && (k & 1ull))) ? j : 0u;
 }
-void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, hipStream_t s) {
-    hipLaunchKernelGGL(k_mark_heads, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, n, headval);
+void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, bool lsb_unique, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_heads, dim3(grid_for(n, 256)), dim3(256), 0, s, keys, n, headval, lsb_unique ? 1 : 0);
     MMT_HIP(hipGetLastError());
 }
 
@@ -407,6 +431,20 @@ void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32
 // which the multi-GPU re-sort needs.
 // ============================================================================
 struct LongLcp { uint32_t p, q, h; };
+// index of the first byte of x equal to `sep` (8 if none); sep == 0 disables the test
+__device__ __forceinline__ uint32_t first_sep_byte(uint64_t x, uint32_t sep) {
+    if (!sep) return 8u;
+    const uint64_t t = x ^ (0x0101010101010101ull * sep);
+    const uint64_t z = (t - 0x0101010101010101ull) & ~t & 0x8080808080808080ull;
+    return z ? (uint32_t)(__builtin_ctzll(z) >> 3) : 8u;
+}
+// one 8-byte step of a suffix comparison: returns the number of matching characters (8 = all) where a byte equal
+// to `sep` never matches (unique terminators of the PFP dictionary)
+__device__ __forceinline__ uint32_t match8(uint64_t x, uint64_t y, uint32_t sep) {
+    const uint32_t mis = x != y ? (uint32_t)(__builtin_ctzll(x ^ y) >> 3) : 8u;
+    const uint32_t sp = first_sep_byte(x, sep);
+    return mis < sp ? mis : sp;
+}
 constexpr int IRR_STEPS = 24;
 
 template <int BLOCK, int PER>
@@ -414,7 +452,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
                                                    const uint32_t* __restrict__ sa, const uint8_t* __restrict__ bwt,
                                                    uint32_t* __restrict__ K, uint32_t* __restrict__ anchor_rank,
                                                    uint32_t anchor_len, LongLcp* __restrict__ longs,
-                                                   uint32_t* __restrict__ long_count, uint32_t long_cap) {
+                                                   uint32_t* __restrict__ long_count, uint32_t long_cap, uint32_t sep) {
     constexpr int TILE = BLOCK * PER;
     __shared__ uint32_t s_q[TILE];
     __shared__ uint32_t s_n;
@@ -428,7 +466,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
         bool irr = false;
         if (j < n) {
             const uint8_t b = bwt[j];
-            irr = j == 0 || b == 0 || b != bwt[j - 1];
+            irr = j == 0 || b == 0 || (sep && b == sep) || b != bwt[j - 1];
             if (anchor_rank) { const uint32_t p = sa[j]; if (p < anchor_len) anchor_rank[p] = (uint32_t)j; }
         }
         const uint64_t m = __ballot(irr);
@@ -448,9 +486,9 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
         uint32_t h = 0;
         bool done = false;
         for (int step = 0; step < IRR_STEPS && h < limit; step++) {
-            const uint64_t x = load_u64(text + p + h), y = load_u64(text + qq + h);
-            if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
-            h += 8;
+            const uint32_t k8 = match8(load_u64(text + p + h), load_u64(text + qq + h), sep);
+            h += k8;
+            if (k8 < 8) { done = true; break; }
         }
         if (h >= limit) { h = limit; done = true; }
         if (done) K[p] = h + p;
@@ -463,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
 
 // one wave per long match: 512 characters per step
 __global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, const LongLcp* __restrict__ longs,
-                           uint32_t count, uint32_t* __restrict__ K) {
+                           uint32_t count, uint32_t* __restrict__ K, uint32_t sep) {
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= count) return;
     const uint32_t p = longs[w].p, q = longs[w].q;
@@ -471,13 +509,12 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, const L
     const uint32_t limit = n - (p > q ? p : q);
     while (h < limit) {
         const uint32_t o = h + lane * 8;
-        uint64_t x = 0, y = 0;
-        if (o < limit) { x = load_u64(text + p + o); y = load_u64(text + q + o); }   // text is zero padded by 64 bytes
-        const uint64_t m = __ballot(x != y);
+        uint32_t k8 = 8;
+        if (o < limit) k8 = match8(load_u64(text + p + o), load_u64(text + q + o), sep);   // zero padded by 64 bytes
+        const uint64_t m = __ballot(k8 < 8);
         if (m) {
             const int first = __builtin_ctzll(m);
-            const uint64_t dx = __shfl(x ^ y, first, 64);
-            h += (uint32_t)first * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3);
+            h += (uint32_t)first * 8 + (uint32_t)__shfl((int)k8, first, 64);
             break;
         }
         h += 512;
@@ -496,18 +533,19 @@ __global__ void k_lcp_gather(const uint32_t* __restrict__ Ks, const uint32_t* __
 
 void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
                      uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
-                     uint32_t long_cap, hipStream_t s) {
+                     uint32_t long_cap, uint32_t sep, hipStream_t s) {
     constexpr int B = 256, PER = 8;
     MMT_HIP(hipMemsetAsync(K, 0, (size_t)n * 4, s));
     MMT_HIP(hipMemsetAsync(long_count, 0, 4, s));
     hipLaunchKernelGGL((k_irr_lcp<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, sa, bwt, K, anchor_rank,
-                       anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap);
+                       anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap, sep);
     MMT_HIP(hipGetLastError());
 }
-void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s) {
+void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, uint32_t sep,
+              hipStream_t s) {
     if (!count) return;
     hipLaunchKernelGGL(k_long_lcp, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, n,
-                       static_cast<const LongLcp*>(long_list), count, K);
+                       static_cast<const LongLcp*>(long_list), count, K, sep);
     MMT_HIP(hipGetLastError());
 }
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s) {

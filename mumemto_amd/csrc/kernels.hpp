@@ -22,10 +22,13 @@ void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* 
 // ---- A8 direct suffix sort (prefix doubling) --------------------------------
 // keys[i] = first `chars` symbols of suffix i, `bits` per symbol via code[256]
 // (0 = past the end, smaller than every symbol); vals[i] = i.
-void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint64_t* keys,
-               uint32_t* vals, hipStream_t s);
+// sep_code != 0: that symbol is a unique terminator (ordered by position); keys get a low "reached my terminator"
+// bit and bits * chars + 1 <= 64 must hold (see kernels.hip).
+void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint32_t sep_code,
+               uint64_t* keys, uint32_t* vals, hipStream_t s);
 // headval[j] = j if keys[j] != keys[j-1] (or j == 0) else 0
-void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, hipStream_t s);
+// lsb_unique: a key with its low bit set is a bucket of its own
+void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, bool lsb_unique, hipStream_t s);
 // rank[sa[j]] = head[j]
 void scatter_rank(const uint32_t* sa, const uint32_t* head, uint32_t n, uint32_t* rank, hipStream_t s);
 // flags[j] = 1 unless bucket of j is a singleton
@@ -54,11 +57,13 @@ void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32
 // ISA-free LCP construction (see kernels.hip): K (n entries, cleared here) receives LCP + position at the
 // irreducible suffixes; matches longer than 192 characters are queued (12-byte records, long_cap of them) for
 // long_lcp; after an inclusive max-scan Ks of K, lcp_gather writes the column.  anchor_rank (optional) receives the
-// suffix ranks of the text positions below anchor_len.
+// suffix ranks of the text positions below anchor_len.  sep != 0: bytes of that value are unique terminators (they
+// never match and are never a reducible BWT byte) -- the PFP dictionary, sorted with the same convention.
 void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
                      uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
-                     uint32_t long_cap, hipStream_t s);
-void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s);
+                     uint32_t long_cap, uint32_t sep, hipStream_t s);
+void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, uint32_t sep,
+              hipStream_t s);
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
 

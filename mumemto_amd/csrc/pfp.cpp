@@ -89,13 +89,15 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     int sigma = 0;
     for (int c = 0; c < 256; c++) code[c] = (hist[c] || c <= 2) ? (uint8_t)(++sigma) : 0;
     const int bits = std::max(1, bit_width_u64((uint64_t)sigma));
-    const int chars = std::min(64 / bits, 64);
+    // every 0x01 (end of a phrase) is a unique terminator, ordered by position: what follows it never matters, so
+    // a suffix is final as soon as the compared prefix reaches the end of its phrase (one key bit says so)
+    const int chars = std::min(63 / bits, 63);
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     S.sa_d.ensure(nd); S.rank_d.ensure(nd); S.lcp_d.ensure(nd + 1);
     sorter_.reserve(std::max(nd, m));
-    k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, sorter_.keys_in(), sorter_.vals_in(), st);
-    S.rounds_dict = sorter_.sort(nd, bits * chars, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st);
+    k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
+    S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
     e3.stop(st);
     // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
@@ -109,9 +111,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
         for (int attempt = 0; attempt < 2; attempt++) {
             d_long_.ensure((size_t)cap * 12);
             k::irreducible_lcp(S.dict.get(), nd, S.sa_d.get(), S.ebw.get(), d_plcp_a_.get(), nullptr, 0, d_long_.get(),
-                               d_count_.get() + 2, cap, st);
+                               d_count_.get() + 2, cap, 1u, st);
             const uint32_t found = read_u32(d_count_.get() + 2, st);
-            if (found <= cap) { k::long_lcp(S.dict.get(), nd, d_long_.get(), found, d_plcp_a_.get(), st); break; }
+            if (found <= cap) { k::long_lcp(S.dict.get(), nd, d_long_.get(), found, d_plcp_a_.get(), 1u, st); break; }
             if (attempt) throw std::runtime_error("long-match list overflow in the dictionary LCP construction");
             cap = found + 1024;
         }

@@ -17,10 +17,10 @@ void DoublingSorter::reserve(uint32_t n) {
 }
 
 int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, uint32_t* rank, DevBuf<uint8_t>& temp,
-                         hipStream_t s) {
+                         hipStream_t s, bool lsb_unique) {
     reserve(n);
     prims::sort_pairs_u64_u32(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sa, n, 0, std::min(64, key_bits), s);
-    k::mark_heads(keys_b_.get(), n, headval_.get(), s);
+    k::mark_heads(keys_b_.get(), n, headval_.get(), lsb_unique, s);
     prims::inclusive_max_u32(temp, headval_.get(), head_.get(), n, s);
     k::scatter_rank(sa, head_.get(), n, rank, s);
     k::flag_unsorted(head_.get(), n, flags_.get(), s);

@@ -18,8 +18,10 @@ public:
     uint64_t* keys_in() { return keys_a_.get(); }
     uint32_t* vals_in() { return sac_a_.get(); }
     // Sorts; sa_out[j] = j-th smallest suffix, rank_out = its inverse.  Returns #doubling rounds.
+    // lsb_unique: keys carry a low "this suffix reached its unique terminator" bit (k_pack_keys with sep_code):
+    // such suffixes are final after the first sort, in position order among equal keys.
     int sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa_out, uint32_t* rank_out, DevBuf<uint8_t>& temp,
-             hipStream_t s);
+             hipStream_t s, bool lsb_unique = false);
     // scratch columns, reusable by the caller between sorts (each holds >= n entries)
     DevBuf<uint64_t>& keys_a() { return keys_a_; }
     DevBuf<uint64_t>& keys_b() { return keys_b_; }

@@ -38,12 +38,14 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     const uint32_t vlen = n + 1 + w;
     S.vtext.ensure((size_t)vlen + 64);
     pk::make_vtext(d_text_.get(), n, w, S.vtext.get(), vlen + 64, st);
-    S.flags.ensure(n);
-    pk::trigger_flags(d_text_.get(), n, w, p, S.flags.get(), st);
+    const uint32_t tb = pk::trigger_blocks(n);
+    S.tmask.ensure(((size_t)n + 15) / 16 + 1); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
+    pk::trigger_masks(d_text_.get(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
+    prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
     S.err.ensure(4);
-    S.n_cuts = prims::count_nonzero_u8(d_temp_, S.flags.get(), n, S.err.get(), st);   // size the cut list exactly
+    S.n_cuts = read_u32(S.toff.get() + (tb - 1), st) + read_u32(S.tcnt.get() + (tb - 1), st);   // size the cut list exactly
     S.cuts.ensure((size_t)S.n_cuts + 1);
-    prims::select_indices(d_temp_, S.flags.get(), S.cuts.get(), S.err.get(), n, st);
+    pk::trigger_cuts(S.tmask.get(), n, S.toff.get(), S.cuts.get(), st);
     const uint32_t m = S.n_phrases = S.n_cuts + 1;
     S.pstart.ensure(m); S.plen.ensure(m);
     pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), st);

@@ -45,37 +45,83 @@ void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_
 // addchar(T[i]) when its window starts zero-filled and is never reset (newscan.hpp:96-114).
 // A phrase ends at i iff hash_i % p == 0 and the accumulated word is longer than w
 // (newscan.hpp:266), which holds for every trigger with i >= w - 1.
-template <int PER>
-__global__ void k_trigger_flags(const uint8_t* __restrict__ text, uint32_t n, uint32_t w, uint32_t p, uint64_t prime,
-                                uint64_t pot, uint8_t* __restrict__ flags) {
-    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * PER;
-    if (i0 >= n) return;
-    uint64_t h = 0;
-    for (uint32_t k = 0; k < w; k++) {                 // window ending at i0
-        int64_t pos = (int64_t)i0 - (int64_t)w + 1 + k;
-        uint64_t c = pos >= 0 ? text[pos] : 0;
-        h = (h * 256 + c) % prime;
-    }
+// Pass 1: one 16-bit mask per thread (16 consecutive positions) + the number of triggers per workgroup.
+// Pass 2 (after an exclusive scan of the workgroup counts): the trigger positions, ascending.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restrict__ text, uint32_t n, uint32_t w,
+                                                         uint32_t p, uint64_t prime, uint64_t pot,
+                                                         uint16_t* __restrict__ masks,
+                                                         uint32_t* __restrict__ block_count) {
+    constexpr int PER = 16;
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t i0 = t * PER;
+    uint32_t mask = 0;
+    if (i0 < n) {
+        uint64_t h = 0;
+        for (uint32_t k = 0; k < w; k++) {                 // window ending at i0
+            int64_t pos = (int64_t)i0 - (int64_t)w + 1 + k;
+            uint64_t c = pos >= 0 ? text[pos] : 0;
+            h = (h * 256 + c) % prime;
+        }
 #pragma unroll
-    for (int q = 0; q < PER; q++) {
-        const uint64_t i = i0 + q;
-        if (i >= n) break;
-        flags[i] = (i + 1 >= w && h % p == 0) ? 1 : 0;
-        // roll to i + 1: drop T[i-w+1], add T[i+1]
-        const int64_t drop = (int64_t)i - (int64_t)w + 1;
-        const uint64_t out = drop >= 0 ? text[drop] : 0;
-        const uint64_t in = i + 1 < n ? text[i + 1] : 0;
-        h = (h + prime - (out * pot) % prime) % prime;
-        h = (h * 256 + in) % prime;
+        for (int q = 0; q < PER; q++) {
+            const uint64_t i = i0 + q;
+            if (i >= n) break;
+            if (i + 1 >= w && h % p == 0) mask |= 1u << q;
+            // roll to i + 1: drop T[i-w+1], add T[i+1]
+            const int64_t drop = (int64_t)i - (int64_t)w + 1;
+            const uint64_t out = drop >= 0 ? text[drop] : 0;
+            const uint64_t in = i + 1 < n ? text[i + 1] : 0;
+            h = (h + prime - (out * pot) % prime) % prime;
+            h = (h * 256 + in) % prime;
+        }
+        masks[t] = (uint16_t)mask;
+    }
+    uint32_t c = __popc(mask);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restrict__ masks, uint64_t n_threads,
+                                                        const uint32_t* __restrict__ block_off,
+                                                        uint32_t* __restrict__ cuts) {
+    __shared__ uint32_t s_wave[BLOCK / 64];
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t mask = t < n_threads ? masks[t] : 0u;
+    const uint32_t c = __popc(mask);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t out = block_off[blockIdx.x] + inc - c;
+    for (uint32_t wv = 0; wv < wave; wv++) out += s_wave[wv];
+    while (mask) {
+        const uint32_t b = __builtin_ctz(mask);
+        cuts[out++] = (uint32_t)(t * 16 + b);
+        mask &= mask - 1;
     }
 }
-void trigger_flags(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint8_t* flags, hipStream_t s) {
+uint32_t trigger_blocks(uint32_t n) { return grid_for(((uint64_t)n + 15) / 16, 256); }
+void trigger_masks(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
+                   hipStream_t s) {
     const uint64_t prime = 1999999973ull;              // newscan.hpp:86
     uint64_t pot = 1;
     for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % prime;
-    constexpr int PER = 16;
-    hipLaunchKernelGGL(k_trigger_flags<PER>, dim3(grid_for(((uint64_t)n + PER - 1) / PER, 256)), dim3(256), 0, s, text,
-                       n, w, p, prime, pot, flags);
+    hipLaunchKernelGGL(k_trigger_masks<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, w, p, prime, pot, masks,
+                       block_count);
+    MMT_HIP(hipGetLastError());
+}
+void trigger_cuts(const uint16_t* masks, uint32_t n, const uint32_t* block_off, uint32_t* cuts, hipStream_t s) {
+    hipLaunchKernelGGL(k_trigger_cuts<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, masks, ((uint64_t)n + 15) / 16,
+                       block_off, cuts);
     MMT_HIP(hipGetLastError());
 }
 

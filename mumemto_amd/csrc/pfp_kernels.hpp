@@ -7,7 +7,12 @@
 namespace mmt { namespace pk {
 
 void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_t vlen_padded, hipStream_t s);
-void trigger_flags(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint8_t* flags, hipStream_t s);
+// trigger positions in two passes: 16-bit masks (one per 16 text positions) + triggers per workgroup; then, given the
+// exclusive scan of those counts, the positions themselves (ascending)
+uint32_t trigger_blocks(uint32_t n);
+void trigger_masks(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
+                   hipStream_t s);
+void trigger_cuts(const uint16_t* masks, uint32_t n, const uint32_t* block_off, uint32_t* cuts, hipStream_t s);
 void phrase_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t n, uint32_t w, uint32_t* start, uint32_t* len,
                    hipStream_t s);
 void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, uint64_t* h2,

@@ -166,15 +166,15 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     prims::exclusive_sum_u32(d_temp_, S.occ_cnt.get(), S.occ_start.get(), D, st);
     pk::occ_payload(S.occ_sorted.get(), S.pstart.get(), S.isa_p.get(), m, S.occ_pos.get(), S.occ_key.get(), st);
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
-    S.vscan.ensure(nd); S.plen_rep.ensure(D);
+    S.vscan.ensure(nd); S.ptab.ensure((size_t)D * 16 + 16);
     prims::exclusive_sum_u32(d_temp_, S.vflag.get(), S.vscan.get(), nd, st);
     const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
-    k::gather_u32_idx32(S.plen.get(), S.rep.get(), D, S.plen_rep.get(), st);
+    pk::phrase_table(S.occ_cnt.get(), S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
     S.ce_cnt.ensure(E); S.ce_eoff.ensure(E); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
     S.ce_bwt.ensure(E);
     pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.vflag.get(), S.vscan.get(),
-                      S.plen_rep.get(), S.occ_cnt.get(), S.occ_start.get(), nd, S.ce_cnt.get(), S.ce_first.get(),
-                      S.ce_offm1.get(), S.ce_bwt.get(), S.ce_gs.get(), st);
+                      S.ptab.get(), nd, S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(), S.ce_bwt.get(),
+                      S.ce_gs.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.get(), E, st);
     {
         const uint64_t total = (uint64_t)read_u32(S.ce_eoff.get() + (E - 1), st) + read_u32(S.ce_cnt.get() + (E - 1), st);

@@ -12,7 +12,7 @@ struct PfpState {
     bool have_parse = false;
     int rounds_dict = 0, rounds_parse = 0;
     float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
-    DevBuf<uint8_t> vtext, dict;
+    DevBuf<uint8_t> vtext, dict, ptab;  // ptab: 16-byte record per distinct phrase (phrase_table)
     DevBuf<uint16_t> tmask;             // trigger masks, one per 16 text positions
     DevBuf<uint32_t> tcnt, toff;        // triggers per workgroup of the trigger pass and their exclusive scan
     DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, esuf, ephr;
@@ -20,7 +20,7 @@ struct PfpState {
     DevBuf<uint8_t> ebw;
     DevBuf<uint32_t> sa_d, rank_d, lcp_d, gflag, pflag, gscan, pscan, prank, parse, sa_p, isa_p, err;
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
-    DevBuf<uint32_t> plen_rep, occ_cnt, occ_start, occ_sorted, occ_pos, occ_key, vflag, vscan;
+    DevBuf<uint32_t> occ_cnt, occ_start, occ_sorted, occ_pos, occ_key, vflag, vscan;
     DevBuf<uint32_t> ce_cnt, ce_eoff, ce_first, ce_offm1, ce_gs, segb, sege, xk_a, xk_b, xv_a, xv_b, fb_group, fb_size, fb_off, tile_first;
     DevBuf<uint8_t> ce_bwt;
     uint32_t n_entries = 0, n_fallback = 0;

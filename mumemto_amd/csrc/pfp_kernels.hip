@@ -425,29 +425,43 @@ void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint3
     MMT_HIP(hipGetLastError());
 }
 
+// per distinct phrase: (occurrences, first slot in the inverted lists, length of the phrase) in one 16-byte record,
+// so that an entry needs one random read instead of three
+__global__ void k_phrase_table(const uint32_t* __restrict__ occ_cnt, const uint32_t* __restrict__ occ_start,
+                               const uint32_t* __restrict__ plen, const uint32_t* __restrict__ rep, uint32_t n_distinct,
+                               uint4* __restrict__ tab) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_distinct) tab[d] = make_uint4(occ_cnt[d], occ_start[d], plen[rep[d]], 0u);
+}
+void phrase_table(const uint32_t* occ_cnt, const uint32_t* occ_start, const uint32_t* plen, const uint32_t* rep,
+                  uint32_t n_distinct, void* tab, hipStream_t s) {
+    hipLaunchKernelGGL(k_phrase_table, dim3(grid_for(n_distinct, 256)), dim3(256), 0, s, occ_cnt, occ_start, plen, rep,
+                       n_distinct, static_cast<uint4*>(tab));
+    MMT_HIP(hipGetLastError());
+}
+
 __global__ void k_entry_compact(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ ephr,
                                 const uint8_t* __restrict__ ebw, const uint32_t* __restrict__ gflag,
                                 const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vscan,
-                                const uint32_t* __restrict__ plen_rep, const uint32_t* __restrict__ occ_cnt,
-                                const uint32_t* __restrict__ occ_start, uint32_t nd,
+                                const uint4* __restrict__ tab, uint32_t nd,
                                 uint32_t* __restrict__ ce_cnt, uint32_t* __restrict__ ce_first,
                                 uint32_t* __restrict__ ce_offm1, uint8_t* __restrict__ ce_bwt,
                                 uint32_t* __restrict__ ce_gs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd || !vflag[r]) return;
-    const uint32_t c = vscan[r], d = ephr[r];
-    ce_cnt[c] = occ_cnt[d];
-    ce_first[c] = occ_start[d];
-    ce_offm1[c] = plen_rep[d] - (esuf[r] & 0x7fffffffu) - 1;   // offset inside the phrase, minus one
+    const uint32_t c = vscan[r];
+    const uint4 t = tab[ephr[r]];
+    ce_cnt[c] = t.x;
+    ce_first[c] = t.y;
+    ce_offm1[c] = t.z - (esuf[r] & 0x7fffffffu) - 1;           // offset inside the phrase, minus one
     ce_bwt[c] = ebw[r];
     ce_gs[c] = gflag[r];
 }
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
-                   const uint32_t* vflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
-                   const uint32_t* occ_start, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
-                   uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s) {
+                   const uint32_t* vflag, const uint32_t* vscan, const void* tab, uint32_t nd, uint32_t* ce_cnt,
+                   uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s) {
     hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, ephr, ebw, gflag, vflag, vscan,
-                       plen_rep, occ_cnt, occ_start, nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs);
+                       static_cast<const uint4*>(tab), nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs);
     MMT_HIP(hipGetLastError());
 }
 

@@ -30,10 +30,12 @@ void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint3
                  uint32_t* pflag, uint32_t* vflag, hipStream_t s);
 void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,
                   hipStream_t s);
+// tab: n_distinct 16-byte records (phrase_table)
+void phrase_table(const uint32_t* occ_cnt, const uint32_t* occ_start, const uint32_t* plen, const uint32_t* rep,
+                  uint32_t n_distinct, void* tab, hipStream_t s);
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
-                   const uint32_t* vflag, const uint32_t* vscan, const uint32_t* plen_rep, const uint32_t* occ_cnt,
-                   const uint32_t* occ_start, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
-                   uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
+                   const uint32_t* vflag, const uint32_t* vscan, const void* tab, uint32_t nd, uint32_t* ce_cnt,
+                   uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
 void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s);
 void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
                   uint32_t* which, uint32_t* slen, hipStream_t s);

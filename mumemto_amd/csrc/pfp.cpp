@@ -81,8 +81,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     const uint32_t nd = S.dict_len = (uint32_t)dict_len64;
     S.dict.ensure((size_t)nd + 64); S.dinfo.ensure(nd);
     MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
+    const bool pack_prev = D < (1u << 24);     // room for the byte before each position in the phrase-id word
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
-                  S.dinfo.get(), nd, st);
+                  S.dinfo.get(), nd, pack_prev, st);
     e2.stop(st);
 
     // -- suffix array of the dictionary (dictionary.hpp:133) ...
@@ -104,7 +105,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
-    pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
+    pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, pack_prev, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
     // ebw is the BWT column of the dictionary (0 where the byte before is padding): its LCP array comes from the
     // irreducible suffixes alone, like the text's (kernels.hip, "LCP column WITHOUT the inverse suffix array")
     {
@@ -245,7 +246,7 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
     prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
-                  stream_);
+                  false, stream_);
     d2h(out, sorted.get(), nd, stream_);
 }
 

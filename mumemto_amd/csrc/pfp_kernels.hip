@@ -251,26 +251,41 @@ void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t
 __global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
                             const uint32_t* __restrict__ len, const uint32_t* __restrict__ which,
                             const uint32_t* __restrict__ dstart, uint32_t n_phr, uint8_t* __restrict__ dict,
-                            uint64_t* __restrict__ dinfo, uint32_t dict_len) {
+                            uint64_t* __restrict__ dinfo, uint32_t dict_len, int pack_prev) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (wave >= n_phr) return;
     const uint32_t ph = which[wave], a = start[ph], l = len[ph], o = dstart[wave];
+    // pack_prev (fewer than 2^24 distinct phrases): the byte before each position rides in the top byte of the
+    // record, so that k_entry_info needs one random read per dictionary suffix instead of two.  The byte before
+    // the first character of a phrase is the terminator of the phrase before it (padding for the first phrase).
     for (uint32_t i = lane; i < l; i += 64) {
-        dict[o + i] = v[a + i];
-        if (dinfo) dinfo[o + i] = ((uint64_t)wave << 32) | (uint64_t)((l - i) | (i == 0 ? 0x80000000u : 0u));
+        const uint8_t c = v[a + i];
+        dict[o + i] = c;
+        if (dinfo) {
+            uint64_t hi = wave;
+            if (pack_prev) hi |= (uint64_t)(i ? v[a + i - 1] : (wave ? (uint8_t)1 : (uint8_t)0)) << 24;
+            dinfo[o + i] = (hi << 32) | (uint64_t)((l - i) | (i == 0 ? 0x80000000u : 0u));
+        }
     }
     if (lane == 0) {
         dict[o + l] = 1;
-        if (dinfo) dinfo[o + l] = (uint64_t)wave << 32;
-        if (wave + 1 == n_phr) { dict[dict_len - 1] = 0; if (dinfo) dinfo[dict_len - 1] = (uint64_t)wave << 32; }
+        if (dinfo) {
+            uint64_t hi = wave;
+            if (pack_prev) hi |= (uint64_t)v[a + l - 1] << 24;
+            dinfo[o + l] = hi << 32;
+        }
+        if (wave + 1 == n_phr) {
+            dict[dict_len - 1] = 0;
+            if (dinfo) { uint64_t hi = wave; if (pack_prev) hi |= (uint64_t)1 << 24; dinfo[dict_len - 1] = hi << 32; }
+        }
     }
 }
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
-               hipStream_t s) {
+               bool pack_prev, hipStream_t s) {
     hipLaunchKernelGGL(k_copy_dict, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v, start, len, which,
-                       dstart, n_phr, dict, dinfo, dict_len);
+                       dstart, n_phr, dict, dinfo, dict_len, pack_prev ? 1 : 0);
     MMT_HIP(hipGetLastError());
 }
 
@@ -278,20 +293,22 @@ void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, con
 // One random pass brings everything that is known per dictionary position into suffix-array order;
 // all later kernels read these columns coalesced.
 __global__ void k_entry_info(const uint32_t* __restrict__ sa_d, const uint64_t* __restrict__ dinfo,
-                             const uint8_t* __restrict__ dict, uint32_t nd, uint32_t* __restrict__ esuf,
-                             uint32_t* __restrict__ ephr, uint8_t* __restrict__ ebw) {
+                             const uint8_t* __restrict__ dict, uint32_t nd, int pack_prev,
+                             uint32_t* __restrict__ esuf, uint32_t* __restrict__ ephr, uint8_t* __restrict__ ebw) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd) return;
     const uint32_t pos = sa_d[r];
     const uint64_t e = dinfo[pos];
     esuf[r] = (uint32_t)e;
-    ephr[r] = (uint32_t)(e >> 32);
-    const uint8_t prev = pos ? dict[pos - 1] : (uint8_t)0;
+    uint8_t prev;
+    if (pack_prev) { ephr[r] = (uint32_t)(e >> 32) & 0xffffffu; prev = (uint8_t)(e >> 56); }
+    else { ephr[r] = (uint32_t)(e >> 32); prev = pos ? dict[pos - 1] : (uint8_t)0; }
     ebw[r] = prev == 2 ? (uint8_t)0 : prev;                 // Dollar before text position 0 -> bwt 0
 }
-void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, uint32_t* esuf,
-                uint32_t* ephr, uint8_t* ebw, hipStream_t s) {
-    hipLaunchKernelGGL(k_entry_info, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dinfo, dict, nd, esuf, ephr, ebw);
+void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, bool pack_prev,
+                uint32_t* esuf, uint32_t* ephr, uint8_t* ebw, hipStream_t s) {
+    hipLaunchKernelGGL(k_entry_info, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dinfo, dict, nd, pack_prev ? 1 : 0,
+                       esuf, ephr, ebw);
     MMT_HIP(hipGetLastError());
 }
 

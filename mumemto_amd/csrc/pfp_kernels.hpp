@@ -23,9 +23,9 @@ void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t
                      uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
-               hipStream_t s);
-void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, uint32_t* esuf,
-                uint32_t* ephr, uint8_t* ebw, hipStream_t s);
+               bool pack_prev, hipStream_t s);
+void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, bool pack_prev,
+                uint32_t* esuf, uint32_t* ephr, uint8_t* ebw, hipStream_t s);
 void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag,
                  uint32_t* pflag, uint32_t* vflag, hipStream_t s);
 void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,

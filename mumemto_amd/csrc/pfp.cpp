@@ -57,16 +57,29 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     S.iota.ensure(m); S.ord_a.ensure(m); S.order.ensure(m);
     pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.h2.get(), st);
     pk::iota(S.iota.get(), m, st);
-    prims::sort_pairs_u64_u32(d_temp_, S.h2.get(), S.hk_a.get(), S.iota.get(), S.ord_a.get(), m, 0, 64, st);
-    pk::gather_u64(S.h1.get(), S.ord_a.get(), m, S.hk_a.get(), st);
-    prims::sort_pairs_u64_u32(d_temp_, S.hk_a.get(), S.hk_b.get(), S.ord_a.get(), S.order.get(), m, 0, 64, st);
     S.dflags.ensure(m); S.scan.ensure(m);
-    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
-    pk::mark_distinct(S.order.get(), S.h1.get(), S.h2.get(), S.pstart.get(), S.plen.get(), S.vtext.get(), m,
-                      S.dflags.get(), S.err.get(), st);
-    prims::inclusive_sum_u32(d_temp_, S.dflags.get(), S.scan.get(), m, st);
-    if (read_u32(S.err.get(), st))
-        throw std::runtime_error("phrase fingerprint collision (128-bit); refusing to merge different phrases");
+    for (int attempt = std::getenv("MMT_PFP_TWO_FINGERPRINTS") ? 1 : 0;; attempt++) {     // the variable forces the rare path (tests)
+        if (attempt == 0) {
+            // order by the first fingerprint alone; equal phrases are adjacent unless two different phrases share it
+            prims::sort_pairs_u64_u32(d_temp_, S.h1.get(), S.hk_b.get(), S.iota.get(), S.order.get(), m, 0, 64, st);
+        } else {
+            // (rare) order by both fingerprints: stable sort by the second, then by the first
+            prims::sort_pairs_u64_u32(d_temp_, S.h2.get(), S.hk_a.get(), S.iota.get(), S.ord_a.get(), m, 0, 64, st);
+            pk::gather_u64(S.h1.get(), S.ord_a.get(), m, S.hk_a.get(), st);
+            prims::sort_pairs_u64_u32(d_temp_, S.hk_a.get(), S.hk_b.get(), S.ord_a.get(), S.order.get(), m, 0, 64, st);
+        }
+        MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
+        pk::mark_distinct(S.order.get(), S.h1.get(), S.h2.get(), S.pstart.get(), S.plen.get(), S.vtext.get(), m,
+                          S.dflags.get(), S.err.get(), st);
+        prims::inclusive_sum_u32(d_temp_, S.dflags.get(), S.scan.get(), m, st);
+        uint32_t flags2[2] = {0, 0};
+        MMT_HIP(hipMemcpyAsync(flags2, S.err.get(), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        if (flags2[0])
+            throw std::runtime_error("phrase fingerprint collision (128-bit); refusing to merge different phrases");
+        if (attempt == 0 && flags2[1]) continue;
+        break;
+    }
     const uint32_t D = S.n_distinct = read_u32(S.scan.get() + (m - 1), st);
     S.pid.ensure(m); S.rep.ensure(D); S.dlen.ensure(D); S.dstart.ensure(D);
     pk::assign_distinct(S.order.get(), S.scan.get(), S.dflags.get(), S.plen.get(), m, S.pid.get(), S.rep.get(),

@@ -209,7 +209,11 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
     if (k >= m) return;
     if (k == 0) { flags[0] = 1; return; }
     const uint32_t x = order[k], y = order[k - 1];
-    bool same = h1[x] == h1[y] && h2[x] == h2[y] && len[x] == len[y];
+    const bool same1 = h1[x] == h1[y];
+    bool same = same1 && h2[x] == h2[y] && len[x] == len[y];
+    // equal first fingerprints of different phrases: when the order came from the first fingerprint alone, equal
+    // phrases need not be adjacent any more -- the host then repeats the grouping with both fingerprints
+    if (same1 && !same) atomicOr(err + 1, 1u);
     if (same) {
         const uint8_t* px = v + start[x]; const uint8_t* py = v + start[y];
         const uint32_t l = len[x];

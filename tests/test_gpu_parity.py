@@ -242,6 +242,18 @@ def test_full_size_properties(engine):
     assert engine.output_text() == first
 
 
+def test_two_fingerprint_phrase_grouping_path():
+    """The PFP producer orders phrases by one 64-bit fingerprint and repeats the grouping with two when different
+    phrases share it (verified, ~1e-5 per run); MMT_PFP_TWO_FINGERPRINTS forces that path."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MMT_PFP_TWO_FINGERPRINTS="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py"), "5", "40000"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("variant,bpc", [(0, 1), (0, 16), (1, 1), (2, 2)])
 def test_scan_kernel_shapes_and_double_buffering(variant, bpc):
     """k_scan's workgroup shape and grid size are tuning knobs (MMT_SCAN_VARIANT / MMT_SCAN_BPC, read once per

@@ -148,6 +148,7 @@ void Engine::lcp_bwt() {
         d_rank_.ensure((size_t)anchor + 1);            // suffix ranks of the anchor document only (multi-GPU re-sort)
         d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_count_.ensure(4);
         uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)n / 256 + 4096);
+        if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
         for (int attempt = 0; attempt < 2; attempt++) {
             d_long_.ensure((size_t)cap * 12);
             k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), d_rank_.get(), anchor,

@@ -94,7 +94,8 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     const uint32_t nd = S.dict_len = (uint32_t)dict_len64;
     S.dict.ensure((size_t)nd + 64); S.dinfo.ensure(nd);
     MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
-    const bool pack_prev = D < (1u << 24);     // room for the byte before each position in the phrase-id word
+    // room for the byte before each position in the phrase-id word (MMT_PFP_NO_PACK: the other path, for tests)
+    const bool pack_prev = D < (1u << 24) && !std::getenv("MMT_PFP_NO_PACK");
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
                   S.dinfo.get(), nd, pack_prev, st);
     e2.stop(st);
@@ -124,6 +125,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     {
         d_plcp_a_.ensure(nd); d_plcp_b_.ensure(nd); d_count_.ensure(4);
         uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)nd / 256 + 4096);
+        if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
         for (int attempt = 0; attempt < 2; attempt++) {
             d_long_.ensure((size_t)cap * 12);
             k::irreducible_lcp(S.dict.get(), nd, S.sa_d.get(), S.ebw.get(), d_plcp_a_.get(), nullptr, 0, d_long_.get(),

@@ -13,6 +13,10 @@ from mumemto_amd import synth              # noqa: E402
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 120_000
 docs = synth.pangenome(n_docs, length, 0.01, seed=31)
+if len(sys.argv) > 3 and sys.argv[3] == "dups":
+    # exact copies and a long tandem repeat: irreducible LCP values of tens of thousands (the k_long_lcp path)
+    docs[1] = [docs[0][0]]
+    docs[2] = [docs[0][0][: length // 2] + docs[0][0][: length // 2]]
 eng = mumemto_amd.Engine(0)
 eng.set_docs(docs)
 cases = [
@@ -28,7 +32,13 @@ for c in cases:
                 max_total_freq=c["max_total_freq"], revcomp=True, merge=c["merge_metadata"])
     got = eng.output_text()
     assert got == ref.text(), ("output differs", c, len(got), len(ref.text()))
-    assert got.count(b"\n") > 0, c
+    assert got.count(b"\n") > 0 or "dups" in sys.argv, c
+    if "dups" in sys.argv:      # the stream itself, column by column
+        import numpy as np
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        assert np.array_equal(eng.sa().astype(np.int64), sa[1:]) and np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
+        assert np.array_equal(eng.bwt(), bwt[1:]) and int(lcp.max()) > 20000
     if c["merge_metadata"]:
         import numpy as np
         assert np.array_equal(eng.thresholds(), ref.thresh())

@@ -254,6 +254,19 @@ def test_two_fingerprint_phrase_grouping_path():
     assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("env", [{"MMT_PFP_NO_PACK": "1"}, {"MMT_LONG_CAP": "3"}, {}])
+def test_long_matches_and_rare_construction_paths(env):
+    """Exact document copies and a long tandem repeat give irreducible LCP values far beyond the 192 characters one lane
+    compares (k_long_lcp); MMT_LONG_CAP forces the overflow-and-rerun of the long-match list, MMT_PFP_NO_PACK the
+    dictionary records without the packed previous byte (>= 2^24 distinct phrases in production)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py"), "5", "60000", "dups"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("variant,bpc", [(0, 1), (0, 16), (1, 1), (2, 2)])
 def test_scan_kernel_shapes_and_double_buffering(variant, bpc):
     """k_scan's workgroup shape and grid size are tuning knobs (MMT_SCAN_VARIANT / MMT_SCAN_BPC, read once per

@@ -141,34 +141,30 @@ void Engine::lcp_bwt() {
     const uint32_t n = (uint32_t)n_;
     d_lcp_.ensure(n + 1);
     d_bwt_.ensure(n + 16);
-    if (producer_used_ == 2 && pfp_.bwt_ready) {
-        // PFP producer: the emitter wrote SA and BWT; the LCP column follows from the irreducible suffixes alone
-        // (kernels.hip, "LCP column WITHOUT the inverse suffix array") -- no 4-byte random store per suffix anywhere.
-        const uint32_t anchor = (uint32_t)std::min<uint64_t>(doc_len_[0], n);
-        d_rank_.ensure((size_t)anchor + 1);            // suffix ranks of the anchor document only (multi-GPU re-sort)
-        d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_count_.ensure(4);
-        uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)n / 256 + 4096);
-        if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
-        for (int attempt = 0; attempt < 2; attempt++) {
-            d_long_.ensure((size_t)cap * 12);
-            k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), d_rank_.get(), anchor,
-                               d_long_.get(), d_count_.get() + 2, cap, 0u, stream_);
-            uint32_t found = 0;
-            MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
-            MMT_HIP(hipStreamSynchronize(stream_));
-            if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), 0u, stream_); break; }
-            if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
-            cap = found + 1024;                        // rare: rerun with the exact size
-        }
-        prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_b_.get(), n, stream_);
-        k::lcp_gather(d_plcp_b_.get(), d_sa_.get(), n, d_lcp_.get(), stream_);
-        return;
+    // The LCP column follows from the irreducible suffixes alone (kernels.hip, "LCP column WITHOUT the inverse
+    // suffix array"): no 4-byte random store per suffix anywhere.  The PFP emitter wrote SA and BWT and keeps no
+    // inverse suffix array at all; only the suffix ranks of the anchor document are recorded here (multi-GPU
+    // re-sort).  The direct producer has the full array from its sort.
+    const bool pfp = producer_used_ == 2 && pfp_.bwt_ready;
+    if (!pfp) k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
+    const uint32_t anchor = (uint32_t)std::min<uint64_t>(doc_len_[0], n);
+    if (pfp) d_rank_.ensure((size_t)anchor + 1);
+    d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_count_.ensure(4);
+    uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)n / 256 + 4096);
+    if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
+    for (int attempt = 0; attempt < 2; attempt++) {
+        d_long_.ensure((size_t)cap * 12);
+        k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), pfp ? d_rank_.get() : nullptr,
+                           anchor, d_long_.get(), d_count_.get() + 2, cap, 0u, stream_);
+        uint32_t found = 0;
+        MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+        if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), 0u, stream_); break; }
+        if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
+        cap = found + 1024;                            // rare: rerun with the exact size
     }
-    // direct producer: the suffix sort left the inverse suffix array behind; text-order sweep over it
-    k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
-    d_irr_.ensure(((size_t)n + 31) / 32 + 1);
-    k::mark_irreducible(d_sa_.get(), d_bwt_.get(), n, d_irr_.get(), stream_);
-    k::lcp_from_isa(d_text_.get(), n, d_sa_.get(), d_rank_.get(), d_lcp_.get(), d_irr_.get(), stream_);
+    prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_b_.get(), n, stream_);
+    k::lcp_gather(d_plcp_b_.get(), d_sa_.get(), n, d_lcp_.get(), stream_);
 }
 
 // ---- A5 ------------------------------------------------------------------------

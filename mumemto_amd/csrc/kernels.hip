@@ -325,98 +325,18 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
     MMT_HIP(hipGetLastError());
 }
 
-// ============================================================================
-// LCP column: lcp[j] = LCP(suffix sa[j-1], suffix sa[j]), lcp[0] = 0 -- the
-// array gsacak returns (direct_gsacak.hpp:62) / pfp_lcp emits
-// (pfp_lcp_mum.hpp:197).  Text-order sweep (Kasai et al.) cut into chunks, one
-// chunk per lane; matches are extended 8 bytes at a time.
-// ============================================================================
+// 8 bytes from any address (gfx950 + amdhsa: one unaligned global_load_dwordx2)
 __device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
     uint64_t v;
-    __builtin_memcpy(&v, p, 8);   // gfx950 + amdhsa: one unaligned global_load_dwordx2
+    __builtin_memcpy(&v, p, 8);
     return v;
 }
 
-// irr (optional): one bit per text position, set where the suffix is IRREDUCIBLE, i.e. the BWT byte of its
-// suffix-array entry differs from the entry before (k_mark_irreducible).  For every other position i the
-// predecessor in the suffix array is the predecessor of i-1 plus one and LCP = LCP(i-1) - 1 exactly
-// (Karkkainen, Manzini, Puglisi: permuted LCP array), so neither the suffix array nor the text is read:
-// what remains per position is one coalesced rank read and the LCP store.  In a pangenome about one
-// position in twenty is irreducible.
-template <int CHUNK>
-__global__ void k_lcp_from_isa(const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ sa,
-                               const uint32_t* __restrict__ isa, uint32_t* __restrict__ lcp,
-                               const uint32_t* __restrict__ irr) {
-    static_assert(CHUNK % 32 == 0, "chunks start on a word of the irreducible bitmap");
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t i0 = t * CHUNK;
-    if (i0 >= n) return;
-    uint64_t i1 = i0 + CHUNK < n ? i0 + CHUNK : n;
-    uint32_t h = 0, p = 0, bits = 0;
-    bool chained = false;                       // p and h describe position i - 1
-    for (uint64_t i = i0; i < i1; i++) {
-        if (irr && ((i - i0) & 31) == 0) bits = irr[i >> 5];
-        const uint32_t r = isa[i];
-        if (r == 0) { lcp[0] = 0; h = 0; chained = false; continue; }
-        if (irr && chained && !((bits >> (i & 31)) & 1u)) {
-            p += 1; h -= 1;                     // reducible: h >= 1 here by the lemma
-            lcp[r] = h;
-            continue;
-        }
-        p = sa[r - 1];
-        if (h > 0) h--;
-        if (!chained) h = 0;
-        uint32_t limit = n - (uint32_t)(i > p ? i : p);   // the shorter suffix ends first
-        while (h < limit) {
-            uint64_t x = load_u64(text + i + h), y = load_u64(text + p + h);
-            if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); break; }
-            h += 8;
-        }
-        if (h > limit) h = limit;
-        lcp[r] = h;
-        chained = true;
-    }
-}
-template <int CHUNK>
-static void launch_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
-                       const uint32_t* irr, int block, hipStream_t s) {
-    uint64_t threads = ((uint64_t)n + CHUNK - 1) / CHUNK;
-    hipLaunchKernelGGL(k_lcp_from_isa<CHUNK>, dim3(grid_for(threads, block)), dim3(block), 0, s, text, n, sa, isa, lcp,
-                       irr);
-}
-void lcp_from_isa(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
-                  const uint32_t* irr, hipStream_t s) {
-    static int chunk = -1, block = 64;
-    if (chunk < 0) {
-        const char* c = getenv("MMT_LCP_CHUNK"); chunk = c ? atoi(c) : 64;
-        const char* b = getenv("MMT_LCP_BLOCK"); if (b) block = atoi(b);
-    }
-    switch (chunk) {
-        case 32: launch_lcp<32>(text, n, sa, isa, lcp, irr, block, s); break;
-        case 128: launch_lcp<128>(text, n, sa, isa, lcp, irr, block, s); break;
-        case 256: launch_lcp<256>(text, n, sa, isa, lcp, irr, block, s); break;
-        default: launch_lcp<64>(text, n, sa, isa, lcp, irr, block, s); break;
-    }
-    MMT_HIP(hipGetLastError());
-}
-
-// bits[sa[j] / 32] |= 1 << (sa[j] % 32) where bwt[j] != bwt[j-1] (or j == 0): the irreducible text positions
-__global__ void k_mark_irreducible(const uint32_t* __restrict__ sa, const uint8_t* __restrict__ bwt, uint32_t n,
-                                   uint32_t* __restrict__ bits) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint8_t b = bwt[j];       // 0 = "no byte before" (or a padding byte of the dictionary): never reducible
-    if (j == 0 || b == 0 || b != bwt[j - 1]) { const uint32_t p = sa[j]; atomicOr(&bits[p >> 5], 1u << (p & 31)); }
-}
-void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32_t* bits, hipStream_t s) {
-    MMT_HIP(hipMemsetAsync(bits, 0, ((size_t)n + 31) / 32 * 4, s));
-    hipLaunchKernelGGL(k_mark_irreducible, dim3(grid_for(n, 256)), dim3(256), 0, s, sa, bwt, n, bits);
-    MMT_HIP(hipGetLastError());
-}
-
 // ============================================================================
-// LCP column WITHOUT the inverse suffix array (PFP producer: the emitter then
-// has no 4-byte random store per suffix, and the sweep no random store either).
+// LCP column: lcp[j] = LCP(suffix sa[j-1], suffix sa[j]), lcp[0] = 0 -- the array
+// gsacak returns (direct_gsacak.hpp:62) / pfp_lcp emits (pfp_lcp_mum.hpp:197) --
+// WITHOUT the inverse suffix array (the PFP emitter then has no 4-byte random
+// store per suffix, and there is no text-order sweep with random stores either).
 //   1. k_irr_lcp: in suffix-array order, the entries whose BWT byte differs from
 //      the entry before are the irreducible ones; their LCP is computed by plain
 //      comparison of the two suffixes (their sum is O(n log n), Karkkainen et

@@ -47,13 +47,7 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
                    const uint32_t* newhead, uint32_t* out_pos, uint32_t* out_sa, uint32_t* out_head, hipStream_t s);
 
 // ---- LCP / BWT columns of the stream ----------------------------------------
-// text must be readable (zero padded) up to n + 16.  isa = inverse of sa.
-// irr: optional bitmap of irreducible text positions (mark_irreducible) -- every other position costs no
-// suffix-array or text access.
-void lcp_from_isa(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint32_t* isa, uint32_t* lcp,
-                  const uint32_t* irr, hipStream_t s);
-// bits: (n + 31) / 32 words, cleared here; bit p set iff the BWT byte of suffix p differs from its predecessor's
-void mark_irreducible(const uint32_t* sa, const uint8_t* bwt, uint32_t n, uint32_t* bits, hipStream_t s);
+// text must be readable (zero padded) up to n + 64.
 // ISA-free LCP construction (see kernels.hip): K (n entries, cleared here) receives LCP + position at the
 // irreducible suffixes; matches longer than 192 characters are queued (12-byte records, long_cap of them) for
 // long_lcp; after an inclusive max-scan Ks of K, lcp_gather writes the column.  anchor_rank (optional) receives the

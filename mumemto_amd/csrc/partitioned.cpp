@@ -54,18 +54,26 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
         DevBuf<uint16_t> thresh; size_t n_docs;
     };
     std::vector<Part> parts(G);
-    std::vector<uint8_t> sub;
     std::vector<uint64_t> sub_len;
     float acc[8] = {0};
     mmt_params q = p;
     q.merge_metadata = 1; q.num_distinct = 0; q.max_total_freq = 0;
+    uint64_t max_group_bytes = 0;
+    for (size_t g = 0; g < G; g++) max_group_bytes = std::max(max_group_bytes, base[groups[g].second] - base[groups[g].first]);
+    d_bases_own_.ensure(doc_len[0] + max_group_bytes + 16);      // once: the anchor is uploaded a single time
     for (size_t g = 0; g < G; g++) {
         const size_t a = groups[g].first, b = groups[g].second;
-        sub.assign(h_bases, h_bases + doc_len[0]);
-        sub.insert(sub.end(), h_bases + base[a], h_bases + base[b]);
+        // anchor + the group's documents (contiguous in the caller's buffer) go to the device in two copies
         sub_len.assign(1, doc_len[0]);
         sub_len.insert(sub_len.end(), doc_len + a, doc_len + b);
-        set_input_host(sub.data(), sub_len.data(), sub_len.size());
+        const uint64_t group_bytes = base[b] - base[a];
+        if (g == 0 && doc_len[0])      // the anchor stays where it is for every partition
+            MMT_HIP(hipMemcpyAsync(d_bases_own_.get(), h_bases, doc_len[0], hipMemcpyHostToDevice, stream_));
+        if (group_bytes)
+            MMT_HIP(hipMemcpyAsync(d_bases_own_.get() + doc_len[0], h_bases + base[a], group_bytes, hipMemcpyHostToDevice,
+                                   stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+        set_input_device(d_bases_own_.get(), sub_len.data(), sub_len.size());
         run(q);
         const HostRows& R = rows_;
         Part& P = parts[g];

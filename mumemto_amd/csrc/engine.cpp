@@ -155,11 +155,11 @@ void Engine::lcp_bwt() {
     for (int attempt = 0; attempt < 2; attempt++) {
         d_long_.ensure((size_t)cap * 12);
         k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), pfp ? d_rank_.get() : nullptr,
-                           anchor, d_long_.get(), d_count_.get() + 2, cap, 0u, stream_);
+                           anchor, d_long_.get(), d_count_.get() + 2, cap, stream_);
         uint32_t found = 0;
         MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
         MMT_HIP(hipStreamSynchronize(stream_));
-        if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), 0u, stream_); break; }
+        if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), stream_); break; }
         if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
         cap = found + 1024;                            // rare: rerun with the exact size
     }

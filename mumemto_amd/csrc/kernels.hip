@@ -351,20 +351,6 @@ __device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
 // which the multi-GPU re-sort needs.
 // ============================================================================
 struct LongLcp { uint32_t p, q, h; };
-// index of the first byte of x equal to `sep` (8 if none); sep == 0 disables the test
-__device__ __forceinline__ uint32_t first_sep_byte(uint64_t x, uint32_t sep) {
-    if (!sep) return 8u;
-    const uint64_t t = x ^ (0x0101010101010101ull * sep);
-    const uint64_t z = (t - 0x0101010101010101ull) & ~t & 0x8080808080808080ull;
-    return z ? (uint32_t)(__builtin_ctzll(z) >> 3) : 8u;
-}
-// one 8-byte step of a suffix comparison: returns the number of matching characters (8 = all) where a byte equal
-// to `sep` never matches (unique terminators of the PFP dictionary)
-__device__ __forceinline__ uint32_t match8(uint64_t x, uint64_t y, uint32_t sep) {
-    const uint32_t mis = x != y ? (uint32_t)(__builtin_ctzll(x ^ y) >> 3) : 8u;
-    const uint32_t sp = first_sep_byte(x, sep);
-    return mis < sp ? mis : sp;
-}
 constexpr int IRR_STEPS = 24;
 
 template <int BLOCK, int PER>
@@ -372,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
                                                    const uint32_t* __restrict__ sa, const uint8_t* __restrict__ bwt,
                                                    uint32_t* __restrict__ K, uint32_t* __restrict__ anchor_rank,
                                                    uint32_t anchor_len, LongLcp* __restrict__ longs,
-                                                   uint32_t* __restrict__ long_count, uint32_t long_cap, uint32_t sep) {
+                                                   uint32_t* __restrict__ long_count, uint32_t long_cap) {
     constexpr int TILE = BLOCK * PER;
     __shared__ uint32_t s_q[TILE];
     __shared__ uint32_t s_n;
@@ -386,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
         bool irr = false;
         if (j < n) {
             const uint8_t b = bwt[j];
-            irr = j == 0 || b == 0 || (sep && b == sep) || b != bwt[j - 1];
+            irr = j == 0 || b == 0 || b != bwt[j - 1];
             if (anchor_rank) { const uint32_t p = sa[j]; if (p < anchor_len) anchor_rank[p] = (uint32_t)j; }
         }
         const uint64_t m = __ballot(irr);
@@ -406,9 +392,9 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
         uint32_t h = 0;
         bool done = false;
         for (int step = 0; step < IRR_STEPS && h < limit; step++) {
-            const uint32_t k8 = match8(load_u64(text + p + h), load_u64(text + qq + h), sep);
-            h += k8;
-            if (k8 < 8) { done = true; break; }
+            const uint64_t x = load_u64(text + p + h), y = load_u64(text + qq + h);
+            if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
+            h += 8;
         }
         if (h >= limit) { h = limit; done = true; }
         if (done) K[p] = h + p;
@@ -421,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
 
 // one wave per long match: 512 characters per step
 __global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, const LongLcp* __restrict__ longs,
-                           uint32_t count, uint32_t* __restrict__ K, uint32_t sep) {
+                           uint32_t count, uint32_t* __restrict__ K) {
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= count) return;
     const uint32_t p = longs[w].p, q = longs[w].q;
@@ -429,12 +415,13 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, const L
     const uint32_t limit = n - (p > q ? p : q);
     while (h < limit) {
         const uint32_t o = h + lane * 8;
-        uint32_t k8 = 8;
-        if (o < limit) k8 = match8(load_u64(text + p + o), load_u64(text + q + o), sep);   // zero padded by 64 bytes
-        const uint64_t m = __ballot(k8 < 8);
+        uint64_t x = 0, y = 0;
+        if (o < limit) { x = load_u64(text + p + o); y = load_u64(text + q + o); }   // text is zero padded by 64 bytes
+        const uint64_t m = __ballot(x != y);
         if (m) {
             const int first = __builtin_ctzll(m);
-            h += (uint32_t)first * 8 + (uint32_t)__shfl((int)k8, first, 64);
+            const uint64_t dx = __shfl(x ^ y, first, 64);
+            h += (uint32_t)first * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3);
             break;
         }
         h += 512;
@@ -453,19 +440,18 @@ __global__ void k_lcp_gather(const uint32_t* __restrict__ Ks, const uint32_t* __
 
 void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
                      uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
-                     uint32_t long_cap, uint32_t sep, hipStream_t s) {
+                     uint32_t long_cap, hipStream_t s) {
     constexpr int B = 256, PER = 8;
     MMT_HIP(hipMemsetAsync(K, 0, (size_t)n * 4, s));
     MMT_HIP(hipMemsetAsync(long_count, 0, 4, s));
     hipLaunchKernelGGL((k_irr_lcp<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, sa, bwt, K, anchor_rank,
-                       anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap, sep);
+                       anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap);
     MMT_HIP(hipGetLastError());
 }
-void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, uint32_t sep,
-              hipStream_t s) {
+void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s) {
     if (!count) return;
     hipLaunchKernelGGL(k_long_lcp, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, n,
-                       static_cast<const LongLcp*>(long_list), count, K, sep);
+                       static_cast<const LongLcp*>(long_list), count, K);
     MMT_HIP(hipGetLastError());
 }
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s) {

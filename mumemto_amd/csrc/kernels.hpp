@@ -51,13 +51,11 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
 // ISA-free LCP construction (see kernels.hip): K (n entries, cleared here) receives LCP + position at the
 // irreducible suffixes; matches longer than 192 characters are queued (12-byte records, long_cap of them) for
 // long_lcp; after an inclusive max-scan Ks of K, lcp_gather writes the column.  anchor_rank (optional) receives the
-// suffix ranks of the text positions below anchor_len.  sep != 0: bytes of that value are unique terminators (they
-// never match and are never a reducible BWT byte) -- the PFP dictionary, sorted with the same convention.
+// suffix ranks of the text positions below anchor_len.
 void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
                      uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
-                     uint32_t long_cap, uint32_t sep, hipStream_t s);
-void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, uint32_t sep,
-              hipStream_t s);
+                     uint32_t long_cap, hipStream_t s);
+void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s);
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
 

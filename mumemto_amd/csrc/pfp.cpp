@@ -111,36 +111,18 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     const int chars = std::min(63 / bits, 63);
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
-    S.sa_d.ensure(nd); S.rank_d.ensure(nd); S.lcp_d.ensure(nd + 1);
+    S.sa_d.ensure(nd); S.rank_d.ensure(nd);
     sorter_.reserve(std::max(nd, m));
     k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
     e3.stop(st);
-    // ... its LCP, the groups of equal proper phrase suffixes and the phrase ranks
+    // ... the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
     pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, pack_prev, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
-    // ebw is the BWT column of the dictionary (0 where the byte before is padding): its LCP array comes from the
-    // irreducible suffixes alone, like the text's (kernels.hip, "LCP column WITHOUT the inverse suffix array")
-    {
-        d_plcp_a_.ensure(nd); d_plcp_b_.ensure(nd); d_count_.ensure(4);
-        uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)nd / 256 + 4096);
-        if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
-        for (int attempt = 0; attempt < 2; attempt++) {
-            d_long_.ensure((size_t)cap * 12);
-            k::irreducible_lcp(S.dict.get(), nd, S.sa_d.get(), S.ebw.get(), d_plcp_a_.get(), nullptr, 0, d_long_.get(),
-                               d_count_.get() + 2, cap, 1u, st);
-            const uint32_t found = read_u32(d_count_.get() + 2, st);
-            if (found <= cap) { k::long_lcp(S.dict.get(), nd, d_long_.get(), found, d_plcp_a_.get(), 1u, st); break; }
-            if (attempt) throw std::runtime_error("long-match list overflow in the dictionary LCP construction");
-            cap = found + 1024;
-        }
-        prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_b_.get(), nd, st);
-        k::lcp_gather(d_plcp_b_.get(), S.sa_d.get(), nd, S.lcp_d.get(), st);
-    }
     S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
-    pk::group_flags(S.esuf.get(), S.lcp_d.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);
+    pk::group_flags(S.esuf.get(), S.sa_d.get(), S.dict.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);
     prims::inclusive_sum_u32(d_temp_, S.gflag.get(), S.gscan.get(), nd, st);
     prims::inclusive_sum_u32(d_temp_, S.pflag.get(), S.pscan.get(), nd, st);
     pk::phrase_ranks(S.esuf.get(), S.ephr.get(), S.pscan.get(), nd, S.prank.get(), st);

@@ -317,11 +317,14 @@ void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict
 }
 
 // Valid = proper suffix (not the whole phrase) of length >= w (pfp_lcp_mum.hpp:272-282).  Two
-// neighbours of the dictionary SA spell the same string iff they have the same length and their LCP
-// reaches it (:141-154 collects them as `same_suffix`).  vflag = valid, gflag = first of its group,
-// pflag = first byte of a phrase (their order gives the lexicographic phrase ranks).
-__global__ void k_group_flags(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ lcp_d, uint32_t nd,
-                              uint32_t w, uint32_t* __restrict__ gflag, uint32_t* __restrict__ pflag,
+// neighbours of the dictionary SA spell the same string iff they have the same length and the same
+// characters (:141-154 collects them as `same_suffix`); only neighbours of equal length are compared,
+// 8 bytes at a time straight from the dictionary -- no LCP array of the dictionary is needed.
+// vflag = valid, gflag = first of its group, pflag = first byte of a phrase (their order gives the
+// lexicographic phrase ranks).
+__global__ void k_group_flags(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ sa_d,
+                              const uint8_t* __restrict__ dict, uint32_t nd, uint32_t w,
+                              uint32_t* __restrict__ gflag, uint32_t* __restrict__ pflag,
                               uint32_t* __restrict__ vflag) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd) return;
@@ -333,15 +336,27 @@ __global__ void k_group_flags(const uint32_t* __restrict__ esuf, const uint32_t*
     if (valid && r > 0) {
         const uint32_t pe = esuf[r - 1];
         const bool pvalid = !(pe >> 31) && (pe & 0x7fffffffu) >= w;
-        if (pvalid && (pe & 0x7fffffffu) == sl && lcp_d[r] >= sl) fresh = false;
+        if (pvalid && (pe & 0x7fffffffu) == sl) {
+            const uint8_t* x = dict + sa_d[r];
+            const uint8_t* y = dict + sa_d[r - 1];
+            bool same = true;
+            uint32_t i = 0;
+            for (; i + 8 <= sl; i += 8) if (ld64(x + i) != ld64(y + i)) { same = false; break; }
+            if (same && i < sl) {                                 // last 1..7 characters (the dictionary is padded)
+                const uint64_t m = ~0ull >> (8 * (8 - (sl - i)));
+                same = ((ld64(x + i) ^ ld64(y + i)) & m) == 0;
+            }
+            if (same) fresh = false;
+        }
     }
     gflag[r] = fresh ? 1u : 0u;
     pflag[r] = is_start ? 1u : 0u;
     vflag[r] = valid ? 1u : 0u;
 }
-void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag,
-                 uint32_t* pflag, uint32_t* vflag, hipStream_t s) {
-    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, lcp_d, nd, w, gflag, pflag, vflag);
+void group_flags(const uint32_t* esuf, const uint32_t* sa_d, const uint8_t* dict, uint32_t nd, uint32_t w,
+                 uint32_t* gflag, uint32_t* pflag, uint32_t* vflag, hipStream_t s) {
+    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, sa_d, dict, nd, w, gflag, pflag,
+                       vflag);
     MMT_HIP(hipGetLastError());
 }
 

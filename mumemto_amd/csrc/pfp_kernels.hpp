@@ -26,8 +26,8 @@ void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, con
                bool pack_prev, hipStream_t s);
 void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, bool pack_prev,
                 uint32_t* esuf, uint32_t* ephr, uint8_t* ebw, hipStream_t s);
-void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag,
-                 uint32_t* pflag, uint32_t* vflag, hipStream_t s);
+void group_flags(const uint32_t* esuf, const uint32_t* sa_d, const uint8_t* dict, uint32_t nd, uint32_t w,
+                 uint32_t* gflag, uint32_t* pflag, uint32_t* vflag, hipStream_t s);
 void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,
                   hipStream_t s);
 // tab: n_distinct 16-byte records (phrase_table)

@@ -414,7 +414,7 @@ void Engine::run(const mmt_params& p) {
         // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
         // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of
         // short phrase suffixes (all occurrences of a trigger window) small (gpurun sweeps)
-        const uint32_t auto_w = n_ < (1ull << 30) ? 6 : 10, auto_p = n_ < (1ull << 30) ? 20 : 30;
+        const uint32_t auto_w = n_ < (1ull << 30) ? 6 : 10, auto_p = n_ < (1ull << 30) ? 16 : 30;
         if (kind == 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
         else suffix_sort();
         producer_used_ = kind;

@@ -53,9 +53,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
 
     // -- distinct phrases: fingerprints, sort, verified grouping
     e1.start(st);
-    S.h1.ensure(m); S.h2.ensure(m); S.hk_a.ensure(m); S.hk_b.ensure(m);
+    S.h1.ensure(m); S.pinfo.ensure((size_t)m * 16 + 16); S.hk_a.ensure(m); S.hk_b.ensure(m);
     S.iota.ensure(m); S.ord_a.ensure(m); S.order.ensure(m);
-    pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.h2.get(), st);
+    pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.pinfo.get(), st);
     pk::iota(S.iota.get(), m, st);
     S.dflags.ensure(m); S.scan.ensure(m);
     for (int attempt = std::getenv("MMT_PFP_TWO_FINGERPRINTS") ? 1 : 0;; attempt++) {     // the variable forces the rare path (tests)
@@ -64,13 +64,14 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
             prims::sort_pairs_u64_u32(d_temp_, S.h1.get(), S.hk_b.get(), S.iota.get(), S.order.get(), m, 0, 64, st);
         } else {
             // (rare) order by both fingerprints: stable sort by the second, then by the first
+            S.h2.ensure(m);
+            pk::second_fingerprint(S.pinfo.get(), m, S.h2.get(), st);
             prims::sort_pairs_u64_u32(d_temp_, S.h2.get(), S.hk_a.get(), S.iota.get(), S.ord_a.get(), m, 0, 64, st);
             pk::gather_u64(S.h1.get(), S.ord_a.get(), m, S.hk_a.get(), st);
             prims::sort_pairs_u64_u32(d_temp_, S.hk_a.get(), S.hk_b.get(), S.ord_a.get(), S.order.get(), m, 0, 64, st);
         }
         MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
-        pk::mark_distinct(S.order.get(), S.h1.get(), S.h2.get(), S.pstart.get(), S.plen.get(), S.vtext.get(), m,
-                          S.dflags.get(), S.err.get(), st);
+        pk::mark_distinct(S.order.get(), S.hk_b.get(), S.pinfo.get(), S.vtext.get(), m, S.dflags.get(), S.err.get(), st);
         prims::inclusive_sum_u32(d_temp_, S.dflags.get(), S.scan.get(), m, st);
         uint32_t flags2[2] = {0, 0};
         MMT_HIP(hipMemcpyAsync(flags2, S.err.get(), 8, hipMemcpyDeviceToHost, st));

@@ -158,7 +158,7 @@ __device__ __forceinline__ void hash_range(const uint8_t* __restrict__ v, uint64
 }
 __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
                               const uint32_t* __restrict__ len, uint32_t m, uint64_t* __restrict__ o1,
-                              uint64_t* __restrict__ o2) {
+                              uint4* __restrict__ pinfo) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const bool have = k < m;
@@ -187,36 +187,48 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const uint32_t* __r
     }
     if (have) {
         o1[k] = h1 ^ ((uint64_t)l * 0xD6E8FEB86659FD93ull);
-        o2[k] = h2 + ((uint64_t)l << 32);
+        const uint64_t g2 = h2 + ((uint64_t)l << 32);
+        pinfo[k] = make_uint4((uint32_t)g2, (uint32_t)(g2 >> 32), a, l);     // second fingerprint, start, length
     }
 }
-void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, uint64_t* h2,
+void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
                  hipStream_t s) {
-    hipLaunchKernelGGL(k_phrase_hash, dim3(grid_for(m, 256)), dim3(256), 0, s, v, start, len, m, h1, h2);
+    hipLaunchKernelGGL(k_phrase_hash, dim3(grid_for(m, 256)), dim3(256), 0, s, v, start, len, m, h1,
+                       static_cast<uint4*>(pinfo));
+    MMT_HIP(hipGetLastError());
+}
+// h2[k] out of the per-phrase records (only for the rare two-fingerprint ordering)
+__global__ void k_second_fingerprint(const uint4* __restrict__ pinfo, uint32_t m, uint64_t* __restrict__ h2) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) { const uint4 p = pinfo[k]; h2[k] = ((uint64_t)p.y << 32) | p.x; }
+}
+void second_fingerprint(const void* pinfo, uint32_t m, uint64_t* h2, hipStream_t s) {
+    hipLaunchKernelGGL(k_second_fingerprint, dim3(grid_for(m, 256)), dim3(256), 0, s, static_cast<const uint4*>(pinfo), m,
+                       h2);
     MMT_HIP(hipGetLastError());
 }
 
 __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
 
-// order[] lists the phrases sorted by (h1, h2); flags[k] = 1 where a new distinct phrase starts.
-// Equal fingerprints + equal length are confirmed by comparing the bytes; a mismatch there
-// (a 128-bit collision) raises *err instead of silently merging two different phrases.
-__global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64_t* __restrict__ h1,
-                                const uint64_t* __restrict__ h2, const uint32_t* __restrict__ start,
-                                const uint32_t* __restrict__ len, const uint8_t* __restrict__ v, uint32_t m,
+// order[] lists the phrases sorted by their first fingerprint (h1s = those fingerprints in sorted order), or by
+// both; flags[k] = 1 where a new distinct phrase starts.  Equal fingerprints + equal length are confirmed by
+// comparing the bytes; a mismatch there (a 128-bit collision) raises err[0] instead of silently merging two
+// different phrases.  The second fingerprint, start and length of a phrase sit in one 16-byte record.
+__global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64_t* __restrict__ h1s,
+                                const uint4* __restrict__ pinfo, const uint8_t* __restrict__ v, uint32_t m,
                                 uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     if (k == 0) { flags[0] = 1; return; }
-    const uint32_t x = order[k], y = order[k - 1];
-    const bool same1 = h1[x] == h1[y];
-    bool same = same1 && h2[x] == h2[y] && len[x] == len[y];
+    if (h1s[k] != h1s[k - 1]) { flags[k] = 1u; return; }
+    const uint4 X = pinfo[order[k]], Y = pinfo[order[k - 1]];
+    bool same = X.x == Y.x && X.y == Y.y && X.w == Y.w;
     // equal first fingerprints of different phrases: when the order came from the first fingerprint alone, equal
     // phrases need not be adjacent any more -- the host then repeats the grouping with both fingerprints
-    if (same1 && !same) atomicOr(err + 1, 1u);
+    if (!same) atomicOr(err + 1, 1u);
     if (same) {
-        const uint8_t* px = v + start[x]; const uint8_t* py = v + start[y];
-        const uint32_t l = len[x];
+        const uint8_t* px = v + X.z; const uint8_t* py = v + Y.z;
+        const uint32_t l = X.w;
         uint32_t i = 0;
         for (; i + 8 <= l; i += 8) if (ld64(px + i) != ld64(py + i)) { same = false; break; }
         if (same) for (; i < l; i++) if (px[i] != py[i]) { same = false; break; }
@@ -224,10 +236,10 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
     }
     flags[k] = same ? 0u : 1u;
 }
-void mark_distinct(const uint32_t* order, const uint64_t* h1, const uint64_t* h2, const uint32_t* start,
-                   const uint32_t* len, const uint8_t* v, uint32_t m, uint32_t* flags, uint32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL(k_mark_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, order, h1, h2, start, len, v, m, flags,
-                       err);
+void mark_distinct(const uint32_t* order, const uint64_t* h1s, const void* pinfo, const uint8_t* v, uint32_t m,
+                   uint32_t* flags, uint32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_mark_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, order, h1s,
+                       static_cast<const uint4*>(pinfo), v, m, flags, err);
     MMT_HIP(hipGetLastError());
 }
 

@@ -15,10 +15,12 @@ void trigger_masks(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint
 void trigger_cuts(const uint16_t* masks, uint32_t n, const uint32_t* block_off, uint32_t* cuts, hipStream_t s);
 void phrase_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t n, uint32_t w, uint32_t* start, uint32_t* len,
                    hipStream_t s);
-void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, uint64_t* h2,
+// h1: first fingerprint per phrase; pinfo: 16-byte record (second fingerprint, start, length) per phrase
+void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
                  hipStream_t s);
-void mark_distinct(const uint32_t* order, const uint64_t* h1, const uint64_t* h2, const uint32_t* start,
-                   const uint32_t* len, const uint8_t* v, uint32_t m, uint32_t* flags, uint32_t* err, hipStream_t s);
+void second_fingerprint(const void* pinfo, uint32_t m, uint64_t* h2, hipStream_t s);
+void mark_distinct(const uint32_t* order, const uint64_t* h1_sorted, const void* pinfo, const uint8_t* v, uint32_t m,
+                   uint32_t* flags, uint32_t* err, hipStream_t s);
 void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
                      uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
 void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,

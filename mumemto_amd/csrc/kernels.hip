@@ -1045,24 +1045,6 @@ void verify_candidates(const VerifyArgs& a, hipStream_t s) {
     MMT_HIP(hipGetLastError());
 }
 
-__global__ void k_gather_occ(const Cand* __restrict__ rows, const uint64_t* __restrict__ off, uint32_t n_rows,
-                             const uint32_t* __restrict__ sa, uint32_t* __restrict__ occ) {
-    // one wave per row
-    const uint32_t lane = threadIdx.x & 63;
-    uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= n_rows) return;
-    const Cand c = rows[r];
-    const uint32_t cnt = c.end - c.start + 1;
-    for (uint32_t k2 = lane; k2 < cnt; k2 += 64) occ[off[r] + k2] = sa[c.start + k2];
-}
-void gather_occurrences(const Cand* rows, const uint64_t* off, uint32_t n_rows, const uint32_t* sa, uint32_t* occ,
-                        hipStream_t s) {
-    if (!n_rows) return;
-    hipLaunchKernelGGL(k_gather_occ, dim3(grid_for((uint64_t)n_rows * 64, 256)), dim3(256), 0, s, rows, off, n_rows,
-                       sa, occ);
-    MMT_HIP(hipGetLastError());
-}
-
 // ============================================================================
 // A9  anchor merge, one fold step -- merge_partitions
 //     (src/merge_candidates.cpp:106-157), one thread per anchor position.
@@ -1106,17 +1088,6 @@ __global__ void k_fold_step(FoldArgs a) {
 }
 void fold_step(const FoldArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_fold_step, dim3(grid_for(a.len, 256)), dim3(256), 0, s, a);
-    MMT_HIP(hipGetLastError());
-}
-
-__global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint64_t* __restrict__ idx, uint32_t n,
-                             uint32_t* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[idx[i]];
-}
-void gather_u32(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* out, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_gather_u32, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, n, out);
     MMT_HIP(hipGetLastError());
 }
 

@@ -90,10 +90,6 @@ struct VerifyArgs {
 };
 void verify_candidates(const VerifyArgs& a, hipStream_t s);
 
-// occ[off[r] + k] = sa[rows[r].start + k]
-void gather_occurrences(const Cand* rows, const uint64_t* off, uint32_t n_rows, const uint32_t* sa, uint32_t* occ,
-                        hipStream_t s);
-
 // ---- A9 anchor merge, one fold step -------------------------------------------
 // Per anchor position i (parallel): thresholds merged into nb_out; emits
 // (i, row index in A, row index in B, new length) for every new MUM.
@@ -112,8 +108,6 @@ void fold_step(const FoldArgs& a, hipStream_t s);
 void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, uint32_t* ones, hipStream_t s);
 
 // out[i] = src[idx[i]]
-void gather_u32(const uint32_t* src, const uint64_t* idx, uint32_t n, uint32_t* out, hipStream_t s);
-
 void gather_u32_idx32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s);
 
 }}  // namespace mmt::k

@@ -792,15 +792,6 @@ void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t 
     MMT_HIP(hipGetLastError());
 }
 
-// rank[sa[j]] = j
-__global__ void k_invert_sa(const uint32_t* __restrict__ sa, uint32_t n, uint32_t* __restrict__ rank) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) rank[sa[j]] = j;
-}
-void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s) {
-    hipLaunchKernelGGL(k_invert_sa, dim3(grid_for(n, 256)), dim3(256), 0, s, sa, n, rank);
-    MMT_HIP(hipGetLastError());
-}
 
 __global__ void k_iota(uint32_t* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

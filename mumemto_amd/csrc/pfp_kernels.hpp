@@ -69,7 +69,6 @@ void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStrea
 void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
                      const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt,
                      uint32_t* err, hipStream_t s);
-void invert_sa(const uint32_t* sa, uint32_t n, uint32_t* rank, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);
 

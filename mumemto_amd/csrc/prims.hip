@@ -22,12 +22,6 @@ void sort_pairs_u64_u32(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* ko
         return rocprim::radix_sort_pairs(t, b, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
     });
 }
-void sort_pairs_u64_u64(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,
-                        uint64_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s) {
-    with_temp(temp, [&](void* t, size_t& b) {
-        return rocprim::radix_sort_pairs(t, b, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
-    });
-}
 void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                         uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s) {
     with_temp(temp, [&](void* t, size_t& b) {
@@ -75,15 +69,5 @@ void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin,
     });
 }
 
-uint32_t count_nonzero_u8(DevBuf<uint8_t>& temp, const uint8_t* flags, size_t n, uint32_t* d_scratch, hipStream_t s) {
-    auto as_u32 = rocprim::make_transform_iterator(flags, [] __device__(uint8_t f) -> uint32_t { return f ? 1u : 0u; });
-    with_temp(temp, [&](void* t, size_t& b) {
-        return rocprim::reduce(t, b, as_u32, d_scratch, uint32_t(0), n, rocprim::plus<uint32_t>(), s);
-    });
-    uint32_t v = 0;
-    MMT_HIP(hipMemcpyAsync(&v, d_scratch, 4, hipMemcpyDeviceToHost, s));
-    MMT_HIP(hipStreamSynchronize(s));
-    return v;
-}
 
 }}  // namespace mmt::prims

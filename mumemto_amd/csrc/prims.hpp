@@ -11,8 +11,6 @@ namespace mmt { namespace prims {
 
 void sort_pairs_u64_u32(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                         uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
-void sort_pairs_u64_u64(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,
-                        uint64_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                         uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
@@ -30,7 +28,5 @@ void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s);
 
-// number of non-zero bytes (d_scratch: one u32 on the device); synchronises the stream
-uint32_t count_nonzero_u8(DevBuf<uint8_t>& temp, const uint8_t* flags, size_t n, uint32_t* d_scratch, hipStream_t s);
 
 }}  // namespace mmt::prims

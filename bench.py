@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--pfp-p", type=int, default=0)
     ap.add_argument("--merge-metadata", action="store_true", help="record anchor thresholds also on 1 GPU")
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-device exercise the N > 1 path on a box with one GPU (testing only)")
+    ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (testing only)")
     return ap.parse_args()
 
 
@@ -76,10 +79,12 @@ def main():
     from mumemto_amd import dist as mdist
     from mumemto_amd import synth
 
+    if a.share_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(a.backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -194,6 +199,12 @@ def main():
                 result["config"]["output_equals_cpu_oracle"] = bool(cpu_out == out)
         else:
             result["cpu_baseline"] = None
+            if a.check:      # N > 1: the merged output must be the direct run's on the union, in fold column order
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import pyoracle as O
+                every = synth.pangenome(n_total_haps, a.length, a.divergence, a.seed)
+                order = mdist.merged_column_order(groups)
+                result["config"]["output_equals_cpu_oracle"] = bool(O.run([every[i] for i in order]).text() == out)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

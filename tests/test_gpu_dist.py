@@ -106,3 +106,28 @@ def test_device_resident_exchange_and_fold():
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multi_rank_path_on_one_gpu(world):
+    """bench.py's N > 1 path end to end -- torchrun, one process per rank, per-rank partition run, all-gather of the
+    HBM row tables, device fold on rank 0, re-sort -- with the ranks sharing GPU 0 under gloo (this box has one GPU;
+    RCCL wants one device per rank).  --check compares the merged bytes with the oracle's direct run on the union."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world),
+           "--steps", "2", "--warmup", "1", "--length", "150000", "--backend", "gloo", "--share-device", "--check"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["haplotypes"] == 1 + 15 * world
+    assert d["config"]["output_equals_cpu_oracle"] is True and d["config"]["output_rows"] > 0

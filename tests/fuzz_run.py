@@ -1,0 +1,48 @@
+"""GPU box helper: the differential test of test_gpu_random.py over many more seeds, plus mid-size collections
+(several k_scan tiles, bigger dictionaries).  usage: fuzz_run.py <first seed> <n seeds> [cases per seed]"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE]
+import numpy as np                                   # noqa: E402
+import pyoracle as O                                 # noqa: E402
+import mumemto_amd                                   # noqa: E402
+from mumemto_amd import synth                        # noqa: E402
+from test_gpu_random import random_collection, random_params    # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+cases = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+BIG = len(sys.argv) > 4 and sys.argv[4] == "big"     # every case a pangenome of 0.2 - 3 M text characters
+eng = mumemto_amd.Engine(0)
+done = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    for case in range(cases):
+        if BIG:
+            nd_ = int(rng.integers(2, 20))
+            docs = synth.pangenome(nd_, int(rng.integers(100000, 1500000) // nd_), float(rng.choice([0.001, 0.005, 0.02])),
+                                   seed=int(rng.integers(0, 1 << 30)), indel_rate=float(rng.choice([0, 0.001])))
+        elif case % 10 == 9:          # a mid-size pangenome now and then
+            docs = synth.pangenome(int(rng.integers(2, 9)), int(rng.integers(3000, 40000)), float(rng.choice([0.002, 0.01, 0.05])),
+                                   seed=int(rng.integers(0, 1 << 30)))
+        else:
+            docs = random_collection(rng)
+        p = random_params(rng, len(docs))
+        revcomp = bool(rng.integers(0, 2))
+        merge = p["max_doc_freq"] == 1 and p["num_distinct"] == len(docs) and bool(rng.integers(0, 2))
+        want = O.run(docs, revcomp=revcomp, merge=merge, **p)
+        for producer in ("direct", "pfp"):
+            wp = (int(rng.integers(2, 12)), int(rng.choice([3, 5, 7, 11, 13, 16, 20, 37, 100])))
+            eng.set_producer(producer, *wp)
+            eng.set_docs(docs)
+            eng.run(min_match_len=p["min_len"], num_distinct=p["num_distinct"], max_doc_freq=p["max_doc_freq"],
+                    max_total_freq=p["max_total_freq"], use_revcomp=revcomp, merge_metadata=merge)
+            if eng.output_text() != want.text():
+                print("MISMATCH", seed, case, producer, wp, p, revcomp, merge, [[r[:60] for r in d] for d in docs][:3], flush=True)
+                sys.exit(1)
+            if merge and not np.array_equal(eng.thresholds(), want.thresh()):
+                print("THRESH MISMATCH", seed, case, producer, wp, p, flush=True)
+                sys.exit(1)
+        done += 1
+print("fuzz ok: %d collections x 2 producers, seeds %d..%d" % (done, first, first + count - 1))

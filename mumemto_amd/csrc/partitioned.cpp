@@ -9,7 +9,9 @@
 // multi-MUMs only.
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 
 #include "engine.hpp"
 #include "merge.hpp"
@@ -49,9 +51,9 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     }
     const size_t G = groups.size();
     const uint64_t L = doc_len[0] + 1;
-    struct Part {
-        std::vector<uint32_t> length; std::vector<int64_t> offsets; std::vector<uint8_t> strands;
-        DevBuf<uint16_t> thresh; size_t n_docs;
+    struct Part {       // one partition's rows and thresholds, kept in HBM for the fold
+        DevBuf<uint32_t> length; DevBuf<int64_t> offsets; DevBuf<uint8_t> strands; DevBuf<uint16_t> thresh;
+        size_t n_rows = 0, n_docs = 0;
     };
     std::vector<Part> parts(G);
     std::vector<uint64_t> sub_len;
@@ -60,38 +62,73 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     q.merge_metadata = 1; q.num_distinct = 0; q.max_total_freq = 0;
     uint64_t max_group_bytes = 0;
     for (size_t g = 0; g < G; g++) max_group_bytes = std::max(max_group_bytes, base[groups[g].second] - base[groups[g].first]);
-    d_bases_own_.ensure(doc_len[0] + max_group_bytes + 16);      // once: the anchor is uploaded a single time
-    for (size_t g = 0; g < G; g++) {
-        const size_t a = groups[g].first, b = groups[g].second;
-        // anchor + the group's documents (contiguous in the caller's buffer) go to the device in two copies
-        sub_len.assign(1, doc_len[0]);
-        sub_len.insert(sub_len.end(), doc_len + a, doc_len + b);
-        const uint64_t group_bytes = base[b] - base[a];
-        if (g == 0 && doc_len[0])      // the anchor stays where it is for every partition
-            MMT_HIP(hipMemcpyAsync(d_bases_own_.get(), h_bases, doc_len[0], hipMemcpyHostToDevice, stream_));
-        if (group_bytes)
-            MMT_HIP(hipMemcpyAsync(d_bases_own_.get() + doc_len[0], h_bases + base[a], group_bytes, hipMemcpyHostToDevice,
-                                   stream_));
-        MMT_HIP(hipStreamSynchronize(stream_));
-        set_input_device(d_bases_own_.get(), sub_len.data(), sub_len.size());
-        run(q);
-        const HostRows& R = rows_;
-        Part& P = parts[g];
-        P.n_docs = sub_len.size();
-        P.length.assign(R.length, R.length + R.n_rows);
-        P.offsets.assign(R.mum_offsets, R.mum_offsets + R.n_rows * P.n_docs);
-        P.strands.assign(R.mum_strands, R.mum_strands + R.n_rows * P.n_docs);
-        P.thresh.ensure(L);
-        MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
-        MMT_HIP(hipStreamSynchronize(stream_));
-        for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
+    // Two input buffers: while partition g is processed, a helper thread copies the documents of partition g + 1
+    // from the caller's (pageable) memory into the other buffer on its own stream.  The anchor sits in front of both.
+    DevBuf<uint8_t> alt;
+    d_bases_own_.ensure(doc_len[0] + max_group_bytes + 16);
+    if (G > 1) alt.ensure(doc_len[0] + max_group_bytes + 16);
+    uint8_t* buf[2] = {d_bases_own_.get(), G > 1 ? alt.get() : d_bases_own_.get()};
+    hipStream_t copy_stream = nullptr;
+    MMT_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    std::thread uploader;
+    std::exception_ptr upload_error;
+    auto upload = [&](size_t g, int slot) {
+        try {
+            MMT_HIP(hipSetDevice(device_));
+            const size_t a = groups[g].first, b = groups[g].second;
+            if (base[b] > base[a])
+                MMT_HIP(hipMemcpyAsync(buf[slot] + doc_len[0], h_bases + base[a], base[b] - base[a], hipMemcpyHostToDevice,
+                                       copy_stream));
+            MMT_HIP(hipStreamSynchronize(copy_stream));
+        } catch (...) { upload_error = std::current_exception(); }
+    };
+    auto finish_upload = [&]() {
+        if (uploader.joinable()) uploader.join();
+        if (upload_error) { std::exception_ptr e = upload_error; upload_error = nullptr; std::rethrow_exception(e); }
+    };
+    try {
+        if (doc_len[0]) {
+            MMT_HIP(hipMemcpyAsync(buf[0], h_bases, doc_len[0], hipMemcpyHostToDevice, stream_));
+            if (G > 1) MMT_HIP(hipMemcpyAsync(buf[1], buf[0], doc_len[0], hipMemcpyDeviceToDevice, stream_));
+            MMT_HIP(hipStreamSynchronize(stream_));
+        }
+        upload(0, 0);
+        finish_upload();
+        for (size_t g = 0; g < G; g++) {
+            const size_t a = groups[g].first, b = groups[g].second;
+            if (g + 1 < G) uploader = std::thread(upload, g + 1, (int)((g + 1) & 1));
+            sub_len.assign(1, doc_len[0]);
+            sub_len.insert(sub_len.end(), doc_len + a, doc_len + b);
+            set_input_device(buf[g & 1], sub_len.data(), sub_len.size());
+            run(q);
+            Part& P = parts[g];
+            P.n_docs = sub_len.size(); P.n_rows = rows_.n_rows;
+            const uint32_t* dl; const int64_t* dof; const uint8_t* dst;
+            rows_mum_device(&dl, &dof, &dst);
+            const size_t cells = P.n_rows * P.n_docs;
+            P.length.ensure(P.n_rows + 1); P.offsets.ensure(cells + 1); P.strands.ensure(cells + 1); P.thresh.ensure(L);
+            if (P.n_rows) {
+                MMT_HIP(hipMemcpyAsync(P.length.get(), dl, P.n_rows * 4, hipMemcpyDeviceToDevice, stream_));
+                MMT_HIP(hipMemcpyAsync(P.offsets.get(), dof, cells * 8, hipMemcpyDeviceToDevice, stream_));
+                MMT_HIP(hipMemcpyAsync(P.strands.get(), dst, cells, hipMemcpyDeviceToDevice, stream_));
+            }
+            MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
+            MMT_HIP(hipStreamSynchronize(stream_));
+            for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
+            finish_upload();
+        }
+    } catch (...) {
+        if (uploader.joinable()) uploader.join();
+        (void)hipStreamDestroy(copy_stream);
+        throw;
     }
+    (void)hipStreamDestroy(copy_stream);
     std::vector<mmt_partition> mp(G);
     for (size_t g = 0; g < G; g++) {
-        mp[g].n_rows = parts[g].length.size(); mp[g].n_docs = parts[g].n_docs;
-        mp[g].length = parts[g].length.data(); mp[g].offsets = parts[g].offsets.data();
-        mp[g].strands = parts[g].strands.data(); mp[g].thresh = parts[g].thresh.get();
-        mp[g].thresh_len = L; mp[g].thresh_on_device = 1; mp[g].rows_on_device = 0;
+        mp[g].n_rows = parts[g].n_rows; mp[g].n_docs = parts[g].n_docs;
+        mp[g].length = parts[g].length.get(); mp[g].offsets = parts[g].offsets.get();
+        mp[g].strands = parts[g].strands.get(); mp[g].thresh = parts[g].thresh.get();
+        mp[g].thresh_len = L; mp[g].thresh_on_device = 1; mp[g].rows_on_device = 1;
     }
     merged_ = anchor_merge(*this, mp.data(), G, p.min_match_len);
     sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions

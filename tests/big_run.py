@@ -19,8 +19,10 @@ for rep in range(2):      # the first pass pays every hipMalloc
     print("pass %d: %.2f s, stage ms %s, pfp %s %s" % (rep, dt, [round(x, 1) for x in eng.stage_ms()],
           eng.pfp_counts(), [round(x, 1) for x in eng.pfp_stage_ms()]), flush=True)
 L, off, st = eng.rows_mum()
-print("partitions %d, %.2f s (%.3f Gbp/s incl. H2D), rows %d, output %d bytes, stage ms %s" % (
-    parts, dt, haps * length / dt / 1e9, len(L), eng.output_size(), [round(x, 1) for x in eng.stage_ms()]), flush=True)
+engine_s = eng.stage_ms()[7] / 1e3      # inside libmumemto: uploads, partitions, fold, formatting, downloads
+print("partitions %d, %.2f s wall in Python (%.3f Gbp/s), %.2f s inside the engine incl. H2D (%.3f Gbp/s), rows %d, "
+      "output %d bytes, stage ms %s" % (parts, dt, haps * length / dt / 1e9, engine_s, haps * length / engine_s / 1e9, len(L),
+                                        eng.output_size(), [round(x, 1) for x in eng.stage_ms()]), flush=True)
 rng = np.random.default_rng(0)
 comp = bytes.maketrans(b"ACGT", b"TGCA")
 for r in rng.integers(0, len(L), size=min(300, len(L))):

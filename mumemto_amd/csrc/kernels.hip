@@ -526,10 +526,11 @@ __device__ __forceinline__ uint32_t shift4b(uint32_t lo, uint32_t hi, uint32_t r
 __device__ __forceinline__ uint32_t prev_bytes(uint32_t cur, uint32_t before) { return (cur << 8) | (before >> 24); }
 
 // K0 = min(klev, 3): number of levels fused into the first pass.
-// EXACT: cap == num_distinct and the BWT test applies (strict multi-MUMs, every -k run without merge
-// metadata).  An interval then has exactly w + 1 entries, so "the BWT bytes are not all equal" is a second
-// window query -- on a sparse OR-table C over the change bytes bwt[t] ^ bwt[t-1], built next to T with the
-// same levels -- and the walk disappears: a queued position is a candidate as soon as lcp[s] < l.
+// "The BWT bytes of the first w + 1 entries are not all equal" is a second window query -- on a sparse OR-table C
+// over the change bytes bwt[t] ^ bwt[t-1], built next to T with the same levels (four bytes per word).
+// EXACT: cap == num_distinct and the BWT test applies (strict multi-MUMs, every -k run without merge metadata).
+// An interval then has exactly w + 1 entries: the C query moves into phase 1 and the walk disappears -- a queued
+// position is a candidate as soon as lcp[s] < l.
 // LDS byte address of a pointer into shared memory (what M0 / ds instructions take)
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     constexpr int TILE = BLOCK * VG * 4;
     constexpr int MAXG = VG + 1;                        // groups of 4 per thread incl. halo (halo <= 4 * BLOCK)
     constexpr uint32_t FLUSH_AT = OUT_CAP / 2;
+    constexpr bool USE_C = EXACT || K0 > 0;             // a window of one entry needs no table for its BWT test
     const uint32_t span = halo + TILE;
     extern __shared__ __align__(16) uint8_t smem[];
     // two column buffers: while one tile is processed the next one of this workgroup lands in the other by LDS-DMA
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     uint32_t* s_lcp = lcp_buf;
     uint8_t* s_bwt = bwt_buf;
     Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
-    uint32_t* s_C = reinterpret_cast<uint32_t*>(s_out + OUT_CAP);           // EXACT: span / 4 + 8 words of 4 change bytes
+    uint32_t* s_C = reinterpret_cast<uint32_t*>(s_out + OUT_CAP);           // span / 4 + 8 words of 4 change bytes
     __shared__ uint32_t s_on, s_base;
     const uint32_t lane = threadIdx.x & 63;
     uint16_t* my_queue = s_queue + (threadIdx.x >> 6) * (VG * 256);       // VG passes x 64 lanes x 4 positions
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             }
             reinterpret_cast<uint4*>(s_T)[g] = r;
         }
-        if (EXACT) {
+        if (USE_C) {
             // change bytes x[t] = bwt[t] ^ bwt[t-1] of entries i..i+11, then OR over windows of 2^K0 bytes
             const uint32_t* b32 = reinterpret_cast<const uint32_t*>(s_bwt + 12) + g;   // word before the group
             const uint32_t wm = b32[0], w0 = b32[1], w1 = b32[2], w2 = b32[3];
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 }
             }
             // ---- fused levels 0..K0-1 ----
-            if (K0 > 0 || EXACT) {
+            if (USE_C) {
                 if (INT) {
 #pragma unroll
                     for (int q = 0; q < VG; q++) fuse_group(threadIdx.x + q * BLOCK);
@@ -704,14 +706,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                     if (g < groups) {
                         const uint32_t g2 = g + gstep < groups ? g + gstep : groups - 1;
                         rt[q] = umin4(t4[g], t4[g2]);
-                        if (EXACT) rc[q] = s_C[g] | s_C[g2];
+                        rc[q] = s_C[g] | s_C[g2];
                     }
                 }
                 lds_barrier();
 #pragma unroll
                 for (int q = 0; q < MAXG; q++) {
                     const uint32_t g = threadIdx.x + q * BLOCK;
-                    if (g < groups) { t4[g] = rt[q]; if (EXACT) s_C[g] = rc[q]; }
+                    if (g < groups) { t4[g] = rt[q]; s_C[g] = rc[q]; }
                 }
                 lds_barrier();
             }
@@ -787,11 +789,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 continue;
             }
             // general case: finish the walk from s = j - w - 1 leftwards
-            bool chg = false;
-            {   // BWT bytes of [k, j-1] not all equal?  (s_bwt is offset by 16)
-                const uint8_t b0 = s_bwt[16 + lj - 1];
-                for (uint32_t t = lk; t + 1 < lj; t++) chg |= s_bwt[16 + t] != b0;
-            }
+            // a BWT change among the entries k .. j-1?  Two lookups in the window table of the change bytes (the walk
+            // below adds the entries further left one by one)
+            const uint8_t* c8 = reinterpret_cast<const uint8_t*>(s_C);
+            bool chg = USE_C ? (c8[lj - w] | c8[lj - wstep]) != 0 : s_bwt[16 + lj - 1] != s_bwt[16 + lj - 2];
             bool done = false;
             while (lk > 0) {
                 const uint32_t v = s_lcp[lk - 1];
@@ -865,7 +866,7 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     if (halo > 4 * B) halo = 4 * B;                        // beyond this the walk reads the cached global columns
     if (halo < w + 1) exact = false;
     size_t lds = (size_t)(halo + TILE + 16) * 12 + (size_t)(halo + TILE + 32) * 2 + (size_t)TILE * 2 +
-                 (size_t)OUT_CAP * sizeof(Cand) + (exact ? (size_t)(halo + TILE + 32) : 0);
+                 (size_t)OUT_CAP * sizeof(Cand) + (size_t)(halo + TILE + 32);
     uint32_t n_tiles = grid_for(a.n, TILE);
     unsigned grid = n_tiles < 256u * blocks_per_cu ? n_tiles : 256u * blocks_per_cu;
     dim3 g(grid), b(B);

@@ -48,17 +48,79 @@ void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out,
         return rocprim::exclusive_scan(t, b, in, out, uint64_t(0), n, rocprim::plus<uint64_t>(), s);
     });
 }
+// ---- stream compaction of flagged indices (hand-written: rocprim::select moves 0.2 TB/s on this shape) ----
+// Pass 1: every thread turns ITEMS consecutive flags into a bit mask and the workgroup counts them; an exclusive
+// scan of the workgroup counts follows; pass 2 rebuilds the masks and writes the indices in order.
+template <typename F, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_flag_counts(const F* __restrict__ flags, size_t n,
+                                                       uint32_t* __restrict__ block_count) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const size_t i0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) if (i0 + q < n && flags[i0 + q]) c++;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
+}
+template <typename F, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_flag_write(const F* __restrict__ flags, size_t n,
+                                                      const uint32_t* __restrict__ block_off,
+                                                      const uint32_t* __restrict__ block_count, uint32_t n_blocks,
+                                                      uint32_t* __restrict__ out, uint32_t* __restrict__ d_count) {
+    __shared__ uint32_t s_wave[BLOCK / 64];
+    const size_t i0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * ITEMS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) if (i0 + q < n && flags[i0 + q]) mask |= 1u << q;
+    const uint32_t c = __popc(mask);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t at = block_off[blockIdx.x] + inc - c;
+    for (uint32_t wv = 0; wv < wave; wv++) at += s_wave[wv];
+    while (mask) {
+        const uint32_t b = __builtin_ctz(mask);
+        out[at++] = (uint32_t)(i0 + b);
+        mask &= mask - 1;
+    }
+    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) *d_count = block_off[n_blocks - 1] + block_count[n_blocks - 1];
+}
+template <typename F>
+static void select_flagged(DevBuf<uint8_t>& temp, const F* flags, uint32_t* out, uint32_t* d_count, size_t n,
+                           hipStream_t s) {
+    constexpr int BLOCK = 256, ITEMS = 16;
+    if (n == 0) { MMT_HIP(hipMemsetAsync(d_count, 0, 4, s)); return; }
+    const uint32_t blocks = (uint32_t)((n + (size_t)BLOCK * ITEMS - 1) / ((size_t)BLOCK * ITEMS));
+    // temp = [workgroup counts | their exclusive scan | scratch of the scan]
+    size_t scan_bytes = 0;
+    MMT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, uint32_t(0), blocks,
+                                    rocprim::plus<uint32_t>(), s));
+    const size_t head = ((size_t)blocks * 8 + 255) & ~(size_t)255;
+    temp.ensure(head + scan_bytes + 256);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(temp.get());
+    uint32_t* off = cnt + blocks;
+    hipLaunchKernelGGL((k_flag_counts<F, BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, flags, n, cnt);
+    MMT_HIP(rocprim::exclusive_scan(temp.get() + head, scan_bytes, cnt, off, uint32_t(0), blocks,
+                                    rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL((k_flag_write<F, BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, flags, n, off, cnt, blocks, out,
+                       d_count);
+    MMT_HIP(hipGetLastError());
+}
 void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                     hipStream_t s) {
-    rocprim::counting_iterator<uint32_t> idx(0);
-    with_temp(temp, [&](void* t, size_t& b) { return rocprim::select(t, b, idx, flags, out, d_count, n, s); });
+    select_flagged(temp, flags, out, d_count, n, s);
 }
-
-
 void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                              hipStream_t s) {
-    rocprim::counting_iterator<uint32_t> idx(0);
-    with_temp(temp, [&](void* t, size_t& b) { return rocprim::select(t, b, idx, flags, out, d_count, n, s); });
+    select_flagged(temp, flags, out, d_count, n, s);
 }
 void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,

@@ -28,10 +28,75 @@ void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* ko
         return rocprim::radix_sort_pairs(t, b, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
     });
 }
+// Running maximum in two passes over the data (workgroup maxima, a small scan of those, then the scan proper with
+// the carry-in): rocprim's single-pass look-back scan reaches 1.1 TB/s on 387 M elements with this operator.
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_block_max(const uint32_t* __restrict__ in, size_t n,
+                                                     uint32_t* __restrict__ block_max) {
+    __shared__ uint32_t s_w[BLOCK / 64];
+    const size_t base = (size_t)blockIdx.x * BLOCK * ITEMS;
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {                  // coalesced: consecutive threads read consecutive elements
+        const size_t i = base + (size_t)q * BLOCK + threadIdx.x;
+        if (i < n) { const uint32_t v = in[i]; m = v > m ? v : m; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const uint32_t y = __shfl_xor(m, o, 64); m = y > m ? y : m; }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = 0;
+        for (int w = 0; w < BLOCK / 64; w++) r = s_w[w] > r ? s_w[w] : r;
+        block_max[blockIdx.x] = r;
+    }
+}
+template <int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_block_max_scan(const uint32_t* __restrict__ in, size_t n,
+                                                          const uint32_t* __restrict__ carry /* exclusive */,
+                                                          uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_w[BLOCK / 64];
+    const size_t base = (size_t)blockIdx.x * BLOCK * ITEMS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t run = carry[blockIdx.x];
+    for (int q = 0; q < ITEMS; q++) {                  // ITEMS rounds of BLOCK consecutive elements
+        const size_t i = base + (size_t)q * BLOCK + threadIdx.x;
+        uint32_t v = i < n ? in[i] : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(v, o, 64); if (lane >= (uint32_t)o && y > v) v = y; }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        uint32_t pre = run;
+        for (uint32_t w2 = 0; w2 < wave; w2++) pre = s_w[w2] > pre ? s_w[w2] : pre;
+        v = v > pre ? v : pre;
+        if (i < n) out[i] = v;
+        uint32_t tot = run;
+        for (int w2 = 0; w2 < BLOCK / 64; w2++) tot = s_w[w2] > tot ? s_w[w2] : tot;
+        run = tot;
+        __syncthreads();
+    }
+}
 void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
-    with_temp(temp, [&](void* t, size_t& b) {
-        return rocprim::inclusive_scan(t, b, in, out, n, rocprim::maximum<uint32_t>(), s);
-    });
+    constexpr int BLOCK = 256, ITEMS = 16;
+    if (n < (size_t)1 << 22) {                          // small inputs: the library scan
+        with_temp(temp, [&](void* t, size_t& b) {
+            return rocprim::inclusive_scan(t, b, in, out, n, rocprim::maximum<uint32_t>(), s);
+        });
+        return;
+    }
+    const uint32_t blocks = (uint32_t)((n + (size_t)BLOCK * ITEMS - 1) / ((size_t)BLOCK * ITEMS));
+    size_t scan_bytes = 0;
+    MMT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, uint32_t(0), blocks,
+                                    rocprim::maximum<uint32_t>(), s));
+    const size_t head = ((size_t)blocks * 8 + 255) & ~(size_t)255;
+    temp.ensure(head + scan_bytes + 256);
+    uint32_t* bmax = reinterpret_cast<uint32_t*>(temp.get());
+    uint32_t* carry = bmax + blocks;
+    hipLaunchKernelGGL((k_block_max<BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, in, n, bmax);
+    MMT_HIP(rocprim::exclusive_scan(temp.get() + head, scan_bytes, bmax, carry, uint32_t(0), blocks,
+                                    rocprim::maximum<uint32_t>(), s));
+    hipLaunchKernelGGL((k_block_max_scan<BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, in, n, carry, out);
+    MMT_HIP(hipGetLastError());
 }
 void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
     with_temp(temp, [&](void* t, size_t& b) {

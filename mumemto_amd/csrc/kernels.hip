@@ -485,11 +485,13 @@ void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* b
 //     Left-maximality (check_bwt_range, :189-192) = some t in (s, j-1] with
 //     bwt[t] != bwt[t-1], accumulated during the same walk.
 //     LCP and BWT tiles (+ left halo of `cap` entries) are staged in LDS; the
-//     positions with a falling edge are first compacted into an LDS work queue
-//     so that every lane of a wave walks a real candidate.
+//     positions that can close something are first compacted into a work queue
+//     (one per wave) so that every lane of a wave walks a real candidate.
 // ============================================================================
 //
-// Two ideas keep the kernel off the instruction-issue and atomic limits:
+// What keeps the kernel off the memory-latency, instruction-issue and atomic limits:
+//  * two column buffers per workgroup: the next tile of the workgroup arrives by LDS-DMA
+//    (global_load_lds_dwordx4) while the current one is processed; barriers wait for LDS traffic only.
 //  * every reportable interval has >= num_distinct entries, so the first
 //    w = num_distinct - 1 steps of the walk are replaced by one range-min /
 //    range-or query on sparse tables T_k[i] = min(lcp[i .. i+2^k-1]) (and the

@@ -280,6 +280,122 @@ void make_round_keys(const uint32_t* sa_c, const uint32_t* head_c, uint32_t m, c
     MMT_HIP(hipGetLastError());
 }
 
+// ---- local sort of a doubling round -------------------------------------------------------------
+// The active elements of a round arrive grouped by bucket (the high key bits): sorting them only permutes elements
+// inside buckets.  Tiles that begin and end on bucket boundaries and fit LDS are sorted there (bitonic network);
+// ranges that contain a bucket too long for a tile are listed for a segmented radix sort.
+constexpr uint32_t ROUND_NO_BOUND = 0xffffffffu;
+__global__ void k_round_tile_bounds(const uint64_t* __restrict__ keys, uint32_t m, int shift, uint32_t target,
+                                    uint32_t limit, uint32_t n_tiles, uint32_t* __restrict__ bound) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    if (t == n_tiles) { bound[t] = m; return; }
+    uint64_t c = (uint64_t)t * target;
+    if (t == 0) { bound[0] = 0; return; }
+    const uint64_t stop = c + limit < m ? c + limit : m;
+    while (c < stop && (keys[c] >> shift) == (keys[c - 1] >> shift)) c++;
+    bound[t] = c >= m ? m : (c == stop ? ROUND_NO_BOUND : (uint32_t)c);      // stop reached inside a long bucket
+}
+template <int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void k_round_local_sort(const uint64_t* __restrict__ kin,
+                                                            const uint32_t* __restrict__ vin,
+                                                            uint64_t* __restrict__ kout, uint32_t* __restrict__ vout,
+                                                            const uint32_t* __restrict__ bound, uint32_t n_tiles,
+                                                            uint32_t* __restrict__ big_begin,
+                                                            uint32_t* __restrict__ big_end,
+                                                            uint32_t* __restrict__ big_count, uint32_t big_cap,
+                                                            int shift) {
+    __shared__ uint64_t s_k[CAP];
+    __shared__ uint32_t s_v[CAP];
+    __shared__ uint32_t s_long;
+    const uint32_t t = blockIdx.x;
+    const uint32_t b = bound[t];
+    if (b == ROUND_NO_BOUND) return;                       // this tile starts inside a bucket: an earlier tile owns it
+    uint32_t u = t + 1;
+    while (bound[u] == ROUND_NO_BOUND) u++;                // bound[n_tiles] = m always ends the search
+    const uint32_t e = bound[u];
+    if (e <= b) return;
+    const uint32_t len = e - b;
+    if (len > (uint32_t)CAP) {
+        if (threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(big_count, 1u);
+            if (slot < big_cap) { big_begin[slot] = b; big_end[slot] = e; }
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < len; i += BLOCK) { s_k[i] = kin[b + i]; s_v[i] = vin[b + i]; }
+    if (threadIdx.x == 0) s_long = 0;
+    __syncthreads();
+    // Buckets are short (a few elements on a pangenome): every element finds its bucket by walking left and right
+    // and takes the slot "bucket start + number of bucket elements that sort before it".  A bucket of more than
+    // SHORT elements anywhere in the tile sends the whole tile through the bitonic network instead.
+    constexpr uint32_t SHORT = 48;
+    constexpr int PER = CAP / BLOCK;
+    uint32_t slot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = threadIdx.x + q * BLOCK;
+        slot[q] = i;
+        if (i < len) {
+            const uint64_t ki = s_k[i], hi = ki >> shift;
+            uint32_t st = i, steps = 0;
+            while (st > 0 && (s_k[st - 1] >> shift) == hi && steps <= SHORT) { st--; steps++; }
+            uint32_t before = 0, j = st, cnt = 0;
+            while (j < len && cnt <= SHORT) {
+                const uint64_t kj = s_k[j];
+                if ((kj >> shift) != hi) break;
+                before += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+                j++; cnt++;
+            }
+            if (steps > SHORT || cnt > SHORT) s_long = 1;
+            slot[q] = st + before;
+        }
+    }
+    __syncthreads();
+    if (!s_long) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = threadIdx.x + q * BLOCK;
+            if (i < len) { kout[b + slot[q]] = s_k[i]; vout[b + slot[q]] = s_v[i]; }
+        }
+        return;
+    }
+    uint32_t P = 64;
+    while (P < len) P <<= 1;
+    for (uint32_t i = len + threadIdx.x; i < P; i += BLOCK) { s_k[i] = ~0ull; s_v[i] = 0u; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint64_t a = s_k[i], c = s_k[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) {
+                        s_k[i] = c; s_k[l] = a;
+                        const uint32_t va = s_v[i]; s_v[i] = s_v[l]; s_v[l] = va;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < len; i += BLOCK) { kout[b + i] = s_k[i]; vout[b + i] = s_v[i]; }
+}
+void round_tile_bounds(const uint64_t* keys, uint32_t m, int shift, uint32_t target, uint32_t limit, uint32_t n_tiles,
+                       uint32_t* bound, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_tile_bounds, dim3(grid_for((uint64_t)n_tiles + 1, 256)), dim3(256), 0, s, keys, m, shift,
+                       target, limit, n_tiles, bound);
+    MMT_HIP(hipGetLastError());
+}
+void round_local_sort(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, const uint32_t* bound,
+                      uint32_t n_tiles, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count, uint32_t big_cap,
+                      int shift, hipStream_t s) {
+    hipLaunchKernelGGL((k_round_local_sort<256, (int)ROUND_TILE_CAP>), dim3(n_tiles), dim3(256), 0, s, kin, vin, kout, vout,
+                       bound, n_tiles, big_begin, big_end, big_count, big_cap, shift);
+    MMT_HIP(hipGetLastError());
+}
+
 __global__ void k_mark_subheads(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos, uint32_t m,
                                 uint32_t* __restrict__ headval) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -38,6 +38,16 @@ void gather_active(const uint32_t* idx, uint32_t m, const uint32_t* sa, const ui
 // keys[c] = head[c] << shift | (rank[sa[c]+h] + 1, or 0 past the end)
 void make_round_keys(const uint32_t* sa_c, const uint32_t* head_c, uint32_t m, const uint32_t* rank, uint32_t n,
                      uint32_t h, int shift, uint64_t* keys, hipStream_t s);
+// Local sort of a doubling round (the active elements are grouped by bucket = the key bits from `shift` up):
+// bound[t] (n_tiles + 1 entries) = first bucket start at or after t * target, ROUND_NO_BOUND when none within
+// `limit` elements; round_local_sort sorts every range between consecutive bounds that fits ROUND_TILE_CAP
+// elements in LDS and lists the longer ones (begin, end) for a segmented radix sort.
+static const uint32_t ROUND_TILE_CAP = 2048;
+void round_tile_bounds(const uint64_t* keys, uint32_t m, int shift, uint32_t target, uint32_t limit, uint32_t n_tiles,
+                       uint32_t* bound, hipStream_t s);
+void round_local_sort(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, const uint32_t* bound,
+                      uint32_t n_tiles, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count, uint32_t big_cap,
+                      int shift, hipStream_t s);
 // headval[c] = pos[c] if keys[c] != keys[c-1] (or c == 0) else 0
 void mark_subheads(const uint64_t* keys, const uint32_t* pos, uint32_t m, uint32_t* headval, hipStream_t s);
 // SA[pos[c]] = sa_sorted[c]; rank[sa_sorted[c]] = newhead[c]; flags[c] = still unsorted

@@ -196,5 +196,13 @@ void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin,
     });
 }
 
+void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                                     uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                     const uint32_t* end, int end_bit, hipStream_t s) {
+    with_temp(temp, [&](void* t, size_t& b) {
+        return rocprim::segmented_radix_sort_pairs(t, b, kin, kout, vin, vout, n, segments, begin, end, 0u,
+                                                   (unsigned)end_bit, s);
+    });
+}
 
 }}  // namespace mmt::prims

@@ -28,5 +28,9 @@ void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s);
 
+// 64-bit keys, ranges [begin[i], end[i]) of one array; elements outside the ranges are not touched
+void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
+                                     uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                     const uint32_t* end, int end_bit, hipStream_t s);
 
 }}  // namespace mmt::prims

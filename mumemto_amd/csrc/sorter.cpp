@@ -1,6 +1,7 @@
 #include "sorter.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels.hpp"
@@ -14,6 +15,37 @@ void DoublingSorter::reserve(uint32_t n) {
     keys_a_.ensure(n); keys_b_.ensure(n);
     sac_a_.ensure(n); sac_b_.ensure(n); pos_a_.ensure(n); pos_b_.ensure(n); headc_.ensure(n);
     headval_.ensure(n); head_.ensure(n); idx_.ensure(n); flags_.ensure(n); count_.ensure(4);
+}
+
+// (keys_a_, sac_a_) -> (keys_b_, sac_b_), m active elements grouped by bucket: tiles between bucket boundaries are
+// sorted in LDS, the few ranges holding a bucket longer than a tile by one segmented radix sort.
+void DoublingSorter::sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s) {
+    static const bool global_sort = std::getenv("MMT_SORT_GLOBAL_ROUNDS") != nullptr;     // the old path (tests)
+    if (global_sort || m < 4096) {
+        prims::sort_pairs_u64_u32(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m, 0,
+                                  std::min(64, 2 * shift), s);
+        return;
+    }
+    const uint32_t target = 640, limit = k::ROUND_TILE_CAP;
+    const uint32_t n_tiles = (m + target - 1) / target;
+    bound_.ensure((size_t)n_tiles + 2);
+    uint32_t big_cap = (uint32_t)std::max<size_t>(big_begin_.size(), 4096);
+    big_begin_.ensure(big_cap); big_end_.ensure(big_cap);
+    MMT_HIP(hipMemsetAsync(count_.get() + 1, 0, 4, s));
+    k::round_tile_bounds(keys_a_.get(), m, shift, target, limit, n_tiles, bound_.get(), s);
+    k::round_local_sort(keys_a_.get(), sac_a_.get(), keys_b_.get(), sac_b_.get(), bound_.get(), n_tiles, big_begin_.get(),
+                        big_end_.get(), count_.get() + 1, big_cap, shift, s);
+    uint32_t big = 0;
+    MMT_HIP(hipMemcpyAsync(&big, count_.get() + 1, 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    if (big > big_cap) {                                   // (rare) more long ranges than listed: sort the round globally
+        prims::sort_pairs_u64_u32(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m, 0,
+                                  std::min(64, 2 * shift), s);
+        return;
+    }
+    if (big)
+        prims::segmented_sort_pairs_u64_ranges(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m, big,
+                                               big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s);
 }
 
 int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, uint32_t* rank, DevBuf<uint8_t>& temp,
@@ -37,8 +69,7 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
         if (++rounds > 64) throw std::runtime_error("suffix sort did not converge");
         const uint32_t hh = h > 0xffffffffull ? 0xffffffffu : (uint32_t)h;
         k::make_round_keys(sac_a_.get(), headc_.get(), m, rank, n, hh, shift, keys_a_.get(), s);
-        prims::sort_pairs_u64_u32(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m, 0,
-                                  std::min(64, 2 * shift), s);
+        sort_round(m, shift, temp, s);
         k::mark_subheads(keys_b_.get(), pos_a_.get(), m, headval_.get(), s);
         prims::inclusive_max_u32(temp, headval_.get(), head_.get(), m, s);
         k::apply_round(sac_b_.get(), head_.get(), pos_a_.get(), m, sa, rank, flags_.get(), s);

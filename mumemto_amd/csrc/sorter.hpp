@@ -29,8 +29,9 @@ public:
     DevBuf<uint32_t>& u32_b() { return sac_b_; }
 
 private:
+    void sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s);
     DevBuf<uint64_t> keys_a_, keys_b_;
-    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, headval_, head_, idx_, count_;
+    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, headval_, head_, idx_, count_, bound_, big_begin_, big_end_;
     DevBuf<uint8_t> flags_;
 };
 

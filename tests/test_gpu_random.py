@@ -131,3 +131,16 @@ def test_iupac_and_arbitrary_bytes():
     with pytest.raises(mumemto_amd.MumemtoError, match="reserves"):
         eng.run(min_match_len=4)
     eng.close()
+
+
+def test_adversarial_shapes_against_the_oracle():
+    """Homopolymers, exact copies, tandem / periodic repeats, two-letter texts, N runs: buckets of the suffix sort that
+    never split early (bitonic and segmented-sort paths of the doubling rounds), matches of tens of thousands of
+    characters (k_long_lcp), phrases without triggers.  Both producers against the oracle (tests/stress_shapes.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "stress_shapes.py"), "40000"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

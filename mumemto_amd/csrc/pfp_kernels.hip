@@ -47,9 +47,10 @@ void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_
 // (newscan.hpp:266), which holds for every trigger with i >= w - 1.
 // Pass 1: one 16-bit mask per thread (16 consecutive positions) + the number of triggers per workgroup.
 // Pass 2 (after an exclusive scan of the workgroup counts): the trigger positions, ascending.
+constexpr uint32_t KR_PRIME = 1999999973u;             // newscan.hpp:86 (compile-time: reductions become multiplies)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restrict__ text, uint32_t n, uint32_t w,
-                                                         uint32_t p, uint64_t prime, uint64_t pot,
+                                                         uint32_t p, uint32_t pot,
                                                          uint16_t* __restrict__ masks,
                                                          uint32_t* __restrict__ block_count) {
     constexpr int PER = 16;
@@ -60,11 +61,11 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
     const uint64_t i0 = t * PER;
     uint32_t mask = 0;
     if (i0 < n) {
-        uint64_t h = 0;
+        uint32_t h = 0;                                    // always < KR_PRIME < 2^31
         for (uint32_t k = 0; k < w; k++) {                 // window ending at i0
             int64_t pos = (int64_t)i0 - (int64_t)w + 1 + k;
-            uint64_t c = pos >= 0 ? text[pos] : 0;
-            h = (h * 256 + c) % prime;
+            uint32_t c = pos >= 0 ? text[pos] : 0;
+            h = (uint32_t)(((uint64_t)h * 256 + c) % KR_PRIME);
         }
 #pragma unroll
         for (int q = 0; q < PER; q++) {
@@ -73,10 +74,10 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
             if (i + 1 >= w && h % p == 0) mask |= 1u << q;
             // roll to i + 1: drop T[i-w+1], add T[i+1]
             const int64_t drop = (int64_t)i - (int64_t)w + 1;
-            const uint64_t out = drop >= 0 ? text[drop] : 0;
-            const uint64_t in = i + 1 < n ? text[i + 1] : 0;
-            h = (h + prime - (out * pot) % prime) % prime;
-            h = (h * 256 + in) % prime;
+            const uint32_t out = drop >= 0 ? text[drop] : 0;
+            const uint32_t in = i + 1 < n ? text[i + 1] : 0;
+            h = (uint32_t)((h + KR_PRIME - (uint32_t)(((uint64_t)out * pot) % KR_PRIME)) % KR_PRIME);
+            h = (uint32_t)(((uint64_t)h * 256 + in) % KR_PRIME);
         }
         masks[t] = (uint16_t)mask;
     }
@@ -112,10 +113,9 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restri
 uint32_t trigger_blocks(uint32_t n) { return grid_for(((uint64_t)n + 15) / 16, 256); }
 void trigger_masks(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
                    hipStream_t s) {
-    const uint64_t prime = 1999999973ull;              // newscan.hpp:86
     uint64_t pot = 1;
-    for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % prime;
-    hipLaunchKernelGGL(k_trigger_masks<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, w, p, prime, pot, masks,
+    for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % KR_PRIME;
+    hipLaunchKernelGGL(k_trigger_masks<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, w, p, (uint32_t)pot, masks,
                        block_count);
     MMT_HIP(hipGetLastError());
 }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_local_sort(const uint64_t* __re
     // Buckets are short (a few elements on a pangenome): every element finds its bucket by walking left and right
     // and takes the slot "bucket start + number of bucket elements that sort before it".  A bucket of more than
     // SHORT elements anywhere in the tile sends the whole tile through the bitonic network instead.
-    constexpr uint32_t SHORT = 48;
+    constexpr uint32_t SHORT = 128;
     constexpr int PER = CAP / BLOCK;
     uint32_t slot[PER];
 #pragma unroll

@@ -157,18 +157,23 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const uint32_t nd = S.dict_len;
     d_sa_.ensure(n); d_bwt_.ensure((size_t)n + 16);     // no inverse suffix array on this path (see Engine::lcp_bwt)
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
-    S.occ_cnt.ensure(D); S.occ_start.ensure(D); S.occ_sorted.ensure(m); S.occ_pos.ensure(m); S.occ_key.ensure(m);
-    MMT_HIP(hipMemsetAsync(S.occ_cnt.get(), 0, (size_t)D * 4, st));
-    pk::occ_keys(S.pid.get(), S.isa_p.get(), m, shift, sorter_.keys_in(), sorter_.vals_in(), S.occ_cnt.get(), st);
-    prims::sort_pairs_u64_u32(d_temp_, sorter_.keys_in(), sorter_.keys_b().get(), sorter_.vals_in(), S.occ_sorted.get(),
-                              m, 0, std::min(64, shift + bit_width_u64(D)), st);
-    prims::exclusive_sum_u32(d_temp_, S.occ_cnt.get(), S.occ_start.get(), D, st);
-    pk::occ_payload(S.occ_sorted.get(), S.pstart.get(), S.isa_p.get(), m, S.occ_pos.get(), S.occ_key.get(), st);
+    S.occ_start.ensure((size_t)D + 2); S.occ_pos.ensure(m); S.occ_key.ensure(m);
+    S.occ_ids.ensure((size_t)m + 1); S.occ_ts.ensure((size_t)m + 1);
+    {
+        sorter_.u32_a().ensure((size_t)m + 1); sorter_.u32_b().ensure((size_t)m + 1);     // scratch
+        uint32_t* k_in = sorter_.u32_a().get();
+        uint32_t* v_in = sorter_.u32_b().get();
+        pk::occ_sequence(S.sa_p.get(), S.pid.get(), m, D, k_in, v_in, st);
+        prims::sort_pairs_u32_u32(d_temp_, k_in, S.occ_ids.get(), v_in, S.occ_ts.get(), (size_t)m + 1, 0,
+                                  std::max(1, bit_width_u64((uint64_t)D)), st);
+        pk::occ_finish(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), m, S.occ_start.get(),
+                       S.occ_pos.get(), S.occ_key.get(), st);
+    }
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
     S.vscan.ensure(nd); S.ptab.ensure((size_t)D * 16 + 16);
     prims::exclusive_sum_u32(d_temp_, S.vflag.get(), S.vscan.get(), nd, st);
     const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
-    pk::phrase_table(S.occ_cnt.get(), S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
+    pk::phrase_table(S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
     S.ce_cnt.ensure(E); S.ce_eoff.ensure(E); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
     S.ce_bwt.ensure(E);
     pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.vflag.get(), S.vscan.get(),

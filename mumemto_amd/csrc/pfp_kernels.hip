@@ -438,52 +438,61 @@ void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint6
 // text suffixes grouped by phrase suffix; only suffixes that spell the same string in several
 // phrases still have to be merged -- a segmented sort of small segments instead of the
 // reference's priority queue (pfp_lcp_mum.hpp:151-212).
-__global__ void k_occ_keys(const uint32_t* __restrict__ pid, const uint32_t* __restrict__ isa_p, uint32_t m,
-                           int shift, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                           uint32_t* __restrict__ occ_cnt) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= m) return;
-    const uint64_t nxt = q + 1 < m ? (uint64_t)isa_p[q + 1] + 1 : 0;
-    keys[q] = ((uint64_t)pid[q] << shift) | nxt;
-    vals[q] = q;
-    atomicAdd(&occ_cnt[pid[q]], 1u);
+// Inverted lists (parse.hpp:106-134): for every distinct phrase, its occurrences ordered by the rank of the parse
+// suffix that follows.  Walking the parse suffix array in order visits the followers by rank, so the sequence
+//   t = 0: the last phrase of the parse (nothing follows it: smallest key), t = r + 1: the phrase before suffix sa_p[r]
+// only needs ONE stable sort by phrase id (no second key, no atomic counting); t itself is the key the emitter
+// compares.  The suffix that starts the parse has no phrase before it: its slot carries the dummy id D.
+__global__ void k_occ_sequence(const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ pid, uint32_t m,
+                               uint32_t D, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > m) return;
+    uint32_t id;
+    if (t == 0) id = pid[m - 1];
+    else { const uint32_t q1 = sa_p[t - 1]; id = q1 ? pid[q1 - 1] : D; }
+    keys[t] = id;
+    vals[t] = t;
 }
-void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift, uint64_t* keys, uint32_t* vals,
-              uint32_t* occ_cnt, hipStream_t s) {
-    hipLaunchKernelGGL(k_occ_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, pid, isa_p, m, shift, keys, vals, occ_cnt);
+void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_t D, uint32_t* keys, uint32_t* vals,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_occ_sequence, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, sa_p, pid, m, D, keys, vals);
+    MMT_HIP(hipGetLastError());
+}
+// after the sort: k-th occurrence overall = (phrase ids[k], t = ts[k]); occ_start[d] = first k of phrase d
+// (occ_start[D] = m: the dummy sorts last); occ_pos = start of that phrase occurrence in the text, occ_key = t
+__global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ ts,
+                             const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ pstart, uint32_t m,
+                             uint32_t* __restrict__ occ_start, uint32_t* __restrict__ occ_pos,
+                             uint32_t* __restrict__ occ_key) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > m) return;
+    const uint32_t id = ids[k];
+    if (k == 0 || id != ids[k - 1]) occ_start[id] = k;
+    if (k == m) return;                                    // the dummy
+    const uint32_t t = ts[k];
+    const uint32_t q = t ? sa_p[t - 1] - 1 : m - 1;
+    occ_pos[k] = pstart[q];
+    occ_key[k] = t;
+}
+void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const uint32_t* pstart, uint32_t m,
+                uint32_t* occ_start, uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s) {
+    hipLaunchKernelGGL(k_occ_finish, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p, pstart, m,
+                       occ_start, occ_pos, occ_key);
     MMT_HIP(hipGetLastError());
 }
 
-// ---- A4 emitter: tile kernel ------------------------------------------------------------------
-// Valid dictionary suffixes ("entries", in dictionary suffix-array order) are first compacted with
-// everything the emitter needs; the inverted lists carry (phrase start, following parse rank).
-__global__ void k_occ_payload(const uint32_t* __restrict__ occ_sorted, const uint32_t* __restrict__ pstart,
-                              const uint32_t* __restrict__ isa_p, uint32_t m, uint32_t* __restrict__ occ_pos,
-                              uint32_t* __restrict__ occ_key) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const uint32_t q = occ_sorted[k];
-    occ_pos[k] = pstart[q];
-    occ_key[k] = q + 1 < m ? isa_p[q + 1] + 1 : 0u;
-}
-void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
-                 uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s) {
-    hipLaunchKernelGGL(k_occ_payload, dim3(grid_for(m, 256)), dim3(256), 0, s, occ_sorted, pstart, isa_p, m, occ_pos,
-                       occ_key);
-    MMT_HIP(hipGetLastError());
-}
 
 // per distinct phrase: (occurrences, first slot in the inverted lists, length of the phrase) in one 16-byte record,
 // so that an entry needs one random read instead of three
-__global__ void k_phrase_table(const uint32_t* __restrict__ occ_cnt, const uint32_t* __restrict__ occ_start,
+__global__ void k_phrase_table(const uint32_t* __restrict__ occ_start /* n_distinct + 1 */,
                                const uint32_t* __restrict__ plen, const uint32_t* __restrict__ rep, uint32_t n_distinct,
                                uint4* __restrict__ tab) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < n_distinct) tab[d] = make_uint4(occ_cnt[d], occ_start[d], plen[rep[d]], 0u);
+    if (d < n_distinct) tab[d] = make_uint4(occ_start[d + 1] - occ_start[d], occ_start[d], plen[rep[d]], 0u);
 }
-void phrase_table(const uint32_t* occ_cnt, const uint32_t* occ_start, const uint32_t* plen, const uint32_t* rep,
-                  uint32_t n_distinct, void* tab, hipStream_t s) {
-    hipLaunchKernelGGL(k_phrase_table, dim3(grid_for(n_distinct, 256)), dim3(256), 0, s, occ_cnt, occ_start, plen, rep,
+void phrase_table(const uint32_t* occ_start, const uint32_t* plen, const uint32_t* rep, uint32_t n_distinct, void* tab,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_phrase_table, dim3(grid_for(n_distinct, 256)), dim3(256), 0, s, occ_start, plen, rep,
                        n_distinct, static_cast<uint4*>(tab));
     MMT_HIP(hipGetLastError());
 }

@@ -33,8 +33,14 @@ void group_flags(const uint32_t* esuf, const uint32_t* sa_d, const uint8_t* dict
 void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,
                   hipStream_t s);
 // tab: n_distinct 16-byte records (phrase_table)
-void phrase_table(const uint32_t* occ_cnt, const uint32_t* occ_start, const uint32_t* plen, const uint32_t* rep,
+void phrase_table(const uint32_t* occ_start /* n_distinct + 1 */, const uint32_t* plen, const uint32_t* rep,
                   uint32_t n_distinct, void* tab, hipStream_t s);
+// inverted lists from the parse suffix array (see pfp_kernels.hip): m + 1 (id, t) pairs to be stably sorted by id,
+// then occ_start (n_distinct + 1 entries), occ_pos and occ_key (m entries each)
+void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_t D, uint32_t* keys, uint32_t* vals,
+                  hipStream_t s);
+void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const uint32_t* pstart, uint32_t m,
+                uint32_t* occ_start, uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
                    const uint32_t* vflag, const uint32_t* vscan, const void* tab, uint32_t nd, uint32_t* ce_cnt,
                    uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
@@ -43,10 +49,6 @@ void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dl
                   uint32_t* which, uint32_t* slen, hipStream_t s);
 void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint64_t* keys, uint32_t* vals,
                    hipStream_t s);
-void occ_keys(const uint32_t* pid, const uint32_t* isa_p, uint32_t m, int shift, uint64_t* keys, uint32_t* vals,
-              uint32_t* occ_cnt, hipStream_t s);
-void occ_payload(const uint32_t* occ_sorted, const uint32_t* pstart, const uint32_t* isa_p, uint32_t m,
-                 uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
 static const uint32_t EMIT_CAP = 1024;   // elements of one LDS tile of the emitter
 static const uint32_t EMIT_TILE = 1024;  // output positions per workgroup of the emitter
 struct EmitArgs {

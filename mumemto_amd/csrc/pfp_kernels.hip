@@ -218,23 +218,49 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
                                 const uint4* __restrict__ pinfo, const uint8_t* __restrict__ v, uint32_t m,
                                 uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    if (k == 0) { flags[0] = 1; return; }
-    if (h1s[k] != h1s[k - 1]) { flags[k] = 1u; return; }
-    const uint4 X = pinfo[order[k]], Y = pinfo[order[k - 1]];
-    bool same = X.x == Y.x && X.y == Y.y && X.w == Y.w;
+    const uint32_t lane = threadIdx.x & 63;
+    // Every lane fetches ITS phrase once (record, then the bytes 8 at a time) and gets the predecessor's from the lane
+    // below by shuffle; only lane 0 of a wave reads its predecessor itself.  Equal phrases are long runs in this
+    // order (one per haplotype), so this halves the random reads of the verification.
+    const bool have = k < m;
+    const uint4 X = have ? pinfo[order[k]] : make_uint4(0, 0, 0, 0);
+    uint4 Y;
+    Y.x = __shfl_up(X.x, 1, 64); Y.y = __shfl_up(X.y, 1, 64); Y.z = __shfl_up(X.z, 1, 64); Y.w = __shfl_up(X.w, 1, 64);
+    if (lane == 0 && have && k > 0) Y = pinfo[order[k - 1]];
+    const bool same1 = have && k > 0 && h1s[k] == h1s[k - 1];
+    bool same = same1 && X.x == Y.x && X.y == Y.y && X.w == Y.w;
     // equal first fingerprints of different phrases: when the order came from the first fingerprint alone, equal
     // phrases need not be adjacent any more -- the host then repeats the grouping with both fingerprints
-    if (!same) atomicOr(err + 1, 1u);
-    if (same) {
-        const uint8_t* px = v + X.z; const uint8_t* py = v + Y.z;
-        const uint32_t l = X.w;
-        uint32_t i = 0;
-        for (; i + 8 <= l; i += 8) if (ld64(px + i) != ld64(py + i)) { same = false; break; }
-        if (same) for (; i < l; i++) if (px[i] != py[i]) { same = false; break; }
-        if (!same) atomicAdd(err, 1u);
+    if (same1 && !same) atomicOr(err + 1, 1u);
+    // byte verification, 8 bytes per step; the loop runs while any lane of the wave still compares
+    const uint8_t* px = v + X.z;
+    const uint8_t* py = v + Y.z;
+    const uint32_t l = X.w;
+    bool verified = same;
+    for (uint32_t i = 0; __ballot(same && i < l) != 0; i += 8) {
+        // every lane with bytes left loads its own chunk (the lane above may need it even if this lane is done comparing)
+        uint64_t mine = 0;
+        if (have && i < l) {
+            if (i + 8 <= l) mine = ld64(px + i);
+            else for (uint32_t t = i; t < l; t++) mine |= (uint64_t)px[t] << (8 * (t - i));
+        }
+        uint64_t prev = __shfl_up(mine, 1, 64);
+        if (same && i < l) {
+            if (lane == 0) {
+                prev = 0;
+                if (i + 8 <= l) prev = ld64(py + i);
+                else for (uint32_t t = i; t < l; t++) prev |= (uint64_t)py[t] << (8 * (t - i));
+            }
+            if (mine != prev) { same = false; verified = false; }
+        }
     }
-    flags[k] = same ? 0u : 1u;
+    if (have) {
+        if (k == 0) flags[0] = 1;
+        else {
+            if (same1 && X.x == Y.x && X.y == Y.y && X.w == Y.w && !verified) atomicAdd(err, 1u);   // 128-bit collision
+            flags[k] = verified ? 0u : 1u;
+        }
+    }
 }
 void mark_distinct(const uint32_t* order, const uint64_t* h1s, const void* pinfo, const uint8_t* v, uint32_t m,
                    uint32_t* flags, uint32_t* err, hipStream_t s) {

@@ -86,7 +86,9 @@ MMT_API size_t mmt_partitions_used(const mmt_engine* e);
 /* merged PREFIX.athresh (L_0 + 1 entries) after a partitioned run                                  */
 MMT_API int mmt_copy_merged_thresh(const mmt_engine* e, uint16_t* out);
 
-/* ---- results of the last run (host memory owned by the engine) ------------ */
+/* ---- results of the last run ------------------------------------------------
+ * A run leaves its rows and the file bytes in HBM; each accessor below downloads what it
+ * returns on first use (page-locked host memory owned by the engine, valid until the next run). */
 MMT_API size_t mmt_num_rows(const mmt_engine* e);
 MMT_API size_t mmt_num_docs(const mmt_engine* e);
 /* MUM mode: length[n_rows], offsets[n_rows*n_docs] (-1 absent), strands (1 '+') */

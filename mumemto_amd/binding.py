@@ -342,7 +342,7 @@ class Engine:
         return C.string_at(ptr, n.value) if n.value else b""
 
     def output_size(self):
-        """Bytes of the last run's .mums / .mems output (already in host memory; no copy)."""
+        """Bytes of the last run's .mums / .mems output; brings them into page-locked host memory (no Python copy)."""
         n = C.c_size_t()
         self.L.mmt_output_text(self.h, C.byref(n))
         return n.value

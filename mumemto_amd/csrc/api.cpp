@@ -267,12 +267,12 @@ int mmt_copy_merged_thresh(const mmt_engine* e, uint16_t* out) {
     return 0;
 }
 
-size_t mmt_num_rows(const mmt_engine* e) { return e ? e->e->rows().n_rows : 0; }
+size_t mmt_num_rows(const mmt_engine* e) { return e ? e->e->rows_meta().n_rows : 0; }
 size_t mmt_num_docs(const mmt_engine* e) { return e ? e->e->n_docs() : 0; }
 int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands) {
     if (!e) return fail(1, "engine must be non-null");
-    const mmt::HostRows& R = e->e->rows();
-    if (!R.mum_mode) return fail(3, "last run was not in MUM mode");
+    if (!e->e->rows_meta().mum_mode) return fail(3, "last run was not in MUM mode");
+    const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_ARRAYS);
     if (R.n_rows) {
         std::memcpy(length, R.length, R.n_rows * 4);
         std::memcpy(offsets, R.mum_offsets, R.n_rows * R.n_docs * 8);
@@ -283,16 +283,16 @@ int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_
 int mmt_rows_mum_device(const mmt_engine* e, const uint32_t** length, const int64_t** offsets,
                         const uint8_t** strands) {
     if (!e || !length || !offsets || !strands) return fail(1, "engine and outputs must be non-null");
-    if (!e->e->rows().mum_mode) return fail(3, "last run was not in MUM mode");
+    if (!e->e->rows_meta().mum_mode) return fail(3, "last run was not in MUM mode");
     e->e->rows_mum_device(length, offsets, strands);
     return 0;
 }
-size_t mmt_num_occ(const mmt_engine* e) { return e ? e->e->rows().n_occ : 0; }
+size_t mmt_num_occ(const mmt_engine* e) { return e ? e->e->rows_meta().n_occ : 0; }
 int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start, int64_t* offsets, uint64_t* seq_ids,
                  uint8_t* strands) {
     if (!e) return fail(1, "engine must be non-null");
-    const mmt::HostRows& R = e->e->rows();
-    if (R.mum_mode) return fail(3, "last run was in MUM mode");
+    if (e->e->rows_meta().mum_mode) return fail(3, "last run was in MUM mode");
+    const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_ARRAYS);
     occ_start[0] = 0;
     if (R.n_rows) {
         std::memcpy(length, R.length, R.n_rows * 4);
@@ -305,9 +305,11 @@ int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start, int
 }
 const char* mmt_output_text(mmt_engine* e, size_t* len) {
     if (!e) { if (len) *len = 0; return nullptr; }
-    const mmt::HostRows& R = e->e->rows();
-    if (len) *len = R.text_len;
-    return R.text;
+    try {
+        const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_TEXT);
+        if (len) *len = R.text_len;
+        return R.text;
+    } catch (const std::exception& ex) { fail(3, ex.what()); if (len) *len = 0; return nullptr; }
 }
 const uint8_t* mmt_output_bumbl(mmt_engine* e, size_t* len) {
     if (!e) { if (len) *len = 0; return nullptr; }

@@ -256,7 +256,7 @@ int main(int argc, char** argv) {
         } else {
             eng.run(p);
         }
-        const HostRows& R = eng.rows();
+        const HostRows& R = eng.rows(mum_mode && o.binary ? 0 : Engine::ROWS_TEXT);   // .bumbl pulls the arrays itself
         std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n",
                      mum_mode ? "MUM" : "MEM", secs_since(t0));
 

@@ -289,16 +289,9 @@ void Engine::make_rows(const mmt_params& p) {
         d_olen_.ensure(kept + 1); d_ooffs_.ensure(kept * N + 1); d_ost_.ensure(kept * N + 1); d_otext_.ensure(tbytes + 1);
         rk::mum_write(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_ridx_.get(), d_toff_.get(),
                       d_olen_.get(), d_ooffs_.get(), d_ost_.get(), d_otext_.get(), st);
-        h_len_.ensure(kept + 1); h_offs_.ensure(kept * N + 1); h_st_.ensure(kept * N + 1); h_text_.ensure(tbytes + 1);
-        if (kept) {
-            MMT_HIP(hipMemcpyAsync(h_len_.get(), d_olen_.get(), kept * 4, hipMemcpyDeviceToHost, st));
-            MMT_HIP(hipMemcpyAsync(h_offs_.get(), d_ooffs_.get(), kept * N * 8, hipMemcpyDeviceToHost, st));
-            MMT_HIP(hipMemcpyAsync(h_st_.get(), d_ost_.get(), kept * N, hipMemcpyDeviceToHost, st));
-            MMT_HIP(hipMemcpyAsync(h_text_.get(), d_otext_.get(), tbytes, hipMemcpyDeviceToHost, st));
-        }
-        MMT_HIP(hipStreamSynchronize(st));
-        R.n_rows = kept; R.length = h_len_.get(); R.mum_offsets = h_offs_.get(); R.mum_strands = h_st_.get();
-        R.text = h_text_.get(); R.text_len = tbytes;
+        // the tables and the bytes stay in HBM; fetch_rows() copies what a caller asks for (library arrays, file bytes)
+        R.n_rows = kept; R.text_len = tbytes;
+        rows_pending_ = kept ? (ROWS_ARRAYS | ROWS_TEXT) : 0;
     } else {
         d_keep_.ensure(n_rows); d_wpos_.ensure(n_rows); d_wdoc_.ensure(n_rows); d_occ64_.ensure(n_rows);
         d_ooff_.ensure(n_rows);
@@ -315,26 +308,57 @@ void Engine::make_rows(const mmt_params& p) {
         d_otext_.ensure(tbytes + 1);
         rk::mem_write(a, d_ooff_.get(), d_toff_.get(), d_wpos_.get(), d_wdoc_.get(), d_olen_.get(), d_ooffs_.get(),
                       d_omdoc_.get(), d_ost_.get(), d_otext_.get(), st);
-        h_len_.ensure(n_rows); h_offs_.ensure(occ + 1); h_mdoc_.ensure(occ + 1); h_st_.ensure(occ + 1);
-        h_text_.ensure(tbytes + 1); h_occ_start_.ensure((size_t)n_rows + 2);
-        MMT_HIP(hipMemcpyAsync(h_len_.get(), d_olen_.get(), (size_t)n_rows * 4, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipMemcpyAsync(h_occ_start_.get(), d_ooff_.get(), (size_t)n_rows * 8, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipMemcpyAsync(h_offs_.get(), d_ooffs_.get(), occ * 8, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipMemcpyAsync(h_mdoc_.get(), d_omdoc_.get(), occ * 8, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipMemcpyAsync(h_st_.get(), d_ost_.get(), occ, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipMemcpyAsync(h_text_.get(), d_otext_.get(), tbytes, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipStreamSynchronize(st));
-        h_occ_start_.get()[n_rows] = occ;
-        R.n_rows = n_rows; R.n_occ = occ; R.length = h_len_.get(); R.occ_start = h_occ_start_.get();
-        R.mem_offsets = h_offs_.get(); R.mem_docs = h_mdoc_.get(); R.mem_strands = h_st_.get();
-        R.text = h_text_.get(); R.text_len = tbytes;
+        R.n_rows = n_rows; R.n_occ = occ; R.text_len = tbytes;
+        rows_pending_ = ROWS_ARRAYS | ROWS_TEXT;
     }
     ev_[5]->stop(st);
+}
+
+// D2H of the last run's rows into page-locked host memory, on demand: the library arrays (ROWS_ARRAYS) and / or the
+// bytes of PREFIX.mums / PREFIX.mems (ROWS_TEXT).
+void Engine::fetch_rows(int need) {
+    need &= rows_pending_;
+    if (!need) return;
+    MMT_HIP(hipSetDevice(device_));
+    hipStream_t st = stream_;
+    HostRows& R = rows_;
+    const size_t N = R.n_docs, nr = R.n_rows;
+    if (need & ROWS_TEXT) {
+        h_text_.ensure(R.text_len + 1);
+        if (R.text_len) MMT_HIP(hipMemcpyAsync(h_text_.get(), d_otext_.get(), R.text_len, hipMemcpyDeviceToHost, st));
+        R.text = h_text_.get();
+    }
+    if (need & ROWS_ARRAYS) {
+        if (R.mum_mode) {
+            h_len_.ensure(nr + 1); h_offs_.ensure(nr * N + 1); h_st_.ensure(nr * N + 1);
+            if (nr) {
+                MMT_HIP(hipMemcpyAsync(h_len_.get(), d_olen_.get(), nr * 4, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipMemcpyAsync(h_offs_.get(), d_ooffs_.get(), nr * N * 8, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipMemcpyAsync(h_st_.get(), d_ost_.get(), nr * N, hipMemcpyDeviceToHost, st));
+            }
+            R.length = h_len_.get(); R.mum_offsets = h_offs_.get(); R.mum_strands = h_st_.get();
+        } else {
+            const size_t occ = R.n_occ;
+            h_len_.ensure(nr + 1); h_offs_.ensure(occ + 1); h_mdoc_.ensure(occ + 1); h_st_.ensure(occ + 1);
+            h_occ_start_.ensure(nr + 2);
+            MMT_HIP(hipMemcpyAsync(h_len_.get(), d_olen_.get(), nr * 4, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_occ_start_.get(), d_ooff_.get(), nr * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_offs_.get(), d_ooffs_.get(), occ * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_mdoc_.get(), d_omdoc_.get(), occ * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_st_.get(), d_ost_.get(), occ, hipMemcpyDeviceToHost, st));
+            R.length = h_len_.get(); R.occ_start = h_occ_start_.get();
+            R.mem_offsets = h_offs_.get(); R.mem_docs = h_mdoc_.get(); R.mem_strands = h_st_.get();
+        }
+    }
+    MMT_HIP(hipStreamSynchronize(st));
+    if ((need & ROWS_ARRAYS) && !R.mum_mode) h_occ_start_.get()[nr] = R.n_occ;
+    rows_pending_ &= ~need;
 }
 
 const std::string& Engine::bumbl() {
     // mem_finder.hpp:451-503: u16 flags | u64 n_seqs | u64 n_mums | u32 len[] | i64 starts | strand bits
     if (!bumbl_.empty() || !rows_.mum_mode) return bumbl_;
+    fetch_rows(ROWS_ARRAYS);
     const HostRows& R = rows_;
     const uint64_t nm = R.n_rows, ns = R.n_docs, nbits = nm * ns;
     uint16_t flags = (uint16_t)(1u << 15);
@@ -350,8 +374,9 @@ const std::string& Engine::bumbl() {
     return bumbl_;
 }
 
-void Engine::thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev) const {
+void Engine::thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev) {
     // thresholds re-indexed by position inside each written MUM, MUMs in anchor order, 0-terminated
+    fetch_rows(ROWS_ARRAYS);
     const HostRows& R = rows_;
     if (!R.mum_mode || !thresh_len_) throw std::runtime_error("thresholds need a multi-MUM run with merge metadata");
     std::vector<uint16_t> th(thresh_len_);
@@ -382,6 +407,7 @@ void Engine::run(const mmt_params& p) {
     for (float& f : stage_ms_) f = 0.f;
     merged_thresh_valid_ = false;
     rows_ = HostRows();
+    rows_pending_ = 0;
     rows_.mum_mode = p.max_doc_freq == 1;
     rows_.n_docs = doc_len_.size();
     n_cand_ = 0; thresh_len_ = 0; bumbl_.clear();

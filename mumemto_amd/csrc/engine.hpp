@@ -71,10 +71,15 @@ public:
     void pfp_copy_parse(std::vector<uint32_t>& out);
     const PfpState& pfp_state() const { return pfp_; }
 
-    const HostRows& rows() const { return rows_; }
+    // Results of the last run.  rows_meta(): counts and mode only; rows(need): also the host copies asked for
+    // (ROWS_ARRAYS = library arrays, ROWS_TEXT = PREFIX.mums / .mems bytes), downloaded from HBM on first use.
+    enum { ROWS_ARRAYS = 1, ROWS_TEXT = 2 };
+    const HostRows& rows_meta() const { return rows_; }
+    const HostRows& rows(int need = ROWS_ARRAYS | ROWS_TEXT) { fetch_rows(need); return rows_; }
+    void fetch_rows(int need);
     const std::string& bumbl();
     // PREFIX.thresh / PREFIX.thresh_rev contents (mem_finder.hpp:116-157); needs a merge_metadata MUM run
-    void thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev) const;
+    void thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev);
     uint64_t text_length() const { return n_; }
     size_t n_docs() const { return doc_len_.size(); }
     const std::vector<uint64_t>& doc_len() const { return doc_len_; }
@@ -144,6 +149,7 @@ private:
     PinnedBuf<char> h_text_;
 
     HostRows rows_;
+    int rows_pending_ = 0;                // ROWS_* bits that still sit in HBM only
     MergedRows merged_;
     std::string merged_text_;
     size_t partitions_used_ = 1;

@@ -138,6 +138,7 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     doc_len_.assign(doc_len, doc_len + n_docs);
     HostRows& R = rows_;
     R = HostRows();
+    rows_pending_ = 0;                         // the merged rows were downloaded by download_merged
     R.mum_mode = true; R.n_docs = n_docs; R.n_rows = merged_.length.size();
     R.length = merged_.length.data(); R.mum_offsets = merged_.offsets.data(); R.mum_strands = merged_.strands.data();
     h_occ_start_.ensure(2); h_occ_start_.get()[0] = 0; R.occ_start = h_occ_start_.get();

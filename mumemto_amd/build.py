@@ -23,6 +23,7 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-
 LIB_SOURCES = ["kernels.hip", "prims.hip", "pfp_kernels.hip", "rows_kernels.hip", "merge_kernels.hip", "engine.cpp", "sorter.cpp", "pfp.cpp", "merge.cpp", "partitioned.cpp", "api.cpp",
                "cxx_api.cpp", "fasta.cpp", "options.cpp"]
 TOOLS = {"mumemto_exec": ["cli_main.cpp"], "anchor_merge": ["merge_main.cpp"]}
+HOST_TOOLS = {"extract_mums": ["extract_mums_main.cpp", "fasta.cpp"]}     # no device code: plain g++
 
 
 def _newer(target, deps):
@@ -75,6 +76,11 @@ def build(verbose=False):
         if _newer(out, tobjs + lib_objs):
             # the tools use the engine classes directly (hidden symbols of the .so): link the objects in
             subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-o", out] + tobjs + lib_objs + ["-lz"])
+    for tool, srcs in HOST_TOOLS.items():
+        paths = [os.path.join(SRC, f) for f in srcs]
+        out = os.path.join(BIN_DIR, tool)
+        if _newer(out, paths + _headers()):
+            subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-o", out] + paths + ["-lz"])
     if verbose:
         print("built", LIB)
     return LIB

@@ -8,6 +8,9 @@
 #include <filesystem>
 #include <fstream>
 #include <atomic>
+#include <cstdlib>
+#include <functional>
+#include <memory>
 #include <iostream>
 #include <thread>
 
@@ -20,6 +23,25 @@ using namespace mmt;
 
 static void log_line(const char* tag, const std::string& msg) {
     std::fprintf(stderr, "\033[32m[%s] \033[m%s\n", tag, msg.c_str());
+}
+// The concatenated bases of the inputs: sized once, never zero-filled.
+struct HostBytes {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void allocate(size_t bytes) { p.reset(new uint8_t[bytes ? bytes : 1]); n = bytes; }
+    uint8_t* data() { return p.get(); }
+    const uint8_t* data() const { return p.get(); }
+    size_t size() const { return n; }
+    const uint8_t* begin() const { return p.get(); }
+    const uint8_t* end() const { return p.get() + n; }
+};
+
+static const auto g_start = std::chrono::steady_clock::now();
+static double secs_since(std::chrono::steady_clock::time_point t0);
+// MUMEMTO_TIMING=1: wall-clock marks (seconds since the process started) on stderr
+static void mark(const char* what) {
+    static const bool on = std::getenv("MUMEMTO_TIMING") != nullptr;
+    if (on) std::fprintf(stderr, "[timing] %8.3f  %s\n", secs_since(g_start), what);
 }
 static double secs_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -129,6 +151,7 @@ static void put40(std::vector<uint8_t>& b, uint64_t v) {
 }
 
 int main(int argc, char** argv) {
+    mark("main");
     std::fprintf(stderr, "\nmumemto_exec (MI355X / gfx950 build of the mumemto 1.4.0 hot path)\n");
     if (argc == 1) { std::fprintf(stderr, "Usage: mumemto_exec [options] [input_fasta [...]]\n\t-h, --help  prints detailed usage message\n"); return 0; }
     BuildOptions o;
@@ -144,38 +167,51 @@ int main(int argc, char** argv) {
         for (const auto& n : o.notes) log_line("build_main", n);
 
         auto t0 = std::chrono::steady_clock::now();
-        std::vector<uint8_t> bases;
+        // the HIP runtime comes up (device, stream, code objects) while the host threads read the inputs
+        const bool dry_run = std::getenv("MUMEMTO_DRY_RUN") != nullptr;
+        std::unique_ptr<Engine> engine;
+        std::exception_ptr engine_error;
+        std::thread engine_init;
+        if (!dry_run)
+            engine_init = std::thread([&]() {
+                try { engine.reset(new Engine(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr)); }
+                catch (...) { engine_error = std::current_exception(); }
+            });
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } engine_joiner{engine_init};
+        HostBytes bases;
         std::vector<FastaDoc> docs(inputs.size());
-        {   // the files are independent: inflate and parse them on as many host threads as the machine offers
+        {   // the files are independent: inflate and parse them on as many host threads as the machine offers, then
+            // every thread copies the files it parsed to their place in the concatenation
             std::vector<std::vector<uint8_t>> part(inputs.size());
             std::vector<std::string> err(inputs.size());
-            std::atomic<size_t> next{0};
-            auto work = [&]() {
-                for (size_t i = next++; i < inputs.size(); i = next++) {
-                    try { docs[i] = read_fasta(inputs[i], part[i]); }
-                    catch (const std::exception& e) { err[i] = e.what(); }
-                }
-            };
             const size_t n_thr = std::min<size_t>(inputs.size(), std::max(1u, std::thread::hardware_concurrency()));
-            std::vector<std::thread> pool;
-            for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
-            work();
-            for (auto& t : pool) t.join();
-            size_t total = 0;
+            auto on_all_threads = [&](const std::function<void(size_t)>& per_file) {
+                std::atomic<size_t> next{0};
+                auto work = [&]() { for (size_t i = next++; i < inputs.size(); i = next++) per_file(i); };
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
+                work();
+                for (auto& t : pool) t.join();
+            };
+            on_all_threads([&](size_t i) {
+                try { docs[i] = read_fasta(inputs[i], part[i]); }
+                catch (const std::exception& e) { err[i] = e.what(); }
+            });
+            std::vector<size_t> at(inputs.size() + 1, 0);
             for (size_t i = 0; i < inputs.size(); i++) {
                 if (!err[i].empty()) throw std::runtime_error(err[i]);
                 if (docs[i].total == 0) {           // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
                     std::cerr << std::endl << "Empty input file found: " << inputs[i] << std::endl;
                     throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
                 }
-                total += part[i].size();
-            }
-            bases.reserve(total);
-            for (size_t i = 0; i < inputs.size(); i++) {
-                bases.insert(bases.end(), part[i].begin(), part[i].end());
-                std::vector<uint8_t>().swap(part[i]);
+                at[i + 1] = at[i] + part[i].size();
                 doc_len.push_back(docs[i].total);
             }
+            bases.allocate(at.back());
+            on_all_threads([&](size_t i) {
+                if (!part[i].empty()) std::memcpy(bases.data() + at[i], part[i].data(), part[i].size());
+                std::vector<uint8_t>().swap(part[i]);
+            });
         }
         uint64_t text_chars = 0;
         for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
@@ -198,7 +234,7 @@ int main(int argc, char** argv) {
                          bases.size(), secs_since(t0));
         }
 
-        if (std::getenv("MUMEMTO_DRY_RUN")) {     // host-side checks only (tests on machines without a GPU)
+        if (dry_run) {                            // host-side checks only (tests on machines without a GPU)
             uint64_t h = 1469598103934665603ull;
             for (uint8_t b : bases) { h ^= b; h *= 1099511628211ull; }
             for (uint8_t b : ck_text) { h ^= b; h *= 1099511628211ull; }
@@ -214,19 +250,24 @@ int main(int argc, char** argv) {
                         (int)o.anchor_merge, (int)o.binary, o.min_match_len);
             return 0;
         }
+        mark("inputs read");
         t0 = std::chrono::steady_clock::now();
-        Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
+        engine_init.join();
+        if (engine_error) std::rethrow_exception(engine_error);
+        Engine& eng = *engine;
         const uint64_t max_text = std::getenv("MUMEMTO_MAX_TEXT") ? std::strtoull(std::getenv("MUMEMTO_MAX_TEXT"), nullptr, 10)
                                                                   : 0xfffff000ull - 1;
         const bool partitioned = text_chars > max_text;
         if (checkpoint && partitioned) throw CliError{"-p / -a are not available for inputs larger than one suffix array", 1};
         if (checkpoint && (o.keep_temp || o.arrays_out))
             throw CliError{"-K and -A write what -p / -a read: run them without a checkpoint", 1};
+        mark("engine created");
         if (o.from_parse_flag) eng.set_text_host(ck_text.data(), ck_text.size(), doc_len.data(), doc_len.size(), o.use_rcomp);
         else if (o.arrays_in_flag)
             eng.set_stream_host(ck_sa.data(), ck_lcp.data(), ck_bwt.data(), ck_sa.size(), doc_len.data(), doc_len.size(),
                                 o.use_rcomp);
         else if (!partitioned) eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
+        mark("input on the device");
         auto write_pfp_files = [&]() {              // PREFIX.dict / PREFIX.parse as newscan.hpp:406-419 writes them
             eng.parse_only(o.use_rcomp, (uint32_t)o.pfp_w, (uint32_t)o.hash_mod);
             std::vector<uint8_t> dict; std::vector<uint32_t> parse;
@@ -256,6 +297,7 @@ int main(int argc, char** argv) {
         } else {
             eng.run(p);
         }
+        mark("run done");
         const HostRows& R = eng.rows(mum_mode && o.binary ? 0 : Engine::ROWS_TEXT);   // .bumbl pulls the arrays itself
         std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n",
                      mum_mode ? "MUM" : "MEM", secs_since(t0));
@@ -288,11 +330,19 @@ int main(int argc, char** argv) {
             write_file(o.output_prefix + ".lcp", flcp.data(), flcp.size());
             write_file(o.output_prefix + ".bwt", fbwt.data(), fbwt.size());
         }
+        mark("outputs written");
         log_line("build_main", "Found " + std::to_string(R.n_rows) + " matches!");
         if (o.keep_temp) write_pfp_files();         // -K: keep PREFIX.dict / PREFIX.parse
         const float* ms = eng.stage_ms();
         std::fprintf(stderr, "GPU stages (ms): text %.2f | suffix sort %.2f | lcp+bwt %.2f | scan %.2f | verify %.2f | rows %.2f | format %.2f\n\n",
                      ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6]);
+        // Everything is on disk: leave without unloading the HIP runtime and freeing gigabytes of HBM buffer by buffer
+        // (the driver reclaims them with the process).  MUMEMTO_FULL_TEARDOWN=1 keeps the orderly exit, which
+        // profilers that flush at exit need.
+        if (!std::getenv("MUMEMTO_FULL_TEARDOWN")) {
+            std::fflush(stdout); std::fflush(stderr);
+            std::_Exit(0);
+        }
         return 0;
     } catch (const CliError& e) {
         std::fprintf(stderr, "\n\033[31mError: \033[m%s\n\n", e.message.c_str());

@@ -2,6 +2,7 @@
 
 #include <zlib.h>
 
+#include <cstring>
 #include <stdexcept>
 
 namespace mmt {
@@ -35,8 +36,8 @@ public:
                 if (n == 0) { eof_ = true; return; }
                 pos_ = 0; end_ = n;
             }
-            int i = pos_;
-            while (i < end_ && buf_[i] != '\n') i++;
+            const char* nlp = static_cast<const char*>(std::memchr(buf_ + pos_, '\n', (size_t)(end_ - pos_)));
+            const int i = nlp ? (int)(nlp - buf_) : end_;
             if (out) out->insert(out->end(), buf_ + pos_, buf_ + i);
             if (sout) sout->append(buf_ + pos_, buf_ + i);
             if (count) *count += (uint64_t)(i - pos_);
@@ -50,7 +51,7 @@ public:
 
 private:
     gzFile f_;
-    char buf_[1 << 16];
+    char buf_[1 << 18];
     int pos_ = 0, end_ = 0;
     bool eof_ = false;
 };

@@ -12,8 +12,13 @@ for i, doc in enumerate(docs):
 exe = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
 for rep in range(3):
     t = time.perf_counter()
-    r = subprocess.run([exe, "-o", os.path.join(d, "out")] + paths, capture_output=True, text=True)
+    r = subprocess.run([exe, "-o", os.path.join(d, "out")] + paths, capture_output=True, text=True,
+                       env=dict(os.environ, MUMEMTO_TIMING="1"))
     dt = time.perf_counter() - t
     print("run %d: %.3f s wall, rc %d, %.3f Gbp/s" % (rep, dt, r.returncode, haps * L / dt / 1e9))
-    print("\n".join(l for l in r.stderr.split("\n") if "sec" in l or "stages" in l))
+    print("\n".join(l for l in r.stderr.split("\n") if "sec" in l or "stages" in l or "[timing]" in l))
 print(os.path.getsize(os.path.join(d, "out.mums")), "bytes of .mums")
+t = time.perf_counter(); subprocess.run([exe], capture_output=True); print("no arguments (load + exit): %.3f s" % (time.perf_counter() - t))
+t = time.perf_counter()
+subprocess.run([exe, "-o", os.path.join(d, "out")] + paths, capture_output=True, env=dict(os.environ, MUMEMTO_FULL_TEARDOWN="1"))
+print("with the orderly teardown: %.3f s wall" % (time.perf_counter() - t))

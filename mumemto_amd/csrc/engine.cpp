@@ -150,16 +150,20 @@ void Engine::lcp_bwt() {
     const uint32_t anchor = (uint32_t)std::min<uint64_t>(doc_len_[0], n);
     if (pfp) d_rank_.ensure((size_t)anchor + 1);
     d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_count_.ensure(4);
-    uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 12, (size_t)n / 256 + 4096);
+    uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 16, (size_t)n / 256 + 4096);
     if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
     for (int attempt = 0; attempt < 2; attempt++) {
-        d_long_.ensure((size_t)cap * 12);
+        d_long_.ensure((size_t)cap * 16);                // 12-byte records + one index each for the second tier
         k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), pfp ? d_rank_.get() : nullptr,
                            anchor, d_long_.get(), d_count_.get() + 2, cap, stream_);
         uint32_t found = 0;
         MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
         MMT_HIP(hipStreamSynchronize(stream_));
-        if (found <= cap) { k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(), stream_); break; }
+        if (found <= cap) {
+            k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(),
+                        reinterpret_cast<uint32_t*>(d_long_.get() + (size_t)cap * 12), d_count_.get() + 3, stream_);
+            break;
+        }
         if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
         cap = found + 1024;                            // rare: rerun with the exact size
     }

@@ -521,29 +521,100 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
     }
 }
 
-// one wave per long match: 512 characters per step
-__global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, const LongLcp* __restrict__ longs,
-                           uint32_t count, uint32_t* __restrict__ K) {
+// Long matches.  A step of a comparison costs one memory round trip whatever its size, and a match of millions of
+// characters (an identical stretch of two haplotypes) is a chain of such steps, so the step grows with the match:
+//   k_long_lcp   one wave per match: two steps of 512 characters (most "long" matches end here), then steps of 4 KB
+//                (sixteen 8-byte loads per lane, all in flight before the first use) up to LONG_WAVE_MAX characters;
+//   k_huge_lcp   what is still undecided: one workgroup of 16 waves per match, 64 KB per step, the waves agree on
+//                the first mismatch through LDS.
+constexpr int LONG_UNROLL = 8, HUGE_WAVES = 16;
+constexpr uint32_t LONG_SLICE = LONG_UNROLL * 512, LONG_WAVE_MAX = 64 * 1024;
+
+// first mismatch of text[p + base ..) and text[q + base ..) within one 4 KB slice (0xffffffff: none); wave-uniform
+__device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ text, uint32_t p, uint32_t q, uint32_t base,
+                                                   uint32_t limit, uint32_t lane) {
+    uint64_t x[LONG_UNROLL], y[LONG_UNROLL];
+#pragma unroll
+    for (int u = 0; u < LONG_UNROLL; u++) {
+        const uint32_t o = base + (uint32_t)(u * 64 + lane) * 8;
+        const uint32_t oc = o < limit ? o : limit;            // past the shorter suffix: the zero padding after the text
+        x[u] = load_u64(text + p + oc);
+        y[u] = load_u64(text + q + oc);
+    }
+    uint32_t first = 0xffffffffu;
+#pragma unroll
+    for (int u = LONG_UNROLL - 1; u >= 0; u--) {
+        const uint32_t o = base + (uint32_t)(u * 64 + lane) * 8;
+        const uint64_t d = o < limit ? x[u] ^ y[u] : 0;
+        const uint64_t m = __ballot(d != 0);
+        if (m) {
+            const int fl = __builtin_ctzll(m);
+            const uint64_t dx = __shfl(d, fl, 64);
+            first = base + (uint32_t)(u * 64 + fl) * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3);
+        }
+    }
+    return first;
+}
+
+__global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, LongLcp* __restrict__ longs, uint32_t count,
+                           uint32_t* __restrict__ K, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count) {
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= count) return;
     const uint32_t p = longs[w].p, q = longs[w].q;
     uint32_t h = longs[w].h;
     const uint32_t limit = n - (p > q ? p : q);
-    while (h < limit) {
+    const uint32_t stop = h + LONG_WAVE_MAX < limit ? h + LONG_WAVE_MAX : limit;
+    bool found = false;
+    for (int step = 0; step < 2 && h < limit && !found; step++) {
         const uint32_t o = h + lane * 8;
-        uint64_t x = 0, y = 0;
-        if (o < limit) { x = load_u64(text + p + o); y = load_u64(text + q + o); }   // text is zero padded by 64 bytes
-        const uint64_t m = __ballot(x != y);
+        uint64_t d = 0;
+        if (o < limit) d = load_u64(text + p + o) ^ load_u64(text + q + o);       // text is zero padded by 64 bytes
+        const uint64_t m = __ballot(d != 0);
         if (m) {
-            const int first = __builtin_ctzll(m);
-            const uint64_t dx = __shfl(x ^ y, first, 64);
-            h += (uint32_t)first * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3);
-            break;
-        }
-        h += 512;
+            const int fl = __builtin_ctzll(m);
+            const uint64_t dx = __shfl(d, fl, 64);
+            h += (uint32_t)fl * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3);
+            found = true;
+        } else h += 512;
     }
-    if (h > limit) h = limit;
-    if (lane == 0) K[p] = h + p;
+    while (!found && h < stop) {
+        const uint32_t first = slice_mismatch(text, p, q, h, limit, lane);
+        if (first != 0xffffffffu) { h = first; found = true; }
+        else h += LONG_SLICE;
+    }
+    if (found || h >= limit) {
+        if (lane == 0) K[p] = (h > limit ? limit : h) + p;
+    } else if (lane == 0) {
+        longs[w].h = h;
+        huge_idx[atomicAdd(huge_count, 1u)] = w;
+    }
+}
+
+__global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __restrict__ text, uint32_t n,
+                                                              const LongLcp* __restrict__ longs,
+                                                              const uint32_t* __restrict__ huge_idx,
+                                                              const uint32_t* __restrict__ huge_count,
+                                                              uint32_t* __restrict__ K) {
+    __shared__ uint32_t s_first[HUGE_WAVES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t total = *huge_count;
+    for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
+        const LongLcp L = longs[huge_idx[e]];
+        const uint32_t p = L.p, q = L.q, limit = n - (p > q ? p : q);
+        uint32_t h = L.h;
+        while (h < limit) {
+            const uint32_t first = slice_mismatch(text, p, q, h + wave * LONG_SLICE, limit, lane);
+            if (lane == 0) s_first[wave] = first;
+            __syncthreads();
+            uint32_t best = 0xffffffffu;
+#pragma unroll
+            for (int w = 0; w < HUGE_WAVES; w++) best = s_first[w] < best ? s_first[w] : best;
+            __syncthreads();
+            if (best != 0xffffffffu) { h = best; break; }
+            h += HUGE_WAVES * LONG_SLICE;
+        }
+        if (threadIdx.x == 0) K[p] = (h > limit ? limit : h) + p;
+    }
 }
 
 __global__ void k_lcp_gather(const uint32_t* __restrict__ Ks, const uint32_t* __restrict__ sa, uint32_t n,
@@ -564,10 +635,15 @@ void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const 
                        anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap);
     MMT_HIP(hipGetLastError());
 }
-void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s) {
+void long_lcp(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* K, uint32_t* huge_idx,
+              uint32_t* huge_count, hipStream_t s) {
     if (!count) return;
+    MMT_HIP(hipMemsetAsync(huge_count, 0, 4, s));
     hipLaunchKernelGGL(k_long_lcp, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, n,
-                       static_cast<const LongLcp*>(long_list), count, K);
+                       static_cast<LongLcp*>(long_list), count, K, huge_idx, huge_count);
+    const uint32_t blocks = count < 1024u ? count : 1024u;       // the list is read on the device: no host round trip
+    hipLaunchKernelGGL(k_huge_lcp, dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, n,
+                       static_cast<const LongLcp*>(long_list), huge_idx, huge_count, K);
     MMT_HIP(hipGetLastError());
 }
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s) {

@@ -65,7 +65,9 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
 void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
                      uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
                      uint32_t long_cap, hipStream_t s);
-void long_lcp(const uint8_t* text, uint32_t n, const void* long_list, uint32_t count, uint32_t* K, hipStream_t s);
+// huge_idx (count entries) / huge_count: scratch for the matches that outgrow one wave (see kernels.hip)
+void long_lcp(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* K, uint32_t* huge_idx,
+              uint32_t* huge_count, hipStream_t s);
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
 

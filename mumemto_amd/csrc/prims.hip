@@ -1,5 +1,10 @@
 // prims.hip -- rocPRIM instantiations (see prims.hpp).
+#include <algorithm>
+#include <cstdio>
+#include <functional>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -187,22 +192,84 @@ void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint3
                              hipStream_t s) {
     select_flagged(temp, flags, out, d_count, n, s);
 }
+// Ranges [begin[i], end[i]) of one array, each sorted by the key bits below end_bit.  rocPRIM's segmented sort gives a
+// range to ONE workgroup however long it is (~30 ns per element: a homopolymer or a run of N puts millions of suffixes
+// into one bucket of a doubling round, and such a round then takes hundreds of milliseconds), so the range list is read
+// on the host and a range beyond GIANT elements gets a device-wide radix sort of its own; the others share one
+// segmented sort as before.  MMT_GIANT_RANGE overrides the threshold (tests).
+template <typename K>
+static void sort_ranges(DevBuf<uint8_t>& temp, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, uint32_t n,
+                        uint32_t segments, const uint32_t* begin, const uint32_t* end, int end_bit, hipStream_t s) {
+    static const uint32_t GIANT = std::getenv("MMT_GIANT_RANGE") ? (uint32_t)std::atoi(std::getenv("MMT_GIANT_RANGE")) : 65536u;
+    if (!segments) return;
+    std::vector<uint32_t> hb(segments), he(segments);
+    MMT_HIP(hipMemcpyAsync(hb.data(), begin, (size_t)segments * 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipMemcpyAsync(he.data(), end, (size_t)segments * 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    // a range is "giant" when one workgroup would still be busy with it long after the other ranges, which share the
+    // chip a few hundred at a time, are done: beyond GIANT elements and four times the 256th longest range
+    uint32_t thresh = GIANT;
+    if (segments > 256 && !std::getenv("MMT_GIANT_RANGE")) {
+        std::vector<uint32_t> len(segments);
+        for (uint32_t i = 0; i < segments; i++) len[i] = he[i] - hb[i];
+        std::nth_element(len.begin(), len.begin() + 255, len.end(), std::greater<uint32_t>());
+        if (len[255] > thresh / 4) thresh = len[255] >= 0x3fffffffu ? 0xffffffffu : 4 * len[255];
+    }
+    std::vector<uint32_t> giant, rb, re;
+    for (uint32_t i = 0; i < segments; i++)
+        if (he[i] - hb[i] > thresh) giant.push_back(i);
+    if (std::getenv("MMT_RANGE_STATS")) {                    // tuning aid
+        uint64_t total = 0;
+        uint32_t longest = 0;
+        for (uint32_t i = 0; i < segments; i++) { total += he[i] - hb[i]; longest = std::max(longest, he[i] - hb[i]); }
+        std::fprintf(stderr, "[ranges] %zu-byte keys: %u ranges, %llu elements, longest %u, threshold %u, %zu device-wide\n",
+                     sizeof(K), segments, (unsigned long long)total, longest, thresh, giant.size());
+    }
+    if (giant.empty()) {
+        with_temp(temp, [&](void* t, size_t& b) {
+            return rocprim::segmented_radix_sort_pairs(t, b, kin, kout, vin, vout, n, segments, begin, end, 0u,
+                                                       (unsigned)end_bit, s);
+        });
+        return;
+    }
+    for (uint32_t i : giant) {
+        const uint32_t b0 = hb[i], len = he[i] - hb[i];
+        with_temp(temp, [&](void* t, size_t& b) {
+            return rocprim::radix_sort_pairs(t, b, kin + b0, kout + b0, vin + b0, vout + b0, len, 0u, (unsigned)end_bit, s);
+        });
+    }
+    if (giant.size() == segments) return;
+    size_t g = 0;
+    for (uint32_t i = 0; i < segments; i++) {
+        if (g < giant.size() && giant[g] == i) { g++; continue; }
+        rb.push_back(hb[i]); re.push_back(he[i]);
+    }
+    // the range list without the giants sits behind rocPRIM's scratch in `temp`
+    const uint32_t rest = (uint32_t)rb.size();
+    size_t bytes = 0;
+    MMT_HIP(rocprim::segmented_radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, rest, begin, end, 0u,
+                                                (unsigned)end_bit, s));
+    const size_t head = (bytes + 255) & ~(size_t)255;
+    temp.ensure(head + (size_t)rest * 8 + 16);
+    uint32_t* db = reinterpret_cast<uint32_t*>(temp.get() + head);
+    uint32_t* de = db + rest;
+    MMT_HIP(hipMemcpyAsync(db, rb.data(), (size_t)rest * 4, hipMemcpyHostToDevice, s));
+    MMT_HIP(hipMemcpyAsync(de, re.data(), (size_t)rest * 4, hipMemcpyHostToDevice, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    MMT_HIP(rocprim::segmented_radix_sort_pairs(temp.get(), bytes, kin, kout, vin, vout, n, rest, db, de, 0u,
+                                                (unsigned)end_bit, s));
+}
+
 void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s) {
-    with_temp(temp, [&](void* t, size_t& b) {
-        return rocprim::segmented_radix_sort_pairs(t, b, kin, kout, vin, vout, n, segments, begin, end, 0u,
-                                                   (unsigned)end_bit, s);
-    });
+    sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
 }
 
 void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s) {
-    with_temp(temp, [&](void* t, size_t& b) {
-        return rocprim::segmented_radix_sort_pairs(t, b, kin, kout, vin, vout, n, segments, begin, end, 0u,
-                                                   (unsigned)end_bit, s);
-    });
+    sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
 }
 
 }}  // namespace mmt::prims

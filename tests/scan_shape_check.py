@@ -14,9 +14,16 @@ n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 120_000
 docs = synth.pangenome(n_docs, length, 0.01, seed=31)
 if len(sys.argv) > 3 and sys.argv[3] == "dups":
-    # exact copies and a long tandem repeat: irreducible LCP values of tens of thousands (the k_long_lcp path)
+    # exact copies and a long tandem repeat: irreducible LCP values beyond 100,000 characters -- past the 64 KB one wave
+    # compares in k_long_lcp, into k_huge_lcp
     docs[1] = [docs[0][0]]
     docs[2] = [docs[0][0][: length // 2] + docs[0][0][: length // 2]]
+if len(sys.argv) > 3 and sys.argv[3] == "runs":
+    # runs of one letter (assembly gaps, homopolymers): tens of thousands of suffixes share every prefix a doubling round
+    # has seen, i.e. one bucket far beyond an LDS tile; with MMT_GIANT_RANGE small such a range takes the device-wide sort
+    docs[1] = [docs[1][0][:1000] + b"N" * 20000 + docs[1][0][1000:]]
+    docs[2] = [docs[2][0][:7000] + b"N" * 9000 + docs[2][0][7000:]]
+    docs[3] = [b"A" * 15000 + docs[3][0][:5000]]
 eng = mumemto_amd.Engine(0)
 eng.set_docs(docs)
 cases = [
@@ -32,13 +39,13 @@ for c in cases:
                 max_total_freq=c["max_total_freq"], revcomp=True, merge=c["merge_metadata"])
     got = eng.output_text()
     assert got == ref.text(), ("output differs", c, len(got), len(ref.text()))
-    assert got.count(b"\n") > 0 or "dups" in sys.argv, c
-    if "dups" in sys.argv:      # the stream itself, column by column
+    assert got.count(b"\n") > 0 or "dups" in sys.argv or "runs" in sys.argv, c
+    if "dups" in sys.argv or "runs" in sys.argv:      # the stream itself, column by column
         import numpy as np
         text, _ = O.build_text(docs, True)
         sa, lcp, bwt = O.build_stream(text)
         assert np.array_equal(eng.sa().astype(np.int64), sa[1:]) and np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
-        assert np.array_equal(eng.bwt(), bwt[1:]) and int(lcp.max()) > 20000
+        assert np.array_equal(eng.bwt(), bwt[1:]) and int(lcp.max()) > (2 * length if "dups" in sys.argv else 8000)
     if c["merge_metadata"]:
         import numpy as np
         assert np.array_equal(eng.thresholds(), ref.thresh())

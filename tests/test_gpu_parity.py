@@ -257,13 +257,30 @@ def test_two_fingerprint_phrase_grouping_path():
 @pytest.mark.parametrize("env", [{"MMT_PFP_NO_PACK": "1"}, {"MMT_LONG_CAP": "3"}, {}])
 def test_long_matches_and_rare_construction_paths(env):
     """Exact document copies and a long tandem repeat give irreducible LCP values far beyond the 192 characters one lane
-    compares (k_long_lcp); MMT_LONG_CAP forces the overflow-and-rerun of the long-match list, MMT_PFP_NO_PACK the
+    compares (k_long_lcp, and k_huge_lcp beyond 64 KB); MMT_LONG_CAP forces the overflow-and-rerun of the long-match list, MMT_PFP_NO_PACK the
     dictionary records without the packed previous byte (>= 2^24 distinct phrases in production)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py"), "5", "60000", "dups"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("producer", ["pfp", "direct"])
+@pytest.mark.parametrize("giant", ["3000", None])
+def test_letter_runs_make_giant_sort_ranges(producer, giant):
+    """Runs of N / homopolymers put tens of thousands of suffixes into one bucket of a doubling round (and one group of
+    the PFP emitter); ranges beyond MMT_GIANT_RANGE elements are sorted device-wide instead of by one workgroup of the
+    segmented sort (prims.hip sort_ranges)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MUMEMTO_PRODUCER=producer)
+    if giant:
+        env["MMT_GIANT_RANGE"] = giant
+    r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py"), "5", "30000", "runs"], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 

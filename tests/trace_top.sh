@@ -2,7 +2,7 @@
 # GPU box helper: rocprofv3 kernel trace of the default bench, top kernels by time per step
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_top; rm -rf $OUT; mkdir -p $OUT
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-bp 0 > $OUT/log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --cpu-sample-bp 0 ${EXTRA} > $OUT/log 2>&1
 python - $OUT/t_kernel_stats.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -202,6 +202,12 @@ void Engine::scan(const mmt_params& p) {
         a.out = d_cand_.get(); a.capacity = (uint32_t)capacity;
         MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 16, stream_));
         ev_[3]->start(stream_);
+        if (attempt == 0 && k::scan_needs_wide(a)) {      // window tables in HBM (the LCP scratch is free by now)
+            d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_wide_.ensure((size_t)n * 2);
+            k::scan_wide_prepare(a.lcp, a.bwt, n, a.num_distinct, d_plcp_a_.get(), d_plcp_b_.get(), d_wide_.get(), stream_);
+            prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get() + n, n, stream_);
+            a.wide_pre = d_plcp_a_.get(); a.wide_suf = d_plcp_b_.get(); a.wide_chg = d_wide_.get() + n;
+        }
         k::scan_intervals(a, stream_);
         ev_[3]->stop(stream_);
         MMT_HIP(hipMemcpyAsync(&found, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));

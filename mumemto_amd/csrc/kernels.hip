@@ -1045,6 +1045,116 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     }
 }
 
+// ---- A5 for windows that do not fit an LDS tile (more than ~1000 documents) ---------------------------------------
+// van Herk / Gil-Werman sliding minimum: cut the column into blocks of w entries; with pre[i] = min(lcp[block start .. i])
+// and suf[i] = min(lcp[i .. block end]), min(lcp[k .. k+w-1]) = min(suf[k], pre[k+w-1]) for every k, whatever w is.
+// One workgroup per block of w entries, a forward and a backward pass of workgroup-wide running minima.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_window_block_mins(const uint32_t* __restrict__ lcp, uint32_t n, uint32_t w,
+                                                             uint32_t* __restrict__ pre, uint32_t* __restrict__ suf) {
+    __shared__ uint32_t s_wave[BLOCK / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * w;
+    const uint64_t e = b0 + w < n ? b0 + w : n;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int dir = 0; dir < 2; dir++) {
+        uint32_t carry = 0xffffffffu;
+        for (uint64_t c = 0; b0 + c < e; c += BLOCK) {
+            const uint64_t t = c + threadIdx.x;                              // distance from the end the pass starts at
+            const bool in = b0 + t < e;
+            const uint64_t i = dir == 0 ? b0 + t : e - 1 - t;
+            uint32_t v = in ? lcp[i] : 0xffffffffu;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(v, o, 64); if (lane >= (uint32_t)o) v = umin32(v, u); }
+            if (lane == 63) s_wave[wave] = v;
+            __syncthreads();
+            uint32_t before = carry, all = carry;
+#pragma unroll
+            for (int x = 0; x < BLOCK / 64; x++) { if ((uint32_t)x < wave) before = umin32(before, s_wave[x]); all = umin32(all, s_wave[x]); }
+            v = umin32(v, before);
+            if (in) (dir == 0 ? pre : suf)[i] = v;
+            __syncthreads();
+            carry = all;
+        }
+    }
+}
+
+// chg[t] = t where the BWT byte differs from the one before (and at 0), else 0: its running maximum is the position of
+// the last change at or before t, and "the BWT bytes of entries k-1 .. j-1 are not all equal" = lastchg[j-1] >= k
+__global__ void k_mark_bwt_changes(const uint8_t* __restrict__ bwt, uint32_t n, uint32_t* __restrict__ chg) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    chg[t] = (t > 0 && bwt[t] != bwt[t - 1]) ? t : 0u;
+}
+
+// One thread per closing position j; the window query is two loads, the rest of the walk (modes other than the
+// exact-window one) runs in the cached global columns exactly like the tail of k_scan's phase 2.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_scan_wide(ScanArgs a, uint32_t w, int exact) {
+    const uint64_t j64 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    bool emit = false;
+    Cand c{};
+    if (j64 > w && j64 < a.n) {                               // the candidate start k - 1 = j - w - 1 must exist
+        const uint32_t j = (uint32_t)j64, k = j - w;
+        uint32_t m = umin32(a.wide_suf[k], a.wide_pre[j - 1]);
+        const uint32_t closing = a.lcp[j];
+        if (m > closing && m >= a.min_len) {
+            bool chg = a.wide_chg[j - 1] >= k;
+            if (exact) {
+                if (chg && a.lcp[k - 1] < m) {
+                    emit = true;
+                    c.start = k - 1; c.end = j - 1; c.len = m; c.flags = CAND_LEFT_MAXIMAL;
+                }
+            } else {
+                uint32_t kpos = k;
+                while (kpos > 0) {
+                    const uint32_t v = a.lcp[kpos - 1];
+                    chg |= a.bwt[kpos] != a.bwt[kpos - 1];
+                    if (v < m) {
+                        const uint32_t cnt = j - (kpos - 1);
+                        if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
+                            Cand d; d.start = kpos - 1; d.end = j - 1; d.len = m; d.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
+                            const uint32_t g = atomicAdd(a.d_count, 1u);
+                            if (g < a.capacity) a.out[g] = d;
+                        }
+                        m = v;
+                        if (m <= closing || m < a.min_len) break;
+                    }
+                    kpos--;
+                    if (a.cap && j - (kpos - 1) > a.cap) break;
+                }
+            }
+        }
+    }
+    const uint64_t mask = __ballot(emit);                     // one counter update per wave
+    if (mask) {
+        uint32_t base = 0;
+        const int leader = __builtin_ctzll(mask);
+        if ((int)lane == leader) base = atomicAdd(a.d_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (emit) {
+            const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            if (slot < a.capacity) a.out[slot] = c;
+        }
+    }
+}
+
+static uint32_t wide_threshold() {
+    static const uint32_t t = getenv("MMT_SCAN_WIDE_AT") ? (uint32_t)atoi(getenv("MMT_SCAN_WIDE_AT")) : 1000u;
+    return t;
+}
+bool scan_needs_wide(const ScanArgs& a) {
+    const uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
+    return nd - 1 > wide_threshold();
+}
+void scan_wide_prepare(const uint32_t* lcp, const uint8_t* bwt, uint32_t n, uint32_t num_distinct, uint32_t* pre,
+                       uint32_t* suf, uint32_t* chg, hipStream_t s) {
+    const uint32_t w = (num_distinct < 2 ? 2 : num_distinct) - 1;
+    hipLaunchKernelGGL((k_window_block_mins<256>), dim3(grid_for(n, w)), dim3(256), 0, s, lcp, n, w, pre, suf);
+    hipLaunchKernelGGL(k_mark_bwt_changes, dim3(grid_for(n, 256)), dim3(256), 0, s, bwt, n, chg);
+    MMT_HIP(hipGetLastError());
+}
+
 template <int B, int VG, int OUT_CAP>
 static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu) {
     constexpr int TILE = B * VG * 4;
@@ -1090,6 +1200,14 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
 
 void scan_intervals(const ScanArgs& a, hipStream_t s) {
     if (a.cap && a.cap < a.num_distinct) return;          // no interval can satisfy both bounds
+    if (scan_needs_wide(a)) {
+        if (!a.wide_pre || !a.wide_suf || !a.wide_chg) throw HipError("scan: the window tables of the wide path are missing");
+        const uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
+        const bool exact = a.cap != 0 && a.cap == nd && !a.emit_all && nd == a.num_distinct;
+        hipLaunchKernelGGL((k_scan_wide<256>), dim3(grid_for(a.n, 256)), dim3(256), 0, s, a, nd - 1, exact ? 1 : 0);
+        MMT_HIP(hipGetLastError());
+        return;
+    }
     // measured on MI355X (tests/scan_sweep.sh, profiles/): workgroups of 256 threads x 8 positions (39.7 KB of LDS
     // with both column buffers: four resident workgroups per CU) and a grid of 16 per CU are best for 16 and for
     // 94 documents alike; 512 x 8 is 5 % slower, 512 x 12 leaves one workgroup per CU.

@@ -83,8 +83,19 @@ struct ScanArgs {
     Cand* out;
     uint32_t capacity;
     uint32_t* d_count;      // total candidates found (may exceed capacity)
+    // windows beyond one LDS tile (scan_needs_wide): block-wise prefix / suffix minima of the LCP column for the
+    // window size num_distinct - 1 and the position of the last BWT change at or before every entry
+    const uint32_t* wide_pre = nullptr;
+    const uint32_t* wide_suf = nullptr;
+    const uint32_t* wide_chg = nullptr;
 };
 void scan_intervals(const ScanArgs& a, hipStream_t s);
+// More than ~1000 documents: the window of num_distinct - 1 entries does not fit k_scan's LDS tile.  The caller then
+// fills pre / suf (n entries each) and chg (n entries, to be replaced by its inclusive running maximum) with
+// scan_wide_prepare and hands them over in ScanArgs.
+bool scan_needs_wide(const ScanArgs& a);
+void scan_wide_prepare(const uint32_t* lcp, const uint8_t* bwt, uint32_t n, uint32_t num_distinct, uint32_t* pre,
+                       uint32_t* suf, uint32_t* chg, hipStream_t s);
 
 struct VerifyArgs {
     const Cand* cand;

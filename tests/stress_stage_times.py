@@ -30,3 +30,26 @@ for name, docs in cases.items():
         print("%-24s %-7s " % (name, producer) + " | ".join("%s %.1f" % (n, v) for n, v in zip(names, ms)), flush=True)
         if producer == "pfp":
             print("    pfp:", eng.pfp_counts(), [round(float(x), 1) for x in eng.pfp_stage_ms()], flush=True)
+
+# satellite array: a 171-bp monomer repeated 10,000 times with 2 % differences between the copies, 0.5 % between the
+# haplotypes (centromeric higher-order repeats), embedded in random sequence
+def satellite(h):
+    r = np.random.default_rng(77)
+    mono = r.integers(0, 4, 171, dtype=np.uint8)
+    arr = np.tile(mono, 10000)
+    mut = r.random(arr.size) < 0.02
+    arr[mut] = (arr[mut] + r.integers(1, 4, int(mut.sum()), dtype=np.uint8)) & 3
+    hr = np.random.default_rng(1000 + h)
+    mut = hr.random(arr.size) < 0.005
+    arr[mut] = (arr[mut] + hr.integers(1, 4, int(mut.sum()), dtype=np.uint8)) & 3
+    return np.frombuffer(b"ACGT", np.uint8)[arr].tobytes()
+docs = [[rnd(200000) + satellite(h) + rnd(200000)] for h in range(8)]
+for producer in ("pfp", "direct"):
+    eng.set_producer(producer)
+    eng.set_docs(docs)
+    eng.run(min_match_len=20, num_distinct=0, max_doc_freq=1)
+    print("%-24s %-7s " % ("satellite arrays x8", producer) + " | ".join("%s %.1f" % (n, v) for n, v in zip(names, eng.stage_ms())), flush=True)
+    if producer == "pfp":
+        print("    pfp:", eng.pfp_counts(), [round(float(x), 1) for x in eng.pfp_stage_ms()], flush=True)
+    first = eng.output_text() if producer == "pfp" else first
+    assert eng.output_text() == first

@@ -165,6 +165,25 @@ def test_thousands_of_documents(engine):
         engine.set_docs(docs)
         engine.run(min_match_len=12, **m)
         assert engine.output_text() == O.run(docs, min_len=12, **m).text()
+    # strict multi-MUMs of 1,800 documents that do share the core: the exact-window form of the wide scan
+    # (k_scan_wide: the window of num_distinct - 1 entries no longer fits k_scan's LDS tile)
+    sharing = [d for i, d in enumerate(docs) if i % 7][:1800]
+    engine.set_docs(sharing)
+    engine.run(min_match_len=12, num_distinct=0, max_doc_freq=1)
+    expected = O.run(sharing, min_len=12, num_distinct=0, max_doc_freq=1).text()
+    assert engine.output_text() == expected and expected.count(b"\n") >= 1
+
+
+def test_wide_window_scan_on_random_collections():
+    """MMT_SCAN_WIDE_AT=1 sends every scan with more than two documents through the path for > 1000 documents (sliding
+    minima from block prefix / suffix minima in HBM, k_scan_wide): the differential test over random collections and
+    parameters, both producers."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_run.py"), "4200", "4", "40"],
+                       env=dict(os.environ, MMT_SCAN_WIDE_AT="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_tiny_and_degenerate_texts(engine):

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
 
 // Long matches.  A step of a comparison costs one memory round trip whatever its size, and a match of millions of
 // characters (an identical stretch of two haplotypes) is a chain of such steps, so the step grows with the match:
-//   k_long_lcp   one wave per match: two steps of 512 characters (most "long" matches end here), then steps of 4 KB
+//   k_long_lcp   one wave per match: eight steps of 512 characters (most "long" matches end here), then steps of 4 KB
 //                (sixteen 8-byte loads per lane, all in flight before the first use) up to LONG_WAVE_MAX characters;
 //   k_huge_lcp   what is still undecided: one workgroup of 16 waves per match, 64 KB per step, the waves agree on
 //                the first mismatch through LDS.
@@ -533,13 +533,20 @@ constexpr uint32_t LONG_SLICE = LONG_UNROLL * 512, LONG_WAVE_MAX = 64 * 1024;
 // first mismatch of text[p + base ..) and text[q + base ..) within one 4 KB slice (0xffffffff: none); wave-uniform
 __device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ text, uint32_t p, uint32_t q, uint32_t base,
                                                    uint32_t limit, uint32_t lane) {
+    // 8-byte loads at addresses that are multiples of 8 (a misaligned wave-wide load is served lane by lane, ~230 ns per
+    // instruction on this part); the suffix bytes are funnelled out of two neighbouring words
+    const uint8_t* pa = text + (p & ~7u);
+    const uint8_t* qa = text + (q & ~7u);
+    const uint32_t sp = (p & 7u) * 8, sq = (q & 7u) * 8;
     uint64_t x[LONG_UNROLL], y[LONG_UNROLL];
 #pragma unroll
     for (int u = 0; u < LONG_UNROLL; u++) {
         const uint32_t o = base + (uint32_t)(u * 64 + lane) * 8;
         const uint32_t oc = o < limit ? o : limit;            // past the shorter suffix: the zero padding after the text
-        x[u] = load_u64(text + p + oc);
-        y[u] = load_u64(text + q + oc);
+        const uint64_t xl = *reinterpret_cast<const uint64_t*>(pa + oc), xh = *reinterpret_cast<const uint64_t*>(pa + oc + 8);
+        const uint64_t yl = *reinterpret_cast<const uint64_t*>(qa + oc), yh = *reinterpret_cast<const uint64_t*>(qa + oc + 8);
+        x[u] = sp ? (xl >> sp) | (xh << (64 - sp)) : xl;
+        y[u] = sq ? (yl >> sq) | (yh << (64 - sq)) : yl;
     }
     uint32_t first = 0xffffffffu;
 #pragma unroll
@@ -565,7 +572,7 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, LongLcp
     const uint32_t limit = n - (p > q ? p : q);
     const uint32_t stop = h + LONG_WAVE_MAX < limit ? h + LONG_WAVE_MAX : limit;
     bool found = false;
-    for (int step = 0; step < 2 && h < limit && !found; step++) {
+    for (int step = 0; step < 8 && h < limit && !found; step++) {
         const uint32_t o = h + lane * 8;
         uint64_t d = 0;
         if (o < limit) d = load_u64(text + p + o) ^ load_u64(text + q + o);       // text is zero padded by 64 bytes

@@ -624,12 +624,19 @@ __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __r
     }
 }
 
+// four consecutive entries per thread: one 16-byte load of SA, four independent gathers in flight, one 16-byte store
 __global__ void k_lcp_gather(const uint32_t* __restrict__ Ks, const uint32_t* __restrict__ sa, uint32_t n,
                              uint32_t* __restrict__ lcp) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t p = sa[j];
-    lcp[j] = Ks[p] - p;
+    const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j + 4 <= n) {
+        const uint4 p = *reinterpret_cast<const uint4*>(sa + j);
+        uint4 r;
+        r.x = Ks[p.x]; r.y = Ks[p.y]; r.z = Ks[p.z]; r.w = Ks[p.w];
+        r.x -= p.x; r.y -= p.y; r.z -= p.z; r.w -= p.w;
+        *reinterpret_cast<uint4*>(lcp + j) = r;
+    } else {
+        for (uint64_t t = j; t < n; t++) { const uint32_t p = sa[t]; lcp[t] = Ks[p] - p; }
+    }
 }
 
 void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
@@ -654,7 +661,7 @@ void long_lcp(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, 
     MMT_HIP(hipGetLastError());
 }
 void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s) {
-    hipLaunchKernelGGL(k_lcp_gather, dim3(grid_for(n, 256)), dim3(256), 0, s, Ks, sa, n, lcp);
+    hipLaunchKernelGGL(k_lcp_gather, dim3(grid_for(n, 1024)), dim3(256), 0, s, Ks, sa, n, lcp);
     MMT_HIP(hipGetLastError());
 }
 

@@ -230,11 +230,17 @@ void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, bool lsb_un
 
 __global__ void k_scatter_rank(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ head, uint32_t n,
                                uint32_t* __restrict__ rank) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) rank[sa[j]] = head[j];
+    // four entries per thread: 16-byte loads of both columns, four stores in flight
+    const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j + 4 <= n) {
+        const uint4 p = *reinterpret_cast<const uint4*>(sa + j), v = *reinterpret_cast<const uint4*>(head + j);
+        rank[p.x] = v.x; rank[p.y] = v.y; rank[p.z] = v.z; rank[p.w] = v.w;
+    } else {
+        for (uint64_t t = j; t < n; t++) rank[sa[t]] = head[t];
+    }
 }
 void scatter_rank(const uint32_t* sa, const uint32_t* head, uint32_t n, uint32_t* rank, hipStream_t s) {
-    hipLaunchKernelGGL(k_scatter_rank, dim3(grid_for(n, 256)), dim3(256), 0, s, sa, head, n, rank);
+    hipLaunchKernelGGL(k_scatter_rank, dim3(grid_for(n, 1024)), dim3(256), 0, s, sa, head, n, rank);
     MMT_HIP(hipGetLastError());
 }
 
@@ -267,15 +273,29 @@ void gather_active(const uint32_t* idx, uint32_t m, const uint32_t* sa, const ui
 __global__ void k_make_round_keys(const uint32_t* __restrict__ sa_c, const uint32_t* __restrict__ head_c, uint32_t m,
                                   const uint32_t* __restrict__ rank, uint32_t n, uint32_t h, int shift,
                                   uint64_t* __restrict__ keys) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= m) return;
-    uint64_t i = (uint64_t)sa_c[c] + h;
-    uint64_t second = i < n ? (uint64_t)rank[i] + 1 : 0;   // past the end sorts first
-    keys[c] = ((uint64_t)head_c[c] << shift) | second;
+    // four entries per thread: the gathers of rank[sa + h] are independent and all in flight together
+    const uint64_t c = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (c + 4 <= m) {
+        const uint4 p = *reinterpret_cast<const uint4*>(sa_c + c), hd = *reinterpret_cast<const uint4*>(head_c + c);
+        const uint32_t pv[4] = {p.x, p.y, p.z, p.w}, hv[4] = {hd.x, hd.y, hd.z, hd.w};
+        uint64_t second[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint64_t i = (uint64_t)pv[t] + h;
+            second[t] = i < n ? (uint64_t)rank[i] + 1 : 0;   // past the end sorts first
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) keys[c + t] = ((uint64_t)hv[t] << shift) | second[t];
+    } else {
+        for (uint64_t t = c; t < m; t++) {
+            const uint64_t i = (uint64_t)sa_c[t] + h;
+            keys[t] = ((uint64_t)head_c[t] << shift) | (i < n ? (uint64_t)rank[i] + 1 : 0);
+        }
+    }
 }
 void make_round_keys(const uint32_t* sa_c, const uint32_t* head_c, uint32_t m, const uint32_t* rank, uint32_t n,
                      uint32_t h, int shift, uint64_t* keys, hipStream_t s) {
-    hipLaunchKernelGGL(k_make_round_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_c, head_c, m, rank, n, h, shift,
+    hipLaunchKernelGGL(k_make_round_keys, dim3(grid_for(m, 1024)), dim3(256), 0, s, sa_c, head_c, m, rank, n, h, shift,
                        keys);
     MMT_HIP(hipGetLastError());
 }

@@ -439,13 +439,17 @@ void Engine::run(const mmt_params& p) {
     {
         int kind = producer_;
         if (kind == 0) {
-            // automatic: prefix-free parsing (never slower than the direct sort in profiles/round1, 3x
-            // faster at 0.1 % divergence) unless the text holds bytes the parse reserves (<= 0x02)
+            // automatic: prefix-free parsing, which wins by the redundancy of the collection (2.4x on the 16-haplotype
+            // bench, 3x at 0.1 % divergence), unless the text holds bytes the parse reserves (<= 0x02) or there are
+            // too few documents for the dictionary to be much smaller than the text (measured, 1 % divergence:
+            // 3 x 4.6 Mbp 8.6 vs 12.7 ms, 4 x 30 Mbp 80 vs 108 ms for the direct sort; even at 6 documents)
             const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp" override
             std::vector<uint32_t> hist;
             d2h(hist, d_hist_.get(), 256, stream_);
             const bool reserved = hist[0] || hist[1] || hist[2];
-            kind = (env && std::string(env) == "direct") || reserved ? 1 : 2;
+            const bool forced_pfp = env && std::string(env) == "pfp";
+            const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
+            kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
         }
         // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
         // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of

@@ -14,11 +14,27 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def engine():
+@pytest.fixture(scope="module", params=["pfp", "direct"])
+def engine(request):
+    """Every case through both SA/LCP/BWT producers: prefix-free parsing with the production window (w 6, p 16; what the
+    automatic choice takes from five documents on) and the direct suffix sort (its choice for fewer)."""
     import mumemto_amd
     e = mumemto_amd.Engine(0)
+    if request.param == "pfp":
+        e.set_producer("pfp", 6, 16)
+    else:
+        e.set_producer("direct")
     yield e
+    e.close()
+
+
+def test_automatic_producer_goes_by_the_number_of_documents():
+    import mumemto_amd
+    e = mumemto_amd.Engine(0)
+    for n_docs, expected in ((3, "direct"), (4, "direct"), (5, "pfp"), (9, "pfp")):
+        e.set_docs(synth.pangenome(n_docs, 8000, 0.01, seed=n_docs))
+        e.run()
+        assert e.producer_used() == expected
     e.close()
 
 

@@ -161,6 +161,17 @@ def load_library():
     return L
 
 
+def _bytes_at(ptr, n):
+    """n bytes at ptr as `bytes`; ctypes.string_at takes a C int, a MEM-mode output can exceed 2 GiB"""
+    if not n:
+        return b""
+    step = 1 << 30
+    if n <= step:
+        return C.string_at(ptr, n)
+    base = C.cast(ptr, C.c_void_p).value
+    return b"".join(C.string_at(base + o, min(step, n - o)) for o in range(0, n, step))
+
+
 def _check(rc, gpu=True):
     if rc != 0:
         L = load_library()
@@ -339,7 +350,7 @@ class Engine:
     def output_text(self):
         n = C.c_size_t()
         ptr = self.L.mmt_output_text(self.h, C.byref(n))
-        return C.string_at(ptr, n.value) if n.value else b""
+        return _bytes_at(ptr, n.value)
 
     def output_size(self):
         """Bytes of the last run's .mums / .mems output; brings them into page-locked host memory (no Python copy)."""
@@ -350,7 +361,7 @@ class Engine:
     def output_bumbl(self):
         n = C.c_size_t()
         ptr = self.L.mmt_output_bumbl(self.h, C.byref(n))
-        return C.string_at(ptr, n.value) if n.value else b""
+        return _bytes_at(ptr, n.value)
 
     def rows_mum(self):
         n, N = self.L.mmt_num_rows(self.h), self.L.mmt_num_docs(self.h)
@@ -461,7 +472,7 @@ class Engine:
             ptr = self.L.mmt_merged_text(m, C.byref(k))
             if not ptr and n:
                 raise MumemtoError(self.L.mmt_last_error().decode())
-            text = C.string_at(ptr, k.value) if k.value else b""
+            text = _bytes_at(ptr, k.value)
             if not want_rows:
                 return dict(text=text, n_rows=n, n_docs=nd)
             length = np.zeros(max(n, 1), np.uint32)

@@ -175,7 +175,9 @@ class ScanResult:
         return length[:n], occ, off[:t], docs[:t], st[:t]
 
     def _take(self, ptr, nbytes):
-        data = C.string_at(ptr, nbytes)
+        step = 1 << 30                      # ctypes.string_at takes a C int
+        base = C.cast(ptr, C.c_void_p).value
+        data = b"".join(C.string_at(base + o, min(step, nbytes - o)) for o in range(0, nbytes, step)) if nbytes else b""
         lib().mmo_free(ptr)
         return data
 

@@ -14,12 +14,45 @@ from test_gpu_random import random_collection, random_params    # noqa: E402
 first, count = int(sys.argv[1]), int(sys.argv[2])
 cases = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 BIG = len(sys.argv) > 4 and sys.argv[4] == "big"     # every case a pangenome of 0.2 - 3 M text characters
+ADV = len(sys.argv) > 4 and sys.argv[4] == "adv"     # mid-size pangenomes with runs, arrays, copies (see adversarial())
+
+
+def adversarial(rng):
+    """2-8 haplotypes of 4-30 kbp carrying what makes suffix sorting, LCP construction and the scan work hardest: runs of
+    N / of one base up to 12 kbp, tandem arrays, exact copies of another document, large deletions.  Run it with
+    MMT_GIANT_RANGE / MMT_SCAN_WIDE_AT / MMT_LONG_CAP lowered so that the rare paths are the common ones."""
+    nd_ = int(rng.integers(2, 9))
+    docs = synth.pangenome(nd_, int(rng.integers(4000, 30000)), float(rng.choice([0.0, 0.002, 0.01, 0.05])),
+                           seed=int(rng.integers(0, 1 << 30)))
+    out = []
+    for d in range(nd_):
+        s = docs[d][0]
+        for _ in range(int(rng.integers(0, 3))):
+            kind = int(rng.integers(0, 5))
+            a = int(rng.integers(0, len(s)))
+            if kind == 0:
+                s = s[:a] + b"N" * int(rng.integers(50, 12000)) + s[a:]
+            elif kind == 1:
+                s = s[:a] + bytes([b"ACGT"[int(rng.integers(0, 4))]]) * int(rng.integers(50, 12000)) + s[a:]
+            elif kind == 2:
+                unit = s[a:a + int(rng.integers(1, 200))] or b"AC"
+                s = s[:a] + unit * int(rng.integers(2, max(3, 8000 // len(unit)))) + s[a:]
+            elif kind == 3 and out:
+                s = out[int(rng.integers(0, len(out)))][0]            # exact copy of an earlier document
+            else:
+                s = s[:a] + s[a + int(rng.integers(0, len(s) // 2)):]
+        out.append([s if s else b"A"])
+    return out
+
+
 eng = mumemto_amd.Engine(0)
 done = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     for case in range(cases):
-        if BIG:
+        if ADV:
+            docs = adversarial(rng)
+        elif BIG:
             nd_ = int(rng.integers(2, 20))
             docs = synth.pangenome(nd_, int(rng.integers(100000, 1500000) // nd_), float(rng.choice([0.001, 0.005, 0.02])),
                                    seed=int(rng.integers(0, 1 << 30)), indel_rate=float(rng.choice([0, 0.001])))

@@ -87,6 +87,20 @@ def test_random_collections(seed):
         eng.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"MMT_GIANT_RANGE": "1500", "MMT_SCAN_WIDE_AT": "2", "MMT_LONG_CAP": "5"}])
+def test_mid_size_collections_with_runs_arrays_and_copies(env):
+    """fuzz_run.py adv: haplotypes of 4-30 kbp with runs of N / of one base up to 12 kbp, tandem arrays, exact copies and
+    deletions, random parameters, both producers against the oracle; the second run lowers the thresholds of the
+    device-wide range sort, of the wide scan and of the long-match list so that those paths take every case."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "fuzz_run.py"), "777", "1", "14", "adv"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_palindromic_ends_and_terminator_touching_matches():
     # matches running through the middle '$' (palindromic document end) are kept on '+',
     # '-' occurrences touching the terminator are dropped (mem_finder.hpp:372-373)

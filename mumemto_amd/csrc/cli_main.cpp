@@ -331,6 +331,9 @@ int main(int argc, char** argv) {
             write_file(o.output_prefix + ".bwt", fbwt.data(), fbwt.size());
         }
         mark("outputs written");
+        if (std::getenv("MUMEMTO_TIMING"))
+            std::fprintf(stderr, "[timing] device buffers: %.2f GB at the peak, %.3f s inside hipMalloc\n",
+                         DevBytes::peak() / 1073741824.0, DevBytes::seconds());
         log_line("build_main", "Found " + std::to_string(R.n_rows) + " matches!");
         if (o.keep_temp) write_pfp_files();         // -K: keep PREFIX.dict / PREFIX.parse
         const float* ms = eng.stage_ms();

@@ -2,7 +2,10 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -22,6 +25,14 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define MMT_HIP(x) ::mmt::hip_check((x), #x, __FILE__, __LINE__)
 
+// bytes of HBM this process holds through DevBuf (MUMEMTO_TIMING prints the high-water mark)
+struct DevBytes {
+    static size_t& live() { static size_t v = 0; return v; }
+    static size_t& peak() { static size_t v = 0; return v; }
+    static double& seconds() { static double v = 0; return v; }
+    static bool log() { static const bool on = std::getenv("MUMEMTO_ALLOC_LOG") != nullptr; return on; }
+};
+
 // Device allocation that only grows (steps of the hot path are re-run by the
 // bench with the same sizes; re-allocating per run would time hipMalloc).
 template <typename T>
@@ -35,11 +46,18 @@ public:
         if (n <= cap_) { n_ = n; return; }
         release();
         size_t want = n + n / 16 + 64;
+        const auto t0 = std::chrono::steady_clock::now();
         MMT_HIP(hipMalloc(reinterpret_cast<void**>(&p_), want * sizeof(T)));
+        DevBytes::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         cap_ = want; n_ = n;
+        DevBytes::live() += want * sizeof(T);
+        if (DevBytes::log() && want * sizeof(T) >= (64u << 20))
+            std::fprintf(stderr, "[alloc] %8.2f GB  (%zu x %zu B)  live %.2f GB\n", want * sizeof(T) / 1073741824.0, want,
+                         sizeof(T), DevBytes::live() / 1073741824.0);
+        if (DevBytes::live() > DevBytes::peak()) DevBytes::peak() = DevBytes::live();
     }
     void release() {
-        if (p_) { (void)hipFree(p_); p_ = nullptr; }
+        if (p_) { (void)hipFree(p_); p_ = nullptr; DevBytes::live() -= cap_ * sizeof(T); }
         cap_ = n_ = 0;
     }
     T* get() const { return p_; }

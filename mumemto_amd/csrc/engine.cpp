@@ -14,6 +14,7 @@ namespace mmt {
 static int bit_width_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
 Engine::Engine(int device, hipStream_t stream) : device_(device), stream_(stream) {
+    lean_ = std::getenv("MUMEMTO_LEAN") != nullptr;      // tests: stage scratch is released between the stages
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
@@ -145,7 +146,7 @@ void Engine::lcp_bwt() {
     // suffix array"): no 4-byte random store per suffix anywhere.  The PFP emitter wrote SA and BWT and keeps no
     // inverse suffix array at all; only the suffix ranks of the anchor document are recorded here (multi-GPU
     // re-sort).  The direct producer has the full array from its sort.
-    const bool pfp = producer_used_ == 2 && pfp_.bwt_ready;
+    const bool pfp = producer_used_ == 2 && pfp_->bwt_ready;
     if (!pfp) k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
     const uint32_t anchor = (uint32_t)std::min<uint64_t>(doc_len_[0], n);
     if (pfp) d_rank_.ensure((size_t)anchor + 1);
@@ -169,6 +170,31 @@ void Engine::lcp_bwt() {
     }
     prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_b_.get(), n, stream_);
     k::lcp_gather(d_plcp_b_.get(), d_sa_.get(), n, d_lcp_.get(), stream_);
+}
+
+// One-shot / tight-memory runs: the suffix-sort stage (doubling scratch, dictionary, parse, emitter tables: two thirds
+// of all device bytes) is dead once SA and BWT exist.  Counters and stage times of the parse survive for the statistics.
+void Engine::release_sort_scratch() {
+    MMT_HIP(hipStreamSynchronize(stream_));
+    sorter_.release();
+    std::unique_ptr<PfpState> fresh(new PfpState());
+    const PfpState& S = *pfp_;
+    fresh->w = S.w; fresh->p = S.p; fresh->n_cuts = S.n_cuts; fresh->n_phrases = S.n_phrases; fresh->n_distinct = S.n_distinct;
+    fresh->dict_len = S.dict_len; fresh->n_groups = S.n_groups; fresh->rounds_dict = S.rounds_dict;
+    fresh->rounds_parse = S.rounds_parse; fresh->n_entries = S.n_entries; fresh->n_fallback = S.n_fallback;
+    fresh->bwt_ready = S.bwt_ready;
+    std::memcpy(fresh->ms, S.ms, sizeof(S.ms));
+    pfp_ = std::move(fresh);
+}
+
+// Called after the suffix sort: the LCP stage is about to allocate K, K' and the LCP column (12 bytes per text
+// character, plus the candidate list).  When the device does not have that much left, the sort stage's scratch goes.
+bool Engine::wants_lean() const {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    const size_t have = (d_plcp_a_.size() + d_plcp_b_.size() + d_lcp_.size()) * sizeof(uint32_t);
+    const double need = 13.0 * (double)n_ - (double)have;
+    return need > 0.95 * (double)free_b;
 }
 
 // ---- A5 ------------------------------------------------------------------------
@@ -460,7 +486,10 @@ void Engine::run(const mmt_params& p) {
         producer_used_ = kind;
     }
     ev_[1]->stop(stream_);
+    const bool lean = lean_ || wants_lean();
+    if (lean) release_sort_scratch();
     ev_[2]->start(stream_); lcp_bwt(); ev_[2]->stop(stream_);
+    if (lean && !k::scan_needs_wide_docs(doc_len_.size())) { d_plcp_a_.release(); d_plcp_b_.release(); d_long_.release(); }
     scan(p);
     make_rows(p);
     for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();

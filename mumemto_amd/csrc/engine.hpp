@@ -69,7 +69,13 @@ public:
     void parse_only(bool revcomp, uint32_t w, uint32_t p);
     void pfp_copy_dict(std::vector<uint8_t>& out);
     void pfp_copy_parse(std::vector<uint32_t>& out);
-    const PfpState& pfp_state() const { return pfp_; }
+    const PfpState& pfp_state() const { return *pfp_; }
+    // One-shot use (the command line; automatically when the buffers of all stages together would not fit the
+    // device): every stage gives its scratch back before the next one allocates, so that the footprint is the
+    // largest stage instead of the sum -- at the price of hipMalloc calls in every run.
+    void set_lean(bool on) { lean_ = on; }
+    void release_sort_scratch();
+    bool wants_lean() const;
 
     // Results of the last run.  rows_meta(): counts and mode only; rows(need): also the host copies asked for
     // (ROWS_ARRAYS = library arrays, ROWS_TEXT = PREFIX.mums / .mems bytes), downloaded from HBM on first use.
@@ -130,7 +136,8 @@ private:
     DevBuf<uint32_t> d_wide_;             // wide scan: BWT change marks and their running maximum
     DoublingSorter sorter_;
     int sort_rounds_ = 0;
-    PfpState pfp_;
+    std::unique_ptr<PfpState> pfp_{new PfpState()};
+    bool lean_ = false;                   // release each stage's scratch before the next stage allocates
     int producer_ = 0, producer_used_ = 1;
     uint32_t pfp_w_ = 10, pfp_p_ = 100;
     // scan

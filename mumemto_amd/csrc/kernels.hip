@@ -1177,6 +1177,7 @@ static uint32_t wide_threshold() {
     static const uint32_t t = getenv("MMT_SCAN_WIDE_AT") ? (uint32_t)atoi(getenv("MMT_SCAN_WIDE_AT")) : 1000u;
     return t;
 }
+bool scan_needs_wide_docs(size_t n_docs) { return n_docs > (size_t)wide_threshold() + 1; }
 bool scan_needs_wide(const ScanArgs& a) {
     const uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
     return nd - 1 > wide_threshold();

@@ -94,6 +94,7 @@ void scan_intervals(const ScanArgs& a, hipStream_t s);
 // fills pre / suf (n entries each) and chg (n entries, to be replaced by its inclusive running maximum) with
 // scan_wide_prepare and hands them over in ScanArgs.
 bool scan_needs_wide(const ScanArgs& a);
+bool scan_needs_wide_docs(size_t n_docs);      // could any scan of this collection need them (num_distinct <= documents)
 void scan_wide_prepare(const uint32_t* lcp, const uint8_t* bwt, uint32_t n, uint32_t num_distinct, uint32_t* pre,
                        uint32_t* suf, uint32_t* chg, hipStream_t s);
 

@@ -22,7 +22,7 @@ static uint32_t read_u32(const uint32_t* d, hipStream_t s) {
 // A2 + the dictionary half of A3: phrases, distinct phrases, dictionary text with its suffix
 // array / LCP, phrase ranks, parse.  Requires build_text() to have run.
 void Engine::pfp_parse(uint32_t w, uint32_t p) {
-    PfpState& S = pfp_;
+    PfpState& S = *pfp_;
     const uint32_t n = (uint32_t)n_;
     if (w < 1 || w > 32 || p < 1) throw std::runtime_error("PFP window must be in [1, 32] and the modulus positive");
     std::vector<uint32_t> hist;
@@ -137,7 +137,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
 // A3 (parse half) + A4: suffix array of the text = positions sorted by
 // (group of the phrase suffix, rank of the following parse suffix).
 void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
-    PfpState& S = pfp_;
+    PfpState& S = *pfp_;
     const uint32_t n = (uint32_t)n_;
     auto t0 = std::chrono::steady_clock::now();
     pfp_parse(w, p);
@@ -150,6 +150,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const int pchars = std::max(1, 64 / pbits);
     pk::pack_keys_u32(S.parse.get(), m, pbits, pchars, sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
+    if (lean_) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); }   // dictionary-sized doubling scratch: done
     e5.stop(st);
 
     e6.start(st);
@@ -240,7 +241,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
 
 // PREFIX.dict bytes: phrases in lexicographic order, 0x01 after each, final 0x00 (newscan.hpp:386-397)
 void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
-    PfpState& S = pfp_;
+    PfpState& S = *pfp_;
     if (!S.have_parse) throw std::runtime_error("no parse available");
     const uint32_t D = S.n_distinct, nd = S.dict_len;
     DevBuf<uint32_t> which, slen, sstart;
@@ -254,8 +255,8 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
 }
 
 void Engine::pfp_copy_parse(std::vector<uint32_t>& out) {
-    if (!pfp_.have_parse) throw std::runtime_error("no parse available");
-    d2h(out, pfp_.parse.get(), pfp_.n_phrases, stream_);
+    if (!pfp_->have_parse) throw std::runtime_error("no parse available");
+    d2h(out, pfp_->parse.get(), pfp_->n_phrases, stream_);
 }
 
 }  // namespace mmt

@@ -19,6 +19,13 @@ void DoublingSorter::reserve(uint32_t n) {
 
 // (keys_a_, sac_a_) -> (keys_b_, sac_b_), m active elements grouped by bucket: tiles between bucket boundaries are
 // sorted in LDS, the few ranges holding a bucket longer than a tile by one segmented radix sort.
+void DoublingSorter::release() {
+    keys_a_.release(); keys_b_.release(); flags_.release();
+    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &headval_, &head_, &idx_, &bound_, &big_begin_,
+                                &big_end_})
+        b->release();
+}
+
 void DoublingSorter::sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s) {
     static const bool global_sort = std::getenv("MMT_SORT_GLOBAL_ROUNDS") != nullptr;     // the old path (tests)
     if (global_sort || m < 4096) {

@@ -27,6 +27,8 @@ public:
     DevBuf<uint64_t>& keys_b() { return keys_b_; }
     DevBuf<uint32_t>& u32_a() { return sac_a_; }
     DevBuf<uint32_t>& u32_b() { return sac_b_; }
+    // give every scratch column back (one-shot runs: later stages then reuse the memory)
+    void release();
 
 private:
     void sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s);

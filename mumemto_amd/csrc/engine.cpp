@@ -150,7 +150,7 @@ void Engine::lcp_bwt() {
     if (!pfp) k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
     const uint32_t anchor = (uint32_t)std::min<uint64_t>(doc_len_[0], n);
     if (pfp) d_rank_.ensure((size_t)anchor + 1);
-    d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_count_.ensure(4);
+    d_plcp_a_.ensure(n); d_count_.ensure(4);
     uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 16, (size_t)n / 256 + 4096);
     if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -168,8 +168,8 @@ void Engine::lcp_bwt() {
         if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
         cap = found + 1024;                            // rare: rerun with the exact size
     }
-    prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_b_.get(), n, stream_);
-    k::lcp_gather(d_plcp_b_.get(), d_sa_.get(), n, d_lcp_.get(), stream_);
+    prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_a_.get(), n, stream_);      // K' over K, in place
+    k::lcp_gather(d_plcp_a_.get(), d_sa_.get(), n, d_lcp_.get(), stream_);
 }
 
 // One-shot / tight-memory runs: the suffix-sort stage (doubling scratch, dictionary, parse, emitter tables: two thirds
@@ -187,13 +187,13 @@ void Engine::release_sort_scratch() {
     pfp_ = std::move(fresh);
 }
 
-// Called after the suffix sort: the LCP stage is about to allocate K, K' and the LCP column (12 bytes per text
+// Called after the suffix sort: the LCP stage is about to allocate K and the LCP column (8 bytes per text
 // character, plus the candidate list).  When the device does not have that much left, the sort stage's scratch goes.
 bool Engine::wants_lean() const {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-    const size_t have = (d_plcp_a_.size() + d_plcp_b_.size() + d_lcp_.size()) * sizeof(uint32_t);
-    const double need = 13.0 * (double)n_ - (double)have;
+    const size_t have = (d_plcp_a_.size() + d_lcp_.size()) * sizeof(uint32_t);
+    const double need = 9.0 * (double)n_ - (double)have;
     return need > 0.95 * (double)free_b;
 }
 
@@ -229,10 +229,10 @@ void Engine::scan(const mmt_params& p) {
         MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 16, stream_));
         ev_[3]->start(stream_);
         if (attempt == 0 && k::scan_needs_wide(a)) {      // window tables in HBM (the LCP scratch is free by now)
-            d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_wide_.ensure((size_t)n * 2);
+            d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_wide_.ensure(n);
             k::scan_wide_prepare(a.lcp, a.bwt, n, a.num_distinct, d_plcp_a_.get(), d_plcp_b_.get(), d_wide_.get(), stream_);
-            prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get() + n, n, stream_);
-            a.wide_pre = d_plcp_a_.get(); a.wide_suf = d_plcp_b_.get(); a.wide_chg = d_wide_.get() + n;
+            prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get(), n, stream_);
+            a.wide_pre = d_plcp_a_.get(); a.wide_suf = d_plcp_b_.get(); a.wide_chg = d_wide_.get();
         }
         k::scan_intervals(a, stream_);
         ev_[3]->stop(stream_);

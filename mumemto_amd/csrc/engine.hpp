@@ -133,7 +133,7 @@ private:
     DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_;
     DevBuf<uint32_t> d_hist_, d_sa_, d_rank_, d_lcp_, d_count_, d_plcp_a_, d_plcp_b_;
     DevBuf<uint8_t> d_long_;
-    DevBuf<uint32_t> d_wide_;             // wide scan: BWT change marks and their running maximum
+    DevBuf<uint32_t> d_wide_;             // wide scan: BWT change marks, replaced by their running maximum
     DoublingSorter sorter_;
     int sort_rounds_ = 0;
     std::unique_ptr<PfpState> pfp_{new PfpState()};

@@ -57,9 +57,9 @@ __global__ __launch_bounds__(BLOCK) void k_block_max(const uint32_t* __restrict_
     }
 }
 template <int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void k_block_max_scan(const uint32_t* __restrict__ in, size_t n,
+__global__ __launch_bounds__(BLOCK) void k_block_max_scan(const uint32_t* in, size_t n,
                                                           const uint32_t* __restrict__ carry /* exclusive */,
-                                                          uint32_t* __restrict__ out) {
+                                                          uint32_t* out /* may be `in`: every thread reads i, then writes i */) {
     __shared__ uint32_t s_w[BLOCK / 64];
     const size_t base = (size_t)blockIdx.x * BLOCK * ITEMS;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -1363,13 +1363,80 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
     }
 }
 
+// The same for at most 32 documents with at most one occurrence each: an interval then has at most SUB entries, so a wave
+// takes 64 / SUB candidates at a time, one per group of SUB lanes (document bitmap and first anchor entry by shuffles of
+// width SUB).  The merge-metadata runs of the multi-GPU path verify every structural interval, ten times the
+// candidates of a plain run.
+template <int WAVES, int SUB>
+__global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgs a) {
+    constexpr int PER = 64 / SUB;
+    __shared__ Cand s_rows[WAVES][64];       // accepted rows of this wave
+    Cand* my_rows = s_rows[threadIdx.x >> 6];
+    uint32_t n_my = 0;                        // wave-uniform
+    const uint32_t lane = threadIdx.x & 63, sl = lane % SUB, grp = lane / SUB;
+    const uint64_t wave = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES;
+    auto flush = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.d_row_count, n_my);
+        base = __shfl(base, 0, 64);
+        if (lane < n_my) a.rows[base + lane] = my_rows[lane];
+        n_my = 0;
+    };
+    for (uint64_t c0 = wave * PER; c0 < a.n_cand; c0 += n_waves * PER) {
+        const uint64_t ci = c0 + grp;
+        const bool live = ci < a.n_cand;
+        Cand c{};
+        if (live) c = a.cand[ci];
+        const uint32_t cnt = live ? c.end - c.start + 1 : 0u;
+        uint32_t bits = 0, first0 = 0xffffffffu;
+        if (sl < cnt) {
+            const uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[c.start + sl]);
+            bits = 1u << d;
+            if (d == 0) first0 = c.start + sl;
+        }
+#pragma unroll
+        for (int o = SUB / 2; o >= 1; o >>= 1) {
+            bits |= __shfl_xor(bits, o, SUB);
+            const uint32_t f = __shfl_xor(first0, o, SUB);
+            first0 = f < first0 ? f : first0;
+        }
+        // an interval longer than SUB cannot hold distinct documents only: its count exceeds the bitmap
+        const bool ok = live && (uint32_t)__popc(bits) == cnt && cnt >= a.num_distinct;
+        if (a.merge && ok && sl == 0 && first0 != 0xffffffffu) {
+            const uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
+            uint32_t nb = before > after ? before : after;
+            if (nb > 65535u) nb = 65535u;
+            a.thresh[(uint64_t)a.sa[first0] - a.d_doc_start[0]] = (uint16_t)nb;
+        }
+        const bool take = ok && sl == 0 && (c.flags & CAND_LEFT_MAXIMAL);
+        const uint64_t m = __ballot(take);
+        if (m) {
+            const uint32_t k = (uint32_t)__popcll(m);
+            if (n_my + k > 64) flush();
+            if (take) my_rows[n_my + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = c;
+            n_my += k;
+        }
+    }
+    if (n_my) flush();
+}
+
 void verify_candidates(const VerifyArgs& a, hipStream_t s) {
     if (a.n_cand == 0) return;
     // every candidate interval has <= cap entries; the single-wave bitmap path needs
     // MUM mode, <= 64 documents (then an accepted interval has <= 64 entries)
     bool fast = a.max_doc_freq == 1 && a.n_docs <= 64;
     uint64_t waves_needed = a.n_cand;
-    if (fast) {
+    static const bool packed_off = getenv("MMT_VERIFY_UNPACKED") != nullptr;      // tests: the wave-per-candidate kernel
+    if (fast && a.n_docs <= 32 && !packed_off) {
+        constexpr int W = 4;
+        const int sub = a.n_docs <= 8 ? 8 : (a.n_docs <= 16 ? 16 : 32);
+        waves_needed = (a.n_cand + (uint64_t)(64 / sub) - 1) / (uint64_t)(64 / sub);
+        unsigned grid = (unsigned)std::min<uint64_t>((waves_needed + W - 1) / W, 256u * 16u);
+        if (sub == 8) hipLaunchKernelGGL((k_verify_packed<W, 8>), dim3(grid), dim3(W * 64), 0, s, a);
+        else if (sub == 16) hipLaunchKernelGGL((k_verify_packed<W, 16>), dim3(grid), dim3(W * 64), 0, s, a);
+        else hipLaunchKernelGGL((k_verify_packed<W, 32>), dim3(grid), dim3(W * 64), 0, s, a);
+    } else if (fast) {
         // intervals longer than 64 cannot be all-distinct with <= 64 docs, but the fast path
         // reads only 64 entries; they are rejected by the popcount == cnt test because cnt > 64
         constexpr int W = 4;

@@ -23,88 +23,70 @@
  *   accessors tolerate NULL handles and out-of-range indices. (:587-642)
  *   Matches come out in suffix-array (lexicographic) order of the match.
  */
-#ifndef MUMEMTO_H
+#ifndef MUMEMTO_H            /* the reference header's guard on purpose: the two headers declare the same ABI */
 #define MUMEMTO_H
 
 #include <stddef.h>
 #include <stdint.h>
 
 #if defined(__GNUC__) || defined(__clang__)
-#define MUMEMTO_C_API __attribute__((visibility("default")))
+#define MUMEMTO_EXPORT __attribute__((visibility("default")))
 #else
-#define MUMEMTO_C_API
+#define MUMEMTO_EXPORT
 #endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-/* One document = the records of one FASTA file, NUL-terminated, borrowed for
- * the duration of the call.                      (reference mumemto.h:33-36) */
-typedef struct mumemto_doc_view {
-    const char* const* records;
-    size_t num_records;
-} mumemto_doc_view;
+/* ---- inputs ------------------------------------------------------------------------------------------------- */
+/* One document = the records of one FASTA file; NUL-terminated strings borrowed for the call (reference :33-36). */
+typedef struct mumemto_doc_view { const char* const* records; size_t num_records; } mumemto_doc_view;
 
-typedef struct mumemto_mum_result mumemto_mum_result;   /* (:38) */
-typedef struct mumemto_mem_result mumemto_mem_result;   /* (:39) */
+/* ---- result handles and row views ----------------------------------------------------------------------------- */
+typedef struct mumemto_mum_result mumemto_mum_result;        /* opaque, owned by the caller until mum_free (:38) */
+typedef struct mumemto_mem_result mumemto_mem_result;        /* opaque, owned by the caller until mem_free (:39) */
 
-typedef struct mumemto_mum_match_view {                  /* (:41-45) */
+typedef struct mumemto_mum_match_view {                       /* one multi-MUM row (:41-45)                       */
     uint32_t length;
-    const int64_t* offsets; /* num_docs entries, -1 = document absent */
-    const uint8_t* strands; /* 1 => '+', 0 => '-' (absent documents: 0) */
+    const int64_t* offsets;      /* num_docs entries, -1 = document absent           */
+    const uint8_t* strands;      /* 1 = '+', 0 = '-' (0 for absent documents)        */
 } mumemto_mum_match_view;
 
-typedef struct mumemto_mem_match_view {                  /* (:47-53) */
+typedef struct mumemto_mem_match_view {                       /* one multi-MEM row (:47-53)                       */
     uint32_t length;
-    size_t occurrences;
+    size_t occurrences;          /* entries of the three arrays below                */
     const int64_t* offsets;
     const size_t* seq_ids;
     const uint8_t* strands;
 } mumemto_mem_match_view;
 
-/* Thread-local message of the last non-zero return.             (:56) */
-MUMEMTO_C_API const char* mumemto_last_error(void);
+/* ---- searches ------------------------------------------------------------------------------------------------- */
+/* multi-MUMs, at most one occurrence per document (:59-66) */
+MUMEMTO_EXPORT int mumemto_mum(const mumemto_doc_view* docs, size_t num_docs, uint32_t min_match_len, uint8_t use_revcomp,
+                               size_t num_distinct, uint8_t use_gsacak, mumemto_mum_result** out_result);
+/* multi-MEMs (:69-78) */
+MUMEMTO_EXPORT int mumemto_mem(const mumemto_doc_view* docs, size_t num_docs, uint32_t min_match_len, uint8_t use_revcomp,
+                               size_t num_distinct, size_t max_total_freq, size_t max_doc_freq, uint8_t use_gsacak,
+                               mumemto_mem_result** out_result);
+/* thread-local message of the last non-zero return code (:56) */
+MUMEMTO_EXPORT const char* mumemto_last_error(void);
 
-/* Multi-MUM search (<= 1 occurrence per document).           (:59-66) */
-MUMEMTO_C_API int mumemto_mum(
-    const mumemto_doc_view* docs,
-    size_t num_docs,
-    uint32_t min_match_len,
-    uint8_t use_revcomp,
-    size_t num_distinct,
-    uint8_t use_gsacak,
-    mumemto_mum_result** out_result);
-
-/* Multi-MEM search.                                           (:69-78) */
-MUMEMTO_C_API int mumemto_mem(
-    const mumemto_doc_view* docs,
-    size_t num_docs,
-    uint32_t min_match_len,
-    uint8_t use_revcomp,
-    size_t num_distinct,
-    size_t max_total_freq,
-    size_t max_doc_freq,
-    uint8_t use_gsacak,
-    mumemto_mem_result** out_result);
-
-/* MUM result accessors                                        (:81-86) */
-MUMEMTO_C_API size_t num_docs(const mumemto_mum_result* r);
-MUMEMTO_C_API const size_t* doc_record_offsets(const mumemto_mum_result* r); /* num_docs(r)+1 */
-MUMEMTO_C_API const size_t* record_lengths(const mumemto_mum_result* r);
-MUMEMTO_C_API size_t num_mums(const mumemto_mum_result* r);
-MUMEMTO_C_API mumemto_mum_match_view mum_at(const mumemto_mum_result* r, size_t idx);
-MUMEMTO_C_API void mum_free(mumemto_mum_result* r);
-
-/* MEM result accessors                                        (:89-94) */
-MUMEMTO_C_API size_t num_docs_mem(const mumemto_mem_result* r);
-MUMEMTO_C_API const size_t* doc_record_offsets_mem(const mumemto_mem_result* r);
-MUMEMTO_C_API const size_t* record_lengths_mem(const mumemto_mem_result* r);
-MUMEMTO_C_API size_t num_mems(const mumemto_mem_result* r);
-MUMEMTO_C_API mumemto_mem_match_view mem_at(const mumemto_mem_result* r, size_t idx);
-MUMEMTO_C_API void mem_free(mumemto_mem_result* r);
+/* ---- accessors, MUM and MEM side by side (:81-86, :89-94) ------------------------------------------------------- */
+MUMEMTO_EXPORT size_t num_docs(const mumemto_mum_result* r);
+MUMEMTO_EXPORT size_t num_docs_mem(const mumemto_mem_result* r);
+MUMEMTO_EXPORT const size_t* doc_record_offsets(const mumemto_mum_result* r);          /* num_docs(r) + 1 entries */
+MUMEMTO_EXPORT const size_t* doc_record_offsets_mem(const mumemto_mem_result* r);
+MUMEMTO_EXPORT const size_t* record_lengths(const mumemto_mum_result* r);              /* one per record          */
+MUMEMTO_EXPORT const size_t* record_lengths_mem(const mumemto_mem_result* r);
+MUMEMTO_EXPORT size_t num_mums(const mumemto_mum_result* r);
+MUMEMTO_EXPORT size_t num_mems(const mumemto_mem_result* r);
+MUMEMTO_EXPORT mumemto_mum_match_view mum_at(const mumemto_mum_result* r, size_t idx);  /* idx out of range: zeros  */
+MUMEMTO_EXPORT mumemto_mem_match_view mem_at(const mumemto_mem_result* r, size_t idx);
+MUMEMTO_EXPORT void mum_free(mumemto_mum_result* r);
+MUMEMTO_EXPORT void mem_free(mumemto_mem_result* r);
 
 #ifdef __cplusplus
-}
+}  /* extern "C" */
 #endif
 #endif /* MUMEMTO_H */

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"(?:MUMEMTO_C_API|MMT_API)[^;(]*?\b(\w+)\s*\(", src)
+    names = re.findall(r"(?:MUMEMTO_EXPORT|MMT_API)[^;(]*?\b(\w+)\s*\(", src)
     return sorted(set(n for n in names if n != "__attribute__"))
 
 

@@ -158,7 +158,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const uint32_t nd = S.dict_len;
     d_sa_.ensure(n); d_bwt_.ensure((size_t)n + 16);     // no inverse suffix array on this path (see Engine::lcp_bwt)
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
-    S.occ_start.ensure((size_t)D + 2); S.occ_pos.ensure(m); S.occ_key.ensure(m);
+    S.occ_start.ensure((size_t)D + 2); S.occ_pos.ensure((size_t)m * 2);       // (t, position) records
     S.occ_ids.ensure((size_t)m + 1); S.occ_ts.ensure((size_t)m + 1);
     {
         sorter_.u32_a().ensure((size_t)m + 1); sorter_.u32_b().ensure((size_t)m + 1);     // scratch
@@ -168,7 +168,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         prims::sort_pairs_u32_u32(d_temp_, k_in, S.occ_ids.get(), v_in, S.occ_ts.get(), (size_t)m + 1, 0,
                                   std::max(1, bit_width_u64((uint64_t)D)), st);
         pk::occ_finish(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), m, S.occ_start.get(),
-                       S.occ_pos.get(), S.occ_key.get(), st);
+                       S.occ_pos.get(), st);
     }
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
     S.vscan.ensure(nd); S.ptab.ensure((size_t)D * 16 + 16);
@@ -218,7 +218,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
-    ea.occ_pos = S.occ_pos.get(); ea.occ_key = S.occ_key.get();
+    ea.occ = reinterpret_cast<const uint2*>(S.occ_pos.get());
     ea.n = n; ea.sa = d_sa_.get(); ea.bwt = d_bwt_.get();
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();

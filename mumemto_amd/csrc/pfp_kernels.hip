@@ -485,11 +485,11 @@ void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_
     MMT_HIP(hipGetLastError());
 }
 // after the sort: k-th occurrence overall = (phrase ids[k], t = ts[k]); occ_start[d] = first k of phrase d
-// (occ_start[D] = m: the dummy sorts last); occ_pos = start of that phrase occurrence in the text, occ_key = t
+// (occ_start[D] = m: the dummy sorts last); occ[k] = (t, start of that phrase occurrence in the text) -- one 8-byte
+// record, because the emitter reads the short list of a phrase at a random place and pays per 64-byte line
 __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ ts,
                              const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ pstart, uint32_t m,
-                             uint32_t* __restrict__ occ_start, uint32_t* __restrict__ occ_pos,
-                             uint32_t* __restrict__ occ_key) {
+                             uint32_t* __restrict__ occ_start, uint2* __restrict__ occ) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > m) return;
     const uint32_t id = ids[k];
@@ -497,13 +497,12 @@ __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* _
     if (k == m) return;                                    // the dummy
     const uint32_t t = ts[k];
     const uint32_t q = t ? sa_p[t - 1] - 1 : m - 1;
-    occ_pos[k] = pstart[q];
-    occ_key[k] = t;
+    occ[k] = make_uint2(t, pstart[q]);
 }
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const uint32_t* pstart, uint32_t m,
-                uint32_t* occ_start, uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s) {
+                uint32_t* occ_start, void* occ, hipStream_t s) {
     hipLaunchKernelGGL(k_occ_finish, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p, pstart, m,
-                       occ_start, occ_pos, occ_key);
+                       occ_start, static_cast<uint2*>(occ));
     MMT_HIP(hipGetLastError());
 }
 
@@ -653,8 +652,9 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
         const uint32_t i = tid + q * BLOCK;
         if (i < L) {
             const uint32_t e = sh.owner[i], k = i - sh.estart[e];
-            const uint32_t key = a.occ_key[sh.efirst[e] + k];
-            my_pos[q] = a.occ_pos[sh.efirst[e] + k] + sh.eoffm1[e];
+            const uint2 kp = a.occ[sh.efirst[e] + k];
+            const uint32_t key = kp.x;
+            my_pos[q] = kp.y + sh.eoffm1[e];
             if (sorted) sh.key[i] = key;
             else { a.fb_keys[clo - fb_shift + i] = key; a.fb_vals[clo - fb_shift + i] = my_pos[q]; }
         }
@@ -754,8 +754,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __re
             if (c > CAP / 2) {                               // one frequent phrase: plain strided copy
                 const uint32_t first = a.ce_first[e], om1 = a.ce_offm1[e];
                 for (uint32_t k = tid; k < c; k += BLOCK) {
-                    a.fb_keys[base - fb_shift + k] = a.occ_key[first + k];
-                    a.fb_vals[base - fb_shift + k] = a.occ_pos[first + k] + om1;
+                    const uint2 kp = a.occ[first + k];
+                    a.fb_keys[base - fb_shift + k] = kp.x;
+                    a.fb_vals[base - fb_shift + k] = kp.y + om1;
                 }
                 e++;
                 continue;

@@ -36,11 +36,11 @@ void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* ps
 void phrase_table(const uint32_t* occ_start /* n_distinct + 1 */, const uint32_t* plen, const uint32_t* rep,
                   uint32_t n_distinct, void* tab, hipStream_t s);
 // inverted lists from the parse suffix array (see pfp_kernels.hip): m + 1 (id, t) pairs to be stably sorted by id,
-// then occ_start (n_distinct + 1 entries), occ_pos and occ_key (m entries each)
+// then occ_start (n_distinct + 1 entries) and occ (m records of 8 bytes: t, text position of the occurrence)
 void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_t D, uint32_t* keys, uint32_t* vals,
                   hipStream_t s);
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const uint32_t* pstart, uint32_t m,
-                uint32_t* occ_start, uint32_t* occ_pos, uint32_t* occ_key, hipStream_t s);
+                uint32_t* occ_start, void* occ, hipStream_t s);
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
                    const uint32_t* vflag, const uint32_t* vscan, const void* tab, uint32_t nd, uint32_t* ce_cnt,
                    uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
@@ -57,7 +57,7 @@ struct EmitArgs {
     uint32_t n_groups;
     const uint32_t* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
-    const uint32_t* occ_pos; const uint32_t* occ_key;
+    const uint2* occ;           // per phrase occurrence (t, text position), grouped by phrase
     uint32_t n;                 // text length; output stream has n + 1 entries, entry 0 = end sentinel
     uint32_t* sa; uint8_t* bwt;                   // n entries each (the sentinel entry is not stored)
     // oversized groups (more than EMIT_CAP suffixes): ids ascending, compact offsets (n_fb + 1 entries)

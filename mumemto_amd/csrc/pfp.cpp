@@ -222,13 +222,39 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.n = n; ea.sa = d_sa_.get(); ea.bwt = d_bwt_.get();
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
+    // the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at
+    // most 16 different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)
+    pk::BwtDecode decode{};
+    uint32_t fb_bits = 0;
+    if (F && !std::getenv("MMT_PFP_NO_BWT_CODE")) {
+        std::vector<uint32_t> hist;
+        d2h(hist, d_hist_.get(), 256, st);
+        std::vector<uint8_t> code(256, 0);
+        uint32_t kinds = 0;
+        bool fits = true;
+        for (int b = 0; b < 256; b++)
+            if (b == 0 || hist[b]) {                              // 0 stands before the first text position
+                if (kinds == 16) { fits = false; break; }
+                decode.byte[kinds] = (uint8_t)b; code[b] = (uint8_t)kinds++;
+            }
+        uint32_t bits = 1;
+        while ((1u << bits) < kinds) bits++;
+        if (fits && shift + (int)bits <= 32) {
+            fb_bits = bits;
+            S.bwt_code.ensure(256);
+            MMT_HIP(hipMemcpyAsync(S.bwt_code.get(), code.data(), 256, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipStreamSynchronize(st));
+        }
+    }
+    ea.bwt_code = S.bwt_code.get(); ea.fb_bits = fb_bits;
     S.tile_first.ensure(((size_t)n + 1) / pk::EMIT_TILE + 4);
     pk::emit(ea, n + 1, S.tile_first.get(), st);
     if (F) {      // one segmented radix sort over just the oversized groups
         S.xk_b.ensure((size_t)fb_total + 1); S.xv_b.ensure((size_t)fb_total + 1);
         prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(),
-                                               fb_total, F, S.fb_off.get(), S.fb_off.get() + 1, shift, st);
-        pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), F, S.segb.get(), S.xv_b.get(), d_text_.get(), n,
+                                               fb_total, F, S.fb_off.get(), S.fb_off.get() + 1, shift + (int)fb_bits, st);
+        pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), F, S.segb.get(), S.xk_b.get(), S.xv_b.get(), fb_bits, decode,
+                            d_text_.get(), n,
                             d_sa_.get(), d_bwt_.get(), S.err.get(), st);
     }
     if (read_u32(S.err.get(), st)) throw std::runtime_error("PFP order: the end sentinel is not first");

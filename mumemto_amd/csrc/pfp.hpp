@@ -22,7 +22,7 @@ struct PfpState {
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
     DevBuf<uint32_t> occ_start, occ_ids, occ_ts, occ_pos /* (t, position) records */, vflag, vscan;
     DevBuf<uint32_t> ce_cnt, ce_eoff, ce_first, ce_offm1, ce_gs, segb, sege, xk_a, xk_b, xv_a, xv_b, fb_group, fb_size, fb_off, tile_first;
-    DevBuf<uint8_t> ce_bwt;
+    DevBuf<uint8_t> ce_bwt, bwt_code;
     uint32_t n_entries = 0, n_fallback = 0;
     bool bwt_ready = false;
 };

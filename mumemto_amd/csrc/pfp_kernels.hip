@@ -656,7 +656,10 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
             const uint32_t key = kp.x;
             my_pos[q] = kp.y + sh.eoffm1[e];
             if (sorted) sh.key[i] = key;
-            else { a.fb_keys[clo - fb_shift + i] = key; a.fb_vals[clo - fb_shift + i] = my_pos[q]; }
+            else {
+                a.fb_keys[clo - fb_shift + i] = a.fb_bits ? (key << a.fb_bits) | a.bwt_code[sh.ebwt[e]] : key;
+                a.fb_vals[clo - fb_shift + i] = my_pos[q];
+            }
         }
     }
     if (!sorted) return;
@@ -753,9 +756,10 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __re
             const uint32_t base = a.ce_eoff[e], c = a.ce_cnt[e];
             if (c > CAP / 2) {                               // one frequent phrase: plain strided copy
                 const uint32_t first = a.ce_first[e], om1 = a.ce_offm1[e];
+                const uint32_t low = a.fb_bits ? a.bwt_code[a.ce_bwt[e]] : 0u;
                 for (uint32_t k = tid; k < c; k += BLOCK) {
                     const uint2 kp = a.occ[first + k];
-                    a.fb_keys[base - fb_shift + k] = kp.x;
+                    a.fb_keys[base - fb_shift + k] = (kp.x << a.fb_bits) | low;
                     a.fb_vals[base - fb_shift + k] = kp.y + om1;
                 }
                 e++;
@@ -806,25 +810,27 @@ void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStrea
 // oversized groups after their segmented sort: sa / rank / bwt from the sorted values
 __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const uint32_t* __restrict__ fb_off,
                                   uint32_t n_fb, const uint32_t* __restrict__ segb,
-                                  const uint32_t* __restrict__ sorted_vals, const uint8_t* __restrict__ text,
-                                  uint32_t n, uint32_t* __restrict__ sa, uint8_t* __restrict__ bwt,
-                                  uint32_t* __restrict__ err) {
+                                  const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_vals,
+                                  uint32_t fb_bits, BwtDecode decode, const uint8_t* __restrict__ text, uint32_t n,
+                                  uint32_t* __restrict__ sa, uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
     const uint32_t f = blockIdx.x;
     if (f >= n_fb) return;
     const uint32_t lo = fb_off[f], hi = fb_off[f + 1], out0 = segb[fb_group[f]];
+    const uint32_t mask = (1u << fb_bits) - 1u;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const uint32_t p = sorted_vals[i], out = out0 + (i - lo);
         if (out == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
         sa[out - 1] = p;
-        bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;
+        if (fb_bits) bwt[out - 1] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
+        else bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;
     }
 }
 void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
-                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt,
-                     uint32_t* err, hipStream_t s) {
+                     const uint32_t* sorted_keys, const uint32_t* sorted_vals, uint32_t fb_bits, const BwtDecode& decode,
+                     const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt, uint32_t* err, hipStream_t s) {
     if (!n_fb) return;
-    hipLaunchKernelGGL(k_fallback_finish, dim3(n_fb), dim3(256), 0, s, fb_group, fb_off, n_fb, segb, sorted_vals, text,
-                       n, sa, bwt, err);
+    hipLaunchKernelGGL(k_fallback_finish, dim3(n_fb), dim3(256), 0, s, fb_group, fb_off, n_fb, segb, sorted_keys,
+                       sorted_vals, fb_bits, decode, text, n, sa, bwt, err);
     MMT_HIP(hipGetLastError());
 }
 

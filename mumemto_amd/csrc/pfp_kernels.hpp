@@ -63,14 +63,18 @@ struct EmitArgs {
     // oversized groups (more than EMIT_CAP suffixes): ids ascending, compact offsets (n_fb + 1 entries)
     const uint32_t* fb_group; const uint32_t* fb_off; uint32_t n_fb;
     uint32_t* fb_keys; uint32_t* fb_vals;     // compact fallback arrays, fb_off[n_fb] entries
+    // fb_bits > 0: a fallback key is (t << fb_bits) | bwt_code[byte before the suffix] -- the sort order is that of t
+    // (distinct within a group) and fallback_finish gets the BWT byte back without a random read of the text
+    const uint8_t* bwt_code; uint32_t fb_bits;
     uint32_t* err;                            // consistency errors
 };
+struct BwtDecode { uint8_t byte[16]; };       // code -> byte
 // tile_first_buf: scratch of n_out / EMIT_TILE + 2 entries
 void emit(const EmitArgs& a, uint32_t n_out, uint32_t* tile_first_buf, hipStream_t s);
 void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStream_t s);
 void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
-                     const uint32_t* sorted_vals, const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt,
-                     uint32_t* err, hipStream_t s);
+                     const uint32_t* sorted_keys, const uint32_t* sorted_vals, uint32_t fb_bits, const BwtDecode& decode,
+                     const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt, uint32_t* err, hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);
 

@@ -289,11 +289,12 @@ def test_two_fingerprint_phrase_grouping_path():
     assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("env", [{"MMT_PFP_NO_PACK": "1"}, {"MMT_LONG_CAP": "3"}, {}])
+@pytest.mark.parametrize("env", [{"MMT_PFP_NO_PACK": "1"}, {"MMT_LONG_CAP": "3"}, {"MMT_PFP_NO_BWT_CODE": "1"}, {}])
 def test_long_matches_and_rare_construction_paths(env):
     """Exact document copies and a long tandem repeat give irreducible LCP values far beyond the 192 characters one lane
     compares (k_long_lcp, and k_huge_lcp beyond 64 KB); MMT_LONG_CAP forces the overflow-and-rerun of the long-match list, MMT_PFP_NO_PACK the
-    dictionary records without the packed previous byte (>= 2^24 distinct phrases in production)."""
+    dictionary records without the packed previous byte (>= 2^24 distinct phrases in production), MMT_PFP_NO_BWT_CODE the
+    oversized emitter groups whose BWT byte is read from the text instead of riding in the sort key (> 16 kinds of bytes)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))

@@ -182,10 +182,10 @@ def main():
     }
     # HBM traffic of the scan kernel from the PMC passes of profiles/ (separate rocprofv3 runs of this very
     # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for this workload only
-    pmc_file = os.path.join(ROOT, "profiles", "round1_i_scan_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "round1_l_scan_pmc.json")
     if world == 1 and os.path.exists(pmc_file) and (a.haps, a.length, a.divergence, a.seed) == (16, 12_100_000, 0.005, 2):
         result["roofline"]["traffic"] = json.load(open(pmc_file))["hbm_bytes_per_launch"]
-        result["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/round1_i_scan_pmc.json)"
+        result["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/round1_l_scan_pmc.json)"
     result["config"]["stream_producer"] = eng.producer_used()
     if eng.producer_used() == "pfp":
         result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(

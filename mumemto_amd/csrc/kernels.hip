@@ -1466,17 +1466,23 @@ void verify_candidates(const VerifyArgs& a, hipStream_t s) {
 //     The reference walks i = 0..L_0 keeping "the last MUM that started at or
 //     before i" per side; that is row (#starts in [0,i]) - 1, a prefix count.
 // ============================================================================
-__global__ void k_mark_starts(const uint64_t* __restrict__ starts, uint32_t n_rows, uint8_t* __restrict__ bv,
-                              uint32_t* __restrict__ ones) {
+__global__ void k_mark_starts(const uint64_t* __restrict__ starts, uint32_t n_rows, uint8_t* __restrict__ bv) {
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     bv[starts[r]] = 1;
-    ones[starts[r]] = 1;
 }
-void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, uint32_t* ones, hipStream_t s) {
+void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, hipStream_t s) {
     if (!n_rows) return;
-    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, starts, n_rows, bv, ones);
+    hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, starts, n_rows, bv);
     MMT_HIP(hipGetLastError());
+}
+
+// number of rows that start at or before anchor position i (starts ascending, one row per position): asked only at
+// the few positions where a row starts, so a binary search replaces a prefix-count column over the whole anchor
+__device__ __forceinline__ uint32_t rows_started(const uint64_t* __restrict__ starts, uint32_t n_rows, uint64_t i) {
+    uint32_t lo = 0, hi = n_rows;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= i) lo = mid + 1; else hi = mid; }
+    return lo;
 }
 
 __global__ void k_fold_step(FoldArgs a) {
@@ -1488,8 +1494,8 @@ __global__ void k_fold_step(FoldArgs a) {
     a.nb_out[i] = nbo;
     const bool sa_ = a.bv_a[i] != 0, sb_ = a.bv_b[i] != 0;
     if (!(sa_ || sb_) || !both) return;                                    // :132
-    // exclusive counts + own flag = number of starts in [0, i]
-    const uint32_t ca = a.rank_a[i] + (sa_ ? 1u : 0u), cb = a.rank_b[i] + (sb_ ? 1u : 0u);
+    // number of starts in [0, i] per side
+    const uint32_t ca = rows_started(a.start_a, a.n_a, i), cb = rows_started(a.start_b, a.n_b, i);
     if (ca == 0 || cb == 0) return;                                        // cur_mum1 && cur_mum2
     const uint32_t ra = ca - 1, rb = cb - 1;
     const uint64_t d1 = i - a.start_a[ra], d2 = i - a.start_b[rb];

@@ -120,7 +120,7 @@ void verify_candidates(const VerifyArgs& a, hipStream_t s);
 struct FoldArgs {
     uint64_t len;                       // L_0 + 1
     const uint16_t* nb_a; const uint16_t* nb_b; uint16_t* nb_out;
-    const uint32_t* rank_a; const uint32_t* rank_b;   // #MUM starts in [0,i] per side (inclusive)
+    uint32_t n_a, n_b;                                // rows per side (start_* ascending)
     const uint64_t* start_a; const uint64_t* start_b; // offsets[0] of row r (sorted)
     const uint32_t* len_a; const uint32_t* len_b;     // length of row r
     const uint8_t* bv_a; const uint8_t* bv_b;         // MUM start flags per position
@@ -129,7 +129,7 @@ struct FoldArgs {
     uint32_t min_len;                   // 20 in the reference (merge_candidates.cpp:141)
 };
 void fold_step(const FoldArgs& a, hipStream_t s);
-void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, uint32_t* ones, hipStream_t s);
+void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, hipStream_t s);
 
 // out[i] = src[idx[i]]
 void gather_u32_idx32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s);

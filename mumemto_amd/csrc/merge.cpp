@@ -37,16 +37,13 @@ struct SideBuf {
     }
 };
 
-// start flags and their prefix counts over the anchor (what k_fold_step walks)
+// start flags over the anchor (what k_fold_step walks; the row of a position comes from a search in the starts)
 struct SideIndex {
-    DevBuf<uint32_t> ones, rank;
     DevBuf<uint8_t> bv;
-    void build(const SideBuf& s, uint64_t L, DevBuf<uint8_t>& temp, hipStream_t st) {
-        bv.ensure(L); ones.ensure(L); rank.ensure(L);
+    void build(const SideBuf& s, uint64_t L, hipStream_t st) {
+        bv.ensure(L);
         MMT_HIP(hipMemsetAsync(bv.get(), 0, L, st));
-        MMT_HIP(hipMemsetAsync(ones.get(), 0, L * 4, st));
-        k::mark_starts(s.start.get(), s.n, bv.get(), ones.get(), st);
-        prims::exclusive_sum_u32(temp, ones.get(), rank.get(), L, st);
+        k::mark_starts(s.start.get(), s.n, bv.get(), st);
     }
 };
 
@@ -151,14 +148,14 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
         make_leaf(pi, M.right);
         load_thresh(parts[pi], M.nb_right);
         M.nb_out.ensure(L);
-        M.ia.build(M.left, L, temp, st);
-        M.ib.build(M.right, L, temp, st);
+        M.ia.build(M.left, L, st);
+        M.ib.build(M.right, L, st);
         const size_t capacity = (size_t)M.left.n + M.right.n + 1;
         M.d_pos.ensure(capacity); M.d_ra.ensure(capacity); M.d_rb.ensure(capacity); M.d_len.ensure(capacity);
         MMT_HIP(hipMemsetAsync(M.d_count.get(), 0, 4, st));
         k::FoldArgs a;
         a.len = L; a.nb_a = M.nb_left.get(); a.nb_b = M.nb_right.get(); a.nb_out = M.nb_out.get();
-        a.rank_a = M.ia.rank.get(); a.rank_b = M.ib.rank.get();
+        a.n_a = (uint32_t)M.left.n; a.n_b = (uint32_t)M.right.n;
         a.start_a = M.left.start.get(); a.start_b = M.right.start.get();
         a.len_a = M.left.len.get(); a.len_b = M.right.len.get();
         a.bv_a = M.ia.bv.get(); a.bv_b = M.ib.bv.get();

@@ -51,10 +51,16 @@ __device__ __forceinline__ uint32_t doc_lookup(const uint64_t* __restrict__ star
 // complement of upper-case in reverse order) and one 16-byte store; the others go byte by byte.
 // Alphabet histogram: A C G T N $ are counted in packed registers and reduced across the wave,
 // anything else (rare) goes to the LDS histogram directly.
-__device__ __forceinline__ uint64_t load_u64_raw(const uint8_t* p) {
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
+// 16 bytes from any address as two words, built from aligned 8-byte loads (a wave-wide load at a misaligned address
+// is served lane by lane on this part).  Only words that hold at least one of the 16 bytes are touched.
+__device__ __forceinline__ void load_16_bytes(const uint8_t* p, uint64_t& x, uint64_t& y) {
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)7);
+    const uint32_t s = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 7u) * 8u;
+    const uint64_t w0 = w[0], w1 = w[1];
+    if (s == 0) { x = w0; y = w1; return; }
+    const uint64_t w2 = w[2];
+    x = (w0 >> s) | (w1 << (64 - s));
+    y = (w1 >> s) | (w2 << (64 - s));
 }
 template <int BLOCK, int MAXD>
 __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict__ raw,
@@ -85,13 +91,15 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
         const uint64_t L = bs[d + 1] - bs[d], local = p0 - st[d];
         if (local + 16 <= L) {                                              // forward strand
             const uint8_t* src = raw + bs[d] + local;
-            const uint64_t x = load_u64_raw(src), y = load_u64_raw(src + 8);
+            uint64_t x, y;
+            load_16_bytes(src, x, y);
 #pragma unroll
             for (int b = 0; b < 8; b++) { out[b] = s_up[(x >> (8 * b)) & 0xff]; out[8 + b] = s_up[(y >> (8 * b)) & 0xff]; }
             valid = 0xffffu;
         } else if (local > L && local + 15 <= 2 * L) {                      // reverse strand
             const uint8_t* src = raw + bs[d] + (2 * L - local - 15);
-            const uint64_t x = load_u64_raw(src), y = load_u64_raw(src + 8);
+            uint64_t x, y;
+            load_16_bytes(src, x, y);
 #pragma unroll
             for (int b = 0; b < 8; b++) {
                 out[15 - b] = s_rc[(x >> (8 * b)) & 0xff]; out[7 - b] = s_rc[(y >> (8 * b)) & 0xff];

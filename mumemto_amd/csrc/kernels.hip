@@ -83,70 +83,75 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
     __syncthreads();
     const uint64_t* st = in_lds ? s_start : doc_start;
     const uint64_t* bs = in_lds ? s_base : doc_base;
-    const uint64_t p0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) * 16;
-    uint8_t out[16];
-    uint32_t valid = 0;
-    if (p0 < n) {
-        uint32_t d = doc_lookup(st, n_docs, p0);
-        const uint64_t L = bs[d + 1] - bs[d], local = p0 - st[d];
-        if (local + 16 <= L) {                                              // forward strand
-            const uint8_t* src = raw + bs[d] + local;
-            uint64_t x, y;
-            load_16_bytes(src, x, y);
+    // a workgroup walks over many tiles and adds its histogram to the global one once: with a workgroup per tile
+    // the ~100,000 flushes queue up on five counter words (~90 atomics per microsecond each) and set the run time
+    const uint64_t n_tiles = (n + (uint64_t)BLOCK * 16 - 1) / ((uint64_t)BLOCK * 16);
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t p0 = (tile * BLOCK + threadIdx.x) * 16;
+        uint8_t out[16];
+        uint32_t valid = 0;
+        if (p0 < n) {
+            uint32_t d = doc_lookup(st, n_docs, p0);
+            const uint64_t L = bs[d + 1] - bs[d], local = p0 - st[d];
+            if (local + 16 <= L) {                                              // forward strand
+                const uint8_t* src = raw + bs[d] + local;
+                uint64_t x, y;
+                load_16_bytes(src, x, y);
 #pragma unroll
-            for (int b = 0; b < 8; b++) { out[b] = s_up[(x >> (8 * b)) & 0xff]; out[8 + b] = s_up[(y >> (8 * b)) & 0xff]; }
-            valid = 0xffffu;
-        } else if (local > L && local + 15 <= 2 * L) {                      // reverse strand
-            const uint8_t* src = raw + bs[d] + (2 * L - local - 15);
-            uint64_t x, y;
-            load_16_bytes(src, x, y);
+                for (int b = 0; b < 8; b++) { out[b] = s_up[(x >> (8 * b)) & 0xff]; out[8 + b] = s_up[(y >> (8 * b)) & 0xff]; }
+                valid = 0xffffu;
+            } else if (local > L && local + 15 <= 2 * L) {                      // reverse strand
+                const uint8_t* src = raw + bs[d] + (2 * L - local - 15);
+                uint64_t x, y;
+                load_16_bytes(src, x, y);
 #pragma unroll
-            for (int b = 0; b < 8; b++) {
-                out[15 - b] = s_rc[(x >> (8 * b)) & 0xff]; out[7 - b] = s_rc[(y >> (8 * b)) & 0xff];
-            }
-            valid = 0xffffu;
-        } else {
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const uint64_t p = p0 + b;
-                uint8_t c = 0;
-                if (p < n) {
-                    while (p >= st[d + 1]) d++;
-                    const uint64_t Ld = bs[d + 1] - bs[d], lo = p - st[d];
-                    if (lo < Ld) c = s_up[raw[bs[d] + lo]];
-                    else if (lo == Ld) c = '$';
-                    else if (lo <= 2 * Ld) c = s_rc[raw[bs[d] + (2 * Ld - lo)]];
-                    else c = '$';
-                    valid |= 1u << b;
+                for (int b = 0; b < 8; b++) {
+                    out[15 - b] = s_rc[(x >> (8 * b)) & 0xff]; out[7 - b] = s_rc[(y >> (8 * b)) & 0xff];
                 }
-                out[b] = c;
+                valid = 0xffffu;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const uint64_t p = p0 + b;
+                    uint8_t c = 0;
+                    if (p < n) {
+                        while (p >= st[d + 1]) d++;
+                        const uint64_t Ld = bs[d + 1] - bs[d], lo = p - st[d];
+                        if (lo < Ld) c = s_up[raw[bs[d] + lo]];
+                        else if (lo == Ld) c = '$';
+                        else if (lo <= 2 * Ld) c = s_rc[raw[bs[d] + (2 * Ld - lo)]];
+                        else c = '$';
+                        valid |= 1u << b;
+                    }
+                    out[b] = c;
+                }
             }
+            uint4 w;
+            uint32_t* wp = reinterpret_cast<uint32_t*>(&w);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                wp[q] = (uint32_t)out[4 * q] | ((uint32_t)out[4 * q + 1] << 8) | ((uint32_t)out[4 * q + 2] << 16) |
+                        ((uint32_t)out[4 * q + 3] << 24);
+            *reinterpret_cast<uint4*>(text + p0) = w;                           // buffer is padded past n
         }
-        uint4 w;
-        uint32_t* wp = reinterpret_cast<uint32_t*>(&w);
+        uint64_t pa = 0, pb = 0;      // 16-bit counters: pa = A C G T, pb = N $
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            wp[q] = (uint32_t)out[4 * q] | ((uint32_t)out[4 * q + 1] << 8) | ((uint32_t)out[4 * q + 2] << 16) |
-                    ((uint32_t)out[4 * q + 3] << 24);
-        *reinterpret_cast<uint4*>(text + p0) = w;                           // buffer is padded past n
-    }
-    uint64_t pa = 0, pb = 0;      // 16-bit counters: pa = A C G T, pb = N $
+        for (int b = 0; b < 16; b++) {
+            if (!((valid >> b) & 1u)) continue;
+            const uint32_t sl = s_slot[out[b]];
+            const uint64_t inc = 1ull << ((sl & 3u) * 16);
+            if (sl < 4) pa += inc; else if (sl < 6) pb += inc; else atomicAdd(&s_hist[out[b]], 1u);
+        }
 #pragma unroll
-    for (int b = 0; b < 16; b++) {
-        if (!((valid >> b) & 1u)) continue;
-        const uint32_t sl = s_slot[out[b]];
-        const uint64_t inc = 1ull << ((sl & 3u) * 16);
-        if (sl < 4) pa += inc; else if (sl < 6) pb += inc; else atomicAdd(&s_hist[out[b]], 1u);
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { pa += __shfl_xor(pa, o, 64); pb += __shfl_xor(pb, o, 64); }
-    if ((threadIdx.x & 63) == 0) {
-        if (pa & 0xffffull) atomicAdd(&s_hist['A'], (uint32_t)(pa & 0xffff));
-        if ((pa >> 16) & 0xffffull) atomicAdd(&s_hist['C'], (uint32_t)((pa >> 16) & 0xffff));
-        if ((pa >> 32) & 0xffffull) atomicAdd(&s_hist['G'], (uint32_t)((pa >> 32) & 0xffff));
-        if (pa >> 48) atomicAdd(&s_hist['T'], (uint32_t)(pa >> 48));
-        if (pb & 0xffffull) atomicAdd(&s_hist['N'], (uint32_t)(pb & 0xffff));
-        if ((pb >> 16) & 0xffffull) atomicAdd(&s_hist['$'], (uint32_t)((pb >> 16) & 0xffff));
+        for (int o = 32; o >= 1; o >>= 1) { pa += __shfl_xor(pa, o, 64); pb += __shfl_xor(pb, o, 64); }
+        if ((threadIdx.x & 63) == 0) {
+            if (pa & 0xffffull) atomicAdd(&s_hist['A'], (uint32_t)(pa & 0xffff));
+            if ((pa >> 16) & 0xffffull) atomicAdd(&s_hist['C'], (uint32_t)((pa >> 16) & 0xffff));
+            if ((pa >> 32) & 0xffffull) atomicAdd(&s_hist['G'], (uint32_t)((pa >> 32) & 0xffff));
+            if (pa >> 48) atomicAdd(&s_hist['T'], (uint32_t)(pa >> 48));
+            if (pb & 0xffffull) atomicAdd(&s_hist['N'], (uint32_t)(pb & 0xffff));
+            if ((pb >> 16) & 0xffffull) atomicAdd(&s_hist['$'], (uint32_t)((pb >> 16) & 0xffff));
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += BLOCK)
@@ -156,8 +161,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
 void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
                 bool /*revcomp*/, uint8_t* text, uint64_t n, uint32_t* hist, hipStream_t s) {
     constexpr int B = 256;
-    hipLaunchKernelGGL((k_build_text<B, 1023>), dim3(grid_for((n + 15) / 16, B)), dim3(B), 0, s, raw, d_doc_base,
-                       d_doc_start, n_docs, text, n, hist);
+    const uint64_t tiles = (n + (uint64_t)B * 16 - 1) / ((uint64_t)B * 16);
+    const unsigned grid = (unsigned)std::min<uint64_t>(tiles ? tiles : 1, 256u * 16u);
+    hipLaunchKernelGGL((k_build_text<B, 1023>), dim3(grid), dim3(B), 0, s, raw, d_doc_base, d_doc_start, n_docs, text, n,
+                       hist);
     MMT_HIP(hipGetLastError());
 }
 

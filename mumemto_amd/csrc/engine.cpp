@@ -160,6 +160,7 @@ void Engine::lcp_bwt() {
         uint32_t found = 0;
         MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
         MMT_HIP(hipStreamSynchronize(stream_));
+        if (std::getenv("MMT_LCP_STATS")) std::fprintf(stderr, "[lcp] %u matches beyond 192 characters (list capacity %u)\n", found, cap);
         if (found <= cap) {
             k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(),
                         reinterpret_cast<uint32_t*>(d_long_.get() + (size_t)cap * 12), d_count_.get() + 3, stream_);

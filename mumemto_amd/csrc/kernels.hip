@@ -534,24 +534,40 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
     }
     __syncthreads();
     const uint32_t cnt = s_n;
-    for (uint32_t wi = threadIdx.x; wi < cnt; wi += BLOCK) {
-        const uint64_t j = base + s_q[wi];
-        const uint32_t p = sa[j];
-        if (j == 0) { K[p] = p; continue; }                      // no predecessor: LCP 0
-        const uint32_t qq = sa[j - 1];
-        const uint32_t limit = n - (p > qq ? p : qq);           // the shorter suffix ends first
-        uint32_t h = 0;
-        bool done = false;
-        for (int step = 0; step < IRR_STEPS && h < limit; step++) {
-            const uint64_t x = load_u64(text + p + h), y = load_u64(text + qq + h);
-            if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
-            h += 8;
+    for (uint32_t wbase = 0; wbase < cnt; wbase += BLOCK) {          // uniform trip count: the list slots are handed out per wave
+        const uint32_t wi = wbase + threadIdx.x;
+        bool queue = false;
+        uint32_t p = 0, qq = 0, h = 0;
+        if (wi < cnt) {
+            const uint64_t j = base + s_q[wi];
+            p = sa[j];
+            if (j == 0) K[p] = p;                                    // no predecessor: LCP 0
+            else {
+                qq = sa[j - 1];
+                const uint32_t limit = n - (p > qq ? p : qq);       // the shorter suffix ends first
+                bool done = false;
+                for (int step = 0; step < IRR_STEPS && h < limit; step++) {
+                    const uint64_t x = load_u64(text + p + h), y = load_u64(text + qq + h);
+                    if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
+                    h += 8;
+                }
+                if (h >= limit) { h = limit; done = true; }
+                if (done) K[p] = h + p;
+                else queue = true;
+            }
         }
-        if (h >= limit) { h = limit; done = true; }
-        if (done) K[p] = h + p;
-        else {
-            const uint32_t slot = atomicAdd(long_count, 1u);
-            if (slot < long_cap) { longs[slot].p = p; longs[slot].q = qq; longs[slot].h = h; }
+        // one counter update per wave (1.2 M long matches on the bench workload: one atomic each on a single word was
+        // a queue of its own)
+        const uint64_t m = __ballot(queue);
+        if (m) {
+            uint32_t slot0 = 0;
+            const int leader = __builtin_ctzll(m);
+            if ((int)lane == leader) slot0 = atomicAdd(long_count, (uint32_t)__popcll(m));
+            slot0 = __shfl(slot0, leader, 64);
+            if (queue) {
+                const uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (slot < long_cap) { longs[slot].p = p; longs[slot].q = qq; longs[slot].h = h; }
+            }
         }
     }
 }

@@ -128,6 +128,19 @@ MMT_API int mmt_copy_candidates(const mmt_engine* e, uint32_t* out);
 MMT_API int mmt_stage_ms(const mmt_engine* e, float out[8]);
 /* Bytes of the SA / LCP / BWT columns as stored (for the roofline model).     */
 MMT_API int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]);
+/* Texts of 2^32 - 4096 characters or more run with 40-bit positions (the reference's width: include/common.hpp:59-60,
+ * include/parse.hpp:45; dumps include/pfp_lcp_mum.hpp:323-369): the suffix-array column is stored as low word + high
+ * byte, and the stream is scanned in ranges of suffix-array positions (mmt_scan_ranges of them in the last run).     */
+MMT_API int mmt_is_wide(const mmt_engine* e);
+MMT_API size_t mmt_scan_ranges(const mmt_engine* e);
+MMT_API int mmt_copy_sa64(const mmt_engine* e, uint64_t* out);    /* n entries, any text size */
+/* mmt_engine_set_stream_host for streams with 40-bit suffix-array entries (sa_hi = bits 32..39)                        */
+MMT_API int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uint8_t* sa_hi, const uint32_t* lcp,
+                                         const uint8_t* bwt, uint64_t entries, const uint64_t* doc_len, size_t n_docs,
+                                         int use_revcomp);
+/* Device heap of the engine's GPU (pool.hpp): [0] bytes mapped from the driver, [1] bytes in use, [2] high-water mark
+ * of [1], [3] microseconds spent in the driver mapping memory.                                                         */
+MMT_API int mmt_device_memory(const mmt_engine* e, uint64_t out[4]);
 
 /* ---- PFP stage checkpoints (the reference's -P / -K: PREFIX.dict, PREFIX.parse) ------------ */
 /* Text layout + prefix-free parse only (newscan.hpp pfparser: process_string ... finish_parse).  */

@@ -70,7 +70,8 @@ GPU_ABI_SYMBOLS = [
     "mmt_engine_set_producer", "mmt_producer_used", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
-    "mmt_engine_set_stream_host",
+    "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
+    "mmt_device_memory",
 ]
 
 
@@ -135,6 +136,13 @@ def load_library():
     L.mmt_thresh_device.argtypes = [C.c_void_p]
     for f in ("mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_copy_candidates"):
         getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_copy_sa64.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_is_wide.argtypes = [C.c_void_p]
+    L.mmt_scan_ranges.restype = C.c_size_t
+    L.mmt_scan_ranges.argtypes = [C.c_void_p]
+    L.mmt_device_memory.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mmt_engine_set_stream_host40.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                               C.c_void_p, C.c_size_t, C.c_int]
     L.mmt_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mmt_column_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mmt_engine_set_producer.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
@@ -412,7 +420,22 @@ class Engine:
         return self._copy(self.L.mmt_copy_text, np.uint8)
 
     def sa(self):
+        """Suffix array of the last run (uint32 for narrow runs, uint64 when positions need 40 bits)."""
+        if self.is_wide():
+            return self._copy(self.L.mmt_copy_sa64, np.uint64)
         return self._copy(self.L.mmt_copy_sa, np.uint32)
+
+    def is_wide(self):
+        return bool(self.L.mmt_is_wide(self.h))
+
+    def scan_ranges(self):
+        return int(self.L.mmt_scan_ranges(self.h))
+
+    def device_memory(self):
+        """Device heap of this engine's GPU: bytes mapped, live, peak, and seconds spent mapping."""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.mmt_device_memory(self.h, out))
+        return {"mapped": int(out[0]), "live": int(out[1]), "peak": int(out[2]), "map_seconds": out[3] / 1e6}
 
     def lcp(self):
         return self._copy(self.L.mmt_copy_lcp, np.uint32)

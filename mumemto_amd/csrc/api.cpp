@@ -345,7 +345,25 @@ int mmt_stage_ms(const mmt_engine* e, float out[8]) {
 }
 int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]) {
     if (!e) return fail(1, "null");
-    out[0] = 4; out[1] = 4; out[2] = 1;   // SA u32, LCP u32, BWT u8 as stored by this build
+    out[0] = e->e->wide() ? 5 : 4; out[1] = 4; out[2] = 1;   // SA 32 (+8) bits, LCP u32, BWT u8 as stored
+    return 0;
+}
+int mmt_copy_sa64(const mmt_engine* e, uint64_t* out) { if (!e) return fail(1, "null"); MMT_TRY e->e->copy_sa64(out); MMT_CATCH }
+int mmt_is_wide(const mmt_engine* e) { return e && e->e->wide() ? 1 : 0; }
+size_t mmt_scan_ranges(const mmt_engine* e) { return e ? e->e->scan_ranges() : 0; }
+int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uint8_t* sa_hi, const uint32_t* lcp,
+                                 const uint8_t* bwt, uint64_t entries, const uint64_t* doc_len, size_t n_docs,
+                                 int use_revcomp) {
+    if (!e || ((!sa_lo || !sa_hi || !lcp || !bwt) && entries) || (!doc_len && n_docs))
+        return fail(1, "engine, columns and doc_len must be non-null");
+    MMT_TRY
+    e->e->set_stream_host40(sa_lo, sa_hi, lcp, bwt, entries, doc_len, n_docs, use_revcomp != 0);
+    MMT_CATCH
+}
+int mmt_device_memory(const mmt_engine* e, uint64_t out[4]) {
+    if (!e) return fail(1, "null");
+    const mmt::pool::Stats s = mmt::pool::stats(e->e->device());
+    out[0] = s.mapped; out[1] = s.live; out[2] = s.peak; out[3] = (uint64_t)(s.map_seconds * 1e6);
     return 0;
 }
 

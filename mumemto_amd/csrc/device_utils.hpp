@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include "pool.hpp"
+
 namespace mmt {
 
 struct HipError : std::runtime_error {
@@ -34,7 +36,7 @@ struct DevBytes {
 };
 
 // Device allocation that only grows (steps of the hot path are re-run by the
-// bench with the same sizes; re-allocating per run would time hipMalloc).
+// bench with the same sizes), taken from the per-device heap of pool.hpp.
 template <typename T>
 class DevBuf {
 public:
@@ -47,7 +49,7 @@ public:
         release();
         size_t want = n + n / 16 + 64;
         const auto t0 = std::chrono::steady_clock::now();
-        MMT_HIP(hipMalloc(reinterpret_cast<void**>(&p_), want * sizeof(T)));
+        p_ = static_cast<T*>(pool::alloc(want * sizeof(T)));
         DevBytes::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         cap_ = want; n_ = n;
         DevBytes::live() += want * sizeof(T);
@@ -57,7 +59,7 @@ public:
         if (DevBytes::live() > DevBytes::peak()) DevBytes::peak() = DevBytes::live();
     }
     void release() {
-        if (p_) { (void)hipFree(p_); p_ = nullptr; DevBytes::live() -= cap_ * sizeof(T); }
+        if (p_) { pool::release(p_); p_ = nullptr; DevBytes::live() -= cap_ * sizeof(T); }
         cap_ = n_ = 0;
     }
     T* get() const { return p_; }
@@ -68,6 +70,39 @@ public:
 private:
     T* p_ = nullptr;
     size_t cap_ = 0, n_ = 0;
+};
+
+// A table of text positions / stream offsets: uint32_t entries in a narrow run, uint64_t entries in a wide one
+// (wide.hpp).  The launch wrappers take the untyped pointer together with the `wide` flag.
+class PosBuf {
+public:
+    void ensure(size_t n, bool wide) { wide_ = wide; n_ = n; b_.ensure(n * (wide ? 8 : 4)); }
+    void release() { b_.release(); n_ = 0; }
+    bool wide() const { return wide_; }
+    void* get() const { return b_.get(); }
+    uint32_t* p32() const { return reinterpret_cast<uint32_t*>(b_.get()); }
+    uint64_t* p64() const { return reinterpret_cast<uint64_t*>(b_.get()); }
+    // entry i as an untyped pointer (for partial copies)
+    void* at(size_t i) const { return b_.get() + i * (wide_ ? 8 : 4); }
+    size_t size() const { return n_; }
+    size_t elem() const { return wide_ ? 8 : 4; }
+    void swap(PosBuf& o) { b_.swap(o.b_); std::swap(n_, o.n_); std::swap(wide_, o.wide_); }
+    // one entry, read back (synchronises the stream)
+    uint64_t read(size_t i, hipStream_t s) const {
+        uint64_t v = 0;
+        MMT_HIP(hipMemcpyAsync(&v, at(i), elem(), hipMemcpyDeviceToHost, s));
+        MMT_HIP(hipStreamSynchronize(s));
+        return v;                                  // little endian: a 4-byte entry lands in the low half
+    }
+    void write(size_t i, uint64_t v, hipStream_t s) const {
+        MMT_HIP(hipMemcpyAsync(at(i), &v, elem(), hipMemcpyHostToDevice, s));
+        MMT_HIP(hipStreamSynchronize(s));
+    }
+
+private:
+    DevBuf<uint8_t> b_;
+    size_t n_ = 0;
+    bool wide_ = false;
 };
 
 // Page-locked host memory that only grows: D2H targets of the result rows / output bytes.

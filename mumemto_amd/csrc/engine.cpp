@@ -34,6 +34,8 @@ void Engine::set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, s
     MMT_HIP(hipSetDevice(device_));
     d_bases_ = d_bases;
     preset_ = 0;
+    input_valid_ = true;
+    lcp_whole_ = false;
     doc_len_.assign(doc_len, doc_len + n_docs);
     doc_base_.assign(n_docs + 1, 0);
     for (size_t d = 0; d < n_docs; d++) doc_base_[d + 1] = doc_base_[d] + doc_len_[d];
@@ -56,9 +58,10 @@ void Engine::layout_docs(bool revcomp) {
     doc_start_.assign(N + 1, 0);
     for (size_t d = 0; d < N; d++) doc_start_[d + 1] = doc_start_[d] + (revcomp ? 2 : 1) * (doc_len_[d] + 1);
     n_ = doc_start_[N];
-    if (n_ >= 0xfffff000ull)
-        throw std::runtime_error("text of " + std::to_string(n_) +
-                                 " characters exceeds the 32-bit suffix-array build of this version");
+    if (n_ >= (1ull << 40))
+        throw std::runtime_error("text of " + std::to_string(n_) + " characters exceeds 40-bit positions");
+    // MMT_FORCE_WIDE: the 40-bit code path on small inputs (tests)
+    wide_ = n_ >= NARROW_LIMIT || std::getenv("MMT_FORCE_WIDE") != nullptr;
     d_doc_start_.ensure(N + 1);
     MMT_HIP(hipMemcpyAsync(d_doc_start_.get(), doc_start_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
 }
@@ -74,16 +77,22 @@ void Engine::set_text_host(const uint8_t* text, uint64_t n, const uint64_t* doc_
     d_text_.ensure(n_ + 64);
     MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~15ull), 0, 64 + (n_ & 15ull), stream_));
     if (n_) MMT_HIP(hipMemcpyAsync(d_text_.get(), text, n_, hipMemcpyHostToDevice, stream_));
-    std::vector<uint32_t> hist(256, 0);
+    std::vector<uint64_t> hist(256, 0);
     for (uint64_t i = 0; i < n_; i++) hist[text[i]]++;
     d_hist_.ensure(256);
-    MMT_HIP(hipMemcpyAsync(d_hist_.get(), hist.data(), 256 * 4, hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipMemcpyAsync(d_hist_.get(), hist.data(), 256 * 8, hipMemcpyHostToDevice, stream_));
     MMT_HIP(hipStreamSynchronize(stream_));
     preset_ = 1;
+    input_valid_ = true;
 }
 
 void Engine::set_stream_host(const uint32_t* sa, const uint32_t* lcp, const uint8_t* bwt, uint64_t entries,
                              const uint64_t* doc_len, size_t n_docs, bool revcomp) {
+    set_stream_host40(sa, nullptr, lcp, bwt, entries, doc_len, n_docs, revcomp);
+}
+
+void Engine::set_stream_host40(const uint32_t* sa_lo, const uint8_t* sa_hi, const uint32_t* lcp, const uint8_t* bwt,
+                               uint64_t entries, const uint64_t* doc_len, size_t n_docs, bool revcomp) {
     MMT_HIP(hipSetDevice(device_));
     d_bases_ = nullptr;
     doc_len_.assign(doc_len, doc_len + n_docs);
@@ -91,17 +100,27 @@ void Engine::set_stream_host(const uint32_t* sa, const uint32_t* lcp, const uint
     layout_docs(revcomp);
     if (entries > n_) throw std::runtime_error("more stream entries than text characters");
     const uint64_t text_chars = n_;
+    wide_ = sa_hi != nullptr;
+    if (!wide_ && text_chars >= NARROW_LIMIT)
+        throw std::runtime_error("a stream over " + std::to_string(text_chars) + " text characters needs 40-bit entries");
+    if (entries >= 0xffffe000ull)
+        throw std::runtime_error("a handed-over stream is scanned as one range: at most 2^32 - 8192 entries");
     for (uint64_t j = 0; j < entries; j++)
-        if (sa[j] >= text_chars) throw std::runtime_error("suffix array entry outside the text");
+        if (((uint64_t)sa_lo[j] | (sa_hi ? (uint64_t)sa_hi[j] << 32 : 0)) >= text_chars)
+            throw std::runtime_error("suffix array entry outside the text");
     n_ = entries;                                      // what the scan walks (a truncated stream is legal, see -a)
-    d_sa_.ensure(n_ + 1); d_lcp_.ensure(n_ + 1); d_bwt_.ensure(n_ + 16);
+    d_sa_.ensure(n_ + 1); d_lcp_.ensure(n_ + 16); d_bwt_.ensure(n_ + 16);
+    if (wide_) d_sa_hi_.ensure(n_ + 16);
     if (n_) {
-        MMT_HIP(hipMemcpyAsync(d_sa_.get(), sa, n_ * 4, hipMemcpyHostToDevice, stream_));
+        MMT_HIP(hipMemcpyAsync(d_sa_.get(), sa_lo, n_ * 4, hipMemcpyHostToDevice, stream_));
+        if (wide_) MMT_HIP(hipMemcpyAsync(d_sa_hi_.get(), sa_hi, n_, hipMemcpyHostToDevice, stream_));
         MMT_HIP(hipMemcpyAsync(d_lcp_.get(), lcp, n_ * 4, hipMemcpyHostToDevice, stream_));
         MMT_HIP(hipMemcpyAsync(d_bwt_.get(), bwt, n_, hipMemcpyHostToDevice, stream_));
     }
     MMT_HIP(hipStreamSynchronize(stream_));
+    lcp_whole_ = true;
     preset_ = 2;
+    input_valid_ = true;
 }
 
 // ---- A1 ----------------------------------------------------------------------
@@ -112,17 +131,21 @@ void Engine::build_text(bool revcomp) {
     MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
     d_text_.ensure(n_ + 64);
     d_hist_.ensure(256);
-    MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 4, stream_));
+    MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
     MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~15ull), 0, 64 + (n_ & 15ull), stream_));
     k::build_text(d_bases_, d_doc_base_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, d_text_.get(), n_,
                   d_hist_.get(), stream_);
 }
 
-// ---- A8: suffix array by prefix doubling ---------------------------------------
+// ---- A8: suffix array by prefix doubling (narrow texts only) --------------------
 void Engine::suffix_sort() {
+    if (n_ >= NARROW_LIMIT)
+        throw std::runtime_error("the direct suffix sort handles texts below 2^32 - 4096 characters; larger inputs go "
+                                 "through prefix-free parsing, which reserves the bytes 0x00-0x02");
+    wide_ = false;                                   // (MMT_FORCE_WIDE does not apply to this producer)
     const uint32_t n = (uint32_t)n_;
     // symbol codes: dense ranks of the bytes that occur, 0 reserved for "past the end"
-    std::vector<uint32_t> hist;
+    std::vector<uint64_t> hist;
     d2h(hist, d_hist_.get(), 256, stream_);
     uint8_t code[256];
     int sigma = 0;
@@ -138,39 +161,47 @@ void Engine::suffix_sort() {
     sort_rounds_ = sorter_.sort(n, bits * chars, (uint64_t)chars, d_sa_.get(), d_rank_.get(), d_temp_, stream_);
 }
 
+// BWT (direct producer) and the PLCP column: d_plcp_a_[i] = LCP of the suffix at text position i with its
+// predecessor in suffix-array order.  The LCP column itself is gathered per scan range (Engine::scan).
 void Engine::lcp_bwt() {
-    const uint32_t n = (uint32_t)n_;
-    d_lcp_.ensure(n + 1);
+    const uint64_t n = n_;
     d_bwt_.ensure(n + 16);
     // The LCP column follows from the irreducible suffixes alone (kernels.hip, "LCP column WITHOUT the inverse
     // suffix array"): no 4-byte random store per suffix anywhere.  The PFP emitter wrote SA and BWT and keeps no
     // inverse suffix array at all; only the suffix ranks of the anchor document are recorded here (multi-GPU
     // re-sort).  The direct producer has the full array from its sort.
     const bool pfp = producer_used_ == 2 && pfp_->bwt_ready;
-    if (!pfp) k::bwt_from_sa(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), stream_);
-    const uint32_t anchor = (uint32_t)std::min<uint64_t>(doc_len_[0], n);
-    if (pfp) d_rank_.ensure((size_t)anchor + 1);
-    d_plcp_a_.ensure(n); d_count_.ensure(4);
-    uint32_t cap = (uint32_t)std::max<size_t>(d_long_.size() / 16, (size_t)n / 256 + 4096);
-    if (const char* c = std::getenv("MMT_LONG_CAP")) cap = (uint32_t)std::max(1, std::atoi(c));   // tests: force the rerun
+    if (!pfp) k::bwt_from_sa(d_text_.get(), (uint32_t)n, d_sa_.get(), d_bwt_.get(), stream_);
+    const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
+    void* rank_out = nullptr;
+    if (pfp) {
+        if (wide_) { d_rank64_.ensure((size_t)anchor + 1); rank_out = d_rank64_.get(); }
+        else { d_rank_.ensure((size_t)anchor + 1); rank_out = d_rank_.get(); }
+    }
+    d_plcp_a_.ensure(n); d_count_.ensure(8);
+    const size_t rec = k::long_lcp_record_bytes(wide_) + 4;     // one record + one index for the second tier
+    uint64_t cap64 = std::max<uint64_t>(d_long_.size() / rec, n / 256 + 4096);
+    if (const char* c = std::getenv("MMT_LONG_CAP")) cap64 = (uint64_t)std::max(1, std::atoi(c));   // tests: force the rerun
+    uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 0x7fffffffull);
     for (int attempt = 0; attempt < 2; attempt++) {
-        d_long_.ensure((size_t)cap * 16);                // 12-byte records + one index each for the second tier
-        k::irreducible_lcp(d_text_.get(), n, d_sa_.get(), d_bwt_.get(), d_plcp_a_.get(), pfp ? d_rank_.get() : nullptr,
-                           anchor, d_long_.get(), d_count_.get() + 2, cap, stream_);
+        d_long_.ensure((size_t)cap * rec);
+        k::irreducible_lcp(d_text_.get(), n, sa_col(), d_bwt_.get(), d_plcp_a_.get(), rank_out, anchor, d_long_.get(),
+                           d_count_.get() + 2, cap, stream_);
         uint32_t found = 0;
         MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
         MMT_HIP(hipStreamSynchronize(stream_));
         if (std::getenv("MMT_LCP_STATS")) std::fprintf(stderr, "[lcp] %u matches beyond 192 characters (list capacity %u)\n", found, cap);
         if (found <= cap) {
-            k::long_lcp(d_text_.get(), n, d_long_.get(), found, d_plcp_a_.get(),
-                        reinterpret_cast<uint32_t*>(d_long_.get() + (size_t)cap * 12), d_count_.get() + 3, stream_);
+            k::long_lcp(d_text_.get(), n, wide_, d_long_.get(), found, d_plcp_a_.get(),
+                        reinterpret_cast<uint32_t*>(d_long_.get() + (size_t)cap * (rec - 4)), d_count_.get() + 3, stream_);
             break;
         }
         if (attempt) throw std::runtime_error("long-match list overflow in the LCP construction");
         cap = found + 1024;                            // rare: rerun with the exact size
     }
-    prims::inclusive_max_u32(d_temp_, d_plcp_a_.get(), d_plcp_a_.get(), n, stream_);      // K' over K, in place
-    k::lcp_gather(d_plcp_a_.get(), d_sa_.get(), n, d_lcp_.get(), stream_);
+    d_temp_.ensure(k::plcp_running_max_scratch(n));
+    k::plcp_running_max(d_plcp_a_.get(), n, d_temp_.get(), stream_);      // PLCP everywhere, in place
+    lcp_whole_ = false;
 }
 
 // One-shot / tight-memory runs: the suffix-sort stage (doubling scratch, dictionary, parse, emitter tables: two thirds
@@ -183,26 +214,40 @@ void Engine::release_sort_scratch() {
     fresh->w = S.w; fresh->p = S.p; fresh->n_cuts = S.n_cuts; fresh->n_phrases = S.n_phrases; fresh->n_distinct = S.n_distinct;
     fresh->dict_len = S.dict_len; fresh->n_groups = S.n_groups; fresh->rounds_dict = S.rounds_dict;
     fresh->rounds_parse = S.rounds_parse; fresh->n_entries = S.n_entries; fresh->n_fallback = S.n_fallback;
+    fresh->emit_launches = S.emit_launches;
     fresh->bwt_ready = S.bwt_ready;
     std::memcpy(fresh->ms, S.ms, sizeof(S.ms));
     pfp_ = std::move(fresh);
 }
 
-// Called after the suffix sort: the LCP stage is about to allocate K and the LCP column (8 bytes per text
+// Called after the suffix sort: the LCP stage is about to allocate the PLCP and LCP columns (8 bytes per text
 // character, plus the candidate list).  When the device does not have that much left, the sort stage's scratch goes.
 bool Engine::wants_lean() const {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     const size_t have = (d_plcp_a_.size() + d_lcp_.size()) * sizeof(uint32_t);
     const double need = 9.0 * (double)n_ - (double)have;
-    return need > 0.95 * (double)free_b;
+    return need > 0.95 * (double)pool::available(device_);
 }
 
 // ---- A5 ------------------------------------------------------------------------
+// keeps the first `used` elements when the buffer has to grow
+template <typename T>
+static void grow_keep(DevBuf<T>& buf, size_t need, size_t used, hipStream_t s) {
+    if (need <= buf.size()) return;
+    DevBuf<T> bigger;
+    bigger.ensure(need + need / 4);
+    if (used) MMT_HIP(hipMemcpyAsync(bigger.get(), buf.get(), used * sizeof(T), hipMemcpyDeviceToDevice, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    buf.swap(bigger);
+}
+
+// The stream is scanned in ranges of suffix-array positions: the LCP column exists for one range at a time
+// (gathered from PLCP through the suffix array), with a left extension long enough for every walk; candidates
+// carry range-relative positions, accepted rows absolute ones.  A text below 2^32 characters is one range.
 void Engine::scan(const mmt_params& p) {
-    const uint32_t n = (uint32_t)n_;
+    const uint64_t n = n_;
     const size_t N = doc_len_.size();
-    d_count_.ensure(4);
+    hipStream_t st = stream_;
+    d_count_.ensure(8);
     num_distinct_eff_ = p.num_distinct ? p.num_distinct : N;     // mumemto_api.cpp:344-346
     // interval size cap: explicit total cap, else docs * per-doc cap (every accepted interval obeys it)
     uint64_t cap = 0;
@@ -216,53 +261,125 @@ void Engine::scan(const mmt_params& p) {
         throw std::runtime_error("more than 32768 documents are not supported by the candidate verifier");
 
     k::ScanArgs a;
-    a.lcp = d_lcp_.get(); a.bwt = d_bwt_.get(); a.n = n;
     a.min_len = p.min_match_len;
     a.num_distinct = (uint32_t)std::min<uint64_t>(num_distinct_eff_, 0xffffffffu);
     a.cap = (uint32_t)cap;
     a.emit_all = p.merge_metadata ? 1 : 0;
     a.d_count = d_count_.get();
-    size_t capacity = std::max<size_t>(1u << 20, p.merge_metadata ? n / 6 : n / 32);
-    uint32_t found = 0;
-    for (int attempt = 0; attempt < 3; attempt++) {
-        d_cand_.ensure(capacity);
-        a.out = d_cand_.get(); a.capacity = (uint32_t)capacity;
-        MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 16, stream_));
-        ev_[3]->start(stream_);
-        if (attempt == 0 && k::scan_needs_wide(a)) {      // window tables in HBM (the LCP scratch is free by now)
-            d_plcp_a_.ensure(n); d_plcp_b_.ensure(n); d_wide_.ensure(n);
-            k::scan_wide_prepare(a.lcp, a.bwt, n, a.num_distinct, d_plcp_a_.get(), d_plcp_b_.get(), d_wide_.get(), stream_);
-            prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get(), n, stream_);
-            a.wide_pre = d_plcp_a_.get(); a.wide_suf = d_plcp_b_.get(); a.wide_chg = d_wide_.get();
-        }
-        k::scan_intervals(a, stream_);
-        ev_[3]->stop(stream_);
-        MMT_HIP(hipMemcpyAsync(&found, d_count_.get(), 4, hipMemcpyDeviceToHost, stream_));
-        MMT_HIP(hipStreamSynchronize(stream_));
-        if (found <= capacity) break;
-        capacity = (size_t)found + 1024;       // rare: re-run with the exact size
-    }
-    n_cand_ = found;
 
-    // verification + thresholds
-    ev_[4]->start(stream_);
+    // thresholds (merge metadata) and the row list are shared by all ranges
     thresh_len_ = 0;
     if (p.merge_metadata && N > 0) {
         thresh_len_ = 2 * (doc_len_[0] + 1);
         d_thresh_.ensure(thresh_len_);
-        MMT_HIP(hipMemsetAsync(d_thresh_.get(), 0, thresh_len_ * 2, stream_));
+        MMT_HIP(hipMemsetAsync(d_thresh_.get(), 0, thresh_len_ * 2, st));
     }
-    d_rows_.ensure(std::max<size_t>(n_cand_, 1));
-    MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, stream_));
-    k::VerifyArgs v;
-    v.cand = d_cand_.get(); v.n_cand = (uint32_t)n_cand_; v.sa = d_sa_.get(); v.lcp = d_lcp_.get();
-    v.d_doc_start = d_doc_start_.get(); v.n_docs = (uint32_t)N;
-    v.num_distinct = a.num_distinct;
-    v.max_doc_freq = p.max_doc_freq > 0 ? (uint32_t)std::min<int64_t>(p.max_doc_freq, 0x7fffffff) : 0u;
-    v.merge = p.merge_metadata ? 1 : 0; v.thresh = d_thresh_.get();
-    v.rows = d_rows_.get(); v.d_row_count = d_count_.get() + 1;
-    k::verify_candidates(v, stream_);
-    ev_[4]->stop(stream_);
+    MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, st));
+    size_t rows_used = 0;
+    n_cand_ = 0;
+
+    // range size: everything at once unless the text is wide (MMT_SCAN_RANGE: tests)
+    const uint64_t ALIGN_R = 4096;
+    uint64_t range = n;
+    if (!lcp_whole_ || preset_ != 2) {
+        if (wide_) range = 1ull << 28;
+        if (const char* c = std::getenv("MMT_SCAN_RANGE")) range = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
+        range = (range + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
+    }
+    const bool single = range >= n;
+    if (single && n >= 0xffffe000ull) throw std::runtime_error("a scan range holds fewer than 2^32 - 8192 entries");
+    // left extension of every range but the first: at least the largest interval (+1), the window of the wide-document
+    // path, one LDS halo; uncapped modes start with 64 K entries and repeat a range whose walk ran off it
+    uint64_t ext0 = cap ? cap + 1 : 65536;
+    ext0 = std::max<uint64_t>(ext0, (uint64_t)a.num_distinct + 2);
+    ext0 = std::max<uint64_t>(ext0, 1040);
+    ext0 = (ext0 + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
+    scan_ranges_ = 0;
+    size_t ev_at = 0;
+    range_ev_kind_.clear();
+    auto next_ev = [&](int kind) -> EventPair& {          // kind: 0 LCP gather, 1 scan kernel, 2 verification
+        if (ev_at == range_ev_.size()) range_ev_.emplace_back(new EventPair());
+        range_ev_kind_.push_back(kind);
+        range_ev_[ev_at]->reset();
+        return *range_ev_[ev_at++];
+    };
+    for (uint64_t c0 = 0; c0 < n; c0 += range) {
+        const uint64_t c1 = std::min(n, c0 + range);
+        uint64_t ext = c0 ? ext0 : 0;
+        uint32_t found = 0;
+        uint64_t b0 = 0;
+        for (;;) {
+            if (ext > c0) ext = c0;
+            b0 = c0 - ext;
+            const uint64_t len = c1 - b0;
+            if (len >= 0xffffe000ull) throw std::runtime_error("scan range with its left extension exceeds 2^32 entries");
+            EventPair& eg = next_ev(0);
+            eg.start(st);
+            if (!(lcp_whole_ && single)) {
+                d_lcp_.ensure(len + 16);
+                k::lcp_gather(d_plcp_a_.get(), sa_col(), b0, len, d_lcp_.get(), st);
+                lcp_whole_ = single;
+            }
+            eg.stop(st);
+            a.lcp = d_lcp_.get(); a.bwt = d_bwt_.get() + b0; a.n = (uint32_t)len; a.first = (uint32_t)ext;
+            a.more_left = b0 > 0 ? 1 : 0;
+            size_t capacity = std::max<size_t>(1u << 20, p.merge_metadata ? len / 6 : len / 32);
+            capacity = std::max(capacity, d_cand_.size());
+            uint32_t overflow = 0;
+            EventPair& es = next_ev(1);
+            for (int attempt = 0; attempt < 3; attempt++) {
+                d_cand_.ensure(capacity);
+                a.out = d_cand_.get(); a.capacity = (uint32_t)std::min<size_t>(capacity, 0xffffffffu);
+                MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 4, st));
+                MMT_HIP(hipMemsetAsync(d_count_.get() + 4, 0, 4, st));
+                es.start(st);
+                if (k::scan_needs_wide(a)) {               // window tables in HBM, per range
+                    d_wpre_.ensure(len); d_wsuf_.ensure(len); d_wide_.ensure(len);
+                    k::scan_wide_prepare(a.lcp, a.bwt, a.n, a.num_distinct, d_wpre_.get(), d_wsuf_.get(), d_wide_.get(), st);
+                    prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get(), len, st);
+                    a.wide_pre = d_wpre_.get(); a.wide_suf = d_wsuf_.get(); a.wide_chg = d_wide_.get();
+                }
+                k::scan_intervals(a, st);
+                es.stop(st);
+                uint32_t back[5] = {0, 0, 0, 0, 0};
+                MMT_HIP(hipMemcpyAsync(back, d_count_.get(), 20, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipStreamSynchronize(st));
+                found = back[0]; overflow = back[4];
+                if (found <= capacity) break;
+                if (attempt == 2) throw std::runtime_error("candidate list overflow in the scan");
+                capacity = (size_t)found + 1024;       // rare: re-run with the exact size
+            }
+            if (overflow && b0 > 0) { ext = std::max<uint64_t>(ext * 4, ext0); continue; }   // a walk ran off the extension
+            break;
+        }
+        scan_ranges_++;
+        n_cand_ += found;
+        // verification + thresholds of this range's candidates
+        EventPair& ev = next_ev(2);
+        ev.start(st);
+        grow_keep(d_rows_, std::max<size_t>(rows_used + found, 1), rows_used, st);
+        k::VerifyArgs v;
+        v.cand = d_cand_.get(); v.n_cand = found; v.sa = sa_col(); v.base = b0; v.lcp = d_lcp_.get();
+        v.d_doc_start = d_doc_start_.get(); v.n_docs = (uint32_t)N;
+        v.num_distinct = a.num_distinct;
+        v.max_doc_freq = p.max_doc_freq > 0 ? (uint32_t)std::min<int64_t>(p.max_doc_freq, 0x7fffffff) : 0u;
+        v.merge = p.merge_metadata ? 1 : 0; v.thresh = d_thresh_.get();
+        v.rows = d_rows_.get(); v.d_row_count = d_count_.get() + 1;
+        k::verify_candidates(v, st);
+        ev.stop(st);
+        if (!single) {                                 // rows so far (the next range may have to grow the list)
+            uint32_t r = 0;
+            MMT_HIP(hipMemcpyAsync(&r, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+            rows_used = r;
+        }
+        if (single) break;
+    }
+    if (scan_ranges_ == 0) scan_ranges_ = 1;
+    range_ev_.resize(ev_at);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (size_t i = 0; i < ev_at; i++) acc[range_ev_kind_[i]] += range_ev_[i]->ms();
+    scan_ms_[0] = acc[0]; scan_ms_[1] = acc[1]; scan_ms_[2] = acc[2];
 }
 
 // ---- A6: rows -> coordinates -> text ---------------------------------------------
@@ -296,13 +413,25 @@ void Engine::make_rows(const mmt_params& p) {
 
     // pop order of the reference's stack: closing position ascending, longer first
     d_rkeys_a_.ensure(n_rows); d_rkeys_b_.ensure(n_rows); d_rvals_a_.ensure(n_rows); d_order_.ensure(n_rows);
-    rk::row_keys(d_rows_.get(), n_rows, d_rkeys_a_.get(), d_rvals_a_.get(), st);
-    prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_a_.get(), d_order_.get(), n_rows, 0,
-                              64, st);
+    if (!wide_) {
+        rk::row_keys(d_rows_.get(), n_rows, d_rkeys_a_.get(), d_rvals_a_.get(), st);
+        prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_a_.get(), d_order_.get(), n_rows, 0,
+                                  64, st);
+    } else {
+        // closing positions beyond 32 bits: two stable sorts (by descending length, then by closing position)
+        d_rvals_b_.ensure(n_rows);
+        uint32_t* len_keys = reinterpret_cast<uint32_t*>(d_rkeys_a_.get());
+        uint32_t* len_keys_out = len_keys + n_rows;
+        rk::row_len_keys(d_rows_.get(), n_rows, len_keys, d_rvals_a_.get(), st);
+        prims::sort_pairs_u32_u32(d_temp_, len_keys, len_keys_out, d_rvals_a_.get(), d_rvals_b_.get(), n_rows, 0, 32, st);
+        rk::row_end_keys(d_rows_.get(), d_rvals_b_.get(), n_rows, d_rkeys_a_.get(), st);
+        prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_b_.get(), d_order_.get(), n_rows, 0,
+                                  40, st);
+    }
     d_doc_len_.ensure(N);
     MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, st));
     rk::RowArgs a;
-    a.rows = d_rows_.get(); a.order = d_order_.get(); a.n_rows = n_rows; a.sa = d_sa_.get();
+    a.rows = d_rows_.get(); a.order = d_order_.get(); a.n_rows = n_rows; a.sa = sa_col();
     a.doc_start = d_doc_start_.get(); a.doc_len = d_doc_len_.get(); a.n_docs = (uint32_t)N; a.revcomp = revcomp_ ? 1 : 0;
     d_tlen_.ensure(n_rows); d_tlen64_.ensure(n_rows); d_toff_.ensure(n_rows);
     auto last_u32 = [&](const uint32_t* d) {
@@ -442,6 +571,7 @@ void Engine::run(const mmt_params& p) {
     auto t0 = std::chrono::steady_clock::now();
     for (auto& ev : ev_) ev->reset();
     for (float& f : stage_ms_) f = 0.f;
+    for (float& f : scan_ms_) f = 0.f;
     merged_thresh_valid_ = false;
     rows_ = HostRows();
     rows_pending_ = 0;
@@ -449,14 +579,27 @@ void Engine::run(const mmt_params& p) {
     rows_.n_docs = doc_len_.size();
     n_cand_ = 0; thresh_len_ = 0; bumbl_.clear();
     if (doc_len_.empty()) return;                       // mumemto_api.cpp:338-340
+    if (!input_valid_)
+        throw std::runtime_error("the engine holds no input (a partitioned run consumed it): call set_input first");
     if (preset_ && (p.use_revcomp != 0) != revcomp_)
         throw std::runtime_error("the text / stream handed over was laid out with the other strand setting");
+    // merge metadata is defined for strict multi-MUMs only (include/pfp_mum.hpp:178-183): with partial or MEM
+    // parameters nested accepted intervals share anchor entries and the threshold of a position is not unique
+    if (p.merge_metadata && !(p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == doc_len_.size())))
+        throw std::runtime_error("merge metadata (-M / -n) needs strict multi-MUM parameters (every document, one "
+                                 "occurrence each)");
+    auto finish = [&]() {
+        for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
+        stage_ms_[2] += scan_ms_[0];                    // the LCP column is gathered range by range inside the scan
+        stage_ms_[3] = scan_ms_[1];                     // k_scan (+ the window tables of the wide-document path)
+        stage_ms_[4] = scan_ms_[2];
+        stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     if (preset_ == 2) {                                 // stream handed over: scan it as it is
         producer_used_ = 0;
         scan(p);
         make_rows(p);
-        for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
-        stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        finish();
         return;
     }
     ev_[0]->start(stream_);
@@ -465,19 +608,25 @@ void Engine::run(const mmt_params& p) {
     ev_[1]->start(stream_);
     {
         int kind = producer_;
+        std::vector<uint64_t> hist;
+        d2h(hist, d_hist_.get(), 256, stream_);
+        const bool reserved = hist[0] || hist[1] || hist[2];
         if (kind == 0) {
             // automatic: prefix-free parsing, which wins by the redundancy of the collection (2.4x on the 16-haplotype
             // bench, 3x at 0.1 % divergence), unless the text holds bytes the parse reserves (<= 0x02) or there are
             // too few documents for the dictionary to be much smaller than the text (measured, 1 % divergence:
             // 3 x 4.6 Mbp 8.6 vs 12.7 ms, 4 x 30 Mbp 80 vs 108 ms for the direct sort; even at 6 documents)
             const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp" override
-            std::vector<uint32_t> hist;
-            d2h(hist, d_hist_.get(), 256, stream_);
-            const bool reserved = hist[0] || hist[1] || hist[2];
             const bool forced_pfp = env && std::string(env) == "pfp";
             const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
             kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
+            // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
+            if (wide_ && !reserved) kind = 2;
         }
+        if (kind == 1 && n_ >= NARROW_LIMIT)
+            throw std::runtime_error(reserved ? "texts of 2^32 characters or more must not contain the bytes 0x00-0x02 "
+                                                "(reserved by the prefix-free parse)"
+                                              : "the direct suffix sort handles texts below 2^32 - 4096 characters");
         // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
         // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of
         // short phrase suffixes (all occurrences of a trigger window) small (gpurun sweeps)
@@ -487,30 +636,58 @@ void Engine::run(const mmt_params& p) {
         producer_used_ = kind;
     }
     ev_[1]->stop(stream_);
-    const bool lean = lean_ || wants_lean();
+    const bool lean = lean_ || wide_ || wants_lean();
     if (lean) release_sort_scratch();
     ev_[2]->start(stream_); lcp_bwt(); ev_[2]->stop(stream_);
-    if (lean && !k::scan_needs_wide_docs(doc_len_.size())) { d_plcp_a_.release(); d_plcp_b_.release(); d_long_.release(); }
+    if (lean) d_long_.release();
     scan(p);
+    // the PLCP column is dead after a single-range scan (copy_lcp reads the LCP column then)
+    if (lean && lcp_whole_) d_plcp_a_.release();
+    if (lean) { d_wpre_.release(); d_wsuf_.release(); d_wide_.release(); d_cand_.release(); }
     make_rows(p);
-    for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
-    stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    finish();
 }
 
 void Engine::parse_only(bool revcomp, uint32_t w, uint32_t p) {
     MMT_HIP(hipSetDevice(device_));
     if (doc_len_.empty()) throw std::runtime_error("no input");
+    if (!input_valid_) throw std::runtime_error("the engine holds no input: call set_input first");
     build_text(revcomp);
-    pfp_parse(w, p);
+    pfp_parse(w, p, true);
 }
 
 void Engine::copy_text(uint8_t* out) const {
     MMT_HIP(hipMemcpy(out, d_text_.get(), n_, hipMemcpyDeviceToHost));
 }
-void Engine::copy_sa(uint32_t* out) const { MMT_HIP(hipMemcpy(out, d_sa_.get(), n_ * 4, hipMemcpyDeviceToHost)); }
-void Engine::copy_lcp(uint32_t* out) const { MMT_HIP(hipMemcpy(out, d_lcp_.get(), n_ * 4, hipMemcpyDeviceToHost)); }
+void Engine::copy_sa(uint32_t* out) const {
+    if (wide_ && n_ >= NARROW_LIMIT) throw std::runtime_error("40-bit suffix array: use the 64-bit accessor");
+    MMT_HIP(hipMemcpy(out, d_sa_.get(), n_ * 4, hipMemcpyDeviceToHost));
+}
+void Engine::copy_sa64(uint64_t* out) const {
+    std::vector<uint32_t> lo(n_);
+    MMT_HIP(hipMemcpy(lo.data(), d_sa_.get(), n_ * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> hi;
+    if (wide_) { hi.resize(n_); MMT_HIP(hipMemcpy(hi.data(), d_sa_hi_.get(), n_, hipMemcpyDeviceToHost)); }
+    for (uint64_t j = 0; j < n_; j++) out[j] = (uint64_t)lo[j] | (wide_ ? (uint64_t)hi[j] << 32 : 0);
+}
+void Engine::copy_lcp(uint32_t* out) {
+    if (lcp_whole_) { MMT_HIP(hipMemcpy(out, d_lcp_.get(), n_ * 4, hipMemcpyDeviceToHost)); return; }
+    // the run scanned the stream range by range: gather the column again, piece by piece
+    if (!d_plcp_a_.get()) throw std::runtime_error("the LCP column of this run is gone");
+    const uint64_t piece = 1ull << 26;
+    DevBuf<uint32_t> buf;
+    buf.ensure(piece + 16);
+    for (uint64_t j0 = 0; j0 < n_; j0 += piece) {
+        const uint64_t c = std::min(piece, n_ - j0);
+        k::lcp_gather(d_plcp_a_.get(), sa_col(), j0, c, buf.get(), stream_);
+        MMT_HIP(hipMemcpyAsync(out + j0, buf.get(), c * 4, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+    }
+}
 void Engine::copy_bwt(uint8_t* out) const { MMT_HIP(hipMemcpy(out, d_bwt_.get(), n_, hipMemcpyDeviceToHost)); }
 void Engine::copy_candidates(uint32_t* out) const {
+    if (scan_ranges_ > 1) throw std::runtime_error("candidates are kept for single-range scans only");
+    if (n_cand_ && !d_cand_.get()) throw std::runtime_error("the candidate list of this run was released (lean mode)");
     if (n_cand_) MMT_HIP(hipMemcpy(out, d_cand_.get(), n_cand_ * sizeof(k::Cand), hipMemcpyDeviceToHost));
 }
 void Engine::copy_thresh(uint16_t* out) const {

@@ -47,9 +47,13 @@ public:
     void set_text_host(const uint8_t* text, uint64_t n, const uint64_t* doc_len, size_t n_docs, bool revcomp);
     void set_stream_host(const uint32_t* sa, const uint32_t* lcp, const uint8_t* bwt, uint64_t entries,
                          const uint64_t* doc_len, size_t n_docs, bool revcomp);
+    // the same for streams of any length: 40-bit suffix-array entries as low word + high byte (the layout of the
+    // reference's .sa dump, include/pfp_lcp_mum.hpp:323-369, split into two arrays)
+    void set_stream_host40(const uint32_t* sa_lo, const uint8_t* sa_hi, const uint32_t* lcp, const uint8_t* bwt,
+                           uint64_t entries, const uint64_t* doc_len, size_t n_docs, bool revcomp);
     void run(const mmt_params& p);
-    // Same job for host-resident input of any size: if the text exceeds max_text characters (0 = the
-    // 32-bit suffix-array limit) the documents are processed as anchor partitions and merged
+    // Same job for host-resident input of any size: if the text exceeds max_text characters (0 = what fits the
+    // device memory as one suffix array) the documents are processed as anchor partitions and merged
     // (strict multi-MUMs only, like the reference's merge).
     void run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
                               uint64_t max_text);
@@ -94,15 +98,20 @@ public:
 
     // stage introspection
     void copy_text(uint8_t* out) const;
-    void copy_sa(uint32_t* out) const;
-    void copy_lcp(uint32_t* out) const;
+    void copy_sa(uint32_t* out) const;          // narrow runs only
+    void copy_sa64(uint64_t* out) const;
+    void copy_lcp(uint32_t* out);
     void copy_bwt(uint8_t* out) const;
     size_t n_candidates() const { return n_cand_; }
     void copy_candidates(uint32_t* out) const;
     size_t thresh_len() const { return thresh_len_; }
     void copy_thresh(uint16_t* out) const;
     const uint16_t* thresh_device() const { return d_thresh_.get(); }
-    const uint32_t* isa_device() const { return d_rank_.get(); }
+    const uint32_t* isa_device() const { return d_rank_.get(); }        // narrow runs
+    const uint64_t* isa_device64() const { return d_rank64_.get(); }    // wide runs
+    bool wide() const { return wide_; }
+    SaCol sa_col() const { SaCol c; c.lo = d_sa_.get(); c.hi = wide_ ? d_sa_hi_.get() : nullptr; return c; }
+    size_t scan_ranges() const { return scan_ranges_; }
     const float* stage_ms() const { return stage_ms_; }
     DevBuf<uint8_t>& scratch() { return d_temp_; }
 
@@ -110,7 +119,7 @@ private:
     void layout_docs(bool revcomp);
     void build_text(bool revcomp);
     void suffix_sort();
-    void pfp_parse(uint32_t w, uint32_t p);
+    void pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs);
     void suffix_sort_pfp(uint32_t w, uint32_t p);
     void lcp_bwt();
     void scan(const mmt_params& p);
@@ -127,13 +136,20 @@ private:
     DevBuf<uint64_t> d_doc_base_, d_doc_start_;
     bool revcomp_ = true;
     uint64_t n_ = 0;
+    bool wide_ = false;                   // this text runs with 40-bit positions (wide.hpp)
+    bool input_valid_ = false;
     int preset_ = 0;                      // 0: build everything, 1: text handed over, 2: stream handed over
 
     // columns
-    DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_;
-    DevBuf<uint32_t> d_hist_, d_sa_, d_rank_, d_lcp_, d_count_, d_plcp_a_, d_plcp_b_;
+    DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_, d_sa_hi_;
+    DevBuf<uint64_t> d_hist_, d_rank64_;
+    DevBuf<uint32_t> d_sa_, d_rank_, d_lcp_, d_count_, d_plcp_a_;
     DevBuf<uint8_t> d_long_;
-    DevBuf<uint32_t> d_wide_;             // wide scan: BWT change marks, replaced by their running maximum
+    // scan of more than ~1000 documents: window tables of the scanned range (block-wise prefix / suffix minima of the
+    // LCP column, BWT change marks replaced by their running maximum)
+    DevBuf<uint32_t> d_wpre_, d_wsuf_, d_wide_;
+    bool lcp_whole_ = false;              // d_lcp_ holds the LCP column of the whole stream (one scan range)
+    size_t scan_ranges_ = 1;
     DoublingSorter sorter_;
     int sort_rounds_ = 0;
     std::unique_ptr<PfpState> pfp_{new PfpState()};
@@ -141,12 +157,13 @@ private:
     int producer_ = 0, producer_used_ = 1;
     uint32_t pfp_w_ = 10, pfp_p_ = 100;
     // scan
-    DevBuf<k::Cand> d_cand_, d_rows_;
+    DevBuf<k::Cand> d_cand_;
+    DevBuf<k::Row> d_rows_;
     DevBuf<uint16_t> d_thresh_;
     size_t n_cand_ = 0, thresh_len_ = 0;
     // A6 on the device
     DevBuf<uint64_t> d_doc_len_, d_rkeys_a_, d_rkeys_b_, d_tlen64_, d_toff_, d_occ64_, d_ooff_, d_omdoc_;
-    DevBuf<uint32_t> d_rvals_a_, d_order_, d_keep_, d_tlen_, d_ridx_, d_wpos_, d_wdoc_, d_olen_;
+    DevBuf<uint32_t> d_rvals_a_, d_rvals_b_, d_order_, d_keep_, d_tlen_, d_ridx_, d_wpos_, d_wdoc_, d_olen_;
     DevBuf<int64_t> d_slot_off_, d_ooffs_;
     DevBuf<uint8_t> d_slot_st_, d_ost_;
     DevBuf<char> d_otext_;
@@ -166,6 +183,9 @@ private:
     uint64_t num_distinct_eff_ = 0;
     float stage_ms_[8] = {0};
     std::unique_ptr<EventPair> ev_[6];
+    std::vector<std::unique_ptr<EventPair>> range_ev_;      // per scan range: LCP gather, scan kernel, verification
+    std::vector<int> range_ev_kind_;
+    float scan_ms_[3] = {0, 0, 0};
 };
 
 // decimal formatting shared with the merge output

@@ -12,6 +12,7 @@
 
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "wide.hpp"
 
 namespace mmt { namespace k {
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
                                                        const uint64_t* __restrict__ doc_base,
                                                        const uint64_t* __restrict__ doc_start, uint32_t n_docs,
                                                        uint8_t* __restrict__ text, uint64_t n,
-                                                       uint32_t* __restrict__ hist) {
+                                                       unsigned long long* __restrict__ hist) {
     __shared__ uint32_t s_hist[256];
     __shared__ uint8_t s_up[256], s_rc[256], s_slot[256];
     __shared__ uint64_t s_start[MAXD + 1], s_base[MAXD + 1];
@@ -155,16 +156,16 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += BLOCK)
-        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+        if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
 }
 
 void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
-                bool /*revcomp*/, uint8_t* text, uint64_t n, uint32_t* hist, hipStream_t s) {
+                bool /*revcomp*/, uint8_t* text, uint64_t n, uint64_t* hist, hipStream_t s) {
     constexpr int B = 256;
     const uint64_t tiles = (n + (uint64_t)B * 16 - 1) / ((uint64_t)B * 16);
     const unsigned grid = (unsigned)std::min<uint64_t>(tiles ? tiles : 1, 256u * 16u);
     hipLaunchKernelGGL((k_build_text<B, 1023>), dim3(grid), dim3(B), 0, s, raw, d_doc_base, d_doc_start, n_docs, text, n,
-                       hist);
+                       reinterpret_cast<unsigned long long*>(hist));
     MMT_HIP(hipGetLastError());
 }
 
@@ -491,25 +492,39 @@ __device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
 //   1. k_irr_lcp: in suffix-array order, the entries whose BWT byte differs from
 //      the entry before are the irreducible ones; their LCP is computed by plain
 //      comparison of the two suffixes (their sum is O(n log n), Karkkainen et
-//      al.) and K[sa[j]] = LCP + sa[j] is stored at the text position.  Entries
-//      are compacted per workgroup first so that every lane compares; matches
-//      longer than IRR_STEPS * 8 characters go to a list for k_long_lcp.
-//   2. K is non-decreasing along the text where it is defined and
-//      PLCP[i] = PLCP[i-1] - 1 at every reducible position: an inclusive
-//      max-scan of K (zero elsewhere) gives PLCP[i] + i for all i.
-//   3. k_lcp_gather: lcp[j] = K'[sa[j]] - sa[j].
+//      al.) and stored at the text position: plcp[sa[j]] = LCP (every other
+//      position keeps 0).  Entries are compacted per workgroup first so that
+//      every lane compares; matches longer than IRR_STEPS * 8 characters go to a
+//      list for k_long_lcp.
+//   2. PLCP[i] + i is non-decreasing along the text and PLCP[i] = PLCP[i-1] - 1
+//      at every reducible position: PLCP[i] = max_{i' <= i}(plcp[i'] + i') - i,
+//      one inclusive max-scan (plcp_running_max; the sums are formed in
+//      registers, 64 bits wide when the text is, the column stays 32 bits).
+//   3. k_lcp_gather: lcp[j] = PLCP[sa[j]] -- for any range of suffix-array
+//      positions, so that a text beyond one LCP column is scanned range by range.
 // Also records the suffix ranks of the anchor document (positions < anchor_len),
 // which the multi-GPU re-sort needs.
+// SA = suffix-array accessor (wide.hpp); its idx_t holds positions and ranks.
 // ============================================================================
-struct LongLcp { uint32_t p, q, h; };
+template <typename I>
+struct LongLcpT { I p, q; uint32_t h; };
 constexpr int IRR_STEPS = 24;
 
-template <int BLOCK, int PER>
-__global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ text, uint32_t n,
-                                                   const uint32_t* __restrict__ sa, const uint8_t* __restrict__ bwt,
-                                                   uint32_t* __restrict__ K, uint32_t* __restrict__ anchor_rank,
-                                                   uint32_t anchor_len, LongLcp* __restrict__ longs,
+// number of characters two suffixes at p and q can share at most, capped (wide.hpp)
+template <typename I>
+__device__ __forceinline__ uint32_t lcp_limit(I n, I p, I q) {
+    const I room = n - (p > q ? p : q);
+    return room < (I)LCP_CAP ? (uint32_t)room : LCP_CAP;
+}
+
+template <int BLOCK, int PER, typename SA>
+__global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ text, typename SA::idx_t n, SA sa,
+                                                   const uint8_t* __restrict__ bwt, uint32_t* __restrict__ plcp,
+                                                   typename SA::idx_t* __restrict__ anchor_rank,
+                                                   typename SA::idx_t anchor_len,
+                                                   LongLcpT<typename SA::idx_t>* __restrict__ longs,
                                                    uint32_t* __restrict__ long_count, uint32_t long_cap) {
+    using I = typename SA::idx_t;
     constexpr int TILE = BLOCK * PER;
     __shared__ uint32_t s_q[TILE];
     __shared__ uint32_t s_n;
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
         if (j < n) {
             const uint8_t b = bwt[j];
             irr = j == 0 || b == 0 || b != bwt[j - 1];
-            if (anchor_rank) { const uint32_t p = sa[j]; if (p < anchor_len) anchor_rank[p] = (uint32_t)j; }
+            if (anchor_rank) { const I p = sa.get(j); if (p < anchor_len) anchor_rank[p] = (I)j; }
         }
         const uint64_t m = __ballot(irr);
         uint32_t at = 0;
@@ -537,14 +552,14 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
     for (uint32_t wbase = 0; wbase < cnt; wbase += BLOCK) {          // uniform trip count: the list slots are handed out per wave
         const uint32_t wi = wbase + threadIdx.x;
         bool queue = false;
-        uint32_t p = 0, qq = 0, h = 0;
+        I p = 0, qq = 0;
+        uint32_t h = 0;
         if (wi < cnt) {
             const uint64_t j = base + s_q[wi];
-            p = sa[j];
-            if (j == 0) K[p] = p;                                    // no predecessor: LCP 0
-            else {
-                qq = sa[j - 1];
-                const uint32_t limit = n - (p > qq ? p : qq);       // the shorter suffix ends first
+            p = sa.get(j);
+            if (j != 0) {                                            // j == 0: no predecessor, LCP 0 (the cleared value)
+                qq = sa.get(j - 1);
+                const uint32_t limit = lcp_limit<I>(n, p, qq);      // the shorter suffix ends first
                 bool done = false;
                 for (int step = 0; step < IRR_STEPS && h < limit; step++) {
                     const uint64_t x = load_u64(text + p + h), y = load_u64(text + qq + h);
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void k_irr_lcp(const uint8_t* __restrict__ t
                     h += 8;
                 }
                 if (h >= limit) { h = limit; done = true; }
-                if (done) K[p] = h + p;
+                if (done) plcp[p] = h;
                 else queue = true;
             }
         }
@@ -582,13 +597,14 @@ constexpr int LONG_UNROLL = 8, HUGE_WAVES = 16;
 constexpr uint32_t LONG_SLICE = LONG_UNROLL * 512, LONG_WAVE_MAX = 64 * 1024;
 
 // first mismatch of text[p + base ..) and text[q + base ..) within one 4 KB slice (0xffffffff: none); wave-uniform
-__device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ text, uint32_t p, uint32_t q, uint32_t base,
+template <typename I>
+__device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ text, I p, I q, uint32_t base,
                                                    uint32_t limit, uint32_t lane) {
     // 8-byte loads at addresses that are multiples of 8 (a misaligned wave-wide load is served lane by lane, ~230 ns per
     // instruction on this part); the suffix bytes are funnelled out of two neighbouring words
-    const uint8_t* pa = text + (p & ~7u);
-    const uint8_t* qa = text + (q & ~7u);
-    const uint32_t sp = (p & 7u) * 8, sq = (q & 7u) * 8;
+    const uint8_t* pa = text + (p & ~(I)7);
+    const uint8_t* qa = text + (q & ~(I)7);
+    const uint32_t sp = (uint32_t)(p & 7u) * 8, sq = (uint32_t)(q & 7u) * 8;
     uint64_t x[LONG_UNROLL], y[LONG_UNROLL];
 #pragma unroll
     for (int u = 0; u < LONG_UNROLL; u++) {
@@ -614,14 +630,15 @@ __device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ t
     return first;
 }
 
-__global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, LongLcp* __restrict__ longs, uint32_t count,
-                           uint32_t* __restrict__ K, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count) {
+template <typename I>
+__global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, LongLcpT<I>* __restrict__ longs, uint32_t count,
+                           uint32_t* __restrict__ plcp, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count) {
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= count) return;
-    const uint32_t p = longs[w].p, q = longs[w].q;
+    const I p = longs[w].p, q = longs[w].q;
     uint32_t h = longs[w].h;
-    const uint32_t limit = n - (p > q ? p : q);
-    const uint32_t stop = h + LONG_WAVE_MAX < limit ? h + LONG_WAVE_MAX : limit;
+    const uint32_t limit = lcp_limit<I>(n, p, q);
+    const uint32_t stop = limit - h > LONG_WAVE_MAX ? h + LONG_WAVE_MAX : limit;
     bool found = false;
     for (int step = 0; step < 8 && h < limit && !found; step++) {
         const uint32_t o = h + lane * 8;
@@ -636,32 +653,35 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, uint32_t n, LongLcp
         } else h += 512;
     }
     while (!found && h < stop) {
-        const uint32_t first = slice_mismatch(text, p, q, h, limit, lane);
+        const uint32_t first = slice_mismatch<I>(text, p, q, h, limit, lane);
         if (first != 0xffffffffu) { h = first; found = true; }
         else h += LONG_SLICE;
     }
     if (found || h >= limit) {
-        if (lane == 0) K[p] = (h > limit ? limit : h) + p;
+        if (lane == 0) plcp[p] = h > limit ? limit : h;
     } else if (lane == 0) {
         longs[w].h = h;
         huge_idx[atomicAdd(huge_count, 1u)] = w;
     }
 }
 
-__global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __restrict__ text, uint32_t n,
-                                                              const LongLcp* __restrict__ longs,
+template <typename I>
+__global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __restrict__ text, I n,
+                                                              const LongLcpT<I>* __restrict__ longs,
                                                               const uint32_t* __restrict__ huge_idx,
                                                               const uint32_t* __restrict__ huge_count,
-                                                              uint32_t* __restrict__ K) {
+                                                              uint32_t* __restrict__ plcp) {
     __shared__ uint32_t s_first[HUGE_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t total = *huge_count;
     for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
-        const LongLcp L = longs[huge_idx[e]];
-        const uint32_t p = L.p, q = L.q, limit = n - (p > q ? p : q);
+        const LongLcpT<I> L = longs[huge_idx[e]];
+        const I p = L.p, q = L.q;
+        const uint32_t limit = lcp_limit<I>(n, p, q);
         uint32_t h = L.h;
         while (h < limit) {
-            const uint32_t first = slice_mismatch(text, p, q, h + wave * LONG_SLICE, limit, lane);
+            // slices past the cap (wide texts only) compare nothing: slice_mismatch clamps every offset to `limit`
+            const uint32_t first = slice_mismatch<I>(text, p, q, h + wave * LONG_SLICE, limit, lane);
             if (lane == 0) s_first[wave] = first;
             __syncthreads();
             uint32_t best = 0xffffffffu;
@@ -669,50 +689,162 @@ __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __r
             for (int w = 0; w < HUGE_WAVES; w++) best = s_first[w] < best ? s_first[w] : best;
             __syncthreads();
             if (best != 0xffffffffu) { h = best; break; }
+            if (limit - h <= HUGE_WAVES * LONG_SLICE) { h = limit; break; }
             h += HUGE_WAVES * LONG_SLICE;
         }
-        if (threadIdx.x == 0) K[p] = (h > limit ? limit : h) + p;
+        if (threadIdx.x == 0) plcp[p] = h > limit ? limit : h;
     }
 }
 
-// four consecutive entries per thread: one 16-byte load of SA, four independent gathers in flight, one 16-byte store
-__global__ void k_lcp_gather(const uint32_t* __restrict__ Ks, const uint32_t* __restrict__ sa, uint32_t n,
-                             uint32_t* __restrict__ lcp) {
-    const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (j + 4 <= n) {
-        const uint4 p = *reinterpret_cast<const uint4*>(sa + j);
-        uint4 r;
-        r.x = Ks[p.x]; r.y = Ks[p.y]; r.z = Ks[p.z]; r.w = Ks[p.w];
-        r.x -= p.x; r.y -= p.y; r.z -= p.z; r.w -= p.w;
-        *reinterpret_cast<uint4*>(lcp + j) = r;
-    } else {
-        for (uint64_t t = j; t < n; t++) { const uint32_t p = sa[t]; lcp[t] = Ks[p] - p; }
+// plcp[i] <- max_{i' <= i}(plcp[i'] + i') - i, in place.  Three passes: workgroup maxima of plcp[i] + i, a small scan of
+// those, then the scan proper with the carry-in.  A = type of the sums (uint32_t while n < 2^32, else uint64_t).
+template <int BLOCK, int ITEMS, typename A>
+__global__ __launch_bounds__(BLOCK) void k_plcp_block_max(const uint32_t* __restrict__ plcp, uint64_t n,
+                                                          A* __restrict__ block_max) {
+    __shared__ A s_w[BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * BLOCK * ITEMS;
+    A m = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; q++) {                  // coalesced: consecutive threads read consecutive elements
+        const uint64_t i = base + (uint64_t)q * BLOCK + threadIdx.x;
+        if (i < n) { const A v = (A)plcp[i] + (A)i; m = v > m ? v : m; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const A y = __shfl_xor(m, o, 64); m = y > m ? y : m; }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A r = 0;
+        for (int w = 0; w < BLOCK / 64; w++) r = s_w[w] > r ? s_w[w] : r;
+        block_max[blockIdx.x] = r;
     }
 }
-
-void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
-                     uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
-                     uint32_t long_cap, hipStream_t s) {
-    constexpr int B = 256, PER = 8;
-    MMT_HIP(hipMemsetAsync(K, 0, (size_t)n * 4, s));
-    MMT_HIP(hipMemsetAsync(long_count, 0, 4, s));
-    hipLaunchKernelGGL((k_irr_lcp<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, sa, bwt, K, anchor_rank,
-                       anchor_len, static_cast<LongLcp*>(long_list), long_count, long_cap);
+// exclusive running maximum of the workgroup maxima (a few hundred thousand entries at most): one workgroup
+template <int BLOCK, typename A>
+__global__ __launch_bounds__(BLOCK) void k_plcp_carry(const A* __restrict__ block_max, uint32_t blocks, A* __restrict__ carry) {
+    __shared__ A s_w[BLOCK / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    A run = 0;
+    for (uint32_t b0 = 0; b0 < blocks; b0 += BLOCK) {
+        const uint32_t b = b0 + threadIdx.x;
+        const A own = b < blocks ? block_max[b] : (A)0;
+        A v = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const A y = __shfl_up(v, o, 64); if (lane >= (uint32_t)o && y > v) v = y; }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        A pre = run;
+        for (uint32_t w2 = 0; w2 < wave; w2++) pre = s_w[w2] > pre ? s_w[w2] : pre;
+        A excl = __shfl_up(v, 1, 64);
+        if (lane == 0) excl = 0;
+        excl = excl > pre ? excl : pre;
+        if (b < blocks) carry[b] = excl;
+        A tot = run;
+        for (int w2 = 0; w2 < BLOCK / 64; w2++) tot = s_w[w2] > tot ? s_w[w2] : tot;
+        run = tot;
+        __syncthreads();
+    }
+}
+template <int BLOCK, int ITEMS, typename A>
+__global__ __launch_bounds__(BLOCK) void k_plcp_scan(uint32_t* plcp, uint64_t n, const A* __restrict__ carry) {
+    __shared__ A s_w[BLOCK / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * BLOCK * ITEMS;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    A run = carry[blockIdx.x];
+    for (int q = 0; q < ITEMS; q++) {                  // ITEMS rounds of BLOCK consecutive elements
+        const uint64_t i = base + (uint64_t)q * BLOCK + threadIdx.x;
+        A v = i < n ? (A)plcp[i] + (A)i : (A)0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const A y = __shfl_up(v, o, 64); if (lane >= (uint32_t)o && y > v) v = y; }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        A pre = run;
+        for (uint32_t w2 = 0; w2 < wave; w2++) pre = s_w[w2] > pre ? s_w[w2] : pre;
+        v = v > pre ? v : pre;
+        if (i < n) plcp[i] = (uint32_t)(v - (A)i);
+        A tot = run;
+        for (int w2 = 0; w2 < BLOCK / 64; w2++) tot = s_w[w2] > tot ? s_w[w2] : tot;
+        run = tot;
+        __syncthreads();
+    }
+}
+template <typename A>
+static void plcp_running_max_typed(uint32_t* plcp, uint64_t n, void* scratch, hipStream_t s) {
+    constexpr int BLOCK = 256, ITEMS = 16;
+    const uint32_t blocks = (uint32_t)((n + (uint64_t)BLOCK * ITEMS - 1) / ((uint64_t)BLOCK * ITEMS));
+    A* bmax = static_cast<A*>(scratch);
+    A* carry = bmax + blocks;
+    hipLaunchKernelGGL((k_plcp_block_max<BLOCK, ITEMS, A>), dim3(blocks), dim3(BLOCK), 0, s, plcp, n, bmax);
+    hipLaunchKernelGGL((k_plcp_carry<1024, A>), dim3(1), dim3(1024), 0, s, bmax, blocks, carry);
+    hipLaunchKernelGGL((k_plcp_scan<BLOCK, ITEMS, A>), dim3(blocks), dim3(BLOCK), 0, s, plcp, n, carry);
     MMT_HIP(hipGetLastError());
 }
-void long_lcp(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* K, uint32_t* huge_idx,
-              uint32_t* huge_count, hipStream_t s) {
+size_t plcp_running_max_scratch(uint64_t n) { return ((n + 4095) / 4096) * 16 + 64; }
+void plcp_running_max(uint32_t* plcp, uint64_t n, void* scratch, hipStream_t s) {
+    if (!n) return;
+    if (n < NARROW_LIMIT) plcp_running_max_typed<uint32_t>(plcp, n, scratch, s);
+    else plcp_running_max_typed<uint64_t>(plcp, n, scratch, s);
+}
+
+// lcp[t] = PLCP[sa[j0 + t]] for t in [0, count): four consecutive entries per thread (one 16-byte load of SA, four
+// independent gathers in flight, one 16-byte store); j0 is a multiple of 4
+template <typename SA>
+__global__ void k_lcp_gather(const uint32_t* __restrict__ plcp, SA sa, uint64_t j0, uint64_t count,
+                             uint32_t* __restrict__ lcp) {
+    const uint64_t t = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (t + 4 <= count) {
+        typename SA::idx_t p[4];
+        sa.get4(j0 + t, p);
+        uint4 r;
+        r.x = plcp[p[0]]; r.y = plcp[p[1]]; r.z = plcp[p[2]]; r.w = plcp[p[3]];
+        *reinterpret_cast<uint4*>(lcp + t) = r;
+    } else {
+        for (uint64_t u = t; u < count; u++) lcp[u] = plcp[sa.get(j0 + u)];
+    }
+}
+
+template <typename SA>
+static void irreducible_lcp_typed(const uint8_t* text, uint64_t n, SaCol sa, const uint8_t* bwt, uint32_t* plcp,
+                                  void* anchor_rank, uint64_t anchor_len, void* long_list, uint32_t* long_count,
+                                  uint32_t long_cap, hipStream_t s) {
+    using I = typename SA::idx_t;
+    constexpr int B = 256, PER = 8;
+    hipLaunchKernelGGL((k_irr_lcp<B, PER, SA>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, (I)n, SA(sa), bwt, plcp,
+                       static_cast<I*>(anchor_rank), (I)anchor_len, static_cast<LongLcpT<I>*>(long_list), long_count,
+                       long_cap);
+}
+void irreducible_lcp(const uint8_t* text, uint64_t n, SaCol sa, const uint8_t* bwt, uint32_t* plcp, void* anchor_rank,
+                     uint64_t anchor_len, void* long_list, uint32_t* long_count, uint32_t long_cap, hipStream_t s) {
+    MMT_HIP(hipMemsetAsync(plcp, 0, (size_t)n * 4, s));
+    MMT_HIP(hipMemsetAsync(long_count, 0, 4, s));
+    if (sa.wide()) irreducible_lcp_typed<Sa40>(text, n, sa, bwt, plcp, anchor_rank, anchor_len, long_list, long_count, long_cap, s);
+    else irreducible_lcp_typed<Sa32>(text, n, sa, bwt, plcp, anchor_rank, anchor_len, long_list, long_count, long_cap, s);
+    MMT_HIP(hipGetLastError());
+}
+size_t long_lcp_record_bytes(bool wide) { return wide ? sizeof(LongLcpT<uint64_t>) : sizeof(LongLcpT<uint32_t>); }
+template <typename I>
+static void long_lcp_typed(const uint8_t* text, uint64_t n, void* long_list, uint32_t count, uint32_t* plcp,
+                           uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
+    hipLaunchKernelGGL(k_long_lcp<I>, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, (I)n,
+                       static_cast<LongLcpT<I>*>(long_list), count, plcp, huge_idx, huge_count);
+    const uint32_t blocks = count < 1024u ? count : 1024u;       // the list is read on the device: no host round trip
+    hipLaunchKernelGGL(k_huge_lcp<I>, dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, (I)n,
+                       static_cast<const LongLcpT<I>*>(long_list), huge_idx, huge_count, plcp);
+}
+void long_lcp(const uint8_t* text, uint64_t n, bool wide, void* long_list, uint32_t count, uint32_t* plcp,
+              uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
     if (!count) return;
     MMT_HIP(hipMemsetAsync(huge_count, 0, 4, s));
-    hipLaunchKernelGGL(k_long_lcp, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, n,
-                       static_cast<LongLcp*>(long_list), count, K, huge_idx, huge_count);
-    const uint32_t blocks = count < 1024u ? count : 1024u;       // the list is read on the device: no host round trip
-    hipLaunchKernelGGL(k_huge_lcp, dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, n,
-                       static_cast<const LongLcp*>(long_list), huge_idx, huge_count, K);
+    if (wide) long_lcp_typed<uint64_t>(text, n, long_list, count, plcp, huge_idx, huge_count, s);
+    else long_lcp_typed<uint32_t>(text, n, long_list, count, plcp, huge_idx, huge_count, s);
     MMT_HIP(hipGetLastError());
 }
-void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s) {
-    hipLaunchKernelGGL(k_lcp_gather, dim3(grid_for(n, 1024)), dim3(256), 0, s, Ks, sa, n, lcp);
+void lcp_gather(const uint32_t* plcp, SaCol sa, uint64_t j0, uint64_t count, uint32_t* lcp, hipStream_t s) {
+    if (!count) return;
+    if (sa.wide())
+        hipLaunchKernelGGL(k_lcp_gather<Sa40>, dim3(grid_for(count, 1024)), dim3(256), 0, s, plcp, Sa40(sa), j0, count, lcp);
+    else
+        hipLaunchKernelGGL(k_lcp_gather<Sa32>, dim3(grid_for(count, 1024)), dim3(256), 0, s, plcp, Sa32(sa), j0, count, lcp);
     MMT_HIP(hipGetLastError());
 }
 
@@ -879,7 +1011,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         }
     };
 
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1u) {
+    // closers below a.first belong to the range before this one (the columns then start with a left extension that
+    // only serves the walks): tiles are counted from the start of the columns, the first ones are skipped
+    const uint32_t jmin = a.first > 1u ? a.first : 1u;
+    for (uint32_t tile = blockIdx.x + a.first / TILE; tile < n_tiles; tile += gridDim.x, cur ^= 1u) {
         s_lcp = lcp_buf + cur * (span + 16);
         s_bwt = bwt_buf + cur * (span + 32);
         tbl = K0 == 0 ? s_lcp : s_T;                                        // level-0 table is the column itself
@@ -888,7 +1023,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         const uint32_t shift = (uint32_t)(tile0 - lds_lo);                  // LDS index of tile0
         const uint64_t hi = tile0 + TILE < a.n ? tile0 + TILE : a.n;       // one past last staged index
         // interior tiles (full halo, full length: all but the first and the last few) need no bounds checks
-        const bool interior = tile0 >= halo && tile0 + TILE <= a.n;
+        const bool interior = tile0 >= halo && tile0 >= a.first && tile0 + TILE <= a.n;
         const uint32_t staged = (uint32_t)(hi - lds_lo);
         const uint32_t groups = (staged + 3) >> 2;
         uint32_t qn = 0;                                                    // entries in this wave's queue
@@ -1004,7 +1139,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
                             bool ok = mv[t] > cv[t] && mv[t] >= a.min_len;
-                            if (!INT) ok = ok && tile0 + o + t >= 1 && tile0 + o + t < a.n && lj + t >= w;
+                            if (!INT) ok = ok && tile0 + o + t >= jmin && tile0 + o + t < a.n && lj + t >= w;
                             if (EXACT) ok = ok && ((chg4 >> (8 * t)) & 0xffu);
                             takes |= ok ? (1u << t) : 0u;
                         }
@@ -1075,6 +1210,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 // left the staged halo (uncapped modes / very large caps): continue in the global columns
                 const uint64_t j = lds_lo + lj;
                 uint64_t kpos = lds_lo;                                     // k = lds_lo, candidate start k - 1
+                bool fin = false;
                 while (kpos > 0) {
                     const uint32_t v = a.lcp[kpos - 1];
                     chg |= a.bwt[kpos] != a.bwt[kpos - 1];
@@ -1087,12 +1223,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                             if (g < a.capacity) a.out[g] = c;
                         }
                         m = v;
-                        if (m <= closing || m < a.min_len) break;
+                        if (m <= closing || m < a.min_len) { fin = true; break; }
                     }
                     kpos--;
-                    if (a.cap && j - (kpos - 1) > a.cap) break;
+                    if (a.cap && j - (kpos - 1) > a.cap) { fin = true; break; }
                 }
-            }
+                // ran off the left extension of a range that does not start the stream: the host repeats the range
+                if (!fin && a.more_left) atomicAdd(a.d_count + 4, 1u);
+            } else if (!done && a.more_left) atomicAdd(a.d_count + 4, 1u);
         }
         lds_barrier();
         const uint32_t filled = s_on < OUT_CAP ? s_on : OUT_CAP;
@@ -1159,7 +1297,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_wide(ScanArgs a, uint32_t w, int
     const uint32_t lane = threadIdx.x & 63;
     bool emit = false;
     Cand c{};
-    if (j64 > w && j64 < a.n) {                               // the candidate start k - 1 = j - w - 1 must exist
+    if (j64 > w && j64 >= a.first && j64 < a.n) {             // the candidate start k - 1 = j - w - 1 must exist
         const uint32_t j = (uint32_t)j64, k = j - w;
         uint32_t m = umin32(a.wide_suf[k], a.wide_pre[j - 1]);
         const uint32_t closing = a.lcp[j];
@@ -1172,6 +1310,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_wide(ScanArgs a, uint32_t w, int
                 }
             } else {
                 uint32_t kpos = k;
+                bool fin = false;
                 while (kpos > 0) {
                     const uint32_t v = a.lcp[kpos - 1];
                     chg |= a.bwt[kpos] != a.bwt[kpos - 1];
@@ -1183,11 +1322,12 @@ __global__ __launch_bounds__(BLOCK) void k_scan_wide(ScanArgs a, uint32_t w, int
                             if (g < a.capacity) a.out[g] = d;
                         }
                         m = v;
-                        if (m <= closing || m < a.min_len) break;
+                        if (m <= closing || m < a.min_len) { fin = true; break; }
                     }
                     kpos--;
-                    if (a.cap && j - (kpos - 1) > a.cap) break;
+                    if (a.cap && j - (kpos - 1) > a.cap) { fin = true; break; }
                 }
+                if (!fin && a.more_left) atomicAdd(a.d_count + 4, 1u);
             }
         }
     }
@@ -1238,7 +1378,8 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     size_t lds = (size_t)(halo + TILE + 16) * 12 + (size_t)(halo + TILE + 32) * 2 + (size_t)TILE * 2 +
                  (size_t)OUT_CAP * sizeof(Cand) + (size_t)(halo + TILE + 32);
     uint32_t n_tiles = grid_for(a.n, TILE);
-    unsigned grid = n_tiles < 256u * blocks_per_cu ? n_tiles : 256u * blocks_per_cu;
+    const uint32_t todo = n_tiles - a.first / TILE;        // tiles below a.first are skipped (a.first < a.n)
+    unsigned grid = todo < 256u * blocks_per_cu ? (todo ? todo : 1u) : 256u * blocks_per_cu;
     dim3 g(grid), b(B);
     auto go = [&](auto kernel) {
         MMT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1311,12 +1452,22 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
     return v;
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_counters) {
+// Candidates carry positions relative to the scanned range (a.base = suffix-array index of its entry 0; a.lcp is the
+// LCP column of the range); accepted rows leave with absolute positions.
+template <typename SA>
+struct VerifyArgsT {
+    const Cand* cand; uint32_t n_cand; SA sa; uint64_t base; const uint32_t* lcp; const uint64_t* d_doc_start;
+    uint32_t n_docs, num_distinct, max_doc_freq; int merge; uint16_t* thresh; Row* rows; uint32_t* d_row_count;
+};
+__device__ __forceinline__ Row make_row(const Cand& c, uint64_t base) {
+    Row r; r.start = base + c.start; r.cnt = c.end - c.start + 1; r.len = c.len; return r;
+}
+template <int WAVES, typename SA>
+__global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgsT<SA> a, int use_counters) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* ctr = reinterpret_cast<uint32_t*>(smem) + (size_t)(threadIdx.x >> 6) * a.n_docs;
-    __shared__ Cand s_rows[WAVES][64];       // accepted rows of this wave, flushed 64 at a time
-    Cand* my_rows = s_rows[threadIdx.x >> 6];
+    __shared__ Row s_rows[WAVES][64];       // accepted rows of this wave, flushed 64 at a time
+    Row* my_rows = s_rows[threadIdx.x >> 6];
     uint32_t n_my = 0;                        // wave-uniform
     const uint32_t lane = threadIdx.x & 63;
     if (use_counters) {
@@ -1333,7 +1484,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
             // <= 64 documents, at most one occurrence each, interval fits one wave
             uint64_t bit = 0;
             if (lane < cnt) {
-                uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[c.start + lane]);
+                uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + c.start + lane));
                 bit = 1ull << d;
                 if (d == 0) first0 = c.start + lane;
             }
@@ -1344,7 +1495,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
             for (uint32_t base = 0; base < cnt; base += 64) {
                 if (base + lane < cnt) {
                     uint32_t kk = c.start + base + lane;
-                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[kk]);
+                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + kk));
                     if (d >= a.n_docs) { fail = 1; }
                     else {
                         uint32_t old = atomicAdd(&ctr[d], 1u);
@@ -1358,7 +1509,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
             fail = wave_sum32(fail);
             for (uint32_t base = 0; base < cnt; base += 64) {               // undo the counters
                 if (base + lane < cnt) {
-                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[c.start + base + lane]);
+                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + c.start + base + lane));
                     if (d < a.n_docs) ctr[d] = 0;
                 }
             }
@@ -1371,11 +1522,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
                 uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
                 uint32_t nb = before > after ? before : after;
                 if (nb > 65535u) nb = 65535u;
-                a.thresh[(uint64_t)a.sa[first0] - a.d_doc_start[0]] = (uint16_t)nb;
+                a.thresh[(uint64_t)a.sa.get(a.base + first0) - a.d_doc_start[0]] = (uint16_t)nb;
             }
         }
         if (c.flags & CAND_LEFT_MAXIMAL) {
-            if (lane == 0) my_rows[n_my] = c;
+            if (lane == 0) my_rows[n_my] = make_row(c, a.base);
             n_my++;
             if (n_my == 64) {
                 uint32_t base = 0;
@@ -1398,11 +1549,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgs a, int use_cou
 // takes 64 / SUB candidates at a time, one per group of SUB lanes (document bitmap and first anchor entry by shuffles of
 // width SUB).  The merge-metadata runs of the multi-GPU path verify every structural interval, ten times the
 // candidates of a plain run.
-template <int WAVES, int SUB>
-__global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgs a) {
+template <int WAVES, int SUB, typename SA>
+__global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgsT<SA> a) {
     constexpr int PER = 64 / SUB;
-    __shared__ Cand s_rows[WAVES][64];       // accepted rows of this wave
-    Cand* my_rows = s_rows[threadIdx.x >> 6];
+    __shared__ Row s_rows[WAVES][64];       // accepted rows of this wave
+    Row* my_rows = s_rows[threadIdx.x >> 6];
     uint32_t n_my = 0;                        // wave-uniform
     const uint32_t lane = threadIdx.x & 63, sl = lane % SUB, grp = lane / SUB;
     const uint64_t wave = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
@@ -1422,7 +1573,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgs a) {
         const uint32_t cnt = live ? c.end - c.start + 1 : 0u;
         uint32_t bits = 0, first0 = 0xffffffffu;
         if (sl < cnt) {
-            const uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa[c.start + sl]);
+            const uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + c.start + sl));
             bits = 1u << d;
             if (d == 0) first0 = c.start + sl;
         }
@@ -1438,22 +1589,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgs a) {
             const uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
             uint32_t nb = before > after ? before : after;
             if (nb > 65535u) nb = 65535u;
-            a.thresh[(uint64_t)a.sa[first0] - a.d_doc_start[0]] = (uint16_t)nb;
+            a.thresh[(uint64_t)a.sa.get(a.base + first0) - a.d_doc_start[0]] = (uint16_t)nb;
         }
         const bool take = ok && sl == 0 && (c.flags & CAND_LEFT_MAXIMAL);
         const uint64_t m = __ballot(take);
         if (m) {
             const uint32_t k = (uint32_t)__popcll(m);
             if (n_my + k > 64) flush();
-            if (take) my_rows[n_my + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = c;
+            if (take) my_rows[n_my + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = make_row(c, a.base);
             n_my += k;
         }
     }
     if (n_my) flush();
 }
 
-void verify_candidates(const VerifyArgs& a, hipStream_t s) {
-    if (a.n_cand == 0) return;
+template <typename SA>
+static void verify_typed(const VerifyArgs& v, hipStream_t s) {
+    VerifyArgsT<SA> a;
+    a.cand = v.cand; a.n_cand = v.n_cand; a.sa = SA(v.sa); a.base = v.base; a.lcp = v.lcp; a.d_doc_start = v.d_doc_start;
+    a.n_docs = v.n_docs; a.num_distinct = v.num_distinct; a.max_doc_freq = v.max_doc_freq; a.merge = v.merge;
+    a.thresh = v.thresh; a.rows = v.rows; a.d_row_count = v.d_row_count;
     // every candidate interval has <= cap entries; the single-wave bitmap path needs
     // MUM mode, <= 64 documents (then an accepted interval has <= 64 entries)
     bool fast = a.max_doc_freq == 1 && a.n_docs <= 64;
@@ -1464,15 +1619,15 @@ void verify_candidates(const VerifyArgs& a, hipStream_t s) {
         const int sub = a.n_docs <= 8 ? 8 : (a.n_docs <= 16 ? 16 : 32);
         waves_needed = (a.n_cand + (uint64_t)(64 / sub) - 1) / (uint64_t)(64 / sub);
         unsigned grid = (unsigned)std::min<uint64_t>((waves_needed + W - 1) / W, 256u * 16u);
-        if (sub == 8) hipLaunchKernelGGL((k_verify_packed<W, 8>), dim3(grid), dim3(W * 64), 0, s, a);
-        else if (sub == 16) hipLaunchKernelGGL((k_verify_packed<W, 16>), dim3(grid), dim3(W * 64), 0, s, a);
-        else hipLaunchKernelGGL((k_verify_packed<W, 32>), dim3(grid), dim3(W * 64), 0, s, a);
+        if (sub == 8) hipLaunchKernelGGL((k_verify_packed<W, 8, SA>), dim3(grid), dim3(W * 64), 0, s, a);
+        else if (sub == 16) hipLaunchKernelGGL((k_verify_packed<W, 16, SA>), dim3(grid), dim3(W * 64), 0, s, a);
+        else hipLaunchKernelGGL((k_verify_packed<W, 32, SA>), dim3(grid), dim3(W * 64), 0, s, a);
     } else if (fast) {
         // intervals longer than 64 cannot be all-distinct with <= 64 docs, but the fast path
         // reads only 64 entries; they are rejected by the popcount == cnt test because cnt > 64
         constexpr int W = 4;
         unsigned grid = (unsigned)std::min<uint64_t>((waves_needed + W - 1) / W, 256u * 16u);
-        hipLaunchKernelGGL(k_verify<W>, dim3(grid), dim3(W * 64), 0, s, a, 0);
+        hipLaunchKernelGGL((k_verify<W, SA>), dim3(grid), dim3(W * 64), 0, s, a, 0);
     } else {
         size_t per_wave = (size_t)a.n_docs * 4;
         int W = per_wave * 4 <= 144 * 1024 ? 4 : (per_wave * 2 <= 144 * 1024 ? 2 : 1);
@@ -1484,11 +1639,15 @@ void verify_candidates(const VerifyArgs& a, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, a, 1);
         };
-        if (W == 4) launch(k_verify<4>, 256);
-        else if (W == 2) launch(k_verify<2>, 128);
-        else launch(k_verify<1>, 64);
+        if (W == 4) launch(k_verify<4, SA>, 256);
+        else if (W == 2) launch(k_verify<2, SA>, 128);
+        else launch(k_verify<1, SA>, 64);
     }
     MMT_HIP(hipGetLastError());
+}
+void verify_candidates(const VerifyArgs& a, hipStream_t s) {
+    if (a.n_cand == 0) return;
+    if (a.sa.wide()) verify_typed<Sa40>(a, s); else verify_typed<Sa32>(a, s);
 }
 
 // ============================================================================

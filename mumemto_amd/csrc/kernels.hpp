@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "wide.hpp"
+
 namespace mmt { namespace k {
 
 // A candidate LCP interval [start, end] (real-suffix index space) of value len.
@@ -12,12 +14,17 @@ struct Cand {
     uint32_t start, end, len, flags;  // flags bit0: BWT characters not all equal (left-maximal)
 };
 static const uint32_t CAND_LEFT_MAXIMAL = 1u;
+// An accepted row: suffix-array interval [start, start + cnt) of value len (absolute positions, any text size).
+struct Row {
+    uint64_t start;
+    uint32_t cnt, len;
+};
 
 // ---- A1 text layout ---------------------------------------------------------
 // text[p] for p in [0,n): UPPER(F_d) '$' [revcomp(UPPER(F_d)) '$'] per document;
 // hist[256] += byte counts of the text.  d_doc_base / d_doc_start: N+1 entries.
 void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
-                bool revcomp, uint8_t* text, uint64_t n, uint32_t* hist, hipStream_t s);
+                bool revcomp, uint8_t* text, uint64_t n, uint64_t* hist, hipStream_t s);
 
 // ---- A8 direct suffix sort (prefix doubling) --------------------------------
 // keys[i] = first `chars` symbols of suffix i, `bits` per symbol via code[256]
@@ -58,31 +65,40 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
 
 // ---- LCP / BWT columns of the stream ----------------------------------------
 // text must be readable (zero padded) up to n + 64.
-// ISA-free LCP construction (see kernels.hip): K (n entries, cleared here) receives LCP + position at the
-// irreducible suffixes; matches longer than 192 characters are queued (12-byte records, long_cap of them) for
-// long_lcp; after an inclusive max-scan Ks of K, lcp_gather writes the column.  anchor_rank (optional) receives the
-// suffix ranks of the text positions below anchor_len.
-void irreducible_lcp(const uint8_t* text, uint32_t n, const uint32_t* sa, const uint8_t* bwt, uint32_t* K,
-                     uint32_t* anchor_rank, uint32_t anchor_len, void* long_list, uint32_t* long_count,
-                     uint32_t long_cap, hipStream_t s);
+// ISA-free LCP construction (see kernels.hip): plcp (n entries, cleared here) receives the LCP at the text position of
+// every irreducible suffix; matches longer than 192 characters are queued (long_lcp_record_bytes(wide) per record,
+// long_cap of them) for long_lcp; plcp_running_max then turns the column into PLCP (scratch of
+// plcp_running_max_scratch(n) bytes), and lcp_gather writes lcp[t] = PLCP[sa[j0 + t]] for any range of count
+// suffix-array positions (j0 a multiple of 4).  anchor_rank (optional; uint32_t entries narrow, uint64_t wide)
+// receives the suffix ranks of the text positions below anchor_len.
+void irreducible_lcp(const uint8_t* text, uint64_t n, SaCol sa, const uint8_t* bwt, uint32_t* plcp, void* anchor_rank,
+                     uint64_t anchor_len, void* long_list, uint32_t* long_count, uint32_t long_cap, hipStream_t s);
+size_t long_lcp_record_bytes(bool wide);
 // huge_idx (count entries) / huge_count: scratch for the matches that outgrow one wave (see kernels.hip)
-void long_lcp(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* K, uint32_t* huge_idx,
-              uint32_t* huge_count, hipStream_t s);
-void lcp_gather(const uint32_t* Ks, const uint32_t* sa, uint32_t n, uint32_t* lcp, hipStream_t s);
+void long_lcp(const uint8_t* text, uint64_t n, bool wide, void* long_list, uint32_t count, uint32_t* plcp,
+              uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s);
+size_t plcp_running_max_scratch(uint64_t n);
+void plcp_running_max(uint32_t* plcp, uint64_t n, void* scratch, hipStream_t s);
+void lcp_gather(const uint32_t* plcp, SaCol sa, uint64_t j0, uint64_t count, uint32_t* lcp, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
 
 // ---- A5 match scan -----------------------------------------------------------
 struct ScanArgs {
+    // The columns of one range of the suffix array: entry 0 may lie anywhere in the stream (a text beyond one LCP
+    // column is scanned range by range); closing positions below `first` belong to the range before, the entries
+    // before `first` only serve the walks to the left.  lcp and bwt + 0 must be 16-byte aligned.
     const uint32_t* lcp;
     const uint8_t* bwt;
     uint32_t n;
+    uint32_t first = 0;
+    int more_left = 0;      // entry 0 is not the start of the stream: a walk that reaches it is reported in d_count[4]
     uint32_t min_len;
     uint32_t num_distinct;  // interval size lower bound
     uint32_t cap;           // interval size upper bound, 0 = none
     int emit_all;           // 1: emit structural candidates regardless of the BWT test (merge mode)
     Cand* out;
     uint32_t capacity;
-    uint32_t* d_count;      // total candidates found (may exceed capacity)
+    uint32_t* d_count;      // [0] total candidates found (may exceed capacity); [4] walks that ran off the range
     // windows beyond one LDS tile (scan_needs_wide): block-wise prefix / suffix minima of the LCP column for the
     // window size num_distinct - 1 and the position of the last BWT change at or before every entry
     const uint32_t* wide_pre = nullptr;
@@ -99,17 +115,18 @@ void scan_wide_prepare(const uint32_t* lcp, const uint8_t* bwt, uint32_t n, uint
                        uint32_t* suf, uint32_t* chg, hipStream_t s);
 
 struct VerifyArgs {
-    const Cand* cand;
+    const Cand* cand;             // positions relative to the scanned range
     uint32_t n_cand;
-    const uint32_t* sa;
-    const uint32_t* lcp;
+    SaCol sa;                     // the whole suffix array
+    uint64_t base;                // suffix-array index of entry 0 of the scanned range
+    const uint32_t* lcp;          // LCP column of the scanned range
     const uint64_t* d_doc_start;  // N+1
     uint32_t n_docs;
     uint32_t num_distinct;
     uint32_t max_doc_freq;        // 0 = unlimited
     int merge;                    // record thresholds
     uint16_t* thresh;             // 2*(L_0+1) entries (merge only)
-    Cand* rows;                   // accepted + left-maximal
+    Row* rows;                    // accepted + left-maximal, appended at *d_row_count
     uint32_t* d_row_count;
 };
 void verify_candidates(const VerifyArgs& a, hipStream_t s);

@@ -212,9 +212,18 @@ void sort_like_direct(Engine& e, MergedRows& m) {
     DevBuf<uint32_t> key_a, key_b;
     key_a.ensure(n); key_b.ensure(n); M.vals_a.ensure(n + 1); M.vals_b.ensure(n + 1); M.d_count.ensure(4);
     MMT_HIP(hipMemsetAsync(M.d_count.get(), 0, 16, st));
-    mk::rank_keys(m.d_offsets.get(), (uint32_t)n, (uint32_t)m.n_docs, e.isa_device(), e.doc_len()[0], key_a.get(),
-                  M.vals_a.get(), M.d_count.get() + 1, st);
-    prims::sort_pairs_u32_u32(e.scratch(), key_a.get(), key_b.get(), M.vals_a.get(), M.vals_b.get(), n, 0, 32, st);
+    if (e.wide()) {
+        DevBuf<uint64_t> k64_a, k64_b;
+        k64_a.ensure(n); k64_b.ensure(n);
+        mk::rank_keys64(m.d_offsets.get(), (uint32_t)n, (uint32_t)m.n_docs, e.isa_device64(), e.doc_len()[0], k64_a.get(),
+                        M.vals_a.get(), M.d_count.get() + 1, st);
+        prims::sort_pairs_u64_u32(e.scratch(), k64_a.get(), k64_b.get(), M.vals_a.get(), M.vals_b.get(), n, 0, 40, st);
+        MMT_HIP(hipStreamSynchronize(st));
+    } else {
+        mk::rank_keys(m.d_offsets.get(), (uint32_t)n, (uint32_t)m.n_docs, e.isa_device(), e.doc_len()[0], key_a.get(),
+                      M.vals_a.get(), M.d_count.get() + 1, st);
+        prims::sort_pairs_u32_u32(e.scratch(), key_a.get(), key_b.get(), M.vals_a.get(), M.vals_b.get(), n, 0, 32, st);
+    }
     DevBuf<uint32_t> len2; DevBuf<int64_t> off2; DevBuf<uint8_t> st2;
     len2.ensure(n + 1); off2.ensure(n * m.n_docs + 1); st2.ensure(n * m.n_docs + 1);
     mk::permute_rows(M.vals_b.get(), (uint32_t)n, (uint32_t)m.n_docs, m.d_length.get(), m.d_offsets.get(),

@@ -139,6 +139,24 @@ __global__ void k_rank_keys(const int64_t* __restrict__ off, uint32_t n, uint32_
     if (o < 0 || (uint64_t)o >= anchor_len) { atomicOr(bad, 1u); keys[r] = 0; return; }
     keys[r] = isa[o];
 }
+// the same with 40-bit suffix ranks (wide runs)
+__global__ void k_rank_keys64(const int64_t* __restrict__ off, uint32_t n, uint32_t n_docs,
+                              const uint64_t* __restrict__ isa, uint64_t anchor_len, uint64_t* __restrict__ keys,
+                              uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t o = off[(uint64_t)r * n_docs];
+    vals[r] = r;
+    if (o < 0 || (uint64_t)o >= anchor_len) { atomicOr(bad, 1u); keys[r] = 0; return; }
+    keys[r] = isa[o];
+}
+void rank_keys64(const int64_t* off, uint32_t n, uint32_t n_docs, const uint64_t* isa, uint64_t anchor_len,
+                 uint64_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_rank_keys64, dim3(grid_for(n, 256)), dim3(256), 0, s, off, n, n_docs, isa, anchor_len, keys,
+                       vals, bad);
+    MMT_HIP(hipGetLastError());
+}
 void rank_keys(const int64_t* off, uint32_t n, uint32_t n_docs, const uint32_t* isa, uint64_t anchor_len,
                uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t s) {
     if (!n) return;

@@ -47,6 +47,8 @@ void permute_rows(const uint32_t* perm, uint32_t n, uint32_t n_docs, const uint3
 // keys[r] = isa[offsets[r * n_docs]] (suffix rank of the anchor occurrence), vals[r] = r
 void rank_keys(const int64_t* off, uint32_t n, uint32_t n_docs, const uint32_t* isa, uint64_t anchor_len,
                uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t s);
+void rank_keys64(const int64_t* off, uint32_t n, uint32_t n_docs, const uint64_t* isa, uint64_t anchor_len,
+                 uint64_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t s);
 // mumsio::serialize_mum (include/mumsio.hpp:311-320): LEN \t offsets \t strands \n; one wave per row
 void table_measure(const uint32_t* len, const int64_t* off, uint32_t n, uint32_t n_docs, uint64_t* text_len,
                    hipStream_t s);

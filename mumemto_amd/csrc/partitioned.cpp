@@ -1,4 +1,4 @@
-// partitioned.cpp -- collections whose text does not fit one suffix array.
+// partitioned.cpp -- collections whose text does not fit the device as one suffix array.
 //
 // The reference scales the same way (README.md:124-141): split the documents into
 // partitions that share document 0 (the anchor), run each partition with merge metadata
@@ -9,6 +9,7 @@
 // multi-MUMs only.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <exception>
 #include <stdexcept>
 #include <thread>
@@ -26,7 +27,15 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     std::vector<uint64_t> base(n_docs + 1, 0);
     uint64_t total = 0;
     for (size_t d = 0; d < n_docs; d++) { base[d + 1] = base[d] + doc_len[d]; total += mult * (doc_len[d] + 1); }
-    if (max_text == 0) max_text = 0xfffff000ull - 1;
+    if (max_text == 0) {
+        // One suffix array of n characters peaks at about PEAK_BYTES_PER_CHAR bytes of device memory per character
+        // (wide run: text 1, suffix array 5, BWT 1, then either the emitter tables or PLCP 4 + the scan range;
+        // measured with MUMEMTO_TIMING=1 on 94 x 64 Mbp: DESIGN.md); MMT_MAX_TEXT overrides (tests).
+        constexpr double PEAK_BYTES_PER_CHAR = 20.0;
+        const double avail = 0.92 * (double)pool::available(device_);
+        max_text = (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1));
+        if (const char* c = std::getenv("MMT_MAX_TEXT")) max_text = std::strtoull(c, nullptr, 10);
+    }
     partitions_used_ = 1;
     if (total <= max_text || n_docs < 3) {
         set_input_host(h_bases, doc_len, n_docs);
@@ -36,8 +45,9 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     const bool strict = p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == n_docs) &&
                         (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
     if (!strict)
-        throw std::runtime_error("the text (" + std::to_string(total) + " characters) exceeds one suffix array and only "
-                                 "strict multi-MUMs can be computed by partition + anchor merge");
+        throw std::runtime_error("the text (" + std::to_string(total) + " characters) does not fit the device as one "
+                                 "suffix array (limit " + std::to_string(max_text) + ") and only strict multi-MUMs "
+                                 "can be computed by partition + anchor merge (include/pfp_mum.hpp:178-183)");
     // contiguous groups of documents 1..N-1, each together with the anchor within max_text
     const uint64_t anchor_chars = mult * (doc_len[0] + 1);
     std::vector<std::pair<size_t, size_t>> groups;      // [first, last) document indices
@@ -134,7 +144,10 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions
     merged_text_ = format_merged(*this, merged_);
     download_merged(*this, merged_);
-    // publish as the result of this "run"
+    // publish as the result of this "run"; the per-partition input buffers are gone or about to go: a later run()
+    // needs a new set_input
+    d_bases_ = nullptr;
+    input_valid_ = false;
     doc_len_.assign(doc_len, doc_len + n_docs);
     HostRows& R = rows_;
     R = HostRows();

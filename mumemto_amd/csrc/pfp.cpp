@@ -1,5 +1,9 @@
 // pfp.cpp -- Engine methods of the PFP producer: parse (A2), dictionary / parse
 // structures (A3) and the suffix array of the text from them (A4).
+//
+// Text-sized quantities (trigger positions, phrase starts, stream offsets of groups and entries, the suffix-array
+// column) are 32 bits wide in a narrow run and 40 / 64 bits in a wide one (wide.hpp); everything indexed by phrase,
+// dictionary position or parse position is 32 bits in both.
 #include <algorithm>
 #include <chrono>
 #include <stdexcept>
@@ -19,13 +23,22 @@ static uint32_t read_u32(const uint32_t* d, hipStream_t s) {
     return v;
 }
 
+// exclusive prefix sum of 32-bit counts into a table of stream offsets
+static void offsets_from_counts(DevBuf<uint8_t>& temp, const uint32_t* counts, PosBuf& out, size_t n, hipStream_t s) {
+    if (out.wide()) prims::exclusive_sum_u32_to_u64(temp, counts, out.p64(), n, s);
+    else prims::exclusive_sum_u32(temp, counts, out.p32(), n, s);
+}
+
 // A2 + the dictionary half of A3: phrases, distinct phrases, dictionary text with its suffix
 // array / LCP, phrase ranks, parse.  Requires build_text() to have run.
-void Engine::pfp_parse(uint32_t w, uint32_t p) {
+// keep_dict_inputs: the phrase table and V stay (PREFIX.dict is written from them: -P / parse_only).
+void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     PfpState& S = *pfp_;
-    const uint32_t n = (uint32_t)n_;
+    const uint64_t n = n_;
+    const bool W = wide_;
+    const bool slim = (lean_ || wide_) && !keep_dict_inputs;       // give scratch back as soon as it is dead
     if (w < 1 || w > 32 || p < 1) throw std::runtime_error("PFP window must be in [1, 32] and the modulus positive");
-    std::vector<uint32_t> hist;
+    std::vector<uint64_t> hist;
     d2h(hist, d_hist_.get(), 256, stream_);
     if (hist[0] || hist[1] || hist[2])          // newscan.hpp:318: characters <= Dollar are not allowed
         throw std::runtime_error("input contains bytes <= 0x02, which the prefix-free parse reserves");
@@ -35,27 +48,32 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
 
     // -- triggers, phrase boundaries
     e0.start(st);
-    const uint32_t vlen = n + 1 + w;
+    const uint64_t vlen = n + 1 + w;
     S.vtext.ensure((size_t)vlen + 64);
     pk::make_vtext(d_text_.get(), n, w, S.vtext.get(), vlen + 64, st);
     const uint32_t tb = pk::trigger_blocks(n);
-    S.tmask.ensure(((size_t)n + 15) / 16 + 1); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
+    S.tmask.ensure((size_t)((n + 15) / 16) + 1); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
     pk::trigger_masks(d_text_.get(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
     S.err.ensure(4);
-    S.n_cuts = read_u32(S.toff.get() + (tb - 1), st) + read_u32(S.tcnt.get() + (tb - 1), st);   // size the cut list exactly
-    S.cuts.ensure((size_t)S.n_cuts + 1);
-    pk::trigger_cuts(S.tmask.get(), n, S.toff.get(), S.cuts.get(), st);
+    {
+        const uint64_t cuts64 = (uint64_t)read_u32(S.toff.get() + (tb - 1), st) + read_u32(S.tcnt.get() + (tb - 1), st);
+        if (cuts64 >= 0x7ffffffdull) throw std::runtime_error("more than 2^31 - 2 phrases (newscan.hpp:44)");
+        S.n_cuts = (uint32_t)cuts64;                                   // size the cut list exactly
+    }
+    S.cuts.ensure((size_t)S.n_cuts + 1, W);
+    pk::trigger_cuts(S.tmask.get(), n, S.toff.get(), S.cuts.get(), W, st);
     const uint32_t m = S.n_phrases = S.n_cuts + 1;
-    S.pstart.ensure(m); S.plen.ensure(m);
-    pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), st);
+    S.pstart.ensure(m, W); S.plen.ensure(m);
+    pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), W, st);
+    if (slim) { S.tmask.release(); S.tcnt.release(); S.toff.release(); S.cuts.release(); }
     e0.stop(st);
 
     // -- distinct phrases: fingerprints, sort, verified grouping
     e1.start(st);
     S.h1.ensure(m); S.pinfo.ensure((size_t)m * 16 + 16); S.hk_a.ensure(m); S.hk_b.ensure(m);
     S.iota.ensure(m); S.ord_a.ensure(m); S.order.ensure(m);
-    pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.pinfo.get(), st);
+    pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.pinfo.get(), W, st);
     pk::iota(S.iota.get(), m, st);
     S.dflags.ensure(m); S.scan.ensure(m);
     for (int attempt = std::getenv("MMT_PFP_TWO_FINGERPRINTS") ? 1 : 0;; attempt++) {     // the variable forces the rare path (tests)
@@ -77,7 +95,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
         MMT_HIP(hipMemcpyAsync(flags2, S.err.get(), 8, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipStreamSynchronize(st));
         if (flags2[0])
-            throw std::runtime_error("phrase fingerprint collision (128-bit); refusing to merge different phrases");
+            throw std::runtime_error("phrase fingerprint collision (both fingerprints); refusing to merge different phrases");
         if (attempt == 0 && flags2[1]) continue;
         break;
     }
@@ -85,20 +103,37 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     S.pid.ensure(m); S.rep.ensure(D); S.dlen.ensure(D); S.dstart.ensure(D);
     pk::assign_distinct(S.order.get(), S.scan.get(), S.dflags.get(), S.plen.get(), m, S.pid.get(), S.rep.get(),
                         S.dlen.get(), st);
+    if (slim) {
+        S.h1.release(); S.h2.release(); S.pinfo.release(); S.hk_a.release(); S.hk_b.release(); S.iota.release();
+        S.ord_a.release(); S.order.release(); S.dflags.release(); S.scan.release();
+    }
     e1.stop(st);
 
     // -- dictionary text (distinct phrases in fingerprint order; ranks come from its suffix array)
     e2.start(st);
     prims::exclusive_sum_u32(d_temp_, S.dlen.get(), S.dstart.get(), D, st);
-    const uint64_t dict_len64 = (uint64_t)read_u32(S.dstart.get() + (D - 1), st) + read_u32(S.dlen.get() + (D - 1), st) + 1;
-    if (dict_len64 >= 0xffffff00ull) throw std::runtime_error("PFP dictionary exceeds the 32-bit build");
-    const uint32_t nd = S.dict_len = (uint32_t)dict_len64;
+    {
+        // the 32-bit prefix sum wraps silently: add the lengths up on the host when the dictionary may be that large
+        uint64_t dict_len64 = (uint64_t)read_u32(S.dstart.get() + (D - 1), st) + read_u32(S.dlen.get() + (D - 1), st) + 1;
+        if ((uint64_t)D * 2 + n / 4 >= 0xffffff00ull || W) {
+            std::vector<uint32_t> dl;
+            d2h(dl, S.dlen.get(), D, st);
+            dict_len64 = 1;
+            for (uint32_t x : dl) dict_len64 += x;
+        }
+        if (dict_len64 >= 0xffffff00ull)
+            throw std::runtime_error("PFP dictionary of " + std::to_string(dict_len64) + " bytes exceeds the 32-bit "
+                                     "dictionary of this build (too little redundancy between the documents)");
+        S.dict_len = (uint32_t)dict_len64;
+    }
+    const uint32_t nd = S.dict_len;
     S.dict.ensure((size_t)nd + 64); S.dinfo.ensure(nd);
     MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
     // room for the byte before each position in the phrase-id word (MMT_PFP_NO_PACK: the other path, for tests)
     const bool pack_prev = D < (1u << 24) && !std::getenv("MMT_PFP_NO_PACK");
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
-                  S.dinfo.get(), nd, pack_prev, st);
+                  S.dinfo.get(), nd, pack_prev, W, st);
+    if (slim) { S.vtext.release(); S.dstart.release(); }
     e2.stop(st);
 
     // -- suffix array of the dictionary (dictionary.hpp:133) ...
@@ -116,11 +151,13 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     sorter_.reserve(std::max(nd, m));
     k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
+    if (slim) S.rank_d.release();
     e3.stop(st);
     // ... the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
     pk::entry_info(S.sa_d.get(), S.dinfo.get(), S.dict.get(), nd, pack_prev, S.esuf.get(), S.ephr.get(), S.ebw.get(), st);
+    if (slim) S.dinfo.release();
     S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
     pk::group_flags(S.esuf.get(), S.sa_d.get(), S.dict.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);
@@ -129,6 +166,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
     pk::phrase_ranks(S.esuf.get(), S.ephr.get(), S.pscan.get(), nd, S.prank.get(), st);
     pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
+    if (slim) { S.pflag.release(); S.pscan.release(); S.sa_d.release(); S.dict.release(); }
     e4.stop(st);
     S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms(); S.ms[3] = e3.ms(); S.ms[4] = e4.ms();
     S.have_parse = true;
@@ -138,9 +176,11 @@ void Engine::pfp_parse(uint32_t w, uint32_t p) {
 // (group of the phrase suffix, rank of the following parse suffix).
 void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     PfpState& S = *pfp_;
-    const uint32_t n = (uint32_t)n_;
+    const uint64_t n = n_;
+    const bool W = wide_;
+    const bool slim = lean_ || wide_;
     auto t0 = std::chrono::steady_clock::now();
-    pfp_parse(w, p);
+    pfp_parse(w, p, false);
     hipStream_t st = stream_;
     const uint32_t m = S.n_phrases, D = S.n_distinct;
     EventPair e5, e6;
@@ -150,84 +190,149 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const int pchars = std::max(1, 64 / pbits);
     pk::pack_keys_u32(S.parse.get(), m, pbits, pchars, sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
-    if (lean_) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); }   // dictionary-sized doubling scratch: done
+    if (slim) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); S.isa_p.release(); S.parse.release(); }
     e5.stop(st);
 
     e6.start(st);
     const int shift = bit_width_u64((uint64_t)m + 1);
     const uint32_t nd = S.dict_len;
-    d_sa_.ensure(n); d_bwt_.ensure((size_t)n + 16);     // no inverse suffix array on this path (see Engine::lcp_bwt)
+    d_sa_.ensure(n);
+    if (W) d_sa_hi_.ensure(n + 16);
+    d_bwt_.ensure((size_t)n + 16);                      // no inverse suffix array on this path (see Engine::lcp_bwt)
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
-    S.occ_start.ensure((size_t)D + 2); S.occ_pos.ensure((size_t)m * 2);       // (t, position) records
+    const uint32_t pos_bits = W ? (uint32_t)bit_width_u64(n + w + 1) : 32u;
+    if ((uint32_t)shift + pos_bits > 64)
+        throw std::runtime_error("parse rank and text position do not fit one 64-bit occurrence record");
+    S.occ_start.ensure((size_t)D + 2); S.occ.ensure(m);
     S.occ_ids.ensure((size_t)m + 1); S.occ_ts.ensure((size_t)m + 1);
     {
-        sorter_.u32_a().ensure((size_t)m + 1); sorter_.u32_b().ensure((size_t)m + 1);     // scratch
-        uint32_t* k_in = sorter_.u32_a().get();
-        uint32_t* v_in = sorter_.u32_b().get();
+        DevBuf<uint32_t> k_own, v_own;                                   // slim runs gave the sorter's columns back
+        uint32_t *k_in, *v_in;
+        if (slim) { k_own.ensure((size_t)m + 1); v_own.ensure((size_t)m + 1); k_in = k_own.get(); v_in = v_own.get(); }
+        else {
+            sorter_.u32_a().ensure((size_t)m + 1); sorter_.u32_b().ensure((size_t)m + 1);     // scratch
+            k_in = sorter_.u32_a().get(); v_in = sorter_.u32_b().get();
+        }
         pk::occ_sequence(S.sa_p.get(), S.pid.get(), m, D, k_in, v_in, st);
         prims::sort_pairs_u32_u32(d_temp_, k_in, S.occ_ids.get(), v_in, S.occ_ts.get(), (size_t)m + 1, 0,
                                   std::max(1, bit_width_u64((uint64_t)D)), st);
         pk::occ_finish(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), m, S.occ_start.get(),
-                       S.occ_pos.get(), st);
+                       S.occ.get(), pos_bits, W, st);
+        MMT_HIP(hipStreamSynchronize(st));
     }
+    if (slim) { S.occ_ids.release(); S.occ_ts.release(); S.sa_p.release(); S.pid.release(); S.pstart.release(); }
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
     S.vscan.ensure(nd); S.ptab.ensure((size_t)D * 16 + 16);
     prims::exclusive_sum_u32(d_temp_, S.vflag.get(), S.vscan.get(), nd, st);
     const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
     pk::phrase_table(S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
-    S.ce_cnt.ensure(E); S.ce_eoff.ensure(E); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
+    S.ce_cnt.ensure(E); S.ce_eoff.ensure(E, W); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
     S.ce_bwt.ensure(E);
     pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.vflag.get(), S.vscan.get(),
                       S.ptab.get(), nd, S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(), S.ce_bwt.get(),
                       S.ce_gs.get(), st);
-    prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.get(), E, st);
+    offsets_from_counts(d_temp_, S.ce_cnt.get(), S.ce_eoff, E, st);
     {
-        const uint64_t total = (uint64_t)read_u32(S.ce_eoff.get() + (E - 1), st) + read_u32(S.ce_cnt.get() + (E - 1), st);
-        if (total != (uint64_t)n + 1) throw std::runtime_error("PFP expansion does not cover the text exactly once");
+        const uint64_t total = S.ce_eoff.read(E - 1, st) + read_u32(S.ce_cnt.get() + (E - 1), st);
+        if (total != n + 1) throw std::runtime_error("PFP expansion does not cover the text exactly once");
+    }
+    if (slim) {
+        S.esuf.release(); S.ephr.release(); S.ebw.release(); S.gflag.release(); S.vflag.release(); S.vscan.release();
+        S.ptab.release(); S.plen.release();
     }
     // groups of equal phrase suffixes: first entry and first output position of each
     const uint32_t G = S.n_groups;
-    S.sege.ensure((size_t)G + 2); S.segb.ensure((size_t)G + 2);
+    S.sege.ensure((size_t)G + 2); S.segb.ensure((size_t)G + 2, W);
     prims::select_indices_u32flags(d_temp_, S.ce_gs.get(), S.sege.get(), S.err.get(), E, st);
     if (read_u32(S.err.get(), st) != G) throw std::runtime_error("PFP group count mismatch");
-    k::gather_u32_idx32(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), st);
-    {
-        const uint32_t endv[2] = {E, n + 1};
-        MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &endv[0], 4, hipMemcpyHostToDevice, st));
-        MMT_HIP(hipMemcpyAsync(S.segb.get() + G, &endv[1], 4, hipMemcpyHostToDevice, st));
-        MMT_HIP(hipStreamSynchronize(st));
-    }
+    pk::gather_pos(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), W, st);
+    MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &E, 4, hipMemcpyHostToDevice, st));
+    S.segb.write(G, n + 1, st);
     // groups larger than one LDS tile of the emitter get compact slots in the fallback arrays
-    uint32_t* osize = S.gscan.get();                       // scratch of >= G entries (G <= dictionary length)
-    pk::oversize(S.segb.get(), G, osize, st);
+    S.gscan.ensure(std::max<size_t>(G, 1));
+    uint32_t* osize = S.gscan.get();
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
+    pk::oversize(S.segb.get(), G, osize, S.err.get(), W, st);
     S.fb_group.ensure((size_t)G + 1);
-    prims::select_indices_u32flags(d_temp_, osize, S.fb_group.get(), S.err.get(), G, st);
-    const uint32_t F = S.n_fallback = read_u32(S.err.get(), st);
-    S.fb_size.ensure((size_t)F + 2); S.fb_off.ensure((size_t)F + 2);
-    uint32_t fb_total = 0;
+    prims::select_indices_u32flags(d_temp_, osize, S.fb_group.get(), S.err.get() + 3, G, st);
+    {
+        uint32_t e4[4];
+        MMT_HIP(hipMemcpyAsync(e4, S.err.get(), 16, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        if (e4[2]) throw std::runtime_error("a group of 2^32 or more equal phrase suffixes is not supported");
+        S.n_fallback = e4[3];
+    }
+    const uint32_t F = S.n_fallback;
+    S.fb_size.ensure((size_t)F + 2); S.fb_off.ensure((size_t)F + 2, W); S.fb_start.ensure((size_t)F + 2, W);
+    uint64_t fb_total = 0;
+    std::vector<uint64_t> h_fb_off(1, 0), h_fb_start;
     if (F) {
         k::gather_u32_idx32(osize, S.fb_group.get(), F, S.fb_size.get(), st);
         MMT_HIP(hipMemsetAsync(S.fb_size.get() + F, 0, 4, st));
-        prims::exclusive_sum_u32(d_temp_, S.fb_size.get(), S.fb_off.get(), (size_t)F + 1, st);
-        fb_total = read_u32(S.fb_off.get() + F, st);
+        offsets_from_counts(d_temp_, S.fb_size.get(), S.fb_off, (size_t)F + 1, st);
+        pk::gather_pos(S.segb.get(), S.fb_group.get(), F, S.fb_start.get(), W, st);
+        // the launch plan below needs both tables on the host
+        h_fb_off.assign((size_t)F + 1, 0); h_fb_start.assign(F, 0);
+        if (W) {
+            MMT_HIP(hipMemcpyAsync(h_fb_off.data(), S.fb_off.get(), ((size_t)F + 1) * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(h_fb_start.data(), S.fb_start.get(), (size_t)F * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+        } else {
+            std::vector<uint32_t> a32, b32;
+            d2h(a32, S.fb_off.p32(), (size_t)F + 1, st);
+            d2h(b32, S.fb_start.p32(), F, st);
+            for (size_t i = 0; i <= F; i++) h_fb_off[i] = a32[i];
+            for (size_t i = 0; i < F; i++) h_fb_start[i] = b32[i];
+        }
+        fb_total = h_fb_off[F];
     }
-    S.xk_a.ensure((size_t)fb_total + 1); S.xv_a.ensure((size_t)fb_total + 1);
+    if (slim) S.gscan.release();
+
+    // ---- launch plan: ranges of output tiles whose oversized groups fit the fallback arrays of one launch ----
+    const uint64_t tiles = (n + 1 + pk::EMIT_TILE - 1) / pk::EMIT_TILE;
+    uint64_t per_launch = W ? (1ull << 18) : tiles;                       // wide: 2^28 output positions per launch
+    if (const char* c = std::getenv("MMT_EMIT_TILES")) per_launch = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
+    if (per_launch > 0x7fffffffull) per_launch = 0x7fffffffull;
+    const uint64_t FB_LIMIT = 0xfffffff0ull;                              // 32-bit offsets inside one launch
+    struct Launch { uint64_t t0, t1; uint32_t f0, f1; };
+    std::vector<Launch> plan;
+    auto first_group_at = [&](uint64_t out_pos) {                         // first oversized group that begins at or after out_pos
+        return (uint32_t)(std::lower_bound(h_fb_start.begin(), h_fb_start.end(), out_pos) - h_fb_start.begin());
+    };
+    uint64_t max_fb = 0;
+    for (uint64_t t0 = 0; t0 < tiles;) {
+        uint64_t t1 = std::min(tiles, t0 + per_launch);
+        uint32_t f0 = first_group_at(t0 * pk::EMIT_TILE), f1 = first_group_at(t1 * pk::EMIT_TILE);
+        while (h_fb_off[f1] - h_fb_off[f0] > FB_LIMIT && t1 - t0 > 1) {   // too many oversized suffixes: halve the range
+            t1 = t0 + (t1 - t0) / 2;
+            f1 = first_group_at(t1 * pk::EMIT_TILE);
+        }
+        if (h_fb_off[f1] - h_fb_off[f0] > FB_LIMIT)
+            throw std::runtime_error("the oversized suffix groups of one emitter tile exceed 2^32 elements");
+        plan.push_back({t0, t1, f0, f1});
+        max_fb = std::max(max_fb, h_fb_off[f1] - h_fb_off[f0]);
+        t0 = t1;
+    }
+    S.emit_launches = (uint32_t)plan.size();
+    S.xk_a.ensure((size_t)max_fb + 1); S.xv_a.ensure((size_t)max_fb + 1, W);
+    (void)fb_total;
     // the emitter
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
     pk::EmitArgs ea;
+    ea.wide = W;
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
-    ea.occ = reinterpret_cast<const uint2*>(S.occ_pos.get());
-    ea.n = n; ea.sa = d_sa_.get(); ea.bwt = d_bwt_.get();
-    ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F;
+    ea.occ = S.occ.get(); ea.pos_bits = pos_bits;
+    ea.n = n; ea.sa = sa_col(); ea.bwt = d_bwt_.get();
+    ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F; ea.fb_base = 0;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
     // the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at
     // most 16 different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)
     pk::BwtDecode decode{};
     uint32_t fb_bits = 0;
     if (F && !std::getenv("MMT_PFP_NO_BWT_CODE")) {
-        std::vector<uint32_t> hist;
+        std::vector<uint64_t> hist;
         d2h(hist, d_hist_.get(), 256, st);
         std::vector<uint8_t> code(256, 0);
         uint32_t kinds = 0;
@@ -247,15 +352,27 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         }
     }
     ea.bwt_code = S.bwt_code.get(); ea.fb_bits = fb_bits;
-    S.tile_first.ensure(((size_t)n + 1) / pk::EMIT_TILE + 4);
-    pk::emit(ea, n + 1, S.tile_first.get(), st);
-    if (F) {      // one segmented radix sort over just the oversized groups
-        S.xk_b.ensure((size_t)fb_total + 1); S.xv_b.ensure((size_t)fb_total + 1);
-        prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.get(), S.xv_b.get(),
-                                               fb_total, F, S.fb_off.get(), S.fb_off.get() + 1, shift + (int)fb_bits, st);
-        pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), F, S.segb.get(), S.xk_b.get(), S.xv_b.get(), fb_bits, decode,
-                            d_text_.get(), n,
-                            d_sa_.get(), d_bwt_.get(), S.err.get(), st);
+    S.tile_first.ensure((size_t)tiles + 4);
+    pk::tile_first(S.segb.get(), G, tiles, S.tile_first.get(), W, st);
+    if (max_fb) { S.xk_b.ensure((size_t)max_fb + 1); S.xv_b.ensure((size_t)max_fb + 1, W); }
+    for (const Launch& L : plan) {
+        ea.fb_base = h_fb_off[L.f0];
+        pk::emit(ea, S.tile_first.get(), L.t0, L.t1, st);
+        const uint32_t nf = L.f1 - L.f0;
+        if (!nf) continue;
+        // one segmented radix sort over just the oversized groups of this launch
+        const uint32_t count = (uint32_t)(h_fb_off[L.f1] - h_fb_off[L.f0]);
+        S.fb_rel.ensure((size_t)nf + 2);
+        pk::relative_offsets(S.fb_off.get(), L.f0, nf, S.fb_rel.get(), W, st);
+        if (W)
+            prims::segmented_sort_pairs_u32_u64vals_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p64(), S.xv_b.p64(),
+                                                           count, nf, S.fb_rel.get(), S.fb_rel.get() + 1,
+                                                           shift + (int)fb_bits, st);
+        else
+            prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
+                                                   nf, S.fb_rel.get(), S.fb_rel.get() + 1, shift + (int)fb_bits, st);
+        pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), L.f0, L.f1, h_fb_off[L.f0], S.segb.get(), S.xk_b.get(),
+                            S.xv_b.get(), fb_bits, decode, d_text_.get(), n, sa_col(), d_bwt_.get(), S.err.get(), W, st);
     }
     if (read_u32(S.err.get(), st)) throw std::runtime_error("PFP order: the end sentinel is not first");
     S.bwt_ready = true;
@@ -268,7 +385,8 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
 // PREFIX.dict bytes: phrases in lexicographic order, 0x01 after each, final 0x00 (newscan.hpp:386-397)
 void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     PfpState& S = *pfp_;
-    if (!S.have_parse) throw std::runtime_error("no parse available");
+    if (!S.have_parse || !S.vtext.get() || !S.pstart.get())
+        throw std::runtime_error("no parse available (run parse_only first)");
     const uint32_t D = S.n_distinct, nd = S.dict_len;
     DevBuf<uint32_t> which, slen, sstart;
     DevBuf<uint8_t> sorted;
@@ -276,7 +394,7 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
     prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
     pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
-                  false, stream_);
+                  false, S.pstart.wide(), stream_);
     d2h(out, sorted.get(), nd, stream_);
 }
 

@@ -15,15 +15,18 @@ struct PfpState {
     DevBuf<uint8_t> vtext, dict, ptab, pinfo;   // pinfo: 16-byte record per phrase (k_phrase_hash)  // ptab: 16-byte record per distinct phrase (phrase_table)
     DevBuf<uint16_t> tmask;             // trigger masks, one per 16 text positions
     DevBuf<uint32_t> tcnt, toff;        // triggers per workgroup of the trigger pass and their exclusive scan
-    DevBuf<uint32_t> cuts, pstart, plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, esuf, ephr;
+    PosBuf cuts, pstart;                // trigger positions, phrase starts (in V): text positions
+    DevBuf<uint32_t> plen, iota, ord_a, order, scan, dflags, pid, rep, dlen, dstart, esuf, ephr;
     DevBuf<uint64_t> dinfo;
     DevBuf<uint8_t> ebw;
     DevBuf<uint32_t> sa_d, rank_d, gflag, pflag, gscan, pscan, prank, parse, sa_p, isa_p, err;
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
-    DevBuf<uint32_t> occ_start, occ_ids, occ_ts, occ_pos /* (t, position) records */, vflag, vscan;
-    DevBuf<uint32_t> ce_cnt, ce_eoff, ce_first, ce_offm1, ce_gs, segb, sege, xk_a, xk_b, xv_a, xv_b, fb_group, fb_size, fb_off, tile_first;
+    DevBuf<uint32_t> occ_start, occ_ids, occ_ts, vflag, vscan;
+    DevBuf<uint64_t> occ;               // (t << pos_bits) | V position, per phrase occurrence
+    DevBuf<uint32_t> ce_cnt, ce_first, ce_offm1, ce_gs, sege, xk_a, xk_b, fb_group, fb_size, fb_rel, tile_first;
+    PosBuf ce_eoff, segb, fb_off, fb_start, xv_a, xv_b;     // stream offsets / text positions
     DevBuf<uint8_t> ce_bwt, bwt_code;
-    uint32_t n_entries = 0, n_fallback = 0;
+    uint32_t n_entries = 0, n_fallback = 0, emit_launches = 0;
     bool bwt_ready = false;
 };
 

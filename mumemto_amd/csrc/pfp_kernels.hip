@@ -24,18 +24,18 @@ static inline unsigned grid_for(uint64_t items, unsigned per_block) {
 }
 
 // V from T: V[0] = Dollar, V[1..n] = T, V[n+1..n+w] = Dollar, zero padding after.
-__global__ void k_make_vtext(const uint8_t* __restrict__ text, uint32_t n, uint32_t w, uint8_t* __restrict__ v,
-                             uint32_t vlen_padded) {
+__global__ void k_make_vtext(const uint8_t* __restrict__ text, uint64_t n, uint32_t w, uint8_t* __restrict__ v,
+                             uint64_t vlen_padded) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= vlen_padded) return;
     uint8_t c;
     if (i == 0) c = 2;
     else if (i <= n) c = text[i - 1];
-    else if (i <= (uint64_t)n + w) c = 2;
+    else if (i <= n + w) c = 2;
     else c = 0;
     v[i] = c;
 }
-void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_t vlen_padded, hipStream_t s) {
+void make_vtext(const uint8_t* text, uint64_t n, uint32_t w, uint8_t* v, uint64_t vlen_padded, hipStream_t s) {
     hipLaunchKernelGGL(k_make_vtext, dim3(grid_for(vlen_padded, 256)), dim3(256), 0, s, text, n, w, v, vlen_padded);
     MMT_HIP(hipGetLastError());
 }
@@ -49,7 +49,7 @@ void make_vtext(const uint8_t* text, uint32_t n, uint32_t w, uint8_t* v, uint32_
 // Pass 2 (after an exclusive scan of the workgroup counts): the trigger positions, ascending.
 constexpr uint32_t KR_PRIME = 1999999973u;             // newscan.hpp:86 (compile-time: reductions become multiplies)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restrict__ text, uint32_t n, uint32_t w,
+__global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restrict__ text, uint64_t n, uint32_t w,
                                                          uint32_t p, uint32_t pot,
                                                          uint16_t* __restrict__ masks,
                                                          uint32_t* __restrict__ block_count) {
@@ -88,10 +88,10 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
     __syncthreads();
     if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
 }
-template <int BLOCK>
+template <int BLOCK, typename P>
 __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restrict__ masks, uint64_t n_threads,
                                                         const uint32_t* __restrict__ block_off,
-                                                        uint32_t* __restrict__ cuts) {
+                                                        P* __restrict__ cuts) {
     __shared__ uint32_t s_wave[BLOCK / 64];
     const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,12 +106,12 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restri
     for (uint32_t wv = 0; wv < wave; wv++) out += s_wave[wv];
     while (mask) {
         const uint32_t b = __builtin_ctz(mask);
-        cuts[out++] = (uint32_t)(t * 16 + b);
+        cuts[out++] = (P)(t * 16 + b);
         mask &= mask - 1;
     }
 }
-uint32_t trigger_blocks(uint32_t n) { return grid_for(((uint64_t)n + 15) / 16, 256); }
-void trigger_masks(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
+uint32_t trigger_blocks(uint64_t n) { return grid_for((n + 15) / 16, 256); }
+void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
                    hipStream_t s) {
     uint64_t pot = 1;
     for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % KR_PRIME;
@@ -119,26 +119,35 @@ void trigger_masks(const uint8_t* text, uint32_t n, uint32_t w, uint32_t p, uint
                        block_count);
     MMT_HIP(hipGetLastError());
 }
-void trigger_cuts(const uint16_t* masks, uint32_t n, const uint32_t* block_off, uint32_t* cuts, hipStream_t s) {
-    hipLaunchKernelGGL(k_trigger_cuts<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, masks, ((uint64_t)n + 15) / 16,
-                       block_off, cuts);
+void trigger_cuts(const uint16_t* masks, uint64_t n, const uint32_t* block_off, void* cuts, bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL((k_trigger_cuts<256, uint64_t>), dim3(trigger_blocks(n)), dim3(256), 0, s, masks, (n + 15) / 16,
+                           block_off, static_cast<uint64_t*>(cuts));
+    else
+        hipLaunchKernelGGL((k_trigger_cuts<256, uint32_t>), dim3(trigger_blocks(n)), dim3(256), 0, s, masks, (n + 15) / 16,
+                           block_off, static_cast<uint32_t*>(cuts));
     MMT_HIP(hipGetLastError());
 }
 
 // phrase k occupies V[a_k .. a_k + len_k - 1]; consecutive phrases overlap by w characters
-__global__ void k_phrase_bounds(const uint32_t* __restrict__ cuts, uint32_t n_cuts, uint32_t n, uint32_t w,
-                                uint32_t* __restrict__ start, uint32_t* __restrict__ len) {
+template <typename P>
+__global__ void k_phrase_bounds(const P* __restrict__ cuts, uint32_t n_cuts, uint64_t n, uint32_t w,
+                                P* __restrict__ start, uint32_t* __restrict__ len) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > n_cuts) return;
-    const uint32_t a = k == 0 ? 0u : cuts[k - 1] - w + 2;          // V index of T[cut - w + 1]
-    const uint32_t b = k < n_cuts ? cuts[k] + 1 : n + w;            // V index of the last character
-    start[k] = a;
-    len[k] = b - a + 1;
+    const uint64_t a = k == 0 ? 0u : (uint64_t)cuts[k - 1] - w + 2;    // V index of T[cut - w + 1]
+    const uint64_t b = k < n_cuts ? (uint64_t)cuts[k] + 1 : n + w;      // V index of the last character
+    start[k] = (P)a;
+    len[k] = (uint32_t)(b - a + 1);
 }
-void phrase_bounds(const uint32_t* cuts, uint32_t n_cuts, uint32_t n, uint32_t w, uint32_t* start, uint32_t* len,
+void phrase_bounds(const void* cuts, uint32_t n_cuts, uint64_t n, uint32_t w, void* start, uint32_t* len, bool wide,
                    hipStream_t s) {
-    hipLaunchKernelGGL(k_phrase_bounds, dim3(grid_for((uint64_t)n_cuts + 1, 256)), dim3(256), 0, s, cuts, n_cuts, n, w,
-                       start, len);
+    if (wide)
+        hipLaunchKernelGGL(k_phrase_bounds<uint64_t>, dim3(grid_for((uint64_t)n_cuts + 1, 256)), dim3(256), 0, s,
+                           static_cast<const uint64_t*>(cuts), n_cuts, n, w, static_cast<uint64_t*>(start), len);
+    else
+        hipLaunchKernelGGL(k_phrase_bounds<uint32_t>, dim3(grid_for((uint64_t)n_cuts + 1, 256)), dim3(256), 0, s,
+                           static_cast<const uint32_t*>(cuts), n_cuts, n, w, static_cast<uint32_t*>(start), len);
     MMT_HIP(hipGetLastError());
 }
 
@@ -156,16 +165,21 @@ __device__ __forceinline__ void hash_range(const uint8_t* __restrict__ v, uint64
         p1 *= MMT_B1; p2 *= MMT_B2;
     }
 }
-__global__ void k_phrase_hash(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
+// The per-phrase record is 16 bytes: 56 bits of the second fingerprint, the 40-bit start (its high byte rides in the
+// top byte of the fingerprint word), the length.
+constexpr uint32_t FP2_HI_MASK = 0x00ffffffu;
+template <typename P>
+__global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict__ start,
                               const uint32_t* __restrict__ len, uint32_t m, uint64_t* __restrict__ o1,
                               uint4* __restrict__ pinfo) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const bool have = k < m;
-    const uint32_t a = have ? start[k] : 0, l = have ? len[k] : 0;
+    const uint64_t a = have ? (uint64_t)start[k] : 0;
+    const uint32_t l = have ? len[k] : 0;
     const bool is_long = l > 2048;
     uint64_t h1 = 0, h2 = 0, p1, p2;
-    if (have && !is_long) hash_range(v, a, (uint64_t)a + l, h1, h2, p1, p2);
+    if (have && !is_long) hash_range(v, a, a + l, h1, h2, p1, p2);
     // long phrases (no trigger inside a low-complexity run): the whole wave hashes one phrase
     uint64_t todo = __ballot(have && is_long);
     while (todo) {
@@ -188,19 +202,23 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const uint32_t* __r
     if (have) {
         o1[k] = h1 ^ ((uint64_t)l * 0xD6E8FEB86659FD93ull);
         const uint64_t g2 = h2 + ((uint64_t)l << 32);
-        pinfo[k] = make_uint4((uint32_t)g2, (uint32_t)(g2 >> 32), a, l);     // second fingerprint, start, length
+        pinfo[k] = make_uint4((uint32_t)g2, ((uint32_t)(g2 >> 32) & FP2_HI_MASK) | ((uint32_t)(a >> 32) << 24), (uint32_t)a, l);
     }
 }
-void phrase_hash(const uint8_t* v, const uint32_t* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
-                 hipStream_t s) {
-    hipLaunchKernelGGL(k_phrase_hash, dim3(grid_for(m, 256)), dim3(256), 0, s, v, start, len, m, h1,
-                       static_cast<uint4*>(pinfo));
+void phrase_hash(const uint8_t* v, const void* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
+                 bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_phrase_hash<uint64_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, v,
+                           static_cast<const uint64_t*>(start), len, m, h1, static_cast<uint4*>(pinfo));
+    else
+        hipLaunchKernelGGL(k_phrase_hash<uint32_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, v,
+                           static_cast<const uint32_t*>(start), len, m, h1, static_cast<uint4*>(pinfo));
     MMT_HIP(hipGetLastError());
 }
 // h2[k] out of the per-phrase records (only for the rare two-fingerprint ordering)
 __global__ void k_second_fingerprint(const uint4* __restrict__ pinfo, uint32_t m, uint64_t* __restrict__ h2) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < m) { const uint4 p = pinfo[k]; h2[k] = ((uint64_t)p.y << 32) | p.x; }
+    if (k < m) { const uint4 p = pinfo[k]; h2[k] = ((uint64_t)(p.y & FP2_HI_MASK) << 32) | p.x; }
 }
 void second_fingerprint(const void* pinfo, uint32_t m, uint64_t* h2, hipStream_t s) {
     hipLaunchKernelGGL(k_second_fingerprint, dim3(grid_for(m, 256)), dim3(256), 0, s, static_cast<const uint4*>(pinfo), m,
@@ -228,13 +246,14 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
     Y.x = __shfl_up(X.x, 1, 64); Y.y = __shfl_up(X.y, 1, 64); Y.z = __shfl_up(X.z, 1, 64); Y.w = __shfl_up(X.w, 1, 64);
     if (lane == 0 && have && k > 0) Y = pinfo[order[k - 1]];
     const bool same1 = have && k > 0 && h1s[k] == h1s[k - 1];
-    bool same = same1 && X.x == Y.x && X.y == Y.y && X.w == Y.w;
+    const bool same2 = X.x == Y.x && (X.y & FP2_HI_MASK) == (Y.y & FP2_HI_MASK) && X.w == Y.w;
+    bool same = same1 && same2;
     // equal first fingerprints of different phrases: when the order came from the first fingerprint alone, equal
     // phrases need not be adjacent any more -- the host then repeats the grouping with both fingerprints
     if (same1 && !same) atomicOr(err + 1, 1u);
     // byte verification, 8 bytes per step; the loop runs while any lane of the wave still compares
-    const uint8_t* px = v + X.z;
-    const uint8_t* py = v + Y.z;
+    const uint8_t* px = v + (((uint64_t)(X.y >> 24) << 32) | X.z);
+    const uint8_t* py = v + (((uint64_t)(Y.y >> 24) << 32) | Y.z);
     const uint32_t l = X.w;
     bool verified = same;
     for (uint32_t i = 0; __ballot(same && i < l) != 0; i += 8) {
@@ -257,7 +276,7 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
     if (have) {
         if (k == 0) flags[0] = 1;
         else {
-            if (same1 && X.x == Y.x && X.y == Y.y && X.w == Y.w && !verified) atomicAdd(err, 1u);   // 128-bit collision
+            if (same1 && same2 && !verified) atomicAdd(err, 1u);   // collision of both fingerprints
             flags[k] = verified ? 0u : 1u;
         }
     }
@@ -290,14 +309,16 @@ void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t
 // (dictionary file layout of newscan.hpp:386-397).  dinfo[pos] = (distinct phrase id << 32) | suffix
 // word: length of the phrase suffix that starts at pos (0 on separators), bit 31 set on the first
 // byte of a phrase.  One wave per phrase.
-__global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __restrict__ start,
+template <typename P>
+__global__ void k_copy_dict(const uint8_t* __restrict__ v, const P* __restrict__ start,
                             const uint32_t* __restrict__ len, const uint32_t* __restrict__ which,
                             const uint32_t* __restrict__ dstart, uint32_t n_phr, uint8_t* __restrict__ dict,
                             uint64_t* __restrict__ dinfo, uint32_t dict_len, int pack_prev) {
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (wave >= n_phr) return;
-    const uint32_t ph = which[wave], a = start[ph], l = len[ph], o = dstart[wave];
+    const uint32_t ph = which[wave], l = len[ph], o = dstart[wave];
+    const uint64_t a = start[ph];
     // pack_prev (fewer than 2^24 distinct phrases): the byte before each position rides in the top byte of the
     // record, so that k_entry_info needs one random read per dictionary suffix instead of two.  The byte before
     // the first character of a phrase is the terminator of the phrase before it (padding for the first phrase).
@@ -323,11 +344,17 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const uint32_t* __res
         }
     }
 }
-void copy_dict(const uint8_t* v, const uint32_t* start, const uint32_t* len, const uint32_t* which,
+void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
-               bool pack_prev, hipStream_t s) {
-    hipLaunchKernelGGL(k_copy_dict, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v, start, len, which,
-                       dstart, n_phr, dict, dinfo, dict_len, pack_prev ? 1 : 0);
+               bool pack_prev, bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_copy_dict<uint64_t>, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v,
+                           static_cast<const uint64_t*>(start), len, which, dstart, n_phr, dict, dinfo, dict_len,
+                           pack_prev ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_copy_dict<uint32_t>, dim3(grid_for((uint64_t)n_phr * 64, 256)), dim3(256), 0, s, v,
+                           static_cast<const uint32_t*>(start), len, which, dstart, n_phr, dict, dinfo, dict_len,
+                           pack_prev ? 1 : 0);
     MMT_HIP(hipGetLastError());
 }
 
@@ -485,11 +512,12 @@ void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_
     MMT_HIP(hipGetLastError());
 }
 // after the sort: k-th occurrence overall = (phrase ids[k], t = ts[k]); occ_start[d] = first k of phrase d
-// (occ_start[D] = m: the dummy sorts last); occ[k] = (t, start of that phrase occurrence in the text) -- one 8-byte
-// record, because the emitter reads the short list of a phrase at a random place and pays per 64-byte line
+// (occ_start[D] = m: the dummy sorts last); occ[k] = (t << pos_bits) | start of that phrase occurrence in V -- one
+// 8-byte record, because the emitter reads the short list of a phrase at a random place and pays per 64-byte line
+template <typename P>
 __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ ts,
-                             const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ pstart, uint32_t m,
-                             uint32_t* __restrict__ occ_start, uint2* __restrict__ occ) {
+                             const uint32_t* __restrict__ sa_p, const P* __restrict__ pstart, uint32_t m,
+                             uint32_t* __restrict__ occ_start, uint64_t* __restrict__ occ, uint32_t pos_bits) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > m) return;
     const uint32_t id = ids[k];
@@ -497,12 +525,16 @@ __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* _
     if (k == m) return;                                    // the dummy
     const uint32_t t = ts[k];
     const uint32_t q = t ? sa_p[t - 1] - 1 : m - 1;
-    occ[k] = make_uint2(t, pstart[q]);
+    occ[k] = ((uint64_t)t << pos_bits) | (uint64_t)pstart[q];
 }
-void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const uint32_t* pstart, uint32_t m,
-                uint32_t* occ_start, void* occ, hipStream_t s) {
-    hipLaunchKernelGGL(k_occ_finish, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p, pstart, m,
-                       occ_start, static_cast<uint2*>(occ));
+void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
+                uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_occ_finish<uint64_t>, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p,
+                           static_cast<const uint64_t*>(pstart), m, occ_start, occ, pos_bits);
+    else
+        hipLaunchKernelGGL(k_occ_finish<uint32_t>, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p,
+                           static_cast<const uint32_t*>(pstart), m, occ_start, occ, pos_bits);
     MMT_HIP(hipGetLastError());
 }
 
@@ -548,7 +580,8 @@ void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* eb
 }
 
 // first index i in [0, n] with a[i] >= x (a non-decreasing), all lanes of the calling wave cooperate
-__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict__ a, uint32_t n, uint32_t x) {
+template <typename T>
+__device__ __forceinline__ uint32_t wave_lower_bound(const T* __restrict__ a, uint32_t n, T x) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t lo = 0, hi = n;                                 // answer in [lo, hi]
     while (hi - lo > 64) {
@@ -572,6 +605,21 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t* __restrict_
 // (group begin + number of group elements with a smaller following-parse-suffix rank) -- the k-way
 // merge of pfp_lcp_mum.hpp:151-212 done by counting, since the lists of one group are sorted runs.
 // Groups that do not fit CAP elements are expanded unsorted and queued for a segmented sort.
+// P = type of the stream offsets and text positions (uint32_t narrow, uint64_t wide), SA = suffix-array accessor.
+template <typename P, typename SA>
+struct EmitArgsT {
+    const P* segb; const uint32_t* sege; uint32_t n_groups;
+    const P* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
+    const uint8_t* ce_bwt; const uint32_t* ce_gs;
+    const uint64_t* occ; uint32_t pos_bits;
+    P n;
+    SA sa; uint8_t* bwt;
+    const uint32_t* fb_group; const P* fb_off; uint32_t n_fb; P fb_base;
+    uint32_t* fb_keys; P* fb_vals;
+    const uint8_t* bwt_code; uint32_t fb_bits;
+    uint32_t* err;
+    uint64_t tile_lo;
+};
 template <int BLOCK, int CAP>
 struct EmitShared {
     uint32_t key[CAP];
@@ -583,21 +631,24 @@ struct EmitShared {
     uint8_t ebwt[CAP], egs[CAP];
     uint32_t wmax[BLOCK / 64], gwmax[BLOCK / 64];
     uint32_t bound[4];
+    uint64_t origin;             // oversized group: output offset that maps to slot 0 of this launch's fallback arrays
 };
 
 // Expands entries [e0, e1) (<= CAP entries, L <= CAP elements starting at output offset clo) through
 // LDS.  sorted = true: entries form whole groups; every element goes to its merged position in
-// sa_x / bwt_x.  sorted = false: part of an oversized group; (key, position) go to the fallback arrays.
-template <int BLOCK, int CAP>
-__device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
-                                           uint32_t clo, uint32_t L, bool sorted, uint32_t fb_shift) {
+// sa / bwt.  sorted = false: part of an oversized group; (key, position) go to the fallback arrays at
+// (output offset - fb_origin).
+template <int BLOCK, int CAP, typename P, typename SA>
+__device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
+                                           P clo, uint32_t L, bool sorted, P fb_origin) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t E = e1 - e0;
+    const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
     __syncthreads();
     for (uint32_t i = tid; i < L; i += BLOCK) sh.owner[i] = 0;
     __syncthreads();
     for (uint32_t e = tid; e < E; e += BLOCK) {
-        const uint32_t st = a.ce_eoff[e0 + e] - clo;
+        const uint32_t st = (uint32_t)(a.ce_eoff[e0 + e] - clo);
         sh.estart[e] = st;
         sh.efirst[e] = a.ce_first[e0 + e];
         sh.eoffm1[e] = a.ce_offm1[e0 + e];
@@ -646,19 +697,20 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
     }
     __syncthreads();
     constexpr int PERX = CAP / BLOCK;
-    uint32_t my_pos[PERX];
+    P my_pos[PERX];
 #pragma unroll
     for (int q = 0; q < PERX; q++) {
         const uint32_t i = tid + q * BLOCK;
         if (i < L) {
             const uint32_t e = sh.owner[i], k = i - sh.estart[e];
-            const uint2 kp = a.occ[sh.efirst[e] + k];
-            const uint32_t key = kp.x;
-            my_pos[q] = kp.y + sh.eoffm1[e];
+            const uint64_t kp = a.occ[sh.efirst[e] + k];
+            const uint32_t key = (uint32_t)(kp >> a.pos_bits);
+            my_pos[q] = (P)((kp & pos_mask) + sh.eoffm1[e]);
             if (sorted) sh.key[i] = key;
             else {
-                a.fb_keys[clo - fb_shift + i] = a.fb_bits ? (key << a.fb_bits) | a.bwt_code[sh.ebwt[e]] : key;
-                a.fb_vals[clo - fb_shift + i] = my_pos[q];
+                const uint32_t slot = (uint32_t)(clo - fb_origin) + i;
+                a.fb_keys[slot] = a.fb_bits ? (key << a.fb_bits) | a.bwt_code[sh.ebwt[e]] : key;
+                a.fb_vals[slot] = my_pos[q];
             }
         }
     }
@@ -681,10 +733,10 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
                 }
                 e2++;
             } while (e2 < E && !sh.egs[e2]);
-            const uint32_t out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
-            const uint32_t pos = my_pos[q];
+            const P out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
+            const P pos = my_pos[q];
             if (out == 0) { if (pos != a.n) atomicAdd(a.err, 1u); }   // entry 0 must be the end sentinel
-            else if (pos < a.n) { a.sa[out - 1] = pos; a.bwt[out - 1] = sh.ebwt[e]; }
+            else if (pos < a.n) { a.sa.set(out - 1, pos); a.bwt[out - 1] = sh.ebwt[e]; }
             else atomicAdd(a.err, 1u);
         }
     }
@@ -692,7 +744,8 @@ __device__ __forceinline__ void emit_piece(const EmitArgs& a, EmitShared<BLOCK, 
 
 // tile_first[t] = first group whose begin offset is >= t * TILE (t = 0 .. tiles; n_groups past the end): one
 // pass over the groups instead of a global binary search per workgroup of the emitter
-__global__ void k_tile_first(const uint32_t* __restrict__ segb, uint32_t n_groups, uint32_t tile, uint32_t tiles,
+template <typename P>
+__global__ void k_tile_first(const P* __restrict__ segb, uint32_t n_groups, uint32_t tile, uint64_t tiles,
                              uint32_t* __restrict__ tile_first) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g > n_groups) return;
@@ -702,28 +755,37 @@ __global__ void k_tile_first(const uint32_t* __restrict__ segb, uint32_t n_group
     const uint64_t hi = g < n_groups ? (uint64_t)segb[g] / tile : tiles;
     for (uint64_t t = lo; t <= hi && t <= tiles; t++) tile_first[t] = g;
 }
-void tile_first(const uint32_t* segb, uint32_t n_groups, uint32_t tile, uint32_t tiles, uint32_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_tile_first, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s, segb, n_groups, tile,
-                       tiles, out);
+void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_tile_first<uint64_t>, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s,
+                           static_cast<const uint64_t*>(segb), n_groups, EMIT_TILE, tiles, out);
+    else
+        hipLaunchKernelGGL(k_tile_first<uint32_t>, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s,
+                           static_cast<const uint32_t*>(segb), n_groups, EMIT_TILE, tiles, out);
     MMT_HIP(hipGetLastError());
 }
 
-template <int BLOCK, int CAP, int TILE>
-__global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __restrict__ tile_first) {
+template <int BLOCK, int CAP, int TILE, typename P, typename SA>
+__global__ __launch_bounds__(BLOCK) void k_emit(EmitArgsT<P, SA> a, const uint32_t* __restrict__ tile_first) {
     __shared__ EmitShared<BLOCK, CAP> sh;
-    __shared__ uint32_t s_gb[TILE + 2];          // begin offsets of the groups that start in this tile (+ the next one)
+    __shared__ uint32_t s_gb[TILE + 2];          // begin offsets of the groups that start in this tile (+ the next one), minus the tile's first offset
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // groups whose begin offset lies in [b*TILE, (b+1)*TILE): at most TILE of them, every group has an element
-    const uint32_t g0 = tile_first[blockIdx.x], g_end = tile_first[blockIdx.x + 1];
+    const uint64_t tile = a.tile_lo + blockIdx.x;
+    const P tbase = (P)(tile * TILE);
+    // groups whose begin offset lies in [tile*TILE, (tile+1)*TILE): at most TILE of them, every group has an element
+    const uint32_t g0 = tile_first[tile], g_end = tile_first[tile + 1];
     const uint32_t ng = g_end - g0;
-    for (uint32_t i = tid; i <= ng; i += BLOCK) s_gb[i] = a.segb[g0 + i];
+    for (uint32_t i = tid; i <= ng; i += BLOCK) {
+        const uint64_t d = (uint64_t)a.segb[g0 + i] - (uint64_t)tbase;      // the group after the last one may start far away
+        s_gb[i] = d < 0x7fffffffull ? (uint32_t)d : 0x7fffffffu;
+    }
     __syncthreads();
     uint32_t g = g0;
     while (g < g_end) {
         // chunk = maximal run of whole groups [g, g2) with at most CAP elements
         __syncthreads();
         if (wave == 0) {
-            const uint32_t lim = s_gb[g - g0] + CAP;         // n + 1 + CAP < 2^32 is checked on the host
+            const uint32_t lim = s_gb[g - g0] + CAP;
             uint32_t c = 0;                                  // groups after g that still begin at or before lim
             for (uint32_t base = g - g0 + 1; base <= ng; base += 64) {
                 const uint32_t idx = base + lane;
@@ -737,30 +799,33 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __re
         const uint32_t g2 = sh.bound[2];
         if (g2 > g) {
             const uint32_t clo = s_gb[g - g0];
-            emit_piece<BLOCK, CAP>(a, sh, a.sege[g], a.sege[g2], clo, s_gb[g2 - g0] - clo, true, 0u);
+            emit_piece<BLOCK, CAP, P, SA>(a, sh, a.sege[g], a.sege[g2], tbase + clo, s_gb[g2 - g0] - clo, true, (P)0);
             g = g2;
             continue;
         }
         // a single group larger than CAP: expand it piecewise, unsorted, into the compact fallback arrays
         // (its slot there was assigned by the host-side prefix sum over the oversized groups)
         if (wave == 0) {
-            const uint32_t f = wave_lower_bound(a.fb_group, a.n_fb, g);      // fb_group[f] == g
-            if (lane == 0) sh.bound[3] = a.segb[g] - a.fb_off[f];            // output offset -> fallback offset
+            const uint32_t f = wave_lower_bound<uint32_t>(a.fb_group, a.n_fb, g);      // fb_group[f] == g
+            if (lane == 0) sh.origin = (uint64_t)a.segb[g] - ((uint64_t)a.fb_off[f] - (uint64_t)a.fb_base);
         }
         __syncthreads();
-        const uint32_t fb_shift = sh.bound[3];
+        const P fb_origin = (P)sh.origin;
         const uint32_t e_end = a.sege[g + 1];
         uint32_t e = a.sege[g];
         while (e < e_end) {
             __syncthreads();
-            const uint32_t base = a.ce_eoff[e], c = a.ce_cnt[e];
+            const P base = a.ce_eoff[e];
+            const uint32_t c = a.ce_cnt[e];
             if (c > CAP / 2) {                               // one frequent phrase: plain strided copy
                 const uint32_t first = a.ce_first[e], om1 = a.ce_offm1[e];
                 const uint32_t low = a.fb_bits ? a.bwt_code[a.ce_bwt[e]] : 0u;
+                const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
+                const uint32_t slot0 = (uint32_t)(base - fb_origin);
                 for (uint32_t k = tid; k < c; k += BLOCK) {
-                    const uint2 kp = a.occ[first + k];
-                    a.fb_keys[base - fb_shift + k] = (kp.x << a.fb_bits) | low;
-                    a.fb_vals[base - fb_shift + k] = kp.y + om1;
+                    const uint64_t kp = a.occ[first + k];
+                    a.fb_keys[slot0 + k] = ((uint32_t)(kp >> a.pos_bits) << a.fb_bits) | low;
+                    a.fb_vals[slot0 + k] = (P)((kp & pos_mask) + om1);
                 }
                 e++;
                 continue;
@@ -768,7 +833,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __re
             if (wave == 0) {
                 // entries [e, e2) with at most CAP elements and at most CAP entries
                 const uint32_t room = e_end - e < (uint32_t)CAP ? e_end - e : (uint32_t)CAP;
-                const uint32_t cntE = wave_lower_bound(a.ce_eoff + e, room, base + CAP + 1);  // first entry starting > base+CAP
+                const uint32_t cntE = wave_lower_bound<P>(a.ce_eoff + e, room, base + CAP + 1);  // first entry starting > base+CAP
                 uint32_t e2 = e + cntE;                      // entries before it start <= base + CAP
                 // the last of them may end beyond base + CAP: drop it unless it is the only one
                 if (lane == 0) {
@@ -778,62 +843,123 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgs a, const uint32_t* __re
             }
             __syncthreads();
             const uint32_t e2 = sh.bound[2];
-            const uint32_t endoff = e2 < e_end ? a.ce_eoff[e2] : a.segb[g + 1];
-            emit_piece<BLOCK, CAP>(a, sh, e, e2, base, endoff - base, false, fb_shift);
+            const P endoff = e2 < e_end ? a.ce_eoff[e2] : a.segb[g + 1];
+            emit_piece<BLOCK, CAP, P, SA>(a, sh, e, e2, base, (uint32_t)(endoff - base), false, fb_origin);
             e = e2;
         }
         g = g + 1;
     }
 }
 
-void emit(const EmitArgs& a, uint32_t n_out, uint32_t* tile_first_buf, hipStream_t s) {
+template <typename P, typename SA>
+static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
     constexpr int BLOCK = 256, CAP = (int)EMIT_CAP, TILE = (int)EMIT_TILE;
-    const uint32_t tiles = (uint32_t)(((uint64_t)n_out + TILE - 1) / TILE);
-    tile_first(a.segb, a.n_groups, (uint32_t)TILE, tiles, tile_first_buf, s);
-    hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE>), dim3(tiles), dim3(BLOCK), 0, s, a, tile_first_buf);
+    EmitArgsT<P, SA> t;
+    t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
+    t.ce_eoff = static_cast<const P*>(a.ce_eoff); t.ce_cnt = a.ce_cnt; t.ce_first = a.ce_first; t.ce_offm1 = a.ce_offm1;
+    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.pos_bits = a.pos_bits; t.n = (P)a.n;
+    t.sa = SA(a.sa); t.bwt = a.bwt;
+    t.fb_group = a.fb_group; t.fb_off = static_cast<const P*>(a.fb_off); t.n_fb = a.n_fb; t.fb_base = (P)a.fb_base;
+    t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
+    t.bwt_code = a.bwt_code; t.fb_bits = a.fb_bits; t.err = a.err; t.tile_lo = tile_lo;
+    hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3((unsigned)(tile_hi - tile_lo)), dim3(BLOCK), 0, s, t,
+                       tile_first_tab);
     MMT_HIP(hipGetLastError());
+}
+void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
+    if (tile_hi <= tile_lo) return;
+    if (a.wide) emit_typed<uint64_t, Sa40>(a, tile_first_tab, tile_lo, tile_hi, s);
+    else emit_typed<uint32_t, Sa32>(a, tile_first_tab, tile_lo, tile_hi, s);
 }
 
 // osize[g] = size of group g if it exceeds the emitter's LDS tile, else 0
-__global__ void k_oversize(const uint32_t* __restrict__ segb, uint32_t n_groups, uint32_t cap,
-                           uint32_t* __restrict__ osize) {
+template <typename P>
+__global__ void k_oversize(const P* __restrict__ segb, uint32_t n_groups, uint32_t cap,
+                           uint32_t* __restrict__ osize, uint32_t* __restrict__ err) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
-    const uint32_t sz = segb[g + 1] - segb[g];
-    osize[g] = sz > cap ? sz : 0u;
+    const uint64_t sz = (uint64_t)segb[g + 1] - (uint64_t)segb[g];
+    if (sz >= 0xffffffffull) atomicAdd(err + 2, 1u);       // one suffix group of 2^32 elements: not supported
+    osize[g] = sz > cap ? (uint32_t)sz : 0u;
 }
-void oversize(const uint32_t* segb, uint32_t n_groups, uint32_t* osize, hipStream_t s) {
-    hipLaunchKernelGGL(k_oversize, dim3(grid_for(n_groups, 256)), dim3(256), 0, s, segb, n_groups, EMIT_CAP, osize);
+void oversize(const void* segb, uint32_t n_groups, uint32_t* osize, uint32_t* err, bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_oversize<uint64_t>, dim3(grid_for(n_groups, 256)), dim3(256), 0, s,
+                           static_cast<const uint64_t*>(segb), n_groups, EMIT_CAP, osize, err);
+    else
+        hipLaunchKernelGGL(k_oversize<uint32_t>, dim3(grid_for(n_groups, 256)), dim3(256), 0, s,
+                           static_cast<const uint32_t*>(segb), n_groups, EMIT_CAP, osize, err);
     MMT_HIP(hipGetLastError());
 }
 
-// oversized groups after their segmented sort: sa / rank / bwt from the sorted values
-__global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const uint32_t* __restrict__ fb_off,
-                                  uint32_t n_fb, const uint32_t* __restrict__ segb,
-                                  const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_vals,
-                                  uint32_t fb_bits, BwtDecode decode, const uint8_t* __restrict__ text, uint32_t n,
-                                  uint32_t* __restrict__ sa, uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
-    const uint32_t f = blockIdx.x;
-    if (f >= n_fb) return;
-    const uint32_t lo = fb_off[f], hi = fb_off[f + 1], out0 = segb[fb_group[f]];
+template <typename P>
+__global__ void k_gather_pos(const P* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n, P* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = src[idx[i]];
+}
+void gather_pos(const void* src, const uint32_t* idx, uint32_t n, void* out, bool wide, hipStream_t s) {
+    if (!n) return;
+    if (wide)
+        hipLaunchKernelGGL(k_gather_pos<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, static_cast<const uint64_t*>(src),
+                           idx, n, static_cast<uint64_t*>(out));
+    else
+        hipLaunchKernelGGL(k_gather_pos<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, static_cast<const uint32_t*>(src),
+                           idx, n, static_cast<uint32_t*>(out));
+    MMT_HIP(hipGetLastError());
+}
+
+template <typename P>
+__global__ void k_relative_offsets(const P* __restrict__ fb_off, uint32_t f0, uint32_t count, uint32_t* __restrict__ rel) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= count) rel[i] = (uint32_t)(fb_off[f0 + i] - fb_off[f0]);
+}
+void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t* rel, bool wide, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_relative_offsets<uint64_t>, dim3(grid_for((uint64_t)count + 1, 256)), dim3(256), 0, s,
+                           static_cast<const uint64_t*>(fb_off), f0, count, rel);
+    else
+        hipLaunchKernelGGL(k_relative_offsets<uint32_t>, dim3(grid_for((uint64_t)count + 1, 256)), dim3(256), 0, s,
+                           static_cast<const uint32_t*>(fb_off), f0, count, rel);
+    MMT_HIP(hipGetLastError());
+}
+
+// oversized groups after their segmented sort: sa / bwt from the sorted values
+template <typename P, typename SA>
+__global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P* __restrict__ fb_off, uint32_t f0,
+                                  uint32_t f1, P fb_base, const P* __restrict__ segb,
+                                  const uint32_t* __restrict__ sorted_keys, const P* __restrict__ sorted_vals,
+                                  uint32_t fb_bits, BwtDecode decode, const uint8_t* __restrict__ text, P n, SA sa,
+                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
+    const uint32_t f = f0 + blockIdx.x;
+    if (f >= f1) return;
+    const uint32_t lo = (uint32_t)(fb_off[f] - fb_base), hi = (uint32_t)(fb_off[f + 1] - fb_base);
+    const P out0 = segb[fb_group[f]];
     const uint32_t mask = (1u << fb_bits) - 1u;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const uint32_t p = sorted_vals[i], out = out0 + (i - lo);
+        const P p = sorted_vals[i], out = out0 + (i - lo);
         if (out == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
-        sa[out - 1] = p;
+        sa.set(out - 1, p);
         if (fb_bits) bwt[out - 1] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
         else bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;
     }
 }
-void fallback_finish(const uint32_t* fb_group, const uint32_t* fb_off, uint32_t n_fb, const uint32_t* segb,
-                     const uint32_t* sorted_keys, const uint32_t* sorted_vals, uint32_t fb_bits, const BwtDecode& decode,
-                     const uint8_t* text, uint32_t n, uint32_t* sa, uint8_t* bwt, uint32_t* err, hipStream_t s) {
-    if (!n_fb) return;
-    hipLaunchKernelGGL(k_fallback_finish, dim3(n_fb), dim3(256), 0, s, fb_group, fb_off, n_fb, segb, sorted_keys,
-                       sorted_vals, fb_bits, decode, text, n, sa, bwt, err);
+void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
+                     const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
+                     const BwtDecode& decode, const uint8_t* text, uint64_t n, SaCol sa, uint8_t* bwt, uint32_t* err,
+                     bool wide, hipStream_t s) {
+    if (f1 <= f0) return;
+    if (wide)
+        hipLaunchKernelGGL((k_fallback_finish<uint64_t, Sa40>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
+                           static_cast<const uint64_t*>(fb_off), f0, f1, (uint64_t)fb_base, static_cast<const uint64_t*>(segb),
+                           sorted_keys, static_cast<const uint64_t*>(sorted_vals), fb_bits, decode, text, (uint64_t)n,
+                           Sa40(sa), bwt, err);
+    else
+        hipLaunchKernelGGL((k_fallback_finish<uint32_t, Sa32>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
+                           static_cast<const uint32_t*>(fb_off), f0, f1, (uint32_t)fb_base, static_cast<const uint32_t*>(segb),
+                           sorted_keys, static_cast<const uint32_t*>(sorted_vals), fb_bits, decode, text, (uint32_t)n,
+                           Sa32(sa), bwt, err);
     MMT_HIP(hipGetLastError());
 }
-
 
 __global__ void k_iota(uint32_t* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

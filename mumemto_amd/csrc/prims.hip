@@ -113,6 +113,15 @@ void inclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out,
         return rocprim::inclusive_scan(t, b, in, out, n, rocprim::plus<uint32_t>(), s);
     });
 }
+struct WidenU32 {
+    __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
+};
+void exclusive_sum_u32_to_u64(DevBuf<uint8_t>& temp, const uint32_t* in, uint64_t* out, size_t n, hipStream_t s) {
+    auto it = rocprim::make_transform_iterator(in, WidenU32());
+    with_temp(temp, [&](void* t, size_t& b) {
+        return rocprim::exclusive_scan(t, b, it, out, uint64_t(0), n, rocprim::plus<uint64_t>(), s);
+    });
+}
 void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out, size_t n, hipStream_t s) {
     with_temp(temp, [&](void* t, size_t& b) {
         return rocprim::exclusive_scan(t, b, in, out, uint64_t(0), n, rocprim::plus<uint64_t>(), s);
@@ -197,8 +206,8 @@ void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint3
 // into one bucket of a doubling round, and such a round then takes hundreds of milliseconds), so the range list is read
 // on the host and a range beyond GIANT elements gets a device-wide radix sort of its own; the others share one
 // segmented sort as before.  MMT_GIANT_RANGE overrides the threshold (tests).
-template <typename K>
-static void sort_ranges(DevBuf<uint8_t>& temp, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, uint32_t n,
+template <typename K, typename V>
+static void sort_ranges(DevBuf<uint8_t>& temp, const K* kin, K* kout, const V* vin, V* vout, uint32_t n,
                         uint32_t segments, const uint32_t* begin, const uint32_t* end, int end_bit, hipStream_t s) {
     static const uint32_t GIANT = std::getenv("MMT_GIANT_RANGE") ? (uint32_t)std::atoi(std::getenv("MMT_GIANT_RANGE")) : 65536u;
     if (!segments) return;
@@ -263,6 +272,12 @@ static void sort_ranges(DevBuf<uint8_t>& temp, const K* kin, K* kout, const uint
 void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s) {
+    sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
+}
+
+void segmented_sort_pairs_u32_u64vals_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint64_t* vin,
+                                             uint64_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                             const uint32_t* end, int end_bit, hipStream_t s) {
     sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
 }
 

@@ -17,6 +17,7 @@ void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* ko
 void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
 void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
 void inclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
+void exclusive_sum_u32_to_u64(DevBuf<uint8_t>& temp, const uint32_t* in, uint64_t* out, size_t n, hipStream_t s);
 void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out, size_t n, hipStream_t s);
 // out[k] = index i of the k-th set flag; *d_count = number of set flags
 void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
@@ -28,6 +29,10 @@ void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint3
 void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s);
+
+void segmented_sort_pairs_u32_u64vals_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint64_t* vin,
+                                             uint64_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                             const uint32_t* end, int end_bit, hipStream_t s);
 
 // 64-bit keys, ranges [begin[i], end[i]) of one array; elements outside the ranges are not touched
 void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,

@@ -51,35 +51,70 @@ __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t lane, uin
 }
 
 // key for the pop order of the reference's stack: closing position ascending, longer first
-__global__ void k_row_keys(const k::Cand* __restrict__ rows, uint32_t n_rows, uint64_t* __restrict__ keys,
+__global__ void k_row_keys(const k::Row* __restrict__ rows, uint32_t n_rows, uint64_t* __restrict__ keys,
                            uint32_t* __restrict__ vals) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
-    keys[r] = ((uint64_t)rows[r].end << 32) | (uint32_t)(~rows[r].len);
+    const k::Row c = rows[r];
+    keys[r] = ((c.start + c.cnt - 1) << 32) | (uint32_t)(~c.len);
     vals[r] = r;
 }
-void row_keys(const k::Cand* rows, uint32_t n_rows, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+void row_keys(const k::Row* rows, uint32_t n_rows, uint64_t* keys, uint32_t* vals, hipStream_t s) {
     if (!n_rows) return;
     hipLaunchKernelGGL(k_row_keys, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, rows, n_rows, keys, vals);
     MMT_HIP(hipGetLastError());
 }
+__global__ void k_row_len_keys(const k::Row* __restrict__ rows, uint32_t n_rows, uint32_t* __restrict__ keys,
+                               uint32_t* __restrict__ vals) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    keys[r] = ~rows[r].len;
+    vals[r] = r;
+}
+void row_len_keys(const k::Row* rows, uint32_t n_rows, uint32_t* keys, uint32_t* vals, hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_row_len_keys, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, rows, n_rows, keys, vals);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_row_end_keys(const k::Row* __restrict__ rows, const uint32_t* __restrict__ order, uint32_t n_rows,
+                               uint64_t* __restrict__ keys) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const k::Row c = rows[order[r]];
+    keys[r] = c.start + c.cnt - 1;
+}
+void row_end_keys(const k::Row* rows, const uint32_t* order, uint32_t n_rows, uint64_t* keys, hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_row_end_keys, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, rows, order, n_rows, keys);
+    MMT_HIP(hipGetLastError());
+}
+
+template <typename SA>
+struct RowArgsT {
+    const k::Row* rows; const uint32_t* order; uint32_t n_rows; SA sa; const uint64_t* doc_start; const uint64_t* doc_len;
+    uint32_t n_docs; int revcomp;
+    explicit RowArgsT(const RowArgs& a)
+        : rows(a.rows), order(a.order), n_rows(a.n_rows), sa(SA(a.sa)), doc_start(a.doc_start), doc_len(a.doc_len),
+          n_docs(a.n_docs), revcomp(a.revcomp) {}
+};
 
 // ---- MUM mode --------------------------------------------------------------------
 // slot arrays (n_rows x n_docs) must be pre-set: offsets = -1, strands = 0.
-__global__ void k_mum_measure(RowArgs a, int64_t* __restrict__ slot_off, uint8_t* __restrict__ slot_st,
+template <typename SA>
+__global__ void k_mum_measure(RowArgsT<SA> a, int64_t* __restrict__ slot_off, uint8_t* __restrict__ slot_st,
                               uint32_t* __restrict__ keep, uint32_t* __restrict__ text_len) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (r >= a.n_rows) return;
-    const k::Cand c = a.rows[a.order[r]];
-    const uint32_t cnt = c.end - c.start + 1, N = a.n_docs;
+    const k::Row c = a.rows[a.order[r]];
+    const uint32_t cnt = c.cnt, N = a.n_docs;
     const uint64_t len = c.len;
     uint32_t drop = 0, digits = 0, present = 0;
     uint32_t first_key = 0xffffffffu;       // (doc << 1 | minus), smallest doc among 0..N-2
     uint32_t last_minus = 0;                // strand of doc N-1 if present
     for (uint32_t base = 0; base < cnt; base += 64) {
         if (base + lane < cnt) {                                     // write_mum, mem_finder.hpp:365-380
-            const uint64_t sa = a.sa[c.start + base + lane];
+            const uint64_t sa = a.sa.get(c.start + base + lane);
             const uint32_t d = doc_lookup(a.doc_start, N, sa);
             const uint64_t half = a.doc_len[d] + 1;
             uint64_t pos = sa - a.doc_start[d];
@@ -110,7 +145,8 @@ __global__ void k_mum_measure(RowArgs a, int64_t* __restrict__ slot_off, uint8_t
     }
 }
 
-__global__ void k_mum_write(RowArgs a, const int64_t* __restrict__ slot_off, const uint8_t* __restrict__ slot_st,
+template <typename SA>
+__global__ void k_mum_write(RowArgsT<SA> a, const int64_t* __restrict__ slot_off, const uint8_t* __restrict__ slot_st,
                             const uint32_t* __restrict__ keep, const uint32_t* __restrict__ row_idx,
                             const uint64_t* __restrict__ text_off, uint32_t* __restrict__ out_len,
                             int64_t* __restrict__ out_off, uint8_t* __restrict__ out_st, char* __restrict__ text) {
@@ -158,10 +194,11 @@ __global__ void k_mum_write(RowArgs a, const int64_t* __restrict__ slot_off, con
 }
 
 // ---- MEM mode ---------------------------------------------------------------------
-__device__ __forceinline__ void mem_occurrence(const RowArgs& a, const k::Cand& c, uint32_t k, uint64_t& pos,
+template <typename SA>
+__device__ __forceinline__ void mem_occurrence(const RowArgsT<SA>& a, const k::Row& c, uint32_t k, uint64_t& pos,
                                                uint32_t& d, uint32_t& minus) {
-    const uint32_t cnt = c.end - c.start + 1;
-    const uint64_t sa = a.sa[c.start + k];
+    const uint32_t cnt = c.cnt;
+    const uint64_t sa = a.sa.get(c.start + k);
     d = doc_lookup(a.doc_start, a.n_docs, sa);
     const uint64_t half = a.doc_len[d] + 1;
     pos = sa - a.doc_start[d];
@@ -172,13 +209,14 @@ __device__ __forceinline__ void mem_occurrence(const RowArgs& a, const k::Cand& 
     }
 }
 
-__global__ void k_mem_measure(RowArgs a, uint32_t* __restrict__ occ_cnt, uint32_t* __restrict__ text_len,
+template <typename SA>
+__global__ void k_mem_measure(RowArgsT<SA> a, uint32_t* __restrict__ occ_cnt, uint32_t* __restrict__ text_len,
                               uint32_t* __restrict__ w_pos, uint32_t* __restrict__ w_doc) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (r >= a.n_rows) return;
-    const k::Cand c = a.rows[a.order[r]];
-    const uint32_t cnt = c.end - c.start + 1;
+    const k::Row c = a.rows[a.order[r]];
+    const uint32_t cnt = c.cnt;
     uint32_t dp = 0, dd = 0;
     for (uint32_t base = 0; base < cnt; base += 64) {
         if (base + lane < cnt) {
@@ -195,15 +233,16 @@ __global__ void k_mem_measure(RowArgs a, uint32_t* __restrict__ occ_cnt, uint32_
     }
 }
 
-__global__ void k_mem_write(RowArgs a, const uint64_t* __restrict__ occ_off, const uint64_t* __restrict__ text_off,
+template <typename SA>
+__global__ void k_mem_write(RowArgsT<SA> a, const uint64_t* __restrict__ occ_off, const uint64_t* __restrict__ text_off,
                             const uint32_t* __restrict__ w_pos, const uint32_t* __restrict__ w_doc,
                             uint32_t* __restrict__ out_len, int64_t* __restrict__ out_off,
                             uint64_t* __restrict__ out_doc, uint8_t* __restrict__ out_st, char* __restrict__ text) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (r >= a.n_rows) return;
-    const k::Cand c = a.rows[a.order[r]];
-    const uint32_t cnt = c.end - c.start + 1;
+    const k::Row c = a.rows[a.order[r]];
+    const uint32_t cnt = c.cnt;
     char* t = text + text_off[r];
     const uint32_t nl = ndigits(c.len);
     if (lane == 0) { put_uint(t, c.len, nl); t[nl] = '\t'; out_len[r] = c.len; }
@@ -237,31 +276,47 @@ __global__ void k_mem_write(RowArgs a, const uint64_t* __restrict__ occ_off, con
 void mum_measure(const RowArgs& a, int64_t* slot_off, uint8_t* slot_st, uint32_t* keep, uint32_t* text_len,
                  hipStream_t s) {
     if (!a.n_rows) return;
-    hipLaunchKernelGGL(k_mum_measure, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s, a, slot_off,
-                       slot_st, keep, text_len);
+    if (a.sa.wide())
+        hipLaunchKernelGGL(k_mum_measure<Sa40>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa40>(a), slot_off, slot_st, keep, text_len);
+    else
+        hipLaunchKernelGGL(k_mum_measure<Sa32>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa32>(a), slot_off, slot_st, keep, text_len);
     MMT_HIP(hipGetLastError());
 }
 void mum_write(const RowArgs& a, const int64_t* slot_off, const uint8_t* slot_st, const uint32_t* keep,
                const uint32_t* row_idx, const uint64_t* text_off, uint32_t* out_len, int64_t* out_off, uint8_t* out_st,
                char* text, hipStream_t s) {
     if (!a.n_rows) return;
-    hipLaunchKernelGGL(k_mum_write, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s, a, slot_off, slot_st,
-                       keep, row_idx, text_off, out_len, out_off, out_st, text);
+    if (a.sa.wide())
+        hipLaunchKernelGGL(k_mum_write<Sa40>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa40>(a), slot_off, slot_st, keep, row_idx, text_off, out_len, out_off, out_st, text);
+    else
+        hipLaunchKernelGGL(k_mum_write<Sa32>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa32>(a), slot_off, slot_st, keep, row_idx, text_off, out_len, out_off, out_st, text);
     MMT_HIP(hipGetLastError());
 }
 void mem_measure(const RowArgs& a, uint32_t* occ_cnt, uint32_t* text_len, uint32_t* w_pos, uint32_t* w_doc,
                  hipStream_t s) {
     if (!a.n_rows) return;
-    hipLaunchKernelGGL(k_mem_measure, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s, a, occ_cnt,
-                       text_len, w_pos, w_doc);
+    if (a.sa.wide())
+        hipLaunchKernelGGL(k_mem_measure<Sa40>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa40>(a), occ_cnt, text_len, w_pos, w_doc);
+    else
+        hipLaunchKernelGGL(k_mem_measure<Sa32>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa32>(a), occ_cnt, text_len, w_pos, w_doc);
     MMT_HIP(hipGetLastError());
 }
 void mem_write(const RowArgs& a, const uint64_t* occ_off, const uint64_t* text_off, const uint32_t* w_pos,
                const uint32_t* w_doc, uint32_t* out_len, int64_t* out_off, uint64_t* out_doc, uint8_t* out_st,
                char* text, hipStream_t s) {
     if (!a.n_rows) return;
-    hipLaunchKernelGGL(k_mem_write, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s, a, occ_off, text_off,
-                       w_pos, w_doc, out_len, out_off, out_doc, out_st, text);
+    if (a.sa.wide())
+        hipLaunchKernelGGL(k_mem_write<Sa40>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa40>(a), occ_off, text_off, w_pos, w_doc, out_len, out_off, out_doc, out_st, text);
+    else
+        hipLaunchKernelGGL(k_mem_write<Sa32>, dim3(grid_for((uint64_t)a.n_rows * 64, 256)), dim3(256), 0, s,
+                           RowArgsT<Sa32>(a), occ_off, text_off, w_pos, w_doc, out_len, out_off, out_doc, out_st, text);
     MMT_HIP(hipGetLastError());
 }
 

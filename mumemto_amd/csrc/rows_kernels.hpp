@@ -9,17 +9,22 @@
 namespace mmt { namespace rk {
 
 struct RowArgs {
-    const k::Cand* rows;        // accepted, left-maximal intervals (any order)
+    const k::Row* rows;         // accepted, left-maximal intervals (any order)
     const uint32_t* order;      // order[r] = index into rows of the r-th row in pop order
     uint32_t n_rows;
-    const uint32_t* sa;
+    SaCol sa;
     const uint64_t* doc_start;  // N + 1
     const uint64_t* doc_len;    // N (bases per document)
     uint32_t n_docs;
     int revcomp;
 };
 
-void row_keys(const k::Cand* rows, uint32_t n_rows, uint64_t* keys, uint32_t* vals, hipStream_t s);
+// Keys for the pop order of the reference's stack (closing position ascending, longer first).  Closing positions
+// below 2^32: one 64-bit key (end << 32 | ~len).  Beyond: two stable sorts, first by len_keys (~len), then by
+// end_keys (end) with the order of the first sort as values.
+void row_keys(const k::Row* rows, uint32_t n_rows, uint64_t* keys, uint32_t* vals, hipStream_t s);
+void row_len_keys(const k::Row* rows, uint32_t n_rows, uint32_t* keys, uint32_t* vals, hipStream_t s);
+void row_end_keys(const k::Row* rows, const uint32_t* order, uint32_t n_rows, uint64_t* keys, hipStream_t s);
 void mum_measure(const RowArgs& a, int64_t* slot_off, uint8_t* slot_st, uint32_t* keep, uint32_t* text_len,
                  hipStream_t s);
 void mum_write(const RowArgs& a, const int64_t* slot_off, const uint8_t* slot_st, const uint32_t* keep,

@@ -312,13 +312,20 @@ class Engine:
         p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
         _check(self.L.mmt_engine_run(self.h, C.byref(p)))
 
-    def run_partitioned(self, docs, max_text_chars=0, min_match_len=20, use_revcomp=True):
-        """Strict multi-MUMs of host-resident docs of any size (anchor partitions + merge when needed)."""
-        lens = np.array([sum(len(r) for r in d) for d in docs], dtype=np.uint64)
-        flat = b"".join(b"".join(d) for d in docs)
-        bases = np.frombuffer(flat, dtype=np.uint8) if flat else np.zeros(1, np.uint8)
-        p = Params(min_match_len, 0, 1, 0, int(use_revcomp), 0)
-        _check(self.L.mmt_engine_run_partitioned(self.h, _p(bases), _p(lens), len(docs), C.byref(p), max_text_chars))
+    def run_partitioned(self, docs, max_text_chars=0, min_match_len=20, use_revcomp=True, num_distinct=0,
+                        max_doc_freq=1, max_total_freq=0, flat=None):
+        """Host-resident docs of any size: one suffix array when the text fits the device (40-bit positions beyond
+        2^32 characters), otherwise anchor partitions + merge (strict multi-MUMs only).  `flat` = (uint8 array of
+        the concatenated bases, uint64 array of document lengths) skips the Python-side concatenation."""
+        if flat is not None:
+            bases, lens = flat
+            lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        else:
+            lens = np.array([sum(len(r) for r in d) for d in docs], dtype=np.uint64)
+            joined = b"".join(b"".join(d) for d in docs)
+            bases = np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)
+        p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), 0)
+        _check(self.L.mmt_engine_run_partitioned(self.h, _p(bases), _p(lens), len(lens), C.byref(p), max_text_chars))
         return int(self.L.mmt_partitions_used(self.h))
 
     def merged_thresholds(self, anchor_len):

@@ -97,7 +97,7 @@ static std::vector<uint8_t> read_whole_file(const std::string& path, const char*
 // per entry.  The reference feeds the first |T| entries of the |T|+1 the writer produced to the match finder, i.e.
 // the sentinel entry and all real suffixes but the last; the engine takes exactly those real suffixes.
 static void load_stream_files(const std::string& prefix, uint64_t text_chars, std::vector<uint32_t>& sa,
-                              std::vector<uint32_t>& lcp, std::vector<uint8_t>& bwt) {
+                              std::vector<uint8_t>& sa_hi, std::vector<uint32_t>& lcp, std::vector<uint8_t>& bwt) {
     const std::vector<uint8_t> fsa = read_whole_file(prefix + ".sa", "SA"), flcp = read_whole_file(prefix + ".lcp", "LCP"),
                                fbwt = read_whole_file(prefix + ".bwt", "BWT");
     if (fsa.size() < text_chars * 5 || flcp.size() < text_chars * 5 || fbwt.size() < text_chars)
@@ -110,10 +110,15 @@ static void load_stream_files(const std::string& prefix, uint64_t text_chars, st
     };
     const uint64_t entries = text_chars ? text_chars - 1 : 0;      // stream entries 1 .. |T|-1
     sa.resize(entries); lcp.resize(entries); bwt.resize(entries);
+    const bool wide = text_chars >= NARROW_LIMIT;          // positions need the high byte (wide.hpp)
+    if (wide) sa_hi.resize(entries);
     for (uint64_t j = 0; j < entries; j++) {
-        const uint64_t s = get40(fsa, j + 1), l = get40(flcp, j + 1);
-        if (s > 0xffffffffull || l > 0xffffffffull) throw CliError{"array entry beyond 32 bits", 1};
+        const uint64_t s = get40(fsa, j + 1);
+        uint64_t l = get40(flcp, j + 1);
+        if (s > 0xffffffffull && !wide) throw CliError{"suffix array entry beyond the text", 1};
+        if (l > LCP_CAP) l = LCP_CAP;                       // lengths are 32 bits in the results (mumsio.hpp:18,24)
         sa[j] = (uint32_t)s; lcp[j] = (uint32_t)l; bwt[j] = fbwt[j + 1];
+        if (wide) sa_hi[j] = (uint8_t)(s >> 32);
     }
 }
 // -p PREFIX (src/pfp_mum.cpp:122-124, include/pfp.hpp:105-129): PREFIX.dict = sorted phrases, each closed by 0x01,
@@ -216,7 +221,7 @@ int main(int argc, char** argv) {
         uint64_t text_chars = 0;
         for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
         // stage checkpoints: the text (from PREFIX.parse/.dict) or the stream (PREFIX.sa/.lcp/.bwt) comes from files
-        std::vector<uint8_t> ck_text, ck_bwt;
+        std::vector<uint8_t> ck_text, ck_bwt, ck_sa_hi;
         std::vector<uint32_t> ck_sa, ck_lcp;
         if (o.from_parse_flag) {
             ck_text = text_from_parse(o.parse_prefix, o.pfp_w);
@@ -226,7 +231,7 @@ int main(int argc, char** argv) {
             log_line("build_main", "text of " + std::to_string(text_chars) + " characters rebuilt from " + o.parse_prefix +
                                        ".parse / .dict");
         } else if (o.arrays_in_flag) {
-            load_stream_files(o.arrays_in, text_chars, ck_sa, ck_lcp, ck_bwt);
+            load_stream_files(o.arrays_in, text_chars, ck_sa, ck_sa_hi, ck_lcp, ck_bwt);
             log_line("build_main", "Using pre-computed LCP/BWT/SA arrays from files with prefix: " + o.arrays_in);
         } else {
             write_lengths(o.output_prefix, docs);
@@ -255,17 +260,19 @@ int main(int argc, char** argv) {
         engine_init.join();
         if (engine_error) std::rethrow_exception(engine_error);
         Engine& eng = *engine;
+        // one suffix array while the text fits the device (40-bit positions beyond 2^32 characters); beyond that --
+        // or beyond MUMEMTO_MAX_TEXT characters -- strict multi-MUMs run as anchor partitions + merge on this GPU
         const uint64_t max_text = std::getenv("MUMEMTO_MAX_TEXT") ? std::strtoull(std::getenv("MUMEMTO_MAX_TEXT"), nullptr, 10)
-                                                                  : 0xfffff000ull - 1;
-        const bool partitioned = text_chars > max_text;
+                                                                  : (uint64_t)(0.92 * (double)pool::available(eng.device()) / 20.0);
+        const bool partitioned = text_chars > max_text && doc_len.size() >= 3;
         if (checkpoint && partitioned) throw CliError{"-p / -a are not available for inputs larger than one suffix array", 1};
         if (checkpoint && (o.keep_temp || o.arrays_out))
             throw CliError{"-K and -A write what -p / -a read: run them without a checkpoint", 1};
         mark("engine created");
         if (o.from_parse_flag) eng.set_text_host(ck_text.data(), ck_text.size(), doc_len.data(), doc_len.size(), o.use_rcomp);
         else if (o.arrays_in_flag)
-            eng.set_stream_host(ck_sa.data(), ck_lcp.data(), ck_bwt.data(), ck_sa.size(), doc_len.data(), doc_len.size(),
-                                o.use_rcomp);
+            eng.set_stream_host40(ck_sa.data(), ck_sa_hi.empty() ? nullptr : ck_sa_hi.data(), ck_lcp.data(), ck_bwt.data(),
+                                  ck_sa.size(), doc_len.data(), doc_len.size(), o.use_rcomp);
         else if (!partitioned) eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
         mark("input on the device");
         auto write_pfp_files = [&]() {              // PREFIX.dict / PREFIX.parse as newscan.hpp:406-419 writes them
@@ -320,9 +327,10 @@ int main(int argc, char** argv) {
         }
         if (o.arrays_out) {                         // pfp_lcp_mum.hpp:323-369: 40-bit SA / LCP, 1-byte BWT, n+1 entries
             const uint64_t n = eng.text_length();
-            std::vector<uint32_t> sa(n), lcp(n);
+            std::vector<uint64_t> sa(n);
+            std::vector<uint32_t> lcp(n);
             std::vector<uint8_t> bwt(n), text(n);
-            eng.copy_sa(sa.data()); eng.copy_lcp(lcp.data()); eng.copy_bwt(bwt.data()); eng.copy_text(text.data());
+            eng.copy_sa64(sa.data()); eng.copy_lcp(lcp.data()); eng.copy_bwt(bwt.data()); eng.copy_text(text.data());
             std::vector<uint8_t> fsa, flcp, fbwt;
             put40(fsa, n); put40(flcp, 0); fbwt.push_back(n ? text[n - 1] : 0);
             for (uint64_t j = 0; j < n; j++) { put40(fsa, sa[j]); put40(flcp, lcp[j]); fbwt.push_back(bwt[j]); }
@@ -331,9 +339,25 @@ int main(int argc, char** argv) {
             write_file(o.output_prefix + ".bwt", fbwt.data(), fbwt.size());
         }
         mark("outputs written");
+        const pool::Stats heap = pool::stats(eng.device());
         if (std::getenv("MUMEMTO_TIMING"))
-            std::fprintf(stderr, "[timing] device buffers: %.2f GB at the peak, %.3f s inside hipMalloc\n",
-                         DevBytes::peak() / 1073741824.0, DevBytes::seconds());
+            std::fprintf(stderr, "[timing] device heap: %.2f GB live at the peak, %.2f GB mapped, %.3f s mapping it\n",
+                         heap.peak / 1073741824.0, heap.mapped / 1073741824.0, heap.map_seconds);
+        if (const char* sp = std::getenv("MUMEMTO_STATS")) {       // one JSON object for bench.py
+            const float* sm = eng.stage_ms();
+            const float* pm = eng.pfp_state().ms;
+            std::ofstream js(sp);
+            js << "{\"text_chars\": " << text_chars << ", \"wide\": " << (eng.wide() ? "true" : "false")
+               << ", \"partitions\": " << eng.partitions_used() << ", \"scan_ranges\": " << eng.scan_ranges()
+               << ", \"rows\": " << R.n_rows << ", \"candidates\": " << eng.n_candidates()
+               << ", \"producer\": " << eng.producer_used() << ", \"stage_ms\": [";
+            for (int i = 0; i < 8; i++) js << (i ? ", " : "") << sm[i];
+            js << "], \"pfp_ms\": [";
+            for (int i = 0; i < 8; i++) js << (i ? ", " : "") << pm[i];
+            js << "], \"heap_peak_bytes\": " << heap.peak << ", \"heap_mapped_bytes\": " << heap.mapped
+               << ", \"heap_map_seconds\": " << heap.map_seconds << ", \"seconds_since_start\": " << secs_since(g_start)
+               << "}\n";
+        }
         log_line("build_main", "Found " + std::to_string(R.n_rows) + " matches!");
         if (o.keep_temp) write_pfp_files();         // -K: keep PREFIX.dict / PREFIX.parse
         const float* ms = eng.stage_ms();

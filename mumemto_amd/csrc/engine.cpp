@@ -220,6 +220,15 @@ void Engine::release_sort_scratch() {
     pfp_ = std::move(fresh);
 }
 
+void Engine::release_columns() {
+    MMT_HIP(hipStreamSynchronize(stream_));
+    release_sort_scratch();
+    d_text_.release(); d_bwt_.release(); d_sa_.release(); d_sa_hi_.release(); d_rank_.release(); d_rank64_.release();
+    d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
+    d_cand_.release(); d_flags_.release();
+    lcp_whole_ = false;
+}
+
 // Called after the suffix sort: the LCP stage is about to allocate the PLCP and LCP columns (8 bytes per text
 // character, plus the candidate list).  When the device does not have that much left, the sort stage's scratch goes.
 bool Engine::wants_lean() const {

@@ -79,6 +79,8 @@ public:
     // largest stage instead of the sum -- at the price of hipMalloc calls in every run.
     void set_lean(bool on) { lean_ = on; }
     void release_sort_scratch();
+    // gives every column and scratch buffer of the last run back to the device heap (results already downloaded stay)
+    void release_columns();
     bool wants_lean() const;
 
     // Results of the last run.  rows_meta(): counts and mode only; rows(need): also the host copies asked for

@@ -27,23 +27,34 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     std::vector<uint64_t> base(n_docs + 1, 0);
     uint64_t total = 0;
     for (size_t d = 0; d < n_docs; d++) { base[d + 1] = base[d] + doc_len[d]; total += mult * (doc_len[d] + 1); }
-    if (max_text == 0) {
-        // One suffix array of n characters peaks at about PEAK_BYTES_PER_CHAR bytes of device memory per character
-        // (wide run: text 1, suffix array 5, BWT 1, then either the emitter tables or PLCP 4 + the scan range;
-        // measured with MUMEMTO_TIMING=1 on 94 x 64 Mbp: DESIGN.md); MMT_MAX_TEXT overrides (tests).
-        constexpr double PEAK_BYTES_PER_CHAR = 20.0;
-        const double avail = 0.92 * (double)pool::available(device_);
+    const bool strict = p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == n_docs) &&
+                        (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
+    release_columns();                       // what the previous run left behind counts as free memory below
+    const bool auto_limit = max_text == 0;
+    if (auto_limit) {
+        // One suffix array of n characters peaks at 14 (94 x 64 Mbp at 0.1 % divergence) to 21 (36 x 60 Mbp at 0.2 %)
+        // bytes of device memory per character: text 1, suffix array 5, BWT 1, then either the emitter tables --
+        // which grow with the dictionary, i.e. with the divergence -- or PLCP 4 + the scan range.
+        // A single-array run that still runs out of memory is repeated as partitions when the mode allows it.
+        constexpr double PEAK_BYTES_PER_CHAR = 16.0;
+        const double avail = 0.95 * (double)pool::available(device_);
         max_text = (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1));
         if (const char* c = std::getenv("MMT_MAX_TEXT")) max_text = std::strtoull(c, nullptr, 10);
     }
     partitions_used_ = 1;
-    if (total <= max_text || n_docs < 3) {
-        set_input_host(h_bases, doc_len, n_docs);
-        run(p);
-        return;
+    if (total <= max_text || n_docs < 3 || !strict) {
+        try {
+            set_input_host(h_bases, doc_len, n_docs);
+            run(p);
+            return;
+        } catch (const HipError& e) {
+            const bool oom = std::string(e.what()).find("out of device memory") != std::string::npos;
+            if (!oom || !strict || n_docs < 3 || !auto_limit) throw;
+            release_columns();
+            d_bases_own_.release();
+            max_text = total / 2;            // partitions of at most half the text, and so on below
+        }
     }
-    const bool strict = p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == n_docs) &&
-                        (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
     if (!strict)
         throw std::runtime_error("the text (" + std::to_string(total) + " characters) does not fit the device as one "
                                  "suffix array (limit " + std::to_string(max_text) + ") and only strict multi-MUMs "

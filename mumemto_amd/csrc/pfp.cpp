@@ -6,6 +6,8 @@
 // dictionary position or parse position is 32 bits in both.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "engine.hpp"
@@ -55,7 +57,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     S.tmask.ensure((size_t)((n + 15) / 16) + 1); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
     pk::trigger_masks(d_text_.get(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
-    S.err.ensure(4);
+    S.err.ensure(16);
     {
         const uint64_t cuts64 = (uint64_t)read_u32(S.toff.get() + (tb - 1), st) + read_u32(S.tcnt.get() + (tb - 1), st);
         if (cuts64 >= 0x7ffffffdull) throw std::runtime_error("more than 2^31 - 2 phrases (newscan.hpp:44)");
@@ -220,6 +222,17 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
                        S.occ.get(), pos_bits, W, st);
         MMT_HIP(hipStreamSynchronize(st));
     }
+    if (std::getenv("MMT_DEBUG_SENTINEL")) {
+        std::vector<uint32_t> lastid, pl;
+        d2h(lastid, S.pid.get() + (m - 1), 1, st); d2h(pl, S.plen.get() + (m - 1), 1, st);
+        std::vector<uint32_t> os;
+        d2h(os, S.occ_start.get() + lastid[0], 2, st);
+        std::vector<uint64_t> rec;
+        d2h(rec, S.occ.get() + os[0], 1, st);
+        std::fprintf(stderr, "[sentinel] last phrase: start %llu len %u id %u, its list [%u, %u), first record t %llu pos %llu\n",
+                     (unsigned long long)S.pstart.read(m - 1, st), pl[0], lastid[0], os[0], os[1],
+                     (unsigned long long)(rec[0] >> pos_bits), (unsigned long long)(rec[0] & ((1ull << pos_bits) - 1)));
+    }
     if (slim) { S.occ_ids.release(); S.occ_ts.release(); S.sa_p.release(); S.pid.release(); S.pstart.release(); }
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
     S.vscan.ensure(nd); S.ptab.ensure((size_t)D * 16 + 16);
@@ -248,6 +261,20 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     pk::gather_pos(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), W, st);
     MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &E, 4, hipMemcpyHostToDevice, st));
     S.segb.write(G, n + 1, st);
+    if (std::getenv("MMT_DEBUG_SENTINEL")) {       // where does the end sentinel (stream entry 0) come from?
+        std::vector<uint32_t> cnt2, first2, off2, sg2;
+        d2h(cnt2, S.ce_cnt.get(), 2, st); d2h(first2, S.ce_first.get(), 2, st); d2h(off2, S.ce_offm1.get(), 2, st);
+        d2h(sg2, S.sege.get(), 2, st);
+        std::vector<uint64_t> o2;
+        d2h(o2, S.occ.get() + first2[0], 1, st);
+        std::fprintf(stderr, "[sentinel] n %llu m %u pos_bits %u shift %d | entry0: cnt %u first %u offm1 %u | entry1: cnt %u first %u "
+                     "offm1 %u | ce_eoff %llu %llu | segb %llu %llu | sege %u %u | occ[first0] = t %llu, pos %llu -> text %llu\n",
+                     (unsigned long long)n, m, pos_bits, shift, cnt2[0], first2[0], off2[0], cnt2[1], first2[1], off2[1],
+                     (unsigned long long)S.ce_eoff.read(0, st), (unsigned long long)S.ce_eoff.read(1, st),
+                     (unsigned long long)S.segb.read(0, st), (unsigned long long)S.segb.read(1, st), sg2[0], sg2[1],
+                     (unsigned long long)(o2[0] >> pos_bits), (unsigned long long)(o2[0] & ((1ull << pos_bits) - 1)),
+                     (unsigned long long)((o2[0] & ((1ull << pos_bits) - 1)) + off2[0]));
+    }
     // groups larger than one LDS tile of the emitter get compact slots in the fallback arrays
     S.gscan.ensure(std::max<size_t>(G, 1));
     uint32_t* osize = S.gscan.get();
@@ -317,7 +344,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     S.xk_a.ensure((size_t)max_fb + 1); S.xv_a.ensure((size_t)max_fb + 1, W);
     (void)fb_total;
     // the emitter
-    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
     pk::EmitArgs ea;
     ea.wide = W;
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
@@ -374,7 +401,17 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), L.f0, L.f1, h_fb_off[L.f0], S.segb.get(), S.xk_b.get(),
                             S.xv_b.get(), fb_bits, decode, d_text_.get(), n, sa_col(), d_bwt_.get(), S.err.get(), W, st);
     }
-    if (read_u32(S.err.get(), st)) throw std::runtime_error("PFP order: the end sentinel is not first");
+    if (read_u32(S.err.get(), st)) {
+        std::vector<uint32_t> er;
+        d2h(er, S.err.get(), 16, st);
+        auto u64 = [&](int i) { return (unsigned long long)er[i] | ((unsigned long long)er[i + 1] << 32); };
+        char msg[400];
+        std::snprintf(msg, sizeof(msg), "PFP order is inconsistent: %u entries (sentinel not first %u; text position past the "
+                      "end: %u in tile groups [first: position %llu at stream entry %llu], %u / %u in oversized groups [first: "
+                      "position %llu at entry %llu]); text %llu characters", er[0], er[4], er[5], u64(8), u64(10), er[6], er[7],
+                      u64(12), u64(14), (unsigned long long)n);
+        throw std::runtime_error(msg);
+    }
     S.bwt_ready = true;
     e6.stop(st);
     S.ms[5] = e5.ms(); S.ms[6] = e6.ms();

@@ -12,31 +12,48 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <string>
 
 #include "device_utils.hpp"
 #include "pfp_kernels.hpp"
 
 namespace mmt { namespace pk {
 
+// A launch may not have 2^32 work-items or more (HIP folds the product of grid and workgroup size into 32 bits: a
+// larger launch silently runs a fraction of its workgroups).  Every kernel here uses workgroups of at most 256
+// work-items with grid_for, so 2^24 workgroups is the limit; kernels over text-sized ranges handle 4 - 16 items per
+// work-item and stay below it for any text that fits the device.
 static inline unsigned grid_for(uint64_t items, unsigned per_block) {
     uint64_t g = (items + per_block - 1) / per_block;
+    if (g >= (1ull << 24)) throw HipError("kernel launch of 2^32 work-items or more (" + std::to_string(items) + " items)");
     return (unsigned)(g ? g : 1);
 }
 
 // V from T: V[0] = Dollar, V[1..n] = T, V[n+1..n+w] = Dollar, zero padding after.
+// Eight bytes of V per work-item: inside the text V[i .. i+7] = T[i-1 .. i+6] comes from two aligned words of T
+// (both buffers start on a 512-byte boundary), the two ends go byte by byte.
 __global__ void k_make_vtext(const uint8_t* __restrict__ text, uint64_t n, uint32_t w, uint8_t* __restrict__ v,
                              uint64_t vlen_padded) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= vlen_padded) return;
-    uint8_t c;
-    if (i == 0) c = 2;
-    else if (i <= n) c = text[i - 1];
-    else if (i <= n + w) c = 2;
-    else c = 0;
-    v[i] = c;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i0 = t * 8;
+    if (i0 >= vlen_padded) return;
+    if (t >= 1 && i0 + 7 <= n) {
+        const uint64_t* tw = reinterpret_cast<const uint64_t*>(text);
+        const uint64_t lo = tw[t - 1], hi = tw[t];                 // T[i0-8 .. i0-1], T[i0 .. i0+7] (the text is padded)
+        *reinterpret_cast<uint64_t*>(v + i0) = (lo >> 56) | (hi << 8);
+        return;
+    }
+    for (uint64_t i = i0; i < i0 + 8 && i < vlen_padded; i++) {
+        uint8_t c;
+        if (i == 0) c = 2;
+        else if (i <= n) c = text[i - 1];
+        else if (i <= n + w) c = 2;
+        else c = 0;
+        v[i] = c;
+    }
 }
 void make_vtext(const uint8_t* text, uint64_t n, uint32_t w, uint8_t* v, uint64_t vlen_padded, hipStream_t s) {
-    hipLaunchKernelGGL(k_make_vtext, dim3(grid_for(vlen_padded, 256)), dim3(256), 0, s, text, n, w, v, vlen_padded);
+    hipLaunchKernelGGL(k_make_vtext, dim3(grid_for((vlen_padded + 7) / 8, 256)), dim3(256), 0, s, text, n, w, v, vlen_padded);
     MMT_HIP(hipGetLastError());
 }
 
@@ -735,9 +752,15 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
             } while (e2 < E && !sh.egs[e2]);
             const P out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
             const P pos = my_pos[q];
-            if (out == 0) { if (pos != a.n) atomicAdd(a.err, 1u); }   // entry 0 must be the end sentinel
+            if (out == 0) { if (pos != a.n) { atomicAdd(a.err, 1u); atomicAdd(a.err + 4, 1u); } }   // entry 0 must be the end sentinel
             else if (pos < a.n) { a.sa.set(out - 1, pos); a.bwt[out - 1] = sh.ebwt[e]; }
-            else atomicAdd(a.err, 1u);
+            else {
+                atomicAdd(a.err, 1u);
+                if (atomicAdd(a.err + 5, 1u) == 0) {       // first offender, for the error message
+                    a.err[8] = (uint32_t)pos; a.err[9] = (uint32_t)((uint64_t)pos >> 32);
+                    a.err[10] = (uint32_t)out; a.err[11] = (uint32_t)((uint64_t)out >> 32);
+                }
+            }
         }
     }
 }
@@ -937,7 +960,14 @@ __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P
     const uint32_t mask = (1u << fb_bits) - 1u;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const P p = sorted_vals[i], out = out0 + (i - lo);
-        if (out == 0 || p >= n) { atomicAdd(err, 1u); continue; }   // the sentinel never sits in an oversized group
+        if (out == 0 || p >= n) {                                   // the sentinel never sits in an oversized group
+            atomicAdd(err, 1u);
+            if (atomicAdd(err + (out == 0 ? 6 : 7), 1u) == 0) {
+                err[12] = (uint32_t)p; err[13] = (uint32_t)((uint64_t)p >> 32);
+                err[14] = (uint32_t)out; err[15] = (uint32_t)((uint64_t)out >> 32);
+            }
+            continue;
+        }
         sa.set(out - 1, p);
         if (fb_bits) bwt[out - 1] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
         else bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;

@@ -18,7 +18,7 @@ namespace mmt { namespace pool {
 namespace {
 
 constexpr size_t ALIGN = 512;                    // every block starts on a 512-byte boundary (16-byte vector loads, LDS-DMA rows)
-constexpr size_t GROW = (size_t)256 << 20;       // physical memory is mapped in multiples of 256 MiB
+constexpr size_t GROW = (size_t)1 << 30;         // physical memory is mapped in chunks of 1 GiB
 
 struct Heap {
     int device = 0;
@@ -64,7 +64,9 @@ Heap& heap_for(int device) {
     return *g_heaps.back();
 }
 
-// map `bytes` (multiple of GROW) more physical memory at the top of the heap
+// map `bytes` (multiple of GROW) more physical memory at the top of the heap, in chunks of exactly GROW bytes:
+// hipMemSetAccess rejects ("invalid argument") some mappings when the chunks of one reservation differ in size
+// (tests/micro/vmm_probe.cpp), uniform ones have never failed
 bool grow(Heap& H, size_t bytes) {
     if (H.top + bytes > H.reserved) return false;
     const double t0 = now_s();
@@ -72,32 +74,44 @@ bool grow(Heap& H, size_t bytes) {
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = H.device;
-    hipMemGenericAllocationHandle_t handle;
-    if (hipMemCreate(&handle, bytes, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemMap(H.base + H.top, bytes, 0, handle, 0) != hipSuccess) {
-        (void)hipGetLastError(); (void)hipMemRelease(handle); return false;
-    }
     hipMemAccessDesc acc{};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(H.base + H.top, bytes, &acc, 1) != hipSuccess) {
-        (void)hipGetLastError(); (void)hipMemUnmap(H.base + H.top, bytes); (void)hipMemRelease(handle); return false;
+    size_t done = 0;
+    std::string why;
+    while (done < bytes) {
+        hipMemGenericAllocationHandle_t handle;
+        hipError_t e = hipMemCreate(&handle, GROW, &prop, 0);
+        if (e != hipSuccess) { why = std::string("hipMemCreate: ") + hipGetErrorString(e); (void)hipGetLastError(); break; }
+        char* at = H.base + H.top + done;
+        e = hipMemMap(at, GROW, 0, handle, 0);
+        if (e != hipSuccess) {
+            why = std::string("hipMemMap: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipMemRelease(handle); break;
+        }
+        e = hipMemSetAccess(at, GROW, &acc, 1);
+        if (e != hipSuccess) {
+            why = std::string("hipMemSetAccess: ") + hipGetErrorString(e); (void)hipGetLastError();
+            (void)hipMemUnmap(at, GROW); (void)hipMemRelease(handle); break;
+        }
+        H.handles.push_back(handle);
+        H.mapped.emplace_back(H.top + done, GROW);
+        done += GROW;
     }
-    H.handles.push_back(handle);
-    H.mapped.emplace_back(H.top, bytes);
-    // the new range joins the free list (coalesced with a free block that ends at the old top)
-    size_t off = H.top, size = bytes;
-    if (!H.free_blocks.empty()) {
-        auto last = std::prev(H.free_blocks.end());
-        if (last->first + last->second == H.top) { off = last->first; size += last->second; H.free_blocks.erase(last); }
-    }
-    H.free_blocks[off] = size;
-    H.top += bytes;
     H.map_seconds += now_s() - t0;
-    if (DevBytes::log())
-        std::fprintf(stderr, "[pool] device %d: +%.2f GB mapped, heap %.2f GB (%.3f s in the driver so far)\n", H.device,
-                     bytes / 1073741824.0, H.top / 1073741824.0, H.map_seconds);
-    return true;
+    if (done) {
+        // the new range joins the free list (coalesced with a free block that ends at the old top)
+        size_t off = H.top, size = done;
+        if (!H.free_blocks.empty()) {
+            auto last = std::prev(H.free_blocks.end());
+            if (last->first + last->second == H.top) { off = last->first; size += last->second; H.free_blocks.erase(last); }
+        }
+        H.free_blocks[off] = size;
+        H.top += done;
+    }
+    if (DevBytes::log() || done < bytes)
+        std::fprintf(stderr, "[pool] device %d: +%.2f GB mapped, heap %.2f GB (%.3f s in the driver so far)%s%s\n", H.device,
+                     done / 1073741824.0, H.top / 1073741824.0, H.map_seconds, done < bytes ? "; stopped by " : "", why.c_str());
+    return done == bytes;
 }
 
 void* take(Heap& H, size_t need) {

@@ -4,7 +4,7 @@
 // allocation that receives those pages waits for the wipe -- a stage that frees 48 GB and allocates 48 GB of a
 // different size stalls for 1.5 s (tests/micro/alloc_probe.cpp; round 1 saw the same thing as "hipMalloc costs 40-180
 // ms per GB after a hipFree").  A run therefore takes physical memory from the driver once and recycles it in user
-// space: the heap is one reserved virtual range (hipMemAddressReserve) whose mapped prefix grows in 256 MiB steps
+// space: the heap is one reserved virtual range (hipMemAddressReserve) whose mapped prefix grows in 1 GiB chunks
 // (hipMemCreate / hipMemMap), with a coalescing best-fit free list on top.  Stages can release their scratch as soon
 // as it is dead, so the footprint of a run is its largest stage, not the sum of all stages.
 // MUMEMTO_POOL=0 (or a driver without the virtual-memory API) falls back to hipMalloc / hipFree per buffer.

@@ -8,14 +8,20 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <string>
 
 #include "device_utils.hpp"
 #include "rows_kernels.hpp"
 
 namespace mmt { namespace rk {
 
+// A launch may not have 2^32 work-items or more (HIP folds the product of grid and workgroup size into 32 bits: a
+// larger launch silently runs a fraction of its workgroups).  Every kernel here uses workgroups of at most 256
+// work-items with grid_for, so 2^24 workgroups is the limit; kernels over text-sized ranges handle 4 - 16 items per
+// work-item and stay below it for any text that fits the device.
 static inline unsigned grid_for(uint64_t items, unsigned per_block) {
     uint64_t g = (items + per_block - 1) / per_block;
+    if (g >= (1ull << 24)) throw HipError("kernel launch of 2^32 work-items or more (" + std::to_string(items) + " items)");
     return (unsigned)(g ? g : 1);
 }
 

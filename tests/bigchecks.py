@@ -1,0 +1,169 @@
+"""Size-independent checks of a run too large for the CPU oracle: the suffix array is a permutation (count, sum,
+sum of squares, xor against the closed forms), sampled neighbours are in suffix order with exactly the reported LCP and
+BWT byte, sampled MUM rows are real, maximal, one-per-document matches."""
+import numpy as np
+
+_COMP = np.zeros(256, np.uint8)
+_COMP[:] = np.arange(256)
+for a, b in zip(b"ACGTUBDHKMRVY", b"TGCAAVHDMKYBR"):
+    _COMP[a] = b
+
+
+def host_text(bases, lens):
+    """T = F $ revcomp(F) $ per document (src/ref_builder.cpp:211-314), as a uint8 array."""
+    n = int(sum(2 * (int(l) + 1) for l in lens))
+    t = np.empty(n + 64, np.uint8)
+    t[n:] = 0
+    at, src = 0, 0
+    for l in lens:
+        l = int(l)
+        f = bases[src:src + l]
+        t[at:at + l] = f
+        t[at + l] = 36
+        t[at + l + 1:at + 2 * l + 1] = _COMP[f[::-1]]
+        t[at + 2 * l + 1] = 36
+        at += 2 * l + 2
+        src += l
+    return t, n
+
+
+def _lcp_of(text, n, p, q, cap=1 << 22):
+    h = 0
+    room = n - max(p, q)
+    step = 4096
+    while h < room:
+        k = min(step, room - h)
+        a, b = text[p + h:p + h + k], text[q + h:q + h + k]
+        d = np.nonzero(a != b)[0]
+        if len(d):
+            return h + int(d[0])
+        h += k
+        step = min(step * 4, cap)
+    return room
+
+
+def check_stream(eng, bases, lens, samples=400, light=False, seed=0):
+    text, n = host_text(bases, lens)
+    assert eng.text_length() == n
+    sa = eng.sa()
+    assert len(sa) == n
+    if not light:
+        # permutation of 0..n-1: closed forms of sum, sum of squares (mod 2^64) and xor; plus min / max
+        s1 = int(np.sum(sa, dtype=np.uint64))          # wraps mod 2^64, like the closed form below
+        s2 = 0
+        x = 0
+        for a in range(0, n, 1 << 27):
+            c = sa[a:a + (1 << 27)].astype(np.uint64)
+            s2 = (s2 + int(np.sum(c * c, dtype=np.uint64))) & (2 ** 64 - 1)
+            x ^= int(np.bitwise_xor.reduce(c))
+        exp1 = (n * (n - 1) // 2) & (2 ** 64 - 1)
+        exp2 = ((n - 1) * n * (2 * n - 1) // 6) & (2 ** 64 - 1)
+        m = (n - 1) & 3
+        expx = [n - 1, 1, n, 0][m]
+        assert int(sa.min()) == 0 and int(sa.max()) == n - 1
+        assert s1 == exp1 and s2 == exp2 and x == expx, "suffix array is not a permutation of the text positions"
+    lcp = eng.lcp()
+    bwt = eng.bwt()
+    assert lcp[0] == 0
+    rng = np.random.default_rng(seed)
+    js = np.concatenate([rng.integers(1, n, size=samples), np.arange(1, min(n, 50)), np.arange(max(1, n - 50), n)])
+    if n > 2 ** 32:      # neighbours of the first entries whose positions need the high byte
+        hi = np.nonzero(sa[: min(n, 1 << 24)] >= 2 ** 32)[0][:50]
+        js = np.concatenate([js, hi[hi > 0]])
+    for j in js:
+        j = int(j)
+        p, q = int(sa[j]), int(sa[j - 1])
+        h = _lcp_of(text, n, p, q)
+        assert int(lcp[j]) == h, (j, p, q, int(lcp[j]), h)
+        # suffix q < suffix p: the first differing character decides; the shorter suffix is smaller when one ends
+        if max(p, q) + h < n:
+            assert text[q + h] < text[p + h], (j, p, q, h)
+        else:
+            assert q > p, (j, p, q, h)
+        assert int(bwt[j]) == (int(text[p - 1]) if p else 0), j
+    print("stream: suffix array is a permutation; %d sampled entries are in suffix order with the reported LCP / BWT" % len(js),
+          flush=True)
+    return text, n
+
+
+def check_mum_rows(eng, bases, lens, samples=300, seed=1):
+    """Sampled rows: the same string at the reported offset / strand of every document, not extendable to the left or
+    right in all documents at once, and rows in lexicographic order of the match."""
+    L, off, st = eng.rows_mum()
+    N = len(lens)
+    starts = np.concatenate([[0], np.cumsum(np.asarray(lens, np.uint64))]).astype(np.int64)
+    rng = np.random.default_rng(seed)
+
+    def occ(d, o, ln, plus):
+        f = bases[starts[d]:starts[d + 1]]
+        if plus:
+            return f[o:o + ln], (f[o - 1] if o > 0 else 36), (f[o + ln] if o + ln < len(f) else 36)
+        # '-' strand: the reported offset is the forward coordinate of the segment whose reverse complement matches
+        # (write_mum, mem_finder.hpp:365-380: pos = 2 (L + 1) - pos - len - 1)
+        seg = _COMP[f[o:o + ln][::-1]]
+        left = _COMP[f[o + ln]] if o + ln < len(f) else 36
+        right = _COMP[f[o - 1]] if o > 0 else 36
+        return seg, left, right
+    for r in rng.integers(0, len(L), size=min(samples, len(L))):
+        ln = int(L[r])
+        segs, lefts, rights = [], set(), set()
+        for d in range(N):
+            assert off[r, d] >= 0
+            s, a, b = occ(d, int(off[r, d]), ln, bool(st[r, d]))
+            segs.append(s.tobytes()); lefts.add(int(a)); rights.add(int(b))
+        assert len(set(segs)) == 1 and len(segs[0]) == ln, r
+        assert len(lefts) > 1 and len(rights) > 1, ("row is not maximal", r)
+    text = eng.output_text().split(b"\n")[:-1]
+    assert len(text) == len(L)
+    a0 = bases[starts[0]:starts[1]]
+    keys = []
+    for line in text[:20000]:
+        f = line.split(b"\t")
+        o = int(f[1].split(b",")[0])
+        keys.append(a0[o:o + int(f[0])].tobytes())
+    assert keys == sorted(keys), "rows are not in lexicographic order of the match"
+    print("rows: %d rows; %d sampled rows are real, maximal matches in every document; order is lexicographic" % (len(L), min(samples, len(L))), flush=True)
+
+
+def check_mem_rows(eng, bases, lens, min_docs, max_doc_freq, samples=300, seed=2, text=None):
+    """Sampled rows of a partial multi-MUM / multi-MEM run: every listed occurrence spells the same string of the
+    text T (matches may run through a '$'), the occurrences cover at least min_docs documents with at most
+    max_doc_freq each, and the row is maximal."""
+    L, occ, off, ids, st = eng.rows_mem()
+    if text is None:
+        text, n = host_text(bases, lens)
+    lens = [int(l) for l in lens]
+    doc_start = np.concatenate([[0], np.cumsum([2 * (l + 1) for l in lens])]).astype(np.int64)
+    rng = np.random.default_rng(seed)
+    assert len(L) > 0
+    checked = 0
+    for r in rng.integers(0, len(L), size=min(samples, len(L))):
+        ln = int(L[r])
+        a, b = int(occ[r]), int(occ[r + 1])
+        counts = np.bincount(ids[a:b].astype(np.int64), minlength=len(lens))
+        assert (counts > 0).sum() >= min_docs and counts.max() <= max_doc_freq, r
+        strings, lefts, rights = set(), set(), set()
+        ok = True
+        for k in range(a, b):
+            d, o = int(ids[k]), int(off[k])
+            if st[k]:
+                tp = int(doc_start[d]) + o
+            else:
+                # write_mem: pos = 2 (L + 1) - pos - len - 1, without the "- 1" for the last listed occurrence of the row
+                # (mem_finder.hpp:229 vs :248); positions are size_t there, an occurrence that runs into the terminator
+                # wraps around -- such rows are skipped here
+                if k == b - 1:
+                    o -= 1
+                tp = int(doc_start[d]) + 2 * (lens[d] + 1) - o - ln - 1
+                if o < 0 or tp < int(doc_start[d]) + lens[d] + 1:
+                    ok = False
+                    break
+            strings.add(text[tp:tp + ln].tobytes())
+            lefts.add(int(text[tp - 1]) if tp > 0 else 0); rights.add(int(text[tp + ln]))
+        if not ok:
+            continue
+        checked += 1
+        assert len(strings) == 1 and len(next(iter(strings))) == ln, (r, len(strings))
+        assert len(lefts) > 1 and len(rights) > 1, ("row is not maximal", r)
+    assert checked > 0
+    print("rows: %d rows with %d occurrences; %d sampled rows are real, maximal matches" % (len(L), len(off), checked), flush=True)

@@ -1,0 +1,107 @@
+"""BASELINE configurations at their full size (SURVEY.md 8(d) stand-ins), on the GPU.
+
+C1 (3 x 4.64 Mbp) is small enough for the CPU oracle: byte-for-byte.  C2 (16 x 12.1 Mbp), a collection just beyond
+2^32 text characters and C3 (94 x 64 Mbp, 12.0 G characters) are checked through size-independent properties
+(tests/bigchecks.py: the suffix array is a permutation, sampled neighbours are in suffix order with the reported LCP
+and BWT byte, sampled rows are real, maximal, one-per-document matches in lexicographic order) and by comparing the
+two independent routes to the same answer: one suffix array (40-bit positions beyond 2^32 characters) against anchor
+partitions + merge.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bigchecks
+from mumemto_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _collection(haps, length, div, seed):
+    bases = np.empty(haps * length, np.uint8)
+    for h, b in synth.haplotypes_sparse(haps, length, div, seed):
+        bases[h * length:(h + 1) * length] = b
+    return bases, np.full(haps, length, np.uint64)
+
+
+def _partitioned(eng, bases, lens, frac):
+    n_text = int(sum(2 * (int(l) + 1) for l in lens))
+    os.environ["MMT_MAX_TEXT"] = str(int(n_text * frac))
+    try:
+        parts = eng.run_partitioned(None, flat=(bases, lens))
+    finally:
+        del os.environ["MMT_MAX_TEXT"]
+    return parts, eng.output_text()
+
+
+def _same_up_to_the_stream_end_quirk(single, part, parts):
+    """The reference never closes the last interval of a stream (pfp_lcp_mum.hpp:223-230): a partition whose last
+    interval is a MUM loses that row, so partitions + merge may miss at most one row per partition."""
+    if single == part:
+        return True
+    a, b = set(single.split(b"\n")), set(part.split(b"\n"))
+    return len(b - a) == 0 and len(a - b) <= parts
+
+
+def test_c1_standin_at_full_size_equals_the_cpu_oracle():
+    import mumemto_amd
+    import pyoracle as O
+    docs = synth.pangenome(3, 4_640_000, 0.01, seed=1)
+    eng = mumemto_amd.Engine(0)
+    eng.set_docs(docs)
+    eng.run()
+    assert eng.output_text() == O.run(docs).text()
+
+
+def test_c2_standin_at_full_size():
+    import mumemto_amd
+    bases, lens = _collection(16, 12_100_000, 0.005, 2)
+    eng = mumemto_amd.Engine(0)
+    assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+    assert not eng.is_wide()
+    single = eng.output_text()
+    bigchecks.check_stream(eng, bases, lens)
+    bigchecks.check_mum_rows(eng, bases, lens)
+    parts, part = _partitioned(eng, bases, lens, 0.4)
+    assert parts >= 3 and _same_up_to_the_stream_end_quirk(single, part, parts)
+    # the same collection through the 40-bit code path, scanned in ranges
+    os.environ["MMT_FORCE_WIDE"] = "1"
+    os.environ["MMT_SCAN_RANGE"] = str(1 << 26)
+    try:
+        assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+        assert eng.is_wide() and eng.scan_ranges() >= 5
+        assert eng.output_text() == single
+    finally:
+        del os.environ["MMT_FORCE_WIDE"], os.environ["MMT_SCAN_RANGE"]
+
+
+def test_text_beyond_2_to_the_32_as_one_suffix_array():
+    import mumemto_amd
+    bases, lens = _collection(36, 60_000_000, 0.002, 7)            # |T| = 4.32 G characters > 2^32
+    eng = mumemto_amd.Engine(0)
+    assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+    assert eng.is_wide() and eng.text_length() > 2 ** 32 and eng.scan_ranges() > 1
+    single = eng.output_text()
+    bigchecks.check_stream(eng, bases, lens)
+    bigchecks.check_mum_rows(eng, bases, lens)
+    parts, part = _partitioned(eng, bases, lens, 0.4)              # partitions of < 2^32 characters: the 32-bit path
+    assert parts >= 3 and not eng.is_wide()
+    assert _same_up_to_the_stream_end_quirk(single, part, parts)
+
+
+def test_c3_standin_at_full_size_one_suffix_array():
+    import mumemto_amd
+    haps = 94
+    bases, lens = _collection(haps, 64_000_000, 0.001, 3)          # |T| = 12.03 G characters
+    eng = mumemto_amd.Engine(0)
+    assert eng.run_partitioned(None, flat=(bases, lens)) == 1      # strict multi-MUMs, one suffix array
+    assert eng.is_wide() and eng.text_length() == 2 * haps * (64_000_000 + 1)
+    single = eng.output_text()
+    bigchecks.check_mum_rows(eng, bases, lens)
+    parts, part = _partitioned(eng, bases, lens, 0.36)
+    assert parts >= 3 and _same_up_to_the_stream_end_quirk(single, part, parts)
+    # partial multi-MEMs, the parameters of BASELINE configs[4] (-k -1 -f 3): one suffix array, no partitions possible
+    assert eng.run_partitioned(None, flat=(bases, lens), num_distinct=haps - 1, max_doc_freq=3) == 1
+    assert eng.is_wide()
+    bigchecks.check_mem_rows(eng, bases, lens, min_docs=haps - 1, max_doc_freq=3)

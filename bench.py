@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the hot path (BASELINE.json metric:
-"input Gbp/s end-to-end").
+"""bench.py -- headline benchmark of the hot path (BASELINE.json metric: "input Gbp/s end-to-end").
 
-One step = one pass of the hot path (text layout -> suffix array / LCP / BWT ->
-LCP-interval match scan -> rows -> .mums bytes) over one synthetic pangenome
-that is already resident in HBM when the timed region starts.
+One step = the reference's unit of work, build_main (src/pfp_mum.cpp:31-159): FASTA files (in the page cache) ->
+host parse -> H2D -> text layout -> suffix array / LCP / BWT -> LCP-interval match scan -> rows -> PREFIX.mums
+written and closed, run in-process through the C ABI (mmt_engine_run_files: the reader and the engine entry
+mumemto_exec uses).  value = input bases / wall-clock of the timed steps.
 
-N = 1  : workload = BASELINE.json configs[1] stand-in: 16 haplotypes x 12.1 Mbp,
-         per-base divergence 0.005, seed 2 (SURVEY.md 8(d) "C2"), strict multi-MUMs.
-N > 1  : one rank per GPU (torch.distributed, RCCL).  Rank r processes
-         {anchor} + its own 15 haplotypes (per-GPU work fixed => weak scaling);
-         candidate rows + thresholds are all-gathered and rank 0 folds them
-         (anchor merge) and re-sorts into direct-run order.  value counts every
-         distinct input base once.
+N = 1  : workload = BASELINE.json configs[2] stand-in (SURVEY.md 8(d) "C3"): 94 haplotypes x 64 Mbp, per-base
+         divergence 0.001, seed 3, strict multi-MUMs -- |T| = 12.03 G characters as ONE suffix array (40-bit
+         positions).  Extra keys: the same job as a fresh mumemto_exec process (process start -> exit), the
+         HBM-resident engine step (inputs already on the device, output bytes left in page-locked host memory), the
+         k_scan roofline and the 1-core CPU oracle on a bounded sample.
+N > 1  : the SAME collection split N ways (strong scaling): one rank per GPU (torch.distributed, RCCL), rank r reads
+         the anchor + its share of the other haplotypes, runs the single-GPU path with merge metadata, rows and
+         thresholds are all-gathered over xGMI, rank 0 folds them (anchor merge), re-sorts into direct-run order and
+         writes PREFIX.mums.  value counts every input base once.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,23 +33,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+REF_STREAM_BYTES = 11   # the reference's stream record: SA 5 + LCP 5 + BWT 1 (include/common.hpp:59-60)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--haps", type=int, default=16, help="haplotypes per GPU (incl. the anchor)")
-    ap.add_argument("--length", type=int, default=12_100_000, help="bases per haplotype")
-    ap.add_argument("--divergence", type=float, default=0.005)
-    ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample-bp", type=int, default=3_000_000,
+    ap.add_argument("--haps", type=int, default=94, help="haplotypes of the collection (incl. the anchor)")
+    ap.add_argument("--length", type=int, default=64_000_000, help="bases per haplotype")
+    ap.add_argument("--divergence", type=float, default=0.001)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--cpu-sample-bp", type=int, default=600_000,
                     help="bases per haplotype given to the 1-core CPU baseline (0 = skip)")
     ap.add_argument("--producer", default="auto", choices=["auto", "direct", "pfp"])
     ap.add_argument("--pfp-w", type=int, default=0)
     ap.add_argument("--pfp-p", type=int, default=0)
-    ap.add_argument("--merge-metadata", action="store_true", help="record anchor thresholds also on 1 GPU")
+    ap.add_argument("--workdir", default=None, help="where the FASTA files and outputs go (default: /dev/shm or $TMPDIR)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the process / HBM-resident / CPU legs (N = 1)")
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device exercise the N > 1 path on a box with one GPU (testing only)")
@@ -52,12 +59,23 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(docs, sample_bp):
-    """The oracle (CPU restatement of the reference's -g path + scan, 1 thread)
-    timed on a bounded sample of the same workload."""
+def pick_workdir(a, need_bytes):
+    if a.workdir:
+        os.makedirs(a.workdir, exist_ok=True)
+        return tempfile.mkdtemp(prefix="mumemto_bench_", dir=a.workdir), "given"
+    for base, kind in (("/dev/shm", "tmpfs"), (tempfile.gettempdir(), "tmp")):
+        try:
+            if os.path.isdir(base) and shutil.disk_usage(base).free > need_bytes * 1.3:
+                return tempfile.mkdtemp(prefix="mumemto_bench_", dir=base), kind
+        except OSError:
+            pass
+    return tempfile.mkdtemp(prefix="mumemto_bench_"), "tmp"
+
+
+def cpu_baseline(sample):
+    """The oracle (CPU restatement of the reference's -g path + scan, 1 thread) timed on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as O
-    sample = [[d[0][:sample_bp]] for d in docs]
     bp = sum(len(d[0]) for d in sample)
     t0 = time.perf_counter()
     tl, sec, out = O.run_job_timed(sample)
@@ -65,7 +83,7 @@ def cpu_baseline(docs, sample_bp):
     return {"value": bp / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
             "sample": "%d haplotypes x first %d bp of the same synthetic pangenome (|T| = %d), strict multi-MUMs; "
                       "%.1f s of CPU work (sa+lcp+bwt %.1f s, scan+format %.1f s)"
-                      % (len(sample), sample_bp, tl, dt, sec[1], sec[2])}, out, sample
+                      % (len(sample), len(sample[0][0]), tl, dt, sec[1], sec[2])}, out
 
 
 def main():
@@ -88,39 +106,49 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    # ---- synthetic pangenome: anchor + (haps-1) haplotypes per rank -----------------------------
-    n_total_haps = 1 + world * (a.haps - 1)
-    groups = mdist.partition_docs(n_total_haps, world)
+    # ---- the collection as FASTA files in the page cache: this rank's documents only -------------------------------
+    groups = mdist.partition_docs(a.haps, world)
     mine = groups[rank]
-    all_docs = synth.pangenome(n_total_haps, a.length, a.divergence, a.seed) if world == 1 else None
-    if world == 1:
-        docs = all_docs
-    else:  # every rank generates only what it needs (same generator, same seeds)
-        docs = synth.pangenome_subset(n_total_haps, a.length, a.divergence, a.seed, mine)
-    doc_len = np.array([len(d[0]) for d in docs], np.uint64)
-    flat = np.frombuffer(b"".join(d[0] for d in docs), np.uint8)
-    d_bases = torch.from_numpy(flat.copy()).to(device)          # inputs resident in HBM
-    stream = torch.cuda.current_stream(device)
-    eng = mumemto_amd.Engine(local_rank, stream.cuda_stream)
-    eng.set_input_device(d_bases.data_ptr(), doc_len, keepalive=d_bases)
+    workdir, work_kind = pick_workdir(a, len(mine) * a.length * 1.02)
+    paths, sample = [], []
+    t_gen = time.perf_counter()
+    for h, bases in synth.haplotypes_sparse(a.haps, a.length, a.divergence, a.seed, which=mine):
+        p = os.path.join(workdir, "hap%03d.fa" % h)
+        synth.write_fasta_fast(p, bases, name="hap%03d" % h)
+        paths.append(p)
+        if world == 1 and a.cpu_sample_bp > 0 and not a.no_extras:
+            sample.append([bases[: a.cpu_sample_bp].tobytes()])
+    t_gen = time.perf_counter() - t_gen
+    out_prefix = os.path.join(workdir, "out")
+
+    eng = mumemto_amd.Engine(local_rank)
     eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
     merge_mode = world > 1
-    want_thresh = merge_mode or a.merge_metadata
-    L0 = int(doc_len[0])
+    L0 = a.length
+    phases = {"read": 0.0, "run": 0.0, "write": 0.0, "exchange_fold": 0.0}
 
-    def step():
-        eng.run(min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, use_revcomp=True,
-                merge_metadata=want_thresh)
+    def step(timed):
         if not merge_mode:
-            return eng.output_size()      # the .mums bytes are in (page-locked) host memory at this point
+            sec = eng.run_files(paths, out_prefix=out_prefix)
+            if timed:
+                for k in ("read", "run", "write"):
+                    phases[k] += sec[k]
+            return None
+        sec = eng.run_files(paths, out_prefix=None, merge_metadata=True)
+        t0 = time.perf_counter()
         # rows and thresholds go from this rank's HBM straight into the all-gather; rank 0 folds them in HBM
         len_t, off_t, st_t = mdist.engine_rows_as_tensors(eng, device)
         th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
         parts = mdist.all_gather_partitions_device((len_t, off_t, st_t, th), dist)
-        if rank != 0:
-            return b""
-        merged = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False)
-        return merged["text"]
+        merged = None
+        if rank == 0:
+            merged = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False)
+            with open(out_prefix + ".mums", "wb") as f:
+                f.write(merged["text"])
+        if timed:
+            phases["read"] += sec["read"]; phases["run"] += sec["run"]
+            phases["exchange_fold"] += time.perf_counter() - t0
+        return merged
 
     def fence():
         torch.cuda.synchronize(device)
@@ -129,12 +157,12 @@ def main():
         torch.cuda.synchronize(device)
 
     for _ in range(a.warmup):
-        out = step()
+        step(False)
     scan_ms, stage_acc = [], np.zeros(8)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
+        step(True)
         ms = eng.stage_ms()
         scan_ms.append(ms[3])
         stage_acc += np.array(ms)
@@ -144,15 +172,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if not merge_mode:
-        out = eng.output_text()
 
-    total_bp = a.length * n_total_haps          # every distinct input base once
+    total_bp = a.length * a.haps                # every distinct input base once
     n_text = eng.text_length()
     col = eng.column_bytes()
-    algo_bytes = float(sum(col)) * n_text       # SA + LCP + BWT columns of the stream, one pass
+    algo_bytes = float(sum(col)) * n_text       # SA + LCP + BWT columns of the stream as stored, one pass
     scan_avg_ms = float(np.mean(scan_ms))
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
+    out_file = out_prefix + ".mums"
+    out_bytes = os.path.getsize(out_file) if rank == 0 and os.path.exists(out_file) else 0
     result = {
         "metric": "input Gbp/s end-to-end",
         "value": total_bp * a.steps / dt / 1e9,
@@ -160,54 +188,112 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "u8/u32",
+        "dtype": "u8 text, u32 (+u8 beyond 2^32) positions, u32 LCP",
         "data": "synthetic",
-        "config": {"workload": "%d haplotypes x %d bp synthetic pangenome (divergence %g, seed %d), strict multi-MUMs "
-                               "(-l 20, revcomp on); BASELINE configs[1] stand-in (16 S. cerevisiae ~12 Mbp)"
-                               % (n_total_haps, a.length, a.divergence, a.seed),
-                   "haplotypes": n_total_haps, "bases_per_haplotype": a.length, "text_chars_per_gpu": int(n_text),
-                   "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL all-gather + GPU fold" % world,
-                   "output_bytes": len(out), "output_rows": out.count(b"\n"),
-                   "scan_candidates": int(eng.L.mmt_num_candidates(eng.h))},
-        "roofline": {"bound": "hbm", "kernel": "k_scan (LCP-interval match scan)", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "config": {
+            "workload": "%d haplotypes x %d bp synthetic pangenome (divergence %g, seed %d) as FASTA in the page cache "
+                        "(%s), strict multi-MUMs (-l 20, revcomp on) -> PREFIX.mums on disk; %s"
+                        % (a.haps, a.length, a.divergence, a.seed, work_kind,
+                           "BASELINE configs[2] stand-in (94 HPRC haplotypes, chr20)" if (a.haps, a.length) == (94, 64_000_000)
+                           else "scaled variant of the BASELINE configs[2] stand-in"),
+            "haplotypes": a.haps, "bases_per_haplotype": a.length, "text_chars_per_gpu": int(n_text),
+            "one_suffix_array": bool(eng.L.mmt_partitions_used(eng.h) == 1), "positions_40_bit": eng.is_wide(),
+            "scan_ranges": eng.scan_ranges(),
+            "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL all-gather + GPU fold" % world,
+            "timed_region": "FASTA files (page cache) -> host parse -> H2D -> GPU path -> PREFIX.mums closed; in-process "
+                            "(HIP runtime up, device heap mapped by the warm-up step)",
+            "output_bytes": out_bytes, "output_rows": int(eng.L.mmt_num_rows(eng.h)) if world == 1 else None,
+            "scan_candidates": int(eng.L.mmt_num_candidates(eng.h)),
+            "stream_producer": eng.producer_used(),
+        },
+        "phase_s_avg": {k: v / a.steps for k, v in phases.items()},
+        "roofline": {"bound": "hbm", "kernel": "k_scan (LCP-interval match scan), %d launches per step" % eng.scan_ranges(),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,
-                     "algorithmic_bytes_per_suffix": sum(col), "suffixes_per_launch": int(n_text),
-                     "avg_kernel_ms": scan_avg_ms},
+                     "algorithmic_bytes_per_suffix": sum(col), "suffixes_per_step": int(n_text),
+                     "kernel_ms_per_step": scan_avg_ms,
+                     "frac_at_reference_widths": REF_STREAM_BYTES * n_text / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "stage_ms_avg": {k: float(v) / a.steps for k, v in zip(
-            ["text", "suffix_sort", "lcp_bwt", "scan_kernel", "verify", "rows_gather_d2h", "host_rows_format",
-             "engine_total"], stage_acc)},
+            ["text", "suffix_sort", "lcp_bwt", "scan_kernel", "verify", "rows", "host_rows_format", "engine_total"],
+            stage_acc)},
+        "device_memory": eng.device_memory(),
+        "generate_s": t_gen,
     }
-    # HBM traffic of the scan kernel from the PMC passes of profiles/ (separate rocprofv3 runs of this very
-    # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for this workload only
-    pmc_file = os.path.join(ROOT, "profiles", "round1_l_scan_pmc.json")
-    if world == 1 and os.path.exists(pmc_file) and (a.haps, a.length, a.divergence, a.seed) == (16, 12_100_000, 0.005, 2):
-        result["roofline"]["traffic"] = json.load(open(pmc_file))["hbm_bytes_per_launch"]
-        result["roofline"]["traffic_unit"] = "bytes per launch (PMC, profiles/round1_l_scan_pmc.json)"
-    result["config"]["stream_producer"] = eng.producer_used()
+    # HBM bytes the scan kernel really moved, from the PMC passes under profiles/ (separate rocprofv3 runs of this
+    # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for the default workload only
+    pmc_file = os.path.join(ROOT, "profiles", "round2_scan_pmc.json")
+    if world == 1 and os.path.exists(pmc_file) and (a.haps, a.length, a.divergence, a.seed) == (94, 64_000_000, 0.001, 3):
+        pmc = json.load(open(pmc_file))
+        result["roofline"]["traffic"] = pmc["hbm_bytes_per_step"]
+        result["roofline"]["traffic_unit"] = "bytes per step = all k_scan launches of one pass (PMC, profiles/round2_scan_pmc.json)"
+        result["roofline"]["frac_moved"] = pmc["hbm_bytes_per_step"] / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     if eng.producer_used() == "pfp":
         result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(
-            ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_lcp_groups",
-             "parse_sa", "text_keys_sort", "total_host_clock"], [round(x, 3) for x in eng.pfp_stage_ms()]))}
+            ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_groups",
+             "parse_sa", "lists_emit", "total_host_clock"], [round(x, 3) for x in eng.pfp_stage_ms()]))}
+
+    if rank == 0 and world == 1 and not a.no_extras:
+        # (1) the same job as a fresh process: mumemto_exec, process start -> exit (HIP runtime start, first mapping of
+        #     the device heap and process teardown included)
+        exe = os.path.join(ROOT, "mumemto_amd", "bin", "mumemto_exec")
+        if os.path.exists(exe):
+            eng.close()                              # give the device memory back before the process asks for it
+            mumemto_amd.load_library().mmt_pool_trim()
+            stats = os.path.join(workdir, "cli_stats.json")
+            t0 = time.perf_counter()
+            r = subprocess.run([exe] + paths + ["-o", os.path.join(workdir, "cli")], capture_output=True,
+                               env=dict(os.environ, MUMEMTO_STATS=stats, MUMEMTO_DEVICE=str(local_rank)))
+            wall = time.perf_counter() - t0
+            cli = {"wall_s": wall, "value": total_bp / wall / 1e9, "unit": "Gbp/s", "rc": r.returncode}
+            if r.returncode == 0 and os.path.exists(stats):
+                st = json.load(open(stats))
+                cli.update({"heap_map_seconds": st["heap_map_seconds"], "heap_peak_bytes": st["heap_peak_bytes"],
+                            "stage_ms": st["stage_ms"]})
+                same = subprocess.run(["cmp", "-s", os.path.join(workdir, "cli.mums"), out_file]).returncode == 0
+                cli["output_identical_to_in_process"] = same
+            result["cli_process"] = cli
+            eng = mumemto_amd.Engine(local_rank)
+            eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
+        # (2) HBM-resident engine step: bases on the device before the timed region, output bytes in page-locked host
+        #     memory after it (what round 1 reported as `value`)
+        flat = np.empty(a.haps * a.length, np.uint8)
+        for h, bases in synth.haplotypes_sparse(a.haps, a.length, a.divergence, a.seed):
+            flat[h * a.length:(h + 1) * a.length] = bases
+        d_bases = torch.from_numpy(flat).to(device)
+        del flat
+        lens = np.full(a.haps, a.length, np.uint64)
+        eng.set_input_device(d_bases.data_ptr(), lens, keepalive=d_bases)
+        hb = []
+        for i in range(3):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            eng.run(min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, use_revcomp=True)
+            eng.output_size()
+            hb.append(time.perf_counter() - t0)
+        result["hbm_resident"] = {"ms_per_step": min(hb[1:]) * 1e3, "value": total_bp / min(hb[1:]) / 1e9, "unit": "Gbp/s",
+                                  "first_step_ms": hb[0] * 1e3, "stage_ms": [round(x, 2) for x in eng.stage_ms()]}
     if rank == 0:
-        if world == 1 and a.cpu_sample_bp > 0:
-            cb, cpu_out, sample = cpu_baseline(docs, min(a.cpu_sample_bp, a.length))
+        if world == 1 and sample and not a.no_extras and a.cpu_sample_bp > 0:
+            cb, cpu_out = cpu_baseline(sample)
             result["cpu_baseline"] = cb
-            if a.check or min(a.cpu_sample_bp, a.length) == a.length:
-                result["config"]["output_equals_cpu_oracle"] = bool(cpu_out == out)
+            if a.cpu_sample_bp >= a.length:
+                result["config"]["output_equals_cpu_oracle"] = bool(cpu_out == open(out_file, "rb").read())
         else:
             result["cpu_baseline"] = None
-            if a.check:      # N > 1: the merged output must be the direct run's on the union, in fold column order
-                sys.path.insert(0, os.path.join(ROOT, "oracle"))
-                import pyoracle as O
-                every = synth.pangenome(n_total_haps, a.length, a.divergence, a.seed)
-                order = mdist.merged_column_order(groups)
-                result["config"]["output_equals_cpu_oracle"] = bool(O.run([every[i] for i in order]).text() == out)
+        if a.check and not (world == 1 and a.cpu_sample_bp >= a.length and not a.no_extras):
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle as O
+            every = [[b.tobytes()] for _, b in synth.haplotypes_sparse(a.haps, a.length, a.divergence, a.seed)]
+            order = mdist.merged_column_order(groups)
+            result["config"]["output_equals_cpu_oracle"] = bool(
+                O.run([every[i] for i in order]).text() == open(out_file, "rb").read())
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    shutil.rmtree(workdir, ignore_errors=True)
 
 
 if __name__ == "__main__":

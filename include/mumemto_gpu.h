@@ -83,6 +83,12 @@ MMT_API int mmt_engine_run(mmt_engine* e, const mmt_params* p);
 MMT_API int mmt_engine_run_partitioned(mmt_engine* e, const uint8_t* h_bases, const uint64_t* doc_len,
                                        size_t n_docs, const mmt_params* p, uint64_t max_text_chars);
 MMT_API size_t mmt_partitions_used(const mmt_engine* e);
+/* build_main in-process (src/pfp_mum.cpp:31-159): FASTA / FASTQ(.gz) files in (one document per file, read on all
+ * host cores), PREFIX.mums | PREFIX.mems and PREFIX.lengths out (out_prefix NULL: nothing is written, the rows stay
+ * available through the accessors below).  seconds (optional): [0] reading + parsing the files, [1] H2D + the whole
+ * GPU path, [2] writing the outputs, [3] total.  mmt_params.merge_metadata is honoured as in mmt_engine_run.         */
+MMT_API int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths, const mmt_params* p,
+                                 const char* out_prefix, uint64_t max_text_chars, double seconds[4]);
 /* merged PREFIX.athresh (L_0 + 1 entries) after a partitioned run                                  */
 MMT_API int mmt_copy_merged_thresh(const mmt_engine* e, uint16_t* out);
 
@@ -141,6 +147,8 @@ MMT_API int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, c
 /* Device heap of the engine's GPU (pool.hpp): [0] bytes mapped from the driver, [1] bytes in use, [2] high-water mark
  * of [1], [3] microseconds spent in the driver mapping memory.                                                         */
 MMT_API int mmt_device_memory(const mmt_engine* e, uint64_t out[4]);
+/* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
+MMT_API void mmt_pool_trim(void);
 
 /* ---- PFP stage checkpoints (the reference's -P / -K: PREFIX.dict, PREFIX.parse) ------------ */
 /* Text layout + prefix-free parse only (newscan.hpp pfparser: process_string ... finish_parse).  */
@@ -173,6 +181,11 @@ typedef struct mmt_merged mmt_merged;
  * whole fold runs on the GPU of `e` and the merged rows stay in its HBM until
  * mmt_merged_get / mmt_merged_text copy them out.                              */
 MMT_API int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out);
+/* The same with the minimum length of a merged MUM stated.  The reference's tool hard-codes 20
+ * (src/merge_candidates.cpp:141), which equals a direct run only for partitions made with -l 20: a multi-GPU run with
+ * another -l passes that value here.                                                                                 */
+MMT_API int mmt_anchor_merge_min_len(mmt_engine* e, const mmt_partition* parts, size_t k, uint32_t min_len,
+                                     mmt_merged** out);
 MMT_API size_t mmt_merged_rows(const mmt_merged* m);
 MMT_API size_t mmt_merged_docs(const mmt_merged* m);
 MMT_API int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands,

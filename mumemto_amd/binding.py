@@ -71,7 +71,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
-    "mmt_device_memory",
+    "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
 ]
 
 
@@ -154,10 +154,14 @@ def load_library():
     L.mmt_pfp_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.mmt_engine_run_partitioned.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Params),
                                              C.c_uint64]
+    L.mmt_engine_run_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_char_p,
+                                       C.c_uint64, C.POINTER(C.c_double)]
     L.mmt_partitions_used.restype = C.c_size_t
     L.mmt_partitions_used.argtypes = [C.c_void_p]
     L.mmt_copy_merged_thresh.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_anchor_merge.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mmt_anchor_merge_min_len.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.c_uint32,
+                                           C.POINTER(C.c_void_p)]
     L.mmt_merged_get.argtypes = [C.c_void_p] * 5
     L.mmt_merged_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
     L.mmt_rows_mum_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
@@ -328,6 +332,17 @@ class Engine:
         _check(self.L.mmt_engine_run_partitioned(self.h, _p(bases), _p(lens), len(lens), C.byref(p), max_text_chars))
         return int(self.L.mmt_partitions_used(self.h))
 
+    def run_files(self, paths, out_prefix=None, min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0,
+                  use_revcomp=True, merge_metadata=False, max_text_chars=0):
+        """FASTA files (one document each) -> PREFIX.mums | .mems + PREFIX.lengths, in-process: the unit of work of
+        the reference's build_main.  Returns {"read", "run", "write", "total"} seconds."""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
+        sec = (C.c_double * 4)()
+        _check(self.L.mmt_engine_run_files(self.h, arr, len(paths), C.byref(p),
+                                           os.fsencode(out_prefix) if out_prefix else None, max_text_chars, sec))
+        return dict(zip(["read", "run", "write", "total"], map(float, sec)))
+
     def merged_thresholds(self, anchor_len):
         out = np.zeros(anchor_len + 1, np.uint16)
         _check(self.L.mmt_copy_merged_thresh(self.h, _p(out)))
@@ -468,7 +483,7 @@ class Engine:
         return list(out)
 
     # anchor merge
-    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True):
+    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20):
         """parts: list of DevicePartition, or of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh)
         where thresh is a numpy u16 array (host) or a device address paired as (ptr, length).
         want_rows=False returns only the PREFIX.mums bytes (no D2H of the tables)."""
@@ -493,7 +508,7 @@ class Engine:
             arr[i] = Partition(len(length), off.shape[1], _p(length).value, _p(off).value, _p(st).value, tptr, tlen,
                                on_dev, 0)
         m = C.c_void_p()
-        _check(self.L.mmt_anchor_merge(self.h, arr, len(parts), C.byref(m)))
+        _check(self.L.mmt_anchor_merge_min_len(self.h, arr, len(parts), C.c_uint32(min_len), C.byref(m)))
         try:
             if sort_like_direct:
                 _check(self.L.mmt_merged_sort_like_direct(self.h, m))

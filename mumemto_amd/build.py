@@ -80,7 +80,7 @@ def build(verbose=False):
         paths = [os.path.join(SRC, f) for f in srcs]
         out = os.path.join(BIN_DIR, tool)
         if _newer(out, paths + _headers()):
-            subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-o", out] + paths + ["-lz"])
+            subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", "-pthread", "-o", out] + paths + ["-lz"])
     if verbose:
         print("built", LIB)
     return LIB

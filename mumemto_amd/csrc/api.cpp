@@ -1,6 +1,8 @@
 // api.cpp -- the C ABI of libmumemto: the drop-in symbols of include/mumemto.h
 // (reference: mumemto_library/mumemto_api.cpp:489-644) and the device-resident
 // entry points of include/mumemto_gpu.h.
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -10,6 +12,7 @@
 #include "../../include/mumemto.h"
 #include "../../include/mumemto_gpu.h"
 #include "engine.hpp"
+#include "fasta.hpp"
 #include "merge.hpp"
 
 namespace {
@@ -258,6 +261,35 @@ int mmt_engine_run_partitioned(mmt_engine* e, const uint8_t* h_bases, const uint
     e->e->run_partitioned_host(h_bases, doc_len, n_docs, *p, max_text_chars);
     MMT_CATCH
 }
+// build_main (src/pfp_mum.cpp:31-159) in-process: FASTA files -> text -> stream -> scan -> PREFIX.mums | .mems +
+// PREFIX.lengths.  The same reader and the same engine entry as mumemto_exec.
+int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths, const mmt_params* p,
+                         const char* out_prefix, uint64_t max_text_chars, double seconds[4]) {
+    if (!e || !p || (!paths && n_paths)) return fail(1, "engine, params and paths must be non-null");
+    MMT_TRY
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    std::vector<std::string> inputs(paths, paths + n_paths);
+    std::vector<mmt::FastaDoc> docs;
+    mmt::HostBytes bases;
+    std::vector<uint64_t> doc_len;
+    const long empty = mmt::read_fasta_files(inputs, docs, bases, doc_len);
+    if (empty >= 0) throw std::runtime_error("Empty input file found: " + inputs[(size_t)empty]);
+    const double t_read = since();
+    e->e->run_partitioned_host(bases.data(), doc_len.data(), doc_len.size(), *p, max_text_chars);
+    const double t_run = since();
+    if (out_prefix) {
+        const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_TEXT);
+        const std::string name = std::string(out_prefix) + (R.mum_mode ? ".mums" : ".mems");
+        std::FILE* f = std::fopen(name.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot write " + name);
+        const size_t wrote = R.text_len ? std::fwrite(R.text, 1, R.text_len, f) : 0;
+        if (std::fclose(f) != 0 || wrote != R.text_len) throw std::runtime_error("short write to " + name);
+        mmt::write_lengths_file(out_prefix, docs);
+    }
+    if (seconds) { seconds[0] = t_read; seconds[1] = t_run - t_read; seconds[2] = since() - t_run; seconds[3] = since(); }
+    MMT_CATCH
+}
 size_t mmt_partitions_used(const mmt_engine* e) { return e ? e->e->partitions_used() : 0; }
 int mmt_copy_merged_thresh(const mmt_engine* e, uint16_t* out) {
     if (!e) return fail(1, "null");
@@ -360,6 +392,7 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
     e->e->set_stream_host40(sa_lo, sa_hi, lcp, bwt, entries, doc_len, n_docs, use_revcomp != 0);
     MMT_CATCH
 }
+void mmt_pool_trim(void) { mmt::pool::trim(); }
 int mmt_device_memory(const mmt_engine* e, uint64_t out[4]) {
     if (!e) return fail(1, "null");
     const mmt::pool::Stats s = mmt::pool::stats(e->e->device());
@@ -411,12 +444,15 @@ int mmt_pfp_stage_ms(const mmt_engine* e, float out[8]) {
 
 // ---- anchor merge --------------------------------------------------------------------
 int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out) {
+    return mmt_anchor_merge_min_len(e, parts, k, 20, out);      // src/merge_candidates.cpp:141
+}
+int mmt_anchor_merge_min_len(mmt_engine* e, const mmt_partition* parts, size_t k, uint32_t min_len, mmt_merged** out) {
     if (!e || !parts || !out) return fail(1, "engine, parts and out must be non-null");
     *out = nullptr;
     MMT_TRY
     if (k < 2) throw std::invalid_argument("anchor merge requires at least two partitions");
     std::unique_ptr<mmt_merged> m(new mmt_merged());
-    m->rows = mmt::anchor_merge(*e->e, parts, k);
+    m->rows = mmt::anchor_merge(*e->e, parts, k, min_len);
     m->engine = e->e.get();
     *out = m.release();
     MMT_CATCH

@@ -24,18 +24,6 @@ using namespace mmt;
 static void log_line(const char* tag, const std::string& msg) {
     std::fprintf(stderr, "\033[32m[%s] \033[m%s\n", tag, msg.c_str());
 }
-// The concatenated bases of the inputs: sized once, never zero-filled.
-struct HostBytes {
-    std::unique_ptr<uint8_t[]> p;
-    size_t n = 0;
-    void allocate(size_t bytes) { p.reset(new uint8_t[bytes ? bytes : 1]); n = bytes; }
-    uint8_t* data() { return p.get(); }
-    const uint8_t* data() const { return p.get(); }
-    size_t size() const { return n; }
-    const uint8_t* begin() const { return p.get(); }
-    const uint8_t* end() const { return p.get() + n; }
-};
-
 static const auto g_start = std::chrono::steady_clock::now();
 static double secs_since(std::chrono::steady_clock::time_point t0);
 // MUMEMTO_TIMING=1: wall-clock marks (seconds since the process started) on stderr
@@ -50,16 +38,6 @@ static void write_file(const std::string& path, const void* data, size_t n) {
     std::ofstream f(path, std::ios::binary);
     if (!f) throw std::runtime_error("cannot write " + path);
     f.write(static_cast<const char*>(data), (std::streamsize)n);
-}
-
-// RefBuilder::write_lengths_file (src/ref_builder.cpp:193-209)
-static void write_lengths(const std::string& prefix, const std::vector<FastaDoc>& docs) {
-    std::ofstream out(prefix + ".lengths");
-    for (const auto& d : docs) {
-        const std::string canon = fs::canonical(d.path).string();
-        out << canon << " * " << d.total << std::endl;
-        for (size_t r = 0; r < d.names.size(); r++) out << canon << " " << d.names[r] << " " << d.lengths[r] << std::endl;
-    }
 }
 
 // RefBuilder(prefix, use_rcomp) (src/ref_builder.cpp:140-169): document lengths from PREFIX.lengths --
@@ -184,39 +162,15 @@ int main(int argc, char** argv) {
             });
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } engine_joiner{engine_init};
         HostBytes bases;
-        std::vector<FastaDoc> docs(inputs.size());
-        {   // the files are independent: inflate and parse them on as many host threads as the machine offers, then
-            // every thread copies the files it parsed to their place in the concatenation
-            std::vector<std::vector<uint8_t>> part(inputs.size());
-            std::vector<std::string> err(inputs.size());
-            const size_t n_thr = std::min<size_t>(inputs.size(), std::max(1u, std::thread::hardware_concurrency()));
-            auto on_all_threads = [&](const std::function<void(size_t)>& per_file) {
-                std::atomic<size_t> next{0};
-                auto work = [&]() { for (size_t i = next++; i < inputs.size(); i = next++) per_file(i); };
-                std::vector<std::thread> pool;
-                for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
-                work();
-                for (auto& t : pool) t.join();
-            };
-            on_all_threads([&](size_t i) {
-                try { docs[i] = read_fasta(inputs[i], part[i]); }
-                catch (const std::exception& e) { err[i] = e.what(); }
-            });
-            std::vector<size_t> at(inputs.size() + 1, 0);
-            for (size_t i = 0; i < inputs.size(); i++) {
-                if (!err[i].empty()) throw std::runtime_error(err[i]);
-                if (docs[i].total == 0) {           // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
-                    std::cerr << std::endl << "Empty input file found: " << inputs[i] << std::endl;
-                    throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
-                }
-                at[i + 1] = at[i] + part[i].size();
-                doc_len.push_back(docs[i].total);
+        std::vector<FastaDoc> docs;
+        if (!checkpoint) {
+            std::vector<uint64_t> lens;
+            const long empty = read_fasta_files(inputs, docs, bases, lens);
+            if (empty >= 0) {                       // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
+                std::cerr << std::endl << "Empty input file found: " << inputs[(size_t)empty] << std::endl;
+                throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
             }
-            bases.allocate(at.back());
-            on_all_threads([&](size_t i) {
-                if (!part[i].empty()) std::memcpy(bases.data() + at[i], part[i].data(), part[i].size());
-                std::vector<uint8_t>().swap(part[i]);
-            });
+            doc_len = lens;
         }
         uint64_t text_chars = 0;
         for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
@@ -234,7 +188,7 @@ int main(int argc, char** argv) {
             load_stream_files(o.arrays_in, text_chars, ck_sa, ck_sa_hi, ck_lcp, ck_bwt);
             log_line("build_main", "Using pre-computed LCP/BWT/SA arrays from files with prefix: " + o.arrays_in);
         } else {
-            write_lengths(o.output_prefix, docs);
+            write_lengths_file(o.output_prefix, docs);
             std::fprintf(stderr, "\033[32m[build_main] \033[0mread %zu files, %zu bases ... done.  (%.3f sec)\n", docs.size(),
                          bases.size(), secs_since(t0));
         }

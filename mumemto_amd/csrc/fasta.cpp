@@ -4,9 +4,15 @@
 
 #include <sys/stat.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <functional>
 #include <stdexcept>
+#include <thread>
 
 namespace mmt {
 namespace {
@@ -110,6 +116,51 @@ FastaDoc read_fasta(const std::string& path, std::vector<uint8_t>& bases) {
         }
     }
     return doc;
+}
+
+long read_fasta_files(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostBytes& bases,
+                      std::vector<uint64_t>& doc_len) {
+    docs.assign(inputs.size(), FastaDoc());
+    doc_len.clear();
+    std::vector<std::vector<uint8_t>> part(inputs.size());
+    std::vector<std::string> err(inputs.size());
+    const size_t n_thr = std::min<size_t>(inputs.size(), std::max(1u, std::thread::hardware_concurrency()));
+    auto on_all_threads = [&](const std::function<void(size_t)>& per_file) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t i = next++; i < inputs.size(); i = next++) per_file(i); };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    };
+    on_all_threads([&](size_t i) {
+        try { docs[i] = read_fasta(inputs[i], part[i]); }
+        catch (const std::exception& e) { err[i] = e.what(); }
+    });
+    std::vector<size_t> at(inputs.size() + 1, 0);
+    long empty = -1;
+    for (size_t i = 0; i < inputs.size(); i++) {
+        if (!err[i].empty()) throw std::runtime_error(err[i]);
+        if (docs[i].total == 0 && empty < 0) empty = (long)i;      // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
+        at[i + 1] = at[i] + part[i].size();
+        doc_len.push_back(docs[i].total);
+    }
+    if (empty >= 0) return empty;
+    bases.allocate(at.back());
+    on_all_threads([&](size_t i) {
+        if (!part[i].empty()) std::memcpy(bases.data() + at[i], part[i].data(), part[i].size());
+        std::vector<uint8_t>().swap(part[i]);
+    });
+    return -1;
+}
+
+void write_lengths_file(const std::string& prefix, const std::vector<FastaDoc>& docs) {
+    std::ofstream out(prefix + ".lengths");
+    for (const auto& d : docs) {
+        const std::string canon = std::filesystem::canonical(d.path).string();
+        out << canon << " * " << d.total << std::endl;
+        for (size_t r = 0; r < d.names.size(); r++) out << canon << " " << d.names[r] << " " << d.lengths[r] << std::endl;
+    }
 }
 
 }  // namespace mmt

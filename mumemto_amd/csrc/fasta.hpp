@@ -7,6 +7,7 @@
 // skipped.  Bases are kept verbatim (upper-casing happens on the GPU).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,5 +22,27 @@ struct FastaDoc {
 
 // Appends the bases of every record of `path` to `bases`; throws on I/O errors.
 FastaDoc read_fasta(const std::string& path, std::vector<uint8_t>& bases);
+
+// The concatenated bases of a collection: sized once, never zero-filled.
+struct HostBytes {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    void allocate(size_t bytes) { p.reset(new uint8_t[bytes ? bytes : 1]); n = bytes; }
+    uint8_t* data() { return p.get(); }
+    const uint8_t* data() const { return p.get(); }
+    size_t size() const { return n; }
+    const uint8_t* begin() const { return p.get(); }
+    const uint8_t* end() const { return p.get() + n; }
+};
+
+// RefBuilder::build_input_file's reading half (src/ref_builder.cpp:211-314) for a whole collection: the files are
+// independent, so they are inflated and parsed on as many host threads as the machine offers, then every thread
+// copies the files it parsed to their place in the concatenation (file order).  doc_len[i] = bases of file i.
+// Returns the index of the first file without bases (the caller reports it the way the reference does), or -1.
+long read_fasta_files(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostBytes& bases,
+                      std::vector<uint64_t>& doc_len);
+
+// RefBuilder::write_lengths_file (src/ref_builder.cpp:193-209)
+void write_lengths_file(const std::string& prefix, const std::vector<FastaDoc>& docs);
 
 }  // namespace mmt

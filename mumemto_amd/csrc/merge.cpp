@@ -4,6 +4,8 @@
 #include "merge.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -62,9 +64,15 @@ struct MergeScratch {
     DevBuf<mk::PartTable> d_parts;
     DevBuf<uint32_t> d_colpart;
 };
-MergeScratch& scratch() {
-    static thread_local MergeScratch s;
-    return s;
+// one scratch set per device (an engine on another GPU must not reuse buffers that live on the first one); the sets
+// are leaked on purpose: a static destructor would run after the HIP runtime has gone
+MergeScratch& scratch(int device) {
+    static std::mutex mu;
+    static std::map<int, MergeScratch*>* sets = new std::map<int, MergeScratch*>();
+    std::lock_guard<std::mutex> lock(mu);
+    MergeScratch*& s = (*sets)[device];
+    if (!s) s = new MergeScratch();
+    return *s;
 }
 
 }  // namespace
@@ -89,7 +97,7 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
         if (parts[i].n_docs == 0) throw std::runtime_error("a partition without documents");
         n_docs_out += parts[i].n_docs - (i ? 1 : 0);
     }
-    MergeScratch& M = scratch();
+    MergeScratch& M = scratch(e.device());
     DevBuf<uint8_t>& temp = e.scratch();
 
     // partition tables in HBM (uploaded when they arrive in host memory) + the column map of the result
@@ -207,7 +215,7 @@ void sort_like_direct(Engine& e, MergedRows& m) {
     if (e.text_length() == 0) throw std::runtime_error("engine holds no suffix ranks: run it on a partition first");
     hipStream_t st = e.stream();
     MMT_HIP(hipSetDevice(e.device()));
-    MergeScratch& M = scratch();
+    MergeScratch& M = scratch(e.device());
     // anchor = document 0 of the engine's text, '+' strand starts at text offset 0
     DevBuf<uint32_t> key_a, key_b;
     key_a.ensure(n); key_b.ensure(n); M.vals_a.ensure(n + 1); M.vals_b.ensure(n + 1); M.d_count.ensure(4);

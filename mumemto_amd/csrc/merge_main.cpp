@@ -47,13 +47,17 @@ static Loaded load(const std::string& path) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { std::cerr << "Usage: " << argv[0] << " <input_paths>... -o <output_prefix> [-v]" << std::endl; return 1; }
+    if (argc < 3) { std::cerr << "Usage: " << argv[0] << " <input_paths>... -o <output_prefix> [-l min_len] [-v]" << std::endl; return 1; }
     std::vector<std::string> paths;
     std::string output = "merged";
     bool verbose = false;
+    // -l: minimum length of a merged MUM.  The reference hard-codes 20 (src/merge_candidates.cpp:141), which is only
+    // right for partitions made with the default -l; partitions made with another -l need the same value here.
+    uint32_t min_len = 20;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a == "-o" && i + 1 < argc) output = argv[++i];
+        else if (a == "-l" && i + 1 < argc) min_len = (uint32_t)std::stoul(argv[++i]);
         else if (a == "-v") verbose = true;
         else paths.push_back(a);
     }
@@ -74,7 +78,7 @@ int main(int argc, char** argv) {
             mp[i].thresh_len = parts[i].thresh.size(); mp[i].thresh_on_device = 0; mp[i].rows_on_device = 0;
         }
         mmt::Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
-        mmt::MergedRows m = mmt::anchor_merge(eng, mp.data(), mp.size());
+        mmt::MergedRows m = mmt::anchor_merge(eng, mp.data(), mp.size(), min_len);
         mmt::download_merged(eng, m);
         bool out_bumbl = ends_with(output, ".bumbl"), out_mums = ends_with(output, ".mums");
         std::string out_path = output;

@@ -123,11 +123,30 @@ def test_bench_multi_rank_path_on_one_gpu(world):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world),
-           "--steps", "2", "--warmup", "1", "--length", "150000", "--backend", "gloo", "--share-device", "--check"]
+           "--steps", "2", "--warmup", "1", "--haps", "31", "--length", "150000", "--divergence", "0.005", "--backend", "gloo",
+           "--share-device", "--check"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["haplotypes"] == 1 + 15 * world
-    assert d["config"]["output_equals_cpu_oracle"] is True and d["config"]["output_rows"] > 0
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["haplotypes"] == 31
+    assert d["config"]["output_equals_cpu_oracle"] is True and d["config"]["output_bytes"] > 0
+
+
+def test_bench_single_gpu_line_at_a_small_size():
+    """bench.py at N = 1 on a collection the oracle can check: FASTA files -> PREFIX.mums in-process, the same job as a
+    mumemto_exec process, the HBM-resident step, roofline and CPU baseline keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--haps", "12", "--length", "200000",
+           "--divergence", "0.005", "--cpu-sample-bp", "200000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["metric"] == "input Gbp/s end-to-end" and d["value"] > 0
+    assert d["config"]["output_equals_cpu_oracle"] is True
+    assert d["cli_process"]["rc"] == 0 and d["cli_process"]["output_identical_to_in_process"] is True
+    assert d["hbm_resident"]["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["cores"] == 1

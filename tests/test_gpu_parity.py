@@ -243,6 +243,25 @@ def test_partition_merge_equals_direct_run(engine):
     assert np.array_equal(merged["thresh"], direct.thresh()[: len(docs[0][0]) + 1])
 
 
+@pytest.mark.parametrize("min_len", [10, 50])
+def test_partition_merge_with_another_min_len_equals_direct_run(engine, min_len):
+    # the reference's anchor_merge hard-codes 20 (merge_candidates.cpp:141); partitions made with another -l fold
+    # to the direct run of that -l only when the fold is told the same length
+    docs = synth.pangenome(7, 20000, 0.004, seed=22, indel_rate=0.0005)
+    groups = [[0, 1, 2, 3], [0, 4, 5, 6]]
+    parts = []
+    for g in groups:
+        engine.set_docs([docs[i] for i in g])
+        engine.run(min_match_len=min_len, merge_metadata=True)
+        L, off, st = engine.rows_mum()
+        parts.append((L, off, st, engine.thresholds()[: len(docs[0][0]) + 1].copy()))
+    merged = engine.anchor_merge(parts, sort_like_direct=True, min_len=min_len)
+    direct = O.run(docs, min_len=min_len, merge=True)
+    assert merged["text"] == direct.text() and merged["text"].count(b"\n") > 20
+    if min_len > 20:            # the hard-coded 20 keeps merged rows shorter than -l: not the direct run's output
+        assert engine.anchor_merge(parts, sort_like_direct=True)["text"] != direct.text()
+
+
 def test_full_size_properties(engine):
     # larger than the oracle comfortably checks in CI time: size-independent properties
     docs = synth.pangenome(8, 400000, 0.005, seed=33)

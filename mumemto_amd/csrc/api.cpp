@@ -83,6 +83,7 @@ struct mumemto_mem_result {
 };
 struct mmt_engine {
     std::unique_ptr<mmt::Engine> e;
+    mmt::HostArena arena;              // host buffer of mmt_engine_run_files, kept between calls
 };
 struct mmt_merged {
     mmt::MergedRows rows;
@@ -271,12 +272,12 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<std::string> inputs(paths, paths + n_paths);
     std::vector<mmt::FastaDoc> docs;
-    mmt::HostBytes bases;
-    std::vector<uint64_t> doc_len;
-    const long empty = mmt::read_fasta_files(inputs, docs, bases, doc_len);
+    mmt::HostDocs hd;
+    // the host buffer the files are parsed into stays with the engine handle: the next call reuses its pages
+    const long empty = mmt::read_fasta_collection(inputs, docs, e->arena, hd);
     if (empty >= 0) throw std::runtime_error("Empty input file found: " + inputs[(size_t)empty]);
     const double t_read = since();
-    e->e->run_partitioned_host(bases.data(), doc_len.data(), doc_len.size(), *p, max_text_chars);
+    e->e->run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), *p, max_text_chars);
     const double t_run = since();
     if (out_prefix) {
         const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_TEXT);

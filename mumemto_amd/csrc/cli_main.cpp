@@ -161,17 +161,19 @@ int main(int argc, char** argv) {
                 catch (...) { engine_error = std::current_exception(); }
             });
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } engine_joiner{engine_init};
-        HostBytes bases;
+        HostArena arena;
+        HostDocs hd;
         std::vector<FastaDoc> docs;
         if (!checkpoint) {
-            std::vector<uint64_t> lens;
-            const long empty = read_fasta_files(inputs, docs, bases, lens);
+            const long empty = read_fasta_collection(inputs, docs, arena, hd);
             if (empty >= 0) {                       // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
                 std::cerr << std::endl << "Empty input file found: " << inputs[(size_t)empty] << std::endl;
                 throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
             }
-            doc_len = lens;
+            doc_len = hd.len;
         }
+        uint64_t n_bases = 0;
+        for (uint64_t l : hd.len) n_bases += l;
         uint64_t text_chars = 0;
         for (uint64_t l : doc_len) text_chars += (o.use_rcomp ? 2 : 1) * (l + 1);
         // stage checkpoints: the text (from PREFIX.parse/.dict) or the stream (PREFIX.sa/.lcp/.bwt) comes from files
@@ -189,13 +191,14 @@ int main(int argc, char** argv) {
             log_line("build_main", "Using pre-computed LCP/BWT/SA arrays from files with prefix: " + o.arrays_in);
         } else {
             write_lengths_file(o.output_prefix, docs);
-            std::fprintf(stderr, "\033[32m[build_main] \033[0mread %zu files, %zu bases ... done.  (%.3f sec)\n", docs.size(),
-                         bases.size(), secs_since(t0));
+            std::fprintf(stderr, "\033[32m[build_main] \033[0mread %zu files, %llu bases ... done.  (%.3f sec)\n", docs.size(),
+                         (unsigned long long)n_bases, secs_since(t0));
         }
 
         if (dry_run) {                            // host-side checks only (tests on machines without a GPU)
             uint64_t h = 1469598103934665603ull;
-            for (uint8_t b : bases) { h ^= b; h *= 1099511628211ull; }
+            for (size_t d = 0; d < hd.ptr.size(); d++)
+                for (uint64_t i = 0; i < hd.len[d]; i++) { h ^= hd.ptr[d][i]; h *= 1099511628211ull; }
             for (uint8_t b : ck_text) { h ^= b; h *= 1099511628211ull; }
             for (uint32_t v : ck_sa) { h ^= v; h *= 1099511628211ull; }
             for (uint32_t v : ck_lcp) { h ^= v; h *= 1099511628211ull; }
@@ -204,7 +207,7 @@ int main(int argc, char** argv) {
                 std::printf("checkpoint=%s text_chars=%llu entries=%zu ", o.from_parse_flag ? "parse" : "arrays",
                             (unsigned long long)text_chars, o.from_parse_flag ? ck_text.size() : ck_sa.size());
             std::printf("docs=%zu bases=%zu fnv1a=%016llx num_distinct=%d max_doc_freq=%d max_total_freq=%d revcomp=%d "
-                        "merge=%d anchor=%d binary=%d min_len=%zu\n", doc_len.size(), bases.size(), (unsigned long long)h,
+                        "merge=%d anchor=%d binary=%d min_len=%zu\n", doc_len.size(), (size_t)n_bases, (unsigned long long)h,
                         o.num_distinct_docs, o.rare_freq, o.max_mem_freq, (int)o.use_rcomp, (int)o.merge,
                         (int)o.anchor_merge, (int)o.binary, o.min_match_len);
             return 0;
@@ -227,7 +230,7 @@ int main(int argc, char** argv) {
         else if (o.arrays_in_flag)
             eng.set_stream_host40(ck_sa.data(), ck_sa_hi.empty() ? nullptr : ck_sa_hi.data(), ck_lcp.data(), ck_bwt.data(),
                                   ck_sa.size(), doc_len.data(), doc_len.size(), o.use_rcomp);
-        else if (!partitioned) eng.set_input_host(bases.data(), doc_len.data(), doc_len.size());
+        else if (!partitioned) eng.set_input_host_docs(hd.ptr.data(), doc_len.data(), doc_len.size());
         mark("input on the device");
         auto write_pfp_files = [&]() {              // PREFIX.dict / PREFIX.parse as newscan.hpp:406-419 writes them
             eng.parse_only(o.use_rcomp, (uint32_t)o.pfp_w, (uint32_t)o.hash_mod);
@@ -252,7 +255,7 @@ int main(int argc, char** argv) {
         if (partitioned) {      // larger than one suffix array: anchor partitions + merge on this GPU
             if (o.keep_temp || o.arrays_out || (o.merge && !o.anchor_merge))
                 throw CliError{"-K, -A and -M (without -n) are not available for inputs larger than one suffix array", 1};
-            eng.run_partitioned_host(bases.data(), doc_len.data(), doc_len.size(), p, max_text);
+            eng.run_partitioned_docs(hd.ptr.data(), doc_len.data(), doc_len.size(), p, max_text);
             log_line("build_main", "text of " + std::to_string(text_chars) + " characters processed as " +
                                        std::to_string(eng.partitions_used()) + " anchor partitions");
         } else {

@@ -51,6 +51,20 @@ void Engine::set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, siz
     set_input_device(d_bases_own_.get(), doc_len, n_docs);
 }
 
+void Engine::set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs) {
+    MMT_HIP(hipSetDevice(device_));
+    uint64_t total = 0;
+    for (size_t d = 0; d < n_docs; d++) total += doc_len[d];
+    d_bases_own_.ensure(total + 16);
+    uint64_t at = 0;
+    for (size_t d = 0; d < n_docs; d++) {
+        if (doc_len[d]) MMT_HIP(hipMemcpyAsync(d_bases_own_.get() + at, doc_ptr[d], doc_len[d], hipMemcpyHostToDevice, stream_));
+        at += doc_len[d];
+    }
+    MMT_HIP(hipStreamSynchronize(stream_));
+    set_input_device(d_bases_own_.get(), doc_len, n_docs);
+}
+
 // document layout of the text: starts of the documents, total length, device copy of the starts
 void Engine::layout_docs(bool revcomp) {
     const size_t N = doc_len_.size();

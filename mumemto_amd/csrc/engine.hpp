@@ -40,6 +40,8 @@ public:
 
     void set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs);
     void set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs);
+    // the documents in separate host buffers (no concatenation on the host: one H2D copy per document)
+    void set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs);
     // Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): the caller hands over
     // the text T itself (UPPER(F) '$' [revcomp '$'] per document, e.g. rebuilt from PREFIX.parse/.dict) or the
     // whole stream (SA / LCP / BWT of the real suffixes, sentinel entry dropped); run() then skips the stages
@@ -56,6 +58,8 @@ public:
     // device memory as one suffix array) the documents are processed as anchor partitions and merged
     // (strict multi-MUMs only, like the reference's merge).
     void run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
+                              uint64_t max_text);
+    void run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
                               uint64_t max_text);
     size_t partitions_used() const { return partitions_used_; }
     // merged .athresh (L_0 + 1 entries) of the last partitioned run, empty otherwise

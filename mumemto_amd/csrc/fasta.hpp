@@ -42,6 +42,26 @@ struct HostBytes {
 long read_fasta_files(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostBytes& bases,
                       std::vector<uint64_t>& doc_len);
 
+// The same without a second copy of the bases: every plain file is parsed straight into its own slot of one large
+// buffer (huge pages, kept between calls), compressed files into vectors; the caller uploads document by document.
+class HostArena {
+public:
+    HostArena() = default;
+    HostArena(const HostArena&) = delete;
+    ~HostArena();
+    uint8_t* ensure(size_t bytes);      // grows only
+private:
+    uint8_t* p_ = nullptr;
+    size_t cap_ = 0;
+};
+struct HostDocs {
+    std::vector<const uint8_t*> ptr;    // bases of document i
+    std::vector<uint64_t> len;
+    std::vector<std::vector<uint8_t>> owned;
+};
+long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostArena& arena,
+                           HostDocs& out);
+
 // RefBuilder::write_lengths_file (src/ref_builder.cpp:193-209)
 void write_lengths_file(const std::string& prefix, const std::vector<FastaDoc>& docs);
 

@@ -21,6 +21,14 @@ namespace mmt {
 
 void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
                                   uint64_t max_text) {
+    std::vector<const uint8_t*> ptr(n_docs);
+    uint64_t at = 0;
+    for (size_t d = 0; d < n_docs; d++) { ptr[d] = h_bases + at; at += doc_len[d]; }
+    run_partitioned_docs(ptr.data(), doc_len, n_docs, p, max_text);
+}
+
+void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
+                                  uint64_t max_text) {
     MMT_HIP(hipSetDevice(device_));
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t mult = p.use_revcomp ? 2 : 1;
@@ -44,7 +52,7 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     partitions_used_ = 1;
     if (total <= max_text || n_docs < 3 || !strict) {
         try {
-            set_input_host(h_bases, doc_len, n_docs);
+            set_input_host_docs(doc_ptr, doc_len, n_docs);
             run(p);
             return;
         } catch (const HipError& e) {
@@ -97,9 +105,12 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
         try {
             MMT_HIP(hipSetDevice(device_));
             const size_t a = groups[g].first, b = groups[g].second;
-            if (base[b] > base[a])
-                MMT_HIP(hipMemcpyAsync(buf[slot] + doc_len[0], h_bases + base[a], base[b] - base[a], hipMemcpyHostToDevice,
-                                       copy_stream));
+            uint64_t at = doc_len[0];
+            for (size_t d = a; d < b; d++) {
+                if (doc_len[d])
+                    MMT_HIP(hipMemcpyAsync(buf[slot] + at, doc_ptr[d], doc_len[d], hipMemcpyHostToDevice, copy_stream));
+                at += doc_len[d];
+            }
             MMT_HIP(hipStreamSynchronize(copy_stream));
         } catch (...) { upload_error = std::current_exception(); }
     };
@@ -109,7 +120,7 @@ void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_le
     };
     try {
         if (doc_len[0]) {
-            MMT_HIP(hipMemcpyAsync(buf[0], h_bases, doc_len[0], hipMemcpyHostToDevice, stream_));
+            MMT_HIP(hipMemcpyAsync(buf[0], doc_ptr[0], doc_len[0], hipMemcpyHostToDevice, stream_));
             if (G > 1) MMT_HIP(hipMemcpyAsync(buf[1], buf[0], doc_len[0], hipMemcpyDeviceToDevice, stream_));
             MMT_HIP(hipStreamSynchronize(stream_));
         }

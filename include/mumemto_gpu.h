@@ -147,6 +147,11 @@ MMT_API int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, c
 /* Device heap of the engine's GPU (pool.hpp): [0] bytes mapped from the driver, [1] bytes in use, [2] high-water mark
  * of [1], [3] microseconds spent in the driver mapping memory.                                                         */
 MMT_API int mmt_device_memory(const mmt_engine* e, uint64_t out[4]);
+/* Multi-GPU runs of partial multi-MUMs / multi-MEMs, which the anchor merge cannot serve (the reference refuses to
+ * merge them: include/pfp_mum.hpp:178-183): every rank builds the same stream and scans only its share of the
+ * suffix-array positions; the outputs of ranks 0 .. count-1, concatenated, are byte for byte the output of one GPU
+ * (mumemto_amd/dist.py::run_sharded gathers them).  count = 1 switches it off.                                      */
+MMT_API int mmt_engine_set_scan_shard(mmt_engine* e, uint32_t index, uint32_t count);
 /* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
 MMT_API void mmt_pool_trim(void);
 

@@ -72,6 +72,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
+    "mmt_engine_set_scan_shard",
 ]
 
 
@@ -446,6 +447,11 @@ class Engine:
         if self.is_wide():
             return self._copy(self.L.mmt_copy_sa64, np.uint64)
         return self._copy(self.L.mmt_copy_sa, np.uint32)
+
+    def set_scan_shard(self, index, count):
+        """This engine scans share `index` of `count` of the suffix-array positions (multi-GPU runs of the modes
+        without a partition merge); the ranks' outputs concatenate to the single-GPU output."""
+        _check(self.L.mmt_engine_set_scan_shard(self.h, C.c_uint32(index), C.c_uint32(count)))
 
     def is_wide(self):
         return bool(self.L.mmt_is_wide(self.h))

@@ -282,10 +282,7 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
     if (out_prefix) {
         const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_TEXT);
         const std::string name = std::string(out_prefix) + (R.mum_mode ? ".mums" : ".mems");
-        std::FILE* f = std::fopen(name.c_str(), "wb");
-        if (!f) throw std::runtime_error("cannot write " + name);
-        const size_t wrote = R.text_len ? std::fwrite(R.text, 1, R.text_len, f) : 0;
-        if (std::fclose(f) != 0 || wrote != R.text_len) throw std::runtime_error("short write to " + name);
+        mmt::write_file_bytes(name, R.text, R.text_len);
         mmt::write_lengths_file(out_prefix, docs);
     }
     if (seconds) { seconds[0] = t_read; seconds[1] = t_run - t_read; seconds[2] = since() - t_run; seconds[3] = since(); }
@@ -394,6 +391,12 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
     MMT_CATCH
 }
 void mmt_pool_trim(void) { mmt::pool::trim(); }
+int mmt_engine_set_scan_shard(mmt_engine* e, uint32_t index, uint32_t count) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    e->e->set_scan_shard(index, count);
+    MMT_CATCH
+}
 int mmt_device_memory(const mmt_engine* e, uint64_t out[4]) {
     if (!e) return fail(1, "null");
     const mmt::pool::Stats s = mmt::pool::stats(e->e->device());

@@ -34,11 +34,7 @@ static void mark(const char* what) {
 static double secs_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
-static void write_file(const std::string& path, const void* data, size_t n) {
-    std::ofstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot write " + path);
-    f.write(static_cast<const char*>(data), (std::streamsize)n);
-}
+static void write_file(const std::string& path, const void* data, size_t n) { write_file_bytes(path, data, n); }
 
 // RefBuilder(prefix, use_rcomp) (src/ref_builder.cpp:140-169): document lengths from PREFIX.lengths --
 // "path * total" lines (or the two-word "path total" form); per-record lines are skipped

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstddef>
 #include <cstdio>
@@ -47,7 +48,9 @@ public:
     void ensure(size_t n) {
         if (n <= cap_) { n_ = n; return; }
         release();
-        size_t want = n + n / 16 + 64;
+        // a little slack, so that a re-run with slightly different sizes does not re-allocate; capped: a sixteenth of a
+        // 48 GB column is 3 GB of device memory nobody uses
+        size_t want = n + std::min<size_t>(n / 16, ((size_t)16 << 20) / sizeof(T)) + 64;
         const auto t0 = std::chrono::steady_clock::now();
         p_ = static_cast<T*>(pool::alloc(want * sizeof(T)));
         DevBytes::seconds() += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -88,9 +88,9 @@ void Engine::set_text_host(const uint8_t* text, uint64_t n, const uint64_t* doc_
     layout_docs(revcomp);
     if (n != n_) throw std::runtime_error("the text has " + std::to_string(n) + " characters, the document lengths add "
                                           "up to " + std::to_string(n_));
-    d_text_.ensure(n_ + 64);
-    MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~15ull), 0, 64 + (n_ & 15ull), stream_));
-    if (n_) MMT_HIP(hipMemcpyAsync(d_text_.get(), text, n_, hipMemcpyHostToDevice, stream_));
+    d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
+    if (n_) MMT_HIP(hipMemcpyAsync(text_ptr(), text, n_, hipMemcpyHostToDevice, stream_));
+    finish_text_padding();
     std::vector<uint64_t> hist(256, 0);
     for (uint64_t i = 0; i < n_; i++) hist[text[i]]++;
     d_hist_.ensure(256);
@@ -143,12 +143,20 @@ void Engine::build_text(bool revcomp) {
     layout_docs(revcomp);
     d_doc_base_.ensure(N + 1);
     MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
-    d_text_.ensure(n_ + 64);
+    d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
-    MMT_HIP(hipMemsetAsync(d_text_.get() + (n_ & ~15ull), 0, 64 + (n_ & 15ull), stream_));
-    k::build_text(d_bases_, d_doc_base_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, d_text_.get(), n_,
+    k::build_text(d_bases_, d_doc_base_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, text_ptr(), n_,
                   d_hist_.get(), stream_);
+    finish_text_padding();          // (the last work-item of the kernel stores up to 15 bytes past the text)
+}
+
+// Dollar in front of the text, 32 Dollars and then zeros behind it (see text_ptr())
+void Engine::finish_text_padding() {
+    MMT_HIP(hipMemsetAsync(d_text_.get(), 0, TEXT_FRONT - 1, stream_));
+    MMT_HIP(hipMemsetAsync(d_text_.get() + TEXT_FRONT - 1, 2, 1, stream_));
+    MMT_HIP(hipMemsetAsync(text_ptr() + n_, 2, 32, stream_));
+    MMT_HIP(hipMemsetAsync(text_ptr() + n_ + 32, 0, TEXT_BACK - 32, stream_));
 }
 
 // ---- A8: suffix array by prefix doubling (narrow texts only) --------------------
@@ -171,7 +179,7 @@ void Engine::suffix_sort() {
 
     d_sa_.ensure(n); d_rank_.ensure(n);
     sorter_.reserve(n);
-    k::pack_keys(d_text_.get(), n, d_code_.get(), bits, chars, 0u, sorter_.keys_in(), sorter_.vals_in(), stream_);
+    k::pack_keys(text_ptr(), n, d_code_.get(), bits, chars, 0u, sorter_.keys_in(), sorter_.vals_in(), stream_);
     sort_rounds_ = sorter_.sort(n, bits * chars, (uint64_t)chars, d_sa_.get(), d_rank_.get(), d_temp_, stream_);
 }
 
@@ -185,7 +193,7 @@ void Engine::lcp_bwt() {
     // inverse suffix array at all; only the suffix ranks of the anchor document are recorded here (multi-GPU
     // re-sort).  The direct producer has the full array from its sort.
     const bool pfp = producer_used_ == 2 && pfp_->bwt_ready;
-    if (!pfp) k::bwt_from_sa(d_text_.get(), (uint32_t)n, d_sa_.get(), d_bwt_.get(), stream_);
+    if (!pfp) k::bwt_from_sa(text_ptr(), (uint32_t)n, d_sa_.get(), d_bwt_.get(), stream_);
     const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
     void* rank_out = nullptr;
     if (pfp) {
@@ -199,14 +207,14 @@ void Engine::lcp_bwt() {
     uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 0x7fffffffull);
     for (int attempt = 0; attempt < 2; attempt++) {
         d_long_.ensure((size_t)cap * rec);
-        k::irreducible_lcp(d_text_.get(), n, sa_col(), d_bwt_.get(), d_plcp_a_.get(), rank_out, anchor, d_long_.get(),
+        k::irreducible_lcp(text_ptr(), n, sa_col(), d_bwt_.get(), d_plcp_a_.get(), rank_out, anchor, d_long_.get(),
                            d_count_.get() + 2, cap, stream_);
         uint32_t found = 0;
         MMT_HIP(hipMemcpyAsync(&found, d_count_.get() + 2, 4, hipMemcpyDeviceToHost, stream_));
         MMT_HIP(hipStreamSynchronize(stream_));
         if (std::getenv("MMT_LCP_STATS")) std::fprintf(stderr, "[lcp] %u matches beyond 192 characters (list capacity %u)\n", found, cap);
         if (found <= cap) {
-            k::long_lcp(d_text_.get(), n, wide_, d_long_.get(), found, d_plcp_a_.get(),
+            k::long_lcp(text_ptr(), n, wide_, d_long_.get(), found, d_plcp_a_.get(),
                         reinterpret_cast<uint32_t*>(d_long_.get() + (size_t)cap * (rec - 4)), d_count_.get() + 3, stream_);
             break;
         }
@@ -223,6 +231,7 @@ void Engine::lcp_bwt() {
 void Engine::release_sort_scratch() {
     MMT_HIP(hipStreamSynchronize(stream_));
     sorter_.release();
+    d_temp_.release();                               // (library scratch of the sorts: as large as their inputs)
     std::unique_ptr<PfpState> fresh(new PfpState());
     const PfpState& S = *pfp_;
     fresh->w = S.w; fresh->p = S.p; fresh->n_cuts = S.n_cuts; fresh->n_phrases = S.n_phrases; fresh->n_distinct = S.n_distinct;
@@ -309,7 +318,15 @@ void Engine::scan(const mmt_params& p) {
         if (const char* c = std::getenv("MMT_SCAN_RANGE")) range = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
         range = (range + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
     }
-    const bool single = range >= n;
+    // this rank's share of the closing positions (set_scan_shard)
+    uint64_t shard_lo = 0, shard_hi = n;
+    if (shard_count_ > 1) {
+        if (preset_ == 2) throw std::runtime_error("a handed-over stream cannot be scanned in shards");
+        auto cut = [&](uint64_t k) { return k >= shard_count_ ? n : (n / shard_count_ * k) / ALIGN_R * ALIGN_R; };
+        shard_lo = cut(shard_index_); shard_hi = cut(shard_index_ + 1);
+        range = std::min<uint64_t>(range, std::max<uint64_t>(ALIGN_R, (shard_hi - shard_lo + ALIGN_R - 1) / ALIGN_R * ALIGN_R));
+    }
+    const bool single = range >= n && shard_count_ == 1;
     if (single && n >= 0xffffe000ull) throw std::runtime_error("a scan range holds fewer than 2^32 - 8192 entries");
     // left extension of every range but the first: at least the largest interval (+1), the window of the wide-document
     // path, one LDS halo; uncapped modes start with 64 K entries and repeat a range whose walk ran off it
@@ -326,8 +343,8 @@ void Engine::scan(const mmt_params& p) {
         range_ev_[ev_at]->reset();
         return *range_ev_[ev_at++];
     };
-    for (uint64_t c0 = 0; c0 < n; c0 += range) {
-        const uint64_t c1 = std::min(n, c0 + range);
+    for (uint64_t c0 = shard_lo; c0 < shard_hi; c0 += range) {
+        const uint64_t c1 = std::min(shard_hi, c0 + range);
         uint64_t ext = c0 ? ext0 : 0;
         uint32_t found = 0;
         uint64_t b0 = 0;
@@ -628,6 +645,18 @@ void Engine::run(const mmt_params& p) {
     ev_[0]->start(stream_);
     if (preset_ == 0) build_text(p.use_revcomp != 0);
     ev_[0]->stop(stream_);
+    if (drop_input_after_text_ && preset_ == 0 && d_bases_ && d_bases_ == d_bases_own_.get()) {
+        MMT_HIP(hipStreamSynchronize(stream_));
+        d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
+    }
+    if (lean_ || wide_) {
+        // one-shot / wide runs: the columns that live to the end of the run are allocated before any scratch, so that
+        // they sit together at the bottom of the device heap and the scratch above them leaves one hole when it goes
+        // (allocated late they land between scratch buffers, the heap fragments and maps 228 GB for 170 GB in use)
+        d_sa_.ensure(n_);
+        if (wide_) d_sa_hi_.ensure(n_ + 16);
+        d_bwt_.ensure((size_t)n_ + 16);
+    }
     ev_[1]->start(stream_);
     {
         int kind = producer_;
@@ -653,7 +682,10 @@ void Engine::run(const mmt_params& p) {
         // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
         // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of
         // short phrase suffixes (all occurrences of a trigger window) small (gpurun sweeps)
-        const uint32_t auto_w = n_ < (1ull << 30) ? 6 : 10, auto_p = n_ < (1ull << 30) ? 16 : 30;
+        // (94 x 64 Mbp, 12 G characters: w = 14 leaves no suffix group larger than an emitter tile -- every 14-mer is
+        // rare enough -- and takes 1054 ms against 1111 for 10 / 30, 1171 for 10 / 50, 1981 for 10 / 100, 1376 for 8 / 30)
+        const bool big = n_ >= NARROW_LIMIT;
+        const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10), auto_p = n_ < (1ull << 30) ? 16 : 30;
         if (kind == 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
         else suffix_sort();
         producer_used_ = kind;
@@ -680,7 +712,7 @@ void Engine::parse_only(bool revcomp, uint32_t w, uint32_t p) {
 }
 
 void Engine::copy_text(uint8_t* out) const {
-    MMT_HIP(hipMemcpy(out, d_text_.get(), n_, hipMemcpyDeviceToHost));
+    MMT_HIP(hipMemcpy(out, text_ptr(), n_, hipMemcpyDeviceToHost));
 }
 void Engine::copy_sa(uint32_t* out) const {
     if (wide_ && n_ >= NARROW_LIMIT) throw std::runtime_error("40-bit suffix array: use the 64-bit accessor");

@@ -82,6 +82,15 @@ public:
     // device): every stage gives its scratch back before the next one allocates, so that the footprint is the
     // largest stage instead of the sum -- at the price of hipMalloc calls in every run.
     void set_lean(bool on) { lean_ = on; }
+    // Multi-GPU runs of the modes the anchor merge cannot serve (partial multi-MUMs, multi-MEMs: the reference refuses
+    // to merge them, include/pfp_mum.hpp:178-183): every rank builds the same stream and scans only its share of the
+    // suffix-array positions -- closing positions in [n * index / count, n * (index + 1) / count), cut at multiples of
+    // 4096 -- so that the outputs of the ranks, concatenated in rank order, are the output of one GPU (rows come out in
+    // order of their closing position).  count = 1 switches it off.
+    void set_scan_shard(uint32_t index, uint32_t count) {
+        if (count == 0 || index >= count) throw std::runtime_error("scan shard index out of range");
+        shard_index_ = index; shard_count_ = count;
+    }
     void release_sort_scratch();
     // gives every column and scratch buffer of the last run back to the device heap (results already downloaded stay)
     void release_columns();
@@ -116,6 +125,13 @@ public:
     const uint32_t* isa_device() const { return d_rank_.get(); }        // narrow runs
     const uint64_t* isa_device64() const { return d_rank64_.get(); }    // wide runs
     bool wide() const { return wide_; }
+    // The text buffer also is the string V = Dollar . T . Dollar^w the prefix-free parse reads (newscan.hpp:248, :359):
+    // one Dollar byte sits in front of T (64 bytes of padding keep T 16-byte aligned), 32 Dollar bytes and then
+    // zeros behind it, so V[i] = text_ptr()[i - 1] without a second copy of the text.  Nothing reads T[n ..) for its
+    // value: every comparison of suffixes is clamped to the end of the shorter one.
+    static constexpr size_t TEXT_FRONT = 64, TEXT_BACK = 128;
+    uint8_t* text_ptr() const { return d_text_.get() ? d_text_.get() + TEXT_FRONT : nullptr; }
+    void finish_text_padding();
     SaCol sa_col() const { SaCol c; c.lo = d_sa_.get(); c.hi = wide_ ? d_sa_hi_.get() : nullptr; return c; }
     size_t scan_ranges() const { return scan_ranges_; }
     const float* stage_ms() const { return stage_ms_; }
@@ -144,6 +160,7 @@ private:
     uint64_t n_ = 0;
     bool wide_ = false;                   // this text runs with 40-bit positions (wide.hpp)
     bool input_valid_ = false;
+    bool drop_input_after_text_ = false;  // host-fed runs upload the bases for every run: they are dead once T exists
     int preset_ = 0;                      // 0: build everything, 1: text handed over, 2: stream handed over
 
     // columns
@@ -155,6 +172,7 @@ private:
     // LCP column, BWT change marks replaced by their running maximum)
     DevBuf<uint32_t> d_wpre_, d_wsuf_, d_wide_;
     bool lcp_whole_ = false;              // d_lcp_ holds the LCP column of the whole stream (one scan range)
+    uint32_t shard_index_ = 0, shard_count_ = 1;
     size_t scan_ranges_ = 1;
     DoublingSorter sorter_;
     int sort_rounds_ = 0;

@@ -2,7 +2,9 @@
 
 #include <zlib.h>
 
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -239,6 +241,21 @@ long read_fasta_files(const std::vector<std::string>& inputs, std::vector<FastaD
         std::vector<uint8_t>().swap(part[i]);
     });
     return -1;
+}
+
+void write_file_bytes(const std::string& path, const void* data, size_t n) {
+    // one writer: write() on a file is serialised by its inode lock, and filling a shared mapping of the file from
+    // sixteen threads was slower than this loop on tmpfs (0.33 against 0.22 s for the 894 MB of the C3 stand-in)
+    const int fd = ::open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) throw std::runtime_error("cannot write " + path);
+    const char* src = static_cast<const char*>(data);
+    size_t at = 0;
+    while (at < n) {
+        const ssize_t w = ::write(fd, src + at, std::min<size_t>(n - at, (size_t)1 << 30));
+        if (w <= 0) { ::close(fd); throw std::runtime_error("short write to " + path); }
+        at += (size_t)w;
+    }
+    if (::close(fd) != 0) throw std::runtime_error("cannot close " + path);
 }
 
 void write_lengths_file(const std::string& prefix, const std::vector<FastaDoc>& docs) {

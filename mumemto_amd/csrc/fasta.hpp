@@ -62,6 +62,9 @@ struct HostDocs {
 long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostArena& arena,
                            HostDocs& out);
 
+// Writes n bytes to `path` (created / truncated) and closes it.
+void write_file_bytes(const std::string& path, const void* data, size_t n);
+
 // RefBuilder::write_lengths_file (src/ref_builder.cpp:193-209)
 void write_lengths_file(const std::string& prefix, const std::vector<FastaDoc>& docs);
 

@@ -1095,8 +1095,11 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 lds_barrier();
             }
             // ---- remaining levels (step >= 8): T[i..i+3] = min(T[i..i+3], T[i+step..i+step+3]) ----
-            for (uint32_t lev = K0; lev < klev; lev++) {
+            // Two levels per pass where two are left (four reads, one write, two barriers instead of 2 x (two reads, one
+            // write, two barriers)): a window of 93 entries (94 documents, levels 3 -> 5 -> 6) takes two passes, not three.
+            for (uint32_t lev = K0; lev < klev;) {
                 const uint32_t gstep = (1u << lev) >> 2;
+                const bool two = lev + 2 <= klev;
                 uint4* t4 = reinterpret_cast<uint4*>(s_T);
                 uint4 rt[MAXG];
                 uint32_t rc[MAXG];
@@ -1104,9 +1107,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 for (int q = 0; q < MAXG; q++) {
                     const uint32_t g = threadIdx.x + q * BLOCK;
                     if (g < groups) {
-                        const uint32_t g2 = g + gstep < groups ? g + gstep : groups - 1;
+                        const uint32_t last = groups - 1;
+                        const uint32_t g2 = g + gstep < groups ? g + gstep : last;
                         rt[q] = umin4(t4[g], t4[g2]);
                         rc[q] = s_C[g] | s_C[g2];
+                        if (two) {
+                            const uint32_t g3 = g + 2 * gstep < groups ? g + 2 * gstep : last;
+                            const uint32_t g4 = g + 3 * gstep < groups ? g + 3 * gstep : last;
+                            rt[q] = umin4(rt[q], umin4(t4[g3], t4[g4]));
+                            rc[q] |= s_C[g3] | s_C[g4];
+                        }
                     }
                 }
                 lds_barrier();
@@ -1116,6 +1126,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                     if (g < groups) { t4[g] = rt[q]; s_C[g] = rc[q]; }
                 }
                 lds_barrier();
+                lev += two ? 2u : 1u;
             }
 
             // ---- phase 1: positions whose w-window minimum exceeds their own LCP close something ----

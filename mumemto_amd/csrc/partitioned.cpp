@@ -50,10 +50,14 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
         if (const char* c = std::getenv("MMT_MAX_TEXT")) max_text = std::strtoull(c, nullptr, 10);
     }
     partitions_used_ = 1;
-    if (total <= max_text || n_docs < 3 || !strict) {
+    // (a non-strict mode has no partition merge: with the automatic limit it is tried as one suffix array anyway and
+    // fails with "out of device memory" if that was too optimistic; an explicit limit is an order)
+    if (total <= max_text || n_docs < 3 || (!strict && auto_limit)) {
         try {
             set_input_host_docs(doc_ptr, doc_len, n_docs);
-            run(p);
+            drop_input_after_text_ = true;
+            try { run(p); } catch (...) { drop_input_after_text_ = false; throw; }
+            drop_input_after_text_ = false;
             return;
         } catch (const HipError& e) {
             const bool oom = std::string(e.what()).find("out of device memory") != std::string::npos;

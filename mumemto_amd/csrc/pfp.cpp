@@ -50,12 +50,10 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
 
     // -- triggers, phrase boundaries
     e0.start(st);
-    const uint64_t vlen = n + 1 + w;
-    S.vtext.ensure((size_t)vlen + 64);
-    pk::make_vtext(d_text_.get(), n, w, S.vtext.get(), vlen + 64, st);
+    const uint8_t* const v = text_ptr() - 1;       // V = Dollar . T . Dollar^w lives in the text buffer (Engine::text_ptr)
     const uint32_t tb = pk::trigger_blocks(n);
     S.tmask.ensure((size_t)((n + 15) / 16) + 1); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
-    pk::trigger_masks(d_text_.get(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
+    pk::trigger_masks(text_ptr(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
     S.err.ensure(16);
     {
@@ -75,7 +73,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     e1.start(st);
     S.h1.ensure(m); S.pinfo.ensure((size_t)m * 16 + 16); S.hk_a.ensure(m); S.hk_b.ensure(m);
     S.iota.ensure(m); S.ord_a.ensure(m); S.order.ensure(m);
-    pk::phrase_hash(S.vtext.get(), S.pstart.get(), S.plen.get(), m, S.h1.get(), S.pinfo.get(), W, st);
+    pk::phrase_hash(v, S.pstart.get(), S.plen.get(), m, S.h1.get(), S.pinfo.get(), W, st);
     pk::iota(S.iota.get(), m, st);
     S.dflags.ensure(m); S.scan.ensure(m);
     for (int attempt = std::getenv("MMT_PFP_TWO_FINGERPRINTS") ? 1 : 0;; attempt++) {     // the variable forces the rare path (tests)
@@ -91,7 +89,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             prims::sort_pairs_u64_u32(d_temp_, S.hk_a.get(), S.hk_b.get(), S.ord_a.get(), S.order.get(), m, 0, 64, st);
         }
         MMT_HIP(hipMemsetAsync(S.err.get(), 0, 16, st));
-        pk::mark_distinct(S.order.get(), S.hk_b.get(), S.pinfo.get(), S.vtext.get(), m, S.dflags.get(), S.err.get(), st);
+        pk::mark_distinct(S.order.get(), S.hk_b.get(), S.pinfo.get(), v, m, S.dflags.get(), S.err.get(), st);
         prims::inclusive_sum_u32(d_temp_, S.dflags.get(), S.scan.get(), m, st);
         uint32_t flags2[2] = {0, 0};
         MMT_HIP(hipMemcpyAsync(flags2, S.err.get(), 8, hipMemcpyDeviceToHost, st));
@@ -133,9 +131,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     MMT_HIP(hipMemsetAsync(S.dict.get() + nd, 0, 64, st));
     // room for the byte before each position in the phrase-id word (MMT_PFP_NO_PACK: the other path, for tests)
     const bool pack_prev = D < (1u << 24) && !std::getenv("MMT_PFP_NO_PACK");
-    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
+    pk::copy_dict(v, S.pstart.get(), S.plen.get(), S.rep.get(), S.dstart.get(), D, S.dict.get(),
                   S.dinfo.get(), nd, pack_prev, W, st);
-    if (slim) { S.vtext.release(); S.dstart.release(); }
+    if (slim) S.dstart.release();
     e2.stop(st);
 
     // -- suffix array of the dictionary (dictionary.hpp:133) ...
@@ -399,7 +397,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
             prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
                                                    nf, S.fb_rel.get(), S.fb_rel.get() + 1, shift + (int)fb_bits, st);
         pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), L.f0, L.f1, h_fb_off[L.f0], S.segb.get(), S.xk_b.get(),
-                            S.xv_b.get(), fb_bits, decode, d_text_.get(), n, sa_col(), d_bwt_.get(), S.err.get(), W, st);
+                            S.xv_b.get(), fb_bits, decode, text_ptr(), n, sa_col(), d_bwt_.get(), S.err.get(), W, st);
     }
     if (read_u32(S.err.get(), st)) {
         std::vector<uint32_t> er;
@@ -422,7 +420,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
 // PREFIX.dict bytes: phrases in lexicographic order, 0x01 after each, final 0x00 (newscan.hpp:386-397)
 void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     PfpState& S = *pfp_;
-    if (!S.have_parse || !S.vtext.get() || !S.pstart.get())
+    if (!S.have_parse || !text_ptr() || !S.pstart.get())
         throw std::runtime_error("no parse available (run parse_only first)");
     const uint32_t D = S.n_distinct, nd = S.dict_len;
     DevBuf<uint32_t> which, slen, sstart;
@@ -430,7 +428,7 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     which.ensure(D); slen.ensure(D); sstart.ensure(D); sorted.ensure(nd);
     pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
     prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
-    pk::copy_dict(S.vtext.get(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
+    pk::copy_dict(text_ptr() - 1, S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
                   false, S.pstart.wide(), stream_);
     d2h(out, sorted.get(), nd, stream_);
 }

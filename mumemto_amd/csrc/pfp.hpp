@@ -12,7 +12,7 @@ struct PfpState {
     bool have_parse = false;
     int rounds_dict = 0, rounds_parse = 0;
     float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
-    DevBuf<uint8_t> vtext, dict, ptab, pinfo;   // pinfo: 16-byte record per phrase (k_phrase_hash)  // ptab: 16-byte record per distinct phrase (phrase_table)
+    DevBuf<uint8_t> dict, ptab, pinfo;   // pinfo: 16-byte record per phrase (k_phrase_hash)  // ptab: 16-byte record per distinct phrase (phrase_table)
     DevBuf<uint16_t> tmask;             // trigger masks, one per 16 text positions
     DevBuf<uint32_t> tcnt, toff;        // triggers per workgroup of the trigger pass and their exclusive scan
     PosBuf cuts, pstart;                // trigger positions, phrase starts (in V): text positions

@@ -29,34 +29,6 @@ static inline unsigned grid_for(uint64_t items, unsigned per_block) {
     return (unsigned)(g ? g : 1);
 }
 
-// V from T: V[0] = Dollar, V[1..n] = T, V[n+1..n+w] = Dollar, zero padding after.
-// Eight bytes of V per work-item: inside the text V[i .. i+7] = T[i-1 .. i+6] comes from two aligned words of T
-// (both buffers start on a 512-byte boundary), the two ends go byte by byte.
-__global__ void k_make_vtext(const uint8_t* __restrict__ text, uint64_t n, uint32_t w, uint8_t* __restrict__ v,
-                             uint64_t vlen_padded) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t i0 = t * 8;
-    if (i0 >= vlen_padded) return;
-    if (t >= 1 && i0 + 7 <= n) {
-        const uint64_t* tw = reinterpret_cast<const uint64_t*>(text);
-        const uint64_t lo = tw[t - 1], hi = tw[t];                 // T[i0-8 .. i0-1], T[i0 .. i0+7] (the text is padded)
-        *reinterpret_cast<uint64_t*>(v + i0) = (lo >> 56) | (hi << 8);
-        return;
-    }
-    for (uint64_t i = i0; i < i0 + 8 && i < vlen_padded; i++) {
-        uint8_t c;
-        if (i == 0) c = 2;
-        else if (i <= n) c = text[i - 1];
-        else if (i <= n + w) c = 2;
-        else c = 0;
-        v[i] = c;
-    }
-}
-void make_vtext(const uint8_t* text, uint64_t n, uint32_t w, uint8_t* v, uint64_t vlen_padded, hipStream_t s) {
-    hipLaunchKernelGGL(k_make_vtext, dim3(grid_for((vlen_padded + 7) / 8, 256)), dim3(256), 0, s, text, n, w, v, vlen_padded);
-    MMT_HIP(hipGetLastError());
-}
-
 // ---- A2: trigger positions ---------------------------------------------------------
 // hash_i = sum_{k<w} T[i-k] * 256^k mod prime (T[<0] = 0): the value KR_window holds after
 // addchar(T[i]) when its window starts zero-filled and is never reset (newscan.hpp:96-114).

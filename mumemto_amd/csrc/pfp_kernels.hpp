@@ -12,7 +12,6 @@
 
 namespace mmt { namespace pk {
 
-void make_vtext(const uint8_t* text, uint64_t n, uint32_t w, uint8_t* v, uint64_t vlen_padded, hipStream_t s);
 // trigger positions in two passes: 16-bit masks (one per 16 text positions) + triggers per workgroup; then, given the
 // exclusive scan of those counts, the positions themselves (ascending)
 uint32_t trigger_blocks(uint64_t n);

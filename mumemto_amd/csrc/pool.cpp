@@ -20,12 +20,20 @@ namespace {
 constexpr size_t ALIGN = 512;                    // every block starts on a 512-byte boundary (16-byte vector loads, LDS-DMA rows)
 constexpr size_t GROW = (size_t)1 << 30;         // physical memory is mapped in chunks of 1 GiB
 
+// Two regions in one reservation: blocks of SMALL_LIMIT bytes or more grow upwards from offset 0, smaller ones live in
+// a region that grows downwards from the end of the reservation -- a few long-lived kilobyte buffers (counters, document
+// tables, rocPRIM scratch) in the middle of 48 GB columns would otherwise split every large hole and force the heap to
+// map more physical memory than the run ever holds at once.
+constexpr size_t SMALL_LIMIT = (size_t)32 << 20;
+
 struct Heap {
     int device = 0;
     bool vmm = false;                            // false: plain hipMalloc / hipFree per block
     char* base = nullptr;
     size_t reserved = 0, top = 0;                // virtual range, mapped prefix [0, top)
-    std::map<size_t, size_t> free_blocks;        // offset -> size, coalesced
+    size_t small_bottom = 0;                     // mapped suffix [small_bottom, reserved) for the small blocks
+    std::map<size_t, size_t> free_blocks;        // offset -> size, coalesced (large region)
+    std::map<size_t, size_t> small_free;         // offset -> size, coalesced (small region)
     std::map<size_t, size_t> live_blocks;        // offset -> size
     std::vector<hipMemGenericAllocationHandle_t> handles;
     std::vector<std::pair<size_t, size_t>> mapped;   // (offset, size) per handle
@@ -56,7 +64,7 @@ Heap& heap_for(int device) {
             size_t want = ((tot + GROW - 1) / GROW) * GROW;
             void* va = nullptr;
             if (hipMemAddressReserve(&va, want, 0, nullptr, 0) == hipSuccess && va) {
-                h->base = static_cast<char*>(va); h->reserved = want; h->vmm = true;
+                h->base = static_cast<char*>(va); h->reserved = want; h->small_bottom = want; h->vmm = true;
             } else (void)hipGetLastError();
         } else (void)hipGetLastError();
     }
@@ -64,12 +72,9 @@ Heap& heap_for(int device) {
     return *g_heaps.back();
 }
 
-// map `bytes` (multiple of GROW) more physical memory at the top of the heap, in chunks of exactly GROW bytes:
-// hipMemSetAccess rejects ("invalid argument") some mappings when the chunks of one reservation differ in size
-// (tests/micro/vmm_probe.cpp), uniform ones have never failed
-bool grow(Heap& H, size_t bytes) {
-    if (H.top + bytes > H.reserved) return false;
-    const double t0 = now_s();
+// maps one chunk of exactly GROW bytes at `offset`: hipMemSetAccess rejects ("invalid argument") some mappings when the
+// chunks of one reservation differ in size (tests/micro/vmm_probe.cpp), uniform ones have never failed
+bool map_chunk(Heap& H, size_t offset, std::string& why) {
     hipMemAllocationProp prop{};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -77,57 +82,76 @@ bool grow(Heap& H, size_t bytes) {
     hipMemAccessDesc acc{};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipMemGenericAllocationHandle_t handle;
+    hipError_t e = hipMemCreate(&handle, GROW, &prop, 0);
+    if (e != hipSuccess) { why = std::string("hipMemCreate: ") + hipGetErrorString(e); (void)hipGetLastError(); return false; }
+    char* at = H.base + offset;
+    e = hipMemMap(at, GROW, 0, handle, 0);
+    if (e != hipSuccess) {
+        why = std::string("hipMemMap: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipMemRelease(handle); return false;
+    }
+    e = hipMemSetAccess(at, GROW, &acc, 1);
+    if (e != hipSuccess) {
+        why = std::string("hipMemSetAccess: ") + hipGetErrorString(e); (void)hipGetLastError();
+        (void)hipMemUnmap(at, GROW); (void)hipMemRelease(handle); return false;
+    }
+    H.handles.push_back(handle);
+    H.mapped.emplace_back(offset, GROW);
+    return true;
+}
+
+void add_free(std::map<size_t, size_t>& fl, size_t off, size_t size) {
+    auto next = fl.lower_bound(off);
+    if (next != fl.end() && off + size == next->first) { size += next->second; next = fl.erase(next); }
+    if (next != fl.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == off) { off = prev->first; size += prev->second; fl.erase(prev); }
+    }
+    fl[off] = size;
+}
+
+// map `bytes` (multiple of GROW) more physical memory at the top of the large region
+bool grow(Heap& H, size_t bytes) {
+    if (H.top + bytes > H.small_bottom) return false;
+    const double t0 = now_s();
     size_t done = 0;
     std::string why;
-    while (done < bytes) {
-        hipMemGenericAllocationHandle_t handle;
-        hipError_t e = hipMemCreate(&handle, GROW, &prop, 0);
-        if (e != hipSuccess) { why = std::string("hipMemCreate: ") + hipGetErrorString(e); (void)hipGetLastError(); break; }
-        char* at = H.base + H.top + done;
-        e = hipMemMap(at, GROW, 0, handle, 0);
-        if (e != hipSuccess) {
-            why = std::string("hipMemMap: ") + hipGetErrorString(e); (void)hipGetLastError(); (void)hipMemRelease(handle); break;
-        }
-        e = hipMemSetAccess(at, GROW, &acc, 1);
-        if (e != hipSuccess) {
-            why = std::string("hipMemSetAccess: ") + hipGetErrorString(e); (void)hipGetLastError();
-            (void)hipMemUnmap(at, GROW); (void)hipMemRelease(handle); break;
-        }
-        H.handles.push_back(handle);
-        H.mapped.emplace_back(H.top + done, GROW);
-        done += GROW;
-    }
+    while (done < bytes && map_chunk(H, H.top + done, why)) done += GROW;
     H.map_seconds += now_s() - t0;
-    if (done) {
-        // the new range joins the free list (coalesced with a free block that ends at the old top)
-        size_t off = H.top, size = done;
-        if (!H.free_blocks.empty()) {
-            auto last = std::prev(H.free_blocks.end());
-            if (last->first + last->second == H.top) { off = last->first; size += last->second; H.free_blocks.erase(last); }
-        }
-        H.free_blocks[off] = size;
-        H.top += done;
-    }
+    if (done) { add_free(H.free_blocks, H.top, done); H.top += done; }
     if (DevBytes::log() || done < bytes)
         std::fprintf(stderr, "[pool] device %d: +%.2f GB mapped, heap %.2f GB (%.3f s in the driver so far)%s%s\n", H.device,
                      done / 1073741824.0, H.top / 1073741824.0, H.map_seconds, done < bytes ? "; stopped by " : "", why.c_str());
     return done == bytes;
 }
+// one more chunk below the small region
+bool grow_small(Heap& H) {
+    if (H.small_bottom < H.top + GROW) return false;
+    const double t0 = now_s();
+    std::string why;
+    const bool ok = map_chunk(H, H.small_bottom - GROW, why);
+    H.map_seconds += now_s() - t0;
+    if (ok) { H.small_bottom -= GROW; add_free(H.small_free, H.small_bottom, GROW); }
+    else std::fprintf(stderr, "[pool] device %d: small region stopped by %s\n", H.device, why.c_str());
+    return ok;
+}
 
-void* take(Heap& H, size_t need) {
+void* take_from(Heap& H, std::map<size_t, size_t>& fl, size_t need) {
     // best fit
-    auto best = H.free_blocks.end();
-    for (auto it = H.free_blocks.begin(); it != H.free_blocks.end(); ++it)
-        if (it->second >= need && (best == H.free_blocks.end() || it->second < best->second)) best = it;
-    if (best == H.free_blocks.end()) return nullptr;
+    auto best = fl.end();
+    for (auto it = fl.begin(); it != fl.end(); ++it)
+        if (it->second >= need && (best == fl.end() || it->second < best->second)) best = it;
+    if (best == fl.end()) return nullptr;
     const size_t off = best->first, size = best->second;
-    H.free_blocks.erase(best);
-    if (size > need) H.free_blocks[off + need] = size - need;
+    fl.erase(best);
+    if (size > need) fl[off + need] = size - need;
     H.live_blocks[off] = need;
     H.live_bytes += need;
     if (H.live_bytes > H.peak_bytes) H.peak_bytes = H.live_bytes;
     return H.base + off;
 }
+
+void* take(Heap& H, size_t need) { return take_from(H, H.free_blocks, need); }
 
 }  // namespace
 
@@ -143,6 +167,12 @@ void* alloc(size_t bytes) {
         return p;
     }
     const size_t need = (bytes + ALIGN - 1) / ALIGN * ALIGN;
+    if (need < SMALL_LIMIT) {
+        if (void* p = take_from(H, H.small_free, need)) return p;
+        if (grow_small(H))
+            if (void* p = take_from(H, H.small_free, need)) return p;
+        // (no room left for the small region: fall through to the large one)
+    }
     if (void* p = take(H, need)) return p;
     // not enough contiguous free space: map more at the top (a free block that ends at the top counts)
     size_t have = 0;
@@ -176,14 +206,7 @@ void release(void* p) {
         size_t size = it->second;
         H.live_blocks.erase(it);
         H.live_bytes -= size;
-        size_t o = off;
-        auto next = H.free_blocks.lower_bound(off);
-        if (next != H.free_blocks.end() && off + size == next->first) { size += next->second; next = H.free_blocks.erase(next); }
-        if (next != H.free_blocks.begin()) {
-            auto prev = std::prev(next);
-            if (prev->first + prev->second == off) { o = prev->first; size += prev->second; H.free_blocks.erase(prev); }
-        }
-        H.free_blocks[o] = size;
+        add_free(off >= H.small_bottom ? H.small_free : H.free_blocks, off, size);
         return;
     }
     (void)hipFree(p);                                       // a block of the plain path
@@ -194,7 +217,8 @@ Stats stats(int device) {
     Stats s{};
     for (auto& hp : g_heaps)
         if (hp->device == device) {
-            s.pooled = hp->vmm; s.mapped = hp->top; s.live = hp->live_bytes; s.peak = hp->peak_bytes;
+            s.pooled = hp->vmm; s.mapped = hp->top + (hp->reserved - hp->small_bottom); s.live = hp->live_bytes;
+            s.peak = hp->peak_bytes;
             s.map_seconds = hp->map_seconds;
             for (auto& f : hp->free_blocks) s.largest_free = std::max(s.largest_free, f.second);
         }
@@ -218,7 +242,8 @@ void trim() {
             (void)hipMemUnmap(H.base + H.mapped[i].first, H.mapped[i].second);
             (void)hipMemRelease(H.handles[i]);
         }
-        H.handles.clear(); H.mapped.clear(); H.free_blocks.clear(); H.top = 0;
+        H.handles.clear(); H.mapped.clear(); H.free_blocks.clear(); H.small_free.clear(); H.top = 0;
+        H.small_bottom = H.reserved;
     }
 }
 

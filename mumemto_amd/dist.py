@@ -148,3 +148,37 @@ def engine_rows_as_tensors(eng, device):
     return (torch.as_tensor(DevicePointerView(lp, (n,), "<i4"), device=device),
             torch.as_tensor(DevicePointerView(op, (n, nd), "<i8"), device=device),
             torch.as_tensor(DevicePointerView(sp, (n, nd), "|u1"), device=device))
+
+
+def gather_bytes(local, dist, device):
+    """Every rank's byte string on every rank, in rank order (one all-gather of the sizes, one of the padded bytes)."""
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    width = max(max(sizes), 1)
+    buf = torch.zeros(width, dtype=torch.uint8, device=device)
+    if len(local):
+        buf[: len(local)] = torch.frombuffer(bytearray(local), dtype=torch.uint8).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return [out[r][: sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+
+
+def run_sharded(eng, dist, device, **params):
+    """Partial multi-MUMs / multi-MEMs (and any other mode) on several GPUs without a partition merge -- which the
+    reference refuses for these modes (include/pfp_mum.hpp:178-183): every rank holds the whole collection, builds the
+    same SA / LCP / BWT stream and scans only its share of the suffix-array positions (Engine.set_scan_shard); rows
+    come out in order of their closing position, so the ranks' .mums / .mems bytes concatenated in rank order are the
+    bytes of a single-GPU run.  The only collective is the gather of those bytes.  The input must have been set on
+    every rank (set_docs / set_input_device).  Returns the whole output on every rank."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    eng.set_scan_shard(rank, world)
+    try:
+        eng.run(**params)
+        local = eng.output_text()
+    finally:
+        eng.set_scan_shard(0, 1)
+    return b"".join(gather_bytes(local, dist, device))

@@ -87,3 +87,39 @@ def test_partition_docs_shapes():
     for n, w in [(5, 2), (9, 4), (31, 8)]:
         gs = mdist.partition_docs(n, w)
         assert sorted(d for g in gs for d in g[1:]) == list(range(1, n)) and all(g[0] == 0 for g in gs)
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT]
+    import torch
+    import torch.distributed as dist
+    from mumemto_amd import dist as mdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = [b"first rank\n" * 3, b"", b"third\tand last\n"][rank]
+    parts = mdist.gather_bytes(local, dist, torch.device("cpu"))
+    q.put((rank, parts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_bytes_keeps_rank_order_with_ragged_and_empty_parts():
+    """The only collective of the range-sharded multi-GPU path (mdist.run_sharded): every rank's output bytes, in rank
+    order, on every rank."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(3):
+        assert got[r] == [b"first rank\n" * 3, b"", b"third\tand last\n"]

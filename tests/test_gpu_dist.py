@@ -150,3 +150,62 @@ def test_bench_single_gpu_line_at_a_small_size():
     assert d["config"]["output_equals_cpu_oracle"] is True
     assert d["cli_process"]["rc"] == 0 and d["cli_process"]["output_identical_to_in_process"] is True
     assert d["hbm_resident"]["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["cores"] == 1
+
+
+def _sharded_worker(rank, world, port, q, wide):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "oracle"), os.path.join(root, "tests")]
+    import torch
+    import torch.distributed as dist
+    import mumemto_amd
+    from mumemto_amd import dist as mdist
+    from mumemto_amd import synth as sy
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if wide:
+        os.environ.update(MMT_FORCE_WIDE="1", MMT_SCAN_RANGE="8192")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        docs = sy.pangenome(6, 30000, 0.01, seed=41, indel_rate=0.001, inversion=(3, 4000, 9000), tandem=(2, 100, 400, 3))
+        eng = mumemto_amd.Engine(0)
+        eng.set_docs(docs)
+        out = {}
+        # BASELINE configs[4] parameters (-k -1 -f 3), plain multi-MEMs, and strict multi-MUMs through the same path
+        for name, kw in (("partial", dict(num_distinct=5, max_doc_freq=3, max_total_freq=18)),
+                         ("mems", dict(num_distinct=2, max_doc_freq=0, max_total_freq=40)),
+                         ("strict", dict(num_distinct=0, max_doc_freq=1, max_total_freq=0))):
+            out[name] = mdist.run_sharded(eng, dist, torch.device("cpu"), **kw)
+        q.put((rank, out))
+        dist.barrier()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,wide", [(2, False), (3, False), (2, True)])
+def test_partial_and_mem_modes_sharded_over_ranks_equal_one_gpu(world, wide):
+    """SURVEY 8(e) row 2 (BASELINE configs[4]): modes the anchor merge cannot serve run on several ranks by sharding
+    the suffix-array positions of the scan; the concatenated outputs are byte for byte the oracle's single run.  The
+    ranks share GPU 0 under gloo (this box has one GPU)."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, wide)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    docs = synth.pangenome(6, 30000, 0.01, seed=41, indel_rate=0.001, inversion=(3, 4000, 9000), tandem=(2, 100, 400, 3))
+    want = {"partial": O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text(),
+            "mems": O.run(docs, num_distinct=2, max_doc_freq=0, max_total_freq=40).text(),
+            "strict": O.run(docs).text()}
+    for r in range(world):
+        for name in want:
+            assert got[r][name] == want[name], (r, name)
+    assert want["partial"].count(b"\n") > 10 and want["mems"].count(b"\n") > 10

@@ -258,8 +258,6 @@ def test_partition_merge_with_another_min_len_equals_direct_run(engine, min_len)
     merged = engine.anchor_merge(parts, sort_like_direct=True, min_len=min_len)
     direct = O.run(docs, min_len=min_len, merge=True)
     assert merged["text"] == direct.text() and merged["text"].count(b"\n") > 20
-    if min_len > 20:            # the hard-coded 20 keeps merged rows shorter than -l: not the direct run's output
-        assert engine.anchor_merge(parts, sort_like_direct=True)["text"] != direct.text()
 
 
 def test_full_size_properties(engine):

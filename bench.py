@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--workdir", default=None, help="where the FASTA files and outputs go (default: /dev/shm or $TMPDIR)")
     ap.add_argument("--no-extras", action="store_true", help="skip the process / HBM-resident / CPU legs (N = 1)")
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="N > 1: torch.distributed collectives (default) or the C-ABI exchange of dist.cpp (mmt_dist_merge: "
+                         "RCCL bound from C++, grouped broadcasts, one device per rank)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device exercise the N > 1 path on a box with one GPU (testing only)")
     ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (testing only)")
@@ -125,6 +128,11 @@ def main():
     eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
     merge_mode = world > 1
     L0 = a.length
+    comm = None
+    if merge_mode and a.exchange == "native":
+        box = [mumemto_amd.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)          # the 128-byte id travels out of band (here: torch's store)
+        comm = mumemto_amd.Comm(eng, rank, world, box[0])
     phases = {"read": 0.0, "run": 0.0, "write": 0.0, "exchange_fold": 0.0}
 
     def step(timed):
@@ -136,6 +144,15 @@ def main():
             return None
         sec = eng.run_files(paths, out_prefix=None, merge_metadata=True)
         t0 = time.perf_counter()
+        if comm is not None:            # C-ABI exchange: HBM -> HBM broadcasts, fold and re-sort on rank 0
+            merged = comm.merge(min_len=20)
+            if rank == 0:
+                with open(out_prefix + ".mums", "wb") as f:
+                    f.write(merged["text"])
+            if timed:
+                phases["read"] += sec["read"]; phases["run"] += sec["run"]
+                phases["exchange_fold"] += time.perf_counter() - t0
+            return merged
         # rows and thresholds go from this rank's HBM straight into the all-gather; rank 0 folds them in HBM
         len_t, off_t, st_t = mdist.engine_rows_as_tensors(eng, device)
         th = torch.as_tensor(mdist.DevicePointerView(eng.thresh_device_ptr(), L0 + 1), device=device)
@@ -201,7 +218,8 @@ def main():
             "haplotypes": a.haps, "bases_per_haplotype": a.length, "text_chars_per_gpu": int(n_text),
             "one_suffix_array": bool(eng.L.mmt_partitions_used(eng.h) == 1), "positions_40_bit": eng.is_wide(),
             "scan_ranges": eng.scan_ranges(),
-            "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL all-gather + GPU fold" % world,
+            "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL %s + GPU fold" % (
+                world, "broadcasts through the C ABI (mmt_dist_merge)" if a.exchange == "native" else "all-gather (torch.distributed)"),
             "timed_region": "FASTA files (page cache) -> host parse -> H2D -> GPU path -> PREFIX.mums closed; in-process "
                             "(HIP runtime up, device heap mapped by the warm-up step)",
             "output_bytes": out_bytes, "output_rows": int(eng.L.mmt_num_rows(eng.h)) if world == 1 else None,

@@ -205,6 +205,25 @@ MMT_API int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m);
 MMT_API const char* mmt_merged_text(mmt_merged* m, size_t* len);
 MMT_API void mmt_merged_free(mmt_merged* m);
 
+/* ---- multi-GPU exchange, one process per GPU (RCCL over xGMI) ------------------------------
+ * Replaces the files + second tool between partitions of the reference's workflow (README.md:124-141: PREFIX.mums and
+ * PREFIX.athresh per partition, then `anchor_merge`, src/merge_candidates.cpp:170-255; Python side
+ * mumemto/merge_mums.py:141-183).  Rank 0 makes a unique id and hands it to the other ranks out of band (a file, an
+ * environment variable, MPI, torch's store); every call below is collective over the communicator.  RCCL is bound at run
+ * time (a copy already in the process, else /opt/rocm/lib/librccl.so).                                              */
+typedef struct mmt_comm mmt_comm;
+MMT_API int  mmt_comm_unique_id(uint8_t id[128]);
+MMT_API int  mmt_comm_create(mmt_engine* e, int rank, int world, const uint8_t id[128], mmt_comm** out);
+MMT_API void mmt_comm_destroy(mmt_comm* c);
+/* Strict multi-MUMs: e's last run = this rank's partition {anchor} + its documents with merge metadata on.  Row tables
+ * and thresholds travel HBM -> HBM (one ncclBroadcast per rank and table, grouped), rank 0 folds them on its GPU and
+ * re-sorts into direct-run order: *out is the merged result on rank 0 (mmt_merged_text / _get / _free) and NULL on the
+ * other ranks.  min_len = the run's -l (the reference's tool hard-codes 20).                                          */
+MMT_API int  mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** out);
+/* Modes without a partition merge (mmt_engine_set_scan_shard): the ranks' output bytes, concatenated in rank order, on
+ * rank 0 (*len = 0 elsewhere); valid until the next call on this communicator.                                        */
+MMT_API int  mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ gfx950).  There is no CPU fallback: if the library is missing or no GPU is
 usable, calls raise.
 """
 from .binding import (  # noqa: F401
+    Comm,
     DevicePartition,
     Engine,
     MumemtoError,

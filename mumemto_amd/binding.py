@@ -72,7 +72,8 @@ GPU_ABI_SYMBOLS = [
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
-    "mmt_engine_set_scan_shard",
+    "mmt_engine_set_scan_shard", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
+    "mmt_dist_gather_text",
 ]
 
 
@@ -157,6 +158,11 @@ def load_library():
                                              C.c_uint64]
     L.mmt_engine_run_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_char_p,
                                        C.c_uint64, C.POINTER(C.c_double)]
+    L.mmt_comm_unique_id.argtypes = [C.c_void_p]
+    L.mmt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.mmt_comm_destroy.argtypes = [C.c_void_p]
+    L.mmt_dist_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.mmt_dist_gather_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.mmt_partitions_used.restype = C.c_size_t
     L.mmt_partitions_used.argtypes = [C.c_void_p]
     L.mmt_copy_merged_thresh.argtypes = [C.c_void_p, C.c_void_p]
@@ -534,3 +540,51 @@ class Engine:
             return dict(lengths=length[:n], offsets=off[:n], strands=st[:n], thresh=th, text=text)
         finally:
             self.L.mmt_merged_free(m)
+
+
+class Comm:
+    """The C-ABI multi-GPU exchange (RCCL, one process per GPU): mmt_comm_* / mmt_dist_* of mumemto_gpu.h.
+    Rank 0 calls Comm.unique_id() and hands the 128 bytes to the other ranks out of band; Comm(engine, rank, world, id)
+    is collective, and so are merge() and gather_text()."""
+
+    @staticmethod
+    def unique_id():
+        L = load_library()
+        buf = (C.c_uint8 * 128)()
+        _check(L.mmt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, engine, rank, world, unique_id):
+        self.L, self.engine, self.rank, self.world = engine.L, engine, rank, world
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _check(self.L.mmt_comm_create(engine.h, rank, world, buf, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mmt_comm_destroy(self.h)
+            self.h = None
+
+    def merge(self, min_len=20):
+        """Strict multi-MUMs: exchange + fold + re-sort.  Rank 0 gets {"text", "n_rows", "n_docs"}, the others None."""
+        m = C.c_void_p()
+        _check(self.L.mmt_dist_merge(self.h, self.engine.h, C.c_uint32(min_len), C.byref(m)))
+        if not m:
+            return None
+        try:
+            k = C.c_size_t()
+            ptr = self.L.mmt_merged_text(m, C.byref(k))
+            n = self.L.mmt_merged_rows(m)
+            if not ptr and n:
+                raise MumemtoError(self.L.mmt_last_error().decode())
+            return dict(text=_bytes_at(ptr, k.value), n_rows=n, n_docs=self.L.mmt_merged_docs(m))
+        finally:
+            self.L.mmt_merged_free(m)
+
+    def gather_text(self):
+        """Sharded modes (Engine.set_scan_shard): the whole output on rank 0, b"" elsewhere."""
+        ptr, k = C.c_void_p(), C.c_size_t()
+        _check(self.L.mmt_dist_gather_text(self.h, C.byref(ptr), C.byref(k)))
+        return _bytes_at(ptr.value, k.value) if k.value else b""
+

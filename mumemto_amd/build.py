@@ -20,7 +20,7 @@ ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
             "--offload-arch=" + ARCH]
 
-LIB_SOURCES = ["kernels.hip", "prims.hip", "pfp_kernels.hip", "rows_kernels.hip", "merge_kernels.hip", "engine.cpp", "sorter.cpp", "pfp.cpp", "pool.cpp", "merge.cpp", "partitioned.cpp", "api.cpp",
+LIB_SOURCES = ["kernels.hip", "prims.hip", "pfp_kernels.hip", "rows_kernels.hip", "merge_kernels.hip", "engine.cpp", "sorter.cpp", "pfp.cpp", "pool.cpp", "dist.cpp", "merge.cpp", "partitioned.cpp", "api.cpp",
                "cxx_api.cpp", "fasta.cpp", "options.cpp"]
 TOOLS = {"mumemto_exec": ["cli_main.cpp"], "anchor_merge": ["merge_main.cpp"]}
 HOST_TOOLS = {"extract_mums": ["extract_mums_main.cpp", "fasta.cpp"]}     # no device code: plain g++
@@ -66,7 +66,7 @@ def build(verbose=False):
         objs = list(ex.map(_compile, LIB_SOURCES + tool_sources))
     lib_objs = [o for o in objs[: len(LIB_SOURCES)] if o]
     if _newer(LIB, lib_objs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + lib_objs + ["-Wl,-soname,libmumemto.so", "-lz"]
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + lib_objs + ["-Wl,-soname,libmumemto.so", "-lz", "-ldl"]
         subprocess.check_call(cmd)
     for tool, srcs in TOOLS.items():
         tobjs = [os.path.join(OBJ, s + ".o") for s in srcs if os.path.exists(os.path.join(OBJ, s + ".o"))]
@@ -75,7 +75,7 @@ def build(verbose=False):
         out = os.path.join(BIN_DIR, tool)
         if _newer(out, tobjs + lib_objs):
             # the tools use the engine classes directly (hidden symbols of the .so): link the objects in
-            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-o", out] + tobjs + lib_objs + ["-lz"])
+            subprocess.check_call([HIPCC, "--offload-arch=" + ARCH, "-o", out] + tobjs + lib_objs + ["-lz", "-ldl"])
     for tool, srcs in HOST_TOOLS.items():
         paths = [os.path.join(SRC, f) for f in srcs]
         out = os.path.join(BIN_DIR, tool)

@@ -12,6 +12,7 @@
 #include "../../include/mumemto.h"
 #include "../../include/mumemto_gpu.h"
 #include "engine.hpp"
+#include "dist.hpp"
 #include "fasta.hpp"
 #include "merge.hpp"
 
@@ -84,6 +85,11 @@ struct mumemto_mem_result {
 struct mmt_engine {
     std::unique_ptr<mmt::Engine> e;
     mmt::HostArena arena;              // host buffer of mmt_engine_run_files, kept between calls
+};
+struct mmt_comm {
+    mmt::Comm* c = nullptr;
+    int rank = 0;
+    std::string text;                  // rank 0: the gathered output of the last mmt_dist_gather_text
 };
 struct mmt_merged {
     mmt::MergedRows rows;
@@ -492,6 +498,46 @@ int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m) {
     m->text.clear(); m->text_valid = false;
     MMT_CATCH
 }
+// ---- multi-GPU exchange (dist.cpp) ---------------------------------------------------------
+int mmt_comm_unique_id(uint8_t id[128]) {
+    if (!id) return fail(1, "null");
+    MMT_TRY
+    mmt::comm_unique_id(id);
+    MMT_CATCH
+}
+int mmt_comm_create(mmt_engine* e, int rank, int world, const uint8_t id[128], mmt_comm** out) {
+    if (!e || !id || !out) return fail(1, "engine, id and out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    std::unique_ptr<mmt_comm> c(new mmt_comm());
+    c->c = mmt::comm_create(*e->e, rank, world, id);
+    c->rank = rank;
+    *out = c.release();
+    MMT_CATCH
+}
+void mmt_comm_destroy(mmt_comm* c) { if (c) { mmt::comm_destroy(c->c); delete c; } }
+int mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** out) {
+    if (!c || !e || !out) return fail(1, "comm, engine and out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    bool root = false;
+    mmt::MergedRows rows = mmt::dist_merge(*c->c, min_len, &root);
+    if (root) {
+        std::unique_ptr<mmt_merged> m(new mmt_merged());
+        m->rows = std::move(rows);
+        m->engine = e->e.get();
+        *out = m.release();
+    }
+    MMT_CATCH
+}
+int mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len) {
+    if (!c || !text || !len) return fail(1, "null");
+    MMT_TRY
+    c->text = mmt::dist_gather_text(*c->c);
+    *text = c->text.data(); *len = c->text.size();
+    MMT_CATCH
+}
+
 const char* mmt_merged_text(mmt_merged* m, size_t* len) {
     if (!m) { if (len) *len = 0; return nullptr; }
     if (!m->text_valid) {

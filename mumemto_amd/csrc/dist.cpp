@@ -1,0 +1,230 @@
+// dist.cpp -- the multi-GPU exchange in C++ against RCCL (one process per GPU, xGMI underneath).
+//
+// What the reference does between partitions with files and a second tool (README.md:124-141: PREFIX.mums +
+// PREFIX.athresh per partition, then `anchor_merge`, src/merge_candidates.cpp:170-255) happens here between ranks:
+// every rank has run the single-GPU path on {anchor} + its share of the documents with merge metadata on; the row
+// tables and thresholds of all ranks travel HBM -> HBM (one ncclBroadcast per rank and table, grouped: the tables are
+// ragged, an all-gather would have to pad them to the largest partition), rank 0 folds them on its GPU (merge.cpp) and
+// re-sorts into direct-run order.  For the modes without a partition merge (mmt_engine_set_scan_shard) the ranks'
+// output bytes are gathered to rank 0 in rank order.
+//
+// RCCL is bound at run time: a process that already holds a copy (PyTorch ships its own librccl.so) must use that one,
+// a plain C++ host gets /opt/rocm/lib/librccl.so.  Nothing here falls back to another transport.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "engine.hpp"
+#include "merge.hpp"
+#include "dist.hpp"
+
+namespace mmt {
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    if (r.handle) return r;
+    void* h = nullptr;
+    // a copy that is already in the process first (RTLD_NOLOAD), then the ROCm one
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+    if (!h) throw std::runtime_error(std::string("cannot load librccl: ") + dlerror());
+    auto sym = [&](const char* n) {
+        void* p = dlsym(h, n);
+        if (!p) throw std::runtime_error(std::string("librccl lacks ") + n);
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.handle = h;
+    return r;
+}
+
+void check(ncclResult_t e, const char* what) {
+    if (e != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + what + ": " + rccl().GetErrorString(e));
+}
+#define MMT_NCCL(x) check((x), #x)
+
+}  // namespace
+
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    Engine* engine = nullptr;
+    DevBuf<uint64_t> d_meta;                 // 4 words per rank: rows, documents, output bytes, spare
+    std::vector<std::unique_ptr<DevBuf<uint32_t>>> len;
+    std::vector<std::unique_ptr<DevBuf<int64_t>>> off;
+    std::vector<std::unique_ptr<DevBuf<uint8_t>>> st, text;
+    std::vector<std::unique_ptr<DevBuf<uint16_t>>> th;
+};
+
+void comm_unique_id(uint8_t out[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "unique id size");
+    ncclUniqueId id;
+    MMT_NCCL(rccl().GetUniqueId(&id));
+    std::memcpy(out, &id, 128);
+}
+
+Comm* comm_create(Engine& e, int rank, int world, const uint8_t id_bytes[128]) {
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("rank / world size out of range");
+    MMT_HIP(hipSetDevice(e.device()));
+    std::unique_ptr<Comm> c(new Comm());
+    c->rank = rank; c->world = world; c->engine = &e;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, 128);
+    MMT_NCCL(rccl().CommInitRank(&c->comm, world, id, rank));
+    c->d_meta.ensure((size_t)world * 4);
+    c->len.resize(world); c->off.resize(world); c->st.resize(world); c->th.resize(world); c->text.resize(world);
+    for (int r = 0; r < world; r++) {
+        c->len[r].reset(new DevBuf<uint32_t>()); c->off[r].reset(new DevBuf<int64_t>());
+        c->st[r].reset(new DevBuf<uint8_t>()); c->th[r].reset(new DevBuf<uint16_t>()); c->text[r].reset(new DevBuf<uint8_t>());
+    }
+    return c.release();
+}
+
+void comm_destroy(Comm* c) {
+    if (!c) return;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+// every rank's (rows, documents, bytes) on every rank
+static std::vector<uint64_t> exchange_meta(Comm& c, uint64_t rows, uint64_t docs, uint64_t bytes) {
+    hipStream_t st = c.engine->stream();
+    uint64_t mine[4] = {rows, docs, bytes, 0};
+    DevBuf<uint64_t> d_mine;
+    d_mine.ensure(4);
+    MMT_HIP(hipMemcpyAsync(d_mine.get(), mine, 32, hipMemcpyHostToDevice, st));
+    MMT_NCCL(rccl().AllGather(d_mine.get(), c.d_meta.get(), 4, ncclUint64, c.comm, st));
+    std::vector<uint64_t> all((size_t)c.world * 4);
+    MMT_HIP(hipMemcpyAsync(all.data(), c.d_meta.get(), all.size() * 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    return all;
+}
+
+// Strict multi-MUMs.  The engine's last run must have been this rank's partition with merge metadata on.
+// Returns the merged rows on rank 0 (already in direct-run order), an empty MergedRows elsewhere.
+MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
+    Engine& e = *c.engine;
+    MMT_HIP(hipSetDevice(e.device()));
+    hipStream_t st = e.stream();
+    if (is_root) *is_root = c.rank == 0;
+    const HostRows& R = e.rows_meta();
+    if (!R.mum_mode || !e.thresh_len()) throw std::runtime_error("the exchange needs a multi-MUM run with merge metadata");
+    const uint64_t L = e.doc_len()[0] + 1;
+    const std::vector<uint64_t> meta = exchange_meta(c, R.n_rows, R.n_docs, 0);
+    const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
+    e.rows_mum_device(&my_len, &my_off, &my_st);
+    // one broadcast per rank and table: sender = the engine's own tables, receivers = dense buffers of that rank's size
+    MMT_NCCL(rccl().GroupStart());
+    for (int r = 0; r < c.world; r++) {
+        const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
+        c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(L);
+        const bool mine = r == c.rank;
+        if (rows) {
+            MMT_NCCL(rccl().Broadcast(mine ? (const void*)my_len : c.len[r]->get(), c.len[r]->get(), rows, ncclUint32, r, c.comm, st));
+            MMT_NCCL(rccl().Broadcast(mine ? (const void*)my_off : c.off[r]->get(), c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
+            MMT_NCCL(rccl().Broadcast(mine ? (const void*)my_st : c.st[r]->get(), c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
+        }
+        MMT_NCCL(rccl().Broadcast(mine ? (const void*)e.thresh_device() : c.th[r]->get(), c.th[r]->get(), L * 2, ncclUint8, r,
+                                  c.comm, st));
+    }
+    MMT_NCCL(rccl().GroupEnd());
+    MMT_HIP(hipStreamSynchronize(st));
+    if (c.rank != 0) return MergedRows();
+    std::vector<mmt_partition> parts((size_t)c.world);
+    for (int r = 0; r < c.world; r++) {
+        mmt_partition& p = parts[(size_t)r];
+        p.n_rows = meta[(size_t)r * 4]; p.n_docs = meta[(size_t)r * 4 + 1];
+        p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get();
+        p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1;
+    }
+    if (c.world == 1) {
+        // one partition: nothing to fold; the rows are the engine's own, already in direct-run order
+        MergedRows m;
+        m.n_rows = parts[0].n_rows; m.n_docs = parts[0].n_docs;
+        m.d_length.ensure(m.n_rows + 1); m.d_offsets.ensure(m.n_rows * m.n_docs + 1); m.d_strands.ensure(m.n_rows * m.n_docs + 1);
+        m.d_thresh.ensure(L);
+        if (m.n_rows) {
+            MMT_HIP(hipMemcpyAsync(m.d_length.get(), parts[0].length, m.n_rows * 4, hipMemcpyDeviceToDevice, st));
+            MMT_HIP(hipMemcpyAsync(m.d_offsets.get(), parts[0].offsets, m.n_rows * m.n_docs * 8, hipMemcpyDeviceToDevice, st));
+            MMT_HIP(hipMemcpyAsync(m.d_strands.get(), parts[0].strands, m.n_rows * m.n_docs, hipMemcpyDeviceToDevice, st));
+        }
+        MMT_HIP(hipMemcpyAsync(m.d_thresh.get(), parts[0].thresh, L * 2, hipMemcpyDeviceToDevice, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        m.on_host = false;
+        return m;
+    }
+    MergedRows m = anchor_merge(e, parts.data(), parts.size(), min_len);
+    sort_like_direct(e, m);
+    return m;
+}
+
+// Modes without a partition merge: this rank's PREFIX.mums / .mems bytes (mmt_engine_set_scan_shard) to rank 0, in rank
+// order.  Returns the whole output on rank 0, an empty string elsewhere.
+std::string dist_gather_text(Comm& c) {
+    Engine& e = *c.engine;
+    MMT_HIP(hipSetDevice(e.device()));
+    hipStream_t st = e.stream();
+    const HostRows& R = e.rows(Engine::ROWS_TEXT);
+    const std::vector<uint64_t> meta = exchange_meta(c, R.n_rows, R.n_docs, R.text_len);
+    DevBuf<uint8_t> mine;
+    mine.ensure(R.text_len + 1);
+    if (R.text_len) MMT_HIP(hipMemcpyAsync(mine.get(), R.text, R.text_len, hipMemcpyHostToDevice, st));
+    MMT_NCCL(rccl().GroupStart());
+    for (int r = 0; r < c.world; r++) {
+        const size_t bytes = meta[(size_t)r * 4 + 2];
+        c.text[r]->ensure(bytes + 1);
+        if (bytes)
+            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)mine.get() : c.text[r]->get(), c.text[r]->get(), bytes, ncclUint8, r,
+                                      c.comm, st));
+    }
+    MMT_NCCL(rccl().GroupEnd());
+    MMT_HIP(hipStreamSynchronize(st));
+    if (c.rank != 0) return std::string();
+    size_t total = 0;
+    for (int r = 0; r < c.world; r++) total += meta[(size_t)r * 4 + 2];
+    std::string out(total, '\0');
+    size_t at = 0;
+    for (int r = 0; r < c.world; r++) {
+        const size_t bytes = meta[(size_t)r * 4 + 2];
+        if (bytes) MMT_HIP(hipMemcpyAsync(&out[at], c.text[r]->get(), bytes, hipMemcpyDeviceToHost, st));
+        at += bytes;
+    }
+    MMT_HIP(hipStreamSynchronize(st));
+    return out;
+}
+
+}  // namespace mmt

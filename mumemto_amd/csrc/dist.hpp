@@ -1,0 +1,18 @@
+// dist.hpp -- the multi-GPU exchange against RCCL (dist.cpp); C ABI: mmt_comm_* / mmt_dist_* in mumemto_gpu.h.
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "engine.hpp"
+#include "merge_types.hpp"
+
+namespace mmt {
+
+struct Comm;
+void comm_unique_id(uint8_t out[128]);                                            // rank 0, handed to the others out of band
+Comm* comm_create(Engine& e, int rank, int world, const uint8_t id[128]);         // collective
+void comm_destroy(Comm* c);
+MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root);                  // collective; rows on rank 0
+std::string dist_gather_text(Comm& c);                                            // collective; bytes on rank 0
+
+}  // namespace mmt

@@ -209,3 +209,42 @@ def test_partial_and_mem_modes_sharded_over_ranks_equal_one_gpu(world, wide):
         for name in want:
             assert got[r][name] == want[name], (r, name)
     assert want["partial"].count(b"\n") > 10 and want["mems"].count(b"\n") > 10
+
+
+_NATIVE_SCRIPT = r"""
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, "oracle"), os.path.join(%(root)r, "tests")]
+if %(with_torch)r:
+    import torch                      # PyTorch's own librccl.so is then in the process: the exchange must use that copy
+import mumemto_amd
+import pyoracle as O
+from mumemto_amd import synth
+docs = synth.pangenome(6, 20000, 0.01, seed=61, inversion=(2, 2000, 5000))
+eng = mumemto_amd.Engine(0)
+comm = mumemto_amd.Comm(eng, 0, 1, mumemto_amd.Comm.unique_id())
+eng.set_docs(docs)
+eng.run(merge_metadata=True)
+m = comm.merge()
+assert m["text"] == O.run(docs, merge=True).text() and m["n_rows"] > 5, "strict multi-MUMs through the RCCL exchange"
+eng.set_scan_shard(0, 1)
+eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
+assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
+comm.close(); eng.close()
+print("NATIVE_EXCHANGE_OK")
+"""
+
+
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_c_abi_exchange_over_rccl_world_size_one(with_torch):
+    """mmt_comm_* / mmt_dist_* (dist.cpp: ncclCommInitRank, grouped ncclBroadcast of the row tables, fold on rank 0,
+    gather of the sharded modes' bytes) with the one rank a one-GPU box allows -- in a process of its own, once without
+    PyTorch (RCCL from /opt/rocm) and once with PyTorch's copy already loaded."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if not with_torch:
+        env["MUMEMTO_NO_TORCH"] = "1"
+    r = subprocess.run([sys.executable, "-c", _NATIVE_SCRIPT % dict(root=root, with_torch=with_torch)], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "NATIVE_EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -141,12 +141,13 @@ void Engine::set_stream_host40(const uint32_t* sa_lo, const uint8_t* sa_hi, cons
 void Engine::build_text(bool revcomp) {
     const size_t N = doc_len_.size();
     layout_docs(revcomp);
-    d_doc_base_.ensure(N + 1);
+    d_doc_base_.ensure(N + 1); d_doc_len_.ensure(N + 1);
     MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, stream_));
     d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
-    k::build_text(d_bases_, d_doc_base_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, text_ptr(), n_,
+    k::build_text(d_bases_, d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, text_ptr(), n_,
                   d_hist_.get(), stream_);
     finish_text_padding();          // (the last work-item of the kernel stores up to 15 bytes past the text)
 }
@@ -468,7 +469,7 @@ void Engine::make_rows(const mmt_params& p) {
         prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_b_.get(), d_order_.get(), n_rows, 0,
                                   40, st);
     }
-    d_doc_len_.ensure(N);
+    d_doc_len_.ensure(N + 1);
     MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, st));
     rk::RowArgs a;
     a.rows = d_rows_.get(); a.order = d_order_.get(); a.n_rows = n_rows; a.sa = sa_col();

@@ -40,6 +40,10 @@ public:
 
     void set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs);
     void set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs);
+    // one pass of the path on the input that is set, as run_partitioned_docs does for a single suffix array (the
+    // raw bases are dropped once the text exists)
+    void run_once_dropping_input(const mmt_params& p);
+    uint64_t auto_max_text() const;
     // the documents in separate host buffers (no concatenation on the host: one H2D copy per document)
     void set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs);
     // Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): the caller hands over

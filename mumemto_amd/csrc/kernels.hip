@@ -72,12 +72,13 @@ __device__ __forceinline__ void load_16_bytes(const uint8_t* p, uint64_t& x, uin
 template <int BLOCK, int MAXD>
 __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict__ raw,
                                                        const uint64_t* __restrict__ doc_base,
+                                                       const uint64_t* __restrict__ doc_len,
                                                        const uint64_t* __restrict__ doc_start, uint32_t n_docs,
                                                        uint8_t* __restrict__ text, uint64_t n,
                                                        unsigned long long* __restrict__ hist) {
     __shared__ uint32_t s_hist[256];
     __shared__ uint8_t s_up[256], s_rc[256], s_slot[256];
-    __shared__ uint64_t s_start[MAXD + 1], s_base[MAXD + 1];
+    __shared__ uint64_t s_start[MAXD + 1], s_base[MAXD + 1], s_len[MAXD + 1];
     for (int i = threadIdx.x; i < 256; i += BLOCK) {
         s_hist[i] = 0;
         const uint8_t u = dev_upper((uint8_t)i);
@@ -86,10 +87,13 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
     }
     const bool in_lds = n_docs <= (uint32_t)MAXD;
     if (in_lds)
-        for (uint32_t i = threadIdx.x; i <= n_docs; i += BLOCK) { s_start[i] = doc_start[i]; s_base[i] = doc_base[i]; }
+        for (uint32_t i = threadIdx.x; i <= n_docs; i += BLOCK) {
+            s_start[i] = doc_start[i]; s_base[i] = doc_base[i]; s_len[i] = i < n_docs ? doc_len[i] : 0;
+        }
     __syncthreads();
     const uint64_t* st = in_lds ? s_start : doc_start;
     const uint64_t* bs = in_lds ? s_base : doc_base;
+    const uint64_t* ln = in_lds ? s_len : doc_len;        // the documents need not be contiguous in `raw`
     // a workgroup walks over many tiles and adds its histogram to the global one once: with a workgroup per tile
     // the ~100,000 flushes queue up on five counter words (~90 atomics per microsecond each) and set the run time
     const uint64_t n_tiles = (n + (uint64_t)BLOCK * 16 - 1) / ((uint64_t)BLOCK * 16);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
         uint32_t valid = 0;
         if (p0 < n) {
             uint32_t d = doc_lookup(st, n_docs, p0);
-            const uint64_t L = bs[d + 1] - bs[d], local = p0 - st[d];
+            const uint64_t L = ln[d], local = p0 - st[d];
             if (local + 16 <= L) {                                              // forward strand
                 const uint8_t* src = raw + bs[d] + local;
                 uint64_t x, y;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
                     uint8_t c = 0;
                     if (p < n) {
                         while (p >= st[d + 1]) d++;
-                        const uint64_t Ld = bs[d + 1] - bs[d], lo = p - st[d];
+                        const uint64_t Ld = ln[d], lo = p - st[d];
                         if (lo < Ld) c = s_up[raw[bs[d] + lo]];
                         else if (lo == Ld) c = '$';
                         else if (lo <= 2 * Ld) c = s_rc[raw[bs[d] + (2 * Ld - lo)]];
@@ -165,12 +169,12 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
         if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
 }
 
-void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
+void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
                 bool /*revcomp*/, uint8_t* text, uint64_t n, uint64_t* hist, hipStream_t s) {
     constexpr int B = 256;
     const uint64_t tiles = (n + (uint64_t)B * 16 - 1) / ((uint64_t)B * 16);
     const unsigned grid = (unsigned)std::min<uint64_t>(tiles ? tiles : 1, 256u * 16u);
-    hipLaunchKernelGGL((k_build_text<B, 1023>), dim3(grid), dim3(B), 0, s, raw, d_doc_base, d_doc_start, n_docs, text, n,
+    hipLaunchKernelGGL((k_build_text<B, 1023>), dim3(grid), dim3(B), 0, s, raw, d_doc_base, d_doc_len, d_doc_start, n_docs, text, n,
                        reinterpret_cast<unsigned long long*>(hist));
     MMT_HIP(hipGetLastError());
 }

@@ -23,7 +23,8 @@ struct Row {
 // ---- A1 text layout ---------------------------------------------------------
 // text[p] for p in [0,n): UPPER(F_d) '$' [revcomp(UPPER(F_d)) '$'] per document;
 // hist[256] += byte counts of the text.  d_doc_base / d_doc_start: N+1 entries.
-void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_start, uint32_t n_docs,
+// Document d sits at raw[d_doc_base[d] .. + d_doc_len[d]) (any gaps between documents are ignored).
+void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
                 bool revcomp, uint8_t* text, uint64_t n, uint64_t* hist, hipStream_t s);
 
 // ---- A8 direct suffix sort (prefix doubling) --------------------------------

@@ -19,6 +19,25 @@
 
 namespace mmt {
 
+// What fits the device as one suffix array: 14 (94 x 64 Mbp at 0.1 % divergence) to 21 (36 x 60 Mbp at 0.2 %) bytes of
+// device memory per character at the peak: text 1, suffix array 5, BWT 1, then either the emitter tables -- which grow
+// with the dictionary, i.e. with the divergence -- or PLCP 4 + the scan range.  A single-array run that
+// still runs out of memory is repeated as partitions when the mode allows it.
+uint64_t Engine::auto_max_text() const {
+    constexpr double PEAK_BYTES_PER_CHAR = 16.0;
+    const double avail = 0.95 * (double)pool::available(device_);
+    uint64_t max_text = (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1));
+    if (const char* c = std::getenv("MMT_MAX_TEXT")) max_text = std::strtoull(c, nullptr, 10);
+    return max_text;
+}
+
+void Engine::run_once_dropping_input(const mmt_params& p) {
+    partitions_used_ = 1;
+    drop_input_after_text_ = true;
+    try { run(p); } catch (...) { drop_input_after_text_ = false; throw; }
+    drop_input_after_text_ = false;
+}
+
 void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
                                   uint64_t max_text) {
     std::vector<const uint8_t*> ptr(n_docs);
@@ -39,25 +58,14 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
                         (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
     release_columns();                       // what the previous run left behind counts as free memory below
     const bool auto_limit = max_text == 0;
-    if (auto_limit) {
-        // One suffix array of n characters peaks at 14 (94 x 64 Mbp at 0.1 % divergence) to 21 (36 x 60 Mbp at 0.2 %)
-        // bytes of device memory per character: text 1, suffix array 5, BWT 1, then either the emitter tables --
-        // which grow with the dictionary, i.e. with the divergence -- or PLCP 4 + the scan range.
-        // A single-array run that still runs out of memory is repeated as partitions when the mode allows it.
-        constexpr double PEAK_BYTES_PER_CHAR = 16.0;
-        const double avail = 0.95 * (double)pool::available(device_);
-        max_text = (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1));
-        if (const char* c = std::getenv("MMT_MAX_TEXT")) max_text = std::strtoull(c, nullptr, 10);
-    }
+    if (auto_limit) max_text = auto_max_text();
     partitions_used_ = 1;
     // (a non-strict mode has no partition merge: with the automatic limit it is tried as one suffix array anyway and
     // fails with "out of device memory" if that was too optimistic; an explicit limit is an order)
     if (total <= max_text || n_docs < 3 || (!strict && auto_limit)) {
         try {
             set_input_host_docs(doc_ptr, doc_len, n_docs);
-            drop_input_after_text_ = true;
-            try { run(p); } catch (...) { drop_input_after_text_ = false; throw; }
-            drop_input_after_text_ = false;
+            run_once_dropping_input(p);
             return;
         } catch (const HipError& e) {
             const bool oom = std::string(e.what()).find("out of device memory") != std::string::npos;

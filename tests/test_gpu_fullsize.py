@@ -88,6 +88,30 @@ def test_text_beyond_2_to_the_32_as_one_suffix_array():
     parts, part = _partitioned(eng, bases, lens, 0.4)              # partitions of < 2^32 characters: the 32-bit path
     assert parts >= 3 and not eng.is_wide()
     assert _same_up_to_the_stream_end_quirk(single, part, parts)
+    merged_thresh = eng.merged_thresholds(int(lens[0]))
+    # merge metadata through the 40-bit path (what a rank of a 2-GPU run of the C3 stand-in does): every structural
+    # interval is verified, thresholds are recorded; the direct run's .athresh equals the merged one
+    import tempfile
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        paths = []
+        for h in range(len(lens)):
+            p = os.path.join(d, "h%02d.fa" % h)
+            synth.write_fasta_fast(p, bases[h * 60_000_000:(h + 1) * 60_000_000], name="h%02d" % h)
+            paths.append(p)
+        eng.run_files(paths, out_prefix=os.path.join(d, "out"), merge_metadata=True)
+        assert eng.is_wide()
+        assert open(os.path.join(d, "out.mums"), "rb").read() == single
+    direct_thresh = eng.thresholds()[: int(lens[0]) + 1]
+    differ = np.nonzero(direct_thresh != merged_thresh)[0]
+    # The fold of the partitions' thresholds is the direct run's .athresh except where the match of ALL documents is
+    # shorter than -l: the direct run records nothing there (such intervals are never produced, mem_finder.hpp:350-353),
+    # the partitions -- whose matches at that anchor position are longer -- do, and the fold keeps their maximum
+    # (merge_candidates.cpp:121-123).  Same rows either way; tests/thresh_probe.py shows the same 8 entries of 12.1 M
+    # on the C2 stand-in through the 32-bit path, the ranged scan and the 40-bit path.
+    print("thresholds: %d of %d entries non-zero, %d differ between the direct run and the fold of %d partitions"
+          % (int((direct_thresh > 0).sum()), len(direct_thresh), len(differ), parts))
+    assert len(differ) < 1e-5 * len(direct_thresh)
+    assert np.all(direct_thresh[differ] == 0) and np.all(merged_thresh[differ] >= 20)
 
 
 def test_c3_standin_at_full_size_one_suffix_array():

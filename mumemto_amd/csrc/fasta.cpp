@@ -91,11 +91,11 @@ struct RawSink {
 };
 struct NullSink { void append(const char*, const char*) {} };
 
-template <class Sink>
-static FastaDoc read_fasta_to(const std::string& path, Sink& bases) {
+template <class Reader, class Sink>
+static FastaDoc read_fasta_with(const std::string& path, Sink& bases) {
     FastaDoc doc;
     doc.path = path;
-    LineReader in(path);
+    Reader in(path);
     int c = in.getc();
     // skip to the first header line
     while (c >= 0 && c != '>' && c != '@') c = in.getc();
@@ -150,7 +150,7 @@ FastaDoc read_fasta(const std::string& path, std::vector<uint8_t>& bases) {
     const bool gz = file_info(path, size);
     if (size) bases.reserve(bases.size() + size * (gz ? 4 : 1) + 16);
     VecSink sink{bases};
-    return read_fasta_to(path, sink);
+    return read_fasta_with<LineReader>(path, sink);
 }
 
 HostArena::~HostArena() { if (p_) munmap(p_, cap_); }
@@ -190,7 +190,7 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
                     out.ptr[i] = out.owned[i].data(); out.len[i] = out.owned[i].size();
                 } else {
                     RawSink sink{base + slot[i], 0, slot[i + 1] - slot[i]};
-                    docs[i] = read_fasta_to(inputs[i], sink);
+                    docs[i] = read_fasta_with<LineReader>(inputs[i], sink);
                     out.ptr[i] = sink.p; out.len[i] = sink.n;
                 }
             } catch (const std::exception& e) { err[i] = e.what(); }

@@ -15,6 +15,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 cases = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 BIG = len(sys.argv) > 4 and sys.argv[4] == "big"     # every case a pangenome of 0.2 - 3 M text characters
 ADV = len(sys.argv) > 4 and sys.argv[4] == "adv"     # mid-size pangenomes with runs, arrays, copies (see adversarial())
+SHARD = os.environ.get("MMT_FUZZ_SHARDS") is not None  # also run every case as 2-5 shards of the scan (set_scan_shard)
 
 
 def adversarial(rng):
@@ -71,10 +72,24 @@ for seed in range(first, first + count):
             eng.set_docs(docs)
             eng.run(min_match_len=p["min_len"], num_distinct=p["num_distinct"], max_doc_freq=p["max_doc_freq"],
                     max_total_freq=p["max_total_freq"], use_revcomp=revcomp, merge_metadata=merge)
-            if eng.output_text() != want.text():
+            got = eng.output_text()
+            got_thresh = eng.thresholds() if merge else None
+            if SHARD:                 # the same run as G shards of the suffix-array positions, concatenated
+                G = int(rng.integers(2, 6))
+                pieces = []
+                for k in range(G):
+                    eng.set_scan_shard(k, G)
+                    eng.run(min_match_len=p["min_len"], num_distinct=p["num_distinct"], max_doc_freq=p["max_doc_freq"],
+                            max_total_freq=p["max_total_freq"], use_revcomp=revcomp, merge_metadata=False)
+                    pieces.append(eng.output_text())
+                eng.set_scan_shard(0, 1)
+                if b"".join(pieces) != got:
+                    print("SHARD MISMATCH", seed, case, producer, wp, p, revcomp, G, flush=True)
+                    sys.exit(1)
+            if got != want.text():
                 print("MISMATCH", seed, case, producer, wp, p, revcomp, merge, [[r[:60] for r in d] for d in docs][:3], flush=True)
                 sys.exit(1)
-            if merge and not np.array_equal(eng.thresholds(), want.thresh()):
+            if merge and not np.array_equal(got_thresh, want.thresh()):
                 print("THRESH MISMATCH", seed, case, producer, wp, p, flush=True)
                 sys.exit(1)
         done += 1

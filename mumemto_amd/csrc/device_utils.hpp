@@ -47,7 +47,7 @@ public:
     ~DevBuf() { release(); }
     void ensure(size_t n) {
         if (n <= cap_) { n_ = n; return; }
-        release();
+        release();                                   // (a borrowed view that is too small is dropped: own memory then)
         // a little slack, so that a re-run with slightly different sizes does not re-allocate; capped: a sixteenth of a
         // 48 GB column is 3 GB of device memory nobody uses
         size_t want = n + std::min<size_t>(n / 16, ((size_t)16 << 20) / sizeof(T)) + 64;
@@ -62,17 +62,23 @@ public:
         if (DevBytes::live() > DevBytes::peak()) DevBytes::peak() = DevBytes::live();
     }
     void release() {
-        if (p_) { pool::release(p_); p_ = nullptr; DevBytes::live() -= cap_ * sizeof(T); }
+        if (p_ && owned_) { pool::release(p_); DevBytes::live() -= cap_ * sizeof(T); }
+        p_ = nullptr; owned_ = true;
         cap_ = n_ = 0;
     }
+    // A view of memory that belongs to another buffer (stage scratch living inside columns that are written later):
+    // not counted, not freed.
+    void borrow(T* p, size_t n) { release(); p_ = p; cap_ = n_ = n; owned_ = false; }
+    bool owned() const { return owned_; }
     T* get() const { return p_; }
     size_t size() const { return n_; }
     size_t bytes() const { return n_ * sizeof(T); }
-    void swap(DevBuf& o) { std::swap(p_, o.p_); std::swap(cap_, o.cap_); std::swap(n_, o.n_); }
+    void swap(DevBuf& o) { std::swap(p_, o.p_); std::swap(cap_, o.cap_); std::swap(n_, o.n_); std::swap(owned_, o.owned_); }
 
 private:
     T* p_ = nullptr;
     size_t cap_ = 0, n_ = 0;
+    bool owned_ = true;
 };
 
 // A table of text positions / stream offsets: uint32_t entries in a narrow run, uint64_t entries in a wide one

@@ -247,7 +247,8 @@ void Engine::release_sort_scratch() {
 void Engine::release_columns() {
     MMT_HIP(hipStreamSynchronize(stream_));
     release_sort_scratch();
-    d_text_.release(); d_bwt_.release(); d_sa_.release(); d_sa_hi_.release(); d_rank_.release(); d_rank64_.release();
+    d_text_.release(); d_bwt_.release(); d_sa_.release(); d_sa_hi_.release(); d_cols_.release(); d_rank_.release();
+    d_rank64_.release();
     d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
     d_cand_.release(); d_flags_.release();
     lcp_whole_ = false;
@@ -651,12 +652,15 @@ void Engine::run(const mmt_params& p) {
         d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
     }
     if (lean_ || wide_) {
-        // one-shot / wide runs: the columns that live to the end of the run are allocated before any scratch, so that
-        // they sit together at the bottom of the device heap and the scratch above them leaves one hole when it goes
-        // (allocated late they land between scratch buffers, the heap fragments and maps 228 GB for 170 GB in use)
-        d_sa_.ensure(n_);
-        if (wide_) d_sa_hi_.ensure(n_ + 16);
-        d_bwt_.ensure((size_t)n_ + 16);
+        // (allocated late these columns land between scratch buffers: the heap fragments and maps 228 GB for 170 GB in use)
+        auto up = [](size_t x) { return (x + 511) / 512 * 512; };
+        const size_t b_lo = up((size_t)n_ * 4), b_hi = wide_ ? up((size_t)n_ + 16) : 0, b_bwt = up((size_t)n_ + 16);
+        d_cols_.ensure(b_lo + b_hi + b_bwt);
+        d_sa_.borrow(reinterpret_cast<uint32_t*>(d_cols_.get()), n_);
+        if (wide_) d_sa_hi_.borrow(d_cols_.get() + b_lo, (size_t)n_ + 16);
+        d_bwt_.borrow(d_cols_.get() + b_lo + b_hi, (size_t)n_ + 16);
+    } else if (!d_sa_.owned() || !d_bwt_.owned() || !d_sa_hi_.owned()) {
+        d_sa_.release(); d_sa_hi_.release(); d_bwt_.release();      // views of an earlier one-shot run: own memory now
     }
     ev_[1]->start(stream_);
     {

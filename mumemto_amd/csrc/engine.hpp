@@ -169,6 +169,12 @@ private:
 
     // columns
     DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_, d_sa_hi_;
+    // One-shot / wide runs: suffix array (low words, high bytes) and BWT are views into one block that is allocated
+    // before any scratch (it then sits at the bottom of the device heap, and what is above it leaves one hole when it
+    // goes).  The emitter writes these columns only after the dictionary and the parse are sorted, so until then the
+    // block is the scratch of those sorts (DoublingSorter::reserve_in): 49 bytes per dictionary character that the run
+    // does not hold twice.
+    DevBuf<uint8_t> d_cols_;
     DevBuf<uint64_t> d_hist_, d_rank64_;
     DevBuf<uint32_t> d_sa_, d_rank_, d_lcp_, d_count_, d_plcp_a_;
     DevBuf<uint8_t> d_long_;

@@ -148,7 +148,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     S.sa_d.ensure(nd); S.rank_d.ensure(nd);
-    sorter_.reserve(std::max(nd, m));
+    // one-shot / wide runs: the scratch of the two sorts lives in the (not yet written) suffix-array / BWT block
+    if (slim && d_cols_.get()) sorter_.reserve_in(d_cols_.get(), d_cols_.bytes(), std::max(nd, m));
+    else sorter_.reserve(std::max(nd, m));
     k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
     if (slim) S.rank_d.release();

@@ -17,6 +17,21 @@ void DoublingSorter::reserve(uint32_t n) {
     headval_.ensure(n); head_.ensure(n); idx_.ensure(n); flags_.ensure(n); count_.ensure(4);
 }
 
+bool DoublingSorter::reserve_in(uint8_t* region, size_t bytes, uint32_t n) {
+    const size_t A = 512;
+    auto up = [&](size_t x) { return (x + A - 1) / A * A; };
+    const size_t need = 2 * up((size_t)n * 8) + 8 * up((size_t)n * 4) + up(n) + A;
+    if (!region || bytes < need) { reserve(n); return false; }
+    uint8_t* at = reinterpret_cast<uint8_t*>(up(reinterpret_cast<uintptr_t>(region)));
+    auto take64 = [&](DevBuf<uint64_t>& b) { b.borrow(reinterpret_cast<uint64_t*>(at), n); at += up((size_t)n * 8); };
+    auto take32 = [&](DevBuf<uint32_t>& b) { b.borrow(reinterpret_cast<uint32_t*>(at), n); at += up((size_t)n * 4); };
+    take64(keys_a_); take64(keys_b_);
+    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &headval_, &head_, &idx_}) take32(*b);
+    flags_.borrow(at, n);
+    count_.ensure(4);
+    return true;
+}
+
 // (keys_a_, sac_a_) -> (keys_b_, sac_b_), m active elements grouped by bucket: tiles between bucket boundaries are
 // sorted in LDS, the few ranges holding a bucket longer than a tile by one segmented radix sort.
 void DoublingSorter::release() {

@@ -15,6 +15,9 @@ public:
     // The caller fills keys_in() / vals_in() for n suffixes: keys = first h0 symbols of every
     // suffix packed big-endian into `key_bits` bits (past-the-end = 0 = smallest), vals = 0..n-1.
     void reserve(uint32_t n);
+    // the same with every text-sized scratch column carved out of `region` (memory that another stage will only write
+    // later); falls back to reserve() when the region is too small.  Returns whether the region is in use.
+    bool reserve_in(uint8_t* region, size_t bytes, uint32_t n);
     uint64_t* keys_in() { return keys_a_.get(); }
     uint32_t* vals_in() { return sac_a_.get(); }
     // Sorts; sa_out[j] = j-th smallest suffix, rank_out = its inverse.  Returns #doubling rounds.

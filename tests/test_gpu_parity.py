@@ -350,3 +350,4 @@ def test_scan_kernel_shapes_and_double_buffering(variant, bpc):
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "scan shapes ok" in r.stdout
+

@@ -12,19 +12,21 @@ pytestmark = pytest.mark.gpu
 def test_device_heap_accounting_and_trim():
     """pool.hpp: every engine buffer comes from one growing heap; closing the engines leaves nothing live, trimming gives
     the physical memory back, and a following run maps it again and still matches the oracle."""
+    import gc
     import mumemto_amd
+    gc.collect()
     L = mumemto_amd.load_library()
     docs = synth.pangenome(6, 30000, 0.01, seed=71)
     want = O.run(docs).text()
+    probe = mumemto_amd.Engine(0)               # (device_memory needs a handle; an idle engine holds no buffers)
+    base_live = probe.device_memory()["live"]   # engines other tests of this process may still hold
     a, b = mumemto_amd.Engine(0), mumemto_amd.Engine(0)
     for eng in (a, b, a):
         eng.set_docs(docs)
         eng.run()
         assert eng.output_text() == want
     m = a.device_memory()
-    assert m["mapped"] >= m["peak"] >= m["live"] > 0
-    if m["live"] > 4 * (1 << 30):
-        pytest.skip("other engines of this process hold device memory")
+    assert m["mapped"] >= m["peak"] >= m["live"] > base_live
     os.environ["MUMEMTO_LEAN"] = "1"            # stage scratch is released and re-used inside the run
     try:
         c = mumemto_amd.Engine(0)
@@ -36,12 +38,12 @@ def test_device_heap_accounting_and_trim():
         del os.environ["MUMEMTO_LEAN"]
     mapped_before = a.device_memory()["mapped"]
     b.close()
-    assert a.device_memory()["live"] > 0
-    probe = mumemto_amd.Engine(0)               # (device_memory needs a handle; an idle engine holds no buffers)
+    assert a.device_memory()["live"] > base_live
     a.close()
-    assert probe.device_memory()["live"] == 0 and probe.device_memory()["mapped"] == mapped_before
-    L.mmt_pool_trim()
-    assert probe.device_memory()["mapped"] == 0
+    assert probe.device_memory()["live"] == base_live and probe.device_memory()["mapped"] == mapped_before
+    if base_live == 0:
+        L.mmt_pool_trim()
+        assert probe.device_memory()["mapped"] == 0
     probe.set_docs(docs)
     probe.run()
     assert probe.output_text() == want and probe.device_memory()["mapped"] > 0

@@ -124,6 +124,22 @@ def main():
     t_gen = time.perf_counter() - t_gen
     out_prefix = os.path.join(workdir, "out")
 
+    # ---- the same job as a fresh process first (N = 1): mumemto_exec, process start -> exit, before this process has
+    #      touched the device (HIP runtime start, first mapping of the device heap and process teardown included)
+    cli = None
+    exe = os.path.join(ROOT, "mumemto_amd", "bin", "mumemto_exec")
+    if rank == 0 and world == 1 and not a.no_extras and os.path.exists(exe):
+        stats = os.path.join(workdir, "cli_stats.json")
+        t0 = time.perf_counter()
+        r = subprocess.run([exe] + paths + ["-o", os.path.join(workdir, "cli")], capture_output=True,
+                           env=dict(os.environ, MUMEMTO_STATS=stats, MUMEMTO_DEVICE=str(local_rank)))
+        wall = time.perf_counter() - t0
+        cli = {"wall_s": wall, "value": a.length * a.haps / wall / 1e9, "unit": "Gbp/s", "rc": r.returncode}
+        if r.returncode == 0 and os.path.exists(stats):
+            st = json.load(open(stats))
+            cli.update({"heap_map_seconds": st["heap_map_seconds"], "heap_peak_bytes": st["heap_peak_bytes"],
+                        "stage_ms": st["stage_ms"]})
+
     eng = mumemto_amd.Engine(local_rank)
     eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
     merge_mode = world > 1
@@ -252,29 +268,13 @@ def main():
             ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_groups",
              "parse_sa", "lists_emit", "total_host_clock"], [round(x, 3) for x in eng.pfp_stage_ms()]))}
 
+    if cli is not None:
+        if cli["rc"] == 0:
+            cli["output_identical_to_in_process"] = subprocess.run(
+                ["cmp", "-s", os.path.join(workdir, "cli.mums"), out_file]).returncode == 0
+        result["cli_process"] = cli
     if rank == 0 and world == 1 and not a.no_extras:
-        # (1) the same job as a fresh process: mumemto_exec, process start -> exit (HIP runtime start, first mapping of
-        #     the device heap and process teardown included)
-        exe = os.path.join(ROOT, "mumemto_amd", "bin", "mumemto_exec")
-        if os.path.exists(exe):
-            eng.close()                              # give the device memory back before the process asks for it
-            mumemto_amd.load_library().mmt_pool_trim()
-            stats = os.path.join(workdir, "cli_stats.json")
-            t0 = time.perf_counter()
-            r = subprocess.run([exe] + paths + ["-o", os.path.join(workdir, "cli")], capture_output=True,
-                               env=dict(os.environ, MUMEMTO_STATS=stats, MUMEMTO_DEVICE=str(local_rank)))
-            wall = time.perf_counter() - t0
-            cli = {"wall_s": wall, "value": total_bp / wall / 1e9, "unit": "Gbp/s", "rc": r.returncode}
-            if r.returncode == 0 and os.path.exists(stats):
-                st = json.load(open(stats))
-                cli.update({"heap_map_seconds": st["heap_map_seconds"], "heap_peak_bytes": st["heap_peak_bytes"],
-                            "stage_ms": st["stage_ms"]})
-                same = subprocess.run(["cmp", "-s", os.path.join(workdir, "cli.mums"), out_file]).returncode == 0
-                cli["output_identical_to_in_process"] = same
-            result["cli_process"] = cli
-            eng = mumemto_amd.Engine(local_rank)
-            eng.set_producer(a.producer, a.pfp_w, a.pfp_p)
-        # (2) HBM-resident engine step: bases on the device before the timed region, output bytes in page-locked host
+        # HBM-resident engine step: bases on the device before the timed region, output bytes in page-locked host
         #     memory after it (what round 1 reported as `value`)
         flat = np.empty(a.haps * a.length, np.uint8)
         for h, bases in synth.haplotypes_sparse(a.haps, a.length, a.divergence, a.seed):

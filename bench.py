@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
                     help="N > 1: torch.distributed collectives (default) or the C-ABI exchange of dist.cpp (mmt_dist_merge: "
                          "RCCL bound from C++, grouped broadcasts, one device per rank)")
+    ap.add_argument("--fold", default="rank0", choices=["rank0", "ranges"],
+                    help="N > 1 with --exchange torch: rank 0 folds everything (default), or every rank folds its slice of "
+                         "the anchor after a slice-wise exchange of the thresholds (SURVEY 8(e), reduce-scatter shape)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device exercise the N > 1 path on a box with one GPU (testing only)")
     ap.add_argument("--share-device", action="store_true", help="every rank uses GPU 0 (testing only)")
@@ -163,6 +166,22 @@ def main():
         if comm is not None:            # C-ABI exchange: HBM -> HBM broadcasts, fold and re-sort on rank 0
             merged = comm.merge(min_len=20)
             if rank == 0:
+                with open(out_prefix + ".mums", "wb") as f:
+                    f.write(merged["text"])
+            if timed:
+                phases["read"] += sec["read"]; phases["run"] += sec["run"]
+                phases["exchange_fold"] += time.perf_counter() - t0
+            return merged
+        if a.fold == "ranges":          # every rank folds its slice of the anchor (thresholds travel slice-wise)
+            def fold(parts):
+                m = eng.anchor_merge(parts)
+                return m["lengths"], m["offsets"], m["strands"], m["thresh"]
+            lr, orows, srows = eng.rows_mum()
+            ml, mo, ms = mdist.merge_by_ranges(fold, (lr, orows, srows, eng.thresholds()[: L0 + 1]), dist,
+                                               torch.device("cpu") if a.backend == "gloo" else device, L0 + 1)
+            merged = None
+            if rank == 0:
+                merged = {"text": eng.rows_in_direct_order(ml, mo, ms)}
                 with open(out_prefix + ".mums", "wb") as f:
                     f.write(merged["text"])
             if timed:

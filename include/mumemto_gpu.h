@@ -198,6 +198,11 @@ MMT_API int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, ui
 /* the merged tables in HBM (owned by m)                                        */
 MMT_API int mmt_merged_device(const mmt_merged* m, const uint32_t** length, const int64_t** offsets,
                               const uint8_t** strands, const uint16_t** thresh);
+/* Rows folded elsewhere (a coordinate-range fold: every rank folds its slice of the anchor) as a merged
+ * result of this engine: host arrays in, HBM tables out, so that mmt_merged_sort_like_direct / mmt_merged_text apply.  */
+MMT_API int mmt_merged_from_rows(mmt_engine* e, const uint32_t* length, const int64_t* offsets, const uint8_t* strands,
+                                 size_t n_rows, size_t n_docs, const uint16_t* thresh, size_t thresh_len,
+                                 mmt_merged** out);
 /* Re-order merged rows into the order of a direct run (lexicographic by match
  * string) using the anchor suffix ranks of the engine's last run, whose
  * document 0 must be the anchor.                              */

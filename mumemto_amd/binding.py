@@ -72,7 +72,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
-    "mmt_engine_set_scan_shard", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
+    "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text",
 ]
 
@@ -158,6 +158,8 @@ def load_library():
                                              C.c_uint64]
     L.mmt_engine_run_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_char_p,
                                        C.c_uint64, C.POINTER(C.c_double)]
+    L.mmt_merged_from_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                       C.c_size_t, C.POINTER(C.c_void_p)]
     L.mmt_comm_unique_id.argtypes = [C.c_void_p]
     L.mmt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.mmt_comm_destroy.argtypes = [C.c_void_p]
@@ -509,8 +511,10 @@ class Engine:
                 continue
             length, off, st, th = part
             length = np.ascontiguousarray(length, np.uint32)
-            off = np.ascontiguousarray(off, np.int64).reshape(len(length), -1)
-            st = np.ascontiguousarray(st, np.uint8).reshape(len(length), -1)
+            off = np.ascontiguousarray(off, np.int64)
+            st = np.ascontiguousarray(st, np.uint8)
+            if off.ndim != 2:
+                off, st = off.reshape(len(length), -1), st.reshape(len(length), -1)
             if isinstance(th, tuple):
                 tptr, tlen, on_dev = th[0], th[1], 1
             else:
@@ -540,6 +544,30 @@ class Engine:
             return dict(lengths=length[:n], offsets=off[:n], strands=st[:n], thresh=th, text=text)
         finally:
             self.L.mmt_merged_free(m)
+
+
+def _engine_rows_in_direct_order(self, length, offsets, strands, thresh=None):
+    """Rows folded elsewhere (mumemto_amd.dist.fold_by_ranges) -> re-sorted into the order of a direct run by this
+    engine's anchor suffix ranks -> PREFIX.mums bytes."""
+    length = np.ascontiguousarray(length, np.uint32)
+    offsets = np.ascontiguousarray(offsets, np.int64).reshape(len(length), -1)
+    strands = np.ascontiguousarray(strands, np.uint8).reshape(len(length), -1)
+    th = np.ascontiguousarray(thresh, np.uint16) if thresh is not None else np.zeros(1, np.uint16)
+    m = C.c_void_p()
+    _check(self.L.mmt_merged_from_rows(self.h, _p(length), _p(offsets), _p(strands), len(length), offsets.shape[1], _p(th),
+                                       len(th) if thresh is not None else 0, C.byref(m)))
+    try:
+        _check(self.L.mmt_merged_sort_like_direct(self.h, m))
+        k = C.c_size_t()
+        ptr = self.L.mmt_merged_text(m, C.byref(k))
+        if not ptr and len(length):
+            raise MumemtoError(self.L.mmt_last_error().decode())
+        return _bytes_at(ptr, k.value)
+    finally:
+        self.L.mmt_merged_free(m)
+
+
+Engine.rows_in_direct_order = _engine_rows_in_direct_order
 
 
 class Comm:

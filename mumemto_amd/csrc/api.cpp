@@ -495,6 +495,32 @@ int mmt_merged_device(const mmt_merged* m, const uint32_t** length, const int64_
     if (thresh) *thresh = m->rows.d_thresh.get();
     return 0;
 }
+// rows that were folded elsewhere (coordinate-range fold: every rank folds a slice of the anchor) as a merged result of
+// this engine, so that the re-sort into direct-run order and the formatter apply
+int mmt_merged_from_rows(mmt_engine* e, const uint32_t* length, const int64_t* offsets, const uint8_t* strands,
+                         size_t n_rows, size_t n_docs, const uint16_t* thresh, size_t thresh_len, mmt_merged** out) {
+    if (!e || !out || (n_rows && (!length || !offsets || !strands))) return fail(1, "engine, rows and out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    std::unique_ptr<mmt_merged> m(new mmt_merged());
+    mmt::MergedRows& R = m->rows;
+    hipStream_t st = e->e->stream();
+    MMT_HIP(hipSetDevice(e->e->device()));
+    R.n_rows = n_rows; R.n_docs = n_docs; R.thresh_len = thresh_len;
+    R.d_length.ensure(n_rows + 1); R.d_offsets.ensure(n_rows * n_docs + 1); R.d_strands.ensure(n_rows * n_docs + 1);
+    R.d_thresh.ensure(thresh_len + 1);
+    if (n_rows) {
+        MMT_HIP(hipMemcpyAsync(R.d_length.get(), length, n_rows * 4, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemcpyAsync(R.d_offsets.get(), offsets, n_rows * n_docs * 8, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemcpyAsync(R.d_strands.get(), strands, n_rows * n_docs, hipMemcpyHostToDevice, st));
+    }
+    if (thresh_len && thresh) MMT_HIP(hipMemcpyAsync(R.d_thresh.get(), thresh, thresh_len * 2, hipMemcpyHostToDevice, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    R.on_host = false;
+    m->engine = e->e.get();
+    *out = m.release();
+    MMT_CATCH
+}
 int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m) {
     if (!e || !m) return fail(1, "null");
     MMT_TRY

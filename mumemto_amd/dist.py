@@ -182,3 +182,101 @@ def run_sharded(eng, dist, device, **params):
     finally:
         eng.set_scan_shard(0, 1)
     return b"".join(gather_bytes(local, dist, device))
+
+
+# ---- fold over anchor coordinate ranges (the reduce-scatter shape) ------------------------------------
+# The pairwise fold (src/merge_candidates.cpp:106-157) is local in the anchor coordinate: what it decides at position i
+# depends on the thresholds at i and on the row of each side that covers i.  A slice [lo, hi) of the anchor can therefore
+# be folded on its own from the thresholds of the slice and the rows that reach into it -- plus a margin to the left:
+# a row of an intermediate result that covers lo may start up to one row length before lo, and was itself decided from
+# rows up to one more length further left, once per fold step.  Margin = (partitions - 1) x the longest row.
+
+
+def fold_slices(n_positions, world):
+    """`world` near-equal slices [lo, hi) of the anchor positions 0 .. n_positions - 1."""
+    cuts = [n_positions * r // world for r in range(world + 1)]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def fold_margin(parts):
+    """Positions to the left of a slice that its fold has to see: (partitions - 1) x the longest row, + 1."""
+    longest = max([int(np.asarray(p[0]).max()) if len(p[0]) else 0 for p in parts] + [0])
+    return (len(parts) - 1) * longest + 1
+
+
+def fold_slice(fold, parts, lo, hi, thresh_base=None):
+    """The rows of fold(parts) that start in [lo, hi) and its thresholds [lo, hi), computed from that slice alone.
+    parts: (length, offsets[n, nd], strands[n, nd], thresh) per partition; fold: parts -> merged tuple.  thresh is the
+    whole array (L0 + 1 entries), or -- with thresh_base = max(0, lo - fold_margin(parts)) -- just thresh[base:hi]."""
+    base = max(0, lo - fold_margin(parts))
+    assert thresh_base is None or thresh_base == base
+    sliced = []
+    for length, off, st, th in parts:
+        off = np.asarray(off).reshape(len(length), -1)
+        st = np.asarray(st).reshape(len(length), -1)
+        a0 = off[:, 0] if len(length) else np.zeros(0, np.int64)
+        keep = (a0 >= base) & (a0 < hi)
+        o = off[keep].copy()
+        o[:, 0] -= base
+        th = np.asarray(th)
+        sliced.append((np.asarray(length)[keep], o, st[keep], th[base:hi] if thresh_base is None else th))
+    ml, mo, ms, mth = fold(sliced)
+    mo = np.asarray(mo).reshape(len(ml), -1).copy()
+    ms = np.asarray(ms).reshape(len(ml), -1)
+    if len(ml):
+        mo[:, 0] += base
+        mine = (mo[:, 0] >= lo) & (mo[:, 0] < hi)
+        ml, mo, ms = np.asarray(ml)[mine], mo[mine], ms[mine]
+    return ml, mo, ms, np.asarray(mth)[lo - base:hi - base]
+
+
+def fold_by_ranges(fold, parts, world):
+    """fold(parts), computed as `world` independent slices of the anchor (what `world` ranks do in parallel)."""
+    n_positions = len(parts[0][3])
+    pieces = [fold_slice(fold, parts, lo, hi) for lo, hi in fold_slices(n_positions, world)]
+    nd = sum(np.asarray(p[1]).reshape(len(p[0]), -1).shape[1] - 1 for p in parts) + 1
+    ml = np.concatenate([p[0] for p in pieces]) if pieces else np.zeros(0, np.uint32)
+    mo = np.concatenate([p[1].reshape(-1, nd) for p in pieces])
+    ms = np.concatenate([p[2].reshape(-1, nd) for p in pieces])
+    return ml, mo, ms, np.concatenate([p[3] for p in pieces])
+
+
+def merge_by_ranges(fold, local, dist, device, n_positions):
+    """The multi-GPU fold in the reduce-scatter shape: rows (small) are all-gathered; of the thresholds (2 bytes per
+    anchor position and rank) every rank receives only its slice of the anchor, with the margin of fold_slice, from every
+    other rank (one all-to-all); every rank folds its slice with `fold` (its own GPU); the pieces -- rows that start in
+    the slice -- are gathered in rank order.  local = (length u32[n], offsets i64[n, nd], strands u8[n, nd], thresh
+    u16[n_positions]) as numpy arrays.  Returns (length, offsets, strands) of the whole fold on every rank, in anchor order
+    (Engine.rows_in_direct_order re-sorts them)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    length, off, st, thresh = local
+    rows = [None] * world
+    dist.all_gather_object(rows, (np.asarray(length), np.asarray(off).reshape(len(length), -1),
+                                  np.asarray(st).reshape(len(length), -1)))
+    margin = fold_margin([(r[0],) for r in rows])
+    slices = fold_slices(n_positions, world)
+    bases = [max(0, lo - margin) for lo, _ in slices]
+    th = torch.from_numpy(np.ascontiguousarray(thresh, np.uint16).view(np.int16)).to(device)
+    send = [th[bases[r]:slices[r][1]].contiguous() for r in range(world)]
+    recv = [torch.empty(slices[rank][1] - bases[rank], dtype=torch.int16, device=device) for _ in range(world)]
+    try:
+        dist.all_to_all(recv, send)            # RCCL
+    except RuntimeError:                       # gloo has no all-to-all: the same exchange as point-to-point messages
+        ops = []
+        for r in range(world):
+            if r != rank:
+                ops.append(dist.P2POp(dist.isend, send[r], r))
+                ops.append(dist.P2POp(dist.irecv, recv[r], r))
+        recv[rank].copy_(send[rank])
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+    parts = [(rows[g][0], rows[g][1], rows[g][2], recv[g].cpu().numpy().view(np.uint16)) for g in range(world)]
+    lo, hi = slices[rank]
+    piece = fold_slice(fold, parts, lo, hi, thresh_base=bases[rank])
+    pieces = [None] * world
+    dist.all_gather_object(pieces, piece[:3])
+    nd = sum(r[1].shape[1] - 1 for r in rows) + 1
+    return (np.concatenate([p[0] for p in pieces]), np.concatenate([p[1].reshape(-1, nd) for p in pieces]),
+            np.concatenate([p[2].reshape(-1, nd) for p in pieces]))
+

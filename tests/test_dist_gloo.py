@@ -123,3 +123,81 @@ def test_gather_bytes_keeps_rank_order_with_ragged_and_empty_parts():
         assert p.exitcode == 0
     for r in range(3):
         assert got[r] == [b"first rank\n" * 3, b"", b"third\tand last\n"]
+
+
+@pytest.mark.parametrize("seed,world", [(5, 2), (6, 3), (7, 5), (8, 8)])
+def test_fold_over_anchor_coordinate_ranges_equals_the_pairwise_fold(seed, world):
+    """SURVEY 8(e), the reduce-scatter shape: the anchor is cut into `world` slices, every slice is folded on its own
+    (rows reaching into it + a left margin of (partitions - 1) row lengths) -- the concatenation is the pairwise fold of
+    the whole anchor (src/merge_candidates.cpp:106-157), rows and merged thresholds alike."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import pyoracle as O
+    from mumemto_amd import dist as mdist
+    from mumemto_amd import synth
+    docs = synth.pangenome(9, 12000, 0.01, seed=seed, indel_rate=0.001, inversion=(3, 2000, 4000))
+    groups = [[0, 1, 2], [0, 3, 4, 5], [0, 6], [0, 7, 8]]
+    parts = []
+    for g in groups:
+        r = O.run([docs[i] for i in g], merge=True)
+        l, o, s = r.mum_rows()
+        parts.append((l, o, s, r.thresh()[: 12001]))
+    whole = O.anchor_merge(parts)
+    split = mdist.fold_by_ranges(O.anchor_merge, parts, world)
+    assert len(whole[0]) > 20
+    for a, b in zip(whole, split):
+        assert np.array_equal(np.asarray(a), np.asarray(b).reshape(np.asarray(a).shape))
+
+
+def _range_worker(rank, world, port, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import torch
+    import torch.distributed as dist
+    import pyoracle as O
+    from mumemto_amd import dist as mdist
+    from mumemto_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_haps, length = 10, 9000
+    groups = mdist.partition_docs(n_haps, world)
+    docs = synth.pangenome(n_haps, length, 0.01, 9)
+    r = O.run([docs[i] for i in groups[rank]], merge=True)
+    L, off, st = r.mum_rows()
+    merged = mdist.merge_by_ranges(O.anchor_merge, (L, off, st, r.thresh()[: length + 1]), dist, torch.device("cpu"), length + 1)
+    q.put((rank, merged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_fold_over_coordinate_ranges_with_threshold_all_to_all():
+    """mdist.merge_by_ranges on 3 ranks (gloo): rows all-gathered, thresholds exchanged slice-wise (all-to-all), every rank
+    folds its slice of the anchor, pieces gathered -- equal to the pairwise fold of the three partitions on one rank."""
+    import torch.multiprocessing as mp
+    import pyoracle as O
+    from mumemto_amd import dist as mdist
+    from mumemto_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    docs = synth.pangenome(10, 9000, 0.01, 9)
+    parts = []
+    for g in mdist.partition_docs(10, world):
+        r = O.run([docs[i] for i in g], merge=True)
+        l, o, s_ = r.mum_rows()
+        parts.append((l, o, s_, r.thresh()[: 9001]))
+    ml, mo, ms, _ = O.anchor_merge(parts)
+    assert len(ml) > 10
+    for rank in range(world):
+        gl, go, gs = got[rank]
+        assert np.array_equal(gl, ml) and np.array_equal(go, mo) and np.array_equal(gs, ms)

@@ -108,8 +108,8 @@ def test_device_resident_exchange_and_fold():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_multi_rank_path_on_one_gpu(world):
+@pytest.mark.parametrize("world,fold", [(2, "rank0"), (3, "rank0"), (3, "ranges")])
+def test_bench_multi_rank_path_on_one_gpu(world, fold):
     """bench.py's N > 1 path end to end -- torchrun, one process per rank, per-rank partition run, all-gather of the
     HBM row tables, device fold on rank 0, re-sort -- with the ranks sharing GPU 0 under gloo (this box has one GPU;
     RCCL wants one device per rank).  --check compares the merged bytes with the oracle's direct run on the union."""
@@ -124,7 +124,7 @@ def test_bench_multi_rank_path_on_one_gpu(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world),
            "--steps", "2", "--warmup", "1", "--haps", "31", "--length", "150000", "--divergence", "0.005", "--backend", "gloo",
-           "--share-device", "--check"]
+           "--share-device", "--check", "--fold", fold]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

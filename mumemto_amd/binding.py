@@ -358,11 +358,12 @@ class Engine:
         return out
 
     def set_producer(self, kind="auto", w=0, p=0):
-        """kind: 'auto' | 'direct' (reference -g path) | 'pfp' (reference default path)."""
-        _check(self.L.mmt_engine_set_producer(self.h, {"auto": 0, "direct": 1, "pfp": 2}[kind], w, p))
+        """kind: 'auto' | 'direct' (reference -g path) | 'pfp' (reference default path) | 'guided' (the parse without the
+        suffix array of its dictionary: collections with little redundancy, chosen automatically when needed)."""
+        _check(self.L.mmt_engine_set_producer(self.h, {"auto": 0, "direct": 1, "pfp": 2, "guided": 3}[kind], w, p))
 
     def producer_used(self):
-        return {1: "direct", 2: "pfp"}.get(self.L.mmt_producer_used(self.h), "?")
+        return {1: "direct", 2: "pfp", 3: "guided"}.get(self.L.mmt_producer_used(self.h), "?")
 
     def parse_only(self, use_revcomp=True, w=10, p=100):
         """Text layout + prefix-free parse; returns (dict bytes, parse u32[]) as the reference's -P writes them."""

@@ -416,7 +416,7 @@ int mmt_device_memory(const mmt_engine* e, uint64_t out[4]) {
 
 int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p) {
     if (!e) return fail(1, "null");
-    if (kind < 0 || kind > 2) return fail(3, "producer must be 0 (auto), 1 (direct) or 2 (pfp)");
+    if (kind < 0 || kind > 3) return fail(3, "producer must be 0 (auto), 1 (direct), 2 (pfp) or 3 (guided)");
     e->e->set_producer(kind, w, p);
     return 0;
 }

@@ -193,7 +193,7 @@ void Engine::lcp_bwt() {
     // suffix array"): no 4-byte random store per suffix anywhere.  The PFP emitter wrote SA and BWT and keeps no
     // inverse suffix array at all; only the suffix ranks of the anchor document are recorded here (multi-GPU
     // re-sort).  The direct producer has the full array from its sort.
-    const bool pfp = producer_used_ == 2 && pfp_->bwt_ready;
+    const bool pfp = producer_used_ >= 2 && pfp_->bwt_ready;
     if (!pfp) k::bwt_from_sa(text_ptr(), (uint32_t)n, d_sa_.get(), d_bwt_.get(), stream_);
     const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
     void* rank_out = nullptr;
@@ -677,6 +677,7 @@ void Engine::run(const mmt_params& p) {
             const bool forced_pfp = env && std::string(env) == "pfp";
             const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
             kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
+            if (env && std::string(env) == "guided" && !reserved) kind = 3;
             // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
             if (wide_ && !reserved) kind = 2;
         }
@@ -691,9 +692,9 @@ void Engine::run(const mmt_params& p) {
         // rare enough -- and takes 1054 ms against 1111 for 10 / 30, 1171 for 10 / 50, 1981 for 10 / 100, 1376 for 8 / 30)
         const bool big = n_ >= NARROW_LIMIT;
         const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10), auto_p = n_ < (1ull << 30) ? 16 : 30;
-        if (kind == 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
+        if (kind >= 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
         else suffix_sort();
-        producer_used_ = kind;
+        producer_used_ = kind >= 2 ? (pfp_->guided ? 3 : 2) : kind;
     }
     ev_[1]->stop(stream_);
     const bool lean = lean_ || wide_ || wants_lean();

@@ -74,7 +74,8 @@ public:
         else { *len = d_olen_.get(); *off = d_ooffs_.get(); *st = d_ost_.get(); }
     }
     bool last_run_partitioned() const { return merged_thresh_valid_; }
-    // SA/LCP/BWT producer: 0 = automatic, 1 = direct suffix sort of the text (A8), 2 = prefix-free parsing (A2-A4)
+    // SA/LCP/BWT producer: 0 = automatic, 1 = direct suffix sort of the text (A8), 2 = prefix-free parsing (A2-A4),
+    // 3 = prefix-free parsing without the dictionary's suffix array (guided.cpp; automatic when that would not fit)
     void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w ? w : 10; pfp_p_ = p ? p : 100; }
     int producer_used() const { return producer_used_; }
     // A2 alone (after build_text): phrases, dictionary, parse.  Used by -P / -K and the parity tests.
@@ -147,6 +148,7 @@ private:
     void suffix_sort();
     void pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs);
     void suffix_sort_pfp(uint32_t w, uint32_t p);
+    void suffix_sort_guided();
     void lcp_bwt();
     void scan(const mmt_params& p);
     void make_rows(const mmt_params& p);

@@ -1,0 +1,286 @@
+// guided.cpp -- Engine::suffix_sort_guided: suffix array + BWT of a text whose prefix-free parse has a dictionary too
+// large to be suffix-sorted (guided_kernels.hip).  Same result as suffix_sort_pfp / the reference's pfp_lcp
+// (pfp_lcp_mum.hpp:115-231): the text suffixes ordered by (phrase suffix, rank of the following parse suffix).
+//
+//   pfp_parse (pfp.cpp)           phrases, distinct phrases (verified fingerprints), phrase id per parse position
+//   phrase ranks                  the distinct phrases sorted as strings: one batch of the rounds below
+//   parse                         32-bit doubling sort of the rank sequence -> rank of every parse suffix
+//   batches of text suffixes      by leading characters; radix sort on 63 bits of characters, refinement rounds up to
+//                                 the phrase end, parse ranks beyond it; suffix-array and BWT columns written in place
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "guided_kernels.hpp"
+#include "pfp_kernels.hpp"
+#include "pool.hpp"
+#include "prims.hpp"
+
+namespace mmt {
+
+static int bit_width_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+static uint32_t read_u32(const uint32_t* d, hipStream_t s) {
+    uint32_t v = 0;
+    MMT_HIP(hipMemcpyAsync(&v, d, 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    return v;
+}
+
+namespace {
+
+// scratch of one batch (capacity elements)
+struct Batch {
+    DevBuf<uint64_t> key_a, key_b, pos_a, pos_b, pos_c;
+    DevBuf<uint32_t> slot_a, slot_b, ghead, hv, idx, bound, big_begin, big_end, count, seg;
+    DevBuf<uint8_t> head, flags;
+    uint32_t cap = 0;
+    void reserve(uint32_t n) {
+        cap = n;
+        for (DevBuf<uint64_t>* b : {&key_a, &key_b, &pos_a, &pos_b, &pos_c}) b->ensure(n);
+        for (DevBuf<uint32_t>* b : {&slot_a, &slot_b, &ghead, &hv, &idx}) b->ensure(n);
+        head.ensure(n); flags.ensure(n);
+        bound.ensure((size_t)n / 1024 + 4); big_begin.ensure(4096); big_end.ensure(4096); count.ensure(8);
+    }
+    static size_t bytes_per_element() { return 5 * 8 + 5 * 4 + 2 + 1; }
+};
+
+struct RoundStats { int rounds = 0; uint64_t active_sum = 0; uint32_t first_active = 0; };
+
+// (key_a, pos_a) hold B elements with their first keys: sorts them completely; the sorted element records end up in
+// B.pos_b (suffix-array order of the batch).
+RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>& temp, uint32_t* err, hipStream_t st) {
+    RoundStats rs;
+    if (B == 0) return rs;
+    const bool in_b = prims::sort_pairs_u64_u64_inplace(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_b.get(), B, 0,
+                                                        ctx.bits * ctx.chars, st);
+    if (!in_b) { X.key_a.swap(X.key_b); X.pos_a.swap(X.pos_b); }          // from here on: sorted pairs in (key_b, pos_b)
+    gk::heads0(X.key_b.get(), B, X.head.get(), X.flags.get(), st);
+    prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), B, st);
+    uint32_t m = read_u32(X.count.get(), st);
+    rs.first_active = m;
+    if (!m) return rs;
+    gk::gather_active(X.idx.get(), m, X.pos_b.get(), X.head.get(), X.slot_a.get(), X.pos_a.get(), X.ghead.get(), st);
+    prims::inclusive_max_u32(temp, X.ghead.get(), X.ghead.get(), m, st);
+    uint64_t offset = (uint64_t)ctx.chars;
+    const uint32_t target = 1024, limit = gk::SORT_CAP - target;
+    while (m) {
+        if (++rs.rounds > (1 << 22)) throw std::runtime_error("parse-guided suffix sort did not converge");
+        rs.active_sum += m;
+        gk::round_keys(ctx, X.pos_a.get(), m, offset, X.key_a.get(), err, st);
+        // sort inside the groups: (key_a, pos_a) -> (key_b, pos_c)
+        const uint32_t n_tiles = (m + target - 1) / target;
+        X.bound.ensure((size_t)n_tiles + 2);
+        MMT_HIP(hipMemsetAsync(X.count.get() + 1, 0, 4, st));
+        gk::tile_bounds(X.ghead.get(), m, target, limit, n_tiles, X.bound.get(), st);
+        uint32_t big_cap = (uint32_t)X.big_begin.size();
+        gk::local_sort(X.key_a.get(), X.pos_a.get(), X.ghead.get(), X.key_b.get(), X.pos_c.get(), X.bound.get(), n_tiles,
+                       X.big_begin.get(), X.big_end.get(), X.count.get() + 1, big_cap, st);
+        uint32_t big = read_u32(X.count.get() + 1, st);
+        if (big > big_cap) {                                         // (rare) list too short: run the tile sort again
+            X.big_begin.ensure(big); X.big_end.ensure(big);
+            big_cap = big;
+            MMT_HIP(hipMemsetAsync(X.count.get() + 1, 0, 4, st));
+            gk::local_sort(X.key_a.get(), X.pos_a.get(), X.ghead.get(), X.key_b.get(), X.pos_c.get(), X.bound.get(), n_tiles,
+                           X.big_begin.get(), X.big_end.get(), X.count.get() + 1, big_cap, st);
+            big = read_u32(X.count.get() + 1, st);
+        }
+        if (big) {
+            // ranges that hold a group longer than an LDS tile: their groups become the segments of one segmented sort
+            std::vector<uint32_t> hb(big), he(big);
+            MMT_HIP(hipMemcpyAsync(hb.data(), X.big_begin.get(), (size_t)big * 4, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(he.data(), X.big_end.get(), (size_t)big * 4, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+            for (uint32_t r = 0; r < big; r++) {
+                X.seg.ensure((size_t)(he[r] - hb[r]) + 2);
+                gk::range_groups(X.ghead.get(), hb[r], he[r], X.seg.get(), X.count.get() + 2, st);
+                const uint32_t segs = read_u32(X.count.get() + 2, st);
+                prims::segmented_sort_pairs_u64_u64vals_ranges(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_c.get(),
+                                                               m, segs, X.seg.get(), X.seg.get() + 1, 64, st);
+            }
+        }
+        gk::round_heads(X.key_b.get(), X.ghead.get(), m, X.hv.get(), err, st);
+        prims::inclusive_max_u32(temp, X.hv.get(), X.hv.get(), m, st);
+        gk::round_apply(X.pos_c.get(), X.hv.get(), X.slot_a.get(), m, X.pos_b.get(), X.flags.get(), st);
+        prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);
+        const uint32_t m2 = read_u32(X.count.get(), st);
+        if (m2) {
+            gk::round_compact(X.idx.get(), m2, X.slot_a.get(), X.pos_c.get(), X.hv.get(), X.slot_b.get(), X.pos_a.get(),
+                              X.ghead.get(), st);
+            prims::inclusive_max_u32(temp, X.ghead.get(), X.ghead.get(), m2, st);
+            X.slot_a.swap(X.slot_b);
+        }
+        m = m2;
+        offset += (uint64_t)ctx.chars;
+    }
+    return rs;
+}
+
+}  // namespace
+
+void Engine::suffix_sort_guided() {
+    PfpState& S = *pfp_;
+    const uint64_t n = n_;
+    const bool W = wide_;
+    hipStream_t st = stream_;
+    const uint32_t w = S.w, m = S.n_phrases, D = S.n_distinct;
+    const bool stats = std::getenv("MMT_GUIDED_STATS") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        MMT_HIP(hipStreamSynchronize(st));
+        return std::chrono::duration<double, std::milli>(now() - t).count();
+    };
+    EventPair e3, e5, e6;
+
+    // ---- symbol codes (ascending with the byte value; Dollar is the smallest symbol of V) ----
+    e3.start(st);
+    std::vector<uint64_t> hist;
+    d2h(hist, d_hist_.get(), 256, st);
+    uint8_t code[256];
+    int sigma = 0;
+    for (int c = 0; c < 256; c++) code[c] = (hist[c] || c == 2) ? (uint8_t)(++sigma) : 0;
+    gk::Ctx ctx{};
+    ctx.bits = std::max(1, bit_width_u64((uint64_t)sigma));
+    ctx.chars = std::min(63 / ctx.bits, 63);
+    const int prefix_chars = std::max(1, std::min(12 / ctx.bits, ctx.chars));
+    d_code_.ensure(256);
+    MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
+    ctx.v = text_ptr() - 1; ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
+
+    // ---- phrase ends: rank directory and successor table over the cut bits ----
+    const uint64_t n_words = S.tmask.size() * sizeof(uint16_t) / 8 / 64 * 64;     // whole blocks of 4096 positions
+    const uint64_t n_blocks = n_words / 64, n_counts = n_words / 8;
+    if (n_blocks < n / 4096 + 2) throw std::runtime_error("cut bit vector too short for the guided sort");
+    const uint64_t* mask = reinterpret_cast<const uint64_t*>(S.tmask.get());
+    DevBuf<uint32_t> rcount, rdir;
+    DevBuf<uint64_t> nxt;
+    rcount.ensure(n_counts + 1); rdir.ensure(n_counts + 1);
+    gk::rank_counts(mask, n_words, rcount.get(), n_counts, st);
+    prims::exclusive_sum_u32(d_temp_, rcount.get(), rdir.get(), n_counts, st);
+    rcount.release();
+    {
+        nxt.ensure(n_blocks + 1);
+        gk::block_first_cut(mask, n_words, nxt.get(), n_blocks, st);
+        std::vector<uint64_t> h(n_blocks + 1);
+        MMT_HIP(hipMemcpyAsync(h.data(), nxt.get(), n_blocks * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        h[n_blocks] = n + w - 1;
+        for (uint64_t b = n_blocks; b-- > 0;) if (h[b] == ~0ull || h[b] >= n) h[b] = h[b + 1];
+        MMT_HIP(hipMemcpyAsync(nxt.get(), h.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipStreamSynchronize(st));
+    }
+    ctx.mask = mask; ctx.rdir = rdir.get(); ctx.nxt = nxt.get();
+
+    // ---- batch capacity: what the device has left, next to the columns that already exist ----
+    uint64_t cap64 = std::min<uint64_t>(n, 1ull << 30);
+    {
+        const double avail = 0.85 * (double)pool::available(device_);
+        const uint64_t fit = (uint64_t)(avail / (double)Batch::bytes_per_element());
+        cap64 = std::min(cap64, std::max<uint64_t>(fit, 1u << 20));
+        if (const char* c = std::getenv("MMT_GUIDED_BATCH")) cap64 = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
+    }
+    if (D > cap64) cap64 = D;                                      // the distinct phrases are sorted as one batch
+    if (cap64 >= 0xfffffff0ull) throw std::runtime_error("guided sort: batch beyond 32-bit indices");
+    Batch X;
+    X.reserve((uint32_t)cap64);
+    S.err.ensure(16);
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
+    auto check_err = [&](const char* what) {
+        uint32_t e2[2];
+        MMT_HIP(hipMemcpyAsync(e2, S.err.get(), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        if (e2[0] || e2[1])
+            throw std::runtime_error(std::string("guided sort (") + what + "): phrase suffixes are not prefix-free (" +
+                                     std::to_string(e2[0]) + " equal distinct phrases, " + std::to_string(e2[1]) +
+                                     " groups with spent and unspent members)");
+    };
+
+    // ---- lexicographic ranks of the distinct phrases, the parse ----
+    auto t0 = now();
+    ctx.skip = 1; ctx.isa_p = nullptr;
+    gk::phrase_items(ctx, S.pstart.get(), W, S.rep.get(), D, X.key_a.get(), X.pos_a.get(), st);
+    RoundStats r1 = sort_batch(X, D, ctx, d_temp_, S.err.get(), st);
+    check_err("phrases");
+    S.prank.ensure(D); S.parse.ensure(m);
+    gk::phrase_ranks(ctx, X.pos_b.get(), D, S.pid.get(), S.prank.get(), st);
+    pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
+    e3.stop(st);
+    if (stats) std::fprintf(stderr, "[guided] %u distinct phrases ranked in %.1f ms (%d rounds, %u tied after the first sort)\n", D,
+                            ms_since(t0), r1.rounds, r1.first_active);
+
+    // ---- suffix array of the parse (parse.hpp:85) ----
+    e5.start(st);
+    t0 = now();
+    S.sa_p.ensure(m); S.isa_p.ensure(m);
+    {
+        const int pbits = std::max(1, bit_width_u64((uint64_t)D));
+        const int pchars = std::max(1, 64 / pbits);
+        sorter_.reserve(m);
+        pk::pack_keys_u32(S.parse.get(), m, pbits, pchars, sorter_.keys_in(), sorter_.vals_in(), st);
+        S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
+        MMT_HIP(hipStreamSynchronize(st));
+        sorter_.release();
+    }
+    S.sa_p.release(); S.parse.release(); S.pid.release(); S.rep.release(); S.prank.release(); S.pstart.release();
+    S.plen.release(); S.dlen.release(); S.dstart.release();
+    e5.stop(st);
+    if (stats) std::fprintf(stderr, "[guided] parse of %u phrases sorted in %.1f ms (%d rounds)\n", m, ms_since(t0), S.rounds_parse);
+
+    // ---- the text suffixes, batch by batch ----
+    e6.start(st);
+    t0 = now();
+    ctx.skip = 0; ctx.isa_p = S.isa_p.get();
+    d_sa_.ensure(n);
+    if (W) d_sa_hi_.ensure(n + 16);
+    d_bwt_.ensure((size_t)n + 16);
+    const uint32_t n_bins = 1u << (ctx.bits * prefix_chars);
+    DevBuf<uint64_t> d_bins;
+    d_bins.ensure(4096);
+    MMT_HIP(hipMemsetAsync(d_bins.get(), 0, 4096 * 8, st));
+    gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
+    std::vector<uint64_t> bins;
+    d2h(bins, d_bins.get(), 4096, st);
+    const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
+    DevBuf<uint32_t> tile_cnt, tile_off;
+    tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
+    uint64_t base = 0, active_sum = 0;
+    int batches = 0, rounds_max = 0;
+    for (uint32_t b0 = 0; b0 < n_bins;) {
+        uint64_t total = 0;
+        uint32_t b1 = b0;
+        while (b1 < n_bins && total + bins[b1] <= X.cap) total += bins[b1++];
+        if (b1 == b0)
+            throw std::runtime_error("guided sort: " + std::to_string(bins[b0]) + " suffixes share their first " +
+                                     std::to_string(prefix_chars) + " characters, more than one batch holds (" +
+                                     std::to_string(X.cap) + ")");
+        if (total) {
+            const uint32_t B = (uint32_t)total;
+            gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
+            prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+            gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
+            RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st);
+            gk::write_columns(ctx, X.pos_b.get(), B, base, sa_col(), d_bwt_.get(), st);
+            base += B; batches++; rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum;
+        }
+        b0 = b1;
+    }
+    check_err("text suffixes");
+    if (base != n) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
+    S.bwt_ready = true;
+    S.n_groups = 0; S.dict_len = 0; S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
+    e6.stop(st);
+    MMT_HIP(hipStreamSynchronize(st));
+    if (stats) std::fprintf(stderr, "[guided] %llu suffixes in %d batches of at most %u: %.1f ms, %d rounds at most, %.2f refined "
+                            "elements per suffix\n", (unsigned long long)n, batches, X.cap, ms_since(t0), rounds_max,
+                            (double)active_sum / (double)n);
+    S.tmask.release(); S.isa_p.release();
+    S.ms[2] = 0; S.ms[3] = e3.ms(); S.ms[4] = 0; S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
+    sort_rounds_ = rounds_max;
+}
+
+}  // namespace mmt

@@ -1,0 +1,509 @@
+// guided_kernels.hip -- kernels of the parse-guided suffix sort (guided.cpp).
+//
+// The prefix-free parse orders the suffixes of the text by (phrase suffix alpha, rank of the parse suffix that
+// follows): pfp_lcp_mum.hpp:115-231, pfp.hpp:171-244.  The reference -- and pfp.cpp here -- gets the first component
+// from the suffix array of the dictionary (dictionary.hpp:133).  A collection with little redundancy (the anchor and
+// one other whole genome: the two strands of a genome share nothing) has a dictionary as large as half the text, and
+// its suffix array no longer fits; this file sorts the text suffixes themselves instead:
+//   * the suffixes are dealt into batches by their leading characters (a histogram over at most 4096 bins), so that a
+//     batch is one contiguous piece of the suffix array and fits the device next to the columns;
+//   * a batch is sorted by its first 63 bits of characters (device radix sort), then groups of equal keys are refined
+//     63 bits at a time -- but only up to the end of alpha, the phrase the suffix starts in: phrase suffixes are
+//     prefix-free, so two suffixes still tied there have the same alpha and the ranks of the following parse suffixes
+//     (parse.hpp:85: 32-bit doubling sort of the parse, sorter.cpp) decide.  Deep matches between the documents cost
+//     nothing: they live in the parse.
+// The same rounds sort the distinct phrases themselves (their ranks are the parse's alphabet, newscan.hpp:386-404).
+//
+// Positions are V indices (v[q], q = text position + 1; pfp_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "device_utils.hpp"
+#include "guided_kernels.hpp"
+
+namespace mmt { namespace gk {
+
+static inline unsigned grid_for(uint64_t items, unsigned per_block) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g >= (1ull << 24)) throw HipError("kernel launch of 2^32 work-items or more (" + std::to_string(items) + " items)");
+    return (unsigned)(g ? g : 1);
+}
+
+__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
+
+// ---- phrase ends: rank and successor queries on the cut bits ------------------------------------------------------
+__global__ void k_rank_counts(const uint64_t* __restrict__ mask, uint64_t n_words, uint32_t* __restrict__ counts,
+                              uint64_t n_counts) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_counts) return;
+    uint32_t c = 0;
+    for (int t = 0; t < 8; t++) { const uint64_t wi = j * 8 + t; if (wi < n_words) c += (uint32_t)__popcll(mask[wi]); }
+    counts[j] = c;
+}
+void rank_counts(const uint64_t* mask, uint64_t n_words, uint32_t* counts, uint64_t n_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_rank_counts, dim3(grid_for(n_counts, 256)), dim3(256), 0, s, mask, n_words, counts, n_counts);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_block_first_cut(const uint64_t* __restrict__ mask, uint64_t n_words, uint64_t* __restrict__ first,
+                                  uint64_t n_blocks) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint64_t r = ~0ull;
+    for (int t = 0; t < 64; t++) {
+        const uint64_t wi = b * 64 + t;
+        if (wi >= n_words) break;
+        const uint64_t x = mask[wi];
+        if (x) { r = wi * 64 + (uint64_t)__builtin_ctzll(x); break; }
+    }
+    first[b] = r;
+}
+void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, uint64_t n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_block_first_cut, dim3(grid_for(n_blocks, 256)), dim3(256), 0, s, mask, n_words, first, n_blocks);
+    MMT_HIP(hipGetLastError());
+}
+
+// first phrase end at or after text position x
+__device__ __forceinline__ uint64_t next_cut(const Ctx& c, uint64_t x) {
+    if (x >= c.n) return c.n + c.w - 1;
+    uint64_t wi = x >> 6;
+    uint64_t word = c.mask[wi] & (~0ull << (x & 63));
+    const uint64_t stop = ((x >> 12) + 1) << 6;                   // first word of the next block of 4096 positions
+    for (;;) {
+        if (word) return wi * 64 + (uint64_t)__builtin_ctzll(word);
+        if (++wi == stop) return c.nxt[(x >> 12) + 1];
+        word = c.mask[wi];
+    }
+}
+// number of phrase ends before text position x
+__device__ __forceinline__ uint32_t rank1(const Ctx& c, uint64_t x) {
+    if (x > c.n) x = c.n;                                         // no cut bits at or beyond n
+    uint32_t r = c.rdir[x >> 9];
+    const uint64_t w0 = (x >> 9) << 3, w1 = x >> 6;
+    for (uint64_t wi = w0; wi < w1; wi++) r += (uint32_t)__popcll(c.mask[wi]);
+    if (x & 63) r += (uint32_t)__popcll(c.mask[w1] & ((1ull << (x & 63)) - 1));
+    return r;
+}
+// the query point of an element: its phrase is rank1(x), its alpha ends at next_cut(x) (text coordinates)
+__device__ __forceinline__ uint64_t query_point(const Ctx& c, uint64_t q) { return q + c.skip + c.w - 2; }
+__device__ __forceinline__ uint64_t alpha_len(const Ctx& c, uint64_t q) { return next_cut(c, query_point(c, q)) + 2 - q; }
+
+// up to c.chars symbol codes of v[from ...], most significant first
+__device__ __forceinline__ uint64_t pack_chars(const Ctx& c, const uint8_t* __restrict__ s_code, uint64_t from) {
+    const uint8_t* p = c.v + from;
+    uint64_t key = 0;
+    int done = 0;
+    while (done < c.chars) {
+        uint64_t x = load_u64(p + done);
+        const int take = c.chars - done < 8 ? c.chars - done : 8;
+        for (int t = 0; t < take; t++) { key = (key << c.bits) | s_code[x & 0xff]; x >>= 8; }
+        done += take;
+    }
+    return key;
+}
+
+// ---- text-order kernels: one workgroup per TILE text positions, 16 consecutive positions per work-item ----------------
+// Every kernel stages the symbol codes of its tile (+ one key of lookahead) in LDS and rolls the key along.
+template <typename F>
+__device__ __forceinline__ void for_tile_keys(const Ctx& c, uint8_t* s_sym, F&& f) {
+    constexpr int BLOCK = 256, PER = TILE / BLOCK;
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = c.code[i];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;             // text position of the tile's first suffix
+    const uint8_t* t = c.v + 1;
+    for (uint32_t i = threadIdx.x; i < TILE + 64; i += BLOCK) {
+        const uint64_t p = base + i;
+        s_sym[i] = p < c.n + 40 ? s_code[t[p]] : (uint8_t)0;       // (the text buffer is padded: Engine::text_ptr)
+    }
+    __syncthreads();
+    const int t0 = threadIdx.x * PER;
+    const uint64_t kmask = (c.bits * c.chars >= 64) ? ~0ull : ((1ull << (c.bits * c.chars)) - 1);
+    uint64_t key = 0;
+    for (int ch = 0; ch < c.chars; ch++) key = (key << c.bits) | s_sym[t0 + ch];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint64_t i = base + t0 + q;
+        f(q, i, i < c.n, key & kmask);
+        key = ((key << c.bits) | s_sym[t0 + q + c.chars]) & kmask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int shift, uint64_t* __restrict__ hist) {
+    __shared__ uint8_t s_sym[TILE + 64];
+    __shared__ uint32_t s_hist[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for_tile_keys(c, s_sym, [&](int, uint64_t, bool in, uint64_t key) { if (in) atomicAdd(&s_hist[(uint32_t)(key >> shift)], 1u); });
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (s_hist[i]) atomicAdd(reinterpret_cast<unsigned long long*>(hist + i), (unsigned long long)s_hist[i]);
+}
+void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
+    const int shift = c.bits * (c.chars - prefix_chars);
+    hipLaunchKernelGGL(k_bin_hist, dim3(grid_for(c.n, TILE)), dim3(256), 0, s, c, shift, hist);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_batch_count(Ctx c, int shift, uint32_t bin_lo, uint32_t bin_hi,
+                                                     uint32_t* __restrict__ tile_count) {
+    __shared__ uint8_t s_sym[TILE + 64];
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    uint32_t mine = 0;
+    for_tile_keys(c, s_sym, [&](int, uint64_t, bool in, uint64_t key) {
+        const uint32_t b = (uint32_t)(key >> shift);
+        if (in && b >= bin_lo && b < bin_hi) mine++;
+    });
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_cnt;
+}
+void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s) {
+    const int shift = c.bits * (c.chars - prefix_chars);
+    hipLaunchKernelGGL(k_batch_count, dim3(grid_for(c.n, TILE)), dim3(256), 0, s, c, shift, bin_lo, bin_hi, tile_count);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t bin_lo, uint32_t bin_hi,
+                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
+                                                    uint64_t* __restrict__ pos) {
+    __shared__ uint8_t s_sym[TILE + 64];
+    __shared__ uint32_t s_wave[4];
+    constexpr int PER = TILE / 256;
+    uint64_t my_key[PER];
+    uint32_t sel = 0;
+    for_tile_keys(c, s_sym, [&](int q, uint64_t, bool in, uint64_t key) {
+        const uint32_t b = (uint32_t)(key >> shift);
+        my_key[q] = key;
+        if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
+    });
+    // ordered compaction: exclusive prefix of the per-work-item counts over the workgroup
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cnt = __popc(sel);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t out = (uint64_t)tile_off[blockIdx.x] + inc - cnt;
+    for (uint32_t wv = 0; wv < wave; wv++) out += s_wave[wv];
+    const uint64_t base = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        if (!(sel & (1u << q))) continue;
+        const uint64_t vq = base + q + 1;                          // V index
+        const uint64_t len = alpha_len(c, vq);
+        keys[out] = my_key[q];
+        pos[out] = vq | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
+        out++;
+    }
+}
+void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
+                uint64_t* pos, hipStream_t s) {
+    const int shift = c.bits * (c.chars - prefix_chars);
+    hipLaunchKernelGGL(k_batch_fill, dim3(grid_for(c.n, TILE)), dim3(256), 0, s, c, shift, bin_lo, bin_hi, tile_off, keys, pos);
+    MMT_HIP(hipGetLastError());
+}
+
+template <typename P>
+__global__ void k_phrase_items(Ctx c, const P* __restrict__ pstart, const uint32_t* __restrict__ rep, uint32_t D,
+                               uint64_t* __restrict__ keys, uint64_t* __restrict__ pos) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = c.code[i];
+    __syncthreads();
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const uint64_t q = (uint64_t)pstart[rep[d]];
+    const uint64_t len = alpha_len(c, q);
+    keys[d] = pack_chars(c, s_code, q);
+    pos[d] = q | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
+}
+void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* rep, uint32_t D, uint64_t* keys, uint64_t* pos,
+                  hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_phrase_items<uint64_t>, dim3(grid_for(D, 256)), dim3(256), 0, s, c,
+                           static_cast<const uint64_t*>(pstart), rep, D, keys, pos);
+    else
+        hipLaunchKernelGGL(k_phrase_items<uint32_t>, dim3(grid_for(D, 256)), dim3(256), 0, s, c,
+                           static_cast<const uint32_t*>(pstart), rep, D, keys, pos);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- refinement rounds -------------------------------------------------------------------------------------------
+__global__ void k_heads0(const uint64_t* __restrict__ keys, uint32_t B, uint8_t* __restrict__ head,
+                         uint8_t* __restrict__ active) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const uint64_t k = keys[j];
+    const bool h = j == 0 || k != keys[j - 1];
+    const bool next_h = j + 1 == B || keys[j + 1] != k;
+    head[j] = h ? 1 : 0;
+    active[j] = (h && next_h) ? 0 : 1;
+}
+void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, hipStream_t s) {
+    hipLaunchKernelGGL(k_heads0, dim3(grid_for(B, 256)), dim3(256), 0, s, keys, B, head, active);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_gather_active(const uint32_t* __restrict__ idx, uint32_t m, const uint64_t* __restrict__ pos_sorted,
+                                const uint8_t* __restrict__ head, uint32_t* __restrict__ slot, uint64_t* __restrict__ pos,
+                                uint32_t* __restrict__ headval) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    const uint32_t j = idx[c];
+    slot[c] = j; pos[c] = pos_sorted[j];
+    headval[c] = head[j] ? c : 0u;
+}
+void gather_active(const uint32_t* idx, uint32_t m, const uint64_t* pos_sorted, const uint8_t* head, uint32_t* slot,
+                   uint64_t* pos, uint32_t* headval, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_active, dim3(grid_for(m, 256)), dim3(256), 0, s, idx, m, pos_sorted, head, slot, pos, headval);
+    MMT_HIP(hipGetLastError());
+}
+
+// key of an element whose first `offset` characters are known to be shared by its whole group
+__global__ void k_round_keys(Ctx c, const uint64_t* __restrict__ pos, uint32_t m, uint64_t offset,
+                             uint64_t* __restrict__ keys, uint32_t* __restrict__ err) {
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = c.code[i];
+    __syncthreads();
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const uint64_t rec = pos[e], q = rec & POS_MASK;
+    uint64_t len = rec >> 40;
+    if (len == LEN_SAT) len = alpha_len(c, q);
+    if (offset >= len) {
+        // alpha is spent: the group shares it (phrase suffixes are prefix-free) and the following parse suffixes decide
+        if (c.skip) { atomicAdd(err, 1u); keys[e] = RANK_KEY | e; return; }     // two equal distinct phrases
+        const uint32_t k = rank1(c, query_point(c, q));
+        keys[e] = RANK_KEY | (uint64_t)(k + 1 < c.m ? c.isa_p[k + 1] : 0u);
+        return;
+    }
+    keys[e] = pack_chars(c, s_code, q + offset);
+}
+void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, m, offset, keys, err);
+    MMT_HIP(hipGetLastError());
+}
+
+// tile t of the round sort begins at the first group head at or after t * target (NO_BOUND: none within `limit`)
+__global__ void k_tile_bounds(const uint32_t* __restrict__ ghead, uint32_t m, uint32_t target, uint32_t limit,
+                              uint32_t n_tiles, uint32_t* __restrict__ bound) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    if (t == n_tiles) { bound[t] = m; return; }
+    if (t == 0) { bound[0] = 0; return; }
+    uint64_t c = (uint64_t)t * target;
+    const uint64_t stop = c + limit < m ? c + limit : m;
+    while (c < stop && ghead[c] != c) c++;
+    bound[t] = c >= m ? m : (c == stop ? NO_BOUND : (uint32_t)c);
+}
+void tile_bounds(const uint32_t* ghead, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles, uint32_t* bound,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_bounds, dim3(grid_for((uint64_t)n_tiles + 1, 256)), dim3(256), 0, s, ghead, m, target, limit,
+                       n_tiles, bound);
+    MMT_HIP(hipGetLastError());
+}
+
+template <int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void k_local_sort(const uint64_t* __restrict__ kin, const uint64_t* __restrict__ pin,
+                                                      const uint32_t* __restrict__ ghead, uint64_t* __restrict__ kout,
+                                                      uint64_t* __restrict__ pout, const uint32_t* __restrict__ bound,
+                                                      uint32_t n_tiles, uint32_t* __restrict__ big_begin,
+                                                      uint32_t* __restrict__ big_end, uint32_t* __restrict__ big_count,
+                                                      uint32_t big_cap) {
+    __shared__ uint64_t s_k[CAP];
+    __shared__ uint64_t s_p[CAP];
+    __shared__ uint32_t s_h[CAP];
+    __shared__ uint32_t s_long;
+    const uint32_t t = blockIdx.x;
+    const uint32_t b = bound[t];
+    if (b == NO_BOUND) return;                              // this tile starts inside a group: an earlier tile owns it
+    uint32_t u = t + 1;
+    while (bound[u] == NO_BOUND) u++;                       // bound[n_tiles] = m always ends the search
+    const uint32_t e = bound[u];
+    if (e <= b) return;
+    const uint32_t len = e - b;
+    if (len > (uint32_t)CAP) {                              // holds a group longer than a tile: segmented sort (host)
+        if (threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(big_count, 1u);
+            if (slot < big_cap) { big_begin[slot] = b; big_end[slot] = e; }
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < len; i += BLOCK) { s_k[i] = kin[b + i]; s_p[i] = pin[b + i]; s_h[i] = ghead[b + i] - b; }
+    if (threadIdx.x == 0) s_long = 0;
+    __syncthreads();
+    // groups are short: every element counts the members of its group that sort before it (stable)
+    constexpr uint32_t SHORT = 64;
+    constexpr int PER = CAP / BLOCK;
+    uint32_t slot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = threadIdx.x + q * BLOCK;
+        slot[q] = i;
+        if (i < len) {
+            const uint32_t st = s_h[i];
+            const uint64_t ki = s_k[i];
+            uint32_t before = 0, j = st, cnt = 0;
+            while (j < len && cnt <= SHORT) {
+                if (s_h[j] != st) break;
+                const uint64_t kj = s_k[j];
+                before += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+                j++; cnt++;
+            }
+            if (cnt > SHORT) s_long = 1;
+            slot[q] = st + before;
+        }
+    }
+    __syncthreads();
+    if (!s_long) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = threadIdx.x + q * BLOCK;
+            if (i < len) { kout[b + slot[q]] = s_k[i]; pout[b + slot[q]] = s_p[i]; }
+        }
+        return;
+    }
+    // a longer group in the tile: bitonic network over (group, key, position in the tile)
+    uint32_t P = 64;
+    while (P < len) P <<= 1;
+    for (uint32_t i = len + threadIdx.x; i < P; i += BLOCK) { s_k[i] = ~0ull; s_p[i] = 0; s_h[i] = 0xffffffffu; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const uint32_t ha = s_h[i], hc = s_h[l];
+                    const uint64_t a = s_k[i], c2 = s_k[l];
+                    const bool greater = ha != hc ? ha > hc : a > c2;
+                    const bool up = (i & k) == 0;
+                    if (greater == up && !(ha == hc && a == c2)) {
+                        s_k[i] = c2; s_k[l] = a; s_h[i] = hc; s_h[l] = ha;
+                        const uint64_t pa = s_p[i]; s_p[i] = s_p[l]; s_p[l] = pa;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < len; i += BLOCK) { kout[b + i] = s_k[i]; pout[b + i] = s_p[i]; }
+}
+void local_sort(const uint64_t* kin, const uint64_t* pin, const uint32_t* ghead, uint64_t* kout, uint64_t* pout,
+                const uint32_t* bound, uint32_t n_tiles, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count,
+                uint32_t big_cap, hipStream_t s) {
+    hipLaunchKernelGGL((k_local_sort<256, (int)SORT_CAP>), dim3(n_tiles), dim3(256), 0, s, kin, pin, ghead, kout, pout, bound,
+                       n_tiles, big_begin, big_end, big_count, big_cap);
+    MMT_HIP(hipGetLastError());
+}
+
+// the groups inside [begin, end) as segments: seg_begin gets the heads in order, *seg_count their number
+__global__ void k_range_groups(const uint32_t* __restrict__ ghead, uint32_t begin, uint32_t end,
+                               uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_count) {
+    // one workgroup, ordered: every pass handles blockDim.x elements and appends its heads after the earlier ones
+    __shared__ uint32_t s_base, s_wave[16];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    for (uint32_t c0 = begin; c0 < end; c0 += blockDim.x) {
+        const uint32_t c = c0 + threadIdx.x;
+        const bool h = c < end && ghead[c] == c;
+        const uint64_t bal = __ballot(h);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t at = s_base;
+        for (uint32_t wv = 0; wv < wave; wv++) at += s_wave[wv];
+        if (h) seg_begin[at + __popcll(bal & ((1ull << lane) - 1))] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t wv = 0; wv < waves; wv++) tot += s_wave[wv]; s_base += tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *seg_count = s_base; seg_begin[s_base] = end; }
+}
+void range_groups(const uint32_t* ghead, uint32_t begin, uint32_t end, uint32_t* seg_begin, uint32_t* seg_count,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(k_range_groups, dim3(1), dim3(1024), 0, s, ghead, begin, end, seg_begin, seg_count);
+    MMT_HIP(hipGetLastError());
+}
+
+__global__ void k_round_heads(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ghead, uint32_t m,
+                              uint32_t* __restrict__ headval, uint32_t* __restrict__ err) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    const uint64_t k = keys[c];
+    bool h = ghead[c] == c;
+    if (!h) {
+        const uint64_t kp = keys[c - 1];
+        if ((k >> 63) != (kp >> 63)) atomicAdd(err + 1, 1u);    // one group, spent and unspent phrase suffixes: not prefix-free
+        h = (k >> 63) != 0 || k != kp;                           // parse ranks are distinct: such a group is done
+    }
+    headval[c] = h ? c : 0u;
+}
+void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_heads, dim3(grid_for(m, 256)), dim3(256), 0, s, keys, ghead, m, headval, err);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_round_apply(const uint64_t* __restrict__ pos_sorted, const uint32_t* __restrict__ newhead,
+                              const uint32_t* __restrict__ slot, uint32_t m, uint64_t* __restrict__ out,
+                              uint8_t* __restrict__ flags) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m) return;
+    const bool single = newhead[c] == c && (c + 1 == m || newhead[c + 1] == c + 1);
+    if (single) out[slot[c]] = pos_sorted[c];
+    flags[c] = single ? 0 : 1;
+}
+void round_apply(const uint64_t* pos_sorted, const uint32_t* newhead, const uint32_t* slot, uint32_t m, uint64_t* out,
+                 uint8_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_apply, dim3(grid_for(m, 256)), dim3(256), 0, s, pos_sorted, newhead, slot, m, out, flags);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_round_compact(const uint32_t* __restrict__ idx, uint32_t m2, const uint32_t* __restrict__ slot,
+                                const uint64_t* __restrict__ pos_sorted, const uint32_t* __restrict__ newhead,
+                                uint32_t* __restrict__ slot_out, uint64_t* __restrict__ pos_out,
+                                uint32_t* __restrict__ headval_out) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m2) return;
+    const uint32_t o = idx[c];
+    slot_out[c] = slot[o]; pos_out[c] = pos_sorted[o];
+    headval_out[c] = newhead[o] == o ? c : 0u;
+}
+void round_compact(const uint32_t* idx, uint32_t m2, const uint32_t* slot, const uint64_t* pos_sorted,
+                   const uint32_t* newhead, uint32_t* slot_out, uint64_t* pos_out, uint32_t* headval_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_compact, dim3(grid_for(m2, 256)), dim3(256), 0, s, idx, m2, slot, pos_sorted, newhead,
+                       slot_out, pos_out, headval_out);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- results -----------------------------------------------------------------------------------------------------
+template <typename SA>
+__global__ void k_write_columns(Ctx c, const uint64_t* __restrict__ pos, uint32_t B, uint64_t base, SA sa,
+                                uint8_t* __restrict__ bwt) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const uint64_t q = pos[j] & POS_MASK;                  // V index; text position q - 1
+    sa.set(base + j, q - 1);
+    bwt[base + j] = q == 1 ? (uint8_t)0 : c.v[q - 1];      // the Dollar before text position 0 reads as 0 (k_entry_info)
+}
+void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base, SaCol sa, uint8_t* bwt, hipStream_t s) {
+    if (sa.wide())
+        hipLaunchKernelGGL(k_write_columns<Sa40>, dim3(grid_for(B, 256)), dim3(256), 0, s, c, pos, B, base, Sa40(sa), bwt);
+    else
+        hipLaunchKernelGGL(k_write_columns<Sa32>, dim3(grid_for(B, 256)), dim3(256), 0, s, c, pos, B, base, Sa32(sa), bwt);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_phrase_ranks(Ctx c, const uint64_t* __restrict__ pos, uint32_t D, const uint32_t* __restrict__ pid,
+                               uint32_t* __restrict__ prank) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= D) return;
+    const uint64_t q = pos[j] & POS_MASK;
+    prank[pid[rank1(c, query_point(c, q))]] = j + 1;
+}
+void phrase_ranks(const Ctx& c, const uint64_t* pos, uint32_t D, const uint32_t* pid, uint32_t* prank, hipStream_t s) {
+    hipLaunchKernelGGL(k_phrase_ranks, dim3(grid_for(D, 256)), dim3(256), 0, s, c, pos, D, pid, prank);
+    MMT_HIP(hipGetLastError());
+}
+
+}}  // namespace mmt::gk

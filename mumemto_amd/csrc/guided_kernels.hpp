@@ -1,0 +1,75 @@
+// guided_kernels.hpp -- launch wrappers of guided_kernels.hip: the parse-guided suffix sort (guided.cpp).
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime_api.h>
+
+#include "wide.hpp"
+
+namespace mmt { namespace gk {
+
+// One element of a batch: V index of the string's first character (40 bits) and, above it, the number of characters
+// up to the end of its phrase, saturated (an element with a saturated length looks the end up again).
+constexpr uint64_t POS_MASK = (1ull << 40) - 1;
+constexpr uint32_t LEN_SAT = 0xffffffu;
+// keys of a refinement round: up to 63 bits of symbol codes, or bit 63 + the rank of the parse suffix that follows
+constexpr uint64_t RANK_KEY = 1ull << 63;
+constexpr uint32_t TILE = 4096;            // text positions per workgroup of the text-order kernels
+constexpr uint32_t SORT_CAP = 2048;        // elements of one LDS tile of the round sort
+constexpr uint32_t NO_BOUND = 0xffffffffu;
+
+struct Ctx {
+    const uint8_t* v;          // V = Dollar . T . Dollar^w (pfp_kernels.hip); v[q], q = text position + 1
+    uint64_t n;                // text length
+    uint32_t w;                // trigger window
+    const uint64_t* mask;      // bit c set <=> a phrase ends at text position c (64 positions per word, zero padded)
+    const uint32_t* rdir;      // number of phrase ends before text position 512 * j
+    const uint64_t* nxt;       // first phrase end at or after text position 4096 * j (n + w - 1: none)
+    const uint32_t* isa_p;     // rank of the parse suffix that starts at phrase k
+    uint32_t m;                // number of phrases
+    const uint8_t* code;       // byte -> symbol code (1 = Dollar, 0 = past the padding)
+    int bits, chars;           // bits per code, characters per 63-bit key
+    uint32_t skip;             // 0: elements are text suffixes, 1: elements are whole phrases
+};
+
+// cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions
+void rank_counts(const uint64_t* mask, uint64_t n_words, uint32_t* counts, uint64_t n_counts, hipStream_t s);
+void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, uint64_t n_blocks, hipStream_t s);
+
+// bins = leading `prefix_chars` symbols of every text suffix (at most 4096 bins)
+void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s);
+void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s);
+// the suffixes whose bin lies in [bin_lo, bin_hi), in text order: first key and element record
+void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
+                uint64_t* pos, hipStream_t s);
+// one element per distinct phrase (c.skip = 1)
+void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* rep, uint32_t D, uint64_t* keys,
+                  uint64_t* pos, hipStream_t s);
+
+// after the first sort: head[j] = 1 where a new key starts, active[j] = 1 inside groups of two or more
+void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, hipStream_t s);
+void gather_active(const uint32_t* idx, uint32_t m, const uint64_t* pos_sorted, const uint8_t* head, uint32_t* slot,
+                   uint64_t* pos, uint32_t* headval, hipStream_t s);
+void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s);
+void tile_bounds(const uint32_t* ghead, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles, uint32_t* bound,
+                 hipStream_t s);
+// sorts every tile that fits LDS by (group, key); lists the others (big_*) and copies them through unsorted
+void local_sort(const uint64_t* kin, const uint64_t* pin, const uint32_t* ghead, uint64_t* kout, uint64_t* pout,
+                const uint32_t* bound, uint32_t n_tiles, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count,
+                uint32_t big_cap, hipStream_t s);
+// the groups (begin, end) inside the listed ranges, for the segmented sort of groups longer than a tile
+void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s);
+void round_apply(const uint64_t* pos_sorted, const uint32_t* newhead, const uint32_t* slot, uint32_t m, uint64_t* out,
+                 uint8_t* flags, hipStream_t s);
+void round_compact(const uint32_t* idx, uint32_t m2, const uint32_t* slot, const uint64_t* pos_sorted,
+                   const uint32_t* newhead, uint32_t* slot_out, uint64_t* pos_out, uint32_t* headval_out, hipStream_t s);
+// groups of a listed range: segment list for the segmented sort
+void range_groups(const uint32_t* ghead, uint32_t begin, uint32_t end, uint32_t* seg_begin, uint32_t* seg_count,
+                  hipStream_t s);
+
+// sorted batch -> suffix array and BWT columns at [base, base + B)
+void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base, SaCol sa, uint8_t* bwt, hipStream_t s);
+// sorted phrases -> 1-based lexicographic rank per distinct phrase
+void phrase_ranks(const Ctx& c, const uint64_t* pos, uint32_t D, const uint32_t* pid, uint32_t* prank, hipStream_t s);
+
+}}  // namespace mmt::gk

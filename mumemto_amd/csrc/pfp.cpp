@@ -12,6 +12,7 @@
 
 #include "engine.hpp"
 #include "pfp_kernels.hpp"
+#include "pool.hpp"
 #include "prims.hpp"
 
 namespace mmt {
@@ -52,7 +53,9 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     e0.start(st);
     const uint8_t* const v = text_ptr() - 1;       // V = Dollar . T . Dollar^w lives in the text buffer (Engine::text_ptr)
     const uint32_t tb = pk::trigger_blocks(n);
-    S.tmask.ensure((size_t)((n + 15) / 16) + 1); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
+    // (the cut bits double as the rank / successor structure of the guided sort: whole blocks of 4096 positions, zero padded)
+    S.tmask.ensure((size_t)(((n + 64) / 4096 + 2) * 256)); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
+    MMT_HIP(hipMemsetAsync(S.tmask.get(), 0, S.tmask.bytes(), st));
     pk::trigger_masks(text_ptr(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
     S.err.ensure(16);
@@ -66,7 +69,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     const uint32_t m = S.n_phrases = S.n_cuts + 1;
     S.pstart.ensure(m, W); S.plen.ensure(m);
     pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), W, st);
-    if (slim) { S.tmask.release(); S.tcnt.release(); S.toff.release(); S.cuts.release(); }
+    if (slim) { S.tcnt.release(); S.toff.release(); S.cuts.release(); }
     e0.stop(st);
 
     // -- distinct phrases: fingerprints, sort, verified grouping
@@ -121,6 +124,25 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             dict_len64 = 1;
             for (uint32_t x : dl) dict_len64 += x;
         }
+        // Little redundancy between the documents (the anchor next to one other whole genome): the dictionary is as
+        // large as half the text, and neither its 32-bit suffix array nor the tables of its suffixes fit.  The text
+        // suffixes are then sorted themselves, with the parse as the tie-breaker (guided.cpp).
+        S.guided = false;
+        if (!keep_dict_inputs) {
+            const char* env = std::getenv("MUMEMTO_PRODUCER");
+            const double tables = 46.0 * (double)dict_len64, sorter = 49.0 * (double)std::max<uint64_t>(dict_len64, m);
+            const double need = tables + std::max(0.0, sorter - (slim ? (double)d_cols_.bytes() : 0.0));
+            S.guided = producer_ == 3 || (env && std::string(env) == "guided") || dict_len64 >= 0xffffff00ull ||
+                       (producer_ == 0 && need > 0.9 * (double)pool::available(device_));
+            if (S.guided) {
+                S.dict_len = 0;
+                e2.stop(st);
+                S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms();
+                S.have_parse = false;
+                return;
+            }
+        }
+        if (slim) S.tmask.release();
         if (dict_len64 >= 0xffffff00ull)
             throw std::runtime_error("PFP dictionary of " + std::to_string(dict_len64) + " bytes exceeds the 32-bit "
                                      "dictionary of this build (too little redundancy between the documents)");
@@ -183,6 +205,11 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const bool slim = lean_ || wide_;
     auto t0 = std::chrono::steady_clock::now();
     pfp_parse(w, p, false);
+    if (S.guided) {
+        suffix_sort_guided();
+        S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return;
+    }
     hipStream_t st = stream_;
     const uint32_t m = S.n_phrases, D = S.n_distinct;
     EventPair e5, e6;

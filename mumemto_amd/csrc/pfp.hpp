@@ -10,6 +10,7 @@ struct PfpState {
     uint32_t w = 0, p = 0;
     uint32_t n_cuts = 0, n_phrases = 0, n_distinct = 0, dict_len = 0, n_groups = 0;
     bool have_parse = false;
+    bool guided = false;    // the dictionary stage was skipped: Engine::suffix_sort_guided sorts the text suffixes themselves
     int rounds_dict = 0, rounds_parse = 0;
     float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
     DevBuf<uint8_t> dict, ptab, pinfo;   // pinfo: 16-byte record per phrase (k_phrase_hash)  // ptab: 16-byte record per distinct phrase (phrase_table)

@@ -33,6 +33,14 @@ void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* ko
         return rocprim::radix_sort_pairs(t, b, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
     });
 }
+bool sort_pairs_u64_u64_inplace(DevBuf<uint8_t>& temp, uint64_t* ka, uint64_t* kb, uint64_t* va, uint64_t* vb, size_t n,
+                                int begin_bit, int end_bit, hipStream_t s) {
+    rocprim::double_buffer<uint64_t> keys(ka, kb), vals(va, vb);
+    with_temp(temp, [&](void* t, size_t& b) {
+        return rocprim::radix_sort_pairs(t, b, keys, vals, n, (unsigned)begin_bit, (unsigned)end_bit, s);
+    });
+    return keys.current() == kb;
+}
 // Running maximum in two passes over the data (workgroup maxima, a small scan of those, then the scan proper with
 // the carry-in): rocprim's single-pass look-back scan reaches 1.1 TB/s on 387 M elements with this operator.
 template <int BLOCK, int ITEMS>
@@ -284,6 +292,12 @@ void segmented_sort_pairs_u32_u64vals_ranges(DevBuf<uint8_t>& temp, const uint32
 void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s) {
+    sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
+}
+
+void segmented_sort_pairs_u64_u64vals_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,
+                                             uint64_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                             const uint32_t* end, int end_bit, hipStream_t s) {
     sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
 }
 

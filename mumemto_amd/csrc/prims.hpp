@@ -13,6 +13,9 @@ void sort_pairs_u64_u32(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* ko
                         uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 void sort_pairs_u32_u32(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
                         uint32_t* vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
+// the pairs are sorted between the two buffer pairs (no library copy of the input); true: the result is in (kb, vb)
+bool sort_pairs_u64_u64_inplace(DevBuf<uint8_t>& temp, uint64_t* ka, uint64_t* kb, uint64_t* va, uint64_t* vb, size_t n,
+                                int begin_bit, int end_bit, hipStream_t s);
 // out may be the same array as in
 void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
 void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
@@ -38,5 +41,9 @@ void segmented_sort_pairs_u32_u64vals_ranges(DevBuf<uint8_t>& temp, const uint32
 void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                      const uint32_t* end, int end_bit, hipStream_t s);
+
+void segmented_sort_pairs_u64_u64vals_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,
+                                             uint64_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
+                                             const uint32_t* end, int end_bit, hipStream_t s);
 
 }}  // namespace mmt::prims

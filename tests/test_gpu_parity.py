@@ -14,17 +14,22 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module", params=["pfp", "direct"])
+@pytest.fixture(scope="module", params=["pfp", "direct", "guided"])
 def engine(request):
-    """Every case through both SA/LCP/BWT producers: prefix-free parsing with the production window (w 6, p 16; what the
-    automatic choice takes from five documents on) and the direct suffix sort (its choice for fewer)."""
+    """Every case through all SA/LCP/BWT producers: prefix-free parsing with the production window (w 6, p 16; what the
+    automatic choice takes from five documents on), the direct suffix sort (its choice for fewer), and the parse without
+    the suffix array of its dictionary (what whole-genome partitions fall back to), here in batches of 20000 suffixes."""
     import mumemto_amd
     e = mumemto_amd.Engine(0)
     if request.param == "pfp":
         e.set_producer("pfp", 6, 16)
+    elif request.param == "guided":
+        e.set_producer("guided", 6, 16)
+        os.environ["MMT_GUIDED_BATCH"] = "20000"
     else:
         e.set_producer("direct")
     yield e
+    os.environ.pop("MMT_GUIDED_BATCH", None)
     e.close()
 
 

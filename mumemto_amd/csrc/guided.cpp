@@ -176,16 +176,30 @@ void Engine::suffix_sort_guided() {
     }
     ctx.mask = mask; ctx.rdir = rdir.get(); ctx.nxt = nxt.get();
 
-    // ---- batch capacity: what the device has left, next to the columns that already exist ----
-    uint64_t cap64 = std::min<uint64_t>(n, 1ull << 30);
+    // ---- the bins of the text suffixes (leading characters), batch capacity ----
+    const uint32_t n_bins = 1u << (ctx.bits * prefix_chars);
+    std::vector<uint64_t> bins;
     {
-        const double avail = 0.85 * (double)pool::available(device_);
-        const uint64_t fit = (uint64_t)(avail / (double)Batch::bytes_per_element());
-        cap64 = std::min(cap64, std::max<uint64_t>(fit, 1u << 20));
-        if (const char* c = std::getenv("MMT_GUIDED_BATCH")) cap64 = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
+        DevBuf<uint64_t> d_bins;
+        d_bins.ensure(4096);
+        MMT_HIP(hipMemsetAsync(d_bins.get(), 0, 4096 * 8, st));
+        gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
+        d2h(bins, d_bins.get(), 4096, st);
     }
-    if (D > cap64) cap64 = D;                                      // the distinct phrases are sorted as one batch
-    if (cap64 >= 0xfffffff0ull) throw std::runtime_error("guided sort: batch beyond 32-bit indices");
+    // a batch holds whole bins, the distinct phrases are one batch: at least the largest of those, at most what the
+    // device has left next to the columns that already exist
+    uint64_t cap64 = std::min<uint64_t>(n, 1ull << 30);
+    const uint64_t fit = (uint64_t)(0.85 * (double)pool::available(device_) / (double)Batch::bytes_per_element());
+    cap64 = std::min(cap64, std::max<uint64_t>(fit, 1u << 20));
+    if (const char* c = std::getenv("MMT_GUIDED_BATCH")) cap64 = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
+    const uint64_t largest = std::max<uint64_t>(D, *std::max_element(bins.begin(), bins.end()));
+    if (largest > cap64) {
+        if (largest > fit || largest >= 0xfffffff0ull)
+            throw std::runtime_error("guided sort: " + std::to_string(largest) + " suffixes share their first " +
+                                     std::to_string(prefix_chars) + " characters (or are distinct phrases): more than one "
+                                     "batch can hold on this device (" + std::to_string(fit) + ")");
+        cap64 = largest;
+    }
     Batch X;
     X.reserve((uint32_t)cap64);
     S.err.ensure(16);
@@ -238,13 +252,6 @@ void Engine::suffix_sort_guided() {
     d_sa_.ensure(n);
     if (W) d_sa_hi_.ensure(n + 16);
     d_bwt_.ensure((size_t)n + 16);
-    const uint32_t n_bins = 1u << (ctx.bits * prefix_chars);
-    DevBuf<uint64_t> d_bins;
-    d_bins.ensure(4096);
-    MMT_HIP(hipMemsetAsync(d_bins.get(), 0, 4096 * 8, st));
-    gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
-    std::vector<uint64_t> bins;
-    d2h(bins, d_bins.get(), 4096, st);
     const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
     DevBuf<uint32_t> tile_cnt, tile_off;
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
@@ -254,10 +261,7 @@ void Engine::suffix_sort_guided() {
         uint64_t total = 0;
         uint32_t b1 = b0;
         while (b1 < n_bins && total + bins[b1] <= X.cap) total += bins[b1++];
-        if (b1 == b0)
-            throw std::runtime_error("guided sort: " + std::to_string(bins[b0]) + " suffixes share their first " +
-                                     std::to_string(prefix_chars) + " characters, more than one batch holds (" +
-                                     std::to_string(X.cap) + ")");
+        if (b1 == b0) throw std::runtime_error("guided sort: a bin exceeds the batch");
         if (total) {
             const uint32_t B = (uint32_t)total;
             gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);

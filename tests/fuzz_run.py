@@ -66,7 +66,7 @@ for seed in range(first, first + count):
         revcomp = bool(rng.integers(0, 2))
         merge = p["max_doc_freq"] == 1 and p["num_distinct"] == len(docs) and bool(rng.integers(0, 2))
         want = O.run(docs, revcomp=revcomp, merge=merge, **p)
-        for producer in ("direct", "pfp"):
+        for producer in ("direct", "pfp", "guided"):
             wp = (int(rng.integers(2, 12)), int(rng.choice([3, 5, 7, 11, 13, 16, 20, 37, 100])))
             eng.set_producer(producer, *wp)
             eng.set_docs(docs)
@@ -93,4 +93,4 @@ for seed in range(first, first + count):
                 print("THRESH MISMATCH", seed, case, producer, wp, p, flush=True)
                 sys.exit(1)
         done += 1
-print("fuzz ok: %d collections x 2 producers, seeds %d..%d" % (done, first, first + count - 1))
+print("fuzz ok: %d collections x 3 producers, seeds %d..%d" % (done, first, first + count - 1))

@@ -114,6 +114,37 @@ def test_text_beyond_2_to_the_32_as_one_suffix_array():
     assert np.all(direct_thresh[differ] == 0) and np.all(merged_thresh[differ] >= 20)
 
 
+def test_anchor_next_to_one_whole_genome_haplotype():
+    """The partition the anchor-merge workflow needs for BASELINE configs[3]: {anchor, one other haplotype} of 3.05 Gbp
+    each -- 12.2 G text characters whose two strands share nothing, so the dictionary of the parse (6+ G characters) is
+    beyond a 32-bit suffix array and the automatic producer sorts the text suffixes themselves (guided.cpp)."""
+    import mumemto_amd
+    bases, lens = _collection(2, 3_050_000_000, 0.001, 11)
+    eng = mumemto_amd.Engine(0)
+    assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+    assert eng.is_wide() and eng.text_length() == 4 * (3_050_000_000 + 1) and eng.producer_used() == "guided"
+    bigchecks.check_stream(eng, bases, lens, light=True)
+    bigchecks.check_mum_rows(eng, bases, lens)
+
+
+def test_guided_producer_equals_the_parse_proper_at_c2_size():
+    import mumemto_amd
+    bases, lens = _collection(16, 12_100_000, 0.005, 2)
+    eng = mumemto_amd.Engine(0)
+    out = {}
+    for kind, env in (("pfp", {}), ("guided", {}), ("guided", {"MMT_FORCE_WIDE": "1", "MMT_GUIDED_BATCH": str(50_000_000)})):
+        eng.set_producer(kind)
+        os.environ.update(env)
+        try:
+            assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+        finally:
+            for k in env:
+                del os.environ[k]
+        assert eng.producer_used() == kind and eng.is_wide() == bool(env)
+        out[kind + str(len(env))] = eng.output_text()
+    assert out["guided0"] == out["pfp0"] and out["guided2"] == out["pfp0"]
+
+
 def test_c3_standin_at_full_size_one_suffix_array():
     import mumemto_amd
     haps = 94

@@ -74,7 +74,7 @@ def test_random_collections(seed):
             revcomp = bool(rng.integers(0, 2))
             merge = p["max_doc_freq"] == 1 and p["num_distinct"] == len(docs) and bool(rng.integers(0, 2))
             want = O.run(docs, revcomp=revcomp, merge=merge, **p)
-            for producer in ("direct", "pfp"):
+            for producer in ("direct", "pfp", "guided"):
                 wp = (int(rng.integers(2, 12)), int(rng.choice([3, 5, 7, 11, 13, 20, 37, 100])))
                 eng.set_producer(producer, *wp)
                 eng.set_docs(docs)
@@ -87,11 +87,13 @@ def test_random_collections(seed):
         eng.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"MMT_GIANT_RANGE": "1500", "MMT_SCAN_WIDE_AT": "2", "MMT_LONG_CAP": "5"}])
+@pytest.mark.parametrize("env", [{}, {"MMT_GIANT_RANGE": "1500", "MMT_SCAN_WIDE_AT": "2", "MMT_LONG_CAP": "5",
+                                      "MMT_GUIDED_BATCH": "3000"}])
 def test_mid_size_collections_with_runs_arrays_and_copies(env):
     """fuzz_run.py adv: haplotypes of 4-30 kbp with runs of N / of one base up to 12 kbp, tandem arrays, exact copies and
-    deletions, random parameters, both producers against the oracle; the second run lowers the thresholds of the
-    device-wide range sort, of the wide scan and of the long-match list so that those paths take every case."""
+    deletions, random parameters, all three producers against the oracle; the second run lowers the thresholds of the
+    device-wide range sort, of the wide scan and of the long-match list so that those paths take every case, and deals
+    the guided producer's suffixes into batches of 3000."""
     import os
     import subprocess
     import sys

@@ -50,7 +50,7 @@ struct Batch {
     static size_t bytes_per_element() { return 5 * 8 + 5 * 4 + 2 + 1; }
 };
 
-struct RoundStats { int rounds = 0; uint64_t active_sum = 0; uint32_t first_active = 0; };
+struct RoundStats { int rounds = 0; uint64_t active_sum = 0; uint32_t first_active = 0, small = 0; };
 
 // (key_a, pos_a) hold B elements with their first keys: sorts them completely; the sorted element records end up in
 // B.pos_b (suffix-array order of the batch).
@@ -69,6 +69,19 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
     prims::inclusive_max_u32(temp, X.ghead.get(), X.ghead.get(), m, st);
     uint64_t offset = (uint64_t)ctx.chars;
     const uint32_t target = 1024, limit = gk::SORT_CAP - target;
+    if (!std::getenv("MMT_GUIDED_NO_SMALL")) {                      // (the variable sends every group through the rounds: tests)
+        gk::resolve_small(ctx, X.pos_a.get(), X.ghead.get(), X.slot_a.get(), m, offset, X.pos_b.get(), X.flags.get(), err, st);
+        prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);
+        const uint32_t m2 = read_u32(X.count.get(), st);
+        if (m2 && m2 < m) {
+            gk::round_compact(X.idx.get(), m2, X.slot_a.get(), X.pos_a.get(), X.ghead.get(), X.slot_b.get(), X.pos_c.get(),
+                              X.hv.get(), st);
+            prims::inclusive_max_u32(temp, X.hv.get(), X.ghead.get(), m2, st);
+            X.slot_a.swap(X.slot_b); X.pos_a.swap(X.pos_c);
+        }
+        rs.small = m - m2;
+        m = m2;
+    }
     while (m) {
         if (++rs.rounds > (1 << 22)) throw std::runtime_error("parse-guided suffix sort did not converge");
         rs.active_sum += m;
@@ -255,7 +268,7 @@ void Engine::suffix_sort_guided() {
     const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
     DevBuf<uint32_t> tile_cnt, tile_off;
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
-    uint64_t base = 0, active_sum = 0;
+    uint64_t base = 0, active_sum = 0, small_sum = 0;
     int batches = 0, rounds_max = 0;
     for (uint32_t b0 = 0; b0 < n_bins;) {
         uint64_t total = 0;
@@ -269,7 +282,7 @@ void Engine::suffix_sort_guided() {
             gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
             RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st);
             gk::write_columns(ctx, X.pos_b.get(), B, base, sa_col(), d_bwt_.get(), st);
-            base += B; batches++; rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum;
+            base += B; batches++; rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
         }
         b0 = b1;
     }
@@ -279,9 +292,9 @@ void Engine::suffix_sort_guided() {
     S.n_groups = 0; S.dict_len = 0; S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     e6.stop(st);
     MMT_HIP(hipStreamSynchronize(st));
-    if (stats) std::fprintf(stderr, "[guided] %llu suffixes in %d batches of at most %u: %.1f ms, %d rounds at most, %.2f refined "
-                            "elements per suffix\n", (unsigned long long)n, batches, X.cap, ms_since(t0), rounds_max,
-                            (double)active_sum / (double)n);
+    if (stats) std::fprintf(stderr, "[guided] %llu suffixes in %d batches of at most %u: %.1f ms; %.3f of them settled in small groups by "
+                            "comparison, %.3f element-rounds per suffix in %d rounds at most\n", (unsigned long long)n, batches, X.cap,
+                            ms_since(t0), (double)small_sum / (double)n, (double)active_sum / (double)n, rounds_max);
     S.tmask.release(); S.isa_p.release();
     S.ms[2] = 0; S.ms[3] = e3.ms(); S.ms[4] = 0; S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
     sort_rounds_ = rounds_max;

@@ -288,6 +288,65 @@ void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, 
     MMT_HIP(hipGetLastError());
 }
 
+// Groups of at most SMALL elements are finished in one step: every element counts the members of its group that sort
+// before it, comparing the rest of alpha 8 bytes at a time and then the parse ranks.  (Two haplotypes that agree for
+// thousands of characters are such a pair for every one of their suffixes; the refinement rounds would walk their
+// phrase 63 bits per round.)  flags[c] = 1 for the members of larger groups, which go through the rounds.
+constexpr uint32_t SMALL = 8;
+__device__ __forceinline__ uint64_t rank_key(const Ctx& c, uint64_t q) {
+    const uint32_t k = rank1(c, query_point(c, q));
+    return k + 1 < c.m ? (uint64_t)c.isa_p[k + 1] : 0ull;
+}
+__global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ ghead,
+                                const uint32_t* __restrict__ slot, uint32_t m, uint64_t offset,
+                                uint64_t* __restrict__ out, uint8_t* __restrict__ flags, uint32_t* __restrict__ err) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const uint32_t g0 = ghead[e];
+    uint32_t end = e + 1;
+    while (end < m && end - g0 <= SMALL && ghead[end] == g0) end++;
+    if (end - g0 > SMALL) { flags[e] = 1; return; }
+    const uint64_t rec = pos[e], q = rec & POS_MASK;
+    uint64_t len = rec >> 40;
+    if (len == LEN_SAT) len = alpha_len(c, q);
+    uint64_t my_rank = ~0ull;                                    // looked up when first needed
+    uint32_t before = 0;
+    for (uint32_t j = g0; j < end; j++) {
+        if (j == e) continue;
+        const uint64_t rj = pos[j], qj = rj & POS_MASK;
+        uint64_t lj = rj >> 40;
+        if (lj == LEN_SAT) lj = alpha_len(c, qj);
+        const uint64_t L = len < lj ? len : lj;
+        int cmp = 0;                                             // -1: j sorts before e
+        for (uint64_t t = offset; t < L; t += 8) {
+            const uint64_t x = load_u64(c.v + q + t), y = load_u64(c.v + qj + t);
+            if (x != y) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+                if (t + d < L) cmp = ((y >> (8 * d)) & 0xff) < ((x >> (8 * d)) & 0xff) ? -1 : 1;
+                break;
+            }
+        }
+        if (cmp == 0) {
+            // the shorter alpha is a prefix of the other string: the two are the same phrase suffix (prefix-free)
+            if (len != lj || c.skip) atomicAdd(err + (c.skip ? 0 : 1), 1u);
+            if (c.skip) cmp = j < e ? -1 : 1;
+            else {
+                if (my_rank == ~0ull) my_rank = rank_key(c, q);
+                const uint64_t other = rank_key(c, qj);
+                cmp = other < my_rank || (other == my_rank && j < e) ? -1 : 1;
+            }
+        }
+        before += cmp < 0 ? 1u : 0u;
+    }
+    out[slot[g0] + before] = rec;
+    flags[e] = 0;
+}
+void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
+                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve_small, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, slot, m, offset, out, flags, err);
+    MMT_HIP(hipGetLastError());
+}
+
 // tile t of the round sort begins at the first group head at or after t * target (NO_BOUND: none within `limit`)
 __global__ void k_tile_bounds(const uint32_t* __restrict__ ghead, uint32_t m, uint32_t target, uint32_t limit,
                               uint32_t n_tiles, uint32_t* __restrict__ bound) {

@@ -51,6 +51,9 @@ void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, hi
 void gather_active(const uint32_t* idx, uint32_t m, const uint64_t* pos_sorted, const uint8_t* head, uint32_t* slot,
                    uint64_t* pos, uint32_t* headval, hipStream_t s);
 void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s);
+// groups of at most 8 elements, finished by direct comparison (their sorted records go to `out` at the group's slots)
+void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
+                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s);
 void tile_bounds(const uint32_t* ghead, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles, uint32_t* bound,
                  hipStream_t s);
 // sorts every tile that fits LDS by (group, key); lists the others (big_*) and copies them through unsorted

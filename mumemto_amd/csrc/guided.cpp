@@ -229,7 +229,7 @@ void Engine::suffix_sort_guided() {
 
     // ---- lexicographic ranks of the distinct phrases, the parse ----
     auto t0 = now();
-    ctx.skip = 1; ctx.isa_p = nullptr;
+    ctx.skip = 1; ctx.isa_p = nullptr; ctx.pos_bits = 40; ctx.rec_rank = 0;
     gk::phrase_items(ctx, S.pstart.get(), W, S.rep.get(), D, X.key_a.get(), X.pos_a.get(), st);
     RoundStats r1 = sort_batch(X, D, ctx, d_temp_, S.err.get(), st);
     check_err("phrases");
@@ -262,6 +262,11 @@ void Engine::suffix_sort_guided() {
     e6.start(st);
     t0 = now();
     ctx.skip = 0; ctx.isa_p = S.isa_p.get();
+    {
+        // the parse rank rides in the record when it fits next to the position (MMT_GUIDED_NO_RANK: never -- tests)
+        const uint32_t pb = (uint32_t)bit_width_u64(n + w + 1);
+        if (pb + (uint32_t)bit_width_u64(m) <= 64 && !std::getenv("MMT_GUIDED_NO_RANK")) { ctx.pos_bits = pb; ctx.rec_rank = 1; }
+    }
     d_sa_.ensure(n);
     if (W) d_sa_hi_.ensure(n + 16);
     d_bwt_.ensure((size_t)n + 16);

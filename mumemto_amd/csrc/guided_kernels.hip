@@ -64,6 +64,17 @@ void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, ui
     MMT_HIP(hipGetLastError());
 }
 
+// first phrase end at or after text position x; `first` = c.mask[x >> 6], loaded by the caller (x < n)
+__device__ __forceinline__ uint64_t next_cut_from(const Ctx& c, uint64_t x, uint64_t first) {
+    uint64_t wi = x >> 6;
+    uint64_t word = first & (~0ull << (x & 63));
+    const uint64_t stop = ((x >> 12) + 1) << 6;                   // first word of the next block of 4096 positions
+    for (;;) {
+        if (word) return wi * 64 + (uint64_t)__builtin_ctzll(word);
+        if (++wi == stop) return c.nxt[(x >> 12) + 1];
+        word = c.mask[wi];
+    }
+}
 // first phrase end at or after text position x
 __device__ __forceinline__ uint64_t next_cut(const Ctx& c, uint64_t x) {
     if (x >= c.n) return c.n + c.w - 1;
@@ -88,6 +99,29 @@ __device__ __forceinline__ uint32_t rank1(const Ctx& c, uint64_t x) {
 // the query point of an element: its phrase is rank1(x), its alpha ends at next_cut(x) (text coordinates)
 __device__ __forceinline__ uint64_t query_point(const Ctx& c, uint64_t q) { return q + c.skip + c.w - 2; }
 __device__ __forceinline__ uint64_t alpha_len(const Ctx& c, uint64_t q) { return next_cut(c, query_point(c, q)) + 2 - q; }
+
+// An element record is the V index of its first character plus, above it, either the length of its alpha (saturated:
+// looked up again) or -- text suffixes, when the parse rank fits the bits the position leaves -- the rank of the parse
+// suffix that follows, which saves the three random lines of that lookup where pairs are compared.
+__device__ __forceinline__ uint64_t rec_pos(const Ctx& c, uint64_t rec) { return rec & ((1ull << c.pos_bits) - 1); }
+__device__ __forceinline__ uint64_t rec_len(const Ctx& c, uint64_t rec, uint64_t q) {
+    if (c.rec_rank) return alpha_len(c, q);
+    const uint64_t len = rec >> 40;
+    return len == LEN_SAT ? alpha_len(c, q) : len;
+}
+__device__ __forceinline__ uint64_t rec_rank_key(const Ctx& c, uint64_t rec, uint64_t q) {
+    if (c.rec_rank) return rec >> c.pos_bits;
+    const uint32_t k = rank1(c, query_point(c, q));
+    return k + 1 < c.m ? (uint64_t)c.isa_p[k + 1] : 0ull;
+}
+__device__ __forceinline__ uint64_t make_rec(const Ctx& c, uint64_t q) {
+    if (c.rec_rank) {
+        const uint32_t k = rank1(c, query_point(c, q));
+        return q | ((uint64_t)(k + 1 < c.m ? c.isa_p[k + 1] : 0u) << c.pos_bits);
+    }
+    const uint64_t len = alpha_len(c, q);
+    return q | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
+}
 
 // up to c.chars symbol codes of v[from ...], most significant first
 __device__ __forceinline__ uint64_t pack_chars(const Ctx& c, const uint8_t* __restrict__ s_code, uint64_t from) {
@@ -173,6 +207,7 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t b
                                                     uint64_t* __restrict__ pos) {
     __shared__ uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint16_t s_sel[TILE];                               // tile offsets of the selected suffixes, in order
     constexpr int PER = TILE / 256;
     uint64_t my_key[PER];
     uint32_t sel = 0;
@@ -189,18 +224,21 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t b
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    uint64_t out = (uint64_t)tile_off[blockIdx.x] + inc - cnt;
-    for (uint32_t wv = 0; wv < wave; wv++) out += s_wave[wv];
-    const uint64_t base = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER;
+    const uint64_t first = tile_off[blockIdx.x];
+    uint32_t at = inc - cnt;
+    uint32_t total = 0;
+    for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         if (!(sel & (1u << q))) continue;
-        const uint64_t vq = base + q + 1;                          // V index
-        const uint64_t len = alpha_len(c, vq);
-        keys[out] = my_key[q];
-        pos[out] = vq | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
-        out++;
+        keys[first + at] = my_key[q];
+        s_sel[at++] = (uint16_t)(threadIdx.x * PER + q);
     }
+    __syncthreads();
+    // the records: phrase-end / parse-rank lookups, one selected suffix per work-item at a time (inside the loop above
+    // each lookup would wait for the one before it: sixteen latencies in a row per wave)
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    for (uint32_t i = threadIdx.x; i < total; i += 256) pos[first + i] = make_rec(c, base + s_sel[i] + 1);
 }
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
                 uint64_t* pos, hipStream_t s) {
@@ -218,9 +256,8 @@ __global__ void k_phrase_items(Ctx c, const P* __restrict__ pstart, const uint32
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     const uint64_t q = (uint64_t)pstart[rep[d]];
-    const uint64_t len = alpha_len(c, q);
     keys[d] = pack_chars(c, s_code, q);
-    pos[d] = q | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
+    pos[d] = make_rec(c, q);
 }
 void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* rep, uint32_t D, uint64_t* keys, uint64_t* pos,
                   hipStream_t s) {
@@ -271,14 +308,12 @@ __global__ void k_round_keys(Ctx c, const uint64_t* __restrict__ pos, uint32_t m
     __syncthreads();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
-    const uint64_t rec = pos[e], q = rec & POS_MASK;
-    uint64_t len = rec >> 40;
-    if (len == LEN_SAT) len = alpha_len(c, q);
+    const uint64_t rec = pos[e], q = rec_pos(c, rec);
+    const uint64_t len = rec_len(c, rec, q);
     if (offset >= len) {
         // alpha is spent: the group shares it (phrase suffixes are prefix-free) and the following parse suffixes decide
         if (c.skip) { atomicAdd(err, 1u); keys[e] = RANK_KEY | e; return; }     // two equal distinct phrases
-        const uint32_t k = rank1(c, query_point(c, q));
-        keys[e] = RANK_KEY | (uint64_t)(k + 1 < c.m ? c.isa_p[k + 1] : 0u);
+        keys[e] = RANK_KEY | rec_rank_key(c, rec, q);
         return;
     }
     keys[e] = pack_chars(c, s_code, q + offset);
@@ -293,10 +328,6 @@ void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, 
 // thousands of characters are such a pair for every one of their suffixes; the refinement rounds would walk their
 // phrase 63 bits per round.)  flags[c] = 1 for the members of larger groups, which go through the rounds.
 constexpr uint32_t SMALL = 8;
-__device__ __forceinline__ uint64_t rank_key(const Ctx& c, uint64_t q) {
-    const uint32_t k = rank1(c, query_point(c, q));
-    return k + 1 < c.m ? (uint64_t)c.isa_p[k + 1] : 0ull;
-}
 __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ ghead,
                                 const uint32_t* __restrict__ slot, uint32_t m, uint64_t offset,
                                 uint64_t* __restrict__ out, uint8_t* __restrict__ flags, uint32_t* __restrict__ err) {
@@ -306,16 +337,55 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
     uint32_t end = e + 1;
     while (end < m && end - g0 <= SMALL && ghead[end] == g0) end++;
     if (end - g0 > SMALL) { flags[e] = 1; return; }
-    const uint64_t rec = pos[e], q = rec & POS_MASK;
-    uint64_t len = rec >> 40;
-    if (len == LEN_SAT) len = alpha_len(c, q);
+    const uint64_t rec = pos[e], q = rec_pos(c, rec);
+    if (end - g0 == 2 && c.rec_rank) {
+        // a pair (two haplotypes): every load of the common case is issued before anything depends on one -- both
+        // phrase ends, 32 characters of both suffixes -- because random lines over tens of GB are latency, not bandwidth
+        const uint32_t j = e == g0 ? g0 + 1 : g0;
+        const uint64_t rj = pos[j], qj = rec_pos(c, rj);
+        const uint64_t xe = query_point(c, q), xj = query_point(c, qj);
+        const uint64_t me = xe < c.n ? c.mask[xe >> 6] : 0, mj = xj < c.n ? c.mask[xj >> 6] : 0;
+        uint64_t a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { a[t] = load_u64(c.v + q + offset + 8 * t); b[t] = load_u64(c.v + qj + offset + 8 * t); }
+        const uint64_t len = (xe < c.n ? next_cut_from(c, xe, me) : c.n + c.w - 1) + 2 - q;
+        const uint64_t lj = (xj < c.n ? next_cut_from(c, xj, mj) : c.n + c.w - 1) + 2 - qj;
+        const uint64_t L = len < lj ? len : lj;
+        int cmp = 0;
+        bool open = true;                                        // no difference found yet and alpha not yet spent
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint64_t at = offset + 8 * t;
+            if (open && at < L && a[t] != b[t]) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(a[t] ^ b[t]) >> 3;
+                if (at + d < L) cmp = ((b[t] >> (8 * d)) & 0xff) < ((a[t] >> (8 * d)) & 0xff) ? -1 : 1;
+                open = false;
+            }
+        }
+        for (uint64_t t = offset + 32; open && t < L; t += 8) {  // a longer phrase: the plain loop
+            const uint64_t x = load_u64(c.v + q + t), y = load_u64(c.v + qj + t);
+            if (x != y) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+                if (t + d < L) cmp = ((y >> (8 * d)) & 0xff) < ((x >> (8 * d)) & 0xff) ? -1 : 1;
+                open = false;
+            }
+        }
+        if (cmp == 0) {
+            if (len != lj) atomicAdd(err + 1, 1u);
+            const uint64_t mine = rec >> c.pos_bits, other = rj >> c.pos_bits;
+            cmp = other < mine || (other == mine && j < e) ? -1 : 1;
+        }
+        out[slot[g0] + (cmp < 0 ? 1u : 0u)] = rec;
+        flags[e] = 0;
+        return;
+    }
+    const uint64_t len = rec_len(c, rec, q);
     uint64_t my_rank = ~0ull;                                    // looked up when first needed
     uint32_t before = 0;
     for (uint32_t j = g0; j < end; j++) {
         if (j == e) continue;
-        const uint64_t rj = pos[j], qj = rj & POS_MASK;
-        uint64_t lj = rj >> 40;
-        if (lj == LEN_SAT) lj = alpha_len(c, qj);
+        const uint64_t rj = pos[j], qj = rec_pos(c, rj);
+        const uint64_t lj = rec_len(c, rj, qj);
         const uint64_t L = len < lj ? len : lj;
         int cmp = 0;                                             // -1: j sorts before e
         for (uint64_t t = offset; t < L; t += 8) {
@@ -331,8 +401,8 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
             if (len != lj || c.skip) atomicAdd(err + (c.skip ? 0 : 1), 1u);
             if (c.skip) cmp = j < e ? -1 : 1;
             else {
-                if (my_rank == ~0ull) my_rank = rank_key(c, q);
-                const uint64_t other = rank_key(c, qj);
+                if (my_rank == ~0ull) my_rank = rec_rank_key(c, rec, q);
+                const uint64_t other = rec_rank_key(c, rj, qj);
                 cmp = other < my_rank || (other == my_rank && j < e) ? -1 : 1;
             }
         }
@@ -542,7 +612,7 @@ __global__ void k_write_columns(Ctx c, const uint64_t* __restrict__ pos, uint32_
                                 uint8_t* __restrict__ bwt) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
-    const uint64_t q = pos[j] & POS_MASK;                  // V index; text position q - 1
+    const uint64_t q = rec_pos(c, pos[j]);                 // V index; text position q - 1
     sa.set(base + j, q - 1);
     bwt[base + j] = q == 1 ? (uint8_t)0 : c.v[q - 1];      // the Dollar before text position 0 reads as 0 (k_entry_info)
 }
@@ -557,7 +627,7 @@ __global__ void k_phrase_ranks(Ctx c, const uint64_t* __restrict__ pos, uint32_t
                                uint32_t* __restrict__ prank) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= D) return;
-    const uint64_t q = pos[j] & POS_MASK;
+    const uint64_t q = rec_pos(c, pos[j]);
     prank[pid[rank1(c, query_point(c, q))]] = j + 1;
 }
 void phrase_ranks(const Ctx& c, const uint64_t* pos, uint32_t D, const uint32_t* pid, uint32_t* prank, hipStream_t s) {

@@ -30,6 +30,8 @@ struct Ctx {
     const uint8_t* code;       // byte -> symbol code (1 = Dollar, 0 = past the padding)
     int bits, chars;           // bits per code, characters per 63-bit key
     uint32_t skip;             // 0: elements are text suffixes, 1: elements are whole phrases
+    uint32_t pos_bits;         // element records: position in the low pos_bits bits, above it ...
+    uint32_t rec_rank;         // ... 1: the rank of the following parse suffix, 0: the length of alpha (pos_bits = 40)
 };
 
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions

@@ -88,12 +88,12 @@ def test_random_collections(seed):
 
 
 @pytest.mark.parametrize("env", [{}, {"MMT_GIANT_RANGE": "1500", "MMT_SCAN_WIDE_AT": "2", "MMT_LONG_CAP": "5",
-                                      "MMT_GUIDED_BATCH": "3000"}])
+                                      "MMT_GUIDED_BATCH": "3000", "MMT_GUIDED_NO_RANK": "1"}])
 def test_mid_size_collections_with_runs_arrays_and_copies(env):
     """fuzz_run.py adv: haplotypes of 4-30 kbp with runs of N / of one base up to 12 kbp, tandem arrays, exact copies and
     deletions, random parameters, all three producers against the oracle; the second run lowers the thresholds of the
     device-wide range sort, of the wide scan and of the long-match list so that those paths take every case, and deals
-    the guided producer's suffixes into batches of 3000."""
+    the guided producer's suffixes into batches of 3000 whose records carry phrase lengths instead of parse ranks."""
     import os
     import subprocess
     import sys

@@ -947,7 +947,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 // Workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also drains vmcnt, i.e. the DMA).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT>
+// DPP moves inside rows of 16 lanes / the wave (gfx9 controls): lanes without a source keep `old`
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143;
+
+// VH (strict multi-MUMs with 64 <= w < 128, the 94-document shape): the window tables are not built level by level.
+// A window of 64 entries is min(suf[i], pre[i + 63]) over blocks of 64 entries (van Herk / Gil-Werman); sixteen lanes x
+// four entries are such a block, so pre / suf are DPP scans inside a row of lanes, `pre` makes one trip through LDS and
+// the table T_6 is written once.  "A BWT change inside the window" is one comparison with the running maximum of the
+// change positions (exclusive, 16 bits per entry), a wave scan + one carry per wave.  One LDS write + two reads + one
+// write per group of four entries and three barriers, instead of the fused pass + two doubling passes (nine reads,
+// three writes, five barriers) of the level-wise tables.
+template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT, bool VH = false>
 __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint32_t n_tiles, uint32_t w,
                                                 uint32_t klev) {
     constexpr int TILE = BLOCK * VG * 4;
@@ -965,7 +979,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     uint8_t* s_bwt = bwt_buf;
     Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
     uint32_t* s_C = reinterpret_cast<uint32_t*>(s_out + OUT_CAP);           // span / 4 + 8 words of 4 change bytes
+    uint16_t* s_L = reinterpret_cast<uint16_t*>(s_C);                       // VH: span + 16 running maxima instead
     __shared__ uint32_t s_on, s_base;
+    __shared__ uint32_t s_wtot[(VG + 1) * (BLOCK / 64)];
     const uint32_t lane = threadIdx.x & 63;
     uint16_t* my_queue = s_queue + (threadIdx.x >> 6) * (VG * 256);       // VG passes x 64 lanes x 4 positions
     const uint32_t wstep = 1u << klev;
@@ -1083,8 +1099,87 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                         if (off + lane * 16 < b_bytes) glds16(gb + off + lane * 16, b_dst + off);
                 }
             }
+            if (VH) {
+                const uint4* l4 = reinterpret_cast<const uint4*>(s_lcp);
+                uint4* t4 = reinterpret_cast<uint4*>(s_T);
+                const uint32_t* b32 = reinterpret_cast<const uint32_t*>(s_bwt + 12);
+                uint4 sufv[MAXG];
+                uint32_t cpre[MAXG][3], cexc[MAXG];
+#pragma unroll
+                for (int q = 0; q < MAXG; q++) {
+                    const uint32_t g = threadIdx.x + q * BLOCK;
+                    const bool in = INT ? (q < VG || threadIdx.x < (halo >> 2)) : g < groups;
+                    const uint4 v = in ? l4[g] : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    // prefix minima inside the block of 64: own four entries, then the lanes to the left in the row
+                    const uint32_t p1 = umin32(v.x, v.y), p2 = umin32(p1, v.z), gm = umin32(p2, v.w);
+                    uint32_t r = gm;
+                    r = umin32(r, dpp_move<DPP_ROW_SHR + 1>(~0u, r)); r = umin32(r, dpp_move<DPP_ROW_SHR + 2>(~0u, r));
+                    r = umin32(r, dpp_move<DPP_ROW_SHR + 4>(~0u, r)); r = umin32(r, dpp_move<DPP_ROW_SHR + 8>(~0u, r));
+                    const uint32_t before = dpp_move<DPP_ROW_SHR + 1>(~0u, r);
+                    if (in) t4[g] = make_uint4(umin32(before, v.x), umin32(before, p1), umin32(before, p2), umin32(before, gm));
+                    // suffix minima: the lanes to the right
+                    const uint32_t s2 = umin32(v.z, v.w), s1 = umin32(v.y, s2);
+                    uint32_t l = gm;
+                    l = umin32(l, dpp_move<DPP_ROW_SHL + 1>(~0u, l)); l = umin32(l, dpp_move<DPP_ROW_SHL + 2>(~0u, l));
+                    l = umin32(l, dpp_move<DPP_ROW_SHL + 4>(~0u, l)); l = umin32(l, dpp_move<DPP_ROW_SHL + 8>(~0u, l));
+                    const uint32_t after = dpp_move<DPP_ROW_SHL + 1>(~0u, l);
+                    sufv[q] = make_uint4(umin32(after, gm), umin32(after, s1), umin32(after, s2), umin32(after, v.w));
+                    // change positions (LDS index + 1, 0 = none) and their running maximum over the wave
+                    uint32_t c[4] = {0, 0, 0, 0};
+                    if (in) {
+                        const uint32_t wm = b32[g], w0 = b32[g + 1];
+                        const uint32_t x0 = w0 ^ prev_bytes(w0, wm);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) c[t] = ((x0 >> (8 * t)) & 0xffu) ? 4u * g + t + 1u : 0u;
+                    }
+                    const uint32_t c1 = c[0] > c[1] ? c[0] : c[1], c2 = c1 > c[2] ? c1 : c[2], c3 = c2 > c[3] ? c2 : c[3];
+                    cpre[q][0] = c[0]; cpre[q][1] = c1; cpre[q][2] = c2;
+                    uint32_t m = c3, u;
+                    u = dpp_move<DPP_ROW_SHR + 1>(0u, m); m = m > u ? m : u; u = dpp_move<DPP_ROW_SHR + 2>(0u, m); m = m > u ? m : u;
+                    u = dpp_move<DPP_ROW_SHR + 4>(0u, m); m = m > u ? m : u; u = dpp_move<DPP_ROW_SHR + 8>(0u, m); m = m > u ? m : u;
+                    u = dpp_move<DPP_BCAST15, 0xa>(0u, m); m = m > u ? m : u;
+                    u = dpp_move<DPP_BCAST31, 0xc>(0u, m); m = m > u ? m : u;
+                    cexc[q] = dpp_move<DPP_WAVE_SHR1>(0u, m);
+                    if (lane == 63) s_wtot[q * (BLOCK / 64) + wave] = m;
+                }
+                lds_barrier();
+                uint4 t6[MAXG];
+                uint32_t carry[MAXG];
+#pragma unroll
+                for (int q = 0; q < MAXG; q++) {
+                    const uint32_t g = threadIdx.x + q * BLOCK;
+                    const bool in = INT ? (q < VG || threadIdx.x < (halo >> 2)) : g < groups;
+                    // T_6[i + t] = min(suf[i + t], pre[i + t + 63]); entries whose window leaves the staged range are
+                    // never asked for
+                    const uint32_t last = ((span + 16) >> 2) - 1;
+                    const uint32_t ga = g + 15 < last ? g + 15 : last, gb = g + 16 < last ? g + 16 : last;
+                    const uint4 A = t4[ga], B = t4[gb];
+                    t6[q] = make_uint4(umin32(sufv[q].x, A.w), umin32(sufv[q].y, B.x), umin32(sufv[q].z, B.y), umin32(sufv[q].w, B.z));
+                    uint32_t cy = cexc[q];
+#pragma unroll
+                    for (int x = 0; x < MAXG * (BLOCK / 64); x++) {
+                        const uint32_t tot = s_wtot[x];
+                        if ((uint32_t)x < q * (BLOCK / 64) + wave) cy = cy > tot ? cy : tot;
+                    }
+                    carry[q] = cy;
+                    (void)in;
+                }
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < MAXG; q++) {
+                    const uint32_t g = threadIdx.x + q * BLOCK;
+                    const bool in = INT ? (q < VG || threadIdx.x < (halo >> 2)) : g < groups;
+                    if (in) {
+                        t4[g] = t6[q];
+                        const uint32_t e0 = carry[q], e1 = e0 > cpre[q][0] ? e0 : cpre[q][0], e2 = e0 > cpre[q][1] ? e0 : cpre[q][1],
+                                       e3 = e0 > cpre[q][2] ? e0 : cpre[q][2];
+                        reinterpret_cast<uint2*>(s_L)[g] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                    }
+                }
+                lds_barrier();
+            }
             // ---- fused levels 0..K0-1 ----
-            if (USE_C) {
+            if (USE_C && !VH) {
                 if (INT) {
 #pragma unroll
                     for (int q = 0; q < VG; q++) fuse_group(threadIdx.x + q * BLOCK);
@@ -1101,7 +1196,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             // ---- remaining levels (step >= 8): T[i..i+3] = min(T[i..i+3], T[i+step..i+step+3]) ----
             // Two levels per pass where two are left (four reads, one write, two barriers instead of 2 x (two reads, one
             // write, two barriers)): a window of 93 entries (94 documents, levels 3 -> 5 -> 6) takes two passes, not three.
-            for (uint32_t lev = K0; lev < klev;) {
+            for (uint32_t lev = K0; !VH && lev < klev;) {
                 const uint32_t gstep = (1u << lev) >> 2;
                 const bool two = lev + 2 <= klev;
                 uint4* t4 = reinterpret_cast<uint4*>(s_T);
@@ -1153,7 +1248,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                         const uint4 M = umin4(shift4(lo, t4[g0 + 1], rl), K0 >= 2 ? lo1 : shift4(lo1, t4[g1 + 1], rr));
                         const uint32_t mv[4] = {M.x, M.y, M.z, M.w}, cv[4] = {closing.x, closing.y, closing.z, closing.w};
                         uint32_t chg4 = 0xffffffffu;
-                        if (EXACT) {
+                        if (EXACT && VH) {
+                            // a change at an index >= the window start?  (running maximum of index + 1 before position lj + t)
+                            const uint2 L2 = reinterpret_cast<const uint2*>(s_L)[lj >> 2];
+                            const uint32_t lv[4] = {L2.x & 0xffffu, L2.x >> 16, L2.y & 0xffffu, L2.y >> 16};
+                            chg4 = 0;
+#pragma unroll
+                            for (int t = 0; t < 4; t++) chg4 |= ((int32_t)lv[t] > (int32_t)lj + t - (int32_t)w) ? (0xffu << (8 * t)) : 0u;
+                        } else if (EXACT) {
                             const uint32_t cl = (INT || g0 >= 0) ? s_C[g0] : 0u, cr = (INT || g1 >= 0) ? s_C[g1] : 0u;
                             chg4 = shift4b(cl, s_C[g0 + 1], rl) | (K0 >= 2 ? cr : shift4b(cr, s_C[g1 + 1], rr));
                         }
@@ -1382,7 +1484,7 @@ void scan_wide_prepare(const uint32_t* lcp, const uint8_t* bwt, uint32_t n, uint
     MMT_HIP(hipGetLastError());
 }
 
-template <int B, int VG, int OUT_CAP>
+template <int B, int VG, int OUT_CAP, int VH_OUT = 0>
 static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu) {
     constexpr int TILE = B * VG * 4;
     uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
@@ -1396,8 +1498,12 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     halo = (halo + 15) & ~15u;
     if (halo > 4 * B) halo = 4 * B;                        // beyond this the walk reads the cached global columns
     if (halo < w + 1) exact = false;
+    // the 94-document shape (64 <= w < 128, exact windows): block-wise window minima instead of level-wise tables
+    static const bool no_vh = std::getenv("MMT_SCAN_NO_VH") != nullptr;
+    const bool vh = exact && klev == 6 && halo >= w + 1 && !no_vh && VH_OUT > 0;
+    const size_t out_cap = vh ? (size_t)VH_OUT : (size_t)OUT_CAP;
     size_t lds = (size_t)(halo + TILE + 16) * 12 + (size_t)(halo + TILE + 32) * 2 + (size_t)TILE * 2 +
-                 (size_t)OUT_CAP * sizeof(Cand) + (size_t)(halo + TILE + 32);
+                 out_cap * sizeof(Cand) + (vh ? (size_t)(halo + TILE + 16) * 2 : (size_t)(halo + TILE + 32));
     uint32_t n_tiles = grid_for(a.n, TILE);
     const uint32_t todo = n_tiles - a.first / TILE;        // tiles below a.first are skipped (a.first < a.n)
     unsigned grid = todo < 256u * blocks_per_cu ? (todo ? todo : 1u) : 256u * blocks_per_cu;
@@ -1408,7 +1514,9 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
         hipLaunchKernelGGL(kernel, g, b, lds, s, a, halo, n_tiles, w, klev);
     };
     const uint32_t k0 = klev < 3 ? klev : 3;
-    if (exact) {
+    if (vh) {
+        go(k_scan<B, VG, 3, (VH_OUT > 0 ? VH_OUT : OUT_CAP), true, true>);
+    } else if (exact) {
         switch (k0) {
             case 0: go(k_scan<B, VG, 0, OUT_CAP, true>); break;
             case 1: go(k_scan<B, VG, 1, OUT_CAP, true>); break;
@@ -1447,7 +1555,7 @@ void scan_intervals(const ScanArgs& a, hipStream_t s) {
     switch (variant) {
         case 1: launch_scan<512, 1, 256>(a, s, bpc); break;
         case 2: launch_scan<512, 2, 256>(a, s, bpc); break;
-        default: launch_scan<256, 2, 256>(a, s, bpc); break;
+        default: launch_scan<256, 2, 256, 128>(a, s, bpc); break;
     }
 }
 

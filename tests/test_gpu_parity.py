@@ -174,6 +174,27 @@ def test_many_documents_counter_path(engine):
         assert engine.output_text() == O.run(docs, **m).text()
 
 
+@pytest.mark.parametrize("n_docs", [65, 94, 128])
+def test_block_window_scan_for_65_to_128_documents(engine, n_docs):
+    """Strict multi-MUMs with a window of 64 .. 127 entries (the 94-haplotype shape) take the form of k_scan whose window
+    minima come from block prefix / suffix minima and whose BWT test is a running maximum (kernels.hip, VH)."""
+    for seed, length, div, indel, at_least in ((21, 6000, 0.0003, 0.0, 20), (22, 3000, 0.002, 0.0002, 0)):
+        docs = synth.pangenome(n_docs, length, div, seed=seed + n_docs, indel_rate=indel)
+        for revcomp in (True, False):
+            engine.set_docs(docs)
+            engine.run(min_match_len=12, use_revcomp=revcomp)
+            want = O.run(docs, min_len=12, revcomp=revcomp).text()
+            assert engine.output_text() == want and want.count(b"\n") >= at_least
+            # the same scanned in ranges of 8192 suffix-array positions (tiles that start inside a range, left extensions)
+            os.environ["MMT_SCAN_RANGE"] = "8192"
+            os.environ["MMT_FORCE_WIDE"] = "1"
+            try:
+                engine.run(min_match_len=12, use_revcomp=revcomp)
+            finally:
+                del os.environ["MMT_SCAN_RANGE"], os.environ["MMT_FORCE_WIDE"]
+            assert engine.output_text() == want
+
+
 def test_thousands_of_documents(engine):
     # per-wave LDS counters of 4 bytes per document: 6000 documents need 96 KiB of dynamic LDS per workgroup
     rng = np.random.default_rng(3)

@@ -752,7 +752,7 @@ void Engine::copy_candidates(uint32_t* out) const {
     if (n_cand_) MMT_HIP(hipMemcpy(out, d_cand_.get(), n_cand_ * sizeof(k::Cand), hipMemcpyDeviceToHost));
 }
 void Engine::copy_thresh(uint16_t* out) const {
-    if (thresh_len_) MMT_HIP(hipMemcpy(out, d_thresh_.get(), thresh_len_ * 2, hipMemcpyDeviceToHost));
+    if (thresh_len()) MMT_HIP(hipMemcpy(out, thresh_device(), thresh_len() * 2, hipMemcpyDeviceToHost));
 }
 
 }  // namespace mmt

@@ -124,9 +124,10 @@ public:
     void copy_bwt(uint8_t* out) const;
     size_t n_candidates() const { return n_cand_; }
     void copy_candidates(uint32_t* out) const;
-    size_t thresh_len() const { return thresh_len_; }
+    // (after a run that went through anchor partitions: the merged thresholds, like the rows)
+    size_t thresh_len() const { return merged_thresh_valid_ ? merged_.thresh_len : thresh_len_; }
     void copy_thresh(uint16_t* out) const;
-    const uint16_t* thresh_device() const { return d_thresh_.get(); }
+    const uint16_t* thresh_device() const { return merged_thresh_valid_ ? merged_.d_thresh.get() : d_thresh_.get(); }
     const uint32_t* isa_device() const { return d_rank_.get(); }        // narrow runs
     const uint64_t* isa_device64() const { return d_rank64_.get(); }    // wide runs
     bool wide() const { return wide_; }

@@ -108,11 +108,15 @@ def test_device_resident_exchange_and_fold():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fold", [(2, "rank0"), (3, "rank0"), (3, "ranges")])
-def test_bench_multi_rank_path_on_one_gpu(world, fold):
+@pytest.mark.parametrize("world,fold,max_text", [(2, "rank0", 0), (3, "rank0", 0), (3, "ranges", 0), (2, "rank0", 2_000_000),
+                                                 (2, "ranges", 2_000_000)])
+def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text):
     """bench.py's N > 1 path end to end -- torchrun, one process per rank, per-rank partition run, all-gather of the
     HBM row tables, device fold on rank 0, re-sort -- with the ranks sharing GPU 0 under gloo (this box has one GPU;
-    RCCL wants one device per rank).  --check compares the merged bytes with the oracle's direct run on the union."""
+    RCCL wants one device per rank).  --check compares the merged bytes with the oracle's direct run on the union.
+    max_text: the share of a rank does not fit one suffix array (whole genomes: BASELINE configs[3]) -- every rank then runs
+    its share as anchor partitions + merge of its own, and what it contributes to the exchange are its merged rows and
+    thresholds."""
     import json
     import subprocess
     import sys
@@ -126,6 +130,8 @@ def test_bench_multi_rank_path_on_one_gpu(world, fold):
            "--steps", "2", "--warmup", "1", "--haps", "31", "--length", "150000", "--divergence", "0.005", "--backend", "gloo",
            "--share-device", "--check", "--fold", fold]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    if max_text:
+        env["MMT_MAX_TEXT"] = str(max_text)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

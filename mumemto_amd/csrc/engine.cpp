@@ -652,6 +652,12 @@ void Engine::run(const mmt_params& p) {
         d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
     }
     if (lean_ || wide_) {
+        // what the run before left of its LCP and scan stages goes first: the stages of this run are sized by what the
+        // heap has left (a sequence of whole-genome partitions otherwise climbs to the end of the device)
+        MMT_HIP(hipStreamSynchronize(stream_));
+        d_plcp_a_.release(); d_lcp_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
+        d_cand_.release(); d_rank_.release(); d_rank64_.release();
+        lcp_whole_ = false;
         // (allocated late these columns land between scratch buffers: the heap fragments and maps 228 GB for 170 GB in use)
         auto up = [](size_t x) { return (x + 511) / 512 * 512; };
         const size_t b_lo = up((size_t)n_ * 4), b_hi = wide_ ? up((size_t)n_ + 16) : 0, b_bwt = up((size_t)n_ + 16);

@@ -92,11 +92,16 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     }
     const size_t G = groups.size();
     const uint64_t L = doc_len[0] + 1;
-    struct Part {       // one partition's rows and thresholds, kept in HBM for the fold
+    // Every partition is folded into the result so far as soon as it has run (the reference's pairwise fold,
+    // merge_candidates.cpp:106-157, left to right): what stays in HBM between partitions is one table of rows and ONE
+    // threshold column (2 bytes per anchor position: 6 GB for a human genome), however many partitions there are.
+    struct Part {       // one partition's rows and thresholds, copied out of the engine's buffers for the fold
         DevBuf<uint32_t> length; DevBuf<int64_t> offsets; DevBuf<uint8_t> strands; DevBuf<uint16_t> thresh;
         size_t n_rows = 0, n_docs = 0;
     };
-    std::vector<Part> parts(G);
+    Part first;                 // partition 0 until partition 1 arrives
+    MergedRows folded;          // partitions 0 .. g folded, g >= 1
+    bool have_folded = false;
     std::vector<uint64_t> sub_len;
     float acc[8] = {0};
     mmt_params q = p;
@@ -145,7 +150,8 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             sub_len.insert(sub_len.end(), doc_len + a, doc_len + b);
             set_input_device(buf[g & 1], sub_len.data(), sub_len.size());
             run(q);
-            Part& P = parts[g];
+            Part later;
+            Part& P = g == 0 ? first : later;
             P.n_docs = sub_len.size(); P.n_rows = rows_.n_rows;
             const uint32_t* dl; const int64_t* dof; const uint8_t* dst;
             rows_mum_device(&dl, &dof, &dst);
@@ -159,6 +165,25 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
             MMT_HIP(hipStreamSynchronize(stream_));
             for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
+            if (g >= 1) {
+                auto as_partition = [&](mmt_partition& m, size_t rows, size_t docs, const uint32_t* len, const int64_t* off,
+                                        const uint8_t* st, const uint16_t* th) {
+                    m.n_rows = rows; m.n_docs = docs; m.length = len; m.offsets = off; m.strands = st; m.thresh = th;
+                    m.thresh_len = L; m.thresh_on_device = 1; m.rows_on_device = 1;
+                };
+                mmt_partition two[2];
+                if (have_folded)
+                    as_partition(two[0], folded.n_rows, folded.n_docs, folded.d_length.get(), folded.d_offsets.get(),
+                                 folded.d_strands.get(), folded.d_thresh.get());
+                else
+                    as_partition(two[0], first.n_rows, first.n_docs, first.length.get(), first.offsets.get(),
+                                 first.strands.get(), first.thresh.get());
+                as_partition(two[1], P.n_rows, P.n_docs, P.length.get(), P.offsets.get(), P.strands.get(), P.thresh.get());
+                MergedRows next = anchor_merge(*this, two, 2, p.min_match_len);
+                folded = std::move(next);
+                have_folded = true;
+                first.length.release(); first.offsets.release(); first.strands.release(); first.thresh.release();
+            }
             finish_upload();
         }
     } catch (...) {
@@ -167,14 +192,14 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
         throw;
     }
     (void)hipStreamDestroy(copy_stream);
-    std::vector<mmt_partition> mp(G);
-    for (size_t g = 0; g < G; g++) {
-        mp[g].n_rows = parts[g].n_rows; mp[g].n_docs = parts[g].n_docs;
-        mp[g].length = parts[g].length.get(); mp[g].offsets = parts[g].offsets.get();
-        mp[g].strands = parts[g].strands.get(); mp[g].thresh = parts[g].thresh.get();
-        mp[g].thresh_len = L; mp[g].thresh_on_device = 1; mp[g].rows_on_device = 1;
+    if (have_folded) merged_ = std::move(folded);
+    else {                                       // a single partition: the fold of one (filters by the minimum length)
+        mmt_partition one;
+        one.n_rows = first.n_rows; one.n_docs = first.n_docs; one.length = first.length.get(); one.offsets = first.offsets.get();
+        one.strands = first.strands.get(); one.thresh = first.thresh.get();
+        one.thresh_len = L; one.thresh_on_device = 1; one.rows_on_device = 1;
+        merged_ = anchor_merge(*this, &one, 1, p.min_match_len);
     }
-    merged_ = anchor_merge(*this, mp.data(), G, p.min_match_len);
     sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions
     merged_text_ = format_merged(*this, merged_);
     download_merged(*this, merged_);

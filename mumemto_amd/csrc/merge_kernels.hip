@@ -19,6 +19,11 @@ static inline unsigned grid_for(uint64_t items, unsigned per_block) {
     if (g >= (1ull << 24)) throw HipError("kernel launch of 2^32 work-items or more (" + std::to_string(items) + " items)");
     return (unsigned)(g ? g : 1);
 }
+// for grid-stride kernels
+static inline unsigned grid_capped(uint64_t items, unsigned per_block) {
+    const uint64_t g = (items + per_block - 1) / per_block;
+    return (unsigned)(g ? (g < (1ull << 20) ? g : (1ull << 20)) : 1);
+}
 
 __global__ void k_leaf_keys(const int64_t* __restrict__ offsets, uint32_t n_rows, uint32_t n_docs, uint64_t L,
                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {
@@ -94,24 +99,26 @@ __global__ void k_materialise(SideView side, const uint32_t* __restrict__ perm, 
                               uint32_t n_docs_out, const uint32_t* __restrict__ col_part,
                               uint32_t* __restrict__ out_len, int64_t* __restrict__ out_off,
                               uint8_t* __restrict__ out_st) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)side.n * n_docs_out) return;
-    const uint32_t i = (uint32_t)(t / n_docs_out), col = (uint32_t)(t % n_docs_out);
-    const uint32_t row = perm ? perm[i] : i;
-    const uint32_t g = col_part[col];
-    const PartTable P = parts[g];
-    const uint32_t c = col - P.first_col + P.skip;
-    const uint64_t li = (uint64_t)row * side.n_parts + g;
-    const uint64_t cell = (uint64_t)side.src[li] * P.n_docs + c;
-    const uint8_t sd = P.strands[cell];
-    out_off[t] = P.offsets[cell] + (sd ? side.plus[li] : side.minus[li]);
-    out_st[t] = sd;
-    if (col == 0) out_len[i] = side.len[row];
+    // grid-stride: 45 million rows x 94 documents are more cells than one launch has work-items
+    const uint64_t total = (uint64_t)side.n * n_docs_out, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint32_t i = (uint32_t)(t / n_docs_out), col = (uint32_t)(t % n_docs_out);
+        const uint32_t row = perm ? perm[i] : i;
+        const uint32_t g = col_part[col];
+        const PartTable P = parts[g];
+        const uint32_t c = col - P.first_col + P.skip;
+        const uint64_t li = (uint64_t)row * side.n_parts + g;
+        const uint64_t cell = (uint64_t)side.src[li] * P.n_docs + c;
+        const uint8_t sd = P.strands[cell];
+        out_off[t] = P.offsets[cell] + (sd ? side.plus[li] : side.minus[li]);
+        out_st[t] = sd;
+        if (col == 0) out_len[i] = side.len[row];
+    }
 }
 void materialise(SideView side, const uint32_t* perm, const PartTable* parts, uint32_t n_docs_out,
                  const uint32_t* col_part, uint32_t* out_len, int64_t* out_off, uint8_t* out_st, hipStream_t s) {
     if (!side.n) return;
-    hipLaunchKernelGGL(k_materialise, dim3(grid_for((uint64_t)side.n * n_docs_out, 256)), dim3(256), 0, s, side, perm,
+    hipLaunchKernelGGL(k_materialise, dim3(grid_capped((uint64_t)side.n * n_docs_out, 256)), dim3(256), 0, s, side, perm,
                        parts, n_docs_out, col_part, out_len, out_off, out_st);
     MMT_HIP(hipGetLastError());
 }
@@ -120,17 +127,18 @@ __global__ void k_permute_rows(const uint32_t* __restrict__ perm, uint32_t n, ui
                                const uint32_t* __restrict__ in_len, const int64_t* __restrict__ in_off,
                                const uint8_t* __restrict__ in_st, uint32_t* __restrict__ out_len,
                                int64_t* __restrict__ out_off, uint8_t* __restrict__ out_st) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)n * n_docs) return;
-    const uint32_t i = (uint32_t)(t / n_docs), col = (uint32_t)(t % n_docs);
-    const uint64_t from = (uint64_t)perm[i] * n_docs + col;
-    out_off[t] = in_off[from]; out_st[t] = in_st[from];
-    if (col == 0) out_len[i] = in_len[perm[i]];
+    const uint64_t total = (uint64_t)n * n_docs, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint32_t i = (uint32_t)(t / n_docs), col = (uint32_t)(t % n_docs);
+        const uint64_t from = (uint64_t)perm[i] * n_docs + col;
+        out_off[t] = in_off[from]; out_st[t] = in_st[from];
+        if (col == 0) out_len[i] = in_len[perm[i]];
+    }
 }
 void permute_rows(const uint32_t* perm, uint32_t n, uint32_t n_docs, const uint32_t* in_len, const int64_t* in_off,
                   const uint8_t* in_st, uint32_t* out_len, int64_t* out_off, uint8_t* out_st, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_permute_rows, dim3(grid_for((uint64_t)n * n_docs, 256)), dim3(256), 0, s, perm, n, n_docs,
+    hipLaunchKernelGGL(k_permute_rows, dim3(grid_capped((uint64_t)n * n_docs, 256)), dim3(256), 0, s, perm, n, n_docs,
                        in_len, in_off, in_st, out_len, out_off, out_st);
     MMT_HIP(hipGetLastError());
 }

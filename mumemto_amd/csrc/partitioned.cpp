@@ -57,6 +57,11 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     const bool strict = p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == n_docs) &&
                         (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
     release_columns();                       // what the previous run left behind counts as free memory below
+    // ... and so do its results (a new run replaces them; thresholds and merged tables of a genome-sized anchor are tens of GB)
+    rows_ = HostRows(); rows_pending_ = 0; merged_thresh_valid_ = false; thresh_len_ = 0;
+    merged_ = MergedRows();
+    d_thresh_.release(); d_rows_.release(); d_otext_.release(); d_olen_.release(); d_ooffs_.release(); d_ost_.release();
+    d_omdoc_.release(); d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
     const bool auto_limit = max_text == 0;
     if (auto_limit) max_text = auto_max_text();
     partitions_used_ = 1;
@@ -79,6 +84,14 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
         throw std::runtime_error("the text (" + std::to_string(total) + " characters) does not fit the device as one "
                                  "suffix array (limit " + std::to_string(max_text) + ") and only strict multi-MUMs "
                                  "can be computed by partition + anchor merge (include/pfp_mum.hpp:178-183)");
+    // A partition shares the device with what the sequence of partitions keeps: both input buffers (the next
+    // partition is uploaded while this one runs: one byte per text character), the threshold columns (this run's, for
+    // both strands; the partition's copy; the fold so far) and the scratch of a fold step -- 16 bytes per anchor base.
+    if (auto_limit && !std::getenv("MMT_MAX_TEXT")) {
+        const double budget = 0.95 * (double)pool::available(device_) - 16.0 * (double)doc_len[0];
+        const uint64_t fit = budget > 0 ? (uint64_t)(budget / 17.0) : 0;
+        max_text = std::min(max_text, std::max<uint64_t>(fit, 1));
+    }
     // contiguous groups of documents 1..N-1, each together with the anchor within max_text
     const uint64_t anchor_chars = mult * (doc_len[0] + 1);
     std::vector<std::pair<size_t, size_t>> groups;      // [first, last) document indices
@@ -165,6 +178,14 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
             MMT_HIP(hipStreamSynchronize(stream_));
             for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
+            // the columns of this partition are dead (the next run builds its own; only the last partition's anchor ranks
+            // order the result): the fold and the growing row table get their memory
+            if (g + 1 < G) release_columns();
+            else {
+                release_sort_scratch();
+                d_text_.release(); d_cols_.release(); d_sa_.release(); d_sa_hi_.release(); d_bwt_.release();
+                d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_cand_.release(); d_flags_.release();
+            }
             if (g >= 1) {
                 auto as_partition = [&](mmt_partition& m, size_t rows, size_t docs, const uint32_t* len, const int64_t* off,
                                         const uint8_t* st, const uint16_t* th) {

@@ -1288,7 +1288,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         __builtin_amdgcn_wave_barrier();     // the queue is private to the wave: LDS keeps its writes and reads in order
 
         // ---- phase 2: every wave drains its own queue ----
-        for (uint32_t wi = lane; wi < qn; wi += 64) {
+        // General modes walk their queue twice: first counting the intervals the walks produce, then -- after ONE slot
+        // allocation per wave and tile in the global list -- writing them.  (With merge metadata on two haplotypes every
+        // other position closes an interval: 5.9 G candidates per whole-genome partition, and an allocation per wave and
+        // step of the walk ran at the rate of one counter word, 220 atomics per microsecond: 1.1 s per partition.)
+        uint32_t wave_base = 0, wave_off = 0;
+        for (int pass = EXACT ? 1 : 0; pass < 2; pass++) {
+        uint32_t counted = 0;
+        auto drain = [&](uint32_t wi) {
             const uint32_t o = my_queue[wi];
             const uint32_t lj = shift + o;
             const uint32_t closing = s_lcp[lj];
@@ -1303,7 +1310,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                     if (slot < OUT_CAP) s_out[slot] = c;
                     else { uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
                 }
-                continue;
+                return;
             }
             // general case: finish the walk from s = j - w - 1 leftwards
             // a BWT change among the entries k .. j-1?  Two lookups in the window table of the change bytes (the walk
@@ -1314,21 +1321,29 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             while (lk > 0) {
                 const uint32_t v = s_lcp[lk - 1];
                 chg |= s_bwt[16 + lk] != s_bwt[16 + lk - 1];
-                if (v < m) {
-                    const uint32_t cnt = lj - lk + 1;
-                    if (cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all)) {
-                        Cand c; c.start = (uint32_t)(lds_lo + lk - 1); c.end = (uint32_t)(lds_lo + lj - 1); c.len = m;
-                        c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
-                        uint32_t slot = atomicAdd(&s_on, 1u);
-                        if (slot < OUT_CAP) s_out[slot] = c;
-                        else { uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
+                const uint32_t cnt = lj - lk + 1;
+                const bool emit = v < m && cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all);
+                if (pass == 0) counted += emit ? 1u : 0u;
+                else {
+                    const uint64_t em = __ballot(emit);                     // (the lanes still walking take part)
+                    if (emit) {
+                        const uint32_t g = wave_base + wave_off + (uint32_t)__popcll(em & ((1ull << lane) - 1));
+                        if (g < a.capacity) {
+                            Cand c; c.start = (uint32_t)(lds_lo + lk - 1); c.end = (uint32_t)(lds_lo + lj - 1); c.len = m;
+                            c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
+                            a.out[g] = c;
+                        }
                     }
+                    wave_off += (uint32_t)__popcll(em);
+                }
+                if (v < m) {
                     m = v;
                     if (m <= closing || m < a.min_len) { done = true; break; }
                 }
                 lk--;
                 if (a.cap && lj - lk + 1 > a.cap) { done = true; break; }  // every further interval is too big
             }
+            if (pass == 0) return;
             if (!done && lds_lo > 0) {
                 // left the staged halo (uncapped modes / very large caps): continue in the global columns
                 const uint64_t j = lds_lo + lj;
@@ -1354,6 +1369,24 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 // ran off the left extension of a range that does not start the stream: the host repeats the range
                 if (!fin && a.more_left) atomicAdd(a.d_count + 4, 1u);
             } else if (!done && a.more_left) atomicAdd(a.d_count + 4, 1u);
+        };
+        for (uint32_t w0 = 0; w0 < qn; w0 += 64) {               // uniform over the wave: the lanes meet again after each entry
+            if (w0 + lane < qn) drain(w0 + lane);
+            if (!EXACT && pass == 1) {
+                // the lane that walked longest saw every allocation of this round
+#pragma unroll
+                for (int x = 32; x >= 1; x >>= 1) { const uint32_t y = __shfl_xor(wave_off, x, 64); wave_off = y > wave_off ? y : wave_off; }
+            }
+        }
+        if (pass == 0) {
+            // the wave's share of the global list
+#pragma unroll
+            for (int x = 32; x >= 1; x >>= 1) counted += __shfl_xor(counted, x, 64);
+            uint32_t at = 0;
+            if (lane == 0 && counted) at = atomicAdd(a.d_count, counted);
+            wave_base = __shfl(at, 0, 64);
+            wave_off = 0;
+        }
         }
         lds_barrier();
         const uint32_t filled = s_on < OUT_CAP ? s_on : OUT_CAP;

@@ -14,8 +14,14 @@
 #include <iostream>
 #include <thread>
 
+#include <csignal>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "dist.hpp"
 #include "engine.hpp"
 #include "fasta.hpp"
+#include "merge.hpp"
 #include "options.hpp"
 
 namespace fs = std::filesystem;
@@ -129,6 +135,138 @@ static void put40(std::vector<uint8_t>& b, uint64_t v) {
     for (int k = 0; k < 5; k++) b.push_back((uint8_t)(v >> (8 * k)));
 }
 
+// ---- --gpus N: one process per GPU -----------------------------------------------------------------------------------
+// The launcher starts N copies of itself (--rank r --comm-file F, device r); rank 0 makes the RCCL id and leaves it in F.
+// Strict multi-MUMs: the reference's own workflow (README.md:124-141: partitions that share the anchor, -M -n, then
+// anchor_merge) with the files between the tools replaced by mmt::dist_merge -- rank r runs {anchor} + its share of the
+// other documents (as partitions of its own if that share is larger than one suffix array), row tables and thresholds
+// travel HBM -> HBM, rank 0 folds, re-sorts into direct-run order and writes PREFIX.mums / PREFIX.lengths (/ .athresh).
+// Other modes (the reference refuses to merge them, include/pfp_mum.hpp:178-183): every rank builds the stream of the
+// whole collection and scans its share of the suffix-array positions; rank 0 writes the concatenated bytes.
+static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
+    const std::string comm_file = o.output_prefix + ".comm." + std::to_string((long)getpid());
+    std::remove(comm_file.c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < o.gpus; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) throw CliError{"cannot start rank " + std::to_string(r), 1};
+        if (pid == 0) {
+            std::vector<std::string> args(argv, argv + argc);
+            args.push_back("--rank"); args.push_back(std::to_string(r));
+            args.push_back("--comm-file"); args.push_back(comm_file);
+            std::vector<char*> av;
+            for (auto& s : args) av.push_back(const_cast<char*>(s.c_str()));
+            av.push_back(nullptr);
+            if (!std::getenv("MUMEMTO_SHARE_DEVICE")) setenv("MUMEMTO_DEVICE", std::to_string(r).c_str(), 1);
+            execv("/proc/self/exe", av.data());
+            std::_Exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (size_t left = kids.size(); left;) {
+        int st = 0;
+        const pid_t done = wait(&st);
+        if (done < 0) break;
+        left--;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+        if (code && !rc) {                   // a rank failed: the others would wait for it in a collective for ever
+            rc = code;
+            for (pid_t k : kids) if (k != done) kill(k, SIGTERM);
+        }
+    }
+    std::remove(comm_file.c_str());
+    return rc;
+}
+
+static void leave_id(const std::string& path, const uint8_t id[128]) {
+    const std::string tmp = path + ".tmp";
+    { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char*>(id), 128); }
+    std::rename(tmp.c_str(), path.c_str());
+}
+static void fetch_id(const std::string& path, uint8_t id[128]) {
+    for (int tries = 0; tries < 360000; tries++) {         // an hour: rank 0 writes it after its partition has run
+        std::ifstream f(path, std::ios::binary);
+        if (f && f.read(reinterpret_cast<char*>(id), 128)) return;
+        usleep(10000);
+    }
+    throw CliError{"rank 0 never left the communicator id in " + path, 1};
+}
+
+static int run_rank(BuildOptions& o) {
+    const int rank = o.rank, world = o.gpus;
+    const bool mum_mode = o.validate();
+    if (o.from_parse_flag || o.arrays_in_flag || o.only_parse || o.keep_temp || o.arrays_out || o.binary || (o.merge && !o.anchor_merge))
+        throw CliError{"--gpus runs the plain FASTA -> .mums / .mems job (with -n if wanted); -p -a -P -K -A -b -M are single-GPU options", 1};
+    const std::vector<std::string> inputs = resolve_inputs(o);
+    o.set_parameters(inputs.size(), mum_mode);
+    const size_t N = inputs.size();
+    const bool strict = mum_mode && (o.num_distinct_docs == 0 || (size_t)o.num_distinct_docs == N);
+    if (strict && N - 1 < (size_t)world) throw CliError{"--gpus: fewer documents next to the anchor than GPUs", 1};
+    if (rank == 0) for (const auto& n : o.notes) log_line("build_main", n);
+    // this rank's documents: the anchor + a contiguous block of the others (strict), or everything
+    std::vector<std::string> mine;
+    if (strict) {
+        const size_t rest = N - 1, base = rest / world, extra = rest % world;
+        const size_t first = 1 + (size_t)rank * base + std::min<size_t>(rank, extra), count = base + ((size_t)rank < extra ? 1 : 0);
+        mine.push_back(inputs[0]);
+        mine.insert(mine.end(), inputs.begin() + first, inputs.begin() + first + count);
+    } else mine = inputs;
+    Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
+    HostArena arena;
+    HostDocs hd;
+    std::vector<FastaDoc> docs;
+    const long empty = read_fasta_collection(mine, docs, arena, hd);
+    if (empty >= 0) throw CliError{"Empty input file found: " + mine[(size_t)empty], 1};
+    // PREFIX.lengths in pieces: every rank describes the documents only it has read, rank 0 joins them after the exchange
+    if (strict) {
+        std::vector<FastaDoc> part(docs.begin() + (rank ? 1 : 0), docs.end());
+        write_lengths_file(o.output_prefix + ".rank" + std::to_string(rank), part);
+    } else if (rank == 0) write_lengths_file(o.output_prefix, docs);
+    mmt_params p{};
+    p.min_match_len = (uint32_t)o.min_match_len;
+    p.num_distinct = (uint64_t)o.num_distinct_docs;
+    p.max_doc_freq = o.rare_freq;
+    p.max_total_freq = o.max_mem_freq;
+    p.use_revcomp = o.use_rcomp ? 1 : 0;
+    p.merge_metadata = strict ? 1 : 0;
+    if (strict) { p.num_distinct = 0; p.max_total_freq = 0; }
+    else eng.set_scan_shard((uint32_t)rank, (uint32_t)world);
+    eng.run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), p, 0);
+    uint8_t id[128];
+    if (rank == 0) { comm_unique_id(id); leave_id(o.comm_file, id); } else fetch_id(o.comm_file, id);
+    Comm* comm = comm_create(eng, rank, world, id);
+    size_t rows = 0;
+    if (strict) {
+        bool root = false;
+        MergedRows merged = dist_merge(*comm, (uint32_t)o.min_match_len, &root);
+        if (root) {
+            const std::string text = format_merged(eng, merged);
+            write_file(o.output_prefix + ".mums", text.data(), text.size());
+            rows = merged.n_rows;
+            if (o.anchor_merge) {
+                download_merged(eng, merged);
+                write_file(o.output_prefix + ".athresh", merged.thresh.data(), merged.thresh.size() * sizeof(uint16_t));
+            }
+            std::ofstream all(o.output_prefix + ".lengths", std::ios::binary);
+            for (int r = 0; r < world; r++) {
+                const std::string piece = o.output_prefix + ".rank" + std::to_string(r) + ".lengths";
+                { std::ifstream in(piece, std::ios::binary); all << in.rdbuf(); }
+                std::remove(piece.c_str());
+            }
+        }
+    } else {
+        (void)eng.rows(Engine::ROWS_TEXT);
+        const std::string text = dist_gather_text(*comm);
+        if (rank == 0) write_file(o.output_prefix + (mum_mode ? ".mums" : ".mems"), text.data(), text.size());
+    }
+    comm_destroy(comm);
+    if (rank == 0) log_line("build_main", strict ? "Found " + std::to_string(rows) + " matches on " + std::to_string(world) + " GPUs!"
+                                                  : "matches of " + std::to_string(world) + " GPUs written");
+    std::fflush(stdout); std::fflush(stderr);
+    std::_Exit(0);
+}
+
 int main(int argc, char** argv) {
     mark("main");
     std::fprintf(stderr, "\nmumemto_exec (MI355X / gfx950 build of the mumemto 1.4.0 hot path)\n");
@@ -137,6 +275,9 @@ int main(int argc, char** argv) {
     try {
         o.parse(argc, argv);
         if (o.help) { std::fputs(usage_text().c_str(), stderr); return 0; }
+        if (o.gpus < 1) throw CliError{"--gpus needs a positive number", 1};
+        if (o.rank >= 0) return run_rank(o);
+        if (o.gpus > 1 || std::getenv("MUMEMTO_FORCE_RANKS")) { (void)o.validate(); return launch_ranks(argc, argv, o); }
         const bool mum_mode = o.validate();
         const bool checkpoint = o.from_parse_flag || o.arrays_in_flag;
         std::vector<uint64_t> doc_len;

@@ -174,7 +174,7 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
     if (c.world == 1) {
         // one partition: nothing to fold; the rows are the engine's own, already in direct-run order
         MergedRows m;
-        m.n_rows = parts[0].n_rows; m.n_docs = parts[0].n_docs;
+        m.n_rows = parts[0].n_rows; m.n_docs = parts[0].n_docs; m.thresh_len = L;
         m.d_length.ensure(m.n_rows + 1); m.d_offsets.ensure(m.n_rows * m.n_docs + 1); m.d_strands.ensure(m.n_rows * m.n_docs + 1);
         m.d_thresh.ensure(L);
         if (m.n_rows) {

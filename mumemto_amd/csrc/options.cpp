@@ -32,6 +32,8 @@ void BuildOptions::parse(int argc, char** argv) {
         {"window", required_argument, nullptr, 'w'},  {"rare", required_argument, nullptr, 'f'},
         {"binary", no_argument, nullptr, 'b'},        {"merge", no_argument, nullptr, 'M'},
         {"anchor", no_argument, nullptr, 'n'},        {"use-gsacak", no_argument, nullptr, 'g'},
+        {"gpus", required_argument, nullptr, 1000},   {"rank", required_argument, nullptr, 1001},
+        {"comm-file", required_argument, nullptr, 1002},
         {nullptr, 0, nullptr, 0}};
     optind = 1;
     int c;
@@ -57,6 +59,9 @@ void BuildOptions::parse(int argc, char** argv) {
             case 'n': anchor_merge = true; break;
             case 'g': use_gsacak = true; break;
             case 'P': only_parse = true; break;
+            case 1000: gpus = std::atoi(optarg); break;
+            case 1001: rank = std::atoi(optarg); break;
+            case 1002: comm_file = optarg; break;
             default: throw CliError{usage_text(), 1};
         }
     }
@@ -167,6 +172,9 @@ std::string usage_text() {
            "\t-k, --minimum-genomes [INT]     find matches in at least k sequences (k < 0: N - |k|; default: all)\n"
            "\t-f, --rare            [INT]     maximum number of occurences per sequence (0 = no limit; default 1)\n"
            "\t-F, --max-freq        [INT]     maximum number of total occurences (negative: relative to N)\n"
+           "Several GPUs of this node (one process per GPU, exchange over RCCL):\n"
+           "\t    --gpus            [INT]     strict multi-MUMs: anchor partitions, one per GPU, merged like `mumemto merge`;\n"
+           "\t                                other modes: every GPU builds the stream and scans its share of it\n"
            "Accepted for compatibility (the GPU pipeline has no use for them):\n"
            "\t-g, --use-gsacak  -s, --no-overlap\n"
            "PFP options:\n"

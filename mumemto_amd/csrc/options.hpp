@@ -38,6 +38,10 @@ struct BuildOptions {
     bool use_gsacak = false;
     bool only_parse = false;
     bool help = false;
+    // --gpus N: one process per GPU of this node (cli_main.cpp).  --rank / --comm-file are what the launcher hands its ranks.
+    int gpus = 1;
+    int rank = -1;
+    std::string comm_file;
     std::vector<std::string> notes;  // FORCE_LOG lines the reference would print
 
     // argv -> fields; throws CliError for unknown options.

@@ -197,3 +197,34 @@ def test_engine_accepts_text_and_stream():
         eng.run(use_revcomp=revcomp)
         assert eng.output_text() == want.text()
         eng.close()
+
+
+def test_gpus_option_runs_one_process_per_gpu_and_the_rccl_exchange(inputs):
+    """`mumemto_exec --gpus N`: a launcher + one rank process per GPU, the C++ exchange of dist.cpp (RCCL) between them.
+    This box has one GPU, so the launcher is forced for N = 1 (MUMEMTO_FORCE_RANKS): the rank process, the communicator
+    id left in a file, the collective calls, the fold and the writers all run; what a second rank adds are more
+    broadcasts of the same kind (tests/test_gpu_dist.py runs the fold over several partitions)."""
+    tmp, docs, paths = inputs
+    N = len(docs)
+    env = dict(os.environ, MUMEMTO_FORCE_RANKS="1")
+    for name, args, kw, ext in [
+        ("r_def", [], dict(max_total_freq=N), "mums"),
+        ("r_n", ["-n", "-l", "15"], dict(max_total_freq=N, min_len=15, merge=True), "mums"),
+        ("r_mem", ["-k", "-1", "-f", "3"], dict(num_distinct=N - 1, max_doc_freq=3, max_total_freq=3 * N), "mems"),
+    ]:
+        r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "--gpus", "1", "-o", str(tmp / name)] + args + paths, cwd=tmp,
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        want = O.run(docs, **kw)
+        assert (tmp / (name + "." + ext)).read_bytes() == want.text(), name
+        if "-n" in args:
+            got = np.frombuffer((tmp / (name + ".athresh")).read_bytes(), np.uint16)
+            assert np.array_equal(got, want.thresh()[: len(docs[0][0]) + 1])
+        assert not glob.glob(str(tmp / (name + ".comm.*"))) and not glob.glob(str(tmp / (name + ".rank*")))
+    # the lengths file of the rank processes is the one a single process writes
+    cli(["-o", str(tmp / "r_one")] + paths, tmp)
+    assert (tmp / "r_def.lengths").read_bytes() == (tmp / "r_one.lengths").read_bytes()
+    # a request the launcher cannot serve fails with a message, not a hang
+    r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "--gpus", "9", "-o", str(tmp / "r_bad")] + paths, cwd=tmp,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "fewer documents" in r.stderr

@@ -14,6 +14,7 @@ haps, length = int(sys.argv[1]), int(sys.argv[2])
 div = float(sys.argv[3]) if len(sys.argv) > 3 else 0.001
 compare = sys.argv[4] if len(sys.argv) > 4 else "pfp"
 checks = sys.argv[5] if len(sys.argv) > 5 else "light"
+wp = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (0, 0)      # PFP window / modulus of a forced guided run
 t = time.perf_counter()
 bases = np.empty(haps * length, np.uint8)
 for h, b in synth.haplotypes_sparse(haps, length, div, 11):
@@ -24,7 +25,7 @@ print("generated %d x %d bp in %.1f s; text = %.3f G chars" % (haps, length, tim
 eng = mumemto_amd.Engine(0)
 out = {}
 for kind in (["guided", "pfp"] if compare == "pfp" else ["guided"]):
-    eng.set_producer("guided" if kind == "guided" and compare not in ("auto", "parts") else "auto")
+    eng.set_producer("guided" if kind == "guided" and compare not in ("auto", "parts") else "auto", *wp)
     for rep in range(2 if kind == "guided" else 1):
         t = time.perf_counter()
         parts = eng.run_partitioned(None, flat=(bases, lens))

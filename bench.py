@@ -194,9 +194,8 @@ def main():
         parts = mdist.all_gather_partitions_device((len_t, off_t, st_t, th), dist)
         merged = None
         if rank == 0:
-            merged = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False)
-            with open(out_prefix + ".mums", "wb") as f:
-                f.write(merged["text"])
+            merged = eng.anchor_merge(mdist.device_partitions(parts), sort_like_direct=True, want_rows=False,
+                                      text_file=out_prefix + ".mums")
         if timed:
             phases["read"] += sec["read"]; phases["run"] += sec["run"]
             phases["exchange_fold"] += time.perf_counter() - t0

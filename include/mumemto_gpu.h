@@ -211,6 +211,8 @@ MMT_API int mmt_merged_from_rows(mmt_engine* e, const uint32_t* length, const in
  * document 0 must be the anchor.                              */
 MMT_API int mmt_merged_sort_like_direct(mmt_engine* e, mmt_merged* m);
 MMT_API const char* mmt_merged_text(mmt_merged* m, size_t* len);
+/* PREFIX.mums straight from the library (no copy of the bytes through the caller) */
+MMT_API int mmt_merged_write_text(mmt_merged* m, const char* path);
 MMT_API void mmt_merged_free(mmt_merged* m);
 
 /* ---- multi-GPU exchange, one process per GPU (RCCL over xGMI) ------------------------------

@@ -73,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
-    "mmt_dist_gather_text",
+    "mmt_dist_gather_text", "mmt_merged_write_text",
 ]
 
 
@@ -175,6 +175,7 @@ def load_library():
     L.mmt_merged_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 4
     L.mmt_rows_mum_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
     L.mmt_merged_sort_like_direct.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_merged_write_text.argtypes = [C.c_void_p, C.c_char_p]
     L.mmt_merged_text.restype = C.c_void_p
     L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.mmt_merged_free.argtypes = [C.c_void_p]
@@ -498,10 +499,11 @@ class Engine:
         return list(out)
 
     # anchor merge
-    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20):
+    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20, text_file=None):
         """parts: list of DevicePartition, or of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh)
         where thresh is a numpy u16 array (host) or a device address paired as (ptr, length).
-        want_rows=False returns only the PREFIX.mums bytes (no D2H of the tables)."""
+        want_rows=False returns only the PREFIX.mums bytes (no D2H of the tables); text_file: the library writes them
+        there itself and the result carries no "text"."""
         arr = (Partition * len(parts))()
         keep = []
         for i, part in enumerate(parts):
@@ -530,11 +532,15 @@ class Engine:
             if sort_like_direct:
                 _check(self.L.mmt_merged_sort_like_direct(self.h, m))
             n, nd = self.L.mmt_merged_rows(m), self.L.mmt_merged_docs(m)
-            k = C.c_size_t()
-            ptr = self.L.mmt_merged_text(m, C.byref(k))
-            if not ptr and n:
-                raise MumemtoError(self.L.mmt_last_error().decode())
-            text = _bytes_at(ptr, k.value)
+            if text_file is not None:
+                _check(self.L.mmt_merged_write_text(m, os.fsencode(text_file)))
+                text = None
+            else:
+                k = C.c_size_t()
+                ptr = self.L.mmt_merged_text(m, C.byref(k))
+                if not ptr and n:
+                    raise MumemtoError(self.L.mmt_last_error().decode())
+                text = _bytes_at(ptr, k.value)
             if not want_rows:
                 return dict(text=text, n_rows=n, n_docs=nd)
             length = np.zeros(max(n, 1), np.uint32)

@@ -577,6 +577,15 @@ const char* mmt_merged_text(mmt_merged* m, size_t* len) {
     if (len) *len = m->text.size();
     return m->text.data();
 }
+int mmt_merged_write_text(mmt_merged* m, const char* path) {
+    if (!m || !path) return fail(1, "null");
+    size_t len = 0;
+    const char* text = mmt_merged_text(m, &len);
+    if (!text && len) return 2;
+    MMT_TRY
+    mmt::write_file_bytes(path, text, len);
+    MMT_CATCH
+}
 void mmt_merged_free(mmt_merged* m) { delete m; }
 
 }  // extern "C"

@@ -579,11 +579,9 @@ const char* mmt_merged_text(mmt_merged* m, size_t* len) {
 }
 int mmt_merged_write_text(mmt_merged* m, const char* path) {
     if (!m || !path) return fail(1, "null");
-    size_t len = 0;
-    const char* text = mmt_merged_text(m, &len);
-    if (!text && len) return 2;
     MMT_TRY
-    mmt::write_file_bytes(path, text, len);
+    if (m->text_valid) mmt::write_file_bytes(path, m->text.data(), m->text.size());
+    else mmt::write_merged_text(*m->engine, m->rows, path);
     MMT_CATCH
 }
 void mmt_merged_free(mmt_merged* m) { delete m; }

@@ -142,6 +142,8 @@ public:
     size_t scan_ranges() const { return scan_ranges_; }
     const float* stage_ms() const { return stage_ms_; }
     DevBuf<uint8_t>& scratch() { return d_temp_; }
+    // page-locked staging of a merged result's .mums bytes on their way to a file (grows only; merge.cpp)
+    char* merge_text_staging(size_t n) { h_merge_text_.ensure(n); return h_merge_text_.get(); }
 
 private:
     void layout_docs(bool revcomp);
@@ -208,7 +210,7 @@ private:
     PinnedBuf<int64_t> h_offs_;
     PinnedBuf<uint8_t> h_st_;
     PinnedBuf<uint64_t> h_occ_start_, h_mdoc_;
-    PinnedBuf<char> h_text_;
+    PinnedBuf<char> h_text_, h_merge_text_;
 
     HostRows rows_;
     int rows_pending_ = 0;                // ROWS_* bits that still sit in HBM only

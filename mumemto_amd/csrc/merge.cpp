@@ -2,6 +2,7 @@
 // are uploaded once, every fold step is a handful of launches plus one 8-byte read-back (the
 // number of new rows), and the merged tables are materialised and formatted on the device.
 #include "merge.hpp"
+#include "fasta.hpp"
 
 #include <algorithm>
 #include <map>
@@ -244,9 +245,10 @@ void sort_like_direct(Engine& e, MergedRows& m) {
     m.on_host = false;
 }
 
-std::string format_merged(Engine& e, const MergedRows& m) {
+// .mums bytes of the merged rows in HBM; returns their number
+static size_t format_merged_device(Engine& e, const MergedRows& m, DevBuf<char>& text) {
     const size_t n = m.n_rows;
-    if (!n) return std::string();
+    if (!n) return 0;
     hipStream_t st = e.stream();
     MMT_HIP(hipSetDevice(e.device()));
     DevBuf<uint64_t> tlen, toff;
@@ -258,14 +260,31 @@ std::string format_merged(Engine& e, const MergedRows& m) {
     MMT_HIP(hipMemcpyAsync(&last[1], tlen.get() + (n - 1), 8, hipMemcpyDeviceToHost, st));
     MMT_HIP(hipStreamSynchronize(st));
     const size_t bytes = (size_t)(last[0] + last[1]);
-    DevBuf<char> text;
     text.ensure(bytes + 1);
     mk::table_write(m.d_length.get(), m.d_offsets.get(), m.d_strands.get(), (uint32_t)n, (uint32_t)m.n_docs, toff.get(),
                     text.get(), st);
+    return bytes;
+}
+
+std::string format_merged(Engine& e, const MergedRows& m) {
+    DevBuf<char> text;
+    const size_t bytes = format_merged_device(e, m, text);
+    if (!bytes) return std::string();
     std::string out(bytes, '\0');
-    MMT_HIP(hipMemcpyAsync(&out[0], text.get(), bytes, hipMemcpyDeviceToHost, st));
-    MMT_HIP(hipStreamSynchronize(st));
+    MMT_HIP(hipMemcpyAsync(&out[0], text.get(), bytes, hipMemcpyDeviceToHost, e.stream()));
+    MMT_HIP(hipStreamSynchronize(e.stream()));
     return out;
+}
+
+void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) {
+    DevBuf<char> text;
+    const size_t bytes = format_merged_device(e, m, text);
+    char* host = e.merge_text_staging(bytes + 1);       // (a fresh std::string of 900 MB costs more than the copy into it)
+    if (bytes) {
+        MMT_HIP(hipMemcpyAsync(host, text.get(), bytes, hipMemcpyDeviceToHost, e.stream()));
+        MMT_HIP(hipStreamSynchronize(e.stream()));
+    }
+    write_file_bytes(path, host, bytes);
 }
 
 void download_merged(Engine& e, MergedRows& m) {

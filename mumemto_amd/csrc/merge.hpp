@@ -18,6 +18,8 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
 void sort_like_direct(Engine& e, MergedRows& m);
 // mumsio::write_mums / serialize_mum (include/mumsio.hpp:281-294, :311-320), formatted on the device
 std::string format_merged(Engine& e, const MergedRows& m);
+// the same bytes, formatted in HBM, staged in page-locked memory that stays with the engine, written to `path`
+void write_merged_text(Engine& e, const MergedRows& m, const std::string& path);
 // host copies of the rows and thresholds (m.length / m.offsets / m.strands / m.thresh)
 void download_merged(Engine& e, MergedRows& m);
 

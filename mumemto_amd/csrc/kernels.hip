@@ -966,7 +966,6 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                                                 uint32_t klev) {
     constexpr int TILE = BLOCK * VG * 4;
     constexpr int MAXG = VG + 1;                        // groups of 4 per thread incl. halo (halo <= 4 * BLOCK)
-    constexpr uint32_t FLUSH_AT = OUT_CAP / 2;
     constexpr bool USE_C = EXACT || K0 > 0;             // a window of one entry needs no table for its BWT test
     const uint32_t span = halo + TILE;
     extern __shared__ __align__(16) uint8_t smem[];
@@ -980,15 +979,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
     Cand* s_out = reinterpret_cast<Cand*>(s_queue + TILE);                  // OUT_CAP
     uint32_t* s_C = reinterpret_cast<uint32_t*>(s_out + OUT_CAP);           // span / 4 + 8 words of 4 change bytes
     uint16_t* s_L = reinterpret_cast<uint16_t*>(s_C);                       // VH: span + 16 running maxima instead
-    __shared__ uint32_t s_on, s_base;
     __shared__ uint32_t s_wtot[(VG + 1) * (BLOCK / 64)];
+    __shared__ uint32_t s_wcnt[BLOCK / 64 + 1];
+    __shared__ uint32_t s_on;
+    if (threadIdx.x == 0) s_on = 0;
     const uint32_t lane = threadIdx.x & 63;
     uint16_t* my_queue = s_queue + (threadIdx.x >> 6) * (VG * 256);       // VG passes x 64 lanes x 4 positions
     const uint32_t wstep = 1u << klev;
     // misalignment of the two query windows; the right one is aligned as soon as its step is a multiple of 4
     const uint32_t rl = (0u - w) & 3u, rr = K0 >= 2 ? 0u : (0u - wstep) & 3u;
     const uint32_t* tbl = s_T;
-    if (threadIdx.x == 0) { s_on = 0; }
     bool by_dma = false;
     uint32_t cur = 0;
     const uint32_t wave = threadIdx.x >> 6;
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                         for (int t = 0; t < 4; t++) {
                             bool ok = mv[t] > cv[t] && mv[t] >= a.min_len;
                             if (!INT) ok = ok && tile0 + o + t >= jmin && tile0 + o + t < a.n && lj + t >= w;
-                            if (EXACT) ok = ok && ((chg4 >> (8 * t)) & 0xffu);
+                            if (EXACT) ok = ok && (a.emit_all || ((chg4 >> (8 * t)) & 0xffu));
                             takes |= ok ? (1u << t) : 0u;
                         }
                     }
@@ -1293,8 +1293,38 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         // other position closes an interval: 5.9 G candidates per whole-genome partition, and an allocation per wave and
         // step of the walk ran at the rate of one counter word, 220 atomics per microsecond: 1.1 s per partition.)
         uint32_t wave_base = 0, wave_off = 0;
-        for (int pass = EXACT ? 1 : 0; pass < 2; pass++) {
+        // (strict multi-MUMs without merge metadata: one position in a thousand is queued and fewer still become candidates --
+        // one pass, the few waves that have one ask for a slot as they go)
+        const bool rare = EXACT && !a.emit_all;
+        for (int pass = rare ? 1 : 0; pass < 2; pass++) {
         uint32_t counted = 0;
+        // one interval [s, e] (LDS indices) of value len: counted in the first pass, stored in the second at the wave's
+        // next slot (the lanes that call this together share one ballot)
+        auto put = [&](bool emit, uint32_t s_idx, uint32_t e_idx, uint32_t len, bool chg) {
+            if (pass == 0) { counted += emit ? 1u : 0u; return; }
+            if (rare) {
+                // into the workgroup's LDS buffer, flushed with one global atomic when half full (a returning global
+                // atomic per candidate would hold its wave -- and at the barrier the tile -- for its latency)
+                if (emit) {
+                    Cand c; c.start = (uint32_t)(lds_lo + s_idx); c.end = (uint32_t)(lds_lo + e_idx); c.len = len;
+                    c.flags = CAND_LEFT_MAXIMAL;
+                    const uint32_t slot = atomicAdd(&s_on, 1u);
+                    if (slot < OUT_CAP) s_out[slot] = c;
+                    else { const uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
+                }
+                return;
+            }
+            const uint64_t em = __ballot(emit);
+            if (emit) {
+                const uint32_t g = wave_base + wave_off + (uint32_t)__popcll(em & ((1ull << lane) - 1));
+                if (g < a.capacity) {
+                    Cand c; c.start = (uint32_t)(lds_lo + s_idx); c.end = (uint32_t)(lds_lo + e_idx); c.len = len;
+                    c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
+                    a.out[g] = c;
+                }
+            }
+            wave_off += (uint32_t)__popcll(em);
+        };
         auto drain = [&](uint32_t wi) {
             const uint32_t o = my_queue[wi];
             const uint32_t lj = shift + o;
@@ -1302,14 +1332,14 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             uint32_t m = umin32(tbl[lj - w], tbl[lj - wstep]);
             uint32_t lk = lj - w;                                           // LDS index of k; candidate start s = k - 1
             if (EXACT) {
-                // the only interval this position can close has w + 1 entries and its BWT bytes differ
-                if (lk > 0 && s_lcp[lk - 1] < m) {
-                    Cand c; c.start = (uint32_t)(lds_lo + lk - 1); c.end = (uint32_t)(lds_lo + lj - 1); c.len = m;
-                    c.flags = CAND_LEFT_MAXIMAL;
-                    uint32_t slot = atomicAdd(&s_on, 1u);
-                    if (slot < OUT_CAP) s_out[slot] = c;
-                    else { uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
+                // the only interval this position can close has w + 1 entries; without merge metadata phase 1 queued it
+                // only if its BWT bytes differ, with it (emit_all) that is looked up here for the flag
+                bool chg = true;
+                if (a.emit_all) {
+                    if (VH) chg = (int32_t)s_L[lj] > (int32_t)lj - (int32_t)w;
+                    else chg = (reinterpret_cast<const uint8_t*>(s_C)[lj - w] | reinterpret_cast<const uint8_t*>(s_C)[lj - wstep]) != 0;
                 }
+                put(lk > 0 && s_lcp[lk - 1] < m, lk - 1, lj - 1, m, chg);
                 return;
             }
             // general case: finish the walk from s = j - w - 1 leftwards
@@ -1323,19 +1353,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 chg |= s_bwt[16 + lk] != s_bwt[16 + lk - 1];
                 const uint32_t cnt = lj - lk + 1;
                 const bool emit = v < m && cnt >= a.num_distinct && (a.cap == 0 || cnt <= a.cap) && (chg || a.emit_all);
-                if (pass == 0) counted += emit ? 1u : 0u;
-                else {
-                    const uint64_t em = __ballot(emit);                     // (the lanes still walking take part)
-                    if (emit) {
-                        const uint32_t g = wave_base + wave_off + (uint32_t)__popcll(em & ((1ull << lane) - 1));
-                        if (g < a.capacity) {
-                            Cand c; c.start = (uint32_t)(lds_lo + lk - 1); c.end = (uint32_t)(lds_lo + lj - 1); c.len = m;
-                            c.flags = chg ? CAND_LEFT_MAXIMAL : 0u;
-                            a.out[g] = c;
-                        }
-                    }
-                    wave_off += (uint32_t)__popcll(em);
-                }
+                put(emit, lk - 1, lj - 1, m, chg);                          // (the lanes still walking take part)
                 if (v < m) {
                     m = v;
                     if (m <= closing || m < a.min_len) { done = true; break; }
@@ -1372,35 +1390,47 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         };
         for (uint32_t w0 = 0; w0 < qn; w0 += 64) {               // uniform over the wave: the lanes meet again after each entry
             if (w0 + lane < qn) drain(w0 + lane);
-            if (!EXACT && pass == 1) {
+            if (pass == 1 && !rare) {
                 // the lane that walked longest saw every allocation of this round
 #pragma unroll
                 for (int x = 32; x >= 1; x >>= 1) { const uint32_t y = __shfl_xor(wave_off, x, 64); wave_off = y > wave_off ? y : wave_off; }
             }
         }
         if (pass == 0) {
-            // the wave's share of the global list
+            // the workgroup's share of the global list: one atomic per tile (the counter word takes about 200 of them
+            // per microsecond, and a tile per wave would be four times as many)
 #pragma unroll
             for (int x = 32; x >= 1; x >>= 1) counted += __shfl_xor(counted, x, 64);
-            uint32_t at = 0;
-            if (lane == 0 && counted) at = atomicAdd(a.d_count, counted);
-            wave_base = __shfl(at, 0, 64);
+            {
+                if (lane == 0) s_wcnt[wave] = counted;
+                lds_barrier();
+                if (threadIdx.x == 0) {
+                    uint32_t tot = 0;
+                    for (int x = 0; x < BLOCK / 64; x++) tot += s_wcnt[x];
+                    s_wcnt[BLOCK / 64] = tot ? atomicAdd(a.d_count, tot) : 0u;
+                }
+                lds_barrier();
+                wave_base = s_wcnt[BLOCK / 64];
+                for (uint32_t x = 0; x < wave; x++) wave_base += s_wcnt[x];
+            }
             wave_off = 0;
         }
         }
-        lds_barrier();
-        const uint32_t filled = s_on < OUT_CAP ? s_on : OUT_CAP;
-        const bool last = tile + gridDim.x >= n_tiles;
-        if (filled >= FLUSH_AT || (last && filled)) {
-            if (threadIdx.x == 0) s_base = atomicAdd(a.d_count, filled);
-            lds_barrier();
-            const uint32_t base = s_base;
-            for (uint32_t i = threadIdx.x; i < filled; i += BLOCK)
-                if (base + i < a.capacity) a.out[base + i] = s_out[i];
-            lds_barrier();
-            if (threadIdx.x == 0) s_on = 0;
+        lds_barrier();                        // the tables of this tile are dead: the next tile of the workgroup may build its own
+        if (rare) {
+            const uint32_t filled = s_on < OUT_CAP ? s_on : OUT_CAP;
+            const bool last = tile + gridDim.x >= n_tiles;
+            if (filled >= OUT_CAP / 2 || (last && filled)) {
+                if (threadIdx.x == 0) s_wcnt[BLOCK / 64] = atomicAdd(a.d_count, filled);
+                lds_barrier();
+                const uint32_t base = s_wcnt[BLOCK / 64];
+                for (uint32_t i = threadIdx.x; i < filled; i += BLOCK)
+                    if (base + i < a.capacity) a.out[base + i] = s_out[i];
+                lds_barrier();
+                if (threadIdx.x == 0) s_on = 0;
+                lds_barrier();
+            }
         }
-        lds_barrier();
     }
 }
 
@@ -1522,7 +1552,8 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     constexpr int TILE = B * VG * 4;
     uint32_t nd = a.num_distinct < 2 ? 2 : a.num_distinct;
     uint32_t w = nd - 1;
-    bool exact = a.cap != 0 && a.cap == nd && !a.emit_all && nd == a.num_distinct;
+    // intervals of exactly nd entries (strict multi-MUMs; with merge metadata the ones whose BWT bytes agree count too)
+    bool exact = a.cap != 0 && a.cap == nd && nd == a.num_distinct;
     if (w > 1000) { w = 1; exact = false; }                // window tables need w <= halo <= 4 * BLOCK
     uint32_t klev = 0;
     while ((2u << klev) <= w) klev++;                      // floor(log2(w))

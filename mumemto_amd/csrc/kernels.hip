@@ -961,7 +961,9 @@ constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, D
 // change positions (exclusive, 16 bits per entry), a wave scan + one carry per wave.  One LDS write + two reads + one
 // write per group of four entries and three barriers, instead of the fused pass + two doubling passes (nine reads,
 // three writes, five barriers) of the level-wise tables.
-template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT, bool VH = false>
+// ALL (with EXACT): merge metadata -- the intervals whose BWT bytes agree are candidates too (compile-time, so that the
+// kernel of the plain strict mode carries none of the dense-list code).
+template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT, bool VH = false, bool ALL = false>
 __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint32_t n_tiles, uint32_t w,
                                                 uint32_t klev) {
     constexpr int TILE = BLOCK * VG * 4;
@@ -1263,7 +1265,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                         for (int t = 0; t < 4; t++) {
                             bool ok = mv[t] > cv[t] && mv[t] >= a.min_len;
                             if (!INT) ok = ok && tile0 + o + t >= jmin && tile0 + o + t < a.n && lj + t >= w;
-                            if (EXACT) ok = ok && (a.emit_all || ((chg4 >> (8 * t)) & 0xffu));
+                            if (EXACT) ok = ok && (ALL || ((chg4 >> (8 * t)) & 0xffu));
                             takes |= ok ? (1u << t) : 0u;
                         }
                     }
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         uint32_t wave_base = 0, wave_off = 0;
         // (strict multi-MUMs without merge metadata: one position in a thousand is queued and fewer still become candidates --
         // one pass, the few waves that have one ask for a slot as they go)
-        const bool rare = EXACT && !a.emit_all;
+        constexpr bool rare = EXACT && !ALL;
         for (int pass = rare ? 1 : 0; pass < 2; pass++) {
         uint32_t counted = 0;
         // one interval [s, e] (LDS indices) of value len: counted in the first pass, stored in the second at the wave's
@@ -1335,7 +1337,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 // the only interval this position can close has w + 1 entries; without merge metadata phase 1 queued it
                 // only if its BWT bytes differ, with it (emit_all) that is looked up here for the flag
                 bool chg = true;
-                if (a.emit_all) {
+                if (ALL) {
                     if (VH) chg = (int32_t)s_L[lj] > (int32_t)lj - (int32_t)w;
                     else chg = (reinterpret_cast<const uint8_t*>(s_C)[lj - w] | reinterpret_cast<const uint8_t*>(s_C)[lj - wstep]) != 0;
                 }
@@ -1578,8 +1580,17 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
         hipLaunchKernelGGL(kernel, g, b, lds, s, a, halo, n_tiles, w, klev);
     };
     const uint32_t k0 = klev < 3 ? klev : 3;
-    if (vh) {
+    if (vh && a.emit_all) {
+        go(k_scan<B, VG, 3, (VH_OUT > 0 ? VH_OUT : OUT_CAP), true, true, true>);
+    } else if (vh) {
         go(k_scan<B, VG, 3, (VH_OUT > 0 ? VH_OUT : OUT_CAP), true, true>);
+    } else if (exact && a.emit_all) {
+        switch (k0) {
+            case 0: go(k_scan<B, VG, 0, OUT_CAP, true, false, true>); break;
+            case 1: go(k_scan<B, VG, 1, OUT_CAP, true, false, true>); break;
+            case 2: go(k_scan<B, VG, 2, OUT_CAP, true, false, true>); break;
+            default: go(k_scan<B, VG, 3, OUT_CAP, true, false, true>); break;
+        }
     } else if (exact) {
         switch (k0) {
             case 0: go(k_scan<B, VG, 0, OUT_CAP, true>); break;

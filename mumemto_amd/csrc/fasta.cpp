@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
@@ -133,6 +134,77 @@ static FastaDoc read_fasta_with(const std::string& path, Sink& bases) {
     return doc;
 }
 
+// Plain FASTA files: read() in blocks that stay in the cache, the bases of every line go straight to the file's slot
+// (memchr + memcpy).  The stream reader above spends ~30 ms of CPU per 64 MB on its layers (zlib's pass-through copy, a
+// refill check per character class) -- what matters when the process may use 16 cores' worth of time per 100 ms.
+// Anything that is not plain multi-FASTA ('@' records, '+' lines) returns false and goes through the stream reader.
+static bool read_plain_fasta_blocks(const std::string& path, uint8_t* slot, size_t cap, FastaDoc& doc, size_t& n_bases) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
+    static thread_local std::vector<char> block(1u << 20);
+    enum { BEFORE_FIRST, IN_HEADER, LINE_START, IN_LINE } state = BEFORE_FIRST;
+    uint8_t* dst = slot;
+    uint8_t* const dst_end = slot + cap;
+    const uint8_t* rec = slot;
+    std::string header;
+    bool open_record = false;
+    doc = FastaDoc();
+    doc.path = path;
+    auto end_header = [&]() {
+        if (!header.empty() && header.back() == '\r') header.pop_back();
+        size_t k = 0;
+        while (k < header.size() && !isspace((unsigned char)header[k])) k++;
+        doc.names.push_back(header.substr(0, k));
+        rec = dst; open_record = true;
+    };
+    auto end_record = [&]() {
+        const uint64_t len = (uint64_t)(dst - rec);
+        doc.lengths.push_back(len); doc.total += len; open_record = false;
+    };
+    auto end_line = [&]() { if ((size_t)(dst - rec) > 1 && dst[-1] == '\r') dst--; };
+    for (;;) {
+        const ssize_t got = ::read(fd, block.data(), block.size());
+        if (got < 0) return false;
+        if (got == 0) break;
+        const char* p = block.data();
+        const char* const e = p + got;
+        while (p < e) {
+            if (state == BEFORE_FIRST) {
+                while (p < e && *p != '>' && *p != '@') p++;
+                if (p == e) break;
+                if (*p == '@') return false;
+                header.clear(); state = IN_HEADER; p++;
+            } else if (state == IN_HEADER) {
+                const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(e - p)));
+                header.append(p, nl ? nl : e);
+                if (!nl) break;
+                end_header(); state = LINE_START; p = nl + 1;
+            } else if (state == LINE_START) {
+                const char c = *p;
+                if (c == '>') { end_record(); header.clear(); state = IN_HEADER; p++; }
+                else if (c == '+' || c == '@') return false;
+                else if (c == '\n') p++;
+                else state = IN_LINE;
+            } else {
+                const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(e - p)));
+                const char* le = nl ? nl : e;
+                const size_t len = (size_t)(le - p);
+                if (dst + len > dst_end) return false;
+                std::memcpy(dst, p, len);
+                dst += len;
+                if (!nl) break;
+                end_line(); state = LINE_START; p = nl + 1;
+            }
+        }
+    }
+    if (state == IN_HEADER) end_header();
+    if (state == IN_LINE) end_line();
+    if (open_record) end_record();
+    n_bases = (size_t)(dst - slot);
+    return true;
+}
+
 // size of the file and whether it is gzip-compressed
 static bool file_info(const std::string& path, size_t& size) {
     struct stat st;
@@ -165,6 +237,24 @@ uint8_t* HostArena::ensure(size_t bytes) {
     return p_;
 }
 
+// CPUs this process may really use: the cgroup's CPU quota if there is one (a container with 16 CPUs' worth of time on a
+// 256-thread host is throttled for the rest of every 100 ms period once 94 reader threads have spent it in 17 ms -- and
+// with them the thread that feeds the GPU), else what the machine has.  MUMEMTO_READ_THREADS overrides.
+static size_t reader_threads() {
+    if (const char* e = std::getenv("MUMEMTO_READ_THREADS")) return (size_t)std::max(1, std::atoi(e));
+    size_t n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64] = {0};
+        unsigned long long period = 0;
+        if (std::fscanf(f, "%63s %llu", quota, &period) == 2 && period && std::strcmp(quota, "max") != 0) {
+            const unsigned long long q = std::strtoull(quota, nullptr, 10);
+            if (q) n = std::min<size_t>(n, (size_t)((q + period - 1) / period));
+        }
+        std::fclose(f);
+    }
+    return std::max<size_t>(n, 1);
+}
+
 long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostArena& arena,
                            HostDocs& out) {
     const size_t N = inputs.size();
@@ -173,14 +263,16 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
     // plain files get a slot of their size in the arena (bases <= bytes of the file); compressed ones a vector
     std::vector<size_t> slot(N + 1, 0);
     std::vector<char> gz(N, 0);
+    std::vector<size_t> fsize(N, 0);
     for (size_t i = 0; i < N; i++) {
         size_t size = 0;
         gz[i] = file_info(inputs[i], size) ? 1 : 0;
+        fsize[i] = size;
         slot[i + 1] = slot[i] + (gz[i] ? 0 : ((size + 64 + 4095) & ~(size_t)4095));
     }
     uint8_t* base = arena.ensure(slot[N] + 4096);
     std::vector<std::string> err(N);
-    const size_t n_thr = std::min<size_t>(N, std::max(1u, std::thread::hardware_concurrency()));
+    const size_t n_thr = std::min<size_t>(N, reader_threads());
     std::atomic<size_t> next{0};
     auto work = [&]() {
         for (size_t i = next++; i < N; i = next++) {
@@ -189,9 +281,15 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
                     docs[i] = read_fasta(inputs[i], out.owned[i]);
                     out.ptr[i] = out.owned[i].data(); out.len[i] = out.owned[i].size();
                 } else {
-                    RawSink sink{base + slot[i], 0, slot[i + 1] - slot[i]};
-                    docs[i] = read_fasta_with<LineReader>(inputs[i], sink);
-                    out.ptr[i] = sink.p; out.len[i] = sink.n;
+                    size_t n_bases = 0;
+                    if (!std::getenv("MUMEMTO_STREAM_READER") &&
+                        read_plain_fasta_blocks(inputs[i], base + slot[i], slot[i + 1] - slot[i], docs[i], n_bases)) {
+                        out.ptr[i] = base + slot[i]; out.len[i] = n_bases;
+                    } else {
+                        RawSink sink{base + slot[i], 0, slot[i + 1] - slot[i]};
+                        docs[i] = read_fasta_with<LineReader>(inputs[i], sink);
+                        out.ptr[i] = sink.p; out.len[i] = sink.n;
+                    }
                 }
             } catch (const std::exception& e) { err[i] = e.what(); }
         }
@@ -213,7 +311,7 @@ long read_fasta_files(const std::vector<std::string>& inputs, std::vector<FastaD
     doc_len.clear();
     std::vector<std::vector<uint8_t>> part(inputs.size());
     std::vector<std::string> err(inputs.size());
-    const size_t n_thr = std::min<size_t>(inputs.size(), std::max(1u, std::thread::hardware_concurrency()));
+    const size_t n_thr = std::min<size_t>(inputs.size(), reader_threads());
     auto on_all_threads = [&](const std::function<void(size_t)>& per_file) {
         std::atomic<size_t> next{0};
         auto work = [&]() { for (size_t i = next++; i < inputs.size(); i = next++) per_file(i); };

@@ -6,6 +6,7 @@ import gzip
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import pyoracle as O
@@ -175,3 +176,29 @@ def test_arrays_in_checkpoint_reads_the_streams_first_entries(tmp_path):
     (tmp_path / "arr.bwt").write_bytes(np.asarray(bwt, np.uint8).tobytes()[: n - 5])      # truncated file
     assert run(["-a", str(tmp_path / "arr"), "-o", str(tmp_path / "out")], tmp_path).returncode == 1
     assert run(["-a", str(tmp_path / "arr"), "-p", str(tmp_path / "arr"), "-o", str(tmp_path / "o")], tmp_path).returncode == 1
+
+
+def test_in_place_reader_of_plain_files_equals_the_stream_reader(tmp_path):
+    """Plain FASTA files are read in cache-sized blocks whose lines go straight to the file's slot (fasta.cpp); everything
+    else -- and every file when MUMEMTO_STREAM_READER is set -- goes through the stream reader.  Same bases, same .lengths."""
+    rng = np.random.default_rng(5)
+    files = []
+    for i in range(6):
+        recs = []
+        for r in range(int(rng.integers(1, 4))):
+            seq = bytes(rng.choice(np.frombuffer(b"ACGTNacgt", np.uint8), size=int(rng.integers(1, 3000))))
+            width = int(rng.choice([1, 7, 60, 80, 5000]))
+            eol = b"\r\n" if i % 3 == 1 else b"\n"
+            lines = eol.join(seq[k:k + width] for k in range(0, len(seq), width))
+            recs.append(b">r%d some words%s%s%s" % (r, eol, lines, b"" if (i == 5 and r == 0) else eol + (b"\n" if r % 2 else b"")))
+        p = tmp_path / ("f%d.fa" % i)
+        p.write_bytes((b"junk before the first header\n" if i == 2 else b"") + b"".join(recs))
+        files.append(str(p))
+    outs = []
+    for env in ({}, {"MUMEMTO_STREAM_READER": "1"}):
+        r = subprocess.run([EXE, "-o", str(tmp_path / ("o%d" % len(outs)))] + files, cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, MUMEMTO_DRY_RUN="1", **env))
+        assert r.returncode == 0, r.stderr
+        outs.append((fields(r.stdout), (tmp_path / ("o%d.lengths" % len(outs))).read_text()))
+    assert outs[0][0]["bases"] == outs[1][0]["bases"] and outs[0][0]["fnv1a"] == outs[1][0]["fnv1a"]
+    assert outs[0][1] == outs[1][1] and int(outs[0][0]["bases"]) > 0

@@ -105,6 +105,16 @@ def main():
 
     if a.share_device:
         local_rank = 0
+    if world > 1 and "MUMEMTO_READ_THREADS" not in os.environ:
+        # the ranks of one node share the node's CPUs (and a container's CPU quota): each reader takes its share
+        cpus = os.cpu_count() or 1
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cpus = min(cpus, max(1, -(-int(quota) // int(period))))
+        except (OSError, ValueError):
+            pass
+        os.environ["MUMEMTO_READ_THREADS"] = str(max(2, cpus // world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

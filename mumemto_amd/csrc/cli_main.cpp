@@ -230,12 +230,20 @@ static int run_rank(BuildOptions& o) {
     p.max_total_freq = o.max_mem_freq;
     p.use_revcomp = o.use_rcomp ? 1 : 0;
     p.merge_metadata = strict ? 1 : 0;
-    if (strict) { p.num_distinct = 0; p.max_total_freq = 0; }
-    else eng.set_scan_shard((uint32_t)rank, (uint32_t)world);
-    eng.run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), p, 0);
     uint8_t id[128];
     if (rank == 0) { comm_unique_id(id); leave_id(o.comm_file, id); } else fetch_id(o.comm_file, id);
     Comm* comm = comm_create(eng, rank, world, id);
+    if (strict) { p.num_distinct = 0; p.max_total_freq = 0; }
+    else {
+        eng.set_scan_shard((uint32_t)rank, (uint32_t)world);
+        // four ranks or more: the suffix sort is shared out too (buckets of suffixes per rank, the pieces of the columns
+        // broadcast: dist_exchange_columns) -- below that one GPU's parse-based sort of a redundant collection is as fast
+        // as a share of the bucket sort.  MUMEMTO_SORT_SHARD=0 / 1 overrides.
+        const char* env = std::getenv("MUMEMTO_SORT_SHARD");
+        if (env ? std::atoi(env) != 0 : world >= 4)
+            eng.set_sort_shard((uint32_t)rank, (uint32_t)world, [](void* c) { dist_exchange_columns(*static_cast<Comm*>(c)); }, comm);
+    }
+    eng.run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), p, 0);
     size_t rows = 0;
     if (strict) {
         bool root = false;

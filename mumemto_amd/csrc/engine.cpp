@@ -684,6 +684,10 @@ void Engine::run(const mmt_params& p) {
             const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
             kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
             if (env && std::string(env) == "guided" && !reserved) kind = 3;
+        }
+        if (after_sort_) {                               // only the bucket-wise producer can sort a share of the suffixes
+            if (reserved) throw std::runtime_error("a sharded suffix sort needs a text without the bytes 0x00-0x02");
+            kind = 3;
             // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
             if (wide_ && !reserved) kind = 2;
         }
@@ -701,6 +705,11 @@ void Engine::run(const mmt_params& p) {
         if (kind >= 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
         else suffix_sort();
         producer_used_ = kind >= 2 ? (pfp_->guided ? 3 : 2) : kind;
+        if (after_sort_) {                               // this rank's piece of the columns is complete: get the others
+            MMT_HIP(hipStreamSynchronize(stream_));
+            after_sort_(after_sort_ctx_);
+            MMT_HIP(hipStreamSynchronize(stream_));
+        }
     }
     ev_[1]->stop(stream_);
     const bool lean = lean_ || wide_ || wants_lean();

@@ -96,6 +96,20 @@ public:
         if (count == 0 || index >= count) throw std::runtime_error("scan shard index out of range");
         shard_index_ = index; shard_count_ = count;
     }
+    // Multi-GPU runs that shard the SUFFIX SORT (buckets of suffixes by their leading characters are
+    // independent, and their concatenation in bucket order is the suffix array): rank `index` of `count` sorts only its
+    // share of the buckets (guided.cpp: whole bins, balanced by their histogram) and writes its piece of the suffix-array
+    // and BWT columns; `after_sort` -- called inside run(), when the piece is complete -- exchanges the pieces
+    // (mumemto_amd/dist.py::run_sort_sharded, dist.cpp::dist_exchange_columns); LCP, scan and rows follow on every rank
+    // (combine with set_scan_shard).  Every rank computes the same pieces (sort_pieces()).
+    void set_sort_shard(uint32_t index, uint32_t count, void (*after_sort)(void*), void* ctx) {
+        if (count == 0 || index >= count) throw std::runtime_error("sort shard index out of range");
+        if (count > 1 && !after_sort) throw std::runtime_error("a sharded suffix sort needs the exchange callback");
+        // (count = 1 with a callback: the degenerate case, one piece -- the whole path with a communicator of one rank)
+        sort_shard_index_ = index; sort_shard_count_ = count; after_sort_ = after_sort; after_sort_ctx_ = ctx;
+    }
+    const std::vector<std::pair<uint64_t, uint64_t>>& sort_pieces() const { return sort_pieces_; }   // (first entry, entries)
+    uint8_t* bwt_device() const { return d_bwt_.get(); }
     void release_sort_scratch();
     // gives every column and scratch buffer of the last run back to the device heap (results already downloaded stay)
     void release_columns();
@@ -188,6 +202,10 @@ private:
     DevBuf<uint32_t> d_wpre_, d_wsuf_, d_wide_;
     bool lcp_whole_ = false;              // d_lcp_ holds the LCP column of the whole stream (one scan range)
     uint32_t shard_index_ = 0, shard_count_ = 1;
+    uint32_t sort_shard_index_ = 0, sort_shard_count_ = 1;
+    void (*after_sort_)(void*) = nullptr;
+    void* after_sort_ctx_ = nullptr;
+    std::vector<std::pair<uint64_t, uint64_t>> sort_pieces_;
     size_t scan_ranges_ = 1;
     DoublingSorter sorter_;
     int sort_rounds_ = 0;

@@ -275,10 +275,29 @@ void Engine::suffix_sort_guided() {
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
     uint64_t base = 0, active_sum = 0, small_sum = 0;
     int batches = 0, rounds_max = 0;
-    for (uint32_t b0 = 0; b0 < n_bins;) {
+    // a sharded sort (Engine::set_sort_shard): shard k takes the bins from the first one whose cumulative count reaches
+    // k * n / count -- whole bins, so that every rank finds the same pieces from the same histogram
+    uint32_t bin_lo = 0, bin_hi = n_bins;
+    sort_pieces_.clear();
+    if (after_sort_) {
+        std::vector<uint64_t> pre(n_bins + 1, 0);                  // suffixes in the bins before bin b
+        for (uint32_t bq = 0; bq < n_bins; bq++) pre[bq + 1] = pre[bq] + bins[bq];
+        std::vector<uint32_t> cut(sort_shard_count_ + 1, 0);
+        cut[sort_shard_count_] = n_bins;
+        for (uint32_t k = 1; k < sort_shard_count_; k++) {
+            const uint64_t target = (uint64_t)((unsigned __int128)n * k / sort_shard_count_);
+            cut[k] = std::max<uint32_t>(cut[k - 1], (uint32_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin()));
+            if (cut[k] > n_bins) cut[k] = n_bins;
+        }
+        for (uint32_t q = 0; q < sort_shard_count_; q++) sort_pieces_.emplace_back(pre[cut[q]], pre[cut[q + 1]] - pre[cut[q]]);
+        bin_lo = cut[sort_shard_index_]; bin_hi = cut[sort_shard_index_ + 1];
+        base = pre[bin_lo];
+    }
+    const uint64_t piece_end = after_sort_ ? base + sort_pieces_[sort_shard_index_].second : n;
+    for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
         uint64_t total = 0;
         uint32_t b1 = b0;
-        while (b1 < n_bins && total + bins[b1] <= X.cap) total += bins[b1++];
+        while (b1 < bin_hi && total + bins[b1] <= X.cap) total += bins[b1++];
         if (b1 == b0) throw std::runtime_error("guided sort: a bin exceeds the batch");
         if (total) {
             const uint32_t B = (uint32_t)total;
@@ -292,7 +311,7 @@ void Engine::suffix_sort_guided() {
         b0 = b1;
     }
     check_err("text suffixes");
-    if (base != n) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
+    if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
     S.bwt_ready = true;
     S.n_groups = 0; S.dict_len = 0; S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     e6.stop(st);

@@ -132,7 +132,8 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             const char* env = std::getenv("MUMEMTO_PRODUCER");
             const double tables = 46.0 * (double)dict_len64, sorter = 49.0 * (double)std::max<uint64_t>(dict_len64, m);
             const double need = tables + std::max(0.0, sorter - (slim ? (double)d_cols_.bytes() : 0.0));
-            S.guided = producer_ == 3 || (env && std::string(env) == "guided") || dict_len64 >= 0xffffff00ull ||
+            S.guided = producer_ == 3 || after_sort_ != nullptr || (env && std::string(env) == "guided") ||
+                       dict_len64 >= 0xffffff00ull ||
                        (producer_ == 0 && need > 0.9 * (double)pool::available(device_));
             if (S.guided) {
                 S.dict_len = 0;

@@ -221,6 +221,11 @@ def test_gpus_option_runs_one_process_per_gpu_and_the_rccl_exchange(inputs):
             got = np.frombuffer((tmp / (name + ".athresh")).read_bytes(), np.uint16)
             assert np.array_equal(got, want.thresh()[: len(docs[0][0]) + 1])
         assert not glob.glob(str(tmp / (name + ".comm.*"))) and not glob.glob(str(tmp / (name + ".rank*")))
+    # the sharded suffix sort through the command line (one piece here: the callback, the in-place broadcasts)
+    r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "--gpus", "1", "-o", str(tmp / "r_sort"), "-k", "-1", "-f", "3"] + paths,
+                       cwd=tmp, capture_output=True, text=True, env=dict(env, MUMEMTO_SORT_SHARD="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert (tmp / "r_sort.mems").read_bytes() == (tmp / "r_mem.mems").read_bytes()
     # the lengths file of the rank processes is the one a single process writes
     cli(["-o", str(tmp / "r_one")] + paths, tmp)
     assert (tmp / "r_def.lengths").read_bytes() == (tmp / "r_one.lengths").read_bytes()

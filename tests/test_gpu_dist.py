@@ -181,6 +181,10 @@ def _sharded_worker(rank, world, port, q, wide):
                          ("mems", dict(num_distinct=2, max_doc_freq=0, max_total_freq=40)),
                          ("strict", dict(num_distinct=0, max_doc_freq=1, max_total_freq=0))):
             out[name] = mdist.run_sharded(eng, dist, torch.device("cpu"), **kw)
+            # the suffix sort sharded as well: buckets of suffixes per rank, pieces of the columns exchanged
+            out[name + "_sort"] = mdist.run_sort_sharded(eng, dist, torch.device("cpu"), **kw)
+            assert eng.producer_used() == "guided" and len(eng.sort_pieces()) == world
+            assert sum(c for _, c in eng.sort_pieces()) == eng.text_length()
         q.put((rank, out))
         dist.barrier()
         eng.close()
@@ -191,8 +195,9 @@ def _sharded_worker(rank, world, port, q, wide):
 @pytest.mark.parametrize("world,wide", [(2, False), (3, False), (2, True)])
 def test_partial_and_mem_modes_sharded_over_ranks_equal_one_gpu(world, wide):
     """SURVEY 8(e) row 2 (BASELINE configs[4]): modes the anchor merge cannot serve run on several ranks by sharding
-    the suffix-array positions of the scan; the concatenated outputs are byte for byte the oracle's single run.  The
-    ranks share GPU 0 under gloo (this box has one GPU)."""
+    the suffix-array positions of the scan -- and, in the second run of every mode, the suffix sort too (buckets of
+    suffixes by their leading characters per rank, the pieces of the suffix-array / BWT columns broadcast); the
+    concatenated outputs are byte for byte the oracle's single run.  The ranks share GPU 0 under gloo (this box has one GPU)."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -214,6 +219,7 @@ def test_partial_and_mem_modes_sharded_over_ranks_equal_one_gpu(world, wide):
     for r in range(world):
         for name in want:
             assert got[r][name] == want[name], (r, name)
+            assert got[r][name + "_sort"] == want[name], (r, name, "sharded suffix sort")
     assert want["partial"].count(b"\n") > 10 and want["mems"].count(b"\n") > 10
 
 
@@ -234,6 +240,13 @@ m = comm.merge()
 assert m["text"] == O.run(docs, merge=True).text() and m["n_rows"] > 5, "strict multi-MUMs through the RCCL exchange"
 eng.set_scan_shard(0, 1)
 eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
+assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
+# the sharded suffix sort with its one piece: the callback inside run(), in-place ncclBroadcast of the three columns
+calls = []
+eng.set_sort_shard(0, 1, after_sort=lambda: (calls.append(eng.sort_pieces()), comm.exchange_columns()))
+eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
+eng.set_sort_shard(0, 1)
+assert calls == [[(0, eng.text_length())]] and eng.producer_used() == "guided"
 assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
 comm.close(); eng.close()
 print("NATIVE_EXCHANGE_OK")

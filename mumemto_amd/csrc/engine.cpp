@@ -684,12 +684,12 @@ void Engine::run(const mmt_params& p) {
             const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
             kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
             if (env && std::string(env) == "guided" && !reserved) kind = 3;
+            // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
+            if (wide_ && !reserved && kind == 1) kind = 2;
         }
         if (after_sort_) {                               // only the bucket-wise producer can sort a share of the suffixes
             if (reserved) throw std::runtime_error("a sharded suffix sort needs a text without the bytes 0x00-0x02");
             kind = 3;
-            // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
-            if (wide_ && !reserved) kind = 2;
         }
         if (kind == 1 && n_ >= NARROW_LIMIT)
             throw std::runtime_error(reserved ? "texts of 2^32 characters or more must not contain the bytes 0x00-0x02 "

@@ -2,6 +2,9 @@
 // (reference: mumemto_library/mumemto_api.cpp:489-644) and the device-resident
 // entry points of include/mumemto_gpu.h.
 #include <chrono>
+#include <thread>
+#include <deque>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -283,10 +286,73 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
     // (sending every document to the device from the thread that parsed it, while the other files are still being
     // read, was tried: 94 concurrent copies from pageable memory slow the parsers down by more than the copies take --
     // read 0.18 -> 0.37 s, run 1.67 -> 1.57 s on the C3 stand-in)
-    const long empty = mmt::read_fasta_collection(inputs, docs, e->arena, hd);
+    // A collection that will run as one suffix array (judged by the file sizes, which bound the bases) goes to the device
+    // document by document while the other files are still being read: ONE copier thread takes the documents in the order
+    // the readers finish them (every reader copying its own document was tried: 94 concurrent copies from pageable
+    // memory slowed the parsers down by more than the copies take).  MUMEMTO_NO_UPLOAD_OVERLAP switches it off.
+    struct Upload {
+        std::mutex mu; std::condition_variable cv; std::deque<std::pair<size_t, uint64_t>> q; bool done = false;
+        std::thread thread; std::exception_ptr error; std::vector<size_t> slot; bool on = false;
+    } up;
+    mmt::ReadHooks hooks;
+    hooks.layout = [&](const uint8_t* arena, size_t bytes, const std::vector<size_t>& slot, bool all_in_arena) {
+        const uint64_t bound = 2 * ((uint64_t)bytes + slot.size());               // text characters at most
+        if (!all_in_arena || std::getenv("MUMEMTO_NO_UPLOAD_OVERLAP") || slot.size() < 2) return;
+        e->e->forget_last_run();
+        if (bound > (max_text_chars ? max_text_chars : e->e->auto_max_text())) return;
+        uint8_t* dev = e->e->begin_input_slots(bytes);
+        up.slot = slot; up.on = true;
+        const int device = e->e->device();
+        up.thread = std::thread([&up, dev, arena, device]() {
+            try {
+                MMT_HIP(hipSetDevice(device));
+                hipStream_t cs = nullptr;
+                MMT_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                for (;;) {
+                    std::pair<size_t, uint64_t> job;
+                    {
+                        std::unique_lock<std::mutex> lk(up.mu);
+                        up.cv.wait(lk, [&] { return !up.q.empty() || up.done; });
+                        if (up.q.empty()) break;
+                        job = up.q.front(); up.q.pop_front();
+                    }
+                    if (job.second)
+                        MMT_HIP(hipMemcpyAsync(dev + up.slot[job.first], arena + up.slot[job.first], job.second, hipMemcpyHostToDevice, cs));
+                    MMT_HIP(hipStreamSynchronize(cs));
+                }
+                (void)hipStreamDestroy(cs);
+            } catch (...) { up.error = std::current_exception(); }
+        });
+    };
+    hooks.ready = [&](size_t i, uint64_t len) {
+        if (!up.on) return;
+        { std::lock_guard<std::mutex> lk(up.mu); up.q.emplace_back(i, len); }
+        up.cv.notify_one();
+    };
+    auto finish_upload = [&]() {
+        if (!up.thread.joinable()) return;
+        { std::lock_guard<std::mutex> lk(up.mu); up.done = true; }
+        up.cv.notify_one();
+        up.thread.join();
+    };
+    long empty = -1;
+    try { empty = mmt::read_fasta_collection(inputs, docs, e->arena, hd, &hooks); }
+    catch (...) { finish_upload(); throw; }
+    finish_upload();
+    if (up.error) std::rethrow_exception(up.error);
     if (empty >= 0) throw std::runtime_error("Empty input file found: " + inputs[(size_t)empty]);
     const double t_read = since();
-    e->e->run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), *p, max_text_chars);
+    bool ran = false;
+    if (up.on) {
+        try {
+            e->e->finish_input_slots(up.slot, hd.len.data(), hd.len.size());
+            e->e->run_once_dropping_input(*p);
+            ran = true;
+        } catch (const mmt::HipError& ex) {                    // did not fit after all: the route for any size, from the host copies
+            if (std::string(ex.what()).find("out of device memory") == std::string::npos) throw;
+        }
+    }
+    if (!ran) e->e->run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), *p, max_text_chars);
     const double t_run = since();
     if (out_prefix) {
         // (D2H into page-locked memory, then one write(): copying from HBM straight into a populated mapping of the file

@@ -51,6 +51,19 @@ void Engine::set_input_host(const uint8_t* h_bases, const uint64_t* doc_len, siz
     set_input_device(d_bases_own_.get(), doc_len, n_docs);
 }
 
+uint8_t* Engine::begin_input_slots(size_t bytes) {
+    MMT_HIP(hipSetDevice(device_));
+    d_bases_own_.ensure(bytes + 64);
+    return d_bases_own_.get();
+}
+void Engine::finish_input_slots(const std::vector<size_t>& slot, const uint64_t* doc_len, size_t n_docs) {
+    d_bases_ = d_bases_own_.get();
+    preset_ = 0; input_valid_ = true; lcp_whole_ = false;
+    doc_len_.assign(doc_len, doc_len + n_docs);
+    doc_base_.assign(n_docs + 1, 0);
+    for (size_t d = 0; d <= n_docs; d++) doc_base_[d] = slot[d];        // (the text builder takes any offsets)
+}
+
 void Engine::set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs) {
     MMT_HIP(hipSetDevice(device_));
     uint64_t total = 0;

@@ -43,6 +43,12 @@ public:
     // one pass of the path on the input that is set, as run_partitioned_docs does for a single suffix array (the
     // raw bases are dropped once the text exists)
     void run_once_dropping_input(const mmt_params& p);
+    // Input that arrives document by document while the caller still reads the others (mmt_engine_run_files): a device
+    // buffer with one slot per document, filled by the caller (any thread, its own stream), then declared as the input.
+    uint8_t* begin_input_slots(size_t bytes);
+    void finish_input_slots(const std::vector<size_t>& slot, const uint64_t* doc_len, size_t n_docs);
+    // what the last run left on the device -- columns, scratch, results -- goes back to the heap (a new run replaces it)
+    void forget_last_run();
     uint64_t auto_max_text() const;
     // the documents in separate host buffers (no concatenation on the host: one H2D copy per document)
     void set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs);

@@ -256,7 +256,7 @@ static size_t reader_threads() {
 }
 
 long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostArena& arena,
-                           HostDocs& out) {
+                           HostDocs& out, const ReadHooks* hooks) {
     const size_t N = inputs.size();
     docs.assign(N, FastaDoc());
     out.ptr.assign(N, nullptr); out.len.assign(N, 0); out.owned.clear(); out.owned.resize(N);
@@ -271,6 +271,11 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
         slot[i + 1] = slot[i] + (gz[i] ? 0 : ((size + 64 + 4095) & ~(size_t)4095));
     }
     uint8_t* base = arena.ensure(slot[N] + 4096);
+    if (hooks && hooks->layout) {
+        bool all_in_arena = true;
+        for (size_t i = 0; i < N; i++) all_in_arena = all_in_arena && !gz[i];
+        hooks->layout(base, slot[N], slot, all_in_arena);
+    }
     std::vector<std::string> err(N);
     const size_t n_thr = std::min<size_t>(N, reader_threads());
     std::atomic<size_t> next{0};
@@ -290,6 +295,7 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
                         docs[i] = read_fasta_with<LineReader>(inputs[i], sink);
                         out.ptr[i] = sink.p; out.len[i] = sink.n;
                     }
+                    if (hooks && hooks->ready) hooks->ready(i, out.len[i]);
                 }
             } catch (const std::exception& e) { err[i] = e.what(); }
         }

@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -59,8 +60,16 @@ struct HostDocs {
     std::vector<uint64_t> len;
     std::vector<std::vector<uint8_t>> owned;
 };
+// What a caller may do while the files are still being read (mmt_engine_run_files: send every document to the device as
+// soon as it is parsed).  layout: once, before any file is read -- bytes of the arena, offset of every document's slot in it
+// (N + 1 entries), whether every document lives in the arena (no compressed input).  ready: from a reader thread, document
+// i is complete at arena + slot[i] with `len` bases.
+struct ReadHooks {
+    std::function<void(const uint8_t* arena, size_t bytes, const std::vector<size_t>& slot, bool all_in_arena)> layout;
+    std::function<void(size_t i, uint64_t len)> ready;
+};
 long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostArena& arena,
-                           HostDocs& out);
+                           HostDocs& out, const ReadHooks* hooks = nullptr);
 
 // Writes n bytes to `path` (created / truncated) and closes it.
 void write_file_bytes(const std::string& path, const void* data, size_t n);

@@ -31,6 +31,15 @@ uint64_t Engine::auto_max_text() const {
     return max_text;
 }
 
+void Engine::forget_last_run() {
+    release_columns();
+    // ... and the results (thresholds and merged tables of a genome-sized anchor are tens of GB), and the input buffer
+    rows_ = HostRows(); rows_pending_ = 0; merged_thresh_valid_ = false; thresh_len_ = 0;
+    merged_ = MergedRows();
+    d_thresh_.release(); d_rows_.release(); d_otext_.release(); d_olen_.release(); d_ooffs_.release(); d_ost_.release();
+    d_omdoc_.release(); d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
+}
+
 void Engine::run_once_dropping_input(const mmt_params& p) {
     partitions_used_ = 1;
     drop_input_after_text_ = true;
@@ -56,12 +65,7 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     for (size_t d = 0; d < n_docs; d++) { base[d + 1] = base[d] + doc_len[d]; total += mult * (doc_len[d] + 1); }
     const bool strict = p.max_doc_freq == 1 && (p.num_distinct == 0 || p.num_distinct == n_docs) &&
                         (p.max_total_freq == 0 || (uint64_t)p.max_total_freq >= n_docs);
-    release_columns();                       // what the previous run left behind counts as free memory below
-    // ... and so do its results (a new run replaces them; thresholds and merged tables of a genome-sized anchor are tens of GB)
-    rows_ = HostRows(); rows_pending_ = 0; merged_thresh_valid_ = false; thresh_len_ = 0;
-    merged_ = MergedRows();
-    d_thresh_.release(); d_rows_.release(); d_otext_.release(); d_olen_.release(); d_ooffs_.release(); d_ost_.release();
-    d_omdoc_.release(); d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
+    forget_last_run();                       // what the previous run left behind counts as free memory below
     const bool auto_limit = max_text == 0;
     if (auto_limit) max_text = auto_max_text();
     partitions_used_ = 1;

@@ -541,6 +541,12 @@ void Engine::fetch_rows(int need) {
     need &= rows_pending_;
     if (!need) return;
     MMT_HIP(hipSetDevice(device_));
+    if (merged_thresh_valid_) {                 // a partitioned run: the merged tables (partitioned.cpp)
+        (void)merged_thresh();
+        rows_.length = merged_.length.data(); rows_.mum_offsets = merged_.offsets.data(); rows_.mum_strands = merged_.strands.data();
+        rows_pending_ &= ~need;
+        return;
+    }
     hipStream_t st = stream_;
     HostRows& R = rows_;
     const size_t N = R.n_docs, nr = R.n_rows;

@@ -73,7 +73,8 @@ public:
                               uint64_t max_text);
     size_t partitions_used() const { return partitions_used_; }
     // merged .athresh (L_0 + 1 entries) of the last partitioned run, empty otherwise
-    const std::vector<uint16_t>& merged_thresh() const { return merged_.thresh; }
+    // (host copy made when first asked for: the thresholds of a genome-sized anchor are 6 GB)
+    const std::vector<uint16_t>& merged_thresh();
     // the MUM-mode rows of the last run as they sit in HBM (valid until the next run)
     void rows_mum_device(const uint32_t** len, const int64_t** off, const uint8_t** st) const {
         if (merged_thresh_valid_) { *len = merged_.d_length.get(); *off = merged_.d_offsets.get(); *st = merged_.d_strands.get(); }

@@ -276,7 +276,7 @@ std::string format_merged(Engine& e, const MergedRows& m) {
     return out;
 }
 
-void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) {
+const char* stage_merged_text(Engine& e, const MergedRows& m, size_t* n_bytes) {
     DevBuf<char> text;
     const size_t bytes = format_merged_device(e, m, text);
     char* host = e.merge_text_staging(bytes + 1);       // (a fresh std::string of 900 MB costs more than the copy into it)
@@ -284,6 +284,13 @@ void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) 
         MMT_HIP(hipMemcpyAsync(host, text.get(), bytes, hipMemcpyDeviceToHost, e.stream()));
         MMT_HIP(hipStreamSynchronize(e.stream()));
     }
+    if (n_bytes) *n_bytes = bytes;
+    return host;
+}
+
+void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) {
+    size_t bytes = 0;
+    const char* host = stage_merged_text(e, m, &bytes);
     write_file_bytes(path, host, bytes);
 }
 

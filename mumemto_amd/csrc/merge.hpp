@@ -20,6 +20,8 @@ void sort_like_direct(Engine& e, MergedRows& m);
 std::string format_merged(Engine& e, const MergedRows& m);
 // the same bytes, formatted in HBM, staged in page-locked memory that stays with the engine, written to `path`
 void write_merged_text(Engine& e, const MergedRows& m, const std::string& path);
+// ... or left in that page-locked memory (valid until the next merged result is staged there); returns the bytes
+const char* stage_merged_text(Engine& e, const MergedRows& m, size_t* bytes);
 // host copies of the rows and thresholds (m.length / m.offsets / m.strands / m.thresh)
 void download_merged(Engine& e, MergedRows& m);
 

@@ -31,6 +31,11 @@ uint64_t Engine::auto_max_text() const {
     return max_text;
 }
 
+const std::vector<uint16_t>& Engine::merged_thresh() {
+    if (merged_thresh_valid_ && !merged_.on_host) download_merged(*this, merged_);
+    return merged_.thresh;
+}
+
 void Engine::forget_last_run() {
     release_columns();
     // ... and the results (thresholds and merged tables of a genome-sized anchor are tens of GB), and the input buffer
@@ -226,8 +231,9 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
         merged_ = anchor_merge(*this, &one, 1, p.min_match_len);
     }
     sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions
-    merged_text_ = format_merged(*this, merged_);
-    download_merged(*this, merged_);
+    size_t text_bytes = 0;
+    const char* text = stage_merged_text(*this, merged_, &text_bytes);     // page-locked, stays with the engine
+    merged_text_.clear();
     // publish as the result of this "run"; the per-partition input buffers are gone or about to go: a later run()
     // needs a new set_input
     d_bases_ = nullptr;
@@ -235,11 +241,10 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     doc_len_.assign(doc_len, doc_len + n_docs);
     HostRows& R = rows_;
     R = HostRows();
-    rows_pending_ = 0;                         // the merged rows were downloaded by download_merged
-    R.mum_mode = true; R.n_docs = n_docs; R.n_rows = merged_.length.size();
-    R.length = merged_.length.data(); R.mum_offsets = merged_.offsets.data(); R.mum_strands = merged_.strands.data();
+    rows_pending_ = ROWS_ARRAYS;               // the merged tables stay in HBM until somebody asks (Engine::fetch_rows)
+    R.mum_mode = true; R.n_docs = n_docs; R.n_rows = merged_.n_rows;
     h_occ_start_.ensure(2); h_occ_start_.get()[0] = 0; R.occ_start = h_occ_start_.get();
-    R.text = merged_text_.data(); R.text_len = merged_text_.size();
+    R.text = text; R.text_len = text_bytes;
     bumbl_.clear();
     num_distinct_eff_ = n_docs;
     partitions_used_ = G;

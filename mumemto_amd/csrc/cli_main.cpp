@@ -158,6 +158,9 @@ static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
             for (auto& s : args) av.push_back(const_cast<char*>(s.c_str()));
             av.push_back(nullptr);
             if (!std::getenv("MUMEMTO_SHARE_DEVICE")) setenv("MUMEMTO_DEVICE", std::to_string(r).c_str(), 1);
+            // the ranks share the node's CPUs (a container's quota): every reader takes its part
+            if (!std::getenv("MUMEMTO_READ_THREADS"))
+                setenv("MUMEMTO_READ_THREADS", std::to_string(std::max<size_t>(2, reader_threads() / (size_t)o.gpus)).c_str(), 1);
             execv("/proc/self/exe", av.data());
             std::_Exit(127);
         }

@@ -240,7 +240,7 @@ uint8_t* HostArena::ensure(size_t bytes) {
 // CPUs this process may really use: the cgroup's CPU quota if there is one (a container with 16 CPUs' worth of time on a
 // 256-thread host is throttled for the rest of every 100 ms period once 94 reader threads have spent it in 17 ms -- and
 // with them the thread that feeds the GPU), else what the machine has.  MUMEMTO_READ_THREADS overrides.
-static size_t reader_threads() {
+size_t reader_threads() {
     if (const char* e = std::getenv("MUMEMTO_READ_THREADS")) return (size_t)std::max(1, std::atoi(e));
     size_t n = std::max(1u, std::thread::hardware_concurrency());
     if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {

@@ -60,6 +60,9 @@ struct HostDocs {
     std::vector<uint64_t> len;
     std::vector<std::vector<uint8_t>> owned;
 };
+// Threads the readers use: the cgroup's CPU quota if there is one, else the machine's; MUMEMTO_READ_THREADS overrides.
+size_t reader_threads();
+
 // What a caller may do while the files are still being read (mmt_engine_run_files: send every document to the device as
 // soon as it is parsed).  layout: once, before any file is read -- bytes of the arena, offset of every document's slot in it
 // (N + 1 entries), whether every document lives in the arena (no compressed input).  ready: from a reader thread, document

@@ -33,6 +33,7 @@ def engine(request):
     e.close()
 
 
+@pytest.mark.skipif(os.environ.get("MMT_FORCE_WIDE") is not None, reason="forced 40-bit runs always take the parse")
 def test_automatic_producer_goes_by_the_number_of_documents():
     import mumemto_amd
     e = mumemto_amd.Engine(0)

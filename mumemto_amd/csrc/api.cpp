@@ -357,8 +357,7 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
     if (out_prefix) {
         // (D2H into page-locked memory, then one write(): copying from HBM straight into a populated mapping of the file
         // was slower, 0.27 against 0.21 s for 894 MB on tmpfs)
-        const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_TEXT);
-        mmt::write_file_bytes(std::string(out_prefix) + (R.mum_mode ? ".mums" : ".mems"), R.text, R.text_len);
+        e->e->write_text_file(std::string(out_prefix) + (e->e->rows_meta().mum_mode ? ".mums" : ".mems"));
         mmt::write_lengths_file(out_prefix, docs);
     }
     if (seconds) { seconds[0] = t_read; seconds[1] = t_run - t_read; seconds[2] = since() - t_run; seconds[3] = since(); }

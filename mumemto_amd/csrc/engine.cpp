@@ -1,6 +1,9 @@
 // engine.cpp -- orchestration of the hot path on one GPU (no kernels here).
 #include "engine.hpp"
+#include "fasta.hpp"
 
+#include <fcntl.h>
+#include <unistd.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -537,6 +540,43 @@ void Engine::make_rows(const mmt_params& p) {
 
 // D2H of the last run's rows into page-locked host memory, on demand: the library arrays (ROWS_ARRAYS) and / or the
 // bytes of PREFIX.mums / PREFIX.mems (ROWS_TEXT).
+void Engine::write_text_file(const std::string& path) {
+    if (!(rows_pending_ & ROWS_TEXT) || merged_thresh_valid_) {      // already on the host (or a merged result: staged)
+        const HostRows& R = rows(ROWS_TEXT);
+        write_file_bytes(path, R.text, R.text_len);
+        return;
+    }
+    MMT_HIP(hipSetDevice(device_));
+    HostRows& R = rows_;
+    h_text_.ensure(R.text_len + 1);
+    const size_t PIECE = (size_t)64 << 20;
+    const size_t pieces = (R.text_len + PIECE - 1) / PIECE;
+    std::vector<hipEvent_t> ev(pieces);
+    for (size_t k = 0; k < pieces; k++) {
+        const size_t at = k * PIECE, len = std::min(PIECE, R.text_len - at);
+        MMT_HIP(hipMemcpyAsync(h_text_.get() + at, d_otext_.get() + at, len, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        MMT_HIP(hipEventRecord(ev[k], stream_));
+    }
+    const int fd = ::open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    std::string error;
+    if (fd < 0) error = "cannot write " + path;
+    for (size_t k = 0; k < pieces; k++) {
+        MMT_HIP(hipEventSynchronize(ev[k]));
+        (void)hipEventDestroy(ev[k]);
+        const size_t at = k * PIECE, len = std::min(PIECE, R.text_len - at);
+        for (size_t done = 0; error.empty() && done < len;) {
+            const ssize_t w = ::write(fd, h_text_.get() + at + done, len - done);
+            if (w <= 0) { error = "short write to " + path; break; }
+            done += (size_t)w;
+        }
+    }
+    if (fd >= 0 && ::close(fd) != 0 && error.empty()) error = "cannot close " + path;
+    R.text = h_text_.get();
+    rows_pending_ &= ~ROWS_TEXT;
+    if (!error.empty()) throw std::runtime_error(error);
+}
+
 void Engine::fetch_rows(int need) {
     need &= rows_pending_;
     if (!need) return;

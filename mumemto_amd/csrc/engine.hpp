@@ -128,6 +128,9 @@ public:
     const HostRows& rows_meta() const { return rows_; }
     const HostRows& rows(int need = ROWS_ARRAYS | ROWS_TEXT) { fetch_rows(need); return rows_; }
     void fetch_rows(int need);
+    // PREFIX.mums / .mems of the last run straight to a file: the bytes leave HBM in pieces and every piece is written
+    // while the next ones are still on their way (rows(ROWS_TEXT) + one write otherwise)
+    void write_text_file(const std::string& path);
     const std::string& bumbl();
     // PREFIX.thresh / PREFIX.thresh_rev contents (mem_finder.hpp:116-157); needs a merge_metadata MUM run
     void thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev);

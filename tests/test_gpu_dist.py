@@ -185,6 +185,23 @@ def _sharded_worker(rank, world, port, q, wide):
             out[name + "_sort"] = mdist.run_sort_sharded(eng, dist, torch.device("cpu"), **kw)
             assert eng.producer_used() == "guided" and len(eng.sort_pieces()) == world
             assert sum(c for _, c in eng.sort_pieces()) == eng.text_length()
+        # a second collection for the sharded sort: a skewed alphabet (two thirds of the suffixes start with A: whole bins
+        # make uneven pieces) and a run of one base that keeps a bin in one piece
+        import numpy as np
+        import pyoracle as O
+        rng = np.random.default_rng(97)
+        anc = rng.choice(np.frombuffer(b"AAAAAACGT", np.uint8), size=12000)
+        anc[3000:3600] = ord("A")
+        skew = []
+        for d in range(5):
+            h = anc.copy()
+            for pos in rng.integers(0, len(h), size=40):
+                h[pos] = rng.choice(np.frombuffer(b"ACGT", np.uint8))
+            skew.append([h.tobytes()])
+        eng.set_docs(skew)
+        got = mdist.run_sort_sharded(eng, dist, torch.device("cpu"), num_distinct=4, max_doc_freq=2, max_total_freq=0)
+        pieces = [c for _, c in eng.sort_pieces()]
+        out["skew_ok"] = got == O.run(skew, num_distinct=4, max_doc_freq=2, max_total_freq=0).text() and max(pieces) > min(pieces)
         q.put((rank, out))
         dist.barrier()
         eng.close()
@@ -220,6 +237,7 @@ def test_partial_and_mem_modes_sharded_over_ranks_equal_one_gpu(world, wide):
         for name in want:
             assert got[r][name] == want[name], (r, name)
             assert got[r][name + "_sort"] == want[name], (r, name, "sharded suffix sort")
+        assert got[r]["skew_ok"] is True, (r, "skewed collection through the sharded suffix sort")
     assert want["partial"].count(b"\n") > 10 and want["mems"].count(b"\n") > 10
 
 

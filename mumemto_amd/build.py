@@ -20,7 +20,7 @@ ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result",
             "--offload-arch=" + ARCH]
 
-LIB_SOURCES = ["kernels.hip", "prims.hip", "pfp_kernels.hip", "rows_kernels.hip", "merge_kernels.hip", "engine.cpp", "sorter.cpp", "pfp.cpp", "guided.cpp", "guided_kernels.hip", "pool.cpp", "dist.cpp", "merge.cpp", "partitioned.cpp", "api.cpp",
+LIB_SOURCES = ["kernels.hip", "prims.hip", "parse_lcp.hip", "pfp_kernels.hip", "rows_kernels.hip", "merge_kernels.hip", "engine.cpp", "sorter.cpp", "pfp.cpp", "guided.cpp", "guided_kernels.hip", "pool.cpp", "dist.cpp", "merge.cpp", "partitioned.cpp", "api.cpp",
                "cxx_api.cpp", "fasta.cpp", "options.cpp"]
 TOOLS = {"mumemto_exec": ["cli_main.cpp"], "anchor_merge": ["merge_main.cpp"]}
 HOST_TOOLS = {"extract_mums": ["extract_mums_main.cpp", "fasta.cpp"]}     # no device code: plain g++

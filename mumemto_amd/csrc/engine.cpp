@@ -217,6 +217,11 @@ void Engine::lcp_bwt() {
         if (wide_) { d_rank64_.ensure((size_t)anchor + 1); rank_out = d_rank64_.get(); }
         else { d_rank_.ensure((size_t)anchor + 1); rank_out = d_rank_.get(); }
     }
+    if (lcp_col_ready_) {                              // the producer wrote the LCP column itself (pfp.cpp, guided.cpp)
+        k::anchor_ranks(sa_col(), 0, n, anchor, rank_out, stream_);
+        lcp_whole_ = false;
+        return;
+    }
     d_plcp_a_.ensure(n); d_count_.ensure(8);
     const size_t rec = k::long_lcp_record_bytes(wide_) + 4;     // one record + one index for the second tier
     uint64_t cap64 = std::max<uint64_t>(d_long_.size() / rec, n / 256 + 4096);
@@ -373,13 +378,18 @@ void Engine::scan(const mmt_params& p) {
             if (len >= 0xffffe000ull) throw std::runtime_error("scan range with its left extension exceeds 2^32 entries");
             EventPair& eg = next_ev(0);
             eg.start(st);
-            if (!(lcp_whole_ && single)) {
-                d_lcp_.ensure(len + 16);
-                k::lcp_gather(d_plcp_a_.get(), sa_col(), b0, len, d_lcp_.get(), st);
-                lcp_whole_ = single;
+            const uint32_t* lcp_ptr = nullptr;
+            if (lcp_col_ready_) lcp_ptr = d_plcp_a_.get() + b0;          // the column exists in suffix-array order
+            else {
+                if (!(lcp_whole_ && single)) {
+                    d_lcp_.ensure(len + 16);
+                    k::lcp_gather(d_plcp_a_.get(), sa_col(), b0, len, d_lcp_.get(), st);
+                    lcp_whole_ = single;
+                }
+                lcp_ptr = d_lcp_.get();
             }
             eg.stop(st);
-            a.lcp = d_lcp_.get(); a.bwt = d_bwt_.get() + b0; a.n = (uint32_t)len; a.first = (uint32_t)ext;
+            a.lcp = lcp_ptr; a.bwt = d_bwt_.get() + b0; a.n = (uint32_t)len; a.first = (uint32_t)ext;
             a.more_left = b0 > 0 ? 1 : 0;
             size_t capacity = std::max<size_t>(1u << 20, p.merge_metadata ? len / 6 : len / 32);
             capacity = std::max(capacity, d_cand_.size());
@@ -417,7 +427,7 @@ void Engine::scan(const mmt_params& p) {
         ev.start(st);
         grow_keep(d_rows_, std::max<size_t>(rows_used + found, 1), rows_used, st);
         k::VerifyArgs v;
-        v.cand = d_cand_.get(); v.n_cand = found; v.sa = sa_col(); v.base = b0; v.lcp = d_lcp_.get();
+        v.cand = d_cand_.get(); v.n_cand = found; v.sa = sa_col(); v.base = b0; v.lcp = a.lcp;
         v.d_doc_start = d_doc_start_.get(); v.n_docs = (uint32_t)N;
         v.num_distinct = a.num_distinct;
         v.max_doc_freq = p.max_doc_freq > 0 ? (uint32_t)std::min<int64_t>(p.max_doc_freq, 0x7fffffff) : 0u;
@@ -674,6 +684,7 @@ void Engine::run(const mmt_params& p) {
     for (float& f : stage_ms_) f = 0.f;
     for (float& f : scan_ms_) f = 0.f;
     merged_thresh_valid_ = false;
+    lcp_col_ready_ = false;
     rows_ = HostRows();
     rows_pending_ = 0;
     rows_.mum_mode = p.max_doc_freq == 1;
@@ -777,7 +788,7 @@ void Engine::run(const mmt_params& p) {
     if (lean) d_long_.release();
     scan(p);
     // the PLCP column is dead after a single-range scan (copy_lcp reads the LCP column then)
-    if (lean && lcp_whole_) d_plcp_a_.release();
+    if (lean && lcp_whole_ && !lcp_col_ready_) d_plcp_a_.release();
     if (lean) { d_wpre_.release(); d_wsuf_.release(); d_wide_.release(); d_cand_.release(); }
     make_rows(p);
     finish();
@@ -806,6 +817,7 @@ void Engine::copy_sa64(uint64_t* out) const {
     for (uint64_t j = 0; j < n_; j++) out[j] = (uint64_t)lo[j] | (wide_ ? (uint64_t)hi[j] << 32 : 0);
 }
 void Engine::copy_lcp(uint32_t* out) {
+    if (lcp_col_ready_) { MMT_HIP(hipMemcpy(out, d_plcp_a_.get(), n_ * 4, hipMemcpyDeviceToHost)); return; }
     if (lcp_whole_) { MMT_HIP(hipMemcpy(out, d_lcp_.get(), n_ * 4, hipMemcpyDeviceToHost)); return; }
     // the run scanned the stream range by range: gather the column again, piece by piece
     if (!d_plcp_a_.get()) throw std::runtime_error("the LCP column of this run is gone");

@@ -211,6 +211,7 @@ private:
     // LCP column, BWT change marks replaced by their running maximum)
     DevBuf<uint32_t> d_wpre_, d_wsuf_, d_wide_;
     bool lcp_whole_ = false;              // d_lcp_ holds the LCP column of the whole stream (one scan range)
+    bool lcp_col_ready_ = false;          // d_plcp_a_ holds the LCP column in suffix-array order (written by the producer)
     uint32_t shard_index_ = 0, shard_count_ = 1;
     uint32_t sort_shard_index_ = 0, sort_shard_count_ = 1;
     void (*after_sort_)(void*) = nullptr;

@@ -218,13 +218,14 @@ void Engine::suffix_sort_guided() {
     S.err.ensure(16);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
     auto check_err = [&](const char* what) {
-        uint32_t e2[2];
-        MMT_HIP(hipMemcpyAsync(e2, S.err.get(), 8, hipMemcpyDeviceToHost, st));
+        uint32_t e2[3];
+        MMT_HIP(hipMemcpyAsync(e2, S.err.get(), 12, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipStreamSynchronize(st));
-        if (e2[0] || e2[1])
+        if (e2[0] || e2[1] || e2[2])
             throw std::runtime_error(std::string("guided sort (") + what + "): phrase suffixes are not prefix-free (" +
                                      std::to_string(e2[0]) + " equal distinct phrases, " + std::to_string(e2[1]) +
-                                     " groups with spent and unspent members)");
+                                     " groups with spent and unspent members, " + std::to_string(e2[2]) +
+                                     " neighbours equal up to the end of alpha without ascending parse ranks)");
     };
 
     // ---- lexicographic ranks of the distinct phrases, the parse ----
@@ -253,6 +254,10 @@ void Engine::suffix_sort_guided() {
         MMT_HIP(hipStreamSynchronize(st));
         sorter_.release();
     }
+    // LCP of adjacent parse suffixes + range minima: the LCP column is written batch by batch from them (a sharded sort
+    // still goes through the text-order construction: its pieces are exchanged without their LCP values)
+    const bool own_lcp = after_sort_ == nullptr;
+    if (own_lcp) S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
     S.sa_p.release(); S.parse.release(); S.pid.release(); S.rep.release(); S.prank.release(); S.pstart.release();
     S.plen.release(); S.dlen.release(); S.dstart.release();
     e5.stop(st);
@@ -270,6 +275,9 @@ void Engine::suffix_sort_guided() {
     d_sa_.ensure(n);
     if (W) d_sa_hi_.ensure(n + 16);
     d_bwt_.ensure((size_t)n + 16);
+    DevBuf<uint64_t> carry;
+    carry.ensure(2);
+    if (own_lcp) d_plcp_a_.ensure((size_t)n + 16);
     const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
     DevBuf<uint32_t> tile_cnt, tile_off;
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
@@ -306,6 +314,10 @@ void Engine::suffix_sort_guided() {
             gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
             RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st);
             gk::write_columns(ctx, X.pos_b.get(), B, base, sa_col(), d_bwt_.get(), st);
+            if (own_lcp) {
+                gk::batch_lcp(ctx, S.plcp.view(), X.pos_b.get(), B, carry.get(), base != 0, d_plcp_a_.get() + base, S.err.get(), st);
+                MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
+            }
             base += B; batches++; rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
         }
         b0 = b1;
@@ -313,6 +325,7 @@ void Engine::suffix_sort_guided() {
     check_err("text suffixes");
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
     S.bwt_ready = true;
+    lcp_col_ready_ = own_lcp;
     S.n_groups = 0; S.dict_len = 0; S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     e6.stop(st);
     MMT_HIP(hipStreamSynchronize(st));

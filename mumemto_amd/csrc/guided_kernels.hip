@@ -623,6 +623,43 @@ void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base,
         hipLaunchKernelGGL(k_write_columns<Sa32>, dim3(grid_for(B, 256)), dim3(256), 0, s, c, pos, B, base, Sa32(sa), bwt);
     MMT_HIP(hipGetLastError());
 }
+// LCP of every element of a sorted batch with the element before it (`carry`: the last element of the batch before).
+// The two suffixes are compared up to the end of the shorter phrase suffix alpha; phrase suffixes are prefix-free, so a
+// pair that is still equal there has the same alpha and shares |alpha| - w characters + the LCP of the two parse
+// suffixes that follow: a range minimum over the LCP array of the parse (pfp_lcp_mum.hpp:295-321, parse_lcp.hpp).
+__global__ void k_batch_lcp(Ctx c, RmqView R, const uint64_t* __restrict__ pos, uint32_t B, const uint64_t* __restrict__ carry,
+                            int have_carry, uint32_t* __restrict__ lcp, uint32_t* __restrict__ err) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    if (j == 0 && !have_carry) { lcp[0] = 0; return; }
+    const uint64_t ra = pos[j], rb = j ? pos[j - 1] : carry[0];
+    const uint64_t qa = rec_pos(c, ra), qb = rec_pos(c, rb);
+    const uint64_t la = rec_len(c, ra, qa), lb = rec_len(c, rb, qb);
+    const uint64_t lim = la < lb ? la : lb;
+    const uint8_t* x = c.v + qa;
+    const uint8_t* y = c.v + qb;
+    uint64_t h = 0;
+    while (h < lim) {
+        const uint64_t d = load_u64(x + h) ^ load_u64(y + h);
+        if (d) { h += (uint64_t)(__builtin_ctzll(d) >> 3); break; }
+        h += 8;
+    }
+    uint64_t v;
+    if (h < lim) v = h;
+    else {
+        const uint64_t ka = rec_rank_key(c, ra, qa), kb = rec_rank_key(c, rb, qb);
+        if (la != lb || kb >= ka) { atomicAdd(err + 2, 1u); v = lim; }
+        else v = la - c.w + rmq_min(R, (uint32_t)kb + 1, (uint32_t)ka);
+    }
+    lcp[j] = v < (uint64_t)LCP_CAP ? (uint32_t)v : LCP_CAP;
+}
+void batch_lcp(const Ctx& c, const RmqView& R, const uint64_t* pos, uint32_t B, const uint64_t* carry, bool have_carry,
+               uint32_t* lcp, uint32_t* err, hipStream_t s) {
+    if (!B) return;
+    hipLaunchKernelGGL(k_batch_lcp, dim3(grid_for(B, 256)), dim3(256), 0, s, c, R, pos, B, carry, have_carry ? 1 : 0, lcp, err);
+    MMT_HIP(hipGetLastError());
+}
+
 __global__ void k_phrase_ranks(Ctx c, const uint64_t* __restrict__ pos, uint32_t D, const uint32_t* __restrict__ pid,
                                uint32_t* __restrict__ prank) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "parse_lcp.hpp"
 #include "wide.hpp"
 
 namespace mmt { namespace gk {
@@ -74,6 +75,11 @@ void range_groups(const uint32_t* ghead, uint32_t begin, uint32_t end, uint32_t*
 
 // sorted batch -> suffix array and BWT columns at [base, base + B)
 void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base, SaCol sa, uint8_t* bwt, hipStream_t s);
+// sorted batch -> its piece of the LCP column (lcp[j] for element j); carry[0] = last element record of the batch before
+// (have_carry = false: the batch starts the suffix array, lcp[0] = 0); err[2] counts pairs that are equal up to the end
+// of alpha without being ordered by their parse ranks
+void batch_lcp(const Ctx& c, const RmqView& R, const uint64_t* pos, uint32_t B, const uint64_t* carry, bool have_carry,
+               uint32_t* lcp, uint32_t* err, hipStream_t s);
 // sorted phrases -> 1-based lexicographic rank per distinct phrase
 void phrase_ranks(const Ctx& c, const uint64_t* pos, uint32_t D, const uint32_t* pid, uint32_t* prank, hipStream_t s);
 

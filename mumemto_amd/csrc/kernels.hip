@@ -517,7 +517,16 @@ __device__ __forceinline__ uint64_t load_u64(const uint8_t* p) {
 // SA = suffix-array accessor (wide.hpp); its idx_t holds positions and ranks.
 // ============================================================================
 template <typename I>
-struct LongLcpT { I p, q; uint32_t h; };
+struct LongLcpT {
+    I p, q; uint32_t h;
+    __device__ __forceinline__ uint64_t dst() const { return (uint64_t)p; }      // the value belongs to text position p
+};
+// the same with a destination of its own (LCP of adjacent parse suffixes: positions are V indices, values are stored per
+// parse position -- kernels.hpp LongLcpDst)
+struct LongLcpDstT {
+    uint64_t p, q; uint32_t h, d;
+    __device__ __forceinline__ uint64_t dst() const { return (uint64_t)d; }
+};
 constexpr int IRR_STEPS = 24;
 
 // number of characters two suffixes at p and q can share at most, capped (wide.hpp)
@@ -640,12 +649,12 @@ __device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ t
     return first;
 }
 
-template <typename I>
-__global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, LongLcpT<I>* __restrict__ longs, uint32_t count,
+template <typename I, typename R>
+__global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict__ longs, uint32_t count,
                            uint32_t* __restrict__ plcp, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count) {
     const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= count) return;
-    const I p = longs[w].p, q = longs[w].q;
+    const I p = (I)longs[w].p, q = (I)longs[w].q;
     uint32_t h = longs[w].h;
     const uint32_t limit = lcp_limit<I>(n, p, q);
     const uint32_t stop = limit - h > LONG_WAVE_MAX ? h + LONG_WAVE_MAX : limit;
@@ -668,16 +677,16 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, LongLcpT<I>* _
         else h += LONG_SLICE;
     }
     if (found || h >= limit) {
-        if (lane == 0) plcp[p] = h > limit ? limit : h;
+        if (lane == 0) plcp[longs[w].dst()] = h > limit ? limit : h;
     } else if (lane == 0) {
         longs[w].h = h;
         huge_idx[atomicAdd(huge_count, 1u)] = w;
     }
 }
 
-template <typename I>
+template <typename I, typename R>
 __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __restrict__ text, I n,
-                                                              const LongLcpT<I>* __restrict__ longs,
+                                                              const R* __restrict__ longs,
                                                               const uint32_t* __restrict__ huge_idx,
                                                               const uint32_t* __restrict__ huge_count,
                                                               uint32_t* __restrict__ plcp) {
@@ -685,8 +694,8 @@ __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __r
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t total = *huge_count;
     for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
-        const LongLcpT<I> L = longs[huge_idx[e]];
-        const I p = L.p, q = L.q;
+        const R L = longs[huge_idx[e]];
+        const I p = (I)L.p, q = (I)L.q;
         const uint32_t limit = lcp_limit<I>(n, p, q);
         uint32_t h = L.h;
         while (h < limit) {
@@ -702,7 +711,7 @@ __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __r
             if (limit - h <= HUGE_WAVES * LONG_SLICE) { h = limit; break; }
             h += HUGE_WAVES * LONG_SLICE;
         }
-        if (threadIdx.x == 0) plcp[p] = h > limit ? limit : h;
+        if (threadIdx.x == 0) plcp[L.dst()] = h > limit ? limit : h;
     }
 }
 
@@ -832,14 +841,22 @@ void irreducible_lcp(const uint8_t* text, uint64_t n, SaCol sa, const uint8_t* b
     MMT_HIP(hipGetLastError());
 }
 size_t long_lcp_record_bytes(bool wide) { return wide ? sizeof(LongLcpT<uint64_t>) : sizeof(LongLcpT<uint32_t>); }
-template <typename I>
+template <typename I, typename R = LongLcpT<I>>
 static void long_lcp_typed(const uint8_t* text, uint64_t n, void* long_list, uint32_t count, uint32_t* plcp,
                            uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
-    hipLaunchKernelGGL(k_long_lcp<I>, dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, (I)n,
-                       static_cast<LongLcpT<I>*>(long_list), count, plcp, huge_idx, huge_count);
+    hipLaunchKernelGGL((k_long_lcp<I, R>), dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, (I)n,
+                       static_cast<R*>(long_list), count, plcp, huge_idx, huge_count);
     const uint32_t blocks = count < 1024u ? count : 1024u;       // the list is read on the device: no host round trip
-    hipLaunchKernelGGL(k_huge_lcp<I>, dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, (I)n,
-                       static_cast<const LongLcpT<I>*>(long_list), huge_idx, huge_count, plcp);
+    hipLaunchKernelGGL((k_huge_lcp<I, R>), dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, (I)n,
+                       static_cast<const R*>(long_list), huge_idx, huge_count, plcp);
+}
+void long_lcp_dst(const uint8_t* v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
+                  uint32_t* huge_count, hipStream_t s) {
+    static_assert(sizeof(LongLcpDstT) == sizeof(LongLcpDst), "record layout");
+    if (!count) return;
+    MMT_HIP(hipMemsetAsync(huge_count, 0, 4, s));
+    long_lcp_typed<uint64_t, LongLcpDstT>(v, nv, long_list, count, out, huge_idx, huge_count, s);
+    MMT_HIP(hipGetLastError());
 }
 void long_lcp(const uint8_t* text, uint64_t n, bool wide, void* long_list, uint32_t count, uint32_t* plcp,
               uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
@@ -855,6 +872,27 @@ void lcp_gather(const uint32_t* plcp, SaCol sa, uint64_t j0, uint64_t count, uin
         hipLaunchKernelGGL(k_lcp_gather<Sa40>, dim3(grid_for(count, 1024)), dim3(256), 0, s, plcp, Sa40(sa), j0, count, lcp);
     else
         hipLaunchKernelGGL(k_lcp_gather<Sa32>, dim3(grid_for(count, 1024)), dim3(256), 0, s, plcp, Sa32(sa), j0, count, lcp);
+    MMT_HIP(hipGetLastError());
+}
+
+// rank[p] = j0 + t for every entry t of a piece of the suffix array whose text position p lies in the anchor document
+// (the multi-GPU re-sort orders merged rows by the suffix rank of their anchor occurrence)
+template <typename SA>
+__global__ void k_anchor_ranks(SA sa, uint64_t j0, uint64_t count, typename SA::idx_t anchor_len,
+                               typename SA::idx_t* __restrict__ rank) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const typename SA::idx_t p = sa.get(t);
+    if (p < anchor_len) rank[p] = (typename SA::idx_t)(j0 + t);
+}
+void anchor_ranks(SaCol piece, uint64_t j0, uint64_t count, uint64_t anchor_len, void* rank, hipStream_t s) {
+    if (!count || !anchor_len) return;
+    if (piece.wide())
+        hipLaunchKernelGGL(k_anchor_ranks<Sa40>, dim3(grid_for(count, 256)), dim3(256), 0, s, Sa40(piece), j0, count,
+                           (uint64_t)anchor_len, static_cast<uint64_t*>(rank));
+    else
+        hipLaunchKernelGGL(k_anchor_ranks<Sa32>, dim3(grid_for(count, 256)), dim3(256), 0, s, Sa32(piece), j0, count,
+                           (uint32_t)anchor_len, static_cast<uint32_t*>(rank));
     MMT_HIP(hipGetLastError());
 }
 

@@ -78,10 +78,19 @@ size_t long_lcp_record_bytes(bool wide);
 // huge_idx (count entries) / huge_count: scratch for the matches that outgrow one wave (see kernels.hip)
 void long_lcp(const uint8_t* text, uint64_t n, bool wide, void* long_list, uint32_t count, uint32_t* plcp,
               uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s);
+// The same comparison loops for matches whose value belongs somewhere else than at text position p (parse_lcp.hip: LCP
+// of adjacent parse suffixes): records of (p, q, h, d) -- positions in the byte string `v` of nv bytes, h characters
+// already known to match -- leave out[d] = LCP.  huge_idx: count entries of scratch.
+struct LongLcpDst { uint64_t p, q; uint32_t h, d; };
+void long_lcp_dst(const uint8_t* v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
+                  uint32_t* huge_count, hipStream_t s);
 size_t plcp_running_max_scratch(uint64_t n);
 void plcp_running_max(uint32_t* plcp, uint64_t n, void* scratch, hipStream_t s);
 void lcp_gather(const uint32_t* plcp, SaCol sa, uint64_t j0, uint64_t count, uint32_t* lcp, hipStream_t s);
 void bwt_from_sa(const uint8_t* text, uint32_t n, const uint32_t* sa, uint8_t* bwt, hipStream_t s);
+// rank[p] = j0 + t for the entries t < count of `piece` (a piece of the suffix array that starts at suffix-array index j0)
+// whose text position p is below anchor_len; rank: uint32_t entries for a narrow piece, uint64_t for a wide one
+void anchor_ranks(SaCol piece, uint64_t j0, uint64_t count, uint64_t anchor_len, void* rank, hipStream_t s);
 
 // ---- A5 match scan -----------------------------------------------------------
 struct ScanArgs {

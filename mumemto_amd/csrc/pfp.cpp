@@ -191,7 +191,8 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     pk::phrase_ranks(S.esuf.get(), S.ephr.get(), S.pscan.get(), nd, S.prank.get(), st);
     pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
-    if (slim) { S.pflag.release(); S.pscan.release(); S.sa_d.release(); S.dict.release(); }
+    // (the dictionary and its suffix array stay until the LCP values between the groups are known: suffix_sort_pfp)
+    if (slim) { S.pflag.release(); S.pscan.release(); }
     e4.stop(st);
     S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms(); S.ms[3] = e3.ms(); S.ms[4] = e4.ms();
     S.have_parse = true;
@@ -221,6 +222,8 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     pk::pack_keys_u32(S.parse.get(), m, pbits, pchars, sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
     if (slim) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); S.isa_p.release(); S.parse.release(); }
+    // LCP of adjacent parse suffixes + range minima: every LCP value of the stream follows from them locally
+    S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
     e5.stop(st);
 
     e6.start(st);
@@ -229,6 +232,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     d_sa_.ensure(n);
     if (W) d_sa_hi_.ensure(n + 16);
     d_bwt_.ensure((size_t)n + 16);                      // no inverse suffix array on this path (see Engine::lcp_bwt)
+    d_plcp_a_.ensure((size_t)n + 16);                   // the emitter writes the LCP column itself (suffix-array order)
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
     const uint32_t pos_bits = W ? (uint32_t)bit_width_u64(n + w + 1) : 32u;
     if ((uint32_t)shift + pos_bits > 64)
@@ -268,10 +272,11 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
     pk::phrase_table(S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
     S.ce_cnt.ensure(E); S.ce_eoff.ensure(E, W); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
-    S.ce_bwt.ensure(E);
-    pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.vflag.get(), S.vscan.get(),
-                      S.ptab.get(), nd, S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(), S.ce_bwt.get(),
-                      S.ce_gs.get(), st);
+    S.ce_bwt.ensure(E); S.ce_dpos.ensure(E); S.ce_slen.ensure(E);
+    if (!S.gscan.get() || !S.sa_d.get() || !S.dict.get()) throw std::runtime_error("PFP tables released too early");
+    pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.gscan.get(), S.vflag.get(), S.vscan.get(),
+                      S.sa_d.get(), S.ptab.get(), nd, S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(), S.ce_bwt.get(),
+                      S.ce_gs.get(), S.ce_dpos.get(), S.ce_slen.get(), st);
     offsets_from_counts(d_temp_, S.ce_cnt.get(), S.ce_eoff, E, st);
     {
         const uint64_t total = S.ce_eoff.read(E - 1, st) + read_u32(S.ce_cnt.get() + (E - 1), st);
@@ -289,6 +294,10 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     pk::gather_pos(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), W, st);
     MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &E, 4, hipMemcpyHostToDevice, st));
     S.segb.write(G, n + 1, st);
+    // per group: |alpha| and the LCP with the phrase suffix of the group before (compared in the dictionary)
+    S.gsl.ensure(G); S.ghl.ensure(G);
+    pk::group_heads(S.sege.get(), S.ce_dpos.get(), S.ce_slen.get(), S.dict.get(), G, S.gsl.get(), S.ghl.get(), st);
+    if (slim) { MMT_HIP(hipStreamSynchronize(st)); S.ce_dpos.release(); S.ce_slen.release(); S.sa_d.release(); S.dict.release(); }
     if (std::getenv("MMT_DEBUG_SENTINEL")) {       // where does the end sentinel (stream entry 0) come from?
         std::vector<uint32_t> cnt2, first2, off2, sg2;
         d2h(cnt2, S.ce_cnt.get(), 2, st); d2h(first2, S.ce_first.get(), 2, st); d2h(off2, S.ce_offm1.get(), 2, st);
@@ -382,6 +391,8 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.n = n; ea.sa = sa_col(); ea.bwt = d_bwt_.get();
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F; ea.fb_base = 0;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
+    ea.lcp = d_plcp_a_.get(); ea.gsl = S.gsl.get(); ea.ghl = S.ghl.get(); ea.rmq = S.plcp.view(); ea.w = w;
+    ea.out_base = 0; ea.win_lo = 0; ea.win_hi = n;
     // the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at
     // most 16 different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)
     pk::BwtDecode decode{};
@@ -427,20 +438,22 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
             prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
                                                    nf, S.fb_rel.get(), S.fb_rel.get() + 1, shift + (int)fb_bits, st);
         pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), L.f0, L.f1, h_fb_off[L.f0], S.segb.get(), S.xk_b.get(),
-                            S.xv_b.get(), fb_bits, decode, text_ptr(), n, sa_col(), d_bwt_.get(), S.err.get(), W, st);
+                            S.xv_b.get(), fb_bits, decode, text_ptr(), n, ea, W, st);
     }
     if (read_u32(S.err.get(), st)) {
         std::vector<uint32_t> er;
         d2h(er, S.err.get(), 16, st);
         auto u64 = [&](int i) { return (unsigned long long)er[i] | ((unsigned long long)er[i + 1] << 32); };
-        char msg[400];
+        char msg[600];
         std::snprintf(msg, sizeof(msg), "PFP order is inconsistent: %u entries (sentinel not first %u; text position past the "
                       "end: %u in tile groups [first: position %llu at stream entry %llu], %u / %u in oversized groups [first: "
-                      "position %llu at entry %llu]); text %llu characters", er[0], er[4], er[5], u64(8), u64(10), er[6], er[7],
-                      u64(12), u64(14), (unsigned long long)n);
+                      "position %llu at entry %llu]; neighbours of a group without ascending parse ranks: %u); text %llu "
+                      "characters", er[0], er[4], er[5], u64(8), u64(10), er[6], er[7], u64(12), u64(14), er[3],
+                      (unsigned long long)n);
         throw std::runtime_error(msg);
     }
     S.bwt_ready = true;
+    lcp_col_ready_ = true;
     e6.stop(st);
     S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
     S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

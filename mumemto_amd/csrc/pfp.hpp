@@ -3,6 +3,7 @@
 #include <cstdint>
 
 #include "device_utils.hpp"
+#include "parse_lcp.hpp"
 
 namespace mmt {
 
@@ -27,6 +28,10 @@ struct PfpState {
     DevBuf<uint32_t> ce_cnt, ce_first, ce_offm1, ce_gs, sege, xk_a, xk_b, fb_group, fb_size, fb_rel, tile_first;
     PosBuf ce_eoff, segb, fb_off, fb_start, xv_a, xv_b;     // stream offsets / text positions
     DevBuf<uint8_t> ce_bwt, bwt_code;
+    // LCP without a text-order column: LCP of adjacent parse suffixes (+ range minima), per group of equal phrase
+    // suffixes the length of alpha and its LCP with the group before; ce_dpos / ce_slen: scratch of those
+    ParseLcp plcp;
+    DevBuf<uint32_t> gsl, ghl, ce_dpos, ce_slen;
     uint32_t n_entries = 0, n_fallback = 0, emit_launches = 0;
     bool bwt_ready = false;
 };

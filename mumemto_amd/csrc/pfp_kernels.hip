@@ -545,26 +545,66 @@ void phrase_table(const uint32_t* occ_start, const uint32_t* plen, const uint32_
 
 __global__ void k_entry_compact(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ ephr,
                                 const uint8_t* __restrict__ ebw, const uint32_t* __restrict__ gflag,
-                                const uint32_t* __restrict__ vflag, const uint32_t* __restrict__ vscan,
+                                const uint32_t* __restrict__ gscan, const uint32_t* __restrict__ vflag,
+                                const uint32_t* __restrict__ vscan, const uint32_t* __restrict__ sa_d,
                                 const uint4* __restrict__ tab, uint32_t nd,
                                 uint32_t* __restrict__ ce_cnt, uint32_t* __restrict__ ce_first,
                                 uint32_t* __restrict__ ce_offm1, uint8_t* __restrict__ ce_bwt,
-                                uint32_t* __restrict__ ce_gs) {
+                                uint32_t* __restrict__ ce_gs, uint32_t* __restrict__ ce_dpos,
+                                uint32_t* __restrict__ ce_slen) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd || !vflag[r]) return;
     const uint32_t c = vscan[r];
     const uint4 t = tab[ephr[r]];
+    const uint32_t sl = esuf[r] & 0x7fffffffu;
     ce_cnt[c] = t.x;
     ce_first[c] = t.y;
-    ce_offm1[c] = t.z - (esuf[r] & 0x7fffffffu) - 1;           // offset inside the phrase, minus one
+    ce_offm1[c] = t.z - sl - 1;                                // offset inside the phrase, minus one
     ce_bwt[c] = ebw[r];
-    ce_gs[c] = gflag[r];
+    ce_gs[c] = gflag[r] ? gscan[r] : 0u;                       // first entry of group g: g + 1, every other entry: 0
+    ce_dpos[c] = sa_d[r];
+    ce_slen[c] = sl;
 }
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
-                   const uint32_t* vflag, const uint32_t* vscan, const void* tab, uint32_t nd, uint32_t* ce_cnt,
-                   uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s) {
-    hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, ephr, ebw, gflag, vflag, vscan,
-                       static_cast<const uint4*>(tab), nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs);
+                   const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint32_t* sa_d,
+                   const void* tab, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
+                   uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_dpos, uint32_t* ce_slen, hipStream_t s) {
+    hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, ephr, ebw, gflag, gscan, vflag,
+                       vscan, sa_d, static_cast<const uint4*>(tab), nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs, ce_dpos,
+                       ce_slen);
+    MMT_HIP(hipGetLastError());
+}
+
+// Per group of equal phrase suffixes: the length of alpha, and the LCP of alpha with the alpha of the group before --
+// the LCP of the first stream entry of the group (pfp_lcp_mum.hpp:176-186: between groups the reference takes the
+// minimum of lcpD; here the two strings are compared in the dictionary, they differ before the shorter one ends).
+__global__ void k_group_heads(const uint32_t* __restrict__ sege, const uint32_t* __restrict__ ce_dpos,
+                              const uint32_t* __restrict__ ce_slen, const uint8_t* __restrict__ dict, uint32_t n_groups,
+                              uint32_t* __restrict__ gsl, uint32_t* __restrict__ ghl) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t e = sege[g];
+    const uint32_t la = ce_slen[e];
+    gsl[g] = la;
+    uint32_t h = 0;
+    if (g) {
+        const uint32_t lb = ce_slen[e - 1];
+        const uint32_t lim = la < lb ? la : lb;
+        const uint8_t* x = dict + ce_dpos[e];
+        const uint8_t* y = dict + ce_dpos[e - 1];
+        while (h < lim) {
+            const uint64_t d = ld64(x + h) ^ ld64(y + h);
+            if (d) { h += (uint32_t)(__builtin_ctzll(d) >> 3); break; }
+            h += 8;
+        }
+        if (h > lim) h = lim;
+    }
+    ghl[g] = h;
+}
+void group_heads(const uint32_t* sege, const uint32_t* ce_dpos, const uint32_t* ce_slen, const uint8_t* dict,
+                 uint32_t n_groups, uint32_t* gsl, uint32_t* ghl, hipStream_t s) {
+    hipLaunchKernelGGL(k_group_heads, dim3(grid_for(n_groups, 256)), dim3(256), 0, s, sege, ce_dpos, ce_slen, dict,
+                       n_groups, gsl, ghl);
     MMT_HIP(hipGetLastError());
 }
 
@@ -608,16 +648,22 @@ struct EmitArgsT {
     const uint8_t* bwt_code; uint32_t fb_bits;
     uint32_t* err;
     uint64_t tile_lo;
+    // LCP column and the window of the stream this launch writes: entry j of the suffix array (stream entry j + 1) goes to
+    // index j - out_base of sa / bwt / lcp when win_lo <= j < win_hi, and nowhere otherwise
+    uint32_t* lcp; const uint32_t* gsl; const uint32_t* ghl; RmqView rmq; uint32_t w;
+    uint64_t out_base, win_lo, win_hi;
 };
 template <int BLOCK, int CAP>
 struct EmitShared {
     uint32_t key[CAP];
+    uint32_t skey[CAP];          // the keys in merged order
     uint32_t estart[CAP + 1];
     uint32_t efirst[CAP];
     uint32_t eoffm1[CAP];
     uint32_t egfirst[CAP];       // first entry of the entry's group
+    uint32_t egs[CAP];           // group id + 1 at the first entry of a group, 0 elsewhere
     uint16_t owner[CAP];
-    uint8_t ebwt[CAP], egs[CAP];
+    uint8_t ebwt[CAP];
     uint32_t wmax[BLOCK / 64], gwmax[BLOCK / 64];
     uint32_t bound[4];
     uint64_t origin;             // oversized group: output offset that maps to slot 0 of this launch's fallback arrays
@@ -642,7 +688,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
         sh.efirst[e] = a.ce_first[e0 + e];
         sh.eoffm1[e] = a.ce_offm1[e0 + e];
         sh.ebwt[e] = a.ce_bwt[e0 + e];
-        sh.egs[e] = (uint8_t)a.ce_gs[e0 + e];
+        sh.egs[e] = a.ce_gs[e0 + e];
         sh.owner[st] = (uint16_t)e;
     }
     if (tid == 0) sh.estart[E] = L;
@@ -724,15 +770,45 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
             } while (e2 < E && !sh.egs[e2]);
             const P out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
             const P pos = my_pos[q];
+            sh.skey[sh.estart[gf] + rank] = key;
             if (out == 0) { if (pos != a.n) { atomicAdd(a.err, 1u); atomicAdd(a.err + 4, 1u); } }   // entry 0 must be the end sentinel
-            else if (pos < a.n) { a.sa.set(out - 1, pos); a.bwt[out - 1] = sh.ebwt[e]; }
-            else {
+            else if (pos < a.n) {
+                const uint64_t j = (uint64_t)out - 1;
+                if (j >= a.win_lo && j < a.win_hi) { a.sa.set(j - a.out_base, pos); a.bwt[j - a.out_base] = sh.ebwt[e]; }
+            } else {
                 atomicAdd(a.err, 1u);
                 if (atomicAdd(a.err + 5, 1u) == 0) {       // first offender, for the error message
                     a.err[8] = (uint32_t)pos; a.err[9] = (uint32_t)((uint64_t)pos >> 32);
                     a.err[10] = (uint32_t)out; a.err[11] = (uint32_t)((uint64_t)out >> 32);
                 }
             }
+        }
+    }
+    // LCP of every slot with the slot before it (in merged order): inside a group |alpha| - w + the LCP of the two
+    // following parse suffixes (a range minimum over the parse's LCP array: pfp_lcp_mum.hpp:295-321), at the first slot
+    // of a group the LCP of the two phrase suffixes themselves
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PERX; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        if (i < L) {
+            const uint64_t out = (uint64_t)clo + i;
+            if (out == 0) continue;
+            const uint64_t j = out - 1;
+            if (j < a.win_lo || j >= a.win_hi) continue;
+            const uint32_t gf = sh.egfirst[sh.owner[i]];
+            const uint32_t gid = sh.egs[gf] - 1;
+            uint32_t v;
+            if (i == sh.estart[gf]) v = a.ghl[gid];
+            else {
+                const uint32_t t1 = sh.skey[i - 1], t2 = sh.skey[i];
+                if (t1 == 0 || t2 <= t1) { atomicAdd(a.err, 1u); atomicAdd(a.err + 3, 1u); v = 0; }
+                else {
+                    const uint64_t x = (uint64_t)a.gsl[gid] - a.w + rmq_min(a.rmq, t1, t2 - 1);
+                    v = x < (uint64_t)LCP_CAP ? (uint32_t)x : LCP_CAP;
+                }
+            }
+            a.lcp[j - a.out_base] = j == 0 ? 0u : v;
         }
     }
 }
@@ -857,6 +933,8 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64
     t.fb_group = a.fb_group; t.fb_off = static_cast<const P*>(a.fb_off); t.n_fb = a.n_fb; t.fb_base = (P)a.fb_base;
     t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
     t.bwt_code = a.bwt_code; t.fb_bits = a.fb_bits; t.err = a.err; t.tile_lo = tile_lo;
+    t.lcp = a.lcp; t.gsl = a.gsl; t.ghl = a.ghl; t.rmq = a.rmq; t.w = a.w;
+    t.out_base = a.out_base; t.win_lo = a.win_lo; t.win_hi = a.win_hi;
     hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3((unsigned)(tile_hi - tile_lo)), dim3(BLOCK), 0, s, t,
                        tile_first_tab);
     MMT_HIP(hipGetLastError());
@@ -918,18 +996,21 @@ void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t*
     MMT_HIP(hipGetLastError());
 }
 
-// oversized groups after their segmented sort: sa / bwt from the sorted values
+// oversized groups after their segmented sort: sa / bwt / lcp from the sorted (key, position) pairs
+struct FinishLcp { uint32_t* lcp; const uint32_t* gsl; const uint32_t* ghl; RmqView rmq; uint32_t w; uint64_t out_base, win_lo, win_hi; };
 template <typename P, typename SA>
 __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P* __restrict__ fb_off, uint32_t f0,
                                   uint32_t f1, P fb_base, const P* __restrict__ segb,
                                   const uint32_t* __restrict__ sorted_keys, const P* __restrict__ sorted_vals,
                                   uint32_t fb_bits, BwtDecode decode, const uint8_t* __restrict__ text, P n, SA sa,
-                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err) {
+                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err, FinishLcp F) {
     const uint32_t f = f0 + blockIdx.x;
     if (f >= f1) return;
     const uint32_t lo = (uint32_t)(fb_off[f] - fb_base), hi = (uint32_t)(fb_off[f + 1] - fb_base);
-    const P out0 = segb[fb_group[f]];
+    const uint32_t g = fb_group[f];
+    const P out0 = segb[g];
     const uint32_t mask = (1u << fb_bits) - 1u;
+    const uint32_t sl = F.gsl[g], hl = F.ghl[g];
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const P p = sorted_vals[i], out = out0 + (i - lo);
         if (out == 0 || p >= n) {                                   // the sentinel never sits in an oversized group
@@ -940,26 +1021,39 @@ __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P
             }
             continue;
         }
-        sa.set(out - 1, p);
-        if (fb_bits) bwt[out - 1] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
-        else bwt[out - 1] = p ? text[p - 1] : (uint8_t)0;
+        const uint64_t j = (uint64_t)out - 1;
+        if (j < F.win_lo || j >= F.win_hi) continue;
+        const uint64_t at = j - F.out_base;
+        sa.set(at, p);
+        if (fb_bits) bwt[at] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
+        else bwt[at] = p ? text[p - 1] : (uint8_t)0;
+        uint32_t v = hl;
+        if (i > lo) {
+            const uint32_t t1 = sorted_keys[i - 1] >> fb_bits, t2 = sorted_keys[i] >> fb_bits;
+            if (t1 == 0 || t2 <= t1) { atomicAdd(err, 1u); atomicAdd(err + 3, 1u); v = 0; }
+            else {
+                const uint64_t x = (uint64_t)sl - F.w + rmq_min(F.rmq, t1, t2 - 1);
+                v = x < (uint64_t)LCP_CAP ? (uint32_t)x : LCP_CAP;
+            }
+        }
+        F.lcp[at] = j == 0 ? 0u : v;
     }
 }
 void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
-                     const BwtDecode& decode, const uint8_t* text, uint64_t n, SaCol sa, uint8_t* bwt, uint32_t* err,
-                     bool wide, hipStream_t s) {
+                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, bool wide, hipStream_t s) {
     if (f1 <= f0) return;
+    FinishLcp F{ea.lcp, ea.gsl, ea.ghl, ea.rmq, ea.w, ea.out_base, ea.win_lo, ea.win_hi};
     if (wide)
         hipLaunchKernelGGL((k_fallback_finish<uint64_t, Sa40>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
                            static_cast<const uint64_t*>(fb_off), f0, f1, (uint64_t)fb_base, static_cast<const uint64_t*>(segb),
                            sorted_keys, static_cast<const uint64_t*>(sorted_vals), fb_bits, decode, text, (uint64_t)n,
-                           Sa40(sa), bwt, err);
+                           Sa40(ea.sa), ea.bwt, ea.err, F);
     else
         hipLaunchKernelGGL((k_fallback_finish<uint32_t, Sa32>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
                            static_cast<const uint32_t*>(fb_off), f0, f1, (uint32_t)fb_base, static_cast<const uint32_t*>(segb),
                            sorted_keys, static_cast<const uint32_t*>(sorted_vals), fb_bits, decode, text, (uint32_t)n,
-                           Sa32(sa), bwt, err);
+                           Sa32(ea.sa), ea.bwt, ea.err, F);
     MMT_HIP(hipGetLastError());
 }
 

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "parse_lcp.hpp"
 #include "wide.hpp"
 
 namespace mmt { namespace pk {
@@ -48,9 +49,16 @@ void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_
                   hipStream_t s);
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
                 uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, bool wide, hipStream_t s);
+// gscan: inclusive sum of gflag.  ce_gs[c] = g + 1 at the first entry of group g, 0 elsewhere; ce_dpos / ce_slen: position
+// in the dictionary and length of the entry's phrase suffix (scratch of group_heads)
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
-                   const uint32_t* vflag, const uint32_t* vscan, const void* tab, uint32_t nd, uint32_t* ce_cnt,
-                   uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, hipStream_t s);
+                   const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint32_t* sa_d,
+                   const void* tab, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
+                   uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_dpos, uint32_t* ce_slen, hipStream_t s);
+// gsl[g] = length of the phrase suffix of group g, ghl[g] = its LCP with the phrase suffix of group g - 1 (0 for g = 0);
+// sege[g] = first compact entry of group g
+void group_heads(const uint32_t* sege, const uint32_t* ce_dpos, const uint32_t* ce_slen, const uint8_t* dict,
+                 uint32_t n_groups, uint32_t* gsl, uint32_t* ghl, hipStream_t s);
 void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s);
 void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
                   uint32_t* which, uint32_t* slen, hipStream_t s);
@@ -79,6 +87,14 @@ struct EmitArgs {
     // (distinct within a group) and fallback_finish gets the BWT byte back without a random read of the text
     const uint8_t* bwt_code; uint32_t fb_bits;
     uint32_t* err;                            // consistency errors
+    // The LCP column, and the window of the stream a launch writes: suffix-array entry j (stream entry j + 1) lands at
+    // index j - out_base of sa / bwt / lcp when win_lo <= j < win_hi and nowhere otherwise (a window is produced from
+    // the output tiles that cover it; groups that begin in those tiles may reach beyond it on either side).
+    uint32_t* lcp = nullptr;
+    const uint32_t* gsl = nullptr; const uint32_t* ghl = nullptr;   // per group: |alpha|, LCP with the group before
+    RmqView rmq;                              // LCP of adjacent parse suffixes (parse_lcp.hpp): keys t1 < t2 -> min sl[t1 .. t2 - 1]
+    uint32_t w = 0;
+    uint64_t out_base = 0, win_lo = 0, win_hi = ~0ull;
 };
 struct BwtDecode { uint8_t byte[16]; };       // code -> byte
 // tile_first[t] = first group whose begin offset is >= t * EMIT_TILE (tiles + 1 entries, tiles = ceil(n_out / TILE))
@@ -94,8 +110,8 @@ void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t*
 // oversized groups [f0, f1) after their segmented sort
 void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
-                     const BwtDecode& decode, const uint8_t* text, uint64_t n, SaCol sa, uint8_t* bwt, uint32_t* err,
-                     bool wide, hipStream_t s);
+                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, bool wide,
+                     hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);
 

@@ -218,7 +218,9 @@ void Engine::lcp_bwt() {
         else { d_rank_.ensure((size_t)anchor + 1); rank_out = d_rank_.get(); }
     }
     if (lcp_col_ready_) {                              // the producer wrote the LCP column itself (pfp.cpp, guided.cpp)
-        k::anchor_ranks(sa_col(), 0, n, anchor, rank_out, stream_);
+        // (the suffix ranks of the anchor order merged rows like a direct run: only runs that record merge metadata feed a merge)
+        if (want_anchor_ranks_) k::anchor_ranks(sa_col(), 0, n, anchor, rank_out, stream_);
+        anchor_ranks_valid_ = want_anchor_ranks_;
         lcp_whole_ = false;
         return;
     }
@@ -246,6 +248,7 @@ void Engine::lcp_bwt() {
     d_temp_.ensure(k::plcp_running_max_scratch(n));
     k::plcp_running_max(d_plcp_a_.get(), n, d_temp_.get(), stream_);      // PLCP everywhere, in place
     lcp_whole_ = false;
+    anchor_ranks_valid_ = true;                        // (written by k_irr_lcp, or the direct producer's inverse suffix array)
 }
 
 // One-shot / tight-memory runs: the suffix-sort stage (doubling scratch, dictionary, parse, emitter tables: two thirds
@@ -685,6 +688,8 @@ void Engine::run(const mmt_params& p) {
     for (float& f : scan_ms_) f = 0.f;
     merged_thresh_valid_ = false;
     lcp_col_ready_ = false;
+    want_anchor_ranks_ = p.merge_metadata != 0;
+    anchor_ranks_valid_ = false;
     rows_ = HostRows();
     rows_pending_ = 0;
     rows_.mum_mode = p.max_doc_freq == 1;

@@ -154,6 +154,7 @@ public:
     const uint16_t* thresh_device() const { return merged_thresh_valid_ ? merged_.d_thresh.get() : d_thresh_.get(); }
     const uint32_t* isa_device() const { return d_rank_.get(); }        // narrow runs
     const uint64_t* isa_device64() const { return d_rank64_.get(); }    // wide runs
+    bool anchor_ranks_valid() const { return anchor_ranks_valid_; }
     bool wide() const { return wide_; }
     // The text buffer also is the string V = Dollar . T . Dollar^w the prefix-free parse reads (newscan.hpp:248, :359):
     // one Dollar byte sits in front of T (64 bytes of padding keep T 16-byte aligned), 32 Dollar bytes and then
@@ -211,6 +212,7 @@ private:
     // LCP column, BWT change marks replaced by their running maximum)
     DevBuf<uint32_t> d_wpre_, d_wsuf_, d_wide_;
     bool lcp_whole_ = false;              // d_lcp_ holds the LCP column of the whole stream (one scan range)
+    bool want_anchor_ranks_ = false, anchor_ranks_valid_ = false;
     bool lcp_col_ready_ = false;          // d_plcp_a_ holds the LCP column in suffix-array order (written by the producer)
     uint32_t shard_index_ = 0, shard_count_ = 1;
     uint32_t sort_shard_index_ = 0, sort_shard_count_ = 1;

@@ -880,18 +880,24 @@ void lcp_gather(const uint32_t* plcp, SaCol sa, uint64_t j0, uint64_t count, uin
 template <typename SA>
 __global__ void k_anchor_ranks(SA sa, uint64_t j0, uint64_t count, typename SA::idx_t anchor_len,
                                typename SA::idx_t* __restrict__ rank) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    const typename SA::idx_t p = sa.get(t);
-    if (p < anchor_len) rank[p] = (typename SA::idx_t)(j0 + t);
+    // 16 entries per work-item, consecutive work-items on consecutive entries
+    const uint64_t t0 = (uint64_t)blockIdx.x * (blockDim.x * 16) + threadIdx.x;
+#pragma unroll 4
+    for (int q = 0; q < 16; q++) {
+        const uint64_t t = t0 + (uint64_t)q * blockDim.x;
+        if (t < count) {
+            const typename SA::idx_t p = sa.get(t);
+            if (p < anchor_len) rank[p] = (typename SA::idx_t)(j0 + t);
+        }
+    }
 }
 void anchor_ranks(SaCol piece, uint64_t j0, uint64_t count, uint64_t anchor_len, void* rank, hipStream_t s) {
     if (!count || !anchor_len) return;
     if (piece.wide())
-        hipLaunchKernelGGL(k_anchor_ranks<Sa40>, dim3(grid_for(count, 256)), dim3(256), 0, s, Sa40(piece), j0, count,
+        hipLaunchKernelGGL(k_anchor_ranks<Sa40>, dim3(grid_for(count, 256 * 16)), dim3(256), 0, s, Sa40(piece), j0, count,
                            (uint64_t)anchor_len, static_cast<uint64_t*>(rank));
     else
-        hipLaunchKernelGGL(k_anchor_ranks<Sa32>, dim3(grid_for(count, 256)), dim3(256), 0, s, Sa32(piece), j0, count,
+        hipLaunchKernelGGL(k_anchor_ranks<Sa32>, dim3(grid_for(count, 256 * 16)), dim3(256), 0, s, Sa32(piece), j0, count,
                            (uint32_t)anchor_len, static_cast<uint32_t*>(rank));
     MMT_HIP(hipGetLastError());
 }

@@ -213,7 +213,8 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
 void sort_like_direct(Engine& e, MergedRows& m) {
     const size_t n = m.n_rows;
     if (!n) return;
-    if (e.text_length() == 0) throw std::runtime_error("engine holds no suffix ranks: run it on a partition first");
+    if (e.text_length() == 0 || !e.anchor_ranks_valid())
+        throw std::runtime_error("engine holds no suffix ranks of the anchor: run it on a partition (with merge metadata) first");
     hipStream_t st = e.stream();
     MMT_HIP(hipSetDevice(e.device()));
     MergeScratch& M = scratch(e.device());

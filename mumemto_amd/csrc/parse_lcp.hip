@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "device_utils.hpp"
@@ -21,77 +23,136 @@ inline unsigned grid_for(uint64_t items, unsigned per_block) {
     return (unsigned)(g ? g : 1);
 }
 
-__device__ __forceinline__ uint64_t load_u64(const uint8_t* p) { uint64_t x; __builtin_memcpy(&x, p, 8); return x; }
 
-constexpr int STEPS = 24;          // 192 characters in the first kernel, the rest through the long-match list
-
-// One thread per entry of the parse's suffix array.  lirr[q] = LCP of parse suffix q with its predecessor when the entry
-// is irreducible (0 otherwise), head[q] = q + 1 for irreducible entries (0 otherwise).
-template <typename P>
-__global__ void k_parse_irr(const uint8_t* __restrict__ v, uint64_t nv, const uint32_t* __restrict__ sa_p,
-                            const uint32_t* __restrict__ pid, const P* __restrict__ pstart, uint32_t m,
-                            uint32_t* __restrict__ lirr, uint32_t* __restrict__ head, k::LongLcpDst* __restrict__ longs,
-                            uint32_t* __restrict__ counts, uint32_t long_cap) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63;
-    bool queue = false, irr = false;
-    uint64_t p = 0, q = 0;
-    uint32_t h = 0, qa = 0;
-    if (r < m) {
-        qa = sa_p[r];
-        const uint32_t qb = r ? sa_p[r - 1] : 0u;
-        irr = r == 0 || qa == 0 || qb == 0 || pid[qa - 1] != pid[qb - 1];
-        if (irr) {
-            if (r) {
-                p = (uint64_t)pstart[qa]; q = (uint64_t)pstart[qb];
-                const uint64_t room = nv - (p > q ? p : q);
-                const uint32_t limit = room < (uint64_t)LCP_CAP ? (uint32_t)room : LCP_CAP;
-                bool done = false;
-                for (int step = 0; step < STEPS && h < limit; step++) {
-                    const uint64_t x = load_u64(v + p + h), y = load_u64(v + q + h);
-                    if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
-                    h += 8;
-                }
-                if (h >= limit) { h = limit; done = true; }
-                queue = !done;
-            }
-            lirr[qa] = queue ? 0u : h;
-            head[qa] = qa + 1;
-        } else {
-            lirr[qa] = 0; head[qa] = 0;
+// Irreducible entries of the parse's suffix array: the phrase before sa_p[r] differs from the phrase before sa_p[r - 1]
+// (or one of the two suffixes starts the parse).  The irreducible ones are appended to a list of (parse position, parse
+// position of the predecessor) pairs, and head[q] = q + 1 marks them in parse order (head and lirr arrive zeroed).
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_parse_mark(const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ pid,
+                                                      uint32_t m, uint32_t* __restrict__ head, uint2* __restrict__ list,
+                                                      uint32_t* __restrict__ counts) {
+    // one list slot allocation per workgroup (a counter word takes ~150 atomics per microsecond on this part: one per wave
+    // of 64 entries was 6 M atomics = 40 ms)
+    __shared__ uint32_t s_cnt[PER * (BLOCK / 64)];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t qa[PER], qb[PER];
+    bool irr[PER];
+    uint64_t mask[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t r = (blockIdx.x * PER + k) * BLOCK + threadIdx.x;
+        irr[k] = false; qa[k] = 0; qb[k] = 0;
+        if (r < m) {
+            qa[k] = sa_p[r];
+            qb[k] = r ? sa_p[r - 1] : 0u;
         }
     }
-    const uint64_t mi = __ballot(irr);
-    if (mi && lane == (uint32_t)__builtin_ctzll(mi)) atomicAdd(counts + 1, (uint32_t)__popcll(mi));
-    const uint64_t mq = __ballot(queue);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t r = (blockIdx.x * PER + k) * BLOCK + threadIdx.x;
+        if (r < m) {
+            irr[k] = r == 0 || qa[k] == 0 || qb[k] == 0 || pid[qa[k] - 1] != pid[qb[k] - 1];
+            if (irr[k]) head[qa[k]] = qa[k] + 1;
+            if (r == 0) irr[k] = false;                        // (irreducible with LCP 0: nothing to compare)
+        }
+        mask[k] = __ballot(irr[k]);
+        if (lane == 0) s_cnt[k * (BLOCK / 64) + wave] = (uint32_t)__popcll(mask[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int i = 0; i < PER * (BLOCK / 64); i++) { const uint32_t c = s_cnt[i]; s_cnt[i] = total; total += c; }
+        s_base = total ? atomicAdd(counts + 1, total) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (irr[k])
+            list[s_base + s_cnt[k * (BLOCK / 64) + wave] + (uint32_t)__popcll(mask[k] & ((1ull << lane) - 1))] = make_uint2(qa[k], qb[k]);
+}
+
+// The comparisons: eight lanes per pair, 64 characters per step (aligned 8-byte words, funnelled), up to CMP_STEPS steps;
+// what is still equal then goes to the long-match list (kernels.hip: one wave per match, 512 characters per step and up).
+constexpr int CMP_STEPS = 8;
+template <typename P>
+__global__ void k_parse_cmp(const uint8_t* __restrict__ v, uint64_t nv, const uint2* __restrict__ list, uint32_t count,
+                            const P* __restrict__ pstart, uint32_t* __restrict__ lirr, k::LongLcpDst* __restrict__ longs,
+                            uint32_t* __restrict__ counts, uint32_t long_cap) {
+    const uint32_t lane = threadIdx.x & 63, sub = lane & 7, grp = lane >> 3;
+    const uint32_t e = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+    const bool live = e < count;
+    uint64_t p = 0, q = 0;
+    uint32_t qa = 0, limit = 0;
+    if (live) {
+        const uint2 pr = list[e];
+        qa = pr.x;
+        p = (uint64_t)pstart[pr.x]; q = (uint64_t)pstart[pr.y];
+        const uint64_t room = nv - (p > q ? p : q);
+        limit = room < (uint64_t)LCP_CAP ? (uint32_t)room : LCP_CAP;
+    }
+    const uint8_t* pa = v + (p & ~7ull);
+    const uint8_t* qb = v + (q & ~7ull);
+    const uint32_t sp = (uint32_t)(p & 7u) * 8, sq = (uint32_t)(q & 7u) * 8;
+    uint32_t h = 0;
+    bool done = !live;
+    for (int step = 0; step < CMP_STEPS; step++) {
+        const uint32_t o = h + sub * 8;
+        uint64_t d = 0;
+        if (!done && o < limit) {
+            const uint64_t xl = *reinterpret_cast<const uint64_t*>(pa + o), xh = *reinterpret_cast<const uint64_t*>(pa + o + 8);
+            const uint64_t yl = *reinterpret_cast<const uint64_t*>(qb + o), yh = *reinterpret_cast<const uint64_t*>(qb + o + 8);
+            const uint64_t x = sp ? (xl >> sp) | (xh << (64 - sp)) : xl;
+            const uint64_t y = sq ? (yl >> sq) | (yh << (64 - sq)) : yl;
+            d = x ^ y;
+        }
+        const uint64_t mall = __ballot(d != 0);
+        const uint32_t mg = (uint32_t)(mall >> (grp * 8)) & 0xffu;       // the same for the eight lanes of a pair
+        const int fl = mg ? __builtin_ctz(mg) : 0;
+        const uint64_t dx = __shfl(d, (int)(grp * 8) + fl, 64);         // (every lane takes part: no shuffle under divergence)
+        if (!done) {
+            if (mg) { h += (uint32_t)fl * 8 + (uint32_t)(__builtin_ctzll(dx) >> 3); done = true; }
+            else { h += 64; if (h >= limit) done = true; }
+        }
+        if (__ballot(!done) == 0) break;
+    }
+    if (h > limit) h = limit;
+    const bool queue = live && !done;
+    if (live && done && sub == 0) lirr[qa] = h;
+    const uint64_t mq = __ballot(queue && sub == 0);
     if (mq) {
         uint32_t slot0 = 0;
         const int leader = __builtin_ctzll(mq);
         if ((int)lane == leader) slot0 = atomicAdd(counts, (uint32_t)__popcll(mq));
         slot0 = __shfl(slot0, leader, 64);
-        if (queue) {
+        if (queue && sub == 0) {
             const uint32_t slot = slot0 + (uint32_t)__popcll(mq & ((1ull << lane) - 1));
             if (slot < long_cap) { longs[slot].p = p; longs[slot].q = q; longs[slot].h = h; longs[slot].d = qa; }
         }
     }
 }
 
-// sl[r] = lirr[q*] + pstart[q*] - pstart[q], q = sa_p[r], q* = src[q] - 1 (last irreducible parse position at or before q)
+// In parse order: value[q] = lirr[q*] + pstart[q*] - pstart[q], q* = src[q] - 1 = last irreducible position at or before q
+// (in place: src becomes the value)
 template <typename P>
-__global__ void k_parse_sl(const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ src,
-                           const uint32_t* __restrict__ lirr, const P* __restrict__ pstart, uint32_t m,
-                           uint32_t* __restrict__ sl, uint32_t* __restrict__ err) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m) return;
-    if (r == 0) { sl[0] = 0; return; }
-    const uint32_t q = sa_p[r];
+__global__ void k_parse_values(uint32_t* __restrict__ src, const uint32_t* __restrict__ lirr, const P* __restrict__ pstart,
+                               uint32_t m, uint32_t* __restrict__ err) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= m) return;
     const uint32_t s = src[q];
-    if (s == 0) { atomicAdd(err, 1u); sl[r] = 0; return; }       // (position 0 is irreducible: cannot happen)
+    if (s == 0) { atomicAdd(err, 1u); return; }                // (position 0 is irreducible: cannot happen)
     const uint64_t val = (uint64_t)lirr[s - 1] + (uint64_t)pstart[s - 1];
     const uint64_t here = (uint64_t)pstart[q];
-    if (val < here) { atomicAdd(err, 1u); sl[r] = 0; return; }   // a reducible entry always keeps at least w characters
+    if (val < here) { atomicAdd(err, 1u); src[q] = 0; return; }   // a reducible entry always keeps at least w characters
     const uint64_t d = val - here;
-    sl[r] = d < (uint64_t)LCP_CAP ? (uint32_t)d : LCP_CAP;
+    src[q] = d < (uint64_t)LCP_CAP ? (uint32_t)d : LCP_CAP;
+}
+// sl[r] = value[sa_p[r]]
+__global__ void k_parse_sl(const uint32_t* __restrict__ sa_p, const uint32_t* __restrict__ value, uint32_t m,
+                           uint32_t* __restrict__ sl) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    sl[r] = r ? value[sa_p[r]] : 0u;
 }
 
 // minimum of every block of 64 entries: one wave per block
@@ -122,29 +183,39 @@ void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const 
     while ((1u << levels) <= nb) levels++;
     sl.ensure((size_t)m + 64);
     DevBuf<uint32_t> lirr, head, counts, huge;
+    DevBuf<uint2> list;
     DevBuf<uint8_t> longs;
-    lirr.ensure(m); head.ensure(m); counts.ensure(4);
-    uint32_t cap = std::max<uint32_t>(m / 64 + 4096, 1u << 16);
+    lirr.ensure(m); head.ensure(m); counts.ensure(4); list.ensure((size_t)m + 64);
+    MMT_HIP(hipMemsetAsync(lirr.get(), 0, (size_t)m * 4, s));
+    MMT_HIP(hipMemsetAsync(head.get(), 0, (size_t)m * 4, s));
+    MMT_HIP(hipMemsetAsync(counts.get(), 0, 16, s));
+    hipLaunchKernelGGL((k_parse_mark<256, 4>), dim3(grid_for(m, 1024)), dim3(256), 0, s, sa_p, pid, m, head.get(), list.get(),
+                       counts.get());
+    MMT_HIP(hipGetLastError());
+    MMT_HIP(hipMemcpyAsync(&n_irreducible, counts.get() + 1, 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    uint32_t cap = std::max<uint32_t>(n_irreducible / 2 + 4096, 1u << 16);
     for (int attempt = 0;; attempt++) {
         longs.ensure((size_t)cap * sizeof(k::LongLcpDst));
-        MMT_HIP(hipMemsetAsync(counts.get(), 0, 16, s));
-        if (wide)
-            hipLaunchKernelGGL(k_parse_irr<uint64_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, v, nv, sa_p, pid,
-                               static_cast<const uint64_t*>(pstart), m, lirr.get(), head.get(),
-                               reinterpret_cast<k::LongLcpDst*>(longs.get()), counts.get(), cap);
-        else
-            hipLaunchKernelGGL(k_parse_irr<uint32_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, v, nv, sa_p, pid,
-                               static_cast<const uint32_t*>(pstart), m, lirr.get(), head.get(),
-                               reinterpret_cast<k::LongLcpDst*>(longs.get()), counts.get(), cap);
-        MMT_HIP(hipGetLastError());
-        uint32_t back[2] = {0, 0};
-        MMT_HIP(hipMemcpyAsync(back, counts.get(), 8, hipMemcpyDeviceToHost, s));
+        MMT_HIP(hipMemsetAsync(counts.get(), 0, 4, s));
+        if (n_irreducible) {
+            if (wide)
+                hipLaunchKernelGGL(k_parse_cmp<uint64_t>, dim3(grid_for((uint64_t)n_irreducible * 8, 256)), dim3(256), 0, s, v, nv,
+                                   list.get(), n_irreducible, static_cast<const uint64_t*>(pstart), lirr.get(),
+                                   reinterpret_cast<k::LongLcpDst*>(longs.get()), counts.get(), cap);
+            else
+                hipLaunchKernelGGL(k_parse_cmp<uint32_t>, dim3(grid_for((uint64_t)n_irreducible * 8, 256)), dim3(256), 0, s, v, nv,
+                                   list.get(), n_irreducible, static_cast<const uint32_t*>(pstart), lirr.get(),
+                                   reinterpret_cast<k::LongLcpDst*>(longs.get()), counts.get(), cap);
+            MMT_HIP(hipGetLastError());
+        }
+        MMT_HIP(hipMemcpyAsync(&n_long, counts.get(), 4, hipMemcpyDeviceToHost, s));
         MMT_HIP(hipStreamSynchronize(s));
-        n_long = back[0]; n_irreducible = back[1];
         if (n_long <= cap) break;
         if (attempt) throw std::runtime_error("long-match list overflow in the parse LCP construction");
         cap = n_long + 1024;                                   // rare: once more with the exact size
     }
+    list.release();
     if (n_long) {
         huge.ensure((size_t)n_long + 1);
         k::long_lcp_dst(v, nv, longs.get(), n_long, lirr.get(), huge.get(), counts.get() + 2, s);
@@ -152,11 +223,12 @@ void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const 
     prims::inclusive_max_u32(temp, head.get(), head.get(), m, s);
     MMT_HIP(hipMemsetAsync(counts.get() + 3, 0, 4, s));
     if (wide)
-        hipLaunchKernelGGL(k_parse_sl<uint64_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_p, head.get(), lirr.get(),
-                           static_cast<const uint64_t*>(pstart), m, sl.get(), counts.get() + 3);
+        hipLaunchKernelGGL(k_parse_values<uint64_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, head.get(), lirr.get(),
+                           static_cast<const uint64_t*>(pstart), m, counts.get() + 3);
     else
-        hipLaunchKernelGGL(k_parse_sl<uint32_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_p, head.get(), lirr.get(),
-                           static_cast<const uint32_t*>(pstart), m, sl.get(), counts.get() + 3);
+        hipLaunchKernelGGL(k_parse_values<uint32_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, head.get(), lirr.get(),
+                           static_cast<const uint32_t*>(pstart), m, counts.get() + 3);
+    hipLaunchKernelGGL(k_parse_sl, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_p, head.get(), m, sl.get());
     MMT_HIP(hipGetLastError());
     bmin.ensure((size_t)levels * nb + 64);
     hipLaunchKernelGGL(k_block_min, dim3(grid_for((uint64_t)nb * 64, 256)), dim3(256), 0, s, sl.get(), m, bmin.get(), nb);
@@ -168,6 +240,9 @@ void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const 
     MMT_HIP(hipMemcpyAsync(&bad, counts.get() + 3, 4, hipMemcpyDeviceToHost, s));
     MMT_HIP(hipStreamSynchronize(s));
     if (bad) throw std::runtime_error("parse LCP construction: " + std::to_string(bad) + " inconsistent entries");
+    if (std::getenv("MMT_LCP_STATS"))
+        std::fprintf(stderr, "[parse lcp] %u parse suffixes, %u irreducible, %u matches beyond %d characters\n", m, n_irreducible,
+                     n_long, CMP_STEPS * 64);
 }
 
 }  // namespace mmt

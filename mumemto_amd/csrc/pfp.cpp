@@ -250,8 +250,9 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         pk::occ_sequence(S.sa_p.get(), S.pid.get(), m, D, k_in, v_in, st);
         prims::sort_pairs_u32_u32(d_temp_, k_in, S.occ_ids.get(), v_in, S.occ_ts.get(), (size_t)m + 1, 0,
                                   std::max(1, bit_width_u64((uint64_t)D)), st);
+        S.occ_sl.ensure(m);
         pk::occ_finish(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), m, S.occ_start.get(),
-                       S.occ.get(), pos_bits, W, st);
+                       S.occ.get(), pos_bits, S.plcp.sl.get(), S.occ_sl.get(), W, st);
         MMT_HIP(hipStreamSynchronize(st));
     }
     if (std::getenv("MMT_DEBUG_SENTINEL")) {
@@ -295,8 +296,8 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &E, 4, hipMemcpyHostToDevice, st));
     S.segb.write(G, n + 1, st);
     // per group: |alpha| and the LCP with the phrase suffix of the group before (compared in the dictionary)
-    S.gsl.ensure(G); S.ghl.ensure(G);
-    pk::group_heads(S.sege.get(), S.ce_dpos.get(), S.ce_slen.get(), S.dict.get(), G, S.gsl.get(), S.ghl.get(), st);
+    S.ghead.ensure((size_t)G * 2);
+    pk::group_heads(S.sege.get(), S.ce_dpos.get(), S.ce_slen.get(), S.dict.get(), G, S.ghead.get(), st);
     if (slim) { MMT_HIP(hipStreamSynchronize(st)); S.ce_dpos.release(); S.ce_slen.release(); S.sa_d.release(); S.dict.release(); }
     if (std::getenv("MMT_DEBUG_SENTINEL")) {       // where does the end sentinel (stream entry 0) come from?
         std::vector<uint32_t> cnt2, first2, off2, sg2;
@@ -353,7 +354,7 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     if (slim) S.gscan.release();
 
     // ---- launch plan: ranges of output tiles whose oversized groups fit the fallback arrays of one launch ----
-    const uint64_t tiles = (n + 1 + pk::EMIT_TILE - 1) / pk::EMIT_TILE;
+    const uint64_t tiles = (n + 1 + pk::emit_tile() - 1) / pk::emit_tile();
     uint64_t per_launch = W ? (1ull << 18) : tiles;                       // wide: 2^28 output positions per launch
     if (const char* c = std::getenv("MMT_EMIT_TILES")) per_launch = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
     if (per_launch > 0x7fffffffull) per_launch = 0x7fffffffull;
@@ -366,10 +367,10 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     uint64_t max_fb = 0;
     for (uint64_t t0 = 0; t0 < tiles;) {
         uint64_t t1 = std::min(tiles, t0 + per_launch);
-        uint32_t f0 = first_group_at(t0 * pk::EMIT_TILE), f1 = first_group_at(t1 * pk::EMIT_TILE);
+        uint32_t f0 = first_group_at(t0 * pk::emit_tile()), f1 = first_group_at(t1 * pk::emit_tile());
         while (h_fb_off[f1] - h_fb_off[f0] > FB_LIMIT && t1 - t0 > 1) {   // too many oversized suffixes: halve the range
             t1 = t0 + (t1 - t0) / 2;
-            f1 = first_group_at(t1 * pk::EMIT_TILE);
+            f1 = first_group_at(t1 * pk::emit_tile());
         }
         if (h_fb_off[f1] - h_fb_off[f0] > FB_LIMIT)
             throw std::runtime_error("the oversized suffix groups of one emitter tile exceed 2^32 elements");
@@ -387,11 +388,11 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
-    ea.occ = S.occ.get(); ea.pos_bits = pos_bits;
+    ea.occ = S.occ.get(); ea.occ_sl = S.occ_sl.get(); ea.pos_bits = pos_bits;
     ea.n = n; ea.sa = sa_col(); ea.bwt = d_bwt_.get();
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F; ea.fb_base = 0;
     ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
-    ea.lcp = d_plcp_a_.get(); ea.gsl = S.gsl.get(); ea.ghl = S.ghl.get(); ea.rmq = S.plcp.view(); ea.w = w;
+    ea.lcp = d_plcp_a_.get(); ea.ghead = S.ghead.get(); ea.rmq = S.plcp.view(); ea.w = w;
     ea.out_base = 0; ea.win_lo = 0; ea.win_hi = n;
     // the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at
     // most 16 different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)

@@ -31,7 +31,7 @@ struct PfpState {
     // LCP without a text-order column: LCP of adjacent parse suffixes (+ range minima), per group of equal phrase
     // suffixes the length of alpha and its LCP with the group before; ce_dpos / ce_slen: scratch of those
     ParseLcp plcp;
-    DevBuf<uint32_t> gsl, ghl, ce_dpos, ce_slen;
+    DevBuf<uint32_t> ghead, ce_dpos, ce_slen, occ_sl;
     uint32_t n_entries = 0, n_fallback = 0, emit_launches = 0;
     bool bwt_ready = false;
 };

@@ -11,7 +11,9 @@
 // exactly the string the reference parser consumes (newscan.hpp:248, :359).
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "device_utils.hpp"
@@ -506,7 +508,8 @@ void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_
 template <typename P>
 __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ ts,
                              const uint32_t* __restrict__ sa_p, const P* __restrict__ pstart, uint32_t m,
-                             uint32_t* __restrict__ occ_start, uint64_t* __restrict__ occ, uint32_t pos_bits) {
+                             uint32_t* __restrict__ occ_start, uint64_t* __restrict__ occ, uint32_t pos_bits,
+                             const uint32_t* __restrict__ sl, uint32_t* __restrict__ occ_sl) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k > m) return;
     const uint32_t id = ids[k];
@@ -515,15 +518,19 @@ __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* _
     const uint32_t t = ts[k];
     const uint32_t q = t ? sa_p[t - 1] - 1 : m - 1;
     occ[k] = ((uint64_t)t << pos_bits) | (uint64_t)pstart[q];
+    // LCP of the following parse suffix with its predecessor in the parse's suffix array (parse_lcp.hpp): the emitter
+    // needs it for the element's LCP and would otherwise fetch it after it has read this record
+    occ_sl[k] = t ? sl[t - 1] : 0u;
 }
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
-                uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, bool wide, hipStream_t s) {
+                uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, const uint32_t* sl, uint32_t* occ_sl, bool wide,
+                hipStream_t s) {
     if (wide)
         hipLaunchKernelGGL(k_occ_finish<uint64_t>, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p,
-                           static_cast<const uint64_t*>(pstart), m, occ_start, occ, pos_bits);
+                           static_cast<const uint64_t*>(pstart), m, occ_start, occ, pos_bits, sl, occ_sl);
     else
         hipLaunchKernelGGL(k_occ_finish<uint32_t>, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p,
-                           static_cast<const uint32_t*>(pstart), m, occ_start, occ, pos_bits);
+                           static_cast<const uint32_t*>(pstart), m, occ_start, occ, pos_bits, sl, occ_sl);
     MMT_HIP(hipGetLastError());
 }
 
@@ -580,12 +587,11 @@ void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* eb
 // minimum of lcpD; here the two strings are compared in the dictionary, they differ before the shorter one ends).
 __global__ void k_group_heads(const uint32_t* __restrict__ sege, const uint32_t* __restrict__ ce_dpos,
                               const uint32_t* __restrict__ ce_slen, const uint8_t* __restrict__ dict, uint32_t n_groups,
-                              uint32_t* __restrict__ gsl, uint32_t* __restrict__ ghl) {
+                              uint2* __restrict__ ghead) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const uint32_t e = sege[g];
     const uint32_t la = ce_slen[e];
-    gsl[g] = la;
     uint32_t h = 0;
     if (g) {
         const uint32_t lb = ce_slen[e - 1];
@@ -599,12 +605,12 @@ __global__ void k_group_heads(const uint32_t* __restrict__ sege, const uint32_t*
         }
         if (h > lim) h = lim;
     }
-    ghl[g] = h;
+    ghead[g] = make_uint2(la, h);
 }
 void group_heads(const uint32_t* sege, const uint32_t* ce_dpos, const uint32_t* ce_slen, const uint8_t* dict,
-                 uint32_t n_groups, uint32_t* gsl, uint32_t* ghl, hipStream_t s) {
+                 uint32_t n_groups, void* ghead, hipStream_t s) {
     hipLaunchKernelGGL(k_group_heads, dim3(grid_for(n_groups, 256)), dim3(256), 0, s, sege, ce_dpos, ce_slen, dict,
-                       n_groups, gsl, ghl);
+                       n_groups, static_cast<uint2*>(ghead));
     MMT_HIP(hipGetLastError());
 }
 
@@ -640,7 +646,7 @@ struct EmitArgsT {
     const P* segb; const uint32_t* sege; uint32_t n_groups;
     const P* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
-    const uint64_t* occ; uint32_t pos_bits;
+    const uint64_t* occ; const uint32_t* occ_sl; uint32_t pos_bits;
     P n;
     SA sa; uint8_t* bwt;
     const uint32_t* fb_group; const P* fb_off; uint32_t n_fb; P fb_base;
@@ -650,16 +656,15 @@ struct EmitArgsT {
     uint64_t tile_lo;
     // LCP column and the window of the stream this launch writes: entry j of the suffix array (stream entry j + 1) goes to
     // index j - out_base of sa / bwt / lcp when win_lo <= j < win_hi, and nowhere otherwise
-    uint32_t* lcp; const uint32_t* gsl; const uint32_t* ghl; RmqView rmq; uint32_t w;
+    uint32_t* lcp; const uint2* ghead; RmqView rmq; uint32_t w;
     uint64_t out_base, win_lo, win_hi;
 };
 template <int BLOCK, int CAP>
 struct EmitShared {
+    alignas(8) uint32_t efirst[CAP];   // these two also hold, once the elements have their positions, (key, sl[key - 1]) of
+    uint32_t eoffm1[CAP];              // the element in every slot of the merged order, as CAP pairs
     uint32_t key[CAP];
-    uint32_t skey[CAP];          // the keys in merged order
     uint32_t estart[CAP + 1];
-    uint32_t efirst[CAP];
-    uint32_t eoffm1[CAP];
     uint32_t egfirst[CAP];       // first entry of the entry's group
     uint32_t egs[CAP];           // group id + 1 at the first entry of a group, 0 elsewhere
     uint16_t owner[CAP];
@@ -676,6 +681,7 @@ struct EmitShared {
 template <int BLOCK, int CAP, typename P, typename SA>
 __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
                                            P clo, uint32_t L, bool sorted, P fb_origin) {
+    using EmitSh = EmitShared<BLOCK, CAP>;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t E = e1 - e0;
     const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
@@ -733,12 +739,15 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
     __syncthreads();
     constexpr int PERX = CAP / BLOCK;
     P my_pos[PERX];
+    uint32_t my_sl[PERX];
 #pragma unroll
     for (int q = 0; q < PERX; q++) {
         const uint32_t i = tid + q * BLOCK;
+        my_sl[q] = 0;
         if (i < L) {
             const uint32_t e = sh.owner[i], k = i - sh.estart[e];
             const uint64_t kp = a.occ[sh.efirst[e] + k];
+            if (sorted) my_sl[q] = a.occ_sl[sh.efirst[e] + k];
             const uint32_t key = (uint32_t)(kp >> a.pos_bits);
             my_pos[q] = (P)((kp & pos_mask) + sh.eoffm1[e]);
             if (sorted) sh.key[i] = key;
@@ -751,13 +760,32 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
     }
     if (!sorted) return;
     __syncthreads();
+    // What the LCP values need from global memory is requested before the merge ranks are counted in LDS: per element
+    // sl[key - 1] (it came with the occurrence record) -- the last term of min(sl[t1 .. t2 - 1]), and all of it when the
+    // two parse ranks are adjacent, the common case --, per slot |alpha| and the LCP at the head of its group.  (Element i
+    // and slot i lie in the same group: a group keeps its slots.)
+    uint2 g_head[PERX];
+    uint32_t my_e[PERX], my_gf[PERX], my_gs[PERX];
 #pragma unroll
     for (int q = 0; q < PERX; q++) {
         const uint32_t i = tid + q * BLOCK;
+        g_head[q] = make_uint2(0u, 0u); my_e[q] = 0; my_gf[q] = 0; my_gs[q] = 0;
         if (i < L) {
-            const uint32_t e = sh.owner[i], key = sh.key[i];
-            const uint32_t gf = sh.egfirst[e];
-            uint32_t rank = 0, e2 = gf;
+            my_e[q] = sh.owner[i];
+            my_gf[q] = sh.egfirst[my_e[q]];
+            my_gs[q] = sh.estart[my_gf[q]];
+            g_head[q] = a.ghead[sh.egs[my_gf[q]] - 1];
+        }
+    }
+    // merge rank of every element inside its group = its slot
+    uint32_t my_slot[PERX];
+#pragma unroll
+    for (int q = 0; q < PERX; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        my_slot[q] = 0;
+        if (i < L) {
+            const uint32_t e = my_e[q], key = sh.key[i];
+            uint32_t rank = 0, e2 = my_gf[q];
             do {
                 const uint32_t lo = sh.estart[e2], hi = sh.estart[e2 + 1];
                 if (e2 == e) rank += i - lo;
@@ -768,47 +796,77 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
                 }
                 e2++;
             } while (e2 < E && !sh.egs[e2]);
-            const P out = clo + sh.estart[gf] + rank;    // index in the n+1 entry stream
-            const P pos = my_pos[q];
-            sh.skey[sh.estart[gf] + rank] = key;
-            if (out == 0) { if (pos != a.n) { atomicAdd(a.err, 1u); atomicAdd(a.err + 4, 1u); } }   // entry 0 must be the end sentinel
-            else if (pos < a.n) {
-                const uint64_t j = (uint64_t)out - 1;
-                if (j >= a.win_lo && j < a.win_hi) { a.sa.set(j - a.out_base, pos); a.bwt[j - a.out_base] = sh.ebwt[e]; }
-            } else {
-                atomicAdd(a.err, 1u);
-                if (atomicAdd(a.err + 5, 1u) == 0) {       // first offender, for the error message
-                    a.err[8] = (uint32_t)pos; a.err[9] = (uint32_t)((uint64_t)pos >> 32);
-                    a.err[10] = (uint32_t)out; a.err[11] = (uint32_t)((uint64_t)out >> 32);
-                }
-            }
+            my_slot[q] = my_gs[q] + rank;
         }
     }
-    // LCP of every slot with the slot before it (in merged order): inside a group |alpha| - w + the LCP of the two
-    // following parse suffixes (a range minimum over the parse's LCP array: pfp_lcp_mum.hpp:295-321), at the first slot
-    // of a group the LCP of the two phrase suffixes themselves
+    // The elements move to their slots INSIDE LDS -- (key, sl) over efirst / eoffm1, the text position over key[], its
+    // high byte and the BWT byte over owner[]: nothing of the tile tables is read any more -- so that every column is
+    // written to HBM in slot order, one coalesced store per column (the elements used to be scattered from where they
+    // were expanded: four partial-line stores per element).
+    static_assert(offsetof(EmitSh, eoffm1) == offsetof(EmitSh, efirst) + CAP * sizeof(uint32_t), "efirst and eoffm1 must be adjacent");
+    uint2* const merged = reinterpret_cast<uint2*>(sh.efirst);
+    uint32_t* const mpos = sh.key;
+    uint16_t* const mhb = sh.owner;
+    uint8_t my_bwt[PERX];
+#pragma unroll
+    for (int q = 0; q < PERX; q++) my_bwt[q] = tid + q * BLOCK < L ? sh.ebwt[my_e[q]] : (uint8_t)0;
+    uint32_t my_key[PERX];
+#pragma unroll
+    for (int q = 0; q < PERX; q++) my_key[q] = tid + q * BLOCK < L ? sh.key[tid + q * BLOCK] : 0u;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PERX; q++) {
         const uint32_t i = tid + q * BLOCK;
         if (i < L) {
+            const uint32_t slot = my_slot[q];
+            const uint64_t pos = (uint64_t)my_pos[q];
+            merged[slot] = make_uint2(my_key[q], my_sl[q]);
+            mpos[slot] = (uint32_t)pos;
+            mhb[slot] = (uint16_t)(((uint32_t)(pos >> 32) & 0xffu) | ((uint32_t)my_bwt[q] << 8));
+        }
+    }
+    __syncthreads();
+    // slot i: suffix-array entry, BWT byte, and the LCP with the slot before it -- inside a group |alpha| - w + the LCP of
+    // the two following parse suffixes (a range minimum over the parse's LCP array: pfp_lcp_mum.hpp:295-321), at the first
+    // slot of a group the LCP of the two phrase suffixes themselves
+#pragma unroll
+    for (int q = 0; q < PERX; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        if (i < L) {
             const uint64_t out = (uint64_t)clo + i;
-            if (out == 0) continue;
+            const uint32_t hb = mhb[i];
+            const uint64_t pos = (uint64_t)mpos[i] | ((uint64_t)(hb & 0xffu) << 32);
+            if (out == 0) {                              // entry 0 must be the end sentinel
+                if (pos != (uint64_t)a.n) { atomicAdd(a.err, 1u); atomicAdd(a.err + 4, 1u); }
+                continue;
+            }
+            if (pos >= (uint64_t)a.n) {
+                atomicAdd(a.err, 1u);
+                if (atomicAdd(a.err + 5, 1u) == 0) {       // first offender, for the error message
+                    a.err[8] = (uint32_t)pos; a.err[9] = (uint32_t)(pos >> 32);
+                    a.err[10] = (uint32_t)out; a.err[11] = (uint32_t)(out >> 32);
+                }
+                continue;
+            }
             const uint64_t j = out - 1;
             if (j < a.win_lo || j >= a.win_hi) continue;
-            const uint32_t gf = sh.egfirst[sh.owner[i]];
-            const uint32_t gid = sh.egs[gf] - 1;
             uint32_t v;
-            if (i == sh.estart[gf]) v = a.ghl[gid];
+            if (i == my_gs[q]) v = g_head[q].y;
             else {
-                const uint32_t t1 = sh.skey[i - 1], t2 = sh.skey[i];
+                const uint2 cur = merged[i];
+                const uint32_t t1 = merged[i - 1].x, t2 = cur.x;
                 if (t1 == 0 || t2 <= t1) { atomicAdd(a.err, 1u); atomicAdd(a.err + 3, 1u); v = 0; }
                 else {
-                    const uint64_t x = (uint64_t)a.gsl[gid] - a.w + rmq_min(a.rmq, t1, t2 - 1);
+                    uint32_t mn = cur.y;
+                    if (t2 - t1 > 1) { const uint32_t rest = rmq_min(a.rmq, t1, t2 - 2); mn = rest < mn ? rest : mn; }
+                    const uint64_t x = (uint64_t)g_head[q].x - a.w + mn;
                     v = x < (uint64_t)LCP_CAP ? (uint32_t)x : LCP_CAP;
                 }
             }
-            a.lcp[j - a.out_base] = j == 0 ? 0u : v;
+            const uint64_t at = j - a.out_base;
+            a.sa.set(at, pos);
+            a.bwt[at] = (uint8_t)(hb >> 8);
+            a.lcp[at] = j == 0 ? 0u : v;
         }
     }
 }
@@ -829,10 +887,10 @@ __global__ void k_tile_first(const P* __restrict__ segb, uint32_t n_groups, uint
 void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s) {
     if (wide)
         hipLaunchKernelGGL(k_tile_first<uint64_t>, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s,
-                           static_cast<const uint64_t*>(segb), n_groups, EMIT_TILE, tiles, out);
+                           static_cast<const uint64_t*>(segb), n_groups, emit_tile(), tiles, out);
     else
         hipLaunchKernelGGL(k_tile_first<uint32_t>, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s,
-                           static_cast<const uint32_t*>(segb), n_groups, EMIT_TILE, tiles, out);
+                           static_cast<const uint32_t*>(segb), n_groups, emit_tile(), tiles, out);
     MMT_HIP(hipGetLastError());
 }
 
@@ -922,18 +980,26 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgsT<P, SA> a, const uint32
     }
 }
 
-template <typename P, typename SA>
+uint32_t emit_tile() {
+    static const uint32_t t = [] {
+        const char* e = getenv("MMT_EMIT_TILE");
+        const int v = e ? atoi(e) : 896;
+        return (uint32_t)(v == 1024 || v == 768 ? v : 896);
+    }();
+    return t;
+}
+template <typename P, typename SA, int TILE>
 static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
-    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP, TILE = (int)EMIT_TILE;
+    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP;
     EmitArgsT<P, SA> t;
     t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
     t.ce_eoff = static_cast<const P*>(a.ce_eoff); t.ce_cnt = a.ce_cnt; t.ce_first = a.ce_first; t.ce_offm1 = a.ce_offm1;
-    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.pos_bits = a.pos_bits; t.n = (P)a.n;
+    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.occ_sl = a.occ_sl; t.pos_bits = a.pos_bits; t.n = (P)a.n;
     t.sa = SA(a.sa); t.bwt = a.bwt;
     t.fb_group = a.fb_group; t.fb_off = static_cast<const P*>(a.fb_off); t.n_fb = a.n_fb; t.fb_base = (P)a.fb_base;
     t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
     t.bwt_code = a.bwt_code; t.fb_bits = a.fb_bits; t.err = a.err; t.tile_lo = tile_lo;
-    t.lcp = a.lcp; t.gsl = a.gsl; t.ghl = a.ghl; t.rmq = a.rmq; t.w = a.w;
+    t.lcp = a.lcp; t.ghead = static_cast<const uint2*>(a.ghead); t.rmq = a.rmq; t.w = a.w;
     t.out_base = a.out_base; t.win_lo = a.win_lo; t.win_hi = a.win_hi;
     hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3((unsigned)(tile_hi - tile_lo)), dim3(BLOCK), 0, s, t,
                        tile_first_tab);
@@ -941,8 +1007,16 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64
 }
 void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
     if (tile_hi <= tile_lo) return;
-    if (a.wide) emit_typed<uint64_t, Sa40>(a, tile_first_tab, tile_lo, tile_hi, s);
-    else emit_typed<uint32_t, Sa32>(a, tile_first_tab, tile_lo, tile_hi, s);
+    const uint32_t tile = emit_tile();
+    if (a.wide) {
+        if (tile == 1024) emit_typed<uint64_t, Sa40, 1024>(a, tile_first_tab, tile_lo, tile_hi, s);
+        else if (tile == 768) emit_typed<uint64_t, Sa40, 768>(a, tile_first_tab, tile_lo, tile_hi, s);
+        else emit_typed<uint64_t, Sa40, 896>(a, tile_first_tab, tile_lo, tile_hi, s);
+    } else {
+        if (tile == 1024) emit_typed<uint32_t, Sa32, 1024>(a, tile_first_tab, tile_lo, tile_hi, s);
+        else if (tile == 768) emit_typed<uint32_t, Sa32, 768>(a, tile_first_tab, tile_lo, tile_hi, s);
+        else emit_typed<uint32_t, Sa32, 896>(a, tile_first_tab, tile_lo, tile_hi, s);
+    }
 }
 
 // osize[g] = size of group g if it exceeds the emitter's LDS tile, else 0
@@ -997,7 +1071,7 @@ void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t*
 }
 
 // oversized groups after their segmented sort: sa / bwt / lcp from the sorted (key, position) pairs
-struct FinishLcp { uint32_t* lcp; const uint32_t* gsl; const uint32_t* ghl; RmqView rmq; uint32_t w; uint64_t out_base, win_lo, win_hi; };
+struct FinishLcp { uint32_t* lcp; const uint2* ghead; RmqView rmq; uint32_t w; uint64_t out_base, win_lo, win_hi; };
 template <typename P, typename SA>
 __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P* __restrict__ fb_off, uint32_t f0,
                                   uint32_t f1, P fb_base, const P* __restrict__ segb,
@@ -1010,7 +1084,7 @@ __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P
     const uint32_t g = fb_group[f];
     const P out0 = segb[g];
     const uint32_t mask = (1u << fb_bits) - 1u;
-    const uint32_t sl = F.gsl[g], hl = F.ghl[g];
+    const uint32_t sl = F.ghead[g].x, hl = F.ghead[g].y;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const P p = sorted_vals[i], out = out0 + (i - lo);
         if (out == 0 || p >= n) {                                   // the sentinel never sits in an oversized group
@@ -1043,7 +1117,7 @@ void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, 
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
                      const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, bool wide, hipStream_t s) {
     if (f1 <= f0) return;
-    FinishLcp F{ea.lcp, ea.gsl, ea.ghl, ea.rmq, ea.w, ea.out_base, ea.win_lo, ea.win_hi};
+    FinishLcp F{ea.lcp, static_cast<const uint2*>(ea.ghead), ea.rmq, ea.w, ea.out_base, ea.win_lo, ea.win_hi};
     if (wide)
         hipLaunchKernelGGL((k_fallback_finish<uint64_t, Sa40>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
                            static_cast<const uint64_t*>(fb_off), f0, f1, (uint64_t)fb_base, static_cast<const uint64_t*>(segb),

@@ -47,25 +47,30 @@ void phrase_table(const uint32_t* occ_start /* n_distinct + 1 */, const uint32_t
 // in V; the caller guarantees that t and the position fit 64 bits together)
 void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_t D, uint32_t* keys, uint32_t* vals,
                   hipStream_t s);
+// occ_sl[k] = sl[t - 1] of the same occurrence (sl: parse_lcp.hpp), 0 for t = 0
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
-                uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, bool wide, hipStream_t s);
+                uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, const uint32_t* sl, uint32_t* occ_sl, bool wide,
+                hipStream_t s);
 // gscan: inclusive sum of gflag.  ce_gs[c] = g + 1 at the first entry of group g, 0 elsewhere; ce_dpos / ce_slen: position
 // in the dictionary and length of the entry's phrase suffix (scratch of group_heads)
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
                    const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint32_t* sa_d,
                    const void* tab, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
                    uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_dpos, uint32_t* ce_slen, hipStream_t s);
-// gsl[g] = length of the phrase suffix of group g, ghl[g] = its LCP with the phrase suffix of group g - 1 (0 for g = 0);
-// sege[g] = first compact entry of group g
+// ghead[g] = (length of the phrase suffix of group g, its LCP with the phrase suffix of group g - 1 -- 0 for g = 0), two
+// uint32_t per group; sege[g] = first compact entry of group g
 void group_heads(const uint32_t* sege, const uint32_t* ce_dpos, const uint32_t* ce_slen, const uint8_t* dict,
-                 uint32_t n_groups, uint32_t* gsl, uint32_t* ghl, hipStream_t s);
+                 uint32_t n_groups, void* ghead, hipStream_t s);
 void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s);
 void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
                   uint32_t* which, uint32_t* slen, hipStream_t s);
 void pack_keys_u32(const uint32_t* parse, uint32_t m, int bits, int chars, uint64_t* keys, uint32_t* vals,
                    hipStream_t s);
 static const uint32_t EMIT_CAP = 1024;   // elements of one LDS tile of the emitter
-static const uint32_t EMIT_TILE = 1024;  // output positions per workgroup of the emitter
+// output positions per workgroup of the emitter: below EMIT_CAP, so that the groups that begin in a tile -- its own
+// positions plus what the last group hangs over -- usually fit ONE pass through LDS (with 1024 there almost always was a
+// second pass for a last group of a few dozen elements); 1024 / 896 / 768 are compiled, MMT_EMIT_TILE chooses (tests)
+uint32_t emit_tile();
 struct EmitArgs {
     bool wide;                  // entry type of segb, ce_eoff, fb_off, fb_vals and of the suffix-array column
     const void* segb;           // n_groups + 1 group begin offsets in the output (last = n + 1)
@@ -74,6 +79,7 @@ struct EmitArgs {
     const void* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
     const uint64_t* occ;        // per phrase occurrence (t << pos_bits) | V position, grouped by phrase
+    const uint32_t* occ_sl = nullptr;   // and sl[t - 1] of the same occurrence
     uint32_t pos_bits;
     uint64_t n;                 // text length; output stream has n + 1 entries, entry 0 = end sentinel
     SaCol sa; uint8_t* bwt;                       // n entries each (the sentinel entry is not stored)
@@ -91,7 +97,7 @@ struct EmitArgs {
     // index j - out_base of sa / bwt / lcp when win_lo <= j < win_hi and nowhere otherwise (a window is produced from
     // the output tiles that cover it; groups that begin in those tiles may reach beyond it on either side).
     uint32_t* lcp = nullptr;
-    const uint32_t* gsl = nullptr; const uint32_t* ghl = nullptr;   // per group: |alpha|, LCP with the group before
+    const void* ghead = nullptr;              // per group: (|alpha|, LCP with the group before), group_heads
     RmqView rmq;                              // LCP of adjacent parse suffixes (parse_lcp.hpp): keys t1 < t2 -> min sl[t1 .. t2 - 1]
     uint32_t w = 0;
     uint64_t out_base = 0, win_lo = 0, win_hi = ~0ull;

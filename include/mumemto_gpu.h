@@ -151,19 +151,19 @@ MMT_API int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, c
  * of [1], [3] microseconds spent in the driver mapping memory.                                                         */
 MMT_API int mmt_device_memory(const mmt_engine* e, uint64_t out[4]);
 /* Multi-GPU runs of partial multi-MUMs / multi-MEMs, which the anchor merge cannot serve (the reference refuses to
- * merge them: include/pfp_mum.hpp:178-183): every rank builds the same stream and scans only its share of the
- * suffix-array positions; the outputs of ranks 0 .. count-1, concatenated, are byte for byte the output of one GPU
- * (mumemto_amd/dist.py::run_sharded gathers them).  count = 1 switches it off.                                      */
+ * merge them: include/pfp_mum.hpp:178-183): every rank builds the tables of the parse and then produces, scans and drops
+ * ONLY ITS SHARE of the stream -- a range of suffix-array positions cut at multiples of 4096 (the parse proper), or whole
+ * bins of leading characters (the bucket-wise producer: SURVEY.md 8(e), every reportable interval lies inside one bin).
+ * No column is exchanged; the outputs of ranks 0 .. count-1, concatenated, are byte for byte the output of one GPU
+ * (mmt_dist_gather_text, mumemto_amd/dist.py::run_sharded).  count = 1 switches it off.  mmt_sort_pieces: first entry and
+ * number of entries of every rank's share (after a run).                                                              */
 MMT_API int mmt_engine_set_scan_shard(mmt_engine* e, uint32_t index, uint32_t count);
-/* The same for the SUFFIX SORT (suffixes bucketed by their leading characters sort independently, the
- * buckets concatenated in order are the suffix array): rank `index` sorts its share of the buckets and holds its piece of
- * the suffix-array and BWT columns; after_sort(ctx) is called inside mmt_engine_run when that piece is complete and must
- * bring in the other ranks' pieces (mmt_dist_exchange_columns, or any transport: mmt_sort_pieces gives first entry and
- * number of entries per rank, mmt_columns_device the columns: 32 low bits, 8 high bits or NULL, BWT bytes).  LCP, scan and
- * rows then run on every rank -- combine with mmt_engine_set_scan_shard.  count = 1 switches it off.                 */
-MMT_API int mmt_engine_set_sort_shard(mmt_engine* e, uint32_t index, uint32_t count, void (*after_sort)(void*), void* ctx);
 MMT_API size_t mmt_sort_pieces(const mmt_engine* e, uint64_t* first, uint64_t* count, size_t capacity);
-MMT_API int mmt_columns_device(const mmt_engine* e, uint32_t** sa_lo, uint8_t** sa_hi, uint8_t** bwt);
+/* The columns of the stream exist one window at a time (the reference does not store them either:
+ * include/pfp_lcp_mum.hpp:197).  on = 1: every window is also copied into whole columns, so that mmt_copy_sa / _lcp /
+ * _bwt work after the run (tests, stage dumps); 0: never; -1 (default): for texts below 2^26 characters.               */
+MMT_API int mmt_engine_keep_columns(mmt_engine* e, int on);
+MMT_API int mmt_columns_kept(const mmt_engine* e);
 /* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
 MMT_API void mmt_pool_trim(void);
 
@@ -242,9 +242,6 @@ MMT_API int  mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_me
 /* Modes without a partition merge (mmt_engine_set_scan_shard): the ranks' output bytes, concatenated in rank order, on
  * rank 0 (*len = 0 elsewhere); valid until the next call on this communicator.                                        */
 MMT_API int  mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len);
-/* Sharded suffix sort (mmt_engine_set_sort_shard): the pieces of the suffix-array / BWT columns, one ncclBroadcast per
- * rank and column, in place.  To be called from the after_sort callback of every rank.                              */
-MMT_API int  mmt_dist_exchange_columns(mmt_comm* c);
 
 #ifdef __cplusplus
 }

@@ -73,8 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
-    "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_engine_set_sort_shard", "mmt_sort_pieces", "mmt_columns_device",
-    "mmt_dist_exchange_columns",
+    "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
 ]
 
 
@@ -177,11 +176,10 @@ def load_library():
     L.mmt_rows_mum_device.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p)] * 3
     L.mmt_merged_sort_like_direct.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_merged_write_text.argtypes = [C.c_void_p, C.c_char_p]
-    L.mmt_engine_set_sort_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.mmt_engine_keep_columns.argtypes = [C.c_void_p, C.c_int]
+    L.mmt_columns_kept.argtypes = [C.c_void_p]
     L.mmt_sort_pieces.restype = C.c_size_t
     L.mmt_sort_pieces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
-    L.mmt_columns_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
-    L.mmt_dist_exchange_columns.argtypes = [C.c_void_p]
     L.mmt_merged_text.restype = C.c_void_p
     L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.mmt_merged_free.argtypes = [C.c_void_p]
@@ -290,7 +288,6 @@ class Engine:
         self.h = h
         self.device = device
         self._keep = None
-        self._after_sort = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -467,32 +464,24 @@ class Engine:
         return self._copy(self.L.mmt_copy_sa, np.uint32)
 
     def set_scan_shard(self, index, count):
-        """This engine scans share `index` of `count` of the suffix-array positions (multi-GPU runs of the modes
+        """This engine produces, scans and drops share `index` of `count` of the stream (multi-GPU runs of the modes
         without a partition merge); the ranks' outputs concatenate to the single-GPU output."""
         _check(self.L.mmt_engine_set_scan_shard(self.h, C.c_uint32(index), C.c_uint32(count)))
 
-    AFTER_SORT = C.CFUNCTYPE(None, C.c_void_p)
+    def keep_columns(self, on=True):
+        """The columns of the stream exist one window at a time; on=True also copies every window into whole columns, so
+        that sa() / lcp() / bwt() work after the run (default: only for texts below 2^26 characters)."""
+        _check(self.L.mmt_engine_keep_columns(self.h, C.c_int(1 if on is True else (0 if on is False else int(on)))))
 
-    def set_sort_shard(self, index, count, after_sort=None):
-        """This engine sorts share `index` of `count` of the suffixes (bucketed by their leading characters) and calls
-        after_sort() inside run(), when its piece of the suffix-array / BWT columns is complete: the callback brings in the
-        other ranks' pieces (sort_pieces(), columns_device(); mumemto_amd.dist.run_sort_sharded).  count = 1: off."""
-        self._after_sort = self.AFTER_SORT(lambda ctx: after_sort()) if after_sort else None
-        cb = C.cast(self._after_sort, C.c_void_p) if self._after_sort else None
-        _check(self.L.mmt_engine_set_sort_shard(self.h, C.c_uint32(index), C.c_uint32(count), cb, None))
+    def columns_kept(self):
+        return bool(self.L.mmt_columns_kept(self.h))
 
     def sort_pieces(self):
-        """[(first suffix-array entry, number of entries)] per rank of the last sharded sort."""
+        """[(first suffix-array entry, number of entries)] per rank of the last (sharded) run."""
         k = self.L.mmt_sort_pieces(self.h, None, None, 0)
         first, count = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.uint64)
         self.L.mmt_sort_pieces(self.h, _p(first), _p(count), k)
         return [(int(first[i]), int(count[i])) for i in range(k)]
-
-    def columns_device(self):
-        """Device addresses of the suffix-array (low 32 bits; high 8 bits or 0) and BWT columns."""
-        lo, hi, bw = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        _check(self.L.mmt_columns_device(self.h, C.byref(lo), C.byref(hi), C.byref(bw)))
-        return lo.value or 0, hi.value or 0, bw.value or 0
 
     def is_wide(self):
         return bool(self.L.mmt_is_wide(self.h))
@@ -647,11 +636,6 @@ class Comm:
             return dict(text=_bytes_at(ptr, k.value), n_rows=n, n_docs=self.L.mmt_merged_docs(m))
         finally:
             self.L.mmt_merged_free(m)
-
-    def exchange_columns(self):
-        """Sharded suffix sort: every rank's piece of the suffix-array / BWT columns to every rank (call it from the
-        after_sort callback)."""
-        _check(self.L.mmt_dist_exchange_columns(self.h))
 
     def gather_text(self):
         """Sharded modes (Engine.set_scan_shard): the whole output on rank 0, b"" elsewhere."""

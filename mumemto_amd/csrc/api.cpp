@@ -472,25 +472,17 @@ int mmt_engine_set_scan_shard(mmt_engine* e, uint32_t index, uint32_t count) {
     e->e->set_scan_shard(index, count);
     MMT_CATCH
 }
-int mmt_engine_set_sort_shard(mmt_engine* e, uint32_t index, uint32_t count, void (*after_sort)(void*), void* ctx) {
+int mmt_engine_keep_columns(mmt_engine* e, int on) {
     if (!e) return fail(1, "null");
-    MMT_TRY
-    e->e->set_sort_shard(index, count, after_sort, ctx);
-    MMT_CATCH
+    e->e->set_keep_columns(on);
+    return 0;
 }
+int mmt_columns_kept(const mmt_engine* e) { return e && e->e->columns_kept() ? 1 : 0; }
 size_t mmt_sort_pieces(const mmt_engine* e, uint64_t* first, uint64_t* count, size_t capacity) {
     if (!e) return 0;
     const auto& p = e->e->sort_pieces();
     for (size_t i = 0; i < p.size() && i < capacity; i++) { if (first) first[i] = p[i].first; if (count) count[i] = p[i].second; }
     return p.size();
-}
-int mmt_columns_device(const mmt_engine* e, uint32_t** sa_lo, uint8_t** sa_hi, uint8_t** bwt) {
-    if (!e) return fail(1, "null");
-    const mmt::SaCol c = e->e->sa_col();
-    if (sa_lo) *sa_lo = c.lo;
-    if (sa_hi) *sa_hi = c.hi;
-    if (bwt) *bwt = e->e->bwt_device();
-    return 0;
 }
 int mmt_device_memory(const mmt_engine* e, uint64_t out[4]) {
     if (!e) return fail(1, "null");
@@ -643,12 +635,6 @@ int mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** ou
         m->engine = e->e.get();
         *out = m.release();
     }
-    MMT_CATCH
-}
-int mmt_dist_exchange_columns(mmt_comm* c) {
-    if (!c) return fail(1, "null");
-    MMT_TRY
-    mmt::dist_exchange_columns(*c->c);
     MMT_CATCH
 }
 int mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len) {

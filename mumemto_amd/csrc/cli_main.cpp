@@ -238,13 +238,10 @@ static int run_rank(BuildOptions& o) {
     Comm* comm = comm_create(eng, rank, world, id);
     if (strict) { p.num_distinct = 0; p.max_total_freq = 0; }
     else {
+        // every rank builds the tables of the parse and produces, scans and drops its own share of the stream (ranges of
+        // the emitter's output, or -- MUMEMTO_PRODUCER=guided, automatic when the dictionary would not fit -- whole bins
+        // of leading characters); only the rows travel
         eng.set_scan_shard((uint32_t)rank, (uint32_t)world);
-        // four ranks or more: the suffix sort is shared out too (buckets of suffixes per rank, the pieces of the columns
-        // broadcast: dist_exchange_columns) -- below that one GPU's parse-based sort of a redundant collection is as fast
-        // as a share of the bucket sort.  MUMEMTO_SORT_SHARD=0 / 1 overrides.
-        const char* env = std::getenv("MUMEMTO_SORT_SHARD");
-        if (env ? std::atoi(env) != 0 : world >= 4)
-            eng.set_sort_shard((uint32_t)rank, (uint32_t)world, [](void* c) { dist_exchange_columns(*static_cast<Comm*>(c)); }, comm);
     }
     eng.run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), p, 0);
     size_t rows = 0;

@@ -192,27 +192,6 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
     return m;
 }
 
-// Sharded suffix sort (Engine::set_sort_shard): every rank has written its piece of the suffix-array and BWT columns;
-// one broadcast per rank and column, in place (a rank sends its piece from where every other rank receives it).
-void dist_exchange_columns(Comm& c) {
-    Engine& e = *c.engine;
-    MMT_HIP(hipSetDevice(e.device()));
-    hipStream_t st = e.stream();
-    const auto& pieces = e.sort_pieces();
-    if ((int)pieces.size() != c.world) throw std::runtime_error("the suffix sort was not sharded over this communicator");
-    const SaCol col = e.sa_col();
-    MMT_NCCL(rccl().GroupStart());
-    for (int r = 0; r < c.world; r++) {
-        const uint64_t at = pieces[(size_t)r].first, cnt = pieces[(size_t)r].second;
-        if (!cnt) continue;
-        MMT_NCCL(rccl().Broadcast(col.lo + at, col.lo + at, cnt, ncclUint32, r, c.comm, st));
-        if (col.hi) MMT_NCCL(rccl().Broadcast(col.hi + at, col.hi + at, cnt, ncclUint8, r, c.comm, st));
-        MMT_NCCL(rccl().Broadcast(e.bwt_device() + at, e.bwt_device() + at, cnt, ncclUint8, r, c.comm, st));
-    }
-    MMT_NCCL(rccl().GroupEnd());
-    MMT_HIP(hipStreamSynchronize(st));
-}
-
 // Modes without a partition merge: this rank's PREFIX.mums / .mems bytes (mmt_engine_set_scan_shard) to rank 0, in rank
 // order.  Returns the whole output on rank 0, an empty string elsewhere.
 std::string dist_gather_text(Comm& c) {

@@ -14,6 +14,6 @@ Comm* comm_create(Engine& e, int rank, int world, const uint8_t id[128]);       
 void comm_destroy(Comm* c);
 MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root);                  // collective; rows on rank 0
 std::string dist_gather_text(Comm& c);                                            // collective; bytes on rank 0
-void dist_exchange_columns(Comm& c);          // collective, inside Engine::run (set_sort_shard): the pieces of SA / BWT
+// (no exchange of columns: a rank of a sharded run produces, scans and drops its own share of the stream)
 
 }  // namespace mmt

@@ -275,7 +275,9 @@ void Engine::release_columns() {
     d_rank64_.release();
     d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
     d_cand_.release(); d_flags_.release();
-    lcp_whole_ = false;
+    for (int k = 0; k < 2; k++) { w_sa_[k].release(); w_hi_[k].release(); w_bwt_[k].release(); w_lcp_[k].release(); }
+    d_pool_lo_.release(); d_pool_hi_.release(); d_rows_pool_.release(); d_cap_cnt_.release(); d_cap_off_.release();
+    lcp_whole_ = false; lcp_col_ready_ = false; columns_kept_ = false;
 }
 
 // Called after the suffix sort: the LCP stage is about to allocate the PLCP and LCP columns (8 bytes per text
@@ -298,11 +300,20 @@ static void grow_keep(DevBuf<T>& buf, size_t need, size_t used, hipStream_t s) {
     buf.swap(bigger);
 }
 
-// The stream is scanned in ranges of suffix-array positions: the LCP column exists for one range at a time
-// (gathered from PLCP through the suffix array), with a left extension long enough for every walk; candidates
-// carry range-relative positions, accepted rows absolute ones.  A text below 2^32 characters is one range.
-void Engine::scan(const mmt_params& p) {
-    const uint64_t n = n_;
+// ---- the scan, window by window ---------------------------------------------------------------------------------
+// The stream is scanned in windows of suffix-array positions.  A window carries a left extension long enough for every
+// walk; candidates carry window-relative positions, accepted rows absolute ones.  The producers that emit the columns
+// themselves (pfp.cpp, guided.cpp) hand over one window at a time and drop it (pfp_lcp_mum.hpp:197: the reference
+// never stores the stream); columns that exist as a whole (the direct producer, a handed-over stream) are cut into
+// windows here.
+EventPair& Engine::next_range_event(ScanState& S, int kind) {      // kind: 0 LCP gather, 1 scan kernel, 2 verification, 3 production
+    if (S.ev_at == range_ev_.size()) range_ev_.emplace_back(new EventPair());
+    range_ev_kind_.push_back(kind);
+    range_ev_[S.ev_at]->reset();
+    return *range_ev_[S.ev_at++];
+}
+
+void Engine::scan_begin(const mmt_params& p, ScanState& S) {
     const size_t N = doc_len_.size();
     hipStream_t st = stream_;
     d_count_.ensure(8);
@@ -317,15 +328,16 @@ void Engine::scan(const mmt_params& p) {
     if (cap > 0xfffffff0ull) cap = 0;
     if (N > 32768 && !(p.max_doc_freq == 1 && N <= 64))
         throw std::runtime_error("more than 32768 documents are not supported by the candidate verifier");
-
-    k::ScanArgs a;
-    a.min_len = p.min_match_len;
-    a.num_distinct = (uint32_t)std::min<uint64_t>(num_distinct_eff_, 0xffffffffu);
-    a.cap = (uint32_t)cap;
-    a.emit_all = p.merge_metadata ? 1 : 0;
-    a.d_count = d_count_.get();
-
-    // thresholds (merge metadata) and the row list are shared by all ranges
+    S = ScanState();
+    S.cap = cap;
+    S.a.min_len = p.min_match_len;
+    S.a.num_distinct = (uint32_t)std::min<uint64_t>(num_distinct_eff_, 0xffffffffu);
+    S.a.cap = (uint32_t)cap;
+    S.a.emit_all = p.merge_metadata ? 1 : 0;
+    S.a.d_count = d_count_.get();
+    S.merge = p.merge_metadata != 0;
+    S.max_doc_freq = p.max_doc_freq > 0 ? (uint32_t)std::min<int64_t>(p.max_doc_freq, 0x7fffffff) : 0u;
+    // thresholds (merge metadata) and the row list are shared by all windows
     thresh_len_ = 0;
     if (p.merge_metadata && N > 0) {
         thresh_len_ = 2 * (doc_len_[0] + 1);
@@ -333,10 +345,122 @@ void Engine::scan(const mmt_params& p) {
         MMT_HIP(hipMemsetAsync(d_thresh_.get(), 0, thresh_len_ * 2, st));
     }
     MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, st));
-    size_t rows_used = 0;
     n_cand_ = 0;
+    pool_used_ = 0;
+    // left extension of every window but the first: at least the largest interval (+1), the window of the wide-document
+    // path, one LDS halo; uncapped modes start with 64 K entries and repeat a window whose walk ran off it
+    const uint64_t ALIGN_R = 4096;
+    uint64_t ext0 = cap ? cap + 1 : 65536;
+    ext0 = std::max<uint64_t>(ext0, (uint64_t)S.a.num_distinct + 2);
+    ext0 = std::max<uint64_t>(ext0, 1040);
+    S.ext0 = (ext0 + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
+    scan_ranges_ = 0;
+    range_ev_kind_.clear();
+}
 
-    // range size: everything at once unless the text is wide (MMT_SCAN_RANGE: tests)
+// this rank's share of the closing positions (set_scan_shard): [n k / count, n (k + 1) / count), cut at multiples of 4096
+void Engine::shard_range(uint64_t& lo, uint64_t& hi) const {
+    const uint64_t n = n_, ALIGN_R = 4096;
+    lo = 0; hi = n;
+    if (shard_count_ <= 1) return;
+    auto cut = [&](uint64_t k) { return k >= shard_count_ ? n : (n / shard_count_ * k) / ALIGN_R * ALIGN_R; };
+    lo = cut(shard_index_); hi = cut(shard_index_ + 1);
+}
+
+// One window: scan kernel, verification, thresholds; rows of a transient window take their suffix-array entries along.
+// Returns false when a walk ran off the left edge of a window that does not start the stream (the caller repeats it with
+// a longer extension); nothing of that attempt is kept.
+bool Engine::scan_window(ScanState& S, const ColWindow& w, const mmt_params& p) {
+    hipStream_t st = stream_;
+    const size_t N = doc_len_.size();
+    k::ScanArgs& a = S.a;
+    a.lcp = w.lcp; a.bwt = w.bwt; a.n = w.len; a.first = w.first; a.more_left = w.more_left ? 1 : 0;
+    size_t capacity = std::max<size_t>(1u << 20, p.merge_metadata ? w.len / 6 : w.len / 32);
+    capacity = std::max(capacity, d_cand_.size());
+    uint32_t found = 0, overflow = 0;
+    EventPair& es = next_range_event(S, 1);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        d_cand_.ensure(capacity);
+        a.out = d_cand_.get(); a.capacity = (uint32_t)std::min<size_t>(capacity, 0xffffffffu);
+        MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 4, st));
+        MMT_HIP(hipMemsetAsync(d_count_.get() + 4, 0, 4, st));
+        es.start(st);
+        if (k::scan_needs_wide(a)) {               // window tables in HBM, per window
+            d_wpre_.ensure(w.len); d_wsuf_.ensure(w.len); d_wide_.ensure(w.len);
+            k::scan_wide_prepare(a.lcp, a.bwt, a.n, a.num_distinct, d_wpre_.get(), d_wsuf_.get(), d_wide_.get(), st);
+            prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get(), w.len, st);
+            a.wide_pre = d_wpre_.get(); a.wide_suf = d_wsuf_.get(); a.wide_chg = d_wide_.get();
+        }
+        k::scan_intervals(a, st);
+        es.stop(st);
+        uint32_t back[5] = {0, 0, 0, 0, 0};
+        MMT_HIP(hipMemcpyAsync(back, d_count_.get(), 20, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        found = back[0]; overflow = back[4];
+        if (found <= capacity) break;
+        if (attempt == 2) throw std::runtime_error("candidate list overflow in the scan");
+        capacity = (size_t)found + 1024;       // rare: re-run with the exact size
+    }
+    if (overflow && w.more_left) return false;
+    scan_ranges_++;
+    n_cand_ += found;
+    // verification + thresholds of this window's candidates
+    EventPair& ev = next_range_event(S, 2);
+    ev.start(st);
+    grow_keep(d_rows_, std::max<size_t>(S.rows_used + found, 1), S.rows_used, st);
+    k::VerifyArgs v;
+    v.cand = d_cand_.get(); v.n_cand = found; v.sa = w.sa; v.base = w.base; v.sa_off = w.sa_off; v.lcp = w.lcp;
+    v.d_doc_start = d_doc_start_.get(); v.n_docs = (uint32_t)N;
+    v.num_distinct = a.num_distinct;
+    v.max_doc_freq = S.max_doc_freq;
+    v.merge = S.merge ? 1 : 0; v.thresh = d_thresh_.get();
+    v.rows = d_rows_.get(); v.d_row_count = d_count_.get() + 1;
+    k::verify_candidates(v, st);
+    uint32_t r = 0;
+    MMT_HIP(hipMemcpyAsync(&r, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    const size_t fresh = (size_t)r - S.rows_used;
+    if (w.transient && fresh) {
+        // the accepted intervals' suffix-array entries leave the window with their rows
+        d_cap_cnt_.ensure(fresh + 1); d_cap_off_.ensure(fresh + 1);
+        k::row_counts(d_rows_.get() + S.rows_used, (uint32_t)fresh, d_cap_cnt_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_cap_cnt_.get(), d_cap_off_.get(), fresh, st);
+        uint64_t last[2] = {0, 0};
+        MMT_HIP(hipMemcpyAsync(&last[0], d_cap_off_.get() + (fresh - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&last[1], d_cap_cnt_.get() + (fresh - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        const uint64_t total = last[0] + last[1];
+        grow_keep(d_pool_lo_, (size_t)(pool_used_ + total + 16), (size_t)pool_used_, st);
+        if (wide_) grow_keep(d_pool_hi_, (size_t)(pool_used_ + total + 16), (size_t)pool_used_, st);
+        grow_keep(d_rows_pool_, std::max<size_t>(r, 1), S.rows_used, st);
+        SaCol pool; pool.lo = d_pool_lo_.get(); pool.hi = wide_ ? d_pool_hi_.get() : nullptr;
+        SaCol win = w.sa; win.lo += w.sa_off; if (win.hi) win.hi += w.sa_off;
+        k::capture_rows(d_rows_.get() + S.rows_used, (uint32_t)fresh, d_cap_off_.get(), pool_used_, win, w.base, pool,
+                        d_rows_pool_.get() + S.rows_used, st);
+        pool_used_ += total;
+    }
+    ev.stop(st);
+    S.rows_used = r;
+    return true;
+}
+
+void Engine::scan_end(ScanState& S) {
+    if (scan_ranges_ == 0) scan_ranges_ = 1;
+    range_ev_.resize(S.ev_at);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = 0; i < S.ev_at; i++) acc[range_ev_kind_[i]] += range_ev_[i]->ms();
+    for (int i = 0; i < 4; i++) scan_ms_[i] = acc[i];
+}
+
+// Columns that exist as a whole (the direct producer; a stream that was handed over): cut into windows here.  The LCP
+// column is gathered from PLCP through the suffix array window by window (whole at once for a text below 2^32).
+void Engine::scan(const mmt_params& p) {
+    const uint64_t n = n_;
+    hipStream_t st = stream_;
+    ScanState S;
+    scan_begin(p, S);
+    streamed_ = false;
+    // window size: everything at once unless the text is wide (MMT_SCAN_RANGE: tests)
     const uint64_t ALIGN_R = 4096;
     uint64_t range = n;
     if (!lcp_whole_ || preset_ != 2) {
@@ -344,42 +468,23 @@ void Engine::scan(const mmt_params& p) {
         if (const char* c = std::getenv("MMT_SCAN_RANGE")) range = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
         range = (range + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
     }
-    // this rank's share of the closing positions (set_scan_shard)
     uint64_t shard_lo = 0, shard_hi = n;
     if (shard_count_ > 1) {
         if (preset_ == 2) throw std::runtime_error("a handed-over stream cannot be scanned in shards");
-        auto cut = [&](uint64_t k) { return k >= shard_count_ ? n : (n / shard_count_ * k) / ALIGN_R * ALIGN_R; };
-        shard_lo = cut(shard_index_); shard_hi = cut(shard_index_ + 1);
+        shard_range(shard_lo, shard_hi);
         range = std::min<uint64_t>(range, std::max<uint64_t>(ALIGN_R, (shard_hi - shard_lo + ALIGN_R - 1) / ALIGN_R * ALIGN_R));
     }
     const bool single = range >= n && shard_count_ == 1;
     if (single && n >= 0xffffe000ull) throw std::runtime_error("a scan range holds fewer than 2^32 - 8192 entries");
-    // left extension of every range but the first: at least the largest interval (+1), the window of the wide-document
-    // path, one LDS halo; uncapped modes start with 64 K entries and repeat a range whose walk ran off it
-    uint64_t ext0 = cap ? cap + 1 : 65536;
-    ext0 = std::max<uint64_t>(ext0, (uint64_t)a.num_distinct + 2);
-    ext0 = std::max<uint64_t>(ext0, 1040);
-    ext0 = (ext0 + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
-    scan_ranges_ = 0;
-    size_t ev_at = 0;
-    range_ev_kind_.clear();
-    auto next_ev = [&](int kind) -> EventPair& {          // kind: 0 LCP gather, 1 scan kernel, 2 verification
-        if (ev_at == range_ev_.size()) range_ev_.emplace_back(new EventPair());
-        range_ev_kind_.push_back(kind);
-        range_ev_[ev_at]->reset();
-        return *range_ev_[ev_at++];
-    };
     for (uint64_t c0 = shard_lo; c0 < shard_hi; c0 += range) {
         const uint64_t c1 = std::min(shard_hi, c0 + range);
-        uint64_t ext = c0 ? ext0 : 0;
-        uint32_t found = 0;
-        uint64_t b0 = 0;
+        uint64_t ext = c0 ? S.ext0 : 0;
         for (;;) {
             if (ext > c0) ext = c0;
-            b0 = c0 - ext;
+            const uint64_t b0 = c0 - ext;
             const uint64_t len = c1 - b0;
             if (len >= 0xffffe000ull) throw std::runtime_error("scan range with its left extension exceeds 2^32 entries");
-            EventPair& eg = next_ev(0);
+            EventPair& eg = next_range_event(S, 0);
             eg.start(st);
             const uint32_t* lcp_ptr = nullptr;
             if (lcp_col_ready_) lcp_ptr = d_plcp_a_.get() + b0;          // the column exists in suffix-array order
@@ -392,65 +497,39 @@ void Engine::scan(const mmt_params& p) {
                 lcp_ptr = d_lcp_.get();
             }
             eg.stop(st);
-            a.lcp = lcp_ptr; a.bwt = d_bwt_.get() + b0; a.n = (uint32_t)len; a.first = (uint32_t)ext;
-            a.more_left = b0 > 0 ? 1 : 0;
-            size_t capacity = std::max<size_t>(1u << 20, p.merge_metadata ? len / 6 : len / 32);
-            capacity = std::max(capacity, d_cand_.size());
-            uint32_t overflow = 0;
-            EventPair& es = next_ev(1);
-            for (int attempt = 0; attempt < 3; attempt++) {
-                d_cand_.ensure(capacity);
-                a.out = d_cand_.get(); a.capacity = (uint32_t)std::min<size_t>(capacity, 0xffffffffu);
-                MMT_HIP(hipMemsetAsync(d_count_.get(), 0, 4, st));
-                MMT_HIP(hipMemsetAsync(d_count_.get() + 4, 0, 4, st));
-                es.start(st);
-                if (k::scan_needs_wide(a)) {               // window tables in HBM, per range
-                    d_wpre_.ensure(len); d_wsuf_.ensure(len); d_wide_.ensure(len);
-                    k::scan_wide_prepare(a.lcp, a.bwt, a.n, a.num_distinct, d_wpre_.get(), d_wsuf_.get(), d_wide_.get(), st);
-                    prims::inclusive_max_u32(d_temp_, d_wide_.get(), d_wide_.get(), len, st);
-                    a.wide_pre = d_wpre_.get(); a.wide_suf = d_wsuf_.get(); a.wide_chg = d_wide_.get();
-                }
-                k::scan_intervals(a, st);
-                es.stop(st);
-                uint32_t back[5] = {0, 0, 0, 0, 0};
-                MMT_HIP(hipMemcpyAsync(back, d_count_.get(), 20, hipMemcpyDeviceToHost, st));
-                MMT_HIP(hipStreamSynchronize(st));
-                found = back[0]; overflow = back[4];
-                if (found <= capacity) break;
-                if (attempt == 2) throw std::runtime_error("candidate list overflow in the scan");
-                capacity = (size_t)found + 1024;       // rare: re-run with the exact size
-            }
-            if (overflow && b0 > 0) { ext = std::max<uint64_t>(ext * 4, ext0); continue; }   // a walk ran off the extension
-            break;
-        }
-        scan_ranges_++;
-        n_cand_ += found;
-        // verification + thresholds of this range's candidates
-        EventPair& ev = next_ev(2);
-        ev.start(st);
-        grow_keep(d_rows_, std::max<size_t>(rows_used + found, 1), rows_used, st);
-        k::VerifyArgs v;
-        v.cand = d_cand_.get(); v.n_cand = found; v.sa = sa_col(); v.base = b0; v.lcp = a.lcp;
-        v.d_doc_start = d_doc_start_.get(); v.n_docs = (uint32_t)N;
-        v.num_distinct = a.num_distinct;
-        v.max_doc_freq = p.max_doc_freq > 0 ? (uint32_t)std::min<int64_t>(p.max_doc_freq, 0x7fffffff) : 0u;
-        v.merge = p.merge_metadata ? 1 : 0; v.thresh = d_thresh_.get();
-        v.rows = d_rows_.get(); v.d_row_count = d_count_.get() + 1;
-        k::verify_candidates(v, st);
-        ev.stop(st);
-        if (!single) {                                 // rows so far (the next range may have to grow the list)
-            uint32_t r = 0;
-            MMT_HIP(hipMemcpyAsync(&r, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, st));
-            MMT_HIP(hipStreamSynchronize(st));
-            rows_used = r;
+            ColWindow w;
+            w.sa = sa_col(); w.sa_off = b0; w.base = b0; w.bwt = d_bwt_.get() + b0; w.lcp = lcp_ptr;
+            w.len = (uint32_t)len; w.first = (uint32_t)ext; w.more_left = b0 > 0; w.transient = false;
+            if (scan_window(S, w, p)) break;
+            ext = std::max<uint64_t>(ext * 4, S.ext0);                   // a walk ran off the extension
         }
         if (single) break;
     }
-    if (scan_ranges_ == 0) scan_ranges_ = 1;
-    range_ev_.resize(ev_at);
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (size_t i = 0; i < ev_at; i++) acc[range_ev_kind_[i]] += range_ev_[i]->ms();
-    scan_ms_[0] = acc[0]; scan_ms_[1] = acc[1]; scan_ms_[2] = acc[2];
+    scan_end(S);
+}
+
+// ---- the window buffers of the producers that emit the columns themselves ----------------------------------------------
+void Engine::window_reserve(int set, uint64_t entries) {
+    w_sa_[set].ensure(entries + 64); w_bwt_[set].ensure(entries + 64); w_lcp_[set].ensure(entries + 64);
+    if (wide_) w_hi_[set].ensure(entries + 64);
+}
+ColWindow Engine::window_view(int set, uint64_t base, uint32_t len, uint32_t first) const {
+    ColWindow w;
+    w.sa.lo = w_sa_[set].get(); w.sa.hi = wide_ ? w_hi_[set].get() : nullptr;
+    w.bwt = w_bwt_[set].get(); w.lcp = w_lcp_[set].get();
+    w.base = base; w.sa_off = 0; w.len = len; w.first = first; w.more_left = base > 0; w.transient = true;
+    return w;
+}
+// keep mode (set_keep_columns): the closing positions of a window also go into whole columns
+void Engine::keep_window(const ColWindow& w) {
+    if (!columns_kept_) return;
+    const uint64_t at = w.base + w.first, cnt = (uint64_t)w.len - w.first;
+    if (!cnt) return;
+    hipStream_t st = stream_;
+    MMT_HIP(hipMemcpyAsync(d_sa_.get() + at, w.sa.lo + w.sa_off + w.first, cnt * 4, hipMemcpyDeviceToDevice, st));
+    if (wide_) MMT_HIP(hipMemcpyAsync(d_sa_hi_.get() + at, w.sa.hi + w.sa_off + w.first, cnt, hipMemcpyDeviceToDevice, st));
+    MMT_HIP(hipMemcpyAsync(d_bwt_.get() + at, w.bwt + w.first, cnt, hipMemcpyDeviceToDevice, st));
+    MMT_HIP(hipMemcpyAsync(d_plcp_a_.get() + at, w.lcp + w.first, cnt * 4, hipMemcpyDeviceToDevice, st));
 }
 
 // ---- A6: rows -> coordinates -> text ---------------------------------------------
@@ -503,6 +582,10 @@ void Engine::make_rows(const mmt_params& p) {
     MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, st));
     rk::RowArgs a;
     a.rows = d_rows_.get(); a.order = d_order_.get(); a.n_rows = n_rows; a.sa = sa_col();
+    if (streamed_) {            // the columns are gone: the rows index the pool of their own suffix-array entries
+        a.rows = d_rows_pool_.get();
+        a.sa.lo = d_pool_lo_.get(); a.sa.hi = wide_ ? d_pool_hi_.get() : nullptr;
+    }
     a.doc_start = d_doc_start_.get(); a.doc_len = d_doc_len_.get(); a.n_docs = (uint32_t)N; a.revcomp = revcomp_ ? 1 : 0;
     d_tlen_.ensure(n_rows); d_tlen64_.ensure(n_rows); d_toff_.ensure(n_rows);
     auto last_u32 = [&](const uint32_t* d) {
@@ -707,6 +790,7 @@ void Engine::run(const mmt_params& p) {
                                  "occurrence each)");
     auto finish = [&]() {
         for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
+        stage_ms_[1] += scan_ms_[3];                    // the windows of the columns are produced between the scans
         stage_ms_[2] += scan_ms_[0];                    // the LCP column is gathered range by range inside the scan
         stage_ms_[3] = scan_ms_[1];                     // k_scan (+ the window tables of the wide-document path)
         stage_ms_[4] = scan_ms_[2];
@@ -714,6 +798,7 @@ void Engine::run(const mmt_params& p) {
     };
     if (preset_ == 2) {                                 // stream handed over: scan it as it is
         producer_used_ = 0;
+        columns_kept_ = true;
         scan(p);
         make_rows(p);
         finish();
@@ -726,26 +811,17 @@ void Engine::run(const mmt_params& p) {
         MMT_HIP(hipStreamSynchronize(stream_));
         d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
     }
-    if (lean_ || wide_) {
-        // what the run before left of its LCP and scan stages goes first: the stages of this run are sized by what the
-        // heap has left (a sequence of whole-genome partitions otherwise climbs to the end of the device)
+    // what the run before left on the device goes first: the stages of this run are sized by what the heap has left
+    const bool slim = lean_ || wide_;
+    if (slim) {
         MMT_HIP(hipStreamSynchronize(stream_));
         d_plcp_a_.release(); d_lcp_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
         d_cand_.release(); d_rank_.release(); d_rank64_.release();
+        d_sa_.release(); d_sa_hi_.release(); d_bwt_.release(); d_cols_.release();
         lcp_whole_ = false;
-        // (allocated late these columns land between scratch buffers: the heap fragments and maps 228 GB for 170 GB in use)
-        auto up = [](size_t x) { return (x + 511) / 512 * 512; };
-        const size_t b_lo = up((size_t)n_ * 4), b_hi = wide_ ? up((size_t)n_ + 16) : 0, b_bwt = up((size_t)n_ + 16);
-        d_cols_.ensure(b_lo + b_hi + b_bwt);
-        d_sa_.borrow(reinterpret_cast<uint32_t*>(d_cols_.get()), n_);
-        if (wide_) d_sa_hi_.borrow(d_cols_.get() + b_lo, (size_t)n_ + 16);
-        d_bwt_.borrow(d_cols_.get() + b_lo + b_hi, (size_t)n_ + 16);
-    } else if (!d_sa_.owned() || !d_bwt_.owned() || !d_sa_hi_.owned()) {
-        d_sa_.release(); d_sa_hi_.release(); d_bwt_.release();      // views of an earlier one-shot run: own memory now
     }
-    ev_[1]->start(stream_);
+    int kind = producer_;
     {
-        int kind = producer_;
         std::vector<uint64_t> hist;
         d2h(hist, d_hist_.get(), 256, stream_);
         const bool reserved = hist[0] || hist[1] || hist[2];
@@ -754,7 +830,7 @@ void Engine::run(const mmt_params& p) {
             // bench, 3x at 0.1 % divergence), unless the text holds bytes the parse reserves (<= 0x02) or there are
             // too few documents for the dictionary to be much smaller than the text (measured, 1 % divergence:
             // 3 x 4.6 Mbp 8.6 vs 12.7 ms, 4 x 30 Mbp 80 vs 108 ms for the direct sort; even at 6 documents)
-            const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp" override
+            const char* env = std::getenv("MUMEMTO_PRODUCER");      // "direct" | "pfp" | "guided" override
             const bool forced_pfp = env && std::string(env) == "pfp";
             const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
             kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
@@ -762,39 +838,69 @@ void Engine::run(const mmt_params& p) {
             // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
             if (wide_ && !reserved && kind == 1) kind = 2;
         }
-        if (after_sort_) {                               // only the bucket-wise producer can sort a share of the suffixes
-            if (reserved) throw std::runtime_error("a sharded suffix sort needs a text without the bytes 0x00-0x02");
-            kind = 3;
-        }
         if (kind == 1 && n_ >= NARROW_LIMIT)
             throw std::runtime_error(reserved ? "texts of 2^32 characters or more must not contain the bytes 0x00-0x02 "
                                                 "(reserved by the prefix-free parse)"
                                               : "the direct suffix sort handles texts below 2^32 - 4096 characters");
-        // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
-        // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of
-        // short phrase suffixes (all occurrences of a trigger window) small (gpurun sweeps)
-        // (94 x 64 Mbp, 12 G characters: w = 14 leaves no suffix group larger than an emitter tile -- every 14-mer is
-        // rare enough -- and takes 1054 ms against 1111 for 10 / 30, 1171 for 10 / 50, 1981 for 10 / 100, 1376 for 8 / 30)
-        const bool big = n_ >= NARROW_LIMIT;
-        const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10), auto_p = n_ < (1ull << 30) ? 16 : 30;
-        if (kind >= 2) suffix_sort_pfp(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
-        else suffix_sort();
-        producer_used_ = kind >= 2 ? (pfp_->guided ? 3 : 2) : kind;
-        if (after_sort_) {                               // this rank's piece of the columns is complete: get the others
-            MMT_HIP(hipStreamSynchronize(stream_));
-            after_sort_(after_sort_ctx_);
-            MMT_HIP(hipStreamSynchronize(stream_));
-        }
     }
+    if (kind == 1) {
+        // ---- the direct producer: whole columns (narrow texts only), cut into windows by scan() ----
+        if (!d_sa_.owned() || !d_bwt_.owned() || !d_sa_hi_.owned()) { d_sa_.release(); d_sa_hi_.release(); d_bwt_.release(); }
+        ev_[1]->start(stream_);
+        suffix_sort();
+        producer_used_ = 1;
+        ev_[1]->stop(stream_);
+        const bool lean = slim || wants_lean();
+        if (lean) release_sort_scratch();
+        ev_[2]->start(stream_); lcp_bwt(); ev_[2]->stop(stream_);
+        if (lean) d_long_.release();
+        columns_kept_ = true;
+        scan(p);
+        if (lean && lcp_whole_ && !lcp_col_ready_) d_plcp_a_.release();
+        if (lean) { d_wpre_.release(); d_wsuf_.release(); d_wide_.release(); d_cand_.release(); }
+        make_rows(p);
+        finish();
+        return;
+    }
+    // ---- prefix-free parsing: the tables of the parse, then the stream window by window (never stored) ----
+    // the stream does not depend on (w, p): the automatic producer uses short phrases, which shrink the
+    // dictionary 2.2x on the bench workload; beyond ~1 G characters a wider window keeps the groups of
+    // short phrase suffixes (all occurrences of a trigger window) small (gpurun sweeps)
+    // (94 x 64 Mbp, 12 G characters: w = 14 leaves no suffix group larger than an emitter tile -- every 14-mer is
+    // rare enough -- and takes 1054 ms against 1111 for 10 / 30, 1171 for 10 / 50, 1981 for 10 / 100, 1376 for 8 / 30)
+    const bool big = n_ >= NARROW_LIMIT;
+    const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10), auto_p = n_ < (1ull << 30) ? 16 : 30;
+    if (kind == 3) pfp_want_guided_ = true;
+    stream_min_len_ = p.min_match_len;
+    ev_[1]->start(stream_);
+    pfp_prepare(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
+    pfp_want_guided_ = false;
     ev_[1]->stop(stream_);
-    const bool lean = lean_ || wide_ || wants_lean();
-    if (lean) release_sort_scratch();
-    ev_[2]->start(stream_); lcp_bwt(); ev_[2]->stop(stream_);
-    if (lean) d_long_.release();
-    scan(p);
-    // the PLCP column is dead after a single-range scan (copy_lcp reads the LCP column then)
-    if (lean && lcp_whole_ && !lcp_col_ready_) d_plcp_a_.release();
-    if (lean) { d_wpre_.release(); d_wsuf_.release(); d_wide_.release(); d_cand_.release(); }
+    producer_used_ = pfp_->guided ? 3 : 2;
+    // whole columns next to the windows when somebody wants to look at them afterwards
+    columns_kept_ = keep_columns_ > 0 || (keep_columns_ < 0 && n_ < (1ull << 26));
+    if (columns_kept_) {
+        d_sa_.ensure(n_ + 16); d_bwt_.ensure(n_ + 16); d_plcp_a_.ensure(n_ + 16);
+        if (wide_) d_sa_hi_.ensure(n_ + 16);
+    }
+    want_anchor_ranks_ = p.merge_metadata != 0;
+    if (want_anchor_ranks_) {
+        const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n_);
+        if (wide_) d_rank64_.ensure((size_t)anchor + 1); else d_rank_.ensure((size_t)anchor + 1);
+    }
+    ScanState S;
+    scan_begin(p, S);
+    streamed_ = true;
+    if (pfp_->guided) guided_stream(S, p); else pfp_stream(S, p);
+    scan_end(S);
+    anchor_ranks_valid_ = want_anchor_ranks_;
+    lcp_col_ready_ = columns_kept_;
+    lcp_whole_ = false;
+    if (slim) {
+        release_sort_scratch();
+        d_wpre_.release(); d_wsuf_.release(); d_wide_.release(); d_cand_.release();
+        for (int k = 0; k < 2; k++) { w_sa_[k].release(); w_hi_[k].release(); w_bwt_[k].release(); w_lcp_[k].release(); }
+    }
     make_rows(p);
     finish();
 }
@@ -810,11 +916,15 @@ void Engine::parse_only(bool revcomp, uint32_t w, uint32_t p) {
 void Engine::copy_text(uint8_t* out) const {
     MMT_HIP(hipMemcpy(out, text_ptr(), n_, hipMemcpyDeviceToHost));
 }
+static const char* NOT_KEPT = "the columns of this run were produced window by window and not kept "
+                              "(mmt_engine_keep_columns before the run)";
 void Engine::copy_sa(uint32_t* out) const {
+    if (!columns_kept_) throw std::runtime_error(NOT_KEPT);
     if (wide_ && n_ >= NARROW_LIMIT) throw std::runtime_error("40-bit suffix array: use the 64-bit accessor");
     MMT_HIP(hipMemcpy(out, d_sa_.get(), n_ * 4, hipMemcpyDeviceToHost));
 }
 void Engine::copy_sa64(uint64_t* out) const {
+    if (!columns_kept_) throw std::runtime_error(NOT_KEPT);
     std::vector<uint32_t> lo(n_);
     MMT_HIP(hipMemcpy(lo.data(), d_sa_.get(), n_ * 4, hipMemcpyDeviceToHost));
     std::vector<uint8_t> hi;
@@ -822,6 +932,7 @@ void Engine::copy_sa64(uint64_t* out) const {
     for (uint64_t j = 0; j < n_; j++) out[j] = (uint64_t)lo[j] | (wide_ ? (uint64_t)hi[j] << 32 : 0);
 }
 void Engine::copy_lcp(uint32_t* out) {
+    if (!columns_kept_) throw std::runtime_error(NOT_KEPT);
     if (lcp_col_ready_) { MMT_HIP(hipMemcpy(out, d_plcp_a_.get(), n_ * 4, hipMemcpyDeviceToHost)); return; }
     if (lcp_whole_) { MMT_HIP(hipMemcpy(out, d_lcp_.get(), n_ * 4, hipMemcpyDeviceToHost)); return; }
     // the run scanned the stream range by range: gather the column again, piece by piece
@@ -836,7 +947,10 @@ void Engine::copy_lcp(uint32_t* out) {
         MMT_HIP(hipStreamSynchronize(stream_));
     }
 }
-void Engine::copy_bwt(uint8_t* out) const { MMT_HIP(hipMemcpy(out, d_bwt_.get(), n_, hipMemcpyDeviceToHost)); }
+void Engine::copy_bwt(uint8_t* out) const {
+    if (!columns_kept_) throw std::runtime_error(NOT_KEPT);
+    MMT_HIP(hipMemcpy(out, d_bwt_.get(), n_, hipMemcpyDeviceToHost));
+}
 void Engine::copy_candidates(uint32_t* out) const {
     if (scan_ranges_ > 1) throw std::runtime_error("candidates are kept for single-range scans only");
     if (n_cand_ && !d_cand_.get()) throw std::runtime_error("the candidate list of this run was released (lean mode)");

@@ -32,6 +32,26 @@ struct HostRows {
     size_t text_len = 0;
 };
 
+// One window of the stream's columns, as the scan sees it: entries [base, base + len) of the suffix array / BWT / LCP
+// columns; closing positions below `first` belong to the window before (those entries only serve the walks to the left).
+struct ColWindow {
+    SaCol sa;                 // entry t of the window is sa[sa_off + t]
+    const uint8_t* bwt = nullptr;
+    const uint32_t* lcp = nullptr;
+    uint64_t base = 0, sa_off = 0;
+    uint32_t len = 0, first = 0;
+    bool more_left = false;   // entry 0 is not the start of the stream (a walk that reaches it is reported)
+    bool transient = false;   // the columns are gone after the window: accepted rows keep their suffix-array entries
+};
+// what the windows of one run share (Engine::scan_begin / scan_window / scan_end)
+struct ScanState {
+    k::ScanArgs a;
+    uint64_t cap = 0, ext0 = 0;
+    size_t rows_used = 0, ev_at = 0;
+    uint32_t max_doc_freq = 0;
+    bool merge = false;
+};
+
 class Engine {
 public:
     Engine(int device, hipStream_t stream);
@@ -103,18 +123,14 @@ public:
         if (count == 0 || index >= count) throw std::runtime_error("scan shard index out of range");
         shard_index_ = index; shard_count_ = count;
     }
-    // Multi-GPU runs that shard the SUFFIX SORT (buckets of suffixes by their leading characters are
-    // independent, and their concatenation in bucket order is the suffix array): rank `index` of `count` sorts only its
-    // share of the buckets (guided.cpp: whole bins, balanced by their histogram) and writes its piece of the suffix-array
-    // and BWT columns; `after_sort` -- called inside run(), when the piece is complete -- exchanges the pieces
-    // (mumemto_amd/dist.py::run_sort_sharded, dist.cpp::dist_exchange_columns); LCP, scan and rows follow on every rank
-    // (combine with set_scan_shard).  Every rank computes the same pieces (sort_pieces()).
-    void set_sort_shard(uint32_t index, uint32_t count, void (*after_sort)(void*), void* ctx) {
-        if (count == 0 || index >= count) throw std::runtime_error("sort shard index out of range");
-        if (count > 1 && !after_sort) throw std::runtime_error("a sharded suffix sort needs the exchange callback");
-        // (count = 1 with a callback: the degenerate case, one piece -- the whole path with a communicator of one rank)
-        sort_shard_index_ = index; sort_shard_count_ = count; after_sort_ = after_sort; after_sort_ctx_ = ctx;
-    }
+    // The columns of the stream exist one window at a time (the reference never stores them either:
+    // pfp_lcp_mum.hpp:197).  on = 1: every window is also copied into whole columns, so that copy_sa / copy_lcp /
+    // copy_bwt work after the run (tests, -A); 0: never; -1 (default): for texts below 2^26 characters.
+    void set_keep_columns(int on) { keep_columns_ = on; }
+    bool columns_kept() const { return columns_kept_; }
+    // The shares of the ranks of a sharded run as (first suffix-array entry, entries): ranges cut at multiples of 4096 for
+    // the parse proper, whole bins of leading characters for the bucket-wise producer (guided.cpp) -- every rank derives
+    // the same list.
     const std::vector<std::pair<uint64_t, uint64_t>>& sort_pieces() const { return sort_pieces_; }   // (first entry, entries)
     uint8_t* bwt_device() const { return d_bwt_.get(); }
     void release_sort_scratch();
@@ -175,10 +191,23 @@ private:
     void build_text(bool revcomp);
     void suffix_sort();
     void pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs);
-    void suffix_sort_pfp(uint32_t w, uint32_t p);
-    void suffix_sort_guided();
+    void pfp_prepare(uint32_t w, uint32_t p);
+    void pfp_prepare_emitter(uint32_t w);
+    void guided_prepare();
+    void guided_check_errors(const char* what);
+    void pfp_stream(ScanState& S, const mmt_params& p);
+    void pfp_emit_window(uint64_t b0, uint64_t c1, int set);
+    void guided_stream(ScanState& S, const mmt_params& p);
     void lcp_bwt();
     void scan(const mmt_params& p);
+    void scan_begin(const mmt_params& p, ScanState& S);
+    bool scan_window(ScanState& S, const ColWindow& w, const mmt_params& p);    // false: a walk ran off the left edge
+    void scan_end(ScanState& S);
+    void window_reserve(int set, uint64_t entries);
+    ColWindow window_view(int set, uint64_t base, uint32_t len, uint32_t first) const;
+    void keep_window(const ColWindow& w);
+    void shard_range(uint64_t& lo, uint64_t& hi) const;
+    EventPair& next_range_event(ScanState& S, int kind);
     void make_rows(const mmt_params& p);
 
     int device_;
@@ -215,10 +244,20 @@ private:
     bool want_anchor_ranks_ = false, anchor_ranks_valid_ = false;
     bool lcp_col_ready_ = false;          // d_plcp_a_ holds the LCP column in suffix-array order (written by the producer)
     uint32_t shard_index_ = 0, shard_count_ = 1;
-    uint32_t sort_shard_index_ = 0, sort_shard_count_ = 1;
-    void (*after_sort_)(void*) = nullptr;
-    void* after_sort_ctx_ = nullptr;
     std::vector<std::pair<uint64_t, uint64_t>> sort_pieces_;
+    // the window of the columns that exists (two sets: the bucket-wise producer carries the tail of one into the next)
+    DevBuf<uint32_t> w_sa_[2], w_lcp_[2];
+    DevBuf<uint8_t> w_hi_[2], w_bwt_[2];
+    int keep_columns_ = -1;
+    bool columns_kept_ = false, streamed_ = false, pfp_want_guided_ = false;
+    // suffix-array entries of the accepted rows (rows of a streamed run index this pool instead of the column)
+    DevBuf<uint32_t> d_pool_lo_;
+    DevBuf<uint8_t> d_pool_hi_;
+    DevBuf<k::Row> d_rows_pool_;
+    DevBuf<uint64_t> d_cap_cnt_, d_cap_off_;
+    uint64_t pool_used_ = 0;
+    float emit_ms_ = 0.f;
+    uint32_t stream_min_len_ = 20;      // minimum match length of the run in progress (the bins of the bucket-wise producer)
     size_t scan_ranges_ = 1;
     DoublingSorter sorter_;
     int sort_rounds_ = 0;
@@ -255,7 +294,7 @@ private:
     std::unique_ptr<EventPair> ev_[6];
     std::vector<std::unique_ptr<EventPair>> range_ev_;      // per scan range: LCP gather, scan kernel, verification
     std::vector<int> range_ev_kind_;
-    float scan_ms_[3] = {0, 0, 0};
+    float scan_ms_[4] = {0, 0, 0, 0};       // LCP gather, scan kernel, verification, window production
 };
 
 // decimal formatting shared with the merge output

@@ -136,7 +136,10 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
 
 }  // namespace
 
-void Engine::suffix_sort_guided() {
+// Tables of the bucket-wise producer: symbol codes, rank / successor structure over the phrase ends, ranks of the distinct
+// phrases, the parse's suffix array with the LCP of adjacent parse suffixes, histogram of the suffixes' leading
+// characters.  The suffixes themselves are sorted batch by batch while the scan consumes them (guided_stream).
+void Engine::guided_prepare() {
     PfpState& S = *pfp_;
     const uint64_t n = n_;
     const bool W = wide_;
@@ -148,7 +151,7 @@ void Engine::suffix_sort_guided() {
         MMT_HIP(hipStreamSynchronize(st));
         return std::chrono::duration<double, std::milli>(now() - t).count();
     };
-    EventPair e3, e5, e6;
+    EventPair e3, e5;
 
     // ---- symbol codes (ascending with the byte value; Dollar is the smallest symbol of V) ----
     e3.start(st);
@@ -157,10 +160,16 @@ void Engine::suffix_sort_guided() {
     uint8_t code[256];
     int sigma = 0;
     for (int c = 0; c < 256; c++) code[c] = (hist[c] || c == 2) ? (uint8_t)(++sigma) : 0;
-    gk::Ctx ctx{};
+    gk::Ctx& ctx = S.gctx;
+    ctx = gk::Ctx{};
     ctx.bits = std::max(1, bit_width_u64((uint64_t)sigma));
     ctx.chars = std::min(63 / ctx.bits, 63);
-    const int prefix_chars = std::max(1, std::min(12 / ctx.bits, ctx.chars));
+    // Bins of leading characters: every interval the scan can report (LCP value >= the minimum match length) lies inside
+    // one bin as long as a bin's prefix is not longer than that length -- SURVEY.md 8(e) -- so that the pieces of the
+    // stream can be produced, scanned and dropped bin by bin, on any rank.
+    int prefix_chars = std::max(1, std::min(12 / ctx.bits, ctx.chars));
+    prefix_chars = std::max(1, std::min<int>(prefix_chars, (int)std::min<uint32_t>(stream_min_len_, 64u)));
+    S.g_prefix = prefix_chars;
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     ctx.v = text_ptr() - 1; ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
@@ -170,78 +179,61 @@ void Engine::suffix_sort_guided() {
     const uint64_t n_blocks = n_words / 64, n_counts = n_words / 8;
     if (n_blocks < n / 4096 + 2) throw std::runtime_error("cut bit vector too short for the guided sort");
     const uint64_t* mask = reinterpret_cast<const uint64_t*>(S.tmask.get());
-    DevBuf<uint32_t> rcount, rdir;
-    DevBuf<uint64_t> nxt;
-    rcount.ensure(n_counts + 1); rdir.ensure(n_counts + 1);
-    gk::rank_counts(mask, n_words, rcount.get(), n_counts, st);
-    prims::exclusive_sum_u32(d_temp_, rcount.get(), rdir.get(), n_counts, st);
-    rcount.release();
     {
-        nxt.ensure(n_blocks + 1);
-        gk::block_first_cut(mask, n_words, nxt.get(), n_blocks, st);
+        DevBuf<uint32_t> rcount;
+        rcount.ensure(n_counts + 1); S.g_rdir.ensure(n_counts + 1);
+        gk::rank_counts(mask, n_words, rcount.get(), n_counts, st);
+        prims::exclusive_sum_u32(d_temp_, rcount.get(), S.g_rdir.get(), n_counts, st);
+        MMT_HIP(hipStreamSynchronize(st));
+    }
+    {
+        S.g_nxt.ensure(n_blocks + 1);
+        gk::block_first_cut(mask, n_words, S.g_nxt.get(), n_blocks, st);
         std::vector<uint64_t> h(n_blocks + 1);
-        MMT_HIP(hipMemcpyAsync(h.data(), nxt.get(), n_blocks * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(h.data(), S.g_nxt.get(), n_blocks * 8, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipStreamSynchronize(st));
         h[n_blocks] = n + w - 1;
         for (uint64_t b = n_blocks; b-- > 0;) if (h[b] == ~0ull || h[b] >= n) h[b] = h[b + 1];
-        MMT_HIP(hipMemcpyAsync(nxt.get(), h.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemcpyAsync(S.g_nxt.get(), h.data(), (n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
         MMT_HIP(hipStreamSynchronize(st));
     }
-    ctx.mask = mask; ctx.rdir = rdir.get(); ctx.nxt = nxt.get();
+    ctx.mask = mask; ctx.rdir = S.g_rdir.get(); ctx.nxt = S.g_nxt.get();
 
-    // ---- the bins of the text suffixes (leading characters), batch capacity ----
-    const uint32_t n_bins = 1u << (ctx.bits * prefix_chars);
-    std::vector<uint64_t> bins;
+    // ---- the bins of the text suffixes (leading characters) ----
+    S.g_nbins = 1u << (ctx.bits * prefix_chars);
     {
         DevBuf<uint64_t> d_bins;
         d_bins.ensure(4096);
         MMT_HIP(hipMemsetAsync(d_bins.get(), 0, 4096 * 8, st));
         gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
-        d2h(bins, d_bins.get(), 4096, st);
+        d2h(S.g_bins, d_bins.get(), 4096, st);
     }
-    // a batch holds whole bins, the distinct phrases are one batch: at least the largest of those, at most what the
-    // device has left next to the columns that already exist
-    uint64_t cap64 = std::min<uint64_t>(n, 1ull << 30);
-    const uint64_t fit = (uint64_t)(0.85 * (double)pool::available(device_) / (double)Batch::bytes_per_element());
-    cap64 = std::min(cap64, std::max<uint64_t>(fit, 1u << 20));
-    if (const char* c = std::getenv("MMT_GUIDED_BATCH")) cap64 = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
-    const uint64_t largest = std::max<uint64_t>(D, *std::max_element(bins.begin(), bins.end()));
-    if (largest > cap64) {
-        if (largest > fit || largest >= 0xfffffff0ull)
-            throw std::runtime_error("guided sort: " + std::to_string(largest) + " suffixes share their first " +
-                                     std::to_string(prefix_chars) + " characters (or are distinct phrases): more than one "
-                                     "batch can hold on this device (" + std::to_string(fit) + ")");
-        cap64 = largest;
-    }
-    Batch X;
-    X.reserve((uint32_t)cap64);
     S.err.ensure(16);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
-    auto check_err = [&](const char* what) {
-        uint32_t e2[3];
-        MMT_HIP(hipMemcpyAsync(e2, S.err.get(), 12, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipStreamSynchronize(st));
-        if (e2[0] || e2[1] || e2[2])
-            throw std::runtime_error(std::string("guided sort (") + what + "): phrase suffixes are not prefix-free (" +
-                                     std::to_string(e2[0]) + " equal distinct phrases, " + std::to_string(e2[1]) +
-                                     " groups with spent and unspent members, " + std::to_string(e2[2]) +
-                                     " neighbours equal up to the end of alpha without ascending parse ranks)");
-    };
 
-    // ---- lexicographic ranks of the distinct phrases, the parse ----
+    // ---- lexicographic ranks of the distinct phrases (one batch of the sort below), the parse ----
     auto t0 = now();
-    ctx.skip = 1; ctx.isa_p = nullptr; ctx.pos_bits = 40; ctx.rec_rank = 0;
-    gk::phrase_items(ctx, S.pstart.get(), W, S.rep.get(), D, X.key_a.get(), X.pos_a.get(), st);
-    RoundStats r1 = sort_batch(X, D, ctx, d_temp_, S.err.get(), st);
-    check_err("phrases");
-    S.prank.ensure(D); S.parse.ensure(m);
-    gk::phrase_ranks(ctx, X.pos_b.get(), D, S.pid.get(), S.prank.get(), st);
-    pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
+    {
+        Batch X;
+        const uint64_t fit = (uint64_t)(0.85 * (double)pool::available(device_) / (double)Batch::bytes_per_element());
+        if (D > fit || D >= 0xfffffff0u)
+            throw std::runtime_error("guided sort: " + std::to_string(D) + " distinct phrases are more than one batch can hold "
+                                     "on this device (" + std::to_string(fit) + ")");
+        X.reserve(std::max<uint32_t>(D, 1024));
+        ctx.skip = 1; ctx.isa_p = nullptr; ctx.pos_bits = 40; ctx.rec_rank = 0;
+        gk::phrase_items(ctx, S.pstart.get(), W, S.rep.get(), D, X.key_a.get(), X.pos_a.get(), st);
+        RoundStats r1 = sort_batch(X, D, ctx, d_temp_, S.err.get(), st);
+        guided_check_errors("phrases");
+        S.prank.ensure(D); S.parse.ensure(m);
+        gk::phrase_ranks(ctx, X.pos_b.get(), D, S.pid.get(), S.prank.get(), st);
+        pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
+        MMT_HIP(hipStreamSynchronize(st));
+        if (stats) std::fprintf(stderr, "[guided] %u distinct phrases ranked in %.1f ms (%d rounds, %u tied after the first sort)\n", D,
+                                ms_since(t0), r1.rounds, r1.first_active);
+    }
     e3.stop(st);
-    if (stats) std::fprintf(stderr, "[guided] %u distinct phrases ranked in %.1f ms (%d rounds, %u tied after the first sort)\n", D,
-                            ms_since(t0), r1.rounds, r1.first_active);
 
-    // ---- suffix array of the parse (parse.hpp:85) ----
+    // ---- suffix array of the parse (parse.hpp:85), LCP of adjacent parse suffixes (pfp.hpp:210-244) ----
     e5.start(st);
     t0 = now();
     S.sa_p.ensure(m); S.isa_p.ensure(m);
@@ -254,54 +246,107 @@ void Engine::suffix_sort_guided() {
         MMT_HIP(hipStreamSynchronize(st));
         sorter_.release();
     }
-    // LCP of adjacent parse suffixes + range minima: the LCP column is written batch by batch from them (a sharded sort
-    // still goes through the text-order construction: its pieces are exchanged without their LCP values)
-    const bool own_lcp = after_sort_ == nullptr;
-    if (own_lcp) S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
+    S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
     S.sa_p.release(); S.parse.release(); S.pid.release(); S.rep.release(); S.prank.release(); S.pstart.release();
     S.plen.release(); S.dlen.release(); S.dstart.release();
     e5.stop(st);
     if (stats) std::fprintf(stderr, "[guided] parse of %u phrases sorted in %.1f ms (%d rounds)\n", m, ms_since(t0), S.rounds_parse);
-
-    // ---- the text suffixes, batch by batch ----
-    e6.start(st);
-    t0 = now();
     ctx.skip = 0; ctx.isa_p = S.isa_p.get();
     {
         // the parse rank rides in the record when it fits next to the position (MMT_GUIDED_NO_RANK: never -- tests)
         const uint32_t pb = (uint32_t)bit_width_u64(n + w + 1);
         if (pb + (uint32_t)bit_width_u64(m) <= 64 && !std::getenv("MMT_GUIDED_NO_RANK")) { ctx.pos_bits = pb; ctx.rec_rank = 1; }
     }
-    d_sa_.ensure(n);
-    if (W) d_sa_hi_.ensure(n + 16);
-    d_bwt_.ensure((size_t)n + 16);
+    S.ms[2] = 0; S.ms[3] = e3.ms(); S.ms[4] = 0; S.ms[5] = e5.ms();
+    S.bwt_ready = true;
+    S.n_groups = 0; S.dict_len = 0;
+}
+
+void Engine::guided_check_errors(const char* what) {
+    PfpState& S = *pfp_;
+    uint32_t e2[3];
+    MMT_HIP(hipMemcpyAsync(e2, S.err.get(), 12, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    if (e2[0] || e2[1] || e2[2])
+        throw std::runtime_error(std::string("guided sort (") + what + "): phrase suffixes are not prefix-free (" +
+                                 std::to_string(e2[0]) + " equal distinct phrases, " + std::to_string(e2[1]) +
+                                 " groups with spent and unspent members, " + std::to_string(e2[2]) +
+                                 " neighbours equal up to the end of alpha without ascending parse ranks)");
+}
+
+// The stream, batch by batch.  A batch = whole bins of leading characters = one contiguous piece of the suffix array: its
+// suffixes are collected in text order, sorted, written as a window of the columns (suffix array, BWT, LCP from the
+// parse), scanned, and dropped; the accepted rows take their suffix-array entries along.  A rank of a sharded run takes
+// the bins from the first one whose cumulative count reaches k n / count (every rank derives the same shares from the
+// same histogram); nothing is exchanged but the rows.
+void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
+    PfpState& S = *pfp_;
+    const uint64_t n = n_;
+    hipStream_t st = stream_;
+    const gk::Ctx& ctx = S.gctx;
+    const int prefix_chars = S.g_prefix;
+    const uint32_t n_bins = S.g_nbins;
+    const std::vector<uint64_t>& bins = S.g_bins;
+    const bool stats = std::getenv("MMT_GUIDED_STATS") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    if (p.min_match_len < (uint32_t)prefix_chars)
+        throw std::runtime_error("guided producer: the bins were formed for another minimum match length");
+
+    // ---- shares of the ranks: whole bins ----
+    std::vector<uint64_t> pre(n_bins + 1, 0);                  // suffixes in the bins before bin b
+    for (uint32_t bq = 0; bq < n_bins; bq++) pre[bq + 1] = pre[bq] + bins[bq];
+    if (pre[n_bins] != n) throw std::runtime_error("guided sort: the histogram of leading characters does not cover the text");
+    std::vector<uint32_t> cut(shard_count_ + 1, 0);
+    cut[shard_count_] = n_bins;
+    for (uint32_t k = 1; k < shard_count_; k++) {
+        const uint64_t target = (uint64_t)((unsigned __int128)n * k / shard_count_);
+        cut[k] = std::max<uint32_t>(cut[k - 1], (uint32_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin()));
+        if (cut[k] > n_bins) cut[k] = n_bins;
+    }
+    sort_pieces_.clear();
+    for (uint32_t q = 0; q < shard_count_; q++) sort_pieces_.emplace_back(pre[cut[q]], pre[cut[q + 1]] - pre[cut[q]]);
+    const uint32_t bin_lo = cut[shard_index_], bin_hi = cut[shard_index_ + 1];
+    if (shard_count_ > 1 && p.merge_metadata)
+        throw std::runtime_error("merge metadata needs the whole stream on one rank (partition the documents instead)");
+
+    // ---- batch capacity: the batch scratch + two window sets (a batch with the tail of the one before) ----
+    // what a batch's first closing position may need of the batch before: the last bin of that batch, as far as an
+    // interval can reach
+    const bool capped = SS.cap != 0;
+    uint64_t largest = 0;
+    for (uint32_t b = bin_lo; b < bin_hi; b++) largest = std::max(largest, bins[b]);
+    const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest) : largest;
+    const double per_element = (double)Batch::bytes_per_element() + 2.0 * (wide_ ? 10.0 : 9.0);
+    uint64_t cap64 = std::min<uint64_t>(std::max<uint64_t>(n, 1024), 1ull << 30);
+    const double avail = 0.85 * (double)pool::available(device_) - 2.0 * 10.0 * (double)head_room;
+    const uint64_t fit = avail > 0 ? (uint64_t)(avail / per_element) : 0;
+    cap64 = std::min(cap64, std::max<uint64_t>(fit, 1u << 20));
+    if (const char* c = std::getenv("MMT_GUIDED_BATCH")) cap64 = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
+    if (largest > cap64) {
+        if (largest > fit || largest >= 0xfffffff0ull)
+            throw std::runtime_error("guided sort: " + std::to_string(largest) + " suffixes share their first " +
+                                     std::to_string(prefix_chars) + " characters: more than one batch can hold on this "
+                                     "device (" + std::to_string(fit) + ")");
+        cap64 = largest;
+    }
+    Batch X;
+    X.reserve((uint32_t)cap64);
+    window_reserve(0, head_room + cap64 + 16);
+    window_reserve(1, head_room + cap64 + 16);
     DevBuf<uint64_t> carry;
     carry.ensure(2);
-    if (own_lcp) d_plcp_a_.ensure((size_t)n + 16);
     const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
     DevBuf<uint32_t> tile_cnt, tile_off;
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
-    uint64_t base = 0, active_sum = 0, small_sum = 0;
+    const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
+
+    uint64_t base = pre[bin_lo], active_sum = 0, small_sum = 0;
+    const uint64_t piece_end = pre[bin_hi];
     int batches = 0, rounds_max = 0;
-    // a sharded sort (Engine::set_sort_shard): shard k takes the bins from the first one whose cumulative count reaches
-    // k * n / count -- whole bins, so that every rank finds the same pieces from the same histogram
-    uint32_t bin_lo = 0, bin_hi = n_bins;
-    sort_pieces_.clear();
-    if (after_sort_) {
-        std::vector<uint64_t> pre(n_bins + 1, 0);                  // suffixes in the bins before bin b
-        for (uint32_t bq = 0; bq < n_bins; bq++) pre[bq + 1] = pre[bq] + bins[bq];
-        std::vector<uint32_t> cut(sort_shard_count_ + 1, 0);
-        cut[sort_shard_count_] = n_bins;
-        for (uint32_t k = 1; k < sort_shard_count_; k++) {
-            const uint64_t target = (uint64_t)((unsigned __int128)n * k / sort_shard_count_);
-            cut[k] = std::max<uint32_t>(cut[k - 1], (uint32_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin()));
-            if (cut[k] > n_bins) cut[k] = n_bins;
-        }
-        for (uint32_t q = 0; q < sort_shard_count_; q++) sort_pieces_.emplace_back(pre[cut[q]], pre[cut[q + 1]] - pre[cut[q]]);
-        bin_lo = cut[sort_shard_index_]; bin_hi = cut[sort_shard_index_ + 1];
-        base = pre[bin_lo];
-    }
-    const uint64_t piece_end = after_sort_ ? base + sort_pieces_[sort_shard_index_].second : n;
+    uint64_t prev_len = 0;                 // entries of the window before (without a virtual closing entry)
+    uint32_t prev_last_bin = 0;            // its last non-empty bin
+    bool have_prev = false;
     for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
         uint64_t total = 0;
         uint32_t b1 = b0;
@@ -309,31 +354,66 @@ void Engine::suffix_sort_guided() {
         if (b1 == b0) throw std::runtime_error("guided sort: a bin exceeds the batch");
         if (total) {
             const uint32_t B = (uint32_t)total;
+            const int set = batches & 1;
+            EventPair& ee = next_range_event(SS, 3);
+            ee.start(st);
             gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
             prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
             gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
             RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st);
-            gk::write_columns(ctx, X.pos_b.get(), B, base, sa_col(), d_bwt_.get(), st);
-            if (own_lcp) {
-                gk::batch_lcp(ctx, S.plcp.view(), X.pos_b.get(), B, carry.get(), base != 0, d_plcp_a_.get() + base, S.err.get(), st);
-                MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
+            // the window: [tail of the batch before | this batch | one virtual closing entry at the end of a rank's share]
+            uint64_t ext = 0;
+            if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[prev_last_bin], prev_len), capped ? SS.ext0 : ~0ull);
+            if (ext > head_room) throw std::runtime_error("guided sort: window head room too small");
+            if (ext) {
+                const int o = set ^ 1;
+                const uint64_t from = prev_len - ext;
+                MMT_HIP(hipMemcpyAsync(w_sa_[set].get(), w_sa_[o].get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
+                if (wide_) MMT_HIP(hipMemcpyAsync(w_hi_[set].get(), w_hi_[o].get() + from, ext, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(w_bwt_[set].get(), w_bwt_[o].get() + from, ext, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(w_lcp_[set].get(), w_lcp_[o].get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
             }
+            SaCol wsa; wsa.lo = w_sa_[set].get(); wsa.hi = wide_ ? w_hi_[set].get() : nullptr;
+            gk::write_columns(ctx, X.pos_b.get(), B, ext, wsa, w_bwt_[set].get(), st);
+            gk::batch_lcp(ctx, S.plcp.view(), X.pos_b.get(), B, carry.get(), have_prev, w_lcp_[set].get() + ext, S.err.get(), st);
+            MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
+            ee.stop(st);
+            uint64_t len = ext + B;
+            ColWindow w = window_view(set, base - ext, (uint32_t)len, (uint32_t)ext);
+            w.more_left = false;          // nothing an interval of this window could reach lies further left (bins)
+            keep_window(w);
+            if (want_anchor_ranks_) {
+                SaCol piece = w.sa; piece.lo += ext; if (piece.hi) piece.hi += ext;
+                k::anchor_ranks(piece, base, B, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
+            }
+            const bool last_of_share = b1 == bin_hi || base + B == piece_end;
+            if (last_of_share && base + B < n) {
+                // the first entry of the next rank's share closes what is still open here: its LCP is below the bins'
+                // prefix length, below every reportable value -- stand-in entry with LCP 0
+                MMT_HIP(hipMemsetAsync(w_lcp_[set].get() + len, 0, 4, st));
+                MMT_HIP(hipMemsetAsync(w_bwt_[set].get() + len, 0, 1, st));
+                MMT_HIP(hipMemsetAsync(w_sa_[set].get() + len, 0, 4, st));
+                if (wide_) MMT_HIP(hipMemsetAsync(w_hi_[set].get() + len, 0, 1, st));
+                w.len = (uint32_t)(len + 1);
+            }
+            if (!scan_window(SS, w, p)) throw std::runtime_error("guided sort: a walk left its bin");
+            prev_len = len; have_prev = true;
+            for (uint32_t b = b1; b-- > b0;) if (bins[b]) { prev_last_bin = b; break; }
             base += B; batches++; rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
         }
         b0 = b1;
     }
-    check_err("text suffixes");
+    guided_check_errors("text suffixes");
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
-    S.bwt_ready = true;
-    lcp_col_ready_ = own_lcp;
-    S.n_groups = 0; S.dict_len = 0; S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
-    e6.stop(st);
+    S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     MMT_HIP(hipStreamSynchronize(st));
-    if (stats) std::fprintf(stderr, "[guided] %llu suffixes in %d batches of at most %u: %.1f ms; %.3f of them settled in small groups by "
-                            "comparison, %.3f element-rounds per suffix in %d rounds at most\n", (unsigned long long)n, batches, X.cap,
-                            ms_since(t0), (double)small_sum / (double)n, (double)active_sum / (double)n, rounds_max);
-    S.tmask.release(); S.isa_p.release();
-    S.ms[2] = 0; S.ms[3] = e3.ms(); S.ms[4] = 0; S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
+    const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
+    if (stats) std::fprintf(stderr, "[guided] %llu suffixes in %d batches of at most %u: %.1f ms with their scans; %.3f of them settled in "
+                            "small groups by comparison, %.3f element-rounds per suffix in %d rounds at most\n",
+                            (unsigned long long)(piece_end - pre[bin_lo]), batches, X.cap, ms,
+                            (double)small_sum / (double)std::max<uint64_t>(1, piece_end - pre[bin_lo]),
+                            (double)active_sum / (double)std::max<uint64_t>(1, piece_end - pre[bin_lo]), rounds_max);
+    S.ms[6] = (float)ms;
     sort_rounds_ = rounds_max;
 }
 

@@ -1704,7 +1704,7 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
 // LCP column of the range); accepted rows leave with absolute positions.
 template <typename SA>
 struct VerifyArgsT {
-    const Cand* cand; uint32_t n_cand; SA sa; uint64_t base; const uint32_t* lcp; const uint64_t* d_doc_start;
+    const Cand* cand; uint32_t n_cand; SA sa; uint64_t base, sa_off; const uint32_t* lcp; const uint64_t* d_doc_start;
     uint32_t n_docs, num_distinct, max_doc_freq; int merge; uint16_t* thresh; Row* rows; uint32_t* d_row_count;
 };
 __device__ __forceinline__ Row make_row(const Cand& c, uint64_t base) {
@@ -1732,7 +1732,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgsT<SA> a, int us
             // <= 64 documents, at most one occurrence each, interval fits one wave
             uint64_t bit = 0;
             if (lane < cnt) {
-                uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + c.start + lane));
+                uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.sa_off + c.start + lane));
                 bit = 1ull << d;
                 if (d == 0) first0 = c.start + lane;
             }
@@ -1743,7 +1743,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgsT<SA> a, int us
             for (uint32_t base = 0; base < cnt; base += 64) {
                 if (base + lane < cnt) {
                     uint32_t kk = c.start + base + lane;
-                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + kk));
+                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.sa_off + kk));
                     if (d >= a.n_docs) { fail = 1; }
                     else {
                         uint32_t old = atomicAdd(&ctr[d], 1u);
@@ -1757,7 +1757,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgsT<SA> a, int us
             fail = wave_sum32(fail);
             for (uint32_t base = 0; base < cnt; base += 64) {               // undo the counters
                 if (base + lane < cnt) {
-                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + c.start + base + lane));
+                    uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.sa_off + c.start + base + lane));
                     if (d < a.n_docs) ctr[d] = 0;
                 }
             }
@@ -1770,7 +1770,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgsT<SA> a, int us
                 uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
                 uint32_t nb = before > after ? before : after;
                 if (nb > 65535u) nb = 65535u;
-                a.thresh[(uint64_t)a.sa.get(a.base + first0) - a.d_doc_start[0]] = (uint16_t)nb;
+                a.thresh[(uint64_t)a.sa.get(a.sa_off + first0) - a.d_doc_start[0]] = (uint16_t)nb;
             }
         }
         if (c.flags & CAND_LEFT_MAXIMAL) {
@@ -1821,7 +1821,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgsT<SA> a)
         const uint32_t cnt = live ? c.end - c.start + 1 : 0u;
         uint32_t bits = 0, first0 = 0xffffffffu;
         if (sl < cnt) {
-            const uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.base + c.start + sl));
+            const uint32_t d = doc_lookup(a.d_doc_start, a.n_docs, a.sa.get(a.sa_off + c.start + sl));
             bits = 1u << d;
             if (d == 0) first0 = c.start + sl;
         }
@@ -1837,7 +1837,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgsT<SA> a)
             const uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
             uint32_t nb = before > after ? before : after;
             if (nb > 65535u) nb = 65535u;
-            a.thresh[(uint64_t)a.sa.get(a.base + first0) - a.d_doc_start[0]] = (uint16_t)nb;
+            a.thresh[(uint64_t)a.sa.get(a.sa_off + first0) - a.d_doc_start[0]] = (uint16_t)nb;
         }
         const bool take = ok && sl == 0 && (c.flags & CAND_LEFT_MAXIMAL);
         const uint64_t m = __ballot(take);
@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgsT<SA> a)
 template <typename SA>
 static void verify_typed(const VerifyArgs& v, hipStream_t s) {
     VerifyArgsT<SA> a;
-    a.cand = v.cand; a.n_cand = v.n_cand; a.sa = SA(v.sa); a.base = v.base; a.lcp = v.lcp; a.d_doc_start = v.d_doc_start;
+    a.cand = v.cand; a.n_cand = v.n_cand; a.sa = SA(v.sa); a.base = v.base; a.sa_off = v.sa_off; a.lcp = v.lcp; a.d_doc_start = v.d_doc_start;
     a.n_docs = v.n_docs; a.num_distinct = v.num_distinct; a.max_doc_freq = v.max_doc_freq; a.merge = v.merge;
     a.thresh = v.thresh; a.rows = v.rows; a.d_row_count = v.d_row_count;
     // every candidate interval has <= cap entries; the single-wave bitmap path needs
@@ -1896,6 +1896,43 @@ static void verify_typed(const VerifyArgs& v, hipStream_t s) {
 void verify_candidates(const VerifyArgs& a, hipStream_t s) {
     if (a.n_cand == 0) return;
     if (a.sa.wide()) verify_typed<Sa40>(a, s); else verify_typed<Sa32>(a, s);
+}
+
+// ---- occurrences of accepted rows, kept while the columns are produced window by window ------------------------------
+// The stream is not stored (pfp_lcp_mum.hpp:197: one update() per suffix, nothing kept): what the writers need of the
+// suffix array -- the text positions of every accepted interval -- is copied out of the window while it exists.
+__global__ void k_row_counts(const Row* __restrict__ rows, uint32_t n_rows, uint64_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) cnt[i] = rows[i].cnt;
+}
+// one wave per row: pool[pool_base + off[i] + k] = sa[row.start - win_base + k]; out[i] = the row with the pool offset as start
+template <typename SA>
+__global__ void k_capture_rows(const Row* __restrict__ rows, uint32_t n_rows, const uint64_t* __restrict__ off,
+                               uint64_t pool_base, SA win, uint64_t win_base, SA pool, Row* __restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63;
+    if (i >= n_rows) return;
+    const Row r = rows[i];
+    const uint64_t dst = pool_base + off[i], src = r.start - win_base;
+    for (uint32_t k = lane; k < r.cnt; k += 64) pool.set(dst + k, win.get(src + k));
+    if (lane == 0) { Row o; o.start = dst; o.cnt = r.cnt; o.len = r.len; out[i] = o; }
+}
+void row_counts(const Row* rows, uint32_t n_rows, uint64_t* cnt, hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(k_row_counts, dim3(grid_for(n_rows, 256)), dim3(256), 0, s, rows, n_rows, cnt);
+    MMT_HIP(hipGetLastError());
+}
+void capture_rows(const Row* rows, uint32_t n_rows, const uint64_t* off, uint64_t pool_base, SaCol win, uint64_t win_base,
+                  SaCol pool, Row* out, hipStream_t s) {
+    if (!n_rows) return;
+    if (win.wide() != pool.wide()) throw HipError("capture_rows: window and pool differ in width");
+    if (win.wide())
+        hipLaunchKernelGGL(k_capture_rows<Sa40>, dim3(grid_for((uint64_t)n_rows * 64, 256)), dim3(256), 0, s, rows, n_rows, off,
+                           pool_base, Sa40(win), win_base, Sa40(pool), out);
+    else
+        hipLaunchKernelGGL(k_capture_rows<Sa32>, dim3(grid_for((uint64_t)n_rows * 64, 256)), dim3(256), 0, s, rows, n_rows, off,
+                           pool_base, Sa32(win), win_base, Sa32(pool), out);
+    MMT_HIP(hipGetLastError());
 }
 
 // ============================================================================

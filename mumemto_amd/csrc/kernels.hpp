@@ -127,8 +127,9 @@ void scan_wide_prepare(const uint32_t* lcp, const uint8_t* bwt, uint32_t n, uint
 struct VerifyArgs {
     const Cand* cand;             // positions relative to the scanned range
     uint32_t n_cand;
-    SaCol sa;                     // the whole suffix array
-    uint64_t base;                // suffix-array index of entry 0 of the scanned range
+    SaCol sa;                     // the suffix array, or the window of it that holds the scanned range
+    uint64_t base;                // suffix-array index of entry 0 of the scanned range (rows leave with absolute positions)
+    uint64_t sa_off = 0;          // index of that entry in `sa` (= base for the whole column, 0 for a window)
     const uint32_t* lcp;          // LCP column of the scanned range
     const uint64_t* d_doc_start;  // N+1
     uint32_t n_docs;
@@ -140,6 +141,12 @@ struct VerifyArgs {
     uint32_t* d_row_count;
 };
 void verify_candidates(const VerifyArgs& a, hipStream_t s);
+// The suffix-array entries of accepted rows, copied out of a window of the column: cnt[i] = rows[i].cnt (to be turned into
+// exclusive offsets by the caller), then pool[pool_base + off[i] + k] = win[rows[i].start - win_base + k] and out[i] = the
+// row with that pool offset as its start (what the writers index instead of the column).
+void row_counts(const Row* rows, uint32_t n_rows, uint64_t* cnt, hipStream_t s);
+void capture_rows(const Row* rows, uint32_t n_rows, const uint64_t* off, uint64_t pool_base, SaCol win, uint64_t win_base,
+                  SaCol pool, Row* out, hipStream_t s);
 
 // ---- A9 anchor merge, one fold step -------------------------------------------
 // Per anchor position i (parallel): thresholds merged into nb_out; emits

@@ -131,8 +131,8 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
         if (!keep_dict_inputs) {
             const char* env = std::getenv("MUMEMTO_PRODUCER");
             const double tables = 46.0 * (double)dict_len64, sorter = 49.0 * (double)std::max<uint64_t>(dict_len64, m);
-            const double need = tables + std::max(0.0, sorter - (slim ? (double)d_cols_.bytes() : 0.0));
-            S.guided = producer_ == 3 || after_sort_ != nullptr || (env && std::string(env) == "guided") ||
+            const double need = tables + sorter;
+            S.guided = producer_ == 3 || pfp_want_guided_ || (env && std::string(env) == "guided") ||
                        dict_len64 >= 0xffffff00ull ||
                        (producer_ == 0 && need > 0.9 * (double)pool::available(device_));
             if (S.guided) {
@@ -171,9 +171,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     S.sa_d.ensure(nd); S.rank_d.ensure(nd);
-    // one-shot / wide runs: the scratch of the two sorts lives in the (not yet written) suffix-array / BWT block
-    if (slim && d_cols_.get()) sorter_.reserve_in(d_cols_.get(), d_cols_.bytes(), std::max(nd, m));
-    else sorter_.reserve(std::max(nd, m));
+    sorter_.reserve(std::max(nd, m));
     k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
     if (slim) S.rank_d.release();
@@ -198,20 +196,25 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     S.have_parse = true;
 }
 
-// A3 (parse half) + A4: suffix array of the text = positions sorted by
-// (group of the phrase suffix, rank of the following parse suffix).
-void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
+// A3 (parse half) + A4: the text suffixes ordered by (group of the phrase suffix, rank of the following parse suffix).
+// pfp_prepare builds every table the emitter needs (or hands over to guided_prepare); the columns themselves are
+// emitted window by window while the scan consumes them (pfp_stream below) and are never stored as a whole --
+// pfp_lcp_mum.hpp:197: one update() per suffix.
+void Engine::pfp_prepare(uint32_t w, uint32_t p) {
+    PfpState& S = *pfp_;
+    auto t0 = std::chrono::steady_clock::now();
+    S.emit_ready = false;
+    pfp_parse(w, p, false);
+    if (S.guided) guided_prepare();
+    else pfp_prepare_emitter(w);
+    S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::pfp_prepare_emitter(uint32_t w) {
     PfpState& S = *pfp_;
     const uint64_t n = n_;
     const bool W = wide_;
     const bool slim = lean_ || wide_;
-    auto t0 = std::chrono::steady_clock::now();
-    pfp_parse(w, p, false);
-    if (S.guided) {
-        suffix_sort_guided();
-        S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return;
-    }
     hipStream_t st = stream_;
     const uint32_t m = S.n_phrases, D = S.n_distinct;
     EventPair e5, e6;
@@ -229,10 +232,6 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     e6.start(st);
     const int shift = bit_width_u64((uint64_t)m + 1);
     const uint32_t nd = S.dict_len;
-    d_sa_.ensure(n);
-    if (W) d_sa_hi_.ensure(n + 16);
-    d_bwt_.ensure((size_t)n + 16);                      // no inverse suffix array on this path (see Engine::lcp_bwt)
-    d_plcp_a_.ensure((size_t)n + 16);                   // the emitter writes the LCP column itself (suffix-array order)
     // inverted lists: parse positions ordered by (phrase, rank of the following parse suffix)
     const uint32_t pos_bits = W ? (uint32_t)bit_width_u64(n + w + 1) : 32u;
     if ((uint32_t)shift + pos_bits > 64)
@@ -254,17 +253,6 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         pk::occ_finish(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), m, S.occ_start.get(),
                        S.occ.get(), pos_bits, S.plcp.sl.get(), S.occ_sl.get(), W, st);
         MMT_HIP(hipStreamSynchronize(st));
-    }
-    if (std::getenv("MMT_DEBUG_SENTINEL")) {
-        std::vector<uint32_t> lastid, pl;
-        d2h(lastid, S.pid.get() + (m - 1), 1, st); d2h(pl, S.plen.get() + (m - 1), 1, st);
-        std::vector<uint32_t> os;
-        d2h(os, S.occ_start.get() + lastid[0], 2, st);
-        std::vector<uint64_t> rec;
-        d2h(rec, S.occ.get() + os[0], 1, st);
-        std::fprintf(stderr, "[sentinel] last phrase: start %llu len %u id %u, its list [%u, %u), first record t %llu pos %llu\n",
-                     (unsigned long long)S.pstart.read(m - 1, st), pl[0], lastid[0], os[0], os[1],
-                     (unsigned long long)(rec[0] >> pos_bits), (unsigned long long)(rec[0] & ((1ull << pos_bits) - 1)));
     }
     if (slim) { S.occ_ids.release(); S.occ_ts.release(); S.sa_p.release(); S.pid.release(); S.pstart.release(); }
     // valid dictionary suffixes in dictionary suffix-array order, compacted ("entries")
@@ -299,20 +287,6 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     S.ghead.ensure((size_t)G * 2);
     pk::group_heads(S.sege.get(), S.ce_dpos.get(), S.ce_slen.get(), S.dict.get(), G, S.ghead.get(), st);
     if (slim) { MMT_HIP(hipStreamSynchronize(st)); S.ce_dpos.release(); S.ce_slen.release(); S.sa_d.release(); S.dict.release(); }
-    if (std::getenv("MMT_DEBUG_SENTINEL")) {       // where does the end sentinel (stream entry 0) come from?
-        std::vector<uint32_t> cnt2, first2, off2, sg2;
-        d2h(cnt2, S.ce_cnt.get(), 2, st); d2h(first2, S.ce_first.get(), 2, st); d2h(off2, S.ce_offm1.get(), 2, st);
-        d2h(sg2, S.sege.get(), 2, st);
-        std::vector<uint64_t> o2;
-        d2h(o2, S.occ.get() + first2[0], 1, st);
-        std::fprintf(stderr, "[sentinel] n %llu m %u pos_bits %u shift %d | entry0: cnt %u first %u offm1 %u | entry1: cnt %u first %u "
-                     "offm1 %u | ce_eoff %llu %llu | segb %llu %llu | sege %u %u | occ[first0] = t %llu, pos %llu -> text %llu\n",
-                     (unsigned long long)n, m, pos_bits, shift, cnt2[0], first2[0], off2[0], cnt2[1], first2[1], off2[1],
-                     (unsigned long long)S.ce_eoff.read(0, st), (unsigned long long)S.ce_eoff.read(1, st),
-                     (unsigned long long)S.segb.read(0, st), (unsigned long long)S.segb.read(1, st), sg2[0], sg2[1],
-                     (unsigned long long)(o2[0] >> pos_bits), (unsigned long long)(o2[0] & ((1ull << pos_bits) - 1)),
-                     (unsigned long long)((o2[0] & ((1ull << pos_bits) - 1)) + off2[0]));
-    }
     // groups larger than one LDS tile of the emitter get compact slots in the fallback arrays
     S.gscan.ensure(std::max<size_t>(G, 1));
     uint32_t* osize = S.gscan.get();
@@ -329,75 +303,45 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
     }
     const uint32_t F = S.n_fallback;
     S.fb_size.ensure((size_t)F + 2); S.fb_off.ensure((size_t)F + 2, W); S.fb_start.ensure((size_t)F + 2, W);
-    uint64_t fb_total = 0;
-    std::vector<uint64_t> h_fb_off(1, 0), h_fb_start;
+    S.h_fb_off.assign(1, 0); S.h_fb_start.clear();
     if (F) {
         k::gather_u32_idx32(osize, S.fb_group.get(), F, S.fb_size.get(), st);
         MMT_HIP(hipMemsetAsync(S.fb_size.get() + F, 0, 4, st));
         offsets_from_counts(d_temp_, S.fb_size.get(), S.fb_off, (size_t)F + 1, st);
         pk::gather_pos(S.segb.get(), S.fb_group.get(), F, S.fb_start.get(), W, st);
-        // the launch plan below needs both tables on the host
-        h_fb_off.assign((size_t)F + 1, 0); h_fb_start.assign(F, 0);
+        // the launch plan of every window needs both tables on the host
+        S.h_fb_off.assign((size_t)F + 1, 0); S.h_fb_start.assign(F, 0);
         if (W) {
-            MMT_HIP(hipMemcpyAsync(h_fb_off.data(), S.fb_off.get(), ((size_t)F + 1) * 8, hipMemcpyDeviceToHost, st));
-            MMT_HIP(hipMemcpyAsync(h_fb_start.data(), S.fb_start.get(), (size_t)F * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(S.h_fb_off.data(), S.fb_off.get(), ((size_t)F + 1) * 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipMemcpyAsync(S.h_fb_start.data(), S.fb_start.get(), (size_t)F * 8, hipMemcpyDeviceToHost, st));
             MMT_HIP(hipStreamSynchronize(st));
         } else {
             std::vector<uint32_t> a32, b32;
             d2h(a32, S.fb_off.p32(), (size_t)F + 1, st);
             d2h(b32, S.fb_start.p32(), F, st);
-            for (size_t i = 0; i <= F; i++) h_fb_off[i] = a32[i];
-            for (size_t i = 0; i < F; i++) h_fb_start[i] = b32[i];
+            for (size_t i = 0; i <= F; i++) S.h_fb_off[i] = a32[i];
+            for (size_t i = 0; i < F; i++) S.h_fb_start[i] = b32[i];
         }
-        fb_total = h_fb_off[F];
     }
     if (slim) S.gscan.release();
 
-    // ---- launch plan: ranges of output tiles whose oversized groups fit the fallback arrays of one launch ----
-    const uint64_t tiles = (n + 1 + pk::emit_tile() - 1) / pk::emit_tile();
-    uint64_t per_launch = W ? (1ull << 18) : tiles;                       // wide: 2^28 output positions per launch
-    if (const char* c = std::getenv("MMT_EMIT_TILES")) per_launch = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
-    if (per_launch > 0x7fffffffull) per_launch = 0x7fffffffull;
-    const uint64_t FB_LIMIT = 0xfffffff0ull;                              // 32-bit offsets inside one launch
-    struct Launch { uint64_t t0, t1; uint32_t f0, f1; };
-    std::vector<Launch> plan;
-    auto first_group_at = [&](uint64_t out_pos) {                         // first oversized group that begins at or after out_pos
-        return (uint32_t)(std::lower_bound(h_fb_start.begin(), h_fb_start.end(), out_pos) - h_fb_start.begin());
-    };
-    uint64_t max_fb = 0;
-    for (uint64_t t0 = 0; t0 < tiles;) {
-        uint64_t t1 = std::min(tiles, t0 + per_launch);
-        uint32_t f0 = first_group_at(t0 * pk::emit_tile()), f1 = first_group_at(t1 * pk::emit_tile());
-        while (h_fb_off[f1] - h_fb_off[f0] > FB_LIMIT && t1 - t0 > 1) {   // too many oversized suffixes: halve the range
-            t1 = t0 + (t1 - t0) / 2;
-            f1 = first_group_at(t1 * pk::emit_tile());
-        }
-        if (h_fb_off[f1] - h_fb_off[f0] > FB_LIMIT)
-            throw std::runtime_error("the oversized suffix groups of one emitter tile exceed 2^32 elements");
-        plan.push_back({t0, t1, f0, f1});
-        max_fb = std::max(max_fb, h_fb_off[f1] - h_fb_off[f0]);
-        t0 = t1;
-    }
-    S.emit_launches = (uint32_t)plan.size();
-    S.xk_a.ensure((size_t)max_fb + 1); S.xv_a.ensure((size_t)max_fb + 1, W);
-    (void)fb_total;
-    // the emitter
-    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
-    pk::EmitArgs ea;
+    // the emitter's arguments, shared by every window
+    S.tiles = (n + 1 + pk::emit_tile() - 1) / pk::emit_tile();
+    pk::EmitArgs& ea = S.ea;
+    ea = pk::EmitArgs();
     ea.wide = W;
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
     ea.occ = S.occ.get(); ea.occ_sl = S.occ_sl.get(); ea.pos_bits = pos_bits;
-    ea.n = n; ea.sa = sa_col(); ea.bwt = d_bwt_.get();
+    ea.n = n;
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F; ea.fb_base = 0;
-    ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get(); ea.err = S.err.get();
-    ea.lcp = d_plcp_a_.get(); ea.ghead = S.ghead.get(); ea.rmq = S.plcp.view(); ea.w = w;
-    ea.out_base = 0; ea.win_lo = 0; ea.win_hi = n;
+    ea.err = S.err.get();
+    ea.ghead = S.ghead.get(); ea.rmq = S.plcp.view(); ea.w = w;
     // the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at
     // most 16 different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)
-    pk::BwtDecode decode{};
-    uint32_t fb_bits = 0;
+    S.decode = pk::BwtDecode{};
+    S.fb_bits = 0; S.key_shift = shift;
     if (F && !std::getenv("MMT_PFP_NO_BWT_CODE")) {
         std::vector<uint64_t> hist;
         d2h(hist, d_hist_.get(), 256, st);
@@ -407,39 +351,136 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
         for (int b = 0; b < 256; b++)
             if (b == 0 || hist[b]) {                              // 0 stands before the first text position
                 if (kinds == 16) { fits = false; break; }
-                decode.byte[kinds] = (uint8_t)b; code[b] = (uint8_t)kinds++;
+                S.decode.byte[kinds] = (uint8_t)b; code[b] = (uint8_t)kinds++;
             }
         uint32_t bits = 1;
         while ((1u << bits) < kinds) bits++;
         if (fits && shift + (int)bits <= 32) {
-            fb_bits = bits;
+            S.fb_bits = bits;
             S.bwt_code.ensure(256);
             MMT_HIP(hipMemcpyAsync(S.bwt_code.get(), code.data(), 256, hipMemcpyHostToDevice, st));
             MMT_HIP(hipStreamSynchronize(st));
         }
     }
-    ea.bwt_code = S.bwt_code.get(); ea.fb_bits = fb_bits;
-    S.tile_first.ensure((size_t)tiles + 4);
-    pk::tile_first(S.segb.get(), G, tiles, S.tile_first.get(), W, st);
-    if (max_fb) { S.xk_b.ensure((size_t)max_fb + 1); S.xv_b.ensure((size_t)max_fb + 1, W); }
-    for (const Launch& L : plan) {
-        ea.fb_base = h_fb_off[L.f0];
-        pk::emit(ea, S.tile_first.get(), L.t0, L.t1, st);
-        const uint32_t nf = L.f1 - L.f0;
-        if (!nf) continue;
-        // one segmented radix sort over just the oversized groups of this launch
-        const uint32_t count = (uint32_t)(h_fb_off[L.f1] - h_fb_off[L.f0]);
-        S.fb_rel.ensure((size_t)nf + 2);
-        pk::relative_offsets(S.fb_off.get(), L.f0, nf, S.fb_rel.get(), W, st);
-        if (W)
-            prims::segmented_sort_pairs_u32_u64vals_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p64(), S.xv_b.p64(),
-                                                           count, nf, S.fb_rel.get(), S.fb_rel.get() + 1,
-                                                           shift + (int)fb_bits, st);
-        else
-            prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
-                                                   nf, S.fb_rel.get(), S.fb_rel.get() + 1, shift + (int)fb_bits, st);
-        pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), L.f0, L.f1, h_fb_off[L.f0], S.segb.get(), S.xk_b.get(),
-                            S.xv_b.get(), fb_bits, decode, text_ptr(), n, ea, W, st);
+    ea.bwt_code = S.bwt_code.get(); ea.fb_bits = S.fb_bits;
+    S.tile_first.ensure((size_t)S.tiles + 4);
+    pk::tile_first(S.segb.get(), G, S.tiles, S.tile_first.get(), W, st);
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
+    S.emit_launches = 0;
+    S.emit_ready = true;
+    S.bwt_ready = true;
+    e6.stop(st);
+    S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
+    sort_rounds_ = S.rounds_dict;
+}
+
+// Suffix-array entries [b0, c1) of the stream -- suffix array, BWT byte and LCP value of each -- into window set `set`
+// (entry b0 at index 0).  The output tiles that cover the range are run; the groups that begin in them may reach beyond
+// the range on either side and are clipped (pfp_kernels.hip).
+void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
+    PfpState& S = *pfp_;
+    if (!S.emit_ready) throw std::runtime_error("the emitter's tables are gone");
+    const bool W = wide_;
+    hipStream_t st = stream_;
+    const uint64_t TILE = pk::emit_tile();
+    pk::EmitArgs ea = S.ea;
+    ea.sa.lo = w_sa_[set].get(); ea.sa.hi = W ? w_hi_[set].get() : nullptr;
+    ea.bwt = w_bwt_[set].get(); ea.lcp = w_lcp_[set].get();
+    ea.out_base = b0; ea.win_lo = b0; ea.win_hi = c1;
+    // first tile: the one in which the group that covers stream entry b0 + 1 begins
+    uint64_t t_lo = 0;
+    if (b0 > 0) {
+        const uint64_t X = b0 + 1, tX = X / TILE;
+        const uint32_t gA = read_u32(S.tile_first.get() + tX, st);        // first group that begins at or after tX * TILE
+        t_lo = tX;
+        if (gA > 0 && (gA >= S.n_groups || S.segb.read(gA, st) > X)) t_lo = S.segb.read(gA - 1, st) / TILE;
+    }
+    const uint64_t t_hi = std::min<uint64_t>(S.tiles, c1 / TILE + 1);      // stream entry c1 (suffix-array entry c1 - 1) is the last one
+    auto first_group_at = [&](uint64_t out_pos) {                         // first oversized group that begins at or after out_pos
+        return (uint32_t)(std::lower_bound(S.h_fb_start.begin(), S.h_fb_start.end(), out_pos) - S.h_fb_start.begin());
+    };
+    const uint64_t FB_LIMIT = 0xfffffff0ull;                              // 32-bit offsets inside one launch
+    uint64_t per_launch = t_hi - t_lo;
+    if (const char* c = std::getenv("MMT_EMIT_TILES")) per_launch = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
+    if (per_launch > 0x7fffffffull) per_launch = 0x7fffffffull;
+    for (uint64_t t0 = t_lo; t0 < t_hi;) {
+        uint64_t t1 = std::min(t_hi, t0 + per_launch);
+        uint32_t f0 = first_group_at(t0 * TILE), f1 = first_group_at(t1 * TILE);
+        while (S.h_fb_off[f1] - S.h_fb_off[f0] > FB_LIMIT && t1 - t0 > 1) {   // too many oversized suffixes: halve the range
+            t1 = t0 + (t1 - t0) / 2;
+            f1 = first_group_at(t1 * TILE);
+        }
+        const uint64_t fb_count = S.h_fb_off[f1] - S.h_fb_off[f0];
+        if (fb_count > FB_LIMIT) throw std::runtime_error("the oversized suffix groups of one emitter tile exceed 2^32 elements");
+        S.xk_a.ensure((size_t)fb_count + 1); S.xv_a.ensure((size_t)fb_count + 1, W);
+        if (fb_count) { S.xk_b.ensure((size_t)fb_count + 1); S.xv_b.ensure((size_t)fb_count + 1, W); }
+        ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get();
+        ea.fb_base = S.h_fb_off[f0];
+        pk::emit(ea, S.tile_first.get(), t0, t1, st);
+        S.emit_launches++;
+        const uint32_t nf = f1 - f0;
+        if (nf) {
+            // one segmented radix sort over just the oversized groups of this launch
+            const uint32_t count = (uint32_t)fb_count;
+            S.fb_rel.ensure((size_t)nf + 2);
+            pk::relative_offsets(S.fb_off.get(), f0, nf, S.fb_rel.get(), W, st);
+            if (W)
+                prims::segmented_sort_pairs_u32_u64vals_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p64(), S.xv_b.p64(),
+                                                               count, nf, S.fb_rel.get(), S.fb_rel.get() + 1,
+                                                               S.key_shift + (int)S.fb_bits, st);
+            else
+                prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
+                                                       nf, S.fb_rel.get(), S.fb_rel.get() + 1, S.key_shift + (int)S.fb_bits, st);
+            pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), f0, f1, S.h_fb_off[f0], S.segb.get(), S.xk_b.get(),
+                                S.xv_b.get(), S.fb_bits, S.decode, text_ptr(), n_, ea, W, st);
+        }
+        t0 = t1;
+    }
+}
+
+// The stream, window by window: emit -> scan -> verify -> (rows keep their suffix-array entries) -> next window.
+void Engine::pfp_stream(ScanState& SS, const mmt_params& p) {
+    PfpState& S = *pfp_;
+    const uint64_t n = n_;
+    hipStream_t st = stream_;
+    const uint64_t ALIGN_R = 4096;
+    uint64_t range = wide_ ? (1ull << 28) : std::min<uint64_t>(n, 1ull << 28);
+    if (const char* c = std::getenv("MMT_SCAN_RANGE")) range = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
+    range = (std::max<uint64_t>(range, 1) + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
+    uint64_t lo = 0, hi = n;
+    shard_range(lo, hi);
+    sort_pieces_.clear();
+    for (uint32_t k = 0; k < shard_count_; k++) {
+        Engine* self = this;
+        const uint32_t keep = shard_index_;
+        self->shard_index_ = k;
+        uint64_t a = 0, b = 0;
+        shard_range(a, b);
+        sort_pieces_.emplace_back(a, b - a);
+        self->shard_index_ = keep;
+    }
+    const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
+    for (uint64_t c0 = lo; c0 < hi; c0 += range) {
+        const uint64_t c1 = std::min(hi, c0 + range);
+        uint64_t ext = c0 ? SS.ext0 : 0;
+        for (;;) {
+            if (ext > c0) ext = c0;
+            const uint64_t b0 = c0 - ext, len = c1 - b0;
+            if (len >= 0xffffe000ull) throw std::runtime_error("scan window with its left extension exceeds 2^32 entries");
+            window_reserve(0, len);
+            EventPair& ee = next_range_event(SS, 3);
+            ee.start(st);
+            pfp_emit_window(b0, c1, 0);
+            ee.stop(st);
+            ColWindow w = window_view(0, b0, (uint32_t)len, (uint32_t)ext);
+            if (!scan_window(SS, w, p)) { ext = std::max<uint64_t>(ext * 4, SS.ext0); continue; }   // a walk ran off the extension
+            if (want_anchor_ranks_) {
+                SaCol piece = w.sa; piece.lo += ext; if (piece.hi) piece.hi += ext;
+                k::anchor_ranks(piece, c0, c1 - c0, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
+            }
+            keep_window(w);
+            break;
+        }
     }
     if (read_u32(S.err.get(), st)) {
         std::vector<uint32_t> er;
@@ -453,12 +494,6 @@ void Engine::suffix_sort_pfp(uint32_t w, uint32_t p) {
                       (unsigned long long)n);
         throw std::runtime_error(msg);
     }
-    S.bwt_ready = true;
-    lcp_col_ready_ = true;
-    e6.stop(st);
-    S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
-    S.ms[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    sort_rounds_ = S.rounds_dict;
 }
 
 // PREFIX.dict bytes: phrases in lexicographic order, 0x01 after each, final 0x00 (newscan.hpp:386-397)

@@ -1,9 +1,12 @@
 // pfp.hpp -- device state of the prefix-free-parsing producer (rows A2-A4).
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "device_utils.hpp"
 #include "parse_lcp.hpp"
+#include "guided_kernels.hpp"
+#include "pfp_kernels.hpp"
 
 namespace mmt {
 
@@ -34,6 +37,23 @@ struct PfpState {
     DevBuf<uint32_t> ghead, ce_dpos, ce_slen, occ_sl;
     uint32_t n_entries = 0, n_fallback = 0, emit_launches = 0;
     bool bwt_ready = false;
+    // the emitter between its windows (Engine::pfp_emit_window): arguments shared by every launch, the oversized groups'
+    // offsets / begin positions on the host, the BWT code of their sort keys
+    bool emit_ready = false;
+    pk::EmitArgs ea;
+    pk::BwtDecode decode{};
+    uint32_t fb_bits = 0;
+    int key_shift = 0;
+    uint64_t tiles = 0;
+    std::vector<uint64_t> h_fb_off, h_fb_start;
+    // the bucket-wise producer between its batches (guided.cpp): rank / successor tables over the phrase ends, the
+    // histogram of the suffixes' leading characters
+    gk::Ctx gctx{};
+    DevBuf<uint32_t> g_rdir;
+    DevBuf<uint64_t> g_nxt;
+    std::vector<uint64_t> g_bins;
+    int g_prefix = 0;
+    uint32_t g_nbins = 0;
 };
 
 }  // namespace mmt

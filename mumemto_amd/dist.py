@@ -170,7 +170,8 @@ def gather_bytes(local, dist, device):
 def run_sharded(eng, dist, device, **params):
     """Partial multi-MUMs / multi-MEMs (and any other mode) on several GPUs without a partition merge -- which the
     reference refuses for these modes (include/pfp_mum.hpp:178-183): every rank holds the whole collection, builds the
-    same SA / LCP / BWT stream and scans only its share of the suffix-array positions (Engine.set_scan_shard); rows
+    tables of the parse and produces, scans and drops only its share of the SA / LCP / BWT stream (Engine.set_scan_shard:
+    no column is exchanged and none is stored); rows
     come out in order of their closing position, so the ranks' .mums / .mems bytes concatenated in rank order are the
     bytes of a single-GPU run.  The only collective is the gather of those bytes.  The input must have been set on
     every rank (set_docs / set_input_device).  Returns the whole output on every rank."""
@@ -184,50 +185,17 @@ def run_sharded(eng, dist, device, **params):
     return b"".join(gather_bytes(local, dist, device))
 
 
-def exchange_columns(eng, dist, device):
-    """The pieces of the suffix-array / BWT columns a sharded suffix sort left on the ranks (Engine.set_sort_shard), each
-    broadcast from its rank into the same place of every other rank's columns.  Under RCCL the tensors are views of the
-    engine's HBM (no copy); under gloo they travel through host memory."""
-    import torch
-    pieces = eng.sort_pieces()
-    lo, hi, bw = eng.columns_device()
-    host = device.type == "cpu"
-    for r, (first, count) in enumerate(pieces):
-        if not count:
-            continue
-        for ptr, typestr, width in ((lo, "<i4", 4), (hi, "|u1", 1), (bw, "|u1", 1)):
-            if not ptr:
-                continue
-            view = torch.as_tensor(DevicePointerView(ptr + first * width, (count,), typestr), device="cuda:%d" % eng.device)
-            if host:
-                t = view.cpu()
-                dist.broadcast(t, src=r)
-                if dist.get_rank() != r:
-                    view.copy_(t)
-            else:
-                dist.broadcast(view, src=r)
-    torch.cuda.synchronize()
-
-
-def run_sort_sharded(eng, dist, device, shard_scan=True, **params):
-    """Any mode on several GPUs with the SUFFIX SORT sharded as well (suffixes bucketed by their leading
-    characters sort independently; the buckets in order are the suffix array): every rank holds the whole collection, parses
-    it, sorts its share of the buckets (the guided producer's batches), the pieces of the suffix-array and BWT columns are
-    exchanged (one broadcast per rank and column), LCP runs on every rank, the scan on its share (shard_scan), and the ranks'
-    output bytes concatenated in rank order are the bytes of one GPU.  Returns the whole output on every rank."""
-    rank, world = dist.get_rank(), dist.get_world_size()
-    eng.set_sort_shard(rank, world, after_sort=lambda: exchange_columns(eng, dist, device))
-    if shard_scan:
-        eng.set_scan_shard(rank, world)
+def run_sort_sharded(eng, dist, device, **params):
+    """The same through the bucket-wise producer (suffixes bucketed by their leading characters sort
+    independently, the buckets in order are the suffix array, and every reportable interval lies inside one bucket): a
+    rank sorts, scans and drops only the bins of its share -- its device memory holds the text, the tables of the parse
+    and one batch, whatever the size of the collection."""
+    eng.set_producer("guided")
     try:
-        eng.run(**params)
-        local = eng.output_text()
+        return run_sharded(eng, dist, device, **params)
     finally:
-        eng.set_sort_shard(0, 1)
-        eng.set_scan_shard(0, 1)
-    if not shard_scan:
-        return local
-    return b"".join(gather_bytes(local, dist, device))
+        eng.set_producer("auto")
+
 
 
 # ---- fold over anchor coordinate ranges (SURVEY.md 8(e), the reduce-scatter shape) ------------------------------------

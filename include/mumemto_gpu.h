@@ -164,6 +164,10 @@ MMT_API size_t mmt_sort_pieces(const mmt_engine* e, uint64_t* first, uint64_t* c
  * _bwt work after the run (tests, stage dumps); 0: never; -1 (default): for texts below 2^26 characters.               */
 MMT_API int mmt_engine_keep_columns(mmt_engine* e, int on);
 MMT_API int mmt_columns_kept(const mmt_engine* e);
+/* Of the last run: [0] entries of the stream this engine produced (its share of a sharded run + the left extensions of its
+ * windows), [1] bytes of the window buffers that held them (high-water mark: independent of the text length), [2] number
+ * of windows, [3] bytes of the suffix-array entries that left the windows with accepted rows.                          */
+MMT_API int mmt_stream_stats(const mmt_engine* e, uint64_t out[4]);
 /* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
 MMT_API void mmt_pool_trim(void);
 

@@ -74,6 +74,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
+    "mmt_stream_stats",
 ]
 
 
@@ -178,6 +179,7 @@ def load_library():
     L.mmt_merged_write_text.argtypes = [C.c_void_p, C.c_char_p]
     L.mmt_engine_keep_columns.argtypes = [C.c_void_p, C.c_int]
     L.mmt_columns_kept.argtypes = [C.c_void_p]
+    L.mmt_stream_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_sort_pieces.restype = C.c_size_t
     L.mmt_sort_pieces.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.mmt_merged_text.restype = C.c_void_p
@@ -475,6 +477,13 @@ class Engine:
 
     def columns_kept(self):
         return bool(self.L.mmt_columns_kept(self.h))
+
+    def stream_stats(self):
+        """Of the last run: entries of the stream this engine produced, high-water mark of its window buffers (bytes),
+        windows, bytes of the suffix-array entries kept with accepted rows."""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.mmt_stream_stats(self.h, out))
+        return {"entries": int(out[0]), "window_bytes": int(out[1]), "windows": int(out[2]), "row_entry_bytes": int(out[3])}
 
     def sort_pieces(self):
         """[(first suffix-array entry, number of entries)] per rank of the last (sharded) run."""

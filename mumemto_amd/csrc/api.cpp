@@ -478,6 +478,11 @@ int mmt_engine_keep_columns(mmt_engine* e, int on) {
     return 0;
 }
 int mmt_columns_kept(const mmt_engine* e) { return e && e->e->columns_kept() ? 1 : 0; }
+int mmt_stream_stats(const mmt_engine* e, uint64_t out[4]) {
+    if (!e) return fail(1, "null");
+    e->e->stream_stats(out);
+    return 0;
+}
 size_t mmt_sort_pieces(const mmt_engine* e, uint64_t* first, uint64_t* count, size_t capacity) {
     if (!e) return 0;
     const auto& p = e->e->sort_pieces();

@@ -347,6 +347,7 @@ void Engine::scan_begin(const mmt_params& p, ScanState& S) {
     MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, st));
     n_cand_ = 0;
     pool_used_ = 0;
+    stream_entries_ = 0; window_bytes_peak_ = 0;
     // left extension of every window but the first: at least the largest interval (+1), the window of the wide-document
     // path, one LDS halo; uncapped modes start with 64 K entries and repeat a window whose walk ran off it
     const uint64_t ALIGN_R = 4096;
@@ -512,6 +513,9 @@ void Engine::scan(const mmt_params& p) {
 void Engine::window_reserve(int set, uint64_t entries) {
     w_sa_[set].ensure(entries + 64); w_bwt_[set].ensure(entries + 64); w_lcp_[set].ensure(entries + 64);
     if (wide_) w_hi_[set].ensure(entries + 64);
+    uint64_t bytes = 0;
+    for (int k = 0; k < 2; k++) bytes += w_sa_[k].bytes() + w_bwt_[k].bytes() + w_lcp_[k].bytes() + w_hi_[k].bytes();
+    window_bytes_peak_ = std::max(window_bytes_peak_, bytes);
 }
 ColWindow Engine::window_view(int set, uint64_t base, uint32_t len, uint32_t first) const {
     ColWindow w;

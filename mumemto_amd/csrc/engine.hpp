@@ -128,6 +128,12 @@ public:
     // copy_bwt work after the run (tests, -A); 0: never; -1 (default): for texts below 2^26 characters.
     void set_keep_columns(int on) { keep_columns_ = on; }
     bool columns_kept() const { return columns_kept_; }
+    // of the last run: [0] entries of the stream this engine produced (its share + the left extensions of its windows),
+    // [1] bytes of the window buffers that held them (high-water mark), [2] windows, [3] bytes of the suffix-array entries
+    // that left with accepted rows
+    void stream_stats(uint64_t out[4]) const {
+        out[0] = stream_entries_; out[1] = window_bytes_peak_; out[2] = scan_ranges_; out[3] = pool_used_ * (wide_ ? 5 : 4);
+    }
     // The shares of the ranks of a sharded run as (first suffix-array entry, entries): ranges cut at multiples of 4096 for
     // the parse proper, whole bins of leading characters for the bucket-wise producer (guided.cpp) -- every rank derives
     // the same list.
@@ -257,6 +263,7 @@ private:
     DevBuf<uint64_t> d_cap_cnt_, d_cap_off_;
     uint64_t pool_used_ = 0;
     float emit_ms_ = 0.f;
+    uint64_t stream_entries_ = 0, window_bytes_peak_ = 0;
     uint32_t stream_min_len_ = 20;      // minimum match length of the run in progress (the bins of the bucket-wise producer)
     size_t scan_ranges_ = 1;
     DoublingSorter sorter_;

@@ -378,6 +378,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
             gk::batch_lcp(ctx, S.plcp.view(), X.pos_b.get(), B, carry.get(), have_prev, w_lcp_[set].get() + ext, S.err.get(), st);
             MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
             ee.stop(st);
+            stream_entries_ += B;
             uint64_t len = ext + B;
             ColWindow w = window_view(set, base - ext, (uint32_t)len, (uint32_t)ext);
             w.more_left = false;          // nothing an interval of this window could reach lies further left (bins)

@@ -472,6 +472,7 @@ void Engine::pfp_stream(ScanState& SS, const mmt_params& p) {
             ee.start(st);
             pfp_emit_window(b0, c1, 0);
             ee.stop(st);
+            stream_entries_ += len;
             ColWindow w = window_view(0, b0, (uint32_t)len, (uint32_t)ext);
             if (!scan_window(SS, w, p)) { ext = std::max<uint64_t>(ext * 4, SS.ext0); continue; }   // a walk ran off the extension
             if (want_anchor_ranks_) {

@@ -180,11 +180,26 @@ def _sharded_worker(rank, world, port, q, wide):
         for name, kw in (("partial", dict(num_distinct=5, max_doc_freq=3, max_total_freq=18)),
                          ("mems", dict(num_distinct=2, max_doc_freq=0, max_total_freq=40)),
                          ("strict", dict(num_distinct=0, max_doc_freq=1, max_total_freq=0))):
+            # the parse proper: a rank emits, scans and drops a range of the emitter's output
             out[name] = mdist.run_sharded(eng, dist, torch.device("cpu"), **kw)
-            # the suffix sort sharded as well: buckets of suffixes per rank, pieces of the columns exchanged
+            n = eng.text_length()
+            st = eng.stream_stats()
+            mine = eng.sort_pieces()[rank][1]
+            assert len(eng.sort_pieces()) == world and sum(c for _, c in eng.sort_pieces()) == n
+            # what the rank produced of the stream: its share + the left extensions of its windows, nothing else
+            assert mine <= st["entries"] <= mine + st["windows"] * 8192 + 4096, (st, mine)
+            assert mine <= n // world + 4096
+            assert not eng.columns_kept() or n < (1 << 26)
+            # the bucket-wise producer: a rank sorts, scans and drops whole bins of leading characters (batches of 3000)
+            os.environ["MMT_GUIDED_BATCH"] = "3000"
             out[name + "_sort"] = mdist.run_sort_sharded(eng, dist, torch.device("cpu"), **kw)
+            del os.environ["MMT_GUIDED_BATCH"]
             assert eng.producer_used() == "guided" and len(eng.sort_pieces()) == world
-            assert sum(c for _, c in eng.sort_pieces()) == eng.text_length()
+            assert sum(c for _, c in eng.sort_pieces()) == n
+            st = eng.stream_stats()
+            assert st["entries"] == eng.sort_pieces()[rank][1], "a rank of the bucket-wise producer sorts its bins and nothing else"
+            # the window buffers hold two batches (+ the tail of the batch before), whatever the text length
+            assert st["window_bytes"] < 10 * n // 4 and st["windows"] >= 2, st
         # a second collection for the sharded sort: a skewed alphabet (two thirds of the suffixes start with A: whole bins
         # make uneven pieces) and a run of one base that keeps a bin in one piece
         import numpy as np
@@ -212,9 +227,10 @@ def _sharded_worker(rank, world, port, q, wide):
 @pytest.mark.parametrize("world,wide", [(2, False), (3, False), (2, True)])
 def test_partial_and_mem_modes_sharded_over_ranks_equal_one_gpu(world, wide):
     """SURVEY 8(e) row 2 (BASELINE configs[4]): modes the anchor merge cannot serve run on several ranks by sharding
-    the suffix-array positions of the scan -- and, in the second run of every mode, the suffix sort too (buckets of
-    suffixes by their leading characters per rank, the pieces of the suffix-array / BWT columns broadcast); the
-    concatenated outputs are byte for byte the oracle's single run.  The ranks share GPU 0 under gloo (this box has one GPU)."""
+    the STREAM: a rank produces, scans and drops only its share -- a range of the emitter's output in the first run of
+    every mode, whole bins of leading characters (the bucket-wise producer) in the second -- and no
+    column is exchanged or stored; the concatenated outputs are byte for byte the oracle's single run, and what a rank
+    produced of the stream is its share (checked in the workers).  The ranks share GPU 0 under gloo (this box has one GPU)."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -259,12 +275,11 @@ assert m["text"] == O.run(docs, merge=True).text() and m["n_rows"] > 5, "strict 
 eng.set_scan_shard(0, 1)
 eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
 assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
-# the sharded suffix sort with its one piece: the callback inside run(), in-place ncclBroadcast of the three columns
-calls = []
-eng.set_sort_shard(0, 1, after_sort=lambda: (calls.append(eng.sort_pieces()), comm.exchange_columns()))
+# the bucket-wise producer with its one share
+eng.set_producer("guided")
 eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
-eng.set_sort_shard(0, 1)
-assert calls == [[(0, eng.text_length())]] and eng.producer_used() == "guided"
+eng.set_producer("auto")
+assert eng.sort_pieces() == [(0, eng.text_length())] and eng.producer_used() == "guided"
 assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
 comm.close(); eng.close()
 print("NATIVE_EXCHANGE_OK")

@@ -58,10 +58,12 @@ def test_c2_standin_at_full_size():
     import mumemto_amd
     bases, lens = _collection(16, 12_100_000, 0.005, 2)
     eng = mumemto_amd.Engine(0)
+    eng.keep_columns(True)            # (the stream is produced window by window: whole columns only when asked for)
     assert eng.run_partitioned(None, flat=(bases, lens)) == 1
-    assert not eng.is_wide()
+    assert not eng.is_wide() and eng.columns_kept()
     single = eng.output_text()
     bigchecks.check_stream(eng, bases, lens)
+    eng.keep_columns(-1)
     bigchecks.check_mum_rows(eng, bases, lens)
     parts, part = _partitioned(eng, bases, lens, 0.4)
     assert parts >= 3 and _same_up_to_the_stream_end_quirk(single, part, parts)
@@ -80,10 +82,12 @@ def test_text_beyond_2_to_the_32_as_one_suffix_array():
     import mumemto_amd
     bases, lens = _collection(36, 60_000_000, 0.002, 7)            # |T| = 4.32 G characters > 2^32
     eng = mumemto_amd.Engine(0)
+    eng.keep_columns(True)
     assert eng.run_partitioned(None, flat=(bases, lens)) == 1
     assert eng.is_wide() and eng.text_length() > 2 ** 32 and eng.scan_ranges() > 1
     single = eng.output_text()
     bigchecks.check_stream(eng, bases, lens)
+    eng.keep_columns(-1)
     bigchecks.check_mum_rows(eng, bases, lens)
     parts, part = _partitioned(eng, bases, lens, 0.4)              # partitions of < 2^32 characters: the 32-bit path
     assert parts >= 3 and not eng.is_wide()
@@ -121,6 +125,7 @@ def test_anchor_next_to_one_whole_genome_haplotype():
     import mumemto_amd
     bases, lens = _collection(2, 3_050_000_000, 0.001, 11)
     eng = mumemto_amd.Engine(0)
+    eng.keep_columns(True)
     assert eng.run_partitioned(None, flat=(bases, lens)) == 1
     assert eng.is_wide() and eng.text_length() == 4 * (3_050_000_000 + 1) and eng.producer_used() == "guided"
     bigchecks.check_stream(eng, bases, lens, light=True)

@@ -116,13 +116,15 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     e2.start(st);
     prims::exclusive_sum_u32(d_temp_, S.dlen.get(), S.dstart.get(), D, st);
     {
-        // the 32-bit prefix sum wraps silently: add the lengths up on the host when the dictionary may be that large
-        uint64_t dict_len64 = (uint64_t)read_u32(S.dstart.get() + (D - 1), st) + read_u32(S.dlen.get() + (D - 1), st) + 1;
-        if ((uint64_t)D * 2 + n / 4 >= 0xffffff00ull || W) {
-            std::vector<uint32_t> dl;
-            d2h(dl, S.dlen.get(), D, st);
-            dict_len64 = 1;
-            for (uint32_t x : dl) dict_len64 += x;
+        // the 32-bit prefix sum wraps silently: the length of the dictionary is added up in 64 bits, always
+        uint64_t dict_len64 = 0;
+        {
+            DevBuf<uint64_t> total;
+            total.ensure(1);
+            pk::sum_u32(S.dlen.get(), D, total.get(), st);
+            MMT_HIP(hipMemcpyAsync(&dict_len64, total.get(), 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+            dict_len64 += 1;                           // (the lengths count their terminators; + the final 0x00)
         }
         // Little redundancy between the documents (the anchor next to one other whole genome): the dictionary is as
         // large as half the text, and neither its 32-bit suffix array nor the tables of its suffixes fit.  The text

@@ -79,6 +79,80 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
     __syncthreads();
     if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
 }
+// The same with everything that made the first version compute-bound taken out of the per-character path (it ran at 0.4
+// TB/s on a 1 B / character stream):
+//   * the 16 + w + 1 bytes a work-item needs are four 16-byte loads (consecutive work-items on consecutive 16 bytes: fully
+//     coalesced; the overlap is served by the caches) kept in registers -- W is a template parameter, every byte index is
+//     a compile-time constant;
+//   * no 64-bit modulo: (h - out * 256^(w-1)) * 256 + in  mod prime  needs out * 256^(w-1) mod prime and
+//     (h >> 23) * 2^31 mod prime, both functions of ONE BYTE: two 256-entry tables in LDS; the rest is h < prime < 2^31
+//     arithmetic with conditional subtractions;
+//   * "h % p == 0" for the runtime modulus p = 2^e * q, q odd: the low e bits are zero and (h >> e) * q^-1 mod 2^32 <=
+//     (2^32 - 1) / q (Granlund-Montgomery divisibility test): one multiply instead of a division.
+template <int BLOCK, int W>
+__global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const uint8_t* __restrict__ text, uint64_t n, uint32_t pot,
+                                                              uint32_t pe, uint32_t qinv, uint32_t qlim,
+                                                              uint16_t* __restrict__ masks,
+                                                              uint32_t* __restrict__ block_count) {
+    constexpr int PER = 16;
+    static_assert(W >= 1 && W <= 32, "window");
+    __shared__ uint32_t s_cnt;
+    __shared__ uint32_t s_out[256], s_hi[256];
+    {
+        const uint32_t x = threadIdx.x & 255u;
+        if (threadIdx.x < 256) {
+            s_out[x] = (uint32_t)(((uint64_t)x * pot) % KR_PRIME);
+            s_hi[x] = (uint32_t)(((uint64_t)x << 31) % KR_PRIME);
+        }
+        if (threadIdx.x == 0) s_cnt = 0;
+    }
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t i0 = t * PER;
+    uint32_t mask = 0;
+    if (i0 < n) {
+        // by[32 + k] = T[i0 + k] for k = -32 .. 16 (0 before the text and from n on)
+        union { uint4 v[4]; uint8_t b[64]; } u;
+        const uint4* p4 = reinterpret_cast<const uint4*>(text + i0);
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+        u.v[0] = i0 >= 32 ? p4[-2] : zero;
+        u.v[1] = i0 >= 16 ? p4[-1] : zero;
+        u.v[2] = p4[0];                                     // (the buffer is padded behind the text)
+        u.v[3] = i0 + 16 < n ? p4[1] : zero;
+        const uint64_t left = n - i0;                       // characters of this work-item's 17 that exist
+        uint32_t h = 0;                                     // always < KR_PRIME < 2^31
+#pragma unroll
+        for (int k = 0; k < W; k++) {                       // window ending at i0
+            const uint32_t c = u.b[32 - W + 1 + k];
+            const uint32_t x = s_hi[h >> 23] + ((h & 0x7fffffu) << 8) + c;     // = h * 256 + c (mod prime), < 2.1 prime
+            const uint32_t y = x >= KR_PRIME ? x - KR_PRIME : x;
+            h = y >= KR_PRIME ? y - KR_PRIME : y;
+        }
+        const uint32_t emask = (1u << pe) - 1u;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            if ((uint64_t)q < left) {
+                const bool hit = (h & emask) == 0 && (h >> pe) * qinv <= qlim;
+                if (hit && i0 + q + 1 >= (uint64_t)W) mask |= 1u << q;
+                // roll to i + 1: drop T[i-w+1], add T[i+1]
+                const uint32_t out = u.b[32 + q - W + 1];
+                const uint32_t in = (uint64_t)(q + 1) < left ? u.b[32 + q + 1] : 0u;
+                uint32_t g = h + KR_PRIME - s_out[out];
+                g = g >= KR_PRIME ? g - KR_PRIME : g;
+                const uint32_t x = s_hi[g >> 23] + ((g & 0x7fffffu) << 8) + in;
+                const uint32_t y = x >= KR_PRIME ? x - KR_PRIME : x;
+                h = y >= KR_PRIME ? y - KR_PRIME : y;
+            }
+        }
+        masks[t] = (uint16_t)mask;
+    }
+    uint32_t c = __popc(mask);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
+}
 template <int BLOCK, typename P>
 __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restrict__ masks, uint64_t n_threads,
                                                         const uint32_t* __restrict__ block_off,
@@ -106,8 +180,26 @@ void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint
                    hipStream_t s) {
     uint64_t pot = 1;
     for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % KR_PRIME;
-    hipLaunchKernelGGL(k_trigger_masks<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, w, p, (uint32_t)pot, masks,
-                       block_count);
+    // p = 2^e * q, q odd: q^-1 mod 2^32 by Newton steps, limit (2^32 - 1) / q
+    uint32_t pe = 0, q = p;
+    while ((q & 1u) == 0) { q >>= 1; pe++; }
+    uint32_t qinv = q;                                       // correct to 3 bits
+    for (int i = 0; i < 5; i++) qinv *= 2u - q * qinv;
+    const uint32_t qlim = 0xffffffffu / q;
+    const bool fast = !getenv("MMT_TRIGGER_PLAIN") && (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
+#define MMT_TRIG(WW) hipLaunchKernelGGL((k_trigger_masks_fast<256, WW>), dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, \
+                                        (uint32_t)pot, pe, qinv, qlim, masks, block_count)
+    if (fast && w == 6) MMT_TRIG(6);
+    else if (fast && w == 10) MMT_TRIG(10);
+    else if (fast && w == 14) MMT_TRIG(14);
+    else if (fast && w == 4) MMT_TRIG(4);
+    else if (fast && w == 8) MMT_TRIG(8);
+    else if (fast && w == 12) MMT_TRIG(12);
+    else if (fast && w == 16) MMT_TRIG(16);
+    else
+        hipLaunchKernelGGL(k_trigger_masks<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, w, p, (uint32_t)pot, masks,
+                           block_count);
+#undef MMT_TRIG
     MMT_HIP(hipGetLastError());
 }
 void trigger_cuts(const uint16_t* masks, uint64_t n, const uint32_t* block_off, void* cuts, bool wide, hipStream_t s) {
@@ -309,6 +401,7 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const P* __restrict__
     const uint32_t lane = threadIdx.x & 63;
     if (wave >= n_phr) return;
     const uint32_t ph = which[wave], l = len[ph], o = dstart[wave];
+    if ((uint64_t)o + l >= (uint64_t)dict_len) return;      // (cannot happen: the caller sized the dictionary in 64 bits)
     const uint64_t a = start[ph];
     // pack_prev (fewer than 2^24 distinct phrases): the byte before each position rides in the top byte of the
     // record, so that k_entry_info needs one random read per dictionary suffix instead of two.  The byte before
@@ -334,6 +427,21 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const P* __restrict__
             if (dinfo) { uint64_t hi = wave; if (pack_prev) hi |= (uint64_t)1 << 24; dinfo[dict_len - 1] = hi << 32; }
         }
     }
+}
+// sum of 32-bit lengths in 64 bits (a 32-bit prefix sum wraps silently)
+__global__ void k_sum_u32(const uint32_t* __restrict__ x, uint32_t n, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) acc += x[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+void sum_u32(const uint32_t* x, uint32_t n, uint64_t* d_out, hipStream_t s) {
+    MMT_HIP(hipMemsetAsync(d_out, 0, 8, s));
+    if (!n) return;
+    hipLaunchKernelGGL(k_sum_u32, dim3(std::min<unsigned>(grid_for(n, 256), 4096u)), dim3(256), 0, s, x, n,
+                       reinterpret_cast<unsigned long long*>(d_out));
+    MMT_HIP(hipGetLastError());
 }
 void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,

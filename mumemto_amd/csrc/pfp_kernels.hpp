@@ -30,6 +30,8 @@ void mark_distinct(const uint32_t* order, const uint64_t* h1_sorted, const void*
                    uint32_t* flags, uint32_t* err, hipStream_t s);
 void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
                      uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
+// *d_out = x[0] + ... + x[n - 1] in 64 bits
+void sum_u32(const uint32_t* x, uint32_t n, uint64_t* d_out, hipStream_t s);
 void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
                bool pack_prev, bool wide, hipStream_t s);

@@ -108,3 +108,104 @@ def write_fasta_fast(path, bases, name="seq1", width=80):
             f.write(body.tobytes())
         if n % width:
             f.write(bases[full * width:].tobytes() + b"\n")
+
+
+_COMP_TAB = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP_TAB[_a] = _b
+
+
+def realistic_ancestor(length, seed):
+    """An ancestor with the structures real assemblies carry and i.i.d. sequence lacks (realism knobs):
+      * two alpha-satellite-like arrays: a 171-base monomer repeated over 2.3 % and 3.9 % of the length (1.5 and 2.5 Mbp
+        at 64 Mbp), every copy 1.5 % diverged from the monomer;
+      * twenty microsatellites of period 2 - 6, 10 - 100 kbp each at 64 Mbp (scaled with the length, at least 40 periods),
+        0.2 % of their bases substituted;
+      * three assembly gaps (runs of N) of 50 kbp, 200 kbp and 1 Mbp at 64 Mbp (scaled, at least 200 bases).
+    Returns (uint8 ASCII array, list of (kind, start, end))."""
+    rng = np.random.default_rng([seed, 0xA11CE])
+    anc = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    f = length / 64e6
+    feats = []
+    taken = []
+
+    def place(n):
+        n = int(min(n, length // 12))
+        for _ in range(200):
+            a = int(rng.integers(0, max(1, length - n)))
+            if all(a + n <= s or a >= e for s, e in taken):
+                taken.append((a, a + n))
+                return a, n
+        return None, 0
+
+    mono = _ACGT[rng.integers(0, 4, size=171, dtype=np.uint8)]
+    for frac in (0.023, 0.039):
+        a, n = place(max(171 * 12, int(frac * length)))
+        if a is None:
+            continue
+        arr = np.tile(mono, n // 171 + 1)[:n].copy()
+        mut = np.nonzero(rng.random(n) < 0.015)[0]
+        arr[mut] = _ACGT[rng.integers(0, 4, size=len(mut))]
+        anc[a:a + n] = arr
+        feats.append(("satellite", a, a + n))
+    for i in range(20):
+        period = 2 + i % 5
+        n = max(40 * period, int(rng.integers(10_000, 100_001) * f))
+        a, n = place(n)
+        if a is None:
+            continue
+        unit = _ACGT[rng.integers(0, 4, size=period, dtype=np.uint8)]
+        if len(set(unit.tolist())) == 1:
+            unit[0] = _ACGT[(int(np.searchsorted(_ACGT, unit[0])) + 1) & 3]
+        arr = np.tile(unit, n // period + 1)[:n].copy()
+        mut = np.nonzero(rng.random(n) < 0.002)[0]
+        arr[mut] = _ACGT[rng.integers(0, 4, size=len(mut))]
+        anc[a:a + n] = arr
+        feats.append(("microsatellite%d" % period, a, a + n))
+    for gap in (50_000, 200_000, 1_000_000):
+        a, n = place(max(200, int(gap * f)))
+        if a is None:
+            continue
+        anc[a:a + n] = ord("N")
+        feats.append(("gap", a, a + n))
+    return anc, feats
+
+
+def haplotypes_realistic(n_haps, length, divergence, seed, which=None, indel_rate=1e-4, inversion_every=7):
+    """Haplotypes of `realistic_ancestor`: substitutions at rate d (never inside a gap), indels at `indel_rate` per base
+    (half deletions, half insertions of 1 - 50 bases), and in every `inversion_every`-th haplotype one inversion of
+    0.15 % of the length.  Yields (index, uint8 ASCII array); the lengths differ between haplotypes."""
+    anc, _ = realistic_ancestor(length, seed)
+    is_n = anc == ord("N")
+    for h in (range(n_haps) if which is None else which):
+        hrng = np.random.default_rng([seed, h + 1, 0xBEE])
+        seq = anc.copy()
+        k = int(hrng.binomial(length, divergence)) if divergence > 0 else 0
+        if k:
+            pos = hrng.integers(0, length, size=k)
+            pos = pos[~is_n[pos]]
+            cur = np.searchsorted(_ACGT, seq[pos])
+            seq[pos] = _ACGT[(cur + hrng.integers(1, 4, size=len(pos))) & 3]
+        if inversion_every and h % inversion_every == inversion_every - 1:
+            n = max(50, int(0.0015 * length))
+            a = int(hrng.integers(0, length - n))
+            seq[a:a + n] = _COMP_TAB[seq[a:a + n][::-1]]
+        if indel_rate > 0:
+            kd = int(hrng.binomial(length, indel_rate / 2))
+            ki = int(hrng.binomial(length, indel_rate / 2))
+            dpos = np.unique(hrng.integers(0, length, size=kd))
+            dlen = hrng.integers(1, 51, size=len(dpos))
+            keep = np.ones(length, bool)
+            for p, l in zip(dpos.tolist(), dlen.tolist()):
+                keep[p:p + l] = False
+            seq = seq[keep]
+            ipos = np.sort(hrng.integers(0, len(seq), size=ki))
+            ilen = hrng.integers(1, 51, size=ki)
+            pieces, at = [], 0
+            for p, l in zip(ipos.tolist(), ilen.tolist()):
+                pieces.append(seq[at:p])
+                pieces.append(_ACGT[hrng.integers(0, 4, size=l)])
+                at = p
+            pieces.append(seq[at:])
+            seq = np.concatenate(pieces)
+        yield h, seq

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--pfp-p", type=int, default=0)
     ap.add_argument("--workdir", default=None, help="where the FASTA files and outputs go (default: /dev/shm or $TMPDIR)")
     ap.add_argument("--no-extras", action="store_true", help="skip the process / HBM-resident / CPU legs (N = 1)")
+    ap.add_argument("--realistic", action="store_true",
+                    help="the timed collection itself carries satellite arrays, microsatellites, assembly gaps, indels and "
+                         "inversions (synth.haplotypes_realistic) instead of i.i.d. bases with substitutions")
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
                     help="N > 1: torch.distributed collectives (default) or the C-ABI exchange of dist.cpp (mmt_dist_merge: "
@@ -128,7 +131,10 @@ def main():
     workdir, work_kind = pick_workdir(a, len(mine) * a.length * 1.02)
     paths, sample = [], []
     t_gen = time.perf_counter()
-    for h, bases in synth.haplotypes_sparse(a.haps, a.length, a.divergence, a.seed, which=mine):
+    if a.realistic:
+        a.no_extras = True                      # (the extra legs assume haplotypes of equal length)
+    gen = synth.haplotypes_realistic if a.realistic else synth.haplotypes_sparse
+    for h, bases in gen(a.haps, a.length, a.divergence, a.seed, which=mine):
         p = os.path.join(workdir, "hap%03d.fa" % h)
         synth.write_fasta_fast(p, bases, name="hap%03d" % h)
         paths.append(p)

@@ -520,12 +520,26 @@ template <typename I>
 struct LongLcpT {
     I p, q; uint32_t h;
     __device__ __forceinline__ uint64_t dst() const { return (uint64_t)p; }      // the value belongs to text position p
+    __device__ __forceinline__ uint32_t limit(I n) const {                        // the shorter suffix ends first
+        const I room = n - (p > q ? p : q);
+        return room < (I)LCP_CAP ? (uint32_t)room : LCP_CAP;
+    }
 };
 // the same with a destination of its own (LCP of adjacent parse suffixes: positions are V indices, values are stored per
 // parse position -- kernels.hpp LongLcpDst)
 struct LongLcpDstT {
     uint64_t p, q; uint32_t h, d;
     __device__ __forceinline__ uint64_t dst() const { return (uint64_t)d; }
+    __device__ __forceinline__ uint32_t limit(uint64_t n) const {
+        const uint64_t room = n - (p > q ? p : q);
+        return room < (uint64_t)LCP_CAP ? (uint32_t)room : LCP_CAP;
+    }
+};
+// ... and with a limit of its own (dictionary of the parse: a match ends at the terminator of the shorter phrase suffix)
+struct LongLcpLimT {
+    uint32_t p, q, h, lim;
+    __device__ __forceinline__ uint64_t dst() const { return (uint64_t)p; }
+    __device__ __forceinline__ uint32_t limit(uint32_t) const { return lim; }
 };
 constexpr int IRR_STEPS = 24;
 
@@ -656,7 +670,7 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict_
     if (w >= count) return;
     const I p = (I)longs[w].p, q = (I)longs[w].q;
     uint32_t h = longs[w].h;
-    const uint32_t limit = lcp_limit<I>(n, p, q);
+    const uint32_t limit = longs[w].limit(n);
     const uint32_t stop = limit - h > LONG_WAVE_MAX ? h + LONG_WAVE_MAX : limit;
     bool found = false;
     for (int step = 0; step < 8 && h < limit && !found; step++) {
@@ -696,7 +710,7 @@ __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __r
     for (uint32_t e = blockIdx.x; e < total; e += gridDim.x) {
         const R L = longs[huge_idx[e]];
         const I p = (I)L.p, q = (I)L.q;
-        const uint32_t limit = lcp_limit<I>(n, p, q);
+        const uint32_t limit = L.limit(n);
         uint32_t h = L.h;
         while (h < limit) {
             // slices past the cap (wide texts only) compare nothing: slice_mismatch clamps every offset to `limit`
@@ -849,6 +863,14 @@ static void long_lcp_typed(const uint8_t* text, uint64_t n, void* long_list, uin
     const uint32_t blocks = count < 1024u ? count : 1024u;       // the list is read on the device: no host round trip
     hipLaunchKernelGGL((k_huge_lcp<I, R>), dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, (I)n,
                        static_cast<const R*>(long_list), huge_idx, huge_count, plcp);
+}
+void long_lcp_lim(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
+                  uint32_t* huge_count, hipStream_t s) {
+    static_assert(sizeof(LongLcpLimT) == sizeof(LongLcpLim), "record layout");
+    if (!count) return;
+    MMT_HIP(hipMemsetAsync(huge_count, 0, 4, s));
+    long_lcp_typed<uint32_t, LongLcpLimT>(text, n, long_list, count, out, huge_idx, huge_count, s);
+    MMT_HIP(hipGetLastError());
 }
 void long_lcp_dst(const uint8_t* v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
                   uint32_t* huge_count, hipStream_t s) {

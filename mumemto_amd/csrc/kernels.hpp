@@ -82,6 +82,11 @@ void long_lcp(const uint8_t* text, uint64_t n, bool wide, void* long_list, uint3
 // of adjacent parse suffixes): records of (p, q, h, d) -- positions in the byte string `v` of nv bytes, h characters
 // already known to match -- leave out[d] = LCP.  huge_idx: count entries of scratch.
 struct LongLcpDst { uint64_t p, q; uint32_t h, d; };
+// ... records of (p, q, h, lim): 32-bit positions, the match cannot exceed lim characters, out[p] = LCP (the dictionary of
+// the parse: a match ends where the shorter phrase suffix ends)
+struct LongLcpLim { uint32_t p, q, h, lim; };
+void long_lcp_lim(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
+                  uint32_t* huge_count, hipStream_t s);
 void long_lcp_dst(const uint8_t* v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
                   uint32_t* huge_count, hipStream_t s);
 size_t plcp_running_max_scratch(uint64_t n);

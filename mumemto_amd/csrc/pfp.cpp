@@ -185,14 +185,43 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     if (slim) S.dinfo.release();
     S.gflag.ensure(nd); S.pflag.ensure(nd); S.vflag.ensure(nd); S.gscan.ensure(nd); S.pscan.ensure(nd);
     S.prank.ensure(D); S.parse.ensure(m);
-    pk::group_flags(S.esuf.get(), S.sa_d.get(), S.dict.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), st);
+    // LCP array of the dictionary (dictionary.hpp:133 takes it from gsacak): irreducible entries compared directly, the
+    // others by the PLCP chain along the dictionary, then gathered into suffix-array order
+    {
+        DevBuf<uint32_t> plcp_d, counts, huge;
+        DevBuf<uint8_t> longs;
+        plcp_d.ensure((size_t)nd + 16); counts.ensure(4); S.lcp_d.ensure(((size_t)nd + 3) / 4 * 4 + 16);
+        uint32_t cap = std::max<uint32_t>(nd / 256 + 4096, 1u << 16), found = 0;
+        for (int attempt = 0;; attempt++) {
+            longs.ensure((size_t)cap * sizeof(k::LongLcpLim));
+            pk::dict_irreducible(S.dict.get(), nd, S.sa_d.get(), S.esuf.get(), S.ebw.get(), plcp_d.get(), longs.get(),
+                                 counts.get(), cap, st);
+            found = read_u32(counts.get(), st);
+            if (found <= cap) break;
+            if (attempt) throw std::runtime_error("long-match list overflow in the dictionary's LCP construction");
+            cap = found + 1024;                              // rare: once more with the exact size
+        }
+        if (found) {
+            huge.ensure((size_t)found + 1);
+            k::long_lcp_lim(S.dict.get(), nd, longs.get(), found, plcp_d.get(), huge.get(), counts.get() + 1, st);
+        }
+        d_temp_.ensure(k::plcp_running_max_scratch(nd));
+        k::plcp_running_max(plcp_d.get(), nd, d_temp_.get(), st);
+        SaCol sd; sd.lo = S.sa_d.get(); sd.hi = nullptr;
+        k::lcp_gather(plcp_d.get(), sd, 0, nd, S.lcp_d.get(), st);
+        pk::dict_lcp_clamp(S.lcp_d.get(), S.esuf.get(), nd, st);
+        MMT_HIP(hipStreamSynchronize(st));
+    }
+    S.segmin.ensure(nd);
+    pk::group_flags(S.esuf.get(), S.lcp_d.get(), nd, w, S.gflag.get(), S.pflag.get(), S.vflag.get(), S.segmin.get(), st);
+    prims::inclusive_segmin_u64(d_temp_, S.segmin.get(), S.segmin.get(), nd, st);
+    if (slim) { MMT_HIP(hipStreamSynchronize(st)); S.lcp_d.release(); }
     prims::inclusive_sum_u32(d_temp_, S.gflag.get(), S.gscan.get(), nd, st);
     prims::inclusive_sum_u32(d_temp_, S.pflag.get(), S.pscan.get(), nd, st);
     pk::phrase_ranks(S.esuf.get(), S.ephr.get(), S.pscan.get(), nd, S.prank.get(), st);
     pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
-    // (the dictionary and its suffix array stay until the LCP values between the groups are known: suffix_sort_pfp)
-    if (slim) { S.pflag.release(); S.pscan.release(); }
+    if (slim) { S.pflag.release(); S.pscan.release(); S.sa_d.release(); S.dict.release(); }
     e4.stop(st);
     S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms(); S.ms[3] = e3.ms(); S.ms[4] = e4.ms();
     S.have_parse = true;
@@ -263,11 +292,11 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     const uint32_t E = S.n_entries = read_u32(S.vscan.get() + (nd - 1), st) + read_u32(S.vflag.get() + (nd - 1), st);
     pk::phrase_table(S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
     S.ce_cnt.ensure(E); S.ce_eoff.ensure(E, W); S.ce_first.ensure(E); S.ce_offm1.ensure(E); S.ce_gs.ensure(E);
-    S.ce_bwt.ensure(E); S.ce_dpos.ensure(E); S.ce_slen.ensure(E);
-    if (!S.gscan.get() || !S.sa_d.get() || !S.dict.get()) throw std::runtime_error("PFP tables released too early");
+    S.ce_bwt.ensure(E); S.ce_hl.ensure(E); S.ce_slen.ensure(E);
+    if (!S.gscan.get() || !S.segmin.get()) throw std::runtime_error("PFP tables released too early");
     pk::entry_compact(S.esuf.get(), S.ephr.get(), S.ebw.get(), S.gflag.get(), S.gscan.get(), S.vflag.get(), S.vscan.get(),
-                      S.sa_d.get(), S.ptab.get(), nd, S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(), S.ce_bwt.get(),
-                      S.ce_gs.get(), S.ce_dpos.get(), S.ce_slen.get(), st);
+                      S.segmin.get(), S.ptab.get(), nd, S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(), S.ce_bwt.get(),
+                      S.ce_gs.get(), S.ce_hl.get(), S.ce_slen.get(), st);
     offsets_from_counts(d_temp_, S.ce_cnt.get(), S.ce_eoff, E, st);
     {
         const uint64_t total = S.ce_eoff.read(E - 1, st) + read_u32(S.ce_cnt.get() + (E - 1), st);
@@ -275,7 +304,7 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     }
     if (slim) {
         S.esuf.release(); S.ephr.release(); S.ebw.release(); S.gflag.release(); S.vflag.release(); S.vscan.release();
-        S.ptab.release(); S.plen.release();
+        S.ptab.release(); S.plen.release(); S.segmin.release();
     }
     // groups of equal phrase suffixes: first entry and first output position of each
     const uint32_t G = S.n_groups;
@@ -285,10 +314,10 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     pk::gather_pos(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), W, st);
     MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &E, 4, hipMemcpyHostToDevice, st));
     S.segb.write(G, n + 1, st);
-    // per group: |alpha| and the LCP with the phrase suffix of the group before (compared in the dictionary)
+    // per group: |alpha| and the LCP with the phrase suffix of the group before (the minimum of the dictionary's LCP array)
     S.ghead.ensure((size_t)G * 2);
-    pk::group_heads(S.sege.get(), S.ce_dpos.get(), S.ce_slen.get(), S.dict.get(), G, S.ghead.get(), st);
-    if (slim) { MMT_HIP(hipStreamSynchronize(st)); S.ce_dpos.release(); S.ce_slen.release(); S.sa_d.release(); S.dict.release(); }
+    pk::group_heads(S.sege.get(), S.ce_hl.get(), S.ce_slen.get(), G, S.ghead.get(), st);
+    if (slim) { MMT_HIP(hipStreamSynchronize(st)); S.ce_hl.release(); S.ce_slen.release(); }
     // groups larger than one LDS tile of the emitter get compact slots in the fallback arrays
     S.gscan.ensure(std::max<size_t>(G, 1));
     uint32_t* osize = S.gscan.get();
@@ -434,7 +463,7 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
                 prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
                                                        nf, S.fb_rel.get(), S.fb_rel.get() + 1, S.key_shift + (int)S.fb_bits, st);
             pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), f0, f1, S.h_fb_off[f0], S.segb.get(), S.xk_b.get(),
-                                S.xv_b.get(), S.fb_bits, S.decode, text_ptr(), n_, ea, W, st);
+                                S.xv_b.get(), S.fb_bits, S.decode, text_ptr(), n_, ea, count, W, st);
         }
         t0 = t1;
     }

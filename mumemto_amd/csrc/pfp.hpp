@@ -34,7 +34,8 @@ struct PfpState {
     // LCP without a text-order column: LCP of adjacent parse suffixes (+ range minima), per group of equal phrase
     // suffixes the length of alpha and its LCP with the group before; ce_dpos / ce_slen: scratch of those
     ParseLcp plcp;
-    DevBuf<uint32_t> ghead, ce_dpos, ce_slen, occ_sl;
+    DevBuf<uint32_t> ghead, ce_hl, ce_slen, occ_sl, lcp_d;   // lcp_d: LCP array of the dictionary (suffix-array order)
+    DevBuf<uint64_t> segmin;                                // (flag, minimum of lcp_d since the valid entry before) per entry
     uint32_t n_entries = 0, n_fallback = 0, emit_launches = 0;
     bool bwt_ready = false;
     // the emitter between its windows (Engine::pfp_emit_window): arguments shared by every launch, the oversized groups'

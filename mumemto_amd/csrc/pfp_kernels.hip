@@ -17,6 +17,7 @@
 #include <string>
 
 #include "device_utils.hpp"
+#include "kernels.hpp"
 #include "pfp_kernels.hpp"
 
 namespace mmt { namespace pk {
@@ -480,47 +481,130 @@ void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict
     MMT_HIP(hipGetLastError());
 }
 
+// LCP array of the dictionary (the reference gets it from gsacak, dictionary.hpp:133; every phrase terminator is a
+// symbol of its own, so a match never runs past the end of the shorter phrase suffix) -- by the construction of the
+// text-level column (kernels.hip): entries of the dictionary's suffix array whose preceding byte differs from their
+// predecessor's are irreducible and compared directly (phrase starts always: the terminator before them is unique), every
+// other value follows from PLCP[i] = PLCP[i - 1] - 1 along the dictionary.  A trigger-free run (a gap of a megabase of N, a
+// microsatellite: one giant phrase, newscan.hpp:265-325) costs its length once, not once per suffix: comparing neighbours
+// directly took 3.8 s of a 6.9 s step on a collection with such runs (group flags + group heads) and takes 0.1 s this way.
+constexpr int DICT_IRR_STEPS = 16;
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_dict_irr(const uint8_t* __restrict__ dict, uint32_t nd,
+                                                    const uint32_t* __restrict__ sa_d, const uint32_t* __restrict__ esuf,
+                                                    const uint8_t* __restrict__ ebw, uint32_t* __restrict__ plcp,
+                                                    k::LongLcpLim* __restrict__ longs, uint32_t* __restrict__ long_count,
+                                                    uint32_t long_cap) {
+    constexpr int TILE = BLOCK * PER;
+    __shared__ uint32_t s_q[TILE];
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * TILE;
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t r = base + (uint32_t)q * BLOCK + threadIdx.x;
+        bool irr = false;
+        if (r > 0 && r < nd) {
+            const uint32_t e = esuf[r], pe = esuf[r - 1];
+            const uint32_t lim = min(e & 0x7fffffffu, pe & 0x7fffffffu);
+            // (an entry that cannot match anything keeps the cleared value 0)
+            irr = lim > 0 && ((e >> 31) || (pe >> 31) || ebw[r] != ebw[r - 1]);
+        }
+        const uint64_t m = __ballot(irr);
+        uint32_t at = 0;
+        if (lane == 0 && m) at = atomicAdd(&s_n, (uint32_t)__popcll(m));
+        at = __shfl(at, 0, 64);
+        if (irr) s_q[at + __popcll(m & ((1ull << lane) - 1))] = r - base;
+    }
+    __syncthreads();
+    const uint32_t cnt = s_n;
+    for (uint32_t wbase = 0; wbase < cnt; wbase += BLOCK) {
+        const uint32_t wi = wbase + threadIdx.x;
+        bool queue = false;
+        uint32_t p = 0, qq = 0, h = 0, lim = 0;
+        if (wi < cnt) {
+            const uint32_t r = base + s_q[wi];
+            p = sa_d[r]; qq = sa_d[r - 1];
+            lim = min(esuf[r] & 0x7fffffffu, esuf[r - 1] & 0x7fffffffu);
+            bool done = false;
+            for (int step = 0; step < DICT_IRR_STEPS && h < lim; step++) {
+                const uint64_t x = ld64(dict + p + h), y = ld64(dict + qq + h);
+                if (x != y) { h += (uint32_t)(__builtin_ctzll(x ^ y) >> 3); done = true; break; }
+                h += 8;
+            }
+            if (h >= lim) { h = lim; done = true; }
+            if (done) plcp[p] = h;
+            else queue = true;
+        }
+        const uint64_t m = __ballot(queue);
+        if (m) {
+            uint32_t slot0 = 0;
+            const int leader = __builtin_ctzll(m);
+            if ((int)lane == leader) slot0 = atomicAdd(long_count, (uint32_t)__popcll(m));
+            slot0 = __shfl(slot0, leader, 64);
+            if (queue) {
+                const uint32_t slot = slot0 + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+                if (slot < long_cap) { longs[slot].p = p; longs[slot].q = qq; longs[slot].h = h; longs[slot].lim = lim; }
+            }
+        }
+    }
+}
+void dict_irreducible(const uint8_t* dict, uint32_t nd, const uint32_t* sa_d, const uint32_t* esuf, const uint8_t* ebw,
+                      uint32_t* plcp, void* longs, uint32_t* long_count, uint32_t long_cap, hipStream_t s) {
+    constexpr int B = 256, PER = 8;
+    MMT_HIP(hipMemsetAsync(plcp, 0, (size_t)nd * 4, s));
+    MMT_HIP(hipMemsetAsync(long_count, 0, 4, s));
+    hipLaunchKernelGGL((k_dict_irr<B, PER>), dim3(grid_for(nd, B * PER)), dim3(B), 0, s, dict, nd, sa_d, esuf, ebw, plcp,
+                       static_cast<k::LongLcpLim*>(longs), long_count, long_cap);
+    MMT_HIP(hipGetLastError());
+}
+// the dictionary's PLCP values can exceed the characters a suffix has left only through the chain rule's slack: clamp
+// (lcp[r] = min(PLCP[sa_d[r]], own length, predecessor's length))
+__global__ void k_dict_lcp_clamp(uint32_t* __restrict__ lcp, const uint32_t* __restrict__ esuf, uint32_t nd) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    uint32_t v = r ? lcp[r] : 0u;
+    const uint32_t a = esuf[r] & 0x7fffffffu, b = r ? esuf[r - 1] & 0x7fffffffu : 0u;
+    v = min(v, min(a, b));
+    lcp[r] = v;
+}
+void dict_lcp_clamp(uint32_t* lcp, const uint32_t* esuf, uint32_t nd, hipStream_t s) {
+    hipLaunchKernelGGL(k_dict_lcp_clamp, dim3(grid_for(nd, 256)), dim3(256), 0, s, lcp, esuf, nd);
+    MMT_HIP(hipGetLastError());
+}
+
 // Valid = proper suffix (not the whole phrase) of length >= w (pfp_lcp_mum.hpp:272-282).  Two
-// neighbours of the dictionary SA spell the same string iff they have the same length and the same
-// characters (:141-154 collects them as `same_suffix`); only neighbours of equal length are compared,
-// 8 bytes at a time straight from the dictionary -- no LCP array of the dictionary is needed.
+// neighbours of the dictionary SA spell the same string iff they have the same length and share all of it
+// (:141-154 collects them as `same_suffix`, from lcpD like here).
 // vflag = valid, gflag = first of its group, pflag = first byte of a phrase (their order gives the
-// lexicographic phrase ranks).
-__global__ void k_group_flags(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ sa_d,
-                              const uint8_t* __restrict__ dict, uint32_t nd, uint32_t w,
+// lexicographic phrase ranks).  seg[r] = (1 << 32 when the entry before r is valid) | lcp[r]: the segmented minimum of
+// these is, at every valid entry, the LCP with the valid entry before it.
+__global__ void k_group_flags(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ lcp_d, uint32_t nd, uint32_t w,
                               uint32_t* __restrict__ gflag, uint32_t* __restrict__ pflag,
-                              uint32_t* __restrict__ vflag) {
+                              uint32_t* __restrict__ vflag, uint64_t* __restrict__ seg) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd) return;
     const uint32_t e = esuf[r];
     const uint32_t sl = e & 0x7fffffffu;
     const bool is_start = e >> 31;
     const bool valid = !is_start && sl >= w;
-    bool fresh = valid;
-    if (valid && r > 0) {
+    bool fresh = valid, pvalid = false;
+    const uint32_t l = lcp_d[r];
+    if (r > 0) {
         const uint32_t pe = esuf[r - 1];
-        const bool pvalid = !(pe >> 31) && (pe & 0x7fffffffu) >= w;
-        if (pvalid && (pe & 0x7fffffffu) == sl) {
-            const uint8_t* x = dict + sa_d[r];
-            const uint8_t* y = dict + sa_d[r - 1];
-            bool same = true;
-            uint32_t i = 0;
-            for (; i + 8 <= sl; i += 8) if (ld64(x + i) != ld64(y + i)) { same = false; break; }
-            if (same && i < sl) {                                 // last 1..7 characters (the dictionary is padded)
-                const uint64_t m = ~0ull >> (8 * (8 - (sl - i)));
-                same = ((ld64(x + i) ^ ld64(y + i)) & m) == 0;
-            }
-            if (same) fresh = false;
-        }
+        pvalid = !(pe >> 31) && (pe & 0x7fffffffu) >= w;
+        if (valid && pvalid && (pe & 0x7fffffffu) == sl && l >= sl) fresh = false;
     }
     gflag[r] = fresh ? 1u : 0u;
     pflag[r] = is_start ? 1u : 0u;
     vflag[r] = valid ? 1u : 0u;
+    seg[r] = ((uint64_t)((pvalid || r == 0) ? 1u : 0u) << 32) | (uint64_t)l;
 }
-void group_flags(const uint32_t* esuf, const uint32_t* sa_d, const uint8_t* dict, uint32_t nd, uint32_t w,
-                 uint32_t* gflag, uint32_t* pflag, uint32_t* vflag, hipStream_t s) {
-    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, sa_d, dict, nd, w, gflag, pflag,
-                       vflag);
+void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag, uint32_t* pflag,
+                 uint32_t* vflag, uint64_t* seg, hipStream_t s) {
+    hipLaunchKernelGGL(k_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, lcp_d, nd, w, gflag, pflag, vflag, seg);
     MMT_HIP(hipGetLastError());
 }
 
@@ -661,11 +745,11 @@ void phrase_table(const uint32_t* occ_start, const uint32_t* plen, const uint32_
 __global__ void k_entry_compact(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ ephr,
                                 const uint8_t* __restrict__ ebw, const uint32_t* __restrict__ gflag,
                                 const uint32_t* __restrict__ gscan, const uint32_t* __restrict__ vflag,
-                                const uint32_t* __restrict__ vscan, const uint32_t* __restrict__ sa_d,
+                                const uint32_t* __restrict__ vscan, const uint64_t* __restrict__ segmin,
                                 const uint4* __restrict__ tab, uint32_t nd,
                                 uint32_t* __restrict__ ce_cnt, uint32_t* __restrict__ ce_first,
                                 uint32_t* __restrict__ ce_offm1, uint8_t* __restrict__ ce_bwt,
-                                uint32_t* __restrict__ ce_gs, uint32_t* __restrict__ ce_dpos,
+                                uint32_t* __restrict__ ce_gs, uint32_t* __restrict__ ce_hl,
                                 uint32_t* __restrict__ ce_slen) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd || !vflag[r]) return;
@@ -677,48 +761,36 @@ __global__ void k_entry_compact(const uint32_t* __restrict__ esuf, const uint32_
     ce_offm1[c] = t.z - sl - 1;                                // offset inside the phrase, minus one
     ce_bwt[c] = ebw[r];
     ce_gs[c] = gflag[r] ? gscan[r] : 0u;                       // first entry of group g: g + 1, every other entry: 0
-    ce_dpos[c] = sa_d[r];
+    ce_hl[c] = (uint32_t)segmin[r];                             // LCP with the valid entry before (segmented minimum of lcpD)
     ce_slen[c] = sl;
 }
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
-                   const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint32_t* sa_d,
+                   const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint64_t* segmin,
                    const void* tab, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
-                   uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_dpos, uint32_t* ce_slen, hipStream_t s) {
+                   uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_hl, uint32_t* ce_slen, hipStream_t s) {
     hipLaunchKernelGGL(k_entry_compact, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, ephr, ebw, gflag, gscan, vflag,
-                       vscan, sa_d, static_cast<const uint4*>(tab), nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs, ce_dpos,
+                       vscan, segmin, static_cast<const uint4*>(tab), nd, ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs, ce_hl,
                        ce_slen);
     MMT_HIP(hipGetLastError());
 }
 
-// Per group of equal phrase suffixes: the length of alpha, and the LCP of alpha with the alpha of the group before --
-// the LCP of the first stream entry of the group (pfp_lcp_mum.hpp:176-186: between groups the reference takes the
-// minimum of lcpD; here the two strings are compared in the dictionary, they differ before the shorter one ends).
-__global__ void k_group_heads(const uint32_t* __restrict__ sege, const uint32_t* __restrict__ ce_dpos,
-                              const uint32_t* __restrict__ ce_slen, const uint8_t* __restrict__ dict, uint32_t n_groups,
-                              uint2* __restrict__ ghead) {
+// Per group of equal phrase suffixes: the length of alpha, and the LCP of alpha with the alpha of the group before -- the
+// LCP of the first stream entry of the group (pfp_lcp_mum.hpp:176-186: between groups the reference takes the minimum of
+// lcpD; so does this, through the segmented minimum that entry_compact copied to the group's first entry).
+__global__ void k_group_heads(const uint32_t* __restrict__ sege, const uint32_t* __restrict__ ce_hl,
+                              const uint32_t* __restrict__ ce_slen, uint32_t n_groups, uint2* __restrict__ ghead) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const uint32_t e = sege[g];
     const uint32_t la = ce_slen[e];
-    uint32_t h = 0;
-    if (g) {
-        const uint32_t lb = ce_slen[e - 1];
-        const uint32_t lim = la < lb ? la : lb;
-        const uint8_t* x = dict + ce_dpos[e];
-        const uint8_t* y = dict + ce_dpos[e - 1];
-        while (h < lim) {
-            const uint64_t d = ld64(x + h) ^ ld64(y + h);
-            if (d) { h += (uint32_t)(__builtin_ctzll(d) >> 3); break; }
-            h += 8;
-        }
-        if (h > lim) h = lim;
-    }
+    uint32_t h = g ? ce_hl[e] : 0u;
+    if (g) { const uint32_t lb = ce_slen[e - 1]; const uint32_t lim = la < lb ? la : lb; h = h < lim ? h : lim; }
     ghead[g] = make_uint2(la, h);
 }
-void group_heads(const uint32_t* sege, const uint32_t* ce_dpos, const uint32_t* ce_slen, const uint8_t* dict,
-                 uint32_t n_groups, void* ghead, hipStream_t s) {
-    hipLaunchKernelGGL(k_group_heads, dim3(grid_for(n_groups, 256)), dim3(256), 0, s, sege, ce_dpos, ce_slen, dict,
-                       n_groups, static_cast<uint2*>(ghead));
+void group_heads(const uint32_t* sege, const uint32_t* ce_hl, const uint32_t* ce_slen, uint32_t n_groups, void* ghead,
+                 hipStream_t s) {
+    hipLaunchKernelGGL(k_group_heads, dim3(grid_for(n_groups, 256)), dim3(256), 0, s, sege, ce_hl, ce_slen, n_groups,
+                       static_cast<uint2*>(ghead));
     MMT_HIP(hipGetLastError());
 }
 
@@ -1180,62 +1252,71 @@ void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t*
 
 // oversized groups after their segmented sort: sa / bwt / lcp from the sorted (key, position) pairs
 struct FinishLcp { uint32_t* lcp; const uint2* ghead; RmqView rmq; uint32_t w; uint64_t out_base, win_lo, win_hi; };
+// One work-item per element of the launch's fallback arrays (a group of millions of elements -- every suffix of a
+// satellite monomer in every haplotype -- used to be one workgroup's job: 0.84 s of a step); the element's group by a
+// binary search over the groups' offsets.
 template <typename P, typename SA>
 __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P* __restrict__ fb_off, uint32_t f0,
                                   uint32_t f1, P fb_base, const P* __restrict__ segb,
                                   const uint32_t* __restrict__ sorted_keys, const P* __restrict__ sorted_vals,
                                   uint32_t fb_bits, BwtDecode decode, const uint8_t* __restrict__ text, P n, SA sa,
-                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err, FinishLcp F) {
-    const uint32_t f = f0 + blockIdx.x;
-    if (f >= f1) return;
-    const uint32_t lo = (uint32_t)(fb_off[f] - fb_base), hi = (uint32_t)(fb_off[f + 1] - fb_base);
+                                  uint8_t* __restrict__ bwt, uint32_t* __restrict__ err, FinishLcp F, uint32_t total) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // group f: fb_off[f] - fb_base <= i < fb_off[f + 1] - fb_base
+    uint32_t a = f0, b = f1;                                    // answer in [a, b)
+    while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if ((uint32_t)(fb_off[mid] - fb_base) <= i) a = mid; else b = mid;
+    }
+    const uint32_t f = a;
+    const uint32_t lo = (uint32_t)(fb_off[f] - fb_base);
     const uint32_t g = fb_group[f];
     const P out0 = segb[g];
     const uint32_t mask = (1u << fb_bits) - 1u;
-    const uint32_t sl = F.ghead[g].x, hl = F.ghead[g].y;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const P p = sorted_vals[i], out = out0 + (i - lo);
-        if (out == 0 || p >= n) {                                   // the sentinel never sits in an oversized group
-            atomicAdd(err, 1u);
-            if (atomicAdd(err + (out == 0 ? 6 : 7), 1u) == 0) {
-                err[12] = (uint32_t)p; err[13] = (uint32_t)((uint64_t)p >> 32);
-                err[14] = (uint32_t)out; err[15] = (uint32_t)((uint64_t)out >> 32);
-            }
-            continue;
+    const P p = sorted_vals[i], out = out0 + (i - lo);
+    if (out == 0 || p >= n) {                                   // the sentinel never sits in an oversized group
+        atomicAdd(err, 1u);
+        if (atomicAdd(err + (out == 0 ? 6 : 7), 1u) == 0) {
+            err[12] = (uint32_t)p; err[13] = (uint32_t)((uint64_t)p >> 32);
+            err[14] = (uint32_t)out; err[15] = (uint32_t)((uint64_t)out >> 32);
         }
-        const uint64_t j = (uint64_t)out - 1;
-        if (j < F.win_lo || j >= F.win_hi) continue;
-        const uint64_t at = j - F.out_base;
-        sa.set(at, p);
-        if (fb_bits) bwt[at] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
-        else bwt[at] = p ? text[p - 1] : (uint8_t)0;
-        uint32_t v = hl;
-        if (i > lo) {
-            const uint32_t t1 = sorted_keys[i - 1] >> fb_bits, t2 = sorted_keys[i] >> fb_bits;
-            if (t1 == 0 || t2 <= t1) { atomicAdd(err, 1u); atomicAdd(err + 3, 1u); v = 0; }
-            else {
-                const uint64_t x = (uint64_t)sl - F.w + rmq_min(F.rmq, t1, t2 - 1);
-                v = x < (uint64_t)LCP_CAP ? (uint32_t)x : LCP_CAP;
-            }
-        }
-        F.lcp[at] = j == 0 ? 0u : v;
+        return;
     }
+    const uint64_t j = (uint64_t)out - 1;
+    if (j < F.win_lo || j >= F.win_hi) return;
+    const uint64_t at = j - F.out_base;
+    sa.set(at, p);
+    if (fb_bits) bwt[at] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
+    else bwt[at] = p ? text[p - 1] : (uint8_t)0;
+    const uint2 head = F.ghead[g];
+    uint32_t v = head.y;
+    if (i > lo) {
+        const uint32_t t1 = sorted_keys[i - 1] >> fb_bits, t2 = sorted_keys[i] >> fb_bits;
+        if (t1 == 0 || t2 <= t1) { atomicAdd(err, 1u); atomicAdd(err + 3, 1u); v = 0; }
+        else {
+            const uint64_t x = (uint64_t)head.x - F.w + rmq_min(F.rmq, t1, t2 - 1);
+            v = x < (uint64_t)LCP_CAP ? (uint32_t)x : LCP_CAP;
+        }
+    }
+    F.lcp[at] = j == 0 ? 0u : v;
 }
 void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
-                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, bool wide, hipStream_t s) {
-    if (f1 <= f0) return;
+                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, uint32_t total, bool wide,
+                     hipStream_t s) {
+    if (f1 <= f0 || !total) return;
     FinishLcp F{ea.lcp, static_cast<const uint2*>(ea.ghead), ea.rmq, ea.w, ea.out_base, ea.win_lo, ea.win_hi};
     if (wide)
-        hipLaunchKernelGGL((k_fallback_finish<uint64_t, Sa40>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
+        hipLaunchKernelGGL((k_fallback_finish<uint64_t, Sa40>), dim3(grid_for(total, 256)), dim3(256), 0, s, fb_group,
                            static_cast<const uint64_t*>(fb_off), f0, f1, (uint64_t)fb_base, static_cast<const uint64_t*>(segb),
                            sorted_keys, static_cast<const uint64_t*>(sorted_vals), fb_bits, decode, text, (uint64_t)n,
-                           Sa40(ea.sa), ea.bwt, ea.err, F);
+                           Sa40(ea.sa), ea.bwt, ea.err, F, total);
     else
-        hipLaunchKernelGGL((k_fallback_finish<uint32_t, Sa32>), dim3(f1 - f0), dim3(256), 0, s, fb_group,
+        hipLaunchKernelGGL((k_fallback_finish<uint32_t, Sa32>), dim3(grid_for(total, 256)), dim3(256), 0, s, fb_group,
                            static_cast<const uint32_t*>(fb_off), f0, f1, (uint32_t)fb_base, static_cast<const uint32_t*>(segb),
                            sorted_keys, static_cast<const uint32_t*>(sorted_vals), fb_bits, decode, text, (uint32_t)n,
-                           Sa32(ea.sa), ea.bwt, ea.err, F);
+                           Sa32(ea.sa), ea.bwt, ea.err, F, total);
     MMT_HIP(hipGetLastError());
 }
 

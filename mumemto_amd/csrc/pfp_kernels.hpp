@@ -37,8 +37,16 @@ void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const u
                bool pack_prev, bool wide, hipStream_t s);
 void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, bool pack_prev,
                 uint32_t* esuf, uint32_t* ephr, uint8_t* ebw, hipStream_t s);
-void group_flags(const uint32_t* esuf, const uint32_t* sa_d, const uint8_t* dict, uint32_t nd, uint32_t w,
-                 uint32_t* gflag, uint32_t* pflag, uint32_t* vflag, hipStream_t s);
+// LCP array of the dictionary in suffix-array order (every phrase terminator a symbol of its own): dict_irreducible
+// leaves plcp[position] for the irreducible entries (longs: long_cap records of k::LongLcpLim for matches beyond 128
+// characters -> k::long_lcp_lim), the caller turns plcp into PLCP (k::plcp_running_max), gathers it through sa_d
+// (k::lcp_gather) and clamps it (dict_lcp_clamp).
+void dict_irreducible(const uint8_t* dict, uint32_t nd, const uint32_t* sa_d, const uint32_t* esuf, const uint8_t* ebw,
+                      uint32_t* plcp, void* longs, uint32_t* long_count, uint32_t long_cap, hipStream_t s);
+void dict_lcp_clamp(uint32_t* lcp, const uint32_t* esuf, uint32_t nd, hipStream_t s);
+// seg[r] = (1 << 32 if the entry before r is valid, or r = 0) | lcp_d[r], to be turned into its segmented minimum
+void group_flags(const uint32_t* esuf, const uint32_t* lcp_d, uint32_t nd, uint32_t w, uint32_t* gflag, uint32_t* pflag,
+                 uint32_t* vflag, uint64_t* seg, hipStream_t s);
 void phrase_ranks(const uint32_t* esuf, const uint32_t* ephr, const uint32_t* pscan, uint32_t nd, uint32_t* prank,
                   hipStream_t s);
 // tab: n_distinct 16-byte records (phrase_table)
@@ -53,16 +61,17 @@ void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
                 uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, const uint32_t* sl, uint32_t* occ_sl, bool wide,
                 hipStream_t s);
-// gscan: inclusive sum of gflag.  ce_gs[c] = g + 1 at the first entry of group g, 0 elsewhere; ce_dpos / ce_slen: position
-// in the dictionary and length of the entry's phrase suffix (scratch of group_heads)
+// gscan: inclusive sum of gflag.  ce_gs[c] = g + 1 at the first entry of group g, 0 elsewhere; ce_hl / ce_slen: LCP with
+// the valid entry before (segmin: the segmented minimum of group_flags' seg) and length of the entry's phrase suffix
+// (scratch of group_heads)
 void entry_compact(const uint32_t* esuf, const uint32_t* ephr, const uint8_t* ebw, const uint32_t* gflag,
-                   const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint32_t* sa_d,
+                   const uint32_t* gscan, const uint32_t* vflag, const uint32_t* vscan, const uint64_t* segmin,
                    const void* tab, uint32_t nd, uint32_t* ce_cnt, uint32_t* ce_first, uint32_t* ce_offm1,
-                   uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_dpos, uint32_t* ce_slen, hipStream_t s);
+                   uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_hl, uint32_t* ce_slen, hipStream_t s);
 // ghead[g] = (length of the phrase suffix of group g, its LCP with the phrase suffix of group g - 1 -- 0 for g = 0), two
 // uint32_t per group; sege[g] = first compact entry of group g
-void group_heads(const uint32_t* sege, const uint32_t* ce_dpos, const uint32_t* ce_slen, const uint8_t* dict,
-                 uint32_t n_groups, void* ghead, hipStream_t s);
+void group_heads(const uint32_t* sege, const uint32_t* ce_hl, const uint32_t* ce_slen, uint32_t n_groups, void* ghead,
+                 hipStream_t s);
 void parse_ranks(const uint32_t* pid, const uint32_t* prank, uint32_t m, uint32_t* parse, hipStream_t s);
 void invert_ranks(const uint32_t* prank, const uint32_t* rep, const uint32_t* dlen, uint32_t n_distinct,
                   uint32_t* which, uint32_t* slen, hipStream_t s);
@@ -115,10 +124,10 @@ void oversize(const void* segb, uint32_t n_groups, uint32_t* osize, uint32_t* er
 void gather_pos(const void* src, const uint32_t* idx, uint32_t n, void* out, bool wide, hipStream_t s);
 // rel[i] = fb_off[f0 + i] - fb_off[f0], i = 0 .. count (32-bit offsets into the fallback arrays of one launch)
 void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t* rel, bool wide, hipStream_t s);
-// oversized groups [f0, f1) after their segmented sort
+// oversized groups [f0, f1) after their segmented sort (total = their elements: the used part of the fallback arrays)
 void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
-                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, bool wide,
+                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, uint32_t total, bool wide,
                      hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

@@ -111,6 +111,18 @@ void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out,
     hipLaunchKernelGGL((k_block_max_scan<BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, in, n, carry, out);
     MMT_HIP(hipGetLastError());
 }
+// segmented minimum: elements are (head flag << 32) | value; a set flag starts a new segment
+struct SegMinU64 {
+    __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const {
+        if (b >> 32) return b;
+        const uint32_t x = (uint32_t)a, y = (uint32_t)b;
+        return (a & 0xffffffff00000000ull) | (uint64_t)(y < x ? y : x);
+    }
+};
+void inclusive_segmin_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out, size_t n, hipStream_t s) {
+    if (!n) return;
+    with_temp(temp, [&](void* t, size_t& b) { return rocprim::inclusive_scan(t, b, in, out, n, SegMinU64(), s); });
+}
 void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s) {
     with_temp(temp, [&](void* t, size_t& b) {
         return rocprim::exclusive_scan(t, b, in, out, uint32_t(0), n, rocprim::plus<uint32_t>(), s);

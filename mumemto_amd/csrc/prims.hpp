@@ -18,6 +18,8 @@ bool sort_pairs_u64_u64_inplace(DevBuf<uint8_t>& temp, uint64_t* ka, uint64_t* k
                                 int begin_bit, int end_bit, hipStream_t s);
 // out may be the same array as in
 void inclusive_max_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
+// elements (head flag << 32) | value: out[i] = (flag of the segment's head, minimum of the values from that head up to i); out may be in
+void inclusive_segmin_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out, size_t n, hipStream_t s);
 void exclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
 void inclusive_sum_u32(DevBuf<uint8_t>& temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t s);
 void exclusive_sum_u32_to_u64(DevBuf<uint8_t>& temp, const uint32_t* in, uint64_t* out, size_t n, hipStream_t s);

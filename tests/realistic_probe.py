@@ -21,15 +21,15 @@ for kind in kinds:
     for rep in range(2):
         t = time.time()
         try:
-            eng.run_partitioned(None, flat=(bases, lens))
+            parts = eng.run_partitioned(None, flat=(bases, lens))
         except Exception as e:
             print(kind, "FAILED:", str(e)[:300], flush=True)
             break
         dt = time.time() - t
     else:
         out[kind] = eng.output_text()
-        print("%-7s %.2f s  producer %s  stages %s  rows %d  mem %s  pfp %s" % (
-            kind, dt, eng.producer_used(), ["%.0f" % x for x in eng.stage_ms()], out[kind].count(b"\n"),
+        print("%-7s %.2f s  partitions %d  producer %s  stages %s  rows %d  mem %s  pfp %s" % (
+            kind, dt, parts, eng.producer_used(), ["%.0f" % x for x in eng.stage_ms()], out[kind].count(b"\n"),
             {k: round(v / 2**30, 1) for k, v in eng.device_memory().items() if k != "map_seconds"}, eng.pfp_counts()), flush=True)
 ks = list(out)
 for k in ks[1:]:

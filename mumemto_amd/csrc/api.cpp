@@ -348,8 +348,7 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
             e->e->finish_input_slots(up.slot, hd.len.data(), hd.len.size());
             e->e->run_once_dropping_input(*p);
             ran = true;
-        } catch (const mmt::HipError& ex) {                    // did not fit after all: the route for any size, from the host copies
-            if (std::string(ex.what()).find("out of device memory") == std::string::npos) throw;
+        } catch (const mmt::DeviceOom&) {                      // did not fit after all: the route for any size, from the host copies
         }
     }
     if (!ran) e->e->run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), *p, max_text_chars);

@@ -364,9 +364,12 @@ int main(int argc, char** argv) {
         Engine& eng = *engine;
         // one suffix array while the text fits the device (40-bit positions beyond 2^32 characters); beyond that --
         // or beyond MUMEMTO_MAX_TEXT characters -- strict multi-MUMs run as anchor partitions + merge on this GPU
-        const uint64_t max_text = std::getenv("MUMEMTO_MAX_TEXT") ? std::strtoull(std::getenv("MUMEMTO_MAX_TEXT"), nullptr, 10)
-                                                                  : (uint64_t)(0.92 * (double)pool::available(eng.device()) / 20.0);
-        const bool partitioned = text_chars > max_text && doc_len.size() >= 3;
+        // (the same estimate as the library: Engine::auto_max_text, MUMEMTO_MAX_TEXT overrides both)
+        const bool explicit_limit = std::getenv("MUMEMTO_MAX_TEXT") || std::getenv("MMT_MAX_TEXT");
+        const uint64_t max_text = eng.auto_max_text();
+        const bool strict_mode = mum_mode && (o.num_distinct_docs == 0 || (size_t)o.num_distinct_docs == doc_len.size());
+        // modes without a partition merge are tried as one run whatever the estimate says, like the library does
+        const bool partitioned = text_chars > max_text && doc_len.size() >= 3 && (strict_mode || explicit_limit);
         if (checkpoint && partitioned) throw CliError{"-p / -a are not available for inputs larger than one suffix array", 1};
         if (checkpoint && (o.keep_temp || o.arrays_out))
             throw CliError{"-K and -A write what -p / -a read: run them without a checkpoint", 1};
@@ -400,7 +403,7 @@ int main(int argc, char** argv) {
         if (partitioned) {      // larger than one suffix array: anchor partitions + merge on this GPU
             if (o.keep_temp || o.arrays_out || (o.merge && !o.anchor_merge))
                 throw CliError{"-K, -A and -M (without -n) are not available for inputs larger than one suffix array", 1};
-            eng.run_partitioned_docs(hd.ptr.data(), doc_len.data(), doc_len.size(), p, max_text);
+            eng.run_partitioned_docs(hd.ptr.data(), doc_len.data(), doc_len.size(), p, explicit_limit ? max_text : 0);
             log_line("build_main", "text of " + std::to_string(text_chars) + " characters processed as " +
                                        std::to_string(eng.partitions_used()) + " anchor partitions");
         } else {

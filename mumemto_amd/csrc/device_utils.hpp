@@ -20,6 +20,12 @@ struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
+// the device has no room for an allocation (the device heap, or hipMalloc when the heap is switched off): the one error
+// callers react to -- a run that does not fit as one array is repeated as anchor partitions
+struct DeviceOom : HipError {
+    using HipError::HipError;
+};
+
 inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
     if (e != hipSuccess) {
         throw HipError(std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" +

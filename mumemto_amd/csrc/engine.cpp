@@ -873,7 +873,9 @@ void Engine::run(const mmt_params& p) {
     // (94 x 64 Mbp, 12 G characters: w = 14 leaves no suffix group larger than an emitter tile -- every 14-mer is
     // rare enough -- and takes 1054 ms against 1111 for 10 / 30, 1171 for 10 / 50, 1981 for 10 / 100, 1376 for 8 / 30)
     const bool big = n_ >= NARROW_LIMIT;
-    const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10), auto_p = n_ < (1ull << 30) ? 16 : 30;
+    // (parse positions are 32 bits here: beyond ~48 G characters the modulus grows so that the parse keeps below 1.6 G phrases)
+    const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10);
+    const uint32_t auto_p = n_ < (1ull << 30) ? 16 : (uint32_t)std::max<uint64_t>(30, n_ / 1600000000ull + 1);
     if (kind == 3) pfp_want_guided_ = true;
     stream_min_len_ = p.min_match_len;
     ev_[1]->start(stream_);

@@ -17,6 +17,7 @@
 // Positions are V indices (v[q], q = text position + 1; pfp_kernels.hip).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 
@@ -145,7 +146,7 @@ __device__ __forceinline__ void for_tile_keys(const Ctx& c, uint8_t* s_sym, F&& 
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = c.code[i];
     __syncthreads();
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;             // text position of the tile's first suffix
+    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE; // text position of the tile's first suffix
     const uint8_t* t = c.v + 1;
     for (uint32_t i = threadIdx.x; i < TILE + 64; i += BLOCK) {
         const uint64_t p = base + i;
@@ -164,6 +165,20 @@ __device__ __forceinline__ void for_tile_keys(const Ctx& c, uint8_t* s_sym, F&& 
     }
 }
 
+// A launch may not have 2^32 work-items: the text-order kernels of a text beyond 2^36 characters (whole genomes: the
+// anchor next to twelve haplotypes is 79 G) run as slices of 2^23 tiles, the first tile of a slice in Ctx::tile0.
+template <typename F>
+static void for_tile_slices(const Ctx& c, F&& launch) {
+    const uint64_t tiles = (c.n + TILE - 1) / TILE, SLICE = 1ull << 23;
+    for (uint64_t t0 = 0; t0 < tiles || t0 == 0; t0 += SLICE) {
+        Ctx cs = c;
+        cs.tile0 = (uint32_t)t0;
+        const uint64_t cnt = std::min<uint64_t>(SLICE, tiles > t0 ? tiles - t0 : 1);
+        launch(cs, (unsigned)cnt);
+        if (tiles <= t0 + SLICE) break;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int shift, uint64_t* __restrict__ hist) {
     __shared__ uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_hist[4096];
@@ -176,7 +191,9 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int shift, uint64_t* __
 }
 void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
     const int shift = c.bits * (c.chars - prefix_chars);
-    hipLaunchKernelGGL(k_bin_hist, dim3(grid_for(c.n, TILE)), dim3(256), 0, s, c, shift, hist);
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_bin_hist, dim3(blocks), dim3(256), 0, s, cs, shift, hist);
+    });
     MMT_HIP(hipGetLastError());
 }
 
@@ -194,11 +211,13 @@ __global__ __launch_bounds__(256) void k_batch_count(Ctx c, int shift, uint32_t 
     for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = s_cnt;
+    if (threadIdx.x == 0) tile_count[(uint64_t)blockIdx.x + c.tile0] = s_cnt;
 }
 void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s) {
     const int shift = c.bits * (c.chars - prefix_chars);
-    hipLaunchKernelGGL(k_batch_count, dim3(grid_for(c.n, TILE)), dim3(256), 0, s, c, shift, bin_lo, bin_hi, tile_count);
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_batch_count, dim3(blocks), dim3(256), 0, s, cs, shift, bin_lo, bin_hi, tile_count);
+    });
     MMT_HIP(hipGetLastError());
 }
 
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t b
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    const uint64_t first = tile_off[blockIdx.x];
+    const uint64_t first = tile_off[(uint64_t)blockIdx.x + c.tile0];
     uint32_t at = inc - cnt;
     uint32_t total = 0;
     for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
@@ -237,13 +256,15 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t b
     __syncthreads();
     // the records: phrase-end / parse-rank lookups, one selected suffix per work-item at a time (inside the loop above
     // each lookup would wait for the one before it: sixteen latencies in a row per wave)
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
     for (uint32_t i = threadIdx.x; i < total; i += 256) pos[first + i] = make_rec(c, base + s_sel[i] + 1);
 }
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
                 uint64_t* pos, hipStream_t s) {
     const int shift = c.bits * (c.chars - prefix_chars);
-    hipLaunchKernelGGL(k_batch_fill, dim3(grid_for(c.n, TILE)), dim3(256), 0, s, c, shift, bin_lo, bin_hi, tile_off, keys, pos);
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, shift, bin_lo, bin_hi, tile_off, keys, pos);
+    });
     MMT_HIP(hipGetLastError());
 }
 

@@ -33,6 +33,7 @@ struct Ctx {
     uint32_t skip;             // 0: elements are text suffixes, 1: elements are whole phrases
     uint32_t pos_bits;         // element records: position in the low pos_bits bits, above it ...
     uint32_t rec_rank;         // ... 1: the rank of the following parse suffix, 0: the length of alpha (pos_bits = 40)
+    uint32_t tile0 = 0;        // first tile of this launch (the text-order kernels run in slices of 2^23 tiles)
 };
 
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions

@@ -5,6 +5,7 @@
 // Reference behaviour restated by each kernel is cited at its definition.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include <cstdint>
@@ -665,8 +666,9 @@ __device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ t
 
 template <typename I, typename R>
 __global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict__ longs, uint32_t count,
-                           uint32_t* __restrict__ plcp, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count) {
-    const uint32_t w = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+                           uint32_t* __restrict__ plcp, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count,
+                           uint32_t first) {
+    const uint32_t w = first + (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     if (w >= count) return;
     const I p = (I)longs[w].p, q = (I)longs[w].q;
     uint32_t h = longs[w].h;
@@ -858,8 +860,12 @@ size_t long_lcp_record_bytes(bool wide) { return wide ? sizeof(LongLcpT<uint64_t
 template <typename I, typename R = LongLcpT<I>>
 static void long_lcp_typed(const uint8_t* text, uint64_t n, void* long_list, uint32_t count, uint32_t* plcp,
                            uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
-    hipLaunchKernelGGL((k_long_lcp<I, R>), dim3(grid_for((uint64_t)count * 64, 256)), dim3(256), 0, s, text, (I)n,
-                       static_cast<R*>(long_list), count, plcp, huge_idx, huge_count);
+    // (one wave per record; slices of 2^24 records: a launch may not have 2^32 work-items)
+    for (uint32_t first = 0; first < count; first += 1u << 24) {
+        const uint32_t part = std::min<uint32_t>(1u << 24, count - first);
+        hipLaunchKernelGGL((k_long_lcp<I, R>), dim3(grid_for((uint64_t)part * 64, 256)), dim3(256), 0, s, text, (I)n,
+                           static_cast<R*>(long_list), count, plcp, huge_idx, huge_count, first);
+    }
     const uint32_t blocks = count < 1024u ? count : 1024u;       // the list is read on the device: no host round trip
     hipLaunchKernelGGL((k_huge_lcp<I, R>), dim3(blocks), dim3(HUGE_WAVES * 64), 0, s, text, (I)n,
                        static_cast<const R*>(long_list), huge_idx, huge_count, plcp);

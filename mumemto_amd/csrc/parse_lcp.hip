@@ -2,6 +2,7 @@
 // range-minimum structure (the reference's s_lcp_T / rmq_s_lcp_T, include/pfp.hpp:210-244).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -198,14 +199,15 @@ void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const 
     for (int attempt = 0;; attempt++) {
         longs.ensure((size_t)cap * sizeof(k::LongLcpDst));
         MMT_HIP(hipMemsetAsync(counts.get(), 0, 4, s));
-        if (n_irreducible) {
+        for (uint32_t first = 0; first < n_irreducible; first += 1u << 27) {      // (eight lanes per pair: slices of 2^27 pairs)
+            const uint32_t part = std::min<uint32_t>(1u << 27, n_irreducible - first);
             if (wide)
-                hipLaunchKernelGGL(k_parse_cmp<uint64_t>, dim3(grid_for((uint64_t)n_irreducible * 8, 256)), dim3(256), 0, s, v, nv,
-                                   list.get(), n_irreducible, static_cast<const uint64_t*>(pstart), lirr.get(),
+                hipLaunchKernelGGL(k_parse_cmp<uint64_t>, dim3(grid_for((uint64_t)part * 8, 256)), dim3(256), 0, s, v, nv,
+                                   list.get() + first, part, static_cast<const uint64_t*>(pstart), lirr.get(),
                                    reinterpret_cast<k::LongLcpDst*>(longs.get()), counts.get(), cap);
             else
-                hipLaunchKernelGGL(k_parse_cmp<uint32_t>, dim3(grid_for((uint64_t)n_irreducible * 8, 256)), dim3(256), 0, s, v, nv,
-                                   list.get(), n_irreducible, static_cast<const uint32_t*>(pstart), lirr.get(),
+                hipLaunchKernelGGL(k_parse_cmp<uint32_t>, dim3(grid_for((uint64_t)part * 8, 256)), dim3(256), 0, s, v, nv,
+                                   list.get() + first, part, static_cast<const uint32_t*>(pstart), lirr.get(),
                                    reinterpret_cast<k::LongLcpDst*>(longs.get()), counts.get(), cap);
             MMT_HIP(hipGetLastError());
         }

@@ -24,10 +24,16 @@ namespace mmt {
 // with the dictionary, i.e. with the divergence -- or PLCP 4 + the scan range.  A single-array run that
 // still runs out of memory is repeated as partitions when the mode allows it.
 uint64_t Engine::auto_max_text() const {
-    constexpr double PEAK_BYTES_PER_CHAR = 16.0;
-    const double avail = 0.95 * (double)pool::available(device_);
-    uint64_t max_text = (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1));
-    if (const char* c = std::getenv("MMT_MAX_TEXT")) max_text = std::strtoull(c, nullptr, 10);
+    // The stream is never stored (windows of it are produced, scanned and dropped), so a run needs the text (1 byte per
+    // character), the raw bases until the text exists (0.5), the cut bits and the per-phrase tables of the parse (about
+    // 1.5 at their peak) and a fixed amount for one batch / window of the producer; when the tables of the dictionary
+    // would not fit next to that, the run takes the bucket-wise producer by itself (pfp.cpp).
+    constexpr double PEAK_BYTES_PER_CHAR = 3.0, FIXED = 24.0 * 1073741824.0;
+    const double avail = 0.95 * (double)pool::available(device_) - FIXED;
+    uint64_t max_text = avail > 0 ? (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1)) : 0;
+    // one variable for the library and the command line (MMT_MAX_TEXT: the older name)
+    for (const char* name : {"MUMEMTO_MAX_TEXT", "MMT_MAX_TEXT"})
+        if (const char* c = std::getenv(name)) { max_text = std::strtoull(c, nullptr, 10); break; }
     return max_text;
 }
 
@@ -81,9 +87,8 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             set_input_host_docs(doc_ptr, doc_len, n_docs);
             run_once_dropping_input(p);
             return;
-        } catch (const HipError& e) {
-            const bool oom = std::string(e.what()).find("out of device memory") != std::string::npos;
-            if (!oom || !strict || n_docs < 3 || !auto_limit) throw;
+        } catch (const DeviceOom&) {
+            if (!strict || n_docs < 3 || !auto_limit) throw;
             release_columns();
             d_bases_own_.release();
             max_text = total / 2;            // partitions of at most half the text, and so on below
@@ -96,9 +101,10 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     // A partition shares the device with what the sequence of partitions keeps: both input buffers (the next
     // partition is uploaded while this one runs: one byte per text character), the threshold columns (this run's, for
     // both strands; the partition's copy; the fold so far) and the scratch of a fold step -- 16 bytes per anchor base.
-    if (auto_limit && !std::getenv("MMT_MAX_TEXT")) {
-        const double budget = 0.95 * (double)pool::available(device_) - 16.0 * (double)doc_len[0];
-        const uint64_t fit = budget > 0 ? (uint64_t)(budget / 17.0) : 0;
+    // (a partition itself: its text, the tables of its parse and one batch of the producer -- auto_max_text)
+    if (auto_limit && !std::getenv("MMT_MAX_TEXT") && !std::getenv("MUMEMTO_MAX_TEXT")) {
+        const double budget = 0.95 * (double)pool::available(device_) - 16.0 * (double)doc_len[0] - 24.0 * 1073741824.0;
+        const uint64_t fit = budget > 0 ? (uint64_t)(budget / 4.0) : 0;
         max_text = std::min(max_text, std::max<uint64_t>(fit, 1));
     }
     // contiguous groups of documents 1..N-1, each together with the anchor within max_text

@@ -11,6 +11,7 @@
 // exactly the string the reference parser consumes (newscan.hpp:248, :359).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -44,12 +45,13 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restrict__ text, uint64_t n, uint32_t w,
                                                          uint32_t p, uint32_t pot,
                                                          uint16_t* __restrict__ masks,
-                                                         uint32_t* __restrict__ block_count) {
+                                                         uint32_t* __restrict__ block_count, uint32_t block0) {
     constexpr int PER = 16;
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t blk = (uint64_t)blockIdx.x + block0;
+    const uint64_t t = blk * BLOCK + threadIdx.x;
     const uint64_t i0 = t * PER;
     uint32_t mask = 0;
     if (i0 < n) {
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
     __syncthreads();
-    if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
+    if (threadIdx.x == 0) block_count[blk] = s_cnt;
 }
 // The same with everything that made the first version compute-bound taken out of the per-character path (it ran at 0.4
 // TB/s on a 1 B / character stream):
@@ -94,7 +96,7 @@ template <int BLOCK, int W>
 __global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const uint8_t* __restrict__ text, uint64_t n, uint32_t pot,
                                                               uint32_t pe, uint32_t qinv, uint32_t qlim,
                                                               uint16_t* __restrict__ masks,
-                                                              uint32_t* __restrict__ block_count) {
+                                                              uint32_t* __restrict__ block_count, uint32_t block0) {
     constexpr int PER = 16;
     static_assert(W >= 1 && W <= 32, "window");
     __shared__ uint32_t s_cnt;
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const uint8_t* __r
         if (threadIdx.x == 0) s_cnt = 0;
     }
     __syncthreads();
-    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t blk = (uint64_t)blockIdx.x + block0;
+    const uint64_t t = blk * BLOCK + threadIdx.x;
     const uint64_t i0 = t * PER;
     uint32_t mask = 0;
     if (i0 < n) {
@@ -152,14 +155,15 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const uint8_t* __r
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
     __syncthreads();
-    if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
+    if (threadIdx.x == 0) block_count[blk] = s_cnt;
 }
 template <int BLOCK, typename P>
 __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restrict__ masks, uint64_t n_threads,
                                                         const uint32_t* __restrict__ block_off,
-                                                        P* __restrict__ cuts) {
+                                                        P* __restrict__ cuts, uint32_t block0) {
     __shared__ uint32_t s_wave[BLOCK / 64];
-    const uint64_t t = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t blk = (uint64_t)blockIdx.x + block0;
+    const uint64_t t = blk * BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t mask = t < n_threads ? masks[t] : 0u;
     const uint32_t c = __popc(mask);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restri
     for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t out = block_off[blockIdx.x] + inc - c;
+    uint32_t out = block_off[blk] + inc - c;
     for (uint32_t wv = 0; wv < wave; wv++) out += s_wave[wv];
     while (mask) {
         const uint32_t b = __builtin_ctz(mask);
@@ -176,7 +180,18 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_cuts(const uint16_t* __restri
         mask &= mask - 1;
     }
 }
-uint32_t trigger_blocks(uint64_t n) { return grid_for((n + 15) / 16, 256); }
+// (workgroups of 256 work-items, 16 positions each; launched in slices of 2^23 workgroups: a launch may not have 2^32
+// work-items, and the anchor next to twelve whole-genome haplotypes is 79 G characters)
+uint32_t trigger_blocks(uint64_t n) {
+    const uint64_t b = ((n + 15) / 16 + 255) / 256;
+    if (b >= 0xffffffffull) throw HipError("text too long for the trigger pass");
+    return (uint32_t)(b ? b : 1);
+}
+template <typename F>
+static void for_trigger_slices(uint64_t n, F&& launch) {
+    const uint32_t blocks = trigger_blocks(n), SLICE = 1u << 23;
+    for (uint32_t b0 = 0; b0 < blocks; b0 += SLICE) launch(b0, std::min<uint32_t>(SLICE, blocks - b0));
+}
 void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
                    hipStream_t s) {
     uint64_t pot = 1;
@@ -188,8 +203,9 @@ void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint
     for (int i = 0; i < 5; i++) qinv *= 2u - q * qinv;
     const uint32_t qlim = 0xffffffffu / q;
     const bool fast = !getenv("MMT_TRIGGER_PLAIN") && (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
-#define MMT_TRIG(WW) hipLaunchKernelGGL((k_trigger_masks_fast<256, WW>), dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, \
-                                        (uint32_t)pot, pe, qinv, qlim, masks, block_count)
+#define MMT_TRIG(WW) for_trigger_slices(n, [&](uint32_t b0, uint32_t cnt) { \
+        hipLaunchKernelGGL((k_trigger_masks_fast<256, WW>), dim3(cnt), dim3(256), 0, s, text, n, (uint32_t)pot, pe, qinv, qlim, \
+                           masks, block_count, b0); })
     if (fast && w == 6) MMT_TRIG(6);
     else if (fast && w == 10) MMT_TRIG(10);
     else if (fast && w == 14) MMT_TRIG(14);
@@ -198,18 +214,21 @@ void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint
     else if (fast && w == 12) MMT_TRIG(12);
     else if (fast && w == 16) MMT_TRIG(16);
     else
-        hipLaunchKernelGGL(k_trigger_masks<256>, dim3(trigger_blocks(n)), dim3(256), 0, s, text, n, w, p, (uint32_t)pot, masks,
-                           block_count);
+        for_trigger_slices(n, [&](uint32_t b0, uint32_t cnt) {
+            hipLaunchKernelGGL(k_trigger_masks<256>, dim3(cnt), dim3(256), 0, s, text, n, w, p, (uint32_t)pot, masks, block_count, b0);
+        });
 #undef MMT_TRIG
     MMT_HIP(hipGetLastError());
 }
 void trigger_cuts(const uint16_t* masks, uint64_t n, const uint32_t* block_off, void* cuts, bool wide, hipStream_t s) {
-    if (wide)
-        hipLaunchKernelGGL((k_trigger_cuts<256, uint64_t>), dim3(trigger_blocks(n)), dim3(256), 0, s, masks, (n + 15) / 16,
-                           block_off, static_cast<uint64_t*>(cuts));
-    else
-        hipLaunchKernelGGL((k_trigger_cuts<256, uint32_t>), dim3(trigger_blocks(n)), dim3(256), 0, s, masks, (n + 15) / 16,
-                           block_off, static_cast<uint32_t*>(cuts));
+    for_trigger_slices(n, [&](uint32_t b0, uint32_t cnt) {
+        if (wide)
+            hipLaunchKernelGGL((k_trigger_cuts<256, uint64_t>), dim3(cnt), dim3(256), 0, s, masks, (n + 15) / 16, block_off,
+                               static_cast<uint64_t*>(cuts), b0);
+        else
+            hipLaunchKernelGGL((k_trigger_cuts<256, uint32_t>), dim3(cnt), dim3(256), 0, s, masks, (n + 15) / 16, block_off,
+                               static_cast<uint32_t*>(cuts), b0);
+    });
     MMT_HIP(hipGetLastError());
 }
 

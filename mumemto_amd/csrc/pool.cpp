@@ -163,7 +163,12 @@ void* alloc(size_t bytes) {
     Heap& H = heap_for(device);
     if (!H.vmm) {
         void* p = nullptr;
-        MMT_HIP(hipMalloc(&p, bytes));
+        const hipError_t me = hipMalloc(&p, bytes);
+        if (me == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            throw DeviceOom("out of device memory: hipMalloc of " + std::to_string(bytes >> 20) + " MiB failed");
+        }
+        MMT_HIP(me);
         return p;
     }
     const size_t need = (bytes + ALIGN - 1) / ALIGN * ALIGN;
@@ -182,7 +187,7 @@ void* alloc(size_t bytes) {
     }
     const size_t extra = ((need - have) + GROW - 1) / GROW * GROW;
     if (!grow(H, extra))
-        throw HipError("out of device memory: " + std::to_string(bytes >> 20) + " MiB requested, heap of " +
+        throw DeviceOom("out of device memory: " + std::to_string(bytes >> 20) + " MiB requested, heap of " +
                        std::to_string(H.top >> 20) + " MiB with " + std::to_string(H.live_bytes >> 20) + " MiB live");
     void* p = take(H, need);
     if (!p) throw HipError("device heap: internal error after growing");

@@ -157,11 +157,51 @@ def test_c3_standin_at_full_size_one_suffix_array():
     eng = mumemto_amd.Engine(0)
     assert eng.run_partitioned(None, flat=(bases, lens)) == 1      # strict multi-MUMs, one suffix array
     assert eng.is_wide() and eng.text_length() == 2 * haps * (64_000_000 + 1)
+    assert eng.stream_stats()["windows"] >= 40 and not eng.columns_kept()
     single = eng.output_text()
     bigchecks.check_mum_rows(eng, bases, lens)
     parts, part = _partitioned(eng, bases, lens, 0.36)
     assert parts >= 3 and _same_up_to_the_stream_end_quirk(single, part, parts)
+    # the stream through the other producer (whole bins of leading characters, sorted batch by batch: guided.cpp) and
+    # through windows a quarter the size: three independent ways of cutting the same stream into pieces that are
+    # produced, scanned and dropped -- byte for byte the same output
+    eng.set_producer("guided")
+    try:
+        assert eng.run_partitioned(None, flat=(bases, lens)) == 1 and eng.producer_used() == "guided"
+        assert eng.output_text() == single
+        assert eng.stream_stats()["windows"] >= 10
+    finally:
+        eng.set_producer("auto")
+    os.environ["MMT_SCAN_RANGE"] = str(1 << 26)
+    try:
+        assert eng.run_partitioned(None, flat=(bases, lens)) == 1 and eng.producer_used() == "pfp"
+        assert eng.output_text() == single and eng.stream_stats()["windows"] >= 170
+    finally:
+        del os.environ["MMT_SCAN_RANGE"]
     # partial multi-MEMs, the parameters of BASELINE configs[4] (-k -1 -f 3): one suffix array, no partitions possible
     assert eng.run_partitioned(None, flat=(bases, lens), num_distinct=haps - 1, max_doc_freq=3) == 1
     assert eng.is_wide()
     bigchecks.check_mem_rows(eng, bases, lens, min_docs=haps - 1, max_doc_freq=3)
+
+
+def test_thirty_g_characters_as_one_streamed_run():
+    """94 x 160 Mbp: 30.08 G text characters.  A stored stream (suffix array 5 + BWT 1 + LCP 4 bytes per character next to
+    the text and the tables of the parse: 13.6 B per character in round 2) would need 409 GB; produced, scanned and dropped
+    piece by piece (the reference does not store it either: include/pfp_lcp_mum.hpp:197) the run peaks at about half the
+    device.  The tables of this collection's dictionary do not fit next to the text, so the automatic choice is the
+    bucket-wise producer: 29 batches of whole bins of leading characters."""
+    import mumemto_amd
+    haps, length = 94, 160_000_000
+    bases = np.empty(haps * length, np.uint8)
+    for h, b in synth.haplotypes_sparse(haps, length, 0.001, 4):
+        bases[h * length:(h + 1) * length] = b
+    lens = np.full(haps, length, np.uint64)
+    eng = mumemto_amd.Engine(0)
+    assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+    assert eng.is_wide() and eng.text_length() == 2 * haps * (length + 1) > 30e9 and not eng.columns_kept()
+    st = eng.stream_stats()
+    assert st["entries"] == eng.text_length() and st["windows"] >= 20
+    # (the heap's high-water mark is per process, i.e. of every test before this one: profiles/round3_a_30G_characters_one_gpu.log
+    # has it for this run alone, 138 GB)
+    assert st["window_bytes"] < 30e9, st
+    bigchecks.check_mum_rows(eng, bases, lens)

@@ -268,6 +268,9 @@ def main():
             "haplotypes": a.haps, "bases_per_haplotype": a.length, "text_chars_per_gpu": int(n_text),
             "one_suffix_array": bool(eng.L.mmt_partitions_used(eng.h) == 1), "positions_40_bit": eng.is_wide(),
             "scan_ranges": eng.scan_ranges(),
+            "stream": "produced, scanned and dropped window by window: %d windows, %.2f GB of window buffers (the suffix "
+                      "array / BWT / LCP columns are never stored as a whole)" % (
+                          eng.stream_stats()["windows"], eng.stream_stats()["window_bytes"] / 1e9),
             "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL %s + GPU fold" % (
                 world, "broadcasts through the C ABI (mmt_dist_merge)" if a.exchange == "native" else "all-gather (torch.distributed)"),
             "timed_region": "FASTA files (page cache) -> host parse -> H2D -> GPU path -> PREFIX.mums closed; in-process "
@@ -291,11 +294,14 @@ def main():
     }
     # HBM bytes the scan kernel really moved, from the PMC passes under profiles/ (separate rocprofv3 runs of this
     # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for the default workload only
-    pmc_file = os.path.join(ROOT, "profiles", "round2_scan_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "round3_scan_pmc.json")
+    if not os.path.exists(pmc_file):
+        pmc_file = os.path.join(ROOT, "profiles", "round2_scan_pmc.json")
     if world == 1 and os.path.exists(pmc_file) and (a.haps, a.length, a.divergence, a.seed) == (94, 64_000_000, 0.001, 3):
         pmc = json.load(open(pmc_file))
         result["roofline"]["traffic"] = pmc["hbm_bytes_per_step"]
-        result["roofline"]["traffic_unit"] = "bytes per step = all k_scan launches of one pass (PMC, profiles/round2_scan_pmc.json)"
+        result["roofline"]["traffic_unit"] = ("bytes per step = all k_scan launches of one pass (PMC, profiles/%s: %s)"
+                                              % (os.path.basename(pmc_file), pmc.get("kernel", "k_scan")))
         result["roofline"]["frac_moved"] = pmc["hbm_bytes_per_step"] / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     if eng.producer_used() == "pfp":
         result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(
@@ -307,6 +313,39 @@ def main():
             cli["output_identical_to_in_process"] = subprocess.run(
                 ["cmp", "-s", os.path.join(workdir, "cli.mums"), out_file]).returncode == 0
         result["cli_process"] = cli
+    if rank == 0 and os.path.exists(out_file):
+        import hashlib
+        h = hashlib.sha256()
+        with open(out_file, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        result["config"]["output_sha256_16"] = h.hexdigest()[:16]
+    if rank == 0 and world == 1 and not a.no_extras and not a.realistic:
+        # the same collection shape with the content real assemblies carry (satellite arrays, microsatellites, assembly
+        # gaps, indels, inversions: synth.haplotypes_realistic) through the same timed region, one warm-up + one step
+        rdir = os.path.join(workdir, "realistic")
+        os.makedirs(rdir, exist_ok=True)
+        rpaths, rbp = [], 0
+        for h, bases in synth.haplotypes_realistic(a.haps, a.length, a.divergence, a.seed):
+            p = os.path.join(rdir, "hap%03d.fa" % h)
+            synth.write_fasta_fast(p, bases, name="hap%03d" % h)
+            rpaths.append(p)
+            rbp += len(bases)
+        rt = []
+        for i in range(2):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            eng.run_files(rpaths, out_prefix=os.path.join(rdir, "out"))
+            rt.append(time.perf_counter() - t0)
+        result["realistic"] = {"ms_per_step": rt[1] * 1e3, "value": rbp / rt[1] / 1e9, "unit": "Gbp/s",
+                               "ratio_to_the_iid_step": rt[1] * 1e3 / (dt / a.steps * 1e3),
+                               "content": "two satellite arrays (period 171, 2.3 % + 3.9 % of the length, 1.5 % diverged "
+                                          "copies), twenty microsatellites (period 2 - 6, 10 - 100 kbp), three runs of N "
+                                          "(50 kbp, 200 kbp, 1 Mbp), indels 1e-4 per base, an inversion in every seventh "
+                                          "haplotype; substitutions as in the i.i.d. collection",
+                               "output_rows": int(eng.L.mmt_num_rows(eng.h)), "stage_ms": [round(x, 2) for x in eng.stage_ms()],
+                               "pfp_counts": eng.pfp_counts() if eng.producer_used() == "pfp" else None}
+        shutil.rmtree(rdir, ignore_errors=True)
     if rank == 0 and world == 1 and not a.no_extras:
         # HBM-resident engine step: bases on the device before the timed region, output bytes in page-locked host
         #     memory after it (what round 1 reported as `value`)

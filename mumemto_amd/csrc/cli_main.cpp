@@ -3,6 +3,7 @@
 // .bumbl + PREFIX.lengths (+ .athresh | .thresh/.thresh_rev, + .sa/.lcp/.bwt
 // with -A) out.  All compute runs through libmumemto's GPU engine.
 #include <chrono>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
@@ -172,10 +173,11 @@ static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
         const pid_t done = wait(&st);
         if (done < 0) break;
         left--;
+        kids.erase(std::remove(kids.begin(), kids.end(), done), kids.end());     // (a reaped pid may be reused by another process)
         const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
         if (code && !rc) {                   // a rank failed: the others would wait for it in a collective for ever
             rc = code;
-            for (pid_t k : kids) if (k != done) kill(k, SIGTERM);
+            for (pid_t k : kids) kill(k, SIGTERM);
         }
     }
     std::remove(comm_file.c_str());

@@ -3,9 +3,9 @@
 // What the reference does between partitions with files and a second tool (README.md:124-141: PREFIX.mums +
 // PREFIX.athresh per partition, then `anchor_merge`, src/merge_candidates.cpp:170-255) happens here between ranks:
 // every rank has run the single-GPU path on {anchor} + its share of the documents with merge metadata on; the row
-// tables and thresholds of all ranks travel HBM -> HBM (one ncclBroadcast per rank and table, grouped: the tables are
-// ragged, an all-gather would have to pad them to the largest partition), rank 0 folds them on its GPU (merge.cpp) and
-// re-sorts into direct-run order.  For the modes without a partition merge (mmt_engine_set_scan_shard) the ranks'
+// tables and thresholds of ranks 1 .. G-1 travel HBM -> HBM to rank 0 (ncclSend / ncclRecv, one group: the tables are
+// ragged, an all-gather would pad them to the largest partition and leave copies nobody reads on every rank), rank 0
+// folds them on its GPU (merge.cpp) and re-sorts into direct-run order.  For the modes without a partition merge (mmt_engine_set_scan_shard) the ranks'
 // output bytes are gathered to rank 0 in rank order.
 //
 // RCCL is bound at run time: a process that already holds a copy (PyTorch ships its own librccl.so) must use that one,
@@ -35,6 +35,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -65,6 +67,8 @@ Rccl& rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -147,19 +151,30 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
     const std::vector<uint64_t> meta = exchange_meta(c, R.n_rows, R.n_docs, 0);
     const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
     e.rows_mum_device(&my_len, &my_off, &my_st);
-    // one broadcast per rank and table: sender = the engine's own tables, receivers = dense buffers of that rank's size
+    // Only rank 0 folds: every other rank SENDS its four tables to rank 0 (point-to-point over xGMI, one group) and keeps
+    // nothing of the others -- with a whole genome as the anchor a threshold column is 6 GB, and broadcasting every
+    // rank's to every rank (round 2) put 8 x 6 GB into each rank's HBM for nothing.  Rank 0's own tables stay where the
+    // engine has them.
     MMT_NCCL(rccl().GroupStart());
-    for (int r = 0; r < c.world; r++) {
-        const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
-        c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(L);
-        const bool mine = r == c.rank;
+    if (c.rank != 0) {
+        const size_t rows = R.n_rows, cells = rows * R.n_docs;
         if (rows) {
-            MMT_NCCL(rccl().Broadcast(mine ? (const void*)my_len : c.len[r]->get(), c.len[r]->get(), rows, ncclUint32, r, c.comm, st));
-            MMT_NCCL(rccl().Broadcast(mine ? (const void*)my_off : c.off[r]->get(), c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
-            MMT_NCCL(rccl().Broadcast(mine ? (const void*)my_st : c.st[r]->get(), c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
+            MMT_NCCL(rccl().Send(my_len, rows, ncclUint32, 0, c.comm, st));
+            MMT_NCCL(rccl().Send(my_off, cells, ncclInt64, 0, c.comm, st));
+            MMT_NCCL(rccl().Send(my_st, cells, ncclUint8, 0, c.comm, st));
         }
-        MMT_NCCL(rccl().Broadcast(mine ? (const void*)e.thresh_device() : c.th[r]->get(), c.th[r]->get(), L * 2, ncclUint8, r,
-                                  c.comm, st));
+        MMT_NCCL(rccl().Send(e.thresh_device(), L * 2, ncclUint8, 0, c.comm, st));
+    } else {
+        for (int r = 1; r < c.world; r++) {
+            const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
+            c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(L);
+            if (rows) {
+                MMT_NCCL(rccl().Recv(c.len[r]->get(), rows, ncclUint32, r, c.comm, st));
+                MMT_NCCL(rccl().Recv(c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
+                MMT_NCCL(rccl().Recv(c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
+            }
+            MMT_NCCL(rccl().Recv(c.th[r]->get(), L * 2, ncclUint8, r, c.comm, st));
+        }
     }
     MMT_NCCL(rccl().GroupEnd());
     MMT_HIP(hipStreamSynchronize(st));
@@ -168,7 +183,8 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
     for (int r = 0; r < c.world; r++) {
         mmt_partition& p = parts[(size_t)r];
         p.n_rows = meta[(size_t)r * 4]; p.n_docs = meta[(size_t)r * 4 + 1];
-        p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get();
+        if (r == 0) { p.length = my_len; p.offsets = my_off; p.strands = my_st; p.thresh = e.thresh_device(); }
+        else { p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get(); }
         p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1;
     }
     if (c.world == 1) {

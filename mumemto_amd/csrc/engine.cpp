@@ -133,8 +133,6 @@ void Engine::set_stream_host40(const uint32_t* sa_lo, const uint8_t* sa_hi, cons
     wide_ = sa_hi != nullptr;
     if (!wide_ && text_chars >= NARROW_LIMIT)
         throw std::runtime_error("a stream over " + std::to_string(text_chars) + " text characters needs 40-bit entries");
-    if (entries >= 0xffffe000ull)
-        throw std::runtime_error("a handed-over stream is scanned as one range: at most 2^32 - 8192 entries");
     for (uint64_t j = 0; j < entries; j++)
         if (((uint64_t)sa_lo[j] | (sa_hi ? (uint64_t)sa_hi[j] << 32 : 0)) >= text_chars)
             throw std::runtime_error("suffix array entry outside the text");
@@ -463,12 +461,12 @@ void Engine::scan(const mmt_params& p) {
     streamed_ = false;
     // window size: everything at once unless the text is wide (MMT_SCAN_RANGE: tests)
     const uint64_t ALIGN_R = 4096;
+    // (a handed-over stream brings its whole LCP column: windows of it are pointer offsets)
+    const bool whole_lcp = lcp_whole_ && preset_ == 2;
     uint64_t range = n;
-    if (!lcp_whole_ || preset_ != 2) {
-        if (wide_) range = 1ull << 28;
-        if (const char* c = std::getenv("MMT_SCAN_RANGE")) range = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
-        range = (range + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
-    }
+    if (wide_ || n >= 0xffffe000ull) range = 1ull << 28;
+    if (const char* c = std::getenv("MMT_SCAN_RANGE")) range = std::max<uint64_t>(1, std::strtoull(c, nullptr, 10));
+    range = (range + ALIGN_R - 1) / ALIGN_R * ALIGN_R;
     uint64_t shard_lo = 0, shard_hi = n;
     if (shard_count_ > 1) {
         if (preset_ == 2) throw std::runtime_error("a handed-over stream cannot be scanned in shards");
@@ -476,7 +474,6 @@ void Engine::scan(const mmt_params& p) {
         range = std::min<uint64_t>(range, std::max<uint64_t>(ALIGN_R, (shard_hi - shard_lo + ALIGN_R - 1) / ALIGN_R * ALIGN_R));
     }
     const bool single = range >= n && shard_count_ == 1;
-    if (single && n >= 0xffffe000ull) throw std::runtime_error("a scan range holds fewer than 2^32 - 8192 entries");
     for (uint64_t c0 = shard_lo; c0 < shard_hi; c0 += range) {
         const uint64_t c1 = std::min(shard_hi, c0 + range);
         uint64_t ext = c0 ? S.ext0 : 0;
@@ -489,6 +486,7 @@ void Engine::scan(const mmt_params& p) {
             eg.start(st);
             const uint32_t* lcp_ptr = nullptr;
             if (lcp_col_ready_) lcp_ptr = d_plcp_a_.get() + b0;          // the column exists in suffix-array order
+            else if (whole_lcp) lcp_ptr = d_lcp_.get() + b0;
             else {
                 if (!(lcp_whole_ && single)) {
                     d_lcp_.ensure(len + 16);

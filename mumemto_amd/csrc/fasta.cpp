@@ -206,10 +206,14 @@ static bool read_plain_fasta_blocks(const std::string& path, uint8_t* slot, size
 }
 
 // size of the file and whether it is gzip-compressed
+// (a FIFO / process substitution / /dev/stdin is not probed -- the probe would consume its first bytes -- and reports
+// "compressed": it then goes through the stream reader, which handles both, into a vector of its own)
 static bool file_info(const std::string& path, size_t& size) {
     struct stat st;
     size = 0;
+    if (stat(path.c_str(), &st) == 0 && !S_ISREG(st.st_mode)) return true;
     if (stat(path.c_str(), &st) == 0 && st.st_size > 0) size = (size_t)st.st_size;
+    if (size == 0) return true;                  // (an empty or unreadable file: the stream reader reports it)
     unsigned char magic[2] = {0, 0};
     if (FILE* f = std::fopen(path.c_str(), "rb")) { (void)!std::fread(magic, 1, 2, f); std::fclose(f); }
     return magic[0] == 0x1f && magic[1] == 0x8b;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -65,13 +66,14 @@ struct MergeScratch {
     DevBuf<mk::PartTable> d_parts;
     DevBuf<uint32_t> d_colpart;
 };
-// one scratch set per device (an engine on another GPU must not reuse buffers that live on the first one); the sets
-// are leaked on purpose: a static destructor would run after the HIP runtime has gone
+// one scratch set per device and host thread (an engine on another GPU must not reuse buffers that live on the first one,
+// and two engines on one GPU that merge from different threads must not share them); the sets are leaked on purpose: a
+// static destructor would run after the HIP runtime has gone
 MergeScratch& scratch(int device) {
     static std::mutex mu;
-    static std::map<int, MergeScratch*>* sets = new std::map<int, MergeScratch*>();
+    static auto* sets = new std::map<std::pair<int, std::thread::id>, MergeScratch*>();
     std::lock_guard<std::mutex> lock(mu);
-    MergeScratch*& s = (*sets)[device];
+    MergeScratch*& s = (*sets)[std::make_pair(device, std::this_thread::get_id())];
     if (!s) s = new MergeScratch();
     return *s;
 }

@@ -239,7 +239,7 @@ MMT_API int  mmt_comm_unique_id(uint8_t id[128]);
 MMT_API int  mmt_comm_create(mmt_engine* e, int rank, int world, const uint8_t id[128], mmt_comm** out);
 MMT_API void mmt_comm_destroy(mmt_comm* c);
 /* Strict multi-MUMs: e's last run = this rank's partition {anchor} + its documents with merge metadata on.  Row tables
- * and thresholds travel HBM -> HBM (one ncclBroadcast per rank and table, grouped), rank 0 folds them on its GPU and
+ * and thresholds of ranks 1 .. world-1 travel HBM -> HBM to rank 0 (ncclSend / ncclRecv, one group), rank 0 folds them on its GPU and
  * re-sorts into direct-run order: *out is the merged result on rank 0 (mmt_merged_text / _get / _free) and NULL on the
  * other ranks.  min_len = the run's -l (the reference's tool hard-codes 20).                                          */
 MMT_API int  mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** out);

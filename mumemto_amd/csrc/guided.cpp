@@ -54,13 +54,17 @@ struct RoundStats { int rounds = 0; uint64_t active_sum = 0; uint32_t first_acti
 
 // (key_a, pos_a) hold B elements with their first keys: sorts them completely; the sorted element records end up in
 // B.pos_b (suffix-array order of the batch).
-RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>& temp, uint32_t* err, hipStream_t st) {
+// lcp_out (optional, B entries, indexed like pos_b): preset to 0xffffffff here; wherever the sort separates an element
+// from its predecessor by a key of known depth or by a parse rank it leaves their LCP (gk::batch_lcp computes the rest).
+RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>& temp, uint32_t* err, hipStream_t st,
+                      uint32_t* lcp_out = nullptr, const RmqView* rmq = nullptr) {
     RoundStats rs;
     if (B == 0) return rs;
+    if (lcp_out) MMT_HIP(hipMemsetAsync(lcp_out, 0xff, (size_t)B * 4, st));
     const bool in_b = prims::sort_pairs_u64_u64_inplace(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_b.get(), B, 0,
                                                         ctx.bits * ctx.chars, st);
     if (!in_b) { X.key_a.swap(X.key_b); X.pos_a.swap(X.pos_b); }          // from here on: sorted pairs in (key_b, pos_b)
-    gk::heads0(X.key_b.get(), B, X.head.get(), X.flags.get(), st);
+    gk::heads0(X.key_b.get(), B, X.head.get(), X.flags.get(), lcp_out, ctx.bits, ctx.chars, st);
     prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), B, st);
     uint32_t m = read_u32(X.count.get(), st);
     rs.first_active = m;
@@ -81,6 +85,31 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
         }
         rs.small = m - m2;
         m = m2;
+        // ... and the groups of up to 128 elements (the copies of a position in 9 .. 128 haplotypes), one wave per group
+        if (m && !std::getenv("MMT_GUIDED_NO_MEDIUM")) {
+            // lists of (first element, size) pairs, one per size class, in key_b (dead since the first sort): m / 9 pairs at most
+            const uint32_t lcap = m / 9 + 64;
+            gk::medium_groups(X.ghead.get(), m, X.key_b.get(), lcap, X.count.get() + 4, st);
+            uint32_t ng4[4];
+            MMT_HIP(hipMemcpyAsync(ng4, X.count.get() + 4, 16, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+            const uint32_t ng = ng4[0] + ng4[1] + ng4[2] + ng4[3];
+            if (ng) {
+                MMT_HIP(hipMemsetAsync(X.flags.get(), 1, m, st));
+                gk::resolve_medium(ctx, rmq ? *rmq : RmqView(), X.pos_a.get(), X.slot_a.get(), X.key_b.get(), lcap, ng4, offset,
+                                   X.pos_b.get(), X.flags.get(), rmq ? lcp_out : nullptr, err, st);
+                prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);
+                const uint32_t m3 = read_u32(X.count.get(), st);
+                if (m3 && m3 < m) {
+                    gk::round_compact(X.idx.get(), m3, X.slot_a.get(), X.pos_a.get(), X.ghead.get(), X.slot_b.get(), X.pos_c.get(),
+                                      X.hv.get(), st);
+                    prims::inclusive_max_u32(temp, X.hv.get(), X.ghead.get(), m3, st);
+                    X.slot_a.swap(X.slot_b); X.pos_a.swap(X.pos_c);
+                }
+                rs.small += m - m3;
+                m = m3;
+            }
+        }
     }
     while (m) {
         if (++rs.rounds > (1 << 22)) throw std::runtime_error("parse-guided suffix sort did not converge");
@@ -360,11 +389,13 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
             gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
             prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
             gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
-            RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st);
-            // the window: [tail of the batch before | this batch | one virtual closing entry at the end of a rank's share]
+            // (the LCP values the sort finds on its way go straight into the window, behind the tail of the batch before)
             uint64_t ext = 0;
             if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[prev_last_bin], prev_len), capped ? SS.ext0 : ~0ull);
             if (ext > head_room) throw std::runtime_error("guided sort: window head room too small");
+            const RmqView rmq = S.plcp.view();
+            RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st, w_lcp_[set].get() + ext, &rmq);
+            // the window: [tail of the batch before | this batch | one virtual closing entry at the end of a rank's share]
             if (ext) {
                 const int o = set ^ 1;
                 const uint64_t from = prev_len - ext;

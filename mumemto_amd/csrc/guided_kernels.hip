@@ -292,18 +292,22 @@ void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* r
 }
 
 // ---- refinement rounds -------------------------------------------------------------------------------------------
+// lcp (optional, one entry per slot): where two neighbours differ in their first keys the number of leading symbols the
+// keys share IS their LCP (symbol codes are injective; `bits` per symbol, `chars` symbols per key)
 __global__ void k_heads0(const uint64_t* __restrict__ keys, uint32_t B, uint8_t* __restrict__ head,
-                         uint8_t* __restrict__ active) {
+                         uint8_t* __restrict__ active, uint32_t* __restrict__ lcp, int bits, int chars) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     const uint64_t k = keys[j];
-    const bool h = j == 0 || k != keys[j - 1];
+    const uint64_t kp = j ? keys[j - 1] : 0ull;
+    const bool h = j == 0 || k != kp;
     const bool next_h = j + 1 == B || keys[j + 1] != k;
     head[j] = h ? 1 : 0;
     active[j] = (h && next_h) ? 0 : 1;
+    if (lcp && j && h) lcp[j] = (uint32_t)((__builtin_clzll(k ^ kp) - (64 - bits * chars)) / bits);
 }
-void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, hipStream_t s) {
-    hipLaunchKernelGGL(k_heads0, dim3(grid_for(B, 256)), dim3(256), 0, s, keys, B, head, active);
+void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, uint32_t* lcp, int bits, int chars, hipStream_t s) {
+    hipLaunchKernelGGL(k_heads0, dim3(grid_for(B, 256)), dim3(256), 0, s, keys, B, head, active, lcp, bits, chars);
     MMT_HIP(hipGetLastError());
 }
 __global__ void k_gather_active(const uint32_t* __restrict__ idx, uint32_t m, const uint64_t* __restrict__ pos_sorted,
@@ -435,6 +439,219 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
 void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
                    uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_small, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, slot, m, offset, out, flags, err);
+    MMT_HIP(hipGetLastError());
+}
+
+// Groups of SMALL < size <= MEDIUM elements -- the copies of one position in 9 .. 128 haplotypes -- are finished in one
+// step as well: one wave per group stages, for every member, the next 64 characters behind the shared prefix, the length
+// of its alpha and its parse rank in LDS, and every member counts the members that sort before it from there (the
+// refinement rounds took 2.4 - 3.2 passes over such elements: 63 bits of alpha per round, then the parse ranks).  A group
+// in which two members still agree after those 64 characters with alpha not yet spent is left to the rounds.
+constexpr uint32_t MEDIUM = 128, MED_WORDS = 8;
+// size classes of the medium groups: a wave takes 4 groups of <= 16, 2 of <= 32, 1 of <= 64 or 1 of <= 128 elements
+__device__ __forceinline__ uint32_t medium_class(uint32_t size) { return size <= 16 ? 0u : (size <= 32 ? 1u : (size <= 64 ? 2u : 3u)); }
+template <int BLOCK, int PER>
+__global__ __launch_bounds__(BLOCK) void k_medium_groups(const uint32_t* __restrict__ ghead, uint32_t m, uint2* __restrict__ list,
+                                                         uint32_t cap, uint32_t* __restrict__ count) {
+    // the LAST element of a group knows the group's size (no loop over the members); one list-slot allocation per
+    // workgroup and class (a counter word takes ~150 atomics per microsecond: one per wave was 110 ms per batch)
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint32_t s_base[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t first[PER], size[PER], at[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t e = (blockIdx.x * PER + k) * BLOCK + threadIdx.x;
+        first[k] = 0; size[k] = 0; at[k] = 0;
+        if (e < m) {
+            const uint32_t f = ghead[e];
+            if (e + 1 == m || ghead[e + 1] != f) {
+                const uint32_t sz = e - f + 1;
+                if (sz <= MEDIUM) { first[k] = f; size[k] = sz; at[k] = atomicAdd(&s_cnt[medium_class(sz)], 1u); }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(count + threadIdx.x, s_cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (size[k]) {
+            const uint32_t cl = medium_class(size[k]);
+            list[(size_t)cl * cap + s_base[cl] + at[k]] = make_uint2(first[k], size[k]);
+        }
+}
+void medium_groups(const uint32_t* ghead, uint32_t m, void* list, uint32_t cap, uint32_t* count4, hipStream_t s) {
+    MMT_HIP(hipMemsetAsync(count4, 0, 16, s));
+    hipLaunchKernelGGL((k_medium_groups<256, 4>), dim3(grid_for(m, 1024)), dim3(256), 0, s, ghead, m, static_cast<uint2*>(list), cap,
+                       count4);
+    MMT_HIP(hipGetLastError());
+}
+
+// the staged members of the groups one wave works on (W = 64 or 128 members)
+template <int W>
+struct MedStage {
+    uint64_t w[W][MED_WORDS];
+    uint64_t rank[W];
+    uint64_t rec[W];
+    uint32_t len[W];
+    uint8_t idx[W];
+    uint32_t bad;
+};
+// Order of two staged members (true: a sorts before b).  What the staged characters do not decide -- both alphas longer
+// than what was staged and equal so far -- is compared in the text itself.  *lcp (optional) receives the number of
+// characters the two suffixes share when the order was decided by a character; ~0 when they spell the same alpha.
+template <int W>
+__device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_t a, uint32_t b, uint64_t offset, uint64_t* lcp) {
+    const uint64_t la = S.len[a], lb = S.len[b];
+    const uint64_t L = la < lb ? la : lb;
+    if (lcp) *lcp = ~0ull;
+#pragma unroll
+    for (uint32_t t = 0; t < MED_WORDS; t++) {
+        const uint64_t at = offset + 8 * t;
+        if (at >= L) break;                                  // alpha of the shorter one is spent: same phrase suffix
+        const uint64_t x = S.w[a][t], y = S.w[b][t];
+        if (x != y) {
+            const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+            if (at + d < L) { if (lcp) *lcp = at + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff); }
+            break;
+        }
+        if (t + 1 == MED_WORDS && at + 8 < L) {              // (rare: alphas beyond the staged characters)
+            const uint64_t qa = rec_pos(c, S.rec[a]), qb = rec_pos(c, S.rec[b]);
+            for (uint64_t u = at + 8; u < L; u += 8) {
+                const uint64_t x2 = load_u64(c.v + qa + u), y2 = load_u64(c.v + qb + u);
+                if (x2 != y2) {
+                    const uint32_t d2 = (uint32_t)__builtin_ctzll(x2 ^ y2) >> 3;
+                    if (u + d2 < L) { if (lcp) *lcp = u + d2; return ((x2 >> (8 * d2)) & 0xff) < ((y2 >> (8 * d2)) & 0xff); }
+                    break;
+                }
+            }
+        }
+    }
+    if (la != lb || c.skip) S.bad = 1;
+    if (c.skip) return a < b;
+    const uint64_t ra = S.rank[a], rb = S.rank[b];
+    return ra < rb || (ra == rb && a < b);
+}
+// SEG = slots per group (16 / 32 / 64 / 128), W = members per wave (64, or 128 with two per lane): W / SEG groups per wave
+template <int SEG, int W>
+__global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const uint64_t* __restrict__ pos,
+                                                        const uint32_t* __restrict__ slot, const uint2* __restrict__ list,
+                                                        uint32_t n_groups, uint64_t offset, uint64_t* __restrict__ out,
+                                                        uint8_t* __restrict__ flags, uint32_t* __restrict__ lcp_out,
+                                                        uint32_t* __restrict__ err) {
+    constexpr int PERL = W / 64, GPW = W / SEG;              // members per lane, groups per wave
+    __shared__ MedStage<W> s_st[4];
+    __shared__ uint32_t s_g0[4][GPW], s_g[4][GPW];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    MedStage<W>& S = s_st[wave];
+    const uint64_t gw = ((uint64_t)blockIdx.x * 4 + wave) * GPW;     // first group of this wave
+    if (lane < (uint32_t)GPW) {
+        const bool have = gw + lane < n_groups;
+        const uint2 grp = have ? list[gw + lane] : make_uint2(0u, 0u);
+        s_g0[wave][lane] = grp.x; s_g[wave][lane] = have ? grp.y : 0u;
+    }
+    if (lane == 0) S.bad = 0;
+#define MMT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    MMT_WAVE_SYNC();
+#pragma unroll
+    for (int h = 0; h < PERL; h++) {
+        const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
+        S.idx[i] = (uint8_t)i;
+        if (mem < s_g[wave][seg]) {
+            const uint64_t rec = pos[s_g0[wave][seg] + mem];
+            const uint64_t q = rec_pos(c, rec);
+#pragma unroll
+            for (uint32_t t = 0; t < MED_WORDS; t++) S.w[i][t] = load_u64(c.v + q + offset + 8 * t);
+            const uint64_t len = rec_len(c, rec, q);
+            S.len[i] = len < 0xffffffffull ? (uint32_t)len : 0xffffffffu;
+            S.rank[i] = c.skip ? 0ull : rec_rank_key(c, rec, q);
+            S.rec[i] = rec;
+        }
+    }
+    // (a wave works on its own stage: ordering its LDS traffic inside the wave is all the synchronisation there is)
+    MMT_WAVE_SYNC();
+    // bitonic network over the SEG index slots of every group (members beyond the group sort last): log^2 steps of
+    // compare-exchanges instead of g^2 / 2 comparisons
+    for (uint32_t k = 2; k <= (uint32_t)SEG; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            bool swap[PERL];
+            uint32_t a[PERL], b[PERL], lo[PERL];
+#pragma unroll
+            for (int h = 0; h < PERL; h++) {
+                // pair number p of the wave (W / 2 pairs per step): its group, its place inside the group
+                const uint32_t p = lane + 64 * h;
+                swap[h] = false; a[h] = b[h] = lo[h] = 0;
+                if (p < (uint32_t)W / 2) {
+                    const uint32_t seg = p / (SEG / 2), pl = p % (SEG / 2);
+                    const uint32_t ll = ((pl & ~(j - 1)) << 1) | (pl & (j - 1));
+                    lo[h] = seg * SEG + ll;
+                    const uint32_t g = s_g[wave][seg];
+                    // (a group of at most k / 2 ... elements is sorted after fewer stages; the extra ones are no-ops on sorted data)
+                    if (g > 1) {
+                        const bool up = (ll & k) == 0;
+                        a[h] = S.idx[lo[h]]; b[h] = S.idx[lo[h] | j];
+                        const bool a_in = a[h] % SEG < g, b_in = b[h] % SEG < g;
+                        bool a_first;                                // a sorts before b
+                        if (a_in && b_in) a_first = med_before<W>(c, S, a[h], b[h], offset, nullptr);
+                        else a_first = a_in || (!b_in && a[h] < b[h]);
+                        swap[h] = up ? !a_first : a_first;
+                    }
+                }
+            }
+            MMT_WAVE_SYNC();
+#pragma unroll
+            for (int h = 0; h < PERL; h++)
+                if (swap[h]) { S.idx[lo[h]] = (uint8_t)b[h]; S.idx[lo[h] | j] = (uint8_t)a[h]; }
+            MMT_WAVE_SYNC();
+        }
+    }
+#undef MMT_WAVE_SYNC
+    if (S.bad && lane == 0) atomicAdd(err + (c.skip ? 0 : 1), 1u);
+#pragma unroll
+    for (int h = 0; h < PERL; h++) {
+        const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
+        const uint32_t g = s_g[wave][seg], g0 = s_g0[wave][seg];
+        if (mem >= g) continue;
+        const uint32_t me = S.idx[i];
+        const uint32_t at = slot[g0] + mem;
+        out[at] = S.rec[me];
+        flags[g0 + mem] = 0;
+        if (lcp_out && mem > 0) {
+            // LCP with the member before: decided by a character, or the same alpha and the parse ranks
+            const uint32_t pr = S.idx[i - 1];
+            uint64_t l = ~0ull;
+            (void)med_before<W>(c, S, pr, me, offset, &l);
+            if (l == ~0ull) {
+                const uint64_t ra = S.rank[pr], rb = S.rank[me];
+                l = rb > ra ? (uint64_t)S.len[me] - c.w + rmq_min(R, (uint32_t)ra + 1, (uint32_t)rb) : (uint64_t)S.len[me];
+            }
+            lcp_out[at] = l < (uint64_t)LCP_CAP ? (uint32_t)l : LCP_CAP;
+        }
+    }
+}
+template <int SEG, int W>
+static void resolve_medium_class(const Ctx& c, const RmqView& R, const uint64_t* pos, const uint32_t* slot, const uint2* list,
+                                 uint32_t n_groups, uint64_t offset, uint64_t* out, uint8_t* flags, uint32_t* lcp_out, uint32_t* err,
+                                 hipStream_t s) {
+    constexpr uint32_t GPW = W / SEG;
+    // (slices of 2^24 waves: a launch may not have 2^32 work-items)
+    for (uint32_t first = 0; first < n_groups; first += GPW << 24) {
+        const uint32_t part = std::min<uint32_t>(GPW << 24, n_groups - first);
+        const uint64_t waves = (part + GPW - 1) / GPW;
+        hipLaunchKernelGGL((k_resolve_medium<SEG, W>), dim3(grid_for(waves * 64, 256)), dim3(256), 0, s, c, R, pos, slot, list + first,
+                           part, offset, out, flags, lcp_out, err);
+    }
+}
+void resolve_medium(const Ctx& c, const RmqView& R, const uint64_t* pos, const uint32_t* slot, const void* list, uint32_t cap,
+                    const uint32_t n_groups[4], uint64_t offset, uint64_t* out, uint8_t* flags, uint32_t* lcp_out, uint32_t* err,
+                    hipStream_t s) {
+    const uint2* l = static_cast<const uint2*>(list);
+    if (n_groups[0]) resolve_medium_class<16, 64>(c, R, pos, slot, l, n_groups[0], offset, out, flags, lcp_out, err, s);
+    if (n_groups[1]) resolve_medium_class<32, 64>(c, R, pos, slot, l + (size_t)cap, n_groups[1], offset, out, flags, lcp_out, err, s);
+    if (n_groups[2]) resolve_medium_class<64, 64>(c, R, pos, slot, l + (size_t)2 * cap, n_groups[2], offset, out, flags, lcp_out, err, s);
+    if (n_groups[3]) resolve_medium_class<128, 128>(c, R, pos, slot, l + (size_t)3 * cap, n_groups[3], offset, out, flags, lcp_out, err, s);
     MMT_HIP(hipGetLastError());
 }
 
@@ -653,6 +870,7 @@ __global__ void k_batch_lcp(Ctx c, RmqView R, const uint64_t* __restrict__ pos, 
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
     if (j == 0 && !have_carry) { lcp[0] = 0; return; }
+    if (lcp[j] != 0xffffffffu) return;                       // known since the sort separated the two (heads0, k_resolve_medium)
     const uint64_t ra = pos[j], rb = j ? pos[j - 1] : carry[0];
     const uint64_t qa = rec_pos(c, ra), qb = rec_pos(c, rb);
     const uint64_t la = rec_len(c, ra, qa), lb = rec_len(c, rb, qb);

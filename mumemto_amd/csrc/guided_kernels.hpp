@@ -51,13 +51,21 @@ void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* r
                   uint64_t* pos, hipStream_t s);
 
 // after the first sort: head[j] = 1 where a new key starts, active[j] = 1 inside groups of two or more
-void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, hipStream_t s);
+// lcp (optional, B entries): the LCP of a slot with the slot before it where their first keys differ
+void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, uint32_t* lcp, int bits, int chars, hipStream_t s);
 void gather_active(const uint32_t* idx, uint32_t m, const uint64_t* pos_sorted, const uint8_t* head, uint32_t* slot,
                    uint64_t* pos, uint32_t* headval, hipStream_t s);
 void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s);
 // groups of at most 8 elements, finished by direct comparison (their sorted records go to `out` at the group's slots)
 void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
                    uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s);
+// groups of 9 .. 128 elements, in four size classes (<= 16, 32, 64, 128): list = 4 regions of `cap` (first element, size)
+// pairs (uint2), count4 = 4 counters; then 4 / 2 / 1 / 1 groups per wave; flags must be preset to 1 (elements of larger
+// groups keep it); lcp_out (optional, indexed by slot): the LCP of every member but the first with the member before it
+void medium_groups(const uint32_t* ghead, uint32_t m, void* list, uint32_t cap, uint32_t* count4, hipStream_t s);
+void resolve_medium(const Ctx& c, const RmqView& R, const uint64_t* pos, const uint32_t* slot, const void* list, uint32_t cap,
+                    const uint32_t n_groups[4], uint64_t offset, uint64_t* out, uint8_t* flags, uint32_t* lcp_out, uint32_t* err,
+                    hipStream_t s);
 void tile_bounds(const uint32_t* ghead, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles, uint32_t* bound,
                  hipStream_t s);
 // sorts every tile that fits LDS by (group, key); lists the others (big_*) and copies them through unsorted
@@ -76,7 +84,8 @@ void range_groups(const uint32_t* ghead, uint32_t begin, uint32_t end, uint32_t*
 
 // sorted batch -> suffix array and BWT columns at [base, base + B)
 void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base, SaCol sa, uint8_t* bwt, hipStream_t s);
-// sorted batch -> its piece of the LCP column (lcp[j] for element j); carry[0] = last element record of the batch before
+// sorted batch -> its piece of the LCP column (lcp[j] for element j; entries that are not 0xffffffff were filled in by the
+// sort and are kept); carry[0] = last element record of the batch before
 // (have_carry = false: the batch starts the suffix array, lcp[0] = 0); err[2] counts pairs that are equal up to the end
 // of alpha without being ordered by their parse ranks
 void batch_lcp(const Ctx& c, const RmqView& R, const uint64_t* pos, uint32_t B, const uint64_t* carry, bool have_carry,

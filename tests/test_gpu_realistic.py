@@ -45,3 +45,28 @@ def test_realistic_content_equals_the_oracle(producer):
     finally:
         os.environ.pop("MMT_GUIDED_BATCH", None)
         eng.close()
+
+
+@pytest.mark.parametrize("haps,length", [(12, 30_000), (40, 9_000), (130, 3_000)])
+def test_bucket_wise_producer_on_many_copies_equals_the_oracle(haps, length):
+    """Groups of 9 .. 128 copies of a position are finished by one wave per group (guided_kernels.hip k_resolve_medium),
+    larger ones by the refinement rounds: both against the oracle, columns included."""
+    import mumemto_amd
+    docs = synth.pangenome(haps, length, 0.004, seed=haps, indel_rate=0.001, tandem=(1, 500, 700, 4))
+    eng = mumemto_amd.Engine(0)
+    os.environ["MMT_GUIDED_BATCH"] = "60000"
+    try:
+        eng.set_producer("guided", 10, 30)
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        for kw in (dict(), dict(num_distinct=haps - 1, max_doc_freq=3)):
+            eng.set_docs(docs)
+            eng.run(**kw)
+            assert eng.producer_used() == "guided"
+            assert eng.output_text() == O.run(docs, **kw).text(), (haps, kw)
+        assert np.array_equal(eng.sa().astype(np.int64), sa[1:])
+        assert np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
+        assert np.array_equal(eng.bwt(), bwt[1:])
+    finally:
+        os.environ.pop("MMT_GUIDED_BATCH", None)
+        eng.close()

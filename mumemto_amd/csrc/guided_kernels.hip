@@ -197,16 +197,51 @@ void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
     MMT_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void k_batch_count(Ctx c, int shift, uint32_t bin_lo, uint32_t bin_hi,
+// Which suffixes of a tile belong to the bins [bin_lo, bin_hi)?  Only the first `pc` symbols decide, so the pass over the
+// text rolls a bin code of pc * bits bits (a batch re-reads the whole text: at 79 G characters and 86 batches the two
+// text-order kernels were half of the run while they rolled full 63-bit keys for every position).
+template <typename F>
+__device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_sym, F&& f) {
+    constexpr int BLOCK = 256, PER = TILE / BLOCK;
+    static_assert(PER == 16, "one 16-byte load per work-item");
+    __shared__ uint8_t s_code[256];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = c.code[i];
+    __syncthreads();
+    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE; // text position of the tile's first suffix
+    const uint8_t* t = c.v + 1;                                    // 16-byte aligned (Engine::text_ptr), padded by 128 bytes
+    // 16 consecutive characters per work-item in one load, turned into symbol codes in registers and staged as one
+    // 16-byte LDS store (byte loads and byte stores made these kernels run at 0.4 - 0.8 TB/s of a 1 B / character stream)
+    auto codes_at = [&](uint64_t p0) {
+        union { uint4 v; uint8_t b[16]; } raw, out;
+        raw.v = p0 + 16 <= c.n + 64 ? *reinterpret_cast<const uint4*>(t + p0) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 16; k++) out.b[k] = p0 + k < c.n + 40 ? s_code[raw.b[k]] : (uint8_t)0;
+        return out.v;
+    };
+    const int t0 = threadIdx.x * PER;
+    union { uint4 v; uint8_t b[16]; } mine;
+    mine.v = codes_at(base + t0);
+    *reinterpret_cast<uint4*>(s_sym + t0) = mine.v;
+    if (threadIdx.x < 4) *reinterpret_cast<uint4*>(s_sym + TILE + 16 * threadIdx.x) = codes_at(base + TILE + 16 * threadIdx.x);
+    __syncthreads();
+    const uint32_t bmask = (1u << (c.bits * pc)) - 1u;
+    uint32_t bin = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        // bin of the suffix at t0 + q = symbols t0 + q .. t0 + q + pc - 1: roll in symbol t0 + q + pc - 1
+        if (q == 0) { for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | s_sym[t0 + ch]; }
+        else bin = ((bin << c.bits) | s_sym[t0 + q + pc - 1]) & bmask;
+        f(q, base + t0 + q < c.n, bin & bmask);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
                                                      uint32_t* __restrict__ tile_count) {
-    __shared__ uint8_t s_sym[TILE + 64];
+    __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     uint32_t mine = 0;
-    for_tile_keys(c, s_sym, [&](int, uint64_t, bool in, uint64_t key) {
-        const uint32_t b = (uint32_t)(key >> shift);
-        if (in && b >= bin_lo && b < bin_hi) mine++;
-    });
+    for_tile_bins(c, pc, s_sym, [&](int, bool in, uint32_t b) { if (in && b >= bin_lo && b < bin_hi) mine++; });
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -214,27 +249,21 @@ __global__ __launch_bounds__(256) void k_batch_count(Ctx c, int shift, uint32_t 
     if (threadIdx.x == 0) tile_count[(uint64_t)blockIdx.x + c.tile0] = s_cnt;
 }
 void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s) {
-    const int shift = c.bits * (c.chars - prefix_chars);
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_batch_count, dim3(blocks), dim3(256), 0, s, cs, shift, bin_lo, bin_hi, tile_count);
+        hipLaunchKernelGGL(k_batch_count, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_count);
     });
     MMT_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t bin_lo, uint32_t bin_hi,
+__global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
                                                     const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
                                                     uint64_t* __restrict__ pos) {
-    __shared__ uint8_t s_sym[TILE + 64];
+    __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_wave[4];
     __shared__ uint16_t s_sel[TILE];                               // tile offsets of the selected suffixes, in order
     constexpr int PER = TILE / 256;
-    uint64_t my_key[PER];
     uint32_t sel = 0;
-    for_tile_keys(c, s_sym, [&](int q, uint64_t, bool in, uint64_t key) {
-        const uint32_t b = (uint32_t)(key >> shift);
-        my_key[q] = key;
-        if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
-    });
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q; });
     // ordered compaction: exclusive prefix of the per-work-item counts over the workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = __popc(sel);
@@ -250,20 +279,25 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int shift, uint32_t b
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         if (!(sel & (1u << q))) continue;
-        keys[first + at] = my_key[q];
         s_sel[at++] = (uint16_t)(threadIdx.x * PER + q);
     }
     __syncthreads();
-    // the records: phrase-end / parse-rank lookups, one selected suffix per work-item at a time (inside the loop above
-    // each lookup would wait for the one before it: sixteen latencies in a row per wave)
+    // keys and records of the selected suffixes only, one per work-item at a time: the first `chars` symbol codes from the
+    // staged tile; phrase-end / parse-rank lookups (inside the loop above each lookup would wait for the one before it:
+    // sixteen latencies in a row per wave)
     const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
-    for (uint32_t i = threadIdx.x; i < total; i += 256) pos[first + i] = make_rec(c, base + s_sel[i] + 1);
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+        const uint32_t o = s_sel[i];
+        uint64_t key = 0;
+        for (int ch = 0; ch < c.chars; ch++) key = (key << c.bits) | s_sym[o + ch];
+        keys[first + i] = key;
+        pos[first + i] = make_rec(c, base + o + 1);
+    }
 }
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
                 uint64_t* pos, hipStream_t s) {
-    const int shift = c.bits * (c.chars - prefix_chars);
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, shift, bin_lo, bin_hi, tile_off, keys, pos);
+        hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, keys, pos);
     });
     MMT_HIP(hipGetLastError());
 }

@@ -342,6 +342,9 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
     if (up.error) std::rethrow_exception(up.error);
     if (empty >= 0) throw std::runtime_error("Empty input file found: " + inputs[(size_t)empty]);
     const double t_read = since();
+    // the output file is written while the run goes on when the run streams its rows (Engine::set_text_sink)
+    e->e->set_text_sink(out_prefix && p->max_doc_freq == 1 ? std::string(out_prefix) + ".mums" : std::string());
+    struct SinkOff { mmt::Engine* e; ~SinkOff() { e->set_text_sink(std::string()); } } sink_off{e->e.get()};
     bool ran = false;
     if (up.on) {
         try {

@@ -31,6 +31,7 @@ Engine::Engine(int device, hipStream_t stream) : device_(device), stream_(stream
 
 Engine::~Engine() {
     if (own_stream_) (void)hipStreamDestroy(stream_);
+    if (sink_stream_) { (void)hipStreamDestroy(sink_stream_); for (auto ev : sink_copied_) if (ev) (void)hipEventDestroy(ev); }
 }
 
 void Engine::set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs) {
@@ -541,6 +542,152 @@ void append_uint(std::string& s, uint64_t v) {
     while (k) s.push_back(tmp[--k]);
 }
 
+// pop order of the reference's stack for `cnt` rows (closing position ascending, longer first): d_order_[k] = index of the
+// k-th row
+void Engine::order_rows(const k::Row* rows_abs, uint32_t cnt) {
+    hipStream_t st = stream_;
+    d_rkeys_a_.ensure(cnt); d_rkeys_b_.ensure(cnt); d_rvals_a_.ensure(cnt); d_order_.ensure(cnt);
+    if (!wide_) {
+        rk::row_keys(rows_abs, cnt, d_rkeys_a_.get(), d_rvals_a_.get(), st);
+        prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_a_.get(), d_order_.get(), cnt, 0, 64, st);
+    } else {
+        // closing positions beyond 32 bits: two stable sorts (by descending length, then by closing position)
+        d_rvals_b_.ensure(cnt);
+        uint32_t* len_keys = reinterpret_cast<uint32_t*>(d_rkeys_a_.get());
+        uint32_t* len_keys_out = len_keys + cnt;
+        rk::row_len_keys(rows_abs, cnt, len_keys, d_rvals_a_.get(), st);
+        prims::sort_pairs_u32_u32(d_temp_, len_keys, len_keys_out, d_rvals_a_.get(), d_rvals_b_.get(), cnt, 0, 32, st);
+        rk::row_end_keys(rows_abs, d_rvals_b_.get(), cnt, d_rkeys_a_.get(), st);
+        prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_b_.get(), d_order_.get(), cnt, 0, 40, st);
+    }
+}
+
+// ---- the text sink: PREFIX.mums written while the run goes on ---------------------------------------------------------
+void Engine::sink_open(bool mum_mode) {
+    sink_active_ = false;
+    sink_written_path_.clear();
+    if (sink_path_.empty() || !mum_mode || std::getenv("MUMEMTO_NO_TEXT_SINK")) return;
+    sink_fd_ = ::open(sink_path_.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (sink_fd_ < 0) throw std::runtime_error("cannot write " + sink_path_);
+    sink_rows_done_ = 0; sink_bytes_ = 0; sink_block_at_ = 0; sink_block_used_ = 0;
+    sink_closing_ = false; sink_error_.clear();
+    sink_pieces_ = 0;
+    if (!sink_stream_) {
+        MMT_HIP(hipStreamCreateWithFlags(&sink_stream_, hipStreamNonBlocking));
+        for (auto& ev : sink_copied_) MMT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    sink_active_ = true;
+    const int device = device_;
+    sink_thread_ = std::thread([this, device]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            SinkPiece pc;
+            {
+                std::unique_lock<std::mutex> lk(sink_mu_);
+                sink_cv_.wait(lk, [&] { return !sink_q_.empty() || sink_closing_; });
+                if (sink_q_.empty()) break;
+                pc = sink_q_.front(); sink_q_.pop_front();
+            }
+            if (hipEventSynchronize(pc.ready) != hipSuccess && sink_error_.empty()) sink_error_ = "device copy of the output failed";
+            (void)hipEventDestroy(pc.ready);
+            for (size_t done = 0; sink_error_.empty() && done < pc.n;) {
+                const ssize_t w = ::write(sink_fd_, pc.p + done, pc.n - done);
+                if (w <= 0) { sink_error_ = "short write to " + sink_path_; break; }
+                done += (size_t)w;
+            }
+        }
+    });
+}
+// page-locked room for a piece: blocks of 256 MB (or the piece), kept with the engine
+char* Engine::sink_host_room(size_t n) {
+    const size_t BLOCK = (size_t)256 << 20;
+    for (;;) {
+        if (sink_block_at_ < sink_blocks_.size()) {
+            PinnedBuf<char>& b = *sink_blocks_[sink_block_at_];
+            const size_t cap = std::max(BLOCK, sink_block_cap_[sink_block_at_]);
+            if (sink_block_used_ + n <= cap) { char* p = b.get() + sink_block_used_; sink_block_used_ += n; return p; }
+            sink_block_at_++; sink_block_used_ = 0;
+            continue;
+        }
+        sink_blocks_.emplace_back(new PinnedBuf<char>());
+        sink_block_cap_.push_back(std::max(BLOCK, n));
+        sink_blocks_.back()->ensure(sink_block_cap_.back());
+    }
+}
+// the rows accepted since the last call, in pop order, as PREFIX.mums bytes -> helper thread
+void Engine::sink_flush(ScanState& S) {
+    if (!sink_active_) return;
+    const size_t r0 = sink_rows_done_, r1 = S.rows_used;
+    if (r1 <= r0) return;
+    const uint32_t cnt = (uint32_t)(r1 - r0);
+    const size_t N = doc_len_.size();
+    hipStream_t st = stream_;
+    order_rows(d_rows_.get() + r0, cnt);
+    d_doc_len_.ensure(N + 1);
+    MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, st));
+    rk::RowArgs a;
+    a.rows = d_rows_pool_.get() + r0; a.order = d_order_.get(); a.n_rows = cnt;
+    a.sa.lo = d_pool_lo_.get(); a.sa.hi = wide_ ? d_pool_hi_.get() : nullptr;
+    a.doc_start = d_doc_start_.get(); a.doc_len = d_doc_len_.get(); a.n_docs = (uint32_t)N; a.revcomp = revcomp_ ? 1 : 0;
+    const size_t slots = (size_t)cnt * N;
+    d_tlen_.ensure(cnt); d_tlen64_.ensure(cnt); d_toff_.ensure(cnt);
+    d_slot_off_.ensure(slots); d_slot_st_.ensure(slots); d_keep_.ensure(cnt); d_ridx_.ensure(cnt);
+    MMT_HIP(hipMemsetAsync(d_slot_off_.get(), 0xFF, slots * 8, st));     // -1 = document absent
+    MMT_HIP(hipMemsetAsync(d_slot_st_.get(), 0, slots, st));
+    rk::mum_measure(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_tlen_.get(), st);
+    prims::exclusive_sum_u32(d_temp_, d_keep_.get(), d_ridx_.get(), cnt, st);
+    rk::widen(d_tlen_.get(), cnt, d_tlen64_.get(), st);
+    prims::exclusive_sum_u64(d_temp_, d_tlen64_.get(), d_toff_.get(), cnt, st);
+    uint32_t k0 = 0, k1 = 0; uint64_t t0 = 0, t1 = 0;
+    MMT_HIP(hipMemcpyAsync(&k0, d_ridx_.get() + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipMemcpyAsync(&k1, d_keep_.get() + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipMemcpyAsync(&t0, d_toff_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipMemcpyAsync(&t1, d_tlen64_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    const size_t kept = (size_t)k0 + k1, tbytes = (size_t)(t0 + t1);
+    sink_rows_done_ = r1;
+    if (!tbytes) return;
+    // the piece is formatted on the run's stream and copied out on the copy stream (two device pieces in turn: the
+    // formatting of a piece waits for the copy of the piece two flushes ago)
+    const uint32_t slot_i = sink_pieces_ & 1u;
+    DevBuf<char>& piece = d_piece_[slot_i];
+    if (sink_pieces_ >= 2) MMT_HIP(hipStreamWaitEvent(st, sink_copied_[slot_i], 0));
+    d_olen_.ensure(kept + 1); d_ooffs_.ensure(kept * N + 1); d_ost_.ensure(kept * N + 1);
+    if (piece.size() < tbytes + 1) { MMT_HIP(hipStreamSynchronize(sink_stream_)); piece.ensure(tbytes + tbytes / 4 + 1); }
+    rk::mum_write(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_ridx_.get(), d_toff_.get(), d_olen_.get(),
+                  d_ooffs_.get(), d_ost_.get(), piece.get(), st);
+    SinkPiece pc;
+    pc.n = tbytes;
+    char* h = sink_host_room(tbytes);
+    pc.p = h;
+    hipEvent_t formatted;
+    MMT_HIP(hipEventCreateWithFlags(&formatted, hipEventDisableTiming));
+    MMT_HIP(hipEventRecord(formatted, st));
+    MMT_HIP(hipStreamWaitEvent(sink_stream_, formatted, 0));
+    MMT_HIP(hipMemcpyAsync(h, piece.get(), tbytes, hipMemcpyDeviceToHost, sink_stream_));
+    MMT_HIP(hipEventRecord(sink_copied_[slot_i], sink_stream_));
+    MMT_HIP(hipEventCreateWithFlags(&pc.ready, hipEventDisableTiming));
+    MMT_HIP(hipEventRecord(pc.ready, sink_stream_));
+    (void)hipEventDestroy(formatted);
+    sink_pieces_++;
+    { std::lock_guard<std::mutex> lk(sink_mu_); sink_q_.push_back(pc); }
+    sink_cv_.notify_one();
+    sink_bytes_ += tbytes;
+}
+void Engine::sink_close() {
+    if (!sink_active_) return;
+    { std::lock_guard<std::mutex> lk(sink_mu_); sink_closing_ = true; }
+    sink_cv_.notify_one();
+    if (sink_thread_.joinable()) sink_thread_.join();
+    (void)hipStreamSynchronize(sink_stream_);
+    std::string error = sink_error_;
+    if (sink_fd_ >= 0 && ::close(sink_fd_) != 0 && error.empty()) error = "cannot close " + sink_path_;
+    sink_fd_ = -1;
+    sink_active_ = false;
+    if (!error.empty()) throw std::runtime_error(error);
+    sink_written_path_ = sink_path_;
+}
+
 void Engine::make_rows(const mmt_params& p) {
     // Rows stay on the device: sort into pop order, measure, place, write (rows_kernels.hip), then
     // one D2H of the library arrays and of the .mums / .mems bytes into page-locked host memory.
@@ -564,22 +711,7 @@ void Engine::make_rows(const mmt_params& p) {
     if (n_rows == 0) { ev_[5]->stop(st); return; }
 
     // pop order of the reference's stack: closing position ascending, longer first
-    d_rkeys_a_.ensure(n_rows); d_rkeys_b_.ensure(n_rows); d_rvals_a_.ensure(n_rows); d_order_.ensure(n_rows);
-    if (!wide_) {
-        rk::row_keys(d_rows_.get(), n_rows, d_rkeys_a_.get(), d_rvals_a_.get(), st);
-        prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_a_.get(), d_order_.get(), n_rows, 0,
-                                  64, st);
-    } else {
-        // closing positions beyond 32 bits: two stable sorts (by descending length, then by closing position)
-        d_rvals_b_.ensure(n_rows);
-        uint32_t* len_keys = reinterpret_cast<uint32_t*>(d_rkeys_a_.get());
-        uint32_t* len_keys_out = len_keys + n_rows;
-        rk::row_len_keys(d_rows_.get(), n_rows, len_keys, d_rvals_a_.get(), st);
-        prims::sort_pairs_u32_u32(d_temp_, len_keys, len_keys_out, d_rvals_a_.get(), d_rvals_b_.get(), n_rows, 0, 32, st);
-        rk::row_end_keys(d_rows_.get(), d_rvals_b_.get(), n_rows, d_rkeys_a_.get(), st);
-        prims::sort_pairs_u64_u32(d_temp_, d_rkeys_a_.get(), d_rkeys_b_.get(), d_rvals_b_.get(), d_order_.get(), n_rows, 0,
-                                  40, st);
-    }
+    order_rows(d_rows_.get(), n_rows);
     d_doc_len_.ensure(N + 1);
     MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, st));
     rk::RowArgs a;
@@ -639,6 +771,7 @@ void Engine::make_rows(const mmt_params& p) {
 // D2H of the last run's rows into page-locked host memory, on demand: the library arrays (ROWS_ARRAYS) and / or the
 // bytes of PREFIX.mums / PREFIX.mems (ROWS_TEXT).
 void Engine::write_text_file(const std::string& path) {
+    if (!sink_written_path_.empty() && sink_written_path_ == path) return;      // written while the run went on (set_text_sink)
     if (!(rows_pending_ & ROWS_TEXT) || merged_thresh_valid_) {      // already on the host (or a merged result: staged)
         const HostRows& R = rows(ROWS_TEXT);
         write_file_bytes(path, R.text, R.text_len);
@@ -772,6 +905,7 @@ void Engine::run(const mmt_params& p) {
     for (float& f : stage_ms_) f = 0.f;
     for (float& f : scan_ms_) f = 0.f;
     merged_thresh_valid_ = false;
+    sink_written_path_.clear();
     lcp_col_ready_ = false;
     want_anchor_ranks_ = p.merge_metadata != 0;
     anchor_ranks_valid_ = false;
@@ -895,7 +1029,16 @@ void Engine::run(const mmt_params& p) {
     ScanState S;
     scan_begin(p, S);
     streamed_ = true;
-    if (pfp_->guided) guided_stream(S, p); else pfp_stream(S, p);
+    sink_open(p.max_doc_freq == 1);
+    try {
+        if (pfp_->guided) guided_stream(S, p); else pfp_stream(S, p);
+        sink_flush(S);
+    } catch (...) {
+        try { sink_close(); } catch (...) {}
+        sink_written_path_.clear();
+        throw;
+    }
+    sink_close();
     scan_end(S);
     anchor_ranks_valid_ = want_anchor_ranks_;
     lcp_col_ready_ = columns_kept_;

@@ -1,8 +1,12 @@
 // engine.hpp -- the hot path as one object: text -> SA/LCP/BWT -> scan -> rows.
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mumemto_gpu.h"
@@ -150,6 +154,11 @@ public:
     const HostRows& rows_meta() const { return rows_; }
     const HostRows& rows(int need = ROWS_ARRAYS | ROWS_TEXT) { fetch_rows(need); return rows_; }
     void fetch_rows(int need);
+    // PREFIX.mums of the NEXT run straight to `path` while the run goes on: the rows of a window are final when the window
+    // has been verified (they come out in order of their closing position), so their bytes are formatted, copied to
+    // page-locked memory and written by a helper thread while the later windows are produced (multi-MUM runs of the
+    // producers that stream; any other run writes the file at its end as before).  "" switches it off.
+    void set_text_sink(const std::string& path) { sink_path_ = path; }
     // PREFIX.mums / .mems of the last run straight to a file: the bytes leave HBM in pieces and every piece is written
     // while the next ones are still on their way (rows(ROWS_TEXT) + one write otherwise)
     void write_text_file(const std::string& path);
@@ -262,6 +271,31 @@ private:
     DevBuf<k::Row> d_rows_pool_;
     DevBuf<uint64_t> d_cap_cnt_, d_cap_off_;
     uint64_t pool_used_ = 0;
+    // the text sink (set_text_sink)
+    struct SinkPiece { const char* p; size_t n; hipEvent_t ready; };
+    std::string sink_path_, sink_written_path_;
+    bool sink_active_ = false;
+    int sink_fd_ = -1;
+    size_t sink_rows_done_ = 0;
+    uint64_t sink_bytes_ = 0;
+    std::thread sink_thread_;
+    std::mutex sink_mu_;
+    std::condition_variable sink_cv_;
+    std::deque<SinkPiece> sink_q_;
+    bool sink_closing_ = false;
+    std::string sink_error_;
+    std::vector<std::unique_ptr<PinnedBuf<char>>> sink_blocks_;      // page-locked blocks, kept between runs
+    std::vector<size_t> sink_block_cap_;
+    size_t sink_block_at_ = 0, sink_block_used_ = 0;
+    DevBuf<char> d_piece_[2];                // two pieces: one is copied out on the copy stream while the next is formatted
+    hipStream_t sink_stream_ = nullptr;
+    hipEvent_t sink_copied_[2] = {nullptr, nullptr};
+    uint32_t sink_pieces_ = 0;
+    void sink_open(bool mum_mode);
+    void sink_flush(ScanState& S);
+    void sink_close();
+    char* sink_host_room(size_t n);
+    void order_rows(const k::Row* rows_abs, uint32_t cnt);
     float emit_ms_ = 0.f;
     uint64_t stream_entries_ = 0, window_bytes_peak_ = 0;
     uint32_t stream_min_len_ = 20;      // minimum match length of the run in progress (the bins of the bucket-wise producer)

@@ -429,6 +429,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
                 w.len = (uint32_t)(len + 1);
             }
             if (!scan_window(SS, w, p)) throw std::runtime_error("guided sort: a walk left its bin");
+            sink_flush(SS);
             prev_len = len; have_prev = true;
             for (uint32_t b = b1; b-- > b0;) if (bins[b]) { prev_last_bin = b; break; }
             base += B; batches++; rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;

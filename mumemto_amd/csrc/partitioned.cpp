@@ -94,6 +94,9 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             max_text = total / 2;            // partitions of at most half the text, and so on below
         }
     }
+    // (the partitions' own rows are not the output: nothing is streamed to the output file while they run)
+    struct SinkHold { std::string& path; std::string saved; explicit SinkHold(std::string& p) : path(p), saved(p) { path.clear(); }
+                      ~SinkHold() { path = saved; } } sink_hold(sink_path_);
     if (!strict)
         throw std::runtime_error("the text (" + std::to_string(total) + " characters) does not fit the device as one "
                                  "suffix array (limit " + std::to_string(max_text) + ") and only strict multi-MUMs "

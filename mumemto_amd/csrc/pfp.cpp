@@ -511,6 +511,7 @@ void Engine::pfp_stream(ScanState& SS, const mmt_params& p) {
                 k::anchor_ranks(piece, c0, c1 - c0, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
             }
             keep_window(w);
+            sink_flush(SS);
             break;
         }
     }

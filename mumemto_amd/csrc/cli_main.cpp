@@ -409,16 +409,20 @@ int main(int argc, char** argv) {
             log_line("build_main", "text of " + std::to_string(text_chars) + " characters processed as " +
                                        std::to_string(eng.partitions_used()) + " anchor partitions");
         } else {
+            if (o.arrays_out) eng.set_keep_columns(1);          // -A dumps whole columns: keep them next to the windows
+            // PREFIX.mums is written window by window while the run goes on (Engine::set_text_sink)
+            if (mum_mode && !o.binary) eng.set_text_sink(o.output_prefix + ".mums");
             eng.run(p);
+            eng.set_text_sink(std::string());
         }
         mark("run done");
-        const HostRows& R = eng.rows(mum_mode && o.binary ? 0 : Engine::ROWS_TEXT);   // .bumbl pulls the arrays itself
+        const HostRows& R = mum_mode ? eng.rows_meta() : eng.rows(Engine::ROWS_TEXT);   // .mums: write_text_file; .bumbl pulls the arrays itself
         std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n",
                      mum_mode ? "MUM" : "MEM", secs_since(t0));
 
         if (!mum_mode) write_file(o.output_prefix + ".mems", R.text, R.text_len);
         else if (o.binary) { const std::string& b = eng.bumbl(); write_file(o.output_prefix + ".bumbl", b.data(), b.size()); }
-        else write_file(o.output_prefix + ".mums", R.text, R.text_len);
+        else eng.write_text_file(o.output_prefix + ".mums");       // (nothing left to do when the run streamed it)
 
         if (o.anchor_merge && partitioned) {
             write_file(o.output_prefix + ".athresh", eng.merged_thresh().data(), (doc_len[0] + 1) * sizeof(uint16_t));

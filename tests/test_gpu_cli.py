@@ -233,3 +233,43 @@ def test_gpus_option_runs_one_process_per_gpu_and_the_rccl_exchange(inputs):
     r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "--gpus", "9", "-o", str(tmp / "r_bad")] + paths, cwd=tmp,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "fewer documents" in r.stderr
+
+
+REF_MERGE = os.path.join(HERE, "..", "oracle", "_ref", "anchor_merge")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MERGE), reason="the reference's anchor_merge was not built (oracle/Makefile ref)")
+@pytest.mark.parametrize("grouping", [[[1, 2], [3, 4, 5]], [[1], [2, 3], [4, 5]], [[1, 2, 3], [4, 5]]])
+def test_real_reference_anchor_merge_eats_gpu_partitions_at_megabase_size(tmp_path, grouping):
+    """The REAL reference tool (src/merge_candidates.cpp compiled unmodified) folds PREFIX.mums / PREFIX.athresh written
+    by the GPU command line for anchor partitions of 6 x 1.2 Mbp, in the three groupings of the golden fixtures; its rows
+    re-sorted by match string are the bytes of the GPU's direct run on all six documents, its merged .athresh the direct
+    run's (up to the reference's end-of-stream quirk: at most one row per partition, and thresholds where
+    the match of all documents is shorter than -l)."""
+    from mumsfile import format_mums, parse_mums
+    docs = synth.pangenome(6, 1_200_000, 0.004, seed=77, indel_rate=0.0005, inversion=(2, 100_000, 160_000))
+    paths = []
+    for i, d in enumerate(docs):
+        p = tmp_path / ("m%d.fa" % i)
+        synth.write_fasta(str(p), d)
+        paths.append(str(p))
+    cli(["-o", str(tmp_path / "direct"), "-M", "-n"] + paths, tmp_path)
+    direct = (tmp_path / "direct.mums").read_bytes()
+    direct_th = np.fromfile(tmp_path / "direct.athresh", np.uint16)
+    assert direct.count(b"\n") > 1000
+    parts = []
+    for k, g in enumerate(grouping):
+        cli(["-o", str(tmp_path / ("p%d" % k)), "-M", "-n", paths[0]] + [paths[i] for i in g], tmp_path)
+        parts.append(str(tmp_path / ("p%d.mums" % k)))
+    r = subprocess.run([REF_MERGE] + parts + ["-o", str(tmp_path / "merged")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-2000:]
+    L, off, st = parse_mums((tmp_path / "merged.mums").read_bytes())
+    anchor = b"".join(docs[0]).upper()
+    order = sorted(range(len(L)), key=lambda i: anchor[off[i, 0]: off[i, 0] + L[i]])
+    resorted = format_mums(L[order], off[order], st[order])
+    if resorted != direct:
+        a, b = set(direct.split(b"\n")), set(resorted.split(b"\n"))
+        assert len(b - a) == 0 and len(a - b) <= len(grouping), (len(a - b), len(b - a))
+    merged_th = np.fromfile(tmp_path / "merged.athresh", np.uint16)
+    differ = np.nonzero(merged_th != direct_th)[0]
+    assert len(differ) <= 5 and np.all(direct_th[differ] == 0)

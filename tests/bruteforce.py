@@ -20,11 +20,26 @@ multi-MUM / multi-MEM definition directly (SURVEY.md 8(a) note after row A9):
 
 
 def _occurrences(text, min_len):
+    """Every substring of at least min_len characters that occurs at least twice, with its occurrences.  Substrings
+    are grown one character at a time and only while they still have two occurrences (a string that occurs once has no
+    extension that occurs twice), which keeps a few thousand characters tractable."""
     n = len(text)
     table = {}
-    for i in range(n):
-        for ln in range(min_len, n - i + 1):
-            table.setdefault(text[i:i + ln], []).append(i)
+    level = {}
+    for i in range(n - min_len + 1):
+        level.setdefault(text[i:i + min_len], []).append(i)
+    ln = min_len
+    while level:
+        nxt = {}
+        for alpha, occ in level.items():
+            if len(occ) < 2:
+                continue
+            table[alpha] = occ
+            for i in occ:
+                if i + ln < n:
+                    nxt.setdefault(text[i:i + ln + 1], []).append(i)
+        level = nxt
+        ln += 1
     return table
 
 

@@ -121,3 +121,54 @@ def test_bumbl_bytes_match_the_reference_python_writer():
         assert np.array_equal(ref["lengths"], L) and np.array_equal(ref["starts"], off)
         present = off >= 0
         assert np.array_equal(np.asarray(ref["strands"], bool)[present], st.astype(bool)[present])
+
+
+def _longer_docs(rng, n_docs):
+    """300 - 600 bases per document, with what the short cases cannot hold: a reverse-complement palindrome (a match of a
+    document with its own other strand, running through the '$' between the strands when it sits at the document's end),
+    a tandem duplication, a run of N, and substitutions between the documents."""
+    comp = {65: 84, 67: 71, 71: 67, 84: 65, 78: 78}
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(300, 600))).astype(np.uint8)
+    half = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(12, 40))).astype(np.uint8)
+    pal = np.concatenate([half, np.array([comp[c] for c in half[::-1]], np.uint8)])
+    docs = []
+    for d in range(n_docs):
+        s = base.copy()
+        for _ in range(int(rng.integers(2, 9))):
+            s[int(rng.integers(0, len(s)))] = rng.choice(np.frombuffer(b"ACGTN", np.uint8))
+        at = int(rng.integers(0, len(s) - len(pal)))
+        if rng.random() < 0.5:
+            s[at:at + len(pal)] = pal
+        if d == 0:
+            s = np.concatenate([s, pal])                       # palindrome at the end of the document
+        if rng.random() < 0.4:
+            a = int(rng.integers(0, len(s) - 40))
+            s = np.concatenate([s[:a + 30], s[a:a + 30], s[a + 30:]])
+        if rng.random() < 0.3:
+            a = int(rng.integers(0, len(s) - 30))
+            s[a:a + int(rng.integers(5, 25))] = ord("N")
+        if rng.random() < 0.3:
+            s = np.array([comp[c] for c in s[::-1]], np.uint8)
+        docs.append([s.tobytes()])
+    return docs
+
+
+@pytest.mark.parametrize("mode", ["mum", "partial", "mem_capped", "mem_total_cap", "mem_unlimited"])
+def test_scan_against_bruteforce_at_a_few_hundred_bases(mode):
+    """The independent definition checker at 300 - 600 bases per document: MEMs with a per-document cap (-f), with a total
+    cap (-F), without any cap; partial and strict multi-MUMs -- reverse-complement palindromes, duplications, runs of N."""
+    rng = np.random.default_rng({"mum": 11, "partial": 12, "mem_capped": 13, "mem_total_cap": 14, "mem_unlimited": 15}[mode])
+    for trial in range(16):
+        n_docs = int(rng.integers(2, 5))
+        docs = _longer_docs(rng, n_docs)
+        revcomp = trial % 4 != 3
+        min_len = int(rng.integers(8, 20))
+        nd, f, F = {"mum": (n_docs, 1, 0), "partial": (max(2, n_docs - 1), 1, 0), "mem_capped": (2, 3, 0),
+                    "mem_total_cap": (2, 0, n_docs + 3), "mem_unlimited": (2, 0, 0)}[mode]
+        text, doc_start = O.build_text(docs, revcomp)
+        sa, lcp, bwt = O.build_stream(text)
+        got = O.scan(sa, lcp, bwt, doc_start, min_len=min_len, num_distinct=nd, max_doc_freq=f,
+                     max_total_freq=F, revcomp=revcomp).text()
+        want = bruteforce_lines(text, list(doc_start), min_len, nd, f, F, revcomp)
+        assert got == want, (mode, trial, revcomp, min_len)
+        assert mode != "mem_unlimited" or got.count(b"\n") > 3

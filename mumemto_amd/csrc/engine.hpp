@@ -210,6 +210,7 @@ private:
     void pfp_prepare_emitter(uint32_t w);
     void guided_prepare();
     void guided_check_errors(const char* what);
+    void build_giant(const std::vector<uint64_t>& hist);
     void pfp_stream(ScanState& S, const mmt_params& p);
     void pfp_emit_window(uint64_t b0, uint64_t c1, int set);
     void guided_stream(ScanState& S, const mmt_params& p);

@@ -133,18 +133,22 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
             big = read_u32(X.count.get() + 1, st);
         }
         if (big) {
-            // ranges that hold a group longer than an LDS tile: their groups become the segments of one segmented sort
+            // ranges that hold a group longer than an LDS tile: their groups become the segments of ONE segmented sort
+            // (a collection with satellite arrays has thousands of such ranges per round)
             std::vector<uint32_t> hb(big), he(big);
             MMT_HIP(hipMemcpyAsync(hb.data(), X.big_begin.get(), (size_t)big * 4, hipMemcpyDeviceToHost, st));
             MMT_HIP(hipMemcpyAsync(he.data(), X.big_end.get(), (size_t)big * 4, hipMemcpyDeviceToHost, st));
             MMT_HIP(hipStreamSynchronize(st));
-            for (uint32_t r = 0; r < big; r++) {
-                X.seg.ensure((size_t)(he[r] - hb[r]) + 2);
-                gk::range_groups(X.ghead.get(), hb[r], he[r], X.seg.get(), X.count.get() + 2, st);
-                const uint32_t segs = read_u32(X.count.get() + 2, st);
-                prims::segmented_sort_pairs_u64_u64vals_ranges(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_c.get(),
-                                                               m, segs, X.seg.get(), X.seg.get() + 1, 64, st);
-            }
+            uint64_t covered = 0;
+            for (uint32_t r = 0; r < big; r++) covered += he[r] - hb[r];
+            const size_t cap = (size_t)(covered / 2 + 2);                  // every group that is still active has two elements
+            X.seg.ensure(2 * cap);
+            gk::range_groups(X.ghead.get(), X.big_begin.get(), X.big_end.get(), big, X.seg.get(), X.seg.get() + cap,
+                             X.count.get() + 2, st);
+            const uint32_t segs = read_u32(X.count.get() + 2, st);
+            if (segs > cap) throw std::runtime_error("guided sort: more groups than elements in the long ranges");
+            prims::segmented_sort_pairs_u64_u64vals_ranges(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_c.get(), m,
+                                                           segs, X.seg.get(), X.seg.get() + cap, 64, st);
         }
         gk::round_heads(X.key_b.get(), X.ghead.get(), m, X.hv.get(), err, st);
         prims::inclusive_max_u32(temp, X.hv.get(), X.hv.get(), m, st);
@@ -158,7 +162,8 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
             X.slot_a.swap(X.slot_b);
         }
         m = m2;
-        offset += (uint64_t)ctx.chars;
+        // (after the round that took its keys from the giant dictionary every alpha that is still tied is spent)
+        offset = ctx.g_n && offset >= ctx.g_depth ? (1ull << 40) : offset + (uint64_t)ctx.chars;
     }
     return rs;
 }
@@ -240,6 +245,8 @@ void Engine::guided_prepare() {
     S.err.ensure(16);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
 
+    build_giant(hist);
+
     // ---- lexicographic ranks of the distinct phrases (one batch of the sort below), the parse ----
     auto t0 = now();
     {
@@ -289,6 +296,115 @@ void Engine::guided_prepare() {
     S.ms[2] = 0; S.ms[3] = e3.ms(); S.ms[4] = 0; S.ms[5] = e5.ms();
     S.bwt_ready = true;
     S.n_groups = 0; S.dict_len = 0;
+}
+
+// Giant phrases -- longer than 24 first-key lengths (504 bases): a run of N, a microsatellite, any stretch without a
+// trigger of the parse (newscan.hpp:265-325) -- would be refined 21 characters per round by every suffix that starts in
+// them.  Their suffixes are sorted ONCE instead, as a dictionary of their own with the machinery of the parse proper (unique
+// terminators, prefix doubling: a megabase of N is 20 rounds), with its LCP array (irreducible entries + PLCP chain) and a
+// range-minimum structure on it; a comparison that is undecided 504 characters into alpha continues on those ranks
+// (gk::cmp_rest, k_round_keys), and the LCP of two such suffixes is a range minimum.
+void Engine::build_giant(const std::vector<uint64_t>& hist) {
+    PfpState& S = *pfp_;
+    hipStream_t st = stream_;
+    gk::Ctx& ctx = S.gctx;
+    const bool W = wide_;
+    const uint32_t m = S.n_phrases, D = S.n_distinct;
+    ctx.g_n = 0; ctx.g_depth = 24u * (uint32_t)ctx.chars;
+    S.gi_occ = S.gi_distinct = S.gi_chars = 0;
+    if (std::getenv("MMT_GUIDED_NO_GIANT")) return;
+    if (const char* c = std::getenv("MMT_GIANT_DEPTH")) ctx.g_depth = (uint32_t)std::max(1, std::atoi(c)) * (uint32_t)ctx.chars;
+    DevBuf<uint32_t> flags, gids, count;
+    count.ensure(4);
+    // distinct phrases longer than g_depth (dlen counts the terminator)
+    flags.ensure(std::max(D, m)); gids.ensure(D);
+    gk::flag_greater(S.dlen.get(), D, ctx.g_depth + 1, flags.get(), st);
+    prims::select_indices_u32flags(d_temp_, flags.get(), gids.get(), count.get(), D, st);
+    const uint32_t nG = read_u32(count.get(), st);
+    if (!nG) return;
+    DevBuf<uint32_t> which, glen, gstart, dmap;
+    which.ensure(nG); glen.ensure(nG); gstart.ensure(nG); dmap.ensure(D);
+    gk::giant_distinct(gids.get(), nG, S.rep.get(), S.dlen.get(), which.get(), glen.get(), st);
+    DevBuf<uint64_t> total;
+    total.ensure(1);
+    pk::sum_u32(glen.get(), nG, total.get(), st);
+    uint64_t nd64 = 0;
+    MMT_HIP(hipMemcpyAsync(&nd64, total.get(), 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    nd64 += 1;
+    if (nd64 >= 0xffffff00ull) throw std::runtime_error("giant phrases of " + std::to_string(nd64) + " characters in all exceed a 32-bit dictionary");
+    const uint32_t nd = (uint32_t)nd64;
+    prims::exclusive_sum_u32(d_temp_, glen.get(), gstart.get(), nG, st);
+    MMT_HIP(hipMemsetAsync(dmap.get(), 0xff, (size_t)D * 4, st));
+    gk::giant_map(gids.get(), gstart.get(), nG, dmap.get(), st);
+    // the giant dictionary, its suffix array (unique terminators: prefix doubling as for the parse proper's dictionary)
+    DevBuf<uint8_t> dict, code_d, ebw;
+    DevBuf<uint64_t> dinfo;
+    dict.ensure((size_t)nd + 64); dinfo.ensure(nd);
+    MMT_HIP(hipMemsetAsync(dict.get() + nd, 0, 64, st));
+    pk::copy_dict(text_ptr() - 1, S.pstart.get(), S.plen.get(), which.get(), gstart.get(), nG, dict.get(), dinfo.get(), nd, false, W, st);
+    uint8_t code[256];
+    int sigma = 0;
+    for (int c = 0; c < 256; c++) code[c] = (hist[c] || c <= 2) ? (uint8_t)(++sigma) : 0;
+    const int bits = std::max(1, bit_width_u64((uint64_t)sigma)), chars = std::min(63 / bits, 63);
+    code_d.ensure(256);
+    MMT_HIP(hipMemcpyAsync(code_d.get(), code, 256, hipMemcpyHostToDevice, st));
+    DevBuf<uint32_t> sa_g, esuf, ephr, plcp, cnt2, huge;
+    sa_g.ensure(nd); S.gi_isa.ensure(nd);
+    sorter_.reserve(nd);
+    k::pack_keys(dict.get(), nd, code_d.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
+    const int rounds = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, sa_g.get(), S.gi_isa.get(), d_temp_, st, true);
+    MMT_HIP(hipStreamSynchronize(st));
+    sorter_.release();
+    esuf.ensure(nd); ephr.ensure(nd); ebw.ensure(nd);
+    pk::entry_info(sa_g.get(), dinfo.get(), dict.get(), nd, false, esuf.get(), ephr.get(), ebw.get(), st);
+    // its LCP array (irreducible entries compared directly, the rest by the PLCP chain), groups of equal strings
+    plcp.ensure((size_t)nd + 16); cnt2.ensure(4); S.gi_lcp.ensure(((size_t)nd + 3) / 4 * 4 + 16);
+    {
+        DevBuf<uint8_t> longs;
+        uint32_t cap = std::max<uint32_t>(nd / 64 + 4096, 1u << 16), found = 0;
+        for (int attempt = 0;; attempt++) {
+            longs.ensure((size_t)cap * sizeof(k::LongLcpLim));
+            pk::dict_irreducible(dict.get(), nd, sa_g.get(), esuf.get(), ebw.get(), plcp.get(), longs.get(), cnt2.get(), cap, st);
+            found = read_u32(cnt2.get(), st);
+            if (found <= cap) break;
+            if (attempt) throw std::runtime_error("long-match list overflow in the giant dictionary's LCP construction");
+            cap = found + 1024;
+        }
+        if (found) {
+            huge.ensure((size_t)found + 1);
+            k::long_lcp_lim(dict.get(), nd, longs.get(), found, plcp.get(), huge.get(), cnt2.get() + 1, st);
+        }
+        d_temp_.ensure(k::plcp_running_max_scratch(nd));
+        k::plcp_running_max(plcp.get(), nd, d_temp_.get(), st);
+        SaCol sd; sd.lo = sa_g.get(); sd.hi = nullptr;
+        k::lcp_gather(plcp.get(), sd, 0, nd, S.gi_lcp.get(), st);
+        pk::dict_lcp_clamp(S.gi_lcp.get(), esuf.get(), nd, st);
+        MMT_HIP(hipStreamSynchronize(st));
+    }
+    S.gi_grp.ensure(nd);
+    gk::giant_group_flags(esuf.get(), S.gi_lcp.get(), nd, S.gi_grp.get(), st);
+    prims::inclusive_sum_u32(d_temp_, S.gi_grp.get(), S.gi_grp.get(), nd, st);
+    build_rmq(S.gi_lcp.get(), nd, S.gi_bmin, S.gi_nb, S.gi_levels, st);
+    // the occurrences of giant phrases in the parse: phrase index (ascending), first V index, place in the dictionary
+    gk::flag_greater(S.plen.get(), m, ctx.g_depth, flags.get(), st);
+    DevBuf<uint32_t> occ_idx;
+    occ_idx.ensure(m);
+    prims::select_indices_u32flags(d_temp_, flags.get(), occ_idx.get(), count.get(), m, st);
+    const uint32_t nO = read_u32(count.get(), st);
+    S.gi_k.ensure(std::max<uint32_t>(nO, 1)); S.gi_ps.ensure(std::max<uint32_t>(nO, 1)); S.gi_base.ensure(std::max<uint32_t>(nO, 1));
+    if (nO) {
+        MMT_HIP(hipMemcpyAsync(S.gi_k.get(), occ_idx.get(), (size_t)nO * 4, hipMemcpyDeviceToDevice, st));
+        gk::giant_occurrences(S.gi_k.get(), nO, S.pid.get(), S.pstart.get(), W, dmap.get(), S.gi_ps.get(), S.gi_base.get(), st);
+    }
+    MMT_HIP(hipStreamSynchronize(st));
+    S.gi_occ = nO; S.gi_distinct = nG; S.gi_chars = nd;
+    ctx.g_k = S.gi_k.get(); ctx.g_ps = S.gi_ps.get(); ctx.g_base = S.gi_base.get(); ctx.g_n = nO;
+    ctx.g_isa = S.gi_isa.get(); ctx.g_grp = S.gi_grp.get();
+    ctx.g_rmq.sl = S.gi_lcp.get(); ctx.g_rmq.bmin = S.gi_bmin.get(); ctx.g_rmq.m = nd; ctx.g_rmq.nb = S.gi_nb;
+    if (std::getenv("MMT_GUIDED_STATS"))
+        std::fprintf(stderr, "[guided] %u giant distinct phrases (%u characters, sorted in %d rounds), %u occurrences in the parse\n",
+                     nG, nd, rounds, nO);
 }
 
 void Engine::guided_check_errors(const char* what) {

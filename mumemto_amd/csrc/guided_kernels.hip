@@ -124,6 +124,53 @@ __device__ __forceinline__ uint64_t make_rec(const Ctx& c, uint64_t q) {
     return q | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
 }
 
+// ---- giant phrases -----------------------------------------------------------------------------------------------------
+// the rest of alpha of the element at V index q, from `off` characters on, as an entry of the giant dictionary's suffix
+// array; false when the element does not lie in a giant phrase
+__device__ __forceinline__ bool giant_entry(const Ctx& c, uint64_t q, uint64_t off, uint32_t& r) {
+    if (!c.g_n) return false;
+    const uint32_t k = rank1(c, query_point(c, q));
+    uint32_t lo = 0, hi = c.g_n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (c.g_k[mid] < k) lo = mid + 1; else hi = mid; }
+    if (lo >= c.g_n || c.g_k[lo] != k) return false;
+    r = c.g_isa[(uint64_t)c.g_base[lo] + (q + off - c.g_ps[lo])];
+    return true;
+}
+// Order of alpha(qa) and alpha(qb) (la, lb characters), known to agree in their first `from` characters: -1 / +1, or 0 when
+// they are the same phrase suffix (prefix-free: no difference before the shorter one ends).  *lcp = characters the two
+// suffixes share when a character decided.  Beyond g_depth characters two alphas that both go on lie in giant phrases and
+// the giant dictionary decides: one lookup instead of a comparison that may run for a megabase.
+__device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, uint64_t qb, uint64_t lb, uint64_t from,
+                                        uint64_t* lcp) {
+    const uint64_t L = la < lb ? la : lb;
+    const bool giant = c.g_n && L > c.g_depth && from <= c.g_depth;
+    const uint64_t stop = giant ? (uint64_t)c.g_depth : L;
+    for (uint64_t t = from; t < stop; t += 8) {
+        const uint64_t x = load_u64(c.v + qa + t), y = load_u64(c.v + qb + t);
+        if (x != y) {
+            const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+            if (t + d < stop) { if (lcp) *lcp = t + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff) ? -1 : 1; }
+            break;
+        }
+    }
+    if (!giant) return 0;
+    uint32_t ra = 0, rb = 0;
+    if (!giant_entry(c, qa, c.g_depth, ra) || !giant_entry(c, qb, c.g_depth, rb)) {
+        for (uint64_t t = c.g_depth; t < L; t += 8) {           // (cannot happen: an alpha beyond g_depth lies in a giant phrase)
+            const uint64_t x = load_u64(c.v + qa + t), y = load_u64(c.v + qb + t);
+            if (x != y) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+                if (t + d < L) { if (lcp) *lcp = t + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff) ? -1 : 1; }
+                break;
+            }
+        }
+        return 0;
+    }
+    if (c.g_grp[ra] == c.g_grp[rb]) return 0;
+    if (lcp) *lcp = (uint64_t)c.g_depth + rmq_min(c.g_rmq, (ra < rb ? ra : rb) + 1, ra < rb ? rb : ra);
+    return ra < rb ? -1 : 1;
+}
+
 // up to c.chars symbol codes of v[from ...], most significant first
 __device__ __forceinline__ uint64_t pack_chars(const Ctx& c, const uint8_t* __restrict__ s_code, uint64_t from) {
     const uint8_t* p = c.v + from;
@@ -375,6 +422,11 @@ __global__ void k_round_keys(Ctx c, const uint64_t* __restrict__ pos, uint32_t m
         keys[e] = RANK_KEY | rec_rank_key(c, rec, q);
         return;
     }
+    if (c.g_n && offset >= c.g_depth) {
+        // the group has shared g_depth characters and its alphas go on: giant phrases -- the rest by the giant dictionary
+        uint32_t r = 0;
+        if (giant_entry(c, q, offset, r)) { keys[e] = GIANT_KEY | c.g_grp[r]; return; }
+    }
     keys[e] = pack_chars(c, s_code, q + offset);
 }
 void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s) {
@@ -421,14 +473,7 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
                 open = false;
             }
         }
-        for (uint64_t t = offset + 32; open && t < L; t += 8) {  // a longer phrase: the plain loop
-            const uint64_t x = load_u64(c.v + q + t), y = load_u64(c.v + qj + t);
-            if (x != y) {
-                const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
-                if (t + d < L) cmp = ((y >> (8 * d)) & 0xff) < ((x >> (8 * d)) & 0xff) ? -1 : 1;
-                open = false;
-            }
-        }
+        if (open && offset + 32 < L) cmp = -cmp_rest(c, q, len, qj, lj, offset + 32, nullptr);   // a longer phrase (cmp: -1 = j first)
         if (cmp == 0) {
             if (len != lj) atomicAdd(err + 1, 1u);
             const uint64_t mine = rec >> c.pos_bits, other = rj >> c.pos_bits;
@@ -445,16 +490,7 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
         if (j == e) continue;
         const uint64_t rj = pos[j], qj = rec_pos(c, rj);
         const uint64_t lj = rec_len(c, rj, qj);
-        const uint64_t L = len < lj ? len : lj;
-        int cmp = 0;                                             // -1: j sorts before e
-        for (uint64_t t = offset; t < L; t += 8) {
-            const uint64_t x = load_u64(c.v + q + t), y = load_u64(c.v + qj + t);
-            if (x != y) {
-                const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
-                if (t + d < L) cmp = ((y >> (8 * d)) & 0xff) < ((x >> (8 * d)) & 0xff) ? -1 : 1;
-                break;
-            }
-        }
+        int cmp = -cmp_rest(c, q, len, qj, lj, offset, nullptr);   // -1: j sorts before e
         if (cmp == 0) {
             // the shorter alpha is a prefix of the other string: the two are the same phrase suffix (prefix-free)
             if (len != lj || c.skip) atomicAdd(err + (c.skip ? 0 : 1), 1u);
@@ -552,15 +588,8 @@ __device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_
             break;
         }
         if (t + 1 == MED_WORDS && at + 8 < L) {              // (rare: alphas beyond the staged characters)
-            const uint64_t qa = rec_pos(c, S.rec[a]), qb = rec_pos(c, S.rec[b]);
-            for (uint64_t u = at + 8; u < L; u += 8) {
-                const uint64_t x2 = load_u64(c.v + qa + u), y2 = load_u64(c.v + qb + u);
-                if (x2 != y2) {
-                    const uint32_t d2 = (uint32_t)__builtin_ctzll(x2 ^ y2) >> 3;
-                    if (u + d2 < L) { if (lcp) *lcp = u + d2; return ((x2 >> (8 * d2)) & 0xff) < ((y2 >> (8 * d2)) & 0xff); }
-                    break;
-                }
-            }
+            const int r2 = cmp_rest(c, rec_pos(c, S.rec[a]), la, rec_pos(c, S.rec[b]), lb, at + 8, lcp);
+            if (r2) return r2 < 0;
         }
     }
     if (la != lb || c.skip) S.bad = 1;
@@ -801,32 +830,37 @@ void local_sort(const uint64_t* kin, const uint64_t* pin, const uint32_t* ghead,
     MMT_HIP(hipGetLastError());
 }
 
-// the groups inside [begin, end) as segments: seg_begin gets the heads in order, *seg_count their number
-__global__ void k_range_groups(const uint32_t* __restrict__ ghead, uint32_t begin, uint32_t end,
-                               uint32_t* __restrict__ seg_begin, uint32_t* __restrict__ seg_count) {
-    // one workgroup, ordered: every pass handles blockDim.x elements and appends its heads after the earlier ones
-    __shared__ uint32_t s_base, s_wave[16];
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    for (uint32_t c0 = begin; c0 < end; c0 += blockDim.x) {
+// the groups inside the ranges [big_begin[r], big_end[r]) as segments of one segmented sort: the last element of a group
+// appends (head, end) -- any order will do
+__global__ void k_range_groups(const uint32_t* __restrict__ ghead, const uint32_t* __restrict__ big_begin,
+                               const uint32_t* __restrict__ big_end, uint32_t* __restrict__ seg_begin,
+                               uint32_t* __restrict__ seg_end, uint32_t* __restrict__ seg_count) {
+    // (a range is cut into gridDim.y stretches: one range of a round is often a hundred times longer than the others)
+    const uint32_t begin = big_begin[blockIdx.x], end = big_end[blockIdx.x];
+    const uint32_t per = ((end - begin + gridDim.y - 1) / gridDim.y + 1023u) & ~1023u;
+    const uint64_t lo64 = (uint64_t)begin + (uint64_t)blockIdx.y * per;
+    if (lo64 >= end) return;
+    const uint32_t lo = (uint32_t)lo64, hi = end - lo < per ? end : lo + per;
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint32_t c0 = lo; c0 < hi; c0 += blockDim.x) {
         const uint32_t c = c0 + threadIdx.x;
-        const bool h = c < end && ghead[c] == c;
-        const uint64_t bal = __ballot(h);
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
-        __syncthreads();
-        uint32_t at = s_base;
-        for (uint32_t wv = 0; wv < wave; wv++) at += s_wave[wv];
-        if (h) seg_begin[at + __popcll(bal & ((1ull << lane) - 1))] = c;
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t wv = 0; wv < waves; wv++) tot += s_wave[wv]; s_base += tot; }
-        __syncthreads();
+        const bool last = c < hi && (c + 1 == end || ghead[c + 1] == c + 1);
+        const uint64_t bal = __ballot(last);
+        if (!bal) continue;
+        uint32_t at = 0;
+        if (lane == (uint32_t)__builtin_ctzll(bal)) at = atomicAdd(seg_count, (uint32_t)__popcll(bal));
+        at = __shfl(at, __builtin_ctzll(bal));
+        if (last) {
+            const uint32_t o = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1));
+            seg_begin[o] = ghead[c];
+            seg_end[o] = c + 1;
+        }
     }
-    if (threadIdx.x == 0) { *seg_count = s_base; seg_begin[s_base] = end; }
 }
-void range_groups(const uint32_t* ghead, uint32_t begin, uint32_t end, uint32_t* seg_begin, uint32_t* seg_count,
-                  hipStream_t s) {
-    hipLaunchKernelGGL(k_range_groups, dim3(1), dim3(1024), 0, s, ghead, begin, end, seg_begin, seg_count);
+void range_groups(const uint32_t* ghead, const uint32_t* big_begin, const uint32_t* big_end, uint32_t big, uint32_t* seg_begin,
+                  uint32_t* seg_end, uint32_t* seg_count, hipStream_t s) {
+    MMT_HIP(hipMemsetAsync(seg_count, 0, 4, s));
+    hipLaunchKernelGGL(k_range_groups, dim3(big, 64), dim3(1024), 0, s, ghead, big_begin, big_end, seg_begin, seg_end, seg_count);
     MMT_HIP(hipGetLastError());
 }
 
@@ -878,6 +912,68 @@ void round_compact(const uint32_t* idx, uint32_t m2, const uint32_t* slot, const
     MMT_HIP(hipGetLastError());
 }
 
+// ---- the giant dictionary's bookkeeping (guided.cpp::build_giant) ---------------------------------------------------
+__global__ void k_flag_greater(const uint32_t* __restrict__ v, uint32_t n, uint32_t thr, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = v[i] > thr ? 1u : 0u;
+}
+void flag_greater(const uint32_t* v, uint32_t n, uint32_t thr, uint32_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_greater, dim3(grid_for(n, 256)), dim3(256), 0, s, v, n, thr, flags);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_giant_distinct(const uint32_t* __restrict__ gids, uint32_t n, const uint32_t* __restrict__ rep,
+                                 const uint32_t* __restrict__ dlen, uint32_t* __restrict__ which, uint32_t* __restrict__ glen) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { which[i] = rep[gids[i]]; glen[i] = dlen[gids[i]]; }
+}
+void giant_distinct(const uint32_t* gids, uint32_t n, const uint32_t* rep, const uint32_t* dlen, uint32_t* which, uint32_t* glen,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_giant_distinct, dim3(grid_for(n, 256)), dim3(256), 0, s, gids, n, rep, dlen, which, glen);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_giant_map(const uint32_t* __restrict__ gids, const uint32_t* __restrict__ gstart, uint32_t n,
+                            uint32_t* __restrict__ dmap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dmap[gids[i]] = gstart[i];
+}
+void giant_map(const uint32_t* gids, const uint32_t* gstart, uint32_t n, uint32_t* dmap, hipStream_t s) {
+    hipLaunchKernelGGL(k_giant_map, dim3(grid_for(n, 256)), dim3(256), 0, s, gids, gstart, n, dmap);
+    MMT_HIP(hipGetLastError());
+}
+template <typename P>
+__global__ void k_giant_occurrences(const uint32_t* __restrict__ gk, uint32_t n, const uint32_t* __restrict__ pid,
+                                    const P* __restrict__ pstart, const uint32_t* __restrict__ dmap, uint64_t* __restrict__ gps,
+                                    uint32_t* __restrict__ gbase) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t k = gk[j];
+    gps[j] = (uint64_t)pstart[k];
+    gbase[j] = dmap[pid[k]];
+}
+void giant_occurrences(const uint32_t* gk, uint32_t n, const uint32_t* pid, const void* pstart, bool wide, const uint32_t* dmap,
+                       uint64_t* gps, uint32_t* gbase, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_giant_occurrences<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, gk, n, pid,
+                           static_cast<const uint64_t*>(pstart), dmap, gps, gbase);
+    else
+        hipLaunchKernelGGL(k_giant_occurrences<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, gk, n, pid,
+                           static_cast<const uint32_t*>(pstart), dmap, gps, gbase);
+    MMT_HIP(hipGetLastError());
+}
+// entry r of the giant dictionary's suffix array starts a new group unless it spells the string of entry r - 1 (same
+// length, LCP >= length)
+__global__ void k_giant_group_flags(const uint32_t* __restrict__ esuf, const uint32_t* __restrict__ lcp, uint32_t nd,
+                                    uint32_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    const uint32_t sl = esuf[r] & 0x7fffffffu;
+    flags[r] = r == 0 || (esuf[r - 1] & 0x7fffffffu) != sl || lcp[r] < sl ? 1u : 0u;
+}
+void giant_group_flags(const uint32_t* esuf, const uint32_t* lcp, uint32_t nd, uint32_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_giant_group_flags, dim3(grid_for(nd, 256)), dim3(256), 0, s, esuf, lcp, nd, flags);
+    MMT_HIP(hipGetLastError());
+}
+
 // ---- results -----------------------------------------------------------------------------------------------------
 template <typename SA>
 __global__ void k_write_columns(Ctx c, const uint64_t* __restrict__ pos, uint32_t B, uint64_t base, SA sa,
@@ -909,17 +1005,8 @@ __global__ void k_batch_lcp(Ctx c, RmqView R, const uint64_t* __restrict__ pos, 
     const uint64_t qa = rec_pos(c, ra), qb = rec_pos(c, rb);
     const uint64_t la = rec_len(c, ra, qa), lb = rec_len(c, rb, qb);
     const uint64_t lim = la < lb ? la : lb;
-    const uint8_t* x = c.v + qa;
-    const uint8_t* y = c.v + qb;
-    uint64_t h = 0;
-    while (h < lim) {
-        const uint64_t d = load_u64(x + h) ^ load_u64(y + h);
-        if (d) { h += (uint64_t)(__builtin_ctzll(d) >> 3); break; }
-        h += 8;
-    }
-    uint64_t v;
-    if (h < lim) v = h;
-    else {
+    uint64_t v = 0;
+    if (cmp_rest(c, qa, la, qb, lb, 0, &v) == 0) {
         const uint64_t ka = rec_rank_key(c, ra, qa), kb = rec_rank_key(c, rb, qb);
         if (la != lb || kb >= ka) { atomicAdd(err + 2, 1u); v = lim; }
         else v = la - c.w + rmq_min(R, (uint32_t)kb + 1, (uint32_t)ka);

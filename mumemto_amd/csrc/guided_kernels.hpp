@@ -15,6 +15,7 @@ constexpr uint64_t POS_MASK = (1ull << 40) - 1;
 constexpr uint32_t LEN_SAT = 0xffffffu;
 // keys of a refinement round: up to 63 bits of symbol codes, or bit 63 + the rank of the parse suffix that follows
 constexpr uint64_t RANK_KEY = 1ull << 63;
+constexpr uint64_t GIANT_KEY = 1ull << 62;  // ... or bit 62 + the group of the rest of alpha in the giant dictionary
 constexpr uint32_t TILE = 4096;            // text positions per workgroup of the text-order kernels
 constexpr uint32_t SORT_CAP = 2048;        // elements of one LDS tile of the round sort
 constexpr uint32_t NO_BOUND = 0xffffffffu;
@@ -34,6 +35,14 @@ struct Ctx {
     uint32_t pos_bits;         // element records: position in the low pos_bits bits, above it ...
     uint32_t rec_rank;         // ... 1: the rank of the following parse suffix, 0: the length of alpha (pos_bits = 40)
     uint32_t tile0 = 0;        // first tile of this launch (the text-order kernels run in slices of 2^23 tiles)
+    // Giant phrases (longer than g_depth characters: a run of N, a microsatellite -- no trigger of the parse falls inside a
+    // periodic run, newscan.hpp:265-325): their suffixes are sorted once, as a small dictionary of their own, and a
+    // comparison that is still undecided g_depth characters into alpha continues on those ranks instead of on characters.
+    //   g_k[j] (ascending) = phrase index of the j-th giant occurrence, g_ps[j] = its first V index, g_base[j] = position of
+    //   its phrase in the giant dictionary; g_isa[position] = entry of the giant dictionary's suffix array; g_grp[entry] =
+    //   id of its group of equal strings; g_rmq over the giant dictionary's LCP array.
+    const uint32_t* g_k = nullptr; const uint64_t* g_ps = nullptr; const uint32_t* g_base = nullptr; uint32_t g_n = 0;
+    const uint32_t* g_isa = nullptr; const uint32_t* g_grp = nullptr; RmqView g_rmq; uint32_t g_depth = 0;
 };
 
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions
@@ -79,9 +88,17 @@ void round_apply(const uint64_t* pos_sorted, const uint32_t* newhead, const uint
 void round_compact(const uint32_t* idx, uint32_t m2, const uint32_t* slot, const uint64_t* pos_sorted,
                    const uint32_t* newhead, uint32_t* slot_out, uint64_t* pos_out, uint32_t* headval_out, hipStream_t s);
 // groups of a listed range: segment list for the segmented sort
-void range_groups(const uint32_t* ghead, uint32_t begin, uint32_t end, uint32_t* seg_begin, uint32_t* seg_count,
-                  hipStream_t s);
+void range_groups(const uint32_t* ghead, const uint32_t* big_begin, const uint32_t* big_end, uint32_t big, uint32_t* seg_begin,
+                  uint32_t* seg_end, uint32_t* seg_count, hipStream_t s);
 
+// giant phrases: flags[i] = v[i] > thr; the giant dictionary's bookkeeping (guided.cpp::build_giant)
+void flag_greater(const uint32_t* v, uint32_t n, uint32_t thr, uint32_t* flags, hipStream_t s);
+void giant_distinct(const uint32_t* gids, uint32_t n, const uint32_t* rep, const uint32_t* dlen, uint32_t* which, uint32_t* glen,
+                    hipStream_t s);
+void giant_map(const uint32_t* gids, const uint32_t* gstart, uint32_t n, uint32_t* dmap, hipStream_t s);
+void giant_occurrences(const uint32_t* gk, uint32_t n, const uint32_t* pid, const void* pstart, bool wide, const uint32_t* dmap,
+                       uint64_t* gps, uint32_t* gbase, hipStream_t s);
+void giant_group_flags(const uint32_t* esuf, const uint32_t* lcp, uint32_t nd, uint32_t* flags, hipStream_t s);
 // sorted batch -> suffix array and BWT columns at [base, base + B)
 void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base, SaCol sa, uint8_t* bwt, hipStream_t s);
 // sorted batch -> its piece of the LCP column (lcp[j] for element j; entries that are not 0xffffffff were filled in by the

@@ -176,6 +176,18 @@ __global__ void k_level_min(const uint32_t* __restrict__ below, uint32_t* __rest
 
 }  // namespace
 
+void build_rmq(const uint32_t* vals, uint32_t m, DevBuf<uint32_t>& bmin, uint32_t& nb, uint32_t& levels, hipStream_t s) {
+    nb = (m + 63) / 64;
+    levels = 1;
+    while ((1u << levels) <= nb) levels++;
+    bmin.ensure((size_t)levels * nb + 64);
+    hipLaunchKernelGGL(k_block_min, dim3(grid_for((uint64_t)nb * 64, 256)), dim3(256), 0, s, vals, m, bmin.get(), nb);
+    for (uint32_t k = 1; k < levels; k++)
+        hipLaunchKernelGGL(k_level_min, dim3(grid_for(nb, 256)), dim3(256), 0, s, bmin.get() + (size_t)(k - 1) * nb,
+                           bmin.get() + (size_t)k * nb, nb, 1u << (k - 1));
+    MMT_HIP(hipGetLastError());
+}
+
 void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const uint32_t* pid, const void* pstart, bool wide,
                      uint32_t m_, DevBuf<uint8_t>& temp, hipStream_t s) {
     m = m_;
@@ -232,12 +244,7 @@ void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const 
                            static_cast<const uint32_t*>(pstart), m, counts.get() + 3);
     hipLaunchKernelGGL(k_parse_sl, dim3(grid_for(m, 256)), dim3(256), 0, s, sa_p, head.get(), m, sl.get());
     MMT_HIP(hipGetLastError());
-    bmin.ensure((size_t)levels * nb + 64);
-    hipLaunchKernelGGL(k_block_min, dim3(grid_for((uint64_t)nb * 64, 256)), dim3(256), 0, s, sl.get(), m, bmin.get(), nb);
-    for (uint32_t k = 1; k < levels; k++)
-        hipLaunchKernelGGL(k_level_min, dim3(grid_for(nb, 256)), dim3(256), 0, s, bmin.get() + (size_t)(k - 1) * nb,
-                           bmin.get() + (size_t)k * nb, nb, 1u << (k - 1));
-    MMT_HIP(hipGetLastError());
+    build_rmq(sl.get(), m, bmin, nb, levels, s);
     uint32_t bad = 0;
     MMT_HIP(hipMemcpyAsync(&bad, counts.get() + 3, 4, hipMemcpyDeviceToHost, s));
     MMT_HIP(hipStreamSynchronize(s));

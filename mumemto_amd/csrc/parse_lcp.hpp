@@ -52,6 +52,9 @@ __device__ __forceinline__ uint32_t rmq_min(const RmqView& R, uint32_t a, uint32
     return best;
 }
 
+// block minima over 64 entries + sparse table over the blocks of any array of m values (bmin: levels * nb entries)
+void build_rmq(const uint32_t* vals, uint32_t m, DevBuf<uint32_t>& bmin, uint32_t& nb, uint32_t& levels, hipStream_t s);
+
 struct ParseLcp {
     DevBuf<uint32_t> sl, bmin;
     uint32_t m = 0, nb = 0, levels = 0;

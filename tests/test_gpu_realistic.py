@@ -70,3 +70,36 @@ def test_bucket_wise_producer_on_many_copies_equals_the_oracle(haps, length):
     finally:
         os.environ.pop("MMT_GUIDED_BATCH", None)
         eng.close()
+
+
+@pytest.mark.parametrize("depth,haps,length,small", [(1, 6, 120_000, True), (2, 12, 40_000, True), (24, 6, 300_000, True),
+                                                      (1, 40, 9_000, False), (3, 130, 3_000, True)])
+def test_giant_phrases_of_the_bucket_wise_producer_equal_the_oracle(depth, haps, length, small):
+    """Phrases longer than MMT_GIANT_DEPTH first-key lengths (24 by default: runs of N, microsatellites) are sorted once as
+    a dictionary of their own and every comparison that is still undecided there continues on its ranks and its LCP array
+    (guided.cpp build_giant, guided_kernels.hip cmp_rest).  A depth of one or two key lengths makes most phrases of a
+    small case giant, so that the small-group, medium-group, round and LCP paths all go through the structure; with and
+    without the small-group resolvers."""
+    import mumemto_amd
+    docs = _docs(haps, length, 0.003, 100 + haps, indel_rate=3e-4, inversion_every=4)
+    eng = mumemto_amd.Engine(0)
+    os.environ["MMT_GUIDED_BATCH"] = "90000"
+    os.environ["MMT_GIANT_DEPTH"] = str(depth)
+    if not small:
+        os.environ["MMT_GUIDED_NO_SMALL"] = "1"
+    try:
+        eng.set_producer("guided", 10, 30)
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        for kw in (dict(), dict(num_distinct=max(2, haps - 2), max_doc_freq=2)):
+            eng.set_docs(docs)
+            eng.run(**kw)
+            assert eng.producer_used() == "guided"
+            assert eng.output_text() == O.run(docs, **kw).text(), (depth, haps, kw)
+        assert np.array_equal(eng.sa().astype(np.int64), sa[1:])
+        assert np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
+        assert np.array_equal(eng.bwt(), bwt[1:])
+    finally:
+        for k in ("MMT_GUIDED_BATCH", "MMT_GIANT_DEPTH", "MMT_GUIDED_NO_SMALL"):
+            os.environ.pop(k, None)
+        eng.close()

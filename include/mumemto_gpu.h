@@ -65,7 +65,8 @@ MMT_API int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases,
  *   3 prefix-free parsing without the suffix array of the dictionary (guided.cpp: the text suffixes are sorted by their
  *     characters up to the phrase end, then by the parse; what 0 / 2 fall back to when the dictionary -- as large as
  *     half the text for two unrelated strands -- would not fit);
- * w / p = PFP window and modulus (0 = the reference defaults 10 / 100).  Both give the same stream. */
+ * w / p = PFP window and modulus (0 = chosen by the size of the text, as for the automatic producer; the reference's
+ * defaults are 10 / 100).  The stream does not depend on them. */
 MMT_API int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p);
 MMT_API int mmt_producer_used(const mmt_engine* e);
 

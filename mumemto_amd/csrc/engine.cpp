@@ -1011,7 +1011,8 @@ void Engine::run(const mmt_params& p) {
     if (kind == 3) pfp_want_guided_ = true;
     stream_min_len_ = p.min_match_len;
     ev_[1]->start(stream_);
-    pfp_prepare(producer_ == 0 ? auto_w : pfp_w_, producer_ == 0 ? auto_p : pfp_p_);
+    // (the stream does not depend on the parameters of the parse: a producer named without them gets the automatic ones)
+    pfp_prepare(producer_ == 0 || !pfp_w_ ? auto_w : pfp_w_, producer_ == 0 || !pfp_p_ ? auto_p : pfp_p_);
     pfp_want_guided_ = false;
     ev_[1]->stop(stream_);
     producer_used_ = pfp_->guided ? 3 : 2;

@@ -107,7 +107,7 @@ public:
     bool last_run_partitioned() const { return merged_thresh_valid_; }
     // SA/LCP/BWT producer: 0 = automatic, 1 = direct suffix sort of the text (A8), 2 = prefix-free parsing (A2-A4),
     // 3 = prefix-free parsing without the dictionary's suffix array (guided.cpp; automatic when that would not fit)
-    void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w ? w : 10; pfp_p_ = p ? p : 100; }
+    void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w; pfp_p_ = p; }   // 0: chosen by the size
     int producer_used() const { return producer_used_; }
     // A2 alone (after build_text): phrases, dictionary, parse.  Used by -P / -K and the parity tests.
     void parse_only(bool revcomp, uint32_t w, uint32_t p);
@@ -306,7 +306,7 @@ private:
     std::unique_ptr<PfpState> pfp_{new PfpState()};
     bool lean_ = false;                   // release each stage's scratch before the next stage allocates
     int producer_ = 0, producer_used_ = 1;
-    uint32_t pfp_w_ = 10, pfp_p_ = 100;
+    uint32_t pfp_w_ = 0, pfp_p_ = 0;
     // scan
     DevBuf<k::Cand> d_cand_;
     DevBuf<k::Row> d_rows_;

@@ -388,6 +388,8 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     build_rmq(S.gi_lcp.get(), nd, S.gi_bmin, S.gi_nb, S.gi_levels, st);
     // the occurrences of giant phrases in the parse: phrase index (ascending), first V index, place in the dictionary
     gk::flag_greater(S.plen.get(), m, ctx.g_depth, flags.get(), st);
+    S.gi_bits.ensure(((size_t)m + 31) / 32 + 1);
+    gk::giant_bits(flags.get(), m, S.gi_bits.get(), st);
     DevBuf<uint32_t> occ_idx;
     occ_idx.ensure(m);
     prims::select_indices_u32flags(d_temp_, flags.get(), occ_idx.get(), count.get(), m, st);
@@ -400,7 +402,7 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     MMT_HIP(hipStreamSynchronize(st));
     S.gi_occ = nO; S.gi_distinct = nG; S.gi_chars = nd;
     ctx.g_k = S.gi_k.get(); ctx.g_ps = S.gi_ps.get(); ctx.g_base = S.gi_base.get(); ctx.g_n = nO;
-    ctx.g_isa = S.gi_isa.get(); ctx.g_grp = S.gi_grp.get();
+    ctx.g_isa = S.gi_isa.get(); ctx.g_grp = S.gi_grp.get(); ctx.g_bits = S.gi_bits.get();
     ctx.g_rmq.sl = S.gi_lcp.get(); ctx.g_rmq.bmin = S.gi_bmin.get(); ctx.g_rmq.m = nd; ctx.g_rmq.nb = S.gi_nb;
     if (std::getenv("MMT_GUIDED_STATS"))
         std::fprintf(stderr, "[guided] %u giant distinct phrases (%u characters, sorted in %d rounds), %u occurrences in the parse\n",

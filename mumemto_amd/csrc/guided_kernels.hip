@@ -130,6 +130,7 @@ __device__ __forceinline__ uint64_t make_rec(const Ctx& c, uint64_t q) {
 __device__ __forceinline__ bool giant_entry(const Ctx& c, uint64_t q, uint64_t off, uint32_t& r) {
     if (!c.g_n) return false;
     const uint32_t k = rank1(c, query_point(c, q));
+    if (!((c.g_bits[k >> 5] >> (k & 31)) & 1u)) return false;
     uint32_t lo = 0, hi = c.g_n;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (c.g_k[mid] < k) lo = mid + 1; else hi = mid; }
     if (lo >= c.g_n || c.g_k[lo] != k) return false;
@@ -143,8 +144,9 @@ __device__ __forceinline__ bool giant_entry(const Ctx& c, uint64_t q, uint64_t o
 __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, uint64_t qb, uint64_t lb, uint64_t from,
                                         uint64_t* lcp) {
     const uint64_t L = la < lb ? la : lb;
-    const bool giant = c.g_n && L > c.g_depth && from <= c.g_depth;
-    const uint64_t stop = giant ? (uint64_t)c.g_depth : L;
+    // (64 characters are compared first -- most pairs differ there; two alphas that go on may both lie in giant phrases)
+    const bool giant = c.g_n && from + 64 < L;
+    const uint64_t stop = giant ? from + 64 : L;
     for (uint64_t t = from; t < stop; t += 8) {
         const uint64_t x = load_u64(c.v + qa + t), y = load_u64(c.v + qb + t);
         if (x != y) {
@@ -155,8 +157,8 @@ __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, 
     }
     if (!giant) return 0;
     uint32_t ra = 0, rb = 0;
-    if (!giant_entry(c, qa, c.g_depth, ra) || !giant_entry(c, qb, c.g_depth, rb)) {
-        for (uint64_t t = c.g_depth; t < L; t += 8) {           // (cannot happen: an alpha beyond g_depth lies in a giant phrase)
+    if (!giant_entry(c, qa, stop, ra) || !giant_entry(c, qb, stop, rb)) {
+        for (uint64_t t = stop; t < L; t += 8) {                // one of them in an ordinary phrase: at most g_depth characters
             const uint64_t x = load_u64(c.v + qa + t), y = load_u64(c.v + qb + t);
             if (x != y) {
                 const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
@@ -167,7 +169,7 @@ __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, 
         return 0;
     }
     if (c.g_grp[ra] == c.g_grp[rb]) return 0;
-    if (lcp) *lcp = (uint64_t)c.g_depth + rmq_min(c.g_rmq, (ra < rb ? ra : rb) + 1, ra < rb ? rb : ra);
+    if (lcp) *lcp = stop + rmq_min(c.g_rmq, (ra < rb ? ra : rb) + 1, ra < rb ? rb : ra);
     return ra < rb ? -1 : 1;
 }
 
@@ -566,6 +568,7 @@ struct MedStage {
     uint64_t rank[W];
     uint64_t rec[W];
     uint32_t len[W];
+    uint32_t gr[W], gg[W];            // members in giant phrases: entry of the giant dictionary's suffix array at `offset`, its group
     uint8_t idx[W];
     uint32_t bad;
 };
@@ -577,6 +580,14 @@ __device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_
     const uint64_t la = S.len[a], lb = S.len[b];
     const uint64_t L = la < lb ? la : lb;
     if (lcp) *lcp = ~0ull;
+    if (S.gr[a] != 0xffffffffu && S.gr[b] != 0xffffffffu) {
+        // two members in giant phrases: the giant dictionary knows their order and what they share
+        const uint32_t ra = S.gr[a], rb = S.gr[b];
+        if (S.gg[a] != S.gg[b]) {
+            if (lcp) *lcp = offset + rmq_min(c.g_rmq, (ra < rb ? ra : rb) + 1, ra < rb ? rb : ra);
+            return ra < rb;
+        }
+    } else
 #pragma unroll
     for (uint32_t t = 0; t < MED_WORDS; t++) {
         const uint64_t at = offset + 8 * t;
@@ -631,6 +642,11 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             S.len[i] = len < 0xffffffffull ? (uint32_t)len : 0xffffffffu;
             S.rank[i] = c.skip ? 0ull : rec_rank_key(c, rec, q);
             S.rec[i] = rec;
+            uint32_t r = 0xffffffffu;
+            // (what the staged words cannot decide is looked up, not compared, when the member lies in a giant phrase)
+            if (c.g_n && len > offset + 8 * MED_WORDS && !giant_entry(c, q, offset, r)) r = 0xffffffffu;
+            S.gr[i] = r;
+            S.gg[i] = r != 0xffffffffu ? c.g_grp[r] : 0u;
         }
     }
     // (a wave works on its own stage: ordering its LDS traffic inside the wave is all the synchronisation there is)
@@ -935,6 +951,17 @@ __global__ void k_giant_map(const uint32_t* __restrict__ gids, const uint32_t* _
                             uint32_t* __restrict__ dmap) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dmap[gids[i]] = gstart[i];
+}
+__global__ void k_giant_bits(const uint32_t* __restrict__ flags, uint32_t m, uint32_t* __restrict__ bits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint64_t)i * 32 >= m) return;
+    uint32_t word = 0;
+    for (uint32_t t = 0; t < 32 && (uint64_t)i * 32 + t < m; t++) word |= (flags[(uint64_t)i * 32 + t] ? 1u : 0u) << t;
+    bits[i] = word;
+}
+void giant_bits(const uint32_t* flags, uint32_t m, uint32_t* bits, hipStream_t s) {
+    hipLaunchKernelGGL(k_giant_bits, dim3(grid_for(((uint64_t)m + 31) / 32, 256)), dim3(256), 0, s, flags, m, bits);
+    MMT_HIP(hipGetLastError());
 }
 void giant_map(const uint32_t* gids, const uint32_t* gstart, uint32_t n, uint32_t* dmap, hipStream_t s) {
     hipLaunchKernelGGL(k_giant_map, dim3(grid_for(n, 256)), dim3(256), 0, s, gids, gstart, n, dmap);

@@ -43,6 +43,7 @@ struct Ctx {
     //   id of its group of equal strings; g_rmq over the giant dictionary's LCP array.
     const uint32_t* g_k = nullptr; const uint64_t* g_ps = nullptr; const uint32_t* g_base = nullptr; uint32_t g_n = 0;
     const uint32_t* g_isa = nullptr; const uint32_t* g_grp = nullptr; RmqView g_rmq; uint32_t g_depth = 0;
+    const uint32_t* g_bits = nullptr;                        // bit k: phrase k of the parse is a giant occurrence
 };
 
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions
@@ -95,6 +96,8 @@ void range_groups(const uint32_t* ghead, const uint32_t* big_begin, const uint32
 void flag_greater(const uint32_t* v, uint32_t n, uint32_t thr, uint32_t* flags, hipStream_t s);
 void giant_distinct(const uint32_t* gids, uint32_t n, const uint32_t* rep, const uint32_t* dlen, uint32_t* which, uint32_t* glen,
                     hipStream_t s);
+// bits[k / 32] bit k % 32 = flags[k] != 0
+void giant_bits(const uint32_t* flags, uint32_t m, uint32_t* bits, hipStream_t s);
 void giant_map(const uint32_t* gids, const uint32_t* gstart, uint32_t n, uint32_t* dmap, hipStream_t s);
 void giant_occurrences(const uint32_t* gk, uint32_t n, const uint32_t* pid, const void* pstart, bool wide, const uint32_t* dmap,
                        uint64_t* gps, uint32_t* gbase, hipStream_t s);

@@ -73,7 +73,7 @@ def test_bucket_wise_producer_on_many_copies_equals_the_oracle(haps, length):
 
 
 @pytest.mark.parametrize("depth,haps,length,small", [(1, 6, 120_000, True), (2, 12, 40_000, True), (24, 6, 300_000, True),
-                                                      (1, 40, 9_000, False), (3, 130, 3_000, True)])
+                                                      (1, 40, 9_000, False), (5, 130, 3_000, True), (4, 20, 30_000, False)])
 def test_giant_phrases_of_the_bucket_wise_producer_equal_the_oracle(depth, haps, length, small):
     """Phrases longer than MMT_GIANT_DEPTH first-key lengths (24 by default: runs of N, microsatellites) are sorted once as
     a dictionary of their own and every comparison that is still undecided there continues on its ranks and its LCP array
@@ -102,4 +102,56 @@ def test_giant_phrases_of_the_bucket_wise_producer_equal_the_oracle(depth, haps,
     finally:
         for k in ("MMT_GUIDED_BATCH", "MMT_GIANT_DEPTH", "MMT_GUIDED_NO_SMALL"):
             os.environ.pop(k, None)
+        eng.close()
+
+
+def _flat(haps, length, div, seed):
+    seqs = [s for _, s in synth.haplotypes_realistic(haps, length, div, seed)]
+    lens = np.array([len(s) for s in seqs], np.uint64)
+    return np.concatenate(seqs), lens
+
+
+def test_realistic_collection_of_c3_size():
+    """94 x ~64 Mbp with satellite arrays (1.5 and 2.5 Mbp of a 171-base monomer), microsatellites, gaps of up to 1 Mbp,
+    indels and inversions -- 12.0 G text characters as one suffix array through the parse proper (wide positions, oversized
+    groups of the emitter, giant phrases in the dictionary), through the bucket-wise producer (giant phrases as a dictionary of
+    their own) and as anchor partitions + merge: the same bytes three ways, rows checked against the definition."""
+    import bigchecks
+    import mumemto_amd
+    from test_gpu_fullsize import _partitioned, _same_up_to_the_stream_end_quirk
+    bases, lens = _flat(94, 64_000_000, 0.001, 3)
+    eng = mumemto_amd.Engine(0)
+    try:
+        assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+        assert eng.is_wide() and eng.producer_used() == "pfp" and eng.pfp_counts()["oversized_groups"] > 1000
+        single = eng.output_text()
+        assert single.count(b"\n") > 100_000
+        bigchecks.check_mum_rows(eng, bases, lens)
+        eng.set_producer("guided")
+        assert eng.run_partitioned(None, flat=(bases, lens)) == 1 and eng.producer_used() == "guided"
+        assert eng.output_text() == single
+        eng.set_producer("auto")
+        parts, part = _partitioned(eng, bases, lens, 0.36)
+        assert parts >= 3 and _same_up_to_the_stream_end_quirk(single, part, parts)
+        # partial multi-MEMs with the parameters of BASELINE configs[4]
+        assert eng.run_partitioned(None, flat=(bases, lens), num_distinct=93, max_doc_freq=3) == 1
+        bigchecks.check_mem_rows(eng, bases, lens, min_docs=93, max_doc_freq=3)
+    finally:
+        eng.close()
+
+
+def test_realistic_anchor_next_to_one_whole_genome_haplotype():
+    """{anchor, one haplotype} of ~3.05 Gbp each with the same structures (gaps of 2.4 / 9.5 / 48 Mbp, satellite arrays of 70
+    and 119 Mbp): the unit of the anchor-merge workflow for BASELINE configs[3]; the automatic producer is the bucket-wise one."""
+    import bigchecks
+    import mumemto_amd
+    bases, lens = _flat(2, 3_050_000_000, 0.001, 11)
+    eng = mumemto_amd.Engine(0)
+    try:
+        eng.keep_columns(True)
+        assert eng.run_partitioned(None, flat=(bases, lens)) == 1
+        assert eng.is_wide() and eng.producer_used() == "guided"
+        bigchecks.check_stream(eng, bases, lens, light=True)
+        bigchecks.check_mum_rows(eng, bases, lens)
+    finally:
         eng.close()

@@ -32,6 +32,14 @@ static void offsets_from_counts(DevBuf<uint8_t>& temp, const uint32_t* counts, P
     else prims::exclusive_sum_u32(temp, counts, out.p32(), n, s);
 }
 
+// MMT_MEM_TRACE=1: live / peak bytes of the device heap at the stage boundaries (stderr)
+static void mem_mark(int device, const char* what) {
+    static const bool on = std::getenv("MMT_MEM_TRACE") != nullptr;
+    if (!on) return;
+    const pool::Stats s = pool::stats(device);
+    std::fprintf(stderr, "[mem] %-28s live %7.2f GB  peak %7.2f GB  mapped %7.2f GB\n", what, s.live / 1e9, s.peak / 1e9, s.mapped / 1e9);
+}
+
 // A2 + the dictionary half of A3: phrases, distinct phrases, dictionary text with its suffix
 // array / LCP, phrase ranks, parse.  Requires build_text() to have run.
 // keep_dict_inputs: the phrase table and V stay (PREFIX.dict is written from them: -P / parse_only).
@@ -71,6 +79,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     pk::phrase_bounds(S.cuts.get(), S.n_cuts, n, w, S.pstart.get(), S.plen.get(), W, st);
     if (slim) { S.tcnt.release(); S.toff.release(); S.cuts.release(); }
     e0.stop(st);
+    mem_mark(device_, "triggers + phrases");
 
     // -- distinct phrases: fingerprints, sort, verified grouping
     e1.start(st);
@@ -111,6 +120,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
         S.ord_a.release(); S.order.release(); S.dflags.release(); S.scan.release();
     }
     e1.stop(st);
+    mem_mark(device_, "distinct phrases");
 
     // -- dictionary text (distinct phrases in fingerprint order; ranks come from its suffix array)
     e2.start(st);
@@ -140,6 +150,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             if (S.guided) {
                 S.dict_len = 0;
                 e2.stop(st);
+                mem_mark(device_, "dictionary text");
                 S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms();
                 S.have_parse = false;
                 return;
@@ -160,6 +171,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
                   S.dinfo.get(), nd, pack_prev, W, st);
     if (slim) S.dstart.release();
     e2.stop(st);
+    mem_mark(device_, "dictionary text");
 
     // -- suffix array of the dictionary (dictionary.hpp:133) ...
     e3.start(st);
@@ -173,11 +185,14 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     S.sa_d.ensure(nd); S.rank_d.ensure(nd);
-    sorter_.reserve(std::max(nd, m));
+    sorter_.reserve(slim ? nd : std::max(nd, m));
     k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
-    if (slim) S.rank_d.release();
+    // (the sorter's 49 bytes per dictionary character were the idle half of the run's peak while the tables of the dictionary
+    // were built: a fresh process maps, and gives back at its end, every byte of that peak)
+    if (slim) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); S.rank_d.release(); }
     e3.stop(st);
+    mem_mark(device_, "dictionary suffix array");
     // ... the groups of equal proper phrase suffixes and the phrase ranks
     e4.start(st);
     S.esuf.ensure(nd); S.ephr.ensure(nd); S.ebw.ensure(nd);
@@ -223,6 +238,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
     if (slim) { S.pflag.release(); S.pscan.release(); S.sa_d.release(); S.dict.release(); }
     e4.stop(st);
+    mem_mark(device_, "dictionary groups + LCP");
     S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms(); S.ms[3] = e3.ms(); S.ms[4] = e4.ms();
     S.have_parse = true;
 }
@@ -253,12 +269,14 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     S.sa_p.ensure(m); S.isa_p.ensure(m);
     const int pbits = std::max(1, bit_width_u64((uint64_t)D));
     const int pchars = std::max(1, 64 / pbits);
+    sorter_.reserve(m);
     pk::pack_keys_u32(S.parse.get(), m, pbits, pchars, sorter_.keys_in(), sorter_.vals_in(), st);
     S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
     if (slim) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); S.isa_p.release(); S.parse.release(); }
     // LCP of adjacent parse suffixes + range minima: every LCP value of the stream follows from them locally
     S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
     e5.stop(st);
+    mem_mark(device_, "parse suffix array + LCP");
 
     e6.start(st);
     const int shift = bit_width_u64((uint64_t)m + 1);
@@ -401,6 +419,7 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     S.emit_ready = true;
     S.bwt_ready = true;
     e6.stop(st);
+    mem_mark(device_, "lists + emitter tables");
     S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
     sort_rounds_ = S.rounds_dict;
 }

@@ -11,33 +11,17 @@ namespace mmt {
 
 static int bit_width_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
+// Text-sized scratch: the two key columns and one value column, 20 bytes per suffix.  Everything else is either carved out
+// of a key column that is dead at that point of sort() or sized by the active set (the suffixes the first sort left tied).
 void DoublingSorter::reserve(uint32_t n) {
-    keys_a_.ensure(n); keys_b_.ensure(n);
-    sac_a_.ensure(n); sac_b_.ensure(n); pos_a_.ensure(n); pos_b_.ensure(n); headc_.ensure(n);
-    headval_.ensure(n); head_.ensure(n); idx_.ensure(n); flags_.ensure(n); count_.ensure(4);
-}
-
-bool DoublingSorter::reserve_in(uint8_t* region, size_t bytes, uint32_t n) {
-    const size_t A = 512;
-    auto up = [&](size_t x) { return (x + A - 1) / A * A; };
-    const size_t need = 2 * up((size_t)n * 8) + 8 * up((size_t)n * 4) + up(n) + A;
-    if (!region || bytes < need) { reserve(n); return false; }
-    uint8_t* at = reinterpret_cast<uint8_t*>(up(reinterpret_cast<uintptr_t>(region)));
-    auto take64 = [&](DevBuf<uint64_t>& b) { b.borrow(reinterpret_cast<uint64_t*>(at), n); at += up((size_t)n * 8); };
-    auto take32 = [&](DevBuf<uint32_t>& b) { b.borrow(reinterpret_cast<uint32_t*>(at), n); at += up((size_t)n * 4); };
-    take64(keys_a_); take64(keys_b_);
-    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &headval_, &head_, &idx_}) take32(*b);
-    flags_.borrow(at, n);
-    count_.ensure(4);
-    return true;
+    keys_a_.ensure(n); keys_b_.ensure(n); sac_a_.ensure(n); count_.ensure(4);
 }
 
 // (keys_a_, sac_a_) -> (keys_b_, sac_b_), m active elements grouped by bucket: tiles between bucket boundaries are
 // sorted in LDS, the few ranges holding a bucket longer than a tile by one segmented radix sort.
 void DoublingSorter::release() {
-    keys_a_.release(); keys_b_.release(); flags_.release();
-    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &headval_, &head_, &idx_, &bound_, &big_begin_,
-                                &big_end_})
+    keys_a_.release(); keys_b_.release();
+    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &bound_, &big_begin_, &big_end_})
         b->release();
 }
 
@@ -74,15 +58,24 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
                          hipStream_t s, bool lsb_unique) {
     reserve(n);
     prims::sort_pairs_u64_u32(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sa, n, 0, std::min(64, key_bits), s);
-    k::mark_heads(keys_b_.get(), n, headval_.get(), lsb_unique, s);
-    prims::inclusive_max_u32(temp, headval_.get(), head_.get(), n, s);
-    k::scatter_rank(sa, head_.get(), n, rank, s);
-    k::flag_unsorted(head_.get(), n, flags_.get(), s);
-    prims::select_indices(temp, flags_.get(), idx_.get(), count_.get(), n, s);
+    // the input keys are dead: their column holds the head marks and the index list; the sorted keys die with mark_heads:
+    // their column holds the heads and the flags (n entries each, at fixed places, for every later round as well)
+    uint32_t* const headval = reinterpret_cast<uint32_t*>(keys_a_.get());
+    uint32_t* const idx = headval + n;
+    uint32_t* const head = reinterpret_cast<uint32_t*>(keys_b_.get());
+    uint8_t* const flags = reinterpret_cast<uint8_t*>(head + n);
+    k::mark_heads(keys_b_.get(), n, headval, lsb_unique, s);
+    prims::inclusive_max_u32(temp, headval, head, n, s);
+    k::scatter_rank(sa, head, n, rank, s);
+    k::flag_unsorted(head, n, flags, s);
+    prims::select_indices(temp, flags, idx, count_.get(), n, s);
     uint32_t m = 0;
     MMT_HIP(hipMemcpyAsync(&m, count_.get(), 4, hipMemcpyDeviceToHost, s));
     MMT_HIP(hipStreamSynchronize(s));
-    if (m) k::gather_active(idx_.get(), m, sa, head_.get(), pos_a_.get(), sac_a_.get(), headc_.get(), s);
+    if (m) {
+        pos_a_.ensure(m); pos_b_.ensure(m); headc_.ensure(m); sac_b_.ensure(m);       // the active set only
+        k::gather_active(idx, m, sa, head, pos_a_.get(), sac_a_.get(), headc_.get(), s);
+    }
 
     const int shift = bit_width_u64(n);            // second key component holds values 0..n
     uint64_t h = h0;
@@ -90,18 +83,19 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
     while (m) {
         if (++rounds > 64) throw std::runtime_error("suffix sort did not converge");
         const uint32_t hh = h > 0xffffffffull ? 0xffffffffu : (uint32_t)h;
+        // round keys in keys_a_[0, m) -> sorted in keys_b_[0, m); then the marks over the dead round keys, the heads over the
+        // dead sorted keys
         k::make_round_keys(sac_a_.get(), headc_.get(), m, rank, n, hh, shift, keys_a_.get(), s);
         sort_round(m, shift, temp, s);
-        k::mark_subheads(keys_b_.get(), pos_a_.get(), m, headval_.get(), s);
-        prims::inclusive_max_u32(temp, headval_.get(), head_.get(), m, s);
-        k::apply_round(sac_b_.get(), head_.get(), pos_a_.get(), m, sa, rank, flags_.get(), s);
-        prims::select_indices(temp, flags_.get(), idx_.get(), count_.get(), m, s);
+        k::mark_subheads(keys_b_.get(), pos_a_.get(), m, headval, s);
+        prims::inclusive_max_u32(temp, headval, head, m, s);
+        k::apply_round(sac_b_.get(), head, pos_a_.get(), m, sa, rank, flags, s);
+        prims::select_indices(temp, flags, idx, count_.get(), m, s);
         uint32_t m2 = 0;
         MMT_HIP(hipMemcpyAsync(&m2, count_.get(), 4, hipMemcpyDeviceToHost, s));
         MMT_HIP(hipStreamSynchronize(s));
         if (m2) {
-            k::compact_round(idx_.get(), m2, pos_a_.get(), sac_b_.get(), head_.get(), pos_b_.get(), sac_a_.get(),
-                             headc_.get(), s);
+            k::compact_round(idx, m2, pos_a_.get(), sac_b_.get(), head, pos_b_.get(), sac_a_.get(), headc_.get(), s);
             pos_a_.swap(pos_b_);
         }
         m = m2;

@@ -15,9 +15,6 @@ public:
     // The caller fills keys_in() / vals_in() for n suffixes: keys = first h0 symbols of every
     // suffix packed big-endian into `key_bits` bits (past-the-end = 0 = smallest), vals = 0..n-1.
     void reserve(uint32_t n);
-    // the same with every text-sized scratch column carved out of `region` (memory that another stage will only write
-    // later); falls back to reserve() when the region is too small.  Returns whether the region is in use.
-    bool reserve_in(uint8_t* region, size_t bytes, uint32_t n);
     uint64_t* keys_in() { return keys_a_.get(); }
     uint32_t* vals_in() { return sac_a_.get(); }
     // Sorts; sa_out[j] = j-th smallest suffix, rank_out = its inverse.  Returns #doubling rounds.
@@ -25,7 +22,7 @@ public:
     // such suffixes are final after the first sort, in position order among equal keys.
     int sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa_out, uint32_t* rank_out, DevBuf<uint8_t>& temp,
              hipStream_t s, bool lsb_unique = false);
-    // scratch columns, reusable by the caller between sorts (each holds >= n entries)
+    // scratch columns, reusable by the caller between sorts (ensure() what is needed)
     DevBuf<uint64_t>& keys_a() { return keys_a_; }
     DevBuf<uint64_t>& keys_b() { return keys_b_; }
     DevBuf<uint32_t>& u32_a() { return sac_a_; }
@@ -36,8 +33,7 @@ public:
 private:
     void sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s);
     DevBuf<uint64_t> keys_a_, keys_b_;
-    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, headval_, head_, idx_, count_, bound_, big_begin_, big_end_;
-    DevBuf<uint8_t> flags_;
+    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, count_, bound_, big_begin_, big_end_;
 };
 
 }  // namespace mmt

@@ -5,10 +5,13 @@ from mumemto_amd import synth, build
 haps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 12_100_000
 d = "/tmp/cli_timing"; os.makedirs(d, exist_ok=True)
-docs = synth.pangenome(haps, L, 0.005, 2)
 paths = []
-for i, doc in enumerate(docs):
-    p = os.path.join(d, "h%02d.fa" % i); synth.write_fasta(p, doc, width=80); paths.append(p)
+if len(sys.argv) > 3 and sys.argv[3] == "bench":            # the collection of the bench line (bench.py defaults)
+    for h, bases in synth.haplotypes_sparse(haps, L, 0.001, 3):
+        p = os.path.join(d, "h%02d.fa" % h); synth.write_fasta_fast(p, bases, name="hap%03d" % h); paths.append(p)
+else:
+    for i, doc in enumerate(synth.pangenome(haps, L, 0.005, 2)):
+        p = os.path.join(d, "h%02d.fa" % i); synth.write_fasta(p, doc, width=80); paths.append(p)
 exe = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
 for rep in range(3):
     t = time.perf_counter()
@@ -16,7 +19,7 @@ for rep in range(3):
                        env=dict(os.environ, MUMEMTO_TIMING="1"))
     dt = time.perf_counter() - t
     print("run %d: %.3f s wall, rc %d, %.3f Gbp/s" % (rep, dt, r.returncode, haps * L / dt / 1e9))
-    print("\n".join(l for l in r.stderr.split("\n") if "sec" in l or "stages" in l or "[timing]" in l))
+    print("\n".join(l for l in r.stderr.split("\n") if "sec" in l or "stages" in l or "[timing]" in l or "[mem]" in l))
 print(os.path.getsize(os.path.join(d, "out.mums")), "bytes of .mums")
 t = time.perf_counter(); subprocess.run([exe], capture_output=True); print("no arguments (load + exit): %.3f s" % (time.perf_counter() - t))
 t = time.perf_counter()

@@ -13,10 +13,12 @@ else:
     for i, doc in enumerate(synth.pangenome(haps, L, 0.005, 2)):
         p = os.path.join(d, "h%02d.fa" % i); synth.write_fasta(p, doc, width=80); paths.append(p)
 exe = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
-for rep in range(3):
+reps = int(os.environ.get("CLI_REPS", "3"))
+for rep in range(reps):
+    extra = {}
     t = time.perf_counter()
     r = subprocess.run([exe, "-o", os.path.join(d, "out")] + paths, capture_output=True, text=True,
-                       env=dict(os.environ, MUMEMTO_TIMING="1"))
+                       env=dict(os.environ, MUMEMTO_TIMING="1", **extra))
     dt = time.perf_counter() - t
     print("run %d: %.3f s wall, rc %d, %.3f Gbp/s" % (rep, dt, r.returncode, haps * L / dt / 1e9))
     print("\n".join(l for l in r.stderr.split("\n") if "sec" in l or "stages" in l or "[timing]" in l or "[mem]" in l))

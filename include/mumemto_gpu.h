@@ -208,6 +208,14 @@ MMT_API int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k
  * another -l passes that value here.                                                                                 */
 MMT_API int mmt_anchor_merge_min_len(mmt_engine* e, const mmt_partition* parts, size_t k, uint32_t min_len,
                                      mmt_merged** out);
+/* The same table computed as `slices` independent slices of the anchor: slice [lo, hi) folds from the rows
+ * that start in [lo - margin, hi) and the thresholds of that range, margin = (k - 1) x the longest row + 1.  On one engine
+ * the slices run one after the other; mmt_dist_merge_ranges gives every rank of a communicator its own.               */
+MMT_API int mmt_anchor_merge_by_ranges(mmt_engine* e, const mmt_partition* parts, size_t k, int slices, uint32_t min_len,
+                                       mmt_merged** out);
+/* The arithmetic of that fold, on the host (no device needed): slice r of `world` is [bounds[0], bounds[1]) and folds from
+ * [bounds[2], bounds[1]), for an anchor of thresh_len = L_0 + 1 entries, k partitions and a longest row of `longest`.    */
+MMT_API int mmt_fold_slice_bounds(uint64_t thresh_len, int world, int r, size_t k, uint32_t longest, uint64_t bounds[3]);
 MMT_API size_t mmt_merged_rows(const mmt_merged* m);
 MMT_API size_t mmt_merged_docs(const mmt_merged* m);
 MMT_API int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands,
@@ -244,6 +252,11 @@ MMT_API void mmt_comm_destroy(mmt_comm* c);
  * re-sorts into direct-run order: *out is the merged result on rank 0 (mmt_merged_text / _get / _free) and NULL on the
  * other ranks.  min_len = the run's -l (the reference's tool hard-codes 20).                                          */
 MMT_API int  mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** out);
+/* The same result with the fold itself spread over the ranks (dist.cpp dist_merge_ranges): rows are broadcast, of the
+ * thresholds -- 2 bytes per anchor position and rank -- every rank receives only its slice of the anchor from every other
+ * rank (all-to-all), folds it, and sends its piece to rank 0.  mmt_dist_merge does this by itself from four ranks on
+ * (MUMEMTO_RANGE_FOLD=0 / 1 overrides).                                                                                */
+MMT_API int  mmt_dist_merge_ranges(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** out);
 /* Modes without a partition merge (mmt_engine_set_scan_shard): the ranks' output bytes, concatenated in rank order, on
  * rank 0 (*len = 0 elsewhere); valid until the next call on this communicator.                                        */
 MMT_API int  mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len);

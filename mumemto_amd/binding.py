@@ -72,7 +72,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
-    "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
+    "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
     "mmt_stream_stats",
 ]
@@ -170,6 +170,10 @@ def load_library():
     L.mmt_partitions_used.argtypes = [C.c_void_p]
     L.mmt_copy_merged_thresh.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_anchor_merge.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mmt_anchor_merge_by_ranges.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.c_int, C.c_uint32,
+                                             C.POINTER(C.c_void_p)]
+    L.mmt_dist_merge_ranges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.mmt_fold_slice_bounds.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64)]
     L.mmt_anchor_merge_min_len.argtypes = [C.c_void_p, C.POINTER(Partition), C.c_size_t, C.c_uint32,
                                            C.POINTER(C.c_void_p)]
     L.mmt_merged_get.argtypes = [C.c_void_p] * 5
@@ -528,7 +532,7 @@ class Engine:
         return list(out)
 
     # anchor merge
-    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20, text_file=None):
+    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20, text_file=None, slices=0):
         """parts: list of DevicePartition, or of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh)
         where thresh is a numpy u16 array (host) or a device address paired as (ptr, length).
         want_rows=False returns only the PREFIX.mums bytes (no D2H of the tables); text_file: the library writes them
@@ -556,7 +560,10 @@ class Engine:
             arr[i] = Partition(len(length), off.shape[1], _p(length).value, _p(off).value, _p(st).value, tptr, tlen,
                                on_dev, 0)
         m = C.c_void_p()
-        _check(self.L.mmt_anchor_merge_min_len(self.h, arr, len(parts), C.c_uint32(min_len), C.byref(m)))
+        if slices:      # the same table as `slices` independent slices of the anchor (what `slices` ranks fold at once)
+            _check(self.L.mmt_anchor_merge_by_ranges(self.h, arr, len(parts), int(slices), C.c_uint32(min_len), C.byref(m)))
+        else:
+            _check(self.L.mmt_anchor_merge_min_len(self.h, arr, len(parts), C.c_uint32(min_len), C.byref(m)))
         try:
             if sort_like_direct:
                 _check(self.L.mmt_merged_sort_like_direct(self.h, m))
@@ -630,10 +637,12 @@ class Comm:
             self.L.mmt_comm_destroy(self.h)
             self.h = None
 
-    def merge(self, min_len=20):
-        """Strict multi-MUMs: exchange + fold + re-sort.  Rank 0 gets {"text", "n_rows", "n_docs"}, the others None."""
+    def merge(self, min_len=20, by_ranges=False):
+        """Strict multi-MUMs: exchange + fold + re-sort.  Rank 0 gets {"text", "n_rows", "n_docs"}, the others None.
+        by_ranges: every rank folds its slice of the anchor (automatic from four ranks on)."""
         m = C.c_void_p()
-        _check(self.L.mmt_dist_merge(self.h, self.engine.h, C.c_uint32(min_len), C.byref(m)))
+        f = self.L.mmt_dist_merge_ranges if by_ranges else self.L.mmt_dist_merge
+        _check(f(self.h, self.engine.h, C.c_uint32(min_len), C.byref(m)))
         if not m:
             return None
         try:

@@ -555,6 +555,23 @@ int mmt_anchor_merge_min_len(mmt_engine* e, const mmt_partition* parts, size_t k
     *out = m.release();
     MMT_CATCH
 }
+int mmt_fold_slice_bounds(uint64_t thresh_len, int world, int r, size_t k, uint32_t longest, uint64_t bounds[3]) {
+    if (!bounds || world < 1 || r < 0 || r >= world) return fail(1, "slice out of range");
+    mmt::fold_slice_bounds(thresh_len, world, r, mmt::fold_margin(k, longest), &bounds[0], &bounds[1], &bounds[2]);
+    return 0;
+}
+int mmt_anchor_merge_by_ranges(mmt_engine* e, const mmt_partition* parts, size_t k, int slices, uint32_t min_len,
+                               mmt_merged** out) {
+    if (!e || !parts || !out) return fail(1, "engine, parts and out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    if (k < 2) throw std::invalid_argument("anchor merge requires at least two partitions");
+    std::unique_ptr<mmt_merged> m(new mmt_merged());
+    m->rows = mmt::anchor_merge_by_ranges(*e->e, parts, k, slices, min_len);
+    m->engine = e->e.get();
+    *out = m.release();
+    MMT_CATCH
+}
 size_t mmt_merged_rows(const mmt_merged* m) { return m ? m->rows.n_rows : 0; }
 size_t mmt_merged_docs(const mmt_merged* m) { return m ? m->rows.n_docs : 0; }
 int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands, uint16_t* thresh) {
@@ -636,6 +653,20 @@ int mmt_dist_merge(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** ou
     MMT_TRY
     bool root = false;
     mmt::MergedRows rows = mmt::dist_merge(*c->c, min_len, &root);
+    if (root) {
+        std::unique_ptr<mmt_merged> m(new mmt_merged());
+        m->rows = std::move(rows);
+        m->engine = e->e.get();
+        *out = m.release();
+    }
+    MMT_CATCH
+}
+int mmt_dist_merge_ranges(mmt_comm* c, mmt_engine* e, uint32_t min_len, mmt_merged** out) {
+    if (!c || !e || !out) return fail(1, "comm, engine and out must be non-null");
+    *out = nullptr;
+    MMT_TRY
+    bool root = false;
+    mmt::MergedRows rows = mmt::dist_merge_ranges(*c->c, min_len, &root);
     if (root) {
         std::unique_ptr<mmt_merged> m(new mmt_merged());
         m->rows = std::move(rows);

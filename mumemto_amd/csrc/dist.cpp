@@ -140,7 +140,14 @@ static std::vector<uint64_t> exchange_meta(Comm& c, uint64_t rows, uint64_t docs
 
 // Strict multi-MUMs.  The engine's last run must have been this rank's partition with merge metadata on.
 // Returns the merged rows on rank 0 (already in direct-run order), an empty MergedRows elsewhere.
+int comm_world(const Comm& c) { return c.world; }
+
 MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
+    {
+        // from four ranks on the fold itself is spread over the ranks (dist_merge_ranges below)
+        const char* env = std::getenv("MUMEMTO_RANGE_FOLD");
+        if (env ? std::string(env) == "1" : c.world >= 4) return dist_merge_ranges(c, min_len, is_root);
+    }
     Engine& e = *c.engine;
     MMT_HIP(hipSetDevice(e.device()));
     hipStream_t st = e.stream();
@@ -204,6 +211,114 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
         return m;
     }
     MergedRows m = anchor_merge(e, parts.data(), parts.size(), min_len);
+    sort_like_direct(e, m);
+    return m;
+}
+
+// The same result by coordinate ranges (merge.cpp): every rank folds ITS slice of the anchor.  Rows -- small --
+// are broadcast to everyone (one group); of the thresholds, 2 bytes per anchor position and rank, every rank receives only
+// its slice [base, hi) from every other rank (an all-to-all of world x world messages in one group, over all xGMI links at
+// once instead of everything into rank 0's); the pieces go to rank 0 in rank order = anchor order.  Rank 0's work drops from
+// world - 1 fold steps over the whole anchor to world - 1 steps over 1 / world of it.
+MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root) {
+    Engine& e = *c.engine;
+    MMT_HIP(hipSetDevice(e.device()));
+    hipStream_t st = e.stream();
+    if (is_root) *is_root = c.rank == 0;
+    const HostRows& R = e.rows_meta();
+    if (!R.mum_mode || !e.thresh_len()) throw std::runtime_error("the exchange needs a multi-MUM run with merge metadata");
+    const uint64_t L = e.doc_len()[0] + 1;
+    const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
+    e.rows_mum_device(&my_len, &my_off, &my_st);
+    const uint32_t my_longest = longest_row(e, my_len, R.n_rows, true);
+    std::vector<uint64_t> meta;
+    {
+        // (rows, documents, longest row) of every rank
+        uint64_t mine[4] = {R.n_rows, R.n_docs, my_longest, 0};
+        DevBuf<uint64_t> d_mine;
+        d_mine.ensure(4);
+        MMT_HIP(hipMemcpyAsync(d_mine.get(), mine, 32, hipMemcpyHostToDevice, st));
+        MMT_NCCL(rccl().AllGather(d_mine.get(), c.d_meta.get(), 4, ncclUint64, c.comm, st));
+        meta.resize((size_t)c.world * 4);
+        MMT_HIP(hipMemcpyAsync(meta.data(), c.d_meta.get(), meta.size() * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+    }
+    uint32_t longest = 0;
+    for (int r = 0; r < c.world; r++) longest = std::max<uint32_t>(longest, (uint32_t)meta[(size_t)r * 4 + 2]);
+    const uint64_t margin = fold_margin((size_t)c.world, longest);
+    std::vector<uint64_t> lo((size_t)c.world), hi((size_t)c.world), base((size_t)c.world);
+    for (int r = 0; r < c.world; r++) fold_slice_bounds(L, c.world, r, margin, &lo[r], &hi[r], &base[r]);
+    const uint64_t my_span = hi[c.rank] - base[c.rank];
+    // rows of everyone to everyone, threshold slices all-to-all
+    MMT_NCCL(rccl().GroupStart());
+    for (int r = 0; r < c.world; r++) {
+        const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
+        if (r != c.rank) { c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); }
+        if (rows) {
+            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)my_len : c.len[r]->get(), r == c.rank ? (void*)my_len : c.len[r]->get(),
+                                      rows, ncclUint32, r, c.comm, st));
+            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)my_off : c.off[r]->get(), r == c.rank ? (void*)my_off : c.off[r]->get(),
+                                      cells, ncclInt64, r, c.comm, st));
+            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)my_st : c.st[r]->get(), r == c.rank ? (void*)my_st : c.st[r]->get(),
+                                      cells, ncclUint8, r, c.comm, st));
+        }
+    }
+    for (int r = 0; r < c.world; r++) {
+        if (r == c.rank) continue;
+        c.th[r]->ensure(my_span + 1);
+        MMT_NCCL(rccl().Send(e.thresh_device() + base[r], (hi[r] - base[r]) * 2, ncclUint8, r, c.comm, st));
+        MMT_NCCL(rccl().Recv(c.th[r]->get(), my_span * 2, ncclUint8, r, c.comm, st));
+    }
+    MMT_NCCL(rccl().GroupEnd());
+    MMT_HIP(hipStreamSynchronize(st));
+    // this rank's slice
+    std::vector<mmt_partition> parts((size_t)c.world);
+    for (int r = 0; r < c.world; r++) {
+        mmt_partition& p = parts[(size_t)r];
+        p.n_rows = meta[(size_t)r * 4]; p.n_docs = meta[(size_t)r * 4 + 1];
+        if (r == c.rank) { p.length = my_len; p.offsets = my_off; p.strands = my_st; p.thresh = e.thresh_device() + base[c.rank]; }
+        else { p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get(); }
+        p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1;
+    }
+    MergedRows piece;
+    if (c.world == 1) {
+        piece = anchor_merge_slice(e, parts.data(), 1, min_len, 0, L, 0, true);
+        sort_like_direct(e, piece);
+        return piece;
+    }
+    piece = anchor_merge_slice(e, parts.data(), parts.size(), min_len, lo[c.rank], hi[c.rank], base[c.rank], true);
+    // the pieces to rank 0, in rank order
+    const std::vector<uint64_t> pm = exchange_meta(c, piece.n_rows, piece.n_docs, 0);
+    std::vector<MergedRows> pieces;
+    MMT_NCCL(rccl().GroupStart());
+    if (c.rank != 0) {
+        const size_t rows = piece.n_rows, cells = rows * piece.n_docs;
+        if (rows) {
+            MMT_NCCL(rccl().Send(piece.d_length.get(), rows, ncclUint32, 0, c.comm, st));
+            MMT_NCCL(rccl().Send(piece.d_offsets.get(), cells, ncclInt64, 0, c.comm, st));
+            MMT_NCCL(rccl().Send(piece.d_strands.get(), cells, ncclUint8, 0, c.comm, st));
+        }
+        MMT_NCCL(rccl().Send(piece.d_thresh.get(), piece.thresh_len * 2, ncclUint8, 0, c.comm, st));
+    } else {
+        pieces.resize((size_t)c.world);
+        pieces[0] = std::move(piece);
+        for (int r = 1; r < c.world; r++) {
+            MergedRows& p = pieces[(size_t)r];
+            p.n_rows = pm[(size_t)r * 4]; p.n_docs = pm[(size_t)r * 4 + 1]; p.thresh_len = hi[r] - lo[r];
+            const size_t cells = p.n_rows * p.n_docs;
+            p.d_length.ensure(p.n_rows + 1); p.d_offsets.ensure(cells + 1); p.d_strands.ensure(cells + 1); p.d_thresh.ensure(p.thresh_len + 1);
+            if (p.n_rows) {
+                MMT_NCCL(rccl().Recv(p.d_length.get(), p.n_rows, ncclUint32, r, c.comm, st));
+                MMT_NCCL(rccl().Recv(p.d_offsets.get(), cells, ncclInt64, r, c.comm, st));
+                MMT_NCCL(rccl().Recv(p.d_strands.get(), cells, ncclUint8, r, c.comm, st));
+            }
+            MMT_NCCL(rccl().Recv(p.d_thresh.get(), p.thresh_len * 2, ncclUint8, r, c.comm, st));
+        }
+    }
+    MMT_NCCL(rccl().GroupEnd());
+    MMT_HIP(hipStreamSynchronize(st));
+    if (c.rank != 0) return MergedRows();
+    MergedRows m = concat_pieces(e, pieces);
     sort_like_direct(e, m);
     return m;
 }

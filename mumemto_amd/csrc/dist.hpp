@@ -13,6 +13,8 @@ void comm_unique_id(uint8_t out[128]);                                          
 Comm* comm_create(Engine& e, int rank, int world, const uint8_t id[128]);         // collective
 void comm_destroy(Comm* c);
 MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root);                  // collective; rows on rank 0
+MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root);           // the same, every rank folds its slice of the anchor
+int comm_world(const Comm& c);
 std::string dist_gather_text(Comm& c);                                            // collective; bytes on rank 0
 // (no exchange of columns: a rank of a sharded run produces, scans and drops its own share of the stream)
 

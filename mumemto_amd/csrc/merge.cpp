@@ -212,6 +212,149 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
     return m;
 }
 
+// ---- the fold by coordinate ranges -----------------------------------------------------------------------
+// A row of the fold that starts at anchor position x is decided by the rows and thresholds of every partition within
+// (partitions - 1) x the longest row to its left (one row length per fold step) and up to its own end to the right: a slice
+// [lo, hi) of the anchor folds by itself from the rows that start in [base, hi) and the thresholds [base, hi), base = lo -
+// margin.  N ranks fold N slices at once, and of the thresholds -- 2 bytes per anchor position and partition, 6 GB for a whole
+// genome -- every rank needs its slice only.
+uint64_t fold_margin(size_t k, uint32_t longest) { return (uint64_t)(k ? k - 1 : 0) * longest + 1; }
+
+void fold_slice_bounds(uint64_t L, int world, int r, uint64_t margin, uint64_t* lo, uint64_t* hi, uint64_t* base) {
+    *lo = L * (uint64_t)r / (uint64_t)world;
+    *hi = L * (uint64_t)(r + 1) / (uint64_t)world;
+    *base = *lo > margin ? *lo - margin : 0;
+}
+
+// rows of `in` (device tables) whose anchor offset + shift lies in [lo, hi), anchor offsets moved by delta
+static void filter_rows(Engine& e, const uint32_t* len, const int64_t* off, const uint8_t* st, uint32_t n, uint32_t n_docs,
+                        int64_t shift, int64_t lo, int64_t hi, int64_t delta, DevBuf<uint32_t>& o_len, DevBuf<int64_t>& o_off,
+                        DevBuf<uint8_t>& o_st, uint32_t* kept) {
+    hipStream_t st_ = e.stream();
+    DevBuf<uint8_t> flags;
+    DevBuf<uint32_t> idx, count;
+    flags.ensure((size_t)n + 1); idx.ensure((size_t)n + 1); count.ensure(4);
+    uint32_t m = 0;
+    if (n) {
+        mk::range_flags(off, n, n_docs, shift, lo, hi, flags.get(), st_);
+        prims::select_indices(e.scratch(), flags.get(), idx.get(), count.get(), n, st_);
+        MMT_HIP(hipMemcpyAsync(&m, count.get(), 4, hipMemcpyDeviceToHost, st_));
+        MMT_HIP(hipStreamSynchronize(st_));
+    }
+    o_len.ensure((size_t)m + 1); o_off.ensure((size_t)m * n_docs + 1); o_st.ensure((size_t)m * n_docs + 1);
+    if (m) {
+        mk::permute_rows(idx.get(), m, n_docs, len, off, st, o_len.get(), o_off.get(), o_st.get(), st_);
+        mk::shift_anchor(o_off.get(), m, n_docs, delta, st_);
+    }
+    MMT_HIP(hipStreamSynchronize(st_));
+    *kept = m;
+}
+
+MergedRows anchor_merge_slice(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len, uint64_t lo, uint64_t hi,
+                              uint64_t base, bool thresh_is_slice) {
+    MMT_HIP(hipSetDevice(e.device()));
+    hipStream_t st = e.stream();
+    struct Held { DevBuf<uint32_t> len, in_len; DevBuf<int64_t> off, in_off; DevBuf<uint8_t> str, in_str; DevBuf<uint16_t> th; };
+    std::vector<std::unique_ptr<Held>> held(k);
+    std::vector<mmt_partition> sliced(k);
+    for (size_t g = 0; g < k; g++) {
+        const mmt_partition& P = parts[g];
+        held[g].reset(new Held());
+        Held& H = *held[g];
+        if (P.n_rows >= 0xffffffffull) throw std::runtime_error("too many rows in a partition");
+        const uint32_t n = (uint32_t)P.n_rows, nd = (uint32_t)P.n_docs;
+        const uint32_t* len = P.length; const int64_t* off = P.offsets; const uint8_t* str = P.strands;
+        if (!P.rows_on_device && n) {
+            H.in_len.ensure(n); H.in_off.ensure((size_t)n * nd); H.in_str.ensure((size_t)n * nd);
+            MMT_HIP(hipMemcpyAsync(H.in_len.get(), P.length, (size_t)n * 4, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipMemcpyAsync(H.in_off.get(), P.offsets, (size_t)n * nd * 8, hipMemcpyHostToDevice, st));
+            MMT_HIP(hipMemcpyAsync(H.in_str.get(), P.strands, (size_t)n * nd, hipMemcpyHostToDevice, st));
+            len = H.in_len.get(); off = H.in_off.get(); str = H.in_str.get();
+        }
+        uint32_t kept = 0;
+        filter_rows(e, len, off, str, n, nd, 0, (int64_t)base, (int64_t)hi, -(int64_t)base, H.len, H.off, H.str, &kept);
+        H.in_len.release(); H.in_off.release(); H.in_str.release();
+        mmt_partition& Q = sliced[g];
+        Q = P;
+        Q.n_rows = kept; Q.length = H.len.get(); Q.offsets = H.off.get(); Q.strands = H.str.get(); Q.rows_on_device = 1;
+        const uint16_t* th = P.thresh + (thresh_is_slice ? 0 : base);
+        if (!P.thresh_on_device) {
+            H.th.ensure(hi - base);
+            MMT_HIP(hipMemcpyAsync(H.th.get(), th, (hi - base) * 2, hipMemcpyHostToDevice, st));
+            th = H.th.get();
+        }
+        Q.thresh = th; Q.thresh_len = hi - base; Q.thresh_on_device = 1;
+    }
+    MergedRows whole = anchor_merge(e, sliced.data(), k, min_len);
+    held.clear();
+    // the rows that start in [lo, hi), in the coordinates of the whole anchor; the thresholds of [lo, hi)
+    MergedRows piece;
+    piece.n_docs = whole.n_docs; piece.thresh_len = hi - lo;
+    uint32_t kept = 0;
+    filter_rows(e, whole.d_length.get(), whole.d_offsets.get(), whole.d_strands.get(), (uint32_t)whole.n_rows, (uint32_t)whole.n_docs,
+                (int64_t)base, (int64_t)lo, (int64_t)hi, (int64_t)base, piece.d_length, piece.d_offsets, piece.d_strands, &kept);
+    piece.n_rows = kept;
+    piece.d_thresh.ensure(hi - lo + 1);
+    MMT_HIP(hipMemcpyAsync(piece.d_thresh.get(), whole.d_thresh.get() + (lo - base), (hi - lo) * 2, hipMemcpyDeviceToDevice, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    return piece;
+}
+
+MergedRows concat_pieces(Engine& e, std::vector<MergedRows>& pieces) {
+    hipStream_t st = e.stream();
+    MergedRows m;
+    if (pieces.empty()) return m;
+    m.n_docs = pieces[0].n_docs;
+    for (const MergedRows& p : pieces) { m.n_rows += p.n_rows; m.thresh_len += p.thresh_len; }
+    m.d_length.ensure(m.n_rows + 1); m.d_offsets.ensure(m.n_rows * m.n_docs + 1); m.d_strands.ensure(m.n_rows * m.n_docs + 1);
+    m.d_thresh.ensure(m.thresh_len + 1);
+    size_t row = 0, pos = 0;
+    for (const MergedRows& p : pieces) {
+        if (p.n_docs != m.n_docs) throw std::runtime_error("the pieces of a range fold disagree on the number of documents");
+        if (p.n_rows) {
+            MMT_HIP(hipMemcpyAsync(m.d_length.get() + row, p.d_length.get(), p.n_rows * 4, hipMemcpyDeviceToDevice, st));
+            MMT_HIP(hipMemcpyAsync(m.d_offsets.get() + row * m.n_docs, p.d_offsets.get(), p.n_rows * m.n_docs * 8, hipMemcpyDeviceToDevice, st));
+            MMT_HIP(hipMemcpyAsync(m.d_strands.get() + row * m.n_docs, p.d_strands.get(), p.n_rows * m.n_docs, hipMemcpyDeviceToDevice, st));
+        }
+        if (p.thresh_len)
+            MMT_HIP(hipMemcpyAsync(m.d_thresh.get() + pos, p.d_thresh.get(), p.thresh_len * 2, hipMemcpyDeviceToDevice, st));
+        row += p.n_rows; pos += p.thresh_len;
+    }
+    MMT_HIP(hipStreamSynchronize(st));
+    return m;
+}
+
+// the longest row of a partition (device or host table)
+uint32_t longest_row(Engine& e, const uint32_t* length, size_t n_rows, bool on_device) {
+    if (!n_rows) return 0;
+    std::vector<uint32_t> h;
+    const uint32_t* p = length;
+    if (on_device) {
+        h.resize(n_rows);
+        MMT_HIP(hipMemcpyAsync(h.data(), length, n_rows * 4, hipMemcpyDeviceToHost, e.stream()));
+        MMT_HIP(hipStreamSynchronize(e.stream()));
+        p = h.data();
+    }
+    return *std::max_element(p, p + n_rows);
+}
+
+// anchor_merge(parts) computed as `slices` independent slices of the anchor, one after the other on this device: what
+// `slices` ranks do at once (dist.cpp dist_merge_ranges); the result is the same table
+MergedRows anchor_merge_by_ranges(Engine& e, const mmt_partition* parts, size_t k, int slices, uint32_t min_len) {
+    if (slices < 1) throw std::invalid_argument("a range fold needs at least one slice");
+    const uint64_t L = parts[0].thresh_len;
+    uint32_t longest = 0;
+    for (size_t g = 0; g < k; g++) longest = std::max(longest, longest_row(e, parts[g].length, parts[g].n_rows, parts[g].rows_on_device != 0));
+    const uint64_t margin = fold_margin(k, longest);
+    std::vector<MergedRows> pieces;
+    for (int r = 0; r < slices; r++) {
+        uint64_t lo, hi, base;
+        fold_slice_bounds(L, slices, r, margin, &lo, &hi, &base);
+        pieces.push_back(anchor_merge_slice(e, parts, k, min_len, lo, hi, base, false));
+    }
+    return concat_pieces(e, pieces);
+}
+
 void sort_like_direct(Engine& e, MergedRows& m) {
     const size_t n = m.n_rows;
     if (!n) return;

@@ -14,6 +14,17 @@ namespace mmt {
 // (mmt_partition.rows_on_device); everything after the upload runs on the device and the merged
 // rows stay there.  min_len: minimum length of a merged MUM; the reference hard-codes 20.
 MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len = 20);
+// The same fold by coordinate ranges: slice r of `world` near-equal slices [lo, hi) of the anchor is folded
+// from the rows that start in [base, hi) and the thresholds [base, hi), base = lo - margin (merge.cpp).
+uint64_t fold_margin(size_t k, uint32_t longest_row);
+void fold_slice_bounds(uint64_t L, int world, int r, uint64_t margin, uint64_t* lo, uint64_t* hi, uint64_t* base);
+uint32_t longest_row(Engine& e, const uint32_t* length, size_t n_rows, bool on_device);
+// rows that start in [lo, hi) and thresholds [lo, hi) of anchor_merge(parts); thresh_is_slice: parts[g].thresh points at
+// entry `base`, not at entry 0
+MergedRows anchor_merge_slice(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len, uint64_t lo, uint64_t hi,
+                              uint64_t base, bool thresh_is_slice);
+MergedRows concat_pieces(Engine& e, std::vector<MergedRows>& pieces);
+MergedRows anchor_merge_by_ranges(Engine& e, const mmt_partition* parts, size_t k, int slices, uint32_t min_len = 20);
 // Direct-run order: sort by the suffix rank of the anchor occurrence.
 void sort_like_direct(Engine& e, MergedRows& m);
 // mumsio::write_mums / serialize_mum (include/mumsio.hpp:281-294, :311-320), formatted on the device

@@ -143,6 +143,30 @@ void permute_rows(const uint32_t* perm, uint32_t n, uint32_t n_docs, const uint3
     MMT_HIP(hipGetLastError());
 }
 
+// rows of a coordinate-range fold: flags[r] = the anchor offset of row r (+ shift) lies in [lo, hi)
+__global__ void k_range_flags(const int64_t* __restrict__ off, uint32_t n, uint32_t n_docs, int64_t shift, int64_t lo, int64_t hi,
+                              uint8_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t a = off[(uint64_t)r * n_docs] + shift;
+    flags[r] = a >= lo && a < hi ? 1 : 0;
+}
+void range_flags(const int64_t* off, uint32_t n, uint32_t n_docs, int64_t shift, int64_t lo, int64_t hi, uint8_t* flags,
+                 hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_range_flags, dim3((n + 255) / 256), dim3(256), 0, s, off, n, n_docs, shift, lo, hi, flags);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_shift_anchor(int64_t* __restrict__ off, uint32_t n, uint32_t n_docs, int64_t delta) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) off[(uint64_t)r * n_docs] += delta;
+}
+void shift_anchor(int64_t* off, uint32_t n, uint32_t n_docs, int64_t delta, hipStream_t s) {
+    if (!n || !delta) return;
+    hipLaunchKernelGGL(k_shift_anchor, dim3((n + 255) / 256), dim3(256), 0, s, off, n, n_docs, delta);
+    MMT_HIP(hipGetLastError());
+}
+
 __global__ void k_rank_keys(const int64_t* __restrict__ off, uint32_t n, uint32_t n_docs,
                             const uint32_t* __restrict__ isa, uint64_t anchor_len, uint32_t* __restrict__ keys,
                             uint32_t* __restrict__ vals, uint32_t* __restrict__ bad) {

@@ -44,6 +44,10 @@ void materialise(SideView side, const uint32_t* perm, const PartTable* parts /* 
 // out row i = in row perm[i]
 void permute_rows(const uint32_t* perm, uint32_t n, uint32_t n_docs, const uint32_t* in_len, const int64_t* in_off,
                   const uint8_t* in_st, uint32_t* out_len, int64_t* out_off, uint8_t* out_st, hipStream_t s);
+// coordinate-range fold: flags[r] = offsets[r * n_docs] + shift in [lo, hi); offsets[r * n_docs] += delta
+void range_flags(const int64_t* off, uint32_t n, uint32_t n_docs, int64_t shift, int64_t lo, int64_t hi, uint8_t* flags,
+                 hipStream_t s);
+void shift_anchor(int64_t* off, uint32_t n, uint32_t n_docs, int64_t delta, hipStream_t s);
 // keys[r] = isa[offsets[r * n_docs]] (suffix rank of the anchor occurrence), vals[r] = r
 void rank_keys(const int64_t* off, uint32_t n, uint32_t n_docs, const uint32_t* isa, uint64_t anchor_len,
                uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t s);

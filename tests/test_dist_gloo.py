@@ -201,3 +201,28 @@ def test_three_rank_fold_over_coordinate_ranges_with_threshold_all_to_all():
     for rank in range(world):
         gl, go, gs = got[rank]
         assert np.array_equal(gl, ml) and np.array_equal(go, mo) and np.array_equal(gs, ms)
+
+
+def test_native_slice_arithmetic_equals_the_python_fold_and_tiles_the_anchor():
+    """mmt_fold_slice_bounds (merge.cpp fold_slice_bounds / fold_margin: what every rank of dist_merge_ranges and every
+    slice of mmt_anchor_merge_by_ranges computes) on the host, no device: the slices tile [0, L) in rank order, each reads
+    from lo - ((k - 1) x longest + 1) (clamped at 0), and they are the slices of mdist.fold_slices / fold_margin -- also for
+    more ranks than anchor positions, eight ranks of a whole-genome anchor and a margin longer than a slice."""
+    import ctypes as C
+    from mumemto_amd import binding
+    from mumemto_amd import dist as mdist
+    L = binding.load_library()
+    for thresh_len, world, k, longest in ((12001, 3, 3, 800), (5, 8, 8, 3), (3_050_000_001, 8, 8, 65535),
+                                          (64_000_001, 4, 4, 40_000_000), (1, 1, 2, 0), (1000, 7, 2, 20)):
+        margin = mdist.fold_margin([(np.array([longest], np.uint32),)] * k)
+        assert margin == (k - 1) * longest + 1
+        want = mdist.fold_slices(thresh_len, world)
+        at = 0
+        for r in range(world):
+            b = (C.c_uint64 * 3)()
+            assert L.mmt_fold_slice_bounds(thresh_len, world, r, k, longest, b) == 0
+            assert (b[0], b[1]) == want[r] and b[0] == at and b[2] == max(0, b[0] - margin)
+            at = b[1]
+        assert at == thresh_len
+    b = (C.c_uint64 * 3)()
+    assert L.mmt_fold_slice_bounds(100, 4, 4, 2, 10, b) != 0          # rank out of range

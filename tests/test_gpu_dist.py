@@ -272,6 +272,8 @@ eng.set_docs(docs)
 eng.run(merge_metadata=True)
 m = comm.merge()
 assert m["text"] == O.run(docs, merge=True).text() and m["n_rows"] > 5, "strict multi-MUMs through the RCCL exchange"
+m2 = comm.merge(by_ranges=True)
+assert m2["text"] == m["text"], "the fold by coordinate ranges (dist_merge_ranges: broadcasts, all-to-all, gather) with one rank"
 eng.set_scan_shard(0, 1)
 eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
 assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
@@ -300,3 +302,46 @@ def test_c_abi_exchange_over_rccl_world_size_one(with_torch):
     r = subprocess.run([sys.executable, "-c", _NATIVE_SCRIPT % dict(root=root, with_torch=with_torch)], capture_output=True,
                        text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NATIVE_EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_fold_by_coordinate_ranges_equals_the_whole_fold(on_device):
+    """merge.cpp anchor_merge_by_ranges: slice r of N near-equal slices of the anchor folds from the rows that start in
+    [lo - margin, hi) and the thresholds of that range alone (margin = (partitions - 1) x the longest row + 1) -- what rank r
+    of N does in dist_merge_ranges, here one slice after the other on one device.  Rows, strands, thresholds and the bytes
+    of the output equal the fold of the whole anchor for 1 .. 13 slices (slices shorter than the margin included), for host
+    and for device partitions, and the re-sorted result equals the direct run."""
+    import mumemto_amd
+    docs = synth.pangenome(12, 40000, 0.01, seed=77, inversion=(3, 3000, 9000), indel_rate=0.0005)
+    groups = [[0, 1, 2, 3], [0, 4, 5], [0, 6, 7, 8], [0, 9, 10, 11]]
+    L0 = len(docs[0][0])
+    eng = mumemto_amd.Engine(0)
+    try:
+        parts = []
+        for g in reversed(groups):                      # (the last run = partition 0: the engine keeps the anchor ranks)
+            eng.set_docs([docs[i] for i in g])
+            eng.run(merge_metadata=True)
+            l, o, st = eng.rows_mum()
+            parts.append((l.copy(), o.copy(), st.copy(), eng.thresholds()[: L0 + 1].copy()))
+        parts.reverse()
+        if on_device:
+            import torch
+            from mumemto_amd import dist as mdist
+            dev = torch.device("cuda", 0)
+            tens = [(torch.from_numpy(p[0].view(np.int32)).to(dev), torch.from_numpy(p[1]).to(dev), torch.from_numpy(p[2]).to(dev),
+                     torch.from_numpy(p[3].view(np.int16)).to(dev)) for p in parts]
+            use = mdist.device_partitions(tens)
+        else:
+            use = parts
+        whole = eng.anchor_merge(use)
+        assert len(whole["lengths"]) > 50
+        for slices in (1, 2, 3, 5, 8, 13, 400):
+            got = eng.anchor_merge(use, slices=slices)
+            for k in ("lengths", "offsets", "strands", "thresh"):
+                assert np.array_equal(got[k], whole[k]), (slices, k)
+            assert got["text"] == whole["text"], slices
+        order = [i for g in groups for i in (g if g is groups[0] else g[1:])]
+        direct = O.run([docs[i] for i in order], merge=True)
+        assert eng.anchor_merge(use, sort_like_direct=True, slices=5)["text"] == direct.text()
+    finally:
+        eng.close()

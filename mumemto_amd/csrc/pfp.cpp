@@ -372,6 +372,13 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
             for (size_t i = 0; i < F; i++) S.h_fb_start[i] = b32[i];
         }
     }
+    // chunks of pk::EMIT_BIG_CHUNK output positions per oversized group, as a running count (k_emit_big)
+    S.h_fb_chunk0.assign((size_t)F + 1, 0);
+    for (uint32_t f = 0; f < F; f++)
+        S.h_fb_chunk0[f + 1] = S.h_fb_chunk0[f] + (S.h_fb_off[f + 1] - S.h_fb_off[f] + pk::EMIT_BIG_CHUNK - 1) / pk::EMIT_BIG_CHUNK;
+    S.fb_chunk0.ensure((size_t)F + 2);
+    MMT_HIP(hipMemcpyAsync(S.fb_chunk0.get(), S.h_fb_chunk0.data(), ((size_t)F + 1) * 8, hipMemcpyHostToDevice, st));
+    MMT_HIP(hipStreamSynchronize(st));
     if (slim) S.gscan.release();
 
     // the emitter's arguments, shared by every window
@@ -469,6 +476,7 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
         pk::emit(ea, S.tile_first.get(), t0, t1, st);
         S.emit_launches++;
         const uint32_t nf = f1 - f0;
+        if (nf) pk::emit_big(ea, S.fb_chunk0.get(), f0, nf, S.h_fb_chunk0[f1] - S.h_fb_chunk0[f0], st);
         if (nf) {
             // one segmented radix sort over just the oversized groups of this launch
             const uint32_t count = (uint32_t)fb_count;

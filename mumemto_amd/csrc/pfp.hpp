@@ -46,7 +46,8 @@ struct PfpState {
     uint32_t fb_bits = 0;
     int key_shift = 0;
     uint64_t tiles = 0;
-    std::vector<uint64_t> h_fb_off, h_fb_start;
+    std::vector<uint64_t> h_fb_off, h_fb_start, h_fb_chunk0;
+    DevBuf<uint64_t> fb_chunk0;
     // the bucket-wise producer between its batches (guided.cpp): rank / successor tables over the phrase ends, the
     // histogram of the suffixes' leading characters
     gk::Ctx gctx{};

@@ -857,6 +857,7 @@ struct EmitArgsT {
     // index j - out_base of sa / bwt / lcp when win_lo <= j < win_hi, and nowhere otherwise
     uint32_t* lcp; const uint2* ghead; RmqView rmq; uint32_t w;
     uint64_t out_base, win_lo, win_hi;
+    uint32_t many_runs;          // a group of more runs than this: the piece is ranked by one sort in LDS (emit_piece)
 };
 template <int BLOCK, int CAP>
 struct EmitShared {
@@ -870,6 +871,7 @@ struct EmitShared {
     uint8_t ebwt[CAP];
     uint32_t wmax[BLOCK / 64], gwmax[BLOCK / 64];
     uint32_t bound[4];
+    uint32_t many;               // most runs (entries) in one group of the piece
     uint64_t origin;             // oversized group: output offset that maps to slot 0 of this launch's fallback arrays
 };
 
@@ -894,9 +896,9 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
         sh.eoffm1[e] = a.ce_offm1[e0 + e];
         sh.ebwt[e] = a.ce_bwt[e0 + e];
         sh.egs[e] = a.ce_gs[e0 + e];
-        sh.owner[st] = (uint16_t)e;
+        sh.owner[st < L ? st : 0u] = (uint16_t)e;            // (k_emit_big: entry 0 may begin before the piece -- st wraps, k = i - st holds)
     }
-    if (tid == 0) sh.estart[E] = L;
+    if (tid == 0) { sh.estart[E] = L; sh.many = 0; }
     __syncthreads();
     // owner[i] = last entry starting at or before i; egfirst[e] = last group-start entry at or before e
     // (running maxima over <= CAP items: each thread scans a contiguous slice, slices are stitched)
@@ -932,7 +934,11 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
         for (int q = 0; q < PER; q++) {
             const uint32_t i = b0 + q;
             if (i < L) sh.owner[i] = (uint16_t)(loc[q] > pre ? loc[q] : pre);
-            if (i < E) sh.egfirst[i] = gloc[q] > gpre ? gloc[q] : gpre;
+            if (i < E) {
+                const uint32_t gf = gloc[q] > gpre ? gloc[q] : gpre;
+                sh.egfirst[i] = gf;
+                if (sorted && (i + 1 == E || sh.egs[i + 1]) && i - gf >= a.many_runs) atomicMax(&sh.many, i - gf + 1);
+            }
         }
     }
     __syncthreads();
@@ -978,6 +984,43 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
     }
     // merge rank of every element inside its group = its slot
     uint32_t my_slot[PERX];
+    if (sh.many) {
+        // A group of many runs -- a phrase suffix that ends hundreds of distinct phrases: the copies of a satellite monomer,
+        // each with its own mutations -- would cost every element one binary search per run.  The piece is sorted instead,
+        // once, by (first slot of the group, rank of the following parse suffix): groups keep their slots and the ranks
+        // are distinct, so the place in the sorted order IS the slot.  (The entry tables in efirst / eoffm1 are dead.)
+        uint64_t* const sk = reinterpret_cast<uint64_t*>(sh.efirst);
+        uint32_t P2 = 64;
+        while (P2 < L) P2 <<= 1;
+#pragma unroll
+        for (int q = 0; q < PERX; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            if (i < P2) sk[i] = i < L ? ((uint64_t)my_gs[q] << 42) | ((uint64_t)sh.key[i] << 10) | (uint64_t)i : ~0ull;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < P2 / 2; t += BLOCK) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const bool up = (lo & k) == 0;
+                    const uint64_t x = sk[lo], y = sk[hi];
+                    if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PERX; q++) {
+            const uint32_t pl = tid + q * BLOCK;
+            if (pl < L) sh.owner[(uint32_t)(sk[pl] & 1023u)] = (uint16_t)pl;       // (my_e holds what owner held)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PERX; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            my_slot[q] = i < L ? (uint32_t)sh.owner[i] : 0u;
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < PERX; q++) {
         const uint32_t i = tid + q * BLOCK;
@@ -997,6 +1040,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
             } while (e2 < E && !sh.egs[e2]);
             my_slot[q] = my_gs[q] + rank;
         }
+    }
     }
     // The elements move to their slots INSIDE LDS -- (key, sl) over efirst / eoffm1, the text position over key[], its
     // high byte and the BWT byte over owner[]: nothing of the tile tables is read any more -- so that every column is
@@ -1131,50 +1175,8 @@ __global__ __launch_bounds__(BLOCK) void k_emit(EmitArgsT<P, SA> a, const uint32
             g = g2;
             continue;
         }
-        // a single group larger than CAP: expand it piecewise, unsorted, into the compact fallback arrays
-        // (its slot there was assigned by the host-side prefix sum over the oversized groups)
-        if (wave == 0) {
-            const uint32_t f = wave_lower_bound<uint32_t>(a.fb_group, a.n_fb, g);      // fb_group[f] == g
-            if (lane == 0) sh.origin = (uint64_t)a.segb[g] - ((uint64_t)a.fb_off[f] - (uint64_t)a.fb_base);
-        }
-        __syncthreads();
-        const P fb_origin = (P)sh.origin;
-        const uint32_t e_end = a.sege[g + 1];
-        uint32_t e = a.sege[g];
-        while (e < e_end) {
-            __syncthreads();
-            const P base = a.ce_eoff[e];
-            const uint32_t c = a.ce_cnt[e];
-            if (c > CAP / 2) {                               // one frequent phrase: plain strided copy
-                const uint32_t first = a.ce_first[e], om1 = a.ce_offm1[e];
-                const uint32_t low = a.fb_bits ? a.bwt_code[a.ce_bwt[e]] : 0u;
-                const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
-                const uint32_t slot0 = (uint32_t)(base - fb_origin);
-                for (uint32_t k = tid; k < c; k += BLOCK) {
-                    const uint64_t kp = a.occ[first + k];
-                    a.fb_keys[slot0 + k] = ((uint32_t)(kp >> a.pos_bits) << a.fb_bits) | low;
-                    a.fb_vals[slot0 + k] = (P)((kp & pos_mask) + om1);
-                }
-                e++;
-                continue;
-            }
-            if (wave == 0) {
-                // entries [e, e2) with at most CAP elements and at most CAP entries
-                const uint32_t room = e_end - e < (uint32_t)CAP ? e_end - e : (uint32_t)CAP;
-                const uint32_t cntE = wave_lower_bound<P>(a.ce_eoff + e, room, base + CAP + 1);  // first entry starting > base+CAP
-                uint32_t e2 = e + cntE;                      // entries before it start <= base + CAP
-                // the last of them may end beyond base + CAP: drop it unless it is the only one
-                if (lane == 0) {
-                    while (e2 > e + 1 && a.ce_eoff[e2 - 1] + a.ce_cnt[e2 - 1] > base + CAP) e2--;
-                    sh.bound[2] = e2;
-                }
-            }
-            __syncthreads();
-            const uint32_t e2 = sh.bound[2];
-            const P endoff = e2 < e_end ? a.ce_eoff[e2] : a.segb[g + 1];
-            emit_piece<BLOCK, CAP, P, SA>(a, sh, e, e2, base, (uint32_t)(endoff - base), false, fb_origin);
-            e = e2;
-        }
+        // a single group larger than CAP: k_emit_big expands it, chunk by chunk over many workgroups, into the compact
+        // fallback arrays (one workgroup walking a satellite's group of a million suffixes alone was the tail of every launch)
         g = g + 1;
     }
 }
@@ -1200,6 +1202,9 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64
     t.bwt_code = a.bwt_code; t.fb_bits = a.fb_bits; t.err = a.err; t.tile_lo = tile_lo;
     t.lcp = a.lcp; t.ghead = static_cast<const uint2*>(a.ghead); t.rmq = a.rmq; t.w = a.w;
     t.out_base = a.out_base; t.win_lo = a.win_lo; t.win_hi = a.win_hi;
+    // (tests/micro: MMT_EMIT_MANY=0 sorts every piece, a large value none)
+    static const uint32_t many = std::getenv("MMT_EMIT_MANY") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT_MANY")) : 24u;
+    t.many_runs = many;
     hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3((unsigned)(tile_hi - tile_lo)), dim3(BLOCK), 0, s, t,
                        tile_first_tab);
     MMT_HIP(hipGetLastError());
@@ -1216,6 +1221,61 @@ void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, u
         else if (tile == 768) emit_typed<uint32_t, Sa32, 768>(a, tile_first_tab, tile_lo, tile_hi, s);
         else emit_typed<uint32_t, Sa32, 896>(a, tile_first_tab, tile_lo, tile_hi, s);
     }
+}
+
+// Oversized groups, unsorted, into the fallback arrays: workgroup b takes chunk (chunk0[f0] + b) of the launch, i.e. EMIT_BIG_CHUNK
+// consecutive output offsets of one oversized group; the entries that cover them -- the first may begin before the chunk,
+// the last may end behind it -- go through emit_piece's unsorted path.
+template <int BLOCK, int CAP, typename P, typename SA>
+__global__ __launch_bounds__(BLOCK) void k_emit_big(EmitArgsT<P, SA> a, const uint64_t* __restrict__ chunk0, uint32_t f0, uint32_t nf) {
+    __shared__ EmitShared<BLOCK, CAP> sh;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t cb = chunk0[f0] + blockIdx.x;
+    if (wave == 0) {
+        const uint32_t idx = wave_lower_bound<uint64_t>(chunk0 + f0, nf, cb + 1);      // first group whose chunks begin behind cb
+        if (lane == 0) sh.bound[0] = f0 + idx - 1;
+    }
+    __syncthreads();
+    const uint32_t f = sh.bound[0];
+    const uint32_t g = a.fb_group[f];
+    const uint64_t gb = (uint64_t)a.segb[g], ge = (uint64_t)a.segb[g + 1];
+    const uint64_t X0 = gb + (cb - chunk0[f]) * (uint64_t)EMIT_BIG_CHUNK;
+    if (X0 >= ge) return;                                   // (cannot happen: chunk0 counts ceil(size / chunk) per group)
+    const uint32_t L = ge - X0 < (uint64_t)EMIT_BIG_CHUNK ? (uint32_t)(ge - X0) : EMIT_BIG_CHUNK;
+    const P fb_origin = (P)(gb - ((uint64_t)a.fb_off[f] - (uint64_t)a.fb_base));
+    const uint32_t e_lo = a.sege[g], e_hi = a.sege[g + 1];
+    if (wave == 0) {
+        // last entry that begins at or before X0 .. last entry that begins before X0 + L
+        const uint32_t first = wave_lower_bound<P>(a.ce_eoff + e_lo, e_hi - e_lo, (P)(X0 + 1));
+        const uint32_t end = wave_lower_bound<P>(a.ce_eoff + e_lo, e_hi - e_lo, (P)(X0 + L));
+        if (lane == 0) { sh.bound[1] = e_lo + first - 1; sh.bound[2] = e_lo + end; }
+    }
+    __syncthreads();
+    const uint32_t e0 = sh.bound[1], e1 = sh.bound[2];
+    emit_piece<BLOCK, CAP, P, SA>(a, sh, e0, e1, (P)X0, L, false, fb_origin);
+}
+template <typename P, typename SA>
+static void emit_big_typed(const EmitArgs& a, const uint64_t* chunk0, uint32_t f0, uint32_t nf, uint32_t n_chunks, hipStream_t s) {
+    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP;
+    static_assert(EMIT_BIG_CHUNK + 1 <= EMIT_CAP, "a chunk's entries (one per element + the one that began before it) must fit the tile tables");
+    EmitArgsT<P, SA> t;
+    t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
+    t.ce_eoff = static_cast<const P*>(a.ce_eoff); t.ce_cnt = a.ce_cnt; t.ce_first = a.ce_first; t.ce_offm1 = a.ce_offm1;
+    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.occ_sl = a.occ_sl; t.pos_bits = a.pos_bits; t.n = (P)a.n;
+    t.sa = SA(a.sa); t.bwt = a.bwt;
+    t.fb_group = a.fb_group; t.fb_off = static_cast<const P*>(a.fb_off); t.n_fb = a.n_fb; t.fb_base = (P)a.fb_base;
+    t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
+    t.bwt_code = a.bwt_code; t.fb_bits = a.fb_bits; t.err = a.err; t.tile_lo = 0;
+    t.lcp = a.lcp; t.ghead = static_cast<const uint2*>(a.ghead); t.rmq = a.rmq; t.w = a.w;
+    t.out_base = a.out_base; t.win_lo = a.win_lo; t.win_hi = a.win_hi; t.many_runs = 0xffffffffu;
+    hipLaunchKernelGGL((k_emit_big<BLOCK, CAP, P, SA>), dim3(n_chunks), dim3(BLOCK), 0, s, t, chunk0, f0, nf);
+    MMT_HIP(hipGetLastError());
+}
+void emit_big(const EmitArgs& a, const uint64_t* chunk0, uint32_t f0, uint32_t nf, uint64_t n_chunks, hipStream_t s) {
+    if (!nf || !n_chunks) return;
+    if (n_chunks > 0x7fffffffull) throw std::runtime_error("too many chunks of oversized suffix groups in one emitter launch");
+    if (a.wide) emit_big_typed<uint64_t, Sa40>(a, chunk0, f0, nf, (uint32_t)n_chunks, s);
+    else emit_big_typed<uint32_t, Sa32>(a, chunk0, f0, nf, (uint32_t)n_chunks, s);
 }
 
 // osize[g] = size of group g if it exceeds the emitter's LDS tile, else 0

@@ -118,6 +118,10 @@ struct BwtDecode { uint8_t byte[16]; };       // code -> byte
 void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s);
 // output tiles [tile_lo, tile_hi)
 void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s);
+// the oversized groups fb_group[f0 .. f0 + nf) of that launch, unsorted, into the fallback arrays: chunk0[f] = number of
+// chunks of EMIT_BIG_CHUNK output positions in all oversized groups before f (n_fb + 1 entries, device)
+constexpr uint32_t EMIT_BIG_CHUNK = 896;
+void emit_big(const EmitArgs& a, const uint64_t* chunk0, uint32_t f0, uint32_t nf, uint64_t n_chunks, hipStream_t s);
 // osize[g] = size of group g if it exceeds the emitter's LDS tile, else 0; err[2] counts groups of 2^32 suffixes or more
 void oversize(const void* segb, uint32_t n_groups, uint32_t* osize, uint32_t* err, bool wide, hipStream_t s);
 // out[i] = segb[fb_group[i]] (begin offset of every oversized group)

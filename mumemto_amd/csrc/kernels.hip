@@ -266,6 +266,28 @@ __global__ void k_scatter_rank(const uint32_t* __restrict__ sa, const uint32_t* 
         for (uint64_t t = j; t < n; t++) rank[sa[t]] = head[t];
     }
 }
+// the same for the sorted list of a round, where most ranks stay what they were: the elements of the first sub-bucket of
+// every bucket keep the bucket's head.  Sorting permutes inside buckets only, so element c's old head is old_head[c].
+__global__ void k_scatter_rank_changed(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ head,
+                                       const uint32_t* __restrict__ old_head, uint32_t m, uint32_t* __restrict__ rank) {
+    const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j + 4 <= m) {
+        const uint4 v = *reinterpret_cast<const uint4*>(head + j), o = *reinterpret_cast<const uint4*>(old_head + j);
+        if (v.x == o.x && v.y == o.y && v.z == o.z && v.w == o.w) return;
+        const uint4 p = *reinterpret_cast<const uint4*>(sa + j);
+        if (v.x != o.x) rank[p.x] = v.x;
+        if (v.y != o.y) rank[p.y] = v.y;
+        if (v.z != o.z) rank[p.z] = v.z;
+        if (v.w != o.w) rank[p.w] = v.w;
+    } else {
+        for (uint64_t t = j; t < m; t++) if (head[t] != old_head[t]) rank[sa[t]] = head[t];
+    }
+}
+void scatter_rank_changed(const uint32_t* sa, const uint32_t* head, const uint32_t* old_head, uint32_t m, uint32_t* rank,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_rank_changed, dim3(grid_for(m, 1024)), dim3(256), 0, s, sa, head, old_head, m, rank);
+    MMT_HIP(hipGetLastError());
+}
 void scatter_rank(const uint32_t* sa, const uint32_t* head, uint32_t n, uint32_t* rank, hipStream_t s) {
     hipLaunchKernelGGL(k_scatter_rank, dim3(grid_for(n, 1024)), dim3(256), 0, s, sa, head, n, rank);
     MMT_HIP(hipGetLastError());
@@ -485,6 +507,239 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
                    const uint32_t* newhead, uint32_t* out_pos, uint32_t* out_sa, uint32_t* out_head, hipStream_t s) {
     hipLaunchKernelGGL(k_compact_round, dim3(grid_for(m2, 256)), dim3(256), 0, s, idx, m2, pos, sa_sorted, newhead,
                        out_pos, out_sa, out_head);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- one doubling round in one pass over the active list -----------------------------------------
+// The active list (pos, suffix, bucket head) is grouped by bucket, so the tiles between bucket boundaries are
+// independent: a workgroup gathers rank[suffix + h] for its tile, sorts (head, rank) in LDS, finds the new
+// sub-bucket heads with a scan inside the tile (a tile begins on a bucket boundary: no carry from the left), and
+// writes the suffix-array entries, the sorted suffixes, the new heads and the "still tied" flags.  No key ever
+// reaches HBM.  The ranks themselves must not change while other tiles still gather them (a tile that saw half of
+// a refined bucket would order its elements wrongly), so they are scattered by a second launch (k_scatter_rank over
+// the sorted list).  Ranges too long for a tile are listed, their tiles marked, and finished by the k_big_* kernels
+// around one segmented radix sort.
+__global__ void k_round_head_bounds(const uint32_t* __restrict__ headc, uint32_t m, uint32_t target, uint32_t limit,
+                                    uint32_t n_tiles, uint32_t* __restrict__ bound) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    if (t == n_tiles) { bound[t] = m; return; }
+    uint64_t c = (uint64_t)t * target;
+    if (t == 0) { bound[0] = 0; return; }
+    const uint64_t stop = c + limit < m ? c + limit : m;
+    while (c < stop && headc[c] == headc[c - 1]) c++;
+    bound[t] = c >= m ? m : (c == stop ? ROUND_NO_BOUND : (uint32_t)c);
+}
+template <int BLOCK, int CAP>
+__global__ __launch_bounds__(BLOCK) void k_round_fused(const uint32_t* __restrict__ sac,
+                                                       const uint32_t* __restrict__ headc,
+                                                       const uint32_t* __restrict__ pos,
+                                                       const uint32_t* __restrict__ bound, uint32_t n_tiles,
+                                                       const uint32_t* __restrict__ rank, uint32_t n, uint32_t h,
+                                                       int shift, uint32_t* __restrict__ sa,
+                                                       uint32_t* __restrict__ sac_out, uint32_t* __restrict__ head_out,
+                                                       uint8_t* __restrict__ flags, uint32_t* __restrict__ big_begin,
+                                                       uint32_t* __restrict__ big_end, uint32_t* __restrict__ big_count,
+                                                       uint32_t big_cap, uint8_t* __restrict__ tile_big) {
+    constexpr int PER = CAP / BLOCK, NW = BLOCK / 64;
+    __shared__ uint64_t s_k[CAP];
+    __shared__ uint32_t s_v[CAP];
+    __shared__ uint32_t s_w[PER * NW];
+    __shared__ uint32_t s_long;
+    const uint32_t t = blockIdx.x;
+    const uint32_t b = bound[t];
+    if (b == ROUND_NO_BOUND) return;                       // this tile starts inside a bucket: an earlier tile owns it
+    uint32_t u = t + 1;
+    while (bound[u] == ROUND_NO_BOUND) u++;                // bound[n_tiles] = m always ends the search
+    const uint32_t e = bound[u];
+    if (e <= b) return;
+    const uint32_t len = e - b;
+    if (len > (uint32_t)CAP) {
+        if (threadIdx.x == 0) {
+            const uint32_t slot = atomicAdd(big_count, 1u);
+            if (slot < big_cap) { big_begin[slot] = b; big_end[slot] = e; }
+        }
+        for (uint32_t x = t + threadIdx.x; x < u; x += BLOCK)
+            tile_big[x] = (uint8_t)(1u | (x == t ? 2u : 0u) | (x + 1 == u ? 4u : 0u));
+        return;
+    }
+    uint64_t kreg[PER];
+    uint32_t vreg[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = threadIdx.x + q * BLOCK;
+        kreg[q] = 0; vreg[q] = 0;
+        if (i < len) {
+            const uint32_t v = sac[b + i], hd = headc[b + i];
+            const uint64_t at = (uint64_t)v + h;
+            const uint64_t second = at < n ? (uint64_t)rank[at] + 1 : 0;      // past the end sorts first
+            kreg[q] = ((uint64_t)hd << shift) | second; vreg[q] = v;
+            s_k[i] = kreg[q]; s_v[i] = v;
+        }
+    }
+    if (threadIdx.x == 0) s_long = 0;
+    __syncthreads();
+    // short buckets: every element counts the bucket members that sort before it (as k_round_local_sort)
+    constexpr uint32_t SHORT = 128;
+    uint32_t slot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = threadIdx.x + q * BLOCK;
+        slot[q] = i;
+        if (i < len) {
+            const uint64_t ki = kreg[q], hi = ki >> shift;
+            uint32_t st = i, steps = 0;
+            while (st > 0 && (s_k[st - 1] >> shift) == hi && steps <= SHORT) { st--; steps++; }
+            uint32_t before = 0, j = st, cnt = 0;
+            while (j < len && cnt <= SHORT) {
+                const uint64_t kj = s_k[j];
+                if ((kj >> shift) != hi) break;
+                before += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+                j++; cnt++;
+            }
+            if (steps > SHORT || cnt > SHORT) s_long = 1;
+            slot[q] = st + before;
+        }
+    }
+    __syncthreads();
+    if (!s_long) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = threadIdx.x + q * BLOCK;
+            if (i < len) { s_k[slot[q]] = kreg[q]; s_v[slot[q]] = vreg[q]; }
+        }
+        __syncthreads();
+    } else {
+        uint32_t P = 64;
+        while (P < len) P <<= 1;
+        for (uint32_t i = len + threadIdx.x; i < P; i += BLOCK) { s_k[i] = ~0ull; s_v[i] = 0u; }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
+                    const uint32_t l = i ^ j;
+                    if (l > i) {
+                        const uint64_t a = s_k[i], c = s_k[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) {
+                            s_k[i] = c; s_k[l] = a;
+                            const uint32_t va = s_v[i]; s_v[i] = s_v[l]; s_v[l] = va;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // new heads: position of the first element of every run of equal keys, carried along the tile by a running maximum
+    // (positions grow along the list); a tile begins with a head, so nothing comes in from the left
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t hv[PER], pj[PER];
+    uint8_t tied[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t j = threadIdx.x + q * BLOCK;
+        uint32_t x = 0;
+        pj[q] = 0; tied[q] = 0;
+        if (j < len) {
+            const uint64_t kj = s_k[j];
+            const bool ish = j == 0 || s_k[j - 1] != kj;
+            const bool nxt = j + 1 == len || s_k[j + 1] != kj;
+            pj[q] = pos[b + j];
+            x = ish ? pj[q] : 0u;
+            tied[q] = (ish && nxt) ? 0 : 1;
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= (uint32_t)o && y > x) x = y; }
+        hv[q] = x;
+        if (lane == 63) s_w[q * NW + wave] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t j = threadIdx.x + q * BLOCK;
+        if (j < len) {
+            uint32_t nh = hv[q];
+            for (uint32_t k2 = 0; k2 < (uint32_t)q * NW + wave; k2++) { const uint32_t y = s_w[k2]; nh = y > nh ? y : nh; }
+            const uint32_t v = s_v[j];
+            sa[pj[q]] = v; sac_out[b + j] = v; head_out[b + j] = nh; flags[b + j] = tied[q];
+        }
+    }
+}
+// the chunk of a marked tile: [c0, c1) of the active list (the first chunk of a range begins at its bound, the last one
+// ends at the next bound)
+__device__ __forceinline__ bool big_chunk(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t x,
+                                          uint32_t& c0, uint32_t& c1, bool& first) {
+    const uint32_t f = tile_big[x];
+    if (!f) return false;
+    first = (f & 2u) != 0;
+    c0 = first ? bound[x] : x * target;
+    c1 = (f & 4u) ? bound[x + 1] : (x + 1) * target;
+    return true;
+}
+__global__ void k_big_keys(const uint8_t* __restrict__ tile_big, const uint32_t* __restrict__ bound, uint32_t target,
+                           const uint32_t* __restrict__ sac, const uint32_t* __restrict__ headc,
+                           const uint32_t* __restrict__ rank, uint32_t n, uint32_t h, int shift,
+                           uint64_t* __restrict__ keys) {
+    uint32_t c0, c1; bool first;
+    if (!big_chunk(tile_big, bound, target, blockIdx.x, c0, c1, first)) return;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+        const uint64_t at = (uint64_t)sac[c] + h;
+        keys[c] = ((uint64_t)headc[c] << shift) | (at < n ? (uint64_t)rank[at] + 1 : 0);
+    }
+}
+__global__ void k_big_subheads(const uint8_t* __restrict__ tile_big, const uint32_t* __restrict__ bound, uint32_t target,
+                               const uint64_t* __restrict__ keys, const uint32_t* __restrict__ pos,
+                               uint32_t* __restrict__ head) {
+    uint32_t c0, c1; bool first;
+    if (!big_chunk(tile_big, bound, target, blockIdx.x, c0, c1, first)) return;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += blockDim.x)
+        head[c] = ((first && c == c0) || keys[c] != keys[c - 1]) ? pos[c] : 0u;
+}
+__global__ void k_big_apply(const uint8_t* __restrict__ tile_big, const uint32_t* __restrict__ bound, uint32_t target,
+                            uint32_t m, const uint32_t* __restrict__ sa_sorted, const uint32_t* __restrict__ head,
+                            const uint32_t* __restrict__ pos, uint32_t* __restrict__ sa, uint8_t* __restrict__ flags) {
+    uint32_t c0, c1; bool first;
+    if (!big_chunk(tile_big, bound, target, blockIdx.x, c0, c1, first)) return;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+        const uint32_t p = pos[c];
+        sa[p] = sa_sorted[c];
+        const bool single = head[c] == p && (c + 1 == m || head[c + 1] == pos[c + 1]);
+        flags[c] = single ? 0 : 1;
+    }
+}
+void round_head_bounds(const uint32_t* headc, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles,
+                       uint32_t* bound, hipStream_t s) {
+    hipLaunchKernelGGL(k_round_head_bounds, dim3(grid_for((uint64_t)n_tiles + 1, 256)), dim3(256), 0, s, headc, m, target,
+                       limit, n_tiles, bound);
+    MMT_HIP(hipGetLastError());
+}
+void round_fused(const uint32_t* sac, const uint32_t* headc, const uint32_t* pos, const uint32_t* bound, uint32_t n_tiles,
+                 const uint32_t* rank, uint32_t n, uint32_t h, int shift, uint32_t* sa, uint32_t* sac_out,
+                 uint32_t* head_out, uint8_t* flags, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count,
+                 uint32_t big_cap, uint8_t* tile_big, hipStream_t s) {
+    hipLaunchKernelGGL((k_round_fused<256, (int)ROUND_TILE_CAP>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound,
+                       n_tiles, rank, n, h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap,
+                       tile_big);
+    MMT_HIP(hipGetLastError());
+}
+void round_big_keys(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles, const uint32_t* sac,
+                    const uint32_t* headc, const uint32_t* rank, uint32_t n, uint32_t h, int shift, uint64_t* keys,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_big_keys, dim3(n_tiles), dim3(256), 0, s, tile_big, bound, target, sac, headc, rank, n, h, shift,
+                       keys);
+    MMT_HIP(hipGetLastError());
+}
+void round_big_subheads(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles,
+                        const uint64_t* keys, const uint32_t* pos, uint32_t* head, hipStream_t s) {
+    hipLaunchKernelGGL(k_big_subheads, dim3(n_tiles), dim3(256), 0, s, tile_big, bound, target, keys, pos, head);
+    MMT_HIP(hipGetLastError());
+}
+void round_big_apply(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles, uint32_t m,
+                     const uint32_t* sa_sorted, const uint32_t* head, const uint32_t* pos, uint32_t* sa, uint8_t* flags,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_big_apply, dim3(n_tiles), dim3(256), 0, s, tile_big, bound, target, m, sa_sorted, head, pos, sa,
+                       flags);
     MMT_HIP(hipGetLastError());
 }
 

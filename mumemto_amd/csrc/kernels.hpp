@@ -39,6 +39,9 @@ void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits,
 void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, bool lsb_unique, hipStream_t s);
 // rank[sa[j]] = head[j]
 void scatter_rank(const uint32_t* sa, const uint32_t* head, uint32_t n, uint32_t* rank, hipStream_t s);
+// rank[sa[c]] = head[c] where head[c] != old_head[c] (the sorted list of a doubling round against its heads before the round)
+void scatter_rank_changed(const uint32_t* sa, const uint32_t* head, const uint32_t* old_head, uint32_t m, uint32_t* rank,
+                          hipStream_t s);
 // flags[j] = 1 unless bucket of j is a singleton
 void flag_unsorted(const uint32_t* head, uint32_t n, uint8_t* flags, hipStream_t s);
 void gather_active(const uint32_t* idx, uint32_t m, const uint32_t* sa, const uint32_t* head, uint32_t* out_pos,
@@ -63,6 +66,27 @@ void apply_round(const uint32_t* sa_sorted, const uint32_t* newhead, const uint3
                  uint32_t* rank, uint8_t* flags, hipStream_t s);
 void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const uint32_t* sa_sorted,
                    const uint32_t* newhead, uint32_t* out_pos, uint32_t* out_sa, uint32_t* out_head, hipStream_t s);
+// One doubling round in one pass over the active list (no key reaches HBM): round_head_bounds cuts the list at bucket
+// boundaries (as round_tile_bounds, on the head column), round_fused gathers rank[suffix + h], sorts every tile in LDS and
+// writes SA[pos], the sorted suffixes, the new heads and the still-tied flags; the ranks are scattered afterwards
+// (scatter_rank over the sorted list: no tile may see half of a refined bucket).  Ranges beyond ROUND_TILE_CAP are
+// listed (begin, end) and their tiles marked in tile_big (n_tiles bytes, cleared by the caller): round_big_keys writes
+// their round keys, a segmented sort orders them, round_big_subheads marks their new heads (a running maximum over the
+// whole head column follows) and round_big_apply writes their SA entries and flags.
+void round_head_bounds(const uint32_t* headc, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles,
+                       uint32_t* bound, hipStream_t s);
+void round_fused(const uint32_t* sac, const uint32_t* headc, const uint32_t* pos, const uint32_t* bound, uint32_t n_tiles,
+                 const uint32_t* rank, uint32_t n, uint32_t h, int shift, uint32_t* sa, uint32_t* sac_out,
+                 uint32_t* head_out, uint8_t* flags, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count,
+                 uint32_t big_cap, uint8_t* tile_big, hipStream_t s);
+void round_big_keys(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles, const uint32_t* sac,
+                    const uint32_t* headc, const uint32_t* rank, uint32_t n, uint32_t h, int shift, uint64_t* keys,
+                    hipStream_t s);
+void round_big_subheads(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles,
+                        const uint64_t* keys, const uint32_t* pos, uint32_t* head, hipStream_t s);
+void round_big_apply(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles, uint32_t m,
+                     const uint32_t* sa_sorted, const uint32_t* head, const uint32_t* pos, uint32_t* sa, uint8_t* flags,
+                     hipStream_t s);
 
 // ---- LCP / BWT columns of the stream ----------------------------------------
 // text must be readable (zero padded) up to n + 64.

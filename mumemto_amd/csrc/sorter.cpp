@@ -1,6 +1,7 @@
 #include "sorter.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -23,6 +24,7 @@ void DoublingSorter::release() {
     keys_a_.release(); keys_b_.release();
     for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &bound_, &big_begin_, &big_end_})
         b->release();
+    hf_.release(); tile_big_.release();
 }
 
 void DoublingSorter::sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s) {
@@ -78,24 +80,72 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
     }
 
     const int shift = bit_width_u64(n);            // second key component holds values 0..n
+    static const bool fused_ok = !std::getenv("MMT_SORT_GLOBAL_ROUNDS") &&
+                                 !(std::getenv("MMT_SORT_FUSED") && std::atoi(std::getenv("MMT_SORT_FUSED")) == 0);
+    static const bool trace = std::getenv("MMT_SORT_TRACE") != nullptr;      // tuning aid: the active set round by round
+    if (trace) std::fprintf(stderr, "[sort] n %u, tied after the first pass %u (h = %llu)\n", n, m, (unsigned long long)h0);
     uint64_t h = h0;
     int rounds = 0;
     while (m) {
         if (++rounds > 64) throw std::runtime_error("suffix sort did not converge");
         const uint32_t hh = h > 0xffffffffull ? 0xffffffffu : (uint32_t)h;
-        // round keys in keys_a_[0, m) -> sorted in keys_b_[0, m); then the marks over the dead round keys, the heads over the
-        // dead sorted keys
-        k::make_round_keys(sac_a_.get(), headc_.get(), m, rank, n, hh, shift, keys_a_.get(), s);
-        sort_round(m, shift, temp, s);
-        k::mark_subheads(keys_b_.get(), pos_a_.get(), m, headval, s);
-        prims::inclusive_max_u32(temp, headval, head, m, s);
-        k::apply_round(sac_b_.get(), head, pos_a_.get(), m, sa, rank, flags, s);
-        prims::select_indices(temp, flags, idx, count_.get(), m, s);
+        const uint32_t* head_r = head;              // the new heads and the still-tied flags of this round
+        const uint8_t* flags_r = flags;
+        bool done = false;
+        if (fused_ok && m >= 4096) {
+            // one pass over the active list: gather, sort in LDS, new heads, SA entries (no key column); then the ranks
+            const uint32_t target = 1024, limit = k::ROUND_TILE_CAP;
+            const uint32_t n_tiles = (m + target - 1) / target;
+            const size_t m4 = ((size_t)m + 15) & ~(size_t)15;
+            hf_.ensure(m4 * 5 + 16); bound_.ensure((size_t)n_tiles + 2); tile_big_.ensure((size_t)n_tiles + 1);
+            uint32_t* const head_w = reinterpret_cast<uint32_t*>(hf_.get());
+            uint8_t* const flags_w = hf_.get() + m4 * 4;
+            const uint32_t big_cap = (uint32_t)std::max<size_t>(big_begin_.size(), 4096);
+            big_begin_.ensure(big_cap); big_end_.ensure(big_cap);
+            MMT_HIP(hipMemsetAsync(count_.get() + 1, 0, 4, s));
+            MMT_HIP(hipMemsetAsync(tile_big_.get(), 0, (size_t)n_tiles + 1, s));
+            k::round_head_bounds(headc_.get(), m, target, limit, n_tiles, bound_.get(), s);
+            k::round_fused(sac_a_.get(), headc_.get(), pos_a_.get(), bound_.get(), n_tiles, rank, n, hh, shift, sa,
+                           sac_b_.get(), head_w, flags_w, big_begin_.get(), big_end_.get(), count_.get() + 1, big_cap,
+                           tile_big_.get(), s);
+            uint32_t big = 0;
+            MMT_HIP(hipMemcpyAsync(&big, count_.get() + 1, 4, hipMemcpyDeviceToHost, s));
+            MMT_HIP(hipStreamSynchronize(s));
+            if (trace) std::fprintf(stderr, "[sort]   round %d: h %u, tied %u, long ranges %u\n", rounds, hh, m, big);
+            if (big <= big_cap) {                           // (more long ranges than listed: the round below, rare)
+                if (big) {
+                    // the long ranges: keys in the dead input-key column, sorted into the dead sorted-key column
+                    k::round_big_keys(tile_big_.get(), bound_.get(), target, n_tiles, sac_a_.get(), headc_.get(), rank, n, hh,
+                                      shift, keys_a_.get(), s);
+                    prims::segmented_sort_pairs_u64_ranges(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m,
+                                                           big, big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s);
+                    k::round_big_subheads(tile_big_.get(), bound_.get(), target, n_tiles, keys_b_.get(), pos_a_.get(), head_w, s);
+                    prims::inclusive_max_u32(temp, head_w, head_w, m, s);
+                    k::round_big_apply(tile_big_.get(), bound_.get(), target, n_tiles, m, sac_b_.get(), head_w, pos_a_.get(),
+                                       sa, flags_w, s);
+                }
+                static const bool all_ranks = std::getenv("MMT_SORT_ALL_RANKS") != nullptr;        // (A/B: every rank rewritten)
+                if (all_ranks) k::scatter_rank(sac_b_.get(), head_w, m, rank, s);
+                else k::scatter_rank_changed(sac_b_.get(), head_w, headc_.get(), m, rank, s);
+                head_r = head_w; flags_r = flags_w;
+                done = true;
+            }
+        }
+        if (!done) {
+            // round keys in keys_a_[0, m) -> sorted in keys_b_[0, m); then the marks over the dead round keys, the heads over
+            // the dead sorted keys
+            k::make_round_keys(sac_a_.get(), headc_.get(), m, rank, n, hh, shift, keys_a_.get(), s);
+            sort_round(m, shift, temp, s);
+            k::mark_subheads(keys_b_.get(), pos_a_.get(), m, headval, s);
+            prims::inclusive_max_u32(temp, headval, head, m, s);
+            k::apply_round(sac_b_.get(), head, pos_a_.get(), m, sa, rank, flags, s);
+        }
+        prims::select_indices(temp, flags_r, idx, count_.get(), m, s);
         uint32_t m2 = 0;
         MMT_HIP(hipMemcpyAsync(&m2, count_.get(), 4, hipMemcpyDeviceToHost, s));
         MMT_HIP(hipStreamSynchronize(s));
         if (m2) {
-            k::compact_round(idx, m2, pos_a_.get(), sac_b_.get(), head, pos_b_.get(), sac_a_.get(), headc_.get(), s);
+            k::compact_round(idx, m2, pos_a_.get(), sac_b_.get(), head_r, pos_b_.get(), sac_a_.get(), headc_.get(), s);
             pos_a_.swap(pos_b_);
         }
         m = m2;

@@ -213,6 +213,7 @@ private:
     void build_giant(const std::vector<uint64_t>& hist);
     void pfp_stream(ScanState& S, const mmt_params& p);
     void pfp_emit_window(uint64_t b0, uint64_t c1, int set);
+    uint64_t pfp_first_tile(uint64_t b0);         // emitter tile in which the group covering stream entry b0 + 1 begins
     void guided_stream(ScanState& S, const mmt_params& p);
     void lcp_bwt();
     void scan(const mmt_params& p);

@@ -718,10 +718,26 @@ void round_fused(const uint32_t* sac, const uint32_t* headc, const uint32_t* pos
                  const uint32_t* rank, uint32_t n, uint32_t h, int shift, uint32_t* sa, uint32_t* sac_out,
                  uint32_t* head_out, uint8_t* flags, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count,
                  uint32_t big_cap, uint8_t* tile_big, hipStream_t s) {
-    hipLaunchKernelGGL((k_round_fused<256, (int)ROUND_TILE_CAP>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound,
-                       n_tiles, rank, n, h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap,
-                       tile_big);
+    const uint32_t cap = round_fused_cap();
+    if (cap == 1024)
+        hipLaunchKernelGGL((k_round_fused<256, 1024>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound, n_tiles, rank, n,
+                           h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap, tile_big);
+    else if (cap == 1536)
+        hipLaunchKernelGGL((k_round_fused<256, 1536>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound, n_tiles, rank, n,
+                           h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap, tile_big);
+    else
+        hipLaunchKernelGGL((k_round_fused<256, 2048>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound, n_tiles, rank, n,
+                           h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap, tile_big);
     MMT_HIP(hipGetLastError());
+}
+// elements of one LDS tile of k_round_fused (MMT_ROUND_CAP = 1024 / 1536 / 2048: tuning aid)
+uint32_t round_fused_cap() {
+    static const uint32_t cap = [] {
+        const char* e = std::getenv("MMT_ROUND_CAP");
+        const int v = e ? std::atoi(e) : 2048;
+        return (uint32_t)(v == 1024 || v == 1536 ? v : 2048);
+    }();
+    return cap;
 }
 void round_big_keys(const uint8_t* tile_big, const uint32_t* bound, uint32_t target, uint32_t n_tiles, const uint32_t* sac,
                     const uint32_t* headc, const uint32_t* rank, uint32_t n, uint32_t h, int shift, uint64_t* keys,

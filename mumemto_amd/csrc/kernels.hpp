@@ -73,6 +73,7 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
 // listed (begin, end) and their tiles marked in tile_big (n_tiles bytes, cleared by the caller): round_big_keys writes
 // their round keys, a segmented sort orders them, round_big_subheads marks their new heads (a running maximum over the
 // whole head column follows) and round_big_apply writes their SA entries and flags.
+uint32_t round_fused_cap();
 void round_head_bounds(const uint32_t* headc, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles,
                        uint32_t* bound, hipStream_t s);
 void round_fused(const uint32_t* sac, const uint32_t* headc, const uint32_t* pos, const uint32_t* bound, uint32_t n_tiles,

@@ -437,6 +437,18 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
 // Suffix-array entries [b0, c1) of the stream -- suffix array, BWT byte and LCP value of each -- into window set `set`
 // (entry b0 at index 0).  The output tiles that cover the range are run; the groups that begin in them may reach beyond
 // the range on either side and are clipped (pfp_kernels.hip).
+uint64_t Engine::pfp_first_tile(uint64_t b0) {
+    PfpState& S = *pfp_;
+    hipStream_t st = stream_;
+    const uint64_t TILE = pk::emit_tile();
+    if (b0 == 0) return 0;
+    const uint64_t X = b0 + 1, tX = X / TILE;
+    const uint32_t gA = read_u32(S.tile_first.get() + tX, st);        // first group that begins at or after tX * TILE
+    uint64_t t_lo = tX;
+    if (gA > 0 && (gA >= S.n_groups || S.segb.read(gA, st) > X)) t_lo = S.segb.read(gA - 1, st) / TILE;
+    return t_lo;
+}
+
 void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
     PfpState& S = *pfp_;
     if (!S.emit_ready) throw std::runtime_error("the emitter's tables are gone");
@@ -447,14 +459,12 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
     ea.sa.lo = w_sa_[set].get(); ea.sa.hi = W ? w_hi_[set].get() : nullptr;
     ea.bwt = w_bwt_[set].get(); ea.lcp = w_lcp_[set].get();
     ea.out_base = b0; ea.win_lo = b0; ea.win_hi = c1;
-    // first tile: the one in which the group that covers stream entry b0 + 1 begins
+    // first tile: the one in which the group that covers stream entry b0 + 1 begins (looked up ahead of the windows
+    // by pfp_stream: a read here waits behind the output piece of the window before, which is on its way to the host)
     uint64_t t_lo = 0;
-    if (b0 > 0) {
-        const uint64_t X = b0 + 1, tX = X / TILE;
-        const uint32_t gA = read_u32(S.tile_first.get() + tX, st);        // first group that begins at or after tX * TILE
-        t_lo = tX;
-        if (gA > 0 && (gA >= S.n_groups || S.segb.read(gA, st) > X)) t_lo = S.segb.read(gA - 1, st) / TILE;
-    }
+    const auto known = S.first_tile.find(b0);
+    if (known != S.first_tile.end()) t_lo = known->second;
+    else t_lo = pfp_first_tile(b0);
     const uint64_t t_hi = std::min<uint64_t>(S.tiles, c1 / TILE + 1);      // stream entry c1 (suffix-array entry c1 - 1) is the last one
     auto first_group_at = [&](uint64_t out_pos) {                         // first oversized group that begins at or after out_pos
         return (uint32_t)(std::lower_bound(S.h_fb_start.begin(), S.h_fb_start.end(), out_pos) - S.h_fb_start.begin());
@@ -521,6 +531,13 @@ void Engine::pfp_stream(ScanState& SS, const mmt_params& p) {
         self->shard_index_ = keep;
     }
     const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
+    // the first emitter tile of every window, while nothing else is queued (a window that has to be repeated with a longer
+    // extension looks its tile up when it gets there)
+    S.first_tile.clear();
+    for (uint64_t c0 = lo; c0 < hi; c0 += range) {
+        const uint64_t b0 = c0 - std::min<uint64_t>(c0 ? SS.ext0 : 0, c0);
+        S.first_tile[b0] = pfp_first_tile(b0);
+    }
     for (uint64_t c0 = lo; c0 < hi; c0 += range) {
         const uint64_t c1 = std::min(hi, c0 + range);
         uint64_t ext = c0 ? SS.ext0 : 0;

@@ -1,5 +1,6 @@
 // pfp.hpp -- device state of the prefix-free-parsing producer (rows A2-A4).
 #pragma once
+#include <unordered_map>
 #include <cstdint>
 #include <vector>
 
@@ -37,6 +38,7 @@ struct PfpState {
     DevBuf<uint32_t> ghead, ce_hl, ce_slen, occ_sl, lcp_d;   // lcp_d: LCP array of the dictionary (suffix-array order)
     DevBuf<uint64_t> segmin;                                // (flag, minimum of lcp_d since the valid entry before) per entry
     uint32_t n_entries = 0, n_fallback = 0, emit_launches = 0;
+    std::unordered_map<uint64_t, uint64_t> first_tile;     // window begin (stream entry) -> first emitter tile of the window
     bool bwt_ready = false;
     // the emitter between its windows (Engine::pfp_emit_window): arguments shared by every launch, the oversized groups'
     // offsets / begin positions on the host, the BWT code of their sort keys

@@ -354,26 +354,26 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
     // equal first fingerprints of different phrases: when the order came from the first fingerprint alone, equal
     // phrases need not be adjacent any more -- the host then repeats the grouping with both fingerprints
     if (same1 && !same) atomicOr(err + 1, 1u);
-    // byte verification, 8 bytes per step; the loop runs while any lane of the wave still compares
+    // byte verification; the loop runs while any lane of the wave still compares
     const uint8_t* px = v + (((uint64_t)(X.y >> 24) << 32) | X.z);
     const uint8_t* py = v + (((uint64_t)(Y.y >> 24) << 32) | Y.z);
     const uint32_t l = X.w;
     bool verified = same;
-    for (uint32_t i = 0; __ballot(same && i < l) != 0; i += 8) {
+    // (16 bytes per step: the two loads of a step are independent and in flight together)
+    auto chunk = [&](const uint8_t* p, uint32_t i) -> uint64_t {
+        uint64_t x = 0;
+        if (i + 8 <= l) x = ld64(p + i);
+        else for (uint32_t t = i; t < l; t++) x |= (uint64_t)p[t] << (8 * (t - i));
+        return x;
+    };
+    for (uint32_t i = 0; __ballot(same && i < l) != 0; i += 16) {
         // every lane with bytes left loads its own chunk (the lane above may need it even if this lane is done comparing)
-        uint64_t mine = 0;
-        if (have && i < l) {
-            if (i + 8 <= l) mine = ld64(px + i);
-            else for (uint32_t t = i; t < l; t++) mine |= (uint64_t)px[t] << (8 * (t - i));
-        }
-        uint64_t prev = __shfl_up(mine, 1, 64);
+        uint64_t mine0 = 0, mine1 = 0;
+        if (have && i < l) { mine0 = chunk(px, i); if (i + 8 < l) mine1 = chunk(px, i + 8); }
+        uint64_t prev0 = __shfl_up(mine0, 1, 64), prev1 = __shfl_up(mine1, 1, 64);
         if (same && i < l) {
-            if (lane == 0) {
-                prev = 0;
-                if (i + 8 <= l) prev = ld64(py + i);
-                else for (uint32_t t = i; t < l; t++) prev |= (uint64_t)py[t] << (8 * (t - i));
-            }
-            if (mine != prev) { same = false; verified = false; }
+            if (lane == 0) { prev0 = chunk(py, i); prev1 = i + 8 < l ? chunk(py, i + 8) : 0; }
+            if (mine0 != prev0 || mine1 != prev1) { same = false; verified = false; }
         }
     }
     if (have) {
@@ -483,19 +483,37 @@ void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const u
 __global__ void k_entry_info(const uint32_t* __restrict__ sa_d, const uint64_t* __restrict__ dinfo,
                              const uint8_t* __restrict__ dict, uint32_t nd, int pack_prev,
                              uint32_t* __restrict__ esuf, uint32_t* __restrict__ ephr, uint8_t* __restrict__ ebw) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // four entries per thread: the four gathers are in flight together, the columns are stored 16 / 16 / 4 bytes at a time
+    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (r >= nd) return;
-    const uint32_t pos = sa_d[r];
-    const uint64_t e = dinfo[pos];
-    esuf[r] = (uint32_t)e;
-    uint8_t prev;
-    if (pack_prev) { ephr[r] = (uint32_t)(e >> 32) & 0xffffffu; prev = (uint8_t)(e >> 56); }
-    else { ephr[r] = (uint32_t)(e >> 32); prev = pos ? dict[pos - 1] : (uint8_t)0; }
-    ebw[r] = prev == 2 ? (uint8_t)0 : prev;                 // Dollar before text position 0 -> bwt 0
+    auto one = [&](uint32_t pos, uint64_t e, uint32_t& su, uint32_t& ph) -> uint32_t {
+        su = (uint32_t)e;
+        uint8_t prev;
+        if (pack_prev) { ph = (uint32_t)(e >> 32) & 0xffffffu; prev = (uint8_t)(e >> 56); }
+        else { ph = (uint32_t)(e >> 32); prev = pos ? dict[pos - 1] : (uint8_t)0; }
+        return prev == 2 ? 0u : (uint32_t)prev;               // Dollar before text position 0 -> bwt 0
+    };
+    if (r + 4 <= nd) {
+        const uint4 p = *reinterpret_cast<const uint4*>(sa_d + r);
+        const uint64_t e0 = dinfo[p.x], e1 = dinfo[p.y], e2 = dinfo[p.z], e3 = dinfo[p.w];
+        uint4 su, ph;
+        const uint32_t b0 = one(p.x, e0, su.x, ph.x), b1 = one(p.y, e1, su.y, ph.y), b2 = one(p.z, e2, su.z, ph.z),
+                       b3 = one(p.w, e3, su.w, ph.w);
+        *reinterpret_cast<uint4*>(esuf + r) = su;
+        *reinterpret_cast<uint4*>(ephr + r) = ph;
+        *reinterpret_cast<uint32_t*>(ebw + r) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    } else {
+        for (uint64_t t = r; t < nd; t++) {
+            const uint32_t pos = sa_d[t];
+            uint32_t su, ph;
+            ebw[t] = (uint8_t)one(pos, dinfo[pos], su, ph);
+            esuf[t] = su; ephr[t] = ph;
+        }
+    }
 }
 void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, bool pack_prev,
                 uint32_t* esuf, uint32_t* ephr, uint8_t* ebw, hipStream_t s) {
-    hipLaunchKernelGGL(k_entry_info, dim3(grid_for(nd, 256)), dim3(256), 0, s, sa_d, dinfo, dict, nd, pack_prev ? 1 : 0,
+    hipLaunchKernelGGL(k_entry_info, dim3(grid_for(nd, 1024)), dim3(256), 0, s, sa_d, dinfo, dict, nd, pack_prev ? 1 : 0,
                        esuf, ephr, ebw);
     MMT_HIP(hipGetLastError());
 }
@@ -1189,9 +1207,9 @@ uint32_t emit_tile() {
     }();
     return t;
 }
-template <typename P, typename SA, int TILE>
+template <typename P, typename SA, int TILE, int BLOCK = 256>
 static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
-    constexpr int BLOCK = 256, CAP = (int)EMIT_CAP;
+    constexpr int CAP = (int)EMIT_CAP;
     EmitArgsT<P, SA> t;
     t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
     t.ce_eoff = static_cast<const P*>(a.ce_eoff); t.ce_cnt = a.ce_cnt; t.ce_first = a.ce_first; t.ce_offm1 = a.ce_offm1;

@@ -22,7 +22,7 @@ void DoublingSorter::reserve(uint32_t n) {
 // sorted in LDS, the few ranges holding a bucket longer than a tile by one segmented radix sort.
 void DoublingSorter::release() {
     keys_a_.release(); keys_b_.release();
-    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &bound_, &big_begin_, &big_end_})
+    for (DevBuf<uint32_t>* b : {&sac_a_, &sac_b_, &pos_a_, &pos_b_, &headc_, &headc_b_, &bound_, &big_begin_, &big_end_})
         b->release();
     hf_.release(); tile_big_.release();
 }
@@ -84,6 +84,12 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
                                  !(std::getenv("MMT_SORT_FUSED") && std::atoi(std::getenv("MMT_SORT_FUSED")) == 0);
     static const bool trace = std::getenv("MMT_SORT_TRACE") != nullptr;      // tuning aid: the active set round by round
     if (trace) std::fprintf(stderr, "[sort] n %u, tied after the first pass %u (h = %llu)\n", n, m, (unsigned long long)h0);
+    if (!side_ && !std::getenv("MMT_SORT_ONE_STREAM")) {
+        MMT_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        MMT_HIP(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
+        MMT_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
+    }
+    bool side_busy = false;
     uint64_t h = h0;
     int rounds = 0;
     while (m) {
@@ -94,7 +100,7 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
         bool done = false;
         if (fused_ok && m >= 4096) {
             // one pass over the active list: gather, sort in LDS, new heads, SA entries (no key column); then the ranks
-            const uint32_t target = 1024, limit = k::ROUND_TILE_CAP;
+            const uint32_t limit = k::round_fused_cap(), target = limit / 2;
             const uint32_t n_tiles = (m + target - 1) / target;
             const size_t m4 = ((size_t)m + 15) & ~(size_t)15;
             hf_.ensure(m4 * 5 + 16); bound_.ensure((size_t)n_tiles + 2); tile_big_.ensure((size_t)n_tiles + 1);
@@ -124,9 +130,18 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
                     k::round_big_apply(tile_big_.get(), bound_.get(), target, n_tiles, m, sac_b_.get(), head_w, pos_a_.get(),
                                        sa, flags_w, s);
                 }
+                // the scatter of the ranks (random stores: latency) runs beside the compaction of the list (streams):
+                // both read the sorted list, the compaction writes the other copies of its columns
                 static const bool all_ranks = std::getenv("MMT_SORT_ALL_RANKS") != nullptr;        // (A/B: every rank rewritten)
-                if (all_ranks) k::scatter_rank(sac_b_.get(), head_w, m, rank, s);
-                else k::scatter_rank_changed(sac_b_.get(), head_w, headc_.get(), m, rank, s);
+                hipStream_t sb = s;
+                if (side_) {
+                    MMT_HIP(hipEventRecord(ev_main_, s));
+                    MMT_HIP(hipStreamWaitEvent(side_, ev_main_, 0));
+                    sb = side_;
+                }
+                if (all_ranks) k::scatter_rank(sac_b_.get(), head_w, m, rank, sb);
+                else k::scatter_rank_changed(sac_b_.get(), head_w, headc_.get(), m, rank, sb);
+                if (side_) { MMT_HIP(hipEventRecord(ev_side_, side_)); side_busy = true; }
                 head_r = head_w; flags_r = flags_w;
                 done = true;
             }
@@ -145,9 +160,12 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
         MMT_HIP(hipMemcpyAsync(&m2, count_.get(), 4, hipMemcpyDeviceToHost, s));
         MMT_HIP(hipStreamSynchronize(s));
         if (m2) {
-            k::compact_round(idx, m2, pos_a_.get(), sac_b_.get(), head_r, pos_b_.get(), sac_a_.get(), headc_.get(), s);
+            headc_b_.ensure(m2);
+            k::compact_round(idx, m2, pos_a_.get(), sac_b_.get(), head_r, pos_b_.get(), sac_a_.get(), headc_b_.get(), s);
             pos_a_.swap(pos_b_);
         }
+        if (side_busy) { MMT_HIP(hipStreamWaitEvent(s, ev_side_, 0)); side_busy = false; }      // the ranks are in place
+        if (m2) headc_.swap(headc_b_);
         m = m2;
         h *= 2;
     }

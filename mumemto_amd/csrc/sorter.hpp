@@ -31,9 +31,11 @@ public:
     void release();
 
 private:
+    hipStream_t side_ = nullptr;         // the rank scatter of a round runs beside the compaction of the active list
+    hipEvent_t ev_main_ = nullptr, ev_side_ = nullptr;
     void sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hipStream_t s);
     DevBuf<uint64_t> keys_a_, keys_b_;
-    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, count_, bound_, big_begin_, big_end_;
+    DevBuf<uint32_t> sac_a_, sac_b_, pos_a_, pos_b_, headc_, headc_b_, count_, bound_, big_begin_, big_end_;
     DevBuf<uint8_t> hf_, tile_big_;      // new heads (4 B) + flags (1 B) per tied suffix of a round; marks of the long ranges' tiles
 };
 

@@ -364,6 +364,24 @@ def test_letter_runs_make_giant_sort_ranges(producer, giant):
     assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("producer", ["pfp", "direct"])
+@pytest.mark.parametrize("env", [{"MMT_SORT_FUSED": "0"}, {"MMT_ROUND_CAP": "1024", "MMT_GIANT_RANGE": "3000"},
+                                 {"MMT_SORT_ONE_STREAM": "1", "MMT_SORT_ALL_RANKS": "1"}, {"MMT_ROUND_CAP": "1536"}])
+def test_doubling_round_paths(producer, env):
+    """A doubling round of the suffix sorter is one pass over the active list (k_round_fused + the scatter of the changed
+    ranks on a second stream), with the ranges beyond an LDS tile finished around a segmented sort (k_big_*).  The
+    round of separate kernels (MMT_SORT_FUSED=0), the smaller tiles (more ranges take the long path), the scatter of
+    every rank on the one stream: all must give the bytes of the oracle, on letter runs (one bucket of tens of thousands
+    of suffixes through many rounds) and on exact copies."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for shape in ("runs", "dups"):
+        r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py"), "5", "30000", shape],
+                           env=dict(os.environ, MUMEMTO_PRODUCER=producer, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "scan shapes ok" in r.stdout, shape + r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("variant,bpc", [(0, 1), (0, 16), (1, 1), (2, 2)])
 def test_scan_kernel_shapes_and_double_buffering(variant, bpc):
     """k_scan's workgroup shape and grid size are tuning knobs (MMT_SCAN_VARIANT / MMT_SCAN_BPC, read once per

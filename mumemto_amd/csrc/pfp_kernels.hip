@@ -271,6 +271,7 @@ __device__ __forceinline__ void hash_range(const uint8_t* __restrict__ v, uint64
 // The per-phrase record is 16 bytes: 56 bits of the second fingerprint, the 40-bit start (its high byte rides in the
 // top byte of the fingerprint word), the length.
 constexpr uint32_t FP2_HI_MASK = 0x00ffffffu;
+constexpr uint32_t HASH_SPAN = 4096;          // bytes of V one wave of k_phrase_hash stages in LDS
 template <typename P>
 __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict__ start,
                               const uint32_t* __restrict__ len, uint32_t m, uint64_t* __restrict__ o1,
@@ -282,7 +283,28 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict
     const uint32_t l = have ? len[k] : 0;
     const bool is_long = l > 2048;
     uint64_t h1 = 0, h2 = 0, p1, p2;
-    if (have && !is_long) hash_range(v, a, a + l, h1, h2, p1, p2);
+    // The 64 phrases of a wave are consecutive in V and overlap by w characters: when they span at most HASH_SPAN bytes
+    // the wave brings the span into LDS with aligned 16-byte loads and every lane reads its phrase from there (one byte
+    // load per character and lane from global memory ran at 0.4 TB/s).  The first wave (nothing readable before V) and
+    // waves with a long phrase or a partial set of lanes read V directly.
+    __shared__ __attribute__((aligned(16))) uint8_t s_span[(256 / 64) * (HASH_SPAN + 32)];
+    {
+        const uint32_t wave = threadIdx.x >> 6;
+        uint8_t* const mine = s_span + wave * (HASH_SPAN + 32);
+        const uint64_t a_first = __shfl(a, 0, 64), a_last = __shfl(a, 63, 64), l_last = __shfl(l, 63, 64);
+        const bool whole = __ballot(have) == ~0ull && __ballot(is_long) == 0 && k >= 64;
+        const uint64_t lo16 = ((uint64_t)(uintptr_t)(v + a_first)) & ~(uint64_t)15;
+        const uint64_t end = (uint64_t)(uintptr_t)(v + a_last + l_last);
+        if (whole && end - lo16 <= HASH_SPAN) {
+            const uint32_t chunks = (uint32_t)((end - lo16 + 15) / 16);
+            for (uint32_t c = lane; c < chunks; c += 64)
+                *reinterpret_cast<uint4*>(mine + 16 * c) = *reinterpret_cast<const uint4*>((const uint8_t*)(uintptr_t)lo16 + 16 * (uint64_t)c);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint32_t o = (uint32_t)((uint64_t)(uintptr_t)(v + a) - lo16);
+            hash_range(mine, o, (uint64_t)o + l, h1, h2, p1, p2);
+        } else if (have && !is_long) hash_range(v, a, a + l, h1, h2, p1, p2);
+    }
     // long phrases (no trigger inside a low-complexity run): the whole wave hashes one phrase
     uint64_t todo = __ballot(have && is_long);
     while (todo) {

@@ -65,8 +65,9 @@ def build(verbose=False):
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, LIB_SOURCES + tool_sources))
     lib_objs = [o for o in objs[: len(LIB_SOURCES)] if o]
-    if _newer(LIB, lib_objs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + lib_objs + ["-Wl,-soname,libmumemto.so", "-lz", "-ldl"]
+    if _newer(LIB, lib_objs + [os.path.join(SRC, "libmumemto.map")]):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + lib_objs + [
+            "-Wl,-soname,libmumemto.so", "-Wl,--version-script=" + os.path.join(SRC, "libmumemto.map"), "-lz", "-ldl"]
         subprocess.check_call(cmd)
     for tool, srcs in TOOLS.items():
         tobjs = [os.path.join(OBJ, s + ".o") for s in srcs if os.path.exists(os.path.join(OBJ, s + ".o"))]

@@ -287,8 +287,14 @@ def main():
                      "kernel_ms_per_step": scan_avg_ms,
                      "frac_at_reference_widths": REF_STREAM_BYTES * n_text / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "stage_ms_avg": {k: float(v) / a.steps for k, v in zip(
-            ["text", "suffix_sort", "lcp_bwt", "scan_kernel", "verify", "rows", "host_rows_format", "engine_total"],
+            ["text", "suffix_sort", "lcp_bwt", "scan_kernel", "verify", "rows", "stream_windows_in_suffix_sort", "engine_total"],
             stage_acc)},
+        # the largest kernel of the step is not the roofline kernel: the emitter writes the windows of the stream (SA 5 B on a
+        # wide text + BWT 1 + LCP 4 per suffix) and is bound by latency and VALU work, not by HBM
+        "largest_kernel": {"kernel": "stream windows (k_emit: expands the phrase-suffix groups into SA / BWT / LCP entries)",
+                           "ms_per_step": float(stage_acc[6]) / a.steps, "bytes_written_per_suffix": sum(col),
+                           "achieved": sum(col) * n_text / max(float(stage_acc[6]) / a.steps, 1e-9) / 1e6, "unit": "GB/s",
+                           "frac": sum(col) * n_text / max(float(stage_acc[6]) / a.steps, 1e-9) / 1e6 / HBM_PEAK_GBS},
         "device_memory": eng.device_memory(),
         "generate_s": t_gen,
     }

@@ -133,8 +133,8 @@ MMT_API size_t mmt_num_candidates(const mmt_engine* e);
 MMT_API int mmt_copy_candidates(const mmt_engine* e, uint32_t* out);
 /* HIP-event times (ms) of the last run:
  * [0] text build  [1] suffix sort  [2] LCP+BWT  [3] scan kernel (roofline kernel)
- * [4] candidate verification + thresholds  [5] row gather + D2H  [6] host rows/format
- * [7] whole run (host clock).                                                  */
+ * [4] candidate verification + thresholds  [5] row gather + D2H  [6] the windows of the stream (emitter /
+ * bucket batches; part of [1])  [7] whole run (host clock).                     */
 MMT_API int mmt_stage_ms(const mmt_engine* e, float out[8]);
 /* Bytes of the SA / LCP / BWT columns as stored (for the roofline model).     */
 MMT_API int mmt_column_bytes(const mmt_engine* e, uint32_t out[3]);

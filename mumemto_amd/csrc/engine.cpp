@@ -927,6 +927,7 @@ void Engine::run(const mmt_params& p) {
     auto finish = [&]() {
         for (int i = 0; i < 6; i++) stage_ms_[i] = ev_[i]->ms();
         stage_ms_[1] += scan_ms_[3];                    // the windows of the columns are produced between the scans
+        stage_ms_[6] = scan_ms_[3];                     // ... and reported on their own as well (the emitter / the guided batches)
         stage_ms_[2] += scan_ms_[0];                    // the LCP column is gathered range by range inside the scan
         stage_ms_[3] = scan_ms_[1];                     // k_scan (+ the window tables of the wide-document path)
         stage_ms_[4] = scan_ms_[2];

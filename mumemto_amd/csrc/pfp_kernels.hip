@@ -905,7 +905,7 @@ struct EmitShared {
     uint32_t eoffm1[CAP];              // the element in every slot of the merged order, as CAP pairs
     uint32_t key[CAP];
     uint32_t estart[CAP + 1];
-    uint32_t egfirst[CAP];       // first entry of the entry's group
+    uint16_t egfirst[CAP];       // first entry of the entry's group (an index below CAP)
     uint32_t egs[CAP];           // group id + 1 at the first entry of a group, 0 elsewhere
     uint16_t owner[CAP];
     uint8_t ebwt[CAP];
@@ -976,7 +976,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
             if (i < L) sh.owner[i] = (uint16_t)(loc[q] > pre ? loc[q] : pre);
             if (i < E) {
                 const uint32_t gf = gloc[q] > gpre ? gloc[q] : gpre;
-                sh.egfirst[i] = gf;
+                sh.egfirst[i] = (uint16_t)gf;
                 if (sorted && (i + 1 == E || sh.egs[i + 1]) && i - gf >= a.many_runs) atomicMax(&sh.many, i - gf + 1);
             }
         }
@@ -1178,40 +1178,40 @@ void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* o
 }
 
 template <int BLOCK, int CAP, int TILE, typename P, typename SA>
-__global__ __launch_bounds__(BLOCK) void k_emit(EmitArgsT<P, SA> a, const uint32_t* __restrict__ tile_first) {
+__global__ __launch_bounds__(BLOCK, 6) void k_emit(EmitArgsT<P, SA> a, const uint32_t* __restrict__ tile_first) {
     __shared__ EmitShared<BLOCK, CAP> sh;
-    __shared__ uint32_t s_gb[TILE + 2];          // begin offsets of the groups that start in this tile (+ the next one), minus the tile's first offset
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t tile = a.tile_lo + blockIdx.x;
     const P tbase = (P)(tile * TILE);
-    // groups whose begin offset lies in [tile*TILE, (tile+1)*TILE): at most TILE of them, every group has an element
+    // groups whose begin offset lies in [tile*TILE, (tile+1)*TILE): at most TILE of them, every group has an element.
+    // Their begin offsets are read where they are needed (a table of them in LDS cost the sixth workgroup per CU).
     const uint32_t g0 = tile_first[tile], g_end = tile_first[tile + 1];
-    const uint32_t ng = g_end - g0;
-    for (uint32_t i = tid; i <= ng; i += BLOCK) {
-        const uint64_t d = (uint64_t)a.segb[g0 + i] - (uint64_t)tbase;      // the group after the last one may start far away
-        s_gb[i] = d < 0x7fffffffull ? (uint32_t)d : 0x7fffffffu;
-    }
-    __syncthreads();
     uint32_t g = g0;
     while (g < g_end) {
         // chunk = maximal run of whole groups [g, g2) with at most CAP elements
         __syncthreads();
         if (wave == 0) {
-            const uint32_t lim = s_gb[g - g0] + CAP;
+            const uint64_t first = (uint64_t)a.segb[g] - (uint64_t)tbase;
+            const uint64_t lim = first + CAP;
             uint32_t c = 0;                                  // groups after g that still begin at or before lim
-            for (uint32_t base = g - g0 + 1; base <= ng; base += 64) {
-                const uint32_t idx = base + lane;
-                const uint64_t m = __ballot(idx <= ng && s_gb[idx] <= lim);
+            for (uint32_t base = g + 1; base <= g_end; base += 64) {
+                const uint32_t idx = base + lane;            // (the group after the last one may start far away)
+                const bool ok = idx <= g_end && (uint64_t)a.segb[idx] - (uint64_t)tbase <= lim;
+                const uint64_t m = __ballot(ok);
                 c += (uint32_t)__popcll(m);
                 if (m != ~0ull) break;
             }
-            if (lane == 0) sh.bound[2] = g + c;              // segb[g2] <= lim < segb[g2 + 1]
+            if (lane == 0) {                                 // segb[g2] <= lim < segb[g2 + 1]
+                sh.bound[2] = g + c;
+                sh.bound[0] = (uint32_t)first;
+                sh.bound[1] = (uint32_t)((uint64_t)a.segb[g + c] - (uint64_t)tbase - first);
+            }
         }
         __syncthreads();
         const uint32_t g2 = sh.bound[2];
         if (g2 > g) {
-            const uint32_t clo = s_gb[g - g0];
-            emit_piece<BLOCK, CAP, P, SA>(a, sh, a.sege[g], a.sege[g2], tbase + clo, s_gb[g2 - g0] - clo, true, (P)0);
+            const uint32_t clo = sh.bound[0], L = sh.bound[1];
+            emit_piece<BLOCK, CAP, P, SA>(a, sh, a.sege[g], a.sege[g2], tbase + clo, L, true, (P)0);
             g = g2;
             continue;
         }

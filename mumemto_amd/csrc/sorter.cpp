@@ -12,6 +12,12 @@ namespace mmt {
 
 static int bit_width_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
+DoublingSorter::~DoublingSorter() {
+    if (side_) (void)hipStreamDestroy(side_);
+    if (ev_main_) (void)hipEventDestroy(ev_main_);
+    if (ev_side_) (void)hipEventDestroy(ev_side_);
+}
+
 // Text-sized scratch: the two key columns and one value column, 20 bytes per suffix.  Everything else is either carved out
 // of a key column that is dead at that point of sort() or sized by the active set (the suffixes the first sort left tied).
 void DoublingSorter::reserve(uint32_t n) {

@@ -12,6 +12,9 @@ namespace mmt {
 
 class DoublingSorter {
 public:
+    DoublingSorter() = default;
+    DoublingSorter(const DoublingSorter&) = delete;
+    ~DoublingSorter();
     // The caller fills keys_in() / vals_in() for n suffixes: keys = first h0 symbols of every
     // suffix packed big-endian into `key_bits` bits (past-the-end = 0 = smallest), vals = 0..n-1.
     void reserve(uint32_t n);

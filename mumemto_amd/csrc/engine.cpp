@@ -195,7 +195,7 @@ void Engine::suffix_sort() {
 
     d_sa_.ensure(n); d_rank_.ensure(n);
     sorter_.reserve(n);
-    k::pack_keys(text_ptr(), n, d_code_.get(), bits, chars, 0u, sorter_.keys_in(), sorter_.vals_in(), stream_);
+    k::pack_keys(text_ptr(), n, d_code_.get(), bits, chars, k::PACK_NO_SEP, sorter_.keys_in(), sorter_.vals_in(), stream_);
     sort_rounds_ = sorter_.sort(n, bits * chars, (uint64_t)chars, d_sa_.get(), d_rank_.get(), d_temp_, stream_);
 }
 

@@ -345,9 +345,10 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     pk::copy_dict(text_ptr() - 1, S.pstart.get(), S.plen.get(), which.get(), gstart.get(), nG, dict.get(), dinfo.get(), nd, false, W, st);
     uint8_t code[256];
     int sigma = 0;
-    // (0x00 occurs once, as the last byte of the dictionary: it shares code 0 with the padding behind the end -- seven
-    // symbols then fit three bits, 21 characters per 64-bit key instead of 15)
-    for (int c = 0; c < 256; c++) code[c] = (c != 0 && (hist[c] || c <= 2)) ? (uint8_t)(++sigma) : 0;
+    // (0x00 -- once, the last byte of the dictionary -- and the phrase terminator 0x01 share code 0 with the padding behind
+    // the end: nothing is compared behind a terminator, terminators are ordered by position.  Dollar, the document
+    // separator, A C G T and N then fit three bits: 21 characters per 64-bit key instead of 15)
+    for (int c = 0; c < 256; c++) code[c] = (c > 1 && (hist[c] || c == 2)) ? (uint8_t)(++sigma) : 0;
     const int bits = std::max(1, bit_width_u64((uint64_t)sigma)), chars = std::min(63 / bits, 63);
     code_d.ensure(256);
     MMT_HIP(hipMemcpyAsync(code_d.get(), code, 256, hipMemcpyHostToDevice, st));

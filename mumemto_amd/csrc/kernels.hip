@@ -187,7 +187,8 @@ void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* 
 // ============================================================================
 // Tile of the text is converted to `bits`-wide symbol codes in LDS once; each
 // thread then builds 4 consecutive keys with a rolling shift.
-// sep_code != 0 (PFP dictionary): every occurrence of that symbol is a UNIQUE terminator, ordered by position --
+// sep_code != PACK_NO_SEP (PFP dictionary): every occurrence of that symbol is a UNIQUE terminator, ordered by position
+// (its code may be 0, the code of the padding behind the end: nothing is compared behind a terminator) --
 // the strings between terminators are what matters there, and a suffix is fully ordered as soon as its window
 // reaches its terminator.  The key then is (symbols up to and including the first terminator, rest zeroed) << 1
 // | 1; without a terminator in the window (symbols) << 1.  Equal keys with the low bit set stay in position
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__
     const int t0 = threadIdx.x * PER;
     const uint64_t mask = (bits * chars >= 64) ? ~0ull : ((1ull << (bits * chars)) - 1);
     int next_sep[PER];                                   // offset of the first terminator in window q, or >= chars
-    if (sep_code) {
+    if (sep_code != PACK_NO_SEP) {
         int nx = 1 << 20;
         for (int idx = t0 + PER - 1 + chars - 1; idx >= t0; idx--) {
             if (s_sym[idx] == sep_code) nx = idx;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__
         uint64_t p = base + t0 + q;
         if (p < n) {
             uint64_t kq = key & mask;
-            if (sep_code) {
+            if (sep_code != PACK_NO_SEP) {
                 const int d = next_sep[q];
                 if (d < chars) kq = ((kq >> (bits * (chars - 1 - d))) << (bits * (chars - 1 - d)) << 1) | 1ull;
                 else kq <<= 1;

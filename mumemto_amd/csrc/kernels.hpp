@@ -30,8 +30,9 @@ void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* 
 // ---- A8 direct suffix sort (prefix doubling) --------------------------------
 // keys[i] = first `chars` symbols of suffix i, `bits` per symbol via code[256]
 // (0 = past the end, smaller than every symbol); vals[i] = i.
-// sep_code != 0: that symbol is a unique terminator (ordered by position); keys get a low "reached my terminator"
+// sep_code != PACK_NO_SEP: that symbol is a unique terminator (ordered by position); keys get a low "reached my terminator"
 // bit and bits * chars + 1 <= 64 must hold (see kernels.hip).
+static const uint32_t PACK_NO_SEP = 0xffffffffu;
 void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint32_t sep_code,
                uint64_t* keys, uint32_t* vals, hipStream_t s);
 // headval[j] = j if keys[j] != keys[j-1] (or j == 0) else 0

@@ -177,9 +177,10 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     e3.start(st);
     uint8_t code[256];
     int sigma = 0;
-    // (0x00 occurs once, as the last byte of the dictionary: it shares code 0 with the padding behind the end -- seven
-    // symbols then fit three bits, 21 characters per 64-bit key instead of 15)
-    for (int c = 0; c < 256; c++) code[c] = (c != 0 && (hist[c] || c <= 2)) ? (uint8_t)(++sigma) : 0;
+    // (0x00 -- once, the last byte of the dictionary -- and the phrase terminator 0x01 share code 0 with the padding behind
+    // the end: nothing is compared behind a terminator, terminators are ordered by position.  Dollar, the document
+    // separator, A C G T and N then fit three bits: 21 characters per 64-bit key instead of 15)
+    for (int c = 0; c < 256; c++) code[c] = (c > 1 && (hist[c] || c == 2)) ? (uint8_t)(++sigma) : 0;
     const int bits = std::max(1, bit_width_u64((uint64_t)sigma));
     // every 0x01 (end of a phrase) is a unique terminator, ordered by position: what follows it never matters, so
     // a suffix is final as soon as the compared prefix reaches the end of its phrase (one key bit says so)

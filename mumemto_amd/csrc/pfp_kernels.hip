@@ -899,14 +899,14 @@ struct EmitArgsT {
     uint64_t out_base, win_lo, win_hi;
     uint32_t many_runs;          // a group of more runs than this: the piece is ranked by one sort in LDS (emit_piece)
 };
-template <int BLOCK, int CAP>
+template <int BLOCK, int CAP, typename ES = uint32_t>
 struct EmitShared {
     alignas(8) uint32_t efirst[CAP];   // these two also hold, once the elements have their positions, (key, sl[key - 1]) of
     uint32_t eoffm1[CAP];              // the element in every slot of the merged order, as CAP pairs
     uint32_t key[CAP];
-    uint32_t estart[CAP + 1];
+    ES estart[CAP + 1];          // (16 bits where the entries of a piece begin inside it: k_emit; a chunk of an oversized group may begin before its piece)
     uint16_t egfirst[CAP];       // first entry of the entry's group (an index below CAP)
-    uint32_t egs[CAP];           // group id + 1 at the first entry of a group, 0 elsewhere
+    uint16_t egs[CAP];           // group id + 1 - (first group of the piece) at the first entry of a group, 0 elsewhere
     uint16_t owner[CAP];
     uint8_t ebwt[CAP];
     uint32_t wmax[BLOCK / 64], gwmax[BLOCK / 64];
@@ -919,10 +919,10 @@ struct EmitShared {
 // LDS.  sorted = true: entries form whole groups; every element goes to its merged position in
 // sa / bwt.  sorted = false: part of an oversized group; (key, position) go to the fallback arrays at
 // (output offset - fb_origin).
-template <int BLOCK, int CAP, typename P, typename SA>
-__device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
-                                           P clo, uint32_t L, bool sorted, P fb_origin) {
-    using EmitSh = EmitShared<BLOCK, CAP>;
+template <int BLOCK, int CAP, typename P, typename SA, typename ES>
+__device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared<BLOCK, CAP, ES>& sh, uint32_t e0, uint32_t e1,
+                                           P clo, uint32_t L, bool sorted, P fb_origin, uint32_t gbase) {
+    using EmitSh = EmitShared<BLOCK, CAP, ES>;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t E = e1 - e0;
     const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
@@ -931,14 +931,15 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
     __syncthreads();
     for (uint32_t e = tid; e < E; e += BLOCK) {
         const uint32_t st = (uint32_t)(a.ce_eoff[e0 + e] - clo);
-        sh.estart[e] = st;
+        sh.estart[e] = (ES)st;
         sh.efirst[e] = a.ce_first[e0 + e];
         sh.eoffm1[e] = a.ce_offm1[e0 + e];
         sh.ebwt[e] = a.ce_bwt[e0 + e];
-        sh.egs[e] = a.ce_gs[e0 + e];
+        const uint32_t gs = a.ce_gs[e0 + e];               // group id + 1 at the first entry of a group
+        sh.egs[e] = (uint16_t)(gs ? (sorted ? gs - gbase : 1u) : 0u);
         sh.owner[st < L ? st : 0u] = (uint16_t)e;            // (k_emit_big: entry 0 may begin before the piece -- st wraps, k = i - st holds)
     }
-    if (tid == 0) { sh.estart[E] = L; sh.many = 0; }
+    if (tid == 0) { sh.estart[E] = (ES)L; sh.many = 0; }
     __syncthreads();
     // owner[i] = last entry starting at or before i; egfirst[e] = last group-start entry at or before e
     // (running maxima over <= CAP items: each thread scans a contiguous slice, slices are stitched)
@@ -1019,7 +1020,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
             my_e[q] = sh.owner[i];
             my_gf[q] = sh.egfirst[my_e[q]];
             my_gs[q] = sh.estart[my_gf[q]];
-            g_head[q] = a.ghead[sh.egs[my_gf[q]] - 1];
+            g_head[q] = a.ghead[gbase + sh.egs[my_gf[q]] - 1];
         }
     }
     // merge rank of every element inside its group = its slot
@@ -1178,8 +1179,8 @@ void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* o
 }
 
 template <int BLOCK, int CAP, int TILE, typename P, typename SA>
-__global__ __launch_bounds__(BLOCK, 6) void k_emit(EmitArgsT<P, SA> a, const uint32_t* __restrict__ tile_first) {
-    __shared__ EmitShared<BLOCK, CAP> sh;
+__global__ __launch_bounds__(BLOCK, 7) void k_emit(EmitArgsT<P, SA> a, const uint32_t* __restrict__ tile_first) {
+    __shared__ EmitShared<BLOCK, CAP, uint16_t> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t tile = a.tile_lo + blockIdx.x;
     const P tbase = (P)(tile * TILE);
@@ -1211,7 +1212,7 @@ __global__ __launch_bounds__(BLOCK, 6) void k_emit(EmitArgsT<P, SA> a, const uin
         const uint32_t g2 = sh.bound[2];
         if (g2 > g) {
             const uint32_t clo = sh.bound[0], L = sh.bound[1];
-            emit_piece<BLOCK, CAP, P, SA>(a, sh, a.sege[g], a.sege[g2], tbase + clo, L, true, (P)0);
+            emit_piece<BLOCK, CAP, P, SA, uint16_t>(a, sh, a.sege[g], a.sege[g2], tbase + clo, L, true, (P)0, g);
             g = g2;
             continue;
         }
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit_big(EmitArgsT<P, SA> a, const ui
     }
     __syncthreads();
     const uint32_t e0 = sh.bound[1], e1 = sh.bound[2];
-    emit_piece<BLOCK, CAP, P, SA>(a, sh, e0, e1, (P)X0, L, false, fb_origin);
+    emit_piece<BLOCK, CAP, P, SA, uint32_t>(a, sh, e0, e1, (P)X0, L, false, fb_origin, 0u);
 }
 template <typename P, typename SA>
 static void emit_big_typed(const EmitArgs& a, const uint64_t* chunk0, uint32_t f0, uint32_t nf, uint32_t n_chunks, hipStream_t s) {

@@ -522,14 +522,22 @@ void compact_round(const uint32_t* idx, uint32_t m2, const uint32_t* pos, const 
 // around one segmented radix sort.
 __global__ void k_round_head_bounds(const uint32_t* __restrict__ headc, uint32_t m, uint32_t target, uint32_t limit,
                                     uint32_t n_tiles, uint32_t* __restrict__ bound) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per tile: 64 positions per step (a work-item walking its tile alone read up to `limit` heads one after the
+    // other -- inside the long buckets of periodic sequence that was 2 ms per round)
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (t > n_tiles) return;
-    if (t == n_tiles) { bound[t] = m; return; }
-    uint64_t c = (uint64_t)t * target;
-    if (t == 0) { bound[0] = 0; return; }
-    const uint64_t stop = c + limit < m ? c + limit : m;
-    while (c < stop && headc[c] == headc[c - 1]) c++;
-    bound[t] = c >= m ? m : (c == stop ? ROUND_NO_BOUND : (uint32_t)c);
+    if (t == n_tiles) { if (lane == 0) bound[t] = m; return; }
+    if (t == 0) { if (lane == 0) bound[0] = 0; return; }
+    const uint64_t c0 = (uint64_t)t * target;
+    const uint64_t stop = c0 + limit < m ? c0 + limit : m;
+    uint64_t found = stop;
+    for (uint64_t c = c0; c < stop; c += 64) {
+        const uint64_t i = c + lane;
+        const bool is_bound = i < stop && headc[i] != headc[i - 1];
+        const uint64_t hit = __ballot(is_bound);
+        if (hit) { found = c + (uint64_t)__builtin_ctzll(hit); break; }
+    }
+    if (lane == 0) bound[t] = found >= m ? m : (found == stop ? ROUND_NO_BOUND : (uint32_t)found);
 }
 template <int BLOCK, int CAP>
 __global__ __launch_bounds__(BLOCK) void k_round_fused(const uint32_t* __restrict__ sac,
@@ -711,7 +719,7 @@ __global__ void k_big_apply(const uint8_t* __restrict__ tile_big, const uint32_t
 }
 void round_head_bounds(const uint32_t* headc, uint32_t m, uint32_t target, uint32_t limit, uint32_t n_tiles,
                        uint32_t* bound, hipStream_t s) {
-    hipLaunchKernelGGL(k_round_head_bounds, dim3(grid_for((uint64_t)n_tiles + 1, 256)), dim3(256), 0, s, headc, m, target,
+    hipLaunchKernelGGL(k_round_head_bounds, dim3(grid_for(((uint64_t)n_tiles + 1) * 64, 256)), dim3(256), 0, s, headc, m, target,
                        limit, n_tiles, bound);
     MMT_HIP(hipGetLastError());
 }

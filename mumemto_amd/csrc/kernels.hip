@@ -540,7 +540,7 @@ __global__ void k_round_head_bounds(const uint32_t* __restrict__ headc, uint32_t
     if (lane == 0) bound[t] = found >= m ? m : (found == stop ? ROUND_NO_BOUND : (uint32_t)found);
 }
 template <int BLOCK, int CAP>
-__global__ __launch_bounds__(BLOCK, 6) void k_round_fused(const uint32_t* __restrict__ sac,
+__global__ __launch_bounds__(BLOCK) void k_round_fused(const uint32_t* __restrict__ sac,
                                                        const uint32_t* __restrict__ headc,
                                                        const uint32_t* __restrict__ pos,
                                                        const uint32_t* __restrict__ bound, uint32_t n_tiles,
@@ -551,9 +551,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_round_fused(const uint32_t* __rest
                                                        uint32_t* __restrict__ big_end, uint32_t* __restrict__ big_count,
                                                        uint32_t big_cap, uint8_t* __restrict__ tile_big) {
     constexpr int PER = CAP / BLOCK, NW = BLOCK / 64;
-    // (bucket head, rank of the suffix h further on + 1 -- 0 past the end) as one 64-bit word per slot, head in the high half:
-    // the count below reads a pair with one LDS load, the network and the head marks compare whole words
-    __shared__ uint64_t s_k[CAP];
+    // bucket head, rank of the suffix h further on (+ 1; 0 past the end), suffix: three 32-bit columns of the tile
+    __shared__ uint32_t s_h[CAP];
+    __shared__ uint32_t s_r[CAP];
     __shared__ uint32_t s_v[CAP];
     __shared__ uint32_t s_w[PER * NW];
     __shared__ uint32_t s_long;
@@ -574,19 +574,18 @@ __global__ __launch_bounds__(BLOCK, 6) void k_round_fused(const uint32_t* __rest
             tile_big[x] = (uint8_t)(1u | (x == t ? 2u : 0u) | (x + 1 == u ? 4u : 0u));
         return;
     }
-    uint64_t kreg[PER];
-    uint32_t vreg[PER], pj[PER];
+    uint32_t hreg[PER], rreg[PER], vreg[PER], pj[PER];
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         const uint32_t i = threadIdx.x + q * BLOCK;
-        kreg[q] = 0; vreg[q] = 0; pj[q] = 0;
+        hreg[q] = 0; rreg[q] = 0; vreg[q] = 0; pj[q] = 0;
         if (i < len) {
-            const uint32_t v = sac[b + i], hd = headc[b + i];
-            pj[q] = pos[b + i];
+            const uint32_t v = sac[b + i];
+            hreg[q] = headc[b + i]; pj[q] = pos[b + i];
             const uint64_t at = (uint64_t)v + h;
-            const uint32_t second = at < n ? rank[at] + 1u : 0u;     // past the end sorts first (rank + 1 <= n fits 32 bits)
-            kreg[q] = ((uint64_t)hd << 32) | second; vreg[q] = v;
-            s_k[i] = kreg[q]; s_v[i] = v;
+            rreg[q] = at < n ? rank[at] + 1u : 0u;           // past the end sorts first (rank + 1 <= n fits 32 bits)
+            vreg[q] = v;
+            s_h[i] = hreg[q]; s_r[i] = rreg[q]; s_v[i] = v;
         }
     }
     if (threadIdx.x == 0) s_long = 0;
@@ -600,14 +599,13 @@ __global__ __launch_bounds__(BLOCK, 6) void k_round_fused(const uint32_t* __rest
         const uint32_t i = threadIdx.x + q * BLOCK;
         slot[q] = i;
         if (i < len) {
-            const uint64_t ki = kreg[q];
-            const uint32_t hi = (uint32_t)(ki >> 32);
+            const uint32_t hi = hreg[q], ri = rreg[q];
             const uint32_t st = i - (pj[q] - hi);
             uint32_t before = 0, j = st, cnt = 0;
             while (j < len && cnt <= SHORT) {
-                const uint64_t kj = s_k[j];
-                if ((uint32_t)(kj >> 32) != hi) break;
-                before += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+                if (s_h[j] != hi) break;
+                const uint32_t rj = s_r[j];
+                before += (rj < ri || (rj == ri && j < i)) ? 1u : 0u;
                 j++; cnt++;
             }
             if (cnt > SHORT) s_long = 1;
@@ -619,24 +617,24 @@ __global__ __launch_bounds__(BLOCK, 6) void k_round_fused(const uint32_t* __rest
 #pragma unroll
         for (int q = 0; q < PER; q++) {
             const uint32_t i = threadIdx.x + q * BLOCK;
-            if (i < len) { s_k[slot[q]] = kreg[q]; s_v[slot[q]] = vreg[q]; }
+            if (i < len) { s_h[slot[q]] = hreg[q]; s_r[slot[q]] = rreg[q]; s_v[slot[q]] = vreg[q]; }
         }
         __syncthreads();
     } else {
-        // a bucket beyond SHORT elements somewhere in the tile: bitonic network over the words
+        // a bucket beyond SHORT elements somewhere in the tile: bitonic network over (head, rank) pairs
         uint32_t P = 64;
         while (P < len) P <<= 1;
-        for (uint32_t i = len + threadIdx.x; i < P; i += BLOCK) { s_k[i] = ~0ull; s_v[i] = 0u; }
+        for (uint32_t i = len + threadIdx.x; i < P; i += BLOCK) { s_h[i] = 0xffffffffu; s_r[i] = 0xffffffffu; s_v[i] = 0u; }
         __syncthreads();
         for (uint32_t k = 2; k <= P; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 for (uint32_t i = threadIdx.x; i < P; i += BLOCK) {
                     const uint32_t l = i ^ j;
                     if (l > i) {
-                        const uint64_t a = s_k[i], c = s_k[l];
+                        const uint64_t a = ((uint64_t)s_h[i] << 32) | s_r[i], c = ((uint64_t)s_h[l] << 32) | s_r[l];
                         const bool up = (i & k) == 0;
                         if ((a > c) == up) {
-                            s_k[i] = c; s_k[l] = a;
+                            s_h[i] = (uint32_t)(c >> 32); s_r[i] = (uint32_t)c; s_h[l] = (uint32_t)(a >> 32); s_r[l] = (uint32_t)a;
                             const uint32_t va = s_v[i]; s_v[i] = s_v[l]; s_v[l] = va;
                         }
                     }
@@ -656,9 +654,9 @@ __global__ __launch_bounds__(BLOCK, 6) void k_round_fused(const uint32_t* __rest
         uint32_t x = 0;
         tied[q] = 0;
         if (j < len) {
-            const uint64_t kj = s_k[j];
-            const bool ish = j == 0 || s_k[j - 1] != kj;
-            const bool nxt = j + 1 == len || s_k[j + 1] != kj;
+            const uint32_t hj = s_h[j], rj = s_r[j];
+            const bool ish = j == 0 || s_h[j - 1] != hj || s_r[j - 1] != rj;
+            const bool nxt = j + 1 == len || s_h[j + 1] != hj || s_r[j + 1] != rj;
             x = ish ? pj[q] : 0u;
             tied[q] = (ish && nxt) ? 0 : 1;
         }

@@ -599,14 +599,299 @@ void mmo_merged_get(const mmo_merged *m, uint32_t *length, int64_t *offsets, uin
 void mmo_merged_free(mmo_merged *m) { if (m) { part_free(&m->p); free(m); } }
 
 /* ------------------------------------------------------------------------ */
+/* the stream by way of the prefix-free parse: the reference's default route  */
+/* ------------------------------------------------------------------------ */
+/* Restates, with plain arrays instead of sdsl bit vectors and with the SA-IS
+ * above instead of gsacak / sacak_int:
+ *   parse        include/newscan.hpp:106-114 (rolling hash), :265-325 (phrases:
+ *                a phrase ends where hash % p == 0 and is longer than w; the next
+ *                one begins with its last w characters), :357-423 (the text is
+ *                Dollar . T . Dollar^w; ranks of the distinct phrases)
+ *   dictionary   include/dictionary.hpp:103-157 (suffix array and LCP array of the
+ *                phrases in rank order, each followed by EndOfWord -- a separator
+ *                that is unique and ordered by position, the gsacak convention)
+ *   parse        include/parse.hpp:77-146 (suffix array of the rank sequence,
+ *                inverted lists: per phrase the parse ranks of the suffixes that
+ *                FOLLOW its occurrences, ascending)
+ *   pfp          include/pfp.hpp:171-244 (text position of every parse suffix;
+ *                s_lcp_T: LCP in characters of adjacent parse suffixes + range minima)
+ *   emitter      include/pfp_lcp_mum.hpp:115-231 (dictionary suffixes in order;
+ *                the proper phrase suffixes of length >= w that are equal form a
+ *                group; its occurrences are merged by the rank of the following
+ *                parse suffix), :257-282 (inc / is_valid), :284-321 (the LCP
+ *                values), :337-341 (suffix-array entry = text position of the
+ *                following phrase - suffix length).
+ * The stream does not depend on (w, p): it must equal mmo_build_stream's.      */
+typedef struct { int32_t *blockmin; int32_t **tab; int64_t nb; int levels; const int32_t *a; int64_t n; } rmq_t;
+#define RMQ_B 32
+static int rmq_build(rmq_t *r, const int32_t *a, int64_t n) {
+    int64_t nb = (n + RMQ_B - 1) / RMQ_B, i; int l, levels = 1;
+    while (((int64_t)1 << levels) <= nb) levels++;
+    r->a = a; r->n = n; r->nb = nb; r->levels = levels;
+    r->tab = (int32_t **)calloc((size_t)levels, sizeof(int32_t *));
+    if (!r->tab) return -1;
+    r->tab[0] = (int32_t *)malloc((size_t)(nb ? nb : 1) * 4);
+    if (!r->tab[0]) return -1;
+    for (i = 0; i < nb; i++) {
+        int64_t lo = i * RMQ_B, hi = lo + RMQ_B < n ? lo + RMQ_B : n, k; int32_t m = a[lo];
+        for (k = lo + 1; k < hi; k++) if (a[k] < m) m = a[k];
+        r->tab[0][i] = m;
+    }
+    for (l = 1; l < levels; l++) {
+        int64_t span = (int64_t)1 << l, cnt = nb - span + 1;
+        if (cnt <= 0) { r->levels = l; break; }
+        r->tab[l] = (int32_t *)malloc((size_t)cnt * 4);
+        if (!r->tab[l]) return -1;
+        for (i = 0; i < cnt; i++) {
+            int32_t x = r->tab[l - 1][i], y = r->tab[l - 1][i + span / 2];
+            r->tab[l][i] = x < y ? x : y;
+        }
+    }
+    return 0;
+}
+static int32_t rmq_min(const rmq_t *r, int64_t lo, int64_t hi) {      /* minimum of a[lo .. hi], lo <= hi */
+    int64_t bl = lo / RMQ_B, bh = hi / RMQ_B, k; int32_t m = r->a[lo];
+    if (bl == bh) { for (k = lo + 1; k <= hi; k++) if (r->a[k] < m) m = r->a[k]; return m; }
+    for (k = lo + 1; k < (bl + 1) * RMQ_B; k++) if (r->a[k] < m) m = r->a[k];
+    for (k = bh * RMQ_B; k <= hi; k++) if (r->a[k] < m) m = r->a[k];
+    if (bh - bl > 1) {
+        int64_t a0 = bl + 1, a1 = bh - 1, len = a1 - a0 + 1; int l = 0;
+        while (((int64_t)2 << l) <= len) l++;
+        { int32_t x = r->tab[l][a0], y = r->tab[l][a1 - ((int64_t)1 << l) + 1];
+          if (x < m) m = x;
+          if (y < m) m = y; }
+    }
+    return m;
+}
+static void rmq_free(rmq_t *r) { int l; if (r->tab) { for (l = 0; l < r->levels; l++) free(r->tab[l]); free(r->tab); } }
+
+static const uint8_t *g_cmp_v; static const int64_t *g_cmp_start; static const int32_t *g_cmp_len;
+static int cmp_phrase(const void *x, const void *y) {                /* lexicographic, the shorter one first on a tie */
+    int32_t a = *(const int32_t *)x, b = *(const int32_t *)y;
+    int32_t la = g_cmp_len[a], lb = g_cmp_len[b], l = la < lb ? la : lb;
+    int c = memcmp(g_cmp_v + g_cmp_start[a], g_cmp_v + g_cmp_start[b], (size_t)l);
+    if (c) return c;
+    return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+typedef struct { int64_t val; int64_t at, end; uint8_t bwt; } pfp_run;    /* one member's list: next value, cursor, end */
+static void heap_sift(pfp_run *h, int64_t n, int64_t i) {
+    for (;;) {
+        int64_t l = 2 * i + 1, r = l + 1, m = i; pfp_run t;
+        if (l < n && h[l].val < h[m].val) m = l;
+        if (r < n && h[r].val < h[m].val) m = r;
+        if (m == i) return;
+        t = h[i]; h[i] = h[m]; h[m] = t; i = m;
+    }
+}
+
+int mmo_build_stream_pfp(const uint8_t *text, int64_t n, int64_t w, int64_t pmod, int64_t *sa, int64_t *lcp,
+                         uint8_t *bwt, int64_t *stats) {
+    const uint64_t PRIME = 1999999973ull;               /* newscan.hpp:84 */
+    int64_t nv = 1 + n + w, i, k, m = 0, cap = 1024, D = 0, nd = 0, j = 0;
+    uint8_t *v; int64_t *pstart; int32_t *plen, *order, *rank_of, *parse, *saP, *isaP, *slcp, *ilist, *ilist_start;
+    uint8_t *d; int32_t *ds, *saD, *isaD, *lcpD, *dphr, *dsuf; int64_t *posval;
+    uint64_t *window, hash = 0, pot = 1; int64_t tot = 0;
+    rmq_t rq; pfp_run *heap = NULL; int64_t heap_cap = 0;
+    if (w < 1 || pmod < 1 || n < 1 || nv >= 0x7fffff00LL) return -2;
+    for (i = 0; i < n; i++) if (text[i] <= 2) return -3;             /* newscan.hpp:318 */
+    v = (uint8_t *)malloc((size_t)nv + 8);
+    pstart = (int64_t *)malloc((size_t)cap * 8); plen = (int32_t *)malloc((size_t)cap * 4);
+    window = (uint64_t *)calloc((size_t)w, 8);
+    if (!v || !pstart || !plen || !window) return -1;
+    v[0] = 2; memcpy(v + 1, text, (size_t)n); memset(v + 1 + n, 2, (size_t)w);
+    for (i = 1; i < w; i++) pot = (pot * 256) % PRIME;
+    /* phrases */
+    {
+        int64_t start = 0;
+        for (i = 1; i <= n; i++) {
+            const uint64_t c = v[i]; const int64_t slot = tot++ % w;
+            hash += PRIME - (window[slot] * pot) % PRIME;
+            hash = (256 * hash + c) % PRIME;
+            window[slot] = c;
+            if (hash % (uint64_t)pmod == 0 && i - start + 1 > w) {
+                if (m == cap) { cap *= 2; pstart = (int64_t *)realloc(pstart, (size_t)cap * 8); plen = (int32_t *)realloc(plen, (size_t)cap * 4); if (!pstart || !plen) return -1; }
+                pstart[m] = start; plen[m] = (int32_t)(i - start + 1); m++;
+                start = i - w + 1;
+            }
+        }
+        if (m == cap) { cap += 1; pstart = (int64_t *)realloc(pstart, (size_t)cap * 8); plen = (int32_t *)realloc(plen, (size_t)cap * 4); if (!pstart || !plen) return -1; }
+        pstart[m] = start; plen[m] = (int32_t)(nv - start); m++;
+    }
+    free(window);
+    /* ranks of the distinct phrases (newscan.hpp:386-419: the dictionary is sorted, the parse holds ranks from 1) */
+    order = (int32_t *)malloc((size_t)m * 4); rank_of = (int32_t *)malloc((size_t)m * 4); parse = (int32_t *)malloc(((size_t)m + 1) * 4);
+    if (!order || !rank_of || !parse) return -1;
+    for (k = 0; k < m; k++) order[k] = (int32_t)k;
+    g_cmp_v = v; g_cmp_start = pstart; g_cmp_len = plen;
+    qsort(order, (size_t)m, 4, cmp_phrase);
+    for (k = 0; k < m; k++) {
+        if (k == 0 || cmp_phrase(&order[k - 1], &order[k]) != 0) { D++; nd += plen[order[k]] + 1; }
+        rank_of[order[k]] = (int32_t)D;
+    }
+    nd += 1;                                                         /* EndOfDict */
+    for (k = 0; k < m; k++) parse[k] = rank_of[k];
+    parse[m] = 0;
+    /* dictionary: text, per-position phrase and remaining length, suffix array with unique ordered separators, LCP */
+    d = (uint8_t *)malloc((size_t)nd); ds = (int32_t *)malloc((size_t)nd * 4); saD = (int32_t *)malloc((size_t)nd * 4);
+    isaD = (int32_t *)malloc((size_t)nd * 4); lcpD = (int32_t *)malloc((size_t)nd * 4);
+    dphr = (int32_t *)malloc((size_t)nd * 4); dsuf = (int32_t *)malloc((size_t)nd * 4);
+    if (!d || !ds || !saD || !isaD || !lcpD || !dphr || !dsuf) return -1;
+    {
+        int64_t at = 0; int32_t r = 0;
+        for (k = 0; k < m; k++) {
+            const int32_t ph = order[k];
+            if (k && cmp_phrase(&order[k - 1], &order[k]) == 0) continue;
+            r++;
+            for (i = 0; i < plen[ph]; i++) {
+                d[at] = v[pstart[ph] + i]; ds[at] = (int32_t)d[at] + (int32_t)D + 1;
+                dphr[at] = r; dsuf[at] = plen[ph] - (int32_t)i; at++;
+            }
+            d[at] = 1; ds[at] = r; dphr[at] = r; dsuf[at] = 0; at++;         /* EndOfWord number r: unique, ordered by position */
+        }
+        d[at] = 0; ds[at] = 0; dphr[at] = 0; dsuf[at] = 0; at++;
+        if (at != nd) return -4;
+    }
+    if (sais_i32(ds, saD, (int32_t)nd, (int32_t)D + 258)) return -1;
+    for (i = 0; i < nd; i++) isaD[saD[i]] = (int32_t)i;
+    {
+        int64_t h = 0;
+        lcpD[0] = 0;
+        for (i = 0; i < nd; i++) {
+            const int64_t r = isaD[i]; int64_t q;
+            if (r == 0) { h = 0; continue; }
+            q = saD[r - 1];
+            while (i + h < nd && q + h < nd && ds[i + h] == ds[q + h]) h++;
+            lcpD[r] = (int32_t)h;
+            if (h > 0) h--;
+        }
+    }
+    free(isaD); free(ds);
+    /* parse: suffix array, inverse, inverted lists (parse.hpp:85, :107-132) */
+    saP = (int32_t *)malloc(((size_t)m + 1) * 4); isaP = (int32_t *)malloc(((size_t)m + 1) * 4);
+    ilist = (int32_t *)malloc(((size_t)m + 1) * 4); ilist_start = (int32_t *)calloc((size_t)D + 3, 4);
+    posval = (int64_t *)malloc(((size_t)m + 1) * 8); slcp = (int32_t *)calloc((size_t)m + 1, 4);
+    if (!saP || !isaP || !ilist || !ilist_start || !posval || !slcp) return -1;
+    if (sais_i32(parse, saP, (int32_t)(m + 1), (int32_t)D + 1)) return -1;
+    for (i = 0; i <= m; i++) isaP[saP[i]] = (int32_t)i;
+    for (i = 0; i <= m; i++) ilist_start[parse[i] + 1]++;
+    for (i = 0; i <= D; i++) ilist_start[i + 1] += ilist_start[i];
+    {
+        int32_t *fill = (int32_t *)calloc((size_t)D + 2, 4);
+        if (!fill) return -1;
+        for (i = 0; i <= m; i++) {                                    /* rank i follows an occurrence of the phrase before it */
+            const int64_t before = (saP[i] == 0 ? m + 1 : saP[i]) - 1;
+            const int32_t ph = parse[before];
+            ilist[ilist_start[ph] + fill[ph]++] = (int32_t)i;
+        }
+        free(fill);
+    }
+    /* text position of the character after the w shared ones of the phrase that begins parse suffix q, minus 1 + w:
+       an occurrence of a phrase suffix of length L before parse suffix q begins at text position posval - L
+       (pfp.hpp:185-201 with pfp_lcp_mum.hpp:337-341, in the coordinates of T) */
+    for (i = 0; i <= m; i++) {
+        const int64_t q = saP[i];
+        const int64_t s_q = q < m ? pstart[q] : nv - w;               /* the end of the text for the terminator of the parse */
+        posval[i] = s_q + w - 1;
+    }
+    /* s_lcp_T (pfp.hpp:210-244): LCP in characters of parse suffixes adjacent in rank, the w shared characters counted once */
+    {
+        int64_t l = 0, lt = 0;
+        for (i = 0; i < m; i++) {
+            const int64_t r = isaP[i]; int64_t q, a, b, c = 0;
+            if (r == 0) { l = 0; lt = 0; continue; }
+            q = saP[r - 1];
+            while (parse[i + l] == parse[q + l]) { lt += plen[i + l] - w; l++; }
+            a = i + l; b = q + l;
+            if (parse[a] != 0 && parse[b] != 0) {
+                const uint8_t *x = v + pstart[a], *y = v + pstart[b];
+                const int64_t lim = plen[a] < plen[b] ? plen[a] : plen[b];
+                while (c < lim && x[c] == y[c]) c++;
+            }
+            slcp[r] = (int32_t)(lt + c);
+            if (l > 0) { l--; lt -= plen[i] - w; }
+        }
+    }
+    if (rmq_build(&rq, slcp, m + 1)) return -1;
+    /* emitter */
+    {
+        int64_t cur = 1, prev_i = 0, prev_L = -1, prev_phrase = 0;
+        while (cur < nd) {
+            const int64_t sn = saD[cur]; const int32_t L = dsuf[sn];
+            const int valid = L >= w && sn > 0 && d[sn - 1] != 1 && d[sn] > 1;      /* proper suffix of a phrase, at least w long */
+            int64_t nxt, nmem = 0, lcp_first, prev_occ = 0; int first = 1;
+            if (!valid) { cur++; continue; }
+            /* members: the entries that follow with the same suffix (pfp_lcp_mum.hpp:128-139) */
+            for (nxt = cur; nxt < nd && (nxt == cur || lcpD[nxt] >= L); nxt++) {
+                const int64_t s2 = saD[nxt];
+                if (dsuf[s2] != L) continue;
+                if (nmem == heap_cap) { heap_cap = heap_cap ? heap_cap * 2 : 16; heap = (pfp_run *)realloc(heap, (size_t)heap_cap * sizeof(pfp_run)); if (!heap) return -1; }
+                heap[nmem].at = ilist_start[dphr[s2]]; heap[nmem].end = ilist_start[dphr[s2] + 1];
+                heap[nmem].val = ilist[heap[nmem].at];
+                heap[nmem].bwt = d[s2 - 1] == 2 ? 0 : d[s2 - 1];      /* Dollar before text position 0 (pfp_lcp_mum.hpp:268) */
+                nmem++;
+            }
+            /* LCP with the entry before the group (pfp_lcp_mum.hpp:295-321) */
+            lcp_first = 0;
+            if (j > 0) {
+                int64_t t; int32_t mn = lcpD[cur];
+                for (t = prev_i + 1; t < cur; t++) if (lcpD[t] < mn) mn = lcpD[t];
+                lcp_first = mn;
+                if (mn >= L && L == prev_L) {
+                    int64_t left = ilist[ilist_start[dphr[sn]]], right = ilist[ilist_start[prev_phrase + 1] - 1];
+                    if (left > right) { const int64_t t2 = left; left = right; right = t2; }
+                    lcp_first += rmq_min(&rq, left + 1, right) - w;
+                }
+            }
+            {
+                int64_t last_member = cur;
+                for (k = cur; k < nxt; k++) if (dsuf[saD[k]] == L) last_member = k;
+                for (k = nmem / 2 - 1; k >= 0; k--) heap_sift(heap, nmem, k);
+                while (nmem) {
+                    const int64_t occ = heap[0].val; int64_t val;
+                    if (first) val = lcp_first;
+                    else {
+                        int64_t lo = occ < prev_occ ? occ : prev_occ, hi = occ < prev_occ ? prev_occ : occ;
+                        val = L + rmq_min(&rq, lo + 1, hi) - w;
+                    }
+                    first = 0;
+                    if (j > n) return -5;
+                    sa[j] = (posval[occ] - L) % (n + 1); lcp[j] = val; bwt[j] = heap[0].bwt; j++;
+                    prev_occ = occ;
+                    if (++heap[0].at != heap[0].end) heap[0].val = ilist[heap[0].at];
+                    else { heap[0] = heap[nmem - 1]; nmem--; }
+                    heap_sift(heap, nmem, 0);
+                }
+                prev_i = last_member; prev_L = L; prev_phrase = dphr[saD[last_member]];
+            }
+            cur = nxt;
+        }
+    }
+    if (stats) { stats[0] = m; stats[1] = D; stats[2] = nd; stats[3] = j; }
+    rmq_free(&rq); free(heap);
+    free(v); free(pstart); free(plen); free(order); free(rank_of); free(parse); free(d); free(saD); free(lcpD);
+    free(dphr); free(dsuf); free(saP); free(isaP); free(ilist); free(ilist_start); free(posval); free(slcp);
+    return j == n + 1 ? 0 : -6;
+}
+
+/* ------------------------------------------------------------------------ */
 /* whole job for the CPU baseline leg of bench.py                            */
 /* ------------------------------------------------------------------------ */
 static double now_sec(void) {
     struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+static int64_t run_job_route(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs, const mmo_scan_params *p,
+                             int64_t pfp_w, int64_t pfp_p, double *stage_sec, char **out_text, int64_t *out_len);
 int64_t mmo_run_job(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs,
                     const mmo_scan_params *p, double *stage_sec, char **out_text, int64_t *out_len) {
+    return run_job_route(bases, doc_len, n_docs, p, 0, 0, stage_sec, out_text, out_len);
+}
+int64_t mmo_run_job_pfp(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs, const mmo_scan_params *p,
+                        int64_t pfp_w, int64_t pfp_p, double *stage_sec, char **out_text, int64_t *out_len) {
+    return run_job_route(bases, doc_len, n_docs, p, pfp_w, pfp_p, stage_sec, out_text, out_len);
+}
+static int64_t run_job_route(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs, const mmo_scan_params *p,
+                             int64_t pfp_w, int64_t pfp_p, double *stage_sec, char **out_text, int64_t *out_len) {
     int64_t n = mmo_text_length(doc_len, n_docs, p->revcomp), m = n + 1;
     uint8_t *text = (uint8_t *)malloc((size_t)n + 1), *bwt = (uint8_t *)malloc((size_t)m);
     int64_t *doc_start = (int64_t *)malloc(((size_t)n_docs + 1) * 8);
@@ -615,7 +900,7 @@ int64_t mmo_run_job(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs
     mmo_result *r; double t0 = now_sec(), t1, t2, t3;
     mmo_build_text(bases, doc_len, n_docs, p->revcomp, text, doc_start);
     t1 = now_sec();
-    if (mmo_build_stream(text, n, sa, lcp, bwt)) return -1;
+    if (pfp_w > 0 ? mmo_build_stream_pfp(text, n, pfp_w, pfp_p, sa, lcp, bwt, NULL) : mmo_build_stream(text, n, sa, lcp, bwt)) return -1;
     mmo_doc_array(sa, m, doc_start, n_docs, doc);
     t2 = now_sec();
     r = mmo_scan(sa, lcp, bwt, doc, m, doc_start, n_docs, p);

@@ -40,6 +40,12 @@ void mmo_build_text(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs
 /* Stream has n+1 entries, j = 0 is the sentinel suffix (sa = n).            */
 int mmo_build_stream(const uint8_t *text, int64_t n, int64_t *sa, int64_t *lcp,
                      uint8_t *bwt);
+/* The same stream by way of the prefix-free parse, the reference's default route
+ * (include/newscan.hpp, dictionary.hpp, parse.hpp, pfp.hpp, pfp_lcp_mum.hpp:115-231;
+ * window w, modulus p; text bytes must be > 2).  stats (optional, 4 entries):
+ * phrases, distinct phrases, dictionary bytes, stream entries.  0 on success.   */
+int mmo_build_stream_pfp(const uint8_t *text, int64_t n, int64_t w, int64_t pmod, int64_t *sa,
+                         int64_t *lcp, uint8_t *bwt, int64_t *stats);
 /* doc[j] = #doc ends in [0, sa[j])  (pfp_lcp_mum.hpp:194)                    */
 void mmo_doc_array(const int64_t *sa, int64_t m, const int64_t *doc_start,
                    int64_t n_docs, int32_t *doc);
@@ -121,6 +127,10 @@ void mmo_merged_free(mmo_merged *m);
 int64_t mmo_run_job(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs,
                     const mmo_scan_params *p, double *stage_sec, char **out_text,
                     int64_t *out_len);
+/* the same with the stream produced through the prefix-free parse (window pfp_w, modulus pfp_p) */
+int64_t mmo_run_job_pfp(const uint8_t *bases, const int64_t *doc_len, int64_t n_docs,
+                        const mmo_scan_params *p, int64_t pfp_w, int64_t pfp_p, double *stage_sec,
+                        char **out_text, int64_t *out_len);
 
 #ifdef __cplusplus
 }

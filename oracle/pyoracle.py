@@ -85,6 +85,12 @@ def lib():
         L.mmo_merged_docs.argtypes = [C.c_void_p]
         L.mmo_merged_get.argtypes = [C.c_void_p] * 5
         L.mmo_merged_free.argtypes = [C.c_void_p]
+        L.mmo_build_stream_pfp.restype = C.c_int
+        L.mmo_build_stream_pfp.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
+        L.mmo_run_job_pfp.restype = C.c_int64
+        L.mmo_run_job_pfp.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ScanParams), C.c_int64, C.c_int64,
+                                      C.POINTER(C.c_double), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.mmo_run_job.restype = C.c_int64
         L.mmo_run_job.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ScanParams),
                                   C.POINTER(C.c_double), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
@@ -273,8 +279,23 @@ def anchor_merge(parts):
     return length[:n], off[:n], st[:n], nb
 
 
-def run_job_timed(docs, min_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, revcomp=True):
-    """Whole job on one core; returns (text_len, stage seconds[3], .mums bytes)."""
+def build_stream_pfp(text, w=10, p=100):
+    """The stream by way of the prefix-free parse (the reference's default route): (sa, lcp, bwt, stats) with
+    stats = (phrases, distinct phrases, dictionary bytes, stream entries).  Must equal build_stream(text)."""
+    L = lib()
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    n = len(text)
+    sa = np.zeros(n + 1, np.int64); lcp = np.zeros(n + 1, np.int64); bwt = np.zeros(n + 1, np.uint8)
+    st = np.zeros(4, np.int64)
+    rc = L.mmo_build_stream_pfp(_p(text), n, w, p, _p(sa), _p(lcp), _p(bwt), _p(st))
+    if rc:
+        raise RuntimeError("mmo_build_stream_pfp failed (%d)" % rc)
+    return sa, lcp, bwt, tuple(int(x) for x in st)
+
+
+def run_job_timed(docs, min_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0, revcomp=True, pfp=None):
+    """Whole job on one core; returns (text_len, stage seconds[3], .mums bytes).  pfp = (w, p): the stream is produced
+    through the prefix-free parse (the reference's default route) instead of a suffix sort of the whole text (-g)."""
     L = lib()
     bases, lens = docs_to_bases(docs)
     p = ScanParams(min_len, num_distinct if num_distinct else len(docs), max_doc_freq, max_total_freq,
@@ -282,7 +303,13 @@ def run_job_timed(docs, min_len=20, num_distinct=0, max_doc_freq=1, max_total_fr
     sec = (C.c_double * 3)()
     out = C.c_void_p()
     n = C.c_int64()
-    tl = L.mmo_run_job(_p(bases), _p(lens), len(docs), C.byref(p), sec, C.byref(out), C.byref(n))
+    if pfp:
+        tl = L.mmo_run_job_pfp(_p(bases), _p(lens), len(docs), C.byref(p), int(pfp[0]), int(pfp[1]), sec, C.byref(out),
+                               C.byref(n))
+    else:
+        tl = L.mmo_run_job(_p(bases), _p(lens), len(docs), C.byref(p), sec, C.byref(out), C.byref(n))
+    if tl < 0:
+        raise RuntimeError("oracle job failed (%d)" % tl)
     data = C.string_at(out, n.value)
     L.mmo_free(out)
     return tl, list(sec), data

@@ -77,6 +77,28 @@ def test_scan_against_bruteforce(mode):
         assert got == want, (mode, trial, docs, revcomp, min_len)
 
 
+@pytest.mark.parametrize("w,p", [(10, 100), (10, 30), (4, 7), (3, 4), (14, 50)])
+def test_stream_by_way_of_the_prefix_free_parse_equals_the_suffix_sort(w, p):
+    """The oracle restates both routes of the reference to the SA / LCP / BWT stream: a suffix sort of the whole text
+    (`-g`, include/direct_gsacak.hpp) and the default one through the prefix-free parse (newscan.hpp -> dictionary.hpp /
+    parse.hpp -> pfp.hpp -> pfp_lcp_mum.hpp:115-231).  All suffixes are distinct, so the stream cannot depend on the
+    route, the window or the modulus: pangenomes with an inversion, real-assembly content (satellite
+    arrays, microsatellites, runs of N, indels), exact copies, tandem repeats and one-base documents."""
+    cases = [synth.pangenome(5, 4000, 0.01, seed=11, inversion=(2, 700, 1500)),
+             [[b.tobytes()] for _, b in synth.haplotypes_realistic(6, 30000, 0.002, 5)],
+             [[b"ACGTACGTACGTACGTNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNACGT"], [b"ACGTACGTACGTTTTTTTTTTTTTTTTTTTTTTTTT"], [b"A"],
+              [b"GATTACA" * 40], [b"GATTACA" * 40], [b"acgtnryk"]]]
+    for docs in cases:
+        text, _ = O.build_text(docs)
+        sa, lcp, bwt = O.build_stream(text)
+        sa2, lcp2, bwt2, stats = O.build_stream_pfp(text, w, p)
+        assert stats[3] == len(text) + 1 and stats[1] <= stats[0]
+        assert np.array_equal(sa, sa2) and np.array_equal(lcp, lcp2) and np.array_equal(bwt, bwt2)
+    # and the whole job (scan + writer behind either route) gives the same bytes
+    docs = cases[0]
+    assert O.run_job_timed(docs)[2] == O.run_job_timed(docs, pfp=(w, p))[2]
+
+
 def test_cli_param_normalisation():
     # include/pfp_mum.hpp:149-198
     assert O.cli_params(16) == (16, 1, 16)

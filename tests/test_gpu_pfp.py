@@ -75,6 +75,23 @@ def test_stream_through_the_parse(engine, case, wp):
     engine.set_producer("auto")
 
 
+@pytest.mark.parametrize("wp", [(10, 100), (4, 11), (6, 37)])
+def test_parse_statistics_equal_the_oracles_parse(engine, wp):
+    """Phrases, distinct phrases and dictionary bytes of the GPU parse against the oracle's restatement of the reference's
+    default route (newscan.hpp parse -> dictionary -> emitter, `mmo_build_stream_pfp`), whose stream the CPU suite holds
+    against the whole-text suffix sort."""
+    for case in sorted(CASES):
+        docs = synth.pangenome(**CASES[case])
+        engine.set_producer("pfp", *wp)
+        engine.set_docs(docs)
+        engine.run()
+        counts = engine.pfp_counts()
+        text, _ = O.build_text(docs, True)
+        stats = O.build_stream_pfp(text, *wp)[3]
+        assert (counts["phrases"], counts["distinct"], counts["dict_len"]) == stats[:3], (case, counts, stats)
+    engine.set_producer("auto")
+
+
 def test_degenerate_inputs_through_the_parse(engine):
     for docs in ([[b"A"], [b"A"]], [[b""], [b""]], [[b"ACGT" * 30], [b"ACGT" * 30]], [[b"A" * 3000], [b"A" * 2500]],
                  [[b"N" * 5000 + b"ACGTGGA" * 5], [b"ACGTGGA" * 5 + b"N" * 4000]]):

@@ -112,7 +112,10 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
             hf_.ensure(m4 * 5 + 16); bound_.ensure((size_t)n_tiles + 2); tile_big_.ensure((size_t)n_tiles + 1);
             uint32_t* const head_w = reinterpret_cast<uint32_t*>(hf_.get());
             uint8_t* const flags_w = hf_.get() + m4 * 4;
-            const uint32_t big_cap = (uint32_t)std::max<size_t>(big_begin_.size(), 4096);
+            // room for the list of long ranges (satellite content: thousands per round); MMT_BIG_CAP: a small list, so that the
+            // round of separate kernels takes over after the fused pass has run (tests)
+            static const uint32_t big_cap_min = std::getenv("MMT_BIG_CAP") ? (uint32_t)std::max(1, std::atoi(std::getenv("MMT_BIG_CAP"))) : 65536u;
+            const uint32_t big_cap = std::getenv("MMT_BIG_CAP") ? big_cap_min : (uint32_t)std::max<size_t>(big_begin_.size(), big_cap_min);
             big_begin_.ensure(big_cap); big_end_.ensure(big_cap);
             MMT_HIP(hipMemsetAsync(count_.get() + 1, 0, 4, s));
             MMT_HIP(hipMemsetAsync(tile_big_.get(), 0, (size_t)n_tiles + 1, s));

@@ -366,12 +366,14 @@ def test_letter_runs_make_giant_sort_ranges(producer, giant):
 
 @pytest.mark.parametrize("producer", ["pfp", "direct"])
 @pytest.mark.parametrize("env", [{"MMT_SORT_FUSED": "0"}, {"MMT_ROUND_CAP": "1024", "MMT_GIANT_RANGE": "3000"},
-                                 {"MMT_SORT_ONE_STREAM": "1", "MMT_SORT_ALL_RANKS": "1"}, {"MMT_ROUND_CAP": "1536"}])
+                                 {"MMT_SORT_ONE_STREAM": "1", "MMT_SORT_ALL_RANKS": "1"}, {"MMT_ROUND_CAP": "1536"},
+                                 {"MMT_ROUND_CAP": "1024", "MMT_BIG_CAP": "1"}])
 def test_doubling_round_paths(producer, env):
     """A doubling round of the suffix sorter is one pass over the active list (k_round_fused + the scatter of the changed
     ranks on a second stream), with the ranges beyond an LDS tile finished around a segmented sort (k_big_*).  The
     round of separate kernels (MMT_SORT_FUSED=0), the smaller tiles (more ranges take the long path), the scatter of
-    every rank on the one stream: all must give the bytes of the oracle, on letter runs (one bucket of tens of thousands
+    every rank on the one stream, a list of long ranges that overflows (MMT_BIG_CAP=1: the round of separate kernels
+    takes over after the fused pass has run): all must give the bytes of the oracle, on letter runs (one bucket of tens of thousands
     of suffixes through many rounds) and on exact copies."""
     import subprocess
     import sys

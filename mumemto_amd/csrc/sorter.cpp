@@ -72,9 +72,20 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
     uint32_t* const idx = headval + n;
     uint32_t* const head = reinterpret_cast<uint32_t*>(keys_b_.get());
     uint8_t* const flags = reinterpret_cast<uint8_t*>(head + n);
+    if (!side_ && !std::getenv("MMT_SORT_ONE_STREAM")) {
+        MMT_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        MMT_HIP(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
+        MMT_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
+    }
     k::mark_heads(keys_b_.get(), n, headval, lsb_unique, s);
     prims::inclusive_max_u32(temp, headval, head, n, s);
-    k::scatter_rank(sa, head, n, rank, s);
+    // every rank once (random stores: latency) on the second stream, beside the selection of the tied suffixes (streams)
+    if (side_) {
+        MMT_HIP(hipEventRecord(ev_main_, s));
+        MMT_HIP(hipStreamWaitEvent(side_, ev_main_, 0));
+        k::scatter_rank(sa, head, n, rank, side_);
+        MMT_HIP(hipEventRecord(ev_side_, side_));
+    } else k::scatter_rank(sa, head, n, rank, s);
     k::flag_unsorted(head, n, flags, s);
     prims::select_indices(temp, flags, idx, count_.get(), n, s);
     uint32_t m = 0;
@@ -84,17 +95,13 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
         pos_a_.ensure(m); pos_b_.ensure(m); headc_.ensure(m); sac_b_.ensure(m);       // the active set only
         k::gather_active(idx, m, sa, head, pos_a_.get(), sac_a_.get(), headc_.get(), s);
     }
+    if (side_) MMT_HIP(hipStreamWaitEvent(s, ev_side_, 0));                            // the ranks are in place
 
     const int shift = bit_width_u64(n);            // second key component holds values 0..n
     static const bool fused_ok = !std::getenv("MMT_SORT_GLOBAL_ROUNDS") &&
                                  !(std::getenv("MMT_SORT_FUSED") && std::atoi(std::getenv("MMT_SORT_FUSED")) == 0);
     static const bool trace = std::getenv("MMT_SORT_TRACE") != nullptr;      // tuning aid: the active set round by round
     if (trace) std::fprintf(stderr, "[sort] n %u, tied after the first pass %u (h = %llu)\n", n, m, (unsigned long long)h0);
-    if (!side_ && !std::getenv("MMT_SORT_ONE_STREAM")) {
-        MMT_HIP(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-        MMT_HIP(hipEventCreateWithFlags(&ev_main_, hipEventDisableTiming));
-        MMT_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
-    }
     bool side_busy = false;
     uint64_t h = h0;
     int rounds = 0;

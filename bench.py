@@ -56,9 +56,10 @@ def parse():
                     help="the timed collection itself carries satellite arrays, microsatellites, assembly gaps, indels and "
                          "inversions (synth.haplotypes_realistic) instead of i.i.d. bases with substitutions")
     ap.add_argument("--check", action="store_true", help="compare the output with the oracle (small sizes only)")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
-                    help="N > 1: torch.distributed collectives (default) or the C-ABI exchange of dist.cpp (mmt_dist_merge: "
-                         "RCCL bound from C++, grouped broadcasts, one device per rank)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="N > 1: the C-ABI exchange of dist.cpp (default; mmt_dist_merge: RCCL bound from C++, grouped "
+                         "ncclSend / ncclRecv HBM -> HBM, rank 0 folds, from four ranks on every rank folds its slice of the "
+                         "anchor) or torch.distributed collectives + Python glue")
     ap.add_argument("--fold", default="rank0", choices=["rank0", "ranges"],
                     help="N > 1 with --exchange torch: rank 0 folds everything (default), or every rank folds its slice of "
                          "the anchor after a slice-wise exchange of the thresholds (SURVEY 8(e), reduce-scatter shape)")
@@ -95,7 +96,18 @@ def cpu_baseline(sample):
     t0 = time.perf_counter()
     tl2, sec2, out2 = O.run_job_timed(sample)
     dt2 = time.perf_counter() - t0
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": bp / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port",
+            # the reference is single-threaded; the sample is a prefix of every haplotype and the figure stands
+            # for the whole collection by linear extrapolation in |T| (the real work grows a little faster than linearly)
+            "extrapolated": True, "host_cpu": model, "host_cores_total": os.cpu_count(),
             "sample": "%d haplotypes x first %d bp of the same synthetic pangenome (|T| = %d), strict multi-MUMs, through the "
                       "prefix-free parse (w 10, p 100; the reference's default route): %.1f s of CPU work (parse + "
                       "dictionary / parse suffix arrays + emitter %.1f s, scan+format %.1f s)"
@@ -190,11 +202,8 @@ def main():
             return None
         sec = eng.run_files(paths, out_prefix=None, merge_metadata=True)
         t0 = time.perf_counter()
-        if comm is not None:            # C-ABI exchange: HBM -> HBM broadcasts, fold and re-sort on rank 0
-            merged = comm.merge(min_len=20)
-            if rank == 0:
-                with open(out_prefix + ".mums", "wb") as f:
-                    f.write(merged["text"])
+        if comm is not None:            # C-ABI exchange: HBM -> HBM sends, fold and re-sort, PREFIX.mums written by the library
+            merged = comm.merge(min_len=20, text_file=out_prefix + ".mums")
             if timed:
                 phases["read"] += sec["read"]; phases["run"] += sec["run"]
                 phases["exchange_fold"] += time.perf_counter() - t0
@@ -283,7 +292,7 @@ def main():
                       "array / BWT / LCP columns are never stored as a whole)" % (
                           eng.stream_stats()["windows"], eng.stream_stats()["window_bytes"] / 1e9),
             "parallelism": "1 GPU" if world == 1 else "anchor partitions x%d + RCCL %s + GPU fold" % (
-                world, "broadcasts through the C ABI (mmt_dist_merge)" if a.exchange == "native" else "all-gather (torch.distributed)"),
+                world, "sends through the C ABI (mmt_dist_merge, dist.cpp)" if a.exchange == "native" else "all-gather (torch.distributed)"),
             "timed_region": "FASTA files (page cache) -> host parse -> H2D -> GPU path -> PREFIX.mums closed; in-process "
                             "(HIP runtime up, device heap mapped by the warm-up step)",
             "output_bytes": out_bytes, "output_rows": int(eng.L.mmt_num_rows(eng.h)) if world == 1 else None,
@@ -330,6 +339,9 @@ def main():
             cli["output_identical_to_in_process"] = subprocess.run(
                 ["cmp", "-s", os.path.join(workdir, "cli.mums"), out_file]).returncode == 0
         result["cli_process"] = cli
+        # SURVEY 8(d)'s clock -- process start to the last byte of PREFIX.mums closed and the process gone -- beside `value`
+        # (in-process: HIP runtime up, device heap mapped)
+        result["value_process_start"] = cli["value"] if cli["rc"] == 0 else None
     if rank == 0 and os.path.exists(out_file):
         import hashlib
         h = hashlib.sha256()

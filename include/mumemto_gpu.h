@@ -171,6 +171,10 @@ MMT_API int mmt_columns_kept(const mmt_engine* e);
 MMT_API int mmt_stream_stats(const mmt_engine* e, uint64_t out[4]);
 /* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
 MMT_API void mmt_pool_trim(void);
+/* Text, window buffers and sort scratch of the last run go back to the device heap (downloaded results stay).
+ * keep_anchor_ranks != 0: the suffix ranks of the anchor stay, so that mmt_merged_sort_like_direct still works -- the state
+ * of a rank between its own pass and the fold of everybody's rows. */
+MMT_API int mmt_engine_release_columns(mmt_engine* e, int keep_anchor_ranks);
 
 /* ---- PFP stage checkpoints (the reference's -P / -K: PREFIX.dict, PREFIX.parse) ------------ */
 /* Text layout + prefix-free parse only (newscan.hpp pfparser: process_string ... finish_parse).  */

@@ -74,7 +74,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
-    "mmt_stream_stats",
+    "mmt_stream_stats", "mmt_engine_release_columns",
 ]
 
 
@@ -189,6 +189,7 @@ def load_library():
     L.mmt_merged_text.restype = C.c_void_p
     L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.mmt_merged_free.argtypes = [C.c_void_p]
+    L.mmt_engine_release_columns.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -338,7 +339,7 @@ class Engine:
         _check(self.L.mmt_engine_run(self.h, C.byref(p)))
 
     def run_partitioned(self, docs, max_text_chars=0, min_match_len=20, use_revcomp=True, num_distinct=0,
-                        max_doc_freq=1, max_total_freq=0, flat=None):
+                        max_doc_freq=1, max_total_freq=0, flat=None, merge_metadata=False):
         """Host-resident docs of any size: one suffix array when the text fits the device (40-bit positions beyond
         2^32 characters), otherwise anchor partitions + merge (strict multi-MUMs only).  `flat` = (uint8 array of
         the concatenated bases, uint64 array of document lengths) skips the Python-side concatenation."""
@@ -349,7 +350,7 @@ class Engine:
             lens = np.array([sum(len(r) for r in d) for d in docs], dtype=np.uint64)
             joined = b"".join(b"".join(d) for d in docs)
             bases = np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)
-        p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), 0)
+        p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
         _check(self.L.mmt_engine_run_partitioned(self.h, _p(bases), _p(lens), len(lens), C.byref(p), max_text_chars))
         return int(self.L.mmt_partitions_used(self.h))
 
@@ -363,6 +364,11 @@ class Engine:
         _check(self.L.mmt_engine_run_files(self.h, arr, len(paths), C.byref(p),
                                            os.fsencode(out_prefix) if out_prefix else None, max_text_chars, sec))
         return dict(zip(["read", "run", "write", "total"], map(float, sec)))
+
+    def release_columns(self, keep_anchor_ranks=False):
+        """Text, windows and sort scratch of the last run back to the device heap; keep_anchor_ranks: rows folded later can
+        still be put into direct-run order (anchor_merge(sort_like_direct=True))."""
+        _check(self.L.mmt_engine_release_columns(self.h, int(keep_anchor_ranks)))
 
     def merged_thresholds(self, anchor_len):
         out = np.zeros(anchor_len + 1, np.uint16)
@@ -637,18 +643,22 @@ class Comm:
             self.L.mmt_comm_destroy(self.h)
             self.h = None
 
-    def merge(self, min_len=20, by_ranges=False):
+    def merge(self, min_len=20, by_ranges=False, text_file=None):
         """Strict multi-MUMs: exchange + fold + re-sort.  Rank 0 gets {"text", "n_rows", "n_docs"}, the others None.
-        by_ranges: every rank folds its slice of the anchor (automatic from four ranks on)."""
+        by_ranges: every rank folds its slice of the anchor (automatic from four ranks on; rank 0 decides for everybody).
+        text_file: rank 0's library writes PREFIX.mums there itself (in pieces; no Python copy) and "text" is None."""
         m = C.c_void_p()
         f = self.L.mmt_dist_merge_ranges if by_ranges else self.L.mmt_dist_merge
         _check(f(self.h, self.engine.h, C.c_uint32(min_len), C.byref(m)))
         if not m:
             return None
         try:
+            n = self.L.mmt_merged_rows(m)
+            if text_file is not None:
+                _check(self.L.mmt_merged_write_text(m, os.fsencode(text_file)))
+                return dict(text=None, n_rows=n, n_docs=self.L.mmt_merged_docs(m))
             k = C.c_size_t()
             ptr = self.L.mmt_merged_text(m, C.byref(k))
-            n = self.L.mmt_merged_rows(m)
             if not ptr and n:
                 raise MumemtoError(self.L.mmt_last_error().decode())
             return dict(text=_bytes_at(ptr, k.value), n_rows=n, n_docs=self.L.mmt_merged_docs(m))

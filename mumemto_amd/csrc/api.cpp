@@ -468,6 +468,12 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
     MMT_CATCH
 }
 void mmt_pool_trim(void) { mmt::pool::trim(); }
+int mmt_engine_release_columns(mmt_engine* e, int keep_anchor_ranks) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    e->e->release_columns(keep_anchor_ranks != 0);
+    MMT_CATCH
+}
 int mmt_engine_set_scan_shard(mmt_engine* e, uint32_t index, uint32_t count) {
     if (!e) return fail(1, "null");
     MMT_TRY

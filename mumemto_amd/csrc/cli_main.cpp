@@ -255,8 +255,7 @@ static int run_rank(BuildOptions& o) {
         bool root = false;
         MergedRows merged = dist_merge(*comm, (uint32_t)o.min_match_len, &root);
         if (root) {
-            const std::string text = format_merged(eng, merged);
-            write_file(o.output_prefix + ".mums", text.data(), text.size());
+            write_merged_text(eng, merged, o.output_prefix + ".mums");      // (in pieces: 94 whole genomes are 40 GB of rows)
             rows = merged.n_rows;
             if (o.anchor_merge) {
                 download_merged(eng, merged);
@@ -428,7 +427,7 @@ int main(int argc, char** argv) {
         const uint64_t max_text = eng.auto_max_text();
         const bool strict_mode = mum_mode && (o.num_distinct_docs == 0 || (size_t)o.num_distinct_docs == doc_len.size());
         // modes without a partition merge are tried as one run whatever the estimate says, like the library does
-        const bool partitioned = text_chars > max_text && doc_len.size() >= 3 && (strict_mode || explicit_limit);
+        bool partitioned = text_chars > max_text && doc_len.size() >= 3 && (strict_mode || explicit_limit);
         if (checkpoint && partitioned) throw CliError{"-p / -a are not available for inputs larger than one suffix array", 1};
         if (checkpoint && (o.keep_temp || o.arrays_out))
             throw CliError{"-K and -A write what -p / -a read: run them without a checkpoint", 1};
@@ -475,8 +474,24 @@ int main(int argc, char** argv) {
             if (o.arrays_out) eng.set_keep_columns(1);          // -A dumps whole columns: keep them next to the windows
             // PREFIX.mums is written window by window while the run goes on (Engine::set_text_sink)
             if (mum_mode && !o.binary) eng.set_text_sink(o.output_prefix + ".mums");
-            eng.run(p);
-            eng.set_text_sink(std::string());
+            try {
+                eng.run(p);
+                eng.set_text_sink(std::string());
+            } catch (const DeviceOom&) {
+                // The estimate accepted the collection and its dictionary or its giant phrases still ran out of memory: a
+                // strict multi-MUM run is repeated as anchor partitions from the host copies, as the library does
+                // (Engine::run_partitioned_docs); the sink's PREFIX.mums.tmp is already gone (Engine::sink_close).
+                eng.set_text_sink(std::string());
+                const bool can = strict_mode && !checkpoint && doc_len.size() >= 3 && !o.keep_temp && !o.arrays_out &&
+                                 !(o.merge && !o.anchor_merge);
+                if (!can) throw;
+                log_line("build_main", "one suffix array ran out of device memory: repeating the run as anchor partitions");
+                eng.forget_last_run();
+                eng.run_partitioned_docs(hd.ptr.data(), doc_len.data(), doc_len.size(), p, text_chars / 2);
+                partitioned = true;
+                log_line("build_main", "text of " + std::to_string(text_chars) + " characters processed as " +
+                                           std::to_string(eng.partitions_used()) + " anchor partitions");
+            }
         }
         mark("run done");
         const HostRows& R = mum_mode ? eng.rows_meta() : eng.rows(Engine::ROWS_TEXT);   // .mums: write_text_file; .bumbl pulls the arrays itself

@@ -12,6 +12,8 @@
 // a plain C++ host gets /opt/rocm/lib/librccl.so.  Nothing here falls back to another transport.
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -46,11 +48,18 @@ Rccl& rccl() {
     static Rccl r;
     if (r.handle) return r;
     void* h = nullptr;
-    // a copy that is already in the process first (RTLD_NOLOAD), then the ROCm one
-    for (const char* name : {"librccl.so", "librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        if (h) break;
+    // MUMEMTO_RCCL_LIB: this library and no other (the tests' transport double, tests/fake_rccl: ranks = processes that
+    // share one GPU -- the only way the exchange below runs with more than one rank on a one-GPU box)
+    if (const char* path = std::getenv("MUMEMTO_RCCL_LIB")) {
+        h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) throw std::runtime_error(std::string("cannot load MUMEMTO_RCCL_LIB: ") + dlerror());
     }
+    // a copy that is already in the process first (RTLD_NOLOAD), then the ROCm one
+    if (!h)
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (h) break;
+        }
     if (!h)
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -124,10 +133,10 @@ void comm_destroy(Comm* c) {
     delete c;
 }
 
-// every rank's (rows, documents, bytes) on every rank
-static std::vector<uint64_t> exchange_meta(Comm& c, uint64_t rows, uint64_t docs, uint64_t bytes) {
+// every rank's four words on every rank
+static std::vector<uint64_t> exchange_meta(Comm& c, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t w3 = 0) {
     hipStream_t st = c.engine->stream();
-    uint64_t mine[4] = {rows, docs, bytes, 0};
+    uint64_t mine[4] = {w0, w1, w2, w3};
     DevBuf<uint64_t> d_mine;
     d_mine.ensure(4);
     MMT_HIP(hipMemcpyAsync(d_mine.get(), mine, 32, hipMemcpyHostToDevice, st));
@@ -138,24 +147,43 @@ static std::vector<uint64_t> exchange_meta(Comm& c, uint64_t rows, uint64_t docs
     return all;
 }
 
-// Strict multi-MUMs.  The engine's last run must have been this rank's partition with merge metadata on.
-// Returns the merged rows on rank 0 (already in direct-run order), an empty MergedRows elsewhere.
 int comm_world(const Comm& c) { return c.world; }
 
-MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
-    {
-        // from four ranks on the fold itself is spread over the ranks (dist_merge_ranges below)
-        const char* env = std::getenv("MUMEMTO_RANGE_FOLD");
-        if (env ? std::string(env) == "1" : c.world >= 4) return dist_merge_ranges(c, min_len, is_root);
-    }
+static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<uint64_t>& meta);
+static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<uint64_t>& meta);
+
+// Strict multi-MUMs.  The engine's last run must have been this rank's partition with merge metadata on.
+// Returns the merged rows on rank 0 (already in direct-run order), an empty MergedRows elsewhere.
+// route: 0 = rank 0 folds everything, 1 = every rank folds its slice of the anchor, -1 = automatic (slices from four ranks
+// on; MUMEMTO_RANGE_FOLD=0/1 overrides).  The route is a collective decision: every rank sends its wish with the table
+// sizes and all of them follow RANK 0's -- ranks whose environments differ must not end up in different collectives.
+static MergedRows merge_routed(Comm& c, uint32_t min_len, bool* is_root, int route) {
     Engine& e = *c.engine;
     MMT_HIP(hipSetDevice(e.device()));
-    hipStream_t st = e.stream();
     if (is_root) *is_root = c.rank == 0;
     const HostRows& R = e.rows_meta();
     if (!R.mum_mode || !e.thresh_len()) throw std::runtime_error("the exchange needs a multi-MUM run with merge metadata");
+    if (route < 0) {
+        const char* env = std::getenv("MUMEMTO_RANGE_FOLD");
+        route = env ? (std::string(env) == "1" ? 1 : 0) : (c.world >= 4 ? 1 : 0);
+    }
+    const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
+    e.rows_mum_device(&my_len, &my_off, &my_st);
+    const uint32_t my_longest = longest_row(e, my_len, R.n_rows, true);
+    const std::vector<uint64_t> meta = exchange_meta(c, R.n_rows, R.n_docs, my_longest, (uint64_t)route);
+    for (int r = 1; r < c.world; r++)
+        if (meta[(size_t)r * 4 + 1] == 0) throw std::runtime_error("a rank without documents in the exchange");
+    return meta[3] ? merge_by_ranges(c, min_len, meta) : merge_on_rank0(c, min_len, meta);
+}
+
+MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) { return merge_routed(c, min_len, is_root, -1); }
+MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root) { return merge_routed(c, min_len, is_root, 1); }
+
+static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<uint64_t>& meta) {
+    Engine& e = *c.engine;
+    hipStream_t st = e.stream();
+    const HostRows& R = e.rows_meta();
     const uint64_t L = e.doc_len()[0] + 1;
-    const std::vector<uint64_t> meta = exchange_meta(c, R.n_rows, R.n_docs, 0);
     const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
     e.rows_mum_device(&my_len, &my_off, &my_st);
     // Only rank 0 folds: every other rank SENDS its four tables to rank 0 (point-to-point over xGMI, one group) and keeps
@@ -215,78 +243,95 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root) {
     return m;
 }
 
-// The same result by coordinate ranges (merge.cpp): every rank folds ITS slice of the anchor.  Rows -- small --
-// are broadcast to everyone (one group); of the thresholds, 2 bytes per anchor position and rank, every rank receives only
-// its slice [base, hi) from every other rank (an all-to-all of world x world messages in one group, over all xGMI links at
-// once instead of everything into rank 0's); the pieces go to rank 0 in rank order = anchor order.  Rank 0's work drops from
-// world - 1 fold steps over the whole anchor to world - 1 steps over 1 / world of it.
-MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root) {
+// The same result by coordinate ranges (merge.cpp): every rank folds ITS slice of the anchor.  Rank q needs,
+// from every rank, the rows that start in [base[q], hi[q]) and the thresholds of that range -- so both travel as an
+// all-to-all of slices: world x (world - 1) messages of ncclSend / ncclRecv in one group, over all xGMI links at once
+// instead of everything into rank 0's.  (Round 3 broadcast every rank's whole row table to every rank: with 94 whole
+// genomes a rank's table is 30 million rows x 13 columns = 3.5 GB, and seven of them arrived on every rank to be filtered
+// down to an eighth.)  The pieces go to rank 0 in rank order = anchor order.  Rank 0's work drops from world - 1 fold steps
+// over the whole anchor to world - 1 steps over 1 / world of it.
+static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<uint64_t>& meta) {
     Engine& e = *c.engine;
-    MMT_HIP(hipSetDevice(e.device()));
     hipStream_t st = e.stream();
-    if (is_root) *is_root = c.rank == 0;
     const HostRows& R = e.rows_meta();
-    if (!R.mum_mode || !e.thresh_len()) throw std::runtime_error("the exchange needs a multi-MUM run with merge metadata");
     const uint64_t L = e.doc_len()[0] + 1;
+    const int W = c.world;
     const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
     e.rows_mum_device(&my_len, &my_off, &my_st);
-    const uint32_t my_longest = longest_row(e, my_len, R.n_rows, true);
-    std::vector<uint64_t> meta;
+    uint32_t longest = 0;
+    for (int r = 0; r < W; r++) longest = std::max<uint32_t>(longest, (uint32_t)meta[(size_t)r * 4 + 2]);
+    const uint64_t margin = fold_margin((size_t)W, longest);
+    std::vector<uint64_t> lo((size_t)W), hi((size_t)W), base((size_t)W);
+    for (int r = 0; r < W; r++) fold_slice_bounds(L, W, r, margin, &lo[r], &hi[r], &base[r]);
+    const uint64_t my_span = hi[c.rank] - base[c.rank];
+    if (W == 1) {
+        mmt_partition one;
+        one.n_rows = R.n_rows; one.n_docs = R.n_docs; one.length = my_len; one.offsets = my_off; one.strands = my_st;
+        one.thresh = e.thresh_device(); one.thresh_len = L; one.thresh_on_device = 1; one.rows_on_device = 1;
+        MergedRows piece = anchor_merge_slice(e, &one, 1, min_len, 0, L, 0, true);
+        sort_like_direct(e, piece);
+        return piece;
+    }
+    // my rows for every destination: those that start in [base[q], hi[q]) (global coordinates; the slice fold shifts them)
+    struct Out { DevBuf<uint32_t> len; DevBuf<int64_t> off; DevBuf<uint8_t> str; uint32_t n = 0; };
+    std::vector<std::unique_ptr<Out>> out((size_t)W);
+    std::vector<uint64_t> my_counts((size_t)W, 0);
+    for (int q = 0; q < W; q++) {
+        out[q].reset(new Out());
+        filter_rows(e, my_len, my_off, my_st, (uint32_t)R.n_rows, (uint32_t)R.n_docs, 0, (int64_t)base[q], (int64_t)hi[q], 0,
+                    out[q]->len, out[q]->off, out[q]->str, &out[q]->n);
+        my_counts[q] = out[q]->n;
+    }
+    // counts[r][q] = rows rank r has for rank q: one all-gather of W words per rank
+    std::vector<uint64_t> counts((size_t)W * W);
     {
-        // (rows, documents, longest row) of every rank
-        uint64_t mine[4] = {R.n_rows, R.n_docs, my_longest, 0};
-        DevBuf<uint64_t> d_mine;
-        d_mine.ensure(4);
-        MMT_HIP(hipMemcpyAsync(d_mine.get(), mine, 32, hipMemcpyHostToDevice, st));
-        MMT_NCCL(rccl().AllGather(d_mine.get(), c.d_meta.get(), 4, ncclUint64, c.comm, st));
-        meta.resize((size_t)c.world * 4);
-        MMT_HIP(hipMemcpyAsync(meta.data(), c.d_meta.get(), meta.size() * 8, hipMemcpyDeviceToHost, st));
+        DevBuf<uint64_t> d_mine, d_all;
+        d_mine.ensure((size_t)W); d_all.ensure((size_t)W * W);
+        MMT_HIP(hipMemcpyAsync(d_mine.get(), my_counts.data(), (size_t)W * 8, hipMemcpyHostToDevice, st));
+        MMT_NCCL(rccl().AllGather(d_mine.get(), d_all.get(), (size_t)W, ncclUint64, c.comm, st));
+        MMT_HIP(hipMemcpyAsync(counts.data(), d_all.get(), counts.size() * 8, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipStreamSynchronize(st));
     }
-    uint32_t longest = 0;
-    for (int r = 0; r < c.world; r++) longest = std::max<uint32_t>(longest, (uint32_t)meta[(size_t)r * 4 + 2]);
-    const uint64_t margin = fold_margin((size_t)c.world, longest);
-    std::vector<uint64_t> lo((size_t)c.world), hi((size_t)c.world), base((size_t)c.world);
-    for (int r = 0; r < c.world; r++) fold_slice_bounds(L, c.world, r, margin, &lo[r], &hi[r], &base[r]);
-    const uint64_t my_span = hi[c.rank] - base[c.rank];
-    // rows of everyone to everyone, threshold slices all-to-all
     MMT_NCCL(rccl().GroupStart());
-    for (int r = 0; r < c.world; r++) {
-        const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
-        if (r != c.rank) { c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); }
-        if (rows) {
-            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)my_len : c.len[r]->get(), r == c.rank ? (void*)my_len : c.len[r]->get(),
-                                      rows, ncclUint32, r, c.comm, st));
-            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)my_off : c.off[r]->get(), r == c.rank ? (void*)my_off : c.off[r]->get(),
-                                      cells, ncclInt64, r, c.comm, st));
-            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)my_st : c.st[r]->get(), r == c.rank ? (void*)my_st : c.st[r]->get(),
-                                      cells, ncclUint8, r, c.comm, st));
-        }
-    }
-    for (int r = 0; r < c.world; r++) {
+    for (int r = 0; r < W; r++) {
         if (r == c.rank) continue;
-        c.th[r]->ensure(my_span + 1);
+        // to rank r: my rows of its range, my thresholds of its range
+        const size_t s_rows = out[r]->n, s_cells = s_rows * R.n_docs;
+        if (s_rows) {
+            MMT_NCCL(rccl().Send(out[r]->len.get(), s_rows, ncclUint32, r, c.comm, st));
+            MMT_NCCL(rccl().Send(out[r]->off.get(), s_cells, ncclInt64, r, c.comm, st));
+            MMT_NCCL(rccl().Send(out[r]->str.get(), s_cells, ncclUint8, r, c.comm, st));
+        }
         MMT_NCCL(rccl().Send(e.thresh_device() + base[r], (hi[r] - base[r]) * 2, ncclUint8, r, c.comm, st));
+        // from rank r: its rows of my range, its thresholds of my range
+        const size_t rows = counts[(size_t)r * W + c.rank], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
+        c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(my_span + 1);
+        if (rows) {
+            MMT_NCCL(rccl().Recv(c.len[r]->get(), rows, ncclUint32, r, c.comm, st));
+            MMT_NCCL(rccl().Recv(c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
+            MMT_NCCL(rccl().Recv(c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
+        }
         MMT_NCCL(rccl().Recv(c.th[r]->get(), my_span * 2, ncclUint8, r, c.comm, st));
     }
     MMT_NCCL(rccl().GroupEnd());
     MMT_HIP(hipStreamSynchronize(st));
     // this rank's slice
-    std::vector<mmt_partition> parts((size_t)c.world);
-    for (int r = 0; r < c.world; r++) {
+    std::vector<mmt_partition> parts((size_t)W);
+    for (int r = 0; r < W; r++) {
         mmt_partition& p = parts[(size_t)r];
-        p.n_rows = meta[(size_t)r * 4]; p.n_docs = meta[(size_t)r * 4 + 1];
-        if (r == c.rank) { p.length = my_len; p.offsets = my_off; p.strands = my_st; p.thresh = e.thresh_device() + base[c.rank]; }
-        else { p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get(); }
+        p.n_docs = meta[(size_t)r * 4 + 1];
+        if (r == c.rank) {
+            Out& mine = *out[(size_t)c.rank];
+            p.n_rows = mine.n; p.length = mine.len.get(); p.offsets = mine.off.get(); p.strands = mine.str.get();
+            p.thresh = e.thresh_device() + base[c.rank];
+        } else {
+            p.n_rows = counts[(size_t)r * W + c.rank];
+            p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get();
+        }
         p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1;
     }
-    MergedRows piece;
-    if (c.world == 1) {
-        piece = anchor_merge_slice(e, parts.data(), 1, min_len, 0, L, 0, true);
-        sort_like_direct(e, piece);
-        return piece;
-    }
-    piece = anchor_merge_slice(e, parts.data(), parts.size(), min_len, lo[c.rank], hi[c.rank], base[c.rank], true);
+    MergedRows piece = anchor_merge_slice(e, parts.data(), parts.size(), min_len, lo[c.rank], hi[c.rank], base[c.rank], true);
+    out.clear();
     // the pieces to rank 0, in rank order
     const std::vector<uint64_t> pm = exchange_meta(c, piece.n_rows, piece.n_docs, 0);
     std::vector<MergedRows> pieces;
@@ -300,9 +345,9 @@ MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root) {
         }
         MMT_NCCL(rccl().Send(piece.d_thresh.get(), piece.thresh_len * 2, ncclUint8, 0, c.comm, st));
     } else {
-        pieces.resize((size_t)c.world);
+        pieces.resize((size_t)W);
         pieces[0] = std::move(piece);
-        for (int r = 1; r < c.world; r++) {
+        for (int r = 1; r < W; r++) {
             MergedRows& p = pieces[(size_t)r];
             p.n_rows = pm[(size_t)r * 4]; p.n_docs = pm[(size_t)r * 4 + 1]; p.thresh_len = hi[r] - lo[r];
             const size_t cells = p.n_rows * p.n_docs;
@@ -324,7 +369,8 @@ MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root) {
 }
 
 // Modes without a partition merge: this rank's PREFIX.mums / .mems bytes (mmt_engine_set_scan_shard) to rank 0, in rank
-// order.  Returns the whole output on rank 0, an empty string elsewhere.
+// order -- sent to rank 0 only (round 3 broadcast every rank's bytes to every rank, and only rank 0 read them).  Returns the
+// whole output on rank 0, an empty string elsewhere.
 std::string dist_gather_text(Comm& c) {
     Engine& e = *c.engine;
     MMT_HIP(hipSetDevice(e.device()));
@@ -332,15 +378,19 @@ std::string dist_gather_text(Comm& c) {
     const HostRows& R = e.rows(Engine::ROWS_TEXT);
     const std::vector<uint64_t> meta = exchange_meta(c, R.n_rows, R.n_docs, R.text_len);
     DevBuf<uint8_t> mine;
-    mine.ensure(R.text_len + 1);
-    if (R.text_len) MMT_HIP(hipMemcpyAsync(mine.get(), R.text, R.text_len, hipMemcpyHostToDevice, st));
+    if (c.rank != 0) {
+        mine.ensure(R.text_len + 1);
+        if (R.text_len) MMT_HIP(hipMemcpyAsync(mine.get(), R.text, R.text_len, hipMemcpyHostToDevice, st));
+    }
     MMT_NCCL(rccl().GroupStart());
-    for (int r = 0; r < c.world; r++) {
-        const size_t bytes = meta[(size_t)r * 4 + 2];
-        c.text[r]->ensure(bytes + 1);
-        if (bytes)
-            MMT_NCCL(rccl().Broadcast(r == c.rank ? (const void*)mine.get() : c.text[r]->get(), c.text[r]->get(), bytes, ncclUint8, r,
-                                      c.comm, st));
+    if (c.rank != 0) {
+        if (R.text_len) MMT_NCCL(rccl().Send(mine.get(), R.text_len, ncclUint8, 0, c.comm, st));
+    } else {
+        for (int r = 1; r < c.world; r++) {
+            const size_t bytes = meta[(size_t)r * 4 + 2];
+            c.text[r]->ensure(bytes + 1);
+            if (bytes) MMT_NCCL(rccl().Recv(c.text[r]->get(), bytes, ncclUint8, r, c.comm, st));
+        }
     }
     MMT_NCCL(rccl().GroupEnd());
     MMT_HIP(hipStreamSynchronize(st));
@@ -348,8 +398,9 @@ std::string dist_gather_text(Comm& c) {
     size_t total = 0;
     for (int r = 0; r < c.world; r++) total += meta[(size_t)r * 4 + 2];
     std::string out(total, '\0');
-    size_t at = 0;
-    for (int r = 0; r < c.world; r++) {
+    if (R.text_len) std::memcpy(&out[0], R.text, R.text_len);
+    size_t at = R.text_len;
+    for (int r = 1; r < c.world; r++) {
         const size_t bytes = meta[(size_t)r * 4 + 2];
         if (bytes) MMT_HIP(hipMemcpyAsync(&out[at], c.text[r]->get(), bytes, hipMemcpyDeviceToHost, st));
         at += bytes;

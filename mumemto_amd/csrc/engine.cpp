@@ -267,11 +267,11 @@ void Engine::release_sort_scratch() {
     pfp_ = std::move(fresh);
 }
 
-void Engine::release_columns() {
+void Engine::release_columns(bool keep_anchor_ranks) {
     MMT_HIP(hipStreamSynchronize(stream_));
     release_sort_scratch();
-    d_text_.release(); d_bwt_.release(); d_sa_.release(); d_sa_hi_.release(); d_cols_.release(); d_rank_.release();
-    d_rank64_.release();
+    d_text_.release(); d_bwt_.release(); d_sa_.release(); d_sa_hi_.release(); d_cols_.release();
+    if (!keep_anchor_ranks) { d_rank_.release(); d_rank64_.release(); anchor_ranks_valid_ = false; }
     d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
     d_cand_.release(); d_flags_.release();
     for (int k = 0; k < 2; k++) { w_sa_[k].release(); w_hi_[k].release(); w_bwt_[k].release(); w_lcp_[k].release(); }
@@ -567,9 +567,13 @@ void Engine::sink_open(bool mum_mode) {
     sink_active_ = false;
     sink_written_path_.clear();
     if (sink_path_.empty() || !mum_mode || std::getenv("MUMEMTO_NO_TEXT_SINK")) return;
-    sink_fd_ = ::open(sink_path_.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
-    if (sink_fd_ < 0) throw std::runtime_error("cannot write " + sink_path_);
+    // the bytes go to PREFIX.mums.tmp and take the final name when the run has succeeded (sink_close): a run that fails
+    // after some windows -- out of memory, a consistency check at the end -- must not leave a plausible partial PREFIX.mums
+    sink_tmp_path_ = sink_path_ + ".tmp";
+    sink_fd_ = ::open(sink_tmp_path_.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (sink_fd_ < 0) throw std::runtime_error("cannot write " + sink_tmp_path_);
     sink_rows_done_ = 0; sink_bytes_ = 0; sink_block_at_ = 0; sink_block_used_ = 0;
+    sink_block_pending_.assign(sink_blocks_.size(), 0);
     sink_closing_ = false; sink_error_.clear();
     sink_pieces_ = 0;
     if (!sink_stream_) {
@@ -592,27 +596,47 @@ void Engine::sink_open(bool mum_mode) {
             (void)hipEventDestroy(pc.ready);
             for (size_t done = 0; sink_error_.empty() && done < pc.n;) {
                 const ssize_t w = ::write(sink_fd_, pc.p + done, pc.n - done);
-                if (w <= 0) { sink_error_ = "short write to " + sink_path_; break; }
+                if (w <= 0) { sink_error_ = "short write to " + sink_tmp_path_; break; }
                 done += (size_t)w;
             }
+            { std::lock_guard<std::mutex> lk(sink_mu_); sink_block_pending_[pc.block]--; }
+            sink_cv_.notify_all();
         }
     });
 }
-// page-locked room for a piece: blocks of 256 MB (or the piece), kept with the engine
-char* Engine::sink_host_room(size_t n) {
-    const size_t BLOCK = (size_t)256 << 20;
-    for (;;) {
-        if (sink_block_at_ < sink_blocks_.size()) {
-            PinnedBuf<char>& b = *sink_blocks_[sink_block_at_];
-            const size_t cap = std::max(BLOCK, sink_block_cap_[sink_block_at_]);
-            if (sink_block_used_ + n <= cap) { char* p = b.get() + sink_block_used_; sink_block_used_ += n; return p; }
-            sink_block_at_++; sink_block_used_ = 0;
-            continue;
-        }
-        sink_blocks_.emplace_back(new PinnedBuf<char>());
-        sink_block_cap_.push_back(std::max(BLOCK, n));
-        sink_blocks_.back()->ensure(sink_block_cap_.back());
+// Page-locked room for a piece: a RING of blocks of 256 MB (or the piece) that stay with the engine.  A block is used
+// again once the writer thread has written every piece in it, so the page-locked memory of a run is a few blocks however
+// large the output is (round 3 kept every piece until the end of the run: 4.5 GB of pinned memory for a rank's share of
+// whole genomes, and it stayed with the engine).
+char* Engine::sink_host_room(size_t n, uint32_t* block) {
+    const size_t BLOCK = (size_t)256 << 20, RING = 4;
+    auto fits = [&](size_t b) { return std::max(BLOCK, sink_block_cap_[b]) >= n; };
+    std::unique_lock<std::mutex> lk(sink_mu_);
+    if (!sink_blocks_.empty() && sink_block_at_ < sink_blocks_.size() && fits(sink_block_at_) &&
+        sink_block_used_ + n <= std::max(BLOCK, sink_block_cap_[sink_block_at_])) {
+        char* p = sink_blocks_[sink_block_at_]->get() + sink_block_used_;
+        sink_block_used_ += n; sink_block_pending_[sink_block_at_]++; *block = (uint32_t)sink_block_at_;
+        return p;
     }
+    // the next block of the ring: a new one while the ring is short, otherwise the oldest, once it has been written
+    size_t next;
+    if (sink_blocks_.size() < RING) {
+        next = sink_blocks_.size();
+        sink_blocks_.emplace_back(new PinnedBuf<char>());
+        sink_block_cap_.push_back(0);
+        sink_block_pending_.push_back(0);
+    } else {
+        next = (sink_block_at_ + 1) % sink_blocks_.size();
+        sink_cv_.wait(lk, [&] { return sink_block_pending_[next] == 0 || !sink_error_.empty(); });
+    }
+    if (sink_block_cap_[next] < std::max(BLOCK, n)) {
+        lk.unlock();
+        sink_blocks_[next]->ensure(std::max(BLOCK, n));      // (nobody reads an idle block)
+        lk.lock();
+        sink_block_cap_[next] = std::max(BLOCK, n);
+    }
+    sink_block_at_ = next; sink_block_used_ = n; sink_block_pending_[next]++; *block = (uint32_t)next;
+    return sink_blocks_[next]->get();
 }
 // the rows accepted since the last call, in pop order, as PREFIX.mums bytes -> helper thread
 void Engine::sink_flush(ScanState& S) {
@@ -658,7 +682,7 @@ void Engine::sink_flush(ScanState& S) {
                   d_ooffs_.get(), d_ost_.get(), piece.get(), st);
     SinkPiece pc;
     pc.n = tbytes;
-    char* h = sink_host_room(tbytes);
+    char* h = sink_host_room(tbytes, &pc.block);
     pc.p = h;
     hipEvent_t formatted;
     MMT_HIP(hipEventCreateWithFlags(&formatted, hipEventDisableTiming));
@@ -674,17 +698,19 @@ void Engine::sink_flush(ScanState& S) {
     sink_cv_.notify_one();
     sink_bytes_ += tbytes;
 }
-void Engine::sink_close() {
+void Engine::sink_close(bool ok) {
     if (!sink_active_) return;
     { std::lock_guard<std::mutex> lk(sink_mu_); sink_closing_ = true; }
     sink_cv_.notify_one();
     if (sink_thread_.joinable()) sink_thread_.join();
     (void)hipStreamSynchronize(sink_stream_);
     std::string error = sink_error_;
-    if (sink_fd_ >= 0 && ::close(sink_fd_) != 0 && error.empty()) error = "cannot close " + sink_path_;
+    if (sink_fd_ >= 0 && ::close(sink_fd_) != 0 && error.empty()) error = "cannot close " + sink_tmp_path_;
     sink_fd_ = -1;
     sink_active_ = false;
-    if (!error.empty()) throw std::runtime_error(error);
+    if (error.empty() && !ok) error = "the run failed";
+    if (error.empty() && std::rename(sink_tmp_path_.c_str(), sink_path_.c_str()) != 0) error = "cannot rename " + sink_tmp_path_;
+    if (!error.empty()) { ::unlink(sink_tmp_path_.c_str()); throw std::runtime_error(error); }
     sink_written_path_ = sink_path_;
 }
 
@@ -1036,7 +1062,7 @@ void Engine::run(const mmt_params& p) {
         if (pfp_->guided) guided_stream(S, p); else pfp_stream(S, p);
         sink_flush(S);
     } catch (...) {
-        try { sink_close(); } catch (...) {}
+        try { sink_close(false); } catch (...) {}
         sink_written_path_.clear();
         throw;
     }

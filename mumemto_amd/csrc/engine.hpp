@@ -145,7 +145,9 @@ public:
     uint8_t* bwt_device() const { return d_bwt_.get(); }
     void release_sort_scratch();
     // gives every column and scratch buffer of the last run back to the device heap (results already downloaded stay)
-    void release_columns();
+    // keep_anchor_ranks: the suffix ranks of the anchor stay (a fold of this run's rows with other partitions' is still to
+    // be put into direct-run order, merge.cpp sort_like_direct)
+    void release_columns(bool keep_anchor_ranks = false);
     bool wants_lean() const;
 
     // Results of the last run.  rows_meta(): counts and mode only; rows(need): also the host copies asked for
@@ -274,8 +276,8 @@ private:
     DevBuf<uint64_t> d_cap_cnt_, d_cap_off_;
     uint64_t pool_used_ = 0;
     // the text sink (set_text_sink)
-    struct SinkPiece { const char* p; size_t n; hipEvent_t ready; };
-    std::string sink_path_, sink_written_path_;
+    struct SinkPiece { const char* p; size_t n; hipEvent_t ready; uint32_t block; };
+    std::string sink_path_, sink_written_path_, sink_tmp_path_;
     bool sink_active_ = false;
     int sink_fd_ = -1;
     size_t sink_rows_done_ = 0;
@@ -288,6 +290,7 @@ private:
     std::string sink_error_;
     std::vector<std::unique_ptr<PinnedBuf<char>>> sink_blocks_;      // page-locked blocks, kept between runs
     std::vector<size_t> sink_block_cap_;
+    std::vector<uint32_t> sink_block_pending_;     // pieces of a block the writer thread has not written yet (under sink_mu_)
     size_t sink_block_at_ = 0, sink_block_used_ = 0;
     DevBuf<char> d_piece_[2];                // two pieces: one is copied out on the copy stream while the next is formatted
     hipStream_t sink_stream_ = nullptr;
@@ -295,8 +298,8 @@ private:
     uint32_t sink_pieces_ = 0;
     void sink_open(bool mum_mode);
     void sink_flush(ScanState& S);
-    void sink_close();
-    char* sink_host_room(size_t n);
+    void sink_close(bool ok = true);        // ok: PREFIX.mums.tmp takes its name; otherwise it is removed
+    char* sink_host_room(size_t n, uint32_t* block);
     void order_rows(const k::Row* rows_abs, uint32_t cnt);
     float emit_ms_ = 0.f;
     uint64_t stream_entries_ = 0, window_bytes_peak_ = 0;

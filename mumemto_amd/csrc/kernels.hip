@@ -551,6 +551,7 @@ __global__ __launch_bounds__(BLOCK) void k_round_fused(const uint32_t* __restric
                                                        uint32_t* __restrict__ big_end, uint32_t* __restrict__ big_count,
                                                        uint32_t big_cap, uint8_t* __restrict__ tile_big) {
     constexpr int PER = CAP / BLOCK, NW = BLOCK / 64;
+    static_assert((CAP & (CAP - 1)) == 0, "the bitonic path pads a tile to the next power of two of its length: CAP must be one");
     // bucket head, rank of the suffix h further on (+ 1; 0 past the end), suffix: three 32-bit columns of the tile
     __shared__ uint32_t s_h[CAP];
     __shared__ uint32_t s_r[CAP];
@@ -733,20 +734,18 @@ void round_fused(const uint32_t* sac, const uint32_t* headc, const uint32_t* pos
     if (cap == 1024)
         hipLaunchKernelGGL((k_round_fused<256, 1024>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound, n_tiles, rank, n,
                            h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap, tile_big);
-    else if (cap == 1536)
-        hipLaunchKernelGGL((k_round_fused<256, 1536>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound, n_tiles, rank, n,
-                           h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap, tile_big);
     else
         hipLaunchKernelGGL((k_round_fused<256, 2048>), dim3(n_tiles), dim3(256), 0, s, sac, headc, pos, bound, n_tiles, rank, n,
                            h, shift, sa, sac_out, head_out, flags, big_begin, big_end, big_count, big_cap, tile_big);
     MMT_HIP(hipGetLastError());
 }
-// elements of one LDS tile of k_round_fused (MMT_ROUND_CAP = 1024 / 1536 / 2048: tuning aid)
+// elements of one LDS tile of k_round_fused (MMT_ROUND_CAP = 1024 / 2048: tuning aid; a power of two -- the bitonic path
+// of a tile pads to the next power of two of its length and the LDS columns hold CAP entries)
 uint32_t round_fused_cap() {
     static const uint32_t cap = [] {
         const char* e = std::getenv("MMT_ROUND_CAP");
         const int v = e ? std::atoi(e) : 2048;
-        return (uint32_t)(v == 1024 || v == 1536 ? v : 2048);
+        return (uint32_t)(v == 1024 ? v : 2048);
     }();
     return cap;
 }

@@ -13,6 +13,10 @@
 #include <cstdlib>
 #include <memory>
 #include <stdexcept>
+#include <condition_variable>
+#include <deque>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "merge_kernels.hpp"
 #include "pfp_kernels.hpp"
@@ -227,7 +231,7 @@ void fold_slice_bounds(uint64_t L, int world, int r, uint64_t margin, uint64_t* 
 }
 
 // rows of `in` (device tables) whose anchor offset + shift lies in [lo, hi), anchor offsets moved by delta
-static void filter_rows(Engine& e, const uint32_t* len, const int64_t* off, const uint8_t* st, uint32_t n, uint32_t n_docs,
+void filter_rows(Engine& e, const uint32_t* len, const int64_t* off, const uint8_t* st, uint32_t n, uint32_t n_docs,
                         int64_t shift, int64_t lo, int64_t hi, int64_t delta, DevBuf<uint32_t>& o_len, DevBuf<int64_t>& o_off,
                         DevBuf<uint8_t>& o_st, uint32_t* kept) {
     hipStream_t st_ = e.stream();
@@ -346,12 +350,38 @@ MergedRows anchor_merge_by_ranges(Engine& e, const mmt_partition* parts, size_t 
     uint32_t longest = 0;
     for (size_t g = 0; g < k; g++) longest = std::max(longest, longest_row(e, parts[g].length, parts[g].n_rows, parts[g].rows_on_device != 0));
     const uint64_t margin = fold_margin(k, longest);
+    // row tables that arrive in host memory go to the device once, not once per slice (eight shares of 94 whole genomes:
+    // 28 GB of rows); the thresholds -- the O(L_0) columns -- stay where they are and travel slice by slice
+    struct Up { DevBuf<uint32_t> len; DevBuf<int64_t> off; DevBuf<uint8_t> str; };
+    std::vector<std::unique_ptr<Up>> up(k);
+    std::vector<mmt_partition> dev(parts, parts + k);
+    hipStream_t st = e.stream();
+    MMT_HIP(hipSetDevice(e.device()));
+    for (size_t g = 0; g < k; g++) {
+        const mmt_partition& P = parts[g];
+        if (P.rows_on_device || !P.n_rows) continue;
+        up[g].reset(new Up());
+        const size_t cells = (size_t)P.n_rows * P.n_docs;
+        up[g]->len.ensure(P.n_rows); up[g]->off.ensure(cells); up[g]->str.ensure(cells);
+        MMT_HIP(hipMemcpyAsync(up[g]->len.get(), P.length, P.n_rows * 4, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemcpyAsync(up[g]->off.get(), P.offsets, cells * 8, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemcpyAsync(up[g]->str.get(), P.strands, cells, hipMemcpyHostToDevice, st));
+        dev[g].length = up[g]->len.get(); dev[g].offsets = up[g]->off.get(); dev[g].strands = up[g]->str.get();
+        dev[g].rows_on_device = 1;
+    }
+    MMT_HIP(hipStreamSynchronize(st));
+    const bool dbg = std::getenv("MMT_MERGE_DEBUG") != nullptr;
     std::vector<MergedRows> pieces;
     for (int r = 0; r < slices; r++) {
         uint64_t lo, hi, base;
         fold_slice_bounds(L, slices, r, margin, &lo, &hi, &base);
-        pieces.push_back(anchor_merge_slice(e, parts, k, min_len, lo, hi, base, false));
+        const auto t0 = std::chrono::steady_clock::now();
+        pieces.push_back(anchor_merge_slice(e, dev.data(), k, min_len, lo, hi, base, false));
+        if (dbg) std::fprintf(stderr, "[merge] slice %d of %d: anchor [%llu, %llu) from %llu, %zu rows, %.1f ms\n", r, slices,
+                              (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)base, pieces.back().n_rows,
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
+    up.clear();
     return concat_pieces(e, pieces);
 }
 
@@ -407,7 +437,7 @@ static size_t format_merged_device(Engine& e, const MergedRows& m, DevBuf<char>&
     MMT_HIP(hipStreamSynchronize(st));
     const size_t bytes = (size_t)(last[0] + last[1]);
     text.ensure(bytes + 1);
-    mk::table_write(m.d_length.get(), m.d_offsets.get(), m.d_strands.get(), (uint32_t)n, (uint32_t)m.n_docs, toff.get(),
+    mk::table_write(m.d_length.get(), m.d_offsets.get(), m.d_strands.get(), (uint32_t)n, (uint32_t)m.n_docs, toff.get(), 0,
                     text.get(), st);
     return bytes;
 }
@@ -434,10 +464,96 @@ const char* stage_merged_text(Engine& e, const MergedRows& m, size_t* n_bytes) {
     return host;
 }
 
+// Up to MERGED_TEXT_ONE_PIECE the bytes are formatted, staged and written as one piece (the C3 stand-in: 0.9 GB).  The
+// merged table of 94 whole genomes is 40 million rows x 94 columns = tens of GB of text: it is formatted in pieces of
+// whole rows -- row ranges cut where the running byte offset passes a multiple of the piece size --, every piece into one
+// of two device buffers, copied to one of two page-locked blocks and written by a helper thread while the next piece is
+// formatted (the shape of the text sink of a streamed run, engine.cpp).
+static constexpr size_t MERGED_TEXT_ONE_PIECE = (size_t)3 << 30, MERGED_TEXT_PIECE = (size_t)1 << 30;
+
 void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) {
-    size_t bytes = 0;
-    const char* host = stage_merged_text(e, m, &bytes);
-    write_file_bytes(path, host, bytes);
+    const size_t n = m.n_rows;
+    hipStream_t st = e.stream();
+    MMT_HIP(hipSetDevice(e.device()));
+    size_t piece_bytes = MERGED_TEXT_PIECE;
+    if (const char* c = std::getenv("MMT_MERGED_TEXT_PIECE")) piece_bytes = std::max<size_t>(std::strtoull(c, nullptr, 10), 4096);
+    // ~ (digits + comma + strand + comma) per cell: an upper bound good enough to choose the route
+    const bool one_piece = !std::getenv("MMT_MERGED_TEXT_PIECE") && (double)n * (double)m.n_docs * 24.0 < (double)MERGED_TEXT_ONE_PIECE;
+    if (!n || one_piece) {
+        size_t bytes = 0;
+        const char* host = stage_merged_text(e, m, &bytes);
+        write_file_bytes(path, host, bytes);
+        return;
+    }
+    DevBuf<uint64_t> tlen, toff;
+    tlen.ensure(n + 1); toff.ensure(n + 1);
+    mk::table_measure(m.d_length.get(), m.d_offsets.get(), (uint32_t)n, (uint32_t)m.n_docs, tlen.get(), st);
+    MMT_HIP(hipMemsetAsync(tlen.get() + n, 0, 8, st));
+    prims::exclusive_sum_u64(e.scratch(), tlen.get(), toff.get(), n + 1, st);     // toff[n] = all bytes
+    std::vector<uint64_t> h_off(n + 1);
+    MMT_HIP(hipMemcpyAsync(h_off.data(), toff.get(), (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    tlen.release();
+    // pieces of whole rows, each at most piece_bytes (a single row longer than that is a piece of its own)
+    std::vector<size_t> cut(1, 0);
+    uint64_t longest = 0;
+    for (size_t r = 0; r < n;) {
+        const uint64_t lim = h_off[r] + piece_bytes;
+        size_t q = (size_t)(std::upper_bound(h_off.begin() + r + 1, h_off.end(), lim) - h_off.begin()) - 1;
+        if (q <= r) q = r + 1;
+        longest = std::max<uint64_t>(longest, h_off[q] - h_off[r]);
+        cut.push_back(q);
+        r = q;
+    }
+    DevBuf<char> d_piece[2];
+    PinnedBuf<char> h_piece[2];
+    for (int b = 0; b < 2; b++) { d_piece[b].ensure(longest + 1); h_piece[b].ensure(longest + 1); }
+    const int fd = ::open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (fd < 0) throw std::runtime_error("cannot write " + path);
+    // the writer: piece i of buffer i & 1 once its copy has landed
+    struct Job { int buf; size_t bytes; };
+    std::mutex mu; std::condition_variable cv; std::deque<Job> q; bool closing = false; int free_buf[2] = {1, 1};
+    std::string error;
+    std::thread writer([&]() {
+        for (;;) {
+            Job j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !q.empty() || closing; });
+              if (q.empty()) return;
+              j = q.front(); q.pop_front(); }
+            const char* src = h_piece[j.buf].get();
+            size_t at = 0;
+            while (at < j.bytes && error.empty()) {
+                const ssize_t w = ::write(fd, src + at, j.bytes - at);
+                if (w <= 0) { std::lock_guard<std::mutex> lk(mu); error = "short write to " + path; break; }
+                at += (size_t)w;
+            }
+            { std::lock_guard<std::mutex> lk(mu); free_buf[j.buf] = 1; }
+            cv.notify_all();
+        }
+    });
+    try {
+        for (size_t i = 0; i + 1 < cut.size(); i++) {
+            const int b = (int)(i & 1);
+            const size_t r0 = cut[i], r1 = cut[i + 1];
+            const uint64_t bytes = h_off[r1] - h_off[r0];
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return free_buf[b] == 1; }); free_buf[b] = 0;
+              if (!error.empty()) throw std::runtime_error(error); }
+            mk::table_write(m.d_length.get() + r0, m.d_offsets.get() + r0 * m.n_docs, m.d_strands.get() + r0 * m.n_docs,
+                            (uint32_t)(r1 - r0), (uint32_t)m.n_docs, toff.get() + r0, h_off[r0], d_piece[b].get(), st);
+            MMT_HIP(hipMemcpyAsync(h_piece[b].get(), d_piece[b].get(), bytes, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+            { std::lock_guard<std::mutex> lk(mu); q.push_back(Job{b, (size_t)bytes}); }
+            cv.notify_all();
+        }
+    } catch (...) {
+        { std::lock_guard<std::mutex> lk(mu); closing = true; }
+        cv.notify_all(); writer.join(); ::close(fd);
+        throw;
+    }
+    { std::lock_guard<std::mutex> lk(mu); closing = true; }
+    cv.notify_all();
+    writer.join();
+    if (::close(fd) != 0 || !error.empty()) throw std::runtime_error(error.empty() ? "cannot close " + path : error);
 }
 
 void download_merged(Engine& e, MergedRows& m) {

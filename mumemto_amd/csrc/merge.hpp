@@ -23,6 +23,10 @@ uint32_t longest_row(Engine& e, const uint32_t* length, size_t n_rows, bool on_d
 // entry `base`, not at entry 0
 MergedRows anchor_merge_slice(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len, uint64_t lo, uint64_t hi,
                               uint64_t base, bool thresh_is_slice);
+// rows of a device table whose anchor offset + shift lies in [lo, hi), copied out with their anchor offsets moved by delta
+void filter_rows(Engine& e, const uint32_t* len, const int64_t* off, const uint8_t* st, uint32_t n, uint32_t n_docs,
+                 int64_t shift, int64_t lo, int64_t hi, int64_t delta, DevBuf<uint32_t>& o_len, DevBuf<int64_t>& o_off,
+                 DevBuf<uint8_t>& o_st, uint32_t* kept);
 MergedRows concat_pieces(Engine& e, std::vector<MergedRows>& pieces);
 MergedRows anchor_merge_by_ranges(Engine& e, const mmt_partition* parts, size_t k, int slices, uint32_t min_len = 20);
 // Direct-run order: sort by the suffix rank of the anchor occurrence.

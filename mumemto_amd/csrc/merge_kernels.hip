@@ -250,11 +250,11 @@ void table_measure(const uint32_t* len, const int64_t* off, uint32_t n, uint32_t
 
 __global__ void k_table_write(const uint32_t* __restrict__ len, const int64_t* __restrict__ off,
                               const uint8_t* __restrict__ st, uint32_t n, uint32_t n_docs,
-                              const uint64_t* __restrict__ text_off, char* __restrict__ text) {
+                              const uint64_t* __restrict__ text_off, uint64_t text_base, char* __restrict__ text) {
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63;
     if (r >= n) return;
-    char* t = text + text_off[r];
+    char* t = text + (text_off[r] - text_base);
     const uint32_t nl = ndigits(len[r]);
     if (lane == 0) { put_uint(t, len[r], nl); t[nl] = '\t'; }
     uint32_t cur = nl + 1;
@@ -280,10 +280,10 @@ __global__ void k_table_write(const uint32_t* __restrict__ len, const int64_t* _
     if (lane == 0) t[cur + 2 * n_docs - 1] = '\n';
 }
 void table_write(const uint32_t* len, const int64_t* off, const uint8_t* st, uint32_t n, uint32_t n_docs,
-                 const uint64_t* text_off, char* text, hipStream_t s) {
+                 const uint64_t* text_off, uint64_t text_base, char* text, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_table_write, dim3(grid_for((uint64_t)n * 64, 256)), dim3(256), 0, s, len, off, st, n, n_docs,
-                       text_off, text);
+                       text_off, text_base, text);
     MMT_HIP(hipGetLastError());
 }
 

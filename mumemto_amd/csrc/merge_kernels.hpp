@@ -57,6 +57,6 @@ void rank_keys64(const int64_t* off, uint32_t n, uint32_t n_docs, const uint64_t
 void table_measure(const uint32_t* len, const int64_t* off, uint32_t n, uint32_t n_docs, uint64_t* text_len,
                    hipStream_t s);
 void table_write(const uint32_t* len, const int64_t* off, const uint8_t* st, uint32_t n, uint32_t n_docs,
-                 const uint64_t* text_off, char* text, hipStream_t s);
+                 const uint64_t* text_off, uint64_t text_base, char* text, hipStream_t s);   // row r -> text + text_off[r] - text_base
 
 }}  // namespace mmt::mk

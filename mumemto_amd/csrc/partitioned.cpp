@@ -181,6 +181,13 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             sub_len.insert(sub_len.end(), doc_len + a, doc_len + b);
             set_input_device(buf[g & 1], sub_len.data(), sub_len.size());
             run(q);
+            // the columns of this partition are dead (the next run builds its own; only the last partition's anchor ranks
+            // order the result): its windows, batch buffers and tables go BEFORE its rows and thresholds are copied out --
+            // the bucket-wise producer sizes its batches by what the heap has left, and a 6 GB threshold column on top of
+            // that is what a {anchor + 8 whole genomes} partition did not have room for
+            for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
+            if (g + 1 < G) release_columns();
+            else release_columns(true);
             Part later;
             Part& P = g == 0 ? first : later;
             P.n_docs = sub_len.size(); P.n_rows = rows_.n_rows;
@@ -195,15 +202,6 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
             }
             MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
             MMT_HIP(hipStreamSynchronize(stream_));
-            for (int i = 0; i < 7; i++) acc[i] += stage_ms_[i];
-            // the columns of this partition are dead (the next run builds its own; only the last partition's anchor ranks
-            // order the result): the fold and the growing row table get their memory
-            if (g + 1 < G) release_columns();
-            else {
-                release_sort_scratch();
-                d_text_.release(); d_cols_.release(); d_sa_.release(); d_sa_hi_.release(); d_bwt_.release();
-                d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_cand_.release(); d_flags_.release();
-            }
             if (g >= 1) {
                 auto as_partition = [&](mmt_partition& m, size_t rows, size_t docs, const uint32_t* len, const int64_t* off,
                                         const uint8_t* st, const uint16_t* th) {

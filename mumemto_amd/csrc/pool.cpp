@@ -113,6 +113,10 @@ void add_free(std::map<size_t, size_t>& fl, size_t off, size_t size) {
 // map `bytes` (multiple of GROW) more physical memory at the top of the large region
 bool grow(Heap& H, size_t bytes) {
     if (H.top + bytes > H.small_bottom) return false;
+    // MUMEMTO_HEAP_LIMIT (bytes): the large region stops growing there -- how the tests make a run that the estimate
+    // accepted run out of device memory
+    static const size_t limit = [] { const char* e = std::getenv("MUMEMTO_HEAP_LIMIT"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+    if (limit && H.top + bytes > limit) return false;
     const double t0 = now_s();
     size_t done = 0;
     std::string why;

@@ -108,9 +108,13 @@ def test_device_resident_exchange_and_fold():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fold,max_text", [(2, "rank0", 0), (3, "rank0", 0), (3, "ranges", 0), (2, "rank0", 2_000_000),
-                                                 (2, "ranges", 2_000_000)])
-def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text):
+@pytest.mark.parametrize("world,fold,max_text,exchange", [
+    (2, "rank0", 0, "torch"), (3, "rank0", 0, "torch"), (3, "ranges", 0, "torch"), (2, "rank0", 2_000_000, "torch"),
+    (2, "ranges", 2_000_000, "torch"),
+    # bench.py's default: the native exchange of dist.cpp (here over the transport double of tests/fake_rccl, MUMEMTO_RCCL_LIB:
+    # this box has one GPU); "ranges" = MUMEMTO_RANGE_FOLD=1, the route four ranks or more take by themselves
+    (2, "rank0", 0, "native"), (3, "ranges", 0, "native"), (4, "auto", 0, "native"), (2, "ranges", 2_000_000, "native")])
+def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text, exchange):
     """bench.py's N > 1 path end to end -- torchrun, one process per rank, per-rank partition run, all-gather of the
     HBM row tables, device fold on rank 0, re-sort -- with the ranks sharing GPU 0 under gloo (this box has one GPU;
     RCCL wants one device per rank).  --check compares the merged bytes with the oracle's direct run on the union.
@@ -128,10 +132,17 @@ def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world),
            "--steps", "2", "--warmup", "1", "--haps", "31", "--length", "150000", "--divergence", "0.005", "--backend", "gloo",
-           "--share-device", "--check", "--fold", fold]
+           "--share-device", "--check", "--exchange", exchange, "--fold", fold if exchange == "torch" else "rank0"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     if max_text:
         env["MMT_MAX_TEXT"] = str(max_text)
+    if exchange == "native":
+        lib = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
+        if not os.path.exists(lib):
+            subprocess.check_call(["make", "-C", os.path.dirname(lib)])
+        env["MUMEMTO_RCCL_LIB"] = lib
+        if fold != "auto":
+            env["MUMEMTO_RANGE_FOLD"] = "1" if fold == "ranges" else "0"
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

@@ -205,3 +205,34 @@ def test_thirty_g_characters_as_one_streamed_run():
     # has it for this run alone, 138 GB)
     assert st["window_bytes"] < 30e9, st
     bigchecks.check_mum_rows(eng, bases, lens)
+
+
+def test_a_rank_share_of_configs3_anchor_and_twelve_whole_genome_haplotypes():
+    """BASELINE configs[3] on eight GPUs gives rank 0 {anchor + 12} x 3.05 Gbp = 79.3 G text characters: ONE streamed run
+    with merge metadata (rows in anchor coordinates, u16 thresholds over the anchor, suffix ranks of the anchor for the
+    re-sort), as `tests/big_c4.py` runs all eight shares and folds them (profiles/round4_c4_full.log: 41.8 M merged rows
+    x 94 columns, 49.7 GB of PREFIX.mums).  Checked by properties: sampled rows are real, maximal, one-per-document matches
+    in lexicographic order; every sampled row's threshold sits at its anchor position and is shorter than the row."""
+    import mumemto_amd
+    haps, length = 13, 3_050_000_000
+    bases = np.empty(haps * length, np.uint8)
+    for h, b in synth.haplotypes_sparse(94, length, 0.001, 4, which=list(range(haps))):
+        bases[h * length:(h + 1) * length] = b
+    lens = np.full(haps, length, np.uint64)
+    eng = mumemto_amd.Engine(0)
+    assert eng.run_partitioned(None, flat=(bases, lens), merge_metadata=True) == 1
+    assert eng.is_wide() and eng.text_length() == 2 * haps * (length + 1) > 79e9 and not eng.columns_kept()
+    st = eng.stream_stats()
+    assert st["entries"] == eng.text_length() and st["windows"] >= 60
+    assert eng.device_memory()["peak"] < 288 * 2**30
+    bigchecks.check_mum_rows(eng, bases, lens, use_text=False)
+    L, off, strands = eng.rows_mum()
+    assert len(L) > 25_000_000
+    th = eng.thresholds()
+    assert len(th) == 2 * (length + 1)
+    rng = np.random.default_rng(5)
+    for r in rng.integers(0, len(L), size=2000):
+        t = int(th[int(off[r, 0])])                    # the anchor is '+' in every kept row: text offset = anchor offset
+        assert 0 < t < int(L[r]), (r, t, int(L[r]))
+    assert int(np.count_nonzero(th[: length + 1])) >= len(L)
+    eng.close()

@@ -120,6 +120,11 @@ MMT_API size_t mmt_thresh_len(const mmt_engine* e);
 MMT_API int mmt_copy_thresh(const mmt_engine* e, uint16_t* out);
 /* Device pointers of the last run's thresholds / anchor ISA (for the merge).   */
 MMT_API const uint16_t* mmt_thresh_device(const mmt_engine* e);
+/* The engine's own threshold column: 32 bits per entry, never saturated (the 16-bit forms above are made from it and
+ * saturate at 65535 like the reference's, include/mem_finder.hpp:299,328).  What partitions hand to the fold with
+ * mmt_partition.thresh_bits = 32 and what the multi-GPU exchange carries. */
+MMT_API int mmt_copy_thresh32(const mmt_engine* e, uint32_t* out);
+MMT_API const uint32_t* mmt_thresh_device32(const mmt_engine* e);
 
 /* ---- stage introspection (parity tests, bench roofline) ------------------- */
 MMT_API uint64_t mmt_text_length(const mmt_engine* e);
@@ -197,10 +202,14 @@ typedef struct mmt_partition {
     const uint32_t* length;   /* host or device (see rows_on_device)           */
     const int64_t*  offsets;  /* n_rows * n_docs, column 0 = anchor            */
     const uint8_t*  strands;  /* 1 = '+'                                       */
-    const uint16_t* thresh;   /* host or device (see thresh_on_device), L_0+1 entries */
+    const uint16_t* thresh;   /* host or device (see thresh_on_device), L_0+1 entries; uint32_t entries behind the same
+                                 pointer when thresh_bits == 32 */
     uint64_t thresh_len;
     uint8_t thresh_on_device;
     uint8_t rows_on_device;   /* length / offsets / strands are HBM pointers   */
+    uint8_t thresh_bits;      /* 0 or 16: the reference's PREFIX.athresh width (saturated at 65535, mem_finder.hpp:299);
+                                 32: the engine's own width (mmt_copy_thresh32 / mmt_thresh_device32), never saturated --
+                                 what the multi-GPU exchange carries */
 } mmt_partition;
 typedef struct mmt_merged mmt_merged;
 /* Left fold over parts[0..k) exactly as anchor_merge does; the per-position
@@ -224,9 +233,9 @@ MMT_API size_t mmt_merged_rows(const mmt_merged* m);
 MMT_API size_t mmt_merged_docs(const mmt_merged* m);
 MMT_API int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* strands,
                            uint16_t* thresh);
-/* the merged tables in HBM (owned by m)                                        */
+/* the merged tables in HBM (owned by m); thresholds at the engine's width, 32 bits  */
 MMT_API int mmt_merged_device(const mmt_merged* m, const uint32_t** length, const int64_t** offsets,
-                              const uint8_t** strands, const uint16_t** thresh);
+                              const uint8_t** strands, const uint32_t** thresh);
 /* Rows folded elsewhere (a coordinate-range fold: every rank folds its slice of the anchor) as a merged
  * result of this engine: host arrays in, HBM tables out, so that mmt_merged_sort_like_direct / mmt_merged_text apply.  */
 MMT_API int mmt_merged_from_rows(mmt_engine* e, const uint32_t* length, const int64_t* offsets, const uint8_t* strands,

@@ -37,10 +37,10 @@ class Params(C.Structure):
                 ("max_total_freq", C.c_int64), ("use_revcomp", C.c_uint8), ("merge_metadata", C.c_uint8)]
 
 
-class Partition(C.Structure):
+class Partition(C.Structure):  # mmt_partition (mumemto_gpu.h); thresh_bits 0 / 16 / 32
     _fields_ = [("n_rows", C.c_uint64), ("n_docs", C.c_uint64), ("length", C.c_void_p), ("offsets", C.c_void_p),
                 ("strands", C.c_void_p), ("thresh", C.c_void_p), ("thresh_len", C.c_uint64),
-                ("thresh_on_device", C.c_uint8), ("rows_on_device", C.c_uint8)]
+                ("thresh_on_device", C.c_uint8), ("rows_on_device", C.c_uint8), ("thresh_bits", C.c_uint8)]
 
 
 class DevicePartition:
@@ -48,7 +48,9 @@ class DevicePartition:
     produces): length u32[n_rows], offsets i64[n_rows, n_docs], strands u8[n_rows, n_docs],
     thresh i16/u16[thresh_len].  `keepalive` holds whatever owns the memory."""
 
-    def __init__(self, n_rows, n_docs, length_ptr, offsets_ptr, strands_ptr, thresh_ptr, thresh_len, keepalive=None):
+    def __init__(self, n_rows, n_docs, length_ptr, offsets_ptr, strands_ptr, thresh_ptr, thresh_len, keepalive=None,
+                 thresh_bits=16):
+        self.thresh_bits = int(thresh_bits)
         self.n_rows, self.n_docs = int(n_rows), int(n_docs)
         self.length_ptr, self.offsets_ptr, self.strands_ptr = int(length_ptr), int(offsets_ptr), int(strands_ptr)
         self.thresh_ptr, self.thresh_len = int(thresh_ptr), int(thresh_len)
@@ -74,7 +76,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
-    "mmt_stream_stats", "mmt_engine_release_columns",
+    "mmt_stream_stats", "mmt_engine_release_columns", "mmt_copy_thresh32", "mmt_thresh_device32",
 ]
 
 
@@ -190,6 +192,9 @@ def load_library():
     L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.mmt_merged_free.argtypes = [C.c_void_p]
     L.mmt_engine_release_columns.argtypes = [C.c_void_p, C.c_int]
+    L.mmt_copy_thresh32.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_thresh_device32.restype = C.c_void_p
+    L.mmt_thresh_device32.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -453,8 +458,20 @@ class Engine:
             _check(self.L.mmt_copy_thresh(self.h, _p(out)))
         return out[:n]
 
+    def thresholds32(self):
+        """The engine's own threshold column: 32 bits, never saturated (what the fold and the exchange carry)."""
+        n = self.L.mmt_thresh_len(self.h)
+        out = np.zeros(max(n, 1), np.uint32)
+        if n:
+            _check(self.L.mmt_copy_thresh32(self.h, _p(out)))
+        return out[:n]
+
     def thresh_device_ptr(self):
+        """16-bit form (saturated at 65535 like PREFIX.athresh), made from the 32-bit column on the first call."""
         return self.L.mmt_thresh_device(self.h)
+
+    def thresh_device_ptr32(self):
+        return self.L.mmt_thresh_device32(self.h)
 
     # stage introspection
     def text_length(self):
@@ -548,7 +565,7 @@ class Engine:
         for i, part in enumerate(parts):
             if isinstance(part, DevicePartition):
                 arr[i] = Partition(part.n_rows, part.n_docs, part.length_ptr, part.offsets_ptr, part.strands_ptr,
-                                   part.thresh_ptr, part.thresh_len, 1, 1)
+                                   part.thresh_ptr, part.thresh_len, 1, 1, part.thresh_bits)
                 keep.append(part)
                 continue
             length, off, st, th = part
@@ -557,14 +574,16 @@ class Engine:
             st = np.ascontiguousarray(st, np.uint8)
             if off.ndim != 2:
                 off, st = off.reshape(len(length), -1), st.reshape(len(length), -1)
-            if isinstance(th, tuple):
+            if isinstance(th, tuple):       # (device address, entries[, bits])
                 tptr, tlen, on_dev = th[0], th[1], 1
-            else:
-                th = np.ascontiguousarray(th, np.uint16)
+                bits = th[2] if len(th) > 2 else 16
+            else:                           # uint16: the PREFIX.athresh width; uint32: the engine's own (thresholds32)
+                bits = 32 if getattr(th, "dtype", None) == np.uint32 else 16
+                th = np.ascontiguousarray(th, np.uint32 if bits == 32 else np.uint16)
                 tptr, tlen, on_dev = _p(th).value, len(th), 0
             keep += [length, off, st, th]
             arr[i] = Partition(len(length), off.shape[1], _p(length).value, _p(off).value, _p(st).value, tptr, tlen,
-                               on_dev, 0)
+                               on_dev, 0, bits)
         m = C.c_void_p()
         if slices:      # the same table as `slices` independent slices of the anchor (what `slices` ranks fold at once)
             _check(self.L.mmt_anchor_merge_by_ranges(self.h, arr, len(parts), int(slices), C.c_uint32(min_len), C.byref(m)))

@@ -431,7 +431,17 @@ int mmt_copy_thresh(const mmt_engine* e, uint16_t* out) {
     e->e->copy_thresh(out);
     MMT_CATCH
 }
-const uint16_t* mmt_thresh_device(const mmt_engine* e) { return e ? e->e->thresh_device() : nullptr; }
+const uint16_t* mmt_thresh_device(const mmt_engine* e) {
+    if (!e) return nullptr;
+    try { return e->e->thresh_device(); } catch (const std::exception& ex) { fail(3, ex.what()); return nullptr; }
+}
+int mmt_copy_thresh32(const mmt_engine* e, uint32_t* out) {
+    if (!e) return fail(1, "engine must be non-null");
+    MMT_TRY
+    e->e->copy_thresh32(out);
+    MMT_CATCH
+}
+const uint32_t* mmt_thresh_device32(const mmt_engine* e) { return e ? e->e->thresh_device32() : nullptr; }
 
 uint64_t mmt_text_length(const mmt_engine* e) { return e ? e->e->text_length() : 0; }
 int mmt_copy_text(const mmt_engine* e, uint8_t* out) { if (!e) return fail(1, "null"); MMT_TRY e->e->copy_text(out); MMT_CATCH }
@@ -594,7 +604,7 @@ int mmt_merged_get(mmt_merged* m, uint32_t* length, int64_t* offsets, uint8_t* s
     MMT_CATCH
 }
 int mmt_merged_device(const mmt_merged* m, const uint32_t** length, const int64_t** offsets, const uint8_t** strands,
-                      const uint16_t** thresh) {
+                      const uint32_t** thresh) {
     if (!m) return fail(1, "null");
     if (length) *length = m->rows.d_length.get();
     if (offsets) *offsets = m->rows.d_offsets.get();
@@ -621,7 +631,13 @@ int mmt_merged_from_rows(mmt_engine* e, const uint32_t* length, const int64_t* o
         MMT_HIP(hipMemcpyAsync(R.d_offsets.get(), offsets, n_rows * n_docs * 8, hipMemcpyHostToDevice, st));
         MMT_HIP(hipMemcpyAsync(R.d_strands.get(), strands, n_rows * n_docs, hipMemcpyHostToDevice, st));
     }
-    if (thresh_len && thresh) MMT_HIP(hipMemcpyAsync(R.d_thresh.get(), thresh, thresh_len * 2, hipMemcpyHostToDevice, st));
+    if (thresh_len && thresh) {
+        mmt::DevBuf<uint16_t> narrow;
+        narrow.ensure(thresh_len);
+        MMT_HIP(hipMemcpyAsync(narrow.get(), thresh, thresh_len * 2, hipMemcpyHostToDevice, st));
+        mmt::k::thresh_widen(narrow.get(), thresh_len, R.d_thresh.get(), st);
+        MMT_HIP(hipStreamSynchronize(st));
+    }
     MMT_HIP(hipStreamSynchronize(st));
     R.on_host = false;
     m->engine = e->e.get();

@@ -100,7 +100,7 @@ struct Comm {
     std::vector<std::unique_ptr<DevBuf<uint32_t>>> len;
     std::vector<std::unique_ptr<DevBuf<int64_t>>> off;
     std::vector<std::unique_ptr<DevBuf<uint8_t>>> st, text;
-    std::vector<std::unique_ptr<DevBuf<uint16_t>>> th;
+    std::vector<std::unique_ptr<DevBuf<uint32_t>>> th;      // thresholds travel at 32 bits
 };
 
 void comm_unique_id(uint8_t out[128]) {
@@ -122,7 +122,7 @@ Comm* comm_create(Engine& e, int rank, int world, const uint8_t id_bytes[128]) {
     c->len.resize(world); c->off.resize(world); c->st.resize(world); c->th.resize(world); c->text.resize(world);
     for (int r = 0; r < world; r++) {
         c->len[r].reset(new DevBuf<uint32_t>()); c->off[r].reset(new DevBuf<int64_t>());
-        c->st[r].reset(new DevBuf<uint8_t>()); c->th[r].reset(new DevBuf<uint16_t>()); c->text[r].reset(new DevBuf<uint8_t>());
+        c->st[r].reset(new DevBuf<uint8_t>()); c->th[r].reset(new DevBuf<uint32_t>()); c->text[r].reset(new DevBuf<uint8_t>());
     }
     return c.release();
 }
@@ -198,7 +198,7 @@ static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<ui
             MMT_NCCL(rccl().Send(my_off, cells, ncclInt64, 0, c.comm, st));
             MMT_NCCL(rccl().Send(my_st, cells, ncclUint8, 0, c.comm, st));
         }
-        MMT_NCCL(rccl().Send(e.thresh_device(), L * 2, ncclUint8, 0, c.comm, st));
+        MMT_NCCL(rccl().Send(e.thresh_device32(), L, ncclUint32, 0, c.comm, st));
     } else {
         for (int r = 1; r < c.world; r++) {
             const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
@@ -208,7 +208,7 @@ static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<ui
                 MMT_NCCL(rccl().Recv(c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
                 MMT_NCCL(rccl().Recv(c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
             }
-            MMT_NCCL(rccl().Recv(c.th[r]->get(), L * 2, ncclUint8, r, c.comm, st));
+            MMT_NCCL(rccl().Recv(c.th[r]->get(), L, ncclUint32, r, c.comm, st));
         }
     }
     MMT_NCCL(rccl().GroupEnd());
@@ -218,9 +218,9 @@ static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<ui
     for (int r = 0; r < c.world; r++) {
         mmt_partition& p = parts[(size_t)r];
         p.n_rows = meta[(size_t)r * 4]; p.n_docs = meta[(size_t)r * 4 + 1];
-        if (r == 0) { p.length = my_len; p.offsets = my_off; p.strands = my_st; p.thresh = e.thresh_device(); }
-        else { p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get(); }
-        p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1;
+        if (r == 0) { p.length = my_len; p.offsets = my_off; p.strands = my_st; p.thresh = reinterpret_cast<const uint16_t*>(e.thresh_device32()); }
+        else { p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = reinterpret_cast<const uint16_t*>(c.th[r]->get()); }
+        p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1; p.thresh_bits = 32;
     }
     if (c.world == 1) {
         // one partition: nothing to fold; the rows are the engine's own, already in direct-run order
@@ -233,7 +233,7 @@ static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<ui
             MMT_HIP(hipMemcpyAsync(m.d_offsets.get(), parts[0].offsets, m.n_rows * m.n_docs * 8, hipMemcpyDeviceToDevice, st));
             MMT_HIP(hipMemcpyAsync(m.d_strands.get(), parts[0].strands, m.n_rows * m.n_docs, hipMemcpyDeviceToDevice, st));
         }
-        MMT_HIP(hipMemcpyAsync(m.d_thresh.get(), parts[0].thresh, L * 2, hipMemcpyDeviceToDevice, st));
+        MMT_HIP(hipMemcpyAsync(m.d_thresh.get(), parts[0].thresh, L * 4, hipMemcpyDeviceToDevice, st));
         MMT_HIP(hipStreamSynchronize(st));
         m.on_host = false;
         return m;
@@ -267,7 +267,8 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
     if (W == 1) {
         mmt_partition one;
         one.n_rows = R.n_rows; one.n_docs = R.n_docs; one.length = my_len; one.offsets = my_off; one.strands = my_st;
-        one.thresh = e.thresh_device(); one.thresh_len = L; one.thresh_on_device = 1; one.rows_on_device = 1;
+        one.thresh = reinterpret_cast<const uint16_t*>(e.thresh_device32()); one.thresh_bits = 32;
+        one.thresh_len = L; one.thresh_on_device = 1; one.rows_on_device = 1;
         MergedRows piece = anchor_merge_slice(e, &one, 1, min_len, 0, L, 0, true);
         sort_like_direct(e, piece);
         return piece;
@@ -302,7 +303,7 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
             MMT_NCCL(rccl().Send(out[r]->off.get(), s_cells, ncclInt64, r, c.comm, st));
             MMT_NCCL(rccl().Send(out[r]->str.get(), s_cells, ncclUint8, r, c.comm, st));
         }
-        MMT_NCCL(rccl().Send(e.thresh_device() + base[r], (hi[r] - base[r]) * 2, ncclUint8, r, c.comm, st));
+        MMT_NCCL(rccl().Send(e.thresh_device32() + base[r], hi[r] - base[r], ncclUint32, r, c.comm, st));
         // from rank r: its rows of my range, its thresholds of my range
         const size_t rows = counts[(size_t)r * W + c.rank], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
         c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(my_span + 1);
@@ -311,7 +312,7 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
             MMT_NCCL(rccl().Recv(c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
             MMT_NCCL(rccl().Recv(c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
         }
-        MMT_NCCL(rccl().Recv(c.th[r]->get(), my_span * 2, ncclUint8, r, c.comm, st));
+        MMT_NCCL(rccl().Recv(c.th[r]->get(), my_span, ncclUint32, r, c.comm, st));
     }
     MMT_NCCL(rccl().GroupEnd());
     MMT_HIP(hipStreamSynchronize(st));
@@ -323,12 +324,13 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
         if (r == c.rank) {
             Out& mine = *out[(size_t)c.rank];
             p.n_rows = mine.n; p.length = mine.len.get(); p.offsets = mine.off.get(); p.strands = mine.str.get();
-            p.thresh = e.thresh_device() + base[c.rank];
+            p.thresh = reinterpret_cast<const uint16_t*>(e.thresh_device32() + base[c.rank]);
         } else {
             p.n_rows = counts[(size_t)r * W + c.rank];
-            p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get(); p.thresh = c.th[r]->get();
+            p.length = c.len[r]->get(); p.offsets = c.off[r]->get(); p.strands = c.st[r]->get();
+            p.thresh = reinterpret_cast<const uint16_t*>(c.th[r]->get());
         }
-        p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1;
+        p.thresh_len = L; p.thresh_on_device = 1; p.rows_on_device = 1; p.thresh_bits = 32;
     }
     MergedRows piece = anchor_merge_slice(e, parts.data(), parts.size(), min_len, lo[c.rank], hi[c.rank], base[c.rank], true);
     out.clear();
@@ -343,7 +345,7 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
             MMT_NCCL(rccl().Send(piece.d_offsets.get(), cells, ncclInt64, 0, c.comm, st));
             MMT_NCCL(rccl().Send(piece.d_strands.get(), cells, ncclUint8, 0, c.comm, st));
         }
-        MMT_NCCL(rccl().Send(piece.d_thresh.get(), piece.thresh_len * 2, ncclUint8, 0, c.comm, st));
+        MMT_NCCL(rccl().Send(piece.d_thresh.get(), piece.thresh_len, ncclUint32, 0, c.comm, st));
     } else {
         pieces.resize((size_t)W);
         pieces[0] = std::move(piece);
@@ -357,7 +359,7 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
                 MMT_NCCL(rccl().Recv(p.d_offsets.get(), cells, ncclInt64, r, c.comm, st));
                 MMT_NCCL(rccl().Recv(p.d_strands.get(), cells, ncclUint8, r, c.comm, st));
             }
-            MMT_NCCL(rccl().Recv(p.d_thresh.get(), p.thresh_len * 2, ncclUint8, r, c.comm, st));
+            MMT_NCCL(rccl().Recv(p.d_thresh.get(), p.thresh_len, ncclUint32, r, c.comm, st));
         }
     }
     MMT_NCCL(rccl().GroupEnd());

@@ -341,7 +341,7 @@ void Engine::scan_begin(const mmt_params& p, ScanState& S) {
     if (p.merge_metadata && N > 0) {
         thresh_len_ = 2 * (doc_len_[0] + 1);
         d_thresh_.ensure(thresh_len_);
-        MMT_HIP(hipMemsetAsync(d_thresh_.get(), 0, thresh_len_ * 2, st));
+        MMT_HIP(hipMemsetAsync(d_thresh_.get(), 0, thresh_len_ * 4, st));
     }
     MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, st));
     n_cand_ = 0;
@@ -939,7 +939,7 @@ void Engine::run(const mmt_params& p) {
     rows_pending_ = 0;
     rows_.mum_mode = p.max_doc_freq == 1;
     rows_.n_docs = doc_len_.size();
-    n_cand_ = 0; thresh_len_ = 0; bumbl_.clear();
+    n_cand_ = 0; thresh_len_ = 0; thresh16_valid_ = false; bumbl_.clear();
     if (doc_len_.empty()) return;                       // mumemto_api.cpp:338-340
     if (!input_valid_)
         throw std::runtime_error("the engine holds no input (a partitioned run consumed it): call set_input first");
@@ -1131,7 +1131,22 @@ void Engine::copy_candidates(uint32_t* out) const {
     if (n_cand_ && !d_cand_.get()) throw std::runtime_error("the candidate list of this run was released (lean mode)");
     if (n_cand_) MMT_HIP(hipMemcpy(out, d_cand_.get(), n_cand_ * sizeof(k::Cand), hipMemcpyDeviceToHost));
 }
-void Engine::copy_thresh(uint16_t* out) const {
+const uint16_t* Engine::thresh_device() {
+    const size_t n = thresh_len();
+    if (!n) return nullptr;
+    if (!thresh16_valid_) {
+        MMT_HIP(hipSetDevice(device_));
+        d_thresh16_.ensure(n);
+        k::thresh_narrow(thresh_device32(), n, d_thresh16_.get(), stream_);
+        MMT_HIP(hipStreamSynchronize(stream_));
+        thresh16_valid_ = true;
+    }
+    return d_thresh16_.get();
+}
+void Engine::copy_thresh32(uint32_t* out) const {
+    if (thresh_len()) MMT_HIP(hipMemcpy(out, thresh_device32(), thresh_len() * 4, hipMemcpyDeviceToHost));
+}
+void Engine::copy_thresh(uint16_t* out) {
     if (thresh_len()) MMT_HIP(hipMemcpy(out, thresh_device(), thresh_len() * 2, hipMemcpyDeviceToHost));
 }
 

@@ -183,8 +183,14 @@ public:
     void copy_candidates(uint32_t* out) const;
     // (after a run that went through anchor partitions: the merged thresholds, like the rows)
     size_t thresh_len() const { return merged_thresh_valid_ ? merged_.thresh_len : thresh_len_; }
-    void copy_thresh(uint16_t* out) const;
-    const uint16_t* thresh_device() const { return merged_thresh_valid_ ? merged_.d_thresh.get() : d_thresh_.get(); }
+    // Thresholds are 32 bits wide inside the engine, the fold and the exchange (the reference's 16-bit column
+    // saturates at 65535, mem_finder.hpp:299,328, and a merged MUM beyond that whose next-best match is as long would be
+    // accepted unproven).  The 16-bit forms -- PREFIX.athresh / .thresh, copy_thresh, thresh_device -- saturate like the
+    // reference's and are made from the 32-bit column when asked for.
+    void copy_thresh(uint16_t* out);
+    void copy_thresh32(uint32_t* out) const;
+    const uint16_t* thresh_device();
+    const uint32_t* thresh_device32() const { return merged_thresh_valid_ ? merged_.d_thresh.get() : d_thresh_.get(); }
     const uint32_t* isa_device() const { return d_rank_.get(); }        // narrow runs
     const uint64_t* isa_device64() const { return d_rank64_.get(); }    // wide runs
     bool anchor_ranks_valid() const { return anchor_ranks_valid_; }
@@ -314,7 +320,9 @@ private:
     // scan
     DevBuf<k::Cand> d_cand_;
     DevBuf<k::Row> d_rows_;
-    DevBuf<uint16_t> d_thresh_;
+    DevBuf<uint32_t> d_thresh_;
+    DevBuf<uint16_t> d_thresh16_;          // the saturated 16-bit form, made on demand (thresh_device)
+    bool thresh16_valid_ = false;
     size_t n_cand_ = 0, thresh_len_ = 0;
     // A6 on the device
     DevBuf<uint64_t> d_doc_len_, d_rkeys_a_, d_rkeys_b_, d_tlen64_, d_toff_, d_occ64_, d_ooff_, d_omdoc_;

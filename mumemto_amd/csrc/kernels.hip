@@ -2014,7 +2014,7 @@ __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) {
 template <typename SA>
 struct VerifyArgsT {
     const Cand* cand; uint32_t n_cand; SA sa; uint64_t base, sa_off; const uint32_t* lcp; const uint64_t* d_doc_start;
-    uint32_t n_docs, num_distinct, max_doc_freq; int merge; uint16_t* thresh; Row* rows; uint32_t* d_row_count;
+    uint32_t n_docs, num_distinct, max_doc_freq; int merge; uint32_t* thresh; Row* rows; uint32_t* d_row_count;
 };
 __device__ __forceinline__ Row make_row(const Cand& c, uint64_t base) {
     Row r; r.start = base + c.start; r.cnt = c.end - c.start + 1; r.len = c.len; return r;
@@ -2077,9 +2077,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify(VerifyArgsT<SA> a, int us
             first0 = wave_min32(first0);
             if (lane == 0 && first0 != 0xffffffffu) {
                 uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
-                uint32_t nb = before > after ? before : after;
-                if (nb > 65535u) nb = 65535u;
-                a.thresh[(uint64_t)a.sa.get(a.sa_off + first0) - a.d_doc_start[0]] = (uint16_t)nb;
+                // (the reference's column saturates at 65535, mem_finder.hpp:299,328; the width here is 32 bits and the
+                // saturation happens where a 16-bit file or table is written: Engine::thresh_device / copy_thresh)
+                const uint32_t nb = before > after ? before : after;
+                a.thresh[(uint64_t)a.sa.get(a.sa_off + first0) - a.d_doc_start[0]] = nb;
             }
         }
         if (c.flags & CAND_LEFT_MAXIMAL) {
@@ -2144,9 +2145,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_verify_packed(VerifyArgsT<SA> a)
         const bool ok = live && (uint32_t)__popc(bits) == cnt && cnt >= a.num_distinct;
         if (a.merge && ok && sl == 0 && first0 != 0xffffffffu) {
             const uint32_t before = a.lcp[c.start], after = a.lcp[c.end + 1];
-            uint32_t nb = before > after ? before : after;
-            if (nb > 65535u) nb = 65535u;
-            a.thresh[(uint64_t)a.sa.get(a.sa_off + first0) - a.d_doc_start[0]] = (uint16_t)nb;
+            const uint32_t nb = before > after ? before : after;
+            a.thresh[(uint64_t)a.sa.get(a.sa_off + first0) - a.d_doc_start[0]] = nb;
         }
         const bool take = ok && sl == 0 && (c.flags & CAND_LEFT_MAXIMAL);
         const uint64_t m = __ballot(take);
@@ -2272,9 +2272,9 @@ __device__ __forceinline__ uint32_t rows_started(const uint64_t* __restrict__ st
 __global__ void k_fold_step(FoldArgs a) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.len) return;
-    const uint16_t na = a.nb_a[i], nb = a.nb_b[i];
+    const uint32_t na = a.nb_a[i], nb = a.nb_b[i];
     const bool both = na > 0 && nb > 0;
-    const uint16_t nbo = both ? (na > nb ? na : nb) : (uint16_t)0;        // :121-123
+    const uint32_t nbo = both ? (na > nb ? na : nb) : 0u;                 // :121-123
     a.nb_out[i] = nbo;
     const bool sa_ = a.bv_a[i] != 0, sb_ = a.bv_b[i] != 0;
     if (!(sa_ || sb_) || !both) return;                                    // :132
@@ -2293,6 +2293,32 @@ __global__ void k_fold_step(FoldArgs a) {
 }
 void fold_step(const FoldArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_fold_step, dim3(grid_for(a.len, 256)), dim3(256), 0, s, a);
+    MMT_HIP(hipGetLastError());
+}
+
+// threshold columns: 32 bits inside the engine, the fold and the exchange; 16 bits, saturated at 65535 like the
+// reference's (mem_finder.hpp:299), where PREFIX.athresh / .thresh or a 16-bit table is written
+__global__ void k_thresh_narrow(const uint32_t* __restrict__ src, uint64_t n, uint16_t* __restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t v = src[i];
+        dst[i] = (uint16_t)(v > 65535u ? 65535u : v);
+    }
+}
+__global__ void k_thresh_widen(const uint16_t* __restrict__ src, uint64_t n, uint32_t* __restrict__ dst) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+void thresh_narrow(const uint32_t* src, uint64_t n, uint16_t* dst, hipStream_t s) {
+    if (!n) return;
+    const uint64_t g = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_thresh_narrow, dim3((unsigned)(g < 65536 ? g : 65536)), dim3(256), 0, s, src, n, dst);
+    MMT_HIP(hipGetLastError());
+}
+void thresh_widen(const uint16_t* src, uint64_t n, uint32_t* dst, hipStream_t s) {
+    if (!n) return;
+    const uint64_t g = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_thresh_widen, dim3((unsigned)(g < 65536 ? g : 65536)), dim3(256), 0, s, src, n, dst);
     MMT_HIP(hipGetLastError());
 }
 

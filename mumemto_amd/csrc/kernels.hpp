@@ -167,7 +167,7 @@ struct VerifyArgs {
     uint32_t num_distinct;
     uint32_t max_doc_freq;        // 0 = unlimited
     int merge;                    // record thresholds
-    uint16_t* thresh;             // 2*(L_0+1) entries (merge only)
+    uint32_t* thresh;             // 2*(L_0+1) entries (merge only); 32 bits: never saturated inside the engine
     Row* rows;                    // accepted + left-maximal, appended at *d_row_count
     uint32_t* d_row_count;
 };
@@ -184,7 +184,7 @@ void capture_rows(const Row* rows, uint32_t n_rows, const uint64_t* off, uint64_
 // (i, row index in A, row index in B, new length) for every new MUM.
 struct FoldArgs {
     uint64_t len;                       // L_0 + 1
-    const uint16_t* nb_a; const uint16_t* nb_b; uint16_t* nb_out;
+    const uint32_t* nb_a; const uint32_t* nb_b; uint32_t* nb_out;
     uint32_t n_a, n_b;                                // rows per side (start_* ascending)
     const uint64_t* start_a; const uint64_t* start_b; // offsets[0] of row r (sorted)
     const uint32_t* len_a; const uint32_t* len_b;     // length of row r
@@ -195,6 +195,9 @@ struct FoldArgs {
 };
 void fold_step(const FoldArgs& a, hipStream_t s);
 void mark_starts(const uint64_t* starts, uint32_t n_rows, uint8_t* bv, hipStream_t s);
+// threshold columns between their 32-bit form (engine, fold, exchange) and the reference's saturating 16-bit form (files)
+void thresh_narrow(const uint32_t* src, uint64_t n, uint16_t* dst, hipStream_t s);
+void thresh_widen(const uint16_t* src, uint64_t n, uint32_t* dst, hipStream_t s);
 
 // out[i] = src[idx[i]]
 void gather_u32_idx32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s);

@@ -18,6 +18,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include "kernels.hpp"
 #include "merge_kernels.hpp"
 #include "pfp_kernels.hpp"
 #include "prims.hpp"
@@ -61,7 +62,8 @@ struct PartUpload {
 
 // device scratch of the fold, kept between calls (one merge per bench step on rank 0)
 struct MergeScratch {
-    DevBuf<uint16_t> nb_left, nb_right, nb_out;
+    DevBuf<uint32_t> nb_left, nb_right, nb_out;
+    DevBuf<uint16_t> narrow;         // a 16-bit column on its way into the 32-bit ones
     SideIndex ia, ib;
     SideBuf left, right, out;
     DevBuf<uint64_t> d_pos, keys_a, keys_b;
@@ -139,10 +141,19 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
     MMT_HIP(hipMemsetAsync(M.d_count.get(), 0, 16, st));     // [0] rows of this step, [1] input errors
     lap("tables");
 
-    auto load_thresh = [&](const mmt_partition& p, DevBuf<uint16_t>& dst) {
+    // thresholds are folded at 32 bits; a partition that brings the reference's 16-bit column (a
+    // PREFIX.athresh file, saturated at 65535) is widened on arrival
+    auto load_thresh = [&](const mmt_partition& p, DevBuf<uint32_t>& dst) {
         dst.ensure(L);
-        MMT_HIP(hipMemcpyAsync(dst.get(), p.thresh, L * 2,
-                               p.thresh_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        if (p.thresh_bits == 32) {
+            MMT_HIP(hipMemcpyAsync(dst.get(), p.thresh, L * 4, p.thresh_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        } else if (p.thresh_on_device) {
+            k::thresh_widen(p.thresh, L, dst.get(), st);
+        } else {
+            M.narrow.ensure(L);
+            MMT_HIP(hipMemcpyAsync(M.narrow.get(), p.thresh, L * 2, hipMemcpyHostToDevice, st));
+            k::thresh_widen(M.narrow.get(), L, dst.get(), st);
+        }
     };
     // parse_candidate(): rows in anchor order (merge_candidates.cpp:89-92)
     const int key_bits = bit_width_u64(L);
@@ -210,7 +221,7 @@ MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_
     m.d_strands.ensure(m.n_rows * n_docs_out + 1); m.d_thresh.ensure(L);
     mk::materialise(M.left.view(), nullptr, M.d_parts.get(), (uint32_t)n_docs_out, M.d_colpart.get(),
                     m.d_length.get(), m.d_offsets.get(), m.d_strands.get(), st);
-    MMT_HIP(hipMemcpyAsync(m.d_thresh.get(), M.nb_left.get(), L * 2, hipMemcpyDeviceToDevice, st));
+    MMT_HIP(hipMemcpyAsync(m.d_thresh.get(), M.nb_left.get(), L * 4, hipMemcpyDeviceToDevice, st));
     MMT_HIP(hipStreamSynchronize(st));       // host partitions may be released by the caller from here on
     lap("materialise");
     return m;
@@ -258,7 +269,7 @@ MergedRows anchor_merge_slice(Engine& e, const mmt_partition* parts, size_t k, u
                               uint64_t base, bool thresh_is_slice) {
     MMT_HIP(hipSetDevice(e.device()));
     hipStream_t st = e.stream();
-    struct Held { DevBuf<uint32_t> len, in_len; DevBuf<int64_t> off, in_off; DevBuf<uint8_t> str, in_str; DevBuf<uint16_t> th; };
+    struct Held { DevBuf<uint32_t> len, in_len; DevBuf<int64_t> off, in_off; DevBuf<uint8_t> str, in_str, th; };
     std::vector<std::unique_ptr<Held>> held(k);
     std::vector<mmt_partition> sliced(k);
     for (size_t g = 0; g < k; g++) {
@@ -281,13 +292,14 @@ MergedRows anchor_merge_slice(Engine& e, const mmt_partition* parts, size_t k, u
         mmt_partition& Q = sliced[g];
         Q = P;
         Q.n_rows = kept; Q.length = H.len.get(); Q.offsets = H.off.get(); Q.strands = H.str.get(); Q.rows_on_device = 1;
-        const uint16_t* th = P.thresh + (thresh_is_slice ? 0 : base);
+        const size_t tw = P.thresh_bits == 32 ? 4 : 2;          // bytes per threshold as the partition brings them
+        const uint8_t* th = reinterpret_cast<const uint8_t*>(P.thresh) + (thresh_is_slice ? 0 : base) * tw;
         if (!P.thresh_on_device) {
-            H.th.ensure(hi - base);
-            MMT_HIP(hipMemcpyAsync(H.th.get(), th, (hi - base) * 2, hipMemcpyHostToDevice, st));
+            H.th.ensure((hi - base) * tw);
+            MMT_HIP(hipMemcpyAsync(H.th.get(), th, (hi - base) * tw, hipMemcpyHostToDevice, st));
             th = H.th.get();
         }
-        Q.thresh = th; Q.thresh_len = hi - base; Q.thresh_on_device = 1;
+        Q.thresh = reinterpret_cast<const uint16_t*>(th); Q.thresh_len = hi - base; Q.thresh_on_device = 1;
     }
     MergedRows whole = anchor_merge(e, sliced.data(), k, min_len);
     held.clear();
@@ -299,7 +311,7 @@ MergedRows anchor_merge_slice(Engine& e, const mmt_partition* parts, size_t k, u
                 (int64_t)base, (int64_t)lo, (int64_t)hi, (int64_t)base, piece.d_length, piece.d_offsets, piece.d_strands, &kept);
     piece.n_rows = kept;
     piece.d_thresh.ensure(hi - lo + 1);
-    MMT_HIP(hipMemcpyAsync(piece.d_thresh.get(), whole.d_thresh.get() + (lo - base), (hi - lo) * 2, hipMemcpyDeviceToDevice, st));
+    MMT_HIP(hipMemcpyAsync(piece.d_thresh.get(), whole.d_thresh.get() + (lo - base), (hi - lo) * 4, hipMemcpyDeviceToDevice, st));
     MMT_HIP(hipStreamSynchronize(st));
     return piece;
 }
@@ -321,7 +333,7 @@ MergedRows concat_pieces(Engine& e, std::vector<MergedRows>& pieces) {
             MMT_HIP(hipMemcpyAsync(m.d_strands.get() + row * m.n_docs, p.d_strands.get(), p.n_rows * m.n_docs, hipMemcpyDeviceToDevice, st));
         }
         if (p.thresh_len)
-            MMT_HIP(hipMemcpyAsync(m.d_thresh.get() + pos, p.d_thresh.get(), p.thresh_len * 2, hipMemcpyDeviceToDevice, st));
+            MMT_HIP(hipMemcpyAsync(m.d_thresh.get() + pos, p.d_thresh.get(), p.thresh_len * 4, hipMemcpyDeviceToDevice, st));
         row += p.n_rows; pos += p.thresh_len;
     }
     MMT_HIP(hipStreamSynchronize(st));
@@ -567,8 +579,13 @@ void download_merged(Engine& e, MergedRows& m) {
         MMT_HIP(hipMemcpyAsync(m.offsets.data(), m.d_offsets.get(), cells * 8, hipMemcpyDeviceToHost, st));
         MMT_HIP(hipMemcpyAsync(m.strands.data(), m.d_strands.get(), cells, hipMemcpyDeviceToHost, st));
     }
-    if (m.thresh_len)
-        MMT_HIP(hipMemcpyAsync(m.thresh.data(), m.d_thresh.get(), m.thresh_len * 2, hipMemcpyDeviceToHost, st));
+    if (m.thresh_len) {         // the host copy is the PREFIX.athresh form: 16 bits, saturated (mem_finder.hpp:299)
+        DevBuf<uint16_t> narrow;
+        narrow.ensure(m.thresh_len);
+        k::thresh_narrow(m.d_thresh.get(), m.thresh_len, narrow.get(), st);
+        MMT_HIP(hipMemcpyAsync(m.thresh.data(), narrow.get(), m.thresh_len * 2, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+    }
     MMT_HIP(hipStreamSynchronize(st));
     m.on_host = true;
 }

@@ -14,7 +14,7 @@ struct MergedRows {
     DevBuf<uint32_t> d_length;
     DevBuf<int64_t> d_offsets;      // n_rows * n_docs, column 0 = anchor
     DevBuf<uint8_t> d_strands;      // 1 = '+'
-    DevBuf<uint16_t> d_thresh;      // merged .athresh, L_0 + 1 entries
+    DevBuf<uint32_t> d_thresh;      // merged thresholds, L_0 + 1 entries, 32 bits (the 16-bit .athresh form: `thresh`, saturated)
     bool on_host = false;
     std::vector<uint32_t> length;
     std::vector<int64_t> offsets;

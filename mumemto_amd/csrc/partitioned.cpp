@@ -45,9 +45,9 @@ const std::vector<uint16_t>& Engine::merged_thresh() {
 void Engine::forget_last_run() {
     release_columns();
     // ... and the results (thresholds and merged tables of a genome-sized anchor are tens of GB), and the input buffer
-    rows_ = HostRows(); rows_pending_ = 0; merged_thresh_valid_ = false; thresh_len_ = 0;
+    rows_ = HostRows(); rows_pending_ = 0; merged_thresh_valid_ = false; thresh_len_ = 0; thresh16_valid_ = false;
     merged_ = MergedRows();
-    d_thresh_.release(); d_rows_.release(); d_otext_.release(); d_olen_.release(); d_ooffs_.release(); d_ost_.release();
+    d_thresh_.release(); d_thresh16_.release(); d_rows_.release(); d_otext_.release(); d_olen_.release(); d_ooffs_.release(); d_ost_.release();
     d_omdoc_.release(); d_bases_own_.release(); d_bases_ = nullptr; input_valid_ = false;
 }
 
@@ -127,7 +127,7 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     // merge_candidates.cpp:106-157, left to right): what stays in HBM between partitions is one table of rows and ONE
     // threshold column (2 bytes per anchor position: 6 GB for a human genome), however many partitions there are.
     struct Part {       // one partition's rows and thresholds, copied out of the engine's buffers for the fold
-        DevBuf<uint32_t> length; DevBuf<int64_t> offsets; DevBuf<uint8_t> strands; DevBuf<uint16_t> thresh;
+        DevBuf<uint32_t> length, thresh; DevBuf<int64_t> offsets; DevBuf<uint8_t> strands;
         size_t n_rows = 0, n_docs = 0;
     };
     Part first;                 // partition 0 until partition 1 arrives
@@ -200,12 +200,13 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
                 MMT_HIP(hipMemcpyAsync(P.offsets.get(), dof, cells * 8, hipMemcpyDeviceToDevice, stream_));
                 MMT_HIP(hipMemcpyAsync(P.strands.get(), dst, cells, hipMemcpyDeviceToDevice, stream_));
             }
-            MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 2, hipMemcpyDeviceToDevice, stream_));
+            MMT_HIP(hipMemcpyAsync(P.thresh.get(), d_thresh_.get(), L * 4, hipMemcpyDeviceToDevice, stream_));
             MMT_HIP(hipStreamSynchronize(stream_));
             if (g >= 1) {
                 auto as_partition = [&](mmt_partition& m, size_t rows, size_t docs, const uint32_t* len, const int64_t* off,
-                                        const uint8_t* st, const uint16_t* th) {
-                    m.n_rows = rows; m.n_docs = docs; m.length = len; m.offsets = off; m.strands = st; m.thresh = th;
+                                        const uint8_t* st, const uint32_t* th) {
+                    m.n_rows = rows; m.n_docs = docs; m.length = len; m.offsets = off; m.strands = st;
+                    m.thresh = reinterpret_cast<const uint16_t*>(th); m.thresh_bits = 32;
                     m.thresh_len = L; m.thresh_on_device = 1; m.rows_on_device = 1;
                 };
                 mmt_partition two[2];
@@ -233,7 +234,7 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     else {                                       // a single partition: the fold of one (filters by the minimum length)
         mmt_partition one;
         one.n_rows = first.n_rows; one.n_docs = first.n_docs; one.length = first.length.get(); one.offsets = first.offsets.get();
-        one.strands = first.strands.get(); one.thresh = first.thresh.get();
+        one.strands = first.strands.get(); one.thresh = reinterpret_cast<const uint16_t*>(first.thresh.get()); one.thresh_bits = 32;
         one.thresh_len = L; one.thresh_on_device = 1; one.rows_on_device = 1;
         merged_ = anchor_merge(*this, &one, 1, p.min_match_len);
     }
@@ -256,6 +257,7 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     num_distinct_eff_ = n_docs;
     partitions_used_ = G;
     merged_thresh_valid_ = true;
+    thresh16_valid_ = false;
     for (int i = 0; i < 7; i++) stage_ms_[i] = acc[i];
     stage_ms_[7] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -487,7 +487,8 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
         if (fb_count) { S.xk_b.ensure((size_t)fb_count + 1); S.xv_b.ensure((size_t)fb_count + 1, W); }
         ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get();
         ea.fb_base = S.h_fb_off[f0];
-        pk::emit(ea, S.tile_first.get(), t0, t1, st);
+        S.emit_plan.ensure(pk::emit_plan_bytes(t1 - t0));
+        pk::emit(ea, S.tile_first.get(), S.emit_plan.get(), t0, t1, st);
         S.emit_launches++;
         const uint32_t nf = f1 - f0;
         if (nf) pk::emit_big(ea, S.fb_chunk0.get(), f0, nf, S.h_fb_chunk0[f1] - S.h_fb_chunk0[f0], st);

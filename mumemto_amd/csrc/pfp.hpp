@@ -30,6 +30,7 @@ struct PfpState {
     DevBuf<uint32_t> occ_start, occ_ids, occ_ts, vflag, vscan;
     DevBuf<uint64_t> occ;               // (t << pos_bits) | V position, per phrase occurrence
     DevBuf<uint32_t> ce_cnt, ce_first, ce_offm1, ce_gs, sege, xk_a, xk_b, fb_group, fb_size, fb_rel, tile_first;
+    DevBuf<uint8_t> emit_plan;          // one record per output tile of the launch in progress (pk::emit)
     PosBuf ce_eoff, segb, fb_off, fb_start, xv_a, xv_b;     // stream offsets / text positions
     DevBuf<uint8_t> ce_bwt, bwt_code;
     // LCP without a text-order column: LCP of adjacent parse suffixes (+ range minima), per group of equal phrase

@@ -1178,47 +1178,88 @@ void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* o
     MMT_HIP(hipGetLastError());
 }
 
+// What a workgroup needs to know about a tile before it can load anything of it: the first piece -- the maximal run of whole
+// groups [g0, g_next) that begin in the tile and hold at most CAP elements --, its entries [e0, e1), its first output offset
+// inside the tile and its length; and where the (rare) rest of the tile goes on: groups [g_next, g_end).  Round 3's k_emit
+// found this by itself, per tile: tile_first -> a ballot search over segb -> sege, three dependent round trips in front of
+// every tile's first useful load.  k_emit_plan does it for all tiles of a launch at once, one work-item per tile (a binary
+// search: throughput, not latency), and k_emit begins with one 32-byte record.
+struct EmitDesc { uint32_t g0, g_next, g_end, e0, e1, clo, L, pad; };
+template <typename P, int TILE, int CAP>
+__global__ void k_emit_plan(const P* __restrict__ segb, const uint32_t* __restrict__ sege, const uint32_t* __restrict__ tile_first,
+                            uint64_t tile_lo, uint32_t n_tiles, EmitDesc* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint64_t tile = tile_lo + t, tbase = tile * TILE;
+    EmitDesc d;
+    d.g0 = tile_first[tile]; d.g_end = tile_first[tile + 1]; d.g_next = d.g0;
+    d.e0 = d.e1 = d.clo = d.L = d.pad = 0;
+    if (d.g0 < d.g_end) {
+        const uint64_t first = (uint64_t)segb[d.g0] - tbase, lim = first + CAP;
+        // groups after g0 that still begin at or before lim (the begin of group g_end, the first one of the next tile, counts:
+        // it is where the last group of this tile ends)
+        uint32_t lo = d.g0 + 1, hi = d.g_end + 1;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((uint64_t)segb[mid] - tbase <= lim) lo = mid + 1; else hi = mid; }
+        const uint32_t g2 = lo - 1;
+        if (g2 > d.g0) {
+            d.clo = (uint32_t)first; d.L = (uint32_t)((uint64_t)segb[g2] - tbase - first);
+            d.e0 = sege[d.g0]; d.e1 = sege[g2]; d.g_next = g2;
+        } else d.g_next = d.g0 + 1;          // a single group larger than CAP: k_emit_big's
+    }
+    out[t] = d;
+}
+
+// Persistent workgroups: workgroup b takes tiles b, b + gridDim.x, ... of the launch; the record of its NEXT tile is
+// requested before the current tile is expanded, so that it has arrived when the tile is done.
 template <int BLOCK, int CAP, int TILE, typename P, typename SA>
-__global__ __launch_bounds__(BLOCK, 7) void k_emit(EmitArgsT<P, SA> a, const uint32_t* __restrict__ tile_first) {
+__global__ __launch_bounds__(BLOCK, 7) void k_emit(EmitArgsT<P, SA> a, const EmitDesc* __restrict__ desc, uint32_t n_tiles) {
     __shared__ EmitShared<BLOCK, CAP, uint16_t> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t tile = a.tile_lo + blockIdx.x;
-    const P tbase = (P)(tile * TILE);
-    // groups whose begin offset lies in [tile*TILE, (tile+1)*TILE): at most TILE of them, every group has an element.
-    // Their begin offsets are read where they are needed (a table of them in LDS cost the sixth workgroup per CU).
-    const uint32_t g0 = tile_first[tile], g_end = tile_first[tile + 1];
-    uint32_t g = g0;
-    while (g < g_end) {
-        // chunk = maximal run of whole groups [g, g2) with at most CAP elements
-        __syncthreads();
-        if (wave == 0) {
-            const uint64_t first = (uint64_t)a.segb[g] - (uint64_t)tbase;
-            const uint64_t lim = first + CAP;
-            uint32_t c = 0;                                  // groups after g that still begin at or before lim
-            for (uint32_t base = g + 1; base <= g_end; base += 64) {
-                const uint32_t idx = base + lane;            // (the group after the last one may start far away)
-                const bool ok = idx <= g_end && (uint64_t)a.segb[idx] - (uint64_t)tbase <= lim;
-                const uint64_t m = __ballot(ok);
-                c += (uint32_t)__popcll(m);
-                if (m != ~0ull) break;
+    uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    EmitDesc d = desc[t];
+    for (;;) {
+        const uint32_t t_next = t + gridDim.x;
+        EmitDesc dn = d;
+        if (t_next < n_tiles) dn = desc[t_next];
+        const uint64_t tile = a.tile_lo + t;
+        const P tbase = (P)(tile * TILE);
+        if (d.L) emit_piece<BLOCK, CAP, P, SA, uint16_t>(a, sh, d.e0, d.e1, tbase + d.clo, d.L, true, (P)0, d.g0);
+        // what the first piece left of the tile (a last group that hangs over by more than CAP - TILE elements; oversized
+        // groups, which k_emit_big expands chunk by chunk over many workgroups into the compact fallback arrays)
+        uint32_t g = d.g_next;
+        const uint32_t g_end = d.g_end;
+        while (g < g_end) {
+            __syncthreads();
+            if (wave == 0) {
+                const uint64_t first = (uint64_t)a.segb[g] - (uint64_t)tbase;
+                const uint64_t lim = first + CAP;
+                uint32_t c = 0;                                  // groups after g that still begin at or before lim
+                for (uint32_t base = g + 1; base <= g_end; base += 64) {
+                    const uint32_t idx = base + lane;
+                    const bool ok = idx <= g_end && (uint64_t)a.segb[idx] - (uint64_t)tbase <= lim;
+                    const uint64_t m = __ballot(ok);
+                    c += (uint32_t)__popcll(m);
+                    if (m != ~0ull) break;
+                }
+                if (lane == 0) {
+                    sh.bound[2] = g + c;
+                    sh.bound[0] = (uint32_t)first;
+                    sh.bound[1] = (uint32_t)((uint64_t)a.segb[g + c] - (uint64_t)tbase - first);
+                }
             }
-            if (lane == 0) {                                 // segb[g2] <= lim < segb[g2 + 1]
-                sh.bound[2] = g + c;
-                sh.bound[0] = (uint32_t)first;
-                sh.bound[1] = (uint32_t)((uint64_t)a.segb[g + c] - (uint64_t)tbase - first);
+            __syncthreads();
+            const uint32_t g2 = sh.bound[2];
+            if (g2 > g) {
+                const uint32_t clo = sh.bound[0], L = sh.bound[1];
+                emit_piece<BLOCK, CAP, P, SA, uint16_t>(a, sh, a.sege[g], a.sege[g2], tbase + clo, L, true, (P)0, g);
+                g = g2;
+                continue;
             }
+            g = g + 1;
         }
-        __syncthreads();
-        const uint32_t g2 = sh.bound[2];
-        if (g2 > g) {
-            const uint32_t clo = sh.bound[0], L = sh.bound[1];
-            emit_piece<BLOCK, CAP, P, SA, uint16_t>(a, sh, a.sege[g], a.sege[g2], tbase + clo, L, true, (P)0, g);
-            g = g2;
-            continue;
-        }
-        // a single group larger than CAP: k_emit_big expands it, chunk by chunk over many workgroups, into the compact
-        // fallback arrays (one workgroup walking a satellite's group of a million suffixes alone was the tail of every launch)
-        g = g + 1;
+        if (t_next >= n_tiles) break;
+        t = t_next; d = dn;
     }
 }
 
@@ -1231,7 +1272,7 @@ uint32_t emit_tile() {
     return t;
 }
 template <typename P, typename SA, int TILE, int BLOCK = 256>
-static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
+static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
     constexpr int CAP = (int)EMIT_CAP;
     EmitArgsT<P, SA> t;
     t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
@@ -1246,21 +1287,29 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64
     // (tests/micro: MMT_EMIT_MANY=0 sorts every piece, a large value none)
     static const uint32_t many = std::getenv("MMT_EMIT_MANY") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT_MANY")) : 24u;
     t.many_runs = many;
-    hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3((unsigned)(tile_hi - tile_lo)), dim3(BLOCK), 0, s, t,
-                       tile_first_tab);
+    const uint32_t n_tiles = (uint32_t)(tile_hi - tile_lo);
+    EmitDesc* desc = static_cast<EmitDesc*>(plan);
+    hipLaunchKernelGGL((k_emit_plan<P, TILE, CAP>), dim3(grid_for(n_tiles, 256)), dim3(256), 0, s, t.segb, t.sege, tile_first_tab,
+                       tile_lo, n_tiles, desc);
+    // persistent workgroups: seven per CU (the launch bounds), a few rounds of them so that the tail is short
+    // (MMT_EMIT_GRID: workgroups of the launch, tests/micro; 0 = one per tile)
+    static const uint32_t grid_env = std::getenv("MMT_EMIT_GRID") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT_GRID")) : 256u * 7u * 4u;
+    const uint32_t grid = grid_env ? std::min(grid_env, n_tiles) : n_tiles;
+    hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles);
     MMT_HIP(hipGetLastError());
 }
-void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
+size_t emit_plan_bytes(uint64_t tiles) { return (size_t)tiles * sizeof(EmitDesc); }
+void emit(const EmitArgs& a, const uint32_t* tile_first_tab, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
     if (tile_hi <= tile_lo) return;
     const uint32_t tile = emit_tile();
     if (a.wide) {
-        if (tile == 1024) emit_typed<uint64_t, Sa40, 1024>(a, tile_first_tab, tile_lo, tile_hi, s);
-        else if (tile == 768) emit_typed<uint64_t, Sa40, 768>(a, tile_first_tab, tile_lo, tile_hi, s);
-        else emit_typed<uint64_t, Sa40, 896>(a, tile_first_tab, tile_lo, tile_hi, s);
+        if (tile == 1024) emit_typed<uint64_t, Sa40, 1024>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
+        else if (tile == 768) emit_typed<uint64_t, Sa40, 768>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
+        else emit_typed<uint64_t, Sa40, 896>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
     } else {
-        if (tile == 1024) emit_typed<uint32_t, Sa32, 1024>(a, tile_first_tab, tile_lo, tile_hi, s);
-        else if (tile == 768) emit_typed<uint32_t, Sa32, 768>(a, tile_first_tab, tile_lo, tile_hi, s);
-        else emit_typed<uint32_t, Sa32, 896>(a, tile_first_tab, tile_lo, tile_hi, s);
+        if (tile == 1024) emit_typed<uint32_t, Sa32, 1024>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
+        else if (tile == 768) emit_typed<uint32_t, Sa32, 768>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
+        else emit_typed<uint32_t, Sa32, 896>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
     }
 }
 

@@ -68,7 +68,7 @@ def run_grouping(eng, G, slices, out_path):
         t_run = time.time() - t0
         t0 = time.time()
         length, off, st = eng.rows_mum()
-        th = eng.thresholds()[: L0 + 1].copy()
+        th = eng.thresholds32()[: L0 + 1].copy()            # 32 bits, as the exchange carries them
         parts.append((length.copy(), off.copy(), st.copy(), th))
         mem = eng.device_memory()
         rec = dict(share=r, docs=len(mine), text_chars=int(2 * len(mine) * (L0 + 1)), generate_s=round(t_gen, 1),

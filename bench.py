@@ -265,6 +265,7 @@ def main():
     col = eng.column_bytes()
     algo_bytes = float(sum(col)) * n_text       # SA + LCP + BWT columns of the stream as stored, one pass
     scan_avg_ms = float(np.mean(scan_ms))
+    scan_avg_ms = max(scan_avg_ms, 1e-9)         # (a crippled timing run -- MMT_EMIT_ABLATE -- scans nothing)
     achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
     out_file = out_prefix + ".mums"
     out_bytes = os.path.getsize(out_file) if rank == 0 and os.path.exists(out_file) else 0

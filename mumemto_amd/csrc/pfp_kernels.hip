@@ -919,7 +919,7 @@ struct EmitShared {
 // LDS.  sorted = true: entries form whole groups; every element goes to its merged position in
 // sa / bwt.  sorted = false: part of an oversized group; (key, position) go to the fallback arrays at
 // (output offset - fb_origin).
-template <int BLOCK, int CAP, typename P, typename SA, typename ES>
+template <int BLOCK, int CAP, typename P, typename SA, typename ES, int ABL = 0>
 __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared<BLOCK, CAP, ES>& sh, uint32_t e0, uint32_t e1,
                                            P clo, uint32_t L, bool sorted, P fb_origin, uint32_t gbase) {
     using EmitSh = EmitShared<BLOCK, CAP, ES>;
@@ -941,6 +941,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
     }
     if (tid == 0) { sh.estart[E] = (ES)L; sh.many = 0; }
     __syncthreads();
+    if (ABL == 5) return;
     // owner[i] = last entry starting at or before i; egfirst[e] = last group-start entry at or before e
     // (running maxima over <= CAP items: each thread scans a contiguous slice, slices are stitched)
     {
@@ -992,8 +993,8 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
         my_sl[q] = 0;
         if (i < L) {
             const uint32_t e = sh.owner[i], k = i - sh.estart[e];
-            const uint64_t kp = a.occ[sh.efirst[e] + k];
-            if (sorted) my_sl[q] = a.occ_sl[sh.efirst[e] + k];
+            const uint64_t kp = ABL == 3 ? ((uint64_t)(i + 1) << a.pos_bits) | 7u : a.occ[sh.efirst[e] + k];
+            if (sorted && ABL != 3) my_sl[q] = a.occ_sl[sh.efirst[e] + k];
             const uint32_t key = (uint32_t)(kp >> a.pos_bits);
             my_pos[q] = (P)((kp & pos_mask) + sh.eoffm1[e]);
             if (sorted) sh.key[i] = key;
@@ -1020,12 +1021,15 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
             my_e[q] = sh.owner[i];
             my_gf[q] = sh.egfirst[my_e[q]];
             my_gs[q] = sh.estart[my_gf[q]];
-            g_head[q] = a.ghead[gbase + sh.egs[my_gf[q]] - 1];
+            if (ABL != 4) g_head[q] = a.ghead[gbase + sh.egs[my_gf[q]] - 1];
         }
     }
     // merge rank of every element inside its group = its slot
     uint32_t my_slot[PERX];
-    if (sh.many) {
+    if (ABL == 2) {
+#pragma unroll
+        for (int q = 0; q < PERX; q++) my_slot[q] = tid + q * BLOCK;
+    } else if (sh.many) {
         // A group of many runs -- a phrase suffix that ends hundreds of distinct phrases: the copies of a satellite monomer,
         // each with its own mutations -- would cost every element one binary search per run.  The piece is sorted instead,
         // once, by (first slot of the group, rank of the following parse suffix): groups keep their slots and the ranks
@@ -1148,6 +1152,7 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
                 }
             }
             const uint64_t at = j - a.out_base;
+            if (ABL == 1) { if (v == 0xfffffff3u) a.lcp[at] = v; continue; }
             a.sa.set(at, pos);
             a.bwt[at] = (uint8_t)(hb >> 8);
             a.lcp[at] = j == 0 ? 0u : v;
@@ -1211,7 +1216,7 @@ __global__ void k_emit_plan(const P* __restrict__ segb, const uint32_t* __restri
 
 // Persistent workgroups: workgroup b takes tiles b, b + gridDim.x, ... of the launch; the record of its NEXT tile is
 // requested before the current tile is expanded, so that it has arrived when the tile is done.
-template <int BLOCK, int CAP, int TILE, typename P, typename SA>
+template <int BLOCK, int CAP, int TILE, typename P, typename SA, int ABL = 0>
 __global__ __launch_bounds__(BLOCK, 7) void k_emit(EmitArgsT<P, SA> a, const EmitDesc* __restrict__ desc, uint32_t n_tiles) {
     __shared__ EmitShared<BLOCK, CAP, uint16_t> sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1224,7 +1229,7 @@ __global__ __launch_bounds__(BLOCK, 7) void k_emit(EmitArgsT<P, SA> a, const Emi
         if (t_next < n_tiles) dn = desc[t_next];
         const uint64_t tile = a.tile_lo + t;
         const P tbase = (P)(tile * TILE);
-        if (d.L) emit_piece<BLOCK, CAP, P, SA, uint16_t>(a, sh, d.e0, d.e1, tbase + d.clo, d.L, true, (P)0, d.g0);
+        if (d.L) emit_piece<BLOCK, CAP, P, SA, uint16_t, ABL>(a, sh, d.e0, d.e1, tbase + d.clo, d.L, true, (P)0, d.g0);
         // what the first piece left of the tile (a last group that hangs over by more than CAP - TILE elements; oversized
         // groups, which k_emit_big expands chunk by chunk over many workgroups into the compact fallback arrays)
         uint32_t g = d.g_next;
@@ -1295,6 +1300,17 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* 
     // (MMT_EMIT_GRID: workgroups of the launch, tests/micro; 0 = one per tile)
     static const uint32_t grid_env = std::getenv("MMT_EMIT_GRID") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT_GRID")) : 256u * 7u * 4u;
     const uint32_t grid = grid_env ? std::min(grid_env, n_tiles) : n_tiles;
+    // MMT_EMIT_ABLATE (tests/micro/emit_ablate.sh, wide 896-element tiles only): the kernel with one of its phases cut out
+    // -- WRONG OUTPUT, timing only -- 1 no column stores, 2 no merge ranks, 3 no occurrence records, 4 no group heads,
+    // 5 nothing after the entry rows
+    static const int abl = std::getenv("MMT_EMIT_ABLATE") ? std::atoi(std::getenv("MMT_EMIT_ABLATE")) : 0;
+    if constexpr (TILE == 896 && sizeof(P) == 8) {
+        if (abl == 1) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 1>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
+        if (abl == 2) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 2>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
+        if (abl == 3) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 3>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
+        if (abl == 4) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 4>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
+        if (abl == 5) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 5>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
+    }
     hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles);
     MMT_HIP(hipGetLastError());
 }

@@ -56,10 +56,11 @@ def test_fold_with_32_bit_thresholds_equals_the_direct_run_where_16_bits_saturat
         m16 = eng.anchor_merge(parts16, sort_like_direct=True)
         assert m32["text"] == direct, "the fold at 32 bits is the direct run"
         extra = set(m16["text"].split(b"\n")) - set(direct.split(b"\n"))
-        assert len(extra) == 1 and next(iter(extra)).startswith(b"66000\t"), "the 16-bit fold accepts the unproven 66,000-base row"
+        # (66,000 bases, or a few more when C's next bases happen to continue X)
+        assert len(extra) == 1 and 66000 <= int(next(iter(extra)).split(b"\t")[0]) < 66020, "the 16-bit fold accepts the unproven 66,000-base row"
         # ... exactly as the reference's anchor_merge does (oracle restatement of src/merge_candidates.cpp)
         om = O.anchor_merge([(p[0], p[1], p[2], p[3]) for p in parts16])
-        assert 66000 in set(int(x) for x in om[0])
+        assert any(66000 <= int(x) < 66020 for x in om[0])
         # by coordinate ranges, and from device-resident 32-bit columns, the same
         assert eng.anchor_merge(parts32, sort_like_direct=True, slices=3)["text"] == direct
         # the 16-bit file form of the merged thresholds saturates, the rows do not depend on it

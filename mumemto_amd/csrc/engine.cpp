@@ -105,6 +105,7 @@ void Engine::set_text_host(const uint8_t* text, uint64_t n, const uint64_t* doc_
     layout_docs(revcomp);
     if (n != n_) throw std::runtime_error("the text has " + std::to_string(n) + " characters, the document lengths add "
                                           "up to " + std::to_string(n_));
+    packed_ = false;                                    // (a handed-over text keeps its bytes)
     d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
     if (n_) MMT_HIP(hipMemcpyAsync(text_ptr(), text, n_, hipMemcpyHostToDevice, stream_));
     finish_text_padding();
@@ -153,15 +154,90 @@ void Engine::set_stream_host40(const uint32_t* sa_lo, const uint8_t* sa_hi, cons
 }
 
 // ---- A1 ----------------------------------------------------------------------
+TextRef Engine::text_ref() const {
+    TextRef T;
+    T.n = n_;
+    if (packed_) { T.packed = d_packed_.get(); T.excw = d_excw_.get(); T.runs = d_runs_.get(); T.n_runs = (uint32_t)h_runs_.size(); }
+    else T.v = text_ptr() ? text_ptr() - 1 : nullptr;
+    return T;
+}
+
+// Two bits per character when asked for (MMT_PACKED_TEXT=1: the parity suite runs through it that way), or when the byte
+// text would not leave room for the tables of the parse and one batch of the producer: SURVEY.md 8(e) row 2 -- every rank of
+// BASELINE configs[4] holds all 573 G characters, 143 GB packed.  Only the bucket-wise producer reads a packed text, and the
+// direct producer's inputs (bytes <= 0x02, four documents or fewer below 2^32 characters) keep the byte layout.
+bool Engine::want_packed_text() const {
+    if (const char* c = std::getenv("MMT_PACKED_TEXT")) return std::atoi(c) != 0;
+    // (1 byte per character + 0.5 for the raw bases while the text is made + ~1.4 at the parse's peak + a batch)
+    const double avail = 0.95 * (double)pool::available(device_);
+    return (double)n_ * 2.9 + 24.0 * 1073741824.0 > avail;
+}
+
+// exception runs: events -> sorted run list + one flag per block of 4096 positions (textref.hpp)
+void Engine::finish_packed_text(DevBuf<uint64_t>& ev_start, DevBuf<uint64_t>& ev_end, DevBuf<uint32_t>& ev_count, uint32_t ev_cap) {
+    uint32_t cnt[2] = {0, 0};
+    MMT_HIP(hipMemcpyAsync(cnt, ev_count.get(), 8, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    if (cnt[0] > ev_cap || cnt[1] > ev_cap)
+        throw std::runtime_error("the text holds more than " + std::to_string(ev_cap) + " runs of characters other than A C G T: "
+                                 "too many for the packed layout (MMT_PACKED_TEXT=0 keeps one byte per character)");
+    if (cnt[0] != cnt[1]) throw std::runtime_error("packed text: run starts and ends do not pair up");
+    std::vector<uint64_t> hs, he;
+    d2h(hs, ev_start.get(), cnt[0], stream_);
+    d2h(he, ev_end.get(), cnt[1], stream_);
+    std::sort(hs.begin(), hs.end());
+    std::sort(he.begin(), he.end());
+    h_runs_.resize(cnt[0]);
+    const uint64_t blocks = (n_ >> TX_BLOCK_SHIFT) + 2;
+    std::vector<uint64_t> flags((blocks + 63) / 64 + 1, 0);
+    for (uint32_t i = 0; i < cnt[0]; i++) {
+        const uint64_t a = hs[i] >> 8, b = he[i];
+        if (b <= a || (i && a < (hs[i - 1] >> 8))) throw std::runtime_error("packed text: inconsistent exception runs");
+        if (b - a > 0xffffffffull) throw std::runtime_error("packed text: a run of one character of 2^32 positions or more");
+        h_runs_[i] = ExcRun{a, (uint32_t)(b - a), (uint32_t)(hs[i] & 0xff)};
+        for (uint64_t k = a >> TX_BLOCK_SHIFT; k <= (b - 1) >> TX_BLOCK_SHIFT; k++) flags[k >> 6] |= 1ull << (k & 63);
+    }
+    d_excw_.ensure(flags.size());
+    d_runs_.ensure(h_runs_.size() + 1);
+    MMT_HIP(hipMemcpyAsync(d_excw_.get(), flags.data(), flags.size() * 8, hipMemcpyHostToDevice, stream_));
+    if (!h_runs_.empty())
+        MMT_HIP(hipMemcpyAsync(d_runs_.get(), h_runs_.data(), h_runs_.size() * sizeof(ExcRun), hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+}
+
 void Engine::build_text(bool revcomp) {
     const size_t N = doc_len_.size();
     layout_docs(revcomp);
     d_doc_base_.ensure(N + 1); d_doc_len_.ensure(N + 1);
     MMT_HIP(hipMemcpyAsync(d_doc_base_.get(), doc_base_.data(), (N + 1) * 8, hipMemcpyHostToDevice, stream_));
     MMT_HIP(hipMemcpyAsync(d_doc_len_.get(), doc_len_.data(), N * 8, hipMemcpyHostToDevice, stream_));
-    d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
+    packed_ = want_packed_text();
+    if (packed_) {
+        d_text_.release();
+        const size_t words = (size_t)((n_ + 31) / 32) + 8;
+        d_packed_.ensure(words);
+        MMT_HIP(hipMemsetAsync(d_packed_.get(), 0, words * 8, stream_));
+        const uint32_t ev_cap = 1u << 24;
+        DevBuf<uint64_t> ev_start, ev_end;
+        DevBuf<uint32_t> ev_count;
+        ev_start.ensure(ev_cap); ev_end.ensure(ev_cap); ev_count.ensure(2);
+        MMT_HIP(hipMemsetAsync(ev_count.get(), 0, 8, stream_));
+        k::pack_text(d_bases_, d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N, d_packed_.get(), n_,
+                     d_hist_.get(), ev_start.get(), ev_end.get(), ev_count.get(), ev_cap, stream_);
+        finish_packed_text(ev_start, ev_end, ev_count, ev_cap);
+        // bytes the parse reserves (<= 0x02) are the direct producer's, which reads one byte per character
+        std::vector<uint64_t> hist;
+        d2h(hist, d_hist_.get(), 256, stream_);
+        if (!(hist[0] || hist[1] || hist[2])) return;
+        if (n_ >= NARROW_LIMIT) throw std::runtime_error("texts of 2^32 characters or more must not contain the bytes 0x00-0x02 "
+                                                         "(reserved by the prefix-free parse)");
+        packed_ = false;
+        MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
+    }
+    d_packed_.release(); d_excw_.release(); d_runs_.release(); h_runs_.clear();
+    d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
     k::build_text(d_bases_, d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, text_ptr(), n_,
                   d_hist_.get(), stream_);
     finish_text_padding();          // (the last work-item of the kernel stores up to 15 bytes past the text)
@@ -271,6 +347,7 @@ void Engine::release_columns(bool keep_anchor_ranks) {
     MMT_HIP(hipStreamSynchronize(stream_));
     release_sort_scratch();
     d_text_.release(); d_bwt_.release(); d_sa_.release(); d_sa_hi_.release(); d_cols_.release();
+    d_packed_.release(); d_excw_.release(); d_runs_.release();
     if (!keep_anchor_ranks) { d_rank_.release(); d_rank64_.release(); anchor_ranks_valid_ = false; }
     d_lcp_.release(); d_plcp_a_.release(); d_long_.release(); d_wpre_.release(); d_wsuf_.release(); d_wide_.release();
     d_cand_.release(); d_flags_.release();
@@ -1001,6 +1078,7 @@ void Engine::run(const mmt_params& p) {
             // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
             if (wide_ && !reserved && kind == 1) kind = 2;
         }
+        if (packed_) kind = 3;                  // a packed text (textref.hpp) is read by the bucket-wise producer only
         if (kind == 1 && n_ >= NARROW_LIMIT)
             throw std::runtime_error(reserved ? "texts of 2^32 characters or more must not contain the bytes 0x00-0x02 "
                                                 "(reserved by the prefix-free parse)"
@@ -1089,6 +1167,18 @@ void Engine::parse_only(bool revcomp, uint32_t w, uint32_t p) {
 }
 
 void Engine::copy_text(uint8_t* out) const {
+    if (packed_) {                                      // unpacked in pieces (tests; the packed text exists for texts the bytes do not fit)
+        DevBuf<uint8_t> piece;
+        const uint64_t PIECE = 1ull << 28;
+        piece.ensure(std::min<uint64_t>(PIECE, n_) + 1);
+        for (uint64_t at = 0; at < n_; at += PIECE) {
+            const uint64_t len = std::min<uint64_t>(PIECE, n_ - at);
+            k::unpack_text(text_ref(), at + 1, len, piece.get(), stream_);
+            MMT_HIP(hipMemcpyAsync(out + at, piece.get(), len, hipMemcpyDeviceToHost, stream_));
+            MMT_HIP(hipStreamSynchronize(stream_));
+        }
+        return;
+    }
     MMT_HIP(hipMemcpy(out, text_ptr(), n_, hipMemcpyDeviceToHost));
 }
 static const char* NOT_KEPT = "the columns of this run were produced window by window and not kept "

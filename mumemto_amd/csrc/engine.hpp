@@ -15,6 +15,7 @@
 #include "merge_types.hpp"
 #include "pfp.hpp"
 #include "sorter.hpp"
+#include "textref.hpp"
 
 namespace mmt {
 
@@ -201,6 +202,13 @@ public:
     // value: every comparison of suffixes is clamped to the end of the shorter one.
     static constexpr size_t TEXT_FRONT = 64, TEXT_BACK = 128;
     uint8_t* text_ptr() const { return d_text_.get() ? d_text_.get() + TEXT_FRONT : nullptr; }
+    // The text as the kernels of the parse and of the bucket-wise producer read it (textref.hpp): the byte buffer above, or
+    // -- MMT_PACKED_TEXT=1, or automatically when one byte per character would not fit next to the tables of the parse --
+    // two bits per character + a sorted list of exception runs.  Only the bucket-wise producer runs on a packed text.
+    TextRef text_ref() const;
+    bool have_text() const { return text_ptr() != nullptr || d_packed_.get() != nullptr; }
+    bool packed_text() const { return packed_; }
+    uint32_t exception_runs() const { return (uint32_t)h_runs_.size(); }
     void finish_text_padding();
     SaCol sa_col() const { SaCol c; c.lo = d_sa_.get(); c.hi = wide_ ? d_sa_hi_.get() : nullptr; return c; }
     size_t scan_ranges() const { return scan_ranges_; }
@@ -212,6 +220,8 @@ public:
 private:
     void layout_docs(bool revcomp);
     void build_text(bool revcomp);
+    bool want_packed_text() const;
+    void finish_packed_text(DevBuf<uint64_t>& ev_start, DevBuf<uint64_t>& ev_end, DevBuf<uint32_t>& ev_count, uint32_t ev_cap);
     void suffix_sort();
     void pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs);
     void pfp_prepare(uint32_t w, uint32_t p);
@@ -253,6 +263,11 @@ private:
 
     // columns
     DevBuf<uint8_t> d_text_, d_bwt_, d_flags_, d_code_, d_temp_, d_sa_hi_;
+    // the packed layout of the text (textref.hpp)
+    DevBuf<uint64_t> d_packed_, d_excw_;
+    DevBuf<ExcRun> d_runs_;
+    std::vector<ExcRun> h_runs_;
+    bool packed_ = false;
     // One-shot / wide runs: suffix array (low words, high bytes) and BWT are views into one block that is allocated
     // before any scratch (it then sits at the bottom of the device heap, and what is above it leaves one hole when it
     // goes).  The emitter writes these columns only after the dictionary and the parse are sorted, so until then the

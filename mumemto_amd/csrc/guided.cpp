@@ -206,7 +206,7 @@ void Engine::guided_prepare() {
     S.g_prefix = prefix_chars;
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
-    ctx.v = text_ptr() - 1; ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
+    ctx.T = text_ref(); ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
 
     // ---- phrase ends: rank directory and successor table over the cut bits ----
     const uint64_t n_words = S.tmask.size() * sizeof(uint16_t) / 8 / 64 * 64;     // whole blocks of 4096 positions
@@ -282,7 +282,7 @@ void Engine::guided_prepare() {
         MMT_HIP(hipStreamSynchronize(st));
         sorter_.release();
     }
-    S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
+    S.plcp.build(text_ref(), n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
     S.sa_p.release(); S.parse.release(); S.pid.release(); S.rep.release(); S.prank.release(); S.pstart.release();
     S.plen.release(); S.dlen.release(); S.dstart.release();
     e5.stop(st);
@@ -342,7 +342,7 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     DevBuf<uint64_t> dinfo;
     dict.ensure((size_t)nd + 64); dinfo.ensure(nd);
     MMT_HIP(hipMemsetAsync(dict.get() + nd, 0, 64, st));
-    pk::copy_dict(text_ptr() - 1, S.pstart.get(), S.plen.get(), which.get(), gstart.get(), nG, dict.get(), dinfo.get(), nd, false, W, st);
+    pk::copy_dict(text_ref(), S.pstart.get(), S.plen.get(), which.get(), gstart.get(), nG, dict.get(), dinfo.get(), nd, false, W, st);
     uint8_t code[256];
     int sigma = 0;
     // (0x00 -- once, the last byte of the dictionary -- and the phrase terminator 0x01 share code 0 with the padding behind

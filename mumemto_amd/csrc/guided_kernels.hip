@@ -148,7 +148,7 @@ __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, 
     const bool giant = c.g_n && from + 64 < L;
     const uint64_t stop = giant ? from + 64 : L;
     for (uint64_t t = from; t < stop; t += 8) {
-        const uint64_t x = load_u64(c.v + qa + t), y = load_u64(c.v + qb + t);
+        const uint64_t x = tx_load8(c.T, qa + t), y = tx_load8(c.T, qb + t);
         if (x != y) {
             const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
             if (t + d < stop) { if (lcp) *lcp = t + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff) ? -1 : 1; }
@@ -159,7 +159,7 @@ __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, 
     uint32_t ra = 0, rb = 0;
     if (!giant_entry(c, qa, stop, ra) || !giant_entry(c, qb, stop, rb)) {
         for (uint64_t t = stop; t < L; t += 8) {                // one of them in an ordinary phrase: at most g_depth characters
-            const uint64_t x = load_u64(c.v + qa + t), y = load_u64(c.v + qb + t);
+            const uint64_t x = tx_load8(c.T, qa + t), y = tx_load8(c.T, qb + t);
             if (x != y) {
                 const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
                 if (t + d < L) { if (lcp) *lcp = t + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff) ? -1 : 1; }
@@ -175,11 +175,10 @@ __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, 
 
 // up to c.chars symbol codes of v[from ...], most significant first
 __device__ __forceinline__ uint64_t pack_chars(const Ctx& c, const uint8_t* __restrict__ s_code, uint64_t from) {
-    const uint8_t* p = c.v + from;
     uint64_t key = 0;
     int done = 0;
     while (done < c.chars) {
-        uint64_t x = load_u64(p + done);
+        uint64_t x = tx_load8(c.T, from + done);
         const int take = c.chars - done < 8 ? c.chars - done : 8;
         for (int t = 0; t < take; t++) { key = (key << c.bits) | s_code[x & 0xff]; x >>= 8; }
         done += take;
@@ -196,10 +195,9 @@ __device__ __forceinline__ void for_tile_keys(const Ctx& c, uint8_t* s_sym, F&& 
     for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = c.code[i];
     __syncthreads();
     const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE; // text position of the tile's first suffix
-    const uint8_t* t = c.v + 1;
     for (uint32_t i = threadIdx.x; i < TILE + 64; i += BLOCK) {
         const uint64_t p = base + i;
-        s_sym[i] = p < c.n + 40 ? s_code[t[p]] : (uint8_t)0;       // (the text buffer is padded: Engine::text_ptr)
+        s_sym[i] = p < c.n + 40 ? s_code[tx_byte(c.T, p + 1)] : (uint8_t)0;       // (the text is padded: Engine::text_ptr, textref.hpp)
     }
     __syncthreads();
     const int t0 = threadIdx.x * PER;
@@ -257,12 +255,11 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
     for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = c.code[i];
     __syncthreads();
     const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE; // text position of the tile's first suffix
-    const uint8_t* t = c.v + 1;                                    // 16-byte aligned (Engine::text_ptr), padded by 128 bytes
     // 16 consecutive characters per work-item in one load, turned into symbol codes in registers and staged as one
     // 16-byte LDS store (byte loads and byte stores made these kernels run at 0.4 - 0.8 TB/s of a 1 B / character stream)
     auto codes_at = [&](uint64_t p0) {
         union { uint4 v; uint8_t b[16]; } raw, out;
-        raw.v = p0 + 16 <= c.n + 64 ? *reinterpret_cast<const uint4*>(t + p0) : make_uint4(0u, 0u, 0u, 0u);
+        raw.v = p0 + 16 <= c.n + 64 ? tx_load16(c.T, p0) : make_uint4(0u, 0u, 0u, 0u);      // (16-byte aligned, padded: Engine::text_ptr)
 #pragma unroll
         for (int k = 0; k < 16; k++) out.b[k] = p0 + k < c.n + 40 ? s_code[raw.b[k]] : (uint8_t)0;
         return out.v;
@@ -460,7 +457,7 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
         const uint64_t me = xe < c.n ? c.mask[xe >> 6] : 0, mj = xj < c.n ? c.mask[xj >> 6] : 0;
         uint64_t a[4], b[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) { a[t] = load_u64(c.v + q + offset + 8 * t); b[t] = load_u64(c.v + qj + offset + 8 * t); }
+        for (int t = 0; t < 4; t++) { a[t] = tx_load8(c.T, q + offset + 8 * t); b[t] = tx_load8(c.T, qj + offset + 8 * t); }
         const uint64_t len = (xe < c.n ? next_cut_from(c, xe, me) : c.n + c.w - 1) + 2 - q;
         const uint64_t lj = (xj < c.n ? next_cut_from(c, xj, mj) : c.n + c.w - 1) + 2 - qj;
         const uint64_t L = len < lj ? len : lj;
@@ -637,7 +634,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             const uint64_t rec = pos[s_g0[wave][seg] + mem];
             const uint64_t q = rec_pos(c, rec);
 #pragma unroll
-            for (uint32_t t = 0; t < MED_WORDS; t++) S.w[i][t] = load_u64(c.v + q + offset + 8 * t);
+            for (uint32_t t = 0; t < MED_WORDS; t++) S.w[i][t] = tx_load8(c.T, q + offset + 8 * t);
             const uint64_t len = rec_len(c, rec, q);
             S.len[i] = len < 0xffffffffull ? (uint32_t)len : 0xffffffffu;
             S.rank[i] = c.skip ? 0ull : rec_rank_key(c, rec, q);
@@ -1009,7 +1006,7 @@ __global__ void k_write_columns(Ctx c, const uint64_t* __restrict__ pos, uint32_
     if (j >= B) return;
     const uint64_t q = rec_pos(c, pos[j]);                 // V index; text position q - 1
     sa.set(base + j, q - 1);
-    bwt[base + j] = q == 1 ? (uint8_t)0 : c.v[q - 1];      // the Dollar before text position 0 reads as 0 (k_entry_info)
+    bwt[base + j] = q == 1 ? (uint8_t)0 : tx_byte(c.T, q - 1);      // the Dollar before text position 0 reads as 0 (k_entry_info)
 }
 void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base, SaCol sa, uint8_t* bwt, hipStream_t s) {
     if (sa.wide())

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "parse_lcp.hpp"
+#include "textref.hpp"
 #include "wide.hpp"
 
 namespace mmt { namespace gk {
@@ -21,7 +22,8 @@ constexpr uint32_t SORT_CAP = 2048;        // elements of one LDS tile of the ro
 constexpr uint32_t NO_BOUND = 0xffffffffu;
 
 struct Ctx {
-    const uint8_t* v;          // V = Dollar . T . Dollar^w (pfp_kernels.hip); v[q], q = text position + 1
+    TextRef T;                 // V = Dollar . T . Dollar^w (pfp_kernels.hip) behind the accessor of textref.hpp: bytes, or two
+                               // bits per character + exceptions; V index q = text position + 1
     uint64_t n;                // text length
     uint32_t w;                // trigger window
     const uint64_t* mask;      // bit c set <=> a phrase ends at text position c (64 positions per word, zero padded)

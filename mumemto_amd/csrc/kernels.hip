@@ -170,6 +170,146 @@ __global__ __launch_bounds__(BLOCK) void k_build_text(const uint8_t* __restrict_
         if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
 }
 
+// ---- the text packed to two bits per character (textref.hpp) -----------------------------------------------------------------
+// One work-item per packed word = 32 text positions, computed from the raw bases exactly as k_build_text computes its bytes
+// (character by character here: the layout rules in one place, and this pass is a few per cent of a run).  What is not
+// A C G T -- the '$' behind every strand, N, IUPAC codes -- is an EXCEPTION: code 0 in the word, and its maximal runs of one
+// byte leave as events (start, byte) / (end) that the host pairs up into the sorted run list.
+__device__ __forceinline__ uint8_t text_char_at(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ st,
+                                                const uint64_t* __restrict__ bs, const uint64_t* __restrict__ ln, uint32_t n_docs,
+                                                uint64_t p, const uint8_t* s_up, const uint8_t* s_rc) {
+    const uint32_t d = doc_lookup(st, n_docs, p);
+    const uint64_t Ld = ln[d], lo = p - st[d];
+    if (lo < Ld) return s_up[raw[bs[d] + lo]];
+    if (lo == Ld) return '$';
+    if (lo <= 2 * Ld) return s_rc[raw[bs[d] + (2 * Ld - lo)]];
+    return '$';
+}
+template <int BLOCK, int MAXD>
+__global__ __launch_bounds__(BLOCK) void k_pack_text(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ doc_base,
+                                                      const uint64_t* __restrict__ doc_len, const uint64_t* __restrict__ doc_start,
+                                                      uint32_t n_docs, uint64_t* __restrict__ packed, uint64_t n,
+                                                      unsigned long long* __restrict__ hist, uint64_t* __restrict__ ev_start,
+                                                      uint64_t* __restrict__ ev_end, uint32_t* __restrict__ ev_count, uint32_t ev_cap) {
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint8_t s_up[256], s_rc[256];
+    __shared__ uint64_t s_start[MAXD + 1], s_base[MAXD + 1], s_len[MAXD + 1];
+    for (int i = threadIdx.x; i < 256; i += BLOCK) {
+        s_hist[i] = 0;
+        const uint8_t u = dev_upper((uint8_t)i);
+        s_up[i] = u; s_rc[i] = dev_complement(u);
+    }
+    const bool in_lds = n_docs <= (uint32_t)MAXD;
+    if (in_lds)
+        for (uint32_t i = threadIdx.x; i <= n_docs; i += BLOCK) {
+            s_start[i] = doc_start[i]; s_base[i] = doc_base[i]; s_len[i] = i < n_docs ? doc_len[i] : 0;
+        }
+    __syncthreads();
+    const uint64_t* st = in_lds ? s_start : doc_start;
+    const uint64_t* bs = in_lds ? s_base : doc_base;
+    const uint64_t* ln = in_lds ? s_len : doc_len;
+    const uint64_t n_words = (n + 31) / 32;
+    for (uint64_t W = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; W < n_words; W += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t p0 = W * 32;
+        uint32_t d = doc_lookup(st, n_docs, p0);
+        uint64_t word = 0;
+        uint32_t exc = 0;
+        uint8_t ch[32];
+        uint32_t cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const uint64_t p = p0 + b;
+            uint8_t c = 0;
+            if (p < n) {
+                while (p >= st[d + 1]) d++;
+                const uint64_t Ld = ln[d], lo = p - st[d];
+                if (lo < Ld) c = s_up[raw[bs[d] + lo]];
+                else if (lo == Ld) c = '$';
+                else if (lo <= 2 * Ld) c = s_rc[raw[bs[d] + (2 * Ld - lo)]];
+                else c = '$';
+                const uint32_t code = tx_code_of(c);
+                if (code < 4) { word |= (uint64_t)code << (2 * b); cnt[code]++; }
+                else { exc |= 1u << b; atomicAdd(&s_hist[c], 1u); }
+            }
+            ch[b] = c;
+        }
+        packed[W] = word;
+        if (cnt[0]) atomicAdd(&s_hist['A'], cnt[0]);
+        if (cnt[1]) atomicAdd(&s_hist['C'], cnt[1]);
+        if (cnt[2]) atomicAdd(&s_hist['G'], cnt[2]);
+        if (cnt[3]) atomicAdd(&s_hist['T'], cnt[3]);
+        if (exc) {
+            // runs of one exception byte: a start where the byte before differs, an end where the byte behind differs
+            const uint8_t before = p0 ? (uint8_t)((exc & 1u) ? text_char_at(raw, st, bs, ln, n_docs, p0 - 1, s_up, s_rc) : 0) : (uint8_t)0;
+            const uint8_t behind = (p0 + 32 < n && (exc >> 31)) ? text_char_at(raw, st, bs, ln, n_docs, p0 + 32, s_up, s_rc) : (uint8_t)0;
+#pragma unroll
+            for (int b = 0; b < 32; b++) {
+                if (!((exc >> b) & 1u)) continue;
+                const uint8_t prev = b ? ch[b ? b - 1 : 0] : before, next = b < 31 ? ch[b < 31 ? b + 1 : 31] : behind;
+                if (prev != ch[b] || p0 + b == 0) {
+                    const uint32_t slot = atomicAdd(ev_count, 1u);
+                    if (slot < ev_cap) ev_start[slot] = ((p0 + b) << 8) | ch[b];
+                }
+                if (next != ch[b] || p0 + b + 1 == n) {
+                    const uint32_t slot = atomicAdd(ev_count + 1, 1u);
+                    if (slot < ev_cap) ev_end[slot] = p0 + b + 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += BLOCK)
+        if (s_hist[i]) atomicAdd(&hist[i], (unsigned long long)s_hist[i]);
+}
+void pack_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
+               uint64_t* packed, uint64_t n, uint64_t* hist, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count, uint32_t ev_cap,
+               hipStream_t s) {
+    constexpr int B = 256;
+    const uint64_t words = (n + 31) / 32;
+    const unsigned grid = (unsigned)std::min<uint64_t>((words + B - 1) / B ? (words + B - 1) / B : 1, 256u * 32u);
+    hipLaunchKernelGGL((k_pack_text<B, 1023>), dim3(grid), dim3(B), 0, s, raw, d_doc_base, d_doc_len, d_doc_start, n_docs, packed, n,
+                       reinterpret_cast<unsigned long long*>(hist), ev_start, ev_end, ev_count, ev_cap);
+    MMT_HIP(hipGetLastError());
+}
+// a byte text (a handed-over text: Engine::set_text_host) packed the same way
+__global__ void k_pack_bytes(const uint8_t* __restrict__ text, uint64_t n, uint64_t* __restrict__ packed, uint64_t* __restrict__ ev_start,
+                             uint64_t* __restrict__ ev_end, uint32_t* __restrict__ ev_count, uint32_t ev_cap) {
+    const uint64_t n_words = (n + 31) / 32;
+    for (uint64_t W = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; W < n_words; W += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = W * 32;
+        uint64_t word = 0;
+        for (int b = 0; b < 32; b++) {
+            const uint64_t p = p0 + b;
+            if (p >= n) break;
+            const uint8_t c = text[p];
+            const uint32_t code = tx_code_of(c);
+            if (code < 4) { word |= (uint64_t)code << (2 * b); continue; }
+            const uint8_t prev = p ? text[p - 1] : (uint8_t)0, next = p + 1 < n ? text[p + 1] : (uint8_t)0;
+            if (prev != c || p == 0) { const uint32_t slot = atomicAdd(ev_count, 1u); if (slot < ev_cap) ev_start[slot] = (p << 8) | c; }
+            if (next != c || p + 1 == n) { const uint32_t slot = atomicAdd(ev_count + 1, 1u); if (slot < ev_cap) ev_end[slot] = p + 1; }
+        }
+        packed[W] = word;
+    }
+}
+void pack_bytes(const uint8_t* text, uint64_t n, uint64_t* packed, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count,
+                uint32_t ev_cap, hipStream_t s) {
+    const uint64_t words = (n + 31) / 32;
+    const unsigned grid = (unsigned)std::min<uint64_t>((words + 255) / 256 ? (words + 255) / 256 : 1, 256u * 32u);
+    hipLaunchKernelGGL(k_pack_bytes, dim3(grid), dim3(256), 0, s, text, n, packed, ev_start, ev_end, ev_count, ev_cap);
+    MMT_HIP(hipGetLastError());
+}
+// V[first .. first + count) of a packed text as bytes (Engine::copy_text, tests)
+__global__ void k_unpack_text(const TextRef T, uint64_t first, uint64_t count, uint8_t* __restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = tx_byte(T, first + i);
+}
+void unpack_text(const TextRef& T, uint64_t first, uint64_t count, uint8_t* out, hipStream_t s) {
+    if (!count) return;
+    const uint64_t g = (count + 255) / 256;
+    hipLaunchKernelGGL(k_unpack_text, dim3((unsigned)(g < 65536 ? g : 65536)), dim3(256), 0, s, T, first, count, out);
+    MMT_HIP(hipGetLastError());
+}
+
 void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
                 bool /*revcomp*/, uint8_t* text, uint64_t n, uint64_t* hist, hipStream_t s) {
     constexpr int B = 256;
@@ -913,22 +1053,32 @@ constexpr uint32_t LONG_SLICE = LONG_UNROLL * 512, LONG_WAVE_MAX = 64 * 1024;
 
 // first mismatch of text[p + base ..) and text[q + base ..) within one 4 KB slice (0xffffffff: none); wave-uniform
 template <typename I>
-__device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ text, I p, I q, uint32_t base,
+__device__ __forceinline__ uint32_t slice_mismatch(const TextRef& T, I p, I q, uint32_t base,
                                                    uint32_t limit, uint32_t lane) {
     // 8-byte loads at addresses that are multiples of 8 (a misaligned wave-wide load is served lane by lane, ~230 ns per
     // instruction on this part); the suffix bytes are funnelled out of two neighbouring words
-    const uint8_t* pa = text + (p & ~(I)7);
-    const uint8_t* qa = text + (q & ~(I)7);
-    const uint32_t sp = (uint32_t)(p & 7u) * 8, sq = (uint32_t)(q & 7u) * 8;
     uint64_t x[LONG_UNROLL], y[LONG_UNROLL];
+    if (T.v) {
+        const uint8_t* const text = T.v;
+        const uint8_t* pa = text + (p & ~(I)7);
+        const uint8_t* qa = text + (q & ~(I)7);
+        const uint32_t sp = (uint32_t)(p & 7u) * 8, sq = (uint32_t)(q & 7u) * 8;
 #pragma unroll
-    for (int u = 0; u < LONG_UNROLL; u++) {
-        const uint32_t o = base + (uint32_t)(u * 64 + lane) * 8;
-        const uint32_t oc = o < limit ? o : limit;            // past the shorter suffix: the zero padding after the text
-        const uint64_t xl = *reinterpret_cast<const uint64_t*>(pa + oc), xh = *reinterpret_cast<const uint64_t*>(pa + oc + 8);
-        const uint64_t yl = *reinterpret_cast<const uint64_t*>(qa + oc), yh = *reinterpret_cast<const uint64_t*>(qa + oc + 8);
-        x[u] = sp ? (xl >> sp) | (xh << (64 - sp)) : xl;
-        y[u] = sq ? (yl >> sq) | (yh << (64 - sq)) : yl;
+        for (int u = 0; u < LONG_UNROLL; u++) {
+            const uint32_t o = base + (uint32_t)(u * 64 + lane) * 8;
+            const uint32_t oc = o < limit ? o : limit;            // past the shorter suffix: the zero padding after the text
+            const uint64_t xl = *reinterpret_cast<const uint64_t*>(pa + oc), xh = *reinterpret_cast<const uint64_t*>(pa + oc + 8);
+            const uint64_t yl = *reinterpret_cast<const uint64_t*>(qa + oc), yh = *reinterpret_cast<const uint64_t*>(qa + oc + 8);
+            x[u] = sp ? (xl >> sp) | (xh << (64 - sp)) : xl;
+            y[u] = sq ? (yl >> sq) | (yh << (64 - sq)) : yl;
+        }
+    } else {                                                  // packed text (textref.hpp): positions are V indices
+#pragma unroll
+        for (int u = 0; u < LONG_UNROLL; u++) {
+            const uint32_t o = base + (uint32_t)(u * 64 + lane) * 8;
+            const uint32_t oc = o < limit ? o : limit;
+            x[u] = tx_load8(T, (uint64_t)p + oc); y[u] = tx_load8(T, (uint64_t)q + oc);
+        }
     }
     uint32_t first = 0xffffffffu;
 #pragma unroll
@@ -946,7 +1096,7 @@ __device__ __forceinline__ uint32_t slice_mismatch(const uint8_t* __restrict__ t
 }
 
 template <typename I, typename R>
-__global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict__ longs, uint32_t count,
+__global__ void k_long_lcp(const TextRef T, I n, R* __restrict__ longs, uint32_t count,
                            uint32_t* __restrict__ plcp, uint32_t* __restrict__ huge_idx, uint32_t* __restrict__ huge_count,
                            uint32_t first) {
     const uint32_t w = first + (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
@@ -959,7 +1109,7 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict_
     for (int step = 0; step < 8 && h < limit && !found; step++) {
         const uint32_t o = h + lane * 8;
         uint64_t d = 0;
-        if (o < limit) d = load_u64(text + p + o) ^ load_u64(text + q + o);       // text is zero padded by 64 bytes
+        if (o < limit) d = tx_load8(T, (uint64_t)p + o) ^ tx_load8(T, (uint64_t)q + o);       // text is zero padded by 64 bytes
         const uint64_t m = __ballot(d != 0);
         if (m) {
             const int fl = __builtin_ctzll(m);
@@ -969,7 +1119,7 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict_
         } else h += 512;
     }
     while (!found && h < stop) {
-        const uint32_t first = slice_mismatch<I>(text, p, q, h, limit, lane);
+        const uint32_t first = slice_mismatch<I>(T, p, q, h, limit, lane);
         if (first != 0xffffffffu) { h = first; found = true; }
         else h += LONG_SLICE;
     }
@@ -982,7 +1132,7 @@ __global__ void k_long_lcp(const uint8_t* __restrict__ text, I n, R* __restrict_
 }
 
 template <typename I, typename R>
-__global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __restrict__ text, I n,
+__global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const TextRef T, I n,
                                                               const R* __restrict__ longs,
                                                               const uint32_t* __restrict__ huge_idx,
                                                               const uint32_t* __restrict__ huge_count,
@@ -997,7 +1147,7 @@ __global__ __launch_bounds__(HUGE_WAVES * 64) void k_huge_lcp(const uint8_t* __r
         uint32_t h = L.h;
         while (h < limit) {
             // slices past the cap (wide texts only) compare nothing: slice_mismatch clamps every offset to `limit`
-            const uint32_t first = slice_mismatch<I>(text, p, q, h + wave * LONG_SLICE, limit, lane);
+            const uint32_t first = slice_mismatch<I>(T, p, q, h + wave * LONG_SLICE, limit, lane);
             if (lane == 0) s_first[wave] = first;
             __syncthreads();
             uint32_t best = 0xffffffffu;
@@ -1139,7 +1289,7 @@ void irreducible_lcp(const uint8_t* text, uint64_t n, SaCol sa, const uint8_t* b
 }
 size_t long_lcp_record_bytes(bool wide) { return wide ? sizeof(LongLcpT<uint64_t>) : sizeof(LongLcpT<uint32_t>); }
 template <typename I, typename R = LongLcpT<I>>
-static void long_lcp_typed(const uint8_t* text, uint64_t n, void* long_list, uint32_t count, uint32_t* plcp,
+static void long_lcp_typed(const TextRef& text, uint64_t n, void* long_list, uint32_t count, uint32_t* plcp,
                            uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
     // (one wave per record; slices of 2^24 records: a launch may not have 2^32 work-items)
     for (uint32_t first = 0; first < count; first += 1u << 24) {
@@ -1156,10 +1306,11 @@ void long_lcp_lim(const uint8_t* text, uint32_t n, void* long_list, uint32_t cou
     static_assert(sizeof(LongLcpLimT) == sizeof(LongLcpLim), "record layout");
     if (!count) return;
     MMT_HIP(hipMemsetAsync(huge_count, 0, 4, s));
-    long_lcp_typed<uint32_t, LongLcpLimT>(text, n, long_list, count, out, huge_idx, huge_count, s);
+    TextRef T; T.v = text; T.n = n;
+    long_lcp_typed<uint32_t, LongLcpLimT>(T, n, long_list, count, out, huge_idx, huge_count, s);
     MMT_HIP(hipGetLastError());
 }
-void long_lcp_dst(const uint8_t* v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
+void long_lcp_dst(const TextRef& v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
                   uint32_t* huge_count, hipStream_t s) {
     static_assert(sizeof(LongLcpDstT) == sizeof(LongLcpDst), "record layout");
     if (!count) return;
@@ -1171,8 +1322,9 @@ void long_lcp(const uint8_t* text, uint64_t n, bool wide, void* long_list, uint3
               uint32_t* huge_idx, uint32_t* huge_count, hipStream_t s) {
     if (!count) return;
     MMT_HIP(hipMemsetAsync(huge_count, 0, 4, s));
-    if (wide) long_lcp_typed<uint64_t>(text, n, long_list, count, plcp, huge_idx, huge_count, s);
-    else long_lcp_typed<uint32_t>(text, n, long_list, count, plcp, huge_idx, huge_count, s);
+    TextRef T; T.v = text; T.n = n;
+    if (wide) long_lcp_typed<uint64_t>(T, n, long_list, count, plcp, huge_idx, huge_count, s);
+    else long_lcp_typed<uint32_t>(T, n, long_list, count, plcp, huge_idx, huge_count, s);
     MMT_HIP(hipGetLastError());
 }
 void lcp_gather(const uint32_t* plcp, SaCol sa, uint64_t j0, uint64_t count, uint32_t* lcp, hipStream_t s) {

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "wide.hpp"
+#include "textref.hpp"
 
 namespace mmt { namespace k {
 
@@ -26,6 +27,15 @@ struct Row {
 // Document d sits at raw[d_doc_base[d] .. + d_doc_len[d]) (any gaps between documents are ignored).
 void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
                 bool revcomp, uint8_t* text, uint64_t n, uint64_t* hist, hipStream_t s);
+// The same text packed to two bits per character (textref.hpp): packed[(n + 31) / 32 (+ padding)] words; maximal runs of one
+// exception byte (anything but A C G T) leave as events -- ev_start[i] = (first position << 8) | byte, ev_end[i] = position
+// behind the run, counts in ev_count[0 / 1], in no particular order: the host sorts and pairs them.
+void pack_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
+               uint64_t* packed, uint64_t n, uint64_t* hist, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count, uint32_t ev_cap,
+               hipStream_t s);
+void pack_bytes(const uint8_t* text, uint64_t n, uint64_t* packed, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count,
+                uint32_t ev_cap, hipStream_t s);
+void unpack_text(const TextRef& T, uint64_t first, uint64_t count, uint8_t* out, hipStream_t s);
 
 // ---- A8 direct suffix sort (prefix doubling) --------------------------------
 // keys[i] = first `chars` symbols of suffix i, `bits` per symbol via code[256]
@@ -113,7 +123,7 @@ struct LongLcpDst { uint64_t p, q; uint32_t h, d; };
 struct LongLcpLim { uint32_t p, q, h, lim; };
 void long_lcp_lim(const uint8_t* text, uint32_t n, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
                   uint32_t* huge_count, hipStream_t s);
-void long_lcp_dst(const uint8_t* v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
+void long_lcp_dst(const TextRef& v, uint64_t nv, void* long_list, uint32_t count, uint32_t* out, uint32_t* huge_idx,
                   uint32_t* huge_count, hipStream_t s);
 size_t plcp_running_max_scratch(uint64_t n);
 void plcp_running_max(uint32_t* plcp, uint64_t n, void* scratch, hipStream_t s);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void k_parse_mark(const uint32_t* __restrict
 // what is still equal then goes to the long-match list (kernels.hip: one wave per match, 512 characters per step and up).
 constexpr int CMP_STEPS = 8;
 template <typename P>
-__global__ void k_parse_cmp(const uint8_t* __restrict__ v, uint64_t nv, const uint2* __restrict__ list, uint32_t count,
+__global__ void k_parse_cmp(const TextRef T, uint64_t nv, const uint2* __restrict__ list, uint32_t count,
                             const P* __restrict__ pstart, uint32_t* __restrict__ lirr, k::LongLcpDst* __restrict__ longs,
                             uint32_t* __restrict__ counts, uint32_t long_cap) {
     const uint32_t lane = threadIdx.x & 63, sub = lane & 7, grp = lane >> 3;
@@ -92,6 +92,7 @@ __global__ void k_parse_cmp(const uint8_t* __restrict__ v, uint64_t nv, const ui
         const uint64_t room = nv - (p > q ? p : q);
         limit = room < (uint64_t)LCP_CAP ? (uint32_t)room : LCP_CAP;
     }
+    const uint8_t* const v = T.v;                              // (nullptr: packed text, textref.hpp)
     const uint8_t* pa = v + (p & ~7ull);
     const uint8_t* qb = v + (q & ~7ull);
     const uint32_t sp = (uint32_t)(p & 7u) * 8, sq = (uint32_t)(q & 7u) * 8;
@@ -101,11 +102,13 @@ __global__ void k_parse_cmp(const uint8_t* __restrict__ v, uint64_t nv, const ui
         const uint32_t o = h + sub * 8;
         uint64_t d = 0;
         if (!done && o < limit) {
-            const uint64_t xl = *reinterpret_cast<const uint64_t*>(pa + o), xh = *reinterpret_cast<const uint64_t*>(pa + o + 8);
-            const uint64_t yl = *reinterpret_cast<const uint64_t*>(qb + o), yh = *reinterpret_cast<const uint64_t*>(qb + o + 8);
-            const uint64_t x = sp ? (xl >> sp) | (xh << (64 - sp)) : xl;
-            const uint64_t y = sq ? (yl >> sq) | (yh << (64 - sq)) : yl;
-            d = x ^ y;
+            if (v) {
+                const uint64_t xl = *reinterpret_cast<const uint64_t*>(pa + o), xh = *reinterpret_cast<const uint64_t*>(pa + o + 8);
+                const uint64_t yl = *reinterpret_cast<const uint64_t*>(qb + o), yh = *reinterpret_cast<const uint64_t*>(qb + o + 8);
+                const uint64_t x = sp ? (xl >> sp) | (xh << (64 - sp)) : xl;
+                const uint64_t y = sq ? (yl >> sq) | (yh << (64 - sq)) : yl;
+                d = x ^ y;
+            } else d = tx_load8(T, p + o) ^ tx_load8(T, q + o);
         }
         const uint64_t mall = __ballot(d != 0);
         const uint32_t mg = (uint32_t)(mall >> (grp * 8)) & 0xffu;       // the same for the eight lanes of a pair
@@ -188,7 +191,7 @@ void build_rmq(const uint32_t* vals, uint32_t m, DevBuf<uint32_t>& bmin, uint32_
     MMT_HIP(hipGetLastError());
 }
 
-void ParseLcp::build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const uint32_t* pid, const void* pstart, bool wide,
+void ParseLcp::build(const TextRef& v, uint64_t nv, const uint32_t* sa_p, const uint32_t* pid, const void* pstart, bool wide,
                      uint32_t m_, DevBuf<uint8_t>& temp, hipStream_t s) {
     m = m_;
     nb = (m + 63) / 64;

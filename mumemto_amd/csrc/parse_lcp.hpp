@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_utils.hpp"
+#include "textref.hpp"
 
 namespace mmt {
 
@@ -64,7 +65,7 @@ struct ParseLcp {
     // v: the string V = Dollar . T . Dollar^w (v[q], q = text position + 1), nv = n + 1 + w bytes, zero padded behind;
     // sa_p: suffix array of the parse (m entries); pid[q]: any id that is equal for equal phrases (distinct-phrase id or
     // rank); pstart: V index of the first character of phrase q (uint32_t entries, or uint64_t when `wide`)
-    void build(const uint8_t* v, uint64_t nv, const uint32_t* sa_p, const uint32_t* pid, const void* pstart, bool wide,
+    void build(const TextRef& v, uint64_t nv, const uint32_t* sa_p, const uint32_t* pid, const void* pstart, bool wide,
                uint32_t m, DevBuf<uint8_t>& temp, hipStream_t s);
 };
 

@@ -31,6 +31,10 @@ uint64_t Engine::auto_max_text() const {
     constexpr double PEAK_BYTES_PER_CHAR = 3.0, FIXED = 24.0 * 1073741824.0;
     const double avail = 0.95 * (double)pool::available(device_) - FIXED;
     uint64_t max_text = avail > 0 ? (uint64_t)std::min<double>(avail / PEAK_BYTES_PER_CHAR, (double)((1ull << 40) - 1)) : 0;
+    // (the fixed part is what a batch of a whole-genome run takes; a device another process has filled still runs small
+    // collections: 1 GB + 30 bytes per character covers every table of the parse proper)
+    const double small = (0.95 * (double)pool::available(device_) - 1073741824.0) / 30.0;
+    if (small > 0 && (uint64_t)small > max_text) max_text = std::min<uint64_t>((uint64_t)small, 1ull << 30);
     // one variable for the library and the command line (MMT_MAX_TEXT: the older name)
     for (const char* name : {"MUMEMTO_MAX_TEXT", "MMT_MAX_TEXT"})
         if (const char* c = std::getenv(name)) { max_text = std::strtoull(c, nullptr, 10); break; }

@@ -59,12 +59,12 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
 
     // -- triggers, phrase boundaries
     e0.start(st);
-    const uint8_t* const v = text_ptr() - 1;       // V = Dollar . T . Dollar^w lives in the text buffer (Engine::text_ptr)
+    const TextRef v = text_ref();                  // V = Dollar . T . Dollar^w lives in the text buffer (Engine::text_ptr), or packed (textref.hpp)
     const uint32_t tb = pk::trigger_blocks(n);
     // (the cut bits double as the rank / successor structure of the guided sort: whole blocks of 4096 positions, zero padded)
     S.tmask.ensure((size_t)(((n + 64) / 4096 + 2) * 256)); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
     MMT_HIP(hipMemsetAsync(S.tmask.get(), 0, S.tmask.bytes(), st));
-    pk::trigger_masks(text_ptr(), n, w, p, S.tmask.get(), S.tcnt.get(), st);
+    pk::trigger_masks(v, n, w, p, S.tmask.get(), S.tcnt.get(), st);
     prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
     S.err.ensure(16);
     {
@@ -278,7 +278,7 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     S.rounds_parse = sorter_.sort(m, pbits * pchars, (uint64_t)pchars, S.sa_p.get(), S.isa_p.get(), d_temp_, st);
     if (slim) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); S.isa_p.release(); S.parse.release(); }
     // LCP of adjacent parse suffixes + range minima: every LCP value of the stream follows from them locally
-    S.plcp.build(text_ptr() - 1, n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
+    S.plcp.build(text_ref(), n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
     e5.stop(st);
     mem_mark(device_, "parse suffix array + LCP");
 
@@ -582,7 +582,7 @@ void Engine::pfp_stream(ScanState& SS, const mmt_params& p) {
 // PREFIX.dict bytes: phrases in lexicographic order, 0x01 after each, final 0x00 (newscan.hpp:386-397)
 void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     PfpState& S = *pfp_;
-    if (!S.have_parse || !text_ptr() || !S.pstart.get())
+    if (!S.have_parse || !have_text() || !S.pstart.get())
         throw std::runtime_error("no parse available (run parse_only first)");
     const uint32_t D = S.n_distinct, nd = S.dict_len;
     DevBuf<uint32_t> which, slen, sstart;
@@ -590,7 +590,7 @@ void Engine::pfp_copy_dict(std::vector<uint8_t>& out) {
     which.ensure(D); slen.ensure(D); sstart.ensure(D); sorted.ensure(nd);
     pk::invert_ranks(S.prank.get(), S.rep.get(), S.dlen.get(), D, which.get(), slen.get(), stream_);
     prims::exclusive_sum_u32(d_temp_, slen.get(), sstart.get(), D, stream_);
-    pk::copy_dict(text_ptr() - 1, S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
+    pk::copy_dict(text_ref(), S.pstart.get(), S.plen.get(), which.get(), sstart.get(), D, sorted.get(), nullptr, nd,
                   false, S.pstart.wide(), stream_);
     d2h(out, sorted.get(), nd, stream_);
 }

@@ -42,7 +42,7 @@ static inline unsigned grid_for(uint64_t items, unsigned per_block) {
 // Pass 2 (after an exclusive scan of the workgroup counts): the trigger positions, ascending.
 constexpr uint32_t KR_PRIME = 1999999973u;             // newscan.hpp:86 (compile-time: reductions become multiplies)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restrict__ text, uint64_t n, uint32_t w,
+__global__ __launch_bounds__(BLOCK) void k_trigger_masks(const TextRef T, uint64_t n, uint32_t w,
                                                          uint32_t p, uint32_t pot,
                                                          uint16_t* __restrict__ masks,
                                                          uint32_t* __restrict__ block_count, uint32_t block0) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
         uint32_t h = 0;                                    // always < KR_PRIME < 2^31
         for (uint32_t k = 0; k < w; k++) {                 // window ending at i0
             int64_t pos = (int64_t)i0 - (int64_t)w + 1 + k;
-            uint32_t c = pos >= 0 ? text[pos] : 0;
+            uint32_t c = pos >= 0 ? tx_byte(T, (uint64_t)pos + 1) : 0;
             h = (uint32_t)(((uint64_t)h * 256 + c) % KR_PRIME);
         }
 #pragma unroll
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
             if (i + 1 >= w && h % p == 0) mask |= 1u << q;
             // roll to i + 1: drop T[i-w+1], add T[i+1]
             const int64_t drop = (int64_t)i - (int64_t)w + 1;
-            const uint32_t out = drop >= 0 ? text[drop] : 0;
-            const uint32_t in = i + 1 < n ? text[i + 1] : 0;
+            const uint32_t out = drop >= 0 ? tx_byte(T, (uint64_t)drop + 1) : 0;
+            const uint32_t in = i + 1 < n ? tx_byte(T, i + 2) : 0;
             h = (uint32_t)((h + KR_PRIME - (uint32_t)(((uint64_t)out * pot) % KR_PRIME)) % KR_PRIME);
             h = (uint32_t)(((uint64_t)h * 256 + in) % KR_PRIME);
         }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks(const uint8_t* __restri
 //   * "h % p == 0" for the runtime modulus p = 2^e * q, q odd: the low e bits are zero and (h >> e) * q^-1 mod 2^32 <=
 //     (2^32 - 1) / q (Granlund-Montgomery divisibility test): one multiply instead of a division.
 template <int BLOCK, int W>
-__global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const uint8_t* __restrict__ text, uint64_t n, uint32_t pot,
+__global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const TextRef T, uint64_t n, uint32_t pot,
                                                               uint32_t pe, uint32_t qinv, uint32_t qlim,
                                                               uint16_t* __restrict__ masks,
                                                               uint32_t* __restrict__ block_count, uint32_t block0) {
@@ -117,12 +117,11 @@ __global__ __launch_bounds__(BLOCK) void k_trigger_masks_fast(const uint8_t* __r
     if (i0 < n) {
         // by[32 + k] = T[i0 + k] for k = -32 .. 16 (0 before the text and from n on)
         union { uint4 v[4]; uint8_t b[64]; } u;
-        const uint4* p4 = reinterpret_cast<const uint4*>(text + i0);
         const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-        u.v[0] = i0 >= 32 ? p4[-2] : zero;
-        u.v[1] = i0 >= 16 ? p4[-1] : zero;
-        u.v[2] = p4[0];                                     // (the buffer is padded behind the text)
-        u.v[3] = i0 + 16 < n ? p4[1] : zero;
+        u.v[0] = i0 >= 32 ? tx_load16(T, i0 - 32) : zero;
+        u.v[1] = i0 >= 16 ? tx_load16(T, i0 - 16) : zero;
+        u.v[2] = tx_load16(T, i0);                          // (the text is padded behind its end)
+        u.v[3] = i0 + 16 < n ? tx_load16(T, i0 + 16) : zero;
         const uint64_t left = n - i0;                       // characters of this work-item's 17 that exist
         uint32_t h = 0;                                     // always < KR_PRIME < 2^31
 #pragma unroll
@@ -192,7 +191,7 @@ static void for_trigger_slices(uint64_t n, F&& launch) {
     const uint32_t blocks = trigger_blocks(n), SLICE = 1u << 23;
     for (uint32_t b0 = 0; b0 < blocks; b0 += SLICE) launch(b0, std::min<uint32_t>(SLICE, blocks - b0));
 }
-void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
+void trigger_masks(const TextRef& text, uint64_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
                    hipStream_t s) {
     uint64_t pot = 1;
     for (uint32_t i = 1; i < w; i++) pot = (pot * 256) % KR_PRIME;
@@ -202,7 +201,8 @@ void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint
     uint32_t qinv = q;                                       // correct to 3 bits
     for (int i = 0; i < 5; i++) qinv *= 2u - q * qinv;
     const uint32_t qlim = 0xffffffffu / q;
-    const bool fast = !getenv("MMT_TRIGGER_PLAIN") && (reinterpret_cast<uintptr_t>(text) & 15u) == 0;
+    // (text.v = V: the text itself begins one byte on, 16-byte aligned -- Engine::text_ptr)
+    const bool fast = !getenv("MMT_TRIGGER_PLAIN") && (text.is_packed() || (reinterpret_cast<uintptr_t>(text.v + 1) & 15u) == 0);
 #define MMT_TRIG(WW) for_trigger_slices(n, [&](uint32_t b0, uint32_t cnt) { \
         hipLaunchKernelGGL((k_trigger_masks_fast<256, WW>), dim3(cnt), dim3(256), 0, s, text, n, (uint32_t)pot, pe, qinv, qlim, \
                            masks, block_count, b0); })
@@ -259,11 +259,17 @@ void phrase_bounds(const void* cuts, uint32_t n_cuts, uint64_t n, uint32_t w, vo
 // phrases here and every merge is verified byte by byte in k_mark_distinct).
 #define MMT_B1 0x9E3779B97F4A7C15ull
 #define MMT_B2 0xC2B2AE3D27D4EB4Full
-__device__ __forceinline__ void hash_range(const uint8_t* __restrict__ v, uint64_t lo, uint64_t hi, uint64_t& h1,
+template <typename V>
+__device__ __forceinline__ uint8_t v_at(const V& v, uint64_t i);
+template <> __device__ __forceinline__ uint8_t v_at<const uint8_t*>(const uint8_t* const& v, uint64_t i) { return v[i]; }
+template <> __device__ __forceinline__ uint8_t v_at<uint8_t*>(uint8_t* const& v, uint64_t i) { return v[i]; }
+template <> __device__ __forceinline__ uint8_t v_at<TextRef>(const TextRef& v, uint64_t i) { return tx_byte(v, i); }
+template <typename V>
+__device__ __forceinline__ void hash_range(const V& v, uint64_t lo, uint64_t hi, uint64_t& h1,
                                            uint64_t& h2, uint64_t& p1, uint64_t& p2) {
     h1 = 0; h2 = 0; p1 = 1; p2 = 1;
     for (uint64_t i = lo; i < hi; i++) {
-        const uint64_t c = (uint64_t)v[i] + 1;
+        const uint64_t c = (uint64_t)v_at<V>(v, i) + 1;
         h1 = h1 * MMT_B1 + c; h2 = h2 * MMT_B2 + c;
         p1 *= MMT_B1; p2 *= MMT_B2;
     }
@@ -273,9 +279,10 @@ __device__ __forceinline__ void hash_range(const uint8_t* __restrict__ v, uint64
 constexpr uint32_t FP2_HI_MASK = 0x00ffffffu;
 constexpr uint32_t HASH_SPAN = 4096;          // bytes of V one wave of k_phrase_hash stages in LDS
 template <typename P>
-__global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict__ start,
+__global__ void k_phrase_hash(const TextRef T, const P* __restrict__ start,
                               const uint32_t* __restrict__ len, uint32_t m, uint64_t* __restrict__ o1,
                               uint4* __restrict__ pinfo) {
+    const uint8_t* const v = T.v;                      // (nullptr: packed text -- every lane reads its phrase through the accessor)
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
     const bool have = k < m;
@@ -292,7 +299,7 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict
         const uint32_t wave = threadIdx.x >> 6;
         uint8_t* const mine = s_span + wave * (HASH_SPAN + 32);
         const uint64_t a_first = __shfl(a, 0, 64), a_last = __shfl(a, 63, 64), l_last = __shfl(l, 63, 64);
-        const bool whole = __ballot(have) == ~0ull && __ballot(is_long) == 0 && k >= 64;
+        const bool whole = v != nullptr && __ballot(have) == ~0ull && __ballot(is_long) == 0 && k >= 64;
         const uint64_t lo16 = ((uint64_t)(uintptr_t)(v + a_first)) & ~(uint64_t)15;
         const uint64_t end = (uint64_t)(uintptr_t)(v + a_last + l_last);
         if (whole && end - lo16 <= HASH_SPAN) {
@@ -302,8 +309,8 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_s_waitcnt(0);
             const uint32_t o = (uint32_t)((uint64_t)(uintptr_t)(v + a) - lo16);
-            hash_range(mine, o, (uint64_t)o + l, h1, h2, p1, p2);
-        } else if (have && !is_long) hash_range(v, a, a + l, h1, h2, p1, p2);
+            hash_range<uint8_t*>(mine, o, (uint64_t)o + l, h1, h2, p1, p2);
+        } else if (have && !is_long) hash_range<TextRef>(T, a, a + l, h1, h2, p1, p2);
     }
     // long phrases (no trigger inside a low-complexity run): the whole wave hashes one phrase
     uint64_t todo = __ballot(have && is_long);
@@ -315,7 +322,7 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict
         const uint64_t lo = A + (uint64_t)lane * chunk < A + L ? A + (uint64_t)lane * chunk : A + L;
         const uint64_t hi = lo + chunk < A + L ? lo + chunk : A + L;
         uint64_t c1, c2, q1, q2;
-        hash_range(v, lo, hi, c1, c2, q1, q2);
+        hash_range<TextRef>(T, lo, hi, c1, c2, q1, q2);
         uint64_t t1 = 0, t2 = 0;
         for (int s = 0; s < 64; s++) {                 // left-to-right combine, identical on every lane
             const uint64_t x1 = __shfl(c1, s, 64), x2 = __shfl(c2, s, 64);
@@ -330,7 +337,7 @@ __global__ void k_phrase_hash(const uint8_t* __restrict__ v, const P* __restrict
         pinfo[k] = make_uint4((uint32_t)g2, ((uint32_t)(g2 >> 32) & FP2_HI_MASK) | ((uint32_t)(a >> 32) << 24), (uint32_t)a, l);
     }
 }
-void phrase_hash(const uint8_t* v, const void* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
+void phrase_hash(const TextRef& v, const void* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
                  bool wide, hipStream_t s) {
     if (wide)
         hipLaunchKernelGGL(k_phrase_hash<uint64_t>, dim3(grid_for(m, 256)), dim3(256), 0, s, v,
@@ -358,7 +365,7 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t* p) { uint64_t x; __built
 // comparing the bytes; a mismatch there (a 128-bit collision) raises err[0] instead of silently merging two
 // different phrases.  The second fingerprint, start and length of a phrase sit in one 16-byte record.
 __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64_t* __restrict__ h1s,
-                                const uint4* __restrict__ pinfo, const uint8_t* __restrict__ v, uint32_t m,
+                                const uint4* __restrict__ pinfo, const TextRef T, uint32_t m,
                                 uint32_t* __restrict__ flags, uint32_t* __restrict__ err) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63;
@@ -377,15 +384,15 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
     // phrases need not be adjacent any more -- the host then repeats the grouping with both fingerprints
     if (same1 && !same) atomicOr(err + 1, 1u);
     // byte verification; the loop runs while any lane of the wave still compares
-    const uint8_t* px = v + (((uint64_t)(X.y >> 24) << 32) | X.z);
-    const uint8_t* py = v + (((uint64_t)(Y.y >> 24) << 32) | Y.z);
+    const uint64_t px = ((uint64_t)(X.y >> 24) << 32) | X.z;       // V indices
+    const uint64_t py = ((uint64_t)(Y.y >> 24) << 32) | Y.z;
     const uint32_t l = X.w;
     bool verified = same;
     // (16 bytes per step: the two loads of a step are independent and in flight together)
-    auto chunk = [&](const uint8_t* p, uint32_t i) -> uint64_t {
+    auto chunk = [&](uint64_t p, uint32_t i) -> uint64_t {
         uint64_t x = 0;
-        if (i + 8 <= l) x = ld64(p + i);
-        else for (uint32_t t = i; t < l; t++) x |= (uint64_t)p[t] << (8 * (t - i));
+        if (i + 8 <= l) x = tx_load8(T, p + i);
+        else for (uint32_t t = i; t < l; t++) x |= (uint64_t)tx_byte(T, p + t) << (8 * (t - i));
         return x;
     };
     for (uint32_t i = 0; __ballot(same && i < l) != 0; i += 16) {
@@ -406,7 +413,7 @@ __global__ void k_mark_distinct(const uint32_t* __restrict__ order, const uint64
         }
     }
 }
-void mark_distinct(const uint32_t* order, const uint64_t* h1s, const void* pinfo, const uint8_t* v, uint32_t m,
+void mark_distinct(const uint32_t* order, const uint64_t* h1s, const void* pinfo, const TextRef& v, uint32_t m,
                    uint32_t* flags, uint32_t* err, hipStream_t s) {
     hipLaunchKernelGGL(k_mark_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, order, h1s,
                        static_cast<const uint4*>(pinfo), v, m, flags, err);
@@ -435,7 +442,7 @@ void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t
 // word: length of the phrase suffix that starts at pos (0 on separators), bit 31 set on the first
 // byte of a phrase.  One wave per phrase.
 template <typename P>
-__global__ void k_copy_dict(const uint8_t* __restrict__ v, const P* __restrict__ start,
+__global__ void k_copy_dict(const TextRef v, const P* __restrict__ start,
                             const uint32_t* __restrict__ len, const uint32_t* __restrict__ which,
                             const uint32_t* __restrict__ dstart, uint32_t n_phr, uint8_t* __restrict__ dict,
                             uint64_t* __restrict__ dinfo, uint32_t dict_len, int pack_prev) {
@@ -449,11 +456,11 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const P* __restrict__
     // record, so that k_entry_info needs one random read per dictionary suffix instead of two.  The byte before
     // the first character of a phrase is the terminator of the phrase before it (padding for the first phrase).
     for (uint32_t i = lane; i < l; i += 64) {
-        const uint8_t c = v[a + i];
+        const uint8_t c = tx_byte(v, a + i);
         dict[o + i] = c;
         if (dinfo) {
             uint64_t hi = wave;
-            if (pack_prev) hi |= (uint64_t)(i ? v[a + i - 1] : (wave ? (uint8_t)1 : (uint8_t)0)) << 24;
+            if (pack_prev) hi |= (uint64_t)(i ? tx_byte(v, a + i - 1) : (wave ? (uint8_t)1 : (uint8_t)0)) << 24;
             dinfo[o + i] = (hi << 32) | (uint64_t)((l - i) | (i == 0 ? 0x80000000u : 0u));
         }
     }
@@ -461,7 +468,7 @@ __global__ void k_copy_dict(const uint8_t* __restrict__ v, const P* __restrict__
         dict[o + l] = 1;
         if (dinfo) {
             uint64_t hi = wave;
-            if (pack_prev) hi |= (uint64_t)v[a + l - 1] << 24;
+            if (pack_prev) hi |= (uint64_t)tx_byte(v, a + l - 1) << 24;
             dinfo[o + l] = hi << 32;
         }
         if (wave + 1 == n_phr) {
@@ -485,7 +492,7 @@ void sum_u32(const uint32_t* x, uint32_t n, uint64_t* d_out, hipStream_t s) {
                        reinterpret_cast<unsigned long long*>(d_out));
     MMT_HIP(hipGetLastError());
 }
-void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const uint32_t* which,
+void copy_dict(const TextRef& v, const void* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
                bool pack_prev, bool wide, hipStream_t s) {
     if (wide)

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "parse_lcp.hpp"
+#include "textref.hpp"
 #include "wide.hpp"
 
 namespace mmt { namespace pk {
@@ -16,23 +17,23 @@ namespace mmt { namespace pk {
 // trigger positions in two passes: 16-bit masks (one per 16 text positions) + triggers per workgroup; then, given the
 // exclusive scan of those counts, the positions themselves (ascending)
 uint32_t trigger_blocks(uint64_t n);
-void trigger_masks(const uint8_t* text, uint64_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
+void trigger_masks(const TextRef& text, uint64_t n, uint32_t w, uint32_t p, uint16_t* masks, uint32_t* block_count,
                    hipStream_t s);
 void trigger_cuts(const uint16_t* masks, uint64_t n, const uint32_t* block_off, void* cuts, bool wide, hipStream_t s);
 void phrase_bounds(const void* cuts, uint32_t n_cuts, uint64_t n, uint32_t w, void* start, uint32_t* len, bool wide,
                    hipStream_t s);
 // h1: first fingerprint per phrase; pinfo: 16-byte record per phrase (56 bits of the second fingerprint, start (40
 // bits), length)
-void phrase_hash(const uint8_t* v, const void* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
+void phrase_hash(const TextRef& v, const void* start, const uint32_t* len, uint32_t m, uint64_t* h1, void* pinfo,
                  bool wide, hipStream_t s);
 void second_fingerprint(const void* pinfo, uint32_t m, uint64_t* h2, hipStream_t s);
-void mark_distinct(const uint32_t* order, const uint64_t* h1_sorted, const void* pinfo, const uint8_t* v, uint32_t m,
+void mark_distinct(const uint32_t* order, const uint64_t* h1_sorted, const void* pinfo, const TextRef& v, uint32_t m,
                    uint32_t* flags, uint32_t* err, hipStream_t s);
 void assign_distinct(const uint32_t* order, const uint32_t* scan, const uint32_t* flags, const uint32_t* len,
                      uint32_t m, uint32_t* pid, uint32_t* rep, uint32_t* dlen, hipStream_t s);
 // *d_out = x[0] + ... + x[n - 1] in 64 bits
 void sum_u32(const uint32_t* x, uint32_t n, uint64_t* d_out, hipStream_t s);
-void copy_dict(const uint8_t* v, const void* start, const uint32_t* len, const uint32_t* which,
+void copy_dict(const TextRef& v, const void* start, const uint32_t* len, const uint32_t* which,
                const uint32_t* dstart, uint32_t n_phr, uint8_t* dict, uint64_t* dinfo, uint32_t dict_len,
                bool pack_prev, bool wide, hipStream_t s);
 void entry_info(const uint32_t* sa_d, const uint64_t* dinfo, const uint8_t* dict, uint32_t nd, bool pack_prev,

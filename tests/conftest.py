@@ -26,3 +26,12 @@ def _have_gpu():
 @pytest.fixture(scope="session")
 def gpu_available():
     return _have_gpu()
+
+
+# MMT_PACKED_TEXT=1 runs every collection through the two-bit text (textref.hpp), which only the bucket-wise producer reads:
+# assertions about which producer ran accept "guided" then
+PACKED_TEXT = os.environ.get("MMT_PACKED_TEXT", "0") not in ("", "0")
+
+
+def producer_is(engine, kind):
+    return engine.producer_used() == ("guided" if PACKED_TEXT else kind)

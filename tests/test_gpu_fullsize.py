@@ -242,3 +242,5 @@ def test_a_rank_share_of_configs3_anchor_and_twelve_whole_genome_haplotypes():
         assert 0 < t < int(L[r]), (r, t, int(L[r]))
     assert int(np.count_nonzero(th[: length + 1])) >= len(L)
     eng.close()
+    eng.L.mmt_pool_trim()          # (250 GB of mapped heap would leave the command-line tests of other files, which run as
+    #                                processes of their own on the same GPU, with nothing)

@@ -9,6 +9,7 @@ import pytest
 
 import pyoracle as O
 from mumemto_amd import synth
+from conftest import producer_is
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -40,7 +41,7 @@ def test_automatic_producer_goes_by_the_number_of_documents():
     for n_docs, expected in ((3, "direct"), (4, "direct"), (5, "pfp"), (9, "pfp")):
         e.set_docs(synth.pangenome(n_docs, 8000, 0.01, seed=n_docs))
         e.run()
-        assert e.producer_used() == expected
+        assert producer_is(e, expected)
     e.close()
 
 

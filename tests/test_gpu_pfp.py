@@ -10,6 +10,7 @@ import pytest
 
 import pyoracle as O
 from mumemto_amd import synth
+from conftest import producer_is, PACKED_TEXT
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "newscan")
@@ -63,7 +64,7 @@ def test_stream_through_the_parse(engine, case, wp):
         engine.set_producer("pfp", *wp)
         engine.set_docs(docs)
         engine.run(use_revcomp=revcomp, merge_metadata=True)
-        assert engine.producer_used() == "pfp"
+        assert producer_is(engine, "pfp")
         text, doc_start = O.build_text(docs, revcomp)
         sa, lcp, bwt = O.build_stream(text)
         assert np.array_equal(engine.sa().astype(np.int64), sa[1:])
@@ -88,7 +89,9 @@ def test_parse_statistics_equal_the_oracles_parse(engine, wp):
         counts = engine.pfp_counts()
         text, _ = O.build_text(docs, True)
         stats = O.build_stream_pfp(text, *wp)[3]
-        assert (counts["phrases"], counts["distinct"], counts["dict_len"]) == stats[:3], (case, counts, stats)
+        # (a packed text -- MMT_PACKED_TEXT=1 -- goes through the bucket-wise producer, which builds no dictionary text)
+        k = 2 if PACKED_TEXT else 3
+        assert (counts["phrases"], counts["distinct"], counts["dict_len"])[:k] == stats[:k], (case, counts, stats)
     engine.set_producer("auto")
 
 
@@ -128,7 +131,7 @@ def _check_fallback(engine, docs, wps):
         assert np.array_equal(engine.sa().astype(np.int64), sa[1:])
         assert np.array_equal(engine.bwt(), bwt[1:])
         assert engine.output_text() == O.run(docs, min_len=20, max_doc_freq=0, num_distinct=2, max_total_freq=50).text()
-    assert saw_fallback
+    assert saw_fallback or PACKED_TEXT          # (the segmented fallback belongs to the emitter of the parse proper)
 
 
 def test_parse_is_the_same_as_a_cpu_restatement_on_bigger_input(engine):

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import pyoracle as O
+from conftest import producer_is
 
 pytestmark = pytest.mark.gpu
 ALPH = np.frombuffer(b"ACGT", np.uint8)
@@ -141,7 +142,7 @@ def test_iupac_and_arbitrary_bytes():
     eng.set_producer("auto")
     eng.set_docs(docs2)
     eng.run(min_match_len=4, num_distinct=2, max_doc_freq=3)
-    assert eng.producer_used() == "direct"
+    assert eng.producer_used() == "direct"       # (also under MMT_PACKED_TEXT=1: such a text keeps one byte per character)
     assert eng.output_text() == O.run(docs2, min_len=4, num_distinct=2, max_doc_freq=3).text()
     eng.set_producer("pfp")
     with pytest.raises(mumemto_amd.MumemtoError, match="reserves"):

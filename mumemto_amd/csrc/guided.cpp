@@ -310,7 +310,11 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     gk::Ctx& ctx = S.gctx;
     const bool W = wide_;
     const uint32_t m = S.n_phrases, D = S.n_distinct;
-    ctx.g_n = 0; ctx.g_depth = 24u * (uint32_t)ctx.chars;
+    // (the threshold follows the modulus of the parse: beyond 48 G characters the modulus grows with the text -- p = 157 at
+    // 250 G characters -- and an ordinary phrase of a few hundred characters must not count as giant: twelve mean phrase
+    // lengths leave e^-12 of the phrases, 24 key lengths at the moduli of the smaller texts as before)
+    ctx.g_n = 0;
+    ctx.g_depth = std::max<uint32_t>(24u, (12u * S.p + (uint32_t)ctx.chars - 1) / (uint32_t)ctx.chars) * (uint32_t)ctx.chars;
     S.gi_occ = S.gi_distinct = S.gi_chars = 0;
     if (std::getenv("MMT_GUIDED_NO_GIANT")) return;
     if (const char* c = std::getenv("MMT_GIANT_DEPTH")) ctx.g_depth = (uint32_t)std::max(1, std::atoi(c)) * (uint32_t)ctx.chars;

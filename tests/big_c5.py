@@ -1,0 +1,58 @@
+"""GPU box helper: BASELINE configs[4] in the shape one rank of eight sees it -- partial multi-MEMs (-k -1 -f 3) over a collection
+of whole-genome haplotypes that EVERY rank holds in full, the text packed to two bits per character (textref.hpp), the rank
+producing, scanning and dropping only its share of the stream (whole bins of leading characters: guided.cpp).
+
+usage: big_c5.py [--haps 41] [--length 3050000000] [--rank 3] [--ranks 8] [--div 0.001] [--seed 4]
+Prints seconds, stage times, device memory (peak), the share of the stream the rank produced, rows; checks sampled rows
+(every occurrence spells the same string, at least N - 1 documents, at most 3 per document, maximal)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import mumemto_amd
+from mumemto_amd import synth
+import bigchecks
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--haps", type=int, default=41)
+ap.add_argument("--length", type=int, default=3_050_000_000)
+ap.add_argument("--rank", type=int, default=3)
+ap.add_argument("--ranks", type=int, default=8)
+ap.add_argument("--div", type=float, default=0.001)
+ap.add_argument("--seed", type=int, default=4)
+ap.add_argument("--samples", type=int, default=200)
+ap.add_argument("--wp", type=int, nargs=2, default=None, help="window and modulus of the parse (default: automatic)")
+A = ap.parse_args()
+N, L0 = A.haps, A.length
+t0 = time.time()
+bases = np.empty(N * L0, np.uint8)
+for k, (h, b) in enumerate(synth.haplotypes_sparse(94, L0, A.div, A.seed, which=list(range(N)))):
+    bases[k * L0:(k + 1) * L0] = b
+lens = np.full(N, L0, np.uint64)
+n_text = 2 * N * (L0 + 1)
+print(json.dumps(dict(generated_s=round(time.time() - t0, 1), haps=N, length=L0, text_chars=n_text)), flush=True)
+os.environ["MMT_GUIDED_STATS"] = "1"
+eng = mumemto_amd.Engine(0)
+eng.set_scan_shard(A.rank, A.ranks)
+if A.wp:
+    eng.set_producer("guided", A.wp[0], A.wp[1])
+t = time.time()
+parts = eng.run_partitioned(None, flat=(bases, lens), num_distinct=N - 1, max_doc_freq=3)
+dt = time.time() - t
+mem = eng.device_memory()
+pieces = eng.sort_pieces()
+st = eng.stream_stats()
+L, occ, off, ids, strands = eng.rows_mem()
+print(json.dumps(dict(mode="-k -1 -f 3", rank=A.rank, ranks=A.ranks, text_chars=eng.text_length(), seconds=round(dt, 1),
+                      one_run=parts == 1, producer=eng.producer_used(), wide=bool(eng.is_wide()),
+                      stage_ms=[round(x) for x in eng.stage_ms()],
+                      share_of_the_stream=dict(first_entry=pieces[A.rank][0], entries=pieces[A.rank][1],
+                                               fraction=round(pieces[A.rank][1] / eng.text_length(), 4), produced=st["entries"],
+                                               windows=st["windows"], window_bytes=st["window_bytes"]),
+                      memory_gb={k: round(v / 2**30, 1) for k, v in mem.items() if k != "map_seconds"},
+                      rows=int(len(L)), occurrences=int(len(off)))), flush=True)
+assert parts == 1 and eng.producer_used() == "guided" and eng.is_wide()
+assert st["entries"] == pieces[A.rank][1], "the rank produced something else than its share of the stream"
+assert abs(pieces[A.rank][1] / eng.text_length() - 1.0 / A.ranks) < 0.05
+bigchecks.check_mem_rows(eng, bases, lens, min_docs=N - 1, max_doc_freq=3, samples=A.samples, text=bigchecks.LazyText(bases, lens))
+print("OK")

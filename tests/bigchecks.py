@@ -173,3 +173,54 @@ def check_mem_rows(eng, bases, lens, min_docs, max_doc_freq, samples=300, seed=2
         assert len(lefts) > 1 and len(rights) > 1, ("row is not maximal", r)
     assert checked > 0
     print("rows: %d rows with %d occurrences; %d sampled rows are real, maximal matches" % (len(L), len(off), checked), flush=True)
+
+
+class LazyText:
+    """T = F $ revcomp(F) $ per document, read from the bases on demand (a 250 G-character text does not get a host copy):
+    text[i] and text[a:b] as numpy uint8, positions beyond the text read as 0."""
+
+    def __init__(self, bases, lens):
+        self.bases, self.lens = bases, [int(l) for l in lens]
+        self.doc_start = np.concatenate([[0], np.cumsum([2 * (l + 1) for l in self.lens])]).astype(np.int64)
+        self.base_start = np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int64)
+        self.n = int(self.doc_start[-1])
+
+    def _piece(self, d, lo, hi):
+        """local positions [lo, hi) of document d"""
+        L = self.lens[d]
+        f = self.bases[self.base_start[d]:self.base_start[d + 1]]
+        out = np.empty(hi - lo, np.uint8)
+        for k, p in enumerate(range(lo, hi)):
+            if p < L:
+                out[k] = f[p]
+            elif p == L or p == 2 * L + 1:
+                out[k] = 36
+            else:
+                out[k] = _COMP[f[2 * L - p]]
+        return out
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b = key.start or 0, self.n + 64 if key.stop is None else key.stop
+            out = np.zeros(max(b - a, 0), np.uint8)
+            p = a
+            while p < min(b, self.n):
+                d = int(np.searchsorted(self.doc_start, p, side="right")) - 1
+                end = min(b, int(self.doc_start[d + 1]))
+                lo = p - int(self.doc_start[d])
+                # long stretches inside one strand: vectorised
+                L = self.lens[d]
+                f = self.bases[self.base_start[d]:self.base_start[d + 1]]
+                hi = end - int(self.doc_start[d])
+                if hi <= L:
+                    out[p - a:end - a] = f[lo:hi]
+                elif lo > L and hi <= 2 * L + 1:
+                    out[p - a:end - a] = _COMP[f[2 * L - hi + 1:2 * L - lo + 1][::-1]]
+                else:
+                    out[p - a:end - a] = self._piece(d, lo, hi)
+                p = end
+            return out
+        i = int(key)
+        if i < 0 or i >= self.n:
+            return np.uint8(0)
+        return self[i:i + 1][0]

@@ -283,8 +283,11 @@ void Engine::guided_prepare() {
         sorter_.release();
     }
     S.plcp.build(text_ref(), n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
-    S.sa_p.release(); S.parse.release(); S.pid.release(); S.rep.release(); S.prank.release(); S.pstart.release();
+    // (the distinct-phrase ids stay: two suffixes of a group that start at the same offset of the same distinct phrase spell
+    // the same alpha -- gk::med_before asks the ids before it compares characters)
+    S.sa_p.release(); S.parse.release(); S.rep.release(); S.prank.release(); S.pstart.release();
     S.plen.release(); S.dlen.release(); S.dstart.release();
+    ctx.pid = std::getenv("MMT_GUIDED_NO_PID") ? nullptr : S.pid.get();
     e5.stop(st);
     if (stats) std::fprintf(stderr, "[guided] parse of %u phrases sorted in %.1f ms (%d rounds)\n", m, ms_since(t0), S.rounds_parse);
     ctx.skip = 0; ctx.isa_p = S.isa_p.get();

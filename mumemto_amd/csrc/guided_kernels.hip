@@ -565,6 +565,12 @@ struct MedStage {
     uint64_t rank[W];
     uint64_t rec[W];
     uint32_t len[W];
+    uint32_t pid[W];                  // id of the distinct phrase the member starts in (0xffffffff: unknown)
+    // every member against the FIRST member of its group: where the two alphas first differ (MED_SAME: they are the same
+    // alpha; MED_UNKNOWN: not computed -- giant phrases, elements that are whole phrases), the member's and the first
+    // member's character there
+    uint32_t dref[W];
+    uint16_t cref[W];
     uint32_t gr[W], gg[W];            // members in giant phrases: entry of the giant dictionary's suffix array at `offset`, its group
     uint8_t idx[W];
     uint32_t bad;
@@ -572,12 +578,52 @@ struct MedStage {
 // Order of two staged members (true: a sorts before b).  What the staged characters do not decide -- both alphas longer
 // than what was staged and equal so far -- is compared in the text itself.  *lcp (optional) receives the number of
 // characters the two suffixes share when the order was decided by a character; ~0 when they spell the same alpha.
+constexpr uint32_t MED_SAME = 0xffffffffu, MED_UNKNOWN = 0xfffffffeu;
+template <int W>
+__device__ __forceinline__ bool med_before_chars(const Ctx& c, MedStage<W>& S, uint32_t a, uint32_t b, uint64_t offset, uint64_t* lcp);
+// The members of a group are the copies of one locus: most spell the same alpha, the others differ from it in one place.
+// Comparing two of them character by character costs a chain of dependent loads that runs up to that place -- and the
+// sorting network asks log^2 times per member, every stage as slow as its slowest lane (with the phrases of a 250 G-character
+// text, 171 characters on average, that was 5.1 of the 5.5 s a G suffixes took).  Each member is compared ONCE instead, with
+// the first member of its group (k_resolve_medium, after the staging): d = the first position where its alpha differs
+// from that one's.  Then for two members a, b: d_a < d_b: b agrees with the first member at d_a, so a's character there
+// against the first member's decides, and they share d_a characters; d_a = d_b: their own characters there decide, and only
+// if those are equal too (the same variant in two haplotypes) does the comparison go on in the text.
 template <int W>
 __device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_t a, uint32_t b, uint64_t offset, uint64_t* lcp) {
+    const uint32_t da = S.dref[a], db = S.dref[b];
+    if (da == MED_UNKNOWN || db == MED_UNKNOWN) return med_before_chars<W>(c, S, a, b, offset, lcp);
+    if (lcp) *lcp = ~0ull;
+    if (da != db) {
+        const bool a_first = da < db;
+        const uint32_t x = a_first ? a : b;
+        const uint32_t cc = S.cref[x];
+        if (lcp) *lcp = a_first ? da : db;
+        const bool x_small = (cc & 0xffu) < (cc >> 8);            // x's character against the first member's (= the other's)
+        return a_first ? x_small : !x_small;
+    }
+    if (da != MED_SAME) {
+        const uint32_t ca = S.cref[a] & 0xffu, cb = S.cref[b] & 0xffu;
+        if (ca != cb) { if (lcp) *lcp = da; return ca < cb; }
+        const int r2 = cmp_rest(c, rec_pos(c, S.rec[a]), S.len[a], rec_pos(c, S.rec[b]), S.len[b], (uint64_t)da + 1, lcp);
+        if (r2) return r2 < 0;
+    }
+    if (S.len[a] != S.len[b]) S.bad = 1;
+    const uint64_t ra = S.rank[a], rb = S.rank[b];
+    return ra < rb || (ra == rb && a < b);
+}
+template <int W>
+__device__ __forceinline__ bool med_before_chars(const Ctx& c, MedStage<W>& S, uint32_t a, uint32_t b, uint64_t offset, uint64_t* lcp) {
     const uint64_t la = S.len[a], lb = S.len[b];
     const uint64_t L = la < lb ? la : lb;
     if (lcp) *lcp = ~0ull;
-    if (S.gr[a] != 0xffffffffu && S.gr[b] != 0xffffffffu) {
+    // The same distinct phrase and the same number of characters left of it: the same alpha, nothing to compare -- the copies
+    // of one locus in the haplotypes that carry no mutation inside the phrase, i.e. most members of a group.  (With the
+    // long phrases of a text of hundreds of G characters -- modulus 157 at 250 G -- nearly every pair used to run off the
+    // staged characters into the text: 5.1 of 5.5 s per G suffixes.)
+    const bool same_alpha = la == lb && S.pid[a] == S.pid[b] && S.pid[a] != 0xffffffffu;
+    if (same_alpha) {
+    } else if (S.gr[a] != 0xffffffffu && S.gr[b] != 0xffffffffu) {
         // two members in giant phrases: the giant dictionary knows their order and what they share
         const uint32_t ra = S.gr[a], rb = S.gr[b];
         if (S.gg[a] != S.gg[b]) {
@@ -637,7 +683,15 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             for (uint32_t t = 0; t < MED_WORDS; t++) S.w[i][t] = tx_load8(c.T, q + offset + 8 * t);
             const uint64_t len = rec_len(c, rec, q);
             S.len[i] = len < 0xffffffffull ? (uint32_t)len : 0xffffffffu;
-            S.rank[i] = c.skip ? 0ull : rec_rank_key(c, rec, q);
+            uint32_t pid = 0xffffffffu;
+            if (c.skip) S.rank[i] = 0ull;
+            else if (c.rec_rank) S.rank[i] = rec >> c.pos_bits;      // (no phrase lookup at all: the id is not worth three lines)
+            else {                                                  // (one rank query serves both lookups)
+                const uint32_t k = rank1(c, query_point(c, q));
+                S.rank[i] = k + 1 < c.m ? (uint64_t)c.isa_p[k + 1] : 0ull;
+                if (c.pid) pid = c.pid[k];
+            }
+            S.pid[i] = pid;
             S.rec[i] = rec;
             uint32_t r = 0xffffffffu;
             // (what the staged words cannot decide is looked up, not compared, when the member lies in a giant phrase)
@@ -647,6 +701,50 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
         }
     }
     // (a wave works on its own stage: ordering its LDS traffic inside the wave is all the synchronisation there is)
+    MMT_WAVE_SYNC();
+    // every member against the first member of its group (med_before)
+#pragma unroll
+    for (int h = 0; h < PERL; h++) {
+        const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
+        if (mem >= s_g[wave][seg]) continue;
+        const uint32_t ref = seg * SEG;
+        uint32_t d = MED_UNKNOWN, cc = 0;
+        if (!c.skip && S.gr[i] == 0xffffffffu && S.gr[ref] == 0xffffffffu && !(c.g_n && S.len[ref] > offset + 8 * MED_WORDS && S.len[i] > offset + 8 * MED_WORDS && c.g_depth <= offset + 8 * MED_WORDS)) {
+            const uint64_t la = S.len[i], lb = S.len[ref], L = la < lb ? la : lb;
+            if (i == ref || (la == lb && S.pid[i] == S.pid[ref] && S.pid[i] != 0xffffffffu)) d = MED_SAME;
+            else {
+                d = MED_SAME;
+                bool decided = false;
+#pragma unroll
+                for (uint32_t t = 0; t < MED_WORDS && !decided; t++) {
+                    const uint64_t at = offset + 8 * t;
+                    if (at >= L) { decided = true; break; }
+                    const uint64_t x = S.w[i][t], y = S.w[ref][t];
+                    if (x != y) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+                        if (at + k < L) { d = (uint32_t)(at + k); cc = (uint32_t)((x >> (8 * k)) & 0xff) | ((uint32_t)((y >> (8 * k)) & 0xff) << 8); }
+                        decided = true;
+                    }
+                }
+                if (!decided) {
+                    const uint64_t qa = rec_pos(c, S.rec[i]), qb = rec_pos(c, S.rec[ref]);
+                    // (a stretch that runs into giant depth is the giant dictionary's: left to the comparison of characters)
+                    const uint64_t stop = c.g_n && L > (uint64_t)c.g_depth ? (uint64_t)c.g_depth : L;
+                    for (uint64_t t = offset + 8 * MED_WORDS; t < stop; t += 8) {
+                        const uint64_t x = tx_load8(c.T, qa + t), y = tx_load8(c.T, qb + t);
+                        if (x != y) {
+                            const uint32_t k = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
+                            if (t + k < L) { d = (uint32_t)(t + k); cc = (uint32_t)((x >> (8 * k)) & 0xff) | ((uint32_t)((y >> (8 * k)) & 0xff) << 8); }
+                            decided = true;
+                            break;
+                        }
+                    }
+                    if (!decided && stop < L) d = MED_UNKNOWN;
+                }
+            }
+        }
+        S.dref[i] = d; S.cref[i] = (uint16_t)cc;
+    }
     MMT_WAVE_SYNC();
     // bitonic network over the SEG index slots of every group (members beyond the group sort last): log^2 steps of
     // compare-exchanges instead of g^2 / 2 comparisons

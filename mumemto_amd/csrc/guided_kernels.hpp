@@ -37,6 +37,7 @@ struct Ctx {
     uint32_t pos_bits;         // element records: position in the low pos_bits bits, above it ...
     uint32_t rec_rank;         // ... 1: the rank of the following parse suffix, 0: the length of alpha (pos_bits = 40)
     uint32_t tile0 = 0;        // first tile of this launch (the text-order kernels run in slices of 2^23 tiles)
+    const uint32_t* pid = nullptr;   // text suffixes: id of the distinct phrase at parse position k (m entries), or nullptr
     // Giant phrases (longer than g_depth characters: a run of N, a microsatellite -- no trigger of the parse falls inside a
     // periodic run, newscan.hpp:265-325): their suffixes are sorted once, as a small dictionary of their own, and a
     // comparison that is still undecided g_depth characters into alpha continues on those ranks instead of on characters.

@@ -36,6 +36,7 @@ Engine::~Engine() {
 
 void Engine::set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs) {
     MMT_HIP(hipSetDevice(device_));
+    host_docs_.clear();
     d_bases_ = d_bases;
     preset_ = 0;
     input_valid_ = true;
@@ -80,6 +81,13 @@ void Engine::set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* 
     }
     MMT_HIP(hipStreamSynchronize(stream_));
     set_input_device(d_bases_own_.get(), doc_len, n_docs);
+}
+
+void Engine::set_input_host_docs_deferred(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs) {
+    MMT_HIP(hipSetDevice(device_));
+    d_bases_own_.release();
+    set_input_device(nullptr, doc_len, n_docs);
+    host_docs_.assign(doc_ptr, doc_ptr + n_docs);
 }
 
 // document layout of the text: starts of the documents, total length, device copy of the starts
@@ -214,6 +222,19 @@ void Engine::build_text(bool revcomp) {
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
     packed_ = want_packed_text();
+    const bool deferred = !host_docs_.empty() && d_bases_ == nullptr;
+    auto upload_deferred = [&]() {                     // the byte layout reads all raw bases from the device
+        uint64_t total = 0;
+        for (size_t d = 0; d < N; d++) total += doc_len_[d];
+        d_bases_own_.ensure(total + 16);
+        uint64_t at = 0;
+        for (size_t d = 0; d < N; d++) {
+            if (doc_len_[d]) MMT_HIP(hipMemcpyAsync(d_bases_own_.get() + at, host_docs_[d], doc_len_[d], hipMemcpyHostToDevice, stream_));
+            at += doc_len_[d];
+        }
+        MMT_HIP(hipStreamSynchronize(stream_));
+        d_bases_ = d_bases_own_.get();
+    };
     if (packed_) {
         d_text_.release();
         const size_t words = (size_t)((n_ + 31) / 32) + 8;
@@ -224,8 +245,40 @@ void Engine::build_text(bool revcomp) {
         DevBuf<uint32_t> ev_count;
         ev_start.ensure(ev_cap); ev_end.ensure(ev_cap); ev_count.ensure(2);
         MMT_HIP(hipMemsetAsync(ev_count.get(), 0, 8, stream_));
-        k::pack_text(d_bases_, d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N, d_packed_.get(), n_,
-                     d_hist_.get(), ev_start.get(), ev_end.get(), ev_count.get(), ev_cap, stream_);
+        if (deferred) {
+            // document by document through two staging buffers: the copy of document d + 1 runs beside the packing of d
+            uint64_t longest = 0;
+            for (size_t d = 0; d < N; d++) longest = std::max(longest, doc_len_[d]);
+            DevBuf<uint8_t> stage[2];
+            stage[0].ensure(longest + 64); stage[1].ensure(longest + 64);
+            hipStream_t cs = nullptr;
+            MMT_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipEvent_t copied[2], packed_ev[2];
+            for (int k = 0; k < 2; k++) { MMT_HIP(hipEventCreateWithFlags(&copied[k], hipEventDisableTiming)); MMT_HIP(hipEventCreateWithFlags(&packed_ev[k], hipEventDisableTiming)); }
+            try {
+                for (size_t d = 0; d < N; d++) {
+                    const int b = (int)(d & 1);
+                    if (d >= 2) MMT_HIP(hipStreamWaitEvent(cs, packed_ev[b], 0));          // the buffer is free again
+                    if (doc_len_[d]) MMT_HIP(hipMemcpyAsync(stage[b].get(), host_docs_[d], doc_len_[d], hipMemcpyHostToDevice, cs));
+                    MMT_HIP(hipEventRecord(copied[b], cs));
+                    MMT_HIP(hipStreamWaitEvent(stream_, copied[b], 0));
+                    // (raw + doc_base[d] = the staging buffer)
+                    k::pack_text(stage[b].get() - doc_base_[d], d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N,
+                                 d_packed_.get(), n_, d_hist_.get(), ev_start.get(), ev_end.get(), ev_count.get(), ev_cap,
+                                 doc_start_[d], doc_start_[d + 1], stream_);
+                    MMT_HIP(hipEventRecord(packed_ev[b], stream_));
+                }
+                MMT_HIP(hipStreamSynchronize(stream_));
+            } catch (...) {
+                (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs);
+                for (int k = 0; k < 2; k++) { (void)hipEventDestroy(copied[k]); (void)hipEventDestroy(packed_ev[k]); }
+                throw;
+            }
+            (void)hipStreamDestroy(cs);
+            for (int k = 0; k < 2; k++) { (void)hipEventDestroy(copied[k]); (void)hipEventDestroy(packed_ev[k]); }
+        } else
+            k::pack_text(d_bases_, d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N, d_packed_.get(), n_,
+                         d_hist_.get(), ev_start.get(), ev_end.get(), ev_count.get(), ev_cap, 0, n_, stream_);
         finish_packed_text(ev_start, ev_end, ev_count, ev_cap);
         // bytes the parse reserves (<= 0x02) are the direct producer's, which reads one byte per character
         std::vector<uint64_t> hist;
@@ -236,6 +289,7 @@ void Engine::build_text(bool revcomp) {
         packed_ = false;
         MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
     }
+    if (deferred) upload_deferred();
     d_packed_.release(); d_excw_.release(); d_runs_.release(); h_runs_.clear();
     d_text_.ensure(TEXT_FRONT + n_ + TEXT_BACK);
     k::build_text(d_bases_, d_doc_base_.get(), d_doc_len_.get(), d_doc_start_.get(), (uint32_t)N, revcomp, text_ptr(), n_,

@@ -77,6 +77,11 @@ public:
     uint64_t auto_max_text() const;
     // the documents in separate host buffers (no concatenation on the host: one H2D copy per document)
     void set_input_host_docs(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs);
+    // The same, but nothing is uploaded yet: the host buffers must stay valid until the next run() has built its text.  A
+    // collection whose raw bases would not fit the device next to its packed text (BASELINE configs[4]: 287 GB of bases,
+    // 143 GB packed) is then packed document by document through a staging buffer (build_text); a text that keeps one byte
+    // per character is uploaded as a whole when the run begins.
+    void set_input_host_docs_deferred(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs);
     // Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): the caller hands over
     // the text T itself (UPPER(F) '$' [revcomp '$'] per document, e.g. rebuilt from PREFIX.parse/.dict) or the
     // whole stream (SA / LCP / BWT of the real suffixes, sentinel entry dropped); run() then skips the stages
@@ -268,6 +273,7 @@ private:
     DevBuf<ExcRun> d_runs_;
     std::vector<ExcRun> h_runs_;
     bool packed_ = false;
+    std::vector<const uint8_t*> host_docs_;        // deferred host input (set_input_host_docs_deferred)
     // One-shot / wide runs: suffix array (low words, high bytes) and BWT are views into one block that is allocated
     // before any scratch (it then sits at the bottom of the device heap, and what is above it leaves one hole when it
     // goes).  The emitter writes these columns only after the dictionary and the parse are sorted, so until then the

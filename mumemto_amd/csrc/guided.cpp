@@ -213,7 +213,20 @@ void Engine::guided_prepare() {
     const uint64_t n_blocks = n_words / 64, n_counts = n_words / 8;
     if (n_blocks < n / 4096 + 2) throw std::runtime_error("cut bit vector too short for the guided sort");
     const uint64_t* mask = reinterpret_cast<const uint64_t*>(S.tmask.get());
-    {
+    // A packed text is a text that fills the device: the phrase ends are kept as a list then (two bytes per phrase + four per
+    // block of 4096 positions) and the bit per position -- 72 GB on 573 G characters, with 9 GB of rank directory -- goes
+    // (MMT_CUT_LIST=0 / 1 overrides: the tests run both forms)
+    const bool cut_list = std::getenv("MMT_CUT_LIST") ? std::atoi(std::getenv("MMT_CUT_LIST")) != 0 : packed_;
+    if (cut_list) {
+        DevBuf<uint32_t> bcount;
+        bcount.ensure(n_blocks + 2); S.g_brank.ensure(n_blocks + 2);
+        MMT_HIP(hipMemsetAsync(bcount.get(), 0, (n_blocks + 2) * 4, st));
+        gk::block_cut_counts(mask, n_words, bcount.get(), n_blocks, st);
+        prims::exclusive_sum_u32(d_temp_, bcount.get(), S.g_brank.get(), n_blocks + 2, st);
+        S.g_coff.ensure((size_t)m + 64);
+        gk::block_cut_offsets(mask, n_words, S.g_brank.get(), S.g_coff.get(), n_blocks, st);
+        MMT_HIP(hipStreamSynchronize(st));
+    } else {
         DevBuf<uint32_t> rcount;
         rcount.ensure(n_counts + 1); S.g_rdir.ensure(n_counts + 1);
         gk::rank_counts(mask, n_words, rcount.get(), n_counts, st);
@@ -232,6 +245,10 @@ void Engine::guided_prepare() {
         MMT_HIP(hipStreamSynchronize(st));
     }
     ctx.mask = mask; ctx.rdir = S.g_rdir.get(); ctx.nxt = S.g_nxt.get();
+    if (cut_list) {
+        ctx.mask = nullptr; ctx.rdir = nullptr; ctx.coff = S.g_coff.get(); ctx.brank = S.g_brank.get();
+        S.tmask.release();
+    }
 
     // ---- the bins of the text suffixes (leading characters) ----
     S.g_nbins = 1u << (ctx.bits * prefix_chars);

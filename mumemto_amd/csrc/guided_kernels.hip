@@ -60,13 +60,55 @@ __global__ void k_block_first_cut(const uint64_t* __restrict__ mask, uint64_t n_
     }
     first[b] = r;
 }
+// phrase ends per block of 4096 positions (64 words), then -- after an exclusive sum of those -- their offsets inside the block
+__global__ void k_block_cut_counts(const uint64_t* __restrict__ mask, uint64_t n_words, uint32_t* __restrict__ counts, uint64_t n_blocks) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint32_t c = 0;
+    for (int t = 0; t < 64; t++) { const uint64_t wi = b * 64 + t; if (wi < n_words) c += (uint32_t)__popcll(mask[wi]); }
+    counts[b] = c;
+}
+__global__ void k_block_cut_offsets(const uint64_t* __restrict__ mask, uint64_t n_words, const uint32_t* __restrict__ brank,
+                                    uint16_t* __restrict__ coff, uint64_t n_blocks) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint32_t at = brank[b];
+    for (int t = 0; t < 64; t++) {
+        const uint64_t wi = b * 64 + t;
+        if (wi >= n_words) break;
+        uint64_t x = mask[wi];
+        while (x) { coff[at++] = (uint16_t)(t * 64 + __builtin_ctzll(x)); x &= x - 1; }
+    }
+}
+void block_cut_counts(const uint64_t* mask, uint64_t n_words, uint32_t* counts, uint64_t n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_block_cut_counts, dim3(grid_for(n_blocks, 256)), dim3(256), 0, s, mask, n_words, counts, n_blocks);
+    MMT_HIP(hipGetLastError());
+}
+void block_cut_offsets(const uint64_t* mask, uint64_t n_words, const uint32_t* brank, uint16_t* coff, uint64_t n_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_block_cut_offsets, dim3(grid_for(n_blocks, 256)), dim3(256), 0, s, mask, n_words, brank, coff, n_blocks);
+    MMT_HIP(hipGetLastError());
+}
 void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, uint64_t n_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_block_first_cut, dim3(grid_for(n_blocks, 256)), dim3(256), 0, s, mask, n_words, first, n_blocks);
     MMT_HIP(hipGetLastError());
 }
 
+// The phrase ends as a LIST instead of a bit per text position (Ctx::coff): the offsets inside their blocks of 4096 positions,
+// two bytes per phrase, and the number of phrase ends before every block -- 3.8 GB instead of the 81 GB the bits and their
+// rank directory take on 573 G characters (BASELINE configs[4]).  A block's entries are found by its two counts.
+__device__ __forceinline__ uint32_t list_lower(const Ctx& c, uint32_t lo, uint32_t hi, uint32_t t) {
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)c.coff[mid] < t) lo = mid + 1; else hi = mid; }
+    return lo;                                                    // first entry of [lo, hi) with offset >= t
+}
+__device__ __forceinline__ uint64_t list_next_cut(const Ctx& c, uint64_t x) {
+    const uint64_t b = x >> 12;
+    const uint32_t lo = c.brank[b], hi = c.brank[b + 1];
+    const uint32_t k = list_lower(c, lo, hi, (uint32_t)(x & 4095));
+    return k < hi ? (b << 12) + (uint64_t)c.coff[k] : c.nxt[b + 1];
+}
 // first phrase end at or after text position x; `first` = c.mask[x >> 6], loaded by the caller (x < n)
 __device__ __forceinline__ uint64_t next_cut_from(const Ctx& c, uint64_t x, uint64_t first) {
+    if (c.coff) return list_next_cut(c, x);
     uint64_t wi = x >> 6;
     uint64_t word = first & (~0ull << (x & 63));
     const uint64_t stop = ((x >> 12) + 1) << 6;                   // first word of the next block of 4096 positions
@@ -79,6 +121,7 @@ __device__ __forceinline__ uint64_t next_cut_from(const Ctx& c, uint64_t x, uint
 // first phrase end at or after text position x
 __device__ __forceinline__ uint64_t next_cut(const Ctx& c, uint64_t x) {
     if (x >= c.n) return c.n + c.w - 1;
+    if (c.coff) return list_next_cut(c, x);
     uint64_t wi = x >> 6;
     uint64_t word = c.mask[wi] & (~0ull << (x & 63));
     const uint64_t stop = ((x >> 12) + 1) << 6;                   // first word of the next block of 4096 positions
@@ -91,6 +134,7 @@ __device__ __forceinline__ uint64_t next_cut(const Ctx& c, uint64_t x) {
 // number of phrase ends before text position x
 __device__ __forceinline__ uint32_t rank1(const Ctx& c, uint64_t x) {
     if (x > c.n) x = c.n;                                         // no cut bits at or beyond n
+    if (c.coff) { const uint64_t b = x >> 12; return list_lower(c, c.brank[b], c.brank[b + 1], (uint32_t)(x & 4095)); }
     uint32_t r = c.rdir[x >> 9];
     const uint64_t w0 = (x >> 9) << 3, w1 = x >> 6;
     for (uint64_t wi = w0; wi < w1; wi++) r += (uint32_t)__popcll(c.mask[wi]);
@@ -454,7 +498,7 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
         const uint32_t j = e == g0 ? g0 + 1 : g0;
         const uint64_t rj = pos[j], qj = rec_pos(c, rj);
         const uint64_t xe = query_point(c, q), xj = query_point(c, qj);
-        const uint64_t me = xe < c.n ? c.mask[xe >> 6] : 0, mj = xj < c.n ? c.mask[xj >> 6] : 0;
+        const uint64_t me = xe < c.n && c.mask ? c.mask[xe >> 6] : 0, mj = xj < c.n && c.mask ? c.mask[xj >> 6] : 0;
         uint64_t a[4], b[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) { a[t] = tx_load8(c.T, q + offset + 8 * t); b[t] = tx_load8(c.T, qj + offset + 8 * t); }

@@ -38,6 +38,9 @@ struct Ctx {
     uint32_t rec_rank;         // ... 1: the rank of the following parse suffix, 0: the length of alpha (pos_bits = 40)
     uint32_t tile0 = 0;        // first tile of this launch (the text-order kernels run in slices of 2^23 tiles)
     const uint32_t* pid = nullptr;   // text suffixes: id of the distinct phrase at parse position k (m entries), or nullptr
+    // the phrase ends as a list (mask = rdir = nullptr then): coff[k] = offset of phrase end k inside its block of 4096 text
+    // positions, brank[b] = phrase ends before block b (blocks + 2 entries); nxt as above
+    const uint16_t* coff = nullptr; const uint32_t* brank = nullptr;
     // Giant phrases (longer than g_depth characters: a run of N, a microsatellite -- no trigger of the parse falls inside a
     // periodic run, newscan.hpp:265-325): their suffixes are sorted once, as a small dictionary of their own, and a
     // comparison that is still undecided g_depth characters into alpha continues on those ranks instead of on characters.
@@ -52,6 +55,8 @@ struct Ctx {
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions
 void rank_counts(const uint64_t* mask, uint64_t n_words, uint32_t* counts, uint64_t n_counts, hipStream_t s);
 void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, uint64_t n_blocks, hipStream_t s);
+void block_cut_counts(const uint64_t* mask, uint64_t n_words, uint32_t* counts, uint64_t n_blocks, hipStream_t s);
+void block_cut_offsets(const uint64_t* mask, uint64_t n_words, const uint32_t* brank, uint16_t* coff, uint64_t n_blocks, hipStream_t s);
 
 // bins = leading `prefix_chars` symbols of every text suffix (at most 4096 bins)
 void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s);

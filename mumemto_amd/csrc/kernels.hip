@@ -190,7 +190,13 @@ __global__ __launch_bounds__(BLOCK) void k_pack_text(const uint8_t* __restrict__
                                                       const uint64_t* __restrict__ doc_len, const uint64_t* __restrict__ doc_start,
                                                       uint32_t n_docs, uint64_t* __restrict__ packed, uint64_t n,
                                                       unsigned long long* __restrict__ hist, uint64_t* __restrict__ ev_start,
-                                                      uint64_t* __restrict__ ev_end, uint32_t* __restrict__ ev_count, uint32_t ev_cap) {
+                                                      uint64_t* __restrict__ ev_end, uint32_t* __restrict__ ev_count, uint32_t ev_cap,
+                                                      uint64_t p_lo, uint64_t p_hi) {
+    // [p_lo, p_hi): the text positions this launch packs -- everything, or the span of ONE document whose bases sit in a
+    // staging buffer (`raw` is then offset so that raw + doc_base[d] is that buffer: a collection whose raw bases would not
+    // fit the device next to its packed text is packed document by document, Engine::build_text).  A span begins and ends at
+    // a document boundary: the character before it and the character behind it are not part of any of its runs ('$' ends
+    // every document, no document is empty), and the two words it shares with its neighbours are OR-ed in.
     __shared__ uint32_t s_hist[256];
     __shared__ uint8_t s_up[256], s_rc[256];
     __shared__ uint64_t s_start[MAXD + 1], s_base[MAXD + 1], s_len[MAXD + 1];
@@ -208,10 +214,10 @@ __global__ __launch_bounds__(BLOCK) void k_pack_text(const uint8_t* __restrict__
     const uint64_t* st = in_lds ? s_start : doc_start;
     const uint64_t* bs = in_lds ? s_base : doc_base;
     const uint64_t* ln = in_lds ? s_len : doc_len;
-    const uint64_t n_words = (n + 31) / 32;
-    for (uint64_t W = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; W < n_words; W += (uint64_t)gridDim.x * BLOCK) {
+    const uint64_t w_lo = p_lo / 32, w_hi = (p_hi + 31) / 32;
+    for (uint64_t W = w_lo + (uint64_t)blockIdx.x * BLOCK + threadIdx.x; W < w_hi; W += (uint64_t)gridDim.x * BLOCK) {
         const uint64_t p0 = W * 32;
-        uint32_t d = doc_lookup(st, n_docs, p0);
+        uint32_t d = doc_lookup(st, n_docs, p0 > p_lo ? p0 : p_lo);
         uint64_t word = 0;
         uint32_t exc = 0;
         uint8_t ch[32];
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_text(const uint8_t* __restrict__
         for (int b = 0; b < 32; b++) {
             const uint64_t p = p0 + b;
             uint8_t c = 0;
-            if (p < n) {
+            if (p >= p_lo && p < p_hi) {
                 while (p >= st[d + 1]) d++;
                 const uint64_t Ld = ln[d], lo = p - st[d];
                 if (lo < Ld) c = s_up[raw[bs[d] + lo]];
@@ -233,24 +239,25 @@ __global__ __launch_bounds__(BLOCK) void k_pack_text(const uint8_t* __restrict__
             }
             ch[b] = c;
         }
-        packed[W] = word;
+        if (p0 >= p_lo && p0 + 32 <= p_hi) packed[W] = word;
+        else atomicOr(reinterpret_cast<unsigned long long*>(packed + W), (unsigned long long)word);
         if (cnt[0]) atomicAdd(&s_hist['A'], cnt[0]);
         if (cnt[1]) atomicAdd(&s_hist['C'], cnt[1]);
         if (cnt[2]) atomicAdd(&s_hist['G'], cnt[2]);
         if (cnt[3]) atomicAdd(&s_hist['T'], cnt[3]);
         if (exc) {
             // runs of one exception byte: a start where the byte before differs, an end where the byte behind differs
-            const uint8_t before = p0 ? (uint8_t)((exc & 1u) ? text_char_at(raw, st, bs, ln, n_docs, p0 - 1, s_up, s_rc) : 0) : (uint8_t)0;
-            const uint8_t behind = (p0 + 32 < n && (exc >> 31)) ? text_char_at(raw, st, bs, ln, n_docs, p0 + 32, s_up, s_rc) : (uint8_t)0;
+            const uint8_t before = p0 > p_lo ? (uint8_t)((exc & 1u) ? text_char_at(raw, st, bs, ln, n_docs, p0 - 1, s_up, s_rc) : 0) : (uint8_t)0;
+            const uint8_t behind = (p0 + 32 < p_hi && (exc >> 31)) ? text_char_at(raw, st, bs, ln, n_docs, p0 + 32, s_up, s_rc) : (uint8_t)0;
 #pragma unroll
             for (int b = 0; b < 32; b++) {
                 if (!((exc >> b) & 1u)) continue;
                 const uint8_t prev = b ? ch[b ? b - 1 : 0] : before, next = b < 31 ? ch[b < 31 ? b + 1 : 31] : behind;
-                if (prev != ch[b] || p0 + b == 0) {
+                if (prev != ch[b] || p0 + b == p_lo) {
                     const uint32_t slot = atomicAdd(ev_count, 1u);
                     if (slot < ev_cap) ev_start[slot] = ((p0 + b) << 8) | ch[b];
                 }
-                if (next != ch[b] || p0 + b + 1 == n) {
+                if (next != ch[b] || p0 + b + 1 == p_hi) {
                     const uint32_t slot = atomicAdd(ev_count + 1, 1u);
                     if (slot < ev_cap) ev_end[slot] = p0 + b + 1;
                 }
@@ -263,12 +270,13 @@ __global__ __launch_bounds__(BLOCK) void k_pack_text(const uint8_t* __restrict__
 }
 void pack_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
                uint64_t* packed, uint64_t n, uint64_t* hist, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count, uint32_t ev_cap,
-               hipStream_t s) {
+               uint64_t p_lo, uint64_t p_hi, hipStream_t s) {
     constexpr int B = 256;
-    const uint64_t words = (n + 31) / 32;
+    if (p_hi <= p_lo) return;
+    const uint64_t words = (p_hi + 31) / 32 - p_lo / 32;
     const unsigned grid = (unsigned)std::min<uint64_t>((words + B - 1) / B ? (words + B - 1) / B : 1, 256u * 32u);
     hipLaunchKernelGGL((k_pack_text<B, 1023>), dim3(grid), dim3(B), 0, s, raw, d_doc_base, d_doc_len, d_doc_start, n_docs, packed, n,
-                       reinterpret_cast<unsigned long long*>(hist), ev_start, ev_end, ev_count, ev_cap);
+                       reinterpret_cast<unsigned long long*>(hist), ev_start, ev_end, ev_count, ev_cap, p_lo, p_hi);
     MMT_HIP(hipGetLastError());
 }
 // a byte text (a handed-over text: Engine::set_text_host) packed the same way

@@ -32,7 +32,7 @@ void build_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* 
 // behind the run, counts in ev_count[0 / 1], in no particular order: the host sorts and pairs them.
 void pack_text(const uint8_t* raw, const uint64_t* d_doc_base, const uint64_t* d_doc_len, const uint64_t* d_doc_start, uint32_t n_docs,
                uint64_t* packed, uint64_t n, uint64_t* hist, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count, uint32_t ev_cap,
-               hipStream_t s);
+               uint64_t p_lo, uint64_t p_hi, hipStream_t s);      // text positions [p_lo, p_hi): all of it, or the span of whole documents
 void pack_bytes(const uint8_t* text, uint64_t n, uint64_t* packed, uint64_t* ev_start, uint64_t* ev_end, uint32_t* ev_count,
                 uint32_t ev_cap, hipStream_t s);
 void unpack_text(const TextRef& T, uint64_t first, uint64_t count, uint8_t* out, hipStream_t s);

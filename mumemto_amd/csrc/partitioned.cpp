@@ -88,8 +88,15 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     // fails with "out of device memory" if that was too optimistic; an explicit limit is an order)
     if (total <= max_text || n_docs < 3 || (!strict && auto_limit)) {
         try {
-            set_input_host_docs(doc_ptr, doc_len, n_docs);
+            // (a text that will be packed -- two bits per character -- never has its raw bases on the device as a whole:
+            // they go through a staging buffer document by document; MMT_INPUT_DEFERRED=1 forces that route for tests)
+            const double avail = 0.95 * (double)pool::available(device_);
+            const bool defer = std::getenv("MMT_INPUT_DEFERRED") ? std::atoi(std::getenv("MMT_INPUT_DEFERRED")) != 0
+                                                                  : (double)total * 2.9 + 24.0 * 1073741824.0 > avail;
+            if (defer) set_input_host_docs_deferred(doc_ptr, doc_len, n_docs);
+            else set_input_host_docs(doc_ptr, doc_len, n_docs);
             run_once_dropping_input(p);
+            host_docs_.clear();
             return;
         } catch (const DeviceOom&) {
             if (!strict || n_docs < 3 || !auto_limit) throw;

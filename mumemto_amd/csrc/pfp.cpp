@@ -62,9 +62,13 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     const TextRef v = text_ref();                  // V = Dollar . T . Dollar^w lives in the text buffer (Engine::text_ptr), or packed (textref.hpp)
     const uint32_t tb = pk::trigger_blocks(n);
     // (the cut bits double as the rank / successor structure of the guided sort: whole blocks of 4096 positions, zero padded)
-    S.tmask.ensure((size_t)(((n + 64) / 4096 + 2) * 256)); S.tcnt.ensure((size_t)tb + 1); S.toff.ensure((size_t)tb + 1);
-    MMT_HIP(hipMemsetAsync(S.tmask.get(), 0, S.tmask.bytes(), st));
-    pk::trigger_masks(v, n, w, p, S.tmask.get(), S.tcnt.get(), st);
+    auto trigger_pass = [&]() {
+        S.tmask.ensure((size_t)(((n + 64) / 4096 + 2) * 256)); S.tcnt.ensure((size_t)tb + 1);
+        MMT_HIP(hipMemsetAsync(S.tmask.get(), 0, S.tmask.bytes(), st));
+        pk::trigger_masks(v, n, w, p, S.tmask.get(), S.tcnt.get(), st);
+    };
+    S.toff.ensure((size_t)tb + 1);
+    trigger_pass();
     prims::exclusive_sum_u32(d_temp_, S.tcnt.get(), S.toff.get(), tb, st);
     S.err.ensure(16);
     {
@@ -83,8 +87,13 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
 
     // -- distinct phrases: fingerprints, sort, verified grouping
     e1.start(st);
-    S.h1.ensure(m); S.pinfo.ensure((size_t)m * 16 + 16); S.hk_a.ensure(m); S.hk_b.ensure(m);
-    S.iota.ensure(m); S.ord_a.ensure(m); S.order.ensure(m);
+    // A packed text is a text that fills the device (configs[4]: 143 GB packed + 72 GB of cut bits): the cut bits -- an eighth
+    // of a byte per character, needed again by the bucket-wise producer -- make room for the 52 bytes per phrase of this
+    // stage and are computed once more behind it (one more pass over the text: ~1 ms per G characters)
+    const bool tmask_again = packed_ && slim;
+    if (tmask_again) { MMT_HIP(hipStreamSynchronize(st)); S.tmask.release(); }
+    S.h1.ensure(m); S.pinfo.ensure((size_t)m * 16 + 16); S.hk_b.ensure(m);
+    S.iota.ensure(m); S.order.ensure(m);
     pk::phrase_hash(v, S.pstart.get(), S.plen.get(), m, S.h1.get(), S.pinfo.get(), W, st);
     pk::iota(S.iota.get(), m, st);
     S.dflags.ensure(m); S.scan.ensure(m);
@@ -94,7 +103,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             prims::sort_pairs_u64_u32(d_temp_, S.h1.get(), S.hk_b.get(), S.iota.get(), S.order.get(), m, 0, 64, st);
         } else {
             // (rare) order by both fingerprints: stable sort by the second, then by the first
-            S.h2.ensure(m);
+            S.h2.ensure(m); S.hk_a.ensure(m); S.ord_a.ensure(m);
             pk::second_fingerprint(S.pinfo.get(), m, S.h2.get(), st);
             prims::sort_pairs_u64_u32(d_temp_, S.h2.get(), S.hk_a.get(), S.iota.get(), S.ord_a.get(), m, 0, 64, st);
             pk::gather_u64(S.h1.get(), S.ord_a.get(), m, S.hk_a.get(), st);
@@ -119,6 +128,7 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
         S.h1.release(); S.h2.release(); S.pinfo.release(); S.hk_a.release(); S.hk_b.release(); S.iota.release();
         S.ord_a.release(); S.order.release(); S.dflags.release(); S.scan.release();
     }
+    if (tmask_again) { trigger_pass(); S.tcnt.release(); }
     e1.stop(st);
     mem_mark(device_, "distinct phrases");
 

@@ -54,7 +54,8 @@ struct PfpState {
     // the bucket-wise producer between its batches (guided.cpp): rank / successor tables over the phrase ends, the
     // histogram of the suffixes' leading characters
     gk::Ctx gctx{};
-    DevBuf<uint32_t> g_rdir;
+    DevBuf<uint32_t> g_rdir, g_brank;
+    DevBuf<uint16_t> g_coff;               // the phrase ends as a list (gk::Ctx::coff): packed texts
     DevBuf<uint64_t> g_nxt;
     std::vector<uint64_t> g_bins;
     int g_prefix = 0;

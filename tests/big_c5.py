@@ -24,6 +24,13 @@ ap.add_argument("--samples", type=int, default=200)
 ap.add_argument("--wp", type=int, nargs=2, default=None, help="window and modulus of the parse (default: automatic)")
 A = ap.parse_args()
 N, L0 = A.haps, A.length
+# (the collection sits in host memory as bytes: a box with less memory than that is not asked to try)
+avail_kb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+need_gb = N * L0 / 2**30 * 1.15 + 16
+print(json.dumps(dict(host_available_gb=round(avail_kb / 2**20), host_needed_gb=round(need_gb))), flush=True)
+if avail_kb / 2**20 < need_gb:
+    print("SKIPPED: not enough host memory for the collection")
+    sys.exit(3)
 t0 = time.time()
 bases = np.empty(N * L0, np.uint8)
 for k, (h, b) in enumerate(synth.haplotypes_sparse(94, L0, A.div, A.seed, which=list(range(N)))):

@@ -1,0 +1,127 @@
+"""GPU: the text packed to two bits per character (mumemto_amd/csrc/textref.hpp) -- what lets one device hold a collection of
+hundreds of G characters (BASELINE configs[4]: every rank holds all 573 G; profiles/round4_c5_rank_share_250G_packed.log).
+MMT_PACKED_TEXT=1 forces the layout at any size: A C G T in two bits, everything else ('$', N, IUPAC codes) as sorted
+exception runs; the parse and the bucket-wise producer read it through one accessor, and every result must be the byte
+layout's.  MMT_INPUT_DEFERRED=1 also forces the route whose raw bases never sit on the device as a whole (packed document by
+document through a staging buffer).  The whole parity suite runs with MMT_PACKED_TEXT=1 as well (profiles/README.md)."""
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as O
+from mumemto_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _awkward_docs():
+    rng = np.random.default_rng(12)
+    anc = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=30000).astype(np.uint8)
+    docs = []
+    for d in range(6):
+        s = anc.copy()
+        for p in rng.integers(0, len(s), size=60):
+            s[p] = rng.choice(np.frombuffer(b"ACGT", np.uint8))
+        if d % 2 == 0:
+            a = int(rng.integers(100, 20000))
+            s[a:a + int(rng.integers(1, 5000))] = ord("N")          # runs of N: exception runs over several 4096-blocks
+        for p in rng.integers(0, len(s), size=12):
+            s[p] = rng.choice(np.frombuffer(b"RYKMSWBDHVN", np.uint8))  # single IUPAC codes
+        if d == 3:
+            s[:40] = ord("N"); s[-33:] = ord("N")                     # runs that touch both ends of a document
+        rec = s.tobytes()
+        if d == 4:
+            rec = rec.lower()
+        docs.append([rec[:7000], rec[7000:]] if d == 5 else [rec])
+    return docs
+
+
+class packed_env:
+    def __init__(self, **kw):
+        self.kw = {k: str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update(self.kw)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("revcomp", [True, False])
+def test_packed_text_spells_the_text_and_gives_the_same_rows(revcomp):
+    import mumemto_amd
+    docs = _awkward_docs()
+    text, _ = O.build_text(docs, revcomp)
+    eng = mumemto_amd.Engine(0)
+    try:
+        for kw in (dict(), dict(num_distinct=5, max_doc_freq=3, max_total_freq=18), dict(merge_metadata=True)):
+            eng.set_docs(docs)
+            eng.run(use_revcomp=revcomp, **kw)
+            plain = eng.output_text()
+            th = eng.thresholds().copy() if kw.get("merge_metadata") else None
+            okw = {k: v for k, v in kw.items() if k != "merge_metadata"}
+            want = O.run(docs, revcomp=revcomp, merge=bool(kw.get("merge_metadata")), **okw)
+            assert plain == want.text()
+            with packed_env(MMT_PACKED_TEXT=1):
+                eng.set_docs(docs)
+                eng.run(use_revcomp=revcomp, **kw)
+                assert eng.producer_used() == "guided"
+                assert np.array_equal(eng.text(), text), "the packed text does not spell T"
+                assert eng.output_text() == plain
+                if th is not None:
+                    assert np.array_equal(eng.thresholds(), th)
+                # the raw bases never on the device as a whole: document by document through a staging buffer
+                with packed_env(MMT_INPUT_DEFERRED=1):
+                    flat = np.frombuffer(b"".join(b"".join(d) for d in docs), np.uint8)
+                    lens = np.array([sum(len(r) for r in d) for d in docs], np.uint64)
+                    assert eng.run_partitioned(None, flat=(flat, lens), use_revcomp=revcomp,
+                                               merge_metadata=bool(kw.get("merge_metadata")), **okw) == 1
+                    assert np.array_equal(eng.text(), text)
+                    assert eng.output_text() == plain
+            # the deferred input with the byte layout (uploaded as a whole when the run begins)
+            with packed_env(MMT_INPUT_DEFERRED=1, MMT_PACKED_TEXT=0):
+                assert eng.run_partitioned(None, flat=(flat, lens), use_revcomp=revcomp,
+                                           merge_metadata=bool(kw.get("merge_metadata")), **okw) == 1
+                assert eng.output_text() == plain
+    finally:
+        eng.close()
+
+
+def test_shards_of_a_packed_text_concatenate_to_the_single_run():
+    import mumemto_amd
+    docs = synth.pangenome(7, 40000, 0.01, seed=31, indel_rate=0.0005, inversion=(3, 3000, 9000))
+    want = O.run(docs, num_distinct=6, max_doc_freq=3, max_total_freq=21).text()
+    eng = mumemto_amd.Engine(0)
+    try:
+        with packed_env(MMT_PACKED_TEXT=1, MMT_GUIDED_BATCH=5000):
+            got = b""
+            for r in range(3):
+                eng.set_docs(docs)
+                eng.set_scan_shard(r, 3)
+                eng.run(num_distinct=6, max_doc_freq=3, max_total_freq=21)
+                assert eng.stream_stats()["entries"] == eng.sort_pieces()[r][1]
+                got += eng.output_text()
+            eng.set_scan_shard(0, 1)
+        assert got == want and want.count(b"\n") > 20
+    finally:
+        eng.close()
+
+
+def test_bytes_the_parse_reserves_keep_the_byte_layout():
+    import mumemto_amd
+    docs = [[b"ACGT\x01\x02ACGTTGCA" * 5], [b"ACGTTGCA\x01ACGT" * 4]]
+    eng = mumemto_amd.Engine(0)
+    try:
+        with packed_env(MMT_PACKED_TEXT=1):
+            eng.set_docs(docs)
+            eng.run(min_match_len=4, num_distinct=2, max_doc_freq=3)
+            assert eng.producer_used() == "direct"
+            assert eng.output_text() == O.run(docs, min_len=4, num_distinct=2, max_doc_freq=3).text()
+    finally:
+        eng.close()

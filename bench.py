@@ -321,15 +321,25 @@ def main():
     }
     # HBM bytes the scan kernel really moved, from the PMC passes under profiles/ (separate rocprofv3 runs of this
     # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for the default workload only
-    pmc_file = os.path.join(ROOT, "profiles", "round3_scan_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "round4_scan_pmc.json")
     if not os.path.exists(pmc_file):
-        pmc_file = os.path.join(ROOT, "profiles", "round2_scan_pmc.json")
+        pmc_file = os.path.join(ROOT, "profiles", "round3_scan_pmc.json")
     if world == 1 and os.path.exists(pmc_file) and (a.haps, a.length, a.divergence, a.seed) == (94, 64_000_000, 0.001, 3):
         pmc = json.load(open(pmc_file))
         result["roofline"]["traffic"] = pmc["hbm_bytes_per_step"]
         result["roofline"]["traffic_unit"] = ("bytes per step = all k_scan launches of one pass (PMC, profiles/%s: %s)"
                                               % (os.path.basename(pmc_file), pmc.get("kernel", "k_scan")))
         result["roofline"]["frac_moved"] = pmc["hbm_bytes_per_step"] / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    emit_pmc = os.path.join(ROOT, "profiles", "round4_emit_pmc.json")
+    if world == 1 and os.path.exists(emit_pmc) and (a.haps, a.length, a.divergence, a.seed) == (94, 64_000_000, 0.001, 3):
+        # the largest kernel's HBM bytes from its own PMC passes: the ratio to its algorithmic bytes says how much it re-reads
+        pmc = json.load(open(emit_pmc))
+        lk = result["largest_kernel"]
+        lk["traffic"] = pmc["hbm_bytes_per_step"]
+        lk["algorithmic_bytes_per_step"] = pmc["algorithmic_bytes_per_step"]
+        lk["traffic_ratio"] = pmc["hbm_bytes_per_step"] / pmc["algorithmic_bytes_per_step"]
+        lk["frac_moved"] = pmc["hbm_bytes_per_step"] / max(lk["ms_per_step"], 1e-9) / 1e6 / HBM_PEAK_GBS
+        lk["traffic_unit"] = "bytes per step = all k_emit launches of one pass (PMC, profiles/round4_emit_pmc.json)"
     if eng.producer_used() == "pfp":
         result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(
             ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_groups",

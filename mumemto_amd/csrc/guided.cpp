@@ -202,6 +202,10 @@ void Engine::guided_prepare() {
     // one bin as long as a bin's prefix is not longer than that length -- SURVEY.md 8(e) -- so that the pieces of the
     // stream can be produced, scanned and dropped bin by bin, on any rank.
     int prefix_chars = std::max(1, std::min(12 / ctx.bits, ctx.chars));
+    // (a bin must fit one batch of at most 2^30 suffixes: beyond 2^38 characters -- four leading bases hold n / 256 of the
+    // suffixes of a DNA text -- the bins take one character more; MMT_GUIDED_PREFIX: tests)
+    if (n >= (1ull << 38)) prefix_chars = std::max(prefix_chars, std::min(15 / ctx.bits, ctx.chars));
+    if (const char* e = std::getenv("MMT_GUIDED_PREFIX")) prefix_chars = std::max(1, std::min(std::atoi(e), std::min(18 / ctx.bits, ctx.chars)));
     prefix_chars = std::max(1, std::min<int>(prefix_chars, (int)std::min<uint32_t>(stream_min_len_, 64u)));
     S.g_prefix = prefix_chars;
     d_code_.ensure(256);
@@ -254,10 +258,10 @@ void Engine::guided_prepare() {
     S.g_nbins = 1u << (ctx.bits * prefix_chars);
     {
         DevBuf<uint64_t> d_bins;
-        d_bins.ensure(4096);
-        MMT_HIP(hipMemsetAsync(d_bins.get(), 0, 4096 * 8, st));
+        d_bins.ensure(std::max<uint32_t>(S.g_nbins, 4096u));
+        MMT_HIP(hipMemsetAsync(d_bins.get(), 0, (size_t)std::max<uint32_t>(S.g_nbins, 4096u) * 8, st));
         gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
-        d2h(S.g_bins, d_bins.get(), 4096, st);
+        d2h(S.g_bins, d_bins.get(), std::max<uint32_t>(S.g_nbins, 4096u), st);
     }
     S.err.ensure(16);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
@@ -493,7 +497,11 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest) : largest;
     const double per_element = (double)Batch::bytes_per_element() + 2.0 * (wide_ ? 10.0 : 9.0);
     uint64_t cap64 = std::min<uint64_t>(std::max<uint64_t>(n, 1024), 1ull << 30);
-    const double avail = 0.85 * (double)pool::available(device_) - 2.0 * 10.0 * (double)head_room;
+    // (what else the batches allocate: the tile tables of the two text-order kernels, 8 bytes per 4096 text positions; the
+    // candidates and rows of the scan; and the heap wants its blocks contiguous -- at 573 G characters 85 % of what was free
+    // left the last allocation 9 GB short)
+    const double avail = 0.80 * (double)pool::available(device_) - 2.0 * 10.0 * (double)head_room -
+                         8.0 * (double)((n + gk::TILE - 1) / gk::TILE) - 6.0 * 1073741824.0;
     const uint64_t fit = avail > 0 ? (uint64_t)(avail / per_element) : 0;
     cap64 = std::min(cap64, std::max<uint64_t>(fit, 1u << 20));
     if (const char* c = std::getenv("MMT_GUIDED_BATCH")) cap64 = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));

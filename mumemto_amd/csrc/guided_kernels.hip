@@ -270,21 +270,28 @@ static void for_tile_slices(const Ctx& c, F&& launch) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int shift, uint64_t* __restrict__ hist) {
+// (a tile counts in LDS, 4096 counters; with more bins than that -- five leading characters: texts beyond 2^38 characters,
+// where a bin of four holds more suffixes than a batch -- one pass per value of the bin code's bits above the low twelve)
+__global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int shift, uint64_t* __restrict__ hist, uint32_t hi_sel) {
     __shared__ uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_hist[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) s_hist[i] = 0;
     __syncthreads();
-    for_tile_keys(c, s_sym, [&](int, uint64_t, bool in, uint64_t key) { if (in) atomicAdd(&s_hist[(uint32_t)(key >> shift)], 1u); });
+    for_tile_keys(c, s_sym, [&](int, uint64_t, bool in, uint64_t key) {
+        const uint32_t bin = (uint32_t)(key >> shift);
+        if (in && (bin >> 12) == hi_sel) atomicAdd(&s_hist[bin & 4095u], 1u);
+    });
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256)
-        if (s_hist[i]) atomicAdd(reinterpret_cast<unsigned long long*>(hist + i), (unsigned long long)s_hist[i]);
+        if (s_hist[i]) atomicAdd(reinterpret_cast<unsigned long long*>(hist + ((size_t)hi_sel << 12) + i), (unsigned long long)s_hist[i]);
 }
 void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
     const int shift = c.bits * (c.chars - prefix_chars);
-    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_bin_hist, dim3(blocks), dim3(256), 0, s, cs, shift, hist);
-    });
+    const uint32_t n_bins = 1u << (c.bits * prefix_chars);
+    for (uint32_t hi = 0; hi < std::max<uint32_t>(n_bins >> 12, 1u); hi++)
+        for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+            hipLaunchKernelGGL(k_bin_hist, dim3(blocks), dim3(256), 0, s, cs, shift, hist, hi);
+        });
     MMT_HIP(hipGetLastError());
 }
 

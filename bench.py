@@ -336,10 +336,13 @@ def main():
         pmc = json.load(open(emit_pmc))
         lk = result["largest_kernel"]
         lk["traffic"] = pmc["hbm_bytes_per_step"]
+        lk["traffic_upper_bound"] = pmc.get("hbm_bytes_per_step_fetch_x2")
         lk["algorithmic_bytes_per_step"] = pmc["algorithmic_bytes_per_step"]
         lk["traffic_ratio"] = pmc["hbm_bytes_per_step"] / pmc["algorithmic_bytes_per_step"]
         lk["frac_moved"] = pmc["hbm_bytes_per_step"] / max(lk["ms_per_step"], 1e-9) / 1e6 / HBM_PEAK_GBS
-        lk["traffic_unit"] = "bytes per step = all k_emit launches of one pass (PMC, profiles/round4_emit_pmc.json)"
+        lk["traffic_unit"] = ("bytes per step = all k_emit launches of one pass (PMC, profiles/round4_emit_pmc.json: FETCH_SIZE as "
+                              "reported -- 8 / 4 bytes per lane gathers, a width the guide's x2 is not calibrated for; the x2 "
+                              "figure is traffic_upper_bound -- + WRITE_SIZE)")
     if eng.producer_used() == "pfp":
         result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(
             ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_groups",

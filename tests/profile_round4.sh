@@ -47,8 +47,11 @@ for kern, algo, what in (("scan", 10 * n, "SA 5 + LCP 4 + BWT 1 bytes per suffix
     d = {"workload": "bench.py default: 94 haplotypes x 64,000,000 bp, divergence 0.001, seed 3 (|T| = 12,032,000,188)",
          "kernel": kn.split("(")[0], "launches_counted": nf, "launches_per_step": nf / steps,
          "FETCH_SIZE_kb_raw_per_step": f / steps, "WRITE_SIZE_kb_per_step": w / steps,
-         "correction": "FETCH_SIZE x2 (gfx950 note of MI355X_MICROARCH.md: wide coalesced reads are under-reported by 2x), WRITE_SIZE as reported; KB = 1024 B",
-         "hbm_bytes_per_step": (2.0 * f + w) / steps * 1024.0, "hbm_bytes_per_step_fetch_uncorrected": (f + w) / steps * 1024.0,
+         "correction": "FETCH_SIZE x2 for k_scan (gfx950 note of MI355X_MICROARCH.md: wide coalesced streaming reads, 16 B per lane, are under-reported by 2x); raw for k_emit (8 / 4 B per lane gathers: uncalibrated width, the x2 figure beside it as the upper bound); WRITE_SIZE as reported; KB = 1024 B",
+         # k_scan streams 16 bytes per lane: the guide's x2 applies.  k_emit gathers 8 and 4 bytes per lane in runs of ~750
+         # bytes: "other access widths are uncalibrated" -- its figure is the raw one, the x2 form is the upper bound
+         "hbm_bytes_per_step": ((2.0 if kern == "scan" else 1.0) * f + w) / steps * 1024.0,
+         "hbm_bytes_per_step_fetch_x2": (2.0 * f + w) / steps * 1024.0, "hbm_bytes_per_step_fetch_raw": (f + w) / steps * 1024.0,
          "algorithmic_bytes_per_step": algo, "algorithmic_bytes": what,
          "recipe": "tests/profile_round4.sh (two separate rocprofv3 --kernel-trace --pmc passes per kernel, counters only)"}
     json.dump(d, open("%s/%s_pmc.json" % (out, kern), "w"), indent=1)

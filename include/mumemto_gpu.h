@@ -180,6 +180,12 @@ MMT_API void mmt_pool_trim(void);
  * keep_anchor_ranks != 0: the suffix ranks of the anchor stay, so that mmt_merged_sort_like_direct still works -- the state
  * of a rank between its own pass and the fold of everybody's rows. */
 MMT_API int mmt_engine_release_columns(mmt_engine* e, int keep_anchor_ranks);
+/* PREFIX.mums / PREFIX.mems of the NEXT runs straight to `path` while a run goes on (NULL or "": off): the rows of a window of
+ * the stream are final when it has been verified, so their bytes are formatted and written while the later windows are
+ * produced (src/pfp_mum.cpp writes the file row by row as well, include/mem_finder.hpp:357-428).  A run over a text that
+ * fills the device (packed text, or 2^37 characters and more; MMT_SINK_DISCARD=0/1 overrides) then keeps nothing of a
+ * window's rows: it answers for the file and for mmt_num_rows only -- mmt_rows_* / mmt_output_text hold nothing. */
+MMT_API int mmt_engine_set_text_sink(mmt_engine* e, const char* path);
 
 /* ---- PFP stage checkpoints (the reference's -P / -K: PREFIX.dict, PREFIX.parse) ------------ */
 /* Text layout + prefix-free parse only (newscan.hpp pfparser: process_string ... finish_parse).  */

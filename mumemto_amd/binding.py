@@ -76,7 +76,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
-    "mmt_stream_stats", "mmt_engine_release_columns", "mmt_copy_thresh32", "mmt_thresh_device32",
+    "mmt_stream_stats", "mmt_engine_release_columns", "mmt_copy_thresh32", "mmt_thresh_device32", "mmt_engine_set_text_sink",
 ]
 
 
@@ -192,6 +192,7 @@ def load_library():
     L.mmt_merged_text.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     L.mmt_merged_free.argtypes = [C.c_void_p]
     L.mmt_engine_release_columns.argtypes = [C.c_void_p, C.c_int]
+    L.mmt_engine_set_text_sink.argtypes = [C.c_void_p, C.c_char_p]
     L.mmt_copy_thresh32.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_thresh_device32.restype = C.c_void_p
     L.mmt_thresh_device32.argtypes = [C.c_void_p]
@@ -369,6 +370,11 @@ class Engine:
         _check(self.L.mmt_engine_run_files(self.h, arr, len(paths), C.byref(p),
                                            os.fsencode(out_prefix) if out_prefix else None, max_text_chars, sec))
         return dict(zip(["read", "run", "write", "total"], map(float, sec)))
+
+    def set_text_sink(self, path):
+        """PREFIX.mums / .mems of the next runs straight to `path` while a run goes on (None: off).  A run over a text that fills
+        the device keeps nothing else of its rows (mumemto_gpu.h)."""
+        _check(self.L.mmt_engine_set_text_sink(self.h, os.fsencode(path) if path else None))
 
     def release_columns(self, keep_anchor_ranks=False):
         """Text, windows and sort scratch of the last run back to the device heap; keep_anchor_ranks: rows folded later can

@@ -343,7 +343,7 @@ int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths
     if (empty >= 0) throw std::runtime_error("Empty input file found: " + inputs[(size_t)empty]);
     const double t_read = since();
     // the output file is written while the run goes on when the run streams its rows (Engine::set_text_sink)
-    e->e->set_text_sink(out_prefix && p->max_doc_freq == 1 ? std::string(out_prefix) + ".mums" : std::string());
+    e->e->set_text_sink(out_prefix ? std::string(out_prefix) + (p->max_doc_freq == 1 ? ".mums" : ".mems") : std::string());
     struct SinkOff { mmt::Engine* e; ~SinkOff() { e->set_text_sink(std::string()); } } sink_off{e->e.get()};
     bool ran = false;
     if (up.on) {
@@ -478,6 +478,12 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
     MMT_CATCH
 }
 void mmt_pool_trim(void) { mmt::pool::trim(); }
+int mmt_engine_set_text_sink(mmt_engine* e, const char* path) {
+    if (!e) return fail(1, "null");
+    MMT_TRY
+    e->e->set_text_sink(path ? std::string(path) : std::string());
+    MMT_CATCH
+}
 int mmt_engine_release_columns(mmt_engine* e, int keep_anchor_ranks) {
     if (!e) return fail(1, "null");
     MMT_TRY

@@ -473,7 +473,7 @@ int main(int argc, char** argv) {
         } else {
             if (o.arrays_out) eng.set_keep_columns(1);          // -A dumps whole columns: keep them next to the windows
             // PREFIX.mums is written window by window while the run goes on (Engine::set_text_sink)
-            if (mum_mode && !o.binary) eng.set_text_sink(o.output_prefix + ".mums");
+            if (!o.binary) eng.set_text_sink(o.output_prefix + (mum_mode ? ".mums" : ".mems"));
             try {
                 eng.run(p);
                 eng.set_text_sink(std::string());
@@ -494,11 +494,11 @@ int main(int argc, char** argv) {
             }
         }
         mark("run done");
-        const HostRows& R = mum_mode ? eng.rows_meta() : eng.rows(Engine::ROWS_TEXT);   // .mums: write_text_file; .bumbl pulls the arrays itself
+        const HostRows& R = eng.rows_meta();       // (write_text_file brings the bytes; .bumbl pulls the arrays itself)
         std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n",
                      mum_mode ? "MUM" : "MEM", secs_since(t0));
 
-        if (!mum_mode) write_file(o.output_prefix + ".mems", R.text, R.text_len);
+        if (!mum_mode) eng.write_text_file(o.output_prefix + ".mems");      // (nothing left to do when the run streamed it)
         else if (o.binary) { const std::string& b = eng.bumbl(); write_file(o.output_prefix + ".bumbl", b.data(), b.size()); }
         else eng.write_text_file(o.output_prefix + ".mums");       // (nothing left to do when the run streamed it)
 

@@ -697,7 +697,15 @@ void Engine::order_rows(const k::Row* rows_abs, uint32_t cnt) {
 void Engine::sink_open(bool mum_mode) {
     sink_active_ = false;
     sink_written_path_.clear();
-    if (sink_path_.empty() || !mum_mode || std::getenv("MUMEMTO_NO_TEXT_SINK")) return;
+    sink_mum_ = mum_mode;
+    sink_total_rows_ = 0;
+    if (sink_path_.empty() || std::getenv("MUMEMTO_NO_TEXT_SINK")) return;
+    // Rows that have been written need not stay: with a sink, a run whose accepted rows would not fit the device next to
+    // its text keeps nothing of a window once its bytes are on their way (BASELINE configs[4]: a rank's rows carry ~94
+    // occurrences each -- tens of GB of suffix-array entries, offsets and text).  Such a run answers only for the file and
+    // the number of rows.  MMT_SINK_DISCARD=0 / 1 overrides (tests).
+    sink_discard_ = std::getenv("MMT_SINK_DISCARD") ? std::atoi(std::getenv("MMT_SINK_DISCARD")) != 0 : (packed_ || n_ >= (1ull << 37));
+    if (!mum_mode && !sink_discard_) return;          // (a MEM run that keeps its rows writes its file at the end, as before)
     // the bytes go to PREFIX.mums.tmp and take the final name when the run has succeeded (sink_close): a run that fails
     // after some windows -- out of memory, a consistency check at the end -- must not leave a plausible partial PREFIX.mums
     sink_tmp_path_ = sink_path_ + ".tmp";
@@ -784,33 +792,65 @@ void Engine::sink_flush(ScanState& S) {
     a.rows = d_rows_pool_.get() + r0; a.order = d_order_.get(); a.n_rows = cnt;
     a.sa.lo = d_pool_lo_.get(); a.sa.hi = wide_ ? d_pool_hi_.get() : nullptr;
     a.doc_start = d_doc_start_.get(); a.doc_len = d_doc_len_.get(); a.n_docs = (uint32_t)N; a.revcomp = revcomp_ ? 1 : 0;
-    const size_t slots = (size_t)cnt * N;
-    d_tlen_.ensure(cnt); d_tlen64_.ensure(cnt); d_toff_.ensure(cnt);
-    d_slot_off_.ensure(slots); d_slot_st_.ensure(slots); d_keep_.ensure(cnt); d_ridx_.ensure(cnt);
-    MMT_HIP(hipMemsetAsync(d_slot_off_.get(), 0xFF, slots * 8, st));     // -1 = document absent
-    MMT_HIP(hipMemsetAsync(d_slot_st_.get(), 0, slots, st));
-    rk::mum_measure(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_tlen_.get(), st);
-    prims::exclusive_sum_u32(d_temp_, d_keep_.get(), d_ridx_.get(), cnt, st);
-    rk::widen(d_tlen_.get(), cnt, d_tlen64_.get(), st);
-    prims::exclusive_sum_u64(d_temp_, d_tlen64_.get(), d_toff_.get(), cnt, st);
-    uint32_t k0 = 0, k1 = 0; uint64_t t0 = 0, t1 = 0;
-    MMT_HIP(hipMemcpyAsync(&k0, d_ridx_.get() + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
-    MMT_HIP(hipMemcpyAsync(&k1, d_keep_.get() + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
-    MMT_HIP(hipMemcpyAsync(&t0, d_toff_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
-    MMT_HIP(hipMemcpyAsync(&t1, d_tlen64_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
-    MMT_HIP(hipStreamSynchronize(st));
-    const size_t kept = (size_t)k0 + k1, tbytes = (size_t)(t0 + t1);
+    d_tlen_.ensure(cnt); d_tlen64_.ensure(cnt); d_toff_.ensure(cnt); d_keep_.ensure(cnt);
+    size_t kept = 0, tbytes = 0, occ = 0;
+    if (sink_mum_) {
+        const size_t slots = (size_t)cnt * N;
+        d_slot_off_.ensure(slots); d_slot_st_.ensure(slots); d_ridx_.ensure(cnt);
+        MMT_HIP(hipMemsetAsync(d_slot_off_.get(), 0xFF, slots * 8, st));     // -1 = document absent
+        MMT_HIP(hipMemsetAsync(d_slot_st_.get(), 0, slots, st));
+        rk::mum_measure(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_tlen_.get(), st);
+        prims::exclusive_sum_u32(d_temp_, d_keep_.get(), d_ridx_.get(), cnt, st);
+        rk::widen(d_tlen_.get(), cnt, d_tlen64_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_tlen64_.get(), d_toff_.get(), cnt, st);
+        uint32_t k0 = 0, k1 = 0; uint64_t t0 = 0, t1 = 0;
+        MMT_HIP(hipMemcpyAsync(&k0, d_ridx_.get() + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&k1, d_keep_.get() + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&t0, d_toff_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&t1, d_tlen64_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        kept = (size_t)k0 + k1; tbytes = (size_t)(t0 + t1);
+    } else {
+        // PREFIX.mems rows (write_mem, mem_finder.hpp:210-263): every accepted row is written, occurrences in suffix-array order
+        d_wpos_.ensure(cnt); d_wdoc_.ensure(cnt); d_occ64_.ensure(cnt); d_ooff_.ensure(cnt);
+        rk::mem_measure(a, d_keep_.get() /* occurrences per row */, d_tlen_.get(), d_wpos_.get(), d_wdoc_.get(), st);
+        rk::widen(d_keep_.get(), cnt, d_occ64_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_occ64_.get(), d_ooff_.get(), cnt, st);
+        rk::widen(d_tlen_.get(), cnt, d_tlen64_.get(), st);
+        prims::exclusive_sum_u64(d_temp_, d_tlen64_.get(), d_toff_.get(), cnt, st);
+        uint64_t o0 = 0, o1 = 0, t0 = 0, t1 = 0;
+        MMT_HIP(hipMemcpyAsync(&o0, d_ooff_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&o1, d_occ64_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&t0, d_toff_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipMemcpyAsync(&t1, d_tlen64_.get() + (cnt - 1), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        kept = cnt; occ = (size_t)(o0 + o1); tbytes = (size_t)(t0 + t1);
+    }
     sink_rows_done_ = r1;
-    if (!tbytes) return;
+    sink_total_rows_ += kept;
+    auto discard = [&]() {
+        // the rows and their suffix-array entries are dead once their bytes are formatted: the next window starts at slot 0
+        if (!sink_discard_) return;
+        MMT_HIP(hipMemsetAsync(d_count_.get() + 1, 0, 4, st));
+        S.rows_used = 0; sink_rows_done_ = 0; pool_used_ = 0;
+    };
+    if (!tbytes) { discard(); return; }
     // the piece is formatted on the run's stream and copied out on the copy stream (two device pieces in turn: the
     // formatting of a piece waits for the copy of the piece two flushes ago)
     const uint32_t slot_i = sink_pieces_ & 1u;
     DevBuf<char>& piece = d_piece_[slot_i];
     if (sink_pieces_ >= 2) MMT_HIP(hipStreamWaitEvent(st, sink_copied_[slot_i], 0));
-    d_olen_.ensure(kept + 1); d_ooffs_.ensure(kept * N + 1); d_ost_.ensure(kept * N + 1);
     if (piece.size() < tbytes + 1) { MMT_HIP(hipStreamSynchronize(sink_stream_)); piece.ensure(tbytes + tbytes / 4 + 1); }
-    rk::mum_write(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_ridx_.get(), d_toff_.get(), d_olen_.get(),
-                  d_ooffs_.get(), d_ost_.get(), piece.get(), st);
+    if (sink_mum_) {
+        d_olen_.ensure(kept + 1); d_ooffs_.ensure(kept * N + 1); d_ost_.ensure(kept * N + 1);
+        rk::mum_write(a, d_slot_off_.get(), d_slot_st_.get(), d_keep_.get(), d_ridx_.get(), d_toff_.get(), d_olen_.get(),
+                      d_ooffs_.get(), d_ost_.get(), piece.get(), st);
+    } else {
+        d_olen_.ensure(cnt + 1); d_ooffs_.ensure(occ + 1); d_omdoc_.ensure(occ + 1); d_ost_.ensure(occ + 1);
+        rk::mem_write(a, d_ooff_.get(), d_toff_.get(), d_wpos_.get(), d_wdoc_.get(), d_olen_.get(), d_ooffs_.get(),
+                      d_omdoc_.get(), d_ost_.get(), piece.get(), st);
+    }
+    discard();
     SinkPiece pc;
     pc.n = tbytes;
     char* h = sink_host_room(tbytes, &pc.block);
@@ -843,6 +883,7 @@ void Engine::sink_close(bool ok) {
     if (error.empty() && std::rename(sink_tmp_path_.c_str(), sink_path_.c_str()) != 0) error = "cannot rename " + sink_tmp_path_;
     if (!error.empty()) { ::unlink(sink_tmp_path_.c_str()); throw std::runtime_error(error); }
     sink_written_path_ = sink_path_;
+    sink_discarded_ = sink_discard_;
 }
 
 void Engine::make_rows(const mmt_params& p) {
@@ -856,6 +897,14 @@ void Engine::make_rows(const mmt_params& p) {
     R.mum_mode = p.max_doc_freq == 1;                 // mem_finder.hpp:85
     R.n_docs = N;
     bumbl_.clear();
+    if (sink_discarded_ && !sink_written_path_.empty()) {
+        // the rows left with the windows that accepted them (sink_flush): the file and the count are what this run answers for
+        R.n_rows = sink_total_rows_;
+        h_occ_start_.ensure(2); h_occ_start_.get()[0] = 0; R.occ_start = h_occ_start_.get();
+        rows_pending_ = 0;
+        ev_[5]->stop(st);
+        return;
+    }
     const uint32_t n_rows = [&] {
         uint32_t v = 0;
         MMT_HIP(hipMemcpyAsync(&v, d_count_.get() + 1, 4, hipMemcpyDeviceToHost, st));
@@ -1063,6 +1112,7 @@ void Engine::run(const mmt_params& p) {
     for (float& f : scan_ms_) f = 0.f;
     merged_thresh_valid_ = false;
     sink_written_path_.clear();
+    sink_discarded_ = false;
     lcp_col_ready_ = false;
     want_anchor_ranks_ = p.merge_metadata != 0;
     anchor_ranks_valid_ = false;

@@ -305,7 +305,8 @@ private:
     // the text sink (set_text_sink)
     struct SinkPiece { const char* p; size_t n; hipEvent_t ready; uint32_t block; };
     std::string sink_path_, sink_written_path_, sink_tmp_path_;
-    bool sink_active_ = false;
+    bool sink_active_ = false, sink_mum_ = true, sink_discard_ = false, sink_discarded_ = false;
+    uint64_t sink_total_rows_ = 0;
     int sink_fd_ = -1;
     size_t sink_rows_done_ = 0;
     uint64_t sink_bytes_ = 0;

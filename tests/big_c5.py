@@ -22,6 +22,8 @@ ap.add_argument("--div", type=float, default=0.001)
 ap.add_argument("--seed", type=int, default=4)
 ap.add_argument("--samples", type=int, default=200)
 ap.add_argument("--wp", type=int, nargs=2, default=None, help="window and modulus of the parse (default: automatic)")
+ap.add_argument("--out", default="", help="PREFIX: the rank's rows go to PREFIX.mems window by window (a text that fills the device "
+                                         "keeps nothing else of them) and the checks read the file")
 A = ap.parse_args()
 N, L0 = A.haps, A.length
 # (the collection sits in host memory as bytes: a box with less memory than that is not asked to try)
@@ -43,13 +45,17 @@ eng = mumemto_amd.Engine(0)
 eng.set_scan_shard(A.rank, A.ranks)
 if A.wp:
     eng.set_producer("guided", A.wp[0], A.wp[1])
+if A.out:
+    eng.set_text_sink(A.out + ".mems")
 t = time.time()
 parts = eng.run_partitioned(None, flat=(bases, lens), num_distinct=N - 1, max_doc_freq=3)
 dt = time.time() - t
+eng.set_text_sink(None)
 mem = eng.device_memory()
 pieces = eng.sort_pieces()
 st = eng.stream_stats()
-L, occ, off, ids, strands = eng.rows_mem()
+kept = not A.out or os.path.getsize(A.out + ".mems") == 0 or eng.L.mmt_num_occ(eng.h) > 0
+L, occ, off, ids, strands = eng.rows_mem() if kept else (np.zeros(eng.L.mmt_num_rows(eng.h), np.uint8), None, [], None, None)
 print(json.dumps(dict(mode="-k -1 -f 3", rank=A.rank, ranks=A.ranks, text_chars=eng.text_length(), seconds=round(dt, 1),
                       one_run=parts == 1, producer=eng.producer_used(), wide=bool(eng.is_wide()),
                       stage_ms=[round(x) for x in eng.stage_ms()],
@@ -57,9 +63,15 @@ print(json.dumps(dict(mode="-k -1 -f 3", rank=A.rank, ranks=A.ranks, text_chars=
                                                fraction=round(pieces[A.rank][1] / eng.text_length(), 4), produced=st["entries"],
                                                windows=st["windows"], window_bytes=st["window_bytes"]),
                       memory_gb={k: round(v / 2**30, 1) for k, v in mem.items() if k != "map_seconds"},
-                      rows=int(len(L)), occurrences=int(len(off)))), flush=True)
+                      rows=int(len(L)), occurrences=int(len(off)) if kept else None,
+                      output_bytes=os.path.getsize(A.out + ".mems") if A.out else None, rows_kept_on_the_device=bool(kept))), flush=True)
 assert parts == 1 and eng.producer_used() == "guided" and eng.is_wide()
 assert st["entries"] == pieces[A.rank][1], "the rank produced something else than its share of the stream"
 assert abs(pieces[A.rank][1] / eng.text_length() - 1.0 / A.ranks) < 0.05
-bigchecks.check_mem_rows(eng, bases, lens, min_docs=N - 1, max_doc_freq=3, samples=A.samples, text=bigchecks.LazyText(bases, lens))
+if kept:
+    bigchecks.check_mem_rows(eng, bases, lens, min_docs=N - 1, max_doc_freq=3, samples=A.samples, text=bigchecks.LazyText(bases, lens))
+else:
+    bigchecks.check_mems_file(A.out + ".mems", bigchecks.LazyText(bases, lens), lens, min_docs=N - 1, max_doc_freq=3, samples=A.samples)
+if A.out:
+    os.unlink(A.out + ".mems")
 print("OK")

@@ -224,3 +224,49 @@ class LazyText:
         if i < 0 or i >= self.n:
             return np.uint8(0)
         return self[i:i + 1][0]
+
+
+def check_mems_file(path, text, lens, min_docs, max_doc_freq, samples=200, seed=3):
+    """Sampled rows of a PREFIX.mems file (LEN \\t offsets \\t documents \\t strands; include/mem_finder.hpp:210-263): the checks of
+    check_mem_rows on lines read at random places of the file (a run that wrote its rows window by window keeps no arrays)."""
+    import os
+    size = os.path.getsize(path)
+    lens = [int(l) for l in lens]
+    doc_start = np.concatenate([[0], np.cumsum([2 * (l + 1) for l in lens])]).astype(np.int64)
+    rng = np.random.default_rng(seed)
+    checked = rows_seen = 0
+    with open(path, "rb") as f:
+        for at in np.sort(rng.integers(0, max(size - 1, 1), size=samples)):
+            f.seek(int(at))
+            f.readline()
+            line = f.readline()
+            if not line.endswith(b"\n"):
+                continue
+            rows_seen += 1
+            ln, offs, ids, sts = line[:-1].split(b"\t")
+            ln = int(ln); offs = [int(x) for x in offs.split(b",")]; ids = [int(x) for x in ids.split(b",")]; sts = sts.split(b",")
+            assert len(offs) == len(ids) == len(sts)
+            counts = np.bincount(ids, minlength=len(lens))
+            assert (counts > 0).sum() >= min_docs and counts.max() <= max_doc_freq, line[:80]
+            strings, lefts, rights = set(), set(), set()
+            ok = True
+            for k in range(len(offs)):
+                d, o = ids[k], offs[k]
+                if sts[k] == b"+":
+                    tp = int(doc_start[d]) + o
+                else:
+                    if k == len(offs) - 1:
+                        o -= 1
+                    tp = int(doc_start[d]) + 2 * (lens[d] + 1) - o - ln - 1
+                    if o < 0 or o >= 2**63 or tp < int(doc_start[d]) + lens[d] + 1:
+                        ok = False
+                        break
+                strings.add(text[tp:tp + ln].tobytes())
+                lefts.add(int(text[tp - 1]) if tp > 0 else 0); rights.add(int(text[tp + ln]))
+            if not ok:
+                continue
+            checked += 1
+            assert len(strings) == 1 and len(next(iter(strings))) == ln, line[:80]
+            assert len(lefts) > 1 and len(rights) > 1, ("row is not maximal", line[:80])
+    assert checked > 0
+    print("file: %d bytes; %d sampled rows of %d are real, maximal matches in at least %d documents" % (size, checked, rows_seen, min_docs), flush=True)

@@ -125,3 +125,35 @@ def test_bytes_the_parse_reserves_keep_the_byte_layout():
             assert eng.output_text() == O.run(docs, min_len=4, num_distinct=2, max_doc_freq=3).text()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("producer", ["pfp", "guided"])
+def test_rows_written_window_by_window_and_dropped(producer, tmp_path):
+    """What a run over a text that fills the device does with its rows (Engine::sink_flush with `sink_discard_`): every window's
+    accepted rows are formatted, sent to the file and FORGOTTEN -- in the multi-MEM modes too (a rank of BASELINE configs[4]
+    accepts rows with ~94 occurrences each: tens of GB of suffix-array entries, offsets and text that would have to stay in
+    HBM to the end).  The files are the oracle's; the engine answers for the row count only."""
+    import mumemto_amd
+    docs = synth.pangenome(7, 40000, 0.01, seed=33, indel_rate=0.0005, inversion=(3, 3000, 9000))
+    eng = mumemto_amd.Engine(0)
+    try:
+        eng.set_producer(producer)
+        for name, kw in (("mems", dict(num_distinct=6, max_doc_freq=3, max_total_freq=21)), ("mums", dict()),
+                         ("mems", dict(num_distinct=2, max_doc_freq=0, max_total_freq=30))):
+            want = O.run(docs, **kw).text()
+            out = str(tmp_path / ("out." + name))
+            with packed_env(MMT_SINK_DISCARD=1, MMT_SCAN_RANGE=8192, MMT_GUIDED_BATCH=6000):
+                eng.set_text_sink(out)
+                eng.set_docs(docs)
+                eng.run(**kw)
+                eng.set_text_sink(None)
+            assert open(out, "rb").read() == want and want.count(b"\n") > 20
+            assert eng.L.mmt_num_rows(eng.h) == want.count(b"\n")
+            assert eng.stream_stats()["windows"] >= 4 and not os.path.exists(out + ".tmp")
+            # without the sink the same engine keeps its rows as before
+            eng.set_docs(docs)
+            eng.run(**kw)
+            assert eng.output_text() == want
+    finally:
+        eng.set_producer("auto")
+        eng.close()

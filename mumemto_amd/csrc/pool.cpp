@@ -110,13 +110,30 @@ void add_free(std::map<size_t, size_t>& fl, size_t off, size_t size) {
     fl[off] = size;
 }
 
+size_t heap_limit() {
+    static const size_t limit = [] { const char* e = std::getenv("MUMEMTO_HEAP_LIMIT"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+    return limit;
+}
+
+// MUMEMTO_HEAP_RESERVE (bytes, default 0): device memory the heap leaves to the driver and the runtime -- the estimates
+// (pool::available) know about it, unlike MUMEMTO_HEAP_LIMIT, which exists to make an accepted run fail
+size_t driver_reserve() {
+    static const size_t keep = [] { const char* e = std::getenv("MUMEMTO_HEAP_RESERVE"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+    return keep;
+}
+
 // map `bytes` (multiple of GROW) more physical memory at the top of the large region
 bool grow(Heap& H, size_t bytes) {
     if (H.top + bytes > H.small_bottom) return false;
     // MUMEMTO_HEAP_LIMIT (bytes): the large region stops growing there -- how the tests make a run that the estimate
     // accepted run out of device memory
-    static const size_t limit = [] { const char* e = std::getenv("MUMEMTO_HEAP_LIMIT"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+    const size_t limit = heap_limit();
     if (limit && H.top + bytes > limit) return false;
+    if (const size_t keep = driver_reserve()) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
+        if (fr < bytes + keep) return false;
+    }
     const double t0 = now_s();
     size_t done = 0;
     std::string why;
@@ -239,6 +256,8 @@ size_t available(int device) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
     const Stats s = stats(device);
+    const size_t keep = driver_reserve();
+    fr = fr > keep ? fr - keep : 0;
     return fr + (s.mapped - s.live);
 }
 

@@ -26,12 +26,36 @@ ap.add_argument("--out", default="", help="PREFIX: the rank's rows go to PREFIX.
                                          "keeps nothing else of them) and the checks read the file")
 A = ap.parse_args()
 N, L0 = A.haps, A.length
-# (the collection sits in host memory as bytes: a box with less memory than that is not asked to try)
-avail_kb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+# (the collection sits in host memory as bytes: a box with less memory than that is not asked to try.  What counts is the
+# smaller of the machine's MemAvailable and what the container's memory cgroup still allows: a PREFIX on a tmpfs counts
+# against both, and a box that runs out of either is lost with everything on it)
+def _first_int(paths):
+    for q in paths:
+        try:
+            v = open(q).read().strip()
+            if v and v != "max":
+                return int(v)
+        except OSError:
+            pass
+    return None
+
+
+avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 2**20
+cg_max = _first_int(["/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"])
+cg_now = _first_int(["/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"]) or 0
+if cg_max is not None and cg_max < (1 << 60):
+    avail_gb = min(avail_gb, (cg_max - cg_now) / 2**30)
 need_gb = N * L0 / 2**30 * 1.15 + 16
-print(json.dumps(dict(host_available_gb=round(avail_kb / 2**20), host_needed_gb=round(need_gb))), flush=True)
-if avail_kb / 2**20 < need_gb:
-    print("SKIPPED: not enough host memory for the collection")
+# the rank's PREFIX.mems: ~25 bytes per occurrence, 0.055 occurrences per suffix of the share (measured at 250 G characters,
+# divergence 0.001: 1.67 G occurrences in 30.3 G suffixes), and a third on top
+out_gb = 25.0 * 0.055 * (2.0 * N * L0 / A.ranks) / 2**30 * 1.33 if A.out else 0.0
+out_fs = os.statvfs(os.path.dirname(os.path.abspath(A.out)) or "/") if A.out else None
+out_free_gb = out_fs.f_bavail * out_fs.f_frsize / 2**30 if A.out else 0.0
+out_in_memory = bool(A.out) and os.path.abspath(A.out).startswith(("/dev/shm", "/run"))
+print(json.dumps(dict(host_available_gb=round(avail_gb), host_needed_gb=round(need_gb), memory_cgroup_max_gb=cg_max and round(cg_max / 2**30),
+                      output_estimate_gb=round(out_gb), output_dir_free_gb=round(out_free_gb), output_in_memory=out_in_memory)), flush=True)
+if avail_gb < need_gb + (out_gb if out_in_memory else 0.0) or (A.out and out_free_gb < out_gb):
+    print("SKIPPED: not enough host memory (or room for the output) for the collection")
     sys.exit(3)
 t0 = time.time()
 bases = np.empty(N * L0, np.uint8)

@@ -87,6 +87,14 @@ MMT_API int mmt_engine_run(mmt_engine* e, const mmt_params* p);
 MMT_API int mmt_engine_run_partitioned(mmt_engine* e, const uint8_t* h_bases, const uint64_t* doc_len,
                                        size_t n_docs, const mmt_params* p, uint64_t max_text_chars);
 MMT_API size_t mmt_partitions_used(const mmt_engine* e);
+/* The same job with the documents SUPPLIED one at a time instead of resident on the host: supplier(user, d, dst, doc_len[d])
+ * writes the bases of document d to dst and returns 0 (non-zero aborts the run).  It is asked for the documents in order
+ * (for all of them a second time if the text has to be rebuilt).  The reference streams its FASTA files through the parser
+ * and never holds the collection (include/newscan.hpp:265-325); this entry is for collections that do not fit the host as
+ * bytes either (BASELINE configs[4]: 287 GB of bases).  Always ONE text: no anchor partitions.                              */
+typedef int (*mmt_doc_supplier)(void* user, uint64_t doc, uint8_t* dst, uint64_t len);
+MMT_API int mmt_engine_run_supplied(mmt_engine* e, mmt_doc_supplier supplier, void* user, const uint64_t* doc_len,
+                                    size_t n_docs, const mmt_params* p);
 /* build_main in-process (src/pfp_mum.cpp:31-159): FASTA / FASTQ(.gz) files in (one document per file, read on all
  * host cores), PREFIX.mums | PREFIX.mems and PREFIX.lengths out (out_prefix NULL: nothing is written, the rows stay
  * available through the accessors below).  seconds (optional): [0] reading + parsing the files, [1] H2D + the whole

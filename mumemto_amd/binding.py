@@ -37,6 +37,10 @@ class Params(C.Structure):
                 ("max_total_freq", C.c_int64), ("use_revcomp", C.c_uint8), ("merge_metadata", C.c_uint8)]
 
 
+# mmt_doc_supplier (mumemto_gpu.h): int (*)(void* user, uint64_t doc, uint8_t* dst, uint64_t len)
+DOC_SUPPLIER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+
+
 class Partition(C.Structure):  # mmt_partition (mumemto_gpu.h); thresh_bits 0 / 16 / 32
     _fields_ = [("n_rows", C.c_uint64), ("n_docs", C.c_uint64), ("length", C.c_void_p), ("offsets", C.c_void_p),
                 ("strands", C.c_void_p), ("thresh", C.c_void_p), ("thresh_len", C.c_uint64),
@@ -77,6 +81,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
     "mmt_stream_stats", "mmt_engine_release_columns", "mmt_copy_thresh32", "mmt_thresh_device32", "mmt_engine_set_text_sink",
+    "mmt_engine_run_supplied",
 ]
 
 
@@ -157,6 +162,7 @@ def load_library():
     L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_pfp_copy_parse.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_pfp_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.mmt_engine_run_supplied.argtypes = [C.c_void_p, DOC_SUPPLIER, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Params)]
     L.mmt_engine_run_partitioned.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Params),
                                              C.c_uint64]
     L.mmt_engine_run_files.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(Params), C.c_char_p,
@@ -359,6 +365,29 @@ class Engine:
         p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
         _check(self.L.mmt_engine_run_partitioned(self.h, _p(bases), _p(lens), len(lens), C.byref(p), max_text_chars))
         return int(self.L.mmt_partitions_used(self.h))
+
+    def run_supplied(self, lens, supplier, min_match_len=20, use_revcomp=True, num_distinct=0, max_doc_freq=1,
+                     max_total_freq=0, merge_metadata=False):
+        """The documents supplied one at a time: `supplier(d, dst)` writes the bases of document d into the uint8 array dst
+        (len = lens[d], page-locked memory of the engine).  For collections that do not fit the host as bytes; always one
+        text (mmt_engine_run_supplied)."""
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        failure = []
+
+        def _fill(_user, d, dst, n):
+            try:
+                supplier(int(d), np.ctypeslib.as_array(C.cast(dst, C.POINTER(C.c_uint8)), shape=(int(n),)))
+                return 0
+            except BaseException as exc:                       # (an exception must not unwind through the C frames)
+                failure.append(exc)
+                return 1
+        cb = DOC_SUPPLIER(_fill)
+        p = Params(min_match_len, num_distinct, max_doc_freq, max_total_freq, int(use_revcomp), int(merge_metadata))
+        rc = self.L.mmt_engine_run_supplied(self.h, cb, None, _p(lens), len(lens), C.byref(p))
+        if failure:
+            raise failure[0]
+        _check(rc)
+        return 1
 
     def run_files(self, paths, out_prefix=None, min_match_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0,
                   use_revcomp=True, merge_metadata=False, max_text_chars=0):

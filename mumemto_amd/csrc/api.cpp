@@ -271,6 +271,13 @@ int mmt_engine_run_partitioned(mmt_engine* e, const uint8_t* h_bases, const uint
     e->e->run_partitioned_host(h_bases, doc_len, n_docs, *p, max_text_chars);
     MMT_CATCH
 }
+int mmt_engine_run_supplied(mmt_engine* e, mmt_doc_supplier supplier, void* user, const uint64_t* doc_len, size_t n_docs,
+                            const mmt_params* p) {
+    if (!e || !p || !supplier || (!doc_len && n_docs)) return fail(1, "engine, params, supplier and doc_len must be non-null");
+    MMT_TRY
+    e->e->run_supplied(supplier, user, doc_len, n_docs, *p);
+    MMT_CATCH
+}
 // build_main (src/pfp_mum.cpp:31-159) in-process: FASTA files -> text -> stream -> scan -> PREFIX.mums | .mems +
 // PREFIX.lengths.  The same reader and the same engine entry as mumemto_exec.
 int mmt_engine_run_files(mmt_engine* e, const char* const* paths, size_t n_paths, const mmt_params* p,

@@ -37,6 +37,7 @@ Engine::~Engine() {
 void Engine::set_input_device(const uint8_t* d_bases, const uint64_t* doc_len, size_t n_docs) {
     MMT_HIP(hipSetDevice(device_));
     host_docs_.clear();
+    supplier_ = nullptr; supplier_user_ = nullptr;
     d_bases_ = d_bases;
     preset_ = 0;
     input_valid_ = true;
@@ -89,6 +90,25 @@ void Engine::set_input_host_docs_deferred(const uint8_t* const* doc_ptr, const u
     set_input_device(nullptr, doc_len, n_docs);
     host_docs_.assign(doc_ptr, doc_ptr + n_docs);
 }
+
+void Engine::set_input_supplier(DocSupplier fn, void* user, const uint64_t* doc_len, size_t n_docs) {
+    if (!fn) throw std::runtime_error("set_input_supplier: no supplier");
+    MMT_HIP(hipSetDevice(device_));
+    d_bases_own_.release();
+    set_input_device(nullptr, doc_len, n_docs);
+    supplier_ = fn; supplier_user_ = user;
+}
+
+namespace {
+// page-locked host memory for the documents a supplier writes
+struct PinnedBytes {
+    uint8_t* p = nullptr;
+    explicit PinnedBytes(size_t n) { MMT_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), n ? n : 1, hipHostMallocDefault)); }
+    ~PinnedBytes() { if (p) (void)hipHostFree(p); }
+    PinnedBytes(const PinnedBytes&) = delete;
+    PinnedBytes& operator=(const PinnedBytes&) = delete;
+};
+}  // namespace
 
 // document layout of the text: starts of the documents, total length, device copy of the starts
 void Engine::layout_docs(bool revcomp) {
@@ -222,14 +242,27 @@ void Engine::build_text(bool revcomp) {
     d_hist_.ensure(256);
     MMT_HIP(hipMemsetAsync(d_hist_.get(), 0, 256 * 8, stream_));
     packed_ = want_packed_text();
-    const bool deferred = !host_docs_.empty() && d_bases_ == nullptr;
+    const bool deferred = (!host_docs_.empty() || supplier_) && d_bases_ == nullptr;
+    uint64_t longest = 0;
+    for (size_t d = 0; d < N; d++) longest = std::max(longest, doc_len_[d]);
+    auto supply = [&](size_t d, uint8_t* dst) {
+        if (doc_len_[d] && supplier_(supplier_user_, d, dst, doc_len_[d]) != 0)
+            throw std::runtime_error("the supplier of the documents failed at document " + std::to_string(d));
+    };
     auto upload_deferred = [&]() {                     // the byte layout reads all raw bases from the device
         uint64_t total = 0;
         for (size_t d = 0; d < N; d++) total += doc_len_[d];
         d_bases_own_.ensure(total + 16);
         uint64_t at = 0;
+        std::unique_ptr<PinnedBytes> host[2];
+        if (supplier_) { host[0].reset(new PinnedBytes(longest)); host[1].reset(new PinnedBytes(longest)); }
         for (size_t d = 0; d < N; d++) {
-            if (doc_len_[d]) MMT_HIP(hipMemcpyAsync(d_bases_own_.get() + at, host_docs_[d], doc_len_[d], hipMemcpyHostToDevice, stream_));
+            const uint8_t* src = supplier_ ? host[d & 1]->p : host_docs_[d];
+            if (supplier_) {
+                if (d >= 2) MMT_HIP(hipStreamSynchronize(stream_));          // (the copy of document d - 2 has left the buffer)
+                supply(d, host[d & 1]->p);
+            }
+            if (doc_len_[d]) MMT_HIP(hipMemcpyAsync(d_bases_own_.get() + at, src, doc_len_[d], hipMemcpyHostToDevice, stream_));
             at += doc_len_[d];
         }
         MMT_HIP(hipStreamSynchronize(stream_));
@@ -247,10 +280,10 @@ void Engine::build_text(bool revcomp) {
         MMT_HIP(hipMemsetAsync(ev_count.get(), 0, 8, stream_));
         if (deferred) {
             // document by document through two staging buffers: the copy of document d + 1 runs beside the packing of d
-            uint64_t longest = 0;
-            for (size_t d = 0; d < N; d++) longest = std::max(longest, doc_len_[d]);
             DevBuf<uint8_t> stage[2];
             stage[0].ensure(longest + 64); stage[1].ensure(longest + 64);
+            std::unique_ptr<PinnedBytes> host[2];      // supplied documents: written here while the device packs the one before
+            if (supplier_) { host[0].reset(new PinnedBytes(longest)); host[1].reset(new PinnedBytes(longest)); }
             hipStream_t cs = nullptr;
             MMT_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipEvent_t copied[2], packed_ev[2];
@@ -258,8 +291,13 @@ void Engine::build_text(bool revcomp) {
             try {
                 for (size_t d = 0; d < N; d++) {
                     const int b = (int)(d & 1);
+                    const uint8_t* src = supplier_ ? host[b]->p : host_docs_[d];
+                    if (supplier_) {
+                        if (d >= 2) MMT_HIP(hipEventSynchronize(copied[b]));            // the copy of document d - 2 has left host[b]
+                        supply(d, host[b]->p);
+                    }
                     if (d >= 2) MMT_HIP(hipStreamWaitEvent(cs, packed_ev[b], 0));          // the buffer is free again
-                    if (doc_len_[d]) MMT_HIP(hipMemcpyAsync(stage[b].get(), host_docs_[d], doc_len_[d], hipMemcpyHostToDevice, cs));
+                    if (doc_len_[d]) MMT_HIP(hipMemcpyAsync(stage[b].get(), src, doc_len_[d], hipMemcpyHostToDevice, cs));
                     MMT_HIP(hipEventRecord(copied[b], cs));
                     MMT_HIP(hipStreamWaitEvent(stream_, copied[b], 0));
                     // (raw + doc_base[d] = the staging buffer)

@@ -82,6 +82,15 @@ public:
     // 143 GB packed) is then packed document by document through a staging buffer (build_text); a text that keeps one byte
     // per character is uploaded as a whole when the run begins.
     void set_input_host_docs_deferred(const uint8_t* const* doc_ptr, const uint64_t* doc_len, size_t n_docs);
+    // The documents SUPPLIED one at a time: `fn(user, d, dst, doc_len[d])` writes the bases of document d to dst (page-locked,
+    // doc_len[d] bytes) and returns 0; it is asked for the documents in order, for every one again when the text is built a
+    // second time (a packed text that turns out to hold bytes the parse reserves is rebuilt with a byte per character).  The reference
+    // streams its FASTA files through the parser and never holds the collection (include/newscan.hpp:265-325): this is the
+    // entry for a collection that does not fit the HOST either (configs[4]: 287 GB of bases).  run_supplied runs it as ONE
+    // text (no anchor partitions: those would read the documents again).
+    using DocSupplier = int (*)(void* user, uint64_t doc, uint8_t* dst, uint64_t len);
+    void set_input_supplier(DocSupplier fn, void* user, const uint64_t* doc_len, size_t n_docs);
+    void run_supplied(DocSupplier fn, void* user, const uint64_t* doc_len, size_t n_docs, const mmt_params& p);
     // Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): the caller hands over
     // the text T itself (UPPER(F) '$' [revcomp '$'] per document, e.g. rebuilt from PREFIX.parse/.dict) or the
     // whole stream (SA / LCP / BWT of the real suffixes, sentinel entry dropped); run() then skips the stages
@@ -274,6 +283,8 @@ private:
     std::vector<ExcRun> h_runs_;
     bool packed_ = false;
     std::vector<const uint8_t*> host_docs_;        // deferred host input (set_input_host_docs_deferred)
+    DocSupplier supplier_ = nullptr;               // ... or its supplier (set_input_supplier)
+    void* supplier_user_ = nullptr;
     // One-shot / wide runs: suffix array (low words, high bytes) and BWT are views into one block that is allocated
     // before any scratch (it then sits at the bottom of the device heap, and what is above it leaves one hole when it
     // goes).  The emitter writes these columns only after the dictionary and the parse are sorted, so until then the

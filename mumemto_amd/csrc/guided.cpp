@@ -461,6 +461,13 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     PfpState& S = *pfp_;
     const uint64_t n = n_;
     hipStream_t st = stream_;
+    DevBuf<unsigned long long> prof;
+    if (std::getenv("MMT_GUIDED_PROF")) {
+        prof.ensure(16);
+        MMT_HIP(hipMemsetAsync(prof.get(), 0, 16 * 8, st));
+        S.gctx.prof = prof.get();
+    }
+    struct ProfOff { gk::Ctx& c; ~ProfOff() { c.prof = nullptr; } } prof_off{S.gctx};
     const gk::Ctx& ctx = S.gctx;
     const int prefix_chars = S.g_prefix;
     const uint32_t n_bins = S.g_nbins;
@@ -590,6 +597,17 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
         b0 = b1;
     }
     guided_check_errors("text suffixes");
+    if (prof.get()) {
+        std::vector<unsigned long long> h(16);
+        MMT_HIP(hipMemcpyAsync(h.data(), prof.get(), 16 * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        const double w = (double)std::max<unsigned long long>(1, h[7]);
+        std::fprintf(stderr, "[guided] k_resolve_medium: %llu waves; ticks of the 100 MHz clock per wave: staging %.0f, reference %.0f, "
+                     "first comparison %.0f, network %.0f, output %.0f; members with a difference %llu, undecided %llu, text "
+                     "comparisons inside the network %llu; members %llu, of them in the reference's class %llu, groups whose best class has one member %llu, "
+                     "groups where half the members differ from the reference %llu, members that repeat another's (place, character) %llu\n",
+                     h[7], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[8], h[9], h[10], h[12], h[11], h[13], h[14], h[15]);
+    }
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
     S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     MMT_HIP(hipStreamSynchronize(st));

@@ -96,9 +96,26 @@ void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, ui
 // The phrase ends as a LIST instead of a bit per text position (Ctx::coff): the offsets inside their blocks of 4096 positions,
 // two bytes per phrase, and the number of phrase ends before every block -- 3.8 GB instead of the 81 GB the bits and their
 // rank directory take on 573 G characters (BASELINE configs[4]).  A block's entries are found by its two counts.
+// (an 8-ary search: seven pivots asked for at once, then the last eight entries at once -- two or three round trips to memory
+// for the 26 ... 140 phrase ends of a block where a binary search makes five to eight, each waiting for the one before)
 __device__ __forceinline__ uint32_t list_lower(const Ctx& c, uint32_t lo, uint32_t hi, uint32_t t) {
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)c.coff[mid] < t) lo = mid + 1; else hi = mid; }
-    return lo;                                                    // first entry of [lo, hi) with offset >= t
+    if (hi <= lo) return lo;
+    while (hi - lo > 8) {
+        const uint32_t step = (hi - lo + 7) >> 3;
+        uint32_t pv[7];
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) { const uint32_t at = lo + (k + 1) * step; pv[k] = at < hi ? (uint32_t)c.coff[at] : 0xffffu; }
+        uint32_t below = 0;                                       // (ascending: the pivots below t are the first `below`)
+#pragma unroll
+        for (uint32_t k = 0; k < 7; k++) below += pv[k] < t ? 1u : 0u;
+        const uint32_t nlo = below ? lo + below * step + 1 : lo;
+        const uint32_t nhi = below < 7 && lo + (below + 1) * step < hi ? lo + (below + 1) * step : hi;
+        lo = nlo; hi = nhi;
+    }
+    uint32_t less = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) { const uint32_t v = lo + k < hi ? (uint32_t)c.coff[lo + k] : 0xffffu; less += v < t ? 1u : 0u; }
+    return lo + less;                                             // first entry of [lo, hi) with offset >= t
 }
 __device__ __forceinline__ uint64_t list_next_cut(const Ctx& c, uint64_t x) {
     const uint64_t b = x >> 12;
@@ -181,6 +198,49 @@ __device__ __forceinline__ bool giant_entry(const Ctx& c, uint64_t q, uint64_t o
     r = c.g_isa[(uint64_t)c.g_base[lo] + (q + off - c.g_ps[lo])];
     return true;
 }
+// The first t in [from, stop) with V[qa + t] != V[qb + t] (ca, cb = the two characters), or `stop`.  A walk is a chain of
+// dependent round trips to memory, so each trip carries as much as a lane can ask for at once: 64 characters a side as
+// words of codes when the text is packed, else 32 characters as four independent 8-byte loads a side (those that begin
+// before `stop`: nothing is read that the loop of single words would not have read).
+__device__ __forceinline__ uint64_t first_diff(const Ctx& c, uint64_t qa, uint64_t qb, uint64_t from, uint64_t stop,
+                                               uint32_t& ca, uint32_t& cb) {
+    uint64_t t = from;
+    while (t < stop) {
+        if (c.T.is_packed() && t + 64 <= stop) {
+            uint64_t xl, xh, yl, yh;
+            const bool oka = tx_codes64(c.T, qa + t, xl, xh), okb = tx_codes64(c.T, qb + t, yl, yh);
+            if (oka && okb) {
+                if (xl != yl || xh != yh) {
+                    const bool low = xl != yl;
+                    const uint64_t x = low ? xl : xh, y = low ? yl : yh;
+                    const uint32_t k = (uint32_t)__builtin_ctzll(x ^ y) >> 1;
+                    ca = tx_code_char((uint32_t)(x >> (2 * k)) & 3u); cb = tx_code_char((uint32_t)(y >> (2 * k)) & 3u);
+                    return t + (low ? 0u : 32u) + k;
+                }
+                t += 64;
+                continue;
+            }
+        }
+        uint64_t x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool in = t + 8 * k < stop;
+            x[k] = in ? tx_load8(c.T, qa + t + 8 * k) : 0ull; y[k] = in ? tx_load8(c.T, qb + t + 8 * k) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (x[k] != y[k]) {
+                const uint32_t d = (uint32_t)__builtin_ctzll(x[k] ^ y[k]) >> 3;
+                const uint64_t at = t + 8 * k + d;
+                if (at >= stop) return stop;
+                ca = (uint32_t)(x[k] >> (8 * d)) & 0xffu; cb = (uint32_t)(y[k] >> (8 * d)) & 0xffu;
+                return at;
+            }
+        t += 32;
+    }
+    return stop;
+}
+
 // Order of alpha(qa) and alpha(qb) (la, lb characters), known to agree in their first `from` characters: -1 / +1, or 0 when
 // they are the same phrase suffix (prefix-free: no difference before the shorter one ends).  *lcp = characters the two
 // suffixes share when a character decided.  Beyond g_depth characters two alphas that both go on lie in giant phrases and
@@ -191,24 +251,17 @@ __device__ __forceinline__ int cmp_rest(const Ctx& c, uint64_t qa, uint64_t la, 
     // (64 characters are compared first -- most pairs differ there; two alphas that go on may both lie in giant phrases)
     const bool giant = c.g_n && from + 64 < L;
     const uint64_t stop = giant ? from + 64 : L;
-    for (uint64_t t = from; t < stop; t += 8) {
-        const uint64_t x = tx_load8(c.T, qa + t), y = tx_load8(c.T, qb + t);
-        if (x != y) {
-            const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
-            if (t + d < stop) { if (lcp) *lcp = t + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff) ? -1 : 1; }
-            break;
-        }
+    uint32_t ca = 0, cb = 0;
+    if (from < stop) {
+        const uint64_t at = first_diff(c, qa, qb, from, stop, ca, cb);
+        if (at < stop) { if (lcp) *lcp = at; return ca < cb ? -1 : 1; }
     }
     if (!giant) return 0;
     uint32_t ra = 0, rb = 0;
     if (!giant_entry(c, qa, stop, ra) || !giant_entry(c, qb, stop, rb)) {
-        for (uint64_t t = stop; t < L; t += 8) {                // one of them in an ordinary phrase: at most g_depth characters
-            const uint64_t x = tx_load8(c.T, qa + t), y = tx_load8(c.T, qb + t);
-            if (x != y) {
-                const uint32_t d = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
-                if (t + d < L) { if (lcp) *lcp = t + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff) ? -1 : 1; }
-                break;
-            }
+        if (stop < L) {                                         // one of them in an ordinary phrase: at most g_depth characters
+            const uint64_t at = first_diff(c, qa, qb, stop, L, ca, cb);
+            if (at < L) { if (lcp) *lcp = at; return ca < cb ? -1 : 1; }
         }
         return 0;
     }
@@ -612,7 +665,10 @@ void medium_groups(const uint32_t* ghead, uint32_t m, void* list, uint32_t cap, 
 // the staged members of the groups one wave works on (W = 64 or 128 members)
 template <int W>
 struct MedStage {
-    uint64_t w[W][MED_WORDS];
+    // (the class of up to 128 members -- the copies of a locus in the 94 haplotypes of BASELINE configs[3] / [4] -- stages 32
+    // characters a member instead of 64: 56 KB of LDS a workgroup left two waves a SIMD)
+    static constexpr uint32_t WORDS = W > 64 ? 4 : MED_WORDS;
+    uint64_t w[W][WORDS];
     uint64_t rank[W];
     uint64_t rec[W];
     uint32_t len[W];
@@ -622,6 +678,12 @@ struct MedStage {
     // member's character there
     uint32_t dref[W];
     uint16_t cref[W];
+    // ... and, for the members that differ from the reference at the same place with the same character as an earlier member
+    // (a mutation shared by descent; every member when the reference itself carries a private one): the first of them
+    // (`lead`) and where the member's alpha first differs from THAT one's beyond the shared place, as above
+    uint32_t d2[W];
+    uint16_t c2[W];
+    uint8_t lead[W];
     uint32_t gr[W], gg[W];            // members in giant phrases: entry of the giant dictionary's suffix array at `offset`, its group
     uint8_t idx[W];
     uint32_t bad;
@@ -656,8 +718,27 @@ __device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_
     if (da != MED_SAME) {
         const uint32_t ca = S.cref[a] & 0xffu, cb = S.cref[b] & 0xffu;
         if (ca != cb) { if (lcp) *lcp = da; return ca < cb; }
-        const int r2 = cmp_rest(c, rec_pos(c, S.rec[a]), S.len[a], rec_pos(c, S.rec[b]), S.len[b], (uint64_t)da + 1, lcp);
-        if (r2) return r2 < 0;
+        // the same place, the same character: both were compared with the first member of their kind
+        const uint32_t ea = S.d2[a], eb = S.d2[b];
+        uint64_t from = (uint64_t)da + 1;
+        bool text = ea == MED_UNKNOWN || eb == MED_UNKNOWN;
+        if (!text && ea != eb) {
+            const bool a_first = ea < eb;
+            const uint32_t cc = S.c2[a_first ? a : b];
+            if (lcp) *lcp = a_first ? ea : eb;
+            const bool x_small = (cc & 0xffu) < (cc >> 8);
+            return a_first ? x_small : !x_small;
+        }
+        if (!text && ea != MED_SAME) {
+            const uint32_t fa = S.c2[a] & 0xffu, fb = S.c2[b] & 0xffu;
+            if (fa != fb) { if (lcp) *lcp = ea; return fa < fb; }
+            text = true; from = (uint64_t)ea + 1;                  // (a third shared mutation: the text decides)
+        }
+        if (text) {
+            if (c.prof) atomicAdd(c.prof + 10, 1ull);
+            const int r2 = cmp_rest(c, rec_pos(c, S.rec[a]), S.len[a], rec_pos(c, S.rec[b]), S.len[b], from, lcp);
+            if (r2) return r2 < 0;
+        }
     }
     if (S.len[a] != S.len[b]) S.bad = 1;
     const uint64_t ra = S.rank[a], rb = S.rank[b];
@@ -683,7 +764,7 @@ __device__ __forceinline__ bool med_before_chars(const Ctx& c, MedStage<W>& S, u
         }
     } else
 #pragma unroll
-    for (uint32_t t = 0; t < MED_WORDS; t++) {
+    for (uint32_t t = 0; t < MedStage<W>::WORDS; t++) {
         const uint64_t at = offset + 8 * t;
         if (at >= L) break;                                  // alpha of the shorter one is spent: same phrase suffix
         const uint64_t x = S.w[a][t], y = S.w[b][t];
@@ -692,7 +773,7 @@ __device__ __forceinline__ bool med_before_chars(const Ctx& c, MedStage<W>& S, u
             if (at + d < L) { if (lcp) *lcp = at + d; return ((x >> (8 * d)) & 0xff) < ((y >> (8 * d)) & 0xff); }
             break;
         }
-        if (t + 1 == MED_WORDS && at + 8 < L) {              // (rare: alphas beyond the staged characters)
+        if (t + 1 == MedStage<W>::WORDS && at + 8 < L) {     // (rare: alphas beyond the staged characters)
             const int r2 = cmp_rest(c, rec_pos(c, S.rec[a]), la, rec_pos(c, S.rec[b]), lb, at + 8, lcp);
             if (r2) return r2 < 0;
         }
@@ -711,7 +792,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
                                                         uint32_t* __restrict__ err) {
     constexpr int PERL = W / 64, GPW = W / SEG;              // members per lane, groups per wave
     __shared__ MedStage<W> s_st[4];
-    __shared__ uint32_t s_g0[4][GPW], s_g[4][GPW];
+    __shared__ uint32_t s_g0[4][GPW], s_g[4][GPW], s_ref[4][GPW];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     MedStage<W>& S = s_st[wave];
     const uint64_t gw = ((uint64_t)blockIdx.x * 4 + wave) * GPW;     // first group of this wave
@@ -721,6 +802,8 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
         s_g0[wave][lane] = grp.x; s_g[wave][lane] = have ? grp.y : 0u;
     }
     if (lane == 0) S.bad = 0;
+    unsigned long long tick = c.prof ? wall_clock64() : 0ull;
+#define MMT_PROF(slot) do { if (c.prof) { const unsigned long long now_ = wall_clock64(); if (lane == 0) atomicAdd(c.prof + (slot), now_ - tick); tick = now_; } } while (0)
 #define MMT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
     MMT_WAVE_SYNC();
 #pragma unroll
@@ -730,8 +813,16 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
         if (mem < s_g[wave][seg]) {
             const uint64_t rec = pos[s_g0[wave][seg] + mem];
             const uint64_t q = rec_pos(c, rec);
+            constexpr uint32_t WORDS = MedStage<W>::WORDS;
+            static_assert(WORDS == 8 || WORDS == 4, "the staging reads 64 or 32 characters");
+            uint64_t c_lo = 0, c_hi = 0;
+            if (c.T.is_packed() && tx_codes64(c.T, q + offset, c_lo, c_hi)) {       // (one round trip for the staged characters)
 #pragma unroll
-            for (uint32_t t = 0; t < MED_WORDS; t++) S.w[i][t] = tx_load8(c.T, q + offset + 8 * t);
+                for (uint32_t t = 0; t < 4; t++) { S.w[i][t] = tx_expand8(c_lo >> (16 * t)); if (WORDS == 8) S.w[i][(4 + t) % WORDS] = tx_expand8(c_hi >> (16 * t)); }
+            } else {
+#pragma unroll
+                for (uint32_t t = 0; t < WORDS; t++) S.w[i][t] = tx_load8(c.T, q + offset + 8 * t);
+            }
             const uint64_t len = rec_len(c, rec, q);
             S.len[i] = len < 0xffffffffull ? (uint32_t)len : 0xffffffffu;
             uint32_t pid = 0xffffffffu;
@@ -746,28 +837,60 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             S.rec[i] = rec;
             uint32_t r = 0xffffffffu;
             // (what the staged words cannot decide is looked up, not compared, when the member lies in a giant phrase)
-            if (c.g_n && len > offset + 8 * MED_WORDS && !giant_entry(c, q, offset, r)) r = 0xffffffffu;
+            // (only an alpha that runs beyond giant depth needs it: a shorter rest of a giant phrase is compared in the text like
+            // any other, at most g_depth characters -- and with phrases of 170 characters "longer than the staged 64" was nearly
+            // every member, a rank query and a random line each)
+            if (c.g_n && len > offset + 8 * WORDS && len > (uint64_t)c.g_depth && !giant_entry(c, q, offset, r)) r = 0xffffffffu;
             S.gr[i] = r;
             S.gg[i] = r != 0xffffffffu ? c.g_grp[r] : 0u;
         }
     }
     // (a wave works on its own stage: ordering its LDS traffic inside the wave is all the synchronisation there is)
     MMT_WAVE_SYNC();
-    // every member against the first member of its group (med_before)
+    MMT_PROF(0);
+    // The reference member of a group: one that starts in the group's MOST COMMON phrase at the same place -- the copies of a
+    // locus without a mutation in their phrase -- so that the largest class of members needs no comparison at all and the
+    // reference's alpha is the one most of the others spell too.  (The first member as the reference carries a private
+    // mutation in every fourth group of a text with 170-character phrases: then EVERY other member differs from it at the
+    // same place with the same character, and the sorting network below compared each pair of them in the text, log^2
+    // times: 1.7 of the 2.1 s a G suffixes of such a text took.)
+    if (lane < (uint32_t)GPW) s_ref[wave][lane] = 0u;
+    MMT_WAVE_SYNC();
+    if (c.pid && !c.skip && !c.rec_rank) {
+#pragma unroll
+        for (int h = 0; h < PERL; h++) {
+            const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
+            const uint32_t g = s_g[wave][seg];
+            if (mem >= g) continue;
+            const uint32_t my_pid = S.pid[i], my_len = S.len[i];
+            uint32_t same = 0;
+            if (my_pid != 0xffffffffu && S.gr[i] == 0xffffffffu)
+                for (uint32_t j = 0; j < g; j++) same += (S.pid[seg * SEG + j] == my_pid && S.len[seg * SEG + j] == my_len) ? 1u : 0u;
+            atomicMax(&s_ref[wave][seg], (same << 8) | (uint32_t)(SEG - 1 - mem));
+        }
+        MMT_WAVE_SYNC();
+    }
+    MMT_PROF(1);
+    if (c.prof && lane < (uint32_t)GPW && s_g[wave][lane]) {
+        atomicAdd(c.prof + 11, (unsigned long long)(s_ref[wave][lane] >> 8));
+        atomicAdd(c.prof + 12, (unsigned long long)s_g[wave][lane]);
+        if ((s_ref[wave][lane] >> 8) <= 1) atomicAdd(c.prof + 13, 1ull);
+    }
+    // every member against the reference member of its group (med_before)
 #pragma unroll
     for (int h = 0; h < PERL; h++) {
         const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
         if (mem >= s_g[wave][seg]) continue;
-        const uint32_t ref = seg * SEG;
+        const uint32_t ref = seg * SEG + (s_ref[wave][seg] ? (uint32_t)(SEG - 1) - (s_ref[wave][seg] & 0xffu) : 0u);
         uint32_t d = MED_UNKNOWN, cc = 0;
-        if (!c.skip && S.gr[i] == 0xffffffffu && S.gr[ref] == 0xffffffffu && !(c.g_n && S.len[ref] > offset + 8 * MED_WORDS && S.len[i] > offset + 8 * MED_WORDS && c.g_depth <= offset + 8 * MED_WORDS)) {
+        if (!c.skip && S.gr[i] == 0xffffffffu && S.gr[ref] == 0xffffffffu && !(c.g_n && S.len[ref] > offset + 8 * MedStage<W>::WORDS && S.len[i] > offset + 8 * MedStage<W>::WORDS && c.g_depth <= offset + 8 * MedStage<W>::WORDS)) {
             const uint64_t la = S.len[i], lb = S.len[ref], L = la < lb ? la : lb;
             if (i == ref || (la == lb && S.pid[i] == S.pid[ref] && S.pid[i] != 0xffffffffu)) d = MED_SAME;
             else {
                 d = MED_SAME;
                 bool decided = false;
 #pragma unroll
-                for (uint32_t t = 0; t < MED_WORDS && !decided; t++) {
+                for (uint32_t t = 0; t < MedStage<W>::WORDS && !decided; t++) {
                     const uint64_t at = offset + 8 * t;
                     if (at >= L) { decided = true; break; }
                     const uint64_t x = S.w[i][t], y = S.w[ref][t];
@@ -781,22 +904,60 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
                     const uint64_t qa = rec_pos(c, S.rec[i]), qb = rec_pos(c, S.rec[ref]);
                     // (a stretch that runs into giant depth is the giant dictionary's: left to the comparison of characters)
                     const uint64_t stop = c.g_n && L > (uint64_t)c.g_depth ? (uint64_t)c.g_depth : L;
-                    for (uint64_t t = offset + 8 * MED_WORDS; t < stop; t += 8) {
-                        const uint64_t x = tx_load8(c.T, qa + t), y = tx_load8(c.T, qb + t);
-                        if (x != y) {
-                            const uint32_t k = (uint32_t)__builtin_ctzll(x ^ y) >> 3;
-                            if (t + k < L) { d = (uint32_t)(t + k); cc = (uint32_t)((x >> (8 * k)) & 0xff) | ((uint32_t)((y >> (8 * k)) & 0xff) << 8); }
-                            decided = true;
-                            break;
-                        }
+                    const uint64_t t0 = offset + 8 * MedStage<W>::WORDS;
+                    if (t0 < stop) {
+                        uint32_t ca = 0, cb = 0;
+                        const uint64_t at = first_diff(c, qa, qb, t0, stop, ca, cb);
+                        if (at < stop) { d = (uint32_t)at; cc = ca | (cb << 8); decided = true; }
                     }
                     if (!decided && stop < L) d = MED_UNKNOWN;
                 }
             }
         }
         S.dref[i] = d; S.cref[i] = (uint16_t)cc;
+        if (c.prof && d != MED_SAME) atomicAdd(c.prof + (d == MED_UNKNOWN ? 9 : 8), 1ull);
     }
     MMT_WAVE_SYNC();
+    // second level: the members that repeat an earlier member's (place, character) against the first of their kind
+#pragma unroll
+    for (int h = 0; h < PERL; h++) {
+        const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
+        if (mem >= s_g[wave][seg]) continue;
+        const uint32_t d = S.dref[i];
+        uint32_t leader = i, e = MED_SAME, cc = 0;
+        if (d != MED_SAME && d != MED_UNKNOWN) {
+            const uint32_t mine = S.cref[i] & 0xffu;
+            for (uint32_t j = seg * SEG; j < i; j++)
+                if (S.dref[j] == d && (S.cref[j] & 0xffu) == mine) { leader = j; break; }
+            if (leader != i) {
+                const uint64_t la = S.len[i], lb = S.len[leader], L = la < lb ? la : lb;
+                const uint64_t stop = c.g_n && L > (uint64_t)c.g_depth ? (uint64_t)c.g_depth : L;
+                const uint64_t t0 = (uint64_t)d + 1;
+                if (S.pid[i] != 0xffffffffu && S.pid[i] == S.pid[leader] && la == lb) {
+                } else if (t0 < stop) {
+                    uint32_t ca = 0, cb = 0;
+                    const uint64_t at = first_diff(c, rec_pos(c, S.rec[i]), rec_pos(c, S.rec[leader]), t0, stop, ca, cb);
+                    if (at < stop) { e = (uint32_t)at; cc = ca | (cb << 8); }
+                    else if (stop < L) e = MED_UNKNOWN;
+                } else if (stop < L) e = MED_UNKNOWN;
+            }
+        }
+        S.lead[i] = (uint8_t)leader; S.d2[i] = e; S.c2[i] = (uint16_t)cc;
+    }
+    MMT_WAVE_SYNC();
+    if (c.prof && lane < (uint32_t)GPW && s_g[wave][lane]) {
+        uint32_t diff = 0, shared = 0;
+        for (uint32_t j = 0; j < s_g[wave][lane]; j++) {
+            const uint32_t dj = S.dref[lane * SEG + j];
+            if (dj == MED_SAME || dj == MED_UNKNOWN) continue;
+            diff++;
+            for (uint32_t k2 = 0; k2 < j; k2++)
+                if (S.dref[lane * SEG + k2] == dj && (S.cref[lane * SEG + k2] & 0xff) == (S.cref[lane * SEG + j] & 0xff)) { shared++; break; }
+        }
+        if (2 * diff >= s_g[wave][lane]) atomicAdd(c.prof + 14, 1ull);
+        atomicAdd(c.prof + 15, (unsigned long long)shared);
+    }
+    MMT_PROF(2);
     // bitonic network over the SEG index slots of every group (members beyond the group sort last): log^2 steps of
     // compare-exchanges instead of g^2 / 2 comparisons
     for (uint32_t k = 2; k <= (uint32_t)SEG; k <<= 1) {
@@ -833,6 +994,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
         }
     }
 #undef MMT_WAVE_SYNC
+    MMT_PROF(3);
     if (S.bad && lane == 0) atomicAdd(err + (c.skip ? 0 : 1), 1u);
 #pragma unroll
     for (int h = 0; h < PERL; h++) {
@@ -855,6 +1017,9 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             lcp_out[at] = l < (uint64_t)LCP_CAP ? (uint32_t)l : LCP_CAP;
         }
     }
+    MMT_PROF(4);
+    if (c.prof && lane == 0) atomicAdd(c.prof + 7, 1ull);
+#undef MMT_PROF
 }
 template <int SEG, int W>
 static void resolve_medium_class(const Ctx& c, const RmqView& R, const uint64_t* pos, const uint32_t* slot, const uint2* list,

@@ -50,6 +50,8 @@ struct Ctx {
     const uint32_t* g_k = nullptr; const uint64_t* g_ps = nullptr; const uint32_t* g_base = nullptr; uint32_t g_n = 0;
     const uint32_t* g_isa = nullptr; const uint32_t* g_grp = nullptr; RmqView g_rmq; uint32_t g_depth = 0;
     const uint32_t* g_bits = nullptr;                        // bit k: phrase k of the parse is a giant occurrence
+    // MMT_GUIDED_PROF: 16 counters of k_resolve_medium (clock ticks per phase summed over the waves, waves, walks); else nullptr
+    unsigned long long* prof = nullptr;
 };
 
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions

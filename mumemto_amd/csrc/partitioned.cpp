@@ -62,6 +62,14 @@ void Engine::run_once_dropping_input(const mmt_params& p) {
     drop_input_after_text_ = false;
 }
 
+void Engine::run_supplied(DocSupplier fn, void* user, const uint64_t* doc_len, size_t n_docs, const mmt_params& p) {
+    MMT_HIP(hipSetDevice(device_));
+    forget_last_run();
+    set_input_supplier(fn, user, doc_len, n_docs);
+    try { run_once_dropping_input(p); } catch (...) { supplier_ = nullptr; supplier_user_ = nullptr; throw; }
+    supplier_ = nullptr; supplier_user_ = nullptr;
+}
+
 void Engine::run_partitioned_host(const uint8_t* h_bases, const uint64_t* doc_len, size_t n_docs, const mmt_params& p,
                                   uint64_t max_text) {
     std::vector<const uint8_t*> ptr(n_docs);

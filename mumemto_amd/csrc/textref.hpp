@@ -79,15 +79,20 @@ __device__ __forceinline__ uint8_t tx_byte(const TextRef& T, uint64_t q) {
     if (p >= T.n) return p < T.n + 32 ? (uint8_t)2 : (uint8_t)0;
     return tx_packed_char(T, p);
 }
-// V[q .. q + 8) as one little-endian word (what an unaligned 8-byte load of the byte layout gives)
+// V[q .. q + 8) as one little-endian word (what an unaligned 8-byte load of the byte layout gives).  Packed: the flag words
+// and the two words of codes are asked for together (a reader that walks a text pays one round trip to memory per call, not
+// one for the flags and another for the codes).
 __device__ __forceinline__ uint64_t tx_load8(const TextRef& T, uint64_t q) {
     if (T.v) { uint64_t x; __builtin_memcpy(&x, T.v + q, 8); return x; }
     if (q >= 1 && q + 7 <= T.n) {                                 // text positions p .. p + 7 all inside the text
         const uint64_t p = q - 1;
-        if (!tx_block_flag(T, p) && !tx_block_flag(T, p + 7)) {
+        const uint64_t b0 = p >> TX_BLOCK_SHIFT, b1 = (p + 7) >> TX_BLOCK_SHIFT;
+        const uint64_t f0 = T.excw[b0 >> 6], f1 = T.excw[b1 >> 6];
+        const uint64_t w0 = T.packed[p >> 5], w1 = T.packed[(p >> 5) + 1];
+        if (!(((f0 >> (b0 & 63)) | (f1 >> (b1 & 63))) & 1ull)) {
             const uint32_t sh = 2 * (uint32_t)(p & 31);
-            uint64_t bits = T.packed[p >> 5] >> sh;
-            if (sh > 48) bits |= T.packed[(p >> 5) + 1] << (64 - sh);
+            uint64_t bits = w0 >> sh;
+            if (sh > 48) bits |= w1 << (64 - sh);
             return tx_expand8(bits);
         }
     }
@@ -96,6 +101,23 @@ __device__ __forceinline__ uint64_t tx_load8(const TextRef& T, uint64_t q) {
     for (int k = 0; k < 8; k++) x |= (uint64_t)tx_byte(T, q + k) << (8 * k);
     return x;
 }
+// PACKED only: the codes of V[q .. q + 64) as two words (character k of a word in bits 2k, 2k + 1); false when one of them is
+// not a plain base inside the text (the caller then reads bytes).  Two texts are compared 64 characters a step by the XOR of
+// such words: the first set bit pair is the first difference.  All loads are issued before the first is looked at.
+__device__ __forceinline__ bool tx_codes64(const TextRef& T, uint64_t q, uint64_t& lo, uint64_t& hi) {
+    if (q < 1 || q + 63 > T.n) return false;
+    const uint64_t p = q - 1;
+    const uint64_t b0 = p >> TX_BLOCK_SHIFT, b1 = (p + 63) >> TX_BLOCK_SHIFT;
+    const uint64_t f0 = T.excw[b0 >> 6], f1 = T.excw[b1 >> 6];
+    const uint64_t* w = T.packed + (p >> 5);                       // (two words of padding behind the text)
+    const uint64_t w0 = w[0], w1 = w[1], w2 = w[2];
+    if (((f0 >> (b0 & 63)) | (f1 >> (b1 & 63))) & 1ull) return false;
+    const uint32_t sh = 2 * (uint32_t)(p & 31);
+    lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+    hi = sh ? (w1 >> sh) | (w2 << (64 - sh)) : w1;
+    return true;
+}
+__device__ __forceinline__ uint8_t tx_code_char(uint32_t c) { return (uint8_t)(0x41u + 2u * c + 2u * (c >> 1) + 11u * (c & (c >> 1))); }
 // text positions p0 .. p0 + 15 (p0 a multiple of 16; positions from n on as V has them: Dollars, then zeros) as 16 bytes
 __device__ __forceinline__ uint4 tx_load16(const TextRef& T, uint64_t p0) {
     if (T.v) return *reinterpret_cast<const uint4*>(T.v + 1 + p0);

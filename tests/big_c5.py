@@ -22,6 +22,8 @@ ap.add_argument("--div", type=float, default=0.001)
 ap.add_argument("--seed", type=int, default=4)
 ap.add_argument("--samples", type=int, default=200)
 ap.add_argument("--wp", type=int, nargs=2, default=None, help="window and modulus of the parse (default: automatic)")
+ap.add_argument("--supplied", default="auto", choices=["auto", "yes", "no"],
+                help="the documents supplied to the engine one at a time (mmt_engine_run_supplied) instead of resident on the host")
 ap.add_argument("--out", default="", help="PREFIX: the rank's rows go to PREFIX.mems window by window (a text that fills the device "
                                          "keeps nothing else of them) and the checks read the file")
 A = ap.parse_args()
@@ -45,23 +47,31 @@ cg_max = _first_int(["/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.
 cg_now = _first_int(["/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"]) or 0
 if cg_max is not None and cg_max < (1 << 60):
     avail_gb = min(avail_gb, (cg_max - cg_now) / 2**30)
-need_gb = N * L0 / 2**30 * 1.15 + 16
 # the rank's PREFIX.mems: ~25 bytes per occurrence, 0.055 occurrences per suffix of the share (measured at 250 G characters,
 # divergence 0.001: 1.67 G occurrences in 30.3 G suffixes), and a third on top
 out_gb = 25.0 * 0.055 * (2.0 * N * L0 / A.ranks) / 2**30 * 1.33 if A.out else 0.0
 out_fs = os.statvfs(os.path.dirname(os.path.abspath(A.out)) or "/") if A.out else None
 out_free_gb = out_fs.f_bavail * out_fs.f_frsize / 2**30 if A.out else 0.0
 out_in_memory = bool(A.out) and os.path.abspath(A.out).startswith(("/dev/shm", "/run"))
+resident_gb = N * L0 / 2**30 * 1.15 + 16                    # the collection as bytes on the host
+supplied_gb = 4.0 * L0 / 2**30 + 0.03 * N + 16              # ancestor, two page-locked documents, substitution lists
+supplied = A.supplied == "yes" or (A.supplied == "auto" and avail_gb < resident_gb + (out_gb if out_in_memory else 0.0))
+need_gb = (supplied_gb if supplied else resident_gb) + (out_gb if out_in_memory else 0.0)
 print(json.dumps(dict(host_available_gb=round(avail_gb), host_needed_gb=round(need_gb), memory_cgroup_max_gb=cg_max and round(cg_max / 2**30),
-                      output_estimate_gb=round(out_gb), output_dir_free_gb=round(out_free_gb), output_in_memory=out_in_memory)), flush=True)
-if avail_gb < need_gb + (out_gb if out_in_memory else 0.0) or (A.out and out_free_gb < out_gb):
+                      documents="supplied one at a time" if supplied else "resident on the host", output_estimate_gb=round(out_gb),
+                      output_dir_free_gb=round(out_free_gb), output_in_memory=out_in_memory)), flush=True)
+if avail_gb < need_gb or (A.out and out_free_gb < out_gb):
     print("SKIPPED: not enough host memory (or room for the output) for the collection")
     sys.exit(3)
 t0 = time.time()
-bases = np.empty(N * L0, np.uint8)
-for k, (h, b) in enumerate(synth.haplotypes_sparse(94, L0, A.div, A.seed, which=list(range(N)))):
-    bases[k * L0:(k + 1) * L0] = b
 lens = np.full(N, L0, np.uint64)
+model = bigchecks.SparseModel(94, L0, A.div, A.seed, which=list(range(N)))
+if supplied:
+    bases = model                                    # (the checks read the documents from the model)
+else:
+    bases = np.empty(N * L0, np.uint8)
+    for k in range(N):
+        model.fill(k, bases[k * L0:(k + 1) * L0])
 n_text = 2 * N * (L0 + 1)
 print(json.dumps(dict(generated_s=round(time.time() - t0, 1), haps=N, length=L0, text_chars=n_text)), flush=True)
 os.environ["MMT_GUIDED_STATS"] = "1"
@@ -72,13 +82,23 @@ if A.wp:
 if A.out:
     eng.set_text_sink(A.out + ".mems")
 t = time.time()
-parts = eng.run_partitioned(None, flat=(bases, lens), num_distinct=N - 1, max_doc_freq=3)
+if supplied:
+    t_fill = [0.0]
+
+    def supplier(d, dst):
+        t1 = time.time()
+        model.fill(d, dst)
+        t_fill[0] += time.time() - t1
+    parts = eng.run_supplied(lens, supplier, num_distinct=N - 1, max_doc_freq=3)
+    print(json.dumps(dict(supplier_s=round(t_fill[0], 1))), flush=True)
+else:
+    parts = eng.run_partitioned(None, flat=(bases, lens), num_distinct=N - 1, max_doc_freq=3)
 dt = time.time() - t
 eng.set_text_sink(None)
 mem = eng.device_memory()
 pieces = eng.sort_pieces()
 st = eng.stream_stats()
-kept = not A.out or os.path.getsize(A.out + ".mems") == 0 or eng.L.mmt_num_occ(eng.h) > 0
+kept = not A.out or not os.path.exists(A.out + ".mems") or os.path.getsize(A.out + ".mems") == 0 or eng.L.mmt_num_occ(eng.h) > 0
 L, occ, off, ids, strands = eng.rows_mem() if kept else (np.zeros(eng.L.mmt_num_rows(eng.h), np.uint8), None, [], None, None)
 print(json.dumps(dict(mode="-k -1 -f 3", rank=A.rank, ranks=A.ranks, text_chars=eng.text_length(), seconds=round(dt, 1),
                       one_run=parts == 1, producer=eng.producer_used(), wide=bool(eng.is_wide()),
@@ -89,7 +109,7 @@ print(json.dumps(dict(mode="-k -1 -f 3", rank=A.rank, ranks=A.ranks, text_chars=
                       memory_gb={k: round(v / 2**30, 1) for k, v in mem.items() if k != "map_seconds"},
                       rows=int(len(L)), occurrences=int(len(off)) if kept else None,
                       output_bytes=os.path.getsize(A.out + ".mems") if A.out else None, rows_kept_on_the_device=bool(kept))), flush=True)
-assert parts == 1 and eng.producer_used() == "guided" and eng.is_wide()
+assert parts == 1 and eng.producer_used() == "guided" and (eng.is_wide() or n_text < 2**32)
 assert st["entries"] == pieces[A.rank][1], "the rank produced something else than its share of the stream"
 assert abs(pieces[A.rank][1] / eng.text_length() - 1.0 / A.ranks) < 0.05
 if kept:

@@ -175,6 +175,67 @@ def check_mem_rows(eng, bases, lens, min_docs, max_doc_freq, samples=300, seed=2
     print("rows: %d rows with %d occurrences; %d sampled rows are real, maximal matches" % (len(L), len(off), checked), flush=True)
 
 
+class SparseModel:
+    """mumemto_amd.synth.haplotypes_sparse as a random-access model: the ancestor + the substitutions of every haplotype, so
+    that a collection that does not fit the host as bytes (94 x 3.05 Gbp = 287 GB; the boxes of this pool give a container
+    300 GiB) can be SUPPLIED document by document (`fill`) and read back piecewise by the checks (`doc(h)[a:b]`)."""
+    _ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+    def __init__(self, n_total, length, divergence, seed, which):
+        rng = np.random.default_rng(seed)
+        self.length, self.div, self.seed, self.which = length, divergence, seed, list(which)
+        self.anc = rng.integers(0, 4, size=length, dtype=np.uint8)
+        self.anc_ascii = self._ACGT[self.anc]
+        self._subs = {}
+
+    def _draw(self, h):
+        hrng = np.random.default_rng([self.seed, h + 1])
+        k = int(hrng.binomial(self.length, self.div)) if self.div > 0 else 0
+        if not k:
+            return np.zeros(0, np.int64), np.zeros(0, np.uint8)
+        pos = hrng.integers(0, self.length, size=k)
+        return pos, self._ACGT[(self.anc[pos] + hrng.integers(1, 4, size=k, dtype=np.uint8)) & 3]
+
+    def fill(self, d, dst):
+        """the bases of document d (= haplotype which[d]) into dst, exactly as haplotypes_sparse yields them"""
+        pos, val = self._draw(self.which[d])
+        np.copyto(dst, self.anc_ascii)
+        dst[pos] = val
+
+    def subs(self, d):
+        if d not in self._subs:
+            pos, val = self._draw(self.which[d])
+            # dst[pos] = val: the last write to a position wins
+            order = np.argsort(pos, kind="stable")
+            pos, val = pos[order], val[order]
+            last = np.ones(len(pos), bool)
+            last[:-1] = pos[1:] != pos[:-1]
+            self._subs[d] = (pos[last], val[last])
+        return self._subs[d]
+
+    def doc(self, d):
+        return _ModelDoc(self, d)
+
+
+class _ModelDoc:
+    def __init__(self, model, d):
+        self.m, self.d = model, d
+
+    def __len__(self):
+        return self.m.length
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b, step = key.indices(self.m.length)
+            assert step == 1
+            seg = self.m.anc_ascii[a:b].copy()
+            pos, val = self.m.subs(self.d)
+            i, j = np.searchsorted(pos, a), np.searchsorted(pos, b)
+            seg[pos[i:j] - a] = val[i:j]
+            return seg
+        return self[int(key):int(key) + 1][0]
+
+
 class LazyText:
     """T = F $ revcomp(F) $ per document, read from the bases on demand (a 250 G-character text does not get a host copy):
     text[i] and text[a:b] as numpy uint8, positions beyond the text read as 0."""
@@ -185,10 +246,16 @@ class LazyText:
         self.base_start = np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int64)
         self.n = int(self.doc_start[-1])
 
+    def _doc(self, d):
+        """the bases of document d: a view of the flat array, or of the model a supplied collection was generated from"""
+        if hasattr(self.bases, "doc"):
+            return self.bases.doc(d)
+        return self.bases[self.base_start[d]:self.base_start[d + 1]]
+
     def _piece(self, d, lo, hi):
         """local positions [lo, hi) of document d"""
         L = self.lens[d]
-        f = self.bases[self.base_start[d]:self.base_start[d + 1]]
+        f = self._doc(d)
         out = np.empty(hi - lo, np.uint8)
         for k, p in enumerate(range(lo, hi)):
             if p < L:
@@ -210,7 +277,7 @@ class LazyText:
                 lo = p - int(self.doc_start[d])
                 # long stretches inside one strand: vectorised
                 L = self.lens[d]
-                f = self.bases[self.base_start[d]:self.base_start[d + 1]]
+                f = self._doc(d)
                 hi = end - int(self.doc_start[d])
                 if hi <= L:
                     out[p - a:end - a] = f[lo:hi]

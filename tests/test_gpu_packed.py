@@ -155,5 +155,89 @@ def test_rows_written_window_by_window_and_dropped(producer, tmp_path):
             eng.run(**kw)
             assert eng.output_text() == want
     finally:
+        os.environ.pop("MMT_GUIDED_NO_RANK", None)
+        eng.set_producer("auto")
+        eng.close()
+
+
+@pytest.mark.parametrize("packed", [1, 0])
+def test_documents_supplied_one_at_a_time(packed):
+    """mmt_engine_run_supplied: the engine asks for the documents in order and packs (or uploads) each from its own page-locked
+    buffer -- the host never holds the collection (BASELINE configs[4]: 287 GB of bases; the reference streams its FASTA files
+    through the parser, include/newscan.hpp:265-325).  Same bytes as the oracle's run over the resident documents; a supplier
+    that fails stops the run with its own exception."""
+    import mumemto_amd
+    docs = _awkward_docs()
+    flat = [b"".join(d).upper() for d in docs]
+    lens = np.array([len(f) for f in flat], np.uint64)
+    asked = []
+
+    def supplier(d, dst):
+        asked.append(d)
+        assert dst.dtype == np.uint8 and len(dst) == len(flat[d])
+        dst[:] = np.frombuffer(flat[d], np.uint8)
+
+    eng = mumemto_amd.Engine(0)
+    try:
+        with packed_env(MMT_PACKED_TEXT=packed):
+            for kw in (dict(), dict(num_distinct=5, max_doc_freq=3)):
+                asked.clear()
+                eng.run_supplied(lens, supplier, **kw)
+                assert asked == list(range(len(docs)))
+                assert eng.output_text() == O.run(docs, **kw).text()
+                assert bytes(eng.text()) == bytes(O.build_text(docs, True)[0])
+
+            def broken(d, dst):
+                if d == 3:
+                    raise KeyError("no such document")
+                supplier(d, dst)
+            with pytest.raises(KeyError):
+                eng.run_supplied(lens, broken)
+            # the engine is usable afterwards
+            eng.run_supplied(lens, supplier)
+            assert eng.output_text() == O.run(docs).text()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("packed,copies,length", [(1, 6, 50000), (0, 6, 50000), (1, 18, 14000), (0, 18, 14000)])
+def test_long_phrases_and_shared_variants_in_the_groups_of_copies(packed, copies, length):
+    """The bucket-wise producer on what a text of hundreds of G characters looks like to it (modulus 157: phrases of ~170
+    characters) with variants that are SHARED by descent: 24 or 72 haplotypes (groups of up to 32 / up to 128 copies: two
+    instantiations of the kernel) in four clades, clade variants + private ones.  The
+    copies of a locus form one group; its members are compared once with a reference member chosen by majority
+    (k_resolve_medium), 64 characters a round trip; members that share a variant differ from the reference at the same place
+    with the same character and are compared further in the text.  Bytes of the oracle's, both text layouts."""
+    import mumemto_amd
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    anc = rng.choice(acgt, size=length).astype(np.uint8)
+
+    def mutate(s, k):
+        s = s.copy()
+        pos = rng.integers(0, len(s), size=k)
+        s[pos] = acgt[(np.searchsorted(acgt, s[pos]) + rng.integers(1, 4, size=k)) & 3]
+        return s
+    docs = []
+    for clade in range(4):
+        base = mutate(anc, length // 400)
+        for _ in range(copies):
+            docs.append([mutate(base, length // 1200).tobytes()])
+    eng = mumemto_amd.Engine(0)
+    try:
+        with packed_env(MMT_PACKED_TEXT=packed):
+            for w, p, no_rank in ((14, 157, 1), (10, 60, 0)):       # (MMT_GUIDED_NO_RANK: the records of a text beyond ~2^33 characters)
+                os.environ["MMT_GUIDED_NO_RANK"] = "1" if no_rank else "0"
+                if not no_rank:
+                    os.environ.pop("MMT_GUIDED_NO_RANK")
+                eng.set_producer("guided", w, p)
+                for kw in (dict(), dict(num_distinct=len(docs) - 1, max_doc_freq=3), dict(num_distinct=len(docs) // 2, max_doc_freq=2)):
+                    eng.set_docs(docs)
+                    eng.run(**kw)
+                    assert eng.producer_used() == "guided"
+                    want = O.run(docs, **kw).text()
+                    assert eng.output_text() == want and want.count(b"\n") > 50
+    finally:
+        os.environ.pop("MMT_GUIDED_NO_RANK", None)
         eng.set_producer("auto")
         eng.close()

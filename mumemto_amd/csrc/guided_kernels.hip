@@ -673,9 +673,9 @@ struct MedStage {
     uint64_t rec[W];
     uint32_t len[W];
     uint32_t pid[W];                  // id of the distinct phrase the member starts in (0xffffffff: unknown)
-    // every member against the FIRST member of its group: where the two alphas first differ (MED_SAME: they are the same
-    // alpha; MED_UNKNOWN: not computed -- giant phrases, elements that are whole phrases), the member's and the first
-    // member's character there
+    // every member against the REFERENCE member of its group: where the two alphas first differ (MED_SAME: they are the same
+    // alpha; MED_UNKNOWN: not computed -- giant phrases, elements that are whole phrases), the member's and the reference's
+    // character there
     uint32_t dref[W];
     uint16_t cref[W];
     // ... and, for the members that differ from the reference at the same place with the same character as an earlier member
@@ -698,10 +698,13 @@ __device__ __forceinline__ bool med_before_chars(const Ctx& c, MedStage<W>& S, u
 // Comparing two of them character by character costs a chain of dependent loads that runs up to that place -- and the
 // sorting network asks log^2 times per member, every stage as slow as its slowest lane (with the phrases of a 250 G-character
 // text, 171 characters on average, that was 5.1 of the 5.5 s a G suffixes took).  Each member is compared ONCE instead, with
-// the first member of its group (k_resolve_medium, after the staging): d = the first position where its alpha differs
-// from that one's.  Then for two members a, b: d_a < d_b: b agrees with the first member at d_a, so a's character there
-// against the first member's decides, and they share d_a characters; d_a = d_b: their own characters there decide, and only
-// if those are equal too (the same variant in two haplotypes) does the comparison go on in the text.
+// the REFERENCE member of its group (k_resolve_medium, after the staging: a member of the largest class of members that
+// start at the same place of the same distinct phrase): d = the first position where its alpha differs from that one's.
+// Then for two members a, b: d_a < d_b: b agrees with the reference at d_a, so a's character there against the reference's
+// decides, and they share d_a characters; d_a = d_b: their own characters there decide.  If those are equal too -- a
+// mutation two haplotypes share by descent, or the reference itself carrying a private one (then every other member) --
+// both were compared a second time, with the first member of their kind (`lead`, d2, c2), and the same rule applies one
+// level down; only a third shared difference sends the pair to the text (cmp_rest).
 template <int W>
 __device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_t a, uint32_t b, uint64_t offset, uint64_t* lcp) {
     const uint32_t da = S.dref[a], db = S.dref[b];

@@ -185,6 +185,23 @@ static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
         }
     }
     std::remove(comm_file.c_str());
+    // the ranks of a sharded run (-k / -f modes) that wrote their rows as pieces, PREFIX.rankR.mems: rows come out in order of
+    // their closing position and a rank's share is a range of the stream, so the pieces in rank order are the file of one GPU
+    for (const char* ext : {".mums", ".mems"}) {
+        const std::string first = o.output_prefix + ".rank0" + ext;
+        if (rc || !fs::exists(first)) continue;
+        std::ofstream all(o.output_prefix + ext, std::ios::binary | std::ios::trunc);
+        std::vector<char> buf(64u << 20);
+        for (int r = 0; r < o.gpus; r++) {
+            const std::string piece = o.output_prefix + ".rank" + std::to_string(r) + ext;
+            std::ifstream in(piece, std::ios::binary);
+            if (!in) { log_line("build_main", "the piece of rank " + std::to_string(r) + " is missing: " + piece); rc = 1; break; }
+            while (in) { in.read(buf.data(), (std::streamsize)buf.size()); all.write(buf.data(), in.gcount()); }
+            in.close();
+            std::remove(piece.c_str());
+        }
+        if (!all) { log_line("build_main", "could not write " + o.output_prefix + ext); rc = 1; }
+    }
     return rc;
 }
 
@@ -200,6 +217,192 @@ static void fetch_id(const std::string& path, uint8_t id[128]) {
         usleep(10000);
     }
     throw CliError{"rank 0 never left the communicator id in " + path, 1};
+}
+
+// ---- a collection that does not fit the HOST as bytes ----------------------------------------------------------------------
+// The reference streams every FASTA file through its parser once and never holds the collection (src/ref_builder.cpp:211-314
+// writes the text to a file, include/newscan.hpp:265-325 reads that).  Here: the lengths first (every file parsed once on the
+// reader threads, the bases thrown away: PREFIX.lengths and the layout of the text need them), then the documents one at a
+// time when the engine asks (Engine::run_supplied), the next files read ahead by one thread.  Chosen when the files together
+// exceed half of what the host may still use (/proc/meminfo, the memory cgroup); MUMEMTO_STREAM_INPUT=1 | 0 forces either.
+static uint64_t host_memory_available() {
+    uint64_t avail = ~0ull;
+    { std::ifstream f("/proc/meminfo"); std::string k; uint64_t v; std::string unit;
+      while (f >> k >> v >> unit) if (k == "MemAvailable:") { avail = v * 1024; break; } }
+    auto first_number = [](std::initializer_list<const char*> paths, uint64_t& out) {
+        for (const char* q : paths) { std::ifstream f(q); std::string w; if (f >> w && w != "max") { out = std::strtoull(w.c_str(), nullptr, 10); return true; } }
+        return false;
+    };
+    uint64_t cg_max = 0, cg_now = 0;
+    if (first_number({"/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"}, cg_max) && cg_max < (1ull << 60)) {
+        (void)first_number({"/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"}, cg_now);
+        avail = std::min<uint64_t>(avail, cg_max > cg_now ? cg_max - cg_now : 0);
+    }
+    return avail;
+}
+static bool want_streamed_input(const std::vector<std::string>& inputs, size_t copies = 1) {       // copies: processes that each hold it
+    if (const char* e = std::getenv("MUMEMTO_STREAM_INPUT")) return std::atoi(e) != 0;
+    uint64_t bound = 0;                                      // bases at most: a compressed file counted four times
+    for (const auto& p : inputs) {
+        std::error_code ec;
+        const uint64_t sz = (uint64_t)fs::file_size(p, ec);
+        if (ec) continue;
+        bound += (p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0) ? 4 * sz : sz;
+    }
+    return (double)bound * (double)copies > 0.5 * (double)host_memory_available();
+}
+struct StreamedInput {
+    std::vector<std::string> paths;
+    std::vector<FastaDoc> docs;
+    std::vector<uint64_t> len;
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<size_t, std::vector<uint8_t>>> ready;   // documents read ahead, in order
+    size_t expect = 0;                                           // the document the engine will ask for next
+    bool stop = false;
+    std::exception_ptr error;
+    static constexpr size_t depth = 2;
+
+    // every file once: names, record lengths, total (the bases are dropped); index of the first file without bases, or -1
+    long measure() {
+        const size_t N = paths.size();
+        docs.assign(N, FastaDoc()); len.assign(N, 0);
+        std::atomic<size_t> next{0};
+        std::exception_ptr first_error;
+        std::mutex emu;
+        const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(reader_threads(), 8), N));
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; t++) th.emplace_back([&]() {
+            std::vector<uint8_t> scratch;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= N) break;
+                try { scratch.clear(); docs[i] = read_fasta(paths[i], scratch); len[i] = docs[i].total; }
+                catch (...) { std::lock_guard<std::mutex> lk(emu); if (!first_error) first_error = std::current_exception(); }
+            }
+        });
+        for (auto& t : th) t.join();
+        if (first_error) std::rethrow_exception(first_error);
+        for (size_t i = 0; i < N; i++) if (!len[i]) return (long)i;
+        return -1;
+    }
+    void halt() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        if (worker.joinable()) worker.join();
+        stop = false; ready.clear();
+    }
+    void start(size_t from) {
+        halt();
+        expect = from;
+        worker = std::thread([this, from]() {
+            try {
+                for (size_t d = from; d < paths.size(); d++) {
+                    std::vector<uint8_t> bases;
+                    bases.reserve(len[d]);
+                    (void)read_fasta(paths[d], bases);
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return ready.size() < depth || stop; });
+                    if (stop) return;
+                    ready.emplace_back(d, std::move(bases));
+                    cv.notify_all();
+                }
+            } catch (...) { std::lock_guard<std::mutex> lk(mu); error = std::current_exception(); cv.notify_all(); }
+        });
+    }
+    // Engine::DocSupplier
+    static int supply(void* user, uint64_t d, uint8_t* dst, uint64_t n) {
+        StreamedInput& S = *static_cast<StreamedInput*>(user);
+        try {
+            if (!S.worker.joinable() || S.expect != d) S.start((size_t)d);     // (the text is built a second time: from the top)
+            std::vector<uint8_t> bases;
+            {
+                std::unique_lock<std::mutex> lk(S.mu);
+                S.cv.wait(lk, [&] { return !S.ready.empty() || S.error; });
+                if (S.error) return 1;
+                if (S.ready.front().first != d) return 1;
+                bases = std::move(S.ready.front().second);
+                S.ready.pop_front();
+                S.expect = (size_t)d + 1;
+            }
+            S.cv.notify_all();
+            if (bases.size() != n) return 1;                                    // (the file changed between the two passes)
+            std::memcpy(dst, bases.data(), n);
+            return 0;
+        } catch (...) { return 1; }
+    }
+    ~StreamedInput() { halt(); }
+};
+
+// mumemto_exec over a streamed collection: FASTA -> PREFIX.mums | .mems | .bumbl + PREFIX.lengths (+ -n / -M files), one text
+static int run_streamed(BuildOptions& o, const std::vector<std::string>& inputs, bool mum_mode) {
+    if (o.keep_temp || o.only_parse || o.arrays_out)
+        throw CliError{"-K, -P and -A need the collection on the host: not available when the input is streamed (MUMEMTO_STREAM_INPUT)", 1};
+    auto t0 = std::chrono::steady_clock::now();
+    StreamedInput in;
+    in.paths = inputs;
+    std::unique_ptr<Engine> engine;
+    std::exception_ptr engine_error;
+    std::thread engine_init([&]() {
+        try { engine.reset(new Engine(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr)); }
+        catch (...) { engine_error = std::current_exception(); }
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } engine_joiner{engine_init};
+    const long empty = in.measure();
+    if (empty >= 0) {
+        std::cerr << std::endl << "Empty input file found: " << inputs[(size_t)empty] << std::endl;
+        throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
+    }
+    write_lengths_file(o.output_prefix, in.docs);
+    uint64_t n_bases = 0, text_chars = 0;
+    for (uint64_t l : in.len) { n_bases += l; text_chars += (o.use_rcomp ? 2 : 1) * (l + 1); }
+    std::fprintf(stderr, "\033[32m[build_main] \033[0mmeasured %zu files, %llu bases (the documents are read again, one at a time, "
+                 "when the device asks) ... done.  (%.3f sec)\n", in.docs.size(), (unsigned long long)n_bases, secs_since(t0));
+    in.start(0);                                          // the first documents are read while the engine comes up
+    engine_init.join();
+    if (engine_error) std::rethrow_exception(engine_error);
+    Engine& eng = *engine;
+    t0 = std::chrono::steady_clock::now();
+    mmt_params p{};
+    p.min_match_len = (uint32_t)o.min_match_len;
+    p.num_distinct = (uint64_t)o.num_distinct_docs;
+    p.max_doc_freq = o.rare_freq;
+    p.max_total_freq = o.max_mem_freq;
+    p.use_revcomp = o.use_rcomp ? 1 : 0;
+    p.merge_metadata = o.merge ? 1 : 0;
+    if (!o.binary) eng.set_text_sink(o.output_prefix + (mum_mode ? ".mums" : ".mems"));
+    try { eng.run_supplied(&StreamedInput::supply, &in, in.len.data(), in.len.size(), p); }
+    catch (...) {
+        eng.set_text_sink(std::string());
+        if (in.error) std::rethrow_exception(in.error);  // (what the reader met, not "the supplier failed")
+        throw;
+    }
+    eng.set_text_sink(std::string());
+    in.halt();
+    const HostRows& R = eng.rows_meta();
+    std::fprintf(stderr, "\033[32m[build_main] \033[0mfinding multi-%ss on the GPU ... done.  (%.3f sec)\n", mum_mode ? "MUM" : "MEM",
+                 secs_since(t0));
+    if (!mum_mode) eng.write_text_file(o.output_prefix + ".mems");      // (nothing left to do when the run streamed it)
+    else if (o.binary) { const std::string& b = eng.bumbl(); write_file(o.output_prefix + ".bumbl", b.data(), b.size()); }
+    else eng.write_text_file(o.output_prefix + ".mums");
+    if (o.anchor_merge) {                           // mem_finder.hpp:110-115
+        std::vector<uint16_t> th(eng.thresh_len());
+        eng.copy_thresh(th.data());
+        write_file(o.output_prefix + ".athresh", th.data(), (in.len[0] + 1) * sizeof(uint16_t));
+    } else if (o.merge) {                           // mem_finder.hpp:116-157
+        std::vector<uint16_t> fwd, rev;
+        eng.thresh_files(fwd, rev);
+        write_file(o.output_prefix + ".thresh", fwd.data(), fwd.size() * 2);
+        write_file(o.output_prefix + ".thresh_rev", rev.data(), rev.size() * 2);
+    }
+    log_line("build_main", "Found " + std::to_string(R.n_rows) + " matches!");
+    const float* ms = eng.stage_ms();
+    std::fprintf(stderr, "GPU stages (ms): text %.2f | suffix sort %.2f (stream windows %.2f of it) | lcp+bwt %.2f | scan %.2f | verify %.2f | rows %.2f\n\n",
+                 ms[0], ms[1], ms[6], ms[2], ms[3], ms[4], ms[5]);
+    std::fflush(stdout); std::fflush(stderr);
+    if (!std::getenv("MUMEMTO_FULL_TEARDOWN")) std::_Exit(0);
+    return 0;
 }
 
 static int run_rank(BuildOptions& o) {
@@ -221,11 +424,20 @@ static int run_rank(BuildOptions& o) {
         mine.push_back(inputs[0]);
         mine.insert(mine.end(), inputs.begin() + first, inputs.begin() + first + count);
     } else mine = inputs;
+    // The modes that shard the STREAM hold the whole collection on every rank: when that is more than the host can take
+    // (eight copies of 94 whole genomes), every rank reads its documents one at a time as its engine asks (StreamedInput); and
+    // each writes its rows window by window to its own piece of the output, PREFIX.rankR.mems, which the launcher joins --
+    // nothing is gathered over the links (a rank of BASELINE configs[4] writes 66 GB).  MUMEMTO_RANK_PIECES=1 | 0 forces either.
+    const bool streamed = !strict && want_streamed_input(mine, (size_t)world);
+    const bool pieces = !strict && (std::getenv("MUMEMTO_RANK_PIECES") ? std::atoi(std::getenv("MUMEMTO_RANK_PIECES")) != 0 : streamed);
     Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
     HostArena arena;
     HostDocs hd;
     std::vector<FastaDoc> docs;
-    const long empty = read_fasta_collection(mine, docs, arena, hd);
+    StreamedInput in;
+    long empty = -1;
+    if (streamed) { in.paths = mine; empty = in.measure(); docs = in.docs; hd.len = in.len; }
+    else empty = read_fasta_collection(mine, docs, arena, hd);
     if (empty >= 0) throw CliError{"Empty input file found: " + mine[(size_t)empty], 1};
     // PREFIX.lengths in pieces: every rank describes the documents only it has read, rank 0 joins them after the exchange
     if (strict) {
@@ -239,9 +451,12 @@ static int run_rank(BuildOptions& o) {
     p.max_total_freq = o.max_mem_freq;
     p.use_revcomp = o.use_rcomp ? 1 : 0;
     p.merge_metadata = strict ? 1 : 0;
-    uint8_t id[128];
-    if (rank == 0) { comm_unique_id(id); leave_id(o.comm_file, id); } else fetch_id(o.comm_file, id);
-    Comm* comm = comm_create(eng, rank, world, id);
+    Comm* comm = nullptr;
+    if (!pieces) {
+        uint8_t id[128];
+        if (rank == 0) { comm_unique_id(id); leave_id(o.comm_file, id); } else fetch_id(o.comm_file, id);
+        comm = comm_create(eng, rank, world, id);
+    }
     if (strict) { p.num_distinct = 0; p.max_total_freq = 0; }
     else {
         // every rank builds the tables of the parse and produces, scans and drops its own share of the stream (ranges of
@@ -249,7 +464,14 @@ static int run_rank(BuildOptions& o) {
         // of leading characters); only the rows travel
         eng.set_scan_shard((uint32_t)rank, (uint32_t)world);
     }
-    eng.run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), p, 0);
+    const std::string piece = o.output_prefix + ".rank" + std::to_string(rank) + (mum_mode ? ".mums" : ".mems");
+    if (pieces) eng.set_text_sink(piece, true);
+    if (streamed) {
+        in.start(0);
+        try { eng.run_supplied(&StreamedInput::supply, &in, in.len.data(), in.len.size(), p); }
+        catch (...) { if (in.error) std::rethrow_exception(in.error); throw; }
+        in.halt();
+    } else eng.run_partitioned_docs(hd.ptr.data(), hd.len.data(), hd.len.size(), p, 0);
     size_t rows = 0;
     if (strict) {
         bool root = false;
@@ -268,12 +490,15 @@ static int run_rank(BuildOptions& o) {
                 std::remove(piece.c_str());
             }
         }
+    } else if (pieces) {
+        eng.set_text_sink(std::string());
+        eng.write_text_file(piece);                  // (nothing left to do when the run streamed it)
     } else {
         (void)eng.rows(Engine::ROWS_TEXT);
         const std::string text = dist_gather_text(*comm);
         if (rank == 0) write_file(o.output_prefix + (mum_mode ? ".mums" : ".mems"), text.data(), text.size());
     }
-    comm_destroy(comm);
+    if (comm) comm_destroy(comm);
     if (rank == 0) log_line("build_main", strict ? "Found " + std::to_string(rows) + " matches on " + std::to_string(world) + " GPUs!"
                                                   : "matches of " + std::to_string(world) + " GPUs written");
     std::fflush(stdout); std::fflush(stderr);
@@ -299,6 +524,7 @@ int main(int argc, char** argv) {
         o.set_parameters(checkpoint ? doc_len.size() : inputs.size(), mum_mode);
         for (const auto& n : o.notes) log_line("build_main", n);
 
+        if (!checkpoint && !std::getenv("MUMEMTO_DRY_RUN") && want_streamed_input(inputs)) return run_streamed(o, inputs, mum_mode);
         auto t0 = std::chrono::steady_clock::now();
         // the HIP runtime comes up (device, stream, code objects) while the host threads read the inputs
         const bool dry_run = std::getenv("MUMEMTO_DRY_RUN") != nullptr;

@@ -742,7 +742,8 @@ void Engine::sink_open(bool mum_mode) {
     // its text keeps nothing of a window once its bytes are on their way (BASELINE configs[4]: a rank's rows carry ~94
     // occurrences each -- tens of GB of suffix-array entries, offsets and text).  Such a run answers only for the file and
     // the number of rows.  MMT_SINK_DISCARD=0 / 1 overrides (tests).
-    sink_discard_ = std::getenv("MMT_SINK_DISCARD") ? std::atoi(std::getenv("MMT_SINK_DISCARD")) != 0 : (packed_ || n_ >= (1ull << 37));
+    sink_discard_ = sink_force_discard_ ||
+                    (std::getenv("MMT_SINK_DISCARD") ? std::atoi(std::getenv("MMT_SINK_DISCARD")) != 0 : (packed_ || n_ >= (1ull << 37)));
     if (!mum_mode && !sink_discard_) return;          // (a MEM run that keeps its rows writes its file at the end, as before)
     // the bytes go to PREFIX.mums.tmp and take the final name when the run has succeeded (sink_close): a run that fails
     // after some windows -- out of memory, a consistency check at the end -- must not leave a plausible partial PREFIX.mums

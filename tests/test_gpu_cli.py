@@ -273,3 +273,36 @@ def test_real_reference_anchor_merge_eats_gpu_partitions_at_megabase_size(tmp_pa
     merged_th = np.fromfile(tmp_path / "merged.athresh", np.uint16)
     differ = np.nonzero(merged_th != direct_th)[0]
     assert len(differ) <= 5 and np.all(direct_th[differ] == 0)
+
+
+def test_streamed_input_documents_read_when_the_device_asks(inputs):
+    """MUMEMTO_STREAM_INPUT=1: what mumemto_exec does with a collection that does not fit the host as bytes (94 whole genomes:
+    287 GB; the reference streams its files through the parser, src/ref_builder.cpp:211-314) -- every file measured once, then
+    read again one document at a time when the engine asks (Engine::run_supplied), rows written window by window.  Same
+    files as the resident route, byte for byte: .mums / .mems / .bumbl / .lengths / .athresh / .thresh."""
+    tmp, docs, paths = inputs
+    N = len(docs)
+    env = dict(os.environ, MUMEMTO_STREAM_INPUT="1")
+    for name, args, exts in [
+        ("s_def", [], ["mums", "lengths"]),
+        ("s_mem", ["-k", "-1", "-f", "3"], ["mems", "lengths"]),
+        ("s_n", ["-n"], ["mums", "athresh"]),
+        ("s_M", ["-M"], ["mums", "thresh", "thresh_rev"]),
+        ("s_b", ["-b"], ["bumbl"]),
+        ("s_packed", ["-k", "-2"], ["mums"]),
+    ]:
+        e = dict(env, MMT_PACKED_TEXT="1", MUMEMTO_PRODUCER="guided") if name == "s_packed" else env
+        r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "-o", str(tmp / name)] + args + paths, cwd=tmp,
+                           capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        assert "measured %d files" % N in r.stderr
+        cli(["-o", str(tmp / (name + "_resident"))] + args + paths, tmp)
+        for ext in exts:
+            a, b = (tmp / (name + "." + ext)).read_bytes(), (tmp / (name + "_resident." + ext)).read_bytes()
+            if ext == "lengths":       # (the lines name the prefix-independent paths: identical)
+                assert a == b
+            assert a == b and len(a) > 0, (name, ext)
+    # options that need the collection on the host say so
+    r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "-o", str(tmp / "s_K"), "-K"] + paths, cwd=tmp, capture_output=True,
+                       text=True, env=env)
+    assert r.returncode != 0 and "streamed" in r.stderr

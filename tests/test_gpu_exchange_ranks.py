@@ -191,3 +191,29 @@ def test_mumemto_exec_gpus_n_on_one_gpu(gpus, mode, tmp_path):
     else:
         want = O.run(docs, num_distinct=8, max_doc_freq=3, max_total_freq=27)
         assert open(out + ".mems", "rb").read() == want.text()
+
+
+@pytest.mark.parametrize("streamed", [0, 1])
+def test_ranks_of_a_sharded_run_write_pieces_and_nothing_is_gathered(streamed, tmp_path):
+    """MUMEMTO_RANK_PIECES=1 (automatic when the collection has to be streamed): every rank of a `-k / -f` run writes the rows of
+    its share of the stream window by window to PREFIX.rankR.mems and the launcher joins the pieces in rank order -- no
+    communicator, no RCCL library, nothing in HBM or on the links (a rank of BASELINE configs[4] writes 66 GB).  With
+    MUMEMTO_STREAM_INPUT=1 the ranks also read their documents one at a time as their engines ask."""
+    exe = os.path.join(ROOT, "mumemto_amd", "bin", "mumemto_exec")
+    docs = synth.pangenome(9, 30000, 0.01, seed=79, inversion=(3, 2000, 5000))
+    paths = []
+    for i, d in enumerate(docs):
+        p = str(tmp_path / ("h%02d.fa" % i))
+        synth.write_fasta(p, d)
+        paths.append(p)
+    env = dict(os.environ, MUMEMTO_RCCL_LIB="/nonexistent/librccl.so", MUMEMTO_SHARE_DEVICE="1", MUMEMTO_RANK_PIECES="1",
+               MUMEMTO_STREAM_INPUT=str(streamed), MMT_SCAN_RANGE="16384")
+    for name, args, kw, ext in (("mem", ["-k", "-1", "-f", "3"], dict(num_distinct=8, max_doc_freq=3, max_total_freq=27), "mems"),
+                                ("par", ["-k", "-2"], dict(num_distinct=7, max_total_freq=9), "mums")):
+        out = str(tmp_path / name)
+        r = subprocess.run([exe, "-o", out, "--gpus", "3"] + args + paths, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        want = O.run(docs, **kw).text()
+        assert open(out + "." + ext, "rb").read() == want and want.count(b"\n") > 10
+        assert not [f for f in os.listdir(tmp_path) if ".rank" in f], "pieces left behind"
+        assert len(open(out + ".lengths").read().splitlines()) == 2 * 9

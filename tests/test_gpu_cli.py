@@ -299,8 +299,6 @@ def test_streamed_input_documents_read_when_the_device_asks(inputs):
         cli(["-o", str(tmp / (name + "_resident"))] + args + paths, tmp)
         for ext in exts:
             a, b = (tmp / (name + "." + ext)).read_bytes(), (tmp / (name + "_resident." + ext)).read_bytes()
-            if ext == "lengths":       # (the lines name the prefix-independent paths: identical)
-                assert a == b
             assert a == b and len(a) > 0, (name, ext)
     # options that need the collection on the host say so
     r = subprocess.run([os.path.join(BIN, "mumemto_exec"), "-o", str(tmp / "s_K"), "-K"] + paths, cwd=tmp, capture_output=True,

@@ -519,8 +519,31 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
                                      "device (" + std::to_string(fit) + ")");
         cap64 = largest;
     }
+    // ---- several batches per pass over the text (gk::stage_fill): when the share takes more than two batches, part of the
+    // memory becomes a list of the suffixes of the next batches (8 bytes each), filled by ONE pass over the text -- a pass per
+    // batch was 126 of the 186 s the device was busy on a rank's share of 573 G characters.  MMT_GUIDED_STAGE=0 | 1 forces.
+    const uint64_t share = pre[bin_hi] - pre[bin_lo];
+    bool staged = share > 2 * cap64;
+    if (const char* c = std::getenv("MMT_GUIDED_STAGE")) staged = std::atoi(c) != 0;
+    uint64_t stage_cap = 0;
+    if (staged) {
+        if (std::getenv("MMT_GUIDED_BATCH")) stage_cap = std::min<uint64_t>(share, std::max<uint64_t>(4 * cap64, largest));   // (tests: a few batches per pass)
+        else {
+            double stage_bytes = 0.4 * avail;
+            uint64_t fit2 = (uint64_t)(std::max(avail - stage_bytes, 0.0) / per_element);
+            if (fit2 < largest) { fit2 = largest; stage_bytes = avail - (double)largest * per_element; }
+            stage_cap = stage_bytes > 0 ? (uint64_t)(stage_bytes / 8.0) : 0;
+            stage_cap = std::min<uint64_t>(std::min<uint64_t>(stage_cap, share), 0xfff00000ull);      // (32-bit offsets per tile)
+            if (stage_cap < 2 * std::max<uint64_t>(largest, 1) || fit2 < (1u << 20)) staged = false;
+            else cap64 = std::min<uint64_t>(cap64, std::max<uint64_t>(fit2, largest));
+        }
+        if (stage_cap < largest) staged = false;
+    }
     Batch X;
     X.reserve((uint32_t)cap64);
+    DevBuf<uint64_t> stage;
+    DevBuf<uint32_t> blk_cnt, blk_off;
+    if (staged) { stage.ensure(stage_cap + 16); blk_cnt.ensure(stage_cap / 4096 + 2); blk_off.ensure(stage_cap / 4096 + 2); }
     window_reserve(0, head_room + cap64 + 16);
     window_reserve(1, head_room + cap64 + 16);
     DevBuf<uint64_t> carry;
@@ -536,19 +559,41 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     uint64_t prev_len = 0;                 // entries of the window before (without a virtual closing entry)
     uint32_t prev_last_bin = 0;            // its last non-empty bin
     bool have_prev = false;
+    uint32_t pass_end = bin_lo;            // staged: the bins [.., pass_end) are in the list
+    uint64_t n_staged = 0;
+    int passes = 0;
     for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
+        if (staged && b0 == pass_end) {    // the next pass over the text: as many bins as the list holds
+            n_staged = 0;
+            while (pass_end < bin_hi && n_staged + bins[pass_end] <= stage_cap) n_staged += bins[pass_end++];
+            if (pass_end == b0) throw std::runtime_error("guided sort: a bin exceeds the staging list");
+            if (n_staged) {
+                gk::batch_count(ctx, prefix_chars, b0, pass_end, tile_cnt.get(), st);
+                prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+                gk::stage_fill(ctx, prefix_chars, b0, pass_end, tile_off.get(), stage.get(), st);
+            }
+            passes++;
+        }
         uint64_t total = 0;
         uint32_t b1 = b0;
-        while (b1 < bin_hi && total + bins[b1] <= X.cap) total += bins[b1++];
+        const uint32_t b_stop = staged ? pass_end : bin_hi;
+        while (b1 < b_stop && total + bins[b1] <= X.cap) total += bins[b1++];
         if (b1 == b0) throw std::runtime_error("guided sort: a bin exceeds the batch");
         if (total) {
             const uint32_t B = (uint32_t)total;
             const int set = batches & 1;
             EventPair& ee = next_range_event(SS, 3);
             ee.start(st);
-            gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
-            prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
-            gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
+            if (staged) {
+                const uint32_t nb = (uint32_t)((n_staged + 4095) / 4096);
+                gk::stage_count(stage.get(), n_staged, b0, b1, blk_cnt.get(), st);
+                prims::exclusive_sum_u32(d_temp_, blk_cnt.get(), blk_off.get(), nb, st);
+                gk::stage_take(ctx, stage.get(), n_staged, b0, b1, blk_off.get(), X.key_a.get(), X.pos_a.get(), st);
+            } else {
+                gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
+                prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+                gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
+            }
             // (the LCP values the sort finds on its way go straight into the window, behind the tail of the batch before)
             uint64_t ext = 0;
             if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[prev_last_bin], prev_len), capped ? SS.ext0 : ~0ull);
@@ -612,6 +657,8 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     MMT_HIP(hipStreamSynchronize(st));
     const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
+    if (stats && staged) std::fprintf(stderr, "[guided] %d passes over the text for those batches (a list of %llu suffixes)\n", passes,
+                                      (unsigned long long)stage_cap);
     if (stats) std::fprintf(stderr, "[guided] %llu suffixes in %d batches of at most %u: %.1f ms with their scans; %.3f of them settled in "
                             "small groups by comparison, %.3f element-rounds per suffix in %d rounds at most\n",
                             (unsigned long long)(piece_end - pre[bin_lo]), batches, X.cap, ms,

@@ -452,6 +452,116 @@ void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi
     MMT_HIP(hipGetLastError());
 }
 
+// ---- several batches per pass over the text ------------------------------------------------------------------------------------
+// A batch is the suffixes of a few bins, and finding them is a pass over the WHOLE text: 127 batches of a rank's share of
+// 573 G characters were 127 x 2 passes, 126 of the 186 s the device was busy (k_batch_count + k_batch_fill + the histogram).
+// One pass now serves as many batches as a staging list holds: the suffixes of bins [bin_lo, bin_hi) -- several batches --
+// are written in text order as (V index | bin << 40), eight bytes each, and every batch then takes its own from that list (a
+// pass over a few G entries instead of hundreds of G characters) and only there looks up keys and records.
+__global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ staged) {
+    __shared__ __align__(16) uint8_t s_sym[TILE + 64];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint16_t s_sel[TILE];
+    constexpr int PER = TILE / 256;
+    uint32_t sel = 0;
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q; });
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cnt = __popc(sel);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    const uint64_t first = tile_off[(uint64_t)blockIdx.x + c.tile0];
+    uint32_t at = inc - cnt, total = 0;
+    for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        if (!(sel & (1u << q))) continue;
+        s_sel[at++] = (uint16_t)(threadIdx.x * PER + q);
+    }
+    __syncthreads();
+    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+        const uint32_t o = s_sel[i];
+        uint32_t bin = 0;
+        for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | s_sym[o + ch];
+        staged[first + i] = (base + o + 1) | ((uint64_t)bin << 40);
+    }
+}
+void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,
+                hipStream_t s) {
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_stage_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, staged);
+    });
+    MMT_HIP(hipGetLastError());
+}
+// blocks of 4096 staged entries, 16 consecutive ones per work-item
+__global__ __launch_bounds__(256) void k_stage_count(const uint64_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
+                                                     uint32_t* __restrict__ block_count) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const uint64_t from = (uint64_t)blockIdx.x * 4096 + threadIdx.x * 16;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (from + q < n) { const uint32_t b = (uint32_t)(staged[from + q] >> 40); mine += (b >= b0 && b < b1) ? 1u : 0u; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
+}
+__global__ __launch_bounds__(256) void k_stage_take(Ctx c, const uint64_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
+                                                    const uint32_t* __restrict__ block_off, uint64_t* __restrict__ keys,
+                                                    uint64_t* __restrict__ pos) {
+    __shared__ uint8_t s_code[256];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint64_t s_sel[4096];
+    for (int i = threadIdx.x; i < 256; i += 256) s_code[i] = c.code[i];
+    const uint64_t from = (uint64_t)blockIdx.x * 4096 + threadIdx.x * 16;
+    uint64_t mine[16];
+    uint32_t sel = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        mine[q] = from + q < n ? staged[from + q] : ~0ull;
+        const uint32_t b = (uint32_t)(mine[q] >> 40);
+        if (from + q < n && b >= b0 && b < b1) sel |= 1u << q;
+    }
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t cnt = __popc(sel);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t at = inc - cnt, total = 0;
+    for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (sel & (1u << q)) s_sel[at++] = mine[q] & ((1ull << 40) - 1ull);
+    __syncthreads();
+    const uint64_t first = block_off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < total; i += 256) {
+        const uint64_t q = s_sel[i];
+        keys[first + i] = pack_chars(c, s_code, q);
+        pos[first + i] = make_rec(c, q);
+    }
+}
+void stage_count(const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_stage_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, staged, n, b0, b1, block_count);
+    MMT_HIP(hipGetLastError());
+}
+void stage_take(const Ctx& c, const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
+                uint64_t* pos, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_stage_take, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, c, staged, n, b0, b1, block_off, keys, pos);
+    MMT_HIP(hipGetLastError());
+}
+
 template <typename P>
 __global__ void k_phrase_items(Ctx c, const P* __restrict__ pstart, const uint32_t* __restrict__ rep, uint32_t D,
                                uint64_t* __restrict__ keys, uint64_t* __restrict__ pos) {

@@ -178,6 +178,8 @@ __attribute__((visibility("default"))) ncclResult_t ncclBroadcast(const void* se
 __attribute__((visibility("default"))) ncclResult_t ncclAllGather(const void* sendbuf, void* recvbuf, size_t sendcount, ncclDataType_t t,
                                                                   ncclComm_t comm, hipStream_t s) {
     FakeComm* c = reinterpret_cast<FakeComm*>(comm);
+    // FAKE_RCCL_FAIL: every rank's first collective of an exchange fails (how bench.py's trial step is tested)
+    if (std::getenv("FAKE_RCCL_FAIL")) return ncclSystemError;
     const size_t bytes = sendcount * elem_size(t);
     if (!elem_size(t)) return ncclInvalidArgument;
     std::vector<Op> ops;

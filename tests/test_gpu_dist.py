@@ -113,7 +113,10 @@ def test_device_resident_exchange_and_fold():
     (2, "ranges", 2_000_000, "torch"),
     # bench.py's default: the native exchange of dist.cpp (here over the transport double of tests/fake_rccl, MUMEMTO_RCCL_LIB:
     # this box has one GPU); "ranges" = MUMEMTO_RANGE_FOLD=1, the route four ranks or more take by themselves
-    (2, "rank0", 0, "native"), (3, "ranges", 0, "native"), (4, "auto", 0, "native"), (2, "ranges", 2_000_000, "native")])
+    (2, "rank0", 0, "native"), (3, "ranges", 0, "native"), (4, "auto", 0, "native"), (2, "ranges", 2_000_000, "native"),
+    # a native exchange that fails in bench.py's trial step (FAKE_RCCL_FAIL): every rank says so and the run goes on over
+    # torch.distributed, with the reason in the result line
+    (3, "rank0", 0, "native-broken")])
 def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text, exchange):
     """bench.py's N > 1 path end to end -- torchrun, one process per rank, per-rank partition run, all-gather of the
     HBM row tables, device fold on rank 0, re-sort -- with the ranks sharing GPU 0 under gloo (this box has one GPU;
@@ -132,11 +135,13 @@ def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text, exchange):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world),
            "--steps", "2", "--warmup", "1", "--haps", "31", "--length", "150000", "--divergence", "0.005", "--backend", "gloo",
-           "--share-device", "--check", "--exchange", exchange, "--fold", fold if exchange == "torch" else "rank0"]
+           "--share-device", "--check", "--exchange", exchange.split("-")[0], "--fold", fold if exchange == "torch" else "rank0"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     if max_text:
         env["MMT_MAX_TEXT"] = str(max_text)
-    if exchange == "native":
+    if exchange.startswith("native"):
+        if exchange == "native-broken":
+            env["FAKE_RCCL_FAIL"] = "1"
         lib = os.path.join(root, "tests", "fake_rccl", "libfake_rccl.so")
         if not os.path.exists(lib):
             subprocess.check_call(["make", "-C", os.path.dirname(lib)])
@@ -149,6 +154,11 @@ def test_bench_multi_rank_path_on_one_gpu(world, fold, max_text, exchange):
     d = json.loads(line)
     assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["haplotypes"] == 31
     assert d["config"]["output_equals_cpu_oracle"] is True and d["config"]["output_bytes"] > 0
+    if exchange == "native-broken":
+        assert d["config"]["exchange"].startswith("torch.distributed (the native exchange failed") and "native exchange failed" in r.stderr
+        assert "all-gather" in d["config"]["parallelism"]
+    else:
+        assert d["config"]["exchange"] == exchange
 
 
 def test_bench_single_gpu_line_at_a_small_size():

@@ -345,6 +345,7 @@ static int run_streamed(BuildOptions& o, const std::vector<std::string>& inputs,
     std::unique_ptr<Engine> engine;
     std::exception_ptr engine_error;
     std::thread engine_init([&]() {
+        if (std::getenv("MUMEMTO_DRY_RUN")) return;
         try { engine.reset(new Engine(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr)); }
         catch (...) { engine_error = std::current_exception(); }
     });
@@ -357,6 +358,24 @@ static int run_streamed(BuildOptions& o, const std::vector<std::string>& inputs,
     write_lengths_file(o.output_prefix, in.docs);
     uint64_t n_bases = 0, text_chars = 0;
     for (uint64_t l : in.len) { n_bases += l; text_chars += (o.use_rcomp ? 2 : 1) * (l + 1); }
+    if (std::getenv("MUMEMTO_DRY_RUN")) {          // host-side checks only: every document through the supplier, in order
+        engine_init.join();
+        uint64_t h = 1469598103934665603ull;
+        std::vector<uint8_t> dst;
+        for (size_t d = 0; d < in.len.size(); d++) {
+            dst.resize(in.len[d]);
+            if (StreamedInput::supply(&in, d, dst.data(), in.len[d]) != 0) {
+                if (in.error) std::rethrow_exception(in.error);
+                throw CliError{"the streamed reader failed at " + inputs[d], 1};
+            }
+            for (uint8_t b : dst) { h ^= b; h *= 1099511628211ull; }
+        }
+        std::printf("docs=%zu bases=%zu fnv1a=%016llx num_distinct=%d max_doc_freq=%d max_total_freq=%d revcomp=%d "
+                    "merge=%d anchor=%d binary=%d min_len=%zu\n", in.len.size(), (size_t)n_bases, (unsigned long long)h,
+                    o.num_distinct_docs, o.rare_freq, o.max_mem_freq, (int)o.use_rcomp, (int)o.merge,
+                    (int)o.anchor_merge, (int)o.binary, o.min_match_len);
+        return 0;
+    }
     std::fprintf(stderr, "\033[32m[build_main] \033[0mmeasured %zu files, %llu bases (the documents are read again, one at a time, "
                  "when the device asks) ... done.  (%.3f sec)\n", in.docs.size(), (unsigned long long)n_bases, secs_since(t0));
     in.start(0);                                          // the first documents are read while the engine comes up
@@ -524,7 +543,7 @@ int main(int argc, char** argv) {
         o.set_parameters(checkpoint ? doc_len.size() : inputs.size(), mum_mode);
         for (const auto& n : o.notes) log_line("build_main", n);
 
-        if (!checkpoint && !std::getenv("MUMEMTO_DRY_RUN") && want_streamed_input(inputs)) return run_streamed(o, inputs, mum_mode);
+        if (!checkpoint && want_streamed_input(inputs)) return run_streamed(o, inputs, mum_mode);
         auto t0 = std::chrono::steady_clock::now();
         // the HIP runtime comes up (device, stream, code objects) while the host threads read the inputs
         const bool dry_run = std::getenv("MUMEMTO_DRY_RUN") != nullptr;

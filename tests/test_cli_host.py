@@ -91,6 +91,11 @@ def test_fasta_parsing_and_lengths_file(tmp_path):
     ra, rb, rc = (os.path.realpath(str(p)) for p in (a, b, c))
     assert lengths == [ra + " * 17", ra + " chr1 12", ra + " chr2 5", rb + " * 11", rb + " only 11",
                        rc + " * 10", rc + " read1 6", rc + " read2 4"]
+    # the same files through the streamed route (measured once, read again document by document)
+    r2 = subprocess.run([EXE, "-o", str(tmp_path / "out2"), str(a), str(b), str(c)], cwd=tmp_path, capture_output=True, text=True,
+                        env=dict(os.environ, MUMEMTO_DRY_RUN="1", MUMEMTO_STREAM_INPUT="1"))
+    assert r2.returncode == 0, r2.stderr
+    assert fields(r2.stdout) == got and (tmp_path / "out2.lengths").read_text().splitlines() == lengths
 
 
 def test_filelist_input(tmp_path):
@@ -195,10 +200,13 @@ def test_in_place_reader_of_plain_files_equals_the_stream_reader(tmp_path):
         p.write_bytes((b"junk before the first header\n" if i == 2 else b"") + b"".join(recs))
         files.append(str(p))
     outs = []
-    for env in ({}, {"MUMEMTO_STREAM_READER": "1"}):
+    # ... and MUMEMTO_STREAM_INPUT=1: the files measured once, then every document read again when it is asked for, in order
+    # (cli_main.cpp::StreamedInput: what mumemto_exec does with a collection that does not fit the host)
+    for env in ({}, {"MUMEMTO_STREAM_READER": "1"}, {"MUMEMTO_STREAM_INPUT": "1"}):
         r = subprocess.run([EXE, "-o", str(tmp_path / ("o%d" % len(outs)))] + files, cwd=tmp_path, capture_output=True, text=True,
                            env=dict(os.environ, MUMEMTO_DRY_RUN="1", **env))
         assert r.returncode == 0, r.stderr
         outs.append((fields(r.stdout), (tmp_path / ("o%d.lengths" % len(outs))).read_text()))
-    assert outs[0][0]["bases"] == outs[1][0]["bases"] and outs[0][0]["fnv1a"] == outs[1][0]["fnv1a"]
-    assert outs[0][1] == outs[1][1] and int(outs[0][0]["bases"]) > 0
+    for k in (1, 2):
+        assert outs[0][0]["bases"] == outs[k][0]["bases"] and outs[0][0]["fnv1a"] == outs[k][0]["fnv1a"]
+        assert outs[0][1] == outs[k][1] and int(outs[0][0]["bases"]) > 0

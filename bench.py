@@ -172,15 +172,29 @@ def main():
     exe = os.path.join(ROOT, "mumemto_amd", "bin", "mumemto_exec")
     if rank == 0 and world == 1 and not a.no_extras and os.path.exists(exe):
         stats = os.path.join(workdir, "cli_stats.json")
-        t0 = time.perf_counter()
-        r = subprocess.run([exe] + paths + ["-o", os.path.join(workdir, "cli")], capture_output=True,
-                           env=dict(os.environ, MUMEMTO_STATS=stats, MUMEMTO_DEVICE=str(local_rank)))
-        wall = time.perf_counter() - t0
-        cli = {"wall_s": wall, "value": a.length * a.haps / wall / 1e9, "unit": "Gbp/s", "rc": r.returncode}
-        if r.returncode == 0 and os.path.exists(stats):
-            st = json.load(open(stats))
-            cli.update({"heap_map_seconds": st["heap_map_seconds"], "heap_peak_bytes": st["heap_peak_bytes"],
-                        "stage_ms": st["stage_ms"]})
+        attempts = []
+        for attempt in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe] + paths + ["-o", os.path.join(workdir, "cli")], capture_output=True,
+                               env=dict(os.environ, MUMEMTO_STATS=stats, MUMEMTO_DEVICE=str(local_rank)))
+            wall = time.perf_counter() - t0
+            cli = {"wall_s": wall, "value": a.length * a.haps / wall / 1e9, "unit": "Gbp/s", "rc": r.returncode}
+            if r.returncode == 0 and os.path.exists(stats):
+                st = json.load(open(stats))
+                cli.update({"heap_map_seconds": st["heap_map_seconds"], "heap_peak_bytes": st["heap_peak_bytes"],
+                            "stage_ms": st["stage_ms"]})
+            attempts.append({"wall_s": wall, "heap_map_seconds": cli.get("heap_map_seconds"), "rc": r.returncode})
+            # A process that starts right behind another one that gave hundreds of GB back (the test suite before this bench)
+            # waits in hipMemCreate while the driver scrubs that memory -- seconds that belong to the other process
+            # (tests/micro/map_threads.cpp: mapping itself is 0.2 ms per GiB).  Then, and only then, the measurement is
+            # taken once more after a pause; both attempts are in the line.
+            if r.returncode != 0 or cli.get("heap_map_seconds", 0.0) < 0.5:
+                break
+            time.sleep(10.0)
+        cli["attempts"] = attempts
+        if len(attempts) > 1:
+            cli["note"] = ("the first attempt spent %.1f s in the driver waiting for device memory another process had just "
+                           "freed to be scrubbed; measured again after 10 s" % attempts[0]["heap_map_seconds"])
 
     eng = mumemto_amd.Engine(local_rank)
     eng.set_producer(a.producer, a.pfp_w, a.pfp_p)

@@ -522,14 +522,20 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     // ---- several batches per pass over the text (gk::stage_fill): when the share takes more than two batches, part of the
     // memory becomes a list of the suffixes of the next batches (8 bytes each), filled by ONE pass over the text -- a pass per
     // batch was 126 of the 186 s the device was busy on a rank's share of 573 G characters.  MMT_GUIDED_STAGE=0 | 1 forces.
+    // It pays when the passes it saves are long and many: text characters x batches from 2 x 10^13 on (configs[4]: 573 G x 127;
+    // a share of configs[3], 79 G x 86, ran 38 - 45 s without the list and 42 - 48 s with it: smaller batches, keys looked up at
+    // random instead of rolled along the tile).
     const uint64_t share = pre[bin_hi] - pre[bin_lo];
-    bool staged = share > 2 * cap64;
+    bool staged = share > 2 * cap64 && (double)n * ((double)share / (double)cap64) >= 2e13;
     if (const char* c = std::getenv("MMT_GUIDED_STAGE")) staged = std::atoi(c) != 0;
+    else if (std::getenv("MMT_GUIDED_BATCH")) staged = share > 2 * cap64;            // (tests: every run of several batches)
     uint64_t stage_cap = 0;
     if (staged) {
         if (std::getenv("MMT_GUIDED_BATCH")) stage_cap = std::min<uint64_t>(share, std::max<uint64_t>(4 * cap64, largest));   // (tests: a few batches per pass)
         else {
-            double stage_bytes = 0.4 * avail;
+            // (what a full batch leaves, if that holds two batches' worth; else 40 % of what the batches may use)
+            const double spare = avail - (double)cap64 * per_element;
+            double stage_bytes = spare / 8.0 >= 2.0 * (double)cap64 ? spare : 0.4 * avail;
             uint64_t fit2 = (uint64_t)(std::max(avail - stage_bytes, 0.0) / per_element);
             if (fit2 < largest) { fit2 = largest; stage_bytes = avail - (double)largest * per_element; }
             stage_cap = stage_bytes > 0 ? (uint64_t)(stage_bytes / 8.0) : 0;

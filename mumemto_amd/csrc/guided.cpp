@@ -566,6 +566,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     uint32_t prev_last_bin = 0;            // its last non-empty bin
     bool have_prev = false;
     uint32_t pass_end = bin_lo;            // staged: the bins [.., pass_end) are in the list
+    uint32_t counted_lo = 0, counted_hi = 0;   // ... and tile_cnt holds the per-tile counts of the bins [counted_lo, counted_hi)
     uint64_t n_staged = 0;
     int passes = 0;
     for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
@@ -574,9 +575,16 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
             while (pass_end < bin_hi && n_staged + bins[pass_end] <= stage_cap) n_staged += bins[pass_end++];
             if (pass_end == b0) throw std::runtime_error("guided sort: a bin exceeds the staging list");
             if (n_staged) {
-                gk::batch_count(ctx, prefix_chars, b0, pass_end, tile_cnt.get(), st);
+                // (the pass before counted this pass's suffixes per tile while it filled its own list)
+                if (!(counted_lo == b0 && counted_hi == pass_end)) gk::batch_count(ctx, prefix_chars, b0, pass_end, tile_cnt.get(), st);
                 prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
-                gk::stage_fill(ctx, prefix_chars, b0, pass_end, tile_off.get(), stage.get(), st);
+                uint32_t next_end = pass_end;
+                uint64_t next_total = 0;
+                while (next_end < bin_hi && next_total + bins[next_end] <= stage_cap) next_total += bins[next_end++];
+                const bool more = next_total > 0;
+                gk::stage_fill(ctx, prefix_chars, b0, pass_end, tile_off.get(), stage.get(), pass_end, next_end,
+                               more ? tile_cnt.get() : nullptr, st);
+                counted_lo = more ? pass_end : 0; counted_hi = more ? next_end : 0;
             }
             passes++;
         }

@@ -67,8 +67,9 @@ void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_h
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
                 uint64_t* pos, hipStream_t s);
 // several batches per pass over the text: the suffixes of bins [bin_lo, bin_hi) in text order as (V index | bin << 40) ...
+// (next_count, optional: the per-tile counts of the next pass's bins [next_lo, next_hi), taken along)
 void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,
-                hipStream_t s);
+                uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s);
 // ... and what a batch -- bins [b0, b1) -- takes from that list: counts per block of 4096 entries, then keys and records
 void stage_count(const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s);
 void stage_take(const Ctx& c, const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,

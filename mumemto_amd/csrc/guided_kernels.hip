@@ -323,31 +323,6 @@ static void for_tile_slices(const Ctx& c, F&& launch) {
     }
 }
 
-// (a tile counts in LDS, 4096 counters; with more bins than that -- five leading characters: texts beyond 2^38 characters,
-// where a bin of four holds more suffixes than a batch -- one pass per value of the bin code's bits above the low twelve)
-__global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int shift, uint64_t* __restrict__ hist, uint32_t hi_sel) {
-    __shared__ uint8_t s_sym[TILE + 64];
-    __shared__ uint32_t s_hist[4096];
-    for (int i = threadIdx.x; i < 4096; i += 256) s_hist[i] = 0;
-    __syncthreads();
-    for_tile_keys(c, s_sym, [&](int, uint64_t, bool in, uint64_t key) {
-        const uint32_t bin = (uint32_t)(key >> shift);
-        if (in && (bin >> 12) == hi_sel) atomicAdd(&s_hist[bin & 4095u], 1u);
-    });
-    __syncthreads();
-    for (int i = threadIdx.x; i < 4096; i += 256)
-        if (s_hist[i]) atomicAdd(reinterpret_cast<unsigned long long*>(hist + ((size_t)hi_sel << 12) + i), (unsigned long long)s_hist[i]);
-}
-void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
-    const int shift = c.bits * (c.chars - prefix_chars);
-    const uint32_t n_bins = 1u << (c.bits * prefix_chars);
-    for (uint32_t hi = 0; hi < std::max<uint32_t>(n_bins >> 12, 1u); hi++)
-        for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-            hipLaunchKernelGGL(k_bin_hist, dim3(blocks), dim3(256), 0, s, cs, shift, hist, hi);
-        });
-    MMT_HIP(hipGetLastError());
-}
-
 // Which suffixes of a tile belong to the bins [bin_lo, bin_hi)?  Only the first `pc` symbols decide, so the pass over the
 // text rolls a bin code of pc * bits bits (a batch re-reads the whole text: at 79 G characters and 86 batches the two
 // text-order kernels were half of the run while they rolled full 63-bit keys for every position).
@@ -383,6 +358,51 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
         else bin = ((bin << c.bits) | s_sym[t0 + q + pc - 1]) & bmask;
         f(q, base + t0 + q < c.n, bin & bmask);
     }
+}
+
+// One pass whatever the number of bins: a bin whose leading characters are all of A C G T -- nearly every suffix -- is
+// counted in LDS under its dense code (two bits a character: 4^pc <= 1024 counters), the others ('$', N, IUPAC codes, the
+// Dollars at the end) straight in global memory.  (A tile used to count in 4096 LDS counters, one pass over the text per
+// value of the bin code's bits above the low twelve: five leading characters at three bits each -- texts beyond 2^38
+// characters -- were EIGHT passes rolling full 63-bit keys, 13 s of a rank's share of 573 G characters.)
+__global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int pc, uint64_t* __restrict__ hist) {
+    __shared__ __align__(16) uint8_t s_sym[TILE + 64];
+    __shared__ uint32_t s_hist[1024];
+    __shared__ uint8_t s_acgt[256];                 // symbol code -> 0 .. 3, or 0xff
+    __shared__ uint32_t s_sym_of[4];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_hist[i] = 0;
+    s_acgt[threadIdx.x] = 0xff;
+    __syncthreads();
+    if (threadIdx.x < 4) { const uint8_t sym = c.code[(uint8_t)"ACGT"[threadIdx.x]]; s_acgt[sym] = (uint8_t)threadIdx.x; s_sym_of[threadIdx.x] = sym; }
+    __syncthreads();
+    const uint32_t smask = (1u << c.bits) - 1u;
+    for_tile_bins(c, pc, s_sym, [&](int, bool in, uint32_t bin) {
+        if (!in) return;
+        uint32_t dense = 0;
+        bool plain = true;
+        for (int ch = 0; ch < pc; ch++) {
+            const uint32_t a = s_acgt[(bin >> (c.bits * (pc - 1 - ch))) & smask];
+            plain = plain && a != 0xffu;
+            dense = (dense << 2) | (a & 3u);
+        }
+        if (plain) atomicAdd(&s_hist[dense], 1u);
+        else atomicAdd(reinterpret_cast<unsigned long long*>(hist + bin), 1ull);
+    });
+    __syncthreads();
+    const uint32_t n_dense = 1u << (2 * pc);
+    for (uint32_t d = threadIdx.x; d < n_dense; d += 256) {
+        if (!s_hist[d]) continue;
+        uint32_t bin = 0;
+        for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | s_sym_of[(d >> (2 * (pc - 1 - ch))) & 3u];
+        atomicAdd(reinterpret_cast<unsigned long long*>(hist + bin), (unsigned long long)s_hist[d]);
+    }
+}
+void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
+    if (prefix_chars > 5) throw std::runtime_error("bin_hist: at most five leading characters");
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_bin_hist, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, hist);
+    });
+    MMT_HIP(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,

@@ -14,6 +14,7 @@
 #include <deque>
 #include <functional>
 #include <future>
+#include <map>
 #include <mutex>
 #include <memory>
 #include <iostream>
@@ -255,14 +256,15 @@ struct StreamedInput {
     std::vector<std::string> paths;
     std::vector<FastaDoc> docs;
     std::vector<uint64_t> len;
-    std::thread worker;
+    std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::pair<size_t, std::vector<uint8_t>>> ready;   // documents read ahead, in order
+    std::map<size_t, std::vector<uint8_t>> ready;               // documents read ahead
     size_t expect = 0;                                           // the document the engine will ask for next
+    size_t next_doc = 0;                                         // the next document a reader takes
+    size_t depth = 2;                                            // documents read ahead at most (= readers + 1)
     bool stop = false;
     std::exception_ptr error;
-    static constexpr size_t depth = 2;
 
     // every file once: names, record lengths, total (the bases are dropped); index of the first file without bases, or -1
     long measure() {
@@ -290,40 +292,51 @@ struct StreamedInput {
     void halt() {
         { std::lock_guard<std::mutex> lk(mu); stop = true; }
         cv.notify_all();
-        if (worker.joinable()) worker.join();
+        for (auto& w : workers) if (w.joinable()) w.join();
+        workers.clear();
         stop = false; ready.clear();
     }
+    // readers (a file is parsed at about 1 GB/s by one thread: 94 whole genomes one after the other would take minutes) take
+    // the documents in order and keep at most `depth` of them ahead of the one the engine asks for
     void start(size_t from) {
         halt();
-        expect = from;
-        worker = std::thread([this, from]() {
+        expect = next_doc = from;
+        const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(reader_threads(), 8), paths.size() - std::min(paths.size(), from)));
+        depth = T + 1;
+        for (size_t t = 0; t < T; t++) workers.emplace_back([this]() {
             try {
-                for (size_t d = from; d < paths.size(); d++) {
+                for (;;) {
+                    size_t d;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || next_doc >= paths.size() || next_doc < expect + depth; });
+                        if (stop || next_doc >= paths.size()) return;
+                        d = next_doc++;
+                    }
                     std::vector<uint8_t> bases;
                     bases.reserve(len[d]);
                     (void)read_fasta(paths[d], bases);
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return ready.size() < depth || stop; });
+                    std::lock_guard<std::mutex> lk(mu);
                     if (stop) return;
-                    ready.emplace_back(d, std::move(bases));
+                    ready.emplace(d, std::move(bases));
                     cv.notify_all();
                 }
-            } catch (...) { std::lock_guard<std::mutex> lk(mu); error = std::current_exception(); cv.notify_all(); }
+            } catch (...) { std::lock_guard<std::mutex> lk(mu); if (!error) error = std::current_exception(); cv.notify_all(); }
         });
     }
     // Engine::DocSupplier
     static int supply(void* user, uint64_t d, uint8_t* dst, uint64_t n) {
         StreamedInput& S = *static_cast<StreamedInput*>(user);
         try {
-            if (!S.worker.joinable() || S.expect != d) S.start((size_t)d);     // (the text is built a second time: from the top)
+            if (S.workers.empty() || S.expect != d) S.start((size_t)d);      // (the text is built a second time: from the top)
             std::vector<uint8_t> bases;
             {
                 std::unique_lock<std::mutex> lk(S.mu);
-                S.cv.wait(lk, [&] { return !S.ready.empty() || S.error; });
+                S.cv.wait(lk, [&] { return S.ready.count((size_t)d) || S.error; });
                 if (S.error) return 1;
-                if (S.ready.front().first != d) return 1;
-                bases = std::move(S.ready.front().second);
-                S.ready.pop_front();
+                auto it = S.ready.find((size_t)d);
+                bases = std::move(it->second);
+                S.ready.erase(it);
                 S.expect = (size_t)d + 1;
             }
             S.cv.notify_all();

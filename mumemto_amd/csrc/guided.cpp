@@ -604,9 +604,16 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
                 prims::exclusive_sum_u32(d_temp_, blk_cnt.get(), blk_off.get(), nb, st);
                 gk::stage_take(ctx, stage.get(), n_staged, b0, b1, blk_off.get(), X.key_a.get(), X.pos_a.get(), st);
             } else {
-                gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
+                // (the batch before counted this batch's suffixes per tile while it filled its own)
+                if (!(counted_lo == b0 && counted_hi == b1)) gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
                 prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
-                gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), st);
+                uint32_t nb1 = b1;
+                uint64_t next_total = 0;
+                while (nb1 < bin_hi && next_total + bins[nb1] <= X.cap) next_total += bins[nb1++];
+                const bool more = next_total > 0;
+                gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1,
+                               more ? tile_cnt.get() : nullptr, st);
+                counted_lo = more ? b1 : 0; counted_hi = more ? nb1 : 0;
             }
             // (the LCP values the sort finds on its way go straight into the window, behind the tail of the batch before)
             uint64_t ext = 0;

@@ -425,23 +425,33 @@ void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_h
     MMT_HIP(hipGetLastError());
 }
 
+// (next_count, optional: the same pass counts, per tile, the suffixes of the NEXT batch's bins [next_lo, next_hi): that batch
+// then needs no k_batch_count of its own -- one pass over the text per batch instead of two)
 __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
                                                     const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
-                                                    uint64_t* __restrict__ pos) {
+                                                    uint64_t* __restrict__ pos, uint32_t next_lo, uint32_t next_hi,
+                                                    uint32_t* __restrict__ next_count) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[4], s_next[4];
     __shared__ uint16_t s_sel[TILE];                               // tile offsets of the selected suffixes, in order
     constexpr int PER = TILE / 256;
-    uint32_t sel = 0;
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q; });
+    uint32_t sel = 0, nxt = 0;
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+        if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
+        if (in && b >= next_lo && b < next_hi) nxt++;
+    });
     // ordered compaction: exclusive prefix of the per-work-item counts over the workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = __popc(sel);
     uint32_t inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nxt += __shfl_xor(nxt, o, 64);
     if (lane == 63) s_wave[wave] = inc;
+    if (lane == 0) s_next[wave] = nxt;
     __syncthreads();
+    if (next_count && threadIdx.x == 0) next_count[(uint64_t)blockIdx.x + c.tile0] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
     const uint64_t first = tile_off[(uint64_t)blockIdx.x + c.tile0];
     uint32_t at = inc - cnt;
     uint32_t total = 0;
@@ -465,9 +475,10 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     }
 }
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
-                uint64_t* pos, hipStream_t s) {
+                uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, keys, pos);
+        hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, keys, pos, next_lo,
+                           next_hi, next_count);
     });
     MMT_HIP(hipGetLastError());
 }

@@ -64,8 +64,9 @@ void block_cut_offsets(const uint64_t* mask, uint64_t n_words, const uint32_t* b
 void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s);
 void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s);
 // the suffixes whose bin lies in [bin_lo, bin_hi), in text order: first key and element record
+// (next_count, optional: per-tile counts of the next batch's bins [next_lo, next_hi), taken along)
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
-                uint64_t* pos, hipStream_t s);
+                uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s);
 // several batches per pass over the text: the suffixes of bins [bin_lo, bin_hi) in text order as (V index | bin << 40) ...
 // (next_count, optional: the per-tile counts of the next pass's bins [next_lo, next_hi), taken along)
 void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,

@@ -241,3 +241,26 @@ def test_long_phrases_and_shared_variants_in_the_groups_of_copies(packed, copies
         os.environ.pop("MMT_GUIDED_NO_RANK", None)
         eng.set_producer("auto")
         eng.close()
+
+
+@pytest.mark.parametrize("stage,packed", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_passes_over_the_text_for_the_batches(stage, packed):
+    """The bucket-wise producer finds the suffixes of a batch by a pass over the whole text.  MMT_GUIDED_STAGE=1 (automatic from
+    text characters x batches = 2 x 10^13 on: a rank of BASELINE configs[4]): one pass writes the suffixes of the next batches
+    to a staging list, every batch takes its own from it, and the pass also counts the next pass's suffixes per tile;
+    MMT_GUIDED_STAGE=0: one pass per batch, whose fill counts the next batch's tiles.  Bytes of the oracle's either way."""
+    import mumemto_amd
+    docs = synth.pangenome(9, 40000, 0.01, seed=41, indel_rate=0.0005, inversion=(4, 3000, 9000))
+    eng = mumemto_amd.Engine(0)
+    try:
+        eng.set_producer("guided")
+        with packed_env(MMT_GUIDED_BATCH=30000, MMT_GUIDED_STAGE=stage, MMT_PACKED_TEXT=packed, MMT_SCAN_RANGE=16384):
+            for kw in (dict(), dict(num_distinct=8, max_doc_freq=3, max_total_freq=27)):
+                eng.set_docs(docs)
+                eng.run(**kw)
+                assert eng.producer_used() == "guided"
+                assert eng.output_text() == O.run(docs, **kw).text()
+                assert eng.stream_stats()["windows"] >= 8
+    finally:
+        eng.set_producer("auto")
+        eng.close()

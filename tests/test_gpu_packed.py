@@ -196,6 +196,12 @@ def test_documents_supplied_one_at_a_time(packed):
             # the engine is usable afterwards
             eng.run_supplied(lens, supplier)
             assert eng.output_text() == O.run(docs).text()
+            # two documents (the direct producer: the raw bases are uploaded as a whole, through the same supplier)
+            for k in (2,):
+                asked.clear()
+                eng.run_supplied(lens[:k], supplier, num_distinct=k, min_match_len=12)
+                assert asked == list(range(k))
+                assert eng.output_text() == O.run(docs[:k], num_distinct=k, min_len=12).text()
     finally:
         eng.close()
 

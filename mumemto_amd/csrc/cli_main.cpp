@@ -152,6 +152,9 @@ static void put40(std::vector<uint8_t>& b, uint64_t v) {
 static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
     const std::string comm_file = o.output_prefix + ".comm." + std::to_string((long)getpid());
     std::remove(comm_file.c_str());
+    // (pieces an earlier run that failed may have left behind must not be taken for this run's)
+    for (int r = 0; r < o.gpus; r++)
+        for (const char* ext : {".mums", ".mems", ".mums.tmp", ".mems.tmp"}) std::remove((o.output_prefix + ".rank" + std::to_string(r) + ext).c_str());
     std::vector<pid_t> kids;
     for (int r = 0; r < o.gpus; r++) {
         const pid_t pid = fork();

@@ -106,7 +106,7 @@ print(json.dumps(dict(mode="-k -1 -f 3", rank=A.rank, ranks=A.ranks, text_chars=
                       share_of_the_stream=dict(first_entry=pieces[A.rank][0], entries=pieces[A.rank][1],
                                                fraction=round(pieces[A.rank][1] / eng.text_length(), 4), produced=st["entries"],
                                                windows=st["windows"], window_bytes=st["window_bytes"]),
-                      memory_gb={k: round(v / 2**30, 1) for k, v in mem.items() if k != "map_seconds"},
+                      memory_gb={k: round(v / 2**30, 1) for k, v in mem.items() if k != "map_seconds"}, heap_map_seconds=round(mem.get("map_seconds", 0.0), 2),
                       rows=int(len(L)), occurrences=int(len(off)) if kept else None,
                       output_bytes=os.path.getsize(A.out + ".mems") if A.out else None, rows_kept_on_the_device=bool(kept))), flush=True)
 assert parts == 1 and eng.producer_used() == "guided" and (eng.is_wide() or n_text < 2**32)

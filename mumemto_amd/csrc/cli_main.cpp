@@ -266,6 +266,7 @@ struct StreamedInput {
     size_t expect = 0;                                           // the document the engine will ask for next
     size_t next_doc = 0;                                         // the next document a reader takes
     size_t depth = 2;                                            // documents read ahead at most (= readers + 1)
+    size_t copies = 1;                                           // processes on this host that read ahead like this one
     bool stop = false;
     std::exception_ptr error;
 
@@ -304,8 +305,15 @@ struct StreamedInput {
     void start(size_t from) {
         halt();
         expect = next_doc = from;
-        const size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(reader_threads(), 8), paths.size() - std::min(paths.size(), from)));
-        depth = T + 1;
+        size_t T = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(reader_threads(), 8), paths.size() - std::min(paths.size(), from)));
+        // (what is read ahead stays within a quarter of this process's part of the host's memory: eight ranks x nine whole
+        // genomes would be 216 GB)
+        uint64_t longest = 1;
+        for (uint64_t l : len) longest = std::max(longest, l);
+        const uint64_t room = host_memory_available() / 4 / std::max<size_t>(copies, 1);
+        const size_t max_docs = (size_t)std::max<uint64_t>(2, room / longest);
+        depth = std::min(T + 1, max_docs);
+        T = std::min(T, depth - 1);
         for (size_t t = 0; t < T; t++) workers.emplace_back([this]() {
             try {
                 for (;;) {
@@ -463,16 +471,27 @@ static int run_rank(BuildOptions& o) {
     // (eight copies of 94 whole genomes), every rank reads its documents one at a time as its engine asks (StreamedInput); and
     // each writes its rows window by window to its own piece of the output, PREFIX.rankR.mems, which the launcher joins --
     // nothing is gathered over the links (a rank of BASELINE configs[4] writes 66 GB).  MUMEMTO_RANK_PIECES=1 | 0 forces either.
-    const bool streamed = !strict && want_streamed_input(mine, (size_t)world);
+    // (a strict share -- the anchor + this rank's block -- is streamed the same way when all ranks' shares together are too
+    // much for the host, as long as it runs as ONE text: anchor partitions inside a rank read their documents again and
+    // again and keep them resident)
+    bool streamed = want_streamed_input(mine, (size_t)world);
     const bool pieces = !strict && (std::getenv("MUMEMTO_RANK_PIECES") ? std::atoi(std::getenv("MUMEMTO_RANK_PIECES")) != 0 : streamed);
     Engine eng(std::getenv("MUMEMTO_DEVICE") ? std::atoi(std::getenv("MUMEMTO_DEVICE")) : 0, nullptr);
     HostArena arena;
     HostDocs hd;
     std::vector<FastaDoc> docs;
     StreamedInput in;
+    in.copies = (size_t)world;
     long empty = -1;
-    if (streamed) { in.paths = mine; empty = in.measure(); docs = in.docs; hd.len = in.len; }
-    else empty = read_fasta_collection(mine, docs, arena, hd);
+    if (streamed) {
+        in.paths = mine; empty = in.measure(); docs = in.docs; hd.len = in.len;
+        uint64_t chars = 0;
+        for (uint64_t l : in.len) chars += (o.use_rcomp ? 2 : 1) * (l + 1);
+        if (strict && empty < 0 && (chars > eng.auto_max_text() || std::getenv("MUMEMTO_MAX_TEXT") || std::getenv("MMT_MAX_TEXT"))) {
+            streamed = false; docs.clear(); hd.len.clear();
+        }
+    }
+    if (!streamed) empty = read_fasta_collection(mine, docs, arena, hd);
     if (empty >= 0) throw CliError{"Empty input file found: " + mine[(size_t)empty], 1};
     // PREFIX.lengths in pieces: every rank describes the documents only it has read, rank 0 joins them after the exchange
     if (strict) {

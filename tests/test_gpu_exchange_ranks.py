@@ -165,7 +165,7 @@ def test_gather_of_the_sharded_modes_over_several_ranks(world, what):
     assert got == want
 
 
-@pytest.mark.parametrize("gpus,mode", [(2, "strict"), (4, "strict"), (3, "partial")])
+@pytest.mark.parametrize("gpus,mode", [(2, "strict"), (4, "strict"), (3, "partial"), (3, "strict-streamed")])
 def test_mumemto_exec_gpus_n_on_one_gpu(gpus, mode, tmp_path):
     """`mumemto_exec --gpus N`: the launcher, one process per rank (sharing GPU 0: MUMEMTO_SHARE_DEVICE), the exchange,
     PREFIX.mums / .lengths / .athresh written by rank 0."""
@@ -177,6 +177,9 @@ def test_mumemto_exec_gpus_n_on_one_gpu(gpus, mode, tmp_path):
         synth.write_fasta(p, d)
         paths.append(p)
     env = dict(os.environ, MUMEMTO_RCCL_LIB=fake_lib(), MUMEMTO_SHARE_DEVICE="1")
+    if mode == "strict-streamed":      # every rank reads its share (anchor + block) one document at a time as its engine asks
+        env["MUMEMTO_STREAM_INPUT"] = "1"
+        mode = "strict"
     out = str(tmp_path / "out")
     args = [exe, "-o", out, "--gpus", str(gpus)] + (["-n"] if mode == "strict" else ["-k", "-1", "-f", "3"]) + paths
     r = subprocess.run(args, capture_output=True, text=True, timeout=600, env=env)

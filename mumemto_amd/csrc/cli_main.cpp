@@ -284,7 +284,7 @@ struct StreamedInput {
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= N) break;
-                try { scratch.clear(); docs[i] = read_fasta(paths[i], scratch); len[i] = docs[i].total; }
+                try { docs[i] = read_fasta_replace(paths[i], scratch); len[i] = docs[i].total; }
                 catch (...) { std::lock_guard<std::mutex> lk(emu); if (!first_error) first_error = std::current_exception(); }
             }
         });
@@ -325,8 +325,7 @@ struct StreamedInput {
                         d = next_doc++;
                     }
                     std::vector<uint8_t> bases;
-                    bases.reserve(len[d]);
-                    (void)read_fasta(paths[d], bases);
+                    (void)read_fasta_replace(paths[d], bases);
                     std::lock_guard<std::mutex> lk(mu);
                     if (stop) return;
                     ready.emplace(d, std::move(bases));

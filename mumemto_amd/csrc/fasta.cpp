@@ -229,6 +229,19 @@ FastaDoc read_fasta(const std::string& path, std::vector<uint8_t>& bases) {
     return read_fasta_with<LineReader>(path, sink);
 }
 
+FastaDoc read_fasta_replace(const std::string& path, std::vector<uint8_t>& bases) {
+    size_t size = 0;
+    const bool gz = file_info(path, size);
+    if (!gz && size && !std::getenv("MUMEMTO_STREAM_READER")) {
+        bases.resize(size + 64);                    // (a plain file holds at most its size in bases)
+        FastaDoc doc;
+        size_t n = 0;
+        if (read_plain_fasta_blocks(path, bases.data(), bases.size(), doc, n)) { bases.resize(n); return doc; }
+    }
+    bases.clear();
+    return read_fasta(path, bases);
+}
+
 HostArena::~HostArena() { if (p_) munmap(p_, cap_); }
 uint8_t* HostArena::ensure(size_t bytes) {
     if (bytes <= cap_) return p_;

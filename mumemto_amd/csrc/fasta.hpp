@@ -24,6 +24,10 @@ struct FastaDoc {
 // Appends the bases of every record of `path` to `bases`; throws on I/O errors.
 FastaDoc read_fasta(const std::string& path, std::vector<uint8_t>& bases);
 
+// The bases of `path` INSTEAD of what `bases` held: plain FASTA files through the block reader (read() in cache-sized blocks,
+// lines copied straight to their place: several times the stream reader's speed), everything else as read_fasta does.
+FastaDoc read_fasta_replace(const std::string& path, std::vector<uint8_t>& bases);
+
 // The concatenated bases of a collection: sized once, never zero-filled.
 struct HostBytes {
     std::unique_ptr<uint8_t[]> p;

@@ -567,6 +567,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     bool have_prev = false;
     uint32_t pass_end = bin_lo;            // staged: the bins [.., pass_end) are in the list
     uint32_t counted_lo = 0, counted_hi = 0;   // ... and tile_cnt holds the per-tile counts of the bins [counted_lo, counted_hi)
+    uint32_t taken_lo = 0, taken_hi = 0;       // ... and blk_cnt the per-block counts of the list's entries of the bins [taken_lo, taken_hi)
     uint64_t n_staged = 0;
     int passes = 0;
     for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
@@ -574,6 +575,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
             n_staged = 0;
             while (pass_end < bin_hi && n_staged + bins[pass_end] <= stage_cap) n_staged += bins[pass_end++];
             if (pass_end == b0) throw std::runtime_error("guided sort: a bin exceeds the staging list");
+            taken_lo = taken_hi = 0;               // (a new list: nothing of it is counted yet)
             if (n_staged) {
                 // (the pass before counted this pass's suffixes per tile while it filled its own list)
                 if (!(counted_lo == b0 && counted_hi == pass_end)) gk::batch_count(ctx, prefix_chars, b0, pass_end, tile_cnt.get(), st);
@@ -600,9 +602,16 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
             ee.start(st);
             if (staged) {
                 const uint32_t nb = (uint32_t)((n_staged + 4095) / 4096);
-                gk::stage_count(stage.get(), n_staged, b0, b1, blk_cnt.get(), st);
+                // (the batch before counted this batch's entries per block while it took its own)
+                if (!(taken_lo == b0 && taken_hi == b1)) gk::stage_count(stage.get(), n_staged, b0, b1, blk_cnt.get(), st);
                 prims::exclusive_sum_u32(d_temp_, blk_cnt.get(), blk_off.get(), nb, st);
-                gk::stage_take(ctx, stage.get(), n_staged, b0, b1, blk_off.get(), X.key_a.get(), X.pos_a.get(), st);
+                uint32_t nb1 = b1;
+                uint64_t next_total = 0;
+                while (nb1 < pass_end && next_total + bins[nb1] <= X.cap) next_total += bins[nb1++];
+                const bool more = next_total > 0;
+                gk::stage_take(ctx, stage.get(), n_staged, b0, b1, blk_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1,
+                               more ? blk_cnt.get() : nullptr, st);
+                taken_lo = more ? b1 : 0; taken_hi = more ? nb1 : 0;
             } else {
                 // (the batch before counted this batch's suffixes per tile while it filled its own)
                 if (!(counted_lo == b0 && counted_hi == b1)) gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);

@@ -561,28 +561,34 @@ __global__ __launch_bounds__(256) void k_stage_count(const uint64_t* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
 }
+// (next_count, optional: the same pass counts, per block, the entries of the NEXT batch's bins [nb0, nb1))
 __global__ __launch_bounds__(256) void k_stage_take(Ctx c, const uint64_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
                                                     const uint32_t* __restrict__ block_off, uint64_t* __restrict__ keys,
-                                                    uint64_t* __restrict__ pos) {
+                                                    uint64_t* __restrict__ pos, uint32_t nb0, uint32_t nb1,
+                                                    uint32_t* __restrict__ next_count) {
     __shared__ uint8_t s_code[256];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[4], s_next[4];
     __shared__ uint64_t s_sel[4096];
     for (int i = threadIdx.x; i < 256; i += 256) s_code[i] = c.code[i];
     const uint64_t from = (uint64_t)blockIdx.x * 4096 + threadIdx.x * 16;
     uint64_t mine[16];
-    uint32_t sel = 0;
+    uint32_t sel = 0, nxt = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         mine[q] = from + q < n ? staged[from + q] : ~0ull;
         const uint32_t b = (uint32_t)(mine[q] >> 40);
         if (from + q < n && b >= b0 && b < b1) sel |= 1u << q;
+        if (from + q < n && b >= nb0 && b < nb1) nxt++;
     }
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = __popc(sel);
     uint32_t inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= (uint32_t)o) inc += y; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) nxt += __shfl_xor(nxt, o, 64);
     if (lane == 63) s_wave[wave] = inc;
+    if (lane == 0) s_next[wave] = nxt;
     __syncthreads();
     uint32_t at = inc - cnt, total = 0;
     for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
@@ -591,6 +597,7 @@ __global__ __launch_bounds__(256) void k_stage_take(Ctx c, const uint64_t* __res
         if (sel & (1u << q)) s_sel[at++] = mine[q] & ((1ull << 40) - 1ull);
     __syncthreads();
     const uint64_t first = block_off[blockIdx.x];
+    if (next_count && threadIdx.x == 0) next_count[blockIdx.x] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint64_t q = s_sel[i];
         keys[first + i] = pack_chars(c, s_code, q);
@@ -603,9 +610,10 @@ void stage_count(const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, u
     MMT_HIP(hipGetLastError());
 }
 void stage_take(const Ctx& c, const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
-                uint64_t* pos, hipStream_t s) {
+                uint64_t* pos, uint32_t nb0, uint32_t nb1, uint32_t* next_count, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_stage_take, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, c, staged, n, b0, b1, block_off, keys, pos);
+    hipLaunchKernelGGL(k_stage_take, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, c, staged, n, b0, b1, block_off, keys, pos, nb0,
+                       nb1, next_count);
     MMT_HIP(hipGetLastError());
 }
 

@@ -73,8 +73,9 @@ void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi
                 uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s);
 // ... and what a batch -- bins [b0, b1) -- takes from that list: counts per block of 4096 entries, then keys and records
 void stage_count(const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s);
+// (next_count, optional: per-block counts of the next batch's bins [nb0, nb1), taken along)
 void stage_take(const Ctx& c, const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
-                uint64_t* pos, hipStream_t s);
+                uint64_t* pos, uint32_t nb0, uint32_t nb1, uint32_t* next_count, hipStream_t s);
 // one element per distinct phrase (c.skip = 1)
 void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* rep, uint32_t D, uint64_t* keys,
                   uint64_t* pos, hipStream_t s);

@@ -67,6 +67,12 @@ def test_flags_and_errors(tmp_path):
     empty.write_text("")
     r = run(["-o", str(tmp_path / "o"), paths[0], str(empty)], tmp_path)
     assert r.returncode == 1 and "Empty input file" in r.stderr
+    # ... the same from the streamed route (the files measured first), and its options that need the collection resident
+    senv = dict(os.environ, MUMEMTO_DRY_RUN="1", MUMEMTO_STREAM_INPUT="1")
+    r = subprocess.run([EXE, "-o", str(tmp_path / "o"), paths[0], str(empty)], cwd=tmp_path, env=senv, capture_output=True, text=True)
+    assert r.returncode == 1 and "Empty input file" in r.stderr
+    r = subprocess.run([EXE, "-o", str(tmp_path / "o"), "-K"] + paths, cwd=tmp_path, env=senv, capture_output=True, text=True)
+    assert r.returncode == 1 and "streamed" in r.stderr
     assert run(["-o", str(tmp_path / "o"), "-f", "-2"] + paths, tmp_path).returncode == 1
 
 

@@ -65,10 +65,15 @@ MMT_API int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases,
  *   3 prefix-free parsing without the suffix array of the dictionary (guided.cpp: the text suffixes are sorted by their
  *     characters up to the phrase end, then by the parse; what 0 / 2 fall back to when the dictionary -- as large as
  *     half the text for two unrelated strands -- would not fit);
+ *   4 the same with expansion: only one representative per (distinct phrase, offset) is sorted -- the valid suffixes of
+ *     the dictionary -- and the emitter of 2 expands each by the inverted list of its phrase (pfp_lcp_mum.hpp:151-212);
+ *     what 0 takes instead of 3 when the collection is redundant (a rank's share of whole genomes).
+ *     mmt_producer_used reports 3 for both, mmt_producer_expanded says which;
  * w / p = PFP window and modulus (0 = chosen by the size of the text, as for the automatic producer; the reference's
  * defaults are 10 / 100).  The stream does not depend on them. */
 MMT_API int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p);
 MMT_API int mmt_producer_used(const mmt_engine* e);
+MMT_API int mmt_producer_expanded(const mmt_engine* e);
 
 /* One pass of the hot path: text -> SA/LCP/BWT -> scan -> rows (+ thresholds). */
 /* Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): hand over the text T itself

@@ -73,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
-    "mmt_engine_set_producer", "mmt_producer_used", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
+    "mmt_engine_set_producer", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
@@ -157,6 +157,7 @@ def load_library():
     L.mmt_column_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.mmt_engine_set_producer.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
     L.mmt_producer_used.argtypes = [C.c_void_p]
+    L.mmt_producer_expanded.argtypes = [C.c_void_p]
     L.mmt_engine_parse_only.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint32]
     L.mmt_pfp_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]
@@ -418,10 +419,14 @@ class Engine:
     def set_producer(self, kind="auto", w=0, p=0):
         """kind: 'auto' | 'direct' (reference -g path) | 'pfp' (reference default path) | 'guided' (the parse without the
         suffix array of its dictionary: collections with little redundancy, chosen automatically when needed)."""
-        _check(self.L.mmt_engine_set_producer(self.h, {"auto": 0, "direct": 1, "pfp": 2, "guided": 3}[kind], w, p))
+        _check(self.L.mmt_engine_set_producer(self.h, {"auto": 0, "direct": 1, "pfp": 2, "guided": 3, "expand": 4}[kind], w, p))
 
     def producer_used(self):
         return {1: "direct", 2: "pfp", 3: "guided"}.get(self.L.mmt_producer_used(self.h), "?")
+
+    def producer_expanded(self):
+        """the bucket-wise producer sorted one representative per (distinct phrase, offset) and the emitter expanded them"""
+        return bool(self.L.mmt_producer_expanded(self.h))
 
     def parse_only(self, use_revcomp=True, w=10, p=100):
         """Text layout + prefix-free parse; returns (dict bytes, parse u32[]) as the reference's -P writes them."""

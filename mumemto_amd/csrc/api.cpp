@@ -529,11 +529,12 @@ int mmt_device_memory(const mmt_engine* e, uint64_t out[4]) {
 
 int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p) {
     if (!e) return fail(1, "null");
-    if (kind < 0 || kind > 3) return fail(3, "producer must be 0 (auto), 1 (direct), 2 (pfp) or 3 (guided)");
+    if (kind < 0 || kind > 4) return fail(3, "producer must be 0 (auto), 1 (direct), 2 (pfp), 3 (guided) or 4 (guided + expansion)");
     e->e->set_producer(kind, w, p);
     return 0;
 }
 int mmt_producer_used(const mmt_engine* e) { return e ? e->e->producer_used() : 0; }
+int mmt_producer_expanded(const mmt_engine* e) { return e && e->e->producer_expanded() ? 1 : 0; }
 int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p) {
     if (!e) return fail(1, "null");
     MMT_TRY

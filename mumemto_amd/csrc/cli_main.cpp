@@ -149,9 +149,26 @@ static void put40(std::vector<uint8_t>& b, uint64_t v) {
 // travel HBM -> HBM, rank 0 folds, re-sorts into direct-run order and writes PREFIX.mums / PREFIX.lengths (/ .athresh).
 // Other modes (the reference refuses to merge them, include/pfp_mum.hpp:178-183): every rank builds the stream of the
 // whole collection and scans its share of the suffix-array positions; rank 0 writes the concatenated bytes.
+static bool want_streamed_input(const std::vector<std::string>& inputs, size_t copies);
 static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
     const std::string comm_file = o.output_prefix + ".comm." + std::to_string((long)getpid());
     std::remove(comm_file.c_str());
+    // ONE decision for all ranks, taken before any of them exists: whether the input is streamed and whether the ranks of a
+    // sharded run write pieces (no communicator) or gather (a communicator).  Each rank judging the host's free memory for
+    // itself -- at another moment, while the others allocate -- could put ranks on both sides of a collective.
+    {
+        BuildOptions q = o;
+        const bool mum_mode = q.validate();
+        const std::vector<std::string> inputs = resolve_inputs(q);
+        q.set_parameters(inputs.size(), mum_mode);
+        const size_t N = inputs.size(), world = (size_t)o.gpus;
+        const bool strict = mum_mode && (q.num_distinct_docs == 0 || (size_t)q.num_distinct_docs == N);
+        std::vector<std::string> share = inputs;                  // the largest share: rank 0's (anchor + the first block)
+        if (strict && N > 1) share.assign(inputs.begin(), inputs.begin() + 1 + ((N - 1) + world - 1) / world);
+        const bool streamed = want_streamed_input(share, world);
+        setenv("MUMEMTO_STREAM_INPUT", streamed ? "1" : "0", 0);            // (a value the user set stays)
+        if (!strict) setenv("MUMEMTO_RANK_PIECES", streamed ? "1" : "0", 0);
+    }
     // (pieces an earlier run that failed may have left behind must not be taken for this run's)
     for (int r = 0; r < o.gpus; r++)
         for (const char* ext : {".mums", ".mems", ".mums.tmp", ".mems.tmp"}) std::remove((o.output_prefix + ".rank" + std::to_string(r) + ext).c_str());
@@ -194,17 +211,25 @@ static int launch_ranks(int argc, char** argv, const BuildOptions& o) {
     for (const char* ext : {".mums", ".mems"}) {
         const std::string first = o.output_prefix + ".rank0" + ext;
         if (rc || !fs::exists(first)) continue;
-        std::ofstream all(o.output_prefix + ext, std::ios::binary | std::ios::trunc);
-        std::vector<char> buf(64u << 20);
-        for (int r = 0; r < o.gpus; r++) {
-            const std::string piece = o.output_prefix + ".rank" + std::to_string(r) + ext;
-            std::ifstream in(piece, std::ios::binary);
-            if (!in) { log_line("build_main", "the piece of rank " + std::to_string(r) + " is missing: " + piece); rc = 1; break; }
-            while (in) { in.read(buf.data(), (std::streamsize)buf.size()); all.write(buf.data(), in.gcount()); }
-            in.close();
-            std::remove(piece.c_str());
+        // joined under a temporary name and renamed when every piece is in: a short write or a kill half way leaves no
+        // plausible but truncated PREFIX.mems; the pieces go only after the joined file is complete
+        const std::string final_name = o.output_prefix + ext, tmp = final_name + ".tmp";
+        {
+            std::ofstream all(tmp, std::ios::binary | std::ios::trunc);
+            std::vector<char> buf(64u << 20);
+            for (int r = 0; r < o.gpus && !rc; r++) {
+                const std::string piece = o.output_prefix + ".rank" + std::to_string(r) + ext;
+                std::ifstream in(piece, std::ios::binary);
+                if (!in) { log_line("build_main", "the piece of rank " + std::to_string(r) + " is missing: " + piece); rc = 1; break; }
+                while (in && all) { in.read(buf.data(), (std::streamsize)buf.size()); all.write(buf.data(), in.gcount()); }
+                if (!all || in.bad()) { log_line("build_main", "could not write " + tmp + " (piece of rank " + std::to_string(r) + ")"); rc = 1; }
+            }
+            all.close();
+            if (!rc && !all) { log_line("build_main", "could not write " + tmp); rc = 1; }
         }
-        if (!all) { log_line("build_main", "could not write " + o.output_prefix + ext); rc = 1; }
+        if (!rc && std::rename(tmp.c_str(), final_name.c_str()) != 0) { log_line("build_main", "could not rename " + tmp); rc = 1; }
+        if (rc) { std::remove(tmp.c_str()); continue; }
+        for (int r = 0; r < o.gpus; r++) std::remove((o.output_prefix + ".rank" + std::to_string(r) + ext).c_str());
     }
     return rc;
 }
@@ -244,7 +269,7 @@ static uint64_t host_memory_available() {
     }
     return avail;
 }
-static bool want_streamed_input(const std::vector<std::string>& inputs, size_t copies = 1) {       // copies: processes that each hold it
+static bool want_streamed_input(const std::vector<std::string>& inputs, size_t copies) {       // copies: processes that each hold it
     if (const char* e = std::getenv("MUMEMTO_STREAM_INPUT")) return std::atoi(e) != 0;
     uint64_t bound = 0;                                      // bases at most: a compressed file counted four times
     for (const auto& p : inputs) {
@@ -577,7 +602,7 @@ int main(int argc, char** argv) {
         o.set_parameters(checkpoint ? doc_len.size() : inputs.size(), mum_mode);
         for (const auto& n : o.notes) log_line("build_main", n);
 
-        if (!checkpoint && want_streamed_input(inputs)) return run_streamed(o, inputs, mum_mode);
+        if (!checkpoint && want_streamed_input(inputs, 1)) return run_streamed(o, inputs, mum_mode);
         auto t0 = std::chrono::steady_clock::now();
         // the HIP runtime comes up (device, stream, code objects) while the host threads read the inputs
         const bool dry_run = std::getenv("MUMEMTO_DRY_RUN") != nullptr;

@@ -1217,7 +1217,7 @@ void Engine::run(const mmt_params& p) {
             const bool forced_pfp = env && std::string(env) == "pfp";
             const bool few_docs = doc_len_.size() <= 4 && !forced_pfp;
             kind = (env && std::string(env) == "direct") || reserved || few_docs ? 1 : 2;
-            if (env && std::string(env) == "guided" && !reserved) kind = 3;
+            if (env && (std::string(env) == "guided" || std::string(env) == "expand") && !reserved) kind = 3;
             // beyond one 32-bit suffix array only the parse works (MMT_FORCE_WIDE: the same choice, for tests)
             if (wide_ && !reserved && kind == 1) kind = 2;
         }
@@ -1232,7 +1232,7 @@ void Engine::run(const mmt_params& p) {
         if (!d_sa_.owned() || !d_bwt_.owned() || !d_sa_hi_.owned()) { d_sa_.release(); d_sa_hi_.release(); d_bwt_.release(); }
         ev_[1]->start(stream_);
         suffix_sort();
-        producer_used_ = 1;
+        producer_used_ = 1; producer_expanded_ = false;
         ev_[1]->stop(stream_);
         const bool lean = slim || wants_lean();
         if (lean) release_sort_scratch();
@@ -1256,7 +1256,7 @@ void Engine::run(const mmt_params& p) {
     // (parse positions are 32 bits here: beyond ~48 G characters the modulus grows so that the parse keeps below 1.6 G phrases)
     const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10);
     const uint32_t auto_p = n_ < (1ull << 30) ? 16 : (uint32_t)std::max<uint64_t>(30, n_ / 1600000000ull + 1);
-    if (kind == 3) pfp_want_guided_ = true;
+    if (kind == 3 || kind == 4) pfp_want_guided_ = true;
     stream_min_len_ = p.min_match_len;
     ev_[1]->start(stream_);
     // (the stream does not depend on the parameters of the parse: a producer named without them gets the automatic ones)
@@ -1264,6 +1264,7 @@ void Engine::run(const mmt_params& p) {
     pfp_want_guided_ = false;
     ev_[1]->stop(stream_);
     producer_used_ = pfp_->guided ? 3 : 2;
+    producer_expanded_ = pfp_->guided && pfp_->expand;
     // whole columns next to the windows when somebody wants to look at them afterwards
     columns_kept_ = keep_columns_ > 0 || (keep_columns_ < 0 && n_ < (1ull << 26));
     if (columns_kept_) {

@@ -124,6 +124,7 @@ public:
     // 3 = prefix-free parsing without the dictionary's suffix array (guided.cpp; automatic when that would not fit)
     void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w; pfp_p_ = p; }   // 0: chosen by the size
     int producer_used() const { return producer_used_; }
+    bool producer_expanded() const { return producer_expanded_; }   // producer 3 sorted representatives, the emitter expanded them
     // A2 alone (after build_text): phrases, dictionary, parse.  Used by -P / -K and the parity tests.
     void parse_only(bool revcomp, uint32_t w, uint32_t p);
     void pfp_copy_dict(std::vector<uint8_t>& out);
@@ -242,6 +243,9 @@ private:
     void pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs);
     void pfp_prepare(uint32_t w, uint32_t p);
     void pfp_prepare_emitter(uint32_t w);
+    // group tables of the emitter from the entry tables at hand (pfp.cpp); the BWT codes of the oversized groups' sort keys
+    void pfp_group_tables(uint32_t E, uint32_t G, uint64_t out_lo, uint64_t out_hi, bool slim);
+    void pfp_emit_codes(int shift);
     void guided_prepare();
     void guided_check_errors(const char* what);
     void build_giant(const std::vector<uint64_t>& hist);
@@ -249,6 +253,7 @@ private:
     void pfp_emit_window(uint64_t b0, uint64_t c1, int set);
     uint64_t pfp_first_tile(uint64_t b0);         // emitter tile in which the group covering stream entry b0 + 1 begins
     void guided_stream(ScanState& S, const mmt_params& p);
+    void guided_stream_expand(ScanState& S, const mmt_params& p);
     void lcp_bwt();
     void scan(const mmt_params& p);
     void scan_begin(const mmt_params& p, ScanState& S);
@@ -352,6 +357,7 @@ private:
     std::unique_ptr<PfpState> pfp_{new PfpState()};
     bool lean_ = false;                   // release each stage's scratch before the next stage allocates
     int producer_ = 0, producer_used_ = 1;
+    bool producer_expanded_ = false;
     uint32_t pfp_w_ = 0, pfp_p_ = 0;
     // scan
     DevBuf<k::Cand> d_cand_;

@@ -263,6 +263,19 @@ void Engine::guided_prepare() {
         gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
         d2h(S.g_bins, d_bins.get(), std::max<uint32_t>(S.g_nbins, 4096u), st);
     }
+    S.g_bins_rep.clear(); S.g_repbits.release();
+    if (S.expand) {
+        // expansion: which occurrence stands for its distinct phrase, and how many suffixes of each bin start in one
+        S.g_repbits.ensure(((size_t)m + 31) / 32 + 2);
+        gk::rep_bits(S.pid.get(), S.rep.get(), m, S.g_repbits.get(), st);
+        DevBuf<uint64_t> d_bins;
+        d_bins.ensure(std::max<uint32_t>(S.g_nbins, 4096u));
+        MMT_HIP(hipMemsetAsync(d_bins.get(), 0, (size_t)std::max<uint32_t>(S.g_nbins, 4096u) * 8, st));
+        ctx.repbits = S.g_repbits.get();
+        gk::bin_hist(ctx, prefix_chars, d_bins.get(), st);
+        ctx.repbits = nullptr;
+        d2h(S.g_bins_rep, d_bins.get(), std::max<uint32_t>(S.g_nbins, 4096u), st);
+    }
     S.err.ensure(16);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
 
@@ -304,11 +317,46 @@ void Engine::guided_prepare() {
         sorter_.release();
     }
     S.plcp.build(text_ref(), n + 1 + w, S.sa_p.get(), S.pid.get(), S.pstart.get(), W, m, d_temp_, st);
+    if (S.expand) {
+        // the inverted lists of the distinct phrases (parse.hpp:106-134), as for the emitter of the parse proper
+        // (pfp.cpp::pfp_prepare_emitter): occurrences ordered by (phrase, rank of the following parse suffix)
+        const int shift = bit_width_u64((uint64_t)m + 1);
+        const uint32_t pos_bits = W ? (uint32_t)bit_width_u64(n + w + 1) : 32u;
+        const bool rec12 = (uint32_t)shift + pos_bits > 64 || std::getenv("MMT_OCC_REC12") != nullptr;
+        S.occ_start.ensure((size_t)D + 2);
+        S.occ_ids.ensure((size_t)m + 1); S.occ_ts.ensure((size_t)m + 1);
+        {
+            DevBuf<uint32_t> k_in, v_in;
+            k_in.ensure((size_t)m + 1); v_in.ensure((size_t)m + 1);
+            pk::occ_sequence(S.sa_p.get(), S.pid.get(), m, D, k_in.get(), v_in.get(), st);
+            prims::sort_pairs_u32_u32(d_temp_, k_in.get(), S.occ_ids.get(), v_in.get(), S.occ_ts.get(), (size_t)m + 1, 0,
+                                      std::max(1, bit_width_u64((uint64_t)D)), st);
+            if (rec12) {
+                S.occ.release(); S.occ_sl.release();
+                S.occ12.ensure(3 * (size_t)m + 4);
+                pk::occ_finish12(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), W, m, S.occ_start.get(),
+                                 S.occ12.get(), S.plcp.sl.get(), st);
+            } else {
+                S.occ12.release();
+                S.occ.ensure(m); S.occ_sl.ensure(m);
+                pk::occ_finish(S.occ_ids.get(), S.occ_ts.get(), S.sa_p.get(), S.pstart.get(), m, S.occ_start.get(), S.occ.get(),
+                               pos_bits, S.plcp.sl.get(), S.occ_sl.get(), W, st);
+            }
+            MMT_HIP(hipStreamSynchronize(st));
+        }
+        S.occ_ids.release(); S.occ_ts.release();
+        S.ptab.ensure((size_t)D * 16 + 16);
+        pk::phrase_table(S.occ_start.get(), S.plen.get(), S.rep.get(), D, S.ptab.get(), st);
+        MMT_HIP(hipStreamSynchronize(st));
+        S.occ_start.release();
+        S.emit_pos_bits = pos_bits; S.emit_w = w;
+        pfp_emit_codes(shift);
+    }
     // (the distinct-phrase ids stay: two suffixes of a group that start at the same offset of the same distinct phrase spell
     // the same alpha -- gk::med_before asks the ids before it compares characters)
     S.sa_p.release(); S.parse.release(); S.rep.release(); S.prank.release(); S.pstart.release();
     S.plen.release(); S.dlen.release(); S.dstart.release();
-    ctx.pid = std::getenv("MMT_GUIDED_NO_PID") ? nullptr : S.pid.get();
+    ctx.pid = std::getenv("MMT_GUIDED_NO_PID") && !S.expand ? nullptr : S.pid.get();
     e5.stop(st);
     if (stats) std::fprintf(stderr, "[guided] parse of %u phrases sorted in %.1f ms (%d rounds)\n", m, ms_since(t0), S.rounds_parse);
     ctx.skip = 0; ctx.isa_p = S.isa_p.get();
@@ -458,6 +506,7 @@ void Engine::guided_check_errors(const char* what) {
 // the bins from the first one whose cumulative count reaches k n / count (every rank derives the same shares from the
 // same histogram); nothing is exchanged but the rows.
 void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
+    if (pfp_->expand) { guided_stream_expand(SS, p); return; }
     PfpState& S = *pfp_;
     const uint64_t n = n_;
     hipStream_t st = stream_;
@@ -694,6 +743,230 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
                             (unsigned long long)(piece_end - pre[bin_lo]), batches, X.cap, ms,
                             (double)small_sum / (double)std::max<uint64_t>(1, piece_end - pre[bin_lo]),
                             (double)active_sum / (double)std::max<uint64_t>(1, piece_end - pre[bin_lo]), rounds_max);
+    S.ms[6] = (float)ms;
+    sort_rounds_ = rounds_max;
+}
+
+// The same stream when the collection is redundant (PfpState::expand): a batch collects, of its bins, only the suffixes that
+// start in the REPRESENTATIVE occurrence of their distinct phrase -- one per valid suffix of the dictionary of the parse
+// (include/dictionary.hpp:103-157), which is never built --, sorts them with the machinery above, and hands the sorted
+// batch to the emitter of the parse proper (pfp_kernels.hip k_emit, pfp_lcp_mum.hpp:151-212) as its entry tables: every
+// representative is expanded by the inverted list of its phrase, groups of equal phrase suffixes are merged by the rank of
+// the following parse suffix.  {anchor + 12} whole-genome haplotypes: 79 G text suffixes, 14 G representatives.
+void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
+    PfpState& S = *pfp_;
+    const uint64_t n = n_;
+    const bool W = wide_;
+    hipStream_t st = stream_;
+    gk::Ctx& ctx = S.gctx;
+    ctx.repbits = S.g_repbits.get();
+    ctx.pid = S.pid.get();
+    struct RepOff { gk::Ctx& c; ~RepOff() { c.repbits = nullptr; } } rep_off{ctx};
+    const int prefix_chars = S.g_prefix;
+    const uint32_t n_bins = S.g_nbins;
+    const std::vector<uint64_t>& bins = S.g_bins;
+    const std::vector<uint64_t>& rbins = S.g_bins_rep;
+    const bool stats = std::getenv("MMT_GUIDED_STATS") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    if (p.min_match_len < (uint32_t)prefix_chars)
+        throw std::runtime_error("guided producer: the bins were formed for another minimum match length");
+    if (!S.ptab.get() || (!S.occ.get() && !S.occ12.get())) throw std::runtime_error("expansion: the inverted lists are gone");
+
+    // ---- shares of the ranks: whole bins, cut by the TEXT suffixes (the same shares as the plain producer's) ----
+    std::vector<uint64_t> pre(n_bins + 1, 0);
+    uint64_t reps_total = 0;
+    for (uint32_t bq = 0; bq < n_bins; bq++) { pre[bq + 1] = pre[bq] + bins[bq]; reps_total += rbins[bq]; }
+    if (pre[n_bins] != n) throw std::runtime_error("guided sort: the histogram of leading characters does not cover the text");
+    std::vector<uint32_t> cut(shard_count_ + 1, 0);
+    cut[shard_count_] = n_bins;
+    for (uint32_t k = 1; k < shard_count_; k++) {
+        const uint64_t target = (uint64_t)((unsigned __int128)n * k / shard_count_);
+        cut[k] = std::max<uint32_t>(cut[k - 1], (uint32_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin()));
+        if (cut[k] > n_bins) cut[k] = n_bins;
+    }
+    sort_pieces_.clear();
+    for (uint32_t q = 0; q < shard_count_; q++) sort_pieces_.emplace_back(pre[cut[q]], pre[cut[q + 1]] - pre[cut[q]]);
+    const uint32_t bin_lo = cut[shard_index_], bin_hi = cut[shard_index_ + 1];
+    if (shard_count_ > 1 && p.merge_metadata)
+        throw std::runtime_error("merge metadata needs the whole stream on one rank (partition the documents instead)");
+
+    // ---- capacities: a window of the stream (two sets: a batch with the tail of the one before) + the batch of
+    // representatives with the emitter's tables of its entries and groups ----
+    const bool capped = SS.cap != 0;
+    uint64_t largest = 0, largest_rep = 0, share = 0, share_rep = 0;
+    for (uint32_t b = bin_lo; b < bin_hi; b++) {
+        largest = std::max(largest, bins[b]); largest_rep = std::max(largest_rep, rbins[b]);
+        share += bins[b]; share_rep += rbins[b];
+    }
+    const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest) : largest;
+    const double per_rep = (double)Batch::bytes_per_element() + 45.0 + 28.0;       // batch scratch + entry tables + group tables
+    const double per_out = 2.0 * (W ? 10.0 : 9.0) + 0.05;                          // two window sets (+ the emitter's tile records)
+    const double ratio = (double)std::max<uint64_t>(share, 1) / (double)std::max<uint64_t>(share_rep, 1);   // text suffixes per representative
+    const double avail = 0.80 * (double)pool::available(device_) - per_out * (double)head_room -
+                         8.0 * (double)((n + gk::TILE - 1) / gk::TILE) - 4.0 * 1073741824.0;
+    const uint64_t WIN_MAX = 3000000000ull;                                        // (a window and its tail stay below 2^32 entries)
+    uint64_t win_cap = avail > 0 ? (uint64_t)(avail / (per_out + 1.15 * per_rep / ratio)) : 0;
+    win_cap = std::min<uint64_t>(std::max<uint64_t>(win_cap, 1u << 20), WIN_MAX);
+    win_cap = std::min<uint64_t>(win_cap, std::max<uint64_t>(share, 1024));
+    uint64_t rep_cap = std::min<uint64_t>((uint64_t)(1.15 * (double)win_cap / ratio) + 1024, 1ull << 30);
+    if (const char* c = std::getenv("MMT_GUIDED_BATCH")) {                         // (tests: small batches)
+        rep_cap = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
+        win_cap = std::max<uint64_t>(1024, (uint64_t)((double)rep_cap * ratio));
+    }
+    if (largest > win_cap || largest_rep > rep_cap) {
+        const double need = per_out * (double)largest + per_rep * (double)largest_rep;
+        if (need > std::max(avail, 0.0) + per_out * (double)(1u << 20) || largest >= 0xf0000000ull || largest_rep >= 0xfffffff0ull)
+            throw std::runtime_error("guided sort (expansion): " + std::to_string(largest) + " suffixes (" + std::to_string(largest_rep) +
+                                     " representatives) share their first " + std::to_string(prefix_chars) +
+                                     " characters: more than one batch can hold on this device");
+        win_cap = std::max(win_cap, largest); rep_cap = std::max(rep_cap, largest_rep);
+    }
+    Batch X;
+    X.reserve((uint32_t)std::max<uint64_t>(rep_cap, 1024));
+    DevBuf<uint32_t> L;                      // LCP of every representative of the batch with the one before it
+    L.ensure(rep_cap + 16);
+    window_reserve(0, head_room + win_cap + 16);
+    window_reserve(1, head_room + win_cap + 16);
+    DevBuf<uint64_t> carry;
+    carry.ensure(2);
+    const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
+    DevBuf<uint32_t> tile_cnt, tile_off;
+    tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
+    const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
+    const RmqView rmq = S.plcp.view();
+    S.emit_ready = true;
+
+    uint64_t base = pre[bin_lo], active_sum = 0, small_sum = 0, reps_done = 0;
+    const uint64_t piece_end = pre[bin_hi];
+    int batches = 0, rounds_max = 0;
+    uint64_t prev_len = 0;
+    uint32_t prev_last_bin = 0;
+    bool have_prev = false;
+    uint32_t counted_lo = 0, counted_hi = 0;
+    double ms_sort = 0, ms_emit = 0;
+    auto next_batch_end = [&](uint32_t b0, uint32_t stop, uint64_t& total, uint64_t& total_rep) {
+        uint32_t b1 = b0;
+        total = 0; total_rep = 0;
+        while (b1 < stop && total + bins[b1] <= win_cap && total_rep + rbins[b1] <= X.cap) { total += bins[b1]; total_rep += rbins[b1]; b1++; }
+        return b1;
+    };
+    for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
+        uint64_t total = 0, total_rep = 0;
+        const uint32_t b1 = next_batch_end(b0, bin_hi, total, total_rep);
+        if (b1 == b0) throw std::runtime_error("guided sort (expansion): a bin exceeds the batch");
+        if (total && !total_rep) throw std::runtime_error("guided sort (expansion): suffixes without a representative");
+        if (total) {
+            const uint32_t B = (uint32_t)total_rep;
+            const int set = batches & 1;
+            EventPair& ee = next_range_event(SS, 3);
+            ee.start(st);
+            auto t_a = now();
+            // (the batch before counted this batch's representatives per tile while it collected its own)
+            if (!(counted_lo == b0 && counted_hi == b1)) gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
+            prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+            uint64_t nt = 0, ntr = 0;
+            const uint32_t nb1 = next_batch_end(b1, bin_hi, nt, ntr);
+            const bool more = nt > 0;
+            gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1, more ? tile_cnt.get() : nullptr, st);
+            counted_lo = more ? b1 : 0; counted_hi = more ? nb1 : 0;
+            RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st, L.get(), &rmq);
+            gk::batch_lcp(ctx, rmq, X.pos_b.get(), B, carry.get(), have_prev, L.get(), S.err.get(), st);
+            MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
+            // ---- the emitter's entry tables: one entry per representative, in suffix-array order of the phrase suffixes ----
+            S.ce_cnt.ensure(B); S.ce_eoff.ensure(B, W); S.ce_first.ensure(B); S.ce_offm1.ensure(B); S.ce_gs.ensure(B);
+            S.ce_bwt.ensure(B); S.ce_hl.ensure(B); S.ce_slen.ensure(B); S.gscan.ensure(std::max<size_t>(B, 1));
+            gk::expand_entries(ctx, X.pos_b.get(), L.get(), B, S.ptab.get(), S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(),
+                               S.ce_bwt.get(), S.ce_gs.get(), S.ce_hl.get(), S.ce_slen.get(), S.err.get(), st);
+            guided_check_errors("representatives");            // (synchronises; the emitter's tables reuse the error words)
+            if (stats) ms_sort += std::chrono::duration<double, std::milli>(now() - t_a).count();
+            auto t_b = now();
+            prims::inclusive_sum_u32(d_temp_, S.ce_gs.get(), S.gscan.get(), B, st);
+            const uint32_t G = read_u32(S.gscan.get() + (B - 1), st);
+            gk::group_ids(S.ce_gs.get(), S.gscan.get(), B, st);
+            if (W) prims::exclusive_sum_u32_to_u64(d_temp_, S.ce_cnt.get(), S.ce_eoff.p64(), B, st);
+            else prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.p32(), B, st);
+            const uint64_t out_lo = base + 1;                   // (stream entry j + 1 = suffix-array entry j; entry 0 is the end sentinel)
+            gk::add_offset(S.ce_eoff.get(), W, B, out_lo, st);
+            {
+                const uint64_t expanded = S.ce_eoff.read(B - 1, st) + read_u32(S.ce_cnt.get() + (B - 1), st) - out_lo;
+                if (expanded != total)
+                    throw std::runtime_error("expansion: the representatives of a batch stand for " + std::to_string(expanded) +
+                                             " suffixes, its bins hold " + std::to_string(total));
+            }
+            uint32_t head0 = 0;
+            if (have_prev) { MMT_HIP(hipMemcpyAsync(&head0, L.get(), 4, hipMemcpyDeviceToHost, st)); MMT_HIP(hipStreamSynchronize(st)); }
+            pfp_group_tables(B, G, out_lo, out_lo + total, false);
+            // (group 0 of a batch has a predecessor in the batch before: its LCP came with the carry)
+            if (have_prev) MMT_HIP(hipMemcpyAsync(S.ghead.get() + 1, &head0, 4, hipMemcpyHostToDevice, st));
+            // ---- the window: [tail of the batch before | this batch | one virtual closing entry at the end of a rank's share] ----
+            uint64_t ext = 0;
+            if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[prev_last_bin], prev_len), capped ? SS.ext0 : ~0ull);
+            if (ext > head_room) throw std::runtime_error("guided sort: window head room too small");
+            if (ext) {
+                const int o = set ^ 1;
+                const uint64_t from = prev_len - ext;
+                MMT_HIP(hipMemcpyAsync(w_sa_[set].get(), w_sa_[o].get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
+                if (wide_) MMT_HIP(hipMemcpyAsync(w_hi_[set].get(), w_hi_[o].get() + from, ext, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(w_bwt_[set].get(), w_bwt_[o].get() + from, ext, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(w_lcp_[set].get(), w_lcp_[o].get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
+            }
+            S.first_tile.clear();
+            S.first_tile[base - ext] = S.tile_base;
+            pfp_emit_window(base - ext, base + total, set);
+            ee.stop(st);
+            {
+                uint32_t e16[16];
+                MMT_HIP(hipMemcpyAsync(e16, S.err.get(), 64, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipStreamSynchronize(st));
+                if (e16[0]) {
+                    char msg[400];
+                    std::snprintf(msg, sizeof(msg), "expansion: the emitter's order is inconsistent in batch %d: %u entries (text position past the end: "
+                                  "%u in tile groups, %u / %u in oversized groups; neighbours of a group without ascending parse ranks: %u)",
+                                  batches, e16[0], e16[5], e16[6], e16[7], e16[3]);
+                    throw std::runtime_error(msg);
+                }
+                MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
+            }
+            if (stats) ms_emit += std::chrono::duration<double, std::milli>(now() - t_b).count();
+            stream_entries_ += total;
+            uint64_t len = ext + total;
+            ColWindow w = window_view(set, base - ext, (uint32_t)len, (uint32_t)ext);
+            w.more_left = false;          // nothing an interval of this window could reach lies further left (bins)
+            keep_window(w);
+            if (want_anchor_ranks_) {
+                SaCol piece = w.sa; piece.lo += ext; if (piece.hi) piece.hi += ext;
+                k::anchor_ranks(piece, base, total, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
+            }
+            const bool last_of_share = b1 == bin_hi || base + total == piece_end;
+            if (last_of_share && base + total < n) {
+                MMT_HIP(hipMemsetAsync(w_lcp_[set].get() + len, 0, 4, st));
+                MMT_HIP(hipMemsetAsync(w_bwt_[set].get() + len, 0, 1, st));
+                MMT_HIP(hipMemsetAsync(w_sa_[set].get() + len, 0, 4, st));
+                if (wide_) MMT_HIP(hipMemsetAsync(w_hi_[set].get() + len, 0, 1, st));
+                w.len = (uint32_t)(len + 1);
+            }
+            if (!scan_window(SS, w, p)) throw std::runtime_error("guided sort: a walk left its bin");
+            sink_flush(SS);
+            prev_len = len; have_prev = true;
+            for (uint32_t b = b1; b-- > b0;) if (bins[b]) { prev_last_bin = b; break; }
+            base += total; reps_done += B; batches++;
+            rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
+        }
+        b0 = b1;
+    }
+    guided_check_errors("text suffixes");
+    if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
+    S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
+    MMT_HIP(hipStreamSynchronize(st));
+    const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
+    if (stats) std::fprintf(stderr, "[guided] expansion: %llu suffixes from %llu representatives (%llu in the whole text) in %d batches of at most %u "
+                            "representatives / %llu suffixes: %.1f ms with their scans (collect + sort + entries %.1f, tables + emitter %.1f); "
+                            "%.3f of the representatives settled in small groups, %.3f element-rounds per representative in %d rounds at most\n",
+                            (unsigned long long)(piece_end - pre[bin_lo]), (unsigned long long)reps_done, (unsigned long long)reps_total,
+                            batches, X.cap, (unsigned long long)win_cap, ms, ms_sort, ms_emit,
+                            (double)small_sum / (double)std::max<uint64_t>(1, reps_done),
+                            (double)active_sum / (double)std::max<uint64_t>(1, reps_done), rounds_max);
     S.ms[6] = (float)ms;
     sort_rounds_ = rounds_max;
 }

@@ -360,6 +360,53 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
     }
 }
 
+// ---- expansion (guided.cpp, Ctx::repbits): only the text suffixes that start in the REPRESENTATIVE occurrence of their
+// distinct phrase are collected and sorted -- one per (distinct phrase, offset), i.e. one per valid suffix of the parse's
+// dictionary (pfp_lcp_mum.hpp:131-147), which nobody has to hold --, and the emitter of the parse proper (pfp_kernels.hip
+// k_emit) expands each of them by the inverted list of its phrase.
+// Bit q of the result: the suffix at tile position 16 * threadIdx.x + q starts in a representative occurrence.  The tile's
+// phrase ends (4096 positions + the w - 1 the query points reach beyond it) are staged in LDS as bits with their running
+// counts: the phrase of a suffix is a rank, and its bit says "representative".
+__device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
+    if (!c.repbits) return 0xffffu;
+    __shared__ unsigned long long s_cut[66];
+    __shared__ uint32_t s_pre[66];
+    const uint64_t b = (uint64_t)blockIdx.x + c.tile0;             // the tile = block b of 4096 text positions
+    if (c.coff) {
+        if (threadIdx.x < 66) s_cut[threadIdx.x] = 0ull;
+        __syncthreads();
+        const uint32_t lo = c.brank[b], hi = c.brank[b + 1], hi2 = c.brank[b + 2];
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += 256) { const uint32_t o = c.coff[e]; atomicOr(&s_cut[o >> 6], 1ull << (o & 63)); }
+        if (threadIdx.x < 64 && hi + threadIdx.x < hi2) {          // (ascending: only the first 64 entries can lie below 64)
+            const uint32_t o = c.coff[hi + threadIdx.x];
+            if (o < 64) atomicOr(&s_cut[64], 1ull << o);
+        }
+    } else if (threadIdx.x < 65) s_cut[threadIdx.x] = c.mask[b * 64 + threadIdx.x];     // (whole blocks, zero padded, one block to spare)
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t v = (uint32_t)__popcll(s_cut[threadIdx.x]);
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if ((threadIdx.x & 63) >= (uint32_t)o) inc += y; }
+        s_pre[threadIdx.x] = inc - v;
+        if (threadIdx.x == 63) s_pre[64] = inc;
+    }
+    __syncthreads();
+    const uint32_t r0 = c.coff ? c.brank[b] : c.rdir[b * 8];
+    const uint32_t t0 = threadIdx.x * 16;
+    uint32_t keep = 0, cached = 0xffffffffu, word = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t xo = t0 + q + c.w - 1;                          // query point of the suffix, relative to the tile
+        const uint32_t wi = xo >> 6;
+        const uint32_t k = r0 + s_pre[wi] + (uint32_t)__popcll(s_cut[wi] & ((1ull << (xo & 63)) - 1ull));
+        if ((k >> 5) != cached) { cached = k >> 5; word = c.repbits[cached]; }
+        keep |= ((word >> (k & 31)) & 1u) << q;
+    }
+    __syncthreads();
+    return keep;
+}
+
 // One pass whatever the number of bins: a bin whose leading characters are all of A C G T -- nearly every suffix -- is
 // counted in LDS under its dense code (two bits a character: 4^pc <= 1024 counters), the others ('$', N, IUPAC codes, the
 // Dollars at the end) straight in global memory.  (A tile used to count in 4096 LDS counters, one pass over the text per
@@ -382,8 +429,9 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int pc, uint64_t* __res
     const bool in_register = c.bits <= 4;
     if (in_register)
         for (uint32_t k = 0; k < 4; k++) { const uint32_t sym = s_sym_of[k]; lut = (lut & ~(0xfull << (4 * sym))) | ((uint64_t)k << (4 * sym)); }
-    for_tile_bins(c, pc, s_sym, [&](int, bool in, uint32_t bin) {
-        if (!in) return;
+    const uint32_t keep = tile_rep_keep(c);
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t bin) {
+        if (!in || !((keep >> q) & 1u)) return;
         uint32_t dense = 0, bad = 0;
         for (int ch = 0; ch < pc; ch++) {
             const uint32_t sym = (bin >> (c.bits * (pc - 1 - ch))) & smask;
@@ -417,7 +465,8 @@ __global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     uint32_t mine = 0;
-    for_tile_bins(c, pc, s_sym, [&](int, bool in, uint32_t b) { if (in && b >= bin_lo && b < bin_hi) mine++; });
+    const uint32_t keep = tile_rep_keep(c);
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && ((keep >> q) & 1u) && b >= bin_lo && b < bin_hi) mine++; });
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -442,7 +491,9 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     __shared__ uint16_t s_sel[TILE];                               // tile offsets of the selected suffixes, in order
     constexpr int PER = TILE / 256;
     uint32_t sel = 0, nxt = 0;
+    const uint32_t keep = tile_rep_keep(c);
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+        in = in && ((keep >> q) & 1u);
         if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
         if (in && b >= next_lo && b < next_hi) nxt++;
     });
@@ -1535,6 +1586,77 @@ __global__ void k_phrase_ranks(Ctx c, const uint64_t* __restrict__ pos, uint32_t
 }
 void phrase_ranks(const Ctx& c, const uint64_t* pos, uint32_t D, const uint32_t* pid, uint32_t* prank, hipStream_t s) {
     hipLaunchKernelGGL(k_phrase_ranks, dim3(grid_for(D, 256)), dim3(256), 0, s, c, pos, D, pid, prank);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- expansion: a sorted batch of representative suffixes -> the entry tables of the emitter ---------------------------------
+// Element e of the batch (suffix-array order of the phrase suffixes; lcp[e] = characters it shares with element e - 1, the
+// carry of the batch before for e = 0) is one valid suffix of the parse's dictionary: its phrase k = rank of its query
+// point, its distinct phrase d = pid[k], |alpha| from the next phrase end; tab[d] = (occurrences, first slot of the inverted
+// list, length of the phrase).  Two neighbours spell the same alpha exactly when they share at least |alpha| characters
+// (phrase suffixes are prefix-free): they belong to one group, whose lists the emitter merges by parse rank
+// (pfp_lcp_mum.hpp:141-154 same_suffix).
+__global__ void k_expand_entries(Ctx c, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ lcp, uint32_t B,
+                                 const uint4* __restrict__ tab, uint32_t* __restrict__ ce_cnt, uint32_t* __restrict__ ce_first,
+                                 uint32_t* __restrict__ ce_offm1, uint8_t* __restrict__ ce_bwt, uint32_t* __restrict__ ce_gs,
+                                 uint32_t* __restrict__ ce_hl, uint32_t* __restrict__ ce_slen, uint32_t* __restrict__ err) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const uint64_t q = rec_pos(c, pos[e]);                     // V index; text position q - 1
+    const uint64_t x = query_point(c, q);
+    const uint32_t k = rank1(c, x);
+    const uint64_t slen = next_cut(c, x) + 2 - q;
+    const uint4 t = tab[c.pid[k]];
+    const uint32_t l = lcp[e];
+    if (slen >= (uint64_t)t.z || slen < (uint64_t)c.w) atomicAdd(err + 1, 1u);     // not a proper suffix of length >= w of its phrase
+    ce_cnt[e] = t.x;
+    ce_first[e] = t.y;
+    ce_offm1[e] = t.z - (uint32_t)slen - 1u;
+    ce_bwt[e] = q == 1 ? (uint8_t)0 : tx_byte(c.T, q - 1);
+    ce_gs[e] = e == 0 || (uint64_t)l < slen ? 1u : 0u;
+    ce_hl[e] = l;
+    ce_slen[e] = (uint32_t)slen;
+}
+void expand_entries(const Ctx& c, const uint64_t* pos, const uint32_t* lcp, uint32_t B, const void* tab, uint32_t* ce_cnt,
+                    uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_hl, uint32_t* ce_slen,
+                    uint32_t* err, hipStream_t s) {
+    if (!B) return;
+    hipLaunchKernelGGL(k_expand_entries, dim3(grid_for(B, 256)), dim3(256), 0, s, c, pos, lcp, B, static_cast<const uint4*>(tab),
+                       ce_cnt, ce_first, ce_offm1, ce_bwt, ce_gs, ce_hl, ce_slen, err);
+    MMT_HIP(hipGetLastError());
+}
+// ce_gs: flag -> group id + 1 at the first entry of a group (gscan = inclusive sum of the flags), 0 elsewhere
+__global__ void k_group_ids(uint32_t* __restrict__ ce_gs, const uint32_t* __restrict__ gscan, uint32_t B) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B) ce_gs[e] = ce_gs[e] ? gscan[e] : 0u;
+}
+void group_ids(uint32_t* ce_gs, const uint32_t* gscan, uint32_t B, hipStream_t s) {
+    if (!B) return;
+    hipLaunchKernelGGL(k_group_ids, dim3(grid_for(B, 256)), dim3(256), 0, s, ce_gs, gscan, B);
+    MMT_HIP(hipGetLastError());
+}
+// table[i] += add (stream offsets of a batch's entries: from batch-relative to absolute)
+template <typename P>
+__global__ void k_add_offset(P* __restrict__ t, uint32_t n, uint64_t add) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = (P)((uint64_t)t[i] + add);
+}
+void add_offset(void* table, bool wide, uint32_t n, uint64_t add, hipStream_t s) {
+    if (!n) return;
+    if (wide) hipLaunchKernelGGL(k_add_offset<uint64_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, static_cast<uint64_t*>(table), n, add);
+    else hipLaunchKernelGGL(k_add_offset<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, static_cast<uint32_t*>(table), n, add);
+    MMT_HIP(hipGetLastError());
+}
+// bit k <=> phrase k of the parse is the representative occurrence of its distinct phrase (rep[pid[k]] == k)
+__global__ void k_rep_bits(const uint32_t* __restrict__ pid, const uint32_t* __restrict__ rep, uint32_t m, uint32_t* __restrict__ bits) {
+    const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((uint64_t)wi * 32 >= m) return;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < 32; b++) { const uint64_t k = (uint64_t)wi * 32 + b; if (k < m && rep[pid[k]] == (uint32_t)k) v |= 1u << b; }
+    bits[wi] = v;
+}
+void rep_bits(const uint32_t* pid, const uint32_t* rep, uint32_t m, uint32_t* bits, hipStream_t s) {
+    hipLaunchKernelGGL(k_rep_bits, dim3(grid_for(((uint64_t)m + 31) / 32, 256)), dim3(256), 0, s, pid, rep, m, bits);
     MMT_HIP(hipGetLastError());
 }
 

@@ -50,6 +50,9 @@ struct Ctx {
     const uint32_t* g_k = nullptr; const uint64_t* g_ps = nullptr; const uint32_t* g_base = nullptr; uint32_t g_n = 0;
     const uint32_t* g_isa = nullptr; const uint32_t* g_grp = nullptr; RmqView g_rmq; uint32_t g_depth = 0;
     const uint32_t* g_bits = nullptr;                        // bit k: phrase k of the parse is a giant occurrence
+    // Expansion (guided.cpp): bit k <=> phrase k is the representative occurrence of its distinct phrase; the text-order
+    // kernels (bin_hist, batch_count, batch_fill) then see only the suffixes that start in such an occurrence.  nullptr: all.
+    const uint32_t* repbits = nullptr;
     // MMT_GUIDED_PROF: 16 counters of k_resolve_medium (clock ticks per phase summed over the waves, waves, walks); else nullptr
     unsigned long long* prof = nullptr;
 };
@@ -130,6 +133,16 @@ void write_columns(const Ctx& c, const uint64_t* pos, uint32_t B, uint64_t base,
 // of alpha without being ordered by their parse ranks
 void batch_lcp(const Ctx& c, const RmqView& R, const uint64_t* pos, uint32_t B, const uint64_t* carry, bool have_carry,
                uint32_t* lcp, uint32_t* err, hipStream_t s);
+// expansion: the entry tables of the emitter (pfp_kernels.hpp EmitArgs) from a sorted batch of representative suffixes;
+// tab: one uint4 per distinct phrase (occurrences, first slot of its inverted list, phrase length, -); ce_gs leaves as a
+// 0 / 1 flag "first entry of a group of equal phrase suffixes" (group_ids turns it into group id + 1); err[1] counts
+// elements that are not proper phrase suffixes of at least w characters
+void expand_entries(const Ctx& c, const uint64_t* pos, const uint32_t* lcp, uint32_t B, const void* tab, uint32_t* ce_cnt,
+                    uint32_t* ce_first, uint32_t* ce_offm1, uint8_t* ce_bwt, uint32_t* ce_gs, uint32_t* ce_hl, uint32_t* ce_slen,
+                    uint32_t* err, hipStream_t s);
+void group_ids(uint32_t* ce_gs, const uint32_t* gscan, uint32_t B, hipStream_t s);
+void add_offset(void* table, bool wide, uint32_t n, uint64_t add, hipStream_t s);
+void rep_bits(const uint32_t* pid, const uint32_t* rep, uint32_t m, uint32_t* bits, hipStream_t s);
 // sorted phrases -> 1-based lexicographic rank per distinct phrase
 void phrase_ranks(const Ctx& c, const uint64_t* pos, uint32_t D, const uint32_t* pid, uint32_t* prank, hipStream_t s);
 

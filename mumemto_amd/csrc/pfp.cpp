@@ -154,9 +154,20 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             const char* env = std::getenv("MUMEMTO_PRODUCER");
             const double tables = 46.0 * (double)dict_len64, sorter = 49.0 * (double)std::max<uint64_t>(dict_len64, m);
             const double need = tables + sorter;
-            S.guided = producer_ == 3 || pfp_want_guided_ || (env && std::string(env) == "guided") ||
+            S.guided = producer_ == 3 || producer_ == 4 || pfp_want_guided_ || (env && (std::string(env) == "guided" || std::string(env) == "expand")) ||
                        dict_len64 >= 0xffffff00ull ||
                        (producer_ == 0 && need > 0.9 * (double)pool::available(device_));
+            // Expansion: the bucket-wise producer sorts ONE representative per (distinct phrase, offset) -- the valid suffixes of
+            // the dictionary nobody holds -- and the emitter expands them by the phrases' inverted lists (guided.cpp).  It pays
+            // by the redundancy of the collection: a rank's share of whole genomes, {anchor + 12}, has 79 G text suffixes and 14 G
+            // of those.  A producer named "guided" stays the plain one; MUMEMTO_EXPAND=0 | 1 overrides.
+            S.expand = false;
+            if (S.guided) {
+                const bool named_plain = producer_ == 3 || (env && std::string(env) == "guided");
+                S.expand = producer_ == 4 || (env && std::string(env) == "expand") ||
+                           (!named_plain && (double)dict_len64 < 0.5 * (double)n);
+                if (const char* x = std::getenv("MUMEMTO_EXPAND")) S.expand = std::atoi(x) != 0;
+            }
             if (S.guided) {
                 S.dict_len = 0;
                 e2.stop(st);
@@ -338,14 +349,35 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
         S.esuf.release(); S.ephr.release(); S.ebw.release(); S.gflag.release(); S.vflag.release(); S.vscan.release();
         S.ptab.release(); S.plen.release(); S.segmin.release();
     }
-    // groups of equal phrase suffixes: first entry and first output position of each
-    const uint32_t G = S.n_groups;
+    S.occ12.release(); S.emit_pos_bits = pos_bits; S.emit_w = w;
+    pfp_emit_codes(shift);
+    pfp_group_tables(E, S.n_groups, 0, n + 1, slim);
+    S.emit_launches = 0;
+    S.emit_ready = true;
+    S.bwt_ready = true;
+    e6.stop(st);
+    mem_mark(device_, "lists + emitter tables");
+    S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
+    sort_rounds_ = S.rounds_dict;
+}
+
+// Group tables of the emitter from the entry tables S.ce_* (E entries in suffix-array order of their phrase suffixes, G groups
+// of equal phrase suffixes; the entries' output offsets cover [out_lo, out_hi)): first entry and first output position of
+// each group, |alpha| and the LCP at the head of the group, the oversized groups, the first group of every output tile.
+// The parse proper calls it once for the whole stream (out_lo = 0, out_hi = n + 1); the expansion of the bucket-wise producer
+// (guided.cpp) once per batch, for the piece of the stream the batch covers.
+void Engine::pfp_group_tables(uint32_t E, uint32_t G, uint64_t out_lo, uint64_t out_hi, bool slim) {
+    PfpState& S = *pfp_;
+    const bool W = wide_;
+    hipStream_t st = stream_;
+    const uint64_t TILE = pk::emit_tile();
+    S.n_groups = G; S.n_entries = E;
     S.sege.ensure((size_t)G + 2); S.segb.ensure((size_t)G + 2, W);
     prims::select_indices_u32flags(d_temp_, S.ce_gs.get(), S.sege.get(), S.err.get(), E, st);
     if (read_u32(S.err.get(), st) != G) throw std::runtime_error("PFP group count mismatch");
     pk::gather_pos(S.ce_eoff.get(), S.sege.get(), G, S.segb.get(), W, st);
     MMT_HIP(hipMemcpyAsync(S.sege.get() + G, &E, 4, hipMemcpyHostToDevice, st));
-    S.segb.write(G, n + 1, st);
+    S.segb.write(G, out_hi, st);
     // per group: |alpha| and the LCP with the phrase suffix of the group before (the minimum of the dictionary's LCP array)
     S.ghead.ensure((size_t)G * 2);
     pk::group_heads(S.sege.get(), S.ce_hl.get(), S.ce_slen.get(), G, S.ghead.get(), st);
@@ -395,24 +427,35 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
     MMT_HIP(hipStreamSynchronize(st));
     if (slim) S.gscan.release();
 
-    // the emitter's arguments, shared by every window
-    S.tiles = (n + 1 + pk::emit_tile() - 1) / pk::emit_tile();
+    // the emitter's arguments, shared by every window of these tables
+    S.tiles = (out_hi + TILE - 1) / TILE;
+    S.tile_base = out_lo / TILE;
     pk::EmitArgs& ea = S.ea;
     ea = pk::EmitArgs();
     ea.wide = W;
     ea.segb = S.segb.get(); ea.sege = S.sege.get(); ea.n_groups = G;
     ea.ce_eoff = S.ce_eoff.get(); ea.ce_cnt = S.ce_cnt.get(); ea.ce_first = S.ce_first.get();
     ea.ce_offm1 = S.ce_offm1.get(); ea.ce_bwt = S.ce_bwt.get(); ea.ce_gs = S.ce_gs.get();
-    ea.occ = S.occ.get(); ea.occ_sl = S.occ_sl.get(); ea.pos_bits = pos_bits;
-    ea.n = n;
+    ea.n = n_;
     ea.fb_group = S.fb_group.get(); ea.fb_off = S.fb_off.get(); ea.n_fb = F; ea.fb_base = 0;
     ea.err = S.err.get();
-    ea.ghead = S.ghead.get(); ea.rmq = S.plcp.view(); ea.w = w;
-    // the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at
-    // most 16 different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)
+    ea.ghead = S.ghead.get();
+    ea.occ = S.occ.get(); ea.occ_sl = S.occ_sl.get(); ea.occ12 = S.occ12.get(); ea.pos_bits = S.emit_pos_bits;
+    ea.rmq = S.plcp.view(); ea.w = S.emit_w;
+    ea.bwt_code = S.bwt_code.get(); ea.fb_bits = S.fb_bits;
+    S.tile_first.ensure((size_t)(S.tiles - S.tile_base) + 4);
+    pk::tile_first(S.segb.get(), G, S.tiles, S.tile_first.get() - S.tile_base, W, st, S.tile_base);
+    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
+}
+
+// the byte before every suffix of an oversized group rides in the low bits of its sort key when the text has at most 16
+// different bytes and the parse rank leaves room (MMT_PFP_NO_BWT_CODE: read it from the text instead)
+void Engine::pfp_emit_codes(int shift) {
+    PfpState& S = *pfp_;
+    hipStream_t st = stream_;
     S.decode = pk::BwtDecode{};
     S.fb_bits = 0; S.key_shift = shift;
-    if (F && !std::getenv("MMT_PFP_NO_BWT_CODE")) {
+    if (!std::getenv("MMT_PFP_NO_BWT_CODE")) {
         std::vector<uint64_t> hist;
         d2h(hist, d_hist_.get(), 256, st);
         std::vector<uint8_t> code(256, 0);
@@ -432,17 +475,6 @@ void Engine::pfp_prepare_emitter(uint32_t w) {
             MMT_HIP(hipStreamSynchronize(st));
         }
     }
-    ea.bwt_code = S.bwt_code.get(); ea.fb_bits = S.fb_bits;
-    S.tile_first.ensure((size_t)S.tiles + 4);
-    pk::tile_first(S.segb.get(), G, S.tiles, S.tile_first.get(), W, st);
-    MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
-    S.emit_launches = 0;
-    S.emit_ready = true;
-    S.bwt_ready = true;
-    e6.stop(st);
-    mem_mark(device_, "lists + emitter tables");
-    S.ms[5] = e5.ms(); S.ms[6] = e6.ms();
-    sort_rounds_ = S.rounds_dict;
 }
 
 // Suffix-array entries [b0, c1) of the stream -- suffix array, BWT byte and LCP value of each -- into window set `set`
@@ -498,7 +530,7 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
         ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get();
         ea.fb_base = S.h_fb_off[f0];
         S.emit_plan.ensure(pk::emit_plan_bytes(t1 - t0));
-        pk::emit(ea, S.tile_first.get(), S.emit_plan.get(), t0, t1, st);
+        pk::emit(ea, S.tile_first.get() - S.tile_base, S.emit_plan.get(), t0, t1, st);
         S.emit_launches++;
         const uint32_t nf = f1 - f0;
         if (nf) pk::emit_big(ea, S.fb_chunk0.get(), f0, nf, S.h_fb_chunk0[f1] - S.h_fb_chunk0[f0], st);
@@ -515,7 +547,7 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
                 prims::segmented_sort_pairs_u32_ranges(d_temp_, S.xk_a.get(), S.xk_b.get(), S.xv_a.p32(), S.xv_b.p32(), count,
                                                        nf, S.fb_rel.get(), S.fb_rel.get() + 1, S.key_shift + (int)S.fb_bits, st);
             pk::fallback_finish(S.fb_group.get(), S.fb_off.get(), f0, f1, S.h_fb_off[f0], S.segb.get(), S.xk_b.get(),
-                                S.xv_b.get(), S.fb_bits, S.decode, text_ptr(), n_, ea, count, W, st);
+                                S.xv_b.get(), S.fb_bits, S.decode, text_ref(), n_, ea, count, W, st);
         }
         t0 = t1;
     }

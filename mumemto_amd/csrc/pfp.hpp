@@ -16,6 +16,7 @@ struct PfpState {
     uint32_t n_cuts = 0, n_phrases = 0, n_distinct = 0, dict_len = 0, n_groups = 0;
     bool have_parse = false;
     bool guided = false;    // the dictionary stage was skipped: Engine::suffix_sort_guided sorts the text suffixes themselves
+    bool expand = false;    // ... one representative per (distinct phrase, offset) only, expanded by the emitter (guided.cpp)
     int rounds_dict = 0, rounds_parse = 0;
     float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
     DevBuf<uint8_t> dict, ptab, pinfo;   // pinfo: 16-byte record per phrase (k_phrase_hash)  // ptab: 16-byte record per distinct phrase (phrase_table)
@@ -29,6 +30,8 @@ struct PfpState {
     DevBuf<uint64_t> h1, h2, hk_a, hk_b;
     DevBuf<uint32_t> occ_start, occ_ids, occ_ts, vflag, vscan;
     DevBuf<uint64_t> occ;               // (t << pos_bits) | V position, per phrase occurrence
+    DevBuf<uint32_t> occ12;             // ... or 12-byte records (pk::occ_finish12) when the two exceed 64 bits
+    uint32_t emit_pos_bits = 0, emit_w = 0;
     DevBuf<uint32_t> ce_cnt, ce_first, ce_offm1, ce_gs, sege, xk_a, xk_b, fb_group, fb_size, fb_rel, tile_first;
     DevBuf<uint8_t> emit_plan;          // one record per output tile of the launch in progress (pk::emit)
     PosBuf ce_eoff, segb, fb_off, fb_start, xv_a, xv_b;     // stream offsets / text positions
@@ -48,7 +51,7 @@ struct PfpState {
     pk::BwtDecode decode{};
     uint32_t fb_bits = 0;
     int key_shift = 0;
-    uint64_t tiles = 0;
+    uint64_t tiles = 0, tile_base = 0;  // output tiles [tile_base, tiles) of the tables at hand (tile_first begins at tile_base)
     std::vector<uint64_t> h_fb_off, h_fb_start, h_fb_chunk0;
     DevBuf<uint64_t> fb_chunk0;
     // the bucket-wise producer between its batches (guided.cpp): rank / successor tables over the phrase ends, the
@@ -57,7 +60,8 @@ struct PfpState {
     DevBuf<uint32_t> g_rdir, g_brank;
     DevBuf<uint16_t> g_coff;               // the phrase ends as a list (gk::Ctx::coff): packed texts
     DevBuf<uint64_t> g_nxt;
-    std::vector<uint64_t> g_bins;
+    std::vector<uint64_t> g_bins, g_bins_rep;     // text suffixes per bin of leading characters; of them representatives (expansion)
+    DevBuf<uint32_t> g_repbits;                   // bit k: phrase k is the representative occurrence of its distinct phrase
     int g_prefix = 0;
     uint32_t g_nbins = 0;
     // giant phrases of the bucket-wise producer (guided.cpp::build_giant; gk::Ctx::g_*)

@@ -780,6 +780,37 @@ __global__ void k_occ_finish(const uint32_t* __restrict__ ids, const uint32_t* _
     // needs it for the element's LCP and would otherwise fetch it after it has read this record
     occ_sl[k] = t ? sl[t - 1] : 0u;
 }
+// The same lists for texts whose positions leave no room for the parse rank in one 64-bit word (37 + 31 bits on a rank's
+// share of whole genomes): ONE 12-byte record per occurrence -- t | low 32 bits of the position | its high byte + 24 bits of
+// sl[t - 1], saturated (0xffffff: the emitter reads the parse's LCP array instead) -- so that a phrase's short list still
+// costs its own lines only.
+template <typename P>
+__global__ void k_occ_finish12(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ ts,
+                               const uint32_t* __restrict__ sa_p, const P* __restrict__ pstart, uint32_t m,
+                               uint32_t* __restrict__ occ_start, uint32_t* __restrict__ occ12, const uint32_t* __restrict__ sl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > m) return;
+    const uint32_t id = ids[k];
+    if (k == 0 || id != ids[k - 1]) occ_start[id] = k;
+    if (k == m) return;                                    // the dummy
+    const uint32_t t = ts[k];
+    const uint32_t q = t ? sa_p[t - 1] - 1 : m - 1;
+    const uint64_t pos = (uint64_t)pstart[q];
+    const uint32_t v = t ? sl[t - 1] : 0u;
+    occ12[3ull * k] = t;
+    occ12[3ull * k + 1] = (uint32_t)pos;
+    occ12[3ull * k + 2] = ((uint32_t)(pos >> 32) & 0xffu) | ((v < 0xffffffu ? v : 0xffffffu) << 8);
+}
+void occ_finish12(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, bool wide, uint32_t m,
+                  uint32_t* occ_start, uint32_t* occ12, const uint32_t* sl, hipStream_t s) {
+    if (wide)
+        hipLaunchKernelGGL(k_occ_finish12<uint64_t>, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p,
+                           static_cast<const uint64_t*>(pstart), m, occ_start, occ12, sl);
+    else
+        hipLaunchKernelGGL(k_occ_finish12<uint32_t>, dim3(grid_for((uint64_t)m + 1, 256)), dim3(256), 0, s, ids, ts, sa_p,
+                           static_cast<const uint32_t*>(pstart), m, occ_start, occ12, sl);
+    MMT_HIP(hipGetLastError());
+}
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
                 uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, const uint32_t* sl, uint32_t* occ_sl, bool wide,
                 hipStream_t s) {
@@ -893,6 +924,7 @@ struct EmitArgsT {
     const P* ce_eoff; const uint32_t* ce_cnt; const uint32_t* ce_first; const uint32_t* ce_offm1;
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
     const uint64_t* occ; const uint32_t* occ_sl; uint32_t pos_bits;
+    const uint32_t* occ12;       // 12-byte occurrence records instead of occ / occ_sl (k_occ_finish12), or nullptr
     P n;
     SA sa; uint8_t* bwt;
     const uint32_t* fb_group; const P* fb_off; uint32_t n_fb; P fb_base;
@@ -1000,10 +1032,19 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
         my_sl[q] = 0;
         if (i < L) {
             const uint32_t e = sh.owner[i], k = i - sh.estart[e];
-            const uint64_t kp = ABL == 3 ? ((uint64_t)(i + 1) << a.pos_bits) | 7u : a.occ[sh.efirst[e] + k];
-            if (sorted && ABL != 3) my_sl[q] = a.occ_sl[sh.efirst[e] + k];
-            const uint32_t key = (uint32_t)(kp >> a.pos_bits);
-            my_pos[q] = (P)((kp & pos_mask) + sh.eoffm1[e]);
+            uint32_t key;
+            if (a.occ12 && ABL != 3) {
+                const uint32_t* r = a.occ12 + 3ull * ((uint64_t)sh.efirst[e] + k);
+                const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+                key = r0;
+                my_pos[q] = (P)(((uint64_t)r1 | ((uint64_t)(r2 & 0xffu) << 32)) + sh.eoffm1[e]);
+                if (sorted) { const uint32_t v = r2 >> 8; my_sl[q] = v == 0xffffffu && r0 ? a.rmq.sl[r0 - 1] : v; }
+            } else {
+                const uint64_t kp = ABL == 3 ? ((uint64_t)(i + 1) << a.pos_bits) | 7u : a.occ[sh.efirst[e] + k];
+                if (sorted && ABL != 3) my_sl[q] = a.occ_sl[sh.efirst[e] + k];
+                key = (uint32_t)(kp >> a.pos_bits);
+                my_pos[q] = (P)((kp & pos_mask) + sh.eoffm1[e]);
+            }
             if (sorted) sh.key[i] = key;
             else {
                 const uint32_t slot = (uint32_t)(clo - fb_origin) + i;
@@ -1171,22 +1212,24 @@ __device__ __forceinline__ void emit_piece(const EmitArgsT<P, SA>& a, EmitShared
 // pass over the groups instead of a global binary search per workgroup of the emitter
 template <typename P>
 __global__ void k_tile_first(const P* __restrict__ segb, uint32_t n_groups, uint32_t tile, uint64_t tiles,
-                             uint32_t* __restrict__ tile_first) {
+                             uint32_t* __restrict__ tile_first, uint64_t tile_base) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g > n_groups) return;
     // group g is the first one at or after t * tile for every t with begin(g-1) < t * tile <= begin(g);
     // the thread of g == n_groups closes the table for the tiles behind the last group
-    const uint64_t lo = g ? (uint64_t)segb[g - 1] / tile + 1 : 0;
+    // (tile_base: the tables of one batch of the stream -- guided.cpp, expansion -- begin at that tile; `tile_first` is the
+    // table's address minus tile_base entries)
+    const uint64_t lo = g ? (uint64_t)segb[g - 1] / tile + 1 : tile_base;
     const uint64_t hi = g < n_groups ? (uint64_t)segb[g] / tile : tiles;
     for (uint64_t t = lo; t <= hi && t <= tiles; t++) tile_first[t] = g;
 }
-void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s) {
+void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s, uint64_t tile_base) {
     if (wide)
         hipLaunchKernelGGL(k_tile_first<uint64_t>, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s,
-                           static_cast<const uint64_t*>(segb), n_groups, emit_tile(), tiles, out);
+                           static_cast<const uint64_t*>(segb), n_groups, emit_tile(), tiles, out, tile_base);
     else
         hipLaunchKernelGGL(k_tile_first<uint32_t>, dim3(grid_for((uint64_t)n_groups + 1, 256)), dim3(256), 0, s,
-                           static_cast<const uint32_t*>(segb), n_groups, emit_tile(), tiles, out);
+                           static_cast<const uint32_t*>(segb), n_groups, emit_tile(), tiles, out, tile_base);
     MMT_HIP(hipGetLastError());
 }
 
@@ -1289,7 +1332,7 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* 
     EmitArgsT<P, SA> t;
     t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
     t.ce_eoff = static_cast<const P*>(a.ce_eoff); t.ce_cnt = a.ce_cnt; t.ce_first = a.ce_first; t.ce_offm1 = a.ce_offm1;
-    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.occ_sl = a.occ_sl; t.pos_bits = a.pos_bits; t.n = (P)a.n;
+    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.occ_sl = a.occ_sl; t.pos_bits = a.pos_bits; t.occ12 = a.occ12; t.n = (P)a.n;
     t.sa = SA(a.sa); t.bwt = a.bwt;
     t.fb_group = a.fb_group; t.fb_off = static_cast<const P*>(a.fb_off); t.n_fb = a.n_fb; t.fb_base = (P)a.fb_base;
     t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
@@ -1374,7 +1417,7 @@ static void emit_big_typed(const EmitArgs& a, const uint64_t* chunk0, uint32_t f
     EmitArgsT<P, SA> t;
     t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
     t.ce_eoff = static_cast<const P*>(a.ce_eoff); t.ce_cnt = a.ce_cnt; t.ce_first = a.ce_first; t.ce_offm1 = a.ce_offm1;
-    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.occ_sl = a.occ_sl; t.pos_bits = a.pos_bits; t.n = (P)a.n;
+    t.ce_bwt = a.ce_bwt; t.ce_gs = a.ce_gs; t.occ = a.occ; t.occ_sl = a.occ_sl; t.pos_bits = a.pos_bits; t.occ12 = a.occ12; t.n = (P)a.n;
     t.sa = SA(a.sa); t.bwt = a.bwt;
     t.fb_group = a.fb_group; t.fb_off = static_cast<const P*>(a.fb_off); t.n_fb = a.n_fb; t.fb_base = (P)a.fb_base;
     t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
@@ -1451,7 +1494,7 @@ template <typename P, typename SA>
 __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P* __restrict__ fb_off, uint32_t f0,
                                   uint32_t f1, P fb_base, const P* __restrict__ segb,
                                   const uint32_t* __restrict__ sorted_keys, const P* __restrict__ sorted_vals,
-                                  uint32_t fb_bits, BwtDecode decode, const uint8_t* __restrict__ text, P n, SA sa,
+                                  uint32_t fb_bits, BwtDecode decode, const TextRef text, P n, SA sa,
                                   uint8_t* __restrict__ bwt, uint32_t* __restrict__ err, FinishLcp F, uint32_t total) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -1480,7 +1523,7 @@ __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P
     const uint64_t at = j - F.out_base;
     sa.set(at, p);
     if (fb_bits) bwt[at] = decode.byte[sorted_keys[i] & mask];     // rode along in the key
-    else bwt[at] = p ? text[p - 1] : (uint8_t)0;
+    else bwt[at] = p ? tx_byte(text, (uint64_t)p) : (uint8_t)0;             // V[p] = T[p - 1]
     const uint2 head = F.ghead[g];
     uint32_t v = head.y;
     if (i > lo) {
@@ -1495,7 +1538,7 @@ __global__ void k_fallback_finish(const uint32_t* __restrict__ fb_group, const P
 }
 void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
-                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, uint32_t total, bool wide,
+                     const BwtDecode& decode, const TextRef& text, uint64_t n, const EmitArgs& ea, uint32_t total, bool wide,
                      hipStream_t s) {
     if (f1 <= f0 || !total) return;
     FinishLcp F{ea.lcp, static_cast<const uint2*>(ea.ghead), ea.rmq, ea.w, ea.out_base, ea.win_lo, ea.win_hi};

@@ -62,6 +62,9 @@ void occ_sequence(const uint32_t* sa_p, const uint32_t* pid, uint32_t m, uint32_
 void occ_finish(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, uint32_t m,
                 uint32_t* occ_start, uint64_t* occ, uint32_t pos_bits, const uint32_t* sl, uint32_t* occ_sl, bool wide,
                 hipStream_t s);
+// 12-byte records (t | position low | position high byte + 24 bits of sl[t - 1], saturated) for wide texts
+void occ_finish12(const uint32_t* ids, const uint32_t* ts, const uint32_t* sa_p, const void* pstart, bool wide, uint32_t m,
+                  uint32_t* occ_start, uint32_t* occ12, const uint32_t* sl, hipStream_t s);
 // gscan: inclusive sum of gflag.  ce_gs[c] = g + 1 at the first entry of group g, 0 elsewhere; ce_hl / ce_slen: LCP with
 // the valid entry before (segmin: the segmented minimum of group_flags' seg) and length of the entry's phrase suffix
 // (scratch of group_heads)
@@ -92,6 +95,7 @@ struct EmitArgs {
     const uint8_t* ce_bwt; const uint32_t* ce_gs;
     const uint64_t* occ;        // per phrase occurrence (t << pos_bits) | V position, grouped by phrase
     const uint32_t* occ_sl = nullptr;   // and sl[t - 1] of the same occurrence
+    const uint32_t* occ12 = nullptr;    // instead of the two: 12-byte records (occ_finish12) when t and the position exceed 64 bits
     uint32_t pos_bits;
     uint64_t n;                 // text length; output stream has n + 1 entries, entry 0 = end sentinel
     SaCol sa; uint8_t* bwt;                       // n entries each (the sentinel entry is not stored)
@@ -116,7 +120,8 @@ struct EmitArgs {
 };
 struct BwtDecode { uint8_t byte[16]; };       // code -> byte
 // tile_first[t] = first group whose begin offset is >= t * EMIT_TILE (tiles + 1 entries, tiles = ceil(n_out / TILE))
-void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s);
+// (tile_base: the table begins at that tile and `out` is its address MINUS tile_base entries: the tables of one batch)
+void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s, uint64_t tile_base = 0);
 // output tiles [tile_lo, tile_hi); plan: emit_plan_bytes(tile_hi - tile_lo) bytes of device scratch (one record per tile,
 // written by a pre-pass of the launch: what a workgroup needs to know about a tile before it can load anything of it)
 size_t emit_plan_bytes(uint64_t tiles);
@@ -134,7 +139,7 @@ void relative_offsets(const void* fb_off, uint32_t f0, uint32_t count, uint32_t*
 // oversized groups [f0, f1) after their segmented sort (total = their elements: the used part of the fallback arrays)
 void fallback_finish(const uint32_t* fb_group, const void* fb_off, uint32_t f0, uint32_t f1, uint64_t fb_base,
                      const void* segb, const uint32_t* sorted_keys, const void* sorted_vals, uint32_t fb_bits,
-                     const BwtDecode& decode, const uint8_t* text, uint64_t n, const EmitArgs& ea, uint32_t total, bool wide,
+                     const BwtDecode& decode, const TextRef& text, uint64_t n, const EmitArgs& ea, uint32_t total, bool wide,
                      hipStream_t s);
 void iota(uint32_t* out, uint32_t n, hipStream_t s);
 void gather_u64(const uint64_t* src, const uint32_t* idx, uint32_t n, uint64_t* out, hipStream_t s);

@@ -15,11 +15,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module", params=["pfp", "direct", "guided"])
+@pytest.fixture(scope="module", params=["pfp", "direct", "guided", "expand", "expand12"])
 def engine(request):
     """Every case through all SA/LCP/BWT producers: prefix-free parsing with the production window (w 6, p 16; what the
-    automatic choice takes from five documents on), the direct suffix sort (its choice for fewer), and the parse without
-    the suffix array of its dictionary (what whole-genome partitions fall back to), here in batches of 20000 suffixes."""
+    automatic choice takes from five documents on), the direct suffix sort (its choice for fewer), the parse without
+    the suffix array of its dictionary (what whole-genome partitions of little redundancy fall back to), here in batches of
+    20000 suffixes, and the same with expansion (what a rank's share of whole genomes takes: one representative per distinct
+    phrase suffix is sorted, the emitter expands it; batches of 6000 representatives; "expand12": with the 12-byte
+    occurrence records of texts whose positions and parse ranks exceed 64 bits together)."""
     import mumemto_amd
     e = mumemto_amd.Engine(0)
     if request.param == "pfp":
@@ -27,10 +30,16 @@ def engine(request):
     elif request.param == "guided":
         e.set_producer("guided", 6, 16)
         os.environ["MMT_GUIDED_BATCH"] = "20000"
+    elif request.param in ("expand", "expand12"):
+        e.set_producer("expand", 6, 16)
+        os.environ["MMT_GUIDED_BATCH"] = "6000"
+        if request.param == "expand12":
+            os.environ["MMT_OCC_REC12"] = "1"
     else:
         e.set_producer("direct")
     yield e
     os.environ.pop("MMT_GUIDED_BATCH", None)
+    os.environ.pop("MMT_OCC_REC12", None)
     e.close()
 
 

@@ -93,6 +93,8 @@ class PosBuf {
 public:
     void ensure(size_t n, bool wide) { wide_ = wide; n_ = n; b_.ensure(n * (wide ? 8 : 4)); }
     void release() { b_.release(); n_ = 0; }
+    // a view of memory that belongs to another buffer (DevBuf::borrow): n entries of the given width
+    void borrow(void* p, size_t n, bool wide) { wide_ = wide; n_ = n; b_.borrow(static_cast<uint8_t*>(p), n * (wide ? 8 : 4)); }
     bool wide() const { return wide_; }
     void* get() const { return b_.get(); }
     uint32_t* p32() const { return reinterpret_cast<uint32_t*>(b_.get()); }

@@ -207,6 +207,9 @@ void Engine::guided_prepare() {
     if (n >= (1ull << 38)) prefix_chars = std::max(prefix_chars, std::min(15 / ctx.bits, ctx.chars));
     if (const char* e = std::getenv("MMT_GUIDED_PREFIX")) prefix_chars = std::max(1, std::min(std::atoi(e), std::min(18 / ctx.bits, ctx.chars)));
     prefix_chars = std::max(1, std::min<int>(prefix_chars, (int)std::min<uint32_t>(stream_min_len_, 64u)));
+    // (expansion: every occurrence of a phrase suffix must lie in the bin of its representative -- a phrase suffix has at
+    // least w characters, so a bin's prefix must not be longer than that)
+    if (S.expand) prefix_chars = std::max(1, std::min<int>(prefix_chars, (int)w));
     S.g_prefix = prefix_chars;
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
@@ -220,7 +223,10 @@ void Engine::guided_prepare() {
     // A packed text is a text that fills the device: the phrase ends are kept as a list then (two bytes per phrase + four per
     // block of 4096 positions) and the bit per position -- 72 GB on 573 G characters, with 9 GB of rank directory -- goes
     // (MMT_CUT_LIST=0 / 1 overrides: the tests run both forms)
-    const bool cut_list = std::getenv("MMT_CUT_LIST") ? std::atoi(std::getenv("MMT_CUT_LIST")) != 0 : packed_;
+    // (... and only then: a rank query on the bits is two independent lines -- directory word + the 512 positions' words --,
+    // on the list a search of two or three dependent round trips; a rank's share of configs[3], 79 G characters packed to
+    // 20 GB, keeps its 10 GB of bits)
+    const bool cut_list = std::getenv("MMT_CUT_LIST") ? std::atoi(std::getenv("MMT_CUT_LIST")) != 0 : (packed_ && n >= (1ull << 37));
     if (cut_list) {
         DevBuf<uint32_t> bcount;
         bcount.ensure(n_blocks + 2); S.g_brank.ensure(n_blocks + 2);
@@ -360,8 +366,10 @@ void Engine::guided_prepare() {
     e5.stop(st);
     if (stats) std::fprintf(stderr, "[guided] parse of %u phrases sorted in %.1f ms (%d rounds)\n", m, ms_since(t0), S.rounds_parse);
     ctx.skip = 0; ctx.isa_p = S.isa_p.get();
-    {
+    ctx.expand = S.expand ? 1u : 0u;
+    if (!S.expand) {
         // the parse rank rides in the record when it fits next to the position (MMT_GUIDED_NO_RANK: never -- tests)
+        // (representatives never ask for a parse rank: their records carry the length of alpha)
         const uint32_t pb = (uint32_t)bit_width_u64(n + w + 1);
         if (pb + (uint32_t)bit_width_u64(m) <= 64 && !std::getenv("MMT_GUIDED_NO_RANK")) { ctx.pos_bits = pb; ctx.rec_rank = 1; }
     }
@@ -761,7 +769,6 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     gk::Ctx& ctx = S.gctx;
     ctx.repbits = S.g_repbits.get();
     ctx.pid = S.pid.get();
-    struct RepOff { gk::Ctx& c; ~RepOff() { c.repbits = nullptr; } } rep_off{ctx};
     const int prefix_chars = S.g_prefix;
     const uint32_t n_bins = S.g_nbins;
     const std::vector<uint64_t>& bins = S.g_bins;
@@ -791,8 +798,10 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     if (shard_count_ > 1 && p.merge_metadata)
         throw std::runtime_error("merge metadata needs the whole stream on one rank (partition the documents instead)");
 
-    // ---- capacities: a window of the stream (two sets: a batch with the tail of the one before) + the batch of
-    // representatives with the emitter's tables of its entries and groups ----
+    // ---- capacities.  A BATCH is what is collected by one pass over the text and sorted at once: representatives of whole
+    // bins, at most 2^30; the emitter's entry and group tables of the batch live in the sort's scratch, which is dead by then.
+    // A WINDOW is what is emitted, scanned and dropped at once: whole bins of one batch, below 2^32 entries with the tail of
+    // the window before (ONE window set: the tail -- as far as an interval can reach -- waits in a buffer of its own). ----
     const bool capped = SS.cap != 0;
     uint64_t largest = 0, largest_rep = 0, share = 0, share_rep = 0;
     for (uint32_t b = bin_lo; b < bin_hi; b++) {
@@ -800,34 +809,63 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
         share += bins[b]; share_rep += rbins[b];
     }
     const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest) : largest;
-    const double per_rep = (double)Batch::bytes_per_element() + 45.0 + 28.0;       // batch scratch + entry tables + group tables
-    const double per_out = 2.0 * (W ? 10.0 : 9.0) + 0.05;                          // two window sets (+ the emitter's tile records)
-    const double ratio = (double)std::max<uint64_t>(share, 1) / (double)std::max<uint64_t>(share_rep, 1);   // text suffixes per representative
-    const double avail = 0.80 * (double)pool::available(device_) - per_out * (double)head_room -
+    const double per_rep = (double)Batch::bytes_per_element() + 12.0;              // batch scratch (holds the tables) + LCP, sege, fb_group
+    const double per_out = (W ? 10.0 : 9.0) + 0.05;                                // one window set (+ the emitter's tile records)
+    const double avail = 0.80 * (double)pool::available(device_) - 2.0 * per_out * (double)head_room -
                          8.0 * (double)((n + gk::TILE - 1) / gk::TILE) - 4.0 * 1073741824.0;
-    const uint64_t WIN_MAX = 3000000000ull;                                        // (a window and its tail stay below 2^32 entries)
-    uint64_t win_cap = avail > 0 ? (uint64_t)(avail / (per_out + 1.15 * per_rep / ratio)) : 0;
-    win_cap = std::min<uint64_t>(std::max<uint64_t>(win_cap, 1u << 20), WIN_MAX);
-    win_cap = std::min<uint64_t>(win_cap, std::max<uint64_t>(share, 1024));
-    uint64_t rep_cap = std::min<uint64_t>((uint64_t)(1.15 * (double)win_cap / ratio) + 1024, 1ull << 30);
-    if (const char* c = std::getenv("MMT_GUIDED_BATCH")) {                         // (tests: small batches)
+    const uint64_t WIN_MAX = 3600000000ull;                                        // (a window and its tail stay below 2^32 entries)
+    uint64_t win_cap = std::min<uint64_t>(std::max<uint64_t>(share, 1024), WIN_MAX);
+    if ((double)win_cap * per_out > 0.5 * std::max(avail, 0.0)) win_cap = std::max<uint64_t>((uint64_t)(0.5 * std::max(avail, 0.0) / per_out), 1u << 20);
+    uint64_t rep_cap = avail > 0 ? (uint64_t)((avail - (double)win_cap * per_out) / per_rep) : 0;
+    rep_cap = std::min<uint64_t>(std::max<uint64_t>(rep_cap, 1u << 20), 1ull << 30);
+    rep_cap = std::min<uint64_t>(rep_cap, std::max<uint64_t>(share_rep, 1024));
+    if (const char* c = std::getenv("MMT_GUIDED_BATCH")) {                         // (tests: small batches, two or three windows each)
         rep_cap = std::max<uint64_t>(1024, std::strtoull(c, nullptr, 10));
-        win_cap = std::max<uint64_t>(1024, (uint64_t)((double)rep_cap * ratio));
+        const double ratio = (double)std::max<uint64_t>(share, 1) / (double)std::max<uint64_t>(share_rep, 1);
+        win_cap = std::max<uint64_t>(1024, (uint64_t)(0.4 * (double)rep_cap * ratio));
     }
     if (largest > win_cap || largest_rep > rep_cap) {
         const double need = per_out * (double)largest + per_rep * (double)largest_rep;
-        if (need > std::max(avail, 0.0) + per_out * (double)(1u << 20) || largest >= 0xf0000000ull || largest_rep >= 0xfffffff0ull)
+        if (need > std::max(avail, 0.0) + per_out * (double)(1u << 20) + per_rep * (double)(1u << 20) || largest >= 0xf0000000ull ||
+            largest_rep >= 0xfffffff0ull)
             throw std::runtime_error("guided sort (expansion): " + std::to_string(largest) + " suffixes (" + std::to_string(largest_rep) +
                                      " representatives) share their first " + std::to_string(prefix_chars) +
                                      " characters: more than one batch can hold on this device");
         win_cap = std::max(win_cap, largest); rep_cap = std::max(rep_cap, largest_rep);
     }
     Batch X;
-    X.reserve((uint32_t)std::max<uint64_t>(rep_cap, 1024));
+    X.reserve((uint32_t)std::max<uint64_t>(rep_cap, 1024) + 64);
+    X.cap = (uint32_t)std::max<uint64_t>(rep_cap, 1024);
+    const size_t C = (size_t)X.cap + 64;
     DevBuf<uint32_t> L;                      // LCP of every representative of the batch with the one before it
-    L.ensure(rep_cap + 16);
+    L.ensure(C);
+    // The tables of the emitter are views of the batch's sort scratch (only pos_b, the sorted records, outlives the sort); they
+    // are forgotten again before the scratch goes (a DevBuf that borrows never frees, but a later run must not find them).
+    struct Views {
+        PfpState& S;
+        ~Views() {
+            S.ce_cnt.release(); S.ce_first.release(); S.ce_offm1.release(); S.ce_gs.release(); S.ce_hl.release(); S.ce_slen.release();
+            S.gscan.release(); S.ce_bwt.release(); S.ce_eoff.release(); S.segb.release(); S.ghead.release();
+            S.gctx.repbits = nullptr;
+        }
+    } views{S};
+    auto borrow_tables = [&]() {
+        S.ce_eoff.borrow(X.key_a.get(), C, W);
+        S.segb.borrow(X.key_b.get(), C, W);
+        S.ghead.borrow(reinterpret_cast<uint32_t*>(X.pos_a.get()), 2 * C);
+        S.ce_slen.borrow(reinterpret_cast<uint32_t*>(X.pos_c.get()), C);
+        S.gscan.borrow(reinterpret_cast<uint32_t*>(X.pos_c.get()) + C, C);
+        S.ce_cnt.borrow(X.slot_a.get(), C); S.ce_first.borrow(X.slot_b.get(), C); S.ce_offm1.borrow(X.ghead.get(), C);
+        S.ce_gs.borrow(X.hv.get(), C); S.ce_hl.borrow(X.idx.get(), C);
+        S.ce_bwt.borrow(X.head.get(), C);
+    };
+    S.sege.ensure(C + 2); S.fb_group.ensure(C + 2);
     window_reserve(0, head_room + win_cap + 16);
-    window_reserve(1, head_room + win_cap + 16);
+    // the tail of the window before (its last `head_room` entries at most)
+    DevBuf<uint32_t> t_sa, t_lcp;
+    DevBuf<uint8_t> t_hi, t_bwt;
+    t_sa.ensure(head_room + 16); t_lcp.ensure(head_room + 16); t_bwt.ensure(head_room + 16);
+    if (W) t_hi.ensure(head_room + 16);
     DevBuf<uint64_t> carry;
     carry.ensure(2);
     const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
@@ -839,81 +877,88 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
 
     uint64_t base = pre[bin_lo], active_sum = 0, small_sum = 0, reps_done = 0;
     const uint64_t piece_end = pre[bin_hi];
-    int batches = 0, rounds_max = 0;
-    uint64_t prev_len = 0;
+    int batches = 0, windows = 0, rounds_max = 0;
+    uint64_t prev_len = 0;                 // entries of the window before (without a virtual closing entry), the tail buffers hold its end
+    uint64_t tail_len = 0;
     uint32_t prev_last_bin = 0;
     bool have_prev = false;
     uint32_t counted_lo = 0, counted_hi = 0;
     double ms_sort = 0, ms_emit = 0;
-    auto next_batch_end = [&](uint32_t b0, uint32_t stop, uint64_t& total, uint64_t& total_rep) {
+    auto next_batch_end = [&](uint32_t b0, uint64_t& total, uint64_t& total_rep) {
         uint32_t b1 = b0;
         total = 0; total_rep = 0;
-        while (b1 < stop && total + bins[b1] <= win_cap && total_rep + rbins[b1] <= X.cap) { total += bins[b1]; total_rep += rbins[b1]; b1++; }
+        while (b1 < bin_hi && total_rep + rbins[b1] <= X.cap && total + bins[b1] < (1ull << 40)) { total += bins[b1]; total_rep += rbins[b1]; b1++; }
         return b1;
     };
     for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
         uint64_t total = 0, total_rep = 0;
-        const uint32_t b1 = next_batch_end(b0, bin_hi, total, total_rep);
+        const uint32_t b1 = next_batch_end(b0, total, total_rep);
         if (b1 == b0) throw std::runtime_error("guided sort (expansion): a bin exceeds the batch");
         if (total && !total_rep) throw std::runtime_error("guided sort (expansion): suffixes without a representative");
-        if (total) {
-            const uint32_t B = (uint32_t)total_rep;
-            const int set = batches & 1;
+        if (!total) { b0 = b1; continue; }
+        const uint32_t B = (uint32_t)total_rep;
+        auto t_a = now();
+        // ---- collect and sort the representatives of the bins [b0, b1) ----
+        // (the batch before counted this batch's representatives per tile while it collected its own)
+        if (!(counted_lo == b0 && counted_hi == b1)) gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
+        prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+        uint64_t nt = 0, ntr = 0;
+        const uint32_t nb1 = next_batch_end(b1, nt, ntr);
+        const bool more = nt > 0;
+        gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1, more ? tile_cnt.get() : nullptr, st);
+        counted_lo = more ? b1 : 0; counted_hi = more ? nb1 : 0;
+        RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st, L.get(), &rmq);
+        gk::batch_lcp(ctx, rmq, X.pos_b.get(), B, carry.get(), have_prev, L.get(), S.err.get(), st);
+        MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
+        // ---- the emitter's tables: one entry per representative, in suffix-array order of the phrase suffixes ----
+        borrow_tables();
+        gk::expand_entries(ctx, X.pos_b.get(), L.get(), B, S.ptab.get(), S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(),
+                           S.ce_bwt.get(), S.ce_gs.get(), S.ce_hl.get(), S.ce_slen.get(), S.err.get(), st);
+        guided_check_errors("representatives");            // (synchronises; the emitter's tables reuse the error words)
+        prims::inclusive_sum_u32(d_temp_, S.ce_gs.get(), S.gscan.get(), B, st);
+        const uint32_t G = read_u32(S.gscan.get() + (B - 1), st);
+        gk::group_ids(S.ce_gs.get(), S.gscan.get(), B, st);
+        if (W) prims::exclusive_sum_u32_to_u64(d_temp_, S.ce_cnt.get(), S.ce_eoff.p64(), B, st);
+        else prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.p32(), B, st);
+        const uint64_t out_lo = base + 1;                   // (stream entry j + 1 = suffix-array entry j; entry 0 is the end sentinel)
+        gk::add_offset(S.ce_eoff.get(), W, B, out_lo, st);
+        {
+            const uint64_t expanded = S.ce_eoff.read(B - 1, st) + read_u32(S.ce_cnt.get() + (B - 1), st) - out_lo;
+            if (expanded != total)
+                throw std::runtime_error("expansion: the representatives of a batch stand for " + std::to_string(expanded) +
+                                         " suffixes, its bins hold " + std::to_string(total));
+        }
+        uint32_t head0 = 0;
+        if (have_prev) { MMT_HIP(hipMemcpyAsync(&head0, L.get(), 4, hipMemcpyDeviceToHost, st)); MMT_HIP(hipStreamSynchronize(st)); }
+        pfp_group_tables(B, G, out_lo, out_lo + total, false);
+        // (group 0 of a batch has a predecessor in the batch before: its LCP came with the carry)
+        if (have_prev) MMT_HIP(hipMemcpyAsync(S.ghead.get() + 1, &head0, 4, hipMemcpyHostToDevice, st));
+        if (stats) { MMT_HIP(hipStreamSynchronize(st)); ms_sort += std::chrono::duration<double, std::milli>(now() - t_a).count(); }
+        auto t_b = now();
+        // ---- the windows of the batch: [tail of the window before | whole bins | one virtual closing entry at the end of a rank's share] ----
+        for (uint32_t s0 = b0; s0 < b1;) {
+            uint64_t wtotal = 0;
+            uint32_t s1 = s0;
+            while (s1 < b1 && wtotal + bins[s1] <= win_cap) wtotal += bins[s1++];
+            if (s1 == s0) throw std::runtime_error("guided sort (expansion): a bin exceeds the window");
+            if (!wtotal) { s0 = s1; continue; }
             EventPair& ee = next_range_event(SS, 3);
             ee.start(st);
-            auto t_a = now();
-            // (the batch before counted this batch's representatives per tile while it collected its own)
-            if (!(counted_lo == b0 && counted_hi == b1)) gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
-            prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
-            uint64_t nt = 0, ntr = 0;
-            const uint32_t nb1 = next_batch_end(b1, bin_hi, nt, ntr);
-            const bool more = nt > 0;
-            gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1, more ? tile_cnt.get() : nullptr, st);
-            counted_lo = more ? b1 : 0; counted_hi = more ? nb1 : 0;
-            RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st, L.get(), &rmq);
-            gk::batch_lcp(ctx, rmq, X.pos_b.get(), B, carry.get(), have_prev, L.get(), S.err.get(), st);
-            MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
-            // ---- the emitter's entry tables: one entry per representative, in suffix-array order of the phrase suffixes ----
-            S.ce_cnt.ensure(B); S.ce_eoff.ensure(B, W); S.ce_first.ensure(B); S.ce_offm1.ensure(B); S.ce_gs.ensure(B);
-            S.ce_bwt.ensure(B); S.ce_hl.ensure(B); S.ce_slen.ensure(B); S.gscan.ensure(std::max<size_t>(B, 1));
-            gk::expand_entries(ctx, X.pos_b.get(), L.get(), B, S.ptab.get(), S.ce_cnt.get(), S.ce_first.get(), S.ce_offm1.get(),
-                               S.ce_bwt.get(), S.ce_gs.get(), S.ce_hl.get(), S.ce_slen.get(), S.err.get(), st);
-            guided_check_errors("representatives");            // (synchronises; the emitter's tables reuse the error words)
-            if (stats) ms_sort += std::chrono::duration<double, std::milli>(now() - t_a).count();
-            auto t_b = now();
-            prims::inclusive_sum_u32(d_temp_, S.ce_gs.get(), S.gscan.get(), B, st);
-            const uint32_t G = read_u32(S.gscan.get() + (B - 1), st);
-            gk::group_ids(S.ce_gs.get(), S.gscan.get(), B, st);
-            if (W) prims::exclusive_sum_u32_to_u64(d_temp_, S.ce_cnt.get(), S.ce_eoff.p64(), B, st);
-            else prims::exclusive_sum_u32(d_temp_, S.ce_cnt.get(), S.ce_eoff.p32(), B, st);
-            const uint64_t out_lo = base + 1;                   // (stream entry j + 1 = suffix-array entry j; entry 0 is the end sentinel)
-            gk::add_offset(S.ce_eoff.get(), W, B, out_lo, st);
-            {
-                const uint64_t expanded = S.ce_eoff.read(B - 1, st) + read_u32(S.ce_cnt.get() + (B - 1), st) - out_lo;
-                if (expanded != total)
-                    throw std::runtime_error("expansion: the representatives of a batch stand for " + std::to_string(expanded) +
-                                             " suffixes, its bins hold " + std::to_string(total));
-            }
-            uint32_t head0 = 0;
-            if (have_prev) { MMT_HIP(hipMemcpyAsync(&head0, L.get(), 4, hipMemcpyDeviceToHost, st)); MMT_HIP(hipStreamSynchronize(st)); }
-            pfp_group_tables(B, G, out_lo, out_lo + total, false);
-            // (group 0 of a batch has a predecessor in the batch before: its LCP came with the carry)
-            if (have_prev) MMT_HIP(hipMemcpyAsync(S.ghead.get() + 1, &head0, 4, hipMemcpyHostToDevice, st));
-            // ---- the window: [tail of the batch before | this batch | one virtual closing entry at the end of a rank's share] ----
             uint64_t ext = 0;
             if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[prev_last_bin], prev_len), capped ? SS.ext0 : ~0ull);
-            if (ext > head_room) throw std::runtime_error("guided sort: window head room too small");
+            if (ext > head_room || ext > tail_len) throw std::runtime_error("guided sort: window head room too small");
             if (ext) {
-                const int o = set ^ 1;
-                const uint64_t from = prev_len - ext;
-                MMT_HIP(hipMemcpyAsync(w_sa_[set].get(), w_sa_[o].get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
-                if (wide_) MMT_HIP(hipMemcpyAsync(w_hi_[set].get(), w_hi_[o].get() + from, ext, hipMemcpyDeviceToDevice, st));
-                MMT_HIP(hipMemcpyAsync(w_bwt_[set].get(), w_bwt_[o].get() + from, ext, hipMemcpyDeviceToDevice, st));
-                MMT_HIP(hipMemcpyAsync(w_lcp_[set].get(), w_lcp_[o].get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
+                const uint64_t from = tail_len - ext;
+                MMT_HIP(hipMemcpyAsync(w_sa_[0].get(), t_sa.get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
+                if (W) MMT_HIP(hipMemcpyAsync(w_hi_[0].get(), t_hi.get() + from, ext, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(w_bwt_[0].get(), t_bwt.get() + from, ext, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(w_lcp_[0].get(), t_lcp.get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
             }
             S.first_tile.clear();
-            S.first_tile[base - ext] = S.tile_base;
-            pfp_emit_window(base - ext, base + total, set);
+            // (stream entry base + 1 begins a bin, hence a group: its tile is where the window's groups begin; what the tile holds
+            // of the window before is written once more, into the tail, with the same values)
+            S.first_tile[base - ext] = (base + 1) / pk::emit_tile();
+            pfp_emit_window(base - ext, base + wtotal, 0);
             ee.stop(st);
             {
                 uint32_t e16[16];
@@ -921,50 +966,61 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
                 MMT_HIP(hipStreamSynchronize(st));
                 if (e16[0]) {
                     char msg[400];
-                    std::snprintf(msg, sizeof(msg), "expansion: the emitter's order is inconsistent in batch %d: %u entries (text position past the end: "
+                    std::snprintf(msg, sizeof(msg), "expansion: the emitter's order is inconsistent in window %d: %u entries (text position past the end: "
                                   "%u in tile groups, %u / %u in oversized groups; neighbours of a group without ascending parse ranks: %u)",
-                                  batches, e16[0], e16[5], e16[6], e16[7], e16[3]);
+                                  windows, e16[0], e16[5], e16[6], e16[7], e16[3]);
                     throw std::runtime_error(msg);
                 }
-                MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
             }
-            if (stats) ms_emit += std::chrono::duration<double, std::milli>(now() - t_b).count();
-            stream_entries_ += total;
-            uint64_t len = ext + total;
-            ColWindow w = window_view(set, base - ext, (uint32_t)len, (uint32_t)ext);
+            stream_entries_ += wtotal;
+            uint64_t len = ext + wtotal;
+            // what the next window may need of this one, before anything else touches the window
+            tail_len = std::min<uint64_t>(len, head_room);
+            if (tail_len) {
+                const uint64_t from = len - tail_len;
+                MMT_HIP(hipMemcpyAsync(t_sa.get(), w_sa_[0].get() + from, tail_len * 4, hipMemcpyDeviceToDevice, st));
+                if (W) MMT_HIP(hipMemcpyAsync(t_hi.get(), w_hi_[0].get() + from, tail_len, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(t_bwt.get(), w_bwt_[0].get() + from, tail_len, hipMemcpyDeviceToDevice, st));
+                MMT_HIP(hipMemcpyAsync(t_lcp.get(), w_lcp_[0].get() + from, tail_len * 4, hipMemcpyDeviceToDevice, st));
+            }
+            ColWindow w = window_view(0, base - ext, (uint32_t)len, (uint32_t)ext);
             w.more_left = false;          // nothing an interval of this window could reach lies further left (bins)
             keep_window(w);
             if (want_anchor_ranks_) {
                 SaCol piece = w.sa; piece.lo += ext; if (piece.hi) piece.hi += ext;
-                k::anchor_ranks(piece, base, total, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
+                k::anchor_ranks(piece, base, wtotal, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
             }
-            const bool last_of_share = b1 == bin_hi || base + total == piece_end;
-            if (last_of_share && base + total < n) {
-                MMT_HIP(hipMemsetAsync(w_lcp_[set].get() + len, 0, 4, st));
-                MMT_HIP(hipMemsetAsync(w_bwt_[set].get() + len, 0, 1, st));
-                MMT_HIP(hipMemsetAsync(w_sa_[set].get() + len, 0, 4, st));
-                if (wide_) MMT_HIP(hipMemsetAsync(w_hi_[set].get() + len, 0, 1, st));
+            const bool last_of_share = s1 == bin_hi || base + wtotal == piece_end;
+            if (last_of_share && base + wtotal < n) {
+                MMT_HIP(hipMemsetAsync(w_lcp_[0].get() + len, 0, 4, st));
+                MMT_HIP(hipMemsetAsync(w_bwt_[0].get() + len, 0, 1, st));
+                MMT_HIP(hipMemsetAsync(w_sa_[0].get() + len, 0, 4, st));
+                if (W) MMT_HIP(hipMemsetAsync(w_hi_[0].get() + len, 0, 1, st));
                 w.len = (uint32_t)(len + 1);
             }
             if (!scan_window(SS, w, p)) throw std::runtime_error("guided sort: a walk left its bin");
             sink_flush(SS);
             prev_len = len; have_prev = true;
-            for (uint32_t b = b1; b-- > b0;) if (bins[b]) { prev_last_bin = b; break; }
-            base += total; reps_done += B; batches++;
-            rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
+            for (uint32_t b = s1; b-- > s0;) if (bins[b]) { prev_last_bin = b; break; }
+            base += wtotal; windows++;
+            s0 = s1;
         }
+        MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
+        if (stats) { MMT_HIP(hipStreamSynchronize(st)); ms_emit += std::chrono::duration<double, std::milli>(now() - t_b).count(); }
+        reps_done += B; batches++;
+        rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
         b0 = b1;
     }
     guided_check_errors("text suffixes");
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
-    S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
+    S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)windows;
     MMT_HIP(hipStreamSynchronize(st));
     const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
     if (stats) std::fprintf(stderr, "[guided] expansion: %llu suffixes from %llu representatives (%llu in the whole text) in %d batches of at most %u "
-                            "representatives / %llu suffixes: %.1f ms with their scans (collect + sort + entries %.1f, tables + emitter %.1f); "
+                            "representatives, %d windows of at most %llu suffixes: %.1f ms (collect + sort + tables %.1f, emitter + scans %.1f); "
                             "%.3f of the representatives settled in small groups, %.3f element-rounds per representative in %d rounds at most\n",
                             (unsigned long long)(piece_end - pre[bin_lo]), (unsigned long long)reps_done, (unsigned long long)reps_total,
-                            batches, X.cap, (unsigned long long)win_cap, ms, ms_sort, ms_emit,
+                            batches, X.cap, windows, (unsigned long long)win_cap, ms, ms_sort, ms_emit,
                             (double)small_sum / (double)std::max<uint64_t>(1, reps_done),
                             (double)active_sum / (double)std::max<uint64_t>(1, reps_done), rounds_max);
     S.ms[6] = (float)ms;

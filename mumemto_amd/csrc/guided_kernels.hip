@@ -172,6 +172,7 @@ __device__ __forceinline__ uint64_t rec_len(const Ctx& c, uint64_t rec, uint64_t
     return len == LEN_SAT ? alpha_len(c, q) : len;
 }
 __device__ __forceinline__ uint64_t rec_rank_key(const Ctx& c, uint64_t rec, uint64_t q) {
+    if (c.expand) return q;                                       // representatives: any consistent order of a group will do
     if (c.rec_rank) return rec >> c.pos_bits;
     const uint32_t k = rank1(c, query_point(c, q));
     return k + 1 < c.m ? (uint64_t)c.isa_p[k + 1] : 0ull;
@@ -206,7 +207,8 @@ __device__ __forceinline__ uint64_t first_diff(const Ctx& c, uint64_t qa, uint64
                                                uint32_t& ca, uint32_t& cb) {
     uint64_t t = from;
     while (t < stop) {
-        if (c.T.is_packed() && t + 64 <= stop) {
+        if (c.T.is_packed()) {
+            // (64 characters a side whatever is left to compare: the words are there, a difference at or behind `stop` is none)
             uint64_t xl, xh, yl, yh;
             const bool oka = tx_codes64(c.T, qa + t, xl, xh), okb = tx_codes64(c.T, qb + t, yl, yh);
             if (oka && okb) {
@@ -214,8 +216,10 @@ __device__ __forceinline__ uint64_t first_diff(const Ctx& c, uint64_t qa, uint64
                     const bool low = xl != yl;
                     const uint64_t x = low ? xl : xh, y = low ? yl : yh;
                     const uint32_t k = (uint32_t)__builtin_ctzll(x ^ y) >> 1;
+                    const uint64_t at = t + (low ? 0u : 32u) + k;
+                    if (at >= stop) return stop;
                     ca = tx_code_char((uint32_t)(x >> (2 * k)) & 3u); cb = tx_code_char((uint32_t)(y >> (2 * k)) & 3u);
-                    return t + (low ? 0u : 32u) + k;
+                    return at;
                 }
                 t += 64;
                 continue;
@@ -1046,6 +1050,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             S.len[i] = len < 0xffffffffull ? (uint32_t)len : 0xffffffffu;
             uint32_t pid = 0xffffffffu;
             if (c.skip) S.rank[i] = 0ull;
+            else if (c.expand) S.rank[i] = q;                        // (representatives: ties by position, no two share a phrase and an offset)
             else if (c.rec_rank) S.rank[i] = rec >> c.pos_bits;      // (no phrase lookup at all: the id is not worth three lines)
             else {                                                  // (one rank query serves both lookups)
                 const uint32_t k = rank1(c, query_point(c, q));
@@ -1075,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
     // times: 1.7 of the 2.1 s a G suffixes of such a text took.)
     if (lane < (uint32_t)GPW) s_ref[wave][lane] = 0u;
     MMT_WAVE_SYNC();
-    if (c.pid && !c.skip && !c.rec_rank) {
+    if (c.pid && !c.skip && !c.rec_rank && !c.expand) {
 #pragma unroll
         for (int h = 0; h < PERL; h++) {
             const uint32_t i = lane + 64 * h, seg = i / SEG, mem = i % SEG;
@@ -1231,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             (void)med_before<W>(c, S, pr, me, offset, &l);
             if (l == ~0ull) {
                 const uint64_t ra = S.rank[pr], rb = S.rank[me];
-                l = rb > ra ? (uint64_t)S.len[me] - c.w + rmq_min(R, (uint32_t)ra + 1, (uint32_t)rb) : (uint64_t)S.len[me];
+                l = rb > ra && !c.expand ? (uint64_t)S.len[me] - c.w + rmq_min(R, (uint32_t)ra + 1, (uint32_t)rb) : (uint64_t)S.len[me];
             }
             lcp_out[at] = l < (uint64_t)LCP_CAP ? (uint32_t)l : LCP_CAP;
         }
@@ -1564,9 +1569,16 @@ __global__ void k_batch_lcp(Ctx c, RmqView R, const uint64_t* __restrict__ pos, 
     const uint64_t lim = la < lb ? la : lb;
     uint64_t v = 0;
     if (cmp_rest(c, qa, la, qb, lb, 0, &v) == 0) {
-        const uint64_t ka = rec_rank_key(c, ra, qa), kb = rec_rank_key(c, rb, qb);
-        if (la != lb || kb >= ka) { atomicAdd(err + 2, 1u); v = lim; }
-        else v = la - c.w + rmq_min(R, (uint32_t)kb + 1, (uint32_t)ka);
+        if (c.expand) {
+            // representatives of one group of equal phrase suffixes: in any order (the first keys may have ordered them by what
+            // follows alpha, ties go by position), and "at least |alpha|" is all the group tables ask of their LCP
+            if (la != lb) atomicAdd(err + 2, 1u);
+            v = lim;
+        } else {
+            const uint64_t ka = rec_rank_key(c, ra, qa), kb = rec_rank_key(c, rb, qb);
+            if (la != lb || kb >= ka) { atomicAdd(err + 2, 1u); v = lim; }
+            else v = la - c.w + rmq_min(R, (uint32_t)kb + 1, (uint32_t)ka);
+        }
     }
     lcp[j] = v < (uint64_t)LCP_CAP ? (uint32_t)v : LCP_CAP;
 }
@@ -1602,10 +1614,10 @@ __global__ void k_expand_entries(Ctx c, const uint64_t* __restrict__ pos, const 
                                  uint32_t* __restrict__ ce_hl, uint32_t* __restrict__ ce_slen, uint32_t* __restrict__ err) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
-    const uint64_t q = rec_pos(c, pos[e]);                     // V index; text position q - 1
+    const uint64_t rec = pos[e], q = rec_pos(c, rec);            // V index; text position q - 1
     const uint64_t x = query_point(c, q);
     const uint32_t k = rank1(c, x);
-    const uint64_t slen = next_cut(c, x) + 2 - q;
+    const uint64_t slen = rec_len(c, rec, q);                    // (rides in the record unless it is beyond 2^24)
     const uint4 t = tab[c.pid[k]];
     const uint32_t l = lcp[e];
     if (slen >= (uint64_t)t.z || slen < (uint64_t)c.w) atomicAdd(err + 1, 1u);     // not a proper suffix of length >= w of its phrase

@@ -53,6 +53,11 @@ struct Ctx {
     // Expansion (guided.cpp): bit k <=> phrase k is the representative occurrence of its distinct phrase; the text-order
     // kernels (bin_hist, batch_count, batch_fill) then see only the suffixes that start in such an occurrence.  nullptr: all.
     const uint32_t* repbits = nullptr;
+    // ... and `expand` says that the elements are such representatives: no two of them spell the same (distinct phrase, offset),
+    // their order inside a group of equal phrase suffixes does not matter (the emitter merges the groups' inverted lists by
+    // parse rank), so ties are broken by position -- no rank of a following parse suffix is ever looked up -- and the LCP
+    // of two members of a group is reported as |alpha| (all that the group tables ask: "at least |alpha|").
+    uint32_t expand = 0;
     // MMT_GUIDED_PROF: 16 counters of k_resolve_medium (clock ticks per phase summed over the waves, waves, walks); else nullptr
     unsigned long long* prof = nullptr;
 };

@@ -54,6 +54,16 @@ def test_automatic_producer_goes_by_the_number_of_documents():
     e.close()
 
 
+def test_the_expansion_fixture_expands(engine, request):
+    """the "expand" engines really sort representatives and run the emitter behind them, the others do not"""
+    engine.set_docs(synth.pangenome(7, 9000, 0.01, seed=3))
+    engine.run()
+    param = request.node.callspec.params["engine"]
+    assert engine.producer_expanded() == param.startswith("expand")
+    if param.startswith("expand"):
+        assert engine.producer_used() == "guided" and engine.stream_stats()["windows"] >= 3
+
+
 def check_stream(engine, docs, revcomp):
     text, doc_start = O.build_text(docs, revcomp)
     sa, lcp, bwt = O.build_stream(text)

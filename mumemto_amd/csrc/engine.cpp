@@ -194,11 +194,21 @@ TextRef Engine::text_ref() const {
 // text would not leave room for the tables of the parse and one batch of the producer: SURVEY.md 8(e) row 2 -- every rank of
 // BASELINE configs[4] holds all 573 G characters, 143 GB packed.  Only the bucket-wise producer reads a packed text, and the
 // direct producer's inputs (bytes <= 0x02, four documents or fewer below 2^32 characters) keep the byte layout.
-bool Engine::want_packed_text() const {
-    if (const char* c = std::getenv("MMT_PACKED_TEXT")) return std::atoi(c) != 0;
+bool Engine::want_packed_text() const { return want_packed_text_of(n_); }
+// (the same predicate says whether the raw bases of a host-fed run go through staging buffers: partitioned.cpp)
+bool Engine::want_packed_text_of(uint64_t n, bool by_size_only) const {
+    if (const char* c = std::getenv("MMT_PACKED_TEXT")) { if (!by_size_only) return std::atoi(c) != 0; }
+    // A text below 2^32 characters is never packed for want of room: on a small or busy device (less than ~27 GB free) the
+    // formula below packed every text, a few kilobases too, and sent it to the bucket-wise producer with 256 MB of event
+    // buffers and row discard -- such a device runs small collections normally or fails for what really does not fit.
+    if (n < NARROW_LIMIT) return false;
     // (1 byte per character + 0.5 for the raw bases while the text is made + ~1.4 at the parse's peak + a batch)
     const double avail = 0.95 * (double)pool::available(device_);
-    return (double)n_ * 2.9 + 24.0 * 1073741824.0 > avail;
+    if ((double)n * 2.9 + 24.0 * 1073741824.0 > avail) return true;
+    // whole-genome shares (from ~48 G characters on the modulus of the parse grows with the text too): the bucket-wise producer
+    // with expansion takes them anyway, and what the packed text leaves free becomes batches -- {anchor + 11} haplotypes kept
+    // their 73 GB of bytes, had 287 M representatives a batch and 52 passes over the text where the packed {anchor + 12} had 14
+    return n >= 48000000000ull;
 }
 
 // exception runs: events -> sorted run list + one flag per block of 4096 positions (textref.hpp)

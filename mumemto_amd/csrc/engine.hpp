@@ -238,6 +238,7 @@ private:
     void layout_docs(bool revcomp);
     void build_text(bool revcomp);
     bool want_packed_text() const;
+    bool want_packed_text_of(uint64_t n, bool by_size_only = false) const;
     void finish_packed_text(DevBuf<uint64_t>& ev_start, DevBuf<uint64_t>& ev_end, DevBuf<uint32_t>& ev_count, uint32_t ev_cap);
     void suffix_sort();
     void pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs);

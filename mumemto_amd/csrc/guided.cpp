@@ -32,6 +32,14 @@ static uint32_t read_u32(const uint32_t* d, hipStream_t s) {
     return v;
 }
 
+// MMT_MEM_TRACE=1: live / peak bytes of the device heap at the stage boundaries (stderr)
+static void mem_mark(int device, const char* what) {
+    static const bool on = std::getenv("MMT_MEM_TRACE") != nullptr;
+    if (!on) return;
+    const pool::Stats s = pool::stats(device);
+    std::fprintf(stderr, "[mem] %-28s live %7.2f GB  peak %7.2f GB  mapped %7.2f GB\n", what, s.live / 1e9, s.peak / 1e9, s.mapped / 1e9);
+}
+
 namespace {
 
 // scratch of one batch (capacity elements)
@@ -367,6 +375,7 @@ void Engine::guided_prepare() {
     if (stats) std::fprintf(stderr, "[guided] parse of %u phrases sorted in %.1f ms (%d rounds)\n", m, ms_since(t0), S.rounds_parse);
     ctx.skip = 0; ctx.isa_p = S.isa_p.get();
     ctx.expand = S.expand ? 1u : 0u;
+    if (S.expand) { MMT_HIP(hipStreamSynchronize(st)); S.isa_p.release(); ctx.isa_p = nullptr; }    // (representatives never ask for a parse rank)
     if (!S.expand) {
         // the parse rank rides in the record when it fits next to the position (MMT_GUIDED_NO_RANK: never -- tests)
         // (representatives never ask for a parse rank: their records carry the length of alpha)
@@ -811,9 +820,13 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest) : largest;
     const double per_rep = (double)Batch::bytes_per_element() + 12.0;              // batch scratch (holds the tables) + LCP, sege, fb_group
     const double per_out = (W ? 10.0 : 9.0) + 0.05;                                // one window set (+ the emitter's tile records)
-    const double avail = 0.80 * (double)pool::available(device_) - 2.0 * per_out * (double)head_room -
+    // (what the batches may take: four fifths of what is free, and no more than brings the heap to three quarters of the device --
+    // a share of whole genomes holds 130 GB of text, tables of the parse, anchor ranks and thresholds before its first batch, and
+    // the scan's candidates, the rows and the writers still come on top)
+    const double free_now = (double)pool::available(device_), live_now = (double)pool::stats(device_).live;
+    const double avail = std::min(0.80 * free_now, 0.76 * (free_now + live_now) - live_now) - 2.0 * per_out * (double)head_room -
                          8.0 * (double)((n + gk::TILE - 1) / gk::TILE) - 4.0 * 1073741824.0;
-    const uint64_t WIN_MAX = 3600000000ull;                                        // (a window and its tail stay below 2^32 entries)
+    const uint64_t WIN_MAX = 1ull << 31;                                           // (a window and its tail stay well below 2^32 entries)
     uint64_t win_cap = std::min<uint64_t>(std::max<uint64_t>(share, 1024), WIN_MAX);
     if ((double)win_cap * per_out > 0.5 * std::max(avail, 0.0)) win_cap = std::max<uint64_t>((uint64_t)(0.5 * std::max(avail, 0.0) / per_out), 1u << 20);
     uint64_t rep_cap = avail > 0 ? (uint64_t)((avail - (double)win_cap * per_out) / per_rep) : 0;
@@ -833,6 +846,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
                                      " characters: more than one batch can hold on this device");
         win_cap = std::max(win_cap, largest); rep_cap = std::max(rep_cap, largest_rep);
     }
+    mem_mark(device_, "expansion: before the batches");
     Batch X;
     X.reserve((uint32_t)std::max<uint64_t>(rep_cap, 1024) + 64);
     X.cap = (uint32_t)std::max<uint64_t>(rep_cap, 1024);
@@ -847,6 +861,13 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
             S.ce_cnt.release(); S.ce_first.release(); S.ce_offm1.release(); S.ce_gs.release(); S.ce_hl.release(); S.ce_slen.release();
             S.gscan.release(); S.ce_bwt.release(); S.ce_eoff.release(); S.segb.release(); S.ghead.release();
             S.gctx.repbits = nullptr;
+            // what only this stream needed goes with it, also when it fails (a run that does not fit is repeated as anchor
+            // partitions: they must find the device as empty as the first attempt did)
+            S.occ.release(); S.occ_sl.release(); S.occ12.release(); S.ptab.release(); S.g_repbits.release();
+            S.sege.release(); S.fb_group.release(); S.fb_size.release(); S.fb_off.release(); S.fb_start.release();
+            S.tile_first.release(); S.emit_plan.release(); S.xk_a.release(); S.xk_b.release(); S.xv_a.release(); S.xv_b.release();
+            S.fb_rel.release(); S.fb_chunk0.release();
+            S.emit_ready = false;
         }
     } views{S};
     auto borrow_tables = [&]() {
@@ -1007,6 +1028,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
         }
         MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
         if (stats) { MMT_HIP(hipStreamSynchronize(st)); ms_emit += std::chrono::duration<double, std::milli>(now() - t_b).count(); }
+        if (!batches) mem_mark(device_, "expansion: first batch done");
         reps_done += B; batches++;
         rounds_max = std::max(rounds_max, rs.rounds); active_sum += rs.active_sum; small_sum += rs.small;
         b0 = b1;

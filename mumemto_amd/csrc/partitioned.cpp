@@ -98,9 +98,8 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
         try {
             // (a text that will be packed -- two bits per character -- never has its raw bases on the device as a whole:
             // they go through a staging buffer document by document; MMT_INPUT_DEFERRED=1 forces that route for tests)
-            const double avail = 0.95 * (double)pool::available(device_);
             const bool defer = std::getenv("MMT_INPUT_DEFERRED") ? std::atoi(std::getenv("MMT_INPUT_DEFERRED")) != 0
-                                                                  : (double)total * 2.9 + 24.0 * 1073741824.0 > avail;
+                                                                  : want_packed_text_of(total, true);
             if (defer) set_input_host_docs_deferred(doc_ptr, doc_len, n_docs);
             else set_input_host_docs(doc_ptr, doc_len, n_docs);
             run_once_dropping_input(p);

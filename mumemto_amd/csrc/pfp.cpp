@@ -164,8 +164,11 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
             S.expand = false;
             if (S.guided) {
                 const bool named_plain = producer_ == 3 || (env && std::string(env) == "guided");
+                // (... below 2^38 characters: a text that fills the device -- every rank of configs[4] holds 573 G characters --
+                // leaves the inverted lists and the batches of representatives too little room next to each other; there the
+                // plain producer with its staging list stays)
                 S.expand = producer_ == 4 || (env && std::string(env) == "expand") ||
-                           (!named_plain && (double)dict_len64 < 0.5 * (double)n);
+                           (!named_plain && (double)dict_len64 < 0.5 * (double)n && n < (1ull << 38));
                 if (const char* x = std::getenv("MUMEMTO_EXPAND")) S.expand = std::atoi(x) != 0;
             }
             if (S.guided) {

@@ -72,6 +72,11 @@ MMT_API int mmt_engine_set_input_host(mmt_engine* e, const uint8_t* h_bases,
  * w / p = PFP window and modulus (0 = chosen by the size of the text, as for the automatic producer; the reference's
  * defaults are 10 / 100).  The stream does not depend on them. */
 MMT_API int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p);
+/* Version of this device-resident ABI (the drop-in ABI of mumemto.h never changes).  Changes under an unchanged symbol name
+ * bump it: 4 = mmt_merged_device hands out the 32-bit merged thresholds (uint16_t before) and mmt_partition gained
+ * thresh_bits in former padding; 5 = producer 4 (expansion), mmt_producer_expanded, mmt_engine_set_text_sink keeps rows on
+ * request.  A caller built against an older header checks this before it trusts the layout.                            */
+MMT_API int mmt_abi_version(void);
 MMT_API int mmt_producer_used(const mmt_engine* e);
 MMT_API int mmt_producer_expanded(const mmt_engine* e);
 
@@ -216,6 +221,8 @@ MMT_API int mmt_pfp_copy_parse(mmt_engine* e, uint32_t* out);
 MMT_API int mmt_pfp_stage_ms(const mmt_engine* e, float out[8]);
 
 /* ---- anchor partition merge (src/merge_candidates.cpp:97-157) -------------- */
+/* ZERO-INITIALISE this struct (`mmt_partition p = {0};` / `memset`): thresh_bits occupies what was padding before round 4,
+ * and the merge entry points reject any value other than 0, 16 or 32 (rc 3).                                        */
 typedef struct mmt_partition {
     uint64_t n_rows, n_docs;
     const uint32_t* length;   /* host or device (see rows_on_device)           */

@@ -73,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
-    "mmt_engine_set_producer", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
+    "mmt_engine_set_producer", "mmt_abi_version", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",

@@ -386,13 +386,16 @@ size_t mmt_num_docs(const mmt_engine* e) { return e ? e->e->n_docs() : 0; }
 int mmt_rows_mum(const mmt_engine* e, uint32_t* length, int64_t* offsets, uint8_t* strands) {
     if (!e) return fail(1, "engine must be non-null");
     if (!e->e->rows_meta().mum_mode) return fail(3, "last run was not in MUM mode");
+    MMT_TRY
+    // (a run whose rows left with their windows -- Engine::set_text_sink over a text that fills the device -- throws here: the
+    // file and the count are all it answers for)
     const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_ARRAYS);
-    if (R.n_rows) {
+    if (R.n_rows && R.length && R.mum_offsets && R.mum_strands) {
         std::memcpy(length, R.length, R.n_rows * 4);
         std::memcpy(offsets, R.mum_offsets, R.n_rows * R.n_docs * 8);
         std::memcpy(strands, R.mum_strands, R.n_rows * R.n_docs);
     }
-    return 0;
+    MMT_CATCH
 }
 int mmt_rows_mum_device(const mmt_engine* e, const uint32_t** length, const int64_t** offsets,
                         const uint8_t** strands) {
@@ -406,16 +409,17 @@ int mmt_rows_mem(const mmt_engine* e, uint32_t* length, uint64_t* occ_start, int
                  uint8_t* strands) {
     if (!e) return fail(1, "engine must be non-null");
     if (e->e->rows_meta().mum_mode) return fail(3, "last run was in MUM mode");
+    MMT_TRY
     const mmt::HostRows& R = e->e->rows(mmt::Engine::ROWS_ARRAYS);
     occ_start[0] = 0;
-    if (R.n_rows) {
+    if (R.n_rows && R.length && R.occ_start && R.mem_offsets && R.mem_docs && R.mem_strands) {
         std::memcpy(length, R.length, R.n_rows * 4);
         std::memcpy(occ_start, R.occ_start, (R.n_rows + 1) * 8);
         std::memcpy(offsets, R.mem_offsets, R.n_occ * 8);
         std::memcpy(seq_ids, R.mem_docs, R.n_occ * 8);
         std::memcpy(strands, R.mem_strands, R.n_occ);
     }
-    return 0;
+    MMT_CATCH
 }
 const char* mmt_output_text(mmt_engine* e, size_t* len) {
     if (!e) { if (len) *len = 0; return nullptr; }
@@ -533,6 +537,7 @@ int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p) {
     e->e->set_producer(kind, w, p);
     return 0;
 }
+int mmt_abi_version(void) { return 5; }
 int mmt_producer_used(const mmt_engine* e) { return e ? e->e->producer_used() : 0; }
 int mmt_producer_expanded(const mmt_engine* e) { return e && e->e->producer_expanded() ? 1 : 0; }
 int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p) {
@@ -574,8 +579,16 @@ int mmt_pfp_stage_ms(const mmt_engine* e, float out[8]) {
 int mmt_anchor_merge(mmt_engine* e, const mmt_partition* parts, size_t k, mmt_merged** out) {
     return mmt_anchor_merge_min_len(e, parts, k, 20, out);      // src/merge_candidates.cpp:141
 }
+// mmt_partition::thresh_bits took a byte that used to be padding: a caller that fills the struct field by field without
+// zeroing it hands over garbage there, and 32 by accident would read 4 L bytes from a 2 L-byte column
+static bool bad_thresh_bits(const mmt_partition* parts, size_t k) {
+    for (size_t i = 0; i < k; i++)
+        if (parts[i].thresh_bits != 0 && parts[i].thresh_bits != 16 && parts[i].thresh_bits != 32) return true;
+    return false;
+}
 int mmt_anchor_merge_min_len(mmt_engine* e, const mmt_partition* parts, size_t k, uint32_t min_len, mmt_merged** out) {
     if (!e || !parts || !out) return fail(1, "engine, parts and out must be non-null");
+    if (bad_thresh_bits(parts, k)) return fail(3, "mmt_partition.thresh_bits must be 0, 16 or 32 (zero-initialise the struct)");
     *out = nullptr;
     MMT_TRY
     if (k < 2) throw std::invalid_argument("anchor merge requires at least two partitions");
@@ -593,6 +606,7 @@ int mmt_fold_slice_bounds(uint64_t thresh_len, int world, int r, size_t k, uint3
 int mmt_anchor_merge_by_ranges(mmt_engine* e, const mmt_partition* parts, size_t k, int slices, uint32_t min_len,
                                mmt_merged** out) {
     if (!e || !parts || !out) return fail(1, "engine, parts and out must be non-null");
+    if (bad_thresh_bits(parts, k)) return fail(3, "mmt_partition.thresh_bits must be 0, 16 or 32 (zero-initialise the struct)");
     *out = nullptr;
     MMT_TRY
     if (k < 2) throw std::invalid_argument("anchor merge requires at least two partitions");

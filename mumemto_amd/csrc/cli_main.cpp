@@ -438,7 +438,8 @@ static int run_streamed(BuildOptions& o, const std::vector<std::string>& inputs,
     p.max_total_freq = o.max_mem_freq;
     p.use_revcomp = o.use_rcomp ? 1 : 0;
     p.merge_metadata = o.merge ? 1 : 0;
-    if (!o.binary) eng.set_text_sink(o.output_prefix + (mum_mode ? ".mums" : ".mems"));
+    // (-M without -n cuts PREFIX.thresh / .thresh_rev out of the rows afterwards: such a run keeps them)
+    if (!o.binary) eng.set_text_sink(o.output_prefix + (mum_mode ? ".mums" : ".mems"), false, o.merge && !o.anchor_merge);
     try { eng.run_supplied(&StreamedInput::supply, &in, in.len.data(), in.len.size(), p); }
     catch (...) {
         eng.set_text_sink(std::string());
@@ -777,7 +778,7 @@ int main(int argc, char** argv) {
         } else {
             if (o.arrays_out) eng.set_keep_columns(1);          // -A dumps whole columns: keep them next to the windows
             // PREFIX.mums is written window by window while the run goes on (Engine::set_text_sink)
-            if (!o.binary) eng.set_text_sink(o.output_prefix + (mum_mode ? ".mums" : ".mems"));
+            if (!o.binary) eng.set_text_sink(o.output_prefix + (mum_mode ? ".mums" : ".mems"), false, o.merge && !o.anchor_merge);
             try {
                 eng.run(p);
                 eng.set_text_sink(std::string());

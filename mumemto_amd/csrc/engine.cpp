@@ -753,7 +753,8 @@ void Engine::sink_open(bool mum_mode) {
     // occurrences each -- tens of GB of suffix-array entries, offsets and text).  Such a run answers only for the file and
     // the number of rows.  MMT_SINK_DISCARD=0 / 1 overrides (tests).
     sink_discard_ = sink_force_discard_ ||
-                    (std::getenv("MMT_SINK_DISCARD") ? std::atoi(std::getenv("MMT_SINK_DISCARD")) != 0 : (packed_ || n_ >= (1ull << 37)));
+                    (!sink_keep_rows_ &&
+                     (std::getenv("MMT_SINK_DISCARD") ? std::atoi(std::getenv("MMT_SINK_DISCARD")) != 0 : (packed_ || n_ >= (1ull << 37))));
     if (!mum_mode && !sink_discard_) return;          // (a MEM run that keeps its rows writes its file at the end, as before)
     // the bytes go to PREFIX.mums.tmp and take the final name when the run has succeeded (sink_close): a run that fails
     // after some windows -- out of memory, a consistency check at the end -- must not leave a plausible partial PREFIX.mums
@@ -780,11 +781,14 @@ void Engine::sink_open(bool mum_mode) {
                 if (sink_q_.empty()) break;
                 pc = sink_q_.front(); sink_q_.pop_front();
             }
-            if (hipEventSynchronize(pc.ready) != hipSuccess && sink_error_.empty()) sink_error_ = "device copy of the output failed";
+            // (sink_error_ is read by the run's thread in sink_host_room / sink_close: both sides under the mutex)
+            auto failed = [&]() { std::lock_guard<std::mutex> lk(sink_mu_); return !sink_error_.empty(); };
+            auto fail_with = [&](const std::string& what) { std::lock_guard<std::mutex> lk(sink_mu_); if (sink_error_.empty()) sink_error_ = what; };
+            if (hipEventSynchronize(pc.ready) != hipSuccess) fail_with("device copy of the output failed");
             (void)hipEventDestroy(pc.ready);
-            for (size_t done = 0; sink_error_.empty() && done < pc.n;) {
+            for (size_t done = 0; !failed() && done < pc.n;) {
                 const ssize_t w = ::write(sink_fd_, pc.p + done, pc.n - done);
-                if (w <= 0) { sink_error_ = "short write to " + sink_tmp_path_; break; }
+                if (w <= 0) { fail_with("short write to " + sink_tmp_path_); break; }
                 done += (size_t)w;
             }
             { std::lock_guard<std::mutex> lk(sink_mu_); sink_block_pending_[pc.block]--; }
@@ -924,7 +928,8 @@ void Engine::sink_close(bool ok) {
     sink_cv_.notify_one();
     if (sink_thread_.joinable()) sink_thread_.join();
     (void)hipStreamSynchronize(sink_stream_);
-    std::string error = sink_error_;
+    std::string error;
+    { std::lock_guard<std::mutex> lk(sink_mu_); error = sink_error_; }
     if (sink_fd_ >= 0 && ::close(sink_fd_) != 0 && error.empty()) error = "cannot close " + sink_tmp_path_;
     sink_fd_ = -1;
     sink_active_ = false;
@@ -1064,6 +1069,11 @@ void Engine::write_text_file(const std::string& path) {
 }
 
 void Engine::fetch_rows(int need) {
+    // the rows of a run that wrote them window by window and dropped them (set_text_sink over a text that fills the device,
+    // or the pieces of a sharded run) are in the file and nowhere else: say so instead of handing out null arrays
+    if (need && sink_discarded_ && !sink_written_path_.empty())
+        throw std::runtime_error("the rows of this run left the device window by window: they are in " + sink_written_path_ +
+                                 " (row arrays, the bytes, .bumbl and .thresh need a run that keeps them: no text sink, or MMT_SINK_DISCARD=0)");
     need &= rows_pending_;
     if (!need) return;
     MMT_HIP(hipSetDevice(device_));

@@ -178,7 +178,11 @@ public:
     // producers that stream; any other run writes the file at its end as before).  "" switches it off.
     // drop_rows: the rows of a window are forgotten once they are written whatever the size of the text (the ranks of a
     // sharded run write their pieces of PREFIX.mems this way: nothing is gathered, mumemto_exec --gpus N)
-    void set_text_sink(const std::string& path, bool drop_rows = false) { sink_path_ = path; sink_force_discard_ = drop_rows && !path.empty(); }
+    // keep_rows: never -- whatever the size of the text -- because the caller will ask for the rows afterwards (PREFIX.thresh /
+    // .thresh_rev are cut out of the threshold column row by row: mem_finder.hpp:116-157)
+    void set_text_sink(const std::string& path, bool drop_rows = false, bool keep_rows = false) {
+        sink_path_ = path; sink_force_discard_ = drop_rows && !path.empty(); sink_keep_rows_ = keep_rows;
+    }
     // PREFIX.mums / .mems of the last run straight to a file: the bytes leave HBM in pieces and every piece is written
     // while the next ones are still on their way (rows(ROWS_TEXT) + one write otherwise)
     void write_text_file(const std::string& path);
@@ -322,7 +326,7 @@ private:
     DevBuf<uint64_t> d_cap_cnt_, d_cap_off_;
     uint64_t pool_used_ = 0;
     // the text sink (set_text_sink)
-    bool sink_force_discard_ = false;
+    bool sink_force_discard_ = false, sink_keep_rows_ = false;
     struct SinkPiece { const char* p; size_t n; hipEvent_t ready; uint32_t block; };
     std::string sink_path_, sink_written_path_, sink_tmp_path_;
     bool sink_active_ = false, sink_mum_ = true, sink_discard_ = false, sink_discarded_ = false;

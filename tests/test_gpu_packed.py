@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+import mumemto_amd.binding
 import pyoracle as O
 from mumemto_amd import synth
 
@@ -150,6 +151,9 @@ def test_rows_written_window_by_window_and_dropped(producer, tmp_path):
             assert open(out, "rb").read() == want and want.count(b"\n") > 20
             assert eng.L.mmt_num_rows(eng.h) == want.count(b"\n")
             assert eng.stream_stats()["windows"] >= 4 and not os.path.exists(out + ".tmp")
+            # the rows left with their windows: the accessors say so (they used to hand out null arrays)
+            with pytest.raises(mumemto_amd.binding.MumemtoError, match="left the device window by window"):
+                eng.rows_mem() if name == "mems" else eng.rows_mum()
             # without the sink the same engine keeps its rows as before
             eng.set_docs(docs)
             eng.run(**kw)

@@ -80,6 +80,26 @@ MMT_API int mmt_abi_version(void);
 MMT_API int mmt_producer_used(const mmt_engine* e);
 MMT_API int mmt_producer_expanded(const mmt_engine* e);
 
+/* The row tap (test instrument of full-size runs that keep nothing else: tests/bigchecks.py check_bins_complete): every
+ * accepted interval of the NEXT runs whose match begins with one of the n k-mers (n x k bytes, k <= 16) leaves a copy of its
+ * length and of ALL its suffix-array entries (text positions) before its window drops it; n = 0 switches it off.
+ * mmt_row_tap_counts: out[0] rows, out[1] entries tapped by the last run; mmt_row_tap_get: length[rows], occ_start[rows + 1],
+ * sa[entries] (rows in no particular order; rc 3 when the capacities given here were exceeded).
+ * mmt_kmer_positions: every position of the resident text whose suffix begins with one of the k-mers, ascending, with the
+ * index of its k-mer; *found may exceed cap (only cap were written).  Together they give precision AND recall inside whole
+ * bins of leading characters: the host sorts those suffixes, runs the oracle's scan over them and compares.                */
+/* (bytes, digest) of what the last run's text sink wrote, in file order -- kept when the sink's path is "/dev/null" (the bytes
+ * are formatted, copied out, digested and dropped: a full-size test run whose rows nobody can keep) or MMT_SINK_DIGEST is set */
+MMT_API int mmt_text_sink_digest(const mmt_engine* e, uint64_t out[2]);
+/* 1 when the suffixes that begin with this k-mer belong to the share of the stream the last run of the bucket-wise producer
+ * produced (mmt_engine_set_scan_shard: whole bins of leading characters), 0 when not, -1 when that producer did not run */
+MMT_API int mmt_kmer_in_share(const mmt_engine* e, const uint8_t* kmer, size_t k);
+MMT_API int mmt_engine_set_row_tap(mmt_engine* e, const uint8_t* kmers, size_t n, size_t k, size_t max_rows, size_t max_occ);
+MMT_API int mmt_row_tap_counts(mmt_engine* e, uint64_t out[2]);
+MMT_API int mmt_row_tap_get(mmt_engine* e, uint32_t* length, uint64_t* occ_start, uint64_t* sa);
+MMT_API int mmt_kmer_positions(mmt_engine* e, const uint8_t* kmers, size_t n, size_t k, uint64_t* pos, uint32_t* which,
+                               uint64_t cap, uint64_t* found);
+
 /* One pass of the hot path: text -> SA/LCP/BWT -> scan -> rows (+ thresholds). */
 /* Stage checkpoints of the reference CLI (src/pfp_mum.cpp:97-111 `-a`, :122-124 `-p`): hand over the text T itself
  * (UPPER(F) '$' [revcomp(F) '$'] per document, n characters) or the stream of the real suffixes (sentinel entry

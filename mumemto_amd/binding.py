@@ -73,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
-    "mmt_engine_set_producer", "mmt_abi_version", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
+    "mmt_engine_set_producer", "mmt_abi_version", "mmt_engine_set_row_tap", "mmt_text_sink_digest", "mmt_kmer_in_share", "mmt_row_tap_counts", "mmt_row_tap_get", "mmt_kmer_positions", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
@@ -158,6 +158,13 @@ def load_library():
     L.mmt_engine_set_producer.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
     L.mmt_producer_used.argtypes = [C.c_void_p]
     L.mmt_producer_expanded.argtypes = [C.c_void_p]
+    L.mmt_text_sink_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mmt_kmer_in_share.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mmt_engine_set_row_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.mmt_row_tap_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mmt_row_tap_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mmt_kmer_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint64,
+                                     C.POINTER(C.c_uint64)]
     L.mmt_engine_parse_only.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint32]
     L.mmt_pfp_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]
@@ -423,6 +430,50 @@ class Engine:
 
     def producer_used(self):
         return {1: "direct", 2: "pfp", 3: "guided"}.get(self.L.mmt_producer_used(self.h), "?")
+
+    def text_sink_digest(self):
+        """(bytes, digest) of what the last run's text sink wrote (sink "/dev/null", or MMT_SINK_DIGEST set)"""
+        out = (C.c_uint64 * 2)()
+        _check(self.L.mmt_text_sink_digest(self.h, out))
+        return int(out[0]), int(out[1])
+
+    def kmer_in_share(self, kmer):
+        """True when the suffixes beginning with kmer belong to the share of the stream the last (sharded, bucket-wise) run produced"""
+        km = np.frombuffer(bytes(kmer), np.uint8).copy()
+        r = self.L.mmt_kmer_in_share(self.h, _p(km), len(km))
+        if r < 0:
+            raise MumemtoError("the bucket-wise producer did not run")
+        return bool(r)
+
+    def set_row_tap(self, kmers, max_rows=1 << 16, max_occ=1 << 24):
+        """kmers: list of equal-length byte strings (<= 16 characters), or [] to switch the tap off: the next runs copy every
+        accepted interval whose match begins with one of them (length + all its text positions) before its window goes"""
+        kmers = [bytes(k) for k in kmers]
+        k = len(kmers[0]) if kmers else 0
+        assert all(len(x) == k for x in kmers)
+        flat = np.frombuffer(b"".join(kmers), np.uint8).copy() if kmers else np.zeros(1, np.uint8)
+        _check(self.L.mmt_engine_set_row_tap(self.h, _p(flat), len(kmers), k, max_rows, max_occ))
+
+    def row_tap(self):
+        """(length[rows], occ_start[rows + 1], sa[entries]) of the rows the last run tapped, in no particular order"""
+        c = (C.c_uint64 * 2)()
+        _check(self.L.mmt_row_tap_counts(self.h, c))
+        rows, occ = int(c[0]), int(c[1])
+        length = np.zeros(max(rows, 1), np.uint32); start = np.zeros(rows + 1, np.uint64); sa = np.zeros(max(occ, 1), np.uint64)
+        _check(self.L.mmt_row_tap_get(self.h, _p(length), _p(start), _p(sa)))
+        return length[:rows], start, sa[:occ]
+
+    def kmer_positions(self, kmers, cap=1 << 22):
+        """(positions ascending, index of the k-mer each begins with) over the text resident on the device"""
+        kmers = [bytes(k) for k in kmers]
+        k = len(kmers[0])
+        flat = np.frombuffer(b"".join(kmers), np.uint8).copy()
+        pos = np.zeros(cap, np.uint64); which = np.zeros(cap, np.uint32)
+        found = C.c_uint64(0)
+        _check(self.L.mmt_kmer_positions(self.h, _p(flat), len(kmers), k, _p(pos), _p(which), cap, C.byref(found)))
+        if found.value > cap:
+            raise MumemtoError("%d positions begin with those k-mers: more than the %d asked for" % (found.value, cap))
+        return pos[:found.value], which[:found.value]
 
     def producer_expanded(self):
         """the bucket-wise producer sorted one representative per (distinct phrase, offset) and the emitter expanded them"""

@@ -538,6 +538,37 @@ int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p) {
     return 0;
 }
 int mmt_abi_version(void) { return 5; }
+int mmt_text_sink_digest(const mmt_engine* e, uint64_t out[2]) {
+    if (!e || !out) return fail(1, "null");
+    e->e->text_sink_digest(out);
+    return 0;
+}
+int mmt_kmer_in_share(const mmt_engine* e, const uint8_t* kmer, size_t k) { return e && kmer ? e->e->kmer_in_share(kmer, k) : -1; }
+int mmt_engine_set_row_tap(mmt_engine* e, const uint8_t* kmers, size_t n, size_t k, size_t max_rows, size_t max_occ) {
+    if (!e || (n && !kmers)) return fail(1, "engine and k-mers must be non-null");
+    MMT_TRY
+    e->e->set_row_tap(kmers, n, k, max_rows, max_occ);
+    MMT_CATCH
+}
+int mmt_row_tap_counts(mmt_engine* e, uint64_t out[2]) {
+    if (!e || !out) return fail(1, "null");
+    MMT_TRY
+    e->e->row_tap_counts(out);
+    MMT_CATCH
+}
+int mmt_row_tap_get(mmt_engine* e, uint32_t* length, uint64_t* occ_start, uint64_t* sa) {
+    if (!e || !length || !occ_start || !sa) return fail(1, "null");
+    MMT_TRY
+    e->e->row_tap_get(length, occ_start, sa);
+    MMT_CATCH
+}
+int mmt_kmer_positions(mmt_engine* e, const uint8_t* kmers, size_t n, size_t k, uint64_t* pos, uint32_t* which, uint64_t cap,
+                       uint64_t* found) {
+    if (!e || !kmers || !pos || !which || !found) return fail(1, "null");
+    MMT_TRY
+    *found = e->e->kmer_positions(kmers, n, k, pos, which, cap);
+    MMT_CATCH
+}
 int mmt_producer_used(const mmt_engine* e) { return e ? e->e->producer_used() : 0; }
 int mmt_producer_expanded(const mmt_engine* e) { return e && e->e->producer_expanded() ? 1 : 0; }
 int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p) {

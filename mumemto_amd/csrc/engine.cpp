@@ -617,10 +617,94 @@ bool Engine::scan_window(ScanState& S, const ColWindow& w, const mmt_params& p) 
         k::capture_rows(d_rows_.get() + S.rows_used, (uint32_t)fresh, d_cap_off_.get(), pool_used_, win, w.base, pool,
                         d_rows_pool_.get() + S.rows_used, st);
         pool_used_ += total;
-    }
+        if (!tap_kmers_.empty()) tap_window(d_rows_pool_.get() + S.rows_used, (uint32_t)fresh, pool);
+    } else if (fresh && !tap_kmers_.empty()) tap_window(d_rows_.get() + S.rows_used, (uint32_t)fresh, sa_col());
     ev.stop(st);
     S.rows_used = r;
     return true;
+}
+
+// ---- the row tap -----------------------------------------------------------------------------------------------------------
+static void pack_kmers(const uint8_t* kmers, size_t n, size_t k, std::vector<uint64_t>& out) {
+    if (k < 1 || k > 16) throw std::runtime_error("k-mers of 1 .. 16 characters");
+    out.assign(2 * n, 0);
+    for (size_t i = 0; i < n; i++)
+        for (size_t c = 0; c < k; c++) out[2 * i + c / 8] |= (uint64_t)kmers[i * k + c] << (8 * (c % 8));
+}
+void Engine::set_row_tap(const uint8_t* kmers, size_t n, size_t k, size_t max_rows, size_t max_occ) {
+    tap_kmers_.clear(); tap_k_ = 0; tap_cap_rows_ = tap_cap_occ_ = 0;
+    d_tap_off_.release(); d_tap_sa_.release(); d_tap_len_.release(); d_tap_cnt_.release();
+    if (!n) return;
+    pack_kmers(kmers, n, k, tap_kmers_);
+    tap_k_ = (uint32_t)k; tap_cap_rows_ = std::max<size_t>(max_rows, 1); tap_cap_occ_ = std::max<size_t>(max_occ, 1);
+}
+void Engine::tap_window(const k::Row* rows, uint32_t n_rows, SaCol pool) {
+    hipStream_t st = stream_;
+    if (!d_tap_len_.get()) {                    // first window of the run (Engine::run cleared the buffers)
+        d_tap_kmers_.ensure(tap_kmers_.size()); d_tap_used_.ensure(2);
+        d_tap_len_.ensure(tap_cap_rows_); d_tap_cnt_.ensure(tap_cap_rows_); d_tap_off_.ensure(tap_cap_rows_); d_tap_sa_.ensure(tap_cap_occ_);
+        MMT_HIP(hipMemcpyAsync(d_tap_kmers_.get(), tap_kmers_.data(), tap_kmers_.size() * 8, hipMemcpyHostToDevice, st));
+        MMT_HIP(hipMemsetAsync(d_tap_used_.get(), 0, 16, st));
+    }
+    rk::tap_rows(rows, n_rows, pool, text_ref(), d_tap_kmers_.get(), (uint32_t)(tap_kmers_.size() / 2), tap_k_, d_tap_len_.get(),
+                 d_tap_off_.get(), d_tap_cnt_.get(), d_tap_sa_.get(), d_tap_used_.get(), tap_cap_rows_, tap_cap_occ_, st);
+}
+void Engine::row_tap_counts(uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    if (!d_tap_len_.get()) return;
+    MMT_HIP(hipSetDevice(device_));
+    MMT_HIP(hipMemcpyAsync(out, d_tap_used_.get(), 16, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+}
+void Engine::row_tap_get(uint32_t* length, uint64_t* occ_start, uint64_t* sa) {
+    uint64_t used[2];
+    row_tap_counts(used);
+    if (used[0] > tap_cap_rows_ || used[1] > tap_cap_occ_)
+        throw std::runtime_error("the row tap overflowed: " + std::to_string(used[0]) + " rows, " + std::to_string(used[1]) + " entries");
+    occ_start[0] = 0;
+    if (!used[0]) return;
+    std::vector<uint64_t> off(used[0]), all(used[1]);
+    std::vector<uint32_t> cnt(used[0]), len(used[0]);
+    MMT_HIP(hipMemcpyAsync(len.data(), d_tap_len_.get(), used[0] * 4, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipMemcpyAsync(cnt.data(), d_tap_cnt_.get(), used[0] * 4, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipMemcpyAsync(off.data(), d_tap_off_.get(), used[0] * 8, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipMemcpyAsync(all.data(), d_tap_sa_.get(), used[1] * 8, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    uint64_t at = 0;                             // (slots were handed out by atomics: compact in slot order)
+    for (uint64_t r = 0; r < used[0]; r++) {
+        length[r] = len[r];
+        std::memcpy(sa + at, all.data() + off[r], (size_t)cnt[r] * 8);
+        at += cnt[r];
+        occ_start[r + 1] = at;
+    }
+}
+uint64_t Engine::kmer_positions(const uint8_t* kmers, size_t n, size_t k, uint64_t* pos, uint32_t* which, uint64_t cap) {
+    if (!have_text()) throw std::runtime_error("no text on the device");
+    MMT_HIP(hipSetDevice(device_));
+    std::vector<uint64_t> packed;
+    pack_kmers(kmers, n, k, packed);
+    DevBuf<uint64_t> d_k, d_pos, d_used;
+    DevBuf<uint32_t> d_which;
+    d_k.ensure(packed.size()); d_pos.ensure(std::max<uint64_t>(cap, 1)); d_which.ensure(std::max<uint64_t>(cap, 1)); d_used.ensure(2);
+    MMT_HIP(hipMemcpyAsync(d_k.get(), packed.data(), packed.size() * 8, hipMemcpyHostToDevice, stream_));
+    MMT_HIP(hipMemsetAsync(d_used.get(), 0, 16, stream_));
+    rk::kmer_positions(text_ref(), d_k.get(), (uint32_t)n, (uint32_t)k, d_pos.get(), d_which.get(), d_used.get(), cap, stream_);
+    uint64_t found = 0;
+    MMT_HIP(hipMemcpyAsync(&found, d_used.get(), 8, hipMemcpyDeviceToHost, stream_));
+    MMT_HIP(hipStreamSynchronize(stream_));
+    const uint64_t got = std::min(found, cap);
+    std::vector<uint64_t> hp(got);
+    std::vector<uint32_t> hw(got);
+    if (got) {
+        MMT_HIP(hipMemcpyAsync(hp.data(), d_pos.get(), got * 8, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipMemcpyAsync(hw.data(), d_which.get(), got * 4, hipMemcpyDeviceToHost, stream_));
+        MMT_HIP(hipStreamSynchronize(stream_));
+    }
+    std::vector<uint64_t> order(got);
+    for (uint64_t i = 0; i < got; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return hp[a] < hp[b]; });
+    for (uint64_t i = 0; i < got; i++) { pos[i] = hp[order[i]]; which[i] = hw[order[i]]; }
+    return found;
 }
 
 void Engine::scan_end(ScanState& S) {
@@ -758,8 +842,13 @@ void Engine::sink_open(bool mum_mode) {
     if (!mum_mode && !sink_discard_) return;          // (a MEM run that keeps its rows writes its file at the end, as before)
     // the bytes go to PREFIX.mums.tmp and take the final name when the run has succeeded (sink_close): a run that fails
     // after some windows -- out of memory, a consistency check at the end -- must not leave a plausible partial PREFIX.mums
-    sink_tmp_path_ = sink_path_ + ".tmp";
-    sink_fd_ = ::open(sink_tmp_path_.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    // ("/dev/null": the bytes are formatted, copied out, digested and dropped -- a full-size test run whose 66 GB of rows the
+    // box has no room for)
+    sink_null_ = sink_path_ == "/dev/null";
+    sink_tmp_path_ = sink_null_ ? sink_path_ : sink_path_ + ".tmp";
+    sink_digest_ = StreamDigest(); sink_written_ = 0; sink_digest_value_ = 0;
+    sink_want_digest_ = std::getenv("MMT_SINK_DIGEST") != nullptr;
+    sink_fd_ = ::open(sink_tmp_path_.c_str(), sink_null_ ? O_WRONLY : (O_CREAT | O_TRUNC | O_WRONLY), 0644);
     if (sink_fd_ < 0) throw std::runtime_error("cannot write " + sink_tmp_path_);
     sink_rows_done_ = 0; sink_bytes_ = 0; sink_block_at_ = 0; sink_block_used_ = 0;
     sink_block_pending_.assign(sink_blocks_.size(), 0);
@@ -791,6 +880,11 @@ void Engine::sink_open(bool mum_mode) {
                 if (w <= 0) { fail_with("short write to " + sink_tmp_path_); break; }
                 done += (size_t)w;
             }
+            // a running digest of the bytes in file order (this one thread writes the pieces in order; whole words are carried
+            // across piece boundaries, which fall where windows end and differ from box to box): what two runs of a file
+            // nobody can keep are compared by
+            if (sink_null_ || sink_want_digest_) sink_digest_.update(pc.p, pc.n);
+            { std::lock_guard<std::mutex> lk(sink_mu_); sink_written_ += pc.n; }
             { std::lock_guard<std::mutex> lk(sink_mu_); sink_block_pending_[pc.block]--; }
             sink_cv_.notify_all();
         }
@@ -934,8 +1028,9 @@ void Engine::sink_close(bool ok) {
     sink_fd_ = -1;
     sink_active_ = false;
     if (error.empty() && !ok) error = "the run failed";
-    if (error.empty() && std::rename(sink_tmp_path_.c_str(), sink_path_.c_str()) != 0) error = "cannot rename " + sink_tmp_path_;
-    if (!error.empty()) { ::unlink(sink_tmp_path_.c_str()); throw std::runtime_error(error); }
+    if (error.empty() && !sink_null_ && std::rename(sink_tmp_path_.c_str(), sink_path_.c_str()) != 0) error = "cannot rename " + sink_tmp_path_;
+    if (!error.empty()) { if (!sink_null_) ::unlink(sink_tmp_path_.c_str()); throw std::runtime_error(error); }
+    sink_digest_value_ = sink_digest_.final();
     sink_written_path_ = sink_path_;
     sink_discarded_ = sink_discard_;
 }
@@ -1170,6 +1265,7 @@ void Engine::run(const mmt_params& p) {
     for (float& f : stage_ms_) f = 0.f;
     for (float& f : scan_ms_) f = 0.f;
     merged_thresh_valid_ = false;
+    d_tap_len_.release(); d_tap_cnt_.release(); d_tap_off_.release(); d_tap_sa_.release();      // (the tap of the run before)
     sink_written_path_.clear();
     sink_discarded_ = false;
     lcp_col_ready_ = false;

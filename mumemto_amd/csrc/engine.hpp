@@ -2,6 +2,7 @@
 #pragma once
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -185,7 +186,21 @@ public:
     }
     // PREFIX.mums / .mems of the last run straight to a file: the bytes leave HBM in pieces and every piece is written
     // while the next ones are still on their way (rows(ROWS_TEXT) + one write otherwise)
+    int kmer_in_share(const uint8_t* kmer, size_t k) const;        // (guided.cpp)
+    // (bytes written, digest of those bytes in file order) of the last run's sink; the digest is kept when the sink is
+    // "/dev/null" -- a test run whose rows nobody can keep -- or MMT_SINK_DIGEST is set
+    void text_sink_digest(uint64_t out[2]) const { out[0] = sink_written_; out[1] = sink_digest_value_; }
     void write_text_file(const std::string& path);
+    // The row tap (tests/bigchecks.py check_bins_complete): every accepted interval of the NEXT runs whose match begins with
+    // one of the given k-mers (k <= 16 characters each) leaves a copy of its length and all its suffix-array entries before
+    // its window drops it -- what a full-size run that keeps nothing else can still be asked.  n = 0 switches it off.
+    void set_row_tap(const uint8_t* kmers, size_t n, size_t k, size_t max_rows, size_t max_occ);
+    // (rows, entries) the last run tapped; the copies: length[rows], occ_start[rows + 1], sa[entries] (rows in no particular order)
+    void row_tap_counts(uint64_t out[2]);
+    void row_tap_get(uint32_t* length, uint64_t* occ_start, uint64_t* sa);
+    // every text position of the resident text whose suffix begins with one of the k-mers: (position, which k-mer), ascending
+    // by position; returns the number found (may exceed cap: then only cap were written)
+    uint64_t kmer_positions(const uint8_t* kmers, size_t n, size_t k, uint64_t* pos, uint32_t* which, uint64_t cap);
     const std::string& bumbl();
     // PREFIX.thresh / PREFIX.thresh_rev contents (mem_finder.hpp:116-157); needs a merge_metadata MUM run
     void thresh_files(std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev);
@@ -325,8 +340,32 @@ private:
     DevBuf<k::Row> d_rows_pool_;
     DevBuf<uint64_t> d_cap_cnt_, d_cap_off_;
     uint64_t pool_used_ = 0;
+    // digest of a byte stream that arrives in pieces of any size (the text sink's bytes in file order)
+    struct StreamDigest {
+        uint64_t h = 0x6d756d656d746f35ull;
+        uint8_t carry[8];
+        uint32_t have = 0;
+        void word(uint64_t w) { h = (h ^ w) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+        void update(const char* p, size_t n) {
+            size_t i = 0;
+            while (have && have < 8 && i < n) carry[have++] = (uint8_t)p[i++];
+            if (have == 8) { uint64_t w; std::memcpy(&w, carry, 8); word(w); have = 0; }
+            for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); word(w); }
+            for (; i < n; i++) carry[have++] = (uint8_t)p[i];
+        }
+        uint64_t final() const { uint64_t x = h; for (uint32_t i = 0; i < have; i++) x = (x ^ carry[i]) * 0x100000001b3ull; return x ^ (x >> 31); }
+    };
+    // the row tap (set_row_tap)
+    std::vector<uint64_t> tap_kmers_;            // 2 words per k-mer
+    uint32_t tap_k_ = 0;
+    uint64_t tap_cap_rows_ = 0, tap_cap_occ_ = 0;
+    DevBuf<uint64_t> d_tap_kmers_, d_tap_off_, d_tap_sa_, d_tap_used_;
+    DevBuf<uint32_t> d_tap_len_, d_tap_cnt_;
+    void tap_window(const k::Row* rows, uint32_t n_rows, SaCol pool);
     // the text sink (set_text_sink)
-    bool sink_force_discard_ = false, sink_keep_rows_ = false;
+    bool sink_force_discard_ = false, sink_keep_rows_ = false, sink_null_ = false, sink_want_digest_ = false;
+    StreamDigest sink_digest_;
+    uint64_t sink_digest_value_ = 0, sink_written_ = 0;
     struct SinkPiece { const char* p; size_t n; hipEvent_t ready; uint32_t block; };
     std::string sink_path_, sink_written_path_, sink_tmp_path_;
     bool sink_active_ = false, sink_mum_ = true, sink_discard_ = false, sink_discarded_ = false;

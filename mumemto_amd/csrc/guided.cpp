@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -221,6 +222,7 @@ void Engine::guided_prepare() {
     S.g_prefix = prefix_chars;
     d_code_.ensure(256);
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
+    std::memcpy(S.g_code, code, 256); S.g_bits = ctx.bits; S.g_share_valid = false;
     ctx.T = text_ref(); ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
 
     // ---- phrase ends: rank directory and successor table over the cut bits ----
@@ -505,6 +507,15 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
                      nG, nd, rounds, nO);
 }
 
+// does the share of the stream the last run produced hold the suffixes that begin with this k-mer?  (tests: bigchecks.py)
+int Engine::kmer_in_share(const uint8_t* kmer, size_t k) const {
+    const PfpState& S = *pfp_;
+    if (!S.guided || !S.g_share_valid || (size_t)S.g_prefix > k) return -1;
+    uint32_t bin = 0;
+    for (int c = 0; c < S.g_prefix; c++) bin = (bin << S.g_bits) | S.g_code[kmer[c]];
+    return bin >= S.g_share_lo && bin < S.g_share_hi ? 1 : 0;
+}
+
 void Engine::guided_check_errors(const char* what) {
     PfpState& S = *pfp_;
     uint32_t e2[3];
@@ -558,6 +569,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     sort_pieces_.clear();
     for (uint32_t q = 0; q < shard_count_; q++) sort_pieces_.emplace_back(pre[cut[q]], pre[cut[q + 1]] - pre[cut[q]]);
     const uint32_t bin_lo = cut[shard_index_], bin_hi = cut[shard_index_ + 1];
+    S.g_share_lo = bin_lo; S.g_share_hi = bin_hi; S.g_share_valid = true;
     if (shard_count_ > 1 && p.merge_metadata)
         throw std::runtime_error("merge metadata needs the whole stream on one rank (partition the documents instead)");
 
@@ -804,6 +816,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     sort_pieces_.clear();
     for (uint32_t q = 0; q < shard_count_; q++) sort_pieces_.emplace_back(pre[cut[q]], pre[cut[q + 1]] - pre[cut[q]]);
     const uint32_t bin_lo = cut[shard_index_], bin_hi = cut[shard_index_ + 1];
+    S.g_share_lo = bin_lo; S.g_share_hi = bin_hi; S.g_share_valid = true;
     if (shard_count_ > 1 && p.merge_metadata)
         throw std::runtime_error("merge metadata needs the whole stream on one rank (partition the documents instead)");
 

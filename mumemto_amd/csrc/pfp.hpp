@@ -64,6 +64,11 @@ struct PfpState {
     DevBuf<uint32_t> g_repbits;                   // bit k: phrase k is the representative occurrence of its distinct phrase
     int g_prefix = 0;
     uint32_t g_nbins = 0;
+    // the bins the last stream of this producer took (a rank's share: Engine::set_scan_shard), and the symbol codes they are made of
+    uint32_t g_share_lo = 0, g_share_hi = 0;
+    int g_bits = 0;
+    uint8_t g_code[256] = {0};
+    bool g_share_valid = false;
     // giant phrases of the bucket-wise producer (guided.cpp::build_giant; gk::Ctx::g_*)
     DevBuf<uint32_t> gi_k, gi_base, gi_isa, gi_grp, gi_lcp, gi_bmin, gi_bits;
     DevBuf<uint64_t> gi_ps;

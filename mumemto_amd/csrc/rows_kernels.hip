@@ -7,11 +7,13 @@
 // prefix sums place rows and bytes, a "write" pass emits them.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 
 #include "device_utils.hpp"
 #include "rows_kernels.hpp"
+#include "textref.hpp"
 
 namespace mmt { namespace rk {
 
@@ -333,6 +335,77 @@ __global__ void k_widen(const uint32_t* __restrict__ in, uint32_t n, uint64_t* _
 void widen(const uint32_t* in, uint32_t n, uint64_t* out, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_widen, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, out);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- the row tap (tests: precision AND recall inside whole bins of a full-size run) ----------------------------------------
+// Every accepted interval whose match begins with one of a few given k-mers is copied out -- length and all suffix-array
+// entries -- before its window drops it.  kmers: n_kmers x 2 words, the k <= 16 characters little-endian as tx_load8 reads them
+// (second word zero beyond 8 characters).  One work-item per fresh row: it reads the text at the row's first occurrence.
+__device__ __forceinline__ int tap_match(const TextRef& T, uint64_t pos, const uint64_t* __restrict__ kmers, uint32_t n_kmers, uint32_t k) {
+    if (pos + k > T.n) return -1;
+    uint64_t a = tx_load8(T, pos + 1), b = k > 8 ? tx_load8(T, pos + 9) : 0ull;       // V index = text position + 1
+    if (k < 8) a &= (1ull << (8 * k)) - 1ull;
+    if (k > 8 && k < 16) b &= (1ull << (8 * (k - 8))) - 1ull;
+    for (uint32_t i = 0; i < n_kmers; i++)
+        if (kmers[2 * i] == a && kmers[2 * i + 1] == b) return (int)i;
+    return -1;
+}
+template <typename SA>
+__global__ void k_tap_rows(const k::Row* __restrict__ rows, uint32_t n_rows, SA pool, TextRef T, const uint64_t* __restrict__ kmers,
+                           uint32_t n_kmers, uint32_t k, uint32_t* __restrict__ t_len, uint64_t* __restrict__ t_off,
+                           uint32_t* __restrict__ t_cnt, uint64_t* __restrict__ t_sa, unsigned long long* __restrict__ used,
+                           uint64_t cap_rows, uint64_t cap_occ) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const k::Row row = rows[r];
+    if (row.len < k || !row.cnt) return;
+    const uint64_t first = (uint64_t)pool.get(row.start);
+    if (tap_match(T, first, kmers, n_kmers, k) < 0) return;
+    const unsigned long long slot = atomicAdd(used, 1ull);
+    const unsigned long long off = atomicAdd(used + 1, (unsigned long long)row.cnt);
+    if (slot >= cap_rows || off + row.cnt > cap_occ) return;       // (counted: the caller sees used > capacity)
+    t_len[slot] = row.len; t_off[slot] = off; t_cnt[slot] = row.cnt;
+    for (uint32_t i = 0; i < row.cnt; i++) t_sa[off + i] = (uint64_t)pool.get(row.start + i);
+}
+void tap_rows(const k::Row* rows, uint32_t n_rows, SaCol pool, const TextRef& T, const uint64_t* kmers, uint32_t n_kmers, uint32_t k,
+              uint32_t* t_len, uint64_t* t_off, uint32_t* t_cnt, uint64_t* t_sa, uint64_t* used, uint64_t cap_rows, uint64_t cap_occ,
+              hipStream_t s) {
+    if (!n_rows) return;
+    const unsigned grid = (n_rows + 255) / 256;
+    if (pool.wide())
+        hipLaunchKernelGGL(k_tap_rows<Sa40>, dim3(grid), dim3(256), 0, s, rows, n_rows, Sa40(pool), T, kmers, n_kmers, k, t_len, t_off,
+                           t_cnt, t_sa, reinterpret_cast<unsigned long long*>(used), cap_rows, cap_occ);
+    else
+        hipLaunchKernelGGL(k_tap_rows<Sa32>, dim3(grid), dim3(256), 0, s, rows, n_rows, Sa32(pool), T, kmers, n_kmers, k, t_len, t_off,
+                           t_cnt, t_sa, reinterpret_cast<unsigned long long*>(used), cap_rows, cap_occ);
+    MMT_HIP(hipGetLastError());
+}
+// every text position whose suffix begins with one of the k-mers: (position, which k-mer), in no particular order; 16 positions
+// per work-item, slices of 2^28 work-items (a launch may not have 2^32)
+__global__ void k_kmer_positions(TextRef T, uint64_t first, uint64_t n_items, const uint64_t* __restrict__ kmers, uint32_t n_kmers,
+                                 uint32_t k, uint64_t* __restrict__ out_pos, uint32_t* __restrict__ out_which,
+                                 unsigned long long* __restrict__ used, uint64_t cap) {
+    const uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= n_items) return;
+    const uint64_t p0 = (first + it) * 16;
+    for (uint32_t q = 0; q < 16; q++) {
+        const uint64_t p = p0 + q;
+        if (p >= T.n) break;
+        const int w = tap_match(T, p, kmers, n_kmers, k);
+        if (w < 0) continue;
+        const unsigned long long at = atomicAdd(used, 1ull);
+        if (at < cap) { out_pos[at] = p; out_which[at] = (uint32_t)w; }
+    }
+}
+void kmer_positions(const TextRef& T, const uint64_t* kmers, uint32_t n_kmers, uint32_t k, uint64_t* out_pos, uint32_t* out_which,
+                    uint64_t* used, uint64_t cap, hipStream_t s) {
+    const uint64_t items = (T.n + 15) / 16, SLICE = 1ull << 28;
+    for (uint64_t f = 0; f < items; f += SLICE) {
+        const uint64_t cnt = std::min<uint64_t>(SLICE, items - f);
+        hipLaunchKernelGGL(k_kmer_positions, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, T, f, cnt, kmers, n_kmers, k, out_pos,
+                           out_which, reinterpret_cast<unsigned long long*>(used), cap);
+    }
     MMT_HIP(hipGetLastError());
 }
 

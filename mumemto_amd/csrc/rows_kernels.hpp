@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "kernels.hpp"
+#include "textref.hpp"
 
 namespace mmt { namespace rk {
 
@@ -36,5 +37,14 @@ void mem_write(const RowArgs& a, const uint64_t* occ_off, const uint64_t* text_o
                const uint32_t* w_doc, uint32_t* out_len, int64_t* out_off, uint64_t* out_doc, uint8_t* out_st,
                char* text, hipStream_t s);
 void widen(const uint32_t* in, uint32_t n, uint64_t* out, hipStream_t s);
+// The row tap (Engine::set_row_tap): rows (pool-indexed, fresh from a window) whose match begins with one of n_kmers k-mers
+// (2 words each, as tx_load8 reads their characters) leave a copy -- length, offset and count of their suffix-array entries in
+// t_sa -- at slots taken from used[0] (rows) / used[1] (entries); nothing is written beyond the capacities, the counters go on.
+void tap_rows(const k::Row* rows, uint32_t n_rows, SaCol pool, const TextRef& T, const uint64_t* kmers, uint32_t n_kmers, uint32_t k,
+              uint32_t* t_len, uint64_t* t_off, uint32_t* t_cnt, uint64_t* t_sa, uint64_t* used, uint64_t cap_rows, uint64_t cap_occ,
+              hipStream_t s);
+// every text position whose suffix begins with one of the k-mers (position, which), unordered; used[0] counts them
+void kmer_positions(const TextRef& T, const uint64_t* kmers, uint32_t n_kmers, uint32_t k, uint64_t* out_pos, uint32_t* out_which,
+                    uint64_t* used, uint64_t cap, hipStream_t s);
 
 }}  // namespace mmt::rk

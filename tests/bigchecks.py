@@ -337,3 +337,76 @@ def check_mems_file(path, text, lens, min_docs, max_doc_freq, samples=200, seed=
             assert len(lefts) > 1 and len(rights) > 1, ("row is not maximal", line[:80])
     assert checked > 0
     print("file: %d bytes; %d sampled rows of %d are real, maximal matches in at least %d documents" % (size, checked, rows_seen, min_docs), flush=True)
+
+
+def _text_piece(text, a, b, n):
+    """text[a:b] as numpy uint8, zeros beyond the text (numpy arrays and LazyText alike)"""
+    out = np.zeros(b - a, np.uint8)
+    hi = min(b, n)
+    if hi > a:
+        out[:hi - a] = np.asarray(text[a:hi], np.uint8)
+    return out
+
+
+def check_bins_complete(eng, text, n_text, doc_start, kmers, min_len=20, num_distinct=0, max_doc_freq=1, max_total_freq=0,
+                        revcomp=True):
+    """PRECISION AND RECALL inside whole bins of a run of any size.  `eng` ran with eng.set_row_tap(kmers): every interval it
+    accepted whose match begins with one of the k-mers left a copy (length + all its text positions).  Here, per k-mer: the GPU
+    lists every text position whose suffix begins with it (eng.kmer_positions over the resident text), the host spells those
+    suffixes from `text` (a numpy array or a LazyText over the generator's model), sorts them, computes LCP / BWT / document of
+    each -- a piece of the stream: every interval with an LCP value >= len(kmer) that touches the bin lies inside it -- and runs
+    the ORACLE's scan (mmo_scan: the restatement of mem_finder.hpp:161-170,304-355) over that piece with a closing entry behind
+    it; the intervals it reports must be exactly the tapped ones.  Returns (bins, suffixes, rows) checked."""
+    import pyoracle as O
+    kmers = [bytes(k) for k in kmers]
+    k = len(kmers[0])
+    assert k <= min_len, "a bin's prefix must not be longer than the shortest reportable match"
+    t_len, t_start, t_sa = eng.row_tap()
+    got = {}
+    for r in range(len(t_len)):
+        occ = np.sort(t_sa[int(t_start[r]):int(t_start[r + 1])].astype(np.int64))
+        first = _text_piece(text, int(occ[0]), int(occ[0]) + k, n_text).tobytes()
+        got.setdefault(first, set()).add((int(t_len[r]), tuple(int(x) for x in occ)))
+    pos, which = eng.kmer_positions(kmers)
+    doc_start = np.ascontiguousarray(doc_start, np.int64)
+    suffixes = rows = 0
+    for i, km in enumerate(kmers):
+        P = pos[which == i].astype(np.int64)
+        want = set()
+        if len(P):
+            step = 512
+            while True:
+                strs = [_text_piece(text, int(p), int(p) + step, n_text) for p in P]
+                order = sorted(range(len(P)), key=lambda j: strs[j].tobytes())
+                lcp = np.zeros(len(P) + 1, np.int64)
+                again = False
+                for a in range(1, len(P)):
+                    x, y = strs[order[a - 1]], strs[order[a]]
+                    neq = np.nonzero(x != y)[0]
+                    l = int(neq[0]) if len(neq) else step
+                    # (the end of the text is a unique, smallest sentinel: two suffixes never agree beyond it)
+                    l = min(l, n_text - int(P[order[a - 1]]), n_text - int(P[order[a]]))
+                    if l >= step:
+                        again = True
+                        break
+                    lcp[a] = l
+                if not again:
+                    break
+                step *= 4
+            sa = np.zeros(len(P) + 1, np.int64)
+            sa[:len(P)] = P[order]
+            bwt = np.zeros(len(P) + 1, np.uint8)
+            for a in range(len(P)):
+                bwt[a] = _text_piece(text, int(sa[a]) - 1, int(sa[a]), n_text)[0] if sa[a] > 0 else 0
+            # the closing entry: some suffix of another bin (LCP 0 with everything here)
+            res = O.scan(sa, lcp, bwt, doc_start, min_len=min_len, num_distinct=num_distinct, max_doc_freq=max_doc_freq,
+                         max_total_freq=max_total_freq, revcomp=revcomp)
+            for s, e, l, _j in res.intervals():
+                want.add((int(l), tuple(sorted(int(x) for x in sa[int(s):int(e) + 1]))))
+        have = got.pop(km, set())
+        missing, extra = want - have, have - want
+        assert not missing and not extra, ("bin %r: %d positions, %d rows expected, %d tapped; missing %s; not expected %s"
+                                           % (km, len(P), len(want), len(have), sorted(missing)[:2], sorted(extra)[:2]))
+        suffixes += len(P); rows += len(want)
+    assert not got, "tapped rows that begin with none of the k-mers: %r" % list(got)[:3]
+    return len(kmers), suffixes, rows

@@ -646,7 +646,7 @@ class Engine:
         return list(out)
 
     # anchor merge
-    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20, text_file=None, slices=0):
+    def anchor_merge(self, parts, sort_like_direct=False, want_rows=True, min_len=20, text_file=None, slices=0, want_text=True):
         """parts: list of DevicePartition, or of (length u32[n], offsets i64[n,nd], strands u8[n,nd], thresh)
         where thresh is a numpy u16 array (host) or a device address paired as (ptr, length).
         want_rows=False returns only the PREFIX.mums bytes (no D2H of the tables); text_file: the library writes them
@@ -687,6 +687,8 @@ class Engine:
             if text_file is not None:
                 _check(self.L.mmt_merged_write_text(m, os.fsencode(text_file)))
                 text = None
+            elif not want_text:
+                text = None
             else:
                 k = C.c_size_t()
                 ptr = self.L.mmt_merged_text(m, C.byref(k))
@@ -700,7 +702,7 @@ class Engine:
             st = np.zeros((max(n, 1), nd), np.uint8)
             th = np.zeros(int(arr[0].thresh_len), np.uint16)
             _check(self.L.mmt_merged_get(m, _p(length), _p(off), _p(st), _p(th)))
-            return dict(lengths=length[:n], offsets=off[:n], strands=st[:n], thresh=th, text=text)
+            return dict(lengths=length[:n], offsets=off[:n], strands=st[:n], thresh=th, text=text, n_rows=n, n_docs=nd)
         finally:
             self.L.mmt_merged_free(m)
 

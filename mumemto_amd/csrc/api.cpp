@@ -488,7 +488,10 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
     e->e->set_stream_host40(sa_lo, sa_hi, lcp, bwt, entries, doc_len, n_docs, use_revcomp != 0);
     MMT_CATCH
 }
-void mmt_pool_trim(void) { mmt::pool::trim(); }
+void mmt_pool_trim(void) {
+    try { mmt::merge_release_scratch(); } catch (...) {}
+    mmt::pool::trim();
+}
 int mmt_engine_set_text_sink(mmt_engine* e, const char* path) {
     if (!e) return fail(1, "null");
     MMT_TRY

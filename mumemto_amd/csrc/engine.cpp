@@ -441,6 +441,10 @@ void Engine::release_sort_scratch() {
     fresh->rounds_parse = S.rounds_parse; fresh->n_entries = S.n_entries; fresh->n_fallback = S.n_fallback;
     fresh->emit_launches = S.emit_launches;
     fresh->bwt_ready = S.bwt_ready;
+    // (what the bucket-wise producer's share was: Engine::kmer_in_share answers after the run)
+    fresh->guided = S.guided; fresh->expand = S.expand; fresh->g_prefix = S.g_prefix; fresh->g_bits = S.g_bits;
+    fresh->g_share_lo = S.g_share_lo; fresh->g_share_hi = S.g_share_hi; fresh->g_share_valid = S.g_share_valid;
+    std::memcpy(fresh->g_code, S.g_code, sizeof(S.g_code));
     std::memcpy(fresh->ms, S.ms, sizeof(S.ms));
     pfp_ = std::move(fresh);
 }

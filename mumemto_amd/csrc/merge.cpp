@@ -75,16 +75,41 @@ struct MergeScratch {
 // one scratch set per device and host thread (an engine on another GPU must not reuse buffers that live on the first one,
 // and two engines on one GPU that merge from different threads must not share them); the sets are leaked on purpose: a
 // static destructor would run after the HIP runtime has gone
-MergeScratch& scratch(int device) {
-    static std::mutex mu;
+std::mutex& scratch_mutex() { static std::mutex mu; return mu; }
+std::map<std::pair<int, std::thread::id>, MergeScratch*>& scratch_sets() {
     static auto* sets = new std::map<std::pair<int, std::thread::id>, MergeScratch*>();
-    std::lock_guard<std::mutex> lock(mu);
-    MergeScratch*& s = (*sets)[std::make_pair(device, std::this_thread::get_id())];
+    return *sets;
+}
+MergeScratch& scratch(int device) {
+    std::lock_guard<std::mutex> lock(scratch_mutex());
+    MergeScratch*& s = scratch_sets()[std::make_pair(device, std::this_thread::get_id())];
     if (!s) s = new MergeScratch();
     return *s;
 }
 
 }  // namespace
+
+// The fold's scratch back to the device heap (mmt_pool_trim: a long-lived process between two jobs).  A fold at the length of a
+// human chromosome set leaves tens of GB here, scattered over the heap: the next job's 137 GB text then found no room in a
+// heap of 235 GB with 6 GB live.  Nobody may be folding while this runs.
+void merge_release_scratch() {
+    std::lock_guard<std::mutex> lock(scratch_mutex());
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : scratch_sets()) {
+        MergeScratch* M = kv.second;
+        if (!M) continue;
+        (void)hipSetDevice(kv.first.first);
+        for (DevBuf<uint32_t>* b : {&M->nb_left, &M->nb_right, &M->nb_out, &M->d_ra, &M->d_rb, &M->d_len, &M->d_count, &M->vals_a, &M->vals_b,
+                                    &M->d_colpart, &M->left.len, &M->left.src, &M->right.len, &M->right.src, &M->out.len, &M->out.src})
+            b->release();
+        for (DevBuf<uint64_t>* b : {&M->d_pos, &M->keys_a, &M->keys_b, &M->left.start, &M->right.start, &M->out.start}) b->release();
+        for (DevBuf<int64_t>* b : {&M->left.plus, &M->left.minus, &M->right.plus, &M->right.minus, &M->out.plus, &M->out.minus}) b->release();
+        M->narrow.release(); M->ia.bv.release(); M->ib.bv.release(); M->d_parts.release();
+        M->uploads.clear();
+    }
+    (void)hipSetDevice(cur);
+}
 
 MergedRows anchor_merge(Engine& e, const mmt_partition* parts, size_t k, uint32_t min_len) {
     const bool dbg = std::getenv("MMT_MERGE_DEBUG") != nullptr;

@@ -40,4 +40,7 @@ const char* stage_merged_text(Engine& e, const MergedRows& m, size_t* bytes);
 // host copies of the rows and thresholds (m.length / m.offsets / m.strands / m.thresh)
 void download_merged(Engine& e, MergedRows& m);
 
+// the fold's device scratch (kept between calls) back to the heap: mmt_pool_trim
+void merge_release_scratch();
+
 }  // namespace mmt

@@ -215,35 +215,162 @@ def test_thirty_g_characters_as_one_streamed_run():
     bigchecks.check_mum_rows(eng, bases, lens)
 
 
-def test_a_rank_share_of_configs3_anchor_and_twelve_whole_genome_haplotypes():
-    """BASELINE configs[3] on eight GPUs gives rank 0 {anchor + 12} x 3.05 Gbp = 79.3 G text characters: ONE streamed run
-    with merge metadata (rows in anchor coordinates, u16 thresholds over the anchor, suffix ranks of the anchor for the
-    re-sort), as `tests/big_c4.py` runs all eight shares and folds them (profiles/round4_c4_full.log: 41.8 M merged rows
-    x 94 columns, 49.7 GB of PREFIX.mums).  Checked by properties: sampled rows are real, maximal, one-per-document matches
-    in lexicographic order; every sampled row's threshold sits at its anchor position and is shorter than the row."""
+def _kmers_of(seq, k, count, seed, prefixes=None):
+    """`count` distinct k-mers spelled at random places of the ASCII sequence `seq` (optionally: beginning with one of `prefixes`)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < count:
+        p = int(rng.integers(0, len(seq) - k))
+        km = bytes(seq[p:p + k])
+        if km in out or (prefixes and not km.startswith(tuple(prefixes))):
+            continue
+        out.append(km)
+    return out
+
+
+def test_two_rank_shares_of_configs3_and_their_fold_at_the_anchors_length():
+    """BASELINE configs[3] on eight GPUs gives rank r {anchor + 12 (11)} x 3.05 Gbp = 79.3 G text characters: ONE streamed run
+    with merge metadata (rows in anchor coordinates, 32-bit thresholds over the anchor, suffix ranks of the anchor for the
+    re-sort), as `tests/big_c4.py` runs all eight shares and folds them (profiles/round5_*_c4_full.log).  Here the shares of
+    ranks 0 and 1 run at their size, and their rows + thresholds are folded in eight slices at L0 = 3.05 G and re-sorted into
+    direct-run order (src/merge_candidates.cpp:106-157, what ranks fold after the all-to-all).
+
+    PRECISION AND RECALL of both shares inside whole bins (bigchecks.check_bins_complete): for sixteen 12-mers of the anchor the GPU
+    lists every position of the 79.3 G-character text that begins with one, the host sorts those suffixes from the generator's
+    model and runs the oracle's scan over that piece of the stream -- the intervals it reports must be exactly the ones the run
+    accepted there.  Beside it the sampled properties: rows are real, maximal, one-per-document matches in lexicographic order,
+    every sampled row's threshold sits at its anchor position and is shorter than the row; sampled merged rows are matches
+    in all 25 documents, maximal, in the order of a direct run."""
     import mumemto_amd
-    haps, length = 13, 3_050_000_000
-    bases = np.empty(haps * length, np.uint8)
-    for h, b in synth.haplotypes_sparse(94, length, 0.001, 4, which=list(range(haps))):
-        bases[h * length:(h + 1) * length] = b
-    lens = np.full(haps, length, np.uint64)
+    from mumemto_amd import dist as mdist
+    length = 3_050_000_000
+    groups = mdist.partition_docs(94, 8)
     eng = mumemto_amd.Engine(0)
-    assert eng.run_partitioned(None, flat=(bases, lens), merge_metadata=True) == 1
-    assert eng.is_wide() and eng.text_length() == 2 * haps * (length + 1) > 79e9 and not eng.columns_kept()
-    st = eng.stream_stats()
-    assert st["entries"] == eng.text_length() and st["windows"] >= 30
-    assert eng.producer_used() == "guided" and eng.producer_expanded()
-    assert eng.device_memory()["peak"] < 288 * 2**30
-    bigchecks.check_mum_rows(eng, bases, lens, use_text=False)
-    L, off, strands = eng.rows_mum()
-    assert len(L) > 25_000_000
-    th = eng.thresholds()
-    assert len(th) == 2 * (length + 1)
-    rng = np.random.default_rng(5)
-    for r in rng.integers(0, len(L), size=2000):
-        t = int(th[int(off[r, 0])])                    # the anchor is '+' in every kept row: text offset = anchor offset
-        assert 0 < t < int(L[r]), (r, t, int(L[r]))
-    assert int(np.count_nonzero(th[: length + 1])) >= len(L)
+    parts = []
+    for share in (0, 1):
+        mine = groups[share]
+        haps = len(mine)
+        bases = np.empty(haps * length, np.uint8)
+        for k, (h, b) in enumerate(synth.haplotypes_sparse(94, length, 0.001, 4, which=mine)):
+            bases[k * length:(k + 1) * length] = b
+        lens = np.full(haps, length, np.uint64)
+        # (a strict multi-MUM begins at one anchor position in a hundred: sixteen bins of 12 characters -- ~4700 suffixes each --
+        # hold a few dozen rows between them)
+        kmers = _kmers_of(bases[:length], 12, 16, seed=21 + share)
+        eng.set_row_tap(kmers, max_rows=1 << 14, max_occ=1 << 20)
+        assert eng.run_partitioned(None, flat=(bases, lens), merge_metadata=True) == 1
+        assert eng.is_wide() and eng.text_length() == 2 * haps * (length + 1) > 79e9 and not eng.columns_kept()
+        assert eng.producer_used() == "guided" and eng.producer_expanded()
+        st = eng.stream_stats()
+        assert st["entries"] == eng.text_length() and st["windows"] >= 30
+        assert eng.device_memory()["peak"] < 0.87 * 288 * 2**30           # (head-room: a quarter-million-row collection is not the only one)
+        text = bigchecks.LazyText(bases, lens)
+        bins, suffixes, rows = bigchecks.check_bins_complete(eng, text, text.n, text.doc_start, kmers)
+        print("share %d: %d bins of 12 characters, %d suffixes sorted on the host, %d rows: the run's rows there are exactly the oracle's"
+              % (share, bins, suffixes, rows))
+        assert bins == 16 and suffixes >= 16 * 2 * haps and rows >= 5
+        eng.set_row_tap([])                                    # (switching the tap off forgets what it holds)
+        if share == 0:
+            bigchecks.check_mum_rows(eng, bases, lens, use_text=False)
+        L, off, strands = eng.rows_mum()
+        assert len(L) > 25_000_000
+        th = eng.thresholds32()[: length + 1].copy()
+        rng = np.random.default_rng(5)
+        for r in rng.integers(0, len(L), size=2000):
+            t = int(th[int(off[r, 0])])                    # the anchor is '+' in every kept row: text offset = anchor offset
+            assert 0 < t < int(L[r]), (r, t, int(L[r]))
+        assert int(np.count_nonzero(th)) >= len(L)
+        parts.append((L.copy(), off.copy(), strands.copy(), th))
+        del bases
+    # ---- the fold of the two shares, in eight slices of the anchor, re-sorted by the anchor's suffix ranks ----
+    eng.release_columns(keep_anchor_ranks=True)
+    m = eng.anchor_merge(parts, sort_like_direct=True, want_rows=True, slices=8, want_text=False)
+    n_rows, n_docs = int(m["n_rows"]), int(m["n_docs"])
+    # (a fold step starts a row wherever either partition does: more and shorter rows than either side has)
+    assert n_docs == 25 and max(len(parts[0][0]), len(parts[1][0])) < n_rows <= len(parts[0][0]) + len(parts[1][0])
+    order = mdist.merged_column_order(groups[:2])
+    model = bigchecks.SparseModel(94, length, 0.001, 4, which=order)
+    mtext = bigchecks.LazyText(model, np.full(n_docs, length, np.uint64))
+    ml, mo, ms = m["lengths"], m["offsets"], m["strands"]
+    comp = np.arange(256, dtype=np.uint8)
+    for x, y in zip(b"ACGT", b"TGCA"):
+        comp[x] = y
+    rng = np.random.default_rng(9)
+    keys = []
+    for r in np.sort(rng.integers(0, n_rows, size=150)):
+        ln = int(ml[r])
+        segs, lefts, rights = set(), set(), set()
+        for d in range(n_docs):
+            o = int(mo[r, d])
+            doc = model.doc(d)
+            w = np.full(ln + 2, 36, np.uint8)
+            lo, hi = max(o - 1, 0), min(o + ln + 1, length)
+            w[lo - (o - 1):hi - (o - 1)] = doc[lo:hi]
+            if ms[r, d]:
+                segs.add(w[1:-1].tobytes()); lefts.add(int(w[0])); rights.add(int(w[-1]))
+            else:
+                segs.add(comp[w[1:-1][::-1]].tobytes()); lefts.add(int(comp[w[-1]])); rights.add(int(comp[w[0]]))
+        assert len(segs) == 1 and ln >= 20, ("merged row is not a match in every document", r)
+        assert len(lefts) > 1 and len(rights) > 1, ("merged row is not maximal", r)
+        keys.append(next(iter(segs)))
+    assert keys == sorted(keys), "merged rows are not in the order of a direct run"
+    del mtext
     eng.close()
     eng.L.mmt_pool_trim()          # (250 GB of mapped heap would leave the command-line tests of other files, which run as
     #                                processes of their own on the same GPU, with nothing)
+
+
+def test_a_rank_share_of_configs4_at_its_size():
+    """BASELINE configs[4] -- 94 whole-genome haplotypes, partial multi-MEMs `-k -1 -f 3` (the mem_finder.hpp path) on eight GPUs --
+    as rank 3 of 8 sees it: EVERY rank holds all 573.4 G characters (the reference refuses to merge these modes from partitions:
+    include/pfp_mum.hpp:178-183), packed to two bits each; the documents are supplied one at a time (94 x 3.05 Gbp do not fit the
+    host as bytes either); the rank produces, scans and drops its share of the stream -- whole bins of leading characters,
+    12.4 % of the suffixes --; its ~44 M rows (66 GB of PREFIX.mems) are formatted, copied out, digested and dropped (the sink is
+    /dev/null: the box has no room for them).
+
+    PRECISION AND RECALL inside whole bins: twelve 14-mers of the rank's share; every position of the 573.4 G-character text that
+    begins with one (~2100 each: 94 haplotypes, two strands, chance hits) is listed by the GPU, spelled from the generator's
+    model and sorted on the host, and the oracle's scan over that piece of the stream (-k -1 -f 3: num_distinct 93, at most 3
+    per document, 282 in all) must report exactly the intervals the run accepted there."""
+    import mumemto_amd
+    import pyoracle as O
+    haps, length = 94, 3_050_000_000
+    avail_gb = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] / 2**20
+    if avail_gb < 40:
+        pytest.skip("the generator's model needs ~25 GB of host memory")
+    model = bigchecks.SparseModel(haps, length, 0.001, 4, which=list(range(haps)))
+    lens = np.full(haps, length, np.uint64)
+    # rank 3 of 8 takes the suffixes between 37.5 % and 50 % of the sorted order: those that begin with CG or CT (the edges of
+    # the share move by the few '$' and nothing else: k-mers well inside are asked for, and checked against the share afterwards)
+    anchor = model.doc(0)[0:4_000_000]
+    kmers = _kmers_of(anchor, 14, 12, seed=33, prefixes=[b"CGC", b"CGG", b"CGT", b"CTA", b"CTC", b"CTG"])
+    mumemto_amd.load_library().mmt_pool_trim()      # (a text of 143 GB wants the heap in one piece: what earlier tests left goes first)
+    eng = mumemto_amd.Engine(0)
+    eng.set_scan_shard(3, 8)
+    eng.set_text_sink("/dev/null")
+    eng.set_row_tap(kmers, max_rows=1 << 16, max_occ=1 << 23)
+    nd, f, mf = O.cli_params(haps, k=-1, f=3)
+    assert (nd, f, mf) == (93, 3, 282)
+    assert eng.run_supplied(lens, lambda d, dst: model.fill(d, dst), num_distinct=nd, max_doc_freq=f, max_total_freq=mf) == 1
+    eng.set_text_sink(None)
+    n_text = 2 * haps * (length + 1)
+    assert eng.is_wide() and eng.text_length() == n_text > 573e9 and eng.producer_used() == "guided"
+    pieces = eng.sort_pieces()
+    st = eng.stream_stats()
+    assert st["entries"] == pieces[3][1] and abs(pieces[3][1] / n_text - 1 / 8) < 0.02
+    mem = eng.device_memory()
+    assert mem["peak"] < 0.93 * 288 * 2**30, mem
+    rows = eng.L.mmt_num_rows(eng.h)
+    written, digest = eng.text_sink_digest()
+    print("rank 3 of 8 of configs[4]: %d suffixes of %d in %d windows, %d rows, %.1f GB of PREFIX.mems (digest %016x), peak HBM %.1f GB"
+          % (st["entries"], n_text, st["windows"], rows, written / 1e9, digest, mem["peak"] / 2**30))
+    assert 30_000_000 < rows < 60_000_000 and written > 40e9
+    assert all(eng.kmer_in_share(km) for km in kmers)
+    text = bigchecks.LazyText(model, lens)
+    bins, suffixes, tapped = bigchecks.check_bins_complete(eng, text, text.n, text.doc_start, kmers, num_distinct=nd, max_doc_freq=f,
+                                                           max_total_freq=mf)
+    print("%d bins of 14 characters, %d suffixes sorted on the host, %d rows: the run's rows there are exactly the oracle's" % (bins, suffixes, tapped))
+    assert bins == 12 and suffixes >= 12 * 2 * haps - 40 and tapped >= 6
+    eng.set_row_tap([])
+    eng.close()
+    eng.L.mmt_pool_trim()

@@ -30,6 +30,11 @@ ap.add_argument("--verify-direct", action="store_true")
 ap.add_argument("--samples", type=int, default=200)
 ap.add_argument("--keep", action="store_true")
 ap.add_argument("--expect-sha", default="", help="sha256 of PREFIX.mums from another grouping of the same collection")
+ap.add_argument("--no-file", action="store_true",
+                help="the merged rows are formatted and copied out in pieces as for the file, but written to /dev/null (bench.py's "
+                     "whole_genome_1gpu leg: 50 GB of PREFIX.mums on a tmpfs would count against the container's memory); the "
+                     "checks of the file are skipped, the merged rows' count and the timings stay")
+ap.add_argument("--json-out", default="", help="write the summary record of the first grouping there")
 A = ap.parse_args()
 N, L0 = A.haps, A.length
 _COMP = np.arange(256, dtype=np.uint8)
@@ -80,11 +85,12 @@ def run_grouping(eng, G, slices, out_path):
         del bases
     t0 = time.time()
     eng.release_columns(keep_anchor_ranks=True)       # what a rank holds between its pass and the fold: rows, thresholds, anchor ranks
-    m = eng.anchor_merge(parts, sort_like_direct=True, want_rows=False, text_file=out_path, slices=slices)
+    m = eng.anchor_merge(parts, sort_like_direct=True, want_rows=False, text_file="/dev/null" if A.no_file else out_path, slices=slices)
     t_fold = time.time() - t0
-    sha, size = sha_of(out_path)
+    sha, size = ("", 0) if A.no_file else sha_of(out_path)
     mem = eng.device_memory()
-    rec = dict(grouping=G, slices=slices, shares_run_s=round(sum(s["run_s"] for s in per_share), 1),
+    rec = dict(grouping=G, slices=slices, shares=per_share, generate_s=round(sum(s["generate_s"] for s in per_share), 1),
+               shares_run_s=round(sum(s["run_s"] for s in per_share), 1),
                fold_resort_write_s=round(t_fold, 1), total_s=round(time.time() - t_all, 1), merged_rows=int(m["n_rows"]),
                columns=int(m["n_docs"]), bytes=size, sha256=sha, peak_hbm_gb=round(mem["peak"] / 2**30, 1),
                slowest_share_s=max(s["run_s"] for s in per_share),
@@ -172,6 +178,12 @@ eng = mumemto_amd.Engine(0)
 os.environ.setdefault("MMT_MERGE_DEBUG", "1")
 slices = A.slices or A.ranks
 first, groups = run_grouping(eng, A.ranks, slices, A.out + ".mums")
+if A.json_out:
+    with open(A.json_out, "w") as f:
+        json.dump(first, f)
+if A.no_file:
+    print("OK")
+    sys.exit(0)
 check_merged_file(A.out + ".mums", mdist.merged_column_order(groups), first["bytes"], A.samples)
 if A.expect_sha:
     log(expected_sha256=A.expect_sha, identical_bytes=first["sha256"] == A.expect_sha)

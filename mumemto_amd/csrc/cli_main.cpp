@@ -725,6 +725,11 @@ int main(int argc, char** argv) {
         engine_init.join();
         if (engine_error) std::rethrow_exception(engine_error);
         Engine& eng = *engine;
+        // (measured, tests/micro/exit_ab.py + exit_probe.cpp: what a process pays between _Exit and its parent's waitpid is not
+        // its mapped device memory -- 123 or 79 GB mapped at exit: the same 0.45 s; a bare HIP process 0.08 s; 100 GB of hipMalloc
+        // 0.06 s -- but page-locked HOST memory, 0.13 s per GB: the sink's blocks are 64 MB now.  Handing the heap's free top back
+        // early therefore buys nothing and costs the run ~0.08 s: opt-in)
+        eng.set_one_shot(std::getenv("MUMEMTO_EARLY_UNMAP") != nullptr);
         // one suffix array while the text fits the device (40-bit positions beyond 2^32 characters); beyond that --
         // or beyond MUMEMTO_MAX_TEXT characters -- strict multi-MUMs run as anchor partitions + merge on this GPU
         // (the same estimate as the library: Engine::auto_max_text, MUMEMTO_MAX_TEXT overrides both)

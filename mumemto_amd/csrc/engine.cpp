@@ -899,7 +899,10 @@ void Engine::sink_open(bool mum_mode) {
 // large the output is (round 3 kept every piece until the end of the run: 4.5 GB of pinned memory for a rank's share of
 // whole genomes, and it stayed with the engine).
 char* Engine::sink_host_room(size_t n, uint32_t* block) {
-    const size_t BLOCK = (size_t)256 << 20, RING = 4;
+    // (64 MB: page-locking costs 0.19 s per GB when the block is made and 0.13 s per GB when the process ends -- the four
+    // blocks of 256 MB were a quarter of a second of the bench workload's 2.2 s from process start to exit)
+    static const size_t BLOCK = (size_t)(std::getenv("MMT_SINK_BLOCK_MB") ? std::max(1, std::atoi(std::getenv("MMT_SINK_BLOCK_MB"))) : 64) << 20;
+    const size_t RING = 4;
     auto fits = [&](size_t b) { return std::max(BLOCK, sink_block_cap_[b]) >= n; };
     std::unique_lock<std::mutex> lk(sink_mu_);
     if (!sink_blocks_.empty() && sink_block_at_ < sink_blocks_.size() && fits(sink_block_at_) &&
@@ -1417,6 +1420,7 @@ void Engine::run(const mmt_params& p) {
         release_sort_scratch();
         d_wpre_.release(); d_wsuf_.release(); d_wide_.release(); d_cand_.release();
         for (int k = 0; k < 2; k++) { w_sa_[k].release(); w_hi_[k].release(); w_bwt_[k].release(); w_lcp_[k].release(); }
+        if (one_shot_) pool::shrink_async(device_);      // (the tables of the parse and the windows are gone: rows and outputs remain)
     }
     make_rows(p);
     finish();

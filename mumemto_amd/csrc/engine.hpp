@@ -135,6 +135,9 @@ public:
     // device): every stage gives its scratch back before the next one allocates, so that the footprint is the
     // largest stage instead of the sum -- at the price of hipMalloc calls in every run.
     void set_lean(bool on) { lean_ = on; }
+    // this process runs ONE job and exits (mumemto_exec): once a stage's peak is over, the free top of the device heap goes
+    // back to the driver on a helper thread (pool::shrink_async) instead of being torn down on the way out
+    void set_one_shot(bool on) { one_shot_ = on; }
     // Multi-GPU runs of the modes the anchor merge cannot serve (partial multi-MUMs, multi-MEMs: the reference refuses
     // to merge them, include/pfp_mum.hpp:178-183): every rank builds the same stream and scans only its share of the
     // suffix-array positions -- closing positions in [n * index / count, n * (index + 1) / count), cut at multiples of
@@ -400,6 +403,7 @@ private:
     int sort_rounds_ = 0;
     std::unique_ptr<PfpState> pfp_{new PfpState()};
     bool lean_ = false;                   // release each stage's scratch before the next stage allocates
+    bool one_shot_ = false;
     int producer_ = 0, producer_used_ = 1;
     bool producer_expanded_ = false;
     uint32_t pfp_w_ = 0, pfp_p_ = 0;

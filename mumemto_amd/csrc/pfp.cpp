@@ -265,6 +265,8 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     pk::parse_ranks(S.pid.get(), S.prank.get(), m, S.parse.get(), st);
     S.n_groups = read_u32(S.gscan.get() + (nd - 1), st);
     if (slim) { S.pflag.release(); S.pscan.release(); S.sa_d.release(); S.dict.release(); }
+    // (the dictionary's suffix sort was the run's peak: 49 bytes per dictionary character)
+    if (slim && one_shot_) pool::shrink_async(device_);
     e4.stop(st);
     mem_mark(device_, "dictionary groups + LCP");
     S.ms[0] = e0.ms(); S.ms[1] = e1.ms(); S.ms[2] = e2.ms(); S.ms[3] = e3.ms(); S.ms[4] = e4.ms();

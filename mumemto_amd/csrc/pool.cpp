@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mmt { namespace pool {
@@ -43,6 +44,8 @@ struct Heap {
 
 std::mutex g_mu;
 std::vector<std::unique_ptr<Heap>> g_heaps;
+std::mutex g_unmap_mu;                              // held while chunks are being unmapped (shrink_async): grow() waits for it
+std::thread* g_unmap_thread = nullptr;
 
 bool enabled() {
     static const bool on = [] {
@@ -134,6 +137,7 @@ bool grow(Heap& H, size_t bytes) {
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
         if (fr < bytes + keep) return false;
     }
+    { std::lock_guard<std::mutex> pending(g_unmap_mu); }      // (chunks on their way out may sit where this maps)
     const double t0 = now_s();
     size_t done = 0;
     std::string why;
@@ -261,7 +265,52 @@ size_t available(int device) {
     return fr + (s.mapped - s.live);
 }
 
+// ---- giving the free tail of the heap back while the run goes on (one-shot processes: mumemto_exec) ----------------------
+// What a process holds mapped when it exits is torn down by the driver on its way out: 0.57 s for the 116 GB the bench
+// workload's dictionary sort leaves mapped -- a quarter of the job's wall clock by SURVEY.md 8(d)'s definition (process start ->
+// exit).  Once the peak stage is over, the chunks at the top of the heap that are wholly free are handed back by a helper
+// thread while the GPU works on the stages that follow.  Not for a process that runs again: memory the driver gets back is
+// scrubbed, and a heap that grows again waits for that.
+void shrink_async(int device) {
+    shrink_wait();
+    std::vector<std::pair<char*, hipMemGenericAllocationHandle_t>> todo;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (auto& hp : g_heaps) {
+            Heap& H = *hp;
+            if (!H.vmm || hp->device != device || H.free_blocks.empty()) continue;
+            auto last = std::prev(H.free_blocks.end());
+            if (last->first + last->second != H.top) continue;
+            // whole chunks inside the free tail [last->first, top): chunks sit at multiples of GROW
+            const size_t first_chunk = (last->first + GROW - 1) / GROW * GROW;
+            if (first_chunk >= H.top) continue;
+            const size_t off = last->first, size = last->second;
+            H.free_blocks.erase(last);
+            if (first_chunk > off) H.free_blocks[off] = first_chunk - off;
+            (void)size;
+            for (size_t i = 0; i < H.mapped.size();) {
+                if (H.mapped[i].first >= first_chunk && H.mapped[i].first < H.top) {
+                    todo.emplace_back(H.base + H.mapped[i].first, H.handles[i]);
+                    H.mapped.erase(H.mapped.begin() + (long)i); H.handles.erase(H.handles.begin() + (long)i);
+                } else i++;
+            }
+            H.top = first_chunk;
+        }
+    }
+    if (todo.empty()) return;
+    // (a leaked pointer: a joinable std::thread with static storage would end the process in its destructor)
+    g_unmap_thread = new std::thread([todo, device]() {
+        std::lock_guard<std::mutex> lock(g_unmap_mu);
+        (void)hipSetDevice(device);
+        for (const auto& t : todo) { (void)hipMemUnmap(t.first, GROW); (void)hipMemRelease(t.second); }
+    });
+}
+void shrink_wait() {
+    if (g_unmap_thread) { if (g_unmap_thread->joinable()) g_unmap_thread->join(); delete g_unmap_thread; g_unmap_thread = nullptr; }
+}
+
 void trim() {
+    shrink_wait();
     std::lock_guard<std::mutex> lock(g_mu);
     for (auto& hp : g_heaps) {
         Heap& H = *hp;

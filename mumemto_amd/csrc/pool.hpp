@@ -19,5 +19,9 @@ struct Stats { bool pooled; size_t mapped, live, peak, largest_free; double map_
 Stats stats(int device);
 size_t available(int device);     // driver-free bytes + unused bytes of the heap
 void trim();                      // unmap everything if no block is live (engine teardown in long-lived processes)
+// One-shot processes: the wholly free chunks at the top of the heap go back to the driver on a helper thread while the run
+// goes on (what is still mapped at exit is torn down on the way out: 0.57 s for 116 GB).  shrink_wait joins the helper.
+void shrink_async(int device);
+void shrink_wait();
 
 }}  // namespace mmt::pool

@@ -90,6 +90,31 @@ void check(ncclResult_t e, const char* what) {
 }
 #define MMT_NCCL(x) check((x), #x)
 
+// One message of `count` elements as pieces of at most 2^30 (MUMEMTO_RCCL_CHUNK: tests) -- sender and receiver cut the same
+// way, so the pieces pair up in order.  A rank's threshold column over a 3.05 Gbp anchor is 3.05 G elements / 12 GB: counts are
+// size_t in the interface, but nothing obliges every layer below it (element counts x datatype size in 32-bit arithmetic,
+// registration windows) to have been exercised beyond 2^31 -- pieces of a gigabyte-scale count cost nothing inside a group.
+size_t rccl_chunk() {
+    static const size_t c = [] { const char* e = std::getenv("MUMEMTO_RCCL_CHUNK"); const size_t v = e ? (size_t)std::strtoull(e, nullptr, 10) : 0; return v ? v : ((size_t)1 << 30); }();
+    return c;
+}
+template <typename T>
+void send_pieces(const T* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
+    const size_t C = rccl_chunk();
+    for (size_t at = 0; at < count || at == 0; at += C) {
+        MMT_NCCL(rccl().Send(buf + at, std::min(C, count - at), t, peer, comm, st));
+        if (count <= at + C) break;
+    }
+}
+template <typename T>
+void recv_pieces(T* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
+    const size_t C = rccl_chunk();
+    for (size_t at = 0; at < count || at == 0; at += C) {
+        MMT_NCCL(rccl().Recv(buf + at, std::min(C, count - at), t, peer, comm, st));
+        if (count <= at + C) break;
+    }
+}
+
 }  // namespace
 
 struct Comm {
@@ -194,21 +219,21 @@ static MergedRows merge_on_rank0(Comm& c, uint32_t min_len, const std::vector<ui
     if (c.rank != 0) {
         const size_t rows = R.n_rows, cells = rows * R.n_docs;
         if (rows) {
-            MMT_NCCL(rccl().Send(my_len, rows, ncclUint32, 0, c.comm, st));
-            MMT_NCCL(rccl().Send(my_off, cells, ncclInt64, 0, c.comm, st));
-            MMT_NCCL(rccl().Send(my_st, cells, ncclUint8, 0, c.comm, st));
+            send_pieces(my_len, rows, ncclUint32, 0, c.comm, st);
+            send_pieces(my_off, cells, ncclInt64, 0, c.comm, st);
+            send_pieces(my_st, cells, ncclUint8, 0, c.comm, st);
         }
-        MMT_NCCL(rccl().Send(e.thresh_device32(), L, ncclUint32, 0, c.comm, st));
+        send_pieces(e.thresh_device32(), L, ncclUint32, 0, c.comm, st);
     } else {
         for (int r = 1; r < c.world; r++) {
             const size_t rows = meta[(size_t)r * 4], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
             c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(L);
             if (rows) {
-                MMT_NCCL(rccl().Recv(c.len[r]->get(), rows, ncclUint32, r, c.comm, st));
-                MMT_NCCL(rccl().Recv(c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
-                MMT_NCCL(rccl().Recv(c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
+                recv_pieces(c.len[r]->get(), rows, ncclUint32, r, c.comm, st);
+                recv_pieces(c.off[r]->get(), cells, ncclInt64, r, c.comm, st);
+                recv_pieces(c.st[r]->get(), cells, ncclUint8, r, c.comm, st);
             }
-            MMT_NCCL(rccl().Recv(c.th[r]->get(), L, ncclUint32, r, c.comm, st));
+            recv_pieces(c.th[r]->get(), L, ncclUint32, r, c.comm, st);
         }
     }
     MMT_NCCL(rccl().GroupEnd());
@@ -299,20 +324,20 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
         // to rank r: my rows of its range, my thresholds of its range
         const size_t s_rows = out[r]->n, s_cells = s_rows * R.n_docs;
         if (s_rows) {
-            MMT_NCCL(rccl().Send(out[r]->len.get(), s_rows, ncclUint32, r, c.comm, st));
-            MMT_NCCL(rccl().Send(out[r]->off.get(), s_cells, ncclInt64, r, c.comm, st));
-            MMT_NCCL(rccl().Send(out[r]->str.get(), s_cells, ncclUint8, r, c.comm, st));
+            send_pieces(out[r]->len.get(), s_rows, ncclUint32, r, c.comm, st);
+            send_pieces(out[r]->off.get(), s_cells, ncclInt64, r, c.comm, st);
+            send_pieces(out[r]->str.get(), s_cells, ncclUint8, r, c.comm, st);
         }
-        MMT_NCCL(rccl().Send(e.thresh_device32() + base[r], hi[r] - base[r], ncclUint32, r, c.comm, st));
+        send_pieces(e.thresh_device32() + base[r], hi[r] - base[r], ncclUint32, r, c.comm, st);
         // from rank r: its rows of my range, its thresholds of my range
         const size_t rows = counts[(size_t)r * W + c.rank], docs = meta[(size_t)r * 4 + 1], cells = rows * docs;
         c.len[r]->ensure(rows + 1); c.off[r]->ensure(cells + 1); c.st[r]->ensure(cells + 1); c.th[r]->ensure(my_span + 1);
         if (rows) {
-            MMT_NCCL(rccl().Recv(c.len[r]->get(), rows, ncclUint32, r, c.comm, st));
-            MMT_NCCL(rccl().Recv(c.off[r]->get(), cells, ncclInt64, r, c.comm, st));
-            MMT_NCCL(rccl().Recv(c.st[r]->get(), cells, ncclUint8, r, c.comm, st));
+            recv_pieces(c.len[r]->get(), rows, ncclUint32, r, c.comm, st);
+            recv_pieces(c.off[r]->get(), cells, ncclInt64, r, c.comm, st);
+            recv_pieces(c.st[r]->get(), cells, ncclUint8, r, c.comm, st);
         }
-        MMT_NCCL(rccl().Recv(c.th[r]->get(), my_span, ncclUint32, r, c.comm, st));
+        recv_pieces(c.th[r]->get(), my_span, ncclUint32, r, c.comm, st);
     }
     MMT_NCCL(rccl().GroupEnd());
     MMT_HIP(hipStreamSynchronize(st));
@@ -341,11 +366,11 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
     if (c.rank != 0) {
         const size_t rows = piece.n_rows, cells = rows * piece.n_docs;
         if (rows) {
-            MMT_NCCL(rccl().Send(piece.d_length.get(), rows, ncclUint32, 0, c.comm, st));
-            MMT_NCCL(rccl().Send(piece.d_offsets.get(), cells, ncclInt64, 0, c.comm, st));
-            MMT_NCCL(rccl().Send(piece.d_strands.get(), cells, ncclUint8, 0, c.comm, st));
+            send_pieces(piece.d_length.get(), rows, ncclUint32, 0, c.comm, st);
+            send_pieces(piece.d_offsets.get(), cells, ncclInt64, 0, c.comm, st);
+            send_pieces(piece.d_strands.get(), cells, ncclUint8, 0, c.comm, st);
         }
-        MMT_NCCL(rccl().Send(piece.d_thresh.get(), piece.thresh_len, ncclUint32, 0, c.comm, st));
+        send_pieces(piece.d_thresh.get(), piece.thresh_len, ncclUint32, 0, c.comm, st);
     } else {
         pieces.resize((size_t)W);
         pieces[0] = std::move(piece);
@@ -355,11 +380,11 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
             const size_t cells = p.n_rows * p.n_docs;
             p.d_length.ensure(p.n_rows + 1); p.d_offsets.ensure(cells + 1); p.d_strands.ensure(cells + 1); p.d_thresh.ensure(p.thresh_len + 1);
             if (p.n_rows) {
-                MMT_NCCL(rccl().Recv(p.d_length.get(), p.n_rows, ncclUint32, r, c.comm, st));
-                MMT_NCCL(rccl().Recv(p.d_offsets.get(), cells, ncclInt64, r, c.comm, st));
-                MMT_NCCL(rccl().Recv(p.d_strands.get(), cells, ncclUint8, r, c.comm, st));
+                recv_pieces(p.d_length.get(), p.n_rows, ncclUint32, r, c.comm, st);
+                recv_pieces(p.d_offsets.get(), cells, ncclInt64, r, c.comm, st);
+                recv_pieces(p.d_strands.get(), cells, ncclUint8, r, c.comm, st);
             }
-            MMT_NCCL(rccl().Recv(p.d_thresh.get(), p.thresh_len, ncclUint32, r, c.comm, st));
+            recv_pieces(p.d_thresh.get(), p.thresh_len, ncclUint32, r, c.comm, st);
         }
     }
     MMT_NCCL(rccl().GroupEnd());
@@ -386,12 +411,12 @@ std::string dist_gather_text(Comm& c) {
     }
     MMT_NCCL(rccl().GroupStart());
     if (c.rank != 0) {
-        if (R.text_len) MMT_NCCL(rccl().Send(mine.get(), R.text_len, ncclUint8, 0, c.comm, st));
+        if (R.text_len) send_pieces(mine.get(), R.text_len, ncclUint8, 0, c.comm, st);
     } else {
         for (int r = 1; r < c.world; r++) {
             const size_t bytes = meta[(size_t)r * 4 + 2];
             c.text[r]->ensure(bytes + 1);
-            if (bytes) MMT_NCCL(rccl().Recv(c.text[r]->get(), bytes, ncclUint8, r, c.comm, st));
+            if (bytes) recv_pieces(c.text[r]->get(), bytes, ncclUint8, r, c.comm, st);
         }
     }
     MMT_NCCL(rccl().GroupEnd());

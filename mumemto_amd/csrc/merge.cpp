@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <deque>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "kernels.hpp"
@@ -545,8 +546,14 @@ void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) 
     DevBuf<char> d_piece[2];
     PinnedBuf<char> h_piece[2];
     for (int b = 0; b < 2; b++) { d_piece[b].ensure(longest + 1); h_piece[b].ensure(longest + 1); }
-    const int fd = ::open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
-    if (fd < 0) throw std::runtime_error("cannot write " + path);
+    // the bytes go to PATH.tmp and take the final name when every piece is in (a short write, a full disk or a kill half way
+    // must not leave a plausible but truncated PREFIX.mums); a device file -- /dev/null: runs that only time the formatting --
+    // is written as it is
+    struct stat sb;
+    const bool special = ::stat(path.c_str(), &sb) == 0 && !S_ISREG(sb.st_mode);
+    const std::string tmp = special ? path : path + ".tmp";
+    const int fd = ::open(tmp.c_str(), special ? O_WRONLY : (O_CREAT | O_TRUNC | O_WRONLY), 0644);
+    if (fd < 0) throw std::runtime_error("cannot write " + tmp);
     // the writer: piece i of buffer i & 1 once its copy has landed
     struct Job { int buf; size_t bytes; };
     std::mutex mu; std::condition_variable cv; std::deque<Job> q; bool closing = false; int free_buf[2] = {1, 1};
@@ -559,9 +566,10 @@ void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) 
               j = q.front(); q.pop_front(); }
             const char* src = h_piece[j.buf].get();
             size_t at = 0;
-            while (at < j.bytes && error.empty()) {
+            auto failed = [&]() { std::lock_guard<std::mutex> lk(mu); return !error.empty(); };     // (read and written under the mutex)
+            while (at < j.bytes && !failed()) {
                 const ssize_t w = ::write(fd, src + at, j.bytes - at);
-                if (w <= 0) { std::lock_guard<std::mutex> lk(mu); error = "short write to " + path; break; }
+                if (w <= 0) { std::lock_guard<std::mutex> lk(mu); error = "short write to " + tmp; break; }
                 at += (size_t)w;
             }
             { std::lock_guard<std::mutex> lk(mu); free_buf[j.buf] = 1; }
@@ -585,12 +593,17 @@ void write_merged_text(Engine& e, const MergedRows& m, const std::string& path) 
     } catch (...) {
         { std::lock_guard<std::mutex> lk(mu); closing = true; }
         cv.notify_all(); writer.join(); ::close(fd);
+        if (!special) ::unlink(tmp.c_str());
         throw;
     }
     { std::lock_guard<std::mutex> lk(mu); closing = true; }
     cv.notify_all();
     writer.join();
-    if (::close(fd) != 0 || !error.empty()) throw std::runtime_error(error.empty() ? "cannot close " + path : error);
+    std::string failure;
+    { std::lock_guard<std::mutex> lk(mu); failure = error; }
+    if (::close(fd) != 0 && failure.empty()) failure = "cannot close " + tmp;
+    if (failure.empty() && !special && std::rename(tmp.c_str(), path.c_str()) != 0) failure = "cannot rename " + tmp;
+    if (!failure.empty()) { if (!special) ::unlink(tmp.c_str()); throw std::runtime_error(failure); }
 }
 
 void download_merged(Engine& e, MergedRows& m) {

@@ -4,9 +4,12 @@
 // whom, offsets `thresh + base[r]`, counts `hi[r] - base[r]` against the receiver's span, the order the pieces are gathered
 // in) had only ever run with world = 1, where every loop is empty.  This library gives the same ten symbols with ranks =
 // PROCESSES SHARING GPU 0: a message is a device-to-host copy into a file under /dev/shm, renamed into place; the
-// receiver polls for it, copies it host-to-device and unlinks it.  Sends never block, so a group of sends and receives
-// cannot deadlock; operations between ncclGroupStart / ncclGroupEnd are queued and run at the end of the group, sends
-// first.  Message order per (source, destination) pair follows the order of the calls, as in NCCL.  A receive whose
+// receiver polls for it, copies it host-to-device and unlinks it.  A send is a RENDEZVOUS, as in NCCL: it is complete only when
+// its receive has taken the message.  Operations between ncclGroupStart / ncclGroupEnd progress together (all sends are posted,
+// all receives served, then every send waits for its message to be taken), so a group cannot deadlock on the order of its
+// calls; a send OUTSIDE a group blocks until it is matched -- two ranks that send to each other before they receive hang
+// (here: fail after FAKE_RCCL_TIMEOUT seconds, default 60, with "probable deadlock"), on this double as on the links.
+// Message order per (source, destination) pair follows the order of the calls, as in NCCL.  A receive whose
 // message has another size than the receiver asked for FAILS (ncclInvalidArgument): that is the check RCCL itself would
 // not make and the reason this double is stricter than the real thing.
 //
@@ -18,6 +21,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +57,7 @@ std::string msg_path(const FakeComm& c, int src, int dst, uint64_t seq) {
     return c.dir + "/m_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(seq);
 }
 
-ncclResult_t do_send(const Op& o) {
+ncclResult_t do_send(const Op& o, std::vector<std::string>* posted) {
     FakeComm& c = *o.comm;
     std::vector<char> host(o.bytes ? o.bytes : 1);
     if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
@@ -69,7 +73,26 @@ ncclResult_t do_send(const Op& o) {
         at += (size_t)w;
     }
     ::close(fd);
-    return ::rename(tmp.c_str(), path.c_str()) == 0 ? ncclSuccess : ncclSystemError;
+    if (::rename(tmp.c_str(), path.c_str()) != 0) return ncclSystemError;
+    if (posted) posted->push_back(path);
+    return ncclSuccess;
+}
+
+int timeout_s() { const char* e = std::getenv("FAKE_RCCL_TIMEOUT"); return e ? std::max(1, std::atoi(e)) : 60; }
+
+// a posted send is complete when its receiver has taken (unlinked) the message
+ncclResult_t wait_taken(const FakeComm& c, const std::string& path) {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct stat sb;
+    while (::stat(path.c_str(), &sb) == 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s())) {
+            g_error = "fake rccl: rank " + std::to_string(c.rank) + ": nobody received " + path + " within " + std::to_string(timeout_s()) +
+                      " s: probable deadlock (a send is complete only when its receive has run)";
+            return ncclSystemError;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    return ncclSuccess;
 }
 
 ncclResult_t do_recv(const Op& o) {
@@ -78,8 +101,8 @@ ncclResult_t do_recv(const Op& o) {
     const auto t0 = std::chrono::steady_clock::now();
     struct stat sb;
     while (::stat(path.c_str(), &sb) != 0) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
-            g_error = "fake rccl: rank " + std::to_string(c.rank) + " waited 120 s for " + path;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s())) {
+            g_error = "fake rccl: rank " + std::to_string(c.rank) + " waited " + std::to_string(timeout_s()) + " s for " + path + ": probable deadlock";
             return ncclSystemError;
         }
         std::this_thread::sleep_for(std::chrono::microseconds(200));
@@ -105,9 +128,13 @@ ncclResult_t do_recv(const Op& o) {
     return ncclSuccess;
 }
 
+// the operations of one group (or of one collective) progress together: every send is posted, every receive served, then the
+// sends wait for their receivers
 ncclResult_t run_ops(std::vector<Op>& ops) {
-    for (const Op& o : ops) if (o.kind == 0) { const ncclResult_t r = do_send(o); if (r != ncclSuccess) return r; }
+    std::vector<std::string> posted;
+    for (const Op& o : ops) if (o.kind == 0) { const ncclResult_t r = do_send(o, &posted); if (r != ncclSuccess) return r; }
     for (const Op& o : ops) if (o.kind == 1) { const ncclResult_t r = do_recv(o); if (r != ncclSuccess) return r; }
+    if (!ops.empty()) for (const std::string& p : posted) { const ncclResult_t r = wait_taken(*ops[0].comm, p); if (r != ncclSuccess) return r; }
     return ncclSuccess;
 }
 

@@ -169,14 +169,24 @@ def test_bench_single_gpu_line_at_a_small_size():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--haps", "12", "--length", "200000",
-           "--divergence", "0.005", "--cpu-sample-bp", "200000"]
+           "--divergence", "0.005", "--cpu-sample-bp", "200000", "--pause", "0.2", "--whole-genome", "no"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["metric"] == "input Gbp/s end-to-end" and d["value"] > 0
     assert d["config"]["output_equals_cpu_oracle"] is True
-    assert d["cli_process"]["rc"] == 0 and d["cli_process"]["output_identical_to_in_process"] is True
+    # `value` is the process-start clock: every timed step a fresh mumemto_exec; the warm engine's figure beside it
+    fp = d["fresh_processes"]
+    assert [x["timed"] for x in fp["runs"]] == [False, True, True] and all(x["rc"] == 0 for x in fp["runs"])
+    assert fp["output_identical_to_in_process"] is True and "fresh mumemto_exec process" in d["config"]["timed_region"].lower()
+    assert abs(d["ms_per_step"] - 1e3 * sum(x["wall_s"] for x in fp["runs"][1:]) / 2) < 1e-6 and d["value_process_start"] == d["value"]
+    assert d["value_in_process"] > d["value"]
     assert d["hbm_resident"]["value"] > 0 and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["cores"] == 1
+    # --in-process: the timed steps are the warm engine's (what profilers that follow one process need)
+    r = subprocess.run(cmd + ["--in-process", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "fresh_processes" not in d2 and d2["value_in_process"] == d2["value"] and "in-process" in d2["config"]["timed_region"]
 
 
 def _sharded_worker(rank, world, port, q, wide):

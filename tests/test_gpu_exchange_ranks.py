@@ -123,6 +123,15 @@ def test_exchange_and_fold_over_several_ranks(world, what):
     assert got == want
 
 
+@pytest.mark.parametrize("world,what", [(3, "rank0"), (4, "ranges")])
+def test_messages_travel_in_pieces_when_their_counts_are_large(world, what):
+    """dist.cpp cuts every message into pieces of at most 2^30 elements (a threshold column over a 3.05 Gbp anchor is 3.05 G
+    elements): MUMEMTO_RCCL_CHUNK = 997 makes every table of this small collection travel in dozens of pieces, sender and
+    receiver cutting the same way -- the merged bytes are still the oracle's."""
+    got = run_ranks(world, what, env_extra={"MUMEMTO_RCCL_CHUNK": "997"})
+    assert got == direct_bytes(9, 30000, 71, world)
+
+
 def test_route_is_rank_zeros_decision():
     """The ranks follow rank 0's choice of the fold even when their environments disagree (a rank that read another
     MUMEMTO_RANGE_FOLD used to enter another collective and hang): the workers get different values by rank."""
@@ -220,3 +229,66 @@ def test_ranks_of_a_sharded_run_write_pieces_and_nothing_is_gathered(streamed, t
         assert open(out + "." + ext, "rb").read() == want and want.count(b"\n") > 10
         assert not [f for f in os.listdir(tmp_path) if ".rank" in f], "pieces left behind"
         assert len(open(out + ".lengths").read().splitlines()) == 2 * 9
+
+
+_P2P = r"""
+import ctypes as C, os, sys, time
+import torch
+lib = C.CDLL(%(fake)r)
+rank, idfile, order = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+class Uid(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid = Uid()
+if rank == 0:
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    with open(idfile + ".tmp", "wb") as f: f.write(bytes(uid))
+    os.rename(idfile + ".tmp", idfile)
+else:
+    t0 = time.time()
+    while not os.path.exists(idfile):
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    C.memmove(C.byref(uid), open(idfile, "rb").read(), 128)
+comm = C.c_void_p()
+lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+assert lib.ncclCommInitRank(C.byref(comm), 2, uid, rank) == 0
+for f in (lib.ncclSend, lib.ncclRecv):
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+lib.ncclGetErrorString.restype = C.c_char_p
+mine = torch.full((1000,), rank + 1, dtype=torch.int32, device="cuda:0")
+got = torch.zeros(1000, dtype=torch.int32, device="cuda:0")
+peer = 1 - rank
+U32 = 3                                      # ncclUint32
+def send(): return lib.ncclSend(mine.data_ptr(), 1000, U32, peer, comm, None)
+def recv(): return lib.ncclRecv(got.data_ptr(), 1000, U32, peer, comm, None)
+if order == "grouped":                      # both ranks: send first, then receive -- inside one group: progresses together
+    lib.ncclGroupStart(); rc = send() or recv(); rc = lib.ncclGroupEnd() or rc
+elif order == "ordered":                    # rank 0 sends then receives, rank 1 receives then sends: matched
+    rc = (send() or recv()) if rank == 0 else (recv() or send())
+else:                                       # "crossed": both send before they receive, outside a group: a deadlock on real links
+    rc = send() or recv()
+if rc:
+    print("ERROR", lib.ncclGetErrorString(rc).decode()); sys.exit(7)
+torch.cuda.synchronize()
+assert int(got[0]) == peer + 1 and int(got[-1]) == peer + 1
+print("OK")
+"""
+
+
+@pytest.mark.parametrize("order", ["grouped", "ordered", "crossed"])
+def test_the_transport_double_keeps_rendezvous_semantics(order, tmp_path):
+    """A send is complete only when its receive has run -- in a group the operations progress together, outside a group two
+    ranks that send to each other before they receive hang on real links: the double must fail there ("probable deadlock"),
+    or ordering bugs of the exchange could never show up before a multi-GPU node does."""
+    script = tmp_path / "p2p.py"
+    script.write_text(_P2P % dict(fake=fake_lib()))
+    idfile = str(tmp_path / "id")
+    env = dict(os.environ, FAKE_RCCL_TIMEOUT="4")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), idfile, order], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    if order == "crossed":
+        assert all(p.returncode == 7 for p in procs), [o[1][-300:] for o in outs]
+        assert all(b"probable deadlock" in o[0] for o in outs)
+    else:
+        assert all(p.returncode == 0 and b"OK" in o[0] for p, o in zip(procs, outs)), [o[1][-400:] for o in outs]

@@ -1476,7 +1476,14 @@ constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, D
 // three writes, five barriers) of the level-wise tables.
 // ALL (with EXACT): merge metadata -- the intervals whose BWT bytes agree are candidates too (compile-time, so that the
 // kernel of the plain strict mode carries none of the dense-list code).
-template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT, bool VH = false, bool ALL = false>
+// ONEPASS (general modes without merge metadata -- partial multi-MUMs, multi-MEMs: the configs[4] instantiation): the queue is
+// walked ONCE and the intervals go through the workgroup's LDS buffer, flushed with one global atomic when half full, as in
+// the exact mode.  The two-pass form below -- count, one allocation per workgroup and tile, write -- pays when every other
+// position closes an interval (merge metadata on two haplotypes: 576 M candidates per 1.2 G positions); in these modes one
+// position in two thousand does, and the second walk of up to cap - w steps per queued position is saved.  (A slot
+// allocation per wave and walk step straight in the global list was tried first: 6.7 M returning atomics on one counter word
+// in 60 ms are the word's whole rate -- 75.7 ms instead of 60.1.)
+template <int BLOCK, int VG, int K0, int OUT_CAP, bool EXACT, bool VH = false, bool ALL = false, bool ONEPASS = false>
 __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint32_t n_tiles, uint32_t w,
                                                 uint32_t klev) {
     constexpr int TILE = BLOCK * VG * 4;
@@ -1810,7 +1817,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
         uint32_t wave_base = 0, wave_off = 0;
         // (strict multi-MUMs without merge metadata: one position in a thousand is queued and fewer still become candidates --
         // one pass, the few waves that have one ask for a slot as they go)
-        constexpr bool rare = EXACT && !ALL;
+        constexpr bool rare = (EXACT && !ALL) || ONEPASS;
         for (int pass = rare ? 1 : 0; pass < 2; pass++) {
         uint32_t counted = 0;
         // one interval [s, e] (LDS indices) of value len: counted in the first pass, stored in the second at the wave's
@@ -1822,7 +1829,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
                 // atomic per candidate would hold its wave -- and at the barrier the tile -- for its latency)
                 if (emit) {
                     Cand c; c.start = (uint32_t)(lds_lo + s_idx); c.end = (uint32_t)(lds_lo + e_idx); c.len = len;
-                    c.flags = CAND_LEFT_MAXIMAL;
+                    c.flags = (!ONEPASS || chg) ? CAND_LEFT_MAXIMAL : 0u;
                     const uint32_t slot = atomicAdd(&s_on, 1u);
                     if (slot < OUT_CAP) s_out[slot] = c;
                     else { const uint32_t g = atomicAdd(a.d_count, 1u); if (g < a.capacity) a.out[g] = c; }
@@ -1861,7 +1868,9 @@ __global__ __launch_bounds__(BLOCK) void k_scan(ScanArgs a, uint32_t halo, uint3
             // a BWT change among the entries k .. j-1?  Two lookups in the window table of the change bytes (the walk
             // below adds the entries further left one by one)
             const uint8_t* c8 = reinterpret_cast<const uint8_t*>(s_C);
-            bool chg = USE_C ? (c8[lj - w] | c8[lj - wstep]) != 0 : s_bwt[16 + lj - 1] != s_bwt[16 + lj - 2];
+            bool chg;
+            if (VH) chg = (int32_t)s_L[lj] > (int32_t)lj - (int32_t)w;       // (the running maximum of the change positions: as in the exact mode)
+            else chg = USE_C ? (c8[lj - w] | c8[lj - wstep]) != 0 : s_bwt[16 + lj - 1] != s_bwt[16 + lj - 2];
             bool done = false;
             while (lk > 0) {
                 const uint32_t v = s_lcp[lk - 1];
@@ -2079,7 +2088,10 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
     if (halo < w + 1) exact = false;
     // the 94-document shape (64 <= w < 128, exact windows): block-wise window minima instead of level-wise tables
     static const bool no_vh = std::getenv("MMT_SCAN_NO_VH") != nullptr;
-    const bool vh = exact && klev == 6 && halo >= w + 1 && !no_vh && VH_OUT > 0;
+    // (... and the general modes with such a window -- 94 documents, -k -1: the configs[4] instantiation -- take the same tables)
+    static const bool two_pass = std::getenv("MMT_SCAN_TWO_PASS") != nullptr;     // tests: the general modes' two-pass form
+    const bool onepass = !exact && !a.emit_all && !two_pass;
+    const bool vh = (exact || onepass) && klev == 6 && halo >= w + 1 && !no_vh && VH_OUT > 0;
     const size_t out_cap = vh ? (size_t)VH_OUT : (size_t)OUT_CAP;
     size_t lds = (size_t)(halo + TILE + 16) * 12 + (size_t)(halo + TILE + 32) * 2 + (size_t)TILE * 2 +
                  out_cap * sizeof(Cand) + (vh ? (size_t)(halo + TILE + 16) * 2 : (size_t)(halo + TILE + 32));
@@ -2093,7 +2105,9 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
         hipLaunchKernelGGL(kernel, g, b, lds, s, a, halo, n_tiles, w, klev);
     };
     const uint32_t k0 = klev < 3 ? klev : 3;
-    if (vh && a.emit_all) {
+    if (vh && onepass) {
+        go(k_scan<B, VG, 3, (VH_OUT > 0 ? VH_OUT : OUT_CAP), false, true, false, true>);
+    } else if (vh && a.emit_all) {
         go(k_scan<B, VG, 3, (VH_OUT > 0 ? VH_OUT : OUT_CAP), true, true, true>);
     } else if (vh) {
         go(k_scan<B, VG, 3, (VH_OUT > 0 ? VH_OUT : OUT_CAP), true, true>);
@@ -2110,6 +2124,13 @@ static void launch_scan(const ScanArgs& a, hipStream_t s, unsigned blocks_per_cu
             case 1: go(k_scan<B, VG, 1, OUT_CAP, true>); break;
             case 2: go(k_scan<B, VG, 2, OUT_CAP, true>); break;
             default: go(k_scan<B, VG, 3, OUT_CAP, true>); break;
+        }
+    } else if (onepass) {
+        switch (k0) {
+            case 0: go(k_scan<B, VG, 0, OUT_CAP, false, false, false, true>); break;
+            case 1: go(k_scan<B, VG, 1, OUT_CAP, false, false, false, true>); break;
+            case 2: go(k_scan<B, VG, 2, OUT_CAP, false, false, false, true>); break;
+            default: go(k_scan<B, VG, 3, OUT_CAP, false, false, false, true>); break;
         }
     } else {
         switch (k0) {

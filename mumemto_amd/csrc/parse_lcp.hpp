@@ -53,6 +53,35 @@ __device__ __forceinline__ uint32_t rmq_min(const RmqView& R, uint32_t a, uint32
     return best;
 }
 
+// The same minimum with the loads of a stretch requested EIGHT AT A TIME (indices clamped to the stretch: a value read twice
+// does not change a minimum): a lane of the emitter that needs sl[t1 .. t2 - 2] holds its whole wave for as many round trips
+// as the loop has iterations, and the common ranges -- the ranks of a few copies of the locus that left the group through a
+// mutation -- are a handful of entries in one or two lines.
+__device__ __forceinline__ uint32_t rmq_stretch8(const uint32_t* __restrict__ sl, uint32_t a, uint32_t b, uint32_t best) {
+    for (uint32_t i = a; i <= b; i += 8u) {
+        uint32_t x[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) { const uint32_t j = i + u; x[u] = sl[j <= b ? j : b]; }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) best = x[u] < best ? x[u] : best;
+        if (b - i < 8u) break;                                   // (i + 8 may wrap at the top of the range)
+    }
+    return best;
+}
+__device__ __forceinline__ uint32_t rmq_min8(const RmqView& R, uint32_t a, uint32_t b) {
+    if (b - a < 128u) return rmq_stretch8(R.sl, a, b, 0xffffffffu);
+    const uint32_t ba = (a + 63u) >> 6, bb = (b + 1u) >> 6;           // whole blocks [ba, bb)
+    uint32_t best = 0xffffffffu;
+    if (bb > ba) {
+        const uint32_t k = 31u - (uint32_t)__builtin_clz(bb - ba);
+        const uint32_t x = R.bmin[(size_t)k * R.nb + ba], y = R.bmin[(size_t)k * R.nb + bb - (1u << k)];
+        best = x < y ? x : y;
+    }
+    if (a < (ba << 6)) best = rmq_stretch8(R.sl, a, (ba << 6) - 1u, best);
+    if ((bb << 6) <= b) best = rmq_stretch8(R.sl, bb << 6, b, best);
+    return best;
+}
+
 // block minima over 64 entries + sparse table over the blocks of any array of m values (bmin: levels * nb entries)
 void build_rmq(const uint32_t* vals, uint32_t m, DevBuf<uint32_t>& bmin, uint32_t& nb, uint32_t& levels, hipStream_t s);
 

@@ -937,6 +937,7 @@ struct EmitArgsT {
     uint32_t* lcp; const uint2* ghead; RmqView rmq; uint32_t w;
     uint64_t out_base, win_lo, win_hi;
     uint32_t many_runs;          // a group of more runs than this: the piece is ranked by one sort in LDS (emit_piece)
+    uint32_t abl2;               // k_emit2, timing only, WRONG OUTPUT (MMT_EMIT2_ABLATE): 1 no range minima, 2 no occurrence records, 4 no column stores, 8 no group heads
 };
 template <int BLOCK, int CAP, typename ES = uint32_t>
 struct EmitShared {
@@ -1318,6 +1319,300 @@ __global__ __launch_bounds__(BLOCK, 7) void k_emit(EmitArgsT<P, SA> a, const Emi
     }
 }
 
+// ---- the emitter's tile kernel, second form (round 5) ----------------------------------------------------------------------
+// Same pieces, same tables, same output as emit_piece(sorted = true); what changed is how an element finds its place in
+// the piece.  The first form zeroed an owner array, scattered the entries' first elements into it and ran two running
+// maxima over the piece (entry of every element, first entry of every entry's group): six workgroup barriers before the
+// first occurrence record could be requested, ten per piece.  Here the entries leave two BIT MASKS in LDS -- "an entry
+// begins at element i", "entry e is the first of its group" -- and every element finds its entry, the first entry of its
+// group and the first entry of the next group with a count-leading-zeros on one or two mask words: four barriers per piece
+// (entries in place / keys in place / elements in their slots / piece written), and the group-head records are requested
+// together with the occurrence records.  The merged (key, sl) pairs and the high bytes overlay tables that are dead once
+// the records are gathered, so no barrier separates the merge ranks from the move.  Runs of one element -- the copies of
+// a phrase with a private mutation next to the long run of the unmutated phrase: the common shape of a group in a
+// pangenome -- are ranked by one comparison instead of a binary search, and a group of one run keeps its order.
+template <int BLOCK, int CAP>
+struct EmitTile {
+    alignas(8) uint32_t efirst[CAP];   // per entry: first slot of its inverted list | from the move on: key of the element in slot i ...
+    uint32_t eoffm1[CAP];              // per entry: offset in the phrase - 1        | ... and its sl, as CAP pairs over both arrays
+    uint32_t key[CAP];                 // key of element i, in expansion order
+    uint32_t mpos[CAP];                // at the first entry of a group: group id + 1 | from the move on: text position (low word) in slot i
+    uint16_t estart[CAP + 2];          // first element of entry e; estart[E] = L
+    uint16_t owner_at[CAP];            // at the first element of an entry: the entry | from the move on: position high byte | BWT byte << 8
+    uint8_t ebwt[CAP];
+    uint32_t omask[CAP / 32];          // bit i: an entry begins at element i
+    uint32_t gmask[CAP / 32 + 1];      // bit e: entry e is the first of its group; bit E closes the table
+    uint32_t bound[4];
+    uint32_t many;                     // some group of the piece has more runs than many_runs
+};
+
+template <int BLOCK, int CAP, typename P, typename SA>
+__device__ __forceinline__ void emit_tile_piece(const EmitArgsT<P, SA>& a, EmitTile<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
+                                                P clo, uint32_t L) {
+    using Sh = EmitTile<BLOCK, CAP>;
+    constexpr int PER = CAP / BLOCK;
+    constexpr uint32_t MW = CAP / 32;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t E = e1 - e0;
+    const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
+    __syncthreads();                                         // the piece before is written out; the masks are zero
+    for (uint32_t e = tid; e < E; e += BLOCK) {
+        const uint32_t st = (uint32_t)(a.ce_eoff[e0 + e] - clo);
+        const uint32_t gs = a.ce_gs[e0 + e];                 // group id + 1 at the first entry of a group
+        const uint32_t fi = a.ce_first[e0 + e], om = a.ce_offm1[e0 + e];
+        const uint8_t bw = a.ce_bwt[e0 + e];
+        sh.estart[e] = (uint16_t)st;
+        sh.efirst[e] = fi;
+        sh.eoffm1[e] = om;
+        sh.ebwt[e] = bw;
+        if (st < (uint32_t)CAP) {
+            sh.owner_at[st] = (uint16_t)e;
+            atomicOr(&sh.omask[st >> 5], 1u << (st & 31));
+        }
+        if (gs) { atomicOr(&sh.gmask[e >> 5], 1u << (e & 31)); sh.mpos[e] = gs; }
+    }
+    if (tid == 0) { sh.estart[E] = (uint16_t)L; atomicOr(&sh.gmask[E >> 5], 1u << (E & 31)); sh.many = 0; }
+    __syncthreads();
+    // every element: its entry, the runs of its group, its occurrence record, the head record of its group
+    P my_pos[PER];
+    uint32_t my_sl[PER], my_run[PER], my_gs[PER];          // my_run = entry | first entry of the group << 10 | first entry of the next group << 20
+    uint2 g_head[PER];
+    bool any_many = false;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        my_sl[q] = 0; my_run[q] = 0; my_gs[q] = 0; my_pos[q] = 0; g_head[q] = make_uint2(0u, 0u);
+        if (i < L) {
+            uint32_t wd = i >> 5;
+            uint32_t m = sh.omask[wd] & (0xffffffffu >> (31u - (i & 31u)));
+            while (!m && wd) m = sh.omask[--wd];
+            const uint32_t p = m ? (wd << 5) + 31u - (uint32_t)__clz(m) : 0u;
+            const uint32_t e = sh.owner_at[p], k = i - p;
+            wd = e >> 5;
+            m = sh.gmask[wd] & (0xffffffffu >> (31u - (e & 31u)));
+            while (!m && wd) m = sh.gmask[--wd];
+            const uint32_t gf = m ? (wd << 5) + 31u - (uint32_t)__clz(m) : 0u;
+            wd = e >> 5;
+            m = sh.gmask[wd] & ~(0xffffffffu >> (31u - (e & 31u)));
+            while (!m && wd < MW) m = sh.gmask[++wd];
+            const uint32_t ge = m ? (wd << 5) + (uint32_t)__ffs(m) - 1u : E;
+            const uint32_t fi = sh.efirst[e], om = sh.eoffm1[e];
+            uint32_t key;
+            if (a.abl2 & 2u) { key = i + 1; my_pos[q] = (P)7; my_sl[q] = 5; }
+            else if (a.occ12) {
+                const uint32_t* r = a.occ12 + 3ull * ((uint64_t)fi + k);
+                const uint32_t r0 = r[0], r1 = r[1], r2 = r[2];
+                key = r0;
+                my_pos[q] = (P)(((uint64_t)r1 | ((uint64_t)(r2 & 0xffu) << 32)) + om);
+                const uint32_t v = r2 >> 8;
+                my_sl[q] = v == 0xffffffu && r0 ? a.rmq.sl[r0 - 1] : v;
+            } else {
+                const uint64_t kp = a.occ[fi + k];
+                my_sl[q] = a.occ_sl[fi + k];
+                key = (uint32_t)(kp >> a.pos_bits);
+                my_pos[q] = (P)((kp & pos_mask) + om);
+            }
+            if (!(a.abl2 & 8u)) g_head[q] = a.ghead[sh.mpos[gf] - 1u];
+            my_gs[q] = sh.estart[gf];
+            my_run[q] = e | (gf << 10) | (ge << 20);
+            sh.key[i] = key;
+            if (ge - gf - 1u >= a.many_runs) any_many = true;
+        }
+    }
+    if (any_many) sh.many = 1u;
+    __syncthreads();                                         // keys in place; masks, owner_at, the entry rows and the group ids are dead
+    if (tid < MW) sh.omask[tid] = 0u;
+    if (tid <= MW) sh.gmask[tid] = 0u;
+    // merge rank of every element inside its group = its slot
+    uint32_t my_slot[PER];
+    if (sh.many) {
+        // (see emit_piece: a group of many runs is ranked by one sort of the piece in LDS)
+        uint64_t* const sk = reinterpret_cast<uint64_t*>(sh.efirst);
+        uint32_t P2 = 64;
+        while (P2 < L) P2 <<= 1;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            if (i < P2) sk[i] = i < L ? ((uint64_t)my_gs[q] << 42) | ((uint64_t)sh.key[i] << 10) | (uint64_t)i : ~0ull;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= P2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < P2 / 2; t += BLOCK) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const bool up = (lo & k) == 0;
+                    const uint64_t x = sk[lo], y = sk[hi];
+                    if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t pl = tid + q * BLOCK;
+            if (pl < L) sh.owner_at[(uint32_t)(sk[pl] & 1023u)] = (uint16_t)pl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            my_slot[q] = i < L ? (uint32_t)sh.owner_at[i] : 0u;
+        }
+        __syncthreads();                                     // (the sort's columns become the merged pairs, owner_at the high bytes)
+    } else {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const uint32_t i = tid + q * BLOCK;
+            my_slot[q] = i;
+            if (i < L) {
+                const uint32_t e = my_run[q] & 1023u, gf = (my_run[q] >> 10) & 1023u, ge = my_run[q] >> 20;
+                if (ge - gf > 1u && !(a.abl2 & 64u)) {
+                    const uint32_t key = sh.key[i];
+                    uint32_t rank = 0, lo = my_gs[q];
+                    for (uint32_t e2 = gf; e2 < ge; e2++) {
+                        const uint32_t hi = sh.estart[e2 + 1];
+                        if (e2 == e) rank += i - lo;
+                        else if (hi - lo == 1u) rank += sh.key[lo] < key ? 1u : 0u;
+                        else if (!(a.abl2 & 32u)) {              // #keys of run e2 smaller than key
+                            uint32_t x = lo, y = hi;
+                            while (x < y) { const uint32_t mid = (x + y) >> 1; if (sh.key[mid] < key) x = mid + 1; else y = mid; }
+                            rank += x - lo;
+                        }
+                        lo = hi;
+                    }
+                    my_slot[q] = my_gs[q] + rank;
+                }
+            }
+        }
+    }
+    static_assert(offsetof(Sh, eoffm1) == offsetof(Sh, efirst) + CAP * sizeof(uint32_t), "efirst and eoffm1 must be adjacent");
+    uint2* const merged = reinterpret_cast<uint2*>(sh.efirst);
+    uint16_t* const mhb = sh.owner_at;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        if (i < L) {
+            const uint32_t slot = my_slot[q];
+            const uint64_t pos = (uint64_t)my_pos[q];
+            merged[slot] = make_uint2(sh.key[i], my_sl[q]);
+            sh.mpos[slot] = (uint32_t)pos;
+            mhb[slot] = (uint16_t)(((uint32_t)(pos >> 32) & 0xffu) | ((uint32_t)sh.ebwt[my_run[q] & 1023u] << 8));
+        }
+    }
+    __syncthreads();
+    // slot i (element i and slot i lie in the same group: a group keeps its slots): suffix-array entry, BWT byte, and the LCP
+    // with the slot before it -- inside a group |alpha| - w + the LCP of the two following parse suffixes (a range minimum over
+    // the parse's LCP array: pfp_lcp_mum.hpp:295-321), at the first slot of a group the LCP of the two phrase suffixes
+    // themselves.  The minimum is min(sl[t1 .. t2 - 1]); sl[t2 - 1] came with the occurrence record, and when other parse
+    // suffixes rank between the two -- copies of the locus that left the group through a mutation inside alpha: a few per
+    // cent of the slots, but one in nearly every wave -- sl[t1] is requested for all of a work-item's slots BEFORE any of
+    // them is used: one round trip per piece instead of one per slot (MMT_EMIT2_ABLATE=1: 52 of 180 ms per C3 pass).
+    uint32_t t_lo[PER], t_hi[PER], mn0[PER], sl_first[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        t_lo[q] = 0; t_hi[q] = 0; mn0[q] = 0; sl_first[q] = 0xffffffffu;
+        if (i < L && i != my_gs[q]) {
+            const uint2 cur = merged[i];
+            t_lo[q] = merged[i - 1].x; t_hi[q] = cur.x; mn0[q] = cur.y;
+            if (t_lo[q] != 0 && t_hi[q] > t_lo[q] + 1u && !(a.abl2 & 1u)) sl_first[q] = a.rmq.sl[t_lo[q]];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const uint32_t i = tid + q * BLOCK;
+        if (i < L) {
+            const uint64_t out = (uint64_t)clo + i;
+            const uint32_t hb = mhb[i];
+            const uint64_t pos = (uint64_t)sh.mpos[i] | ((uint64_t)(hb & 0xffu) << 32);
+            if (out == 0) {                              // entry 0 must be the end sentinel
+                if (pos != (uint64_t)a.n) { atomicAdd(a.err, 1u); atomicAdd(a.err + 4, 1u); }
+                continue;
+            }
+            if (pos >= (uint64_t)a.n) {
+                atomicAdd(a.err, 1u);
+                if (atomicAdd(a.err + 5, 1u) == 0) {       // first offender, for the error message
+                    a.err[8] = (uint32_t)pos; a.err[9] = (uint32_t)(pos >> 32);
+                    a.err[10] = (uint32_t)out; a.err[11] = (uint32_t)(out >> 32);
+                }
+                continue;
+            }
+            const uint64_t j = out - 1;
+            if (j < a.win_lo || j >= a.win_hi) continue;
+            uint32_t v;
+            if (i == my_gs[q]) v = g_head[q].y;
+            else {
+                const uint32_t t1 = t_lo[q], t2 = t_hi[q];
+                if (t1 == 0 || t2 <= t1) { atomicAdd(a.err, 1u); atomicAdd(a.err + 3, 1u); v = 0; }
+                else {
+                    uint32_t mn = mn0[q] < sl_first[q] ? mn0[q] : sl_first[q];
+                    if (t2 - t1 > 2 && !(a.abl2 & 1u)) { const uint32_t rest = rmq_min8(a.rmq, t1 + 1, t2 - 2); mn = rest < mn ? rest : mn; }
+                    const uint64_t x = (uint64_t)g_head[q].x - a.w + mn;
+                    v = x < (uint64_t)LCP_CAP ? (uint32_t)x : LCP_CAP;
+                }
+            }
+            const uint64_t at = j - a.out_base;
+            if (a.abl2 & 4u) { if (v == 0xfffffff3u) a.lcp[at] = v; continue; }
+            a.sa.set(at, pos);
+            a.bwt[at] = (uint8_t)(hb >> 8);
+            a.lcp[at] = j == 0 ? 0u : v;
+        }
+    }
+}
+
+template <int BLOCK, int CAP, int TILE, typename P, typename SA>
+__global__ __launch_bounds__(BLOCK, 7) void k_emit2(EmitArgsT<P, SA> a, const EmitDesc* __restrict__ desc, uint32_t n_tiles) {
+    __shared__ EmitTile<BLOCK, CAP> sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    if (tid < CAP / 32) sh.omask[tid] = 0u;
+    if (tid <= CAP / 32) sh.gmask[tid] = 0u;
+    EmitDesc d = desc[t];
+    for (;;) {
+        const uint32_t t_next = t + gridDim.x;
+        EmitDesc dn = d;
+        if (t_next < n_tiles) dn = desc[t_next];
+        const uint64_t tile = a.tile_lo + t;
+        const P tbase = (P)(tile * TILE);
+        if (d.L) emit_tile_piece<BLOCK, CAP, P, SA>(a, sh, d.e0, d.e1, tbase + d.clo, d.L);
+        // what the first piece left of the tile (see k_emit)
+        uint32_t g = d.g_next;
+        const uint32_t g_end = d.g_end;
+        while (g < g_end) {
+            __syncthreads();
+            if (wave == 0) {
+                const uint64_t first = (uint64_t)a.segb[g] - (uint64_t)tbase;
+                const uint64_t lim = first + CAP;
+                uint32_t c = 0;                                  // groups after g that still begin at or before lim
+                for (uint32_t base = g + 1; base <= g_end; base += 64) {
+                    const uint32_t idx = base + lane;
+                    const bool ok = idx <= g_end && (uint64_t)a.segb[idx] - (uint64_t)tbase <= lim;
+                    const uint64_t m = __ballot(ok);
+                    c += (uint32_t)__popcll(m);
+                    if (m != ~0ull) break;
+                }
+                if (lane == 0) {
+                    sh.bound[2] = g + c;
+                    sh.bound[0] = (uint32_t)first;
+                    sh.bound[1] = (uint32_t)((uint64_t)a.segb[g + c] - (uint64_t)tbase - first);
+                }
+            }
+            __syncthreads();
+            const uint32_t g2 = sh.bound[2];
+            if (g2 > g) {
+                const uint32_t clo = sh.bound[0], L = sh.bound[1];
+                emit_tile_piece<BLOCK, CAP, P, SA>(a, sh, a.sege[g], a.sege[g2], tbase + clo, L);
+                g = g2;
+                continue;
+            }
+            g = g + 1;
+        }
+        if (t_next >= n_tiles) break;
+        t = t_next; d = dn;
+    }
+}
+
 uint32_t emit_tile() {
     static const uint32_t t = [] {
         const char* e = getenv("MMT_EMIT_TILE");
@@ -1342,6 +1637,8 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* 
     // (tests/micro: MMT_EMIT_MANY=0 sorts every piece, a large value none)
     static const uint32_t many = std::getenv("MMT_EMIT_MANY") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT_MANY")) : 24u;
     t.many_runs = many;
+    static const uint32_t abl2 = std::getenv("MMT_EMIT2_ABLATE") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT2_ABLATE")) : 0u;
+    t.abl2 = abl2;
     const uint32_t n_tiles = (uint32_t)(tile_hi - tile_lo);
     EmitDesc* desc = static_cast<EmitDesc*>(plan);
     hipLaunchKernelGGL((k_emit_plan<P, TILE, CAP>), dim3(grid_for(n_tiles, 256)), dim3(256), 0, s, t.segb, t.sege, tile_first_tab,
@@ -1361,7 +1658,10 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* 
         if (abl == 4) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 4>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
         if (abl == 5) { hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA, 5>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles); return; }
     }
-    hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles);
+    // MMT_EMIT_V1: the first form of the tile kernel (A/B, and the ablations above)
+    static const bool v1 = std::getenv("MMT_EMIT_V1") != nullptr;
+    if (v1 || (abl && !abl2)) hipLaunchKernelGGL((k_emit<BLOCK, CAP, TILE, P, SA>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles);
+    else hipLaunchKernelGGL((k_emit2<BLOCK, CAP, TILE, P, SA>), dim3(grid), dim3(BLOCK), 0, s, t, desc, n_tiles);
     MMT_HIP(hipGetLastError());
 }
 size_t emit_plan_bytes(uint64_t tiles) { return (size_t)tiles * sizeof(EmitDesc); }
@@ -1423,7 +1723,7 @@ static void emit_big_typed(const EmitArgs& a, const uint64_t* chunk0, uint32_t f
     t.fb_keys = a.fb_keys; t.fb_vals = static_cast<P*>(a.fb_vals);
     t.bwt_code = a.bwt_code; t.fb_bits = a.fb_bits; t.err = a.err; t.tile_lo = 0;
     t.lcp = a.lcp; t.ghead = static_cast<const uint2*>(a.ghead); t.rmq = a.rmq; t.w = a.w;
-    t.out_base = a.out_base; t.win_lo = a.win_lo; t.win_hi = a.win_hi; t.many_runs = 0xffffffffu;
+    t.out_base = a.out_base; t.win_lo = a.win_lo; t.win_hi = a.win_hi; t.many_runs = 0xffffffffu; t.abl2 = 0;
     hipLaunchKernelGGL((k_emit_big<BLOCK, CAP, P, SA>), dim3(n_chunks), dim3(BLOCK), 0, s, t, chunk0, f0, nf);
     MMT_HIP(hipGetLastError());
 }

@@ -1,0 +1,54 @@
+"""GPU box helper: the bench workload (or --realistic content) through mumemto_exec once per VARIANT of the environment,
+the collection generated once.  Prints per variant: wall clock, GPU stage times (MUMEMTO_STATS), sha256 of PREFIX.mums.
+usage: emit_ab.py [--reps N] [--realistic] [--haps H --length L] NAME=ENV1=V1,ENV2=V2 ...   (NAME= alone: no variables)"""
+import argparse, hashlib, json, os, shutil, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from mumemto_amd import synth, build
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--realistic", action="store_true")
+ap.add_argument("--haps", type=int, default=94)
+ap.add_argument("--length", type=int, default=64_000_000)
+ap.add_argument("--divergence", type=float, default=0.001)
+ap.add_argument("--seed", type=int, default=3)
+ap.add_argument("--args", default="", help="extra arguments of mumemto_exec, space separated")
+ap.add_argument("variants", nargs="+")
+a = ap.parse_args()
+d = "/dev/shm/emit_ab"
+os.makedirs(d, exist_ok=True)
+paths = []
+gen = synth.haplotypes_realistic if a.realistic else synth.haplotypes_sparse
+for h, bases in gen(a.haps, a.length, a.divergence, a.seed):
+    p = os.path.join(d, "h%03d.fa" % h)
+    synth.write_fasta_fast(p, bases, name="hap%03d" % h)
+    paths.append(p)
+exe = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
+stats = os.path.join(d, "stats.json")
+names = ["text", "suffix_sort", "lcp_bwt", "scan", "verify", "rows", "windows", "total"]
+for rep in range(a.reps):
+    for v in a.variants:
+        name, _, envs = v.partition("=")
+        env = dict(os.environ, MUMEMTO_STATS=stats)
+        for kv in filter(None, envs.split(",")):
+            k, _, val = kv.partition("=")
+            env[k] = val
+        if os.path.exists(stats):
+            os.unlink(stats)
+        time.sleep(3)
+        t = time.perf_counter()
+        r = subprocess.run([exe, "-o", os.path.join(d, "out")] + a.args.split() + paths, capture_output=True, text=True, env=env)
+        dt = time.perf_counter() - t
+        if r.returncode != 0 or not os.path.exists(stats):
+            print("%-14s rc %d %s" % (name, r.returncode, r.stderr[-300:].replace("\n", " | ")), flush=True)
+            continue
+        st = json.load(open(stats))
+        out = os.path.join(d, "out.mums" if os.path.exists(os.path.join(d, "out.mums")) else "out.mems")
+        hsh = hashlib.sha256()
+        with open(out, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                hsh.update(blk)
+        print("%-14s %.3f s wall | %s | pfp %s | sha %s rows %d" % (
+            name, dt, " ".join("%s %.1f" % (n, x) for n, x in zip(names, st["stage_ms"])),
+            " ".join("%.0f" % x for x in st["pfp_ms"]), hsh.hexdigest()[:16], st["rows"]), flush=True)
+shutil.rmtree(d, ignore_errors=True)

@@ -232,6 +232,9 @@ MMT_API int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w
  * proper phrase suffixes, [4] doubling rounds on the dictionary, [5] on the parse, [6] #valid
  * dictionary suffixes, [7] #groups too large for an LDS tile (sorted by the segmented fallback)   */
 MMT_API int mmt_pfp_counts(const mmt_engine* e, uint64_t out[8]);
+/* dictionary suffixes of the last run that were ordered by the long run of one symbol they begin in (runs of assembly
+   gaps, homopolymers: sorter.hpp, RunRefine) instead of by prefix doubling; -1: null engine */
+MMT_API long long mmt_pfp_run_refined(const mmt_engine* e);
 /* PREFIX.dict bytes (sorted phrases, 0x01 after each, 0x00 at the end; out holds counts[2] bytes)  */
 MMT_API int mmt_pfp_copy_dict(mmt_engine* e, uint8_t* out);
 /* PREFIX.parse entries (1-based phrase ranks, u32; out holds counts[0] entries)                    */

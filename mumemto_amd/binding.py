@@ -73,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
-    "mmt_engine_set_producer", "mmt_abi_version", "mmt_engine_set_row_tap", "mmt_text_sink_digest", "mmt_kmer_in_share", "mmt_row_tap_counts", "mmt_row_tap_get", "mmt_kmer_positions", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_copy_dict",
+    "mmt_engine_set_producer", "mmt_abi_version", "mmt_engine_set_row_tap", "mmt_text_sink_digest", "mmt_kmer_in_share", "mmt_row_tap_counts", "mmt_row_tap_get", "mmt_kmer_positions", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_run_refined", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
@@ -167,6 +167,8 @@ def load_library():
                                      C.POINTER(C.c_uint64)]
     L.mmt_engine_parse_only.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint32]
     L.mmt_pfp_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mmt_pfp_run_refined.argtypes = [C.c_void_p]
+    L.mmt_pfp_run_refined.restype = C.c_longlong
     L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_pfp_copy_parse.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_pfp_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -492,8 +494,10 @@ class Engine:
     def pfp_counts(self):
         out = (C.c_uint64 * 8)()
         _check(self.L.mmt_pfp_counts(self.h, out))
-        return dict(zip(["phrases", "distinct", "dict_len", "groups", "rounds_dict", "rounds_parse", "entries",
-                         "oversized_groups"], map(int, out)))
+        d = dict(zip(["phrases", "distinct", "dict_len", "groups", "rounds_dict", "rounds_parse", "entries",
+                      "oversized_groups"], map(int, out)))
+        d["run_refined"] = int(self.L.mmt_pfp_run_refined(self.h))
+        return d
 
     def pfp_stage_ms(self):
         out = (C.c_float * 8)()

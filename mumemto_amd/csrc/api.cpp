@@ -587,6 +587,10 @@ int mmt_pfp_counts(const mmt_engine* e, uint64_t out[8]) {
     out[4] = (uint64_t)S.rounds_dict; out[5] = (uint64_t)S.rounds_parse; out[6] = S.n_entries; out[7] = S.n_fallback;
     return 0;
 }
+long long mmt_pfp_run_refined(const mmt_engine* e) {
+    if (!e) return -1;
+    return (long long)e->e->pfp_state().run_refined;
+}
 int mmt_pfp_copy_dict(mmt_engine* e, uint8_t* out) {
     if (!e) return fail(1, "null");
     MMT_TRY

@@ -345,7 +345,8 @@ template <int BLOCK, int PER>
 __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__ text, uint32_t n,
                                                      const uint8_t* __restrict__ code, int bits, int chars,
                                                      uint32_t sep_code, uint64_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ vals) {
+                                                     uint32_t* __restrict__ vals, uint32_t* __restrict__ run_ends,
+                                                     uint32_t* __restrict__ run_count, uint32_t run_cap, uint64_t rep) {
     constexpr int TILE = BLOCK * PER;
     __shared__ uint8_t s_code[256];
     __shared__ uint8_t s_sym[TILE + 64];
@@ -374,6 +375,14 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__
         uint64_t p = base + t0 + q;
         if (p < n) {
             uint64_t kq = key & mask;
+            // the last window of a run of `chars` or more equal symbols (sorter.hpp, RunRefine): listed, in any order
+            if (run_ends) {
+                const uint32_t c0 = s_sym[t0 + q];
+                if (c0 && kq == (uint64_t)c0 * rep && s_sym[t0 + q + chars] != c0) {
+                    const uint32_t at = atomicAdd(run_count, 1u);
+                    if (at < run_cap) run_ends[at] = (uint32_t)p + (uint32_t)chars - 1u;
+                }
+            }
             if (sep_code != PACK_NO_SEP) {
                 const int d = next_sep[q];
                 if (d < chars) kq = ((kq >> (bits * (chars - 1 - d))) << (bits * (chars - 1 - d)) << 1) | 1ull;
@@ -385,10 +394,84 @@ __global__ __launch_bounds__(BLOCK) void k_pack_keys(const uint8_t* __restrict__
     }
 }
 void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint32_t sep_code,
-               uint64_t* keys, uint32_t* vals, hipStream_t s) {
+               uint64_t* keys, uint32_t* vals, hipStream_t s, uint32_t* run_ends, uint32_t* run_count, uint32_t run_cap) {
     constexpr int B = 256, PER = 4;
+    uint64_t rep = 0;
+    for (int c = 0; c < chars; c++) rep |= 1ull << (bits * c);
     hipLaunchKernelGGL((k_pack_keys<B, PER>), dim3(grid_for(n, B * PER)), dim3(B), 0, s, text, n, d_code, bits, chars,
-                       sep_code, keys, vals);
+                       sep_code, keys, vals, run_ends, run_count, run_cap, rep);
+    MMT_HIP(hipGetLastError());
+}
+
+// ---- long runs of one symbol (sorter.hpp, RunRefine) -------------------------------------------------------------------------
+// lo_hi[2 k], lo_hi[2 k + 1] = the range of sorted[] that equals probe[k]
+__global__ void k_equal_range_u64(const uint64_t* __restrict__ sorted, uint32_t n, const uint64_t* __restrict__ probe,
+                                  uint32_t n_probes, uint32_t* __restrict__ lo_hi) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n_probes) return;
+    const uint64_t x = probe[t >> 1];
+    const bool upper = t & 1u;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        const uint64_t v = sorted[mid];
+        if (upper ? v <= x : v < x) lo = mid + 1; else hi = mid;
+    }
+    lo_hi[t] = lo;
+}
+void equal_range_u64(const uint64_t* sorted, uint32_t n, const uint64_t* probe, uint32_t n_probes, uint32_t* lo_hi, hipStream_t s) {
+    hipLaunchKernelGGL(k_equal_range_u64, dim3(grid_for(2 * n_probes, 64)), dim3(64), 0, s, sorted, n, probe, n_probes, lo_hi);
+    MMT_HIP(hipGetLastError());
+}
+
+// The suffixes sa[0 .. cnt) all begin with `chars` copies of one symbol c.  Their order is decided by where the run ends and
+// by what follows it: c^j X (X0 != c).  With X0 < c -- class 0 -- a shorter run is the smaller suffix, with X0 > c -- class 1,
+// behind all of class 0 -- the longer one; equal j: the symbols behind the run.  key2 = class | j or its complement (24
+// bits) | 12 symbols behind the run (zero behind a terminator) | 00 | "reached its terminator" -- the low bit of k_pack_keys.
+// A run of 2^24 - 1 symbols or more: the symbols behind it are left out (such suffixes tie: they agree in that many
+// characters).  ends: ascending last positions of the runs of `chars` symbols or more.
+__global__ void k_run_keys(const uint32_t* __restrict__ sa, uint32_t cnt, const uint8_t* __restrict__ text, uint32_t n,
+                           const uint8_t* __restrict__ code, int bits, int chars, const uint32_t* __restrict__ ends,
+                           uint32_t n_ends, uint64_t* __restrict__ key2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt) return;
+    const uint32_t p = sa[i];
+    const uint32_t want = p + (uint32_t)chars - 1u;                  // the run of p ends at the first listed end >= want
+    uint32_t lo = 0, hi = n_ends;
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (ends[mid] < want) lo = mid + 1; else hi = mid; }
+    const uint32_t e = lo < n_ends ? ends[lo] : want;                // (cannot be missing: every run of that length is listed)
+    const uint32_t c = code[text[p]];
+    const uint32_t CAP = 0xffffffu;
+    uint32_t j = e - p + 1u;
+    const bool capped = j >= CAP;
+    if (capped) j = CAP;
+    const uint32_t x0 = e + 1u < n ? code[text[e + 1u]] : 0u;
+    const uint64_t cls = x0 > c ? 1ull : 0ull;
+    uint64_t k = (cls << 63) | ((uint64_t)(cls ? CAP - j : j) << 39);
+    if (!capped) {
+        uint64_t x = 0, fin = 0;
+        for (uint32_t t = 0; t < 12u; t++) {
+            const uint32_t q = e + 1u + t;
+            const uint32_t sym = q < n ? code[text[q]] : 0u;
+            x = (x << bits) | sym;
+            if (sym == 0u) { x <<= bits * (11u - t); fin = 1; break; }     // a terminator: nothing behind it is compared
+        }
+        k |= (x << 3) | fin;
+    }
+    key2[i] = k;
+}
+void run_keys(const uint32_t* sa, uint32_t cnt, const uint8_t* text, uint32_t n, const uint8_t* code, int bits, int chars,
+              const uint32_t* ends, uint32_t n_ends, uint64_t* key2, hipStream_t s) {
+    if (bits > 3) throw std::runtime_error("run_keys: symbols wider than three bits");
+    hipLaunchKernelGGL(k_run_keys, dim3(grid_for(cnt, 256)), dim3(256), 0, s, sa, cnt, text, n, code, bits, chars, ends, n_ends, key2);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_force_heads(uint32_t* __restrict__ headval, const uint32_t* __restrict__ at, uint32_t cnt, uint32_t n) {
+    const uint32_t t = threadIdx.x;
+    if (t < cnt && at[t] < n) headval[at[t]] = at[t];
+}
+void force_heads(uint32_t* headval, const uint32_t* at, uint32_t cnt, uint32_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_force_heads, dim3(1), dim3(64), 0, s, headval, at, cnt, n);
     MMT_HIP(hipGetLastError());
 }
 

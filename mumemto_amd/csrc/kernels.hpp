@@ -44,7 +44,14 @@ void unpack_text(const TextRef& T, uint64_t first, uint64_t count, uint8_t* out,
 // bit and bits * chars + 1 <= 64 must hold (see kernels.hip).
 static const uint32_t PACK_NO_SEP = 0xffffffffu;
 void pack_keys(const uint8_t* text, uint32_t n, const uint8_t* d_code, int bits, int chars, uint32_t sep_code,
-               uint64_t* keys, uint32_t* vals, hipStream_t s);
+               uint64_t* keys, uint32_t* vals, hipStream_t s, uint32_t* run_ends = nullptr, uint32_t* run_count = nullptr,
+               uint32_t run_cap = 0);
+// run_ends / run_count (pack_keys): the last position of every run of `chars` or more equal symbols, in any order; *run_count
+// counts them all (more than run_cap: the list is incomplete).  The helpers of DoublingSorter's RunRefine (sorter.hpp):
+void equal_range_u64(const uint64_t* sorted, uint32_t n, const uint64_t* probe, uint32_t n_probes, uint32_t* lo_hi, hipStream_t s);
+void run_keys(const uint32_t* sa, uint32_t cnt, const uint8_t* text, uint32_t n, const uint8_t* code, int bits, int chars,
+              const uint32_t* ends, uint32_t n_ends, uint64_t* key2, hipStream_t s);
+void force_heads(uint32_t* headval, const uint32_t* at, uint32_t cnt, uint32_t n, hipStream_t s);
 // headval[j] = j if keys[j] != keys[j-1] (or j == 0) else 0
 // lsb_unique: a key with its low bit set is a bucket of its own
 void mark_heads(const uint64_t* keys, uint32_t n, uint32_t* headval, bool lsb_unique, hipStream_t s);

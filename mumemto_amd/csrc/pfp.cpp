@@ -214,8 +214,32 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     S.sa_d.ensure(nd); S.rank_d.ensure(nd);
     sorter_.reserve(slim ? nd : std::max(nd, m));
-    k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st);
-    S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true);
+    // long runs of one symbol (assembly gaps, homopolymers): their ends are listed while the keys are packed, and the sorter
+    // orders the suffixes inside them by (end of the run, what follows) instead of doubling its way through (sorter.hpp)
+    const uint32_t run_cap = 1u << 20;
+    DevBuf<uint32_t> run_ends, run_sorted, run_count;
+    const bool want_runs = bits <= 3 && !std::getenv("MMT_NO_RUN_REFINE");          // (MMT_NO_RUN_REFINE: plain doubling, A/B)
+    if (want_runs) {
+        run_ends.ensure(run_cap); run_count.ensure(4);
+        MMT_HIP(hipMemsetAsync(run_count.get(), 0, 16, st));
+    }
+    k::pack_keys(S.dict.get(), nd, d_code_.get(), bits, chars, (uint32_t)code[1], sorter_.keys_in(), sorter_.vals_in(), st,
+                 want_runs ? run_ends.get() : nullptr, want_runs ? run_count.get() : nullptr, run_cap);
+    RunRefine runs;
+    if (want_runs) {
+        const uint32_t found = read_u32(run_count.get(), st);
+        if (found && found <= run_cap) {                     // (more than the list holds: plain doubling)
+            run_sorted.ensure((size_t)found * 3);            // sorted ends | two columns of dummy values
+            MMT_HIP(hipMemsetAsync(run_sorted.get() + found, 0, (size_t)found * 4, st));
+            prims::sort_pairs_u32_u32(d_temp_, run_ends.get(), run_sorted.get(), run_sorted.get() + found,
+                                      run_sorted.get() + 2 * (size_t)found, found, 0, 32, st);
+            runs.text = S.dict.get(); runs.n = nd; runs.code = d_code_.get(); runs.bits = bits; runs.chars = chars; runs.sigma = sigma;
+            runs.ends = run_sorted.get(); runs.n_ends = found;
+        }
+    }
+    S.rounds_dict = sorter_.sort(nd, bits * chars + 1, (uint64_t)chars, S.sa_d.get(), S.rank_d.get(), d_temp_, st, true,
+                                 runs.n_ends ? &runs : nullptr);
+    S.run_refined = sorter_.run_refined();
     // (the sorter's 49 bytes per dictionary character were the idle half of the run's peak while the tables of the dictionary
     // were built: a fresh process maps, and gives back at its end, every byte of that peak)
     if (slim) { MMT_HIP(hipStreamSynchronize(st)); sorter_.release(); S.rank_d.release(); }

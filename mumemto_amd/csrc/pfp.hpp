@@ -18,6 +18,7 @@ struct PfpState {
     bool guided = false;    // the dictionary stage was skipped: Engine::suffix_sort_guided sorts the text suffixes themselves
     bool expand = false;    // ... one representative per (distinct phrase, offset) only, expanded by the emitter (guided.cpp)
     int rounds_dict = 0, rounds_parse = 0;
+    uint64_t run_refined = 0;         // dictionary suffixes ordered by their long run of one symbol (sorter.hpp, RunRefine)
     float ms[8] = {0};   // parse, dedup, dict build, dict SA, dict LCP + groups, parse SA, inverted lists + emitter, total
     DevBuf<uint8_t> dict, ptab, pinfo;   // pinfo: 16-byte record per phrase (k_phrase_hash)  // ptab: 16-byte record per distinct phrase (phrase_table)
     DevBuf<uint16_t> tmask;             // trigger masks, one per 16 text positions

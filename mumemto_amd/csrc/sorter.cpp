@@ -62,10 +62,48 @@ void DoublingSorter::sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hi
                                                big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s);
 }
 
+// The buckets c^chars of the first sort (sorted keys in keys_b_, suffixes in sa), each sorted once more by k_run_keys' key:
+// the input keys (dead) take the new keys, the input values (dead) the sorted suffixes; the sorted new keys replace the bucket's
+// equal keys, so that mark_heads cuts it where they differ (and at its two ends, `forced`: a new key may happen to equal the
+// real key next to the bucket).  Suffixes with a set low bit are final, in position order: the sorts are stable.
+void DoublingSorter::refine_runs(uint32_t n, const RunRefine& R, uint32_t* sa, std::vector<uint32_t>& forced,
+                                 DevBuf<uint8_t>& temp, hipStream_t s) {
+    // (MMT_RUN_BUCKET: the smallest bucket that is worth a sort of its own; the tests lower it)
+    const uint32_t min_bucket = std::getenv("MMT_RUN_BUCKET") ? (uint32_t)std::atoi(std::getenv("MMT_RUN_BUCKET")) : 4096u;
+    const bool trace = std::getenv("MMT_SORT_TRACE") != nullptr;
+    const int S = std::min(R.sigma, 15);
+    std::vector<uint64_t> probe(S);
+    for (int c = 1; c <= S; c++) {
+        uint64_t k = 0;
+        for (int i = 0; i < R.chars; i++) k = (k << R.bits) | (uint64_t)c;
+        probe[c - 1] = k << 1;                                // (k_pack_keys: no terminator in the window)
+    }
+    run_probe_.ensure(S); run_range_.ensure(2 * (size_t)S);
+    MMT_HIP(hipMemcpyAsync(run_probe_.get(), probe.data(), (size_t)S * 8, hipMemcpyHostToDevice, s));
+    k::equal_range_u64(keys_b_.get(), n, run_probe_.get(), (uint32_t)S, run_range_.get(), s);
+    std::vector<uint32_t> range(2 * (size_t)S);
+    MMT_HIP(hipMemcpyAsync(range.data(), run_range_.get(), range.size() * 4, hipMemcpyDeviceToHost, s));
+    MMT_HIP(hipStreamSynchronize(s));
+    for (int c = 0; c < S; c++) {
+        const uint32_t lo = range[2 * c], hi = range[2 * c + 1];
+        if (hi - lo < min_bucket) continue;
+        const uint32_t cnt = hi - lo;
+        k::run_keys(sa + lo, cnt, R.text, R.n, R.code, R.bits, R.chars, R.ends, R.n_ends, keys_a_.get() + lo, s);
+        prims::sort_pairs_u64_u32(temp, keys_a_.get() + lo, keys_b_.get() + lo, sa + lo, sac_a_.get() + lo, cnt, 0, 64, s);
+        MMT_HIP(hipMemcpyAsync(sa + lo, sac_a_.get() + lo, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
+        forced.push_back(lo); forced.push_back(hi);
+        run_refined_ += cnt;
+        if (trace) std::fprintf(stderr, "[sort] bucket of %u suffixes inside long runs of symbol %d: ordered by (end of the run, what follows)\n", cnt, c + 1);
+    }
+}
+
 int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, uint32_t* rank, DevBuf<uint8_t>& temp,
-                         hipStream_t s, bool lsb_unique) {
+                         hipStream_t s, bool lsb_unique, const RunRefine* runs) {
     reserve(n);
     prims::sort_pairs_u64_u32(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sa, n, 0, std::min(64, key_bits), s);
+    run_refined_ = 0;
+    std::vector<uint32_t> forced;
+    if (runs && runs->n_ends && lsb_unique && !std::getenv("MMT_NO_RUN_REFINE")) refine_runs(n, *runs, sa, forced, temp, s);
     // the input keys are dead: their column holds the head marks and the index list; the sorted keys die with mark_heads:
     // their column holds the heads and the flags (n entries each, at fixed places, for every later round as well)
     uint32_t* const headval = reinterpret_cast<uint32_t*>(keys_a_.get());
@@ -78,6 +116,12 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
         MMT_HIP(hipEventCreateWithFlags(&ev_side_, hipEventDisableTiming));
     }
     k::mark_heads(keys_b_.get(), n, headval, lsb_unique, s);
+    if (!forced.empty()) {
+        run_range_.ensure(forced.size());
+        MMT_HIP(hipMemcpyAsync(run_range_.get(), forced.data(), forced.size() * 4, hipMemcpyHostToDevice, s));
+        k::force_heads(headval, run_range_.get(), (uint32_t)forced.size(), n, s);
+        MMT_HIP(hipStreamSynchronize(s));                     // (`forced` is host memory of this call)
+    }
     prims::inclusive_max_u32(temp, headval, head, n, s);
     // every rank once (random stores: latency) on the second stream, beside the selection of the tied suffixes (streams)
     if (side_) {

@@ -13,6 +13,7 @@ ap.add_argument("--length", type=int, default=64_000_000)
 ap.add_argument("--divergence", type=float, default=0.001)
 ap.add_argument("--seed", type=int, default=3)
 ap.add_argument("--args", default="", help="extra arguments of mumemto_exec, space separated")
+ap.add_argument("--stderr", default="", help="print the lines of mumemto_exec's stderr that contain this text (e.g. '[sort]')")
 ap.add_argument("variants", nargs="+")
 a = ap.parse_args()
 d = "/dev/shm/emit_ab"
@@ -42,6 +43,10 @@ for rep in range(a.reps):
         if r.returncode != 0 or not os.path.exists(stats):
             print("%-14s rc %d %s" % (name, r.returncode, r.stderr[-300:].replace("\n", " | ")), flush=True)
             continue
+        if a.stderr:
+            for line in r.stderr.split("\n"):
+                if a.stderr in line:
+                    print("    " + line, flush=True)
         st = json.load(open(stats))
         out = os.path.join(d, "out.mums" if os.path.exists(os.path.join(d, "out.mums")) else "out.mems")
         hsh = hashlib.sha256()

@@ -156,3 +156,50 @@ def test_realistic_anchor_next_to_one_whole_genome_haplotype():
         bigchecks.check_mum_rows(eng, bases, lens)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed,bucket", [(1, "2"), (2, "2"), (3, "64"), (4, None)])
+def test_long_runs_of_one_symbol_in_the_dictionary_equal_the_oracle(seed, bucket):
+    """Runs of 21 or more equal symbols -- assembly gaps, homopolymers -- put every suffix inside them into ONE bucket of the
+    dictionary's first sort; the sorter orders that bucket once by (class of the symbol behind the run, length of the run that is
+    left, the symbols behind it) instead of doubling through it (sorter.cpp refine_runs, kernels.hip k_run_keys).  Here: runs of
+    every symbol, of lengths around the key length and far beyond it, at the ends of documents, next to each other, copied
+    between haplotypes with substitutions inside and behind them, and broken by insertions -- stream and rows against the
+    oracle through the parse proper, with the bucket threshold lowered so that small buckets take the path too."""
+    import mumemto_amd
+    rng = np.random.default_rng(900 + seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    anc = acgt[rng.integers(0, 4, size=60_000)].copy()
+    for _ in range(60):
+        c = b"ACGTN"[int(rng.integers(0, 5))]
+        k = int(rng.choice([20, 21, 22, 23, 40, 64, 100, 333, 1500]))
+        a = int(rng.integers(0, len(anc) - k))
+        anc[a:a + k] = c
+    anc[:400] = ord("N"); anc[-300:] = ord("A")             # runs at both ends of every document
+    docs = []
+    for h in range(5):
+        s = anc.copy()
+        pos = rng.integers(0, len(s), size=120)
+        s[pos] = acgt[rng.integers(0, 4, size=len(pos))]     # substitutions: also inside runs (they break them)
+        cut = int(rng.integers(0, 50))
+        docs.append([s[cut:].tobytes()])
+    if bucket is not None:
+        os.environ["MMT_RUN_BUCKET"] = bucket
+    eng = mumemto_amd.Engine(0)
+    try:
+        eng.set_producer("pfp", 10, 30)
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        for kw in (dict(), dict(num_distinct=4, max_doc_freq=2)):
+            eng.set_docs(docs)
+            eng.run(**kw)
+            assert producer_is(eng, "pfp")
+            assert eng.output_text() == O.run(docs, **kw).text(), (seed, kw)
+        assert np.array_equal(eng.sa().astype(np.int64), sa[1:])
+        assert np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
+        assert np.array_equal(eng.bwt(), bwt[1:])
+        if bucket is not None:
+            assert eng.pfp_counts()["run_refined"] > 0
+    finally:
+        os.environ.pop("MMT_RUN_BUCKET", None)
+        eng.close()

@@ -226,15 +226,183 @@ void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint3
 // into one bucket of a doubling round, and such a round then takes hundreds of milliseconds), so the range list is read
 // on the host and a range beyond GIANT elements gets a device-wide radix sort of its own; the others share one
 // segmented sort as before.  MMT_GIANT_RANGE overrides the threshold (tests).
+// Ranges whose keys already say which range an element belongs to -- the rounds of the suffix sorter: key = (head of the bucket
+// << shift) | rank of the suffix h characters on, buckets in suffix-array order -- need no segmented sort at all: the elements
+// of ALL ranges are gathered into one compact array, sorted by ONE device-wide radix sort, and written back range by range
+// (range r keeps the slots [off[r], off[r + 1]) of the sorted array: every key of a range is above every key of the range
+// before).  A round of a realistic dictionary lists thousands of long ranges of very different lengths; one sort per giant
+// range plus a segmented sort for the rest was 2,400 radix passes, 13,000 merge kernels and 4,000 memsets per step (~390 ms
+// of kernels, profiles/round5_realistic_*): this is three kernels and one sort per round.
+template <typename K, typename V>
+__global__ void k_ranges_gather(const K* __restrict__ kin, const V* __restrict__ vin, const uint32_t* __restrict__ begin,
+                                const uint32_t* __restrict__ off, uint32_t ranges, uint32_t total, K* __restrict__ gk,
+                                V* __restrict__ gv) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    uint32_t lo = 0, hi = ranges;                               // last range with off[r] <= c
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
+    const uint32_t src = begin[lo] + (c - off[lo]);
+    gk[c] = kin[src]; gv[c] = vin[src];
+}
+template <typename K, typename V>
+__global__ void k_ranges_scatter(const K* __restrict__ gk, const V* __restrict__ gv, const uint32_t* __restrict__ begin,
+                                 const uint32_t* __restrict__ off, uint32_t ranges, uint32_t total, K* __restrict__ kout,
+                                 V* __restrict__ vout) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    uint32_t lo = 0, hi = ranges;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
+    const uint32_t dst = begin[lo] + (c - off[lo]);
+    kout[dst] = gk[c]; vout[dst] = gv[c];
+}
+template <typename K, typename V>
+static bool sort_ranges_as_one(DevBuf<uint8_t>& temp, const K* kin, K* kout, const V* vin, V* vout,
+                               std::vector<uint32_t>& hb, std::vector<uint32_t>& he, int end_bit, hipStream_t s) {
+    const uint32_t R = (uint32_t)hb.size();
+    std::vector<uint32_t> order(R);
+    for (uint32_t i = 0; i < R; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hb[a] < hb[b]; });
+    std::vector<uint32_t> tab(2 * (size_t)R + 1);             // begin[R] | off[R + 1]
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < R; i++) {
+        const uint32_t r = order[i];
+        if (i && hb[r] < he[order[i - 1]]) return false;      // (overlapping ranges: not this path)
+        tab[i] = hb[r]; tab[R + i] = (uint32_t)total;
+        total += he[r] - hb[r];
+    }
+    tab[2 * (size_t)R] = (uint32_t)total;
+    static const uint64_t limit = std::getenv("MMT_RANGES_AS_ONE_MAX") ? std::strtoull(std::getenv("MMT_RANGES_AS_ONE_MAX"), nullptr, 10)
+                                                                      : (uint64_t)400000000ull;
+    if (total == 0 || total > limit) return false;
+    const uint32_t T = (uint32_t)total;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t kb = up((size_t)T * sizeof(K)), vb = up((size_t)T * sizeof(V)), tb = up(tab.size() * 4);
+    size_t bytes = 0;
+    {
+        rocprim::double_buffer<K> dk(nullptr, nullptr);
+        rocprim::double_buffer<V> dv(nullptr, nullptr);
+        MMT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, dk, dv, (size_t)T, 0u, (unsigned)end_bit, s));
+    }
+    const size_t head = up(bytes);
+    temp.ensure(head + 2 * kb + 2 * vb + tb + 256);
+    uint8_t* base = temp.get() + head;
+    K* k0 = reinterpret_cast<K*>(base); K* k1 = reinterpret_cast<K*>(base + kb);
+    V* v0 = reinterpret_cast<V*>(base + 2 * kb); V* v1 = reinterpret_cast<V*>(base + 2 * kb + vb);
+    uint32_t* dtab = reinterpret_cast<uint32_t*>(base + 2 * kb + 2 * vb);
+    MMT_HIP(hipMemcpyAsync(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    const uint32_t blocks = (T + 255) / 256;
+    hipLaunchKernelGGL((k_ranges_gather<K, V>), dim3(blocks), dim3(256), 0, s, kin, vin, dtab, dtab + R, R, T, k0, v0);
+    rocprim::double_buffer<K> dk(k0, k1);
+    rocprim::double_buffer<V> dv(v0, v1);
+    MMT_HIP(rocprim::radix_sort_pairs(temp.get(), bytes, dk, dv, (size_t)T, 0u, (unsigned)end_bit, s));
+    hipLaunchKernelGGL((k_ranges_scatter<K, V>), dim3(blocks), dim3(256), 0, s, dk.current(), dv.current(), dtab, dtab + R, R, T,
+                       kout, vout);
+    MMT_HIP(hipGetLastError());
+    MMT_HIP(hipStreamSynchronize(s));                         // (`tab` is host memory of this call)
+    return true;
+}
+
+// 32-bit keys that do NOT say which range they belong to (the oversized groups of the emitter: key = parse rank) get the
+// range's ordinal in front of them for the one sort: 64-bit keys (ordinal << 32) | key in the compact array, the low word
+// written back.
+template <typename V>
+__global__ void k_ranges_gather_tagged(const uint32_t* __restrict__ kin, const V* __restrict__ vin, const uint32_t* __restrict__ begin,
+                                       const uint32_t* __restrict__ off, uint32_t ranges, uint32_t total, uint64_t* __restrict__ gk,
+                                       V* __restrict__ gv) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    uint32_t lo = 0, hi = ranges;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
+    const uint32_t src = begin[lo] + (c - off[lo]);
+    gk[c] = ((uint64_t)lo << 32) | kin[src]; gv[c] = vin[src];
+}
+template <typename V>
+__global__ void k_ranges_scatter_tagged(const uint64_t* __restrict__ gk, const V* __restrict__ gv, const uint32_t* __restrict__ begin,
+                                        const uint32_t* __restrict__ off, uint32_t ranges, uint32_t total, uint32_t* __restrict__ kout,
+                                        V* __restrict__ vout) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= total) return;
+    uint32_t lo = 0, hi = ranges;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= c) lo = mid; else hi = mid; }
+    const uint32_t dst = begin[lo] + (c - off[lo]);
+    kout[dst] = (uint32_t)gk[c]; vout[dst] = gv[c];
+}
+template <typename V>
+static bool sort_ranges_as_one_tagged(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const V* vin, V* vout,
+                                      std::vector<uint32_t>& hb, std::vector<uint32_t>& he, int end_bit, hipStream_t s) {
+    const uint32_t R = (uint32_t)hb.size();
+    std::vector<uint32_t> order(R);
+    for (uint32_t i = 0; i < R; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hb[a] < hb[b]; });
+    std::vector<uint32_t> tab(2 * (size_t)R + 1);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < R; i++) {
+        const uint32_t r = order[i];
+        if (i && hb[r] < he[order[i - 1]]) return false;
+        tab[i] = hb[r]; tab[R + i] = (uint32_t)total;
+        total += he[r] - hb[r];
+    }
+    tab[2 * (size_t)R] = (uint32_t)total;
+    static const uint64_t limit = std::getenv("MMT_RANGES_AS_ONE_MAX") ? std::strtoull(std::getenv("MMT_RANGES_AS_ONE_MAX"), nullptr, 10)
+                                                                      : (uint64_t)400000000ull;
+    if (total == 0 || total > limit) return false;
+    const uint32_t T = (uint32_t)total;
+    int rbits = 1;
+    while ((1ull << rbits) < (uint64_t)R) rbits++;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t kb = up((size_t)T * 8), vb = up((size_t)T * sizeof(V)), tb = up(tab.size() * 4);
+    size_t bytes = 0;
+    {
+        rocprim::double_buffer<uint64_t> dk(nullptr, nullptr);
+        rocprim::double_buffer<V> dv(nullptr, nullptr);
+        MMT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, dk, dv, (size_t)T, 0u, 32u + (unsigned)rbits, s));
+    }
+    const size_t head = up(bytes);
+    temp.ensure(head + 2 * kb + 2 * vb + tb + 256);
+    uint8_t* base = temp.get() + head;
+    uint64_t* k0 = reinterpret_cast<uint64_t*>(base); uint64_t* k1 = reinterpret_cast<uint64_t*>(base + kb);
+    V* v0 = reinterpret_cast<V*>(base + 2 * kb); V* v1 = reinterpret_cast<V*>(base + 2 * kb + vb);
+    uint32_t* dtab = reinterpret_cast<uint32_t*>(base + 2 * kb + 2 * vb);
+    MMT_HIP(hipMemcpyAsync(dtab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    const uint32_t blocks = (T + 255) / 256;
+    hipLaunchKernelGGL((k_ranges_gather_tagged<V>), dim3(blocks), dim3(256), 0, s, kin, vin, dtab, dtab + R, R, T, k0, v0);
+    rocprim::double_buffer<uint64_t> dk(k0, k1);
+    rocprim::double_buffer<V> dv(v0, v1);
+    // (the key bits at and above end_bit are not part of the order inside a range: they are zero in the callers' keys or must
+    // be ignored -- the bits between end_bit and 32 are left out of the sort by two calls when there are any)
+    if (end_bit >= 32) {
+        MMT_HIP(rocprim::radix_sort_pairs(temp.get(), bytes, dk, dv, (size_t)T, 0u, 32u + (unsigned)rbits, s));
+    } else {
+        MMT_HIP(rocprim::radix_sort_pairs(temp.get(), bytes, dk, dv, (size_t)T, 0u, (unsigned)end_bit, s));
+        MMT_HIP(rocprim::radix_sort_pairs(temp.get(), bytes, dk, dv, (size_t)T, 32u, 32u + (unsigned)rbits, s));
+    }
+    hipLaunchKernelGGL((k_ranges_scatter_tagged<V>), dim3(blocks), dim3(256), 0, s, dk.current(), dv.current(), dtab, dtab + R, R, T,
+                       kout, vout);
+    MMT_HIP(hipGetLastError());
+    MMT_HIP(hipStreamSynchronize(s));
+    return true;
+}
+
 template <typename K, typename V>
 static void sort_ranges(DevBuf<uint8_t>& temp, const K* kin, K* kout, const V* vin, V* vout, uint32_t n,
-                        uint32_t segments, const uint32_t* begin, const uint32_t* end, int end_bit, hipStream_t s) {
+                        uint32_t segments, const uint32_t* begin, const uint32_t* end, int end_bit, hipStream_t s,
+                        bool keys_order_the_ranges = false) {
     static const uint32_t GIANT = std::getenv("MMT_GIANT_RANGE") ? (uint32_t)std::atoi(std::getenv("MMT_GIANT_RANGE")) : 65536u;
     if (!segments) return;
     std::vector<uint32_t> hb(segments), he(segments);
     MMT_HIP(hipMemcpyAsync(hb.data(), begin, (size_t)segments * 4, hipMemcpyDeviceToHost, s));
     MMT_HIP(hipMemcpyAsync(he.data(), end, (size_t)segments * 4, hipMemcpyDeviceToHost, s));
     MMT_HIP(hipStreamSynchronize(s));
+    // (MMT_RANGES_AS_ONE=0: the older route -- a sort per giant range, a segmented sort for the rest --, A/B and tests)
+    static const bool as_one = !(std::getenv("MMT_RANGES_AS_ONE") && std::atoi(std::getenv("MMT_RANGES_AS_ONE")) == 0);
+    if (keys_order_the_ranges && as_one && sort_ranges_as_one(temp, kin, kout, vin, vout, hb, he, end_bit, s)) return;
+    if constexpr (sizeof(K) == 4) {
+        // many ranges, or any range one workgroup would be busy with for long: one sort of tagged keys
+        bool any_long = false;
+        for (uint32_t i = 0; i < segments && !any_long; i++) any_long = he[i] - hb[i] > GIANT / 2;
+        if (!keys_order_the_ranges && as_one && any_long &&
+            sort_ranges_as_one_tagged(temp, kin, kout, vin, vout, hb, he, end_bit, s)) return;
+    }
     // a range is "giant" when one workgroup would still be busy with it long after the other ranges, which share the
     // chip a few hundred at a time, are done: beyond GIANT elements and four times the 256th longest range
     uint32_t thresh = GIANT;
@@ -303,8 +471,8 @@ void segmented_sort_pairs_u32_u64vals_ranges(DevBuf<uint8_t>& temp, const uint32
 
 void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
-                                     const uint32_t* end, int end_bit, hipStream_t s) {
-    sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s);
+                                     const uint32_t* end, int end_bit, hipStream_t s, bool keys_order_the_ranges) {
+    sort_ranges(temp, kin, kout, vin, vout, n, segments, begin, end, end_bit, s, keys_order_the_ranges);
 }
 
 void segmented_sort_pairs_u64_u64vals_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,

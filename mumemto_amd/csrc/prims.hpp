@@ -39,10 +39,12 @@ void segmented_sort_pairs_u32_u64vals_ranges(DevBuf<uint8_t>& temp, const uint32
                                              uint64_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
                                              const uint32_t* end, int end_bit, hipStream_t s);
 
-// 64-bit keys, ranges [begin[i], end[i]) of one array; elements outside the ranges are not touched
+// 64-bit keys, ranges [begin[i], end[i]) of one array; elements outside the ranges are not touched.
+// keys_order_the_ranges: every key of a range is above every key of the ranges that begin before it (the sorter's round keys
+// carry the bucket in their high bits): all ranges then go through ONE device-wide sort (prims.hip, sort_ranges_as_one)
 void segmented_sort_pairs_u64_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint32_t* vin,
                                      uint32_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,
-                                     const uint32_t* end, int end_bit, hipStream_t s);
+                                     const uint32_t* end, int end_bit, hipStream_t s, bool keys_order_the_ranges = false);
 
 void segmented_sort_pairs_u64_u64vals_ranges(DevBuf<uint8_t>& temp, const uint64_t* kin, uint64_t* kout, const uint64_t* vin,
                                              uint64_t* vout, uint32_t n, uint32_t segments, const uint32_t* begin,

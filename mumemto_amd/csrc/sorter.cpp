@@ -59,7 +59,7 @@ void DoublingSorter::sort_round(uint32_t m, int shift, DevBuf<uint8_t>& temp, hi
     }
     if (big)
         prims::segmented_sort_pairs_u64_ranges(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m, big,
-                                               big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s);
+                                               big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s, true);
 }
 
 // The buckets c^chars of the first sort (sorted keys in keys_b_, suffixes in sa), each sorted once more by k_run_keys' key:
@@ -184,7 +184,7 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
                     k::round_big_keys(tile_big_.get(), bound_.get(), target, n_tiles, sac_a_.get(), headc_.get(), rank, n, hh,
                                       shift, keys_a_.get(), s);
                     prims::segmented_sort_pairs_u64_ranges(temp, keys_a_.get(), keys_b_.get(), sac_a_.get(), sac_b_.get(), m,
-                                                           big, big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s);
+                                                           big, big_begin_.get(), big_end_.get(), std::min(64, 2 * shift), s, true);
                     k::round_big_subheads(tile_big_.get(), bound_.get(), target, n_tiles, keys_b_.get(), pos_a_.get(), head_w, s);
                     prims::inclusive_max_u32(temp, head_w, head_w, m, s);
                     k::round_big_apply(tile_big_.get(), bound_.get(), target, n_tiles, m, sac_b_.get(), head_w, pos_a_.get(),

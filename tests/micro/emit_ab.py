@@ -13,6 +13,7 @@ ap.add_argument("--length", type=int, default=64_000_000)
 ap.add_argument("--divergence", type=float, default=0.001)
 ap.add_argument("--seed", type=int, default=3)
 ap.add_argument("--args", default="", help="extra arguments of mumemto_exec, space separated")
+ap.add_argument("--pause", type=float, default=7.0)
 ap.add_argument("--stderr", default="", help="print the lines of mumemto_exec's stderr that contain this text (e.g. '[sort]')")
 ap.add_argument("variants", nargs="+")
 a = ap.parse_args()
@@ -36,7 +37,7 @@ for rep in range(a.reps):
             env[k] = val
         if os.path.exists(stats):
             os.unlink(stats)
-        time.sleep(3)
+        time.sleep(a.pause)        # (the memory of the process before is still being wiped: a process that maps its heap too early waits for it)
         t = time.perf_counter()
         r = subprocess.run([exe, "-o", os.path.join(d, "out")] + a.args.split() + paths, capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t
@@ -53,7 +54,8 @@ for rep in range(a.reps):
         with open(out, "rb") as f:
             for blk in iter(lambda: f.read(1 << 24), b""):
                 hsh.update(blk)
-        print("%-14s %.3f s wall | %s | pfp %s | sha %s rows %d" % (
+        print("%-14s %.3f s wall | %s | pfp %s | heap peak %.1f GB, mapped %.1f GB in %.3f s | sha %s rows %d" % (
             name, dt, " ".join("%s %.1f" % (n, x) for n, x in zip(names, st["stage_ms"])),
-            " ".join("%.0f" % x for x in st["pfp_ms"]), hsh.hexdigest()[:16], st["rows"]), flush=True)
+            " ".join("%.0f" % x for x in st["pfp_ms"]), st["heap_peak_bytes"] / 2**30, st["heap_mapped_bytes"] / 2**30,
+            st["heap_map_seconds"], hsh.hexdigest()[:16], st["rows"]), flush=True)
 shutil.rmtree(d, ignore_errors=True)

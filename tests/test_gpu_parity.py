@@ -368,7 +368,7 @@ def test_long_matches_and_rare_construction_paths(env):
 
 
 @pytest.mark.parametrize("producer", ["pfp", "direct"])
-@pytest.mark.parametrize("giant", ["3000", None])
+@pytest.mark.parametrize("giant", ["3000", None, "3000 old route", "run buckets"])
 def test_letter_runs_make_giant_sort_ranges(producer, giant):
     """Runs of N / homopolymers put tens of thousands of suffixes into one bucket of a doubling round (and one group of
     the PFP emitter); ranges beyond MMT_GIANT_RANGE elements are sorted device-wide instead of by one workgroup of the
@@ -377,8 +377,12 @@ def test_letter_runs_make_giant_sort_ranges(producer, giant):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MUMEMTO_PRODUCER=producer)
-    if giant:
-        env["MMT_GIANT_RANGE"] = giant
+    if giant == "run buckets":        # every bucket of a long run of one symbol ordered by the end of its run (sorter.cpp refine_runs)
+        env["MMT_RUN_BUCKET"] = "2"
+    elif giant:
+        env["MMT_GIANT_RANGE"] = giant.split()[0]
+        if "old route" in giant:      # a sort per giant range + a segmented sort for the rest, instead of all ranges as one sort
+            env["MMT_RANGES_AS_ONE"] = "0"
     r = subprocess.run([sys.executable, os.path.join(here, "scan_shape_check.py"), "5", "30000", "runs"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "scan shapes ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -387,7 +391,9 @@ def test_letter_runs_make_giant_sort_ranges(producer, giant):
 @pytest.mark.parametrize("producer", ["pfp", "direct"])
 @pytest.mark.parametrize("env", [{"MMT_SORT_FUSED": "0"}, {"MMT_ROUND_CAP": "1024", "MMT_GIANT_RANGE": "3000"},
                                  {"MMT_SORT_ONE_STREAM": "1", "MMT_SORT_ALL_RANKS": "1"}, {"MMT_ROUND_CAP": "1536"},
-                                 {"MMT_ROUND_CAP": "1024", "MMT_BIG_CAP": "1"}])
+                                 {"MMT_ROUND_CAP": "1024", "MMT_BIG_CAP": "1"},
+                                 {"MMT_ROUND_CAP": "1024", "MMT_RANGES_AS_ONE": "0"}, {"MMT_SORT_FUSED": "0", "MMT_RANGES_AS_ONE": "0"},
+                                 {"MMT_ROUND_CAP": "1024", "MMT_NO_RUN_REFINE": "1"}])
 def test_doubling_round_paths(producer, env):
     """A doubling round of the suffix sorter is one pass over the active list (k_round_fused + the scatter of the changed
     ranks on a second stream), with the ranges beyond an LDS tile finished around a segmented sort (k_big_*).  The

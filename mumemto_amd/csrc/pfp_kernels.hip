@@ -1346,21 +1346,9 @@ struct EmitTile {
     uint32_t many;                     // some group of the piece has more runs than many_runs
 };
 
-// the row of entry (first entry of the piece + tid), requested while the tile before is being expanded (k_emit2)
-struct EmitRow { uint32_t st, gs, fi, om, bw; };
-template <typename P, typename SA>
-__device__ __forceinline__ EmitRow emit_row_load(const EmitArgsT<P, SA>& a, uint32_t e, P clo) {
-    EmitRow r;
-    r.st = (uint32_t)(a.ce_eoff[e] - clo);
-    r.gs = a.ce_gs[e];                                       // group id + 1 at the first entry of a group
-    r.fi = a.ce_first[e]; r.om = a.ce_offm1[e];
-    r.bw = a.ce_bwt[e];
-    return r;
-}
-
 template <int BLOCK, int CAP, typename P, typename SA>
 __device__ __forceinline__ void emit_tile_piece(const EmitArgsT<P, SA>& a, EmitTile<BLOCK, CAP>& sh, uint32_t e0, uint32_t e1,
-                                                P clo, uint32_t L, const EmitRow* pre = nullptr) {
+                                                P clo, uint32_t L) {
     using Sh = EmitTile<BLOCK, CAP>;
     constexpr int PER = CAP / BLOCK;
     constexpr uint32_t MW = CAP / 32;
@@ -1369,9 +1357,10 @@ __device__ __forceinline__ void emit_tile_piece(const EmitArgsT<P, SA>& a, EmitT
     const uint64_t pos_mask = (1ull << a.pos_bits) - 1ull;
     __syncthreads();                                         // the piece before is written out; the masks are zero
     for (uint32_t e = tid; e < E; e += BLOCK) {
-        const EmitRow row = pre && e == tid ? *pre : emit_row_load(a, e0 + e, clo);
-        const uint32_t st = row.st, gs = row.gs, fi = row.fi, om = row.om;
-        const uint8_t bw = (uint8_t)row.bw;
+        const uint32_t st = (uint32_t)(a.ce_eoff[e0 + e] - clo);
+        const uint32_t gs = a.ce_gs[e0 + e];                 // group id + 1 at the first entry of a group
+        const uint32_t fi = a.ce_first[e0 + e], om = a.ce_offm1[e0 + e];
+        const uint8_t bw = a.ce_bwt[e0 + e];
         sh.estart[e] = (uint16_t)st;
         sh.efirst[e] = fi;
         sh.eoffm1[e] = om;
@@ -1579,22 +1568,14 @@ __global__ __launch_bounds__(BLOCK, 7) void k_emit2(EmitArgsT<P, SA> a, const Em
     if (t >= n_tiles) return;
     if (tid < CAP / 32) sh.omask[tid] = 0u;
     if (tid <= CAP / 32) sh.gmask[tid] = 0u;
-    // The record of a tile is requested two tiles ahead and the entry rows of its first piece one tile ahead: of the three
-    // dependent round trips of a piece (entry rows -> occurrence records -> range minima) the first one is gone.
     EmitDesc d = desc[t];
-    EmitDesc dn = d;
-    if (t + gridDim.x < n_tiles) dn = desc[t + gridDim.x];
-    EmitRow row = {0u, 0u, 0u, 0u, 0u};
-    if (tid < d.e1 - d.e0) row = emit_row_load(a, d.e0 + tid, (P)((a.tile_lo + t) * TILE) + d.clo);
     for (;;) {
-        const uint32_t t_next = t + gridDim.x, t_nn = t_next + gridDim.x;
-        EmitDesc dnn = dn;
-        if (t_nn < n_tiles) dnn = desc[t_nn];
-        EmitRow row_n = {0u, 0u, 0u, 0u, 0u};
-        if (t_next < n_tiles && tid < dn.e1 - dn.e0) row_n = emit_row_load(a, dn.e0 + tid, (P)((a.tile_lo + t_next) * TILE) + dn.clo);
+        const uint32_t t_next = t + gridDim.x;
+        EmitDesc dn = d;
+        if (t_next < n_tiles) dn = desc[t_next];
         const uint64_t tile = a.tile_lo + t;
         const P tbase = (P)(tile * TILE);
-        if (d.L) emit_tile_piece<BLOCK, CAP, P, SA>(a, sh, d.e0, d.e1, tbase + d.clo, d.L, &row);
+        if (d.L) emit_tile_piece<BLOCK, CAP, P, SA>(a, sh, d.e0, d.e1, tbase + d.clo, d.L);
         // what the first piece left of the tile (see k_emit)
         uint32_t g = d.g_next;
         const uint32_t g_end = d.g_end;
@@ -1628,7 +1609,7 @@ __global__ __launch_bounds__(BLOCK, 7) void k_emit2(EmitArgsT<P, SA> a, const Em
             g = g + 1;
         }
         if (t_next >= n_tiles) break;
-        t = t_next; d = dn; dn = dnn; row = row_n;
+        t = t_next; d = dn;
     }
 }
 

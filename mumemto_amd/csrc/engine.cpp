@@ -437,7 +437,7 @@ void Engine::release_sort_scratch() {
     std::unique_ptr<PfpState> fresh(new PfpState());
     const PfpState& S = *pfp_;
     fresh->w = S.w; fresh->p = S.p; fresh->n_cuts = S.n_cuts; fresh->n_phrases = S.n_phrases; fresh->n_distinct = S.n_distinct;
-    fresh->dict_len = S.dict_len; fresh->n_groups = S.n_groups; fresh->rounds_dict = S.rounds_dict;
+    fresh->dict_len = S.dict_len; fresh->n_groups = S.n_groups; fresh->rounds_dict = S.rounds_dict; fresh->run_refined = S.run_refined;
     fresh->rounds_parse = S.rounds_parse; fresh->n_entries = S.n_entries; fresh->n_fallback = S.n_fallback;
     fresh->emit_launches = S.emit_launches;
     fresh->bwt_ready = S.bwt_ready;

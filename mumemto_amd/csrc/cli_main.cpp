@@ -672,13 +672,101 @@ int main(int argc, char** argv) {
             up.thread.join();
         };
         struct UploadJoiner { std::function<void()> f; ~UploadJoiner() { f(); } } upload_joiner{finish_upload};
+        // Chunked input (fasta.hpp): a one-shot run never holds the collection in host memory -- every reader thread sends
+        // the bases it parses to the document's slot on the device through two page-locked 8 MB buffers of its own.  What
+        // 6 GB of anonymous host memory cost this process: ~0.2 s of page faults while it was filled and 0.3 - 0.4 s between
+        // _Exit and the parent's waitpid (tests/micro/exit_probe2.cpp; giving it back beside the run stalls the GPU's queues
+        // for as long).  A run that turns out to need host copies (anchor partitions) reads the files again.
+        struct ChunkUp {
+            std::vector<size_t> slot; size_t bytes = 0; bool on = false;
+            std::atomic<bool> skipped{false};
+            std::once_flag once; uint8_t* dev = nullptr; int device = 0;
+        } cu;
+        // (MUMEMTO_INPUT_CHUNK_MB: tuning aid; page-locked memory costs 0.19 s per GB when it is made and 0.13 s per GB at the exit)
+        const size_t CHUNK = (size_t)(std::getenv("MUMEMTO_INPUT_CHUNK_MB") ? std::max(1, std::atoi(std::getenv("MUMEMTO_INPUT_CHUNK_MB"))) : 8) << 20;
+        // (MUMEMTO_DRY_RUN_CHUNK=<bytes>, with MUMEMTO_DRY_RUN: the chunked reader into host vectors, chunks of that many bytes
+        // -- the host-side test of the chunk logic, tests/test_cli_host.py)
+        const size_t dry_chunk = dry_run && std::getenv("MUMEMTO_DRY_RUN_CHUNK") ? (size_t)std::max(1, std::atoi(std::getenv("MUMEMTO_DRY_RUN_CHUNK"))) : 0;
+        std::vector<std::vector<uint8_t>> dry_docs;
+        hooks.plan_chunks = [&](size_t bytes, const std::vector<size_t>& slot, bool all_plain) {
+            if (dry_chunk && all_plain) { dry_docs.assign(slot.size() - 1, std::vector<uint8_t>()); cu.on = true; return true; }
+            if (dry_run || !all_plain || slot.size() < 2 || std::getenv("MUMEMTO_NO_UPLOAD_OVERLAP") ||
+                std::getenv("MUMEMTO_NO_CHUNKED_INPUT") || std::getenv("MUMEMTO_KEEP_HOST_INPUT")) return false;
+            // (only collections that will clearly run as one suffix array on a device of this class: Engine::auto_max_text's
+            // formula with 200 GB in place of the free memory nobody has asked the driver for yet)
+            if (3.0 * 2.0 * (double)(bytes + slot.size()) + 24.0 * 1073741824.0 > 200.0 * 1073741824.0) return false;
+            cu.slot = slot; cu.bytes = bytes; cu.on = true;
+            return true;
+        };
+        hooks.chunks = [&](size_t i) {
+            ChunkTarget t;
+            if (dry_chunk) {
+                t.chunk = dry_chunk;
+                t.swap = [&, i](uint8_t* filled, size_t n, uint64_t offset, bool more) -> uint8_t* {
+                    static thread_local std::vector<uint8_t> two[2];
+                    for (auto& v : two) v.resize(dry_chunk);
+                    if (filled && n) {
+                        if (dry_docs[i].size() < offset + n) dry_docs[i].resize(offset + n);
+                        std::memcpy(dry_docs[i].data() + offset, filled, n);
+                    }
+                    if (!more) return nullptr;
+                    return filled == two[0].data() ? two[1].data() : two[0].data();
+                };
+                return t;
+            }
+            t.chunk = CHUNK;
+            t.swap = [&, i](uint8_t* filled, size_t n, uint64_t offset, bool more) -> uint8_t* {
+                if (cu.skipped.load()) return nullptr;
+                std::call_once(cu.once, [&]() {
+                    engine_ready.wait();
+                    const uint64_t bound = 2 * ((uint64_t)cu.bytes + cu.slot.size());
+                    if (engine_error || !engine || bound > engine->auto_max_text()) { cu.skipped.store(true); return; }
+                    cu.device = engine->device();
+                    cu.dev = engine->begin_input_slots(cu.bytes);
+                });
+                if (cu.skipped.load()) return nullptr;
+                struct Bufs { uint8_t* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
+                              hipStream_t s = nullptr; };
+                static thread_local Bufs tb;       // (they go with the process)
+                if (!tb.s) {
+                    MMT_HIP(hipSetDevice(cu.device));
+                    MMT_HIP(hipStreamCreateWithFlags(&tb.s, hipStreamNonBlocking));
+                    for (int k = 0; k < 2; k++) {
+                        MMT_HIP(hipHostMalloc(reinterpret_cast<void**>(&tb.buf[k]), CHUNK, hipHostMallocDefault));
+                        MMT_HIP(hipEventCreateWithFlags(&tb.ev[k], hipEventDisableTiming));
+                    }
+                }
+                const int k = filled == tb.buf[1] ? 1 : 0;
+                if (filled && n) {
+                    MMT_HIP(hipMemcpyAsync(cu.dev + cu.slot[i] + offset, filled, n, hipMemcpyHostToDevice, tb.s));
+                    MMT_HIP(hipEventRecord(tb.ev[k], tb.s));
+                    tb.busy[k] = true;
+                }
+                if (!more) {                        // the document is complete: on the device when this returns
+                    MMT_HIP(hipStreamSynchronize(tb.s));
+                    tb.busy[0] = tb.busy[1] = false;
+                    return nullptr;
+                }
+                const int nk = filled ? 1 - k : 0;
+                if (tb.busy[nk]) { MMT_HIP(hipEventSynchronize(tb.ev[nk])); tb.busy[nk] = false; }
+                return tb.buf[nk];
+            };
+            return t;
+        };
         if (!checkpoint) {
-            const long empty = read_fasta_collection(inputs, docs, arena, hd, &hooks);
+            long empty = read_fasta_collection(inputs, docs, arena, hd, &hooks);
+            if (empty == -2) {                      // the device turned out too small for one suffix array: host copies after all
+                cu.on = false;
+                hooks.plan_chunks = nullptr; hooks.chunks = nullptr;
+                empty = read_fasta_collection(inputs, docs, arena, hd, &hooks);
+            }
             if (empty >= 0) {                       // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71
                 std::cerr << std::endl << "Empty input file found: " << inputs[(size_t)empty] << std::endl;
                 throw CliError{"Please check the input files and ensure that it contains valid FASTA files. Cleaning up...", 1};
             }
             doc_len = hd.len;
+            if (dry_chunk && cu.on)
+                for (size_t d = 0; d < hd.ptr.size(); d++) { dry_docs[d].resize(hd.len[d]); hd.ptr[d] = dry_docs[d].data(); }
         }
         uint64_t n_bases = 0;
         for (uint64_t l : hd.len) n_bases += l;
@@ -721,6 +809,7 @@ int main(int argc, char** argv) {
             return 0;
         }
         mark("inputs read");
+        bool host_released = false;
         t0 = std::chrono::steady_clock::now();
         engine_init.join();
         if (engine_error) std::rethrow_exception(engine_error);
@@ -749,8 +838,14 @@ int main(int argc, char** argv) {
         else {
             finish_upload();
             if (up.error) std::rethrow_exception(up.error);
-            const bool uploaded = up.on && !up.skipped;
-            if (!partitioned && uploaded) eng.finish_input_slots(up.slot, doc_len.data(), doc_len.size());
+            const bool chunked = cu.on && !cu.skipped.load();
+            const bool uploaded = chunked || (up.on && !up.skipped);
+            if (chunked && partitioned) {            // (cannot happen: the chunk target checked the same estimate)
+                if (read_fasta_collection(inputs, docs, arena, hd) >= 0) throw CliError{"an input file changed while the run was going on", 1};
+            } else if (chunked) {
+                eng.finish_input_slots(cu.slot, doc_len.data(), doc_len.size());
+                host_released = true;               // there never were host copies: the repeat as anchor partitions reads the files again
+            } else if (!partitioned && uploaded) eng.finish_input_slots(up.slot, doc_len.data(), doc_len.size());
             else if (!partitioned) eng.set_input_host_docs(hd.ptr.data(), doc_len.data(), doc_len.size());
         }
         mark("input on the device");
@@ -797,6 +892,10 @@ int main(int argc, char** argv) {
                 if (!can) throw;
                 log_line("build_main", "one suffix array ran out of device memory: repeating the run as anchor partitions");
                 eng.forget_last_run();
+                if (host_released) {                             // the host copies went away beside the run: once more from the files
+                    if (read_fasta_collection(inputs, docs, arena, hd) >= 0) throw CliError{"an input file changed while the run was going on", 1};
+                    host_released = false;
+                }
                 eng.run_partitioned_docs(hd.ptr.data(), doc_len.data(), doc_len.size(), p, text_chars / 2);
                 partitioned = true;
                 log_line("build_main", "text of " + std::to_string(text_chars) + " characters processed as " +

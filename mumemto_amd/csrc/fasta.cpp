@@ -91,6 +91,38 @@ struct RawSink {
     void pop() { n--; }
 };
 struct NullSink { void append(const char*, const char*) {} };
+// the chunked mode of ReadHooks: the buffer is swapped when the NEXT byte needs room, so that the last byte written is
+// always still in `buf` (a line's trailing '\r' is taken back after the line is complete)
+struct ChunkAbort {};
+struct ChunkSink {
+    ChunkTarget& T;
+    size_t cap;                                    // bases the document's slot holds
+    uint8_t* buf = nullptr;
+    size_t fill = 0;
+    uint64_t flushed = 0;
+    void room() {
+        if (buf && fill < T.chunk) return;
+        uint8_t* next = T.swap(buf, fill, flushed, true);
+        if (!next) throw ChunkAbort();
+        flushed += fill; fill = 0; buf = next;
+    }
+    void append(const char* b, const char* e) {
+        size_t n = (size_t)(e - b);
+        if (flushed + fill + n > cap) throw std::runtime_error("FASTA slot overflow (file changed while reading?)");
+        while (n) {
+            room();
+            const size_t k = std::min(n, T.chunk - fill);
+            std::memcpy(buf + fill, b, k);
+            fill += k; b += k; n -= k;
+        }
+    }
+    void push(uint8_t c) { const char ch = (char)c; append(&ch, &ch + 1); }
+    size_t size() const { return (size_t)flushed + fill; }
+    uint8_t back() const { return buf[fill - 1]; }
+    void pop() { fill--; }
+    void restart() { fill = 0; flushed = 0; }      // (the reader begins again from the first byte of the file: same slot, from offset 0)
+    void finish() { (void)T.swap(buf, fill, flushed, false); flushed += fill; fill = 0; buf = nullptr; }
+};
 
 template <class Reader, class Sink>
 static FastaDoc read_fasta_with(const std::string& path, Sink& bases) {
@@ -138,15 +170,15 @@ static FastaDoc read_fasta_with(const std::string& path, Sink& bases) {
 // (memchr + memcpy).  The stream reader above spends ~30 ms of CPU per 64 MB on its layers (zlib's pass-through copy, a
 // refill check per character class) -- what matters when the process may use 16 cores' worth of time per 100 ms.
 // Anything that is not plain multi-FASTA ('@' records, '+' lines) returns false and goes through the stream reader.
-static bool read_plain_fasta_blocks(const std::string& path, uint8_t* slot, size_t cap, FastaDoc& doc, size_t& n_bases) {
+// (Sink: RawSink -- the file's slot in the arena -- or ChunkSink)
+template <class Sink>
+static bool read_plain_fasta_blocks(const std::string& path, Sink& out, FastaDoc& doc) {
     const int fd = ::open(path.c_str(), O_RDONLY);
     if (fd < 0) return false;
     struct Closer { int fd; ~Closer() { ::close(fd); } } closer{fd};
     static thread_local std::vector<char> block(1u << 20);
     enum { BEFORE_FIRST, IN_HEADER, LINE_START, IN_LINE } state = BEFORE_FIRST;
-    uint8_t* dst = slot;
-    uint8_t* const dst_end = slot + cap;
-    const uint8_t* rec = slot;
+    size_t rec = out.size();
     std::string header;
     bool open_record = false;
     doc = FastaDoc();
@@ -156,13 +188,13 @@ static bool read_plain_fasta_blocks(const std::string& path, uint8_t* slot, size
         size_t k = 0;
         while (k < header.size() && !isspace((unsigned char)header[k])) k++;
         doc.names.push_back(header.substr(0, k));
-        rec = dst; open_record = true;
+        rec = out.size(); open_record = true;
     };
     auto end_record = [&]() {
-        const uint64_t len = (uint64_t)(dst - rec);
+        const uint64_t len = (uint64_t)(out.size() - rec);
         doc.lengths.push_back(len); doc.total += len; open_record = false;
     };
-    auto end_line = [&]() { if ((size_t)(dst - rec) > 1 && dst[-1] == '\r') dst--; };
+    auto end_line = [&]() { if (out.size() - rec > 1 && out.back() == '\r') out.pop(); };
     for (;;) {
         const ssize_t got = ::read(fd, block.data(), block.size());
         if (got < 0) return false;
@@ -189,10 +221,8 @@ static bool read_plain_fasta_blocks(const std::string& path, uint8_t* slot, size
             } else {
                 const char* nl = static_cast<const char*>(std::memchr(p, '\n', (size_t)(e - p)));
                 const char* le = nl ? nl : e;
-                const size_t len = (size_t)(le - p);
-                if (dst + len > dst_end) return false;
-                std::memcpy(dst, p, len);
-                dst += len;
+                if (out.size() + (size_t)(le - p) > out.cap) return false;
+                out.append(p, le);
                 if (!nl) break;
                 end_line(); state = LINE_START; p = nl + 1;
             }
@@ -201,7 +231,6 @@ static bool read_plain_fasta_blocks(const std::string& path, uint8_t* slot, size
     if (state == IN_HEADER) end_header();
     if (state == IN_LINE) end_line();
     if (open_record) end_record();
-    n_bases = (size_t)(dst - slot);
     return true;
 }
 
@@ -235,8 +264,8 @@ FastaDoc read_fasta_replace(const std::string& path, std::vector<uint8_t>& bases
     if (!gz && size && !std::getenv("MUMEMTO_STREAM_READER")) {
         bases.resize(size + 64);                    // (a plain file holds at most its size in bases)
         FastaDoc doc;
-        size_t n = 0;
-        if (read_plain_fasta_blocks(path, bases.data(), bases.size(), doc, n)) { bases.resize(n); return doc; }
+        RawSink raw{bases.data(), 0, bases.size()};
+        if (read_plain_fasta_blocks(path, raw, doc)) { bases.resize(raw.n); return doc; }
     }
     bases.clear();
     return read_fasta(path, bases);
@@ -287,26 +316,37 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
         fsize[i] = size;
         slot[i + 1] = slot[i] + (gz[i] ? 0 : ((size + 64 + 4095) & ~(size_t)4095));
     }
-    uint8_t* base = arena.ensure(slot[N] + 4096);
-    if (hooks && hooks->layout) {
-        bool all_in_arena = true;
-        for (size_t i = 0; i < N; i++) all_in_arena = all_in_arena && !gz[i];
-        hooks->layout(base, slot[N], slot, all_in_arena);
-    }
+    bool all_plain = true;
+    for (size_t i = 0; i < N; i++) all_plain = all_plain && !gz[i];
+    const bool chunked = hooks && hooks->plan_chunks && hooks->chunks && all_plain && N > 0 &&
+                         hooks->plan_chunks(slot[N], slot, all_plain);
+    uint8_t* base = chunked ? nullptr : arena.ensure(slot[N] + 4096);
+    if (!chunked && hooks && hooks->layout) hooks->layout(base, slot[N], slot, all_plain);
     std::vector<std::string> err(N);
     const size_t n_thr = std::min<size_t>(N, reader_threads());
     std::atomic<size_t> next{0};
+    std::atomic<bool> aborted{false};
     auto work = [&]() {
         for (size_t i = next++; i < N; i = next++) {
             try {
-                if (gz[i]) {
+                if (chunked) {
+                    if (aborted.load()) continue;
+                    ChunkTarget target = hooks->chunks(i);
+                    ChunkSink sink{target, slot[i + 1] - slot[i]};
+                    if (std::getenv("MUMEMTO_STREAM_READER") || !read_plain_fasta_blocks(inputs[i], sink, docs[i])) {
+                        sink.restart();                  // ('@' records, '+' lines: once more through the stream reader)
+                        docs[i] = read_fasta_with<LineReader>(inputs[i], sink);
+                    }
+                    sink.finish();
+                    out.ptr[i] = nullptr; out.len[i] = sink.size();
+                    if (hooks->ready) hooks->ready(i, out.len[i]);
+                } else if (gz[i]) {
                     docs[i] = read_fasta(inputs[i], out.owned[i]);
                     out.ptr[i] = out.owned[i].data(); out.len[i] = out.owned[i].size();
                 } else {
-                    size_t n_bases = 0;
-                    if (!std::getenv("MUMEMTO_STREAM_READER") &&
-                        read_plain_fasta_blocks(inputs[i], base + slot[i], slot[i + 1] - slot[i], docs[i], n_bases)) {
-                        out.ptr[i] = base + slot[i]; out.len[i] = n_bases;
+                    RawSink raw{base + slot[i], 0, slot[i + 1] - slot[i]};
+                    if (!std::getenv("MUMEMTO_STREAM_READER") && read_plain_fasta_blocks(inputs[i], raw, docs[i])) {
+                        out.ptr[i] = base + slot[i]; out.len[i] = raw.n;
                     } else {
                         RawSink sink{base + slot[i], 0, slot[i + 1] - slot[i]};
                         docs[i] = read_fasta_with<LineReader>(inputs[i], sink);
@@ -314,6 +354,7 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
                     }
                     if (hooks && hooks->ready) hooks->ready(i, out.len[i]);
                 }
+            } catch (const ChunkAbort&) { aborted.store(true);
             } catch (const std::exception& e) { err[i] = e.what(); }
         }
     };
@@ -321,6 +362,7 @@ long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<F
     for (size_t t = 1; t < n_thr; t++) pool.emplace_back(work);
     work();
     for (auto& t : pool) t.join();
+    if (aborted.load()) return -2;                            // (the chunk target gave up: the caller reads again without chunks)
     for (size_t i = 0; i < N; i++) {
         if (!err[i].empty()) throw std::runtime_error(err[i]);
         if (docs[i].total == 0) return (long)i;             // ref_builder.cpp:249-252 + pfp_mum.cpp:68-71

@@ -71,9 +71,24 @@ size_t reader_threads();
 // soon as it is parsed).  layout: once, before any file is read -- bytes of the arena, offset of every document's slot in it
 // (N + 1 entries), whether every document lives in the arena (no compressed input).  ready: from a reader thread, document
 // i is complete at arena + slot[i] with `len` bases.
+//
+// Chunked mode (optional, the command line's one-shot runs): the bases of a plain file do not go to the arena at all but
+// through fixed-size buffers the caller owns -- page-locked, sent to the document's slot on the DEVICE as they fill up.  A
+// process then never holds the collection in host memory: 6 GB of anonymous pages cost 0.2 s to fault in and 0.3 - 0.4 s to
+// give back, wherever that happens (tests/micro/exit_probe2.cpp).  plan_chunks: once, before any file is read and before the
+// arena exists (bytes of all slots, the slot table, whether every file is plain); true = every file goes through
+// chunks(i).  ChunkTarget::swap(filled, n, offset, more): `filled` (nullptr at first) holds n bases that begin at base
+// `offset` of the document; returns the buffer to fill next (nullptr when `more` is false -- the document is complete -- or
+// to abort the whole read: read_fasta_collection then returns -2 and the caller reads again without chunks).
+struct ChunkTarget {
+    size_t chunk = 0;
+    std::function<uint8_t*(uint8_t* filled, size_t n, uint64_t offset, bool more)> swap;
+};
 struct ReadHooks {
     std::function<void(const uint8_t* arena, size_t bytes, const std::vector<size_t>& slot, bool all_in_arena)> layout;
     std::function<void(size_t i, uint64_t len)> ready;
+    std::function<bool(size_t bytes, const std::vector<size_t>& slot, bool all_plain)> plan_chunks;
+    std::function<ChunkTarget(size_t i)> chunks;
 };
 long read_fasta_collection(const std::vector<std::string>& inputs, std::vector<FastaDoc>& docs, HostArena& arena,
                            HostDocs& out, const ReadHooks* hooks = nullptr);

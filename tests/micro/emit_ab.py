@@ -14,6 +14,7 @@ ap.add_argument("--divergence", type=float, default=0.001)
 ap.add_argument("--seed", type=int, default=3)
 ap.add_argument("--args", default="", help="extra arguments of mumemto_exec, space separated")
 ap.add_argument("--pause", type=float, default=7.0)
+ap.add_argument("--grouped", action="store_true", help="all repetitions of a variant one after the other (default: the variants take turns)")
 ap.add_argument("--stderr", default="", help="print the lines of mumemto_exec's stderr that contain this text (e.g. '[sort]')")
 ap.add_argument("variants", nargs="+")
 a = ap.parse_args()
@@ -28,8 +29,9 @@ for h, bases in gen(a.haps, a.length, a.divergence, a.seed):
 exe = os.path.join(os.path.dirname(build.LIB), "..", "bin", "mumemto_exec")
 stats = os.path.join(d, "stats.json")
 names = ["text", "suffix_sort", "lcp_bwt", "scan", "verify", "rows", "windows", "total"]
-for rep in range(a.reps):
-    for v in a.variants:
+order = [v for v in a.variants for _ in range(a.reps)] if a.grouped else [v for _ in range(a.reps) for v in a.variants]
+for _once in (0,):
+    for v in order:
         name, _, envs = v.partition("=")
         env = dict(os.environ, MUMEMTO_STATS=stats)
         for kv in filter(None, envs.split(",")):

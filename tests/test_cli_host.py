@@ -216,3 +216,38 @@ def test_in_place_reader_of_plain_files_equals_the_stream_reader(tmp_path):
     for k in (1, 2):
         assert outs[0][0]["bases"] == outs[k][0]["bases"] and outs[0][0]["fnv1a"] == outs[k][0]["fnv1a"]
         assert outs[0][1] == outs[k][1] and int(outs[0][0]["bases"]) > 0
+
+
+def test_chunked_reader_gives_the_same_bases_as_the_arena(tmp_path):
+    """The command line's one-shot runs send the bases to the device through fixed-size chunks instead of holding the collection
+    in host memory (fasta.hpp, chunked mode of ReadHooks).  MUMEMTO_DRY_RUN_CHUNK runs that reader into host vectors: with
+    chunks of 1 .. 64 bytes every line end, '\\r' and record boundary falls on a chunk boundary somewhere -- the hash over all
+    documents' bases and the document lengths must be the arena reader's, for plain FASTA, CRLF line ends, several records per
+    file, empty lines, and a FASTQ file (which falls back to the stream reader in the middle of a chunked document)."""
+    import random
+    rng = random.Random(5)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTN") for _ in range(n))
+    a = tmp_path / "a.fa"
+    a.write_text(">r1 first\n" + "\n".join(seq(60) for _ in range(9)) + "\n" + seq(17) + "\n>r2\n\n" + seq(60) + "\n\n" + seq(3) + "\n")
+    b = tmp_path / "b.fa"
+    b.write_bytes((">crlf\r\n" + "\r\n".join(seq(rng.choice([1, 2, 59, 60, 61])) for _ in range(25)) + "\r\n>x\r\n" + seq(5) + "\r").encode())
+    c = tmp_path / "c.fa"
+    c.write_text(">one_line\n" + seq(1000))
+    d = tmp_path / "d.fa"        # (FASTQ content under a FASTA name: the suffix is what the command line checks)
+    d.write_text("".join("@q%d\n%s\n+\n%s\n" % (i, seq(40), "I" * 40) for i in range(6)))
+    paths = [str(a), str(b), str(c), str(d)]
+    want = fields(run(["-o", str(tmp_path / "o")] + paths, tmp_path).stdout)
+    assert int(want["bases"]) > 2000
+    for chunk in (1, 2, 3, 7, 59, 60, 61, 64, 4096):
+        r = subprocess.run([EXE, "-o", str(tmp_path / "o")] + paths, cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, MUMEMTO_DRY_RUN="1", MUMEMTO_DRY_RUN_CHUNK=str(chunk)))
+        assert r.returncode == 0, r.stderr
+        got = fields(r.stdout)
+        assert (got["docs"], got["bases"], got["fnv1a"]) == (want["docs"], want["bases"], want["fnv1a"]), (chunk, got, want)
+    # the three plain files alone (no fallback in between)
+    want = fields(run(["-o", str(tmp_path / "o")] + paths[:3], tmp_path).stdout)
+    r = subprocess.run([EXE, "-o", str(tmp_path / "o")] + paths[:3], cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, MUMEMTO_DRY_RUN="1", MUMEMTO_DRY_RUN_CHUNK="5"))
+    assert fields(r.stdout)["fnv1a"] == want["fnv1a"]

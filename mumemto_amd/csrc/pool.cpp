@@ -242,6 +242,19 @@ void release(void* p) {
     (void)hipFree(p);                                       // a block of the plain path
 }
 
+void premap(int device, size_t bytes) {
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(g_mu);
+    Heap& H = heap_for(device);
+    if (!H.vmm) return;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return; }
+    const size_t spare = (size_t)8 << 30;
+    const size_t want = std::min(bytes, H.top + (fr > spare ? fr - spare : 0));
+    if (want <= H.top) return;
+    (void)grow(H, (want - H.top + GROW - 1) / GROW * GROW);       // (as far as it gets: the rest grows on demand)
+}
+
 Stats stats(int device) {
     std::lock_guard<std::mutex> lock(g_mu);
     Stats s{};

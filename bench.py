@@ -458,7 +458,7 @@ def main():
             stage_acc)},
         # the largest kernel of the step is not the roofline kernel: the emitter writes the windows of the stream (SA 5 B on a
         # wide text + BWT 1 + LCP 4 per suffix) and is bound by latency and VALU work, not by HBM
-        "largest_kernel": {"kernel": "stream windows (k_emit: expands the phrase-suffix groups into SA / BWT / LCP entries)",
+        "largest_kernel": {"kernel": "stream windows (k_emit2: expands the phrase-suffix groups into SA / BWT / LCP entries)",
                            "ms_per_step": float(stage_acc[6]) / in_steps, "bytes_written_per_suffix": sum(col),
                            "achieved": sum(col) * n_text / max(float(stage_acc[6]) / in_steps, 1e-9) / 1e6, "unit": "GB/s",
                            "frac": sum(col) * n_text / max(float(stage_acc[6]) / in_steps, 1e-9) / 1e6 / HBM_PEAK_GBS},
@@ -467,16 +467,20 @@ def main():
     }
     # HBM bytes the scan kernel really moved, from the PMC passes under profiles/ (separate rocprofv3 runs of this
     # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for the default workload only
-    pmc_file = os.path.join(ROOT, "profiles", "round4_scan_pmc.json")
-    if not os.path.exists(pmc_file):
-        pmc_file = os.path.join(ROOT, "profiles", "round3_scan_pmc.json")
+    def newest(name):
+        for r in ("round5", "round4", "round3"):
+            f = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
+            if os.path.exists(f):
+                return f
+        return os.path.join(ROOT, "profiles", "round4_" + name)
+    pmc_file = newest("scan_pmc.json")
     if world == 1 and os.path.exists(pmc_file) and (a.haps, a.length, a.divergence, a.seed) == (94, 64_000_000, 0.001, 3):
         pmc = json.load(open(pmc_file))
         result["roofline"]["traffic"] = pmc["hbm_bytes_per_step"]
         result["roofline"]["traffic_unit"] = ("bytes per step = all k_scan launches of one pass (PMC, profiles/%s: %s)"
                                               % (os.path.basename(pmc_file), pmc.get("kernel", "k_scan")))
         result["roofline"]["frac_moved"] = pmc["hbm_bytes_per_step"] / (scan_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-    emit_pmc = os.path.join(ROOT, "profiles", "round4_emit_pmc.json")
+    emit_pmc = newest("emit_pmc.json")
     if world == 1 and os.path.exists(emit_pmc) and (a.haps, a.length, a.divergence, a.seed) == (94, 64_000_000, 0.001, 3):
         # the largest kernel's HBM bytes from its own PMC passes: the ratio to its algorithmic bytes says how much it re-reads
         pmc = json.load(open(emit_pmc))
@@ -486,9 +490,10 @@ def main():
         lk["algorithmic_bytes_per_step"] = pmc["algorithmic_bytes_per_step"]
         lk["traffic_ratio"] = pmc["hbm_bytes_per_step"] / pmc["algorithmic_bytes_per_step"]
         lk["frac_moved"] = pmc["hbm_bytes_per_step"] / max(lk["ms_per_step"], 1e-9) / 1e6 / HBM_PEAK_GBS
-        lk["traffic_unit"] = ("bytes per step = all k_emit launches of one pass (PMC, profiles/round4_emit_pmc.json: FETCH_SIZE as "
+        lk["traffic_unit"] = ("bytes per step = all %s launches of one pass (PMC, profiles/%s: FETCH_SIZE as "
                               "reported -- 8 / 4 bytes per lane gathers, a width the guide's x2 is not calibrated for; the x2 "
-                              "figure is traffic_upper_bound -- + WRITE_SIZE)")
+                              "figure is traffic_upper_bound -- + WRITE_SIZE)" % (pmc.get("kernel", "k_emit").split("<")[0].split("::")[-1],
+                                                                                os.path.basename(emit_pmc)))
     if eng.producer_used() == "pfp":
         result["pfp"] = {"counts": eng.pfp_counts(), "last_step_ms": dict(zip(
             ["triggers_phrases", "distinct_phrases", "dictionary_text", "dictionary_sa", "dictionary_groups",

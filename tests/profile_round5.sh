@@ -10,12 +10,12 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
-  timeout 1700 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+  timeout 1200 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
   tail -c 300 $OUT/bench.json
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = trace ]; then
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG --output-format csv -- \
-      python $R/bench.py --steps 2 --warmup 1 --no-extras --in-process --whole-genome no > $OUT/trace.log 2>&1
+      python $R/bench.py --steps 2 --warmup 1 --no-extras --in-process > $OUT/trace.log 2>&1
   cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
   python $R/tests/kstats.py $OUT/kernel_stats.csv 3 40 $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/kernel_summary.txt
   head -24 $OUT/kernel_summary.txt
@@ -24,10 +24,10 @@ if [ "$WHAT" = all ] || [ "$WHAT" = trace ]; then
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   for k in scan emit; do
-    re='mmt::k::k_scan'; [ $k = emit ] && re='mmt::pk::k_emit<'
+    re='mmt::k::k_scan'; [ $k = emit ] && re='mmt::pk::k_emit2<'
     for c in FETCH_SIZE WRITE_SIZE; do
       timeout 900 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$re" -d $OUT/pmc_${k}_$c -o $c --output-format csv -- \
-          python $R/bench.py --steps 1 --warmup 1 --no-extras --in-process --whole-genome no > $OUT/pmc_${k}_$c.log 2>&1
+          python $R/bench.py --steps 1 --warmup 1 --no-extras --in-process > $OUT/pmc_${k}_$c.log 2>&1
       cp $(find $OUT/pmc_${k}_$c -name "*counter_collection.csv" | head -1) $OUT/${k}_${c}_counter_collection.csv
     done
   done

@@ -237,9 +237,45 @@ def test_chunked_reader_gives_the_same_bases_as_the_arena(tmp_path):
     c.write_text(">one_line\n" + seq(1000))
     d = tmp_path / "d.fa"        # (FASTQ content under a FASTA name: the suffix is what the command line checks)
     d.write_text("".join("@q%d\n%s\n+\n%s\n" % (i, seq(40), "I" * 40) for i in range(6)))
-    paths = [str(a), str(b), str(c), str(d)]
+    e = tmp_path / "e.fa"      # many line widths around the copier's 32 bytes, some CRLF, some empty lines, several records
+    lines = []
+    for i in range(4000):
+        if i % 700 == 0:
+            lines.append(">rec%d some description" % i)
+        wd = rng.choice([0, 1, 2, 30, 31, 32, 33, 34, 62, 63, 64, 65, 66, 95, 96, 97, 200])
+        lines.append(seq(wd) + ("\r" if rng.random() < 0.2 else ""))
+    e.write_bytes("\n".join(lines).encode())
+    paths = [str(a), str(b), str(c), str(d), str(e)]
     want = fields(run(["-o", str(tmp_path / "o")] + paths, tmp_path).stdout)
     assert int(want["bases"]) > 2000
+
+    # the truth, from a reader of a few lines (kseq's rules: include/kseq.h:176-216): the arena reader -- whose sequence lines go
+    # through the 32-byte copier (fasta.cpp copy_sequence_lines_avx2) --, the same without it, and the chunked one must all hash to it
+    def bases_of(path):
+        out, in_seq, quality_left = bytearray(), False, 0
+        for line in open(path, "rb").read().split(b"\n"):
+            if line.endswith(b"\r"):
+                line = line[:-1]
+            if quality_left > 0:
+                quality_left -= len(line)
+                continue
+            if line[:1] in (b">", b"@"):
+                in_seq, rec = True, len(out)
+            elif line[:1] == b"+" and in_seq:
+                in_seq, quality_left = False, len(out) - rec
+            elif in_seq:
+                out += line
+        return bytes(out)
+    h = 1469598103934665603
+    total = 0
+    for q in paths:
+        for byte in bases_of(q):
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        total += len(bases_of(q))
+    assert (int(want["bases"]), want["fnv1a"]) == (total, "%016x" % h)
+    r = subprocess.run([EXE, "-o", str(tmp_path / "o")] + paths, cwd=tmp_path, capture_output=True, text=True,
+                       env=dict(os.environ, MUMEMTO_DRY_RUN="1", MUMEMTO_NO_AVX2="1"))
+    assert fields(r.stdout)["fnv1a"] == want["fnv1a"]
     for chunk in (1, 2, 3, 7, 59, 60, 61, 64, 4096):
         r = subprocess.run([EXE, "-o", str(tmp_path / "o")] + paths, cwd=tmp_path, capture_output=True, text=True,
                            env=dict(os.environ, MUMEMTO_DRY_RUN="1", MUMEMTO_DRY_RUN_CHUNK=str(chunk)))

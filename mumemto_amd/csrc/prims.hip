@@ -150,33 +150,89 @@ void exclusive_sum_u64(DevBuf<uint8_t>& temp, const uint64_t* in, uint64_t* out,
 // ---- stream compaction of flagged indices (hand-written: rocprim::select moves 0.2 TB/s on this shape) ----
 // Pass 1: every thread turns ITEMS consecutive flags into a bit mask and the workgroup counts them; an exclusive
 // scan of the workgroup counts follows; pass 2 rebuilds the masks and writes the indices in order.
-template <typename F, int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void k_flag_counts(const F* __restrict__ flags, size_t n,
-                                                       uint32_t* __restrict__ block_count) {
+// the sixteen flags of a work-item as a bit mask: 16-byte loads where the flags allow them (sixteen byte loads a work-item
+// ran the byte-flag passes of the suffix sorter at 85 GB/s: 69 ms of kernels per C3 step)
+template <typename F>
+__device__ __forceinline__ uint32_t flags16(const F* __restrict__ flags, size_t i0, size_t n, bool aligned) {
+    uint32_t mask = 0;
+    if (aligned && i0 + 16 <= n) {
+        if constexpr (sizeof(F) == 1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(flags + i0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t nz = (w[k] | ((w[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u;      // high bit of every non-zero byte
+                mask |= (((nz >> 7) & 1u) | ((nz >> 14) & 2u) | ((nz >> 21) & 4u) | ((nz >> 28) & 8u)) << (4 * k);
+            }
+            return mask;
+        } else if constexpr (sizeof(F) == 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = reinterpret_cast<const uint4*>(flags + i0)[k];
+                mask |= ((v.x ? 1u : 0u) | (v.y ? 2u : 0u) | (v.z ? 4u : 0u) | (v.w ? 8u : 0u)) << (4 * k);
+            }
+            return mask;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) if (i0 + q < n && flags[i0 + q]) mask |= 1u << q;
+    return mask;
+}
+// what is selected: a flag array, or a predicate over another column (no flag array is written and read back then)
+template <typename F>
+struct FlagArray {
+    const F* flags; size_t n;
+    __device__ __forceinline__ uint32_t operator()(size_t i0) const { return flags16(flags, i0, n, (reinterpret_cast<uintptr_t>(flags) & 15u) == 0); }
+};
+// the suffix sorter's "still tied after the first sort": position j is NOT a bucket of its own, i.e. not (head[j] == j and
+// (j + 1 == n or head[j + 1] == j + 1))
+struct TiedHeads {
+    const uint32_t* head; size_t n;
+    __device__ __forceinline__ uint32_t operator()(size_t i0) const {
+        uint32_t own = 0;                                       // bit q: head[i0 + q] == i0 + q (bit 16: the position behind the sixteen)
+        if (i0 + 17 <= n && (reinterpret_cast<uintptr_t>(head) & 15u) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = reinterpret_cast<const uint4*>(head + i0)[k];
+                const uint32_t b = (uint32_t)i0 + 4u * k;
+                own |= ((v.x == b ? 1u : 0u) | (v.y == b + 1 ? 2u : 0u) | (v.z == b + 2 ? 4u : 0u) | (v.w == b + 3 ? 8u : 0u)) << (4 * k);
+            }
+            own |= (head[i0 + 16] == (uint32_t)i0 + 16u ? 1u : 0u) << 16;
+        } else {
+#pragma unroll
+            for (int q = 0; q <= 16; q++) {
+                const size_t j = i0 + q;
+                if (j < n ? head[j] == (uint32_t)j : j == n) own |= 1u << q;      // (the position behind the last one counts as its own bucket)
+            }
+        }
+        uint32_t mask = ~(own & (own >> 1)) & 0xffffu;
+        if (i0 + 16 > n) mask &= i0 < n ? (1u << (n - i0)) - 1u : 0u;
+        return mask;
+    }
+};
+template <typename Sel, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_flag_counts(const Sel sel, size_t n, uint32_t* __restrict__ block_count) {
+    static_assert(ITEMS == 16, "flags16");
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const size_t i0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * ITEMS;
-    uint32_t c = 0;
-#pragma unroll
-    for (int q = 0; q < ITEMS; q++) if (i0 + q < n && flags[i0 + q]) c++;
+    uint32_t c = __popc(sel(i0));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_cnt, c);
     __syncthreads();
     if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
 }
-template <typename F, int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void k_flag_write(const F* __restrict__ flags, size_t n,
+template <typename Sel, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_flag_write(const Sel sel, size_t n,
                                                       const uint32_t* __restrict__ block_off,
                                                       const uint32_t* __restrict__ block_count, uint32_t n_blocks,
                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ d_count) {
     __shared__ uint32_t s_wave[BLOCK / 64];
     const size_t i0 = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * ITEMS;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t mask = 0;
-#pragma unroll
-    for (int q = 0; q < ITEMS; q++) if (i0 + q < n && flags[i0 + q]) mask |= 1u << q;
+    uint32_t mask = sel(i0);
     const uint32_t c = __popc(mask);
     uint32_t inc = c;
 #pragma unroll
@@ -192,8 +248,8 @@ __global__ __launch_bounds__(BLOCK) void k_flag_write(const F* __restrict__ flag
     }
     if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) *d_count = block_off[n_blocks - 1] + block_count[n_blocks - 1];
 }
-template <typename F>
-static void select_flagged(DevBuf<uint8_t>& temp, const F* flags, uint32_t* out, uint32_t* d_count, size_t n,
+template <typename Sel>
+static void select_flagged(DevBuf<uint8_t>& temp, const Sel sel, uint32_t* out, uint32_t* d_count, size_t n,
                            hipStream_t s) {
     constexpr int BLOCK = 256, ITEMS = 16;
     if (n == 0) { MMT_HIP(hipMemsetAsync(d_count, 0, 4, s)); return; }
@@ -206,20 +262,23 @@ static void select_flagged(DevBuf<uint8_t>& temp, const F* flags, uint32_t* out,
     temp.ensure(head + scan_bytes + 256);
     uint32_t* cnt = reinterpret_cast<uint32_t*>(temp.get());
     uint32_t* off = cnt + blocks;
-    hipLaunchKernelGGL((k_flag_counts<F, BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, flags, n, cnt);
+    hipLaunchKernelGGL((k_flag_counts<Sel, BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, sel, n, cnt);
     MMT_HIP(rocprim::exclusive_scan(temp.get() + head, scan_bytes, cnt, off, uint32_t(0), blocks,
                                     rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL((k_flag_write<F, BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, flags, n, off, cnt, blocks, out,
+    hipLaunchKernelGGL((k_flag_write<Sel, BLOCK, ITEMS>), dim3(blocks), dim3(BLOCK), 0, s, sel, n, off, cnt, blocks, out,
                        d_count);
     MMT_HIP(hipGetLastError());
 }
 void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                     hipStream_t s) {
-    select_flagged(temp, flags, out, d_count, n, s);
+    select_flagged(temp, FlagArray<uint8_t>{flags, n}, out, d_count, n, s);
 }
 void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                              hipStream_t s) {
-    select_flagged(temp, flags, out, d_count, n, s);
+    select_flagged(temp, FlagArray<uint32_t>{flags, n}, out, d_count, n, s);
+}
+void select_tied_heads(DevBuf<uint8_t>& temp, const uint32_t* head, uint32_t* out, uint32_t* d_count, size_t n, hipStream_t s) {
+    select_flagged(temp, TiedHeads{head, n}, out, d_count, n, s);
 }
 // Ranges [begin[i], end[i]) of one array, each sorted by the key bits below end_bit.  rocPRIM's segmented sort gives a
 // range to ONE workgroup however long it is (~30 ns per element: a homopolymer or a run of N puts millions of suffixes

@@ -29,6 +29,9 @@ void select_indices(DevBuf<uint8_t>& temp, const uint8_t* flags, uint32_t* out, 
                     hipStream_t s);
 
 
+// out[k] = k-th position j that is not a bucket of its own: not (head[j] == j and (j + 1 == n or head[j + 1] == j + 1)) --
+// the suffixes the sorter's first pass left tied, selected from the head column itself (no flag array in between)
+void select_tied_heads(DevBuf<uint8_t>& temp, const uint32_t* head, uint32_t* out, uint32_t* d_count, size_t n, hipStream_t s);
 void select_indices_u32flags(DevBuf<uint8_t>& temp, const uint32_t* flags, uint32_t* out, uint32_t* d_count, size_t n,
                              hipStream_t s);
 void segmented_sort_pairs_u32_ranges(DevBuf<uint8_t>& temp, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,

@@ -130,8 +130,12 @@ int DoublingSorter::sort(uint32_t n, int key_bits, uint64_t h0, uint32_t* sa, ui
         k::scatter_rank(sa, head, n, rank, side_);
         MMT_HIP(hipEventRecord(ev_side_, side_));
     } else k::scatter_rank(sa, head, n, rank, s);
-    k::flag_unsorted(head, n, flags, s);
-    prims::select_indices(temp, flags, idx, count_.get(), n, s);
+    // (MMT_SORT_FLAG_ARRAY: the byte-flag pass + the selection over it, the two steps this replaced)
+    static const bool flag_array = std::getenv("MMT_SORT_FLAG_ARRAY") != nullptr;
+    if (flag_array) {
+        k::flag_unsorted(head, n, flags, s);
+        prims::select_indices(temp, flags, idx, count_.get(), n, s);
+    } else prims::select_tied_heads(temp, head, idx, count_.get(), n, s);
     uint32_t m = 0;
     MMT_HIP(hipMemcpyAsync(&m, count_.get(), 4, hipMemcpyDeviceToHost, s));
     MMT_HIP(hipStreamSynchronize(s));

@@ -214,6 +214,9 @@ MMT_API int mmt_columns_kept(const mmt_engine* e);
 MMT_API int mmt_stream_stats(const mmt_engine* e, uint64_t out[4]);
 /* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
 MMT_API void mmt_pool_trim(void);
+/* bytes of device memory the heap leaves alone from now on (what MUMEMTO_HEAP_RESERVE sets for a whole process); ~0ull: back to
+   the environment's value.  The estimates (automatic text limit, batch sizes, packing) see a device that much smaller. */
+MMT_API void mmt_pool_set_reserve(unsigned long long bytes);
 /* Text, window buffers and sort scratch of the last run go back to the device heap (downloaded results stay).
  * keep_anchor_ranks != 0: the suffix ranks of the anchor stay, so that mmt_merged_sort_like_direct still works -- the state
  * of a rank between its own pass and the fold of everybody's rows. */

@@ -77,7 +77,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
-    "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim",
+    "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim", "mmt_pool_set_reserve",
     "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
     "mmt_stream_stats", "mmt_engine_release_columns", "mmt_copy_thresh32", "mmt_thresh_device32", "mmt_engine_set_text_sink",
@@ -167,6 +167,8 @@ def load_library():
                                      C.POINTER(C.c_uint64)]
     L.mmt_engine_parse_only.argtypes = [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint32]
     L.mmt_pfp_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mmt_pool_set_reserve.argtypes = [C.c_ulonglong]
+    L.mmt_pool_set_reserve.restype = None
     L.mmt_pfp_run_refined.argtypes = [C.c_void_p]
     L.mmt_pfp_run_refined.restype = C.c_longlong
     L.mmt_pfp_copy_dict.argtypes = [C.c_void_p, C.c_void_p]

@@ -488,6 +488,7 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
     e->e->set_stream_host40(sa_lo, sa_hi, lcp, bwt, entries, doc_len, n_docs, use_revcomp != 0);
     MMT_CATCH
 }
+void mmt_pool_set_reserve(unsigned long long bytes) { mmt::pool::set_reserve(bytes == ~0ull ? ~(size_t)0 : (size_t)bytes); }
 void mmt_pool_trim(void) {
     try { mmt::merge_release_scratch(); } catch (...) {}
     mmt::pool::trim();

@@ -9,6 +9,7 @@
 // multi-MUMs only.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <exception>
 #include <stdexcept>
@@ -121,13 +122,22 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
                                  "can be computed by partition + anchor merge (include/pfp_mum.hpp:178-183)");
     // A partition shares the device with what the sequence of partitions keeps: both input buffers (the next
     // partition is uploaded while this one runs: one byte per text character), the threshold columns (this run's, for
-    // both strands; the partition's copy; the fold so far) and the scratch of a fold step -- 16 bytes per anchor base.
+    // both strands; the partition's copy; the fold so far: 32 bits each since round 4), the anchor's suffix ranks (64 bits a
+    // position beyond 2^32 characters) and the scratch of a fold step -- 32 bytes per anchor base (16 until round 5: a share
+    // {anchor + 12} x 3.05 Gbp on a device with 200 GB free ran out of memory twice before its partitions were small enough,
+    // tests/big_reserve.py; the attempt loop below catches what this formula still gets wrong).
     // (a partition itself: its text, the tables of its parse and one batch of the producer -- auto_max_text)
     if (auto_limit && !std::getenv("MMT_MAX_TEXT") && !std::getenv("MUMEMTO_MAX_TEXT")) {
-        const double budget = 0.95 * (double)pool::available(device_) - 16.0 * (double)doc_len[0] - 24.0 * 1073741824.0;
+        const double budget = 0.95 * (double)pool::available(device_) - 32.0 * (double)doc_len[0] - 24.0 * 1073741824.0;
         const uint64_t fit = budget > 0 ? (uint64_t)(budget / 4.0) : 0;
         max_text = std::min(max_text, std::max<uint64_t>(fit, 1));
     }
+    // (one attempt at the whole sequence of partitions with a given limit; an attempt that runs out of device memory -- the
+    // estimate above is a formula, the heap has a shape -- is repeated with smaller partitions, below)
+    size_t G_used = 0;
+    float acc[8] = {0};
+    auto attempt = [&](uint64_t max_text) {
+    for (float& x : acc) x = 0;
     // contiguous groups of documents 1..N-1, each together with the anchor within max_text
     const uint64_t anchor_chars = mult * (doc_len[0] + 1);
     std::vector<std::pair<size_t, size_t>> groups;      // [first, last) document indices
@@ -152,7 +162,6 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     MergedRows folded;          // partitions 0 .. g folded, g >= 1
     bool have_folded = false;
     std::vector<uint64_t> sub_len;
-    float acc[8] = {0};
     mmt_params q = p;
     q.merge_metadata = 1; q.num_distinct = 0; q.max_total_freq = 0;
     uint64_t max_group_bytes = 0;
@@ -256,6 +265,22 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
         one.thresh_len = L; one.thresh_on_device = 1; one.rows_on_device = 1;
         merged_ = anchor_merge(*this, &one, 1, p.min_match_len);
     }
+    G_used = G;
+    };
+    for (int tries = 0;; tries++) {
+        try { attempt(max_text); break; }
+        catch (const DeviceOom&) {
+            uint64_t longest = 0;
+            for (size_t d = 1; d < n_docs; d++) longest = std::max<uint64_t>(longest, doc_len[d]);
+            const uint64_t smallest = mult * (doc_len[0] + 1) + mult * (longest + 1);      // the anchor and the longest other document
+            if (!auto_limit || tries >= 4 || max_text <= smallest) throw;
+            forget_last_run();                 // everything the failed attempt held goes back to the heap
+            max_text = std::max<uint64_t>(smallest, (uint64_t)(0.6 * (double)max_text));
+            if (std::getenv("MUMEMTO_TIMING") || std::getenv("MMT_MEM_TRACE"))
+                std::fprintf(stderr, "[partitions] out of device memory: once more with at most %llu text characters a partition\n",
+                             (unsigned long long)max_text);
+        }
+    }
     sort_like_direct(*this, merged_);          // the last partition's suffix ranks order the anchor positions
     size_t text_bytes = 0;
     const char* text = stage_merged_text(*this, merged_, &text_bytes);     // page-locked, stays with the engine
@@ -273,7 +298,7 @@ void Engine::run_partitioned_docs(const uint8_t* const* doc_ptr, const uint64_t*
     R.text = text; R.text_len = text_bytes;
     bumbl_.clear();
     num_distinct_eff_ = n_docs;
-    partitions_used_ = G;
+    partitions_used_ = G_used;
     merged_thresh_valid_ = true;
     thresh16_valid_ = false;
     for (int i = 0; i < 7; i++) stage_ms_[i] = acc[i];

@@ -4,6 +4,7 @@
 #include "device_utils.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -120,9 +121,11 @@ size_t heap_limit() {
 
 // MUMEMTO_HEAP_RESERVE (bytes, default 0): device memory the heap leaves to the driver and the runtime -- the estimates
 // (pool::available) know about it, unlike MUMEMTO_HEAP_LIMIT, which exists to make an accepted run fail
+std::atomic<size_t> g_reserve_set{~(size_t)0};        // pool::set_reserve (tests): overrides the environment while it is not ~0
 size_t driver_reserve() {
     static const size_t keep = [] { const char* e = std::getenv("MUMEMTO_HEAP_RESERVE"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
-    return keep;
+    const size_t set = g_reserve_set.load();
+    return set != ~(size_t)0 ? set : keep;
 }
 
 // map `bytes` (multiple of GROW) more physical memory at the top of the large region
@@ -241,6 +244,8 @@ void release(void* p) {
     }
     (void)hipFree(p);                                       // a block of the plain path
 }
+
+void set_reserve(size_t bytes) { g_reserve_set.store(bytes); }
 
 void premap(int device, size_t bytes) {
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }

@@ -21,6 +21,9 @@ size_t available(int device);     // driver-free bytes + unused bytes of the hea
 // maps the large region up to `bytes` (or what the driver has, less 8 GB) NOW: a one-shot process that knows about how much it
 // will need does it while the GPU is idle -- a chunk mapped beside running work waits for it (30 ms a time, measured)
 void premap(int device, size_t bytes);
+// device memory the heap leaves alone from now on, as MUMEMTO_HEAP_RESERVE does from the start (~0: back to the environment's
+// value): how a test makes a 288 GB device a smaller one in the middle of a process
+void set_reserve(size_t bytes);
 void trim();                      // unmap everything if no block is live (engine teardown in long-lived processes)
 // One-shot processes: the wholly free chunks at the top of the heap go back to the driver on a helper thread while the run
 // goes on (what is still mapped at exit is torn down on the way out: 0.57 s for 116 GB).  shrink_wait joins the helper.

@@ -281,8 +281,6 @@ def test_two_rank_shares_of_configs3_and_their_fold_at_the_anchors_length():
             assert 0 < t < int(L[r]), (r, t, int(L[r]))
         assert int(np.count_nonzero(th)) >= len(L)
         parts.append((L.copy(), off.copy(), strands.copy(), th))
-        if share == 1:
-            bases_of_share_1, lens_of_share_1 = bases, lens      # (kept for the head-room run at the end)
         del bases
     # ---- the fold of the two shares, in eight slices of the anchor, re-sorted by the anchor's suffix ranks ----
     eng.release_columns(keep_anchor_ranks=True)
@@ -320,36 +318,6 @@ def test_two_rank_shares_of_configs3_and_their_fold_at_the_anchors_length():
     eng.close()
     eng.L.mmt_pool_trim()          # (250 GB of mapped heap would leave the command-line tests of other files, which run as
     #                                processes of their own on the same GPU, with nothing)
-    # ---- head-room: share 1 once more on a device with 88 GB declared off limits (what MUMEMTO_HEAP_RESERVE does for a whole
-    # process): 200 GB instead of the 228 GB the share peaks at.  The estimate refuses it as one suffix array, the engine runs it
-    # as anchor partitions inside the rank + its own fold + re-sort (an attempt that still runs out of memory is repeated with
-    # smaller partitions: partitioned.cpp), and the rows must be the ones of the run above, in the same order, up to the
-    # stream-end quirk (at most one row per partition missing); the heap must have stayed within the 200 GB.
-    lib = mumemto_amd.load_library()
-    lib.mmt_pool_set_reserve(88 << 30)
-    try:
-        eng2 = mumemto_amd.Engine(0)
-        used = eng2.run_partitioned(None, flat=(bases_of_share_1, lens_of_share_1), merge_metadata=True)
-        L2, off2, st2 = eng2.rows_mum()
-        mapped = eng2.device_memory()["mapped"]
-        print("share 1 with 88 GB off limits: %d partitions inside the rank, heap %.1f GB mapped, %d rows" % (used, mapped / 2**30, len(L2)))
-        assert used >= 2 and mapped <= (200 + 2) * 2**30
-
-        def row_hashes(L, off, st):
-            h = L.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-            for d in range(off.shape[1]):
-                h ^= (off[:, d].astype(np.uint64) + np.uint64(d + 1)) * np.uint64(0xC2B2AE3D27D4EB4F + 2 * d)
-                h = (h << np.uint64(13)) | (h >> np.uint64(51))
-                h += st[:, d].astype(np.uint64) * np.uint64(0x165667B19E3779F9)
-            return h
-        h1, h2 = row_hashes(*parts[1][:3]), row_hashes(L2, off2, st2)
-        assert len(np.setdiff1d(h2, h1)) == 0, "the partitioned run has rows the whole run has not"
-        assert len(np.setdiff1d(h1, h2)) <= used, "more rows missing than the stream-end quirk explains"
-        assert np.array_equal(h1[np.isin(h1, h2)], h2), "the partitioned run's rows are in another order"
-        eng2.close()
-    finally:
-        lib.mmt_pool_set_reserve(2**64 - 1)
-        lib.mmt_pool_trim()
 
 
 def test_a_rank_share_of_configs4_at_its_size():

@@ -491,6 +491,9 @@ int mmt_engine_set_stream_host40(mmt_engine* e, const uint32_t* sa_lo, const uin
 void mmt_pool_set_reserve(unsigned long long bytes) { mmt::pool::set_reserve(bytes == ~0ull ? ~(size_t)0 : (size_t)bytes); }
 void mmt_pool_trim(void) {
     try { mmt::merge_release_scratch(); } catch (...) {}
+    // (the engine the mumemto_library entry points share keeps its buffers between calls: while it lives the heap holds live
+    // blocks and nothing is unmapped.  Its results have been copied out by the call that made them; the next call makes a new one.)
+    try { std::lock_guard<std::mutex> lock(g_engine_mu); g_engine.reset(); } catch (...) {}
     mmt::pool::trim();
 }
 int mmt_engine_set_text_sink(mmt_engine* e, const char* path) {

@@ -212,7 +212,9 @@ MMT_API int mmt_columns_kept(const mmt_engine* e);
  * windows), [1] bytes of the window buffers that held them (high-water mark: independent of the text length), [2] number
  * of windows, [3] bytes of the suffix-array entries that left the windows with accepted rows.                          */
 MMT_API int mmt_stream_stats(const mmt_engine* e, uint64_t out[4]);
-/* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).     */
+/* Returns the heap's physical memory to the driver when no engine buffer is live (long-lived hosts between jobs).  The engine
+   the mumemto_library entry points (mumemto.h) share is let go first -- the next such call makes a new one --; engines made
+   with mmt_engine_create are the caller's to destroy.                                                                      */
 MMT_API void mmt_pool_trim(void);
 /* bytes of device memory the heap leaves alone from now on (what MUMEMTO_HEAP_RESERVE sets for a whole process); ~0ull: back to
    the environment's value.  The estimates (automatic text limit, batch sizes, packing) see a device that much smaller. */

@@ -26,7 +26,9 @@ def test_device_heap_accounting_and_trim():
         eng.run()
         assert eng.output_text() == want
     m = a.device_memory()
-    assert m["mapped"] >= m["peak"] >= m["live"] > base_live
+    # (the peak is the high-water mark of the whole process: tests before this one may have held -- and, since mmt_pool_trim lets go
+    # of the library's shared engine too, given back -- far more than is mapped now)
+    assert m["mapped"] >= m["live"] > base_live and m["peak"] >= m["live"]
     os.environ["MUMEMTO_LEAN"] = "1"            # stage scratch is released and re-used inside the run
     try:
         c = mumemto_amd.Engine(0)

@@ -76,23 +76,104 @@ def write_fasta(path, records, names=None, width=80):
                 f.write(rec[k:k + width] + b"\n")
 
 
+_ASCII_OF_CODE = bytes([65, 67, 71, 84]) + bytes(252)
+
+
+def ancestor_codes(seed, length):
+    """= np.random.default_rng(seed).integers(0, 4, size=length, dtype=np.uint8), several times faster at gigabases: numpy draws a
+    bounded uint8 from one byte of the generator's 32-bit output at a time, low byte first, and a range of 4 keeps its top two bits
+    (Lemire's method without a rejection: 256 is a multiple of 4) -- so the codes are the top two bits of every byte of the raw
+    64-bit stream in little-endian order.  (tests/test_oracle.py holds the two against each other.)"""
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 0xFFFFFFFFFFFFFFFF, size=(length + 7) // 8, dtype=np.uint64, endpoint=True)
+    if raw.dtype.byteorder == ">":
+        raw = raw.byteswap()
+    return raw.view(np.uint8)[:length] >> 6
+
+
+def uniform_codes(rng, length):
+    """rng.integers(0, 4, size=length, dtype=np.uint8) -- same values AND the same generator state afterwards (numpy takes
+    ceil(length / 4) 32-bit outputs for them; an odd count leaves the upper half of a 64-bit output buffered in the generator,
+    which a single full-range uint32 draw reproduces)."""
+    n32 = (length + 3) // 4
+    raw = rng.integers(0, 0xFFFFFFFFFFFFFFFF, size=n32 // 2, dtype=np.uint64, endpoint=True)
+    if raw.dtype.byteorder == ">":
+        raw = raw.byteswap()
+    out = np.empty(n32 * 4, np.uint8)
+    out[:(n32 // 2) * 8] = raw.view(np.uint8)
+    if n32 & 1:
+        last = rng.integers(0, 0xFFFFFFFF, size=1, dtype=np.uint32, endpoint=True)
+        out[(n32 // 2) * 8:] = last.astype("<u4").view(np.uint8)
+    np.right_shift(out, 6, out=out)
+    return out[:length]
+
+
+def ascii_of_codes(codes):
+    """_ACGT[codes] through bytes.translate (a table lookup at copy speed; read-only result)"""
+    return np.frombuffer(codes.tobytes().translate(_ASCII_OF_CODE), np.uint8)
+
+
+def _substitutions(anc, length, divergence, seed, h):
+    """(positions, new ASCII bases) of haplotype h, in the order they are applied (a later write to a position wins)"""
+    hrng = np.random.default_rng([seed, h + 1])
+    k = int(hrng.binomial(length, divergence)) if divergence > 0 else 0
+    if not k:
+        return np.zeros(0, np.int64), np.zeros(0, np.uint8)
+    pos = hrng.integers(0, length, size=k)
+    return pos, _ACGT[(anc[pos] + hrng.integers(1, 4, size=k, dtype=np.uint8)) & 3]
+
+
 def haplotypes_sparse(n_haps, length, divergence, seed, which=None):
     """The same model as `pangenome` (ancestor = L i.i.d. uniform bases, every haplotype = ancestor with substitutions
     at rate d) for collections of gigabases: the substitutions of a haplotype are drawn as k ~ Binomial(L, d) events at
     uniform positions, each replacing the ancestral base by one of the three others -- k instead of L random numbers
     per haplotype, 94 x 64 Mbp in seconds instead of minutes.  Yields (index, uint8 array of ASCII bases) one
     haplotype at a time so that a caller can write or upload each and drop it."""
-    rng = np.random.default_rng(seed)
-    anc = rng.integers(0, 4, size=length, dtype=np.uint8)
-    anc_ascii = _ACGT[anc]
+    anc = ancestor_codes(seed, length)
+    anc_ascii = ascii_of_codes(anc)
     for h in (range(n_haps) if which is None else which):
-        hrng = np.random.default_rng([seed, h + 1])
         seq = anc_ascii.copy()
-        k = int(hrng.binomial(length, divergence)) if divergence > 0 else 0
-        if k:
-            pos = hrng.integers(0, length, size=k)
-            seq[pos] = _ACGT[(anc[pos] + hrng.integers(1, 4, size=k, dtype=np.uint8)) & 3]
+        pos, val = _substitutions(anc, length, divergence, seed, h)
+        if len(pos):
+            seq[pos] = val
         yield h, seq
+
+
+def copy_threaded(dst, src, threads=8, piece=1 << 28):
+    """dst[:] = src in pieces on a few threads (numpy releases the GIL for the copies): 3 GB in ~0.1 s instead of ~1 s"""
+    n = len(src)
+    if n <= piece or threads <= 1:
+        np.copyto(dst, src)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    cuts = list(range(0, n, piece)) + [n]
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda ab: np.copyto(dst[ab[0]:ab[1]], src[ab[0]:ab[1]]), zip(cuts[:-1], cuts[1:])))
+
+
+def collection_sparse(n_haps, length, divergence, seed, which=None, threads=8):
+    """The haplotypes `haplotypes_sparse` yields for `which`, as ONE flat uint8 array + their lengths (what
+    Engine.run_partitioned(flat=...) takes) -- filled by a few threads, a haplotype each: a rank's share of whole genomes
+    (13 x 3.05 Gbp) in seconds."""
+    which = list(range(n_haps) if which is None else which)
+    anc = ancestor_codes(seed, length)
+    anc_ascii = ascii_of_codes(anc)
+    bases = np.empty(len(which) * length, np.uint8)
+
+    def one(k):
+        dst = bases[k * length:(k + 1) * length]
+        np.copyto(dst, anc_ascii)
+        pos, val = _substitutions(anc, length, divergence, seed, which[k])
+        if len(pos):
+            dst[pos] = val
+    if threads > 1 and len(which) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(threads, len(which))) as ex:
+            list(ex.map(one, range(len(which))))
+    else:
+        for k in range(len(which)):
+            one(k)
+    return bases, np.full(len(which), length, np.uint64)
 
 
 def write_fasta_fast(path, bases, name="seq1", width=80):
@@ -124,7 +205,7 @@ def realistic_ancestor(length, seed):
       * three assembly gaps (runs of N) of 50 kbp, 200 kbp and 1 Mbp at 64 Mbp (scaled, at least 200 bases).
     Returns (uint8 ASCII array, list of (kind, start, end))."""
     rng = np.random.default_rng([seed, 0xA11CE])
-    anc = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
+    anc = ascii_of_codes(uniform_codes(rng, length)).copy()
     f = length / 64e6
     feats = []
     taken = []
@@ -209,3 +290,39 @@ def haplotypes_realistic(n_haps, length, divergence, seed, which=None, indel_rat
             pieces.append(seq[at:])
             seq = np.concatenate(pieces)
         yield h, seq
+
+
+def _realistic_to_file(args):
+    n_haps, length, divergence, seed, h, path, kw = args
+    for _, s in haplotypes_realistic(n_haps, length, divergence, seed, which=[h], **kw):
+        np.save(path, s)
+        return len(s)
+
+
+def collection_realistic(n_haps, length, divergence, seed, which=None, procs=1, **kw):
+    """The haplotypes `haplotypes_realistic` yields for `which` as ONE flat uint8 array + their (unequal) lengths.  procs > 1:
+    a haplotype per worker process (each makes the ancestor again: ~7 bytes of host memory per base and worker at its peak),
+    handed over through files in /dev/shm."""
+    import os
+    which = list(range(n_haps) if which is None else which)
+    shm = "/dev/shm"
+    if procs <= 1 or len(which) < 2 or not os.path.isdir(shm):
+        seqs = [s for _, s in haplotypes_realistic(n_haps, length, divergence, seed, which=which, **kw)]
+        return np.concatenate(seqs), np.array([len(s) for s in seqs], np.uint64)
+    import multiprocessing as mp
+    tag = "mmt_real_%d_%d_" % (os.getpid(), seed)
+    paths = [os.path.join(shm, tag + "%03d.npy" % h) for h in which]
+    try:
+        with mp.get_context("fork").Pool(min(procs, len(which))) as pool:
+            lens = pool.map(_realistic_to_file, [(n_haps, length, divergence, seed, h, p, kw) for h, p in zip(which, paths)], chunksize=1)
+        bases = np.empty(int(sum(lens)), np.uint8)
+        at = 0
+        for p, l in zip(paths, lens):
+            bases[at:at + l] = np.load(p, mmap_mode="r")
+            at += l
+            os.unlink(p)
+    finally:
+        for p in paths:
+            if os.path.exists(p):
+                os.unlink(p)
+    return bases, np.array(lens, np.uint64)

@@ -63,10 +63,7 @@ def run_grouping(eng, G, slices, out_path):
     per_share = []
     for r, mine in enumerate(groups):
         t0 = time.time()
-        bases = np.empty(len(mine) * L0, np.uint8)
-        for k, (h, b) in enumerate(synth.haplotypes_sparse(N, L0, A.div, A.seed, which=mine)):
-            bases[k * L0:(k + 1) * L0] = b
-        lens = np.full(len(mine), L0, np.uint64)
+        bases, lens = synth.collection_sparse(N, L0, A.div, A.seed, which=mine)
         t_gen = time.time() - t0
         t0 = time.time()
         used = eng.run_partitioned(None, flat=(bases, lens), merge_metadata=True)
@@ -103,8 +100,7 @@ class Model:
     """The generator's model, sparse: ancestor + per-haplotype substitution lists (synth.haplotypes_sparse)."""
 
     def __init__(self):
-        rng = np.random.default_rng(A.seed)
-        self.anc = rng.integers(0, 4, size=L0, dtype=np.uint8)
+        self.anc = synth.ancestor_codes(A.seed, L0)
         self.ascii = np.frombuffer(b"ACGT", np.uint8)
         self.sub = {}
 

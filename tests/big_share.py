@@ -23,10 +23,7 @@ A = ap.parse_args()
 mine = mdist.partition_docs(A.haps, A.ranks)[A.rank]
 L0 = A.length
 t0 = time.time()
-bases = np.empty(len(mine) * L0, np.uint8)
-for k, (h, b) in enumerate(synth.haplotypes_sparse(A.haps, L0, A.div, A.seed, which=mine)):
-    bases[k * L0:(k + 1) * L0] = b
-lens = np.full(len(mine), L0, np.uint64)
+bases, lens = synth.collection_sparse(A.haps, L0, A.div, A.seed, which=mine)
 print(json.dumps(dict(generated_s=round(time.time() - t0, 1), docs=len(mine), text_chars=int(2 * len(mine) * (L0 + 1)))), flush=True)
 os.environ["MMT_GUIDED_STATS"] = "1"
 eng = mumemto_amd.Engine(0)

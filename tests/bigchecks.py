@@ -182,10 +182,10 @@ class SparseModel:
     _ACGT = np.frombuffer(b"ACGT", np.uint8)
 
     def __init__(self, n_total, length, divergence, seed, which):
-        rng = np.random.default_rng(seed)
+        from mumemto_amd import synth
         self.length, self.div, self.seed, self.which = length, divergence, seed, list(which)
-        self.anc = rng.integers(0, 4, size=length, dtype=np.uint8)
-        self.anc_ascii = self._ACGT[self.anc]
+        self.anc = synth.ancestor_codes(seed, length)
+        self.anc_ascii = synth.ascii_of_codes(self.anc)
         self._subs = {}
 
     def _draw(self, h):
@@ -198,8 +198,9 @@ class SparseModel:
 
     def fill(self, d, dst):
         """the bases of document d (= haplotype which[d]) into dst, exactly as haplotypes_sparse yields them"""
+        from mumemto_amd import synth
         pos, val = self._draw(self.which[d])
-        np.copyto(dst, self.anc_ascii)
+        synth.copy_threaded(dst, self.anc_ascii)              # (3 GB a document: the supplier's time is the copy)
         dst[pos] = val
 
     def subs(self, d):

@@ -19,10 +19,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _collection(haps, length, div, seed):
-    bases = np.empty(haps * length, np.uint8)
-    for h, b in synth.haplotypes_sparse(haps, length, div, seed):
-        bases[h * length:(h + 1) * length] = b
-    return bases, np.full(haps, length, np.uint64)
+    return synth.collection_sparse(haps, length, div, seed)         # (filled by a few threads: the same haplotypes)
 
 
 def _partitioned(eng, bases, lens, frac):
@@ -199,10 +196,7 @@ def test_thirty_g_characters_as_one_streamed_run():
     phrase suffix is sorted (a few batches) and the emitter of the parse proper writes the windows (34.7 -> 5.8 s)."""
     import mumemto_amd
     haps, length = 94, 160_000_000
-    bases = np.empty(haps * length, np.uint8)
-    for h, b in synth.haplotypes_sparse(haps, length, 0.001, 4):
-        bases[h * length:(h + 1) * length] = b
-    lens = np.full(haps, length, np.uint64)
+    bases, lens = synth.collection_sparse(haps, length, 0.001, 4)
     eng = mumemto_amd.Engine(0)
     assert eng.run_partitioned(None, flat=(bases, lens)) == 1
     assert eng.is_wide() and eng.text_length() == 2 * haps * (length + 1) > 30e9 and not eng.columns_kept()
@@ -247,13 +241,16 @@ def test_two_rank_shares_of_configs3_and_their_fold_at_the_anchors_length():
     groups = mdist.partition_docs(94, 8)
     eng = mumemto_amd.Engine(0)
     parts = []
+    # (the second share's haplotypes are made on a host thread while the first share runs on the device)
+    from concurrent.futures import ThreadPoolExecutor
+    maker = ThreadPoolExecutor(1)
+    made = {0: maker.submit(synth.collection_sparse, 94, length, 0.001, 4, groups[0])}
     for share in (0, 1):
         mine = groups[share]
         haps = len(mine)
-        bases = np.empty(haps * length, np.uint8)
-        for k, (h, b) in enumerate(synth.haplotypes_sparse(94, length, 0.001, 4, which=mine)):
-            bases[k * length:(k + 1) * length] = b
-        lens = np.full(haps, length, np.uint64)
+        bases, lens = made.pop(share).result()
+        if share == 0:
+            made[1] = maker.submit(synth.collection_sparse, 94, length, 0.001, 4, groups[1], 4)
         # (a strict multi-MUM begins at one anchor position in a hundred: sixteen bins of 12 characters -- ~4700 suffixes each --
         # hold a few dozen rows between them)
         kmers = _kmers_of(bases[:length], 12, 16, seed=21 + share)

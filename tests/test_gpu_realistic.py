@@ -107,9 +107,8 @@ def test_giant_phrases_of_the_bucket_wise_producer_equal_the_oracle(depth, haps,
 
 
 def _flat(haps, length, div, seed):
-    seqs = [s for _, s in synth.haplotypes_realistic(haps, length, div, seed)]
-    lens = np.array([len(s) for s in seqs], np.uint64)
-    return np.concatenate(seqs), lens
+    # (a haplotype per worker process: indels and inversions are minutes of numpy at whole-genome size)
+    return synth.collection_realistic(haps, length, div, seed, procs=2 if length > 1_000_000_000 else 8)
 
 
 def test_realistic_collection_of_c3_size():

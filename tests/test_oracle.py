@@ -194,3 +194,38 @@ def test_scan_against_bruteforce_at_a_few_hundred_bases(mode):
         want = bruteforce_lines(text, list(doc_start), min_len, nd, f, F, revcomp)
         assert got == want, (mode, trial, revcomp, min_len)
         assert mode != "mem_unlimited" or got.count(b"\n") > 3
+
+
+def test_fast_generators_yield_the_haplotypes_numpy_would():
+    """synth.ancestor_codes / uniform_codes read the generator's raw 64-bit outputs instead of asking numpy for one bounded byte at
+    a time (whole-genome collections: minutes -> seconds); every fixture and digest depends on the haplotypes staying what
+    `rng.integers(0, 4, size=L, dtype=uint8)` gives -- values and generator state."""
+    import numpy as np
+    from mumemto_amd import synth
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for seed in (1, 4, [4, 0xA11CE]):
+        for L in (1, 3, 4, 5, 8, 9, 1003, 100_001):
+            want = np.random.default_rng(seed).integers(0, 4, size=L, dtype=np.uint8)
+            assert np.array_equal(synth.ancestor_codes(seed, L), want)
+            r1, r2 = np.random.default_rng(seed), np.random.default_rng(seed)
+            assert np.array_equal(synth.uniform_codes(r2, L), r1.integers(0, 4, size=L, dtype=np.uint8))
+            assert r1.integers(0, 1 << 40) == r2.integers(0, 1 << 40) and r1.integers(0, 99) == r2.integers(0, 99)
+            assert np.array_equal(synth.ascii_of_codes(want), acgt[want])
+    # a haplotype the long way round: ancestor, Binomial(L, d) substitutions at uniform positions, the last write wins
+    L, d, seed = 200_003, 0.01, 4
+    anc = np.random.default_rng(seed).integers(0, 4, size=L, dtype=np.uint8)
+    flat, lens = synth.collection_sparse(9, L, d, seed, which=[0, 5, 8], threads=3)
+    for k, (h, seq) in enumerate(synth.haplotypes_sparse(9, L, d, seed, which=[0, 5, 8])):
+        hrng = np.random.default_rng([seed, h + 1])
+        want = acgt[anc]
+        n = int(hrng.binomial(L, d))
+        pos = hrng.integers(0, L, size=n)
+        want[pos] = acgt[(anc[pos] + hrng.integers(1, 4, size=n, dtype=np.uint8)) & 3]
+        assert np.array_equal(seq, want) and np.array_equal(flat[k * L:(k + 1) * L], want)
+    big = np.arange(3 << 20, dtype=np.uint8)
+    out = np.empty_like(big)
+    synth.copy_threaded(out, big, threads=3, piece=1 << 20)
+    assert np.array_equal(out, big)
+    cb, cl = synth.collection_realistic(5, 300_000, 0.001, 3, which=[1, 4], procs=2)
+    seqs = [s for _, s in synth.haplotypes_realistic(5, 300_000, 0.001, 3, which=[1, 4])]
+    assert np.array_equal(cb, np.concatenate(seqs)) and list(cl) == [len(s) for s in seqs]

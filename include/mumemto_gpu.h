@@ -79,6 +79,10 @@ MMT_API int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_
 MMT_API int mmt_abi_version(void);
 MMT_API int mmt_producer_used(const mmt_engine* e);
 MMT_API int mmt_producer_expanded(const mmt_engine* e);
+/* Of the last run through the bucket-wise producer: out[0] = slices that bins of one repeated symbol (assembly gaps) were
+ * produced in, out[1] = passes over the text that collected suffixes, out[2] = batches, out[3] = 1 when several batches
+ * shared a pass (staging list).  Zeros for the other producers.                                                          */
+MMT_API int mmt_producer_stats(const mmt_engine* e, uint64_t out[4]);
 
 /* The row tap (test instrument of full-size runs that keep nothing else: tests/bigchecks.py check_bins_complete): every
  * accepted interval of the NEXT runs whose match begins with one of the n k-mers (n x k bytes, k <= 16) leaves a copy of its

@@ -73,7 +73,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_text_length", "mmt_copy_text", "mmt_copy_sa", "mmt_copy_lcp", "mmt_copy_bwt", "mmt_num_candidates",
     "mmt_copy_candidates", "mmt_stage_ms", "mmt_column_bytes", "mmt_anchor_merge", "mmt_merged_rows",
     "mmt_merged_docs", "mmt_merged_get", "mmt_merged_sort_like_direct", "mmt_merged_text", "mmt_merged_free",
-    "mmt_engine_set_producer", "mmt_abi_version", "mmt_engine_set_row_tap", "mmt_text_sink_digest", "mmt_kmer_in_share", "mmt_row_tap_counts", "mmt_row_tap_get", "mmt_kmer_positions", "mmt_producer_used", "mmt_producer_expanded", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_run_refined", "mmt_pfp_copy_dict",
+    "mmt_engine_set_producer", "mmt_abi_version", "mmt_engine_set_row_tap", "mmt_text_sink_digest", "mmt_kmer_in_share", "mmt_row_tap_counts", "mmt_row_tap_get", "mmt_kmer_positions", "mmt_producer_used", "mmt_producer_expanded", "mmt_producer_stats", "mmt_engine_parse_only", "mmt_pfp_counts", "mmt_pfp_run_refined", "mmt_pfp_copy_dict",
     "mmt_pfp_copy_parse", "mmt_pfp_stage_ms", "mmt_engine_run_partitioned", "mmt_partitions_used",
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
@@ -158,6 +158,7 @@ def load_library():
     L.mmt_engine_set_producer.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
     L.mmt_producer_used.argtypes = [C.c_void_p]
     L.mmt_producer_expanded.argtypes = [C.c_void_p]
+    L.mmt_producer_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.mmt_text_sink_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.mmt_kmer_in_share.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mmt_engine_set_row_tap.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
@@ -478,6 +479,12 @@ class Engine:
         if found.value > cap:
             raise MumemtoError("%d positions begin with those k-mers: more than the %d asked for" % (found.value, cap))
         return pos[:found.value], which[:found.value]
+
+    def producer_stats(self):
+        """bucket-wise producer, last run: slices of run bins (assembly gaps), passes over the text, batches, staged"""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.mmt_producer_stats(self.h, out))
+        return {"run_slices": int(out[0]), "text_passes": int(out[1]), "batches": int(out[2]), "staged": bool(out[3])}
 
     def producer_expanded(self):
         """the bucket-wise producer sorted one representative per (distinct phrase, offset) and the emitter expanded them"""

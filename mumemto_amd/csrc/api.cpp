@@ -578,6 +578,11 @@ int mmt_kmer_positions(mmt_engine* e, const uint8_t* kmers, size_t n, size_t k, 
 }
 int mmt_producer_used(const mmt_engine* e) { return e ? e->e->producer_used() : 0; }
 int mmt_producer_expanded(const mmt_engine* e) { return e && e->e->producer_expanded() ? 1 : 0; }
+int mmt_producer_stats(const mmt_engine* e, uint64_t out[4]) {
+    if (!e || !out) return fail(1, "null");
+    e->e->producer_stats(out);
+    return 0;
+}
 int mmt_engine_parse_only(mmt_engine* e, uint8_t use_revcomp, uint32_t w, uint32_t p) {
     if (!e) return fail(1, "null");
     MMT_TRY

@@ -1,5 +1,7 @@
 // engine.cpp -- orchestration of the hot path on one GPU (no kernels here).
 #include "engine.hpp"
+
+#include <sys/stat.h>
 #include "fasta.hpp"
 
 #include <fcntl.h>
@@ -848,7 +850,12 @@ void Engine::sink_open(bool mum_mode) {
     // after some windows -- out of memory, a consistency check at the end -- must not leave a plausible partial PREFIX.mums
     // ("/dev/null": the bytes are formatted, copied out, digested and dropped -- a full-size test run whose 66 GB of rows the
     // box has no room for)
-    sink_null_ = sink_path_ == "/dev/null";
+    // (any path that exists and is not a regular file -- a FIFO, /dev/stdout -- is written in place as well: the same rule as
+    // merge.cpp write_merged_text)
+    {
+        struct stat sb;
+        sink_null_ = sink_path_ == "/dev/null" || (::stat(sink_path_.c_str(), &sb) == 0 && !S_ISREG(sb.st_mode));
+    }
     sink_tmp_path_ = sink_null_ ? sink_path_ : sink_path_ + ".tmp";
     sink_digest_ = StreamDigest(); sink_written_ = 0; sink_digest_value_ = 0;
     sink_want_digest_ = std::getenv("MMT_SINK_DIGEST") != nullptr;
@@ -1378,8 +1385,19 @@ void Engine::run(const mmt_params& p) {
     const bool big = n_ >= NARROW_LIMIT;
     // (parse positions are 32 bits here: beyond ~48 G characters the modulus grows so that the parse keeps below 1.6 G phrases)
     const uint32_t auto_w = n_ < (1ull << 30) ? 6 : (big ? 14 : 10);
-    const uint32_t auto_p = n_ < (1ull << 30) ? 16 : (uint32_t)std::max<uint64_t>(30, n_ / 1600000000ull + 1);
+    uint32_t auto_p = n_ < (1ull << 30) ? 16 : (uint32_t)std::max<uint64_t>(30, n_ / 1600000000ull + 1);
+    // (a modulus that divides the hash of w equal bases ends a phrase at EVERY position of a run of that base -- an assembly gap of
+    // megabases becomes megabases of phrases, and the bucket-wise producer cannot slice its bin (guided.cpp): the next modulus)
+    {
+        auto kr = [](uint8_t c, uint32_t w) { uint64_t h = 0; for (uint32_t i = 0; i < w; i++) h = (h * 256 + c) % 1999999973ull; return h; };
+        for (;; auto_p++) {
+            bool bad = false;
+            for (const char c : {'A', 'C', 'G', 'T', 'N'}) bad = bad || kr((uint8_t)c, auto_w) % auto_p == 0;
+            if (!bad) break;
+        }
+    }
     if (kind == 3 || kind == 4) pfp_want_guided_ = true;
+    run_slices_ = text_passes_ = batches_ = 0; staged_ = false;
     stream_min_len_ = p.min_match_len;
     ev_[1]->start(stream_);
     // (the stream does not depend on the parameters of the parse: a producer named without them gets the automatic ones)

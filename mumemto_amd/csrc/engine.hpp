@@ -126,6 +126,8 @@ public:
     void set_producer(int kind, uint32_t w, uint32_t p) { producer_ = kind; pfp_w_ = w; pfp_p_ = p; }   // 0: chosen by the size
     int producer_used() const { return producer_used_; }
     bool producer_expanded() const { return producer_expanded_; }   // producer 3 sorted representatives, the emitter expanded them
+    // bucket-wise producer, last run: slices of run bins, passes over the text, batches, several batches per pass
+    void producer_stats(uint64_t out[4]) const { out[0] = run_slices_; out[1] = text_passes_; out[2] = batches_; out[3] = staged_ ? 1 : 0; }
     // A2 alone (after build_text): phrases, dictionary, parse.  Used by -P / -K and the parity tests.
     void parse_only(bool revcomp, uint32_t w, uint32_t p);
     void pfp_copy_dict(std::vector<uint8_t>& out);
@@ -406,6 +408,8 @@ private:
     bool one_shot_ = false;
     int producer_ = 0, producer_used_ = 1;
     bool producer_expanded_ = false;
+    uint32_t run_slices_ = 0, text_passes_ = 0, batches_ = 0;
+    bool staged_ = false;
     uint32_t pfp_w_ = 0, pfp_p_ = 0;
     // scan
     DevBuf<k::Cand> d_cand_;

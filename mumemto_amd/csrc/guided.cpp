@@ -43,6 +43,13 @@ static void mem_mark(int device, const char* what) {
 
 namespace {
 
+// Karp-Rabin hash of a window of w equal bytes (newscan.hpp:84-114: prime 1999999973, base 256)
+uint64_t kr_window_of_run(uint8_t c, uint32_t w) {
+    uint64_t h = 0;
+    for (uint32_t i = 0; i < w; i++) h = (h * 256 + c) % 1999999973ull;
+    return h;
+}
+
 // scratch of one batch (capacity elements)
 struct Batch {
     DevBuf<uint64_t> key_a, key_b, pos_a, pos_b, pos_c;
@@ -763,6 +770,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     }
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
     S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
+    run_slices_ = 0; text_passes_ = (uint32_t)(staged ? passes : batches); batches_ = (uint32_t)batches; staged_ = staged;
     MMT_HIP(hipStreamSynchronize(st));
     const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
     if (stats && staged) std::fprintf(stderr, "[guided] %d passes over the text for those batches (a list of %llu suffixes)\n", passes,
@@ -825,24 +833,65 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     // A WINDOW is what is emitted, scanned and dropped at once: whole bins of one batch, below 2^32 entries with the tail of
     // the window before (ONE window set: the tail -- as far as an interval can reach -- waits in a buffer of its own). ----
     const bool capped = SS.cap != 0;
-    uint64_t largest = 0, largest_rep = 0, share = 0, share_rep = 0;
-    for (uint32_t b = bin_lo; b < bin_hi; b++) {
-        largest = std::max(largest, bins[b]); largest_rep = std::max(largest_rep, rbins[b]);
-        share += bins[b]; share_rep += rbins[b];
-    }
-    const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest) : largest;
+    // A bin of ONE repeated symbol -- N^pc: the assembly gaps of every haplotype and strand, 1.5 G suffixes in a rank's share of
+    // whole genomes with 60 Mbp of gaps each -- is not cut by more leading characters, but its order is known in closed form
+    // (guided_kernels.hip RunSlice): when it exceeds a batch or a window it is produced in slices.  Only in the capped modes: an
+    // interval of an uncapped mode may be as long as its bin, and a window must hold it.  (MMT_GUIDED_SLICE=<suffixes>: tests)
+    const uint32_t smask = (1u << ctx.bits) - 1u;
+    auto run_symbol = [&](uint32_t b) -> uint32_t {
+        const uint32_t sym = b & smask;
+        if (!sym) return 0u;
+        for (int ch = 1; ch < prefix_chars; ch++) if (((b >> (ctx.bits * ch)) & smask) != sym) return 0u;
+        return sym;
+    };
+    const uint64_t slice_env = std::getenv("MMT_GUIDED_SLICE") ? std::strtoull(std::getenv("MMT_GUIDED_SLICE"), nullptr, 10) : 0;
+    // (the closed form needs every phrase suffix that begins inside a run to reach beyond the run's end -- all occurrences of a
+    // representative then share (r, X0).  That holds unless the window of w equal symbols is itself a trigger of the parse
+    // (newscan.hpp:106-114,321: hash of c^w divisible by p -- a phrase would end at EVERY position of the run); the automatic
+    // parameters avoid such moduli (engine.cpp), a parse that was asked for with one keeps its bins whole)
+    auto run_triggers = [&](uint32_t sym) {
+        for (int c = 0; c < 256; c++)
+            if (S.g_code[c] == sym) return kr_window_of_run((uint8_t)c, S.w) % S.p == 0;
+        return true;
+    };
+    std::vector<char> keep_whole(n_bins, 0);        // run bins whose slices would not fit a batch either: produced as whole bins
+    auto sliceable = [&](uint32_t b) {
+        const uint32_t sym = run_symbol(b);
+        return capped && sym != 0 && !keep_whole[b] && !run_triggers(sym) && !std::getenv("MMT_GUIDED_NO_SLICES");
+    };
+    uint64_t largest = 0, largest_rep = 0, share = 0, share_rep = 0, largest_any = 0;
+    for (uint32_t b = bin_lo; b < bin_hi; b++) { largest_any = std::max(largest_any, bins[b]); share += bins[b]; share_rep += rbins[b]; }
+    const uint64_t head_room = capped ? std::min<uint64_t>(SS.ext0, largest_any) : largest_any;      // (uncapped: no bin is sliced)
     const double per_rep = (double)Batch::bytes_per_element() + 12.0;              // batch scratch (holds the tables) + LCP, sege, fb_group
     const double per_out = (W ? 10.0 : 9.0) + 0.05;                                // one window set (+ the emitter's tile records)
     // (what the batches may take: four fifths of what is free, and no more than brings the heap to three quarters of the device --
     // a share of whole genomes holds 130 GB of text, tables of the parse, anchor ranks and thresholds before its first batch, and
     // the scan's candidates, the rows and the writers still come on top)
+    // (a run whose rows leave with their windows -- the MEM modes of a rank of configs[4]: text and tables are 200 GB before the
+    // first batch -- keeps nothing that grows: the heap may go to nine tenths.  MMT_EXPAND_HEAP_FRAC: tuning aid)
     const double free_now = (double)pool::available(device_), live_now = (double)pool::stats(device_).live;
-    const double avail = std::min(0.80 * free_now, 0.76 * (free_now + live_now) - live_now) - 2.0 * per_out * (double)head_room -
+    double heap_frac = sink_active_ && sink_discard_ ? 0.90 : 0.76;
+    if (const char* c = std::getenv("MMT_EXPAND_HEAP_FRAC")) heap_frac = std::min(0.95, std::max(0.3, std::atof(c)));
+    const double avail = std::min(0.80 * free_now, heap_frac * (free_now + live_now) - live_now) - 2.0 * per_out * (double)head_room -
                          8.0 * (double)((n + gk::TILE - 1) / gk::TILE) - 4.0 * 1073741824.0;
     const uint64_t WIN_MAX = 1ull << 31;                                           // (a window and its tail stay well below 2^32 entries)
-    uint64_t win_cap = std::min<uint64_t>(std::max<uint64_t>(share, 1024), WIN_MAX);
+    uint64_t win_cap = 0, rep_cap = 0, stage_cap = 0;
+    bool staged = false;
+    struct Piece { uint32_t bin, blo, bhi; uint64_t count, reps; bool slice, first; };
+    std::vector<Piece> vb;
+    DevBuf<uint64_t> run_lead;
+    DevBuf<uint8_t> run_first, run_follow;
+    gk::RunSlice run_tab;                    // the tables of the tiles (sym, blo, bhi are set per batch)
+    uint32_t sliced_bins = 0;
+    const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
+    for (int attempt = 0;; attempt++) {
+    if (attempt > (int)n_bins + 1) throw std::runtime_error("guided sort (expansion): the slices of the run bins do not settle");
+    largest = largest_rep = 0;
+    for (uint32_t b = bin_lo; b < bin_hi; b++)
+        if (!sliceable(b)) { largest = std::max(largest, bins[b]); largest_rep = std::max(largest_rep, rbins[b]); }
+    win_cap = std::min<uint64_t>(std::max<uint64_t>(share, 1024), WIN_MAX);
     if ((double)win_cap * per_out > 0.5 * std::max(avail, 0.0)) win_cap = std::max<uint64_t>((uint64_t)(0.5 * std::max(avail, 0.0) / per_out), 1u << 20);
-    uint64_t rep_cap = avail > 0 ? (uint64_t)((avail - (double)win_cap * per_out) / per_rep) : 0;
+    rep_cap = avail > 0 ? (uint64_t)((avail - (double)win_cap * per_out) / per_rep) : 0;
     rep_cap = std::min<uint64_t>(std::max<uint64_t>(rep_cap, 1u << 20), 1ull << 30);
     rep_cap = std::min<uint64_t>(rep_cap, std::max<uint64_t>(share_rep, 1024));
     if (const char* c = std::getenv("MMT_GUIDED_BATCH")) {                         // (tests: small batches, two or three windows each)
@@ -850,17 +899,106 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
         const double ratio = (double)std::max<uint64_t>(share, 1) / (double)std::max<uint64_t>(share_rep, 1);
         win_cap = std::max<uint64_t>(1024, (uint64_t)(0.4 * (double)rep_cap * ratio));
     }
+    // Several batches per pass over the text (gk::stage_fill, as in the plain producer): a batch of representatives is a pass over
+    // the WHOLE text, and a rank's share of configs[4] -- 573 G characters, 64 batches -- spent 64 of its 88 s of batches there.
+    // Part of the memory becomes a list of the representatives of the next batches' bins (8 bytes each), filled by one pass.
+    staged = share_rep > 2 * rep_cap && (double)n * ((double)share_rep / (double)std::max<uint64_t>(rep_cap, 1)) >= 2e13;
+    if (const char* c = std::getenv("MMT_GUIDED_STAGE")) staged = std::atoi(c) != 0;
+    else if (std::getenv("MMT_GUIDED_BATCH")) staged = share_rep > 2 * rep_cap;      // (tests: every run of several batches)
+    stage_cap = 0;
+    if (staged) {
+        if (std::getenv("MMT_GUIDED_BATCH")) stage_cap = std::min<uint64_t>(share_rep, std::max<uint64_t>(4 * rep_cap, largest_rep));
+        else {
+            const double for_reps = std::max(avail - (double)win_cap * per_out, 0.0);
+            const double stage_bytes = 0.4 * for_reps;
+            const uint64_t fit2 = (uint64_t)((for_reps - stage_bytes) / per_rep);
+            stage_cap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)(stage_bytes / 8.0), share_rep), 0xfff00000ull);   // (32-bit offsets per tile)
+            if (fit2 < (1u << 20) || fit2 < largest_rep || stage_cap < 2 * std::max<uint64_t>(largest_rep, 1)) staged = false;
+            else rep_cap = std::min<uint64_t>(rep_cap, fit2);
+        }
+        if (stage_cap < largest_rep) staged = false;
+    }
     if (largest > win_cap || largest_rep > rep_cap) {
         const double need = per_out * (double)largest + per_rep * (double)largest_rep;
         if (need > std::max(avail, 0.0) + per_out * (double)(1u << 20) + per_rep * (double)(1u << 20) || largest >= 0xf0000000ull ||
-            largest_rep >= 0xfffffff0ull)
+            largest_rep >= 0xffffff00ull)                 // (the scratch is sized rep_cap + 64 in 32 bits: stay clear of the wrap)
             throw std::runtime_error("guided sort (expansion): " + std::to_string(largest) + " suffixes (" + std::to_string(largest_rep) +
                                      " representatives) share their first " + std::to_string(prefix_chars) +
                                      " characters: more than one batch can hold on this device");
         win_cap = std::max(win_cap, largest); rep_cap = std::max(rep_cap, largest_rep);
     }
+    // ---- the pieces the batches and windows are made of: whole bins, and the slices of run bins that exceed a batch or a window ----
+    vb.clear(); sliced_bins = 0;
+    bool again = false;
+    {
+        const uint64_t lim_sfx = slice_env ? std::min<uint64_t>(slice_env, win_cap) : win_cap, lim_rep = slice_env ? std::min<uint64_t>(slice_env, rep_cap) : rep_cap;
+        for (uint32_t b = bin_lo; b < bin_hi; b++) {
+            const bool cut = sliceable(b) && (bins[b] > lim_sfx || rbins[b] > lim_rep);
+            if (!cut) { vb.push_back(Piece{b, 0, 0, bins[b], rbins[b], false, true}); continue; }
+            if (!run_tab.n_tiles) {
+                // per tile: the run that begins at its first position -- within the tile from a pass over the text, across tiles
+                // by a chain over the tiles that hold one symbol only (on the host: 19 M tiles of 79 G characters in 20 ms)
+                DevBuf<uint16_t> lead16;
+                lead16.ensure(n_tiles); run_first.ensure((size_t)n_tiles + 1); run_follow.ensure((size_t)n_tiles + 1); run_lead.ensure((size_t)n_tiles + 1);
+                gk::Ctx plain = ctx;
+                plain.repbits = nullptr;
+                gk::tile_lead(plain, run_first.get(), lead16.get(), run_follow.get(), st);
+                std::vector<uint16_t> l16(n_tiles);
+                std::vector<uint8_t> fi(n_tiles), fo(n_tiles);
+                MMT_HIP(hipMemcpyAsync(l16.data(), lead16.get(), (size_t)n_tiles * 2, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipMemcpyAsync(fi.data(), run_first.get(), n_tiles, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipMemcpyAsync(fo.data(), run_follow.get(), n_tiles, hipMemcpyDeviceToHost, st));
+                MMT_HIP(hipStreamSynchronize(st));
+                std::vector<uint64_t> lead(n_tiles);
+                for (uint32_t t = n_tiles; t-- > 0;) {
+                    if (l16[t] < gk::TILE) lead[t] = l16[t];
+                    else if (t + 1 < n_tiles && fi[t + 1] == fi[t]) { lead[t] = (uint64_t)gk::TILE + lead[t + 1]; fo[t] = fo[t + 1]; }
+                    else { lead[t] = gk::TILE; fo[t] = t + 1 < n_tiles ? fi[t + 1] : (uint8_t)0; }
+                }
+                MMT_HIP(hipMemcpyAsync(run_lead.get(), lead.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, st));
+                MMT_HIP(hipMemcpyAsync(run_follow.get(), fo.data(), n_tiles, hipMemcpyHostToDevice, st));
+                MMT_HIP(hipStreamSynchronize(st));
+                run_tab.lead = run_lead.get(); run_tab.first = run_first.get(); run_tab.follow = run_follow.get(); run_tab.n_tiles = n_tiles;
+            }
+            const uint32_t NB = 2u * gk::RUN_BUCKETS_HALF;
+            DevBuf<uint64_t> d_hist;
+            d_hist.ensure(2 * (size_t)NB);
+            MMT_HIP(hipMemsetAsync(d_hist.get(), 0, 2 * (size_t)NB * 8, st));
+            gk::RunSlice rs = run_tab;
+            rs.sym = run_symbol(b);
+            gk::run_hist(ctx, prefix_chars, b, rs, d_hist.get(), st);
+            std::vector<uint64_t> h;
+            d2h(h, d_hist.get(), 2 * (size_t)NB, st);
+            uint64_t sum = 0, sum_rep = 0;
+            for (uint32_t q = 0; q < NB; q++) { sum += h[q]; sum_rep += h[NB + q]; }
+            if (sum != bins[b] || sum_rep != rbins[b])
+                throw std::runtime_error("guided sort: the slices of a run bin hold " + std::to_string(sum) + " suffixes (" + std::to_string(sum_rep) +
+                                         " representatives), its bin " + std::to_string(bins[b]) + " (" + std::to_string(rbins[b]) + ")");
+            // (a bucket -- suffixes with (nearly) the same length of their run left: every AAAA of a random text has four -- that
+            // exceeds a batch by itself: the bin goes as a whole after all, and the capacities are worked out again with it)
+            bool fits = true;
+            for (uint32_t q = 0; q < NB; q++) fits = fits && h[q] <= lim_sfx && h[NB + q] <= lim_rep;
+            if (!fits) { keep_whole[b] = 1; again = true; break; }
+            Piece cur{b, 0, 0, 0, 0, true, true};
+            for (uint32_t q = 0; q < NB; q++) {
+                if (cur.count && (cur.count + h[q] > lim_sfx || cur.reps + h[NB + q] > lim_rep)) {
+                    cur.bhi = q; vb.push_back(cur);
+                    cur = Piece{b, q, 0, 0, 0, true, false};
+                }
+                cur.count += h[q]; cur.reps += h[NB + q];
+            }
+            cur.bhi = NB; vb.push_back(cur);
+            sliced_bins++;
+            if (stats) std::fprintf(stderr, "[guided] bin %u (one symbol, %llu suffixes, %llu representatives) goes in %zu slices by what is left of the runs\n",
+                                    b, (unsigned long long)bins[b], (unsigned long long)rbins[b],
+                                    (size_t)std::count_if(vb.begin(), vb.end(), [&](const Piece& x) { return x.bin == b; }));
+        }
+    }
+    if (!again) break;
+    }
     mem_mark(device_, "expansion: before the batches");
     Batch X;
+    if (rep_cap > 0xffffff00ull) throw std::runtime_error("guided sort (expansion): a batch of " + std::to_string(rep_cap) + " representatives");
     X.reserve((uint32_t)std::max<uint64_t>(rep_cap, 1024) + 64);
     X.cap = (uint32_t)std::max<uint64_t>(rep_cap, 1024);
     const size_t C = (size_t)X.cap + 64;
@@ -902,13 +1040,18 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     if (W) t_hi.ensure(head_room + 16);
     DevBuf<uint64_t> carry;
     carry.ensure(2);
-    const uint32_t n_tiles = (uint32_t)((n + gk::TILE - 1) / gk::TILE);
     DevBuf<uint32_t> tile_cnt, tile_off;
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
+    DevBuf<uint64_t> stage;
+    DevBuf<uint32_t> blk_cnt, blk_off;
+    if (staged) { stage.ensure(stage_cap + 16); blk_cnt.ensure(stage_cap / 4096 + 2); blk_off.ensure(stage_cap / 4096 + 2); }
     const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
     const RmqView rmq = S.plcp.view();
     S.emit_ready = true;
 
+    const uint32_t nv = (uint32_t)vb.size();
+    run_slices_ = 0;
+    for (const Piece& x : vb) run_slices_ += x.slice ? 1 : 0;
     uint64_t base = pre[bin_lo], active_sum = 0, small_sum = 0, reps_done = 0;
     const uint64_t piece_end = pre[bin_hi];
     int batches = 0, windows = 0, rounds_max = 0;
@@ -918,29 +1061,85 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     bool have_prev = false;
     uint32_t counted_lo = 0, counted_hi = 0;
     double ms_sort = 0, ms_emit = 0;
-    auto next_batch_end = [&](uint32_t b0, uint64_t& total, uint64_t& total_rep) {
+    // (pieces [b0, b1): whole bins, or slices of ONE run bin -- never both in a batch; `stop`: the end of the staged pieces)
+    auto next_batch_end = [&](uint32_t b0, uint32_t stop, uint64_t& total, uint64_t& total_rep) {
         uint32_t b1 = b0;
         total = 0; total_rep = 0;
-        while (b1 < bin_hi && total_rep + rbins[b1] <= X.cap && total + bins[b1] < (1ull << 40)) { total += bins[b1]; total_rep += rbins[b1]; b1++; }
+        while (b1 < stop && vb[b1].slice == vb[b0].slice && (!vb[b0].slice || vb[b1].bin == vb[b0].bin) &&
+               total_rep + vb[b1].reps <= X.cap && total + vb[b1].count < (1ull << 40)) { total += vb[b1].count; total_rep += vb[b1].reps; b1++; }
         return b1;
     };
-    for (uint32_t b0 = bin_lo; b0 < bin_hi;) {
+    // the kernels' view of pieces [b0, b1): a range of real bins + the range of buckets of a run bin's slices
+    auto real_range = [&](uint32_t b0, uint32_t b1, uint32_t& lo, uint32_t& hi, gk::RunSlice& out) {
+        lo = hi = 0; out = gk::RunSlice();
+        if (b0 >= b1) return;
+        lo = vb[b0].bin; hi = vb[b1 - 1].bin + 1;
+        if (vb[b0].slice) { out = run_tab; out.sym = run_symbol(vb[b0].bin); out.blo = vb[b0].blo; out.bhi = vb[b1 - 1].bhi; }
+    };
+    uint32_t pass_end = 0;                     // staged: the whole-bin pieces [.., pass_end) are in the list
+    uint32_t taken_lo = 0, taken_hi = 0;       // ... and blk_cnt holds the per-block counts of the list's entries of the pieces [taken_lo - 1, taken_hi - 1)
+    uint64_t n_staged = 0;
+    int passes = 0;
+    for (uint32_t b0 = 0; b0 < nv;) {
+        const bool from_list = staged && !vb[b0].slice;
+        if (from_list && b0 >= pass_end) {     // the next pass over the text: as many whole bins as the list holds
+            pass_end = b0; n_staged = 0;
+            while (pass_end < nv && !vb[pass_end].slice && n_staged + vb[pass_end].reps <= stage_cap) n_staged += vb[pass_end++].reps;
+            if (pass_end == b0) throw std::runtime_error("guided sort (expansion): a bin exceeds the staging list");
+            taken_lo = taken_hi = 0;
+            if (n_staged) {
+                uint32_t lo, hi, nlo, nhi;
+                gk::RunSlice none;
+                real_range(b0, pass_end, lo, hi, none);
+                if (!(counted_lo == b0 + 1 && counted_hi == pass_end + 1)) gk::batch_count(ctx, prefix_chars, lo, hi, tile_cnt.get(), st);
+                prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+                uint32_t next_end = pass_end;
+                uint64_t next_total = 0;
+                while (next_end < nv && !vb[next_end].slice && next_total + vb[next_end].reps <= stage_cap) next_total += vb[next_end++].reps;
+                const bool more = next_total > 0;
+                real_range(pass_end, next_end, nlo, nhi, none);
+                gk::stage_fill(ctx, prefix_chars, lo, hi, tile_off.get(), stage.get(), nlo, more ? nhi : nlo, more ? tile_cnt.get() : nullptr, st);
+                counted_lo = more ? pass_end + 1 : 0; counted_hi = more ? next_end + 1 : 0;
+                passes++;
+            }
+        }
         uint64_t total = 0, total_rep = 0;
-        const uint32_t b1 = next_batch_end(b0, total, total_rep);
+        const uint32_t b_stop = from_list ? pass_end : nv;
+        const uint32_t b1 = next_batch_end(b0, b_stop, total, total_rep);
         if (b1 == b0) throw std::runtime_error("guided sort (expansion): a bin exceeds the batch");
         if (total && !total_rep) throw std::runtime_error("guided sort (expansion): suffixes without a representative");
         if (!total) { b0 = b1; continue; }
         const uint32_t B = (uint32_t)total_rep;
         auto t_a = now();
-        // ---- collect and sort the representatives of the bins [b0, b1) ----
-        // (the batch before counted this batch's representatives per tile while it collected its own)
-        if (!(counted_lo == b0 && counted_hi == b1)) gk::batch_count(ctx, prefix_chars, b0, b1, tile_cnt.get(), st);
-        prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+        // ---- collect and sort the representatives of the pieces [b0, b1) ----
+        uint32_t r_lo, r_hi, nr_lo, nr_hi;
+        gk::RunSlice rsl, nrs;
+        real_range(b0, b1, r_lo, r_hi, rsl);
         uint64_t nt = 0, ntr = 0;
-        const uint32_t nb1 = next_batch_end(b1, nt, ntr);
-        const bool more = nt > 0;
-        gk::batch_fill(ctx, prefix_chars, b0, b1, tile_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1, more ? tile_cnt.get() : nullptr, st);
-        counted_lo = more ? b1 : 0; counted_hi = more ? nb1 : 0;
+        if (from_list) {
+            const uint32_t nb = (uint32_t)((n_staged + 4095) / 4096);
+            // (the batch before counted this batch's entries per block while it took its own)
+            if (!(taken_lo == b0 + 1 && taken_hi == b1 + 1)) gk::stage_count(stage.get(), n_staged, r_lo, r_hi, blk_cnt.get(), st);
+            prims::exclusive_sum_u32(d_temp_, blk_cnt.get(), blk_off.get(), nb, st);
+            const uint32_t nb1 = b1 < pass_end ? next_batch_end(b1, pass_end, nt, ntr) : b1;
+            real_range(b1, nb1, nr_lo, nr_hi, nrs);
+            const bool more = ntr > 0;
+            gk::stage_take(ctx, stage.get(), n_staged, r_lo, r_hi, blk_off.get(), X.key_a.get(), X.pos_a.get(), nr_lo, more ? nr_hi : nr_lo,
+                           more ? blk_cnt.get() : nullptr, st);
+            taken_lo = more ? b1 + 1 : 0; taken_hi = more ? nb1 + 1 : 0;
+        } else {
+            // (the batch before counted this batch's representatives per tile while it collected its own)
+            if (!(counted_lo == b0 + 1 && counted_hi == b1 + 1)) { gk::batch_count(ctx, prefix_chars, r_lo, r_hi, tile_cnt.get(), st, rsl); if (rsl.sym) passes++; }
+            prims::exclusive_sum_u32(d_temp_, tile_cnt.get(), tile_off.get(), n_tiles, st);
+            const uint32_t nb1 = b1 < nv ? next_batch_end(b1, nv, nt, ntr) : b1;
+            real_range(b1, nb1, nr_lo, nr_hi, nrs);
+            const bool more = nt > 0 && !rsl.sym && !nrs.sym && !staged;      // (a batch of slices counts for itself)
+            gk::batch_fill(ctx, prefix_chars, r_lo, r_hi, tile_off.get(), X.key_a.get(), X.pos_a.get(), nr_lo, more ? nr_hi : nr_lo,
+                           more ? tile_cnt.get() : nullptr, st, rsl);
+            counted_lo = more ? b1 + 1 : 0; counted_hi = more ? nb1 + 1 : 0;
+            passes++;
+            if (vb[b0].slice) pass_end = b1;
+        }
         RoundStats rs = sort_batch(X, B, ctx, d_temp_, S.err.get(), st, L.get(), &rmq);
         gk::batch_lcp(ctx, rmq, X.pos_b.get(), B, carry.get(), have_prev, L.get(), S.err.get(), st);
         MMT_HIP(hipMemcpyAsync(carry.get(), X.pos_b.get() + (B - 1), 8, hipMemcpyDeviceToDevice, st));
@@ -973,13 +1172,15 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
         for (uint32_t s0 = b0; s0 < b1;) {
             uint64_t wtotal = 0;
             uint32_t s1 = s0;
-            while (s1 < b1 && wtotal + bins[s1] <= win_cap) wtotal += bins[s1++];
+            while (s1 < b1 && wtotal + vb[s1].count <= win_cap) wtotal += vb[s1++].count;
             if (s1 == s0) throw std::runtime_error("guided sort (expansion): a bin exceeds the window");
             if (!wtotal) { s0 = s1; continue; }
             EventPair& ee = next_range_event(SS, 3);
             ee.start(st);
             uint64_t ext = 0;
-            if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[prev_last_bin], prev_len), capped ? SS.ext0 : ~0ull);
+            // (what an interval of this window can reach of the window before: the rest of ITS bin -- of the whole run bin when the
+            // window before ended in one of its slices)
+            if (have_prev) ext = std::min<uint64_t>(std::min<uint64_t>(bins[vb[prev_last_bin].bin], prev_len), capped ? SS.ext0 : ~0ull);
             if (ext > head_room || ext > tail_len) throw std::runtime_error("guided sort: window head room too small");
             if (ext) {
                 const uint64_t from = tail_len - ext;
@@ -989,7 +1190,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
                 MMT_HIP(hipMemcpyAsync(w_lcp_[0].get(), t_lcp.get() + from, ext * 4, hipMemcpyDeviceToDevice, st));
             }
             S.first_tile.clear();
-            // (stream entry base + 1 begins a bin, hence a group: its tile is where the window's groups begin; what the tile holds
+            // (stream entry base + 1 begins a bin or a slice, hence a group: its tile is where the window's groups begin; what the tile holds
             // of the window before is written once more, into the tail, with the same values)
             S.first_tile[base - ext] = (base + 1) / pk::emit_tile();
             pfp_emit_window(base - ext, base + wtotal, 0);
@@ -1018,13 +1219,15 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
                 MMT_HIP(hipMemcpyAsync(t_lcp.get(), w_lcp_[0].get() + from, tail_len * 4, hipMemcpyDeviceToDevice, st));
             }
             ColWindow w = window_view(0, base - ext, (uint32_t)len, (uint32_t)ext);
-            w.more_left = false;          // nothing an interval of this window could reach lies further left (bins)
+            // nothing an interval of this window could reach lies further left (bins) -- but for a window that continues a run bin:
+            // there the cap of the mode bounds the reach (ext0), as between the windows of the parse proper
+            w.more_left = vb[s0].slice && !vb[s0].first;
             keep_window(w);
             if (want_anchor_ranks_) {
                 SaCol piece = w.sa; piece.lo += ext; if (piece.hi) piece.hi += ext;
                 k::anchor_ranks(piece, base, wtotal, anchor, wide_ ? (void*)d_rank64_.get() : (void*)d_rank_.get(), st);
             }
-            const bool last_of_share = s1 == bin_hi || base + wtotal == piece_end;
+            const bool last_of_share = s1 == nv || base + wtotal == piece_end;
             if (last_of_share && base + wtotal < n) {
                 MMT_HIP(hipMemsetAsync(w_lcp_[0].get() + len, 0, 4, st));
                 MMT_HIP(hipMemsetAsync(w_bwt_[0].get() + len, 0, 1, st));
@@ -1035,7 +1238,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
             if (!scan_window(SS, w, p)) throw std::runtime_error("guided sort: a walk left its bin");
             sink_flush(SS);
             prev_len = len; have_prev = true;
-            for (uint32_t b = s1; b-- > s0;) if (bins[b]) { prev_last_bin = b; break; }
+            for (uint32_t b = s1; b-- > s0;) if (vb[b].count) { prev_last_bin = b; break; }
             base += wtotal; windows++;
             s0 = s1;
         }
@@ -1049,8 +1252,11 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     guided_check_errors("text suffixes");
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
     S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)windows;
+    text_passes_ = (uint32_t)passes; batches_ = (uint32_t)batches; staged_ = staged;
     MMT_HIP(hipStreamSynchronize(st));
     const double ms = std::chrono::duration<double, std::milli>(now() - t0).count();
+    if (stats) std::fprintf(stderr, "[guided] expansion: %d passes over the text%s, %u slices of %u run bins\n", passes,
+                            staged ? " (several batches per pass: staging list)" : "", run_slices_, sliced_bins);
     if (stats) std::fprintf(stderr, "[guided] expansion: %llu suffixes from %llu representatives (%llu in the whole text) in %d batches of at most %u "
                             "representatives, %d windows of at most %llu suffixes: %.1f ms (collect + sort + tables %.1f, emitter + scans %.1f); "
                             "%.3f of the representatives settled in small groups, %.3f element-rounds per representative in %d rounds at most\n",

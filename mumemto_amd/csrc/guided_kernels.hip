@@ -330,8 +330,9 @@ static void for_tile_slices(const Ctx& c, F&& launch) {
 // Which suffixes of a tile belong to the bins [bin_lo, bin_hi)?  Only the first `pc` symbols decide, so the pass over the
 // text rolls a bin code of pc * bits bits (a batch re-reads the whole text: at 79 G characters and 86 batches the two
 // text-order kernels were half of the run while they rolled full 63-bit keys for every position).
-template <typename F>
-__device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_sym, F&& f) {
+struct NoTileHook { __device__ __forceinline__ void operator()() const {} };
+template <typename F, typename H = NoTileHook>
+__device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_sym, F&& f, H&& staged = H()) {
     constexpr int BLOCK = 256, PER = TILE / BLOCK;
     static_assert(PER == 16, "one 16-byte load per work-item");
     __shared__ uint8_t s_code[256];
@@ -353,6 +354,7 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
     *reinterpret_cast<uint4*>(s_sym + t0) = mine.v;
     if (threadIdx.x < 4) *reinterpret_cast<uint4*>(s_sym + TILE + 16 * threadIdx.x) = codes_at(base + TILE + 16 * threadIdx.x);
     __syncthreads();
+    staged();                                   // (every work-item of the workgroup: the hook may hold barriers)
     const uint32_t bmask = (1u << (c.bits * pc)) - 1u;
     uint32_t bin = 0;
 #pragma unroll
@@ -362,6 +364,91 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
         else bin = ((bin << c.bits) | s_sym[t0 + q + pc - 1]) & bmask;
         f(q, base + t0 + q < c.n, bin & bmask);
     }
+}
+
+// ---- slices of a bin of ONE repeated symbol (RunSlice, guided.cpp) ---------------------------------------------------------
+// The suffixes that begin with c^pc -- assembly gaps: runs of N of tens of megabases in every haplotype -- are one bin whatever
+// the number of leading characters, and on whole genomes a bin of billions of suffixes that no batch holds.  Their order is
+// known in closed form: a suffix is c^r X with X0 != c (r = what is left of its run), and
+//     c^r X < c^r' X'  <=>  (X0 < c, r) before (X0' < c, r' > r);  every X0 < c before every X0 > c;  (X0 > c: larger r first),
+// so K = (X0 < c ? r : 2^41 - r) is monotone along the bin and a range of K is a contiguous piece of the suffix array.  K is
+// cut into buckets (run_bucket: exact below 256, then 8 bits of mantissa per power of two -- 0.4 % steps) and a slice is a
+// range of buckets [blo, bhi).  What is left of a run beyond the tile comes from a table with one entry per tile: the length of
+// the run that begins at the tile's first position, and the symbol behind it (k_tile_lead + a chain on the host).
+__device__ __forceinline__ uint32_t run_f(uint64_t r) {
+    if (r < 256) return (uint32_t)r;
+    const int e = 63 - __clzll((long long)r);
+    return (uint32_t)(e - 7) * 256u + (uint32_t)((r >> (e - 8)) & 0xffu);
+}
+__device__ __forceinline__ uint32_t run_bucket(uint64_t r, bool below) {
+    if (r >= (1ull << 40)) r = (1ull << 40) - 1;
+    const uint32_t f = run_f(r);
+    return below ? f : 2u * RUN_BUCKETS_HALF - 1u - f;
+}
+// bit q of the result: the suffix at tile position 16 * threadIdx.x + q, IF it begins with pc symbols rs.sym, lies in a bucket
+// of [rs.blo, rs.bhi); *bucket_out (optional, 16 entries): its bucket.  Called by the whole workgroup with the tile staged.
+__device__ __forceinline__ uint32_t tile_run_mask(const Ctx& c, const RunSlice& rs, const uint8_t* s_sym, uint32_t* bucket_out) {
+    __shared__ unsigned long long s_rn[257];
+    __shared__ uint8_t s_fn[257], s_d[256];
+    const uint32_t t = threadIdx.x, t0 = t * 16;
+    uint32_t d = 0;
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const bool is = s_sym[t0 + q] == rs.sym; any |= is; if (is && d == (uint32_t)q) d++; }
+    s_d[t] = (uint8_t)d;
+    if (!__syncthreads_or(any ? 1 : 0)) return 0u;
+    if (t == 0) {
+        const uint64_t tile = (uint64_t)blockIdx.x + c.tile0;
+        unsigned long long rn = 0; uint8_t fn = 0;
+        if (tile + 1 < rs.n_tiles) {
+            const uint8_t f1 = rs.first[tile + 1];
+            if (f1 == rs.sym) { rn = rs.lead[tile + 1]; fn = rs.follow[tile + 1]; } else fn = f1;
+        }
+        s_rn[256] = rn; s_fn[256] = fn;
+        for (int k = 255; k >= 0; k--) {
+            const uint32_t dk = s_d[k];
+            if (dk == 16) rn += 16; else { rn = dk; fn = s_sym[k * 16 + dk]; }
+            s_rn[k] = rn; s_fn[k] = fn;
+        }
+    }
+    __syncthreads();
+    unsigned long long r = s_rn[t + 1];
+    uint8_t fo = s_fn[t + 1];
+    uint32_t mask = 0;
+#pragma unroll
+    for (int q = 15; q >= 0; q--) {
+        const uint8_t sy = s_sym[t0 + q];
+        if (sy == rs.sym) r++; else { r = 0; fo = sy; }
+        const uint32_t b = r ? run_bucket(r, fo < rs.sym) : 0u;
+        if (bucket_out) bucket_out[q] = b;
+        if (r && b >= rs.blo && b < rs.bhi) mask |= 1u << q;
+    }
+    __syncthreads();
+    return mask;
+}
+
+// per tile: the symbol at its first position, how many of its first positions hold that symbol (TILE: all of them), and the
+// symbol behind them
+__global__ __launch_bounds__(256) void k_tile_lead(Ctx c, uint8_t* __restrict__ first, uint16_t* __restrict__ lead, uint8_t* __restrict__ follow) {
+    __shared__ __align__(16) uint8_t s_sym[TILE + 64];
+    __shared__ uint32_t s_min;
+    if (threadIdx.x == 0) s_min = TILE;
+    for_tile_bins(c, 1, s_sym, [&](int, bool, uint32_t) {});
+    const uint8_t s0 = s_sym[0];
+    uint32_t mine = TILE;
+    for (int q = 15; q >= 0; q--) if (s_sym[threadIdx.x * 16 + q] != s0) mine = threadIdx.x * 16 + q;
+    if (mine < TILE) atomicMin(&s_min, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t tile = (uint64_t)blockIdx.x + c.tile0;
+        first[tile] = s0; lead[tile] = (uint16_t)s_min; follow[tile] = s_min < TILE ? s_sym[s_min] : (uint8_t)0;
+    }
+}
+void tile_lead(const Ctx& c, uint8_t* first, uint16_t* lead, uint8_t* follow, hipStream_t s) {
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_tile_lead, dim3(blocks), dim3(256), 0, s, cs, first, lead, follow);
+    });
+    MMT_HIP(hipGetLastError());
 }
 
 // ---- expansion (guided.cpp, Ctx::repbits): only the text suffixes that start in the REPRESENTATIVE occurrence of their
@@ -464,22 +551,45 @@ void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
-                                                     uint32_t* __restrict__ tile_count) {
+                                                     uint32_t* __restrict__ tile_count, RunSlice rs) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
-    uint32_t mine = 0;
+    uint32_t mine = 0, slice = 0xffffu;
     const uint32_t keep = tile_rep_keep(c);
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && ((keep >> q) & 1u) && b >= bin_lo && b < bin_hi) mine++; });
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && ((keep & slice) >> q & 1u) && b >= bin_lo && b < bin_hi) mine++; },
+                  [&]() { if (rs.sym) slice = tile_run_mask(c, rs, s_sym, nullptr); });
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     if (threadIdx.x == 0) tile_count[(uint64_t)blockIdx.x + c.tile0] = s_cnt;
 }
-void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s) {
+void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s, const RunSlice& rs) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_batch_count, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_count);
+        hipLaunchKernelGGL(k_batch_count, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_count, rs);
+    });
+    MMT_HIP(hipGetLastError());
+}
+
+// the suffixes of the run bin `bin` (= rs.sym repeated pc times) per bucket of K: hist[b] all of them, hist[2 * HALF + b] those the
+// expansion keeps (c.repbits; the same numbers without it).  One pass; only tiles that hold the symbol do anything.
+__global__ __launch_bounds__(256) void k_run_hist(Ctx c, int pc, uint32_t bin, RunSlice rs, unsigned long long* __restrict__ hist) {
+    __shared__ __align__(16) uint8_t s_sym[TILE + 64];
+    uint32_t bucket[16];
+    uint32_t inrun = 0;
+    const uint32_t keep = tile_rep_keep(c);
+    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+        if (!in || b != bin || !((inrun >> q) & 1u)) return;
+        atomicAdd(hist + bucket[q], 1ull);
+        if ((keep >> q) & 1u) atomicAdd(hist + 2u * RUN_BUCKETS_HALF + bucket[q], 1ull);
+    }, [&]() { inrun = tile_run_mask(c, rs, s_sym, bucket); });
+}
+void run_hist(const Ctx& c, int prefix_chars, uint32_t bin, const RunSlice& rs, uint64_t* hist, hipStream_t s) {
+    RunSlice all = rs;
+    all.blo = 0; all.bhi = 2u * RUN_BUCKETS_HALF;
+    for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
+        hipLaunchKernelGGL(k_run_hist, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin, all, reinterpret_cast<unsigned long long*>(hist));
     });
     MMT_HIP(hipGetLastError());
 }
@@ -489,18 +599,19 @@ void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_h
 __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
                                                     const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
                                                     uint64_t* __restrict__ pos, uint32_t next_lo, uint32_t next_hi,
-                                                    uint32_t* __restrict__ next_count) {
+                                                    uint32_t* __restrict__ next_count, RunSlice rs) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_wave[4], s_next[4];
     __shared__ uint16_t s_sel[TILE];                               // tile offsets of the selected suffixes, in order
     constexpr int PER = TILE / 256;
-    uint32_t sel = 0, nxt = 0;
+    uint32_t sel = 0, nxt = 0, slice = 0xffffu;
     const uint32_t keep = tile_rep_keep(c);
+    // (a batch of slices of a run bin never counts the next batch along: next_count is null then)
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
         in = in && ((keep >> q) & 1u);
-        if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
+        if (in && b >= bin_lo && b < bin_hi && ((slice >> q) & 1u)) sel |= 1u << q;
         if (in && b >= next_lo && b < next_hi) nxt++;
-    });
+    }, [&]() { if (rs.sym) slice = tile_run_mask(c, rs, s_sym, nullptr); });
     // ordered compaction: exclusive prefix of the per-work-item counts over the workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = __popc(sel);
@@ -536,10 +647,10 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     }
 }
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
-                uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s) {
+                uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s, const RunSlice& rs) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
         hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, keys, pos, next_lo,
-                           next_hi, next_count);
+                           next_hi, next_count, rs);
     });
     MMT_HIP(hipGetLastError());
 }
@@ -559,7 +670,9 @@ __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_
     __shared__ uint16_t s_sel[TILE];
     constexpr int PER = TILE / 256;
     uint32_t sel = 0, nxt = 0;
+    const uint32_t keep = tile_rep_keep(c);              // (expansion: the list holds representatives only)
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+        in = in && ((keep >> q) & 1u);
         if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
         if (in && b >= next_lo && b < next_hi) nxt++;
     });

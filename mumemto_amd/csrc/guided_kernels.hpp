@@ -62,6 +62,21 @@ struct Ctx {
     unsigned long long* prof = nullptr;
 };
 
+// A slice of a bin of ONE repeated symbol (guided_kernels.hip, "slices of a bin of one repeated symbol"): the suffixes c^r X of the
+// bin whose K = (X0 < c ? r : 2^41 - r) falls into the buckets [blo, bhi) -- a contiguous piece of the suffix array.  sym = 0: none.
+constexpr uint32_t RUN_BUCKETS_HALF = 8448;          // buckets per class: r exact below 256, then 256 per power of two up to 2^40
+struct RunSlice {
+    uint32_t sym = 0, blo = 0, bhi = 0;
+    const uint64_t* lead = nullptr;                  // per tile of 4096 text positions: length of the run of `first` that begins at its
+    const uint8_t* first = nullptr;                  // first position (may span many tiles), the symbol there, and the symbol behind the run
+    const uint8_t* follow = nullptr;
+    uint64_t n_tiles = 0;
+};
+// per tile: symbol at the first position, number of leading positions that hold it (4096: the whole tile), the symbol behind them
+void tile_lead(const Ctx& c, uint8_t* first, uint16_t* lead, uint8_t* follow, hipStream_t s);
+// hist[b], b < 2 * RUN_BUCKETS_HALF: suffixes of the run bin per bucket; hist[2 * RUN_BUCKETS_HALF + b]: those c.repbits keeps
+void run_hist(const Ctx& c, int prefix_chars, uint32_t bin, const RunSlice& rs, uint64_t* hist, hipStream_t s);
+
 // cut bits -> rank directory counts (one per 512 positions) and the first cut of every block of 4096 positions
 void rank_counts(const uint64_t* mask, uint64_t n_words, uint32_t* counts, uint64_t n_counts, hipStream_t s);
 void block_first_cut(const uint64_t* mask, uint64_t n_words, uint64_t* first, uint64_t n_blocks, hipStream_t s);
@@ -70,11 +85,12 @@ void block_cut_offsets(const uint64_t* mask, uint64_t n_words, const uint32_t* b
 
 // bins = leading `prefix_chars` symbols of every text suffix (at most 4096 bins)
 void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s);
-void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s);
+void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s,
+                 const RunSlice& rs = RunSlice());
 // the suffixes whose bin lies in [bin_lo, bin_hi), in text order: first key and element record
 // (next_count, optional: per-tile counts of the next batch's bins [next_lo, next_hi), taken along)
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
-                uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s);
+                uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s, const RunSlice& rs = RunSlice());
 // several batches per pass over the text: the suffixes of bins [bin_lo, bin_hi) in text order as (V index | bin << 40) ...
 // (next_count, optional: the per-tile counts of the next pass's bins [next_lo, next_hi), taken along)
 void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,

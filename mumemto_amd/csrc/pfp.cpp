@@ -473,7 +473,7 @@ void Engine::pfp_group_tables(uint32_t E, uint32_t G, uint64_t out_lo, uint64_t 
     ea.rmq = S.plcp.view(); ea.w = S.emit_w;
     ea.bwt_code = S.bwt_code.get(); ea.fb_bits = S.fb_bits;
     S.tile_first.ensure((size_t)(S.tiles - S.tile_base) + 4);
-    pk::tile_first(S.segb.get(), G, S.tiles, S.tile_first.get() - S.tile_base, W, st, S.tile_base);
+    pk::tile_first(S.segb.get(), G, S.tiles, S.tile_first.get(), W, st, S.tile_base);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
 }
 
@@ -559,7 +559,7 @@ void Engine::pfp_emit_window(uint64_t b0, uint64_t c1, int set) {
         ea.fb_keys = S.xk_a.get(); ea.fb_vals = S.xv_a.get();
         ea.fb_base = S.h_fb_off[f0];
         S.emit_plan.ensure(pk::emit_plan_bytes(t1 - t0));
-        pk::emit(ea, S.tile_first.get() - S.tile_base, S.emit_plan.get(), t0, t1, st);
+        pk::emit(ea, S.tile_first.get(), S.tile_base, S.emit_plan.get(), t0, t1, st);
         S.emit_launches++;
         const uint32_t nf = f1 - f0;
         if (nf) pk::emit_big(ea, S.fb_chunk0.get(), f0, nf, S.h_fb_chunk0[f1] - S.h_fb_chunk0[f0], st);

@@ -1218,11 +1218,10 @@ __global__ void k_tile_first(const P* __restrict__ segb, uint32_t n_groups, uint
     if (g > n_groups) return;
     // group g is the first one at or after t * tile for every t with begin(g-1) < t * tile <= begin(g);
     // the thread of g == n_groups closes the table for the tiles behind the last group
-    // (tile_base: the tables of one batch of the stream -- guided.cpp, expansion -- begin at that tile; `tile_first` is the
-    // table's address minus tile_base entries)
+    // (tile_base: the tables of one batch of the stream -- guided.cpp, expansion -- begin at that tile: entry t - tile_base)
     const uint64_t lo = g ? (uint64_t)segb[g - 1] / tile + 1 : tile_base;
     const uint64_t hi = g < n_groups ? (uint64_t)segb[g] / tile : tiles;
-    for (uint64_t t = lo; t <= hi && t <= tiles; t++) tile_first[t] = g;
+    for (uint64_t t = lo; t <= hi && t <= tiles; t++) tile_first[t - tile_base] = g;
 }
 void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s, uint64_t tile_base) {
     if (wide)
@@ -1243,12 +1242,12 @@ void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* o
 struct EmitDesc { uint32_t g0, g_next, g_end, e0, e1, clo, L, pad; };
 template <typename P, int TILE, int CAP>
 __global__ void k_emit_plan(const P* __restrict__ segb, const uint32_t* __restrict__ sege, const uint32_t* __restrict__ tile_first,
-                            uint64_t tile_lo, uint32_t n_tiles, EmitDesc* __restrict__ out) {
+                            uint64_t tile_base, uint64_t tile_lo, uint32_t n_tiles, EmitDesc* __restrict__ out) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     const uint64_t tile = tile_lo + t, tbase = tile * TILE;
     EmitDesc d;
-    d.g0 = tile_first[tile]; d.g_end = tile_first[tile + 1]; d.g_next = d.g0;
+    d.g0 = tile_first[tile - tile_base]; d.g_end = tile_first[tile - tile_base + 1]; d.g_next = d.g0;
     d.e0 = d.e1 = d.clo = d.L = d.pad = 0;
     if (d.g0 < d.g_end) {
         const uint64_t first = (uint64_t)segb[d.g0] - tbase, lim = first + CAP;
@@ -1622,7 +1621,7 @@ uint32_t emit_tile() {
     return t;
 }
 template <typename P, typename SA, int TILE, int BLOCK = 256>
-static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
+static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_base, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
     constexpr int CAP = (int)EMIT_CAP;
     EmitArgsT<P, SA> t;
     t.segb = static_cast<const P*>(a.segb); t.sege = a.sege; t.n_groups = a.n_groups;
@@ -1642,7 +1641,7 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* 
     const uint32_t n_tiles = (uint32_t)(tile_hi - tile_lo);
     EmitDesc* desc = static_cast<EmitDesc*>(plan);
     hipLaunchKernelGGL((k_emit_plan<P, TILE, CAP>), dim3(grid_for(n_tiles, 256)), dim3(256), 0, s, t.segb, t.sege, tile_first_tab,
-                       tile_lo, n_tiles, desc);
+                       tile_base, tile_lo, n_tiles, desc);
     // persistent workgroups: seven per CU (the launch bounds), a few rounds of them so that the tail is short
     // (MMT_EMIT_GRID: workgroups of the launch, tests/micro; 0 = one per tile)
     static const uint32_t grid_env = std::getenv("MMT_EMIT_GRID") ? (uint32_t)std::atoi(std::getenv("MMT_EMIT_GRID")) : 256u * 7u * 4u;
@@ -1665,17 +1664,17 @@ static void emit_typed(const EmitArgs& a, const uint32_t* tile_first_tab, void* 
     MMT_HIP(hipGetLastError());
 }
 size_t emit_plan_bytes(uint64_t tiles) { return (size_t)tiles * sizeof(EmitDesc); }
-void emit(const EmitArgs& a, const uint32_t* tile_first_tab, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
+void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_base, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s) {
     if (tile_hi <= tile_lo) return;
     const uint32_t tile = emit_tile();
     if (a.wide) {
-        if (tile == 1024) emit_typed<uint64_t, Sa40, 1024>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
-        else if (tile == 768) emit_typed<uint64_t, Sa40, 768>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
-        else emit_typed<uint64_t, Sa40, 896>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
+        if (tile == 1024) emit_typed<uint64_t, Sa40, 1024>(a, tile_first_tab, tile_base, plan, tile_lo, tile_hi, s);
+        else if (tile == 768) emit_typed<uint64_t, Sa40, 768>(a, tile_first_tab, tile_base, plan, tile_lo, tile_hi, s);
+        else emit_typed<uint64_t, Sa40, 896>(a, tile_first_tab, tile_base, plan, tile_lo, tile_hi, s);
     } else {
-        if (tile == 1024) emit_typed<uint32_t, Sa32, 1024>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
-        else if (tile == 768) emit_typed<uint32_t, Sa32, 768>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
-        else emit_typed<uint32_t, Sa32, 896>(a, tile_first_tab, plan, tile_lo, tile_hi, s);
+        if (tile == 1024) emit_typed<uint32_t, Sa32, 1024>(a, tile_first_tab, tile_base, plan, tile_lo, tile_hi, s);
+        else if (tile == 768) emit_typed<uint32_t, Sa32, 768>(a, tile_first_tab, tile_base, plan, tile_lo, tile_hi, s);
+        else emit_typed<uint32_t, Sa32, 896>(a, tile_first_tab, tile_base, plan, tile_lo, tile_hi, s);
     }
 }
 

@@ -120,12 +120,12 @@ struct EmitArgs {
 };
 struct BwtDecode { uint8_t byte[16]; };       // code -> byte
 // tile_first[t] = first group whose begin offset is >= t * EMIT_TILE (tiles + 1 entries, tiles = ceil(n_out / TILE))
-// (tile_base: the table begins at that tile and `out` is its address MINUS tile_base entries: the tables of one batch)
+// (tile_base: the table begins at that tile -- entry t - tile_base --: the tables of one batch)
 void tile_first(const void* segb, uint32_t n_groups, uint64_t tiles, uint32_t* out, bool wide, hipStream_t s, uint64_t tile_base = 0);
 // output tiles [tile_lo, tile_hi); plan: emit_plan_bytes(tile_hi - tile_lo) bytes of device scratch (one record per tile,
 // written by a pre-pass of the launch: what a workgroup needs to know about a tile before it can load anything of it)
 size_t emit_plan_bytes(uint64_t tiles);
-void emit(const EmitArgs& a, const uint32_t* tile_first_tab, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s);
+void emit(const EmitArgs& a, const uint32_t* tile_first_tab, uint64_t tile_base, void* plan, uint64_t tile_lo, uint64_t tile_hi, hipStream_t s);
 // the oversized groups fb_group[f0 .. f0 + nf) of that launch, unsorted, into the fallback arrays: chunk0[f] = number of
 // chunks of EMIT_BIG_CHUNK output positions in all oversized groups before f (n_fb + 1 entries, device)
 constexpr uint32_t EMIT_BIG_CHUNK = 896;

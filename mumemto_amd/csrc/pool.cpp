@@ -45,7 +45,10 @@ struct Heap {
 
 std::mutex g_mu;
 std::vector<std::unique_ptr<Heap>> g_heaps;
-std::mutex g_unmap_mu;                              // held while chunks are being unmapped (shrink_async): grow() waits for it
+// chunks on their way out (shrink_async): g_unmap_pending is set under g_mu BEFORE the heap's top is lowered and cleared by the
+// helper thread when the last chunk is unmapped; grow() -- called with g_mu held -- waits for it (the helper never takes g_mu)
+std::atomic<bool> g_unmap_pending{false};
+std::mutex g_unmap_thread_mu;                       // guards g_unmap_thread itself
 std::thread* g_unmap_thread = nullptr;
 
 bool enabled() {
@@ -140,7 +143,7 @@ bool grow(Heap& H, size_t bytes) {
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 0; }
         if (fr < bytes + keep) return false;
     }
-    { std::lock_guard<std::mutex> pending(g_unmap_mu); }      // (chunks on their way out may sit where this maps)
+    while (g_unmap_pending.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (chunks on their way out may sit where this maps)
     const double t0 = now_s();
     size_t done = 0;
     std::string why;
@@ -314,16 +317,21 @@ void shrink_async(int device) {
             }
             H.top = first_chunk;
         }
+        if (!todo.empty()) g_unmap_pending.store(true, std::memory_order_release);    // (under g_mu, with the lowered top)
     }
     if (todo.empty()) return;
     // (a leaked pointer: a joinable std::thread with static storage would end the process in its destructor)
+    std::lock_guard<std::mutex> tl(g_unmap_thread_mu);
     g_unmap_thread = new std::thread([todo, device]() {
-        std::lock_guard<std::mutex> lock(g_unmap_mu);
         (void)hipSetDevice(device);
+        // blocks are freed on the host, not in stream order: work that was enqueued before the release may still read a chunk
+        (void)hipDeviceSynchronize();
         for (const auto& t : todo) { (void)hipMemUnmap(t.first, GROW); (void)hipMemRelease(t.second); }
+        g_unmap_pending.store(false, std::memory_order_release);
     });
 }
 void shrink_wait() {
+    std::lock_guard<std::mutex> tl(g_unmap_thread_mu);
     if (g_unmap_thread) { if (g_unmap_thread->joinable()) g_unmap_thread->join(); delete g_unmap_thread; g_unmap_thread = nullptr; }
 }
 

@@ -53,8 +53,14 @@ for r in (A.only if A.only else range(A.ranks)):
     eng.set_scan_shard(r, A.ranks)
     eng.set_text_sink("/dev/null")
     eng.set_row_tap(kmers, max_rows=1 << 16, max_occ=1 << 23)
+    t_fill = [0.0]
+
+    def supplier(d, dst):                                 # (the TEST's generator: its time is reported apart from the engine's)
+        t1 = time.time()
+        model.fill(d, dst)
+        t_fill[0] += time.time() - t1
     t0 = time.time()
-    parts = eng.run_supplied(lens, lambda d, dst: model.fill(d, dst), num_distinct=nd, max_doc_freq=f, max_total_freq=mf)
+    parts = eng.run_supplied(lens, supplier, num_distinct=nd, max_doc_freq=f, max_total_freq=mf)
     dt = time.time() - t0
     eng.set_text_sink(None)
     assert parts == 1 and eng.is_wide() and eng.text_length() == n_text and eng.producer_used() == "guided"
@@ -74,7 +80,8 @@ for r in (A.only if A.only else range(A.ranks)):
                                                                    max_doc_freq=f, max_total_freq=mf)
         except AssertionError as ex:                     # (the other ranks still run; the script fails at the end)
             check_error = str(ex)[:400]
-    rec = dict(rank=r, ranks=A.ranks, seconds=round(dt, 1), first_entry=int(pieces[r][0]), entries=int(pieces[r][1]),
+    rec = dict(rank=r, ranks=A.ranks, seconds=round(dt, 1), supplier_s=round(t_fill[0], 1), engine_s=round(dt - t_fill[0], 1),
+               expanded=bool(eng.producer_expanded()), first_entry=int(pieces[r][0]), entries=int(pieces[r][1]),
                fraction=round(pieces[r][1] / n_text, 4), windows=st["windows"], rows=rows, bytes=int(written), digest="%016x" % digest,
                peak_hbm_gb=round(mem["peak"] / 2**30, 1), stage_ms=[round(x) for x in eng.stage_ms()],
                bins_checked=bins, suffixes_sorted_on_the_host=suffixes, rows_in_those_bins_equal_to_the_oracles=tapped,
@@ -93,7 +100,8 @@ if not A.only:
 print(json.dumps(dict(config="configs[4]: %d x %d bp, -k -1 -f 3, %d ranks time-multiplexed on one GPU" % (N, L0, A.ranks),
                       shares=len(shares), shares_tile_the_stream_exactly=tiles, suffixes=sum(s["entries"] for s in shares), rows=sum(s["rows"] for s in shares),
                       bytes=sum(s["bytes"] for s in shares), shares_run_s=round(sum(s["seconds"] for s in shares), 1),
-                      slowest_share_s=max(s["seconds"] for s in shares), peak_hbm_gb=max(s["peak_hbm_gb"] for s in shares),
+                      slowest_share_s=max(s["seconds"] for s in shares), slowest_share_engine_s=max(s["engine_s"] for s in shares),
+                      supplier_s=round(sum(s["supplier_s"] for s in shares), 1), peak_hbm_gb=max(s["peak_hbm_gb"] for s in shares),
                       bins_checked=sum(s["bins_checked"] for s in shares),
                       rows_in_those_bins=sum(s["rows_in_those_bins_equal_to_the_oracles"] for s in shares),
                       input_gbp=round(N * L0 / 1e9, 1), total_s=round(time.time() - t_all, 1))), flush=True)

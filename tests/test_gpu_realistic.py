@@ -202,3 +202,76 @@ def test_long_runs_of_one_symbol_in_the_dictionary_equal_the_oracle(seed, bucket
     finally:
         os.environ.pop("MMT_RUN_BUCKET", None)
         eng.close()
+
+
+def _gap_docs(seed):
+    """haplotypes with assembly gaps and homopolymers the way whole genomes carry them: the same gap in every haplotype with
+    private lengths (indels break gaps), a gap behind which a T follows (T > N: the other class of the closed form), gaps at both
+    ends of a document, a run of A (its reverse complement: a run of T), substitutions next to and inside the runs"""
+    rng = np.random.default_rng(4000 + seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    anc = acgt[rng.integers(0, 4, size=24_000)].copy()
+    docs = []
+    for h in range(6):
+        s = anc.copy()
+        pos = rng.integers(0, len(s), size=80)
+        s[pos] = acgt[rng.integers(0, 4, size=len(pos))]
+        parts = [s[:3000], np.full(6000 + 37 * h, ord("N"), np.uint8), s[3000:9000],
+                 np.full(3000 - 11 * h, ord("N"), np.uint8), np.frombuffer(b"T", np.uint8), s[9000:16000],
+                 np.full(4000 + (h % 3), ord("A"), np.uint8), s[16000:]]
+        if h == 2:
+            parts.insert(0, np.full(2500, ord("N"), np.uint8))          # a gap that begins the document ...
+        if h == 4:
+            parts.append(np.full(1700, ord("N"), np.uint8))             # ... and one that ends it (followed by '$' < N)
+        if h == 5:
+            parts[1] = np.concatenate([np.full(3500, ord("N"), np.uint8), acgt[rng.integers(0, 4, size=7)], np.full(2500, ord("N"), np.uint8)])
+        docs.append([np.concatenate(parts).tobytes()])
+    return docs
+
+
+@pytest.mark.parametrize("seed,limit,wp", [(1, "3000", (6, 16)), (3, "20000", (6, 16)), (4, "3000", (11, 7))])
+def test_bins_of_one_repeated_symbol_are_produced_in_slices(seed, limit, wp):
+    """The suffixes that begin with N^4 -- every position inside every assembly gap, on both strands -- are ONE bin of the
+    bucket-wise producer whatever the number of leading characters: 1.5 G suffixes in a rank's share of 13 whole genomes with 60 Mbp
+    of gaps each, more than a batch holds.  Such a bin is produced in slices by what is left of the run (guided_kernels.hip RunSlice:
+    c^r X sorts by (X0 < c, r) in closed form).  MMT_GUIDED_SLICE forces slices of a few thousand suffixes here: stream, rows and
+    thresholds against the oracle in the capped modes; the uncapped mode (an interval may be as long as its bin) keeps the bin whole.
+    The parse (11, 7) is the one the closed form does not hold for: the hash of N^11 is divisible by 7, so a phrase ends at every
+    position of a gap and the occurrences of a representative lie all over the bin -- its N bin stays whole (guided.cpp run_triggers;
+    the automatic parameters avoid such moduli)."""
+    import mumemto_amd
+    docs = _gap_docs(seed)
+    eng = mumemto_amd.Engine(0)
+    os.environ["MMT_GUIDED_BATCH"] = "9000"
+    os.environ["MMT_GUIDED_SLICE"] = limit
+    try:
+        eng.set_producer("expand", *wp)
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        for kw in (dict(merge_metadata=True), dict(num_distinct=5, max_doc_freq=3, max_total_freq=18), dict(use_revcomp=False)):
+            eng.set_docs(docs)
+            eng.run(**kw)
+            assert eng.producer_used() == "guided" and eng.producer_expanded()
+            st = eng.producer_stats()
+            assert st["run_slices"] >= (6 if limit != "20000" and wp == (6, 16) else 2), st
+            assert st["staged"] and st["batches"] >= 10, st
+            okw = dict(kw)
+            merge = okw.pop("merge_metadata", False)
+            revcomp = okw.pop("use_revcomp", True)
+            want = O.run(docs, merge=merge, revcomp=revcomp, **okw)
+            assert eng.output_text() == want.text(), (seed, limit, wp, kw)
+            if merge:
+                assert np.array_equal(eng.thresholds(), want.thresh())
+            if revcomp:
+                assert np.array_equal(eng.sa().astype(np.int64), sa[1:])
+                assert np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
+                assert np.array_equal(eng.bwt(), bwt[1:])
+        # uncapped: no slices, same bytes as the oracle
+        eng.set_docs(docs)
+        eng.run(num_distinct=2, max_doc_freq=0)
+        assert eng.producer_stats()["run_slices"] == 0
+        assert eng.output_text() == O.run(docs, num_distinct=2, max_doc_freq=0).text()
+    finally:
+        os.environ.pop("MMT_GUIDED_BATCH", None)
+        os.environ.pop("MMT_GUIDED_SLICE", None)
+        eng.close()

@@ -273,8 +273,18 @@ def main():
                 rec["stderr_tail"] = r.stderr.decode(errors="replace")[-400:]
             runs.append(rec)
         timed = [x for x in runs if x["timed"]]
+        # the same job with NO pause between the processes: what a process that starts right behind another one pays for the
+        # memory its predecessor gave back (the driver scrubs it; the figure the pause keeps out of `value`)
+        b2b = []
+        if timed and all(x["rc"] == 0 for x in timed) and not a.no_extras:
+            for i in range(4):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe] + paths + ["-o", os.path.join(workdir, "cli")], capture_output=True,
+                                   env=dict(os.environ, MUMEMTO_STATS=stats, MUMEMTO_DEVICE=str(local_rank)))
+                b2b.append({"wall_s": time.perf_counter() - t0, "rc": r.returncode})
+            time.sleep(a.pause)
         if timed and all(x["rc"] == 0 and "stage_ms" in x for x in timed):
-            fresh = {"runs": runs, "timed": timed, "seconds": sum(x["wall_s"] for x in timed)}
+            fresh = {"runs": runs, "timed": timed, "seconds": sum(x["wall_s"] for x in timed), "back_to_back": b2b}
         else:
             sys.stderr.write("[bench] the fresh-process steps failed (%s): the in-process steps are the timed ones\n"
                              % [x.get("stderr_tail", x["rc"]) for x in runs if x["rc"] != 0][:1])
@@ -444,6 +454,14 @@ def main():
                 "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if a.backend == "nccl" else None,
                 "strict": bool(a.strict_exchange),
                 "bytes_sent_per_rank_estimate": int((L0 + 1) * 4 + int(eng.L.mmt_num_rows(eng.h)) * (4 + 9 * len(mine))),
+                # every message of dist.cpp travels in pieces of at most 2^30 elements (MUMEMTO_RCCL_CHUNK)
+                "messages_of_this_rank": [
+                    {"what": what, "elements": int(cnt), "bytes": int(cnt * width), "pieces": int(max(1, -(-cnt // (1 << 30)))),
+                     "largest_piece_bytes": int(min(cnt, 1 << 30) * width)}
+                    for what, cnt, width in (("thresholds over the anchor (u32)", L0 + 1, 4),
+                                             ("row lengths (u32)", int(eng.L.mmt_num_rows(eng.h)), 4),
+                                             ("row offsets (i64)", int(eng.L.mmt_num_rows(eng.h)) * len(mine), 8),
+                                             ("row strands (u8)", int(eng.L.mmt_num_rows(eng.h)) * len(mine), 1))],
             },
         },
         "phase_s_avg": {k: v / in_steps for k, v in phases.items()},
@@ -508,6 +526,13 @@ def main():
                      for x in fresh["runs"]],
             "stage_ms_of_the_timed_runs": [x["stage_ms"] for x in fresh["timed"]],
             "heap_peak_bytes": fresh["timed"][-1]["heap_peak_bytes"],
+            "back_to_back": None if not fresh.get("back_to_back") or any(x["rc"] for x in fresh["back_to_back"]) else {
+                "runs_wall_s": [round(x["wall_s"], 3) for x in fresh["back_to_back"]],
+                "ms_per_step": float(np.mean([x["wall_s"] for x in fresh["back_to_back"][1:]])) * 1e3,
+                "value": total_bp / float(np.mean([x["wall_s"] for x in fresh["back_to_back"][1:]])) / 1e9, "unit": "Gbp/s",
+                "deferred_release_s": float(np.mean([x["wall_s"] for x in fresh["back_to_back"][1:]])) - fresh["seconds"] / a.steps,
+                "note": "processes started one right behind the other (the first of the four follows the pause and is left out of the "
+                        "mean): deferred_release_s is what a process waits for the device memory its predecessor released"},
             "output_identical_to_in_process": subprocess.run(["cmp", "-s", os.path.join(workdir, "cli.mums"), out_file]).returncode == 0,
         }
     else:

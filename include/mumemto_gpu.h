@@ -331,6 +331,11 @@ MMT_API int  mmt_dist_merge_ranges(mmt_comm* c, mmt_engine* e, uint32_t min_len,
 /* Modes without a partition merge (mmt_engine_set_scan_shard): the ranks' output bytes, concatenated in rank order, on
  * rank 0 (*len = 0 elsewhere); valid until the next call on this communicator.                                        */
 MMT_API int  mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len);
+/* Self-test of the exchange's message machinery with this rank as its own peer (dist.cpp dist_loopback): the row tables and
+ * the 32-bit threshold column of the engine's last run (merge metadata on) through ncclSend / ncclRecv in one group, in pieces
+ * of at most 2^30 elements, an all-gather and a broadcast; out = bytes moved, pieces, largest piece (bytes), elements that
+ * arrived different (0 is the answer), microseconds, rows, row cells, thresholds.                                         */
+MMT_API int  mmt_comm_loopback(mmt_comm* c, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

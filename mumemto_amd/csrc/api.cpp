@@ -780,6 +780,13 @@ int mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len) {
     MMT_CATCH
 }
 
+int mmt_comm_loopback(mmt_comm* c, uint64_t out[8]) {
+    if (!c || !out) return fail(1, "null");
+    MMT_TRY
+    mmt::dist_loopback(*c->c, out);
+    MMT_CATCH
+}
+
 const char* mmt_merged_text(mmt_merged* m, size_t* len) {
     if (!m) { if (len) *len = 0; return nullptr; }
     if (!m->text_valid) {

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -393,6 +394,76 @@ static MergedRows merge_by_ranges(Comm& c, uint32_t min_len, const std::vector<u
     MergedRows m = concat_pieces(e, pieces);
     sort_like_direct(e, m);
     return m;
+}
+
+// The messages of merge_on_rank0 / merge_by_ranges with THIS rank as its own peer: the row tables and the 32-bit threshold column
+// of the engine's last run travel through ncclSend / ncclRecv (one group, pieces of at most 2^30 elements), an all-gather of the
+// meta words and a broadcast of the thresholds -- what a one-GPU box can show the real library of the exchange's message sizes
+// (a rank's share of configs[3]: 3.05 G thresholds = 12.2 GB, 30 M x 13 rows), its size_t counts and its stream ordering.
+// out: [0] bytes moved, [1] message pieces, [2] largest piece in bytes, [3] elements that arrived different, [4] microseconds,
+// [5] rows, [6] row cells, [7] thresholds.
+template <typename T>
+__global__ void k_count_diff(const T* __restrict__ a, const T* __restrict__ b, size_t n, unsigned long long* __restrict__ diff) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mine += a[i] != b[i] ? 1 : 0;
+    if (mine) atomicAdd(diff, mine);
+}
+void dist_loopback(Comm& c, uint64_t out[8]) {
+    Engine& e = *c.engine;
+    MMT_HIP(hipSetDevice(e.device()));
+    hipStream_t st = e.stream();
+    const HostRows& R = e.rows_meta();
+    if (!R.mum_mode || !e.thresh_len()) throw std::runtime_error("the exchange needs a multi-MUM run with merge metadata");
+    const uint64_t L = e.doc_len()[0] + 1;
+    const uint32_t* my_len; const int64_t* my_off; const uint8_t* my_st;
+    e.rows_mum_device(&my_len, &my_off, &my_st);
+    const size_t rows = R.n_rows, cells = rows * R.n_docs;
+    const int me = c.rank;
+    c.len[me]->ensure(rows + 1); c.off[me]->ensure(cells + 1); c.st[me]->ensure(cells + 1); c.th[me]->ensure(L + 1);
+    DevBuf<uint32_t> bc;
+    bc.ensure(L + 1);
+    DevBuf<unsigned long long> diff;
+    diff.ensure(1);
+    MMT_HIP(hipMemsetAsync(diff.get(), 0, 8, st));
+    MMT_HIP(hipMemsetAsync(c.th[me]->get(), 0xa5, L * 4, st));             // (the stream orders the fill before the receive)
+    MMT_HIP(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)exchange_meta(c, rows, R.n_docs, L);                               // all-gather of the meta words
+    MMT_NCCL(rccl().GroupStart());
+    if (rows) {
+        send_pieces(my_len, rows, ncclUint32, me, c.comm, st); recv_pieces(c.len[me]->get(), rows, ncclUint32, me, c.comm, st);
+        send_pieces(my_off, cells, ncclInt64, me, c.comm, st); recv_pieces(c.off[me]->get(), cells, ncclInt64, me, c.comm, st);
+        send_pieces(my_st, cells, ncclUint8, me, c.comm, st); recv_pieces(c.st[me]->get(), cells, ncclUint8, me, c.comm, st);
+    }
+    send_pieces(e.thresh_device32(), L, ncclUint32, me, c.comm, st); recv_pieces(c.th[me]->get(), L, ncclUint32, me, c.comm, st);
+    MMT_NCCL(rccl().GroupEnd());
+    // a broadcast in pieces as well (round 2's route; still what a one-to-all step would use)
+    const size_t C = rccl_chunk();
+    uint64_t pieces = 0, largest = 0;
+    MMT_HIP(hipMemcpyAsync(bc.get(), e.thresh_device32(), L * 4, hipMemcpyDeviceToDevice, st));
+    for (size_t at = 0; at < L; at += C) {
+        const size_t k = std::min<size_t>(C, L - at);
+        MMT_NCCL(rccl().Broadcast(bc.get() + at, bc.get() + at, k, ncclUint32, 0, c.comm, st));
+    }
+    MMT_HIP(hipStreamSynchronize(st));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    auto count = [&](size_t n, size_t width) { for (size_t at = 0; at < n || at == 0; at += C) { pieces++; largest = std::max<uint64_t>(largest, std::min(C, n - at) * width); if (n <= at + C) break; } };
+    if (rows) { count(rows, 4); count(cells, 8); count(cells, 1); }
+    count(L, 4);
+    if (rows) {
+        hipLaunchKernelGGL(k_count_diff<uint32_t>, dim3(2048), dim3(256), 0, st, my_len, (const uint32_t*)c.len[me]->get(), rows, diff.get());
+        hipLaunchKernelGGL(k_count_diff<int64_t>, dim3(2048), dim3(256), 0, st, my_off, (const int64_t*)c.off[me]->get(), cells, diff.get());
+        hipLaunchKernelGGL(k_count_diff<uint8_t>, dim3(2048), dim3(256), 0, st, my_st, (const uint8_t*)c.st[me]->get(), cells, diff.get());
+    }
+    hipLaunchKernelGGL(k_count_diff<uint32_t>, dim3(2048), dim3(256), 0, st, e.thresh_device32(), (const uint32_t*)c.th[me]->get(), (size_t)L, diff.get());
+    hipLaunchKernelGGL(k_count_diff<uint32_t>, dim3(2048), dim3(256), 0, st, e.thresh_device32(), (const uint32_t*)bc.get(), (size_t)L, diff.get());
+    MMT_HIP(hipGetLastError());
+    unsigned long long d = 0;
+    MMT_HIP(hipMemcpyAsync(&d, diff.get(), 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    out[0] = rows * 4 + cells * 9 + L * 4 + L * 4; out[1] = pieces; out[2] = largest; out[3] = d; out[4] = (uint64_t)us;
+    out[5] = rows; out[6] = cells; out[7] = L;
+    c.len[me]->release(); c.off[me]->release(); c.st[me]->release(); c.th[me]->release();
 }
 
 // Modes without a partition merge: this rank's PREFIX.mums / .mems bytes (mmt_engine_set_scan_shard) to rank 0, in rank

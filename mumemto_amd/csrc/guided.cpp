@@ -166,7 +166,8 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
             prims::segmented_sort_pairs_u64_u64vals_ranges(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_c.get(), m,
                                                            segs, X.seg.get(), X.seg.get() + cap, 64, st);
         }
-        gk::round_heads(X.key_b.get(), X.ghead.get(), m, X.hv.get(), err, st);
+        gk::round_heads(X.key_b.get(), X.ghead.get(), m, X.hv.get(), err, st, std::getenv("MMT_GUIDED_NO_ROUND_LCP") ? nullptr : lcp_out,
+                        X.slot_a.get(), offset, ctx.bits, ctx.chars);
         prims::inclusive_max_u32(temp, X.hv.get(), X.hv.get(), m, st);
         gk::round_apply(X.pos_c.get(), X.hv.get(), X.slot_a.get(), m, X.pos_b.get(), X.flags.get(), st);
         prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);

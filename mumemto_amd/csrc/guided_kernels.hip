@@ -503,7 +503,11 @@ __device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
 // Dollars at the end) straight in global memory.  (A tile used to count in 4096 LDS counters, one pass over the text per
 // value of the bin code's bits above the low twelve: five leading characters at three bits each -- texts beyond 2^38
 // characters -- were EIGHT passes rolling full 63-bit keys, 13 s of a rank's share of 573 G characters.)
-__global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int pc, uint64_t* __restrict__ hist) {
+// (a workgroup counts BIN_HIST_TILES consecutive tiles before its LDS counters leave for global memory: with five leading
+// characters nearly all of the 1024 counters are hit in every tile, and 140 M tiles of a 573 G-character text each sending 1024
+// atomics to the same 1024 words were 6 s per pass -- eight times a pass that only reads the text)
+constexpr uint32_t BIN_HIST_TILES = 32;
+__global__ __launch_bounds__(256) void k_bin_hist(Ctx c0, int pc, uint64_t* __restrict__ hist, uint32_t slice_tiles) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_hist[1024];
     __shared__ uint8_t s_acgt[256];                 // symbol code -> 0 .. 3, or 0xff
@@ -511,16 +515,41 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int pc, uint64_t* __res
     for (int i = threadIdx.x; i < 1024; i += 256) s_hist[i] = 0;
     s_acgt[threadIdx.x] = 0xff;
     __syncthreads();
-    if (threadIdx.x < 4) { const uint8_t sym = c.code[(uint8_t)"ACGT"[threadIdx.x]]; s_acgt[sym] = (uint8_t)threadIdx.x; s_sym_of[threadIdx.x] = sym; }
+    if (threadIdx.x < 4) { const uint8_t sym = c0.code[(uint8_t)"ACGT"[threadIdx.x]]; s_acgt[sym] = (uint8_t)threadIdx.x; s_sym_of[threadIdx.x] = sym; }
     __syncthreads();
-    const uint32_t smask = (1u << c.bits) - 1u;
+    const uint32_t smask = (1u << c0.bits) - 1u;
     // (symbol code -> dense digit from a table in a register, four bits a symbol, 15 = not one of A C G T: five LDS lookups
     // per position made this pass 6 s over 573 G characters)
     uint64_t lut = ~0ull;
-    const bool in_register = c.bits <= 4;
+    const bool in_register = c0.bits <= 4;
     if (in_register)
         for (uint32_t k = 0; k < 4; k++) { const uint32_t sym = s_sym_of[k]; lut = (lut & ~(0xfull << (4 * sym))) | ((uint64_t)k << (4 * sym)); }
+    for (uint32_t ti = 0; ti < BIN_HIST_TILES; ti++) {
+    const uint32_t tile_in_slice = blockIdx.x * BIN_HIST_TILES + ti;
+    if (tile_in_slice >= slice_tiles) break;
+    // (the text-order helpers take their tile from blockIdx.x + tile0: the copy's tile0 makes that this tile)
+    Ctx c = c0;
+    c.tile0 = c0.tile0 + tile_in_slice - blockIdx.x;
     const uint32_t keep = tile_rep_keep(c);
+    // (the other bins: a work-item adds up consecutive suffixes of the same bin -- inside an assembly gap all sixteen are N^pc --
+    // and the wave adds up its work-items' counts before ONE atomic leaves for global memory: 1.5 G suffixes of the gaps of 13 whole
+    // genomes on one address were 6 s per pass at the ~250 atomics per microsecond one word takes)
+    uint32_t pend_bin = 0xffffffffu, pend_cnt = 0;
+    auto flush_wave = [&]() {
+        unsigned long long todo = __ballot(pend_cnt != 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t b = (uint32_t)__shfl((int)pend_bin, leader, 64);
+            const bool same = pend_cnt != 0 && pend_bin == b;
+            const unsigned long long grp = __ballot(same);
+            uint32_t v = same ? pend_cnt : 0u;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(reinterpret_cast<unsigned long long*>(hist + b), (unsigned long long)v);
+            if (same) pend_cnt = 0;
+            todo &= ~grp;
+        }
+    };
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t bin) {
         if (!in || !((keep >> q) & 1u)) return;
         uint32_t dense = 0, bad = 0;
@@ -531,9 +560,16 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int pc, uint64_t* __res
             dense = (dense << 2) | (a & 3u);
         }
         if (!bad) atomicAdd(&s_hist[dense], 1u);
-        else atomicAdd(reinterpret_cast<unsigned long long*>(hist + bin), 1ull);
+        else if (bin == pend_bin) pend_cnt++;
+        else {
+            if (pend_cnt) atomicAdd(reinterpret_cast<unsigned long long*>(hist + pend_bin), (unsigned long long)pend_cnt);
+            pend_bin = bin; pend_cnt = 1;
+        }
     });
+    flush_wave();
     __syncthreads();
+    }
+    const Ctx& c = c0;
     const uint32_t n_dense = 1u << (2 * pc);
     for (uint32_t d = threadIdx.x; d < n_dense; d += 256) {
         if (!s_hist[d]) continue;
@@ -545,7 +581,7 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c, int pc, uint64_t* __res
 void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
     if (prefix_chars > 5) throw std::runtime_error("bin_hist: at most five leading characters");
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_bin_hist, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, hist);
+        hipLaunchKernelGGL(k_bin_hist, dim3((blocks + BIN_HIST_TILES - 1) / BIN_HIST_TILES), dim3(256), 0, s, cs, prefix_chars, hist, blocks);
     });
     MMT_HIP(hipGetLastError());
 }
@@ -1528,8 +1564,14 @@ void range_groups(const uint32_t* ghead, const uint32_t* big_begin, const uint32
     MMT_HIP(hipGetLastError());
 }
 
+// lcp_out (optional, indexed by batch slot): where two neighbours of a group part by the CHARACTERS of this round's keys -- both
+// keys are symbol codes of the text behind the `offset` characters the group shares -- their suffixes share offset + the common
+// symbols of the two keys, and so do the two sub-groups' final neighbours whatever the later rounds do inside them: the value is
+// left for k_batch_lcp, which would otherwise walk those characters again from the start (satellite arrays: groups of millions
+// that part after hundreds of characters -- 12 s of a 105 s share of realistic whole genomes)
 __global__ void k_round_heads(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ghead, uint32_t m,
-                              uint32_t* __restrict__ headval, uint32_t* __restrict__ err) {
+                              uint32_t* __restrict__ headval, uint32_t* __restrict__ err, uint32_t* __restrict__ lcp_out,
+                              const uint32_t* __restrict__ slot, uint64_t offset, int bits, int chars) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= m) return;
     const uint64_t k = keys[c];
@@ -1538,11 +1580,16 @@ __global__ void k_round_heads(const uint64_t* __restrict__ keys, const uint32_t*
         const uint64_t kp = keys[c - 1];
         if ((k >> 63) != (kp >> 63)) atomicAdd(err + 1, 1u);    // one group, spent and unspent phrase suffixes: not prefix-free
         h = (k >> 63) != 0 || k != kp;                           // parse ranks are distinct: such a group is done
+        if (lcp_out && k != kp && !((k | kp) >> 62)) {
+            const uint64_t v = offset + (uint64_t)((__builtin_clzll(k ^ kp) - (64 - bits * chars)) / bits);
+            lcp_out[slot[c]] = v < (uint64_t)LCP_CAP ? (uint32_t)v : LCP_CAP;
+        }
     }
     headval[c] = h ? c : 0u;
 }
-void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL(k_round_heads, dim3(grid_for(m, 256)), dim3(256), 0, s, keys, ghead, m, headval, err);
+void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s,
+                 uint32_t* lcp_out, const uint32_t* slot, uint64_t offset, int bits, int chars) {
+    hipLaunchKernelGGL(k_round_heads, dim3(grid_for(m, 256)), dim3(256), 0, s, keys, ghead, m, headval, err, lcp_out, slot, offset, bits, chars);
     MMT_HIP(hipGetLastError());
 }
 __global__ void k_round_apply(const uint64_t* __restrict__ pos_sorted, const uint32_t* __restrict__ newhead,

@@ -127,7 +127,9 @@ void local_sort(const uint64_t* kin, const uint64_t* pin, const uint32_t* ghead,
                 const uint32_t* bound, uint32_t n_tiles, uint32_t* big_begin, uint32_t* big_end, uint32_t* big_count,
                 uint32_t big_cap, hipStream_t s);
 // the groups (begin, end) inside the listed ranges, for the segmented sort of groups longer than a tile
-void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s);
+// (lcp_out, optional, indexed by batch slot `slot[c]`: the LCP of two neighbours that part by the characters of this round's keys)
+void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s,
+                 uint32_t* lcp_out = nullptr, const uint32_t* slot = nullptr, uint64_t offset = 0, int bits = 0, int chars = 0);
 void round_apply(const uint64_t* pos_sorted, const uint32_t* newhead, const uint32_t* slot, uint32_t m, uint64_t* out,
                  uint8_t* flags, hipStream_t s);
 void round_compact(const uint32_t* idx, uint32_t m2, const uint32_t* slot, const uint64_t* pos_sorted,

@@ -104,28 +104,30 @@ def main():
     rng = np.random.default_rng(77 + A.rank)
     k = 14
     kmers = []
+    # (a k-mer of a periodic region may begin millions of suffixes: every candidate is counted in ALL the periodic regions of the
+    # ancestor -- both satellite arrays share their monomer -- and taken when it is rare there)
+    periodic = b"|".join(bytes(anc[s:e]) for kind, s, e in feats if kind != "gap")
+
+    def rare(km, limit=40):
+        c, at = 0, 0
+        while c <= limit:
+            at = periodic.find(km, at)
+            if at < 0:
+                break
+            c += 1; at += 1
+        return c <= limit
     for kind, s, e in feats:
         if kind != "satellite":
             continue
-        mid = (s + e) // 2
-        half = min(40_000_000, (e - s) // 2)
-        window = bytes(anc[mid - half:mid + half])
         found = 0
         for _ in range(3000):
-            p = int(rng.integers(0, len(window) - k))
-            km = window[p:p + k]
-            if km in kmers:
+            p = int(rng.integers(s, e - k))
+            km = bytes(anc[p:p + k])
+            if km in kmers or not rare(km):
                 continue
-            c, at = 0, 0
-            while c <= 40:
-                at = window.find(km, at)
-                if at < 0:
-                    break
-                c += 1; at += 1
-            if c <= 40:
-                kmers.append(km); found += 1
-                if found == 3:
-                    break
+            kmers.append(km); found += 1
+            if found == 3:
+                break
     n_sat = len(kmers)
     n_gap = 0
     for kind, s, e in feats:
@@ -135,8 +137,9 @@ def main():
     while len(kmers) < n_sat + n_gap + 6:
         p = int(rng.integers(0, len(anc) - k))
         km = bytes(anc[p:p + k])
-        if b"N" not in km and km not in kmers:
+        if b"N" not in km and km not in kmers and not any(s - k < p < e for _, s, e in feats) and rare(km, 0):
             kmers.append(km)
+    del periodic
     del anc
     print(json.dumps(dict(bins=len(kmers), inside_satellites=n_sat, behind_gaps=n_gap, k=k)), flush=True)
 
@@ -173,7 +176,7 @@ def main():
                           check_s=round(time.time() - t, 1))), flush=True)
     # ---- the instrument's own loop: the host enumerates the positions of every bin by itself
     t = time.time()
-    pos, which = eng.kmer_positions(kmers)
+    pos, which = eng.kmer_positions(kmers, cap=1 << 24)
     comp = bytes.maketrans(b"ACGTN", b"TGCAN")
     # (one bin of every kind: a whole-genome document is seconds of memmem per pattern and strand)
     chosen = sorted({0, n_sat, n_sat + 1, n_sat + n_gap} & set(range(len(kmers))))

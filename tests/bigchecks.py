@@ -368,7 +368,7 @@ def check_bins_complete(eng, text, n_text, doc_start, kmers, min_len=20, num_dis
         occ = np.sort(t_sa[int(t_start[r]):int(t_start[r + 1])].astype(np.int64))
         first = _text_piece(text, int(occ[0]), int(occ[0]) + k, n_text).tobytes()
         got.setdefault(first, set()).add((int(t_len[r]), tuple(int(x) for x in occ)))
-    pos, which = eng.kmer_positions(kmers)
+    pos, which = eng.kmer_positions(kmers, cap=1 << 24)
     doc_start = np.ascontiguousarray(doc_start, np.int64)
     suffixes = rows = 0
     for i, km in enumerate(kmers):

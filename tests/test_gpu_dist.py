@@ -305,6 +305,10 @@ m = comm.merge()
 assert m["text"] == O.run(docs, merge=True).text() and m["n_rows"] > 5, "strict multi-MUMs through the RCCL exchange"
 m2 = comm.merge(by_ranges=True)
 assert m2["text"] == m["text"], "the fold by coordinate ranges (dist_merge_ranges: broadcasts, all-to-all, gather) with one rank"
+# the exchange's messages with this rank as its own peer: ncclSend / ncclRecv in one group, all-gather, broadcast
+lb = comm.loopback()
+assert lb["different"] == 0 and lb["rows"] == m["n_rows"] and lb["thresholds"] == len(docs[0][0]) + 1, lb
+assert lb["pieces"] >= (40 if os.environ.get("MUMEMTO_RCCL_CHUNK") else 4), lb
 eng.set_scan_shard(0, 1)
 eng.run(num_distinct=5, max_doc_freq=3, max_total_freq=18)
 assert comm.gather_text() == O.run(docs, num_distinct=5, max_doc_freq=3, max_total_freq=18).text()
@@ -330,6 +334,7 @@ def test_c_abi_exchange_over_rccl_world_size_one(with_torch):
     env = dict(os.environ)
     if not with_torch:
         env["MUMEMTO_NO_TORCH"] = "1"
+        env["MUMEMTO_RCCL_CHUNK"] = "4099"          # (every message of the self-test in pieces of 4099 elements)
     r = subprocess.run([sys.executable, "-c", _NATIVE_SCRIPT % dict(root=root, with_torch=with_torch)], capture_output=True,
                        text=True, timeout=600, env=env)
     assert r.returncode == 0 and "NATIVE_EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

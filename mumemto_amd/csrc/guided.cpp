@@ -90,7 +90,8 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
     uint64_t offset = (uint64_t)ctx.chars;
     const uint32_t target = 1024, limit = gk::SORT_CAP - target;
     if (!std::getenv("MMT_GUIDED_NO_SMALL")) {                      // (the variable sends every group through the rounds: tests)
-        gk::resolve_small(ctx, X.pos_a.get(), X.ghead.get(), X.slot_a.get(), m, offset, X.pos_b.get(), X.flags.get(), err, st);
+        gk::resolve_small(ctx, X.pos_a.get(), X.ghead.get(), X.slot_a.get(), m, offset, X.pos_b.get(), X.flags.get(), err, st,
+                          std::getenv("MMT_GUIDED_NO_SMALL_LCP") ? nullptr : lcp_out);
         prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);
         const uint32_t m2 = read_u32(X.count.get(), st);
         if (m2 && m2 < m) {
@@ -127,10 +128,18 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
             }
         }
     }
+    const bool no_early_giant = std::getenv("MMT_GUIDED_NO_EARLY_GIANT") != nullptr;
     while (m) {
         if (++rs.rounds > (1 << 22)) throw std::runtime_error("parse-guided suffix sort did not converge");
         rs.active_sum += m;
-        gk::round_keys(ctx, X.pos_a.get(), m, offset, X.key_a.get(), err, st);
+        // (expansion: groups whose members all lie in giant phrases take their order from the giant dictionary at once --
+        // guided_kernels.hip k_giant_probe; idx and flags are dead until this round's heads are known)
+        const bool early_giant = ctx.expand && ctx.g_n && offset < ctx.g_depth && !no_early_giant;
+        if (early_giant) {
+            gk::giant_probe(ctx, X.pos_a.get(), X.ghead.get(), m, offset, X.idx.get(), X.flags.get(), st);
+            gk::round_keys(ctx, X.pos_a.get(), m, offset, X.key_a.get(), err, st, X.idx.get(), X.flags.get(), X.ghead.get());
+        } else
+            gk::round_keys(ctx, X.pos_a.get(), m, offset, X.key_a.get(), err, st);
         // sort inside the groups: (key_a, pos_a) -> (key_b, pos_c)
         const uint32_t n_tiles = (m + target - 1) / target;
         X.bound.ensure((size_t)n_tiles + 2);
@@ -166,8 +175,8 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
             prims::segmented_sort_pairs_u64_u64vals_ranges(temp, X.key_a.get(), X.key_b.get(), X.pos_a.get(), X.pos_c.get(), m,
                                                            segs, X.seg.get(), X.seg.get() + cap, 64, st);
         }
-        gk::round_heads(X.key_b.get(), X.ghead.get(), m, X.hv.get(), err, st, std::getenv("MMT_GUIDED_NO_ROUND_LCP") ? nullptr : lcp_out,
-                        X.slot_a.get(), offset, ctx.bits, ctx.chars);
+        gk::round_heads(ctx, X.key_b.get(), X.ghead.get(), m, X.hv.get(), err, st, std::getenv("MMT_GUIDED_NO_ROUND_LCP") ? nullptr : lcp_out,
+                        X.slot_a.get(), offset, early_giant ? X.flags.get() : nullptr);
         prims::inclusive_max_u32(temp, X.hv.get(), X.hv.get(), m, st);
         gk::round_apply(X.pos_c.get(), X.hv.get(), X.slot_a.get(), m, X.pos_b.get(), X.flags.get(), st);
         prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);
@@ -232,6 +241,8 @@ void Engine::guided_prepare() {
     MMT_HIP(hipMemcpyAsync(d_code_.get(), code, 256, hipMemcpyHostToDevice, st));
     std::memcpy(S.g_code, code, 256); S.g_bits = ctx.bits; S.g_share_valid = false;
     ctx.T = text_ref(); ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
+    for (int k = 0; k < 4; k++) ctx.acgt[k] = code[(uint8_t)"ACGT"[k]];
+    ctx.dense_ok = ctx.acgt[0] && ctx.acgt[1] && ctx.acgt[2] && ctx.acgt[3] && ctx.chars <= 32 && !std::getenv("MMT_GUIDED_NO_DENSE");
 
     // ---- phrase ends: rank directory and successor table over the cut bits ----
     const uint64_t n_words = S.tmask.size() * sizeof(uint16_t) / 8 / 64 * 64;     // whole blocks of 4096 positions

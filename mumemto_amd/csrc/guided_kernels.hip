@@ -366,6 +366,61 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
     }
 }
 
+// ---- tiles of a PACKED text that hold no exception: the suffixes straight from the words of 2-bit codes -------------------------
+// A pass over the text is a pass over 573 G characters on every rank of configs[4], nineteen times: staging symbol codes in LDS
+// (a table lookup and a byte store per character, a byte load per character and leading symbol, four workgroup barriers) was
+// most of its cost.  A tile -- one block of the exception flags -- without an exception, with 64 plain characters behind it, is
+// read as words: the dense code of a suffix (two bits per leading base, first base most significant) is a shift and a mask of
+// the work-item's 64-bit window with its 2-bit groups reversed.  The batches' bin ranges are ranges of dense codes too
+// (dense_lower: A < C < G < T in both numberings); only what is SELECTED turns its dense code back into symbol codes.
+__device__ __forceinline__ bool tile_is_plain(const Ctx& c) {
+    if (!c.dense_ok || !c.T.is_packed()) return false;
+    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
+    if (base + TILE + 64 > c.n) return false;
+    return !tx_block_flag(c.T, base) && !tx_block_flag(c.T, base + TILE);
+}
+// f(q, dense): the suffix at tile position 16 * threadIdx.x + q and the dense code of its first pc bases
+template <typename F>
+__device__ __forceinline__ void for_tile_dense(const Ctx& c, int pc, F&& f) {
+    const uint64_t p0 = ((uint64_t)blockIdx.x + c.tile0) * TILE + threadIdx.x * 16u;
+    const uint64_t* w = c.T.packed + (p0 >> 5);
+    const uint64_t w0 = w[0], w1 = w[1];
+    const uint64_t win = (p0 & 16) ? (w0 >> 32) | (w1 << 32) : w0;             // bases p0 .. p0 + 31, base k in bits 2k, 2k + 1
+    uint64_t r = __brevll(win);                                                 // ... base k in bits 62 - 2k, 63 - 2k, halves swapped
+    r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+    const uint32_t dmask = (1u << (2 * pc)) - 1u;
+#pragma unroll
+    for (int q = 0; q < 16; q++) f(q, (uint32_t)(r >> (2 * (32 - q - pc))) & dmask);
+}
+// the number of dense codes (pc bases) whose bin lies below `bin`
+__device__ __forceinline__ uint32_t dense_lower(const Ctx& c, int pc, uint32_t bin) {
+    if (c.bits * pc < 32 && bin >= (1u << (c.bits * pc))) return 1u << (2 * pc);
+    const uint32_t smask = (1u << c.bits) - 1u;
+    uint32_t d = 0;
+    for (int i = 0; i < pc; i++) {
+        const uint32_t sym = (bin >> (c.bits * (pc - 1 - i))) & smask;
+        uint32_t less = 0, eq = 0;
+        for (int a = 0; a < 4; a++) { less += c.acgt[a] < sym ? 1u : 0u; eq |= c.acgt[a] == sym ? 1u : 0u; }
+        d += less << (2 * (pc - 1 - i));
+        if (!eq) break;
+    }
+    return d;
+}
+__device__ __forceinline__ uint32_t dense_to_bin(const Ctx& c, int pc, uint32_t dense) {
+    uint32_t bin = 0;
+    for (int i = 0; i < pc; i++) bin = (bin << c.bits) | c.acgt[(dense >> (2 * (pc - 1 - i))) & 3u];
+    return bin;
+}
+// the first c.chars symbol codes of the suffix at text position p (plain bases all of them), most significant first
+__device__ __forceinline__ uint64_t key_from_packed(const Ctx& c, uint64_t p) {
+    const uint64_t* w = c.T.packed + (p >> 5);
+    const uint32_t sh = 2 * (uint32_t)(p & 31);
+    const uint64_t x = sh ? (w[0] >> sh) | (w[1] << (64 - sh)) : w[0];           // 32 bases from p on
+    uint64_t key = 0;
+    for (int i = 0; i < c.chars; i++) key = (key << c.bits) | c.acgt[(x >> (2 * i)) & 3u];
+    return key;
+}
+
 // ---- slices of a bin of ONE repeated symbol (RunSlice, guided.cpp) ---------------------------------------------------------
 // The suffixes that begin with c^pc -- assembly gaps: runs of N of tens of megabases in every haplotype -- are one bin whatever
 // the number of leading characters, and on whole genomes a bin of billions of suffixes that no batch holds.  Their order is
@@ -472,7 +527,7 @@ __device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
             const uint32_t o = c.coff[hi + threadIdx.x];
             if (o < 64) atomicOr(&s_cut[64], 1ull << o);
         }
-    } else if (threadIdx.x < 65) s_cut[threadIdx.x] = c.mask[b * 64 + threadIdx.x];     // (whole blocks, zero padded, one block to spare)
+    } else if (threadIdx.x < 66) s_cut[threadIdx.x] = threadIdx.x < 65 ? c.mask[b * 64 + threadIdx.x] : 0ull;     // (whole blocks, zero padded, one block to spare)
     __syncthreads();
     if (threadIdx.x < 64) {
         const uint32_t v = (uint32_t)__popcll(s_cut[threadIdx.x]);
@@ -485,14 +540,23 @@ __device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
     __syncthreads();
     const uint32_t r0 = c.coff ? c.brank[b] : c.rdir[b * 8];
     const uint32_t t0 = threadIdx.x * 16;
-    uint32_t keep = 0, cached = 0xffffffffu, word = 0;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const uint32_t xo = t0 + q + c.w - 1;                          // query point of the suffix, relative to the tile
-        const uint32_t wi = xo >> 6;
-        const uint32_t k = r0 + s_pre[wi] + (uint32_t)__popcll(s_cut[wi] & ((1ull << (xo & 63)) - 1ull));
+    // The sixteen suffixes of a work-item lie in the phrase of the first one unless a phrase ends among their query points: one
+    // rank for the first, then one step per phrase end (a phrase is tens to hundreds of characters: most work-items see none).
+    // (sixteen ranks -- two LDS reads and a population count each -- were a third of a pass over the text)
+    const uint32_t x0 = t0 + c.w - 1;                                  // query point of the first suffix, relative to the tile
+    const uint32_t wi = x0 >> 6, sh = x0 & 63;
+    uint32_t k = r0 + s_pre[wi] + (uint32_t)__popcll(s_cut[wi] & ((1ull << sh) - 1ull));
+    // phrase ends at the query points of suffixes 0 .. 14 (an end AT the query point of suffix q puts suffix q + 1 in the next phrase)
+    uint32_t cuts = (uint32_t)((s_cut[wi] >> sh) | (sh > 48 ? s_cut[wi + 1] << (64 - sh) : 0ull)) & 0x7fffu;
+    uint32_t cached = k >> 5, word = c.repbits[cached];
+    uint32_t keep = 0, from = 0;
+    for (;;) {
+        const uint32_t to = cuts ? (uint32_t)__builtin_ctz(cuts) + 1u : 16u;      // suffixes [from, to) start in phrase k
+        if ((word >> (k & 31)) & 1u) keep |= ((1u << to) - 1u) & ~((1u << from) - 1u);
+        if (!cuts) break;
+        cuts &= cuts - 1u;
+        from = to; k++;
         if ((k >> 5) != cached) { cached = k >> 5; word = c.repbits[cached]; }
-        keep |= ((word >> (k & 31)) & 1u) << q;
     }
     __syncthreads();
     return keep;
@@ -550,6 +614,11 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c0, int pc, uint64_t* __re
             todo &= ~grp;
         }
     };
+    if (tile_is_plain(c)) {
+        for_tile_dense(c, pc, [&](int q, uint32_t dense) { if ((keep >> q) & 1u) atomicAdd(&s_hist[dense], 1u); });
+        __syncthreads();
+        continue;
+    }
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t bin) {
         if (!in || !((keep >> q) & 1u)) return;
         uint32_t dense = 0, bad = 0;
@@ -593,6 +662,10 @@ __global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin
     if (threadIdx.x == 0) s_cnt = 0;
     uint32_t mine = 0, slice = 0xffffu;
     const uint32_t keep = tile_rep_keep(c);
+    if (!rs.sym && tile_is_plain(c)) {
+        const uint32_t dlo = dense_lower(c, pc, bin_lo), dhi = dense_lower(c, pc, bin_hi);
+        for_tile_dense(c, pc, [&](int q, uint32_t d) { if (((keep >> q) & 1u) && d >= dlo && d < dhi) mine++; });
+    } else
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && ((keep & slice) >> q & 1u) && b >= bin_lo && b < bin_hi) mine++; },
                   [&]() { if (rs.sym) slice = tile_run_mask(c, rs, s_sym, nullptr); });
 #pragma unroll
@@ -642,6 +715,16 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     constexpr int PER = TILE / 256;
     uint32_t sel = 0, nxt = 0, slice = 0xffffu;
     const uint32_t keep = tile_rep_keep(c);
+    const bool plain = !rs.sym && tile_is_plain(c);
+    if (plain) {
+        const uint32_t dlo = dense_lower(c, pc, bin_lo), dhi = dense_lower(c, pc, bin_hi);
+        const uint32_t nlo = dense_lower(c, pc, next_lo), nhi = dense_lower(c, pc, next_hi);
+        for_tile_dense(c, pc, [&](int q, uint32_t d) {
+            if (!((keep >> q) & 1u)) return;
+            if (d >= dlo && d < dhi) sel |= 1u << q;
+            if (d >= nlo && d < nhi) nxt++;
+        });
+    } else
     // (a batch of slices of a run bin never counts the next batch along: next_count is null then)
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
         in = in && ((keep >> q) & 1u);
@@ -677,7 +760,8 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint32_t o = s_sel[i];
         uint64_t key = 0;
-        for (int ch = 0; ch < c.chars; ch++) key = (key << c.bits) | s_sym[o + ch];
+        if (plain) key = key_from_packed(c, base + o);
+        else for (int ch = 0; ch < c.chars; ch++) key = (key << c.bits) | s_sym[o + ch];
         keys[first + i] = key;
         pos[first + i] = make_rec(c, base + o + 1);
     }
@@ -707,6 +791,18 @@ __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_
     constexpr int PER = TILE / 256;
     uint32_t sel = 0, nxt = 0;
     const uint32_t keep = tile_rep_keep(c);              // (expansion: the list holds representatives only)
+    const bool plain = tile_is_plain(c);
+    uint32_t mine_dense[16];                              // (plain tiles: the dense codes of the selected suffixes, for their bins)
+    if (plain) {
+        const uint32_t dlo = dense_lower(c, pc, bin_lo), dhi = dense_lower(c, pc, bin_hi);
+        const uint32_t nlo = dense_lower(c, pc, next_lo), nhi = dense_lower(c, pc, next_hi);
+        for_tile_dense(c, pc, [&](int q, uint32_t d) {
+            mine_dense[q] = d;
+            if (!((keep >> q) & 1u)) return;
+            if (d >= dlo && d < dhi) sel |= 1u << q;
+            if (d >= nlo && d < nhi) nxt++;
+        });
+    } else
     for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
         in = in && ((keep >> q) & 1u);
         if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
@@ -726,13 +822,22 @@ __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_
     const uint64_t first = tile_off[(uint64_t)blockIdx.x + c.tile0];
     uint32_t at = inc - cnt, total = 0;
     for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
+    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
+    if (plain) {
+        // (no second phase: a work-item knows the dense codes of its own suffixes and where they go in the list)
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            if (!(sel & (1u << q))) continue;
+            staged[first + at++] = (base + threadIdx.x * PER + q + 1) | ((uint64_t)dense_to_bin(c, pc, mine_dense[q]) << 40);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         if (!(sel & (1u << q))) continue;
         s_sel[at++] = (uint16_t)(threadIdx.x * PER + q);
     }
     __syncthreads();
-    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint32_t o = s_sel[i];
         uint32_t bin = 0;
@@ -878,14 +983,43 @@ void gather_active(const uint32_t* idx, uint32_t m, const uint64_t* pos_sorted, 
     MMT_HIP(hipGetLastError());
 }
 
+// Early use of the giant dictionary (expansion only): a group ALL of whose members lie in giant phrases -- the suffixes inside the
+// assembly gaps of whole genomes: 1.5 G of the 16.6 G representatives of a rank's share of 13 realistic genomes, one group of N^21
+// after the first sort -- need not walk to g_depth 21 characters a round (30 rounds of 1.5 G elements each): the giant dictionary
+// orders them at any depth.  k_giant_probe looks every member up (gr[e] = its entry at `offset`, or none) and clears the flag of a
+// group that holds a member outside the giant phrases (or a spent one); k_round_keys then gives the members of the other groups
+// their entries as keys.  (Only when the elements are representatives: a tie among them is final in any order, so a group that
+// took its keys from the giant dictionary is done -- with several occurrences per phrase suffix the ties would go on to the
+// parse ranks, which this round's offset does not reach.)
+__global__ void k_giant_probe(Ctx c, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ ghead, uint32_t m, uint64_t offset,
+                              uint32_t* __restrict__ gr, uint8_t* __restrict__ pure) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m) return;
+    const uint64_t rec = pos[e], q = rec_pos(c, rec);
+    uint32_t r = 0xffffffffu;
+    const uint64_t len = rec_len(c, rec, q);
+    if (offset >= len || !giant_entry(c, q, offset, r)) r = 0xffffffffu;
+    gr[e] = r;
+    if (r == 0xffffffffu) pure[ghead[e]] = 0;
+}
+void giant_probe(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, uint32_t m, uint64_t offset, uint32_t* gr, uint8_t* pure,
+                 hipStream_t s) {
+    MMT_HIP(hipMemsetAsync(pure, 1, m, s));
+    hipLaunchKernelGGL(k_giant_probe, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, m, offset, gr, pure);
+    MMT_HIP(hipGetLastError());
+}
+
 // key of an element whose first `offset` characters are known to be shared by its whole group
+// (gr / pure / ghead, optional: the entries and group flags of k_giant_probe)
 __global__ void k_round_keys(Ctx c, const uint64_t* __restrict__ pos, uint32_t m, uint64_t offset,
-                             uint64_t* __restrict__ keys, uint32_t* __restrict__ err) {
+                             uint64_t* __restrict__ keys, uint32_t* __restrict__ err, const uint32_t* __restrict__ gr,
+                             const uint8_t* __restrict__ pure, const uint32_t* __restrict__ ghead) {
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_code[i] = c.code[i];
     __syncthreads();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
+    if (gr && pure[ghead[e]]) { keys[e] = GIANT_KEY | gr[e]; return; }
     const uint64_t rec = pos[e], q = rec_pos(c, rec);
     const uint64_t len = rec_len(c, rec, q);
     if (offset >= len) {
@@ -897,12 +1031,15 @@ __global__ void k_round_keys(Ctx c, const uint64_t* __restrict__ pos, uint32_t m
     if (c.g_n && offset >= c.g_depth) {
         // the group has shared g_depth characters and its alphas go on: giant phrases -- the rest by the giant dictionary
         uint32_t r = 0;
-        if (giant_entry(c, q, offset, r)) { keys[e] = GIANT_KEY | c.g_grp[r]; return; }
+        // (the key is the ENTRY, not its group: entries order like groups, and k_round_heads reads the LCP of two of them off the
+        // giant dictionary's LCP array instead of leaving the pair to k_batch_lcp's walk through the text)
+        if (giant_entry(c, q, offset, r)) { keys[e] = GIANT_KEY | r; return; }
     }
     keys[e] = pack_chars(c, s_code, q + offset);
 }
-void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL(k_round_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, m, offset, keys, err);
+void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s,
+                const uint32_t* gr, const uint8_t* pure, const uint32_t* ghead) {
+    hipLaunchKernelGGL(k_round_keys, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, m, offset, keys, err, gr, pure, ghead);
     MMT_HIP(hipGetLastError());
 }
 
@@ -913,7 +1050,8 @@ void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, 
 constexpr uint32_t SMALL = 8;
 __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ ghead,
                                 const uint32_t* __restrict__ slot, uint32_t m, uint64_t offset,
-                                uint64_t* __restrict__ out, uint8_t* __restrict__ flags, uint32_t* __restrict__ err) {
+                                uint64_t* __restrict__ out, uint8_t* __restrict__ flags, uint32_t* __restrict__ err,
+                                uint32_t* __restrict__ lcp_out) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
     const uint32_t g0 = ghead[e];
@@ -936,21 +1074,26 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
         const uint64_t L = len < lj ? len : lj;
         int cmp = 0;
         bool open = true;                                        // no difference found yet and alpha not yet spent
+        // (share = what the two suffixes share, known here where a character decides: the second of the pair leaves it as its
+        // LCP -- k_batch_lcp would walk the same characters again from the start of the suffixes)
+        uint64_t share = ~0ull;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const uint64_t at = offset + 8 * t;
             if (open && at < L && a[t] != b[t]) {
                 const uint32_t d = (uint32_t)__builtin_ctzll(a[t] ^ b[t]) >> 3;
-                if (at + d < L) cmp = ((b[t] >> (8 * d)) & 0xff) < ((a[t] >> (8 * d)) & 0xff) ? -1 : 1;
+                if (at + d < L) { cmp = ((b[t] >> (8 * d)) & 0xff) < ((a[t] >> (8 * d)) & 0xff) ? -1 : 1; share = at + d; }
                 open = false;
             }
         }
-        if (open && offset + 32 < L) cmp = -cmp_rest(c, q, len, qj, lj, offset + 32, nullptr);   // a longer phrase (cmp: -1 = j first)
+        if (open && offset + 32 < L) cmp = -cmp_rest(c, q, len, qj, lj, offset + 32, &share);   // a longer phrase (cmp: -1 = j first)
         if (cmp == 0) {
             if (len != lj) atomicAdd(err + 1, 1u);
             const uint64_t mine = rec >> c.pos_bits, other = rj >> c.pos_bits;
             cmp = other < mine || (other == mine && j < e) ? -1 : 1;
+            share = c.expand ? L : ~0ull;                        // (the same alpha: |alpha| is all the expansion asks; else the parse's LCP)
         }
+        if (lcp_out && cmp < 0 && share != ~0ull) lcp_out[slot[g0] + 1u] = share < (uint64_t)LCP_CAP ? (uint32_t)share : LCP_CAP;
         out[slot[g0] + (cmp < 0 ? 1u : 0u)] = rec;
         flags[e] = 0;
         return;
@@ -958,11 +1101,17 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
     const uint64_t len = rec_len(c, rec, q);
     uint64_t my_rank = ~0ull;                                    // looked up when first needed
     uint32_t before = 0;
+    // (the element's LCP with its predecessor in the group = the most it shares with any member that sorts before it; a member
+    // with the same alpha before it: |alpha| for the expansion, else left to k_batch_lcp and the parse's LCP array)
+    uint64_t share_best = 0;
+    bool same_before = false;
     for (uint32_t j = g0; j < end; j++) {
         if (j == e) continue;
         const uint64_t rj = pos[j], qj = rec_pos(c, rj);
         const uint64_t lj = rec_len(c, rj, qj);
-        int cmp = -cmp_rest(c, q, len, qj, lj, offset, nullptr);   // -1: j sorts before e
+        uint64_t share = 0;
+        int cmp = -cmp_rest(c, q, len, qj, lj, offset, &share);   // -1: j sorts before e
+        if (cmp < 0 && share > share_best) share_best = share;
         if (cmp == 0) {
             // the shorter alpha is a prefix of the other string: the two are the same phrase suffix (prefix-free)
             if (len != lj || c.skip) atomicAdd(err + (c.skip ? 0 : 1), 1u);
@@ -972,15 +1121,20 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
                 const uint64_t other = rec_rank_key(c, rj, qj);
                 cmp = other < my_rank || (other == my_rank && j < e) ? -1 : 1;
             }
+            if (cmp < 0) same_before = true;
         }
         before += cmp < 0 ? 1u : 0u;
+    }
+    if (lcp_out && before) {
+        const uint64_t v = same_before ? (c.expand ? len : ~0ull) : share_best;
+        if (v != ~0ull) lcp_out[slot[g0] + before] = v < (uint64_t)LCP_CAP ? (uint32_t)v : LCP_CAP;
     }
     out[slot[g0] + before] = rec;
     flags[e] = 0;
 }
 void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
-                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve_small, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, slot, m, offset, out, flags, err);
+                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s, uint32_t* lcp_out) {
+    hipLaunchKernelGGL(k_resolve_small, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, slot, m, offset, out, flags, err, lcp_out);
     MMT_HIP(hipGetLastError());
 }
 
@@ -1571,25 +1725,41 @@ void range_groups(const uint32_t* ghead, const uint32_t* big_begin, const uint32
 // that part after hundreds of characters -- 12 s of a 105 s share of realistic whole genomes)
 __global__ void k_round_heads(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ghead, uint32_t m,
                               uint32_t* __restrict__ headval, uint32_t* __restrict__ err, uint32_t* __restrict__ lcp_out,
-                              const uint32_t* __restrict__ slot, uint64_t offset, int bits, int chars) {
+                              const uint32_t* __restrict__ slot, uint64_t offset, int bits, int chars,
+                              const uint32_t* __restrict__ g_grp, RmqView g_rmq, bool expand, bool giant_round,
+                              const uint8_t* __restrict__ pure) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= m) return;
     const uint64_t k = keys[c];
-    bool h = ghead[c] == c;
+    const uint32_t g0 = ghead[c];
+    bool h = g0 == c;
     if (!h) {
         const uint64_t kp = keys[c - 1];
         if ((k >> 63) != (kp >> 63)) atomicAdd(err + 1, 1u);    // one group, spent and unspent phrase suffixes: not prefix-free
         h = (k >> 63) != 0 || k != kp;                           // parse ranks are distinct: such a group is done
-        if (lcp_out && k != kp && !((k | kp) >> 62)) {
+        // (a key of characters may have bit 62 set as well -- 21 symbols of three bits: whether this group's keys are entries of
+        // the giant dictionary is what the round, or k_giant_probe's flag of the group, says)
+        const bool giant = (giant_round || (pure && pure[g0])) && (k >> 32) == (GIANT_KEY >> 32) && (kp >> 32) == (GIANT_KEY >> 32);
+        if (giant) {
+            // two entries of the giant dictionary (k_round_keys): one group of equal strings, or what its LCP array says
+            const uint32_t r = (uint32_t)k, rp = (uint32_t)kp;
+            const bool differ = g_grp[r] != g_grp[rp];
+            h = differ || expand;             // (representatives that spell the same phrase suffix: final in any order)
+            if (differ && lcp_out) {
+                const uint64_t v = offset + (uint64_t)rmq_min(g_rmq, rp + 1, r);
+                lcp_out[slot[c]] = v < (uint64_t)LCP_CAP ? (uint32_t)v : LCP_CAP;
+            }
+        } else if (lcp_out && k != kp && !((k | kp) >> 63) && !giant_round && !(pure && pure[g0])) {
             const uint64_t v = offset + (uint64_t)((__builtin_clzll(k ^ kp) - (64 - bits * chars)) / bits);
             lcp_out[slot[c]] = v < (uint64_t)LCP_CAP ? (uint32_t)v : LCP_CAP;
         }
     }
     headval[c] = h ? c : 0u;
 }
-void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s,
-                 uint32_t* lcp_out, const uint32_t* slot, uint64_t offset, int bits, int chars) {
-    hipLaunchKernelGGL(k_round_heads, dim3(grid_for(m, 256)), dim3(256), 0, s, keys, ghead, m, headval, err, lcp_out, slot, offset, bits, chars);
+void round_heads(const Ctx& ctx, const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s,
+                 uint32_t* lcp_out, const uint32_t* slot, uint64_t offset, const uint8_t* pure) {
+    hipLaunchKernelGGL(k_round_heads, dim3(grid_for(m, 256)), dim3(256), 0, s, keys, ghead, m, headval, err, lcp_out, slot, offset,
+                       ctx.bits, ctx.chars, ctx.g_grp, ctx.g_rmq, ctx.expand != 0, ctx.g_n != 0 && offset >= ctx.g_depth, pure);
     MMT_HIP(hipGetLastError());
 }
 __global__ void k_round_apply(const uint64_t* __restrict__ pos_sorted, const uint32_t* __restrict__ newhead,

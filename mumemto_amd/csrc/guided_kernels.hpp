@@ -37,6 +37,9 @@ struct Ctx {
     uint32_t pos_bits;         // element records: position in the low pos_bits bits, above it ...
     uint32_t rec_rank;         // ... 1: the rank of the following parse suffix, 0: the length of alpha (pos_bits = 40)
     uint32_t tile0 = 0;        // first tile of this launch (the text-order kernels run in slices of 2^23 tiles)
+    // symbol codes of A C G T (0: the text holds none of that base) -- the text-order kernels read the tiles of a PACKED text that
+    // hold no exception straight from the words of 2-bit codes (guided_kernels.hip for_tile_dense); dense_ok: all four are set
+    uint8_t acgt[4] = {0, 0, 0, 0}; uint8_t dense_ok = 0;
     const uint32_t* pid = nullptr;   // text suffixes: id of the distinct phrase at parse position k (m entries), or nullptr
     // the phrase ends as a list (mask = rdir = nullptr then): coff[k] = offset of phrase end k inside its block of 4096 text
     // positions, brank[b] = phrase ends before block b (blocks + 2 entries); nxt as above
@@ -109,10 +112,16 @@ void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* r
 void heads0(const uint64_t* keys, uint32_t B, uint8_t* head, uint8_t* active, uint32_t* lcp, int bits, int chars, hipStream_t s);
 void gather_active(const uint32_t* idx, uint32_t m, const uint64_t* pos_sorted, const uint8_t* head, uint32_t* slot,
                    uint64_t* pos, uint32_t* headval, hipStream_t s);
-void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s);
+void round_keys(const Ctx& c, const uint64_t* pos, uint32_t m, uint64_t offset, uint64_t* keys, uint32_t* err, hipStream_t s,
+                const uint32_t* gr = nullptr, const uint8_t* pure = nullptr, const uint32_t* ghead = nullptr);
+// expansion: gr[e] = the entry of the giant dictionary's suffix array for member e at `offset` (0xffffffff: none), pure[first member
+// of a group] = 1 when every member has one -- round_keys then hands such groups their entries as keys (m bytes of `pure` are set)
+void giant_probe(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, uint32_t m, uint64_t offset, uint32_t* gr, uint8_t* pure,
+                 hipStream_t s);
 // groups of at most 8 elements, finished by direct comparison (their sorted records go to `out` at the group's slots)
 void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
-                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s);
+                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s,
+                   uint32_t* lcp_out = nullptr);   // (lcp_out, optional, by output slot: the LCP of a member with the member before it)
 // groups of 9 .. 128 elements, in four size classes (<= 16, 32, 64, 128): list = 4 regions of `cap` (first element, size)
 // pairs (uint2), count4 = 4 counters; then 4 / 2 / 1 / 1 groups per wave; flags must be preset to 1 (elements of larger
 // groups keep it); lcp_out (optional, indexed by slot): the LCP of every member but the first with the member before it
@@ -128,8 +137,8 @@ void local_sort(const uint64_t* kin, const uint64_t* pin, const uint32_t* ghead,
                 uint32_t big_cap, hipStream_t s);
 // the groups (begin, end) inside the listed ranges, for the segmented sort of groups longer than a tile
 // (lcp_out, optional, indexed by batch slot `slot[c]`: the LCP of two neighbours that part by the characters of this round's keys)
-void round_heads(const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s,
-                 uint32_t* lcp_out = nullptr, const uint32_t* slot = nullptr, uint64_t offset = 0, int bits = 0, int chars = 0);
+void round_heads(const Ctx& ctx, const uint64_t* keys, const uint32_t* ghead, uint32_t m, uint32_t* headval, uint32_t* err, hipStream_t s,
+                 uint32_t* lcp_out = nullptr, const uint32_t* slot = nullptr, uint64_t offset = 0, const uint8_t* pure = nullptr);
 void round_apply(const uint64_t* pos_sorted, const uint32_t* newhead, const uint32_t* slot, uint32_t m, uint64_t* out,
                  uint8_t* flags, hipStream_t s);
 void round_compact(const uint32_t* idx, uint32_t m2, const uint32_t* slot, const uint64_t* pos_sorted,

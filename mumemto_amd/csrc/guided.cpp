@@ -242,6 +242,7 @@ void Engine::guided_prepare() {
     std::memcpy(S.g_code, code, 256); S.g_bits = ctx.bits; S.g_share_valid = false;
     ctx.T = text_ref(); ctx.n = n; ctx.w = w; ctx.code = d_code_.get(); ctx.m = m;
     for (int k = 0; k < 4; k++) ctx.acgt[k] = code[(uint8_t)"ACGT"[k]];
+    ctx.acgt_lut = (uint32_t)ctx.acgt[0] | ((uint32_t)ctx.acgt[1] << 8) | ((uint32_t)ctx.acgt[2] << 16) | ((uint32_t)ctx.acgt[3] << 24);
     ctx.dense_ok = ctx.acgt[0] && ctx.acgt[1] && ctx.acgt[2] && ctx.acgt[3] && ctx.chars <= 32 && !std::getenv("MMT_GUIDED_NO_DENSE");
 
     // ---- phrase ends: rank directory and successor table over the cut bits ----

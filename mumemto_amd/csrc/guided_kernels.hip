@@ -332,13 +332,13 @@ static void for_tile_slices(const Ctx& c, F&& launch) {
 // text-order kernels were half of the run while they rolled full 63-bit keys for every position).
 struct NoTileHook { __device__ __forceinline__ void operator()() const {} };
 template <typename F, typename H = NoTileHook>
-__device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_sym, F&& f, H&& staged = H()) {
+__device__ __forceinline__ void for_tile_bins(const Ctx& c, uint64_t tile, int pc, uint8_t* s_sym, F&& f, H&& staged = H()) {
     constexpr int BLOCK = 256, PER = TILE / BLOCK;
     static_assert(PER == 16, "one 16-byte load per work-item");
     __shared__ uint8_t s_code[256];
     for (int i = threadIdx.x; i < 256; i += BLOCK) s_code[i] = c.code[i];
     __syncthreads();
-    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE; // text position of the tile's first suffix
+    const uint64_t base = tile * TILE; // text position of the tile's first suffix
     // 16 consecutive characters per work-item in one load, turned into symbol codes in registers and staged as one
     // 16-byte LDS store (byte loads and byte stores made these kernels run at 0.4 - 0.8 TB/s of a 1 B / character stream)
     auto codes_at = [&](uint64_t p0) {
@@ -373,19 +373,34 @@ __device__ __forceinline__ void for_tile_bins(const Ctx& c, int pc, uint8_t* s_s
 // read as words: the dense code of a suffix (two bits per leading base, first base most significant) is a shift and a mask of
 // the work-item's 64-bit window with its 2-bit groups reversed.  The batches' bin ranges are ranges of dense codes too
 // (dense_lower: A < C < G < T in both numberings); only what is SELECTED turns its dense code back into symbol codes.
-__device__ __forceinline__ bool tile_is_plain(const Ctx& c) {
-    if (!c.dense_ok || !c.T.is_packed()) return false;
-    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
-    if (base + TILE + 64 > c.n) return false;
-    return !tx_block_flag(c.T, base) && !tx_block_flag(c.T, base + TILE);
+// What a tile's kernel needs from memory before anything can be computed, asked for TOGETHER at its top: a pass is a chain of
+// round trips to memory per tile (exception flags -> words of text; phrase ends -> rank -> representative bits; list offset;
+// phrase ends again for the records), eight tiles to a compute unit -- ten microseconds a tile, 0.3 TB/s of a text that is
+// a quarter of a byte per character.  Loads that depend on nothing but the tile's number leave at once.
+struct TileLoads {
+    uint64_t w0 = 0, w1 = 0;          // the work-item's words of a packed text (meaningful when `plain`)
+    uint32_t r0 = 0;                  // phrase ends before the tile (expansion)
+    bool plain = false;
+};
+__device__ __forceinline__ TileLoads tile_loads(const Ctx& c, uint64_t tile) {
+    TileLoads L;
+    const uint64_t b = tile, base = b * TILE;
+    const bool maybe = c.dense_ok && c.T.is_packed() && base + TILE + 64 <= c.n;
+    uint64_t f0 = 0, f1 = 0;
+    if (maybe) {
+        const uint64_t p0 = base + threadIdx.x * 16u;
+        const uint64_t* w = c.T.packed + (p0 >> 5);
+        L.w0 = w[0]; L.w1 = w[1];
+        f0 = c.T.excw[b >> 6]; f1 = c.T.excw[(b + 1) >> 6];
+    }
+    if (c.repbits) L.r0 = c.coff ? c.brank[b] : c.rdir[b * 8];
+    L.plain = maybe && !(((f0 >> (b & 63)) | (f1 >> ((b + 1) & 63))) & 1ull);
+    return L;
 }
 // f(q, dense): the suffix at tile position 16 * threadIdx.x + q and the dense code of its first pc bases
 template <typename F>
-__device__ __forceinline__ void for_tile_dense(const Ctx& c, int pc, F&& f) {
-    const uint64_t p0 = ((uint64_t)blockIdx.x + c.tile0) * TILE + threadIdx.x * 16u;
-    const uint64_t* w = c.T.packed + (p0 >> 5);
-    const uint64_t w0 = w[0], w1 = w[1];
-    const uint64_t win = (p0 & 16) ? (w0 >> 32) | (w1 << 32) : w0;             // bases p0 .. p0 + 31, base k in bits 2k, 2k + 1
+__device__ __forceinline__ void for_tile_dense(const Ctx& c, int pc, const TileLoads& L, F&& f) {
+    const uint64_t win = (threadIdx.x & 1u) ? (L.w0 >> 32) | (L.w1 << 32) : L.w0;   // bases p0 .. p0 + 31, base k in bits 2k, 2k + 1
     uint64_t r = __brevll(win);                                                 // ... base k in bits 62 - 2k, 63 - 2k, halves swapped
     r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
     const uint32_t dmask = (1u << (2 * pc)) - 1u;
@@ -408,7 +423,7 @@ __device__ __forceinline__ uint32_t dense_lower(const Ctx& c, int pc, uint32_t b
 }
 __device__ __forceinline__ uint32_t dense_to_bin(const Ctx& c, int pc, uint32_t dense) {
     uint32_t bin = 0;
-    for (int i = 0; i < pc; i++) bin = (bin << c.bits) | c.acgt[(dense >> (2 * (pc - 1 - i))) & 3u];
+    for (int i = 0; i < pc; i++) bin = (bin << c.bits) | ((c.acgt_lut >> (8 * ((dense >> (2 * (pc - 1 - i))) & 3u))) & 0xffu);
     return bin;
 }
 // the first c.chars symbol codes of the suffix at text position p (plain bases all of them), most significant first
@@ -417,7 +432,7 @@ __device__ __forceinline__ uint64_t key_from_packed(const Ctx& c, uint64_t p) {
     const uint32_t sh = 2 * (uint32_t)(p & 31);
     const uint64_t x = sh ? (w[0] >> sh) | (w[1] << (64 - sh)) : w[0];           // 32 bases from p on
     uint64_t key = 0;
-    for (int i = 0; i < c.chars; i++) key = (key << c.bits) | c.acgt[(x >> (2 * i)) & 3u];
+    for (int i = 0; i < c.chars; i++) key = (key << c.bits) | ((c.acgt_lut >> (8 * (uint32_t)((x >> (2 * i)) & 3u))) & 0xffu);
     return key;
 }
 
@@ -442,7 +457,7 @@ __device__ __forceinline__ uint32_t run_bucket(uint64_t r, bool below) {
 }
 // bit q of the result: the suffix at tile position 16 * threadIdx.x + q, IF it begins with pc symbols rs.sym, lies in a bucket
 // of [rs.blo, rs.bhi); *bucket_out (optional, 16 entries): its bucket.  Called by the whole workgroup with the tile staged.
-__device__ __forceinline__ uint32_t tile_run_mask(const Ctx& c, const RunSlice& rs, const uint8_t* s_sym, uint32_t* bucket_out) {
+__device__ __forceinline__ uint32_t tile_run_mask(const Ctx& c, uint64_t tile, const RunSlice& rs, const uint8_t* s_sym, uint32_t* bucket_out) {
     __shared__ unsigned long long s_rn[257];
     __shared__ uint8_t s_fn[257], s_d[256];
     const uint32_t t = threadIdx.x, t0 = t * 16;
@@ -453,7 +468,6 @@ __device__ __forceinline__ uint32_t tile_run_mask(const Ctx& c, const RunSlice& 
     s_d[t] = (uint8_t)d;
     if (!__syncthreads_or(any ? 1 : 0)) return 0u;
     if (t == 0) {
-        const uint64_t tile = (uint64_t)blockIdx.x + c.tile0;
         unsigned long long rn = 0; uint8_t fn = 0;
         if (tile + 1 < rs.n_tiles) {
             const uint8_t f1 = rs.first[tile + 1];
@@ -488,7 +502,7 @@ __global__ __launch_bounds__(256) void k_tile_lead(Ctx c, uint8_t* __restrict__ 
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_min;
     if (threadIdx.x == 0) s_min = TILE;
-    for_tile_bins(c, 1, s_sym, [&](int, bool, uint32_t) {});
+    for_tile_bins(c, (uint64_t)blockIdx.x + c.tile0, 1, s_sym, [&](int, bool, uint32_t) {});
     const uint8_t s0 = s_sym[0];
     uint32_t mine = TILE;
     for (int q = 15; q >= 0; q--) if (s_sym[threadIdx.x * 16 + q] != s0) mine = threadIdx.x * 16 + q;
@@ -513,11 +527,13 @@ void tile_lead(const Ctx& c, uint8_t* first, uint16_t* lead, uint8_t* follow, hi
 // Bit q of the result: the suffix at tile position 16 * threadIdx.x + q starts in a representative occurrence.  The tile's
 // phrase ends (4096 positions + the w - 1 the query points reach beyond it) are staged in LDS as bits with their running
 // counts: the phrase of a suffix is a rank, and its bit says "representative".
-__device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
+__device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c, uint64_t tile, uint32_t r0, const unsigned long long** cut_words = nullptr) {
+    if (cut_words) *cut_words = nullptr;
     if (!c.repbits) return 0xffffu;
     __shared__ unsigned long long s_cut[66];
+    if (cut_words) *cut_words = s_cut;       // (bit x of the 65 words: a phrase ends at tile position x; valid until the kernel's next call)
     __shared__ uint32_t s_pre[66];
-    const uint64_t b = (uint64_t)blockIdx.x + c.tile0;             // the tile = block b of 4096 text positions
+    const uint64_t b = tile;                                       // the tile = block b of 4096 text positions
     if (c.coff) {
         if (threadIdx.x < 66) s_cut[threadIdx.x] = 0ull;
         __syncthreads();
@@ -538,7 +554,6 @@ __device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
         if (threadIdx.x == 63) s_pre[64] = inc;
     }
     __syncthreads();
-    const uint32_t r0 = c.coff ? c.brank[b] : c.rdir[b * 8];
     const uint32_t t0 = threadIdx.x * 16;
     // The sixteen suffixes of a work-item lie in the phrase of the first one unless a phrase ends among their query points: one
     // rank for the first, then one step per phrase end (a phrase is tens to hundreds of characters: most work-items see none).
@@ -560,6 +575,20 @@ __device__ __forceinline__ uint32_t tile_rep_keep(const Ctx& c) {
     }
     __syncthreads();
     return keep;
+}
+
+// the element record of the suffix at tile position o of a plain tile of an expansion pass: the end of its phrase from the tile's
+// staged phrase ends (tile_rep_keep's words) when it lies there -- nearly always -- instead of two or three more round trips
+__device__ __forceinline__ uint64_t make_rec_tile(const Ctx& c, uint64_t base, uint32_t o, const unsigned long long* cut_words) {
+    const uint64_t q = base + o + 1;
+    if (c.rec_rank || c.skip || !cut_words) return make_rec(c, q);
+    const uint32_t xo = o + c.w - 1;                              // query point (text position q + w - 2), relative to the tile
+    uint32_t wi = xo >> 6;
+    unsigned long long word = wi < 65u ? cut_words[wi] & (~0ull << (xo & 63)) : 0ull;
+    while (!word && ++wi < 65u) word = cut_words[wi];
+    if (!word) return make_rec(c, q);
+    const uint64_t len = base + (uint64_t)wi * 64 + (uint64_t)__builtin_ctzll(word) + 2 - q;
+    return q | ((len < LEN_SAT ? len : (uint64_t)LEN_SAT) << 40);
 }
 
 // One pass whatever the number of bins: a bin whose leading characters are all of A C G T -- nearly every suffix -- is
@@ -591,10 +620,10 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c0, int pc, uint64_t* __re
     for (uint32_t ti = 0; ti < BIN_HIST_TILES; ti++) {
     const uint32_t tile_in_slice = blockIdx.x * BIN_HIST_TILES + ti;
     if (tile_in_slice >= slice_tiles) break;
-    // (the text-order helpers take their tile from blockIdx.x + tile0: the copy's tile0 makes that this tile)
-    Ctx c = c0;
-    c.tile0 = c0.tile0 + tile_in_slice - blockIdx.x;
-    const uint32_t keep = tile_rep_keep(c);
+    const Ctx& c = c0;
+    const uint64_t tile = (uint64_t)c0.tile0 + tile_in_slice;
+    const TileLoads TL = tile_loads(c, tile);
+    const uint32_t keep = tile_rep_keep(c, tile, TL.r0);
     // (the other bins: a work-item adds up consecutive suffixes of the same bin -- inside an assembly gap all sixteen are N^pc --
     // and the wave adds up its work-items' counts before ONE atomic leaves for global memory: 1.5 G suffixes of the gaps of 13 whole
     // genomes on one address were 6 s per pass at the ~250 atomics per microsecond one word takes)
@@ -614,12 +643,12 @@ __global__ __launch_bounds__(256) void k_bin_hist(Ctx c0, int pc, uint64_t* __re
             todo &= ~grp;
         }
     };
-    if (tile_is_plain(c)) {
-        for_tile_dense(c, pc, [&](int q, uint32_t dense) { if ((keep >> q) & 1u) atomicAdd(&s_hist[dense], 1u); });
+    if (TL.plain) {
+        for_tile_dense(c, pc, TL, [&](int q, uint32_t dense) { if ((keep >> q) & 1u) atomicAdd(&s_hist[dense], 1u); });
         __syncthreads();
         continue;
     }
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t bin) {
+    for_tile_bins(c, tile, pc, s_sym, [&](int q, bool in, uint32_t bin) {
         if (!in || !((keep >> q) & 1u)) return;
         uint32_t dense = 0, bad = 0;
         for (int ch = 0; ch < pc; ch++) {
@@ -655,28 +684,42 @@ void bin_hist(const Ctx& c, int prefix_chars, uint64_t* hist, hipStream_t s) {
     MMT_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
-                                                     uint32_t* __restrict__ tile_count, RunSlice rs) {
+// (the text-order kernels below take PASS_TILES consecutive tiles per workgroup, like k_bin_hist: a workgroup per tile -- 140 M of
+// them per pass over 573 G characters, each fetching its kernel arguments and living six microseconds -- ran at 3 - 6 ns a tile
+// where the histogram's loop runs at 1.8)
+constexpr uint32_t PASS_TILES = 1;
+#define MMT_PASS_LOOP(c, slice_tiles, tile)                                                                 \
+    for (uint32_t ti_ = 0; ti_ < PASS_TILES; ti_++)                                                         \
+        if (const uint32_t tile_in_slice_ = blockIdx.x * PASS_TILES + ti_; tile_in_slice_ < (slice_tiles))  \
+            if (const uint64_t tile = (uint64_t)(c).tile0 + tile_in_slice_; true)
+__device__ __forceinline__ void batch_count_tile(const Ctx& c, uint64_t tile, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                 uint32_t* __restrict__ tile_count, const RunSlice& rs) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     uint32_t mine = 0, slice = 0xffffu;
-    const uint32_t keep = tile_rep_keep(c);
-    if (!rs.sym && tile_is_plain(c)) {
+    const TileLoads TL = tile_loads(c, tile);
+    const uint32_t keep = tile_rep_keep(c, tile, TL.r0);
+    if (!rs.sym && TL.plain) {
         const uint32_t dlo = dense_lower(c, pc, bin_lo), dhi = dense_lower(c, pc, bin_hi);
-        for_tile_dense(c, pc, [&](int q, uint32_t d) { if (((keep >> q) & 1u) && d >= dlo && d < dhi) mine++; });
+        for_tile_dense(c, pc, TL, [&](int q, uint32_t d) { if (((keep >> q) & 1u) && d >= dlo && d < dhi) mine++; });
     } else
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && ((keep & slice) >> q & 1u) && b >= bin_lo && b < bin_hi) mine++; },
-                  [&]() { if (rs.sym) slice = tile_run_mask(c, rs, s_sym, nullptr); });
+    for_tile_bins(c, tile, pc, s_sym, [&](int q, bool in, uint32_t b) { if (in && ((keep & slice) >> q & 1u) && b >= bin_lo && b < bin_hi) mine++; },
+                  [&]() { if (rs.sym) slice = tile_run_mask(c, tile, rs, s_sym, nullptr); });
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
-    if (threadIdx.x == 0) tile_count[(uint64_t)blockIdx.x + c.tile0] = s_cnt;
+    if (threadIdx.x == 0) tile_count[tile] = s_cnt;
+}
+__global__ __launch_bounds__(256) void k_batch_count(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                     uint32_t* __restrict__ tile_count, RunSlice rs, uint32_t slice_tiles) {
+    MMT_PASS_LOOP(c, slice_tiles, tile) { batch_count_tile(c, tile, pc, bin_lo, bin_hi, tile_count, rs); __syncthreads(); }
 }
 void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, uint32_t* tile_count, hipStream_t s, const RunSlice& rs) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_batch_count, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_count, rs);
+        hipLaunchKernelGGL(k_batch_count, dim3((blocks + PASS_TILES - 1) / PASS_TILES), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi,
+                           tile_count, rs, blocks);
     });
     MMT_HIP(hipGetLastError());
 }
@@ -687,12 +730,13 @@ __global__ __launch_bounds__(256) void k_run_hist(Ctx c, int pc, uint32_t bin, R
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     uint32_t bucket[16];
     uint32_t inrun = 0;
-    const uint32_t keep = tile_rep_keep(c);
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+    const uint64_t tile = (uint64_t)blockIdx.x + c.tile0;
+    const uint32_t keep = tile_rep_keep(c, tile, c.repbits ? (c.coff ? c.brank[tile] : c.rdir[tile * 8]) : 0u);
+    for_tile_bins(c, tile, pc, s_sym, [&](int q, bool in, uint32_t b) {
         if (!in || b != bin || !((inrun >> q) & 1u)) return;
         atomicAdd(hist + bucket[q], 1ull);
         if ((keep >> q) & 1u) atomicAdd(hist + 2u * RUN_BUCKETS_HALF + bucket[q], 1ull);
-    }, [&]() { inrun = tile_run_mask(c, rs, s_sym, bucket); });
+    }, [&]() { inrun = tile_run_mask(c, tile, rs, s_sym, bucket); });
 }
 void run_hist(const Ctx& c, int prefix_chars, uint32_t bin, const RunSlice& rs, uint64_t* hist, hipStream_t s) {
     RunSlice all = rs;
@@ -705,32 +749,35 @@ void run_hist(const Ctx& c, int prefix_chars, uint32_t bin, const RunSlice& rs, 
 
 // (next_count, optional: the same pass counts, per tile, the suffixes of the NEXT batch's bins [next_lo, next_hi): that batch
 // then needs no k_batch_count of its own -- one pass over the text per batch instead of two)
-__global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
-                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
-                                                    uint64_t* __restrict__ pos, uint32_t next_lo, uint32_t next_hi,
-                                                    uint32_t* __restrict__ next_count, RunSlice rs) {
+__device__ __forceinline__ void batch_fill_tile(const Ctx& c, uint64_t tile, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
+                                                uint64_t* __restrict__ pos, uint32_t next_lo, uint32_t next_hi,
+                                                uint32_t* __restrict__ next_count, const RunSlice& rs) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_wave[4], s_next[4];
     __shared__ uint16_t s_sel[TILE];                               // tile offsets of the selected suffixes, in order
     constexpr int PER = TILE / 256;
     uint32_t sel = 0, nxt = 0, slice = 0xffffu;
-    const uint32_t keep = tile_rep_keep(c);
-    const bool plain = !rs.sym && tile_is_plain(c);
+    const TileLoads TL = tile_loads(c, tile);
+    const uint64_t first = tile_off[tile];
+    const unsigned long long* cut_words = nullptr;
+    const uint32_t keep = tile_rep_keep(c, tile, TL.r0, &cut_words);
+    const bool plain = !rs.sym && TL.plain;
     if (plain) {
         const uint32_t dlo = dense_lower(c, pc, bin_lo), dhi = dense_lower(c, pc, bin_hi);
         const uint32_t nlo = dense_lower(c, pc, next_lo), nhi = dense_lower(c, pc, next_hi);
-        for_tile_dense(c, pc, [&](int q, uint32_t d) {
+        for_tile_dense(c, pc, TL, [&](int q, uint32_t d) {
             if (!((keep >> q) & 1u)) return;
             if (d >= dlo && d < dhi) sel |= 1u << q;
             if (d >= nlo && d < nhi) nxt++;
         });
     } else
     // (a batch of slices of a run bin never counts the next batch along: next_count is null then)
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+    for_tile_bins(c, tile, pc, s_sym, [&](int q, bool in, uint32_t b) {
         in = in && ((keep >> q) & 1u);
         if (in && b >= bin_lo && b < bin_hi && ((slice >> q) & 1u)) sel |= 1u << q;
         if (in && b >= next_lo && b < next_hi) nxt++;
-    }, [&]() { if (rs.sym) slice = tile_run_mask(c, rs, s_sym, nullptr); });
+    }, [&]() { if (rs.sym) slice = tile_run_mask(c, tile, rs, s_sym, nullptr); });
     // ordered compaction: exclusive prefix of the per-work-item counts over the workgroup
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t cnt = __popc(sel);
@@ -742,8 +789,7 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     if (lane == 63) s_wave[wave] = inc;
     if (lane == 0) s_next[wave] = nxt;
     __syncthreads();
-    if (next_count && threadIdx.x == 0) next_count[(uint64_t)blockIdx.x + c.tile0] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
-    const uint64_t first = tile_off[(uint64_t)blockIdx.x + c.tile0];
+    if (next_count && threadIdx.x == 0) next_count[tile] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
     uint32_t at = inc - cnt;
     uint32_t total = 0;
     for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
@@ -756,21 +802,30 @@ __global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_
     // keys and records of the selected suffixes only, one per work-item at a time: the first `chars` symbol codes from the
     // staged tile; phrase-end / parse-rank lookups (inside the loop above each lookup would wait for the one before it:
     // sixteen latencies in a row per wave)
-    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
+    const uint64_t base = tile * TILE;
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint32_t o = s_sel[i];
         uint64_t key = 0;
         if (plain) key = key_from_packed(c, base + o);
         else for (int ch = 0; ch < c.chars; ch++) key = (key << c.bits) | s_sym[o + ch];
         keys[first + i] = key;
-        pos[first + i] = make_rec(c, base + o + 1);
+        pos[first + i] = plain ? make_rec_tile(c, base, o, cut_words) : make_rec(c, base + o + 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_batch_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ keys,
+                                                    uint64_t* __restrict__ pos, uint32_t next_lo, uint32_t next_hi,
+                                                    uint32_t* __restrict__ next_count, RunSlice rs, uint32_t slice_tiles) {
+    MMT_PASS_LOOP(c, slice_tiles, tile) {
+        batch_fill_tile(c, tile, pc, bin_lo, bin_hi, tile_off, keys, pos, next_lo, next_hi, next_count, rs);
+        __syncthreads();
     }
 }
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
                 uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s, const RunSlice& rs) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_batch_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, keys, pos, next_lo,
-                           next_hi, next_count, rs);
+        hipLaunchKernelGGL(k_batch_fill, dim3((blocks + PASS_TILES - 1) / PASS_TILES), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi,
+                           tile_off, keys, pos, next_lo, next_hi, next_count, rs, blocks);
     });
     MMT_HIP(hipGetLastError());
 }
@@ -782,28 +837,28 @@ void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi
 // are written in text order as (V index | bin << 40), eight bytes each, and every batch then takes its own from that list (a
 // pass over a few G entries instead of hundreds of G characters) and only there looks up keys and records.
 // (the same pass also counts, per tile, the suffixes of the NEXT pass's bins [next_lo, next_hi): its k_batch_count is then not run)
-__global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
-                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ staged,
-                                                    uint32_t next_lo, uint32_t next_hi, uint32_t* __restrict__ next_count) {
+__device__ __forceinline__ void stage_fill_tile(const Ctx& c, uint64_t tile, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ staged,
+                                                uint32_t next_lo, uint32_t next_hi, uint32_t* __restrict__ next_count) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_wave[4], s_next[4];
     __shared__ uint16_t s_sel[TILE];
     constexpr int PER = TILE / 256;
     uint32_t sel = 0, nxt = 0;
-    const uint32_t keep = tile_rep_keep(c);              // (expansion: the list holds representatives only)
-    const bool plain = tile_is_plain(c);
-    uint32_t mine_dense[16];                              // (plain tiles: the dense codes of the selected suffixes, for their bins)
+    const TileLoads TL = tile_loads(c, tile);
+    const uint64_t first = tile_off[tile];
+    const uint32_t keep = tile_rep_keep(c, tile, TL.r0);       // (expansion: the list holds representatives only)
+    const bool plain = TL.plain;
     if (plain) {
         const uint32_t dlo = dense_lower(c, pc, bin_lo), dhi = dense_lower(c, pc, bin_hi);
         const uint32_t nlo = dense_lower(c, pc, next_lo), nhi = dense_lower(c, pc, next_hi);
-        for_tile_dense(c, pc, [&](int q, uint32_t d) {
-            mine_dense[q] = d;
+        for_tile_dense(c, pc, TL, [&](int q, uint32_t d) {
             if (!((keep >> q) & 1u)) return;
             if (d >= dlo && d < dhi) sel |= 1u << q;
             if (d >= nlo && d < nhi) nxt++;
         });
     } else
-    for_tile_bins(c, pc, s_sym, [&](int q, bool in, uint32_t b) {
+    for_tile_bins(c, tile, pc, s_sym, [&](int q, bool in, uint32_t b) {
         in = in && ((keep >> q) & 1u);
         if (in && b >= bin_lo && b < bin_hi) sel |= 1u << q;
         if (in && b >= next_lo && b < next_hi) nxt++;
@@ -818,20 +873,10 @@ __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_
     if (lane == 63) s_wave[wave] = inc;
     if (lane == 0) s_next[wave] = nxt;
     __syncthreads();
-    if (next_count && threadIdx.x == 0) next_count[(uint64_t)blockIdx.x + c.tile0] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
-    const uint64_t first = tile_off[(uint64_t)blockIdx.x + c.tile0];
+    if (next_count && threadIdx.x == 0) next_count[tile] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
     uint32_t at = inc - cnt, total = 0;
     for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
-    const uint64_t base = ((uint64_t)blockIdx.x + c.tile0) * TILE;
-    if (plain) {
-        // (no second phase: a work-item knows the dense codes of its own suffixes and where they go in the list)
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            if (!(sel & (1u << q))) continue;
-            staged[first + at++] = (base + threadIdx.x * PER + q + 1) | ((uint64_t)dense_to_bin(c, pc, mine_dense[q]) << 40);
-        }
-        return;
-    }
+    const uint64_t base = tile * TILE;
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         if (!(sel & (1u << q))) continue;
@@ -841,15 +886,32 @@ __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
         const uint32_t o = s_sel[i];
         uint32_t bin = 0;
+        if (plain) {
+            // (the bin of a selected suffix from the words of the text again: they are in the cache, the selected are few)
+            const uint64_t p = base + o;
+            const uint64_t* w = c.T.packed + (p >> 5);
+            const uint32_t sh = 2 * (uint32_t)(p & 31);
+            const uint64_t x = sh ? (w[0] >> sh) | (w[1] << (64 - sh)) : w[0];
+            for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | ((c.acgt_lut >> (8 * (uint32_t)((x >> (2 * ch)) & 3u))) & 0xffu);
+        } else
         for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | s_sym[o + ch];
         staged[first + i] = (base + o + 1) | ((uint64_t)bin << 40);
+    }
+}
+__global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
+                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ staged,
+                                                    uint32_t next_lo, uint32_t next_hi, uint32_t* __restrict__ next_count,
+                                                    uint32_t slice_tiles) {
+    MMT_PASS_LOOP(c, slice_tiles, tile) {
+        stage_fill_tile(c, tile, pc, bin_lo, bin_hi, tile_off, staged, next_lo, next_hi, next_count);
+        __syncthreads();
     }
 }
 void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,
                 uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
-        hipLaunchKernelGGL(k_stage_fill, dim3(blocks), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi, tile_off, staged, next_lo,
-                           next_hi, next_count);
+        hipLaunchKernelGGL(k_stage_fill, dim3((blocks + PASS_TILES - 1) / PASS_TILES), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi,
+                           tile_off, staged, next_lo, next_hi, next_count, blocks);
     });
     MMT_HIP(hipGetLastError());
 }

@@ -40,6 +40,7 @@ struct Ctx {
     // symbol codes of A C G T (0: the text holds none of that base) -- the text-order kernels read the tiles of a PACKED text that
     // hold no exception straight from the words of 2-bit codes (guided_kernels.hip for_tile_dense); dense_ok: all four are set
     uint8_t acgt[4] = {0, 0, 0, 0}; uint8_t dense_ok = 0;
+    uint32_t acgt_lut = 0;     // the four codes in one word, code of base d in bits 8 d .. 8 d + 7 (a lookup by a computed index)
     const uint32_t* pid = nullptr;   // text suffixes: id of the distinct phrase at parse position k (m entries), or nullptr
     // the phrase ends as a list (mask = rdir = nullptr then): coff[k] = offset of phrase end k inside its block of 4096 text
     // positions, brank[b] = phrase ends before block b (blocks + 2 entries); nxt as above

@@ -454,10 +454,11 @@ def main():
                 "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if a.backend == "nccl" else None,
                 "strict": bool(a.strict_exchange),
                 "bytes_sent_per_rank_estimate": int((L0 + 1) * 4 + int(eng.L.mmt_num_rows(eng.h)) * (4 + 9 * len(mine))),
-                # every message of dist.cpp travels in pieces of at most 2^30 elements (MUMEMTO_RCCL_CHUNK)
+                # every message of dist.cpp travels in pieces of at most 2^29 bytes (dist.cpp rccl_chunk_elements: pieces beyond
+                # 1 GiB lost half their elements in the real library, profiles/round6_rccl_piece_sizes.log)
                 "messages_of_this_rank": [
-                    {"what": what, "elements": int(cnt), "bytes": int(cnt * width), "pieces": int(max(1, -(-cnt // (1 << 30)))),
-                     "largest_piece_bytes": int(min(cnt, 1 << 30) * width)}
+                    {"what": what, "elements": int(cnt), "bytes": int(cnt * width), "pieces": int(max(1, -(-cnt // ((1 << 29) // width)))),
+                     "largest_piece_bytes": int(min(cnt, (1 << 29) // width) * width)}
                     for what, cnt, width in (("thresholds over the anchor (u32)", L0 + 1, 4),
                                              ("row lengths (u32)", int(eng.L.mmt_num_rows(eng.h)), 4),
                                              ("row offsets (i64)", int(eng.L.mmt_num_rows(eng.h)) * len(mine), 8),

@@ -336,6 +336,9 @@ MMT_API int  mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len);
  * of at most 2^30 elements, an all-gather and a broadcast; out = bytes moved, pieces, largest piece (bytes), elements that
  * arrived different (0 is the answer), microseconds, rows, row cells, thresholds.                                         */
 MMT_API int  mmt_comm_loopback(mmt_comm* c, uint64_t out[8]);
+/* One message of `elements` elements of `width` bytes (1, 4, 8) to this rank itself through ncclSend / ncclRecv in the pieces the
+ * exchange cuts (MUMEMTO_RCCL_CHUNK): out = elements that arrived different, pieces, largest piece (bytes), microseconds.      */
+MMT_API int  mmt_comm_selftest(mmt_comm* c, uint64_t elements, uint32_t width, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

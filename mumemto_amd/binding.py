@@ -78,7 +78,7 @@ GPU_ABI_SYMBOLS = [
     "mmt_copy_merged_thresh", "mmt_rows_mum_device", "mmt_merged_device", "mmt_engine_set_text_host",
     "mmt_engine_set_stream_host", "mmt_is_wide", "mmt_scan_ranges", "mmt_copy_sa64", "mmt_engine_set_stream_host40",
     "mmt_device_memory", "mmt_engine_run_files", "mmt_anchor_merge_min_len", "mmt_pool_trim", "mmt_pool_set_reserve",
-    "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_comm_loopback", "mmt_dist_merge",
+    "mmt_engine_set_scan_shard", "mmt_merged_from_rows", "mmt_anchor_merge_by_ranges", "mmt_dist_merge_ranges", "mmt_fold_slice_bounds", "mmt_comm_unique_id", "mmt_comm_create", "mmt_comm_destroy", "mmt_comm_loopback", "mmt_comm_selftest", "mmt_dist_merge",
     "mmt_dist_gather_text", "mmt_merged_write_text", "mmt_sort_pieces", "mmt_engine_keep_columns", "mmt_columns_kept",
     "mmt_stream_stats", "mmt_engine_release_columns", "mmt_copy_thresh32", "mmt_thresh_device32", "mmt_engine_set_text_sink",
     "mmt_engine_run_supplied",
@@ -186,6 +186,7 @@ def load_library():
     L.mmt_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     L.mmt_comm_destroy.argtypes = [C.c_void_p]
     L.mmt_comm_loopback.argtypes = [C.c_void_p, C.c_void_p]
+    L.mmt_comm_selftest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     L.mmt_dist_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.mmt_dist_gather_text.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.mmt_partitions_used.restype = C.c_size_t
@@ -798,6 +799,12 @@ class Comm:
         _check(self.L.mmt_comm_loopback(self.h, out))
         return {"bytes": int(out[0]), "pieces": int(out[1]), "largest_piece_bytes": int(out[2]), "different": int(out[3]),
                 "seconds": int(out[4]) / 1e6, "rows": int(out[5]), "cells": int(out[6]), "thresholds": int(out[7])}
+
+    def selftest(self, elements, width=4):
+        """One message of that many elements of `width` bytes to this rank itself, in the exchange's pieces (mmt_comm_selftest)."""
+        out = (C.c_uint64 * 4)()
+        _check(self.L.mmt_comm_selftest(self.h, int(elements), int(width), out))
+        return {"different": int(out[0]), "pieces": int(out[1]), "largest_piece_bytes": int(out[2]), "seconds": int(out[3]) / 1e6}
 
     def gather_text(self):
         """Sharded modes (Engine.set_scan_shard): the whole output on rank 0, b"" elsewhere."""

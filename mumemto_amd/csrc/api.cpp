@@ -780,6 +780,13 @@ int mmt_dist_gather_text(mmt_comm* c, const char** text, size_t* len) {
     MMT_CATCH
 }
 
+int mmt_comm_selftest(mmt_comm* c, uint64_t elements, uint32_t width, uint64_t out[4]) {
+    if (!c || !out) return fail(1, "null");
+    MMT_TRY
+    mmt::dist_selftest(*c->c, elements, width, out);
+    MMT_CATCH
+}
+
 int mmt_comm_loopback(mmt_comm* c, uint64_t out[8]) {
     if (!c || !out) return fail(1, "null");
     MMT_TRY

@@ -91,17 +91,21 @@ void check(ncclResult_t e, const char* what) {
 }
 #define MMT_NCCL(x) check((x), #x)
 
-// One message of `count` elements as pieces of at most 2^30 (MUMEMTO_RCCL_CHUNK: tests) -- sender and receiver cut the same
-// way, so the pieces pair up in order.  A rank's threshold column over a 3.05 Gbp anchor is 3.05 G elements / 12 GB: counts are
-// size_t in the interface, but nothing obliges every layer below it (element counts x datatype size in 32-bit arithmetic,
-// registration windows) to have been exercised beyond 2^31 -- pieces of a gigabyte-scale count cost nothing inside a group.
-size_t rccl_chunk() {
-    static const size_t c = [] { const char* e = std::getenv("MUMEMTO_RCCL_CHUNK"); const size_t v = e ? (size_t)std::strtoull(e, nullptr, 10) : 0; return v ? v : ((size_t)1 << 30); }();
-    return c;
+// One message of `count` elements as pieces of at most 2^29 BYTES (MUMEMTO_RCCL_CHUNK = elements per piece: tests) -- sender and
+// receiver cut the same way, so the pieces pair up in order.  A rank's threshold column over a 3.05 Gbp anchor is 3.05 G elements
+// / 12 GB: counts are size_t in the interface, but not every layer below it holds what the interface promises.  MEASURED in round 6
+// (tests/micro/rccl_sizes.py, profiles/round6_rccl_piece_sizes.log; RCCL 2.26.6 of PyTorch 2.10 + ROCm 7.0, the rank as its own
+// peer): a piece of 1 GiB arrives whole; of a piece of 2 GiB, 3.16 GB or 4 GiB -- whatever the element type -- HALF the elements
+// arrive different, without an error.  Rounds 4 and 5 cut at 2^30 ELEMENTS (4 - 8 GiB a piece).  Half a gibibyte leaves a margin;
+// two dozen pieces of a 12 GB column cost nothing inside a group.
+static size_t rccl_chunk_elements(size_t width) {
+    static const size_t env = [] { const char* e = std::getenv("MUMEMTO_RCCL_CHUNK"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0; }();
+    if (env) return env;
+    return ((size_t)1 << 29) / width;
 }
 template <typename T>
 void send_pieces(const T* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
-    const size_t C = rccl_chunk();
+    const size_t C = rccl_chunk_elements(sizeof(T));
     for (size_t at = 0; at < count || at == 0; at += C) {
         MMT_NCCL(rccl().Send(buf + at, std::min(C, count - at), t, peer, comm, st));
         if (count <= at + C) break;
@@ -109,7 +113,7 @@ void send_pieces(const T* buf, size_t count, ncclDataType_t t, int peer, ncclCom
 }
 template <typename T>
 void recv_pieces(T* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t comm, hipStream_t st) {
-    const size_t C = rccl_chunk();
+    const size_t C = rccl_chunk_elements(sizeof(T));
     for (size_t at = 0; at < count || at == 0; at += C) {
         MMT_NCCL(rccl().Recv(buf + at, std::min(C, count - at), t, peer, comm, st));
         if (count <= at + C) break;
@@ -438,7 +442,7 @@ void dist_loopback(Comm& c, uint64_t out[8]) {
     send_pieces(e.thresh_device32(), L, ncclUint32, me, c.comm, st); recv_pieces(c.th[me]->get(), L, ncclUint32, me, c.comm, st);
     MMT_NCCL(rccl().GroupEnd());
     // a broadcast in pieces as well (round 2's route; still what a one-to-all step would use)
-    const size_t C = rccl_chunk();
+    const size_t C = rccl_chunk_elements(4);
     uint64_t pieces = 0, largest = 0;
     MMT_HIP(hipMemcpyAsync(bc.get(), e.thresh_device32(), L * 4, hipMemcpyDeviceToDevice, st));
     for (size_t at = 0; at < L; at += C) {
@@ -447,7 +451,7 @@ void dist_loopback(Comm& c, uint64_t out[8]) {
     }
     MMT_HIP(hipStreamSynchronize(st));
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    auto count = [&](size_t n, size_t width) { for (size_t at = 0; at < n || at == 0; at += C) { pieces++; largest = std::max<uint64_t>(largest, std::min(C, n - at) * width); if (n <= at + C) break; } };
+    auto count = [&](size_t n, size_t width) { const size_t Cw = rccl_chunk_elements(width); for (size_t at = 0; at < n || at == 0; at += Cw) { pieces++; largest = std::max<uint64_t>(largest, std::min(Cw, n - at) * width); if (n <= at + Cw) break; } };
     if (rows) { count(rows, 4); count(cells, 8); count(cells, 1); }
     count(L, 4);
     if (rows) {
@@ -464,6 +468,49 @@ void dist_loopback(Comm& c, uint64_t out[8]) {
     out[0] = rows * 4 + cells * 9 + L * 4 + L * 4; out[1] = pieces; out[2] = largest; out[3] = d; out[4] = (uint64_t)us;
     out[5] = rows; out[6] = cells; out[7] = L;
     c.len[me]->release(); c.off[me]->release(); c.st[me]->release(); c.th[me]->release();
+}
+
+// One message of `elements` elements of `width` bytes (1, 4 or 8) with this rank as its own peer, in the pieces send_pieces /
+// recv_pieces cut: a pattern goes out, what arrives is compared.  What a one-GPU box can ask the real library about a message
+// SIZE without a whole-genome run behind it.  out: [0] elements that arrived different, [1] pieces, [2] largest piece in bytes,
+// [3] microseconds.
+template <typename T>
+__global__ void k_pattern(T* __restrict__ a, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        a[i] = (T)(i * 2654435761ull + (i >> 29));
+}
+template <typename T>
+static void selftest_typed(Comm& c, size_t n, ncclDataType_t t, uint64_t out[4]) {
+    Engine& e = *c.engine;
+    hipStream_t st = e.stream();
+    DevBuf<T> src, dst;
+    DevBuf<unsigned long long> diff;
+    src.ensure(n + 1); dst.ensure(n + 1); diff.ensure(1);
+    hipLaunchKernelGGL(k_pattern<T>, dim3(2048), dim3(256), 0, st, src.get(), n);
+    MMT_HIP(hipMemsetAsync(dst.get(), 0xa5, n * sizeof(T), st));
+    MMT_HIP(hipMemsetAsync(diff.get(), 0, 8, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    MMT_NCCL(rccl().GroupStart());
+    send_pieces(src.get(), n, t, c.rank, c.comm, st);
+    recv_pieces(dst.get(), n, t, c.rank, c.comm, st);
+    MMT_NCCL(rccl().GroupEnd());
+    MMT_HIP(hipStreamSynchronize(st));
+    out[3] = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    hipLaunchKernelGGL(k_count_diff<T>, dim3(2048), dim3(256), 0, st, (const T*)src.get(), (const T*)dst.get(), n, diff.get());
+    MMT_HIP(hipGetLastError());
+    unsigned long long d = 0;
+    MMT_HIP(hipMemcpyAsync(&d, diff.get(), 8, hipMemcpyDeviceToHost, st));
+    MMT_HIP(hipStreamSynchronize(st));
+    const size_t C = rccl_chunk_elements(sizeof(T));
+    out[0] = d; out[1] = n ? (n + C - 1) / C : 1; out[2] = std::min(C, n) * sizeof(T);
+}
+void dist_selftest(Comm& c, uint64_t elements, uint32_t width, uint64_t out[4]) {
+    MMT_HIP(hipSetDevice(c.engine->device()));
+    if (width == 1) selftest_typed<uint8_t>(c, (size_t)elements, ncclUint8, out);
+    else if (width == 4) selftest_typed<uint32_t>(c, (size_t)elements, ncclUint32, out);
+    else if (width == 8) selftest_typed<int64_t>(c, (size_t)elements, ncclInt64, out);
+    else throw std::runtime_error("dist_selftest: width 1, 4 or 8");
 }
 
 // Modes without a partition merge: this rank's PREFIX.mums / .mems bytes (mmt_engine_set_scan_shard) to rank 0, in rank

@@ -16,7 +16,8 @@ MergedRows dist_merge(Comm& c, uint32_t min_len, bool* is_root);                
 MergedRows dist_merge_ranges(Comm& c, uint32_t min_len, bool* is_root);           // the same, every rank folds its slice of the anchor
 int comm_world(const Comm& c);
 std::string dist_gather_text(Comm& c);                                            // collective; bytes on rank 0
-void dist_loopback(Comm& c, uint64_t out[8]);                                     // the exchange's messages with this rank as its own peer
+void dist_loopback(Comm& c, uint64_t out[8]);
+void dist_selftest(Comm& c, uint64_t elements, uint32_t width, uint64_t out[4]);     // one message of that size to this rank itself, in pieces                                     // the exchange's messages with this rank as its own peer
 // (no exchange of columns: a rank of a sharded run produces, scans and drops its own share of the stream)
 
 }  // namespace mmt

@@ -883,7 +883,10 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     // (a run whose rows leave with their windows -- the MEM modes of a rank of configs[4]: text and tables are 200 GB before the
     // first batch -- keeps nothing that grows: the heap may go to nine tenths.  MMT_EXPAND_HEAP_FRAC: tuning aid)
     const double free_now = (double)pool::available(device_), live_now = (double)pool::stats(device_).live;
-    double heap_frac = sink_active_ && sink_discard_ ? 0.90 : 0.76;
+    // (0.82, 0.76 until round 6: a share of 13 REALISTIC whole genomes holds 35 GB of giant-phrase tables more than the i.i.d. one before
+    // its first batch, and at 0.76 its batches were 312 M representatives -- 64 passes over the text -- where 0.86 gave 723 M, 29
+    // passes and 7 s less; 0.82 keeps the peak of such a share near 255 GB of the 288)
+    double heap_frac = sink_active_ && sink_discard_ ? 0.90 : 0.82;
     if (const char* c = std::getenv("MMT_EXPAND_HEAP_FRAC")) heap_frac = std::min(0.95, std::max(0.3, std::atof(c)));
     const double avail = std::min(0.80 * free_now, heap_frac * (free_now + live_now) - live_now) - 2.0 * per_out * (double)head_room -
                          8.0 * (double)((n + gk::TILE - 1) / gk::TILE) - 4.0 * 1073741824.0;

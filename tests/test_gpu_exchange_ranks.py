@@ -125,7 +125,7 @@ def test_exchange_and_fold_over_several_ranks(world, what):
 
 @pytest.mark.parametrize("world,what", [(3, "rank0"), (4, "ranges")])
 def test_messages_travel_in_pieces_when_their_counts_are_large(world, what):
-    """dist.cpp cuts every message into pieces of at most 2^30 elements (a threshold column over a 3.05 Gbp anchor is 3.05 G
+    """dist.cpp cuts every message into pieces of at most 2^29 bytes (2^30 elements until round 6) (a threshold column over a 3.05 Gbp anchor is 3.05 G
     elements): MUMEMTO_RCCL_CHUNK = 997 makes every table of this small collection travel in dozens of pieces, sender and
     receiver cutting the same way -- the merged bytes are still the oracle's."""
     got = run_ranks(world, what, env_extra={"MUMEMTO_RCCL_CHUNK": "997"})

@@ -270,7 +270,7 @@ def test_two_rank_shares_of_configs3_and_their_fold_at_the_anchors_length():
         if share == 0:
             bigchecks.check_mum_rows(eng, bases, lens, use_text=False)
             # the exchange's messages at THIS size through the real RCCL, the rank as its own peer (dist.cpp dist_loopback): 30 M x 13
-            # row tables and the 3.05 G thresholds (12.2 GB) as grouped ncclSend / ncclRecv in pieces of 2^30 elements, the all-gather
+            # row tables and the 3.05 G thresholds (12.2 GB) as grouped ncclSend / ncclRecv in pieces of 2^29 bytes, the all-gather
             # of the meta words, a broadcast -- counts beyond 2^31, size_t arithmetic and stream ordering meet the library itself
             comm = mumemto_amd.Comm(eng, 0, 1, mumemto_amd.Comm.unique_id())
             try:
@@ -280,7 +280,9 @@ def test_two_rank_shares_of_configs3_and_their_fold_at_the_anchors_length():
             print("loopback through RCCL: %.1f GB in %d pieces (largest %.2f GB) in %.2f s, %d elements differ"
                   % (lb["bytes"] / 1e9, lb["pieces"], lb["largest_piece_bytes"] / 1e9, lb["seconds"], lb["different"]))
             assert lb["different"] == 0 and lb["thresholds"] == length + 1 and lb["rows"] > 25_000_000
-            assert lb["largest_piece_bytes"] == 4 << 30 and lb["pieces"] >= 6
+            # (pieces of half a gibibyte: of a piece beyond 1 GiB half the elements arrived different in RCCL 2.26 -- this very
+            # assertion found it at 2^30 ELEMENTS a piece; tests/micro/rccl_sizes.py, profiles/round6_rccl_piece_sizes.log)
+            assert lb["largest_piece_bytes"] == 1 << 29 and lb["pieces"] >= 30
         L, off, strands = eng.rows_mum()
         assert len(L) > 25_000_000
         th = eng.thresholds32()[: length + 1].copy()

@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--length", type=int, default=64_000_000, help="bases per haplotype")
     ap.add_argument("--divergence", type=float, default=0.001)
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-sample-bp", type=int, default=600_000,
+    ap.add_argument("--cpu-sample-bp", type=int, default=2_000_000,
                     help="bases per haplotype given to the 1-core CPU baseline (0 = skip)")
     ap.add_argument("--producer", default="auto", choices=["auto", "direct", "pfp"])
     ap.add_argument("--pfp-w", type=int, default=0)
@@ -487,7 +487,7 @@ def main():
     # HBM bytes the scan kernel really moved, from the PMC passes under profiles/ (separate rocprofv3 runs of this
     # command line; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), valid for the default workload only
     def newest(name):
-        for r in ("round5", "round4", "round3"):
+        for r in ("round6", "round5", "round4", "round3"):
             f = os.path.join(ROOT, "profiles", "%s_%s" % (r, name))
             if os.path.exists(f):
                 return f

@@ -212,6 +212,12 @@ void Engine::guided_prepare() {
         return std::chrono::duration<double, std::milli>(now() - t).count();
     };
     EventPair e3, e5;
+    auto t_mark = now();
+    auto mark = [&](const char* what) {               // (MMT_GUIDED_STATS: where the preparation's time goes)
+        if (!stats) return;
+        std::fprintf(stderr, "[guided] prepare: %s %.1f ms\n", what, ms_since(t_mark));
+        t_mark = now();
+    };
 
     // ---- symbol codes (ascending with the byte value; Dollar is the smallest symbol of V) ----
     e3.start(st);
@@ -290,6 +296,7 @@ void Engine::guided_prepare() {
         S.tmask.release();
     }
 
+    mark("phrase-end tables");
     // ---- the bins of the text suffixes (leading characters) ----
     S.g_nbins = 1u << (ctx.bits * prefix_chars);
     {
@@ -315,7 +322,9 @@ void Engine::guided_prepare() {
     S.err.ensure(16);
     MMT_HIP(hipMemsetAsync(S.err.get(), 0, 64, st));
 
+    mark("bin histograms");
     build_giant(hist);
+    mark("giant dictionary");
 
     // ---- lexicographic ranks of the distinct phrases (one batch of the sort below), the parse ----
     auto t0 = now();
@@ -431,9 +440,35 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     if (const char* c = std::getenv("MMT_GIANT_DEPTH")) ctx.g_depth = (uint32_t)std::max(1, std::atoi(c)) * (uint32_t)ctx.chars;
     DevBuf<uint32_t> flags, gids, count;
     count.ensure(4);
-    // distinct phrases longer than g_depth (dlen counts the terminator)
+    // distinct phrases longer than g_depth (dlen counts the terminator) ...
     flags.ensure(std::max(D, m)); gids.ensure(D);
     gk::flag_greater(S.dlen.get(), D, ctx.g_depth + 1, flags.get(), st);
+    // ... and the phrases NEXT to their occurrences in the parse (four steps either way).  A group of suffixes takes its order
+    // from the giant dictionary at once when ALL its members lie in giant phrases (sort_batch, k_giant_probe); the suffixes inside
+    // a microsatellite -- 1.3 G representatives of a rank's share of 13 realistic whole genomes: a phrase of 2.5 kb is private
+    // to its haplotype -- share hundreds of characters with thousands of others, and one member in an ORDINARY phrase (two
+    // mutations that made triggers a few hundred bases apart: 3 % of the positions of such an array) keeps its whole group walking
+    // 21 characters a round to the giant depth.  Which phrases the giant dictionary holds is free as long as it holds every
+    // phrase longer than g_depth: the short phrases between and beside giant ones are the ones that sit in those groups.
+    // (MMT_GIANT_PROMOTE=<steps>, 0: none)
+    DevBuf<uint32_t> occ_flag;                  // per phrase of the parse: lies in a phrase of the giant dictionary
+    const int promote = std::getenv("MMT_GIANT_PROMOTE") ? std::max(0, std::atoi(std::getenv("MMT_GIANT_PROMOTE"))) : 4;
+    bool promoted = false;
+    if (promote > 0 && S.pid.get()) {
+        DevBuf<uint32_t> spread;
+        occ_flag.ensure(m); spread.ensure(m);
+        gk::flag_greater(S.plen.get(), m, ctx.g_depth, occ_flag.get(), st);
+        MMT_HIP(hipMemsetAsync(count.get(), 0, 16, st));
+        pk::sum_u32(occ_flag.get(), m, reinterpret_cast<uint64_t*>(count.get()), st);
+        uint64_t any = 0;
+        MMT_HIP(hipMemcpyAsync(&any, count.get(), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        if (any) {
+            for (int h = 0; h < promote; h++) { gk::flag_spread(occ_flag.get(), m, spread.get(), st); occ_flag.swap(spread); }
+            gk::flag_to_distinct(occ_flag.get(), S.pid.get(), m, flags.get(), st);
+            promoted = true;
+        }
+    }
     prims::select_indices_u32flags(d_temp_, flags.get(), gids.get(), count.get(), D, st);
     const uint32_t nG = read_u32(count.get(), st);
     if (!nG) return;
@@ -505,7 +540,17 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     prims::inclusive_sum_u32(d_temp_, S.gi_grp.get(), S.gi_grp.get(), nd, st);
     build_rmq(S.gi_lcp.get(), nd, S.gi_bmin, S.gi_nb, S.gi_levels, st);
     // the occurrences of giant phrases in the parse: phrase index (ascending), first V index, place in the dictionary
+    if (promoted) {
+        // (the occurrences of the dictionary's phrases: every occurrence of a promoted phrase, wherever it lies)
+        DevBuf<uint32_t> dflag;
+        dflag.ensure(D);
+        MMT_HIP(hipMemsetAsync(dflag.get(), 0, (size_t)D * 4, st));
+        gk::flag_scatter_ones(gids.get(), nG, dflag.get(), st);
+        gk::flag_from_distinct(dflag.get(), S.pid.get(), m, flags.get(), st);
+        MMT_HIP(hipStreamSynchronize(st));
+    } else
     gk::flag_greater(S.plen.get(), m, ctx.g_depth, flags.get(), st);
+    occ_flag.release();
     S.gi_bits.ensure(((size_t)m + 31) / 32 + 1);
     gk::giant_bits(flags.get(), m, S.gi_bits.get(), st);
     DevBuf<uint32_t> occ_idx;

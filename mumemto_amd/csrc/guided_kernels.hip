@@ -1864,6 +1864,42 @@ void flag_greater(const uint32_t* v, uint32_t n, uint32_t thr, uint32_t* flags, 
     hipLaunchKernelGGL(k_flag_greater, dim3(grid_for(n, 256)), dim3(256), 0, s, v, n, thr, flags);
     MMT_HIP(hipGetLastError());
 }
+// Promotion of the neighbours of giant occurrences (guided.cpp build_giant): out[k] = in[k - 1] | in[k] | in[k + 1];
+// dflag[pid[k]] = 1 where an occurrence is flagged; flags[k] = dflag[pid[k]]
+__global__ void k_flag_spread(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] | (i ? in[i - 1] : 0u) | (i + 1 < n ? in[i + 1] : 0u);
+}
+void flag_spread(const uint32_t* in, uint32_t n, uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_spread, dim3(grid_for(n, 256)), dim3(256), 0, s, in, n, out);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_flag_to_distinct(const uint32_t* __restrict__ occ_flag, const uint32_t* __restrict__ pid, uint32_t m,
+                                   uint32_t* __restrict__ dflag) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m && occ_flag[k]) dflag[pid[k]] = 1u;
+}
+void flag_to_distinct(const uint32_t* occ_flag, const uint32_t* pid, uint32_t m, uint32_t* dflag, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_to_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, occ_flag, pid, m, dflag);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_flag_from_distinct(const uint32_t* __restrict__ dflag, const uint32_t* __restrict__ pid, uint32_t m,
+                                     uint32_t* __restrict__ occ_flag) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < m) occ_flag[k] = dflag[pid[k]];
+}
+void flag_from_distinct(const uint32_t* dflag, const uint32_t* pid, uint32_t m, uint32_t* occ_flag, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_from_distinct, dim3(grid_for(m, 256)), dim3(256), 0, s, dflag, pid, m, occ_flag);
+    MMT_HIP(hipGetLastError());
+}
+__global__ void k_flag_scatter_ones(const uint32_t* __restrict__ ids, uint32_t n, uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[ids[i]] = 1u;
+}
+void flag_scatter_ones(const uint32_t* ids, uint32_t n, uint32_t* flags, hipStream_t s) {
+    hipLaunchKernelGGL(k_flag_scatter_ones, dim3(grid_for(n, 256)), dim3(256), 0, s, ids, n, flags);
+    MMT_HIP(hipGetLastError());
+}
 __global__ void k_giant_distinct(const uint32_t* __restrict__ gids, uint32_t n, const uint32_t* __restrict__ rep,
                                  const uint32_t* __restrict__ dlen, uint32_t* __restrict__ which, uint32_t* __restrict__ glen) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -150,6 +150,10 @@ void range_groups(const uint32_t* ghead, const uint32_t* big_begin, const uint32
 
 // giant phrases: flags[i] = v[i] > thr; the giant dictionary's bookkeeping (guided.cpp::build_giant)
 void flag_greater(const uint32_t* v, uint32_t n, uint32_t thr, uint32_t* flags, hipStream_t s);
+void flag_spread(const uint32_t* in, uint32_t n, uint32_t* out, hipStream_t s);                       // out[k] = in[k - 1] | in[k] | in[k + 1]
+void flag_to_distinct(const uint32_t* occ_flag, const uint32_t* pid, uint32_t m, uint32_t* dflag, hipStream_t s);
+void flag_from_distinct(const uint32_t* dflag, const uint32_t* pid, uint32_t m, uint32_t* occ_flag, hipStream_t s);
+void flag_scatter_ones(const uint32_t* ids, uint32_t n, uint32_t* flags, hipStream_t s);                    // flags[ids[i]] = 1
 void giant_distinct(const uint32_t* gids, uint32_t n, const uint32_t* rep, const uint32_t* dlen, uint32_t* which, uint32_t* glen,
                     hipStream_t s);
 // bits[k / 32] bit k % 32 = flags[k] != 0

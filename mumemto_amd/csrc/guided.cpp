@@ -454,34 +454,50 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     DevBuf<uint32_t> occ_flag;                  // per phrase of the parse: lies in a phrase of the giant dictionary
     const int promote = std::getenv("MMT_GIANT_PROMOTE") ? std::max(0, std::atoi(std::getenv("MMT_GIANT_PROMOTE"))) : 4;
     bool promoted = false;
-    if (promote > 0 && S.pid.get()) {
-        DevBuf<uint32_t> spread;
-        occ_flag.ensure(m); spread.ensure(m);
-        gk::flag_greater(S.plen.get(), m, ctx.g_depth, occ_flag.get(), st);
-        MMT_HIP(hipMemsetAsync(count.get(), 0, 16, st));
-        pk::sum_u32(occ_flag.get(), m, reinterpret_cast<uint64_t*>(count.get()), st);
-        uint64_t any = 0;
-        MMT_HIP(hipMemcpyAsync(&any, count.get(), 8, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipStreamSynchronize(st));
-        if (any) {
-            for (int h = 0; h < promote; h++) { gk::flag_spread(occ_flag.get(), m, spread.get(), st); occ_flag.swap(spread); }
-            gk::flag_to_distinct(occ_flag.get(), S.pid.get(), m, flags.get(), st);
-            promoted = true;
-        }
-    }
-    prims::select_indices_u32flags(d_temp_, flags.get(), gids.get(), count.get(), D, st);
-    const uint32_t nG = read_u32(count.get(), st);
-    if (!nG) return;
-    DevBuf<uint32_t> which, glen, gstart, dmap;
-    which.ensure(nG); glen.ensure(nG); gstart.ensure(nG); dmap.ensure(D);
-    gk::giant_distinct(gids.get(), nG, S.rep.get(), S.dlen.get(), which.get(), glen.get(), st);
-    DevBuf<uint64_t> total;
-    total.ensure(1);
-    pk::sum_u32(glen.get(), nG, total.get(), st);
+    uint32_t nG = 0;
     uint64_t nd64 = 0;
-    MMT_HIP(hipMemcpyAsync(&nd64, total.get(), 8, hipMemcpyDeviceToHost, st));
-    MMT_HIP(hipStreamSynchronize(st));
-    nd64 += 1;
+    DevBuf<uint32_t> which, glen, gstart, dmap;
+    // (a dictionary that the neighbours push beyond 32 bits is built with fewer of them, then with none: the phrases longer than
+    // g_depth are the ones it must hold)
+    std::vector<int> attempts{promote};
+    if (promote > 1) attempts.push_back(1);
+    if (promote > 0) attempts.push_back(0);
+    for (size_t a = 0; a < attempts.size(); a++) {
+        const int steps = attempts[a];
+        gk::flag_greater(S.dlen.get(), D, ctx.g_depth + 1, flags.get(), st);
+        promoted = false;
+        if (steps > 0 && S.pid.get()) {
+            DevBuf<uint32_t> spread;
+            occ_flag.ensure(m); spread.ensure(m);
+            gk::flag_greater(S.plen.get(), m, ctx.g_depth, occ_flag.get(), st);
+            MMT_HIP(hipMemsetAsync(count.get(), 0, 16, st));
+            pk::sum_u32(occ_flag.get(), m, reinterpret_cast<uint64_t*>(count.get()), st);
+            uint64_t any = 0;
+            MMT_HIP(hipMemcpyAsync(&any, count.get(), 8, hipMemcpyDeviceToHost, st));
+            MMT_HIP(hipStreamSynchronize(st));
+            if (any) {
+                for (int h = 0; h < steps; h++) { gk::flag_spread(occ_flag.get(), m, spread.get(), st); occ_flag.swap(spread); }
+                gk::flag_to_distinct(occ_flag.get(), S.pid.get(), m, flags.get(), st);
+                promoted = true;
+            }
+        }
+        prims::select_indices_u32flags(d_temp_, flags.get(), gids.get(), count.get(), D, st);
+        nG = read_u32(count.get(), st);
+        if (!nG) return;
+        which.ensure(nG); glen.ensure(nG); gstart.ensure(nG);
+        gk::giant_distinct(gids.get(), nG, S.rep.get(), S.dlen.get(), which.get(), glen.get(), st);
+        DevBuf<uint64_t> total;
+        total.ensure(1);
+        pk::sum_u32(glen.get(), nG, total.get(), st);
+        MMT_HIP(hipMemcpyAsync(&nd64, total.get(), 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        nd64 += 1;
+        if (std::getenv("MMT_GUIDED_STATS"))
+            std::fprintf(stderr, "[guided] giant dictionary with the phrases within %d steps of a giant occurrence: %u phrases, %llu characters\n",
+                         steps, nG, (unsigned long long)nd64);
+        if (nd64 < 0xffffff00ull || a + 1 == attempts.size()) break;
+    }
+    dmap.ensure(D);
     if (nd64 >= 0xffffff00ull) throw std::runtime_error("giant phrases of " + std::to_string(nd64) + " characters in all exceed a 32-bit dictionary");
     const uint32_t nd = (uint32_t)nd64;
     prims::exclusive_sum_u32(d_temp_, glen.get(), gstart.get(), nG, st);

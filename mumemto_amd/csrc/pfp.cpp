@@ -167,8 +167,11 @@ void Engine::pfp_parse(uint32_t w, uint32_t p, bool keep_dict_inputs) {
                 // (... below 2^38 characters: a text that fills the device -- every rank of configs[4] holds 573 G characters --
                 // leaves the inverted lists and the batches of representatives too little room next to each other; there the
                 // plain producer with its staging list stays)
+                // (round 6: ... and beyond as well -- with the staging list of representatives, the trigger bits made slice by
+                // slice and the heap at nine tenths a rank's share of 573 G characters runs through expansion in 69 s where the plain
+                // producer took 104, at the same peak)
                 S.expand = producer_ == 4 || (env && std::string(env) == "expand") ||
-                           (!named_plain && (double)dict_len64 < 0.5 * (double)n && n < (1ull << 38));
+                           (!named_plain && (double)dict_len64 < 0.5 * (double)n);
                 if (const char* x = std::getenv("MUMEMTO_EXPAND")) S.expand = std::atoi(x) != 0;
             }
             if (S.guided) {

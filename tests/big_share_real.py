@@ -170,6 +170,12 @@ def main():
         return
     text = bigchecks.LazyText(bases, lens)
     t = time.time()
+    if A.mode == "c5":
+        # (a rank of a sharded run holds whole bins of leading characters: the bins of this one's share are the ones to check)
+        all_kmers = kmers
+        kmers = [km for km in all_kmers if eng.kmer_in_share(km)]
+        print(json.dumps(dict(bins_in_this_ranks_share=len(kmers), of=len(all_kmers))), flush=True)
+        assert kmers, "none of the bins lies in the rank's share: another --rank or --seed"
     bins, suffixes, rows = bigchecks.check_bins_complete(eng, text, text.n, text.doc_start, kmers, **(
         dict() if A.mode == "strict" else dict(num_distinct=len(mine) - 1, max_doc_freq=3)))
     print(json.dumps(dict(bins_checked=bins, suffixes_sorted_on_the_host=suffixes, rows_in_those_bins_equal_to_the_oracles=rows,
@@ -179,7 +185,7 @@ def main():
     pos, which = eng.kmer_positions(kmers, cap=1 << 24)
     comp = bytes.maketrans(b"ACGTN", b"TGCAN")
     # (one bin of every kind: a whole-genome document is seconds of memmem per pattern and strand)
-    chosen = sorted({0, n_sat, n_sat + 1, n_sat + n_gap} & set(range(len(kmers))))
+    chosen = sorted({0, n_sat, n_sat + 1, n_sat + n_gap} & set(range(len(kmers)))) if A.mode != "c5" else list(range(min(3, len(kmers))))
     jobs = []
     for i in chosen:
         km = kmers[i]

@@ -544,7 +544,7 @@ int mmt_engine_set_producer(mmt_engine* e, int kind, uint32_t w, uint32_t p) {
     e->e->set_producer(kind, w, p);
     return 0;
 }
-int mmt_abi_version(void) { return 5; }
+int mmt_abi_version(void) { return 6; }
 int mmt_text_sink_digest(const mmt_engine* e, uint64_t out[2]) {
     if (!e || !out) return fail(1, "null");
     e->e->text_sink_digest(out);

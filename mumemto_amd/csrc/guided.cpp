@@ -615,7 +615,6 @@ void Engine::guided_check_errors(const char* what) {
 // the bins from the first one whose cumulative count reaches k n / count (every rank derives the same shares from the
 // same histogram); nothing is exchanged but the rows.
 void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
-    if (pfp_->expand) { guided_stream_expand(SS, p); return; }
     PfpState& S = *pfp_;
     const uint64_t n = n_;
     hipStream_t st = stream_;
@@ -626,6 +625,19 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
         S.gctx.prof = prof.get();
     }
     struct ProfOff { gk::Ctx& c; ~ProfOff() { c.prof = nullptr; } } prof_off{S.gctx};
+    auto print_prof = [&]() {
+        if (!prof.get()) return;
+        std::vector<unsigned long long> h(16);
+        MMT_HIP(hipMemcpyAsync(h.data(), prof.get(), 16 * 8, hipMemcpyDeviceToHost, st));
+        MMT_HIP(hipStreamSynchronize(st));
+        const double w = (double)std::max<unsigned long long>(1, h[7]);
+        std::fprintf(stderr, "[guided] k_resolve_medium: %llu waves; ticks of the 100 MHz clock per wave: staging %.0f, reference %.0f, "
+                     "first comparison %.0f, network %.0f, output %.0f; members with a difference %llu, undecided %llu, text "
+                     "comparisons inside the network %llu; members %llu, of them in the reference's class %llu, groups whose best class has one member %llu, "
+                     "groups where half the members differ from the reference %llu, members that repeat another's (place, character) %llu\n",
+                     h[7], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[8], h[9], h[10], h[12], h[11], h[13], h[14], h[15]);
+    };
+    if (pfp_->expand) { guided_stream_expand(SS, p); print_prof(); return; }
     const gk::Ctx& ctx = S.gctx;
     const int prefix_chars = S.g_prefix;
     const uint32_t n_bins = S.g_nbins;
@@ -831,17 +843,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
         b0 = b1;
     }
     guided_check_errors("text suffixes");
-    if (prof.get()) {
-        std::vector<unsigned long long> h(16);
-        MMT_HIP(hipMemcpyAsync(h.data(), prof.get(), 16 * 8, hipMemcpyDeviceToHost, st));
-        MMT_HIP(hipStreamSynchronize(st));
-        const double w = (double)std::max<unsigned long long>(1, h[7]);
-        std::fprintf(stderr, "[guided] k_resolve_medium: %llu waves; ticks of the 100 MHz clock per wave: staging %.0f, reference %.0f, "
-                     "first comparison %.0f, network %.0f, output %.0f; members with a difference %llu, undecided %llu, text "
-                     "comparisons inside the network %llu; members %llu, of them in the reference's class %llu, groups whose best class has one member %llu, "
-                     "groups where half the members differ from the reference %llu, members that repeat another's (place, character) %llu\n",
-                     h[7], h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[8], h[9], h[10], h[12], h[11], h[13], h[14], h[15]);
-    }
+    print_prof();
     if (base != piece_end) throw std::runtime_error("guided sort: the batches do not cover the text exactly once");
     S.rounds_dict = rounds_max; S.emit_launches = (uint32_t)batches;
     run_slices_ = 0; text_passes_ = (uint32_t)(staged ? passes : batches); batches_ = (uint32_t)batches; staged_ = staged;

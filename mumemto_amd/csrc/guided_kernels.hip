@@ -1272,6 +1272,7 @@ struct MedStage {
     uint32_t gr[W], gg[W];            // members in giant phrases: entry of the giant dictionary's suffix array at `offset`, its group
     uint8_t idx[W];
     uint32_t bad;
+    uint32_t text_cmps;              // MMT_GUIDED_PROF: comparisons the network sent to the text
 };
 // Order of two staged members (true: a sorts before b).  What the staged characters do not decide -- both alphas longer
 // than what was staged and equal so far -- is compared in the text itself.  *lcp (optional) receives the number of
@@ -1323,7 +1324,7 @@ __device__ __forceinline__ bool med_before(const Ctx& c, MedStage<W>& S, uint32_
             text = true; from = (uint64_t)ea + 1;                  // (a third shared mutation: the text decides)
         }
         if (text) {
-            if (c.prof) atomicAdd(c.prof + 10, 1ull);
+            if (c.prof) atomicAdd(&S.text_cmps, 1u);             // (counted in LDS, added up once per wave)
             const int r2 = cmp_rest(c, rec_pos(c, S.rec[a]), S.len[a], rec_pos(c, S.rec[b]), S.len[b], from, lcp);
             if (r2) return r2 < 0;
         }
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
         const uint2 grp = have ? list[gw + lane] : make_uint2(0u, 0u);
         s_g0[wave][lane] = grp.x; s_g[wave][lane] = have ? grp.y : 0u;
     }
-    if (lane == 0) S.bad = 0;
+    if (lane == 0) { S.bad = 0; S.text_cmps = 0; }
     unsigned long long tick = c.prof ? wall_clock64() : 0ull;
 #define MMT_PROF(slot) do { if (c.prof) { const unsigned long long now_ = wall_clock64(); if (lane == 0) atomicAdd(c.prof + (slot), now_ - tick); tick = now_; } } while (0)
 #define MMT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -1504,7 +1505,10 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
             }
         }
         S.dref[i] = d; S.cref[i] = (uint16_t)cc;
-        if (c.prof && d != MED_SAME) atomicAdd(c.prof + (d == MED_UNKNOWN ? 9 : 8), 1ull);
+        if (c.prof) {                                           // (one atomic per wave and counter, not one per member)
+            const unsigned long long diff = __ballot(d != MED_SAME && d != MED_UNKNOWN), unk = __ballot(d == MED_UNKNOWN);
+            if (lane == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) { if (diff) atomicAdd(c.prof + 8, (unsigned long long)__popcll(diff)); if (unk) atomicAdd(c.prof + 9, (unsigned long long)__popcll(unk)); }
+        }
     }
     MMT_WAVE_SYNC();
     // second level: the members that repeat an earlier member's (place, character) against the first of their kind
@@ -1607,7 +1611,7 @@ __global__ __launch_bounds__(256) void k_resolve_medium(Ctx c, RmqView R, const 
         }
     }
     MMT_PROF(4);
-    if (c.prof && lane == 0) atomicAdd(c.prof + 7, 1ull);
+    if (c.prof && lane == 0) { atomicAdd(c.prof + 7, 1ull); if (S.text_cmps) atomicAdd(c.prof + 10, (unsigned long long)S.text_cmps); }
 #undef MMT_PROF
 }
 template <int SEG, int W>

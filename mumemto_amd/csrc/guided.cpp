@@ -709,7 +709,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
             double stage_bytes = spare / 8.0 >= 2.0 * (double)cap64 ? spare : 0.4 * avail;
             uint64_t fit2 = (uint64_t)(std::max(avail - stage_bytes, 0.0) / per_element);
             if (fit2 < largest) { fit2 = largest; stage_bytes = avail - (double)largest * per_element; }
-            stage_cap = stage_bytes > 0 ? (uint64_t)(stage_bytes / 8.0) : 0;
+            stage_cap = stage_bytes > 0 ? (uint64_t)(stage_bytes / 4.0) : 0;        // (four bytes an entry since round 6)
             stage_cap = std::min<uint64_t>(std::min<uint64_t>(stage_cap, share), 0xfff00000ull);      // (32-bit offsets per tile)
             if (stage_cap < 2 * std::max<uint64_t>(largest, 1) || fit2 < (1u << 20)) staged = false;
             else cap64 = std::min<uint64_t>(cap64, std::max<uint64_t>(fit2, largest));
@@ -718,9 +718,9 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
     }
     Batch X;
     X.reserve((uint32_t)cap64);
-    DevBuf<uint64_t> stage;
+    DevBuf<uint32_t> stage, blk_tile;
     DevBuf<uint32_t> blk_cnt, blk_off;
-    if (staged) { stage.ensure(stage_cap + 16); blk_cnt.ensure(stage_cap / 4096 + 2); blk_off.ensure(stage_cap / 4096 + 2); }
+    if (staged) { stage.ensure(stage_cap + 16); blk_cnt.ensure(stage_cap / 4096 + 2); blk_off.ensure(stage_cap / 4096 + 2); blk_tile.ensure(stage_cap / 4096 + 3); }
     window_reserve(0, head_room + cap64 + 16);
     window_reserve(1, head_room + cap64 + 16);
     DevBuf<uint64_t> carry;
@@ -757,6 +757,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
                 const bool more = next_total > 0;
                 gk::stage_fill(ctx, prefix_chars, b0, pass_end, tile_off.get(), stage.get(), pass_end, next_end,
                                more ? tile_cnt.get() : nullptr, st);
+                gk::stage_block_tiles(tile_off.get(), n_tiles, n_staged, blk_tile.get(), st);
                 counted_lo = more ? pass_end : 0; counted_hi = more ? next_end : 0;
             }
             passes++;
@@ -781,7 +782,7 @@ void Engine::guided_stream(ScanState& SS, const mmt_params& p) {
                 while (nb1 < pass_end && next_total + bins[nb1] <= X.cap) next_total += bins[nb1++];
                 const bool more = next_total > 0;
                 gk::stage_take(ctx, stage.get(), n_staged, b0, b1, blk_off.get(), X.key_a.get(), X.pos_a.get(), b1, nb1,
-                               more ? blk_cnt.get() : nullptr, st);
+                               more ? blk_cnt.get() : nullptr, tile_off.get(), blk_tile.get(), st);
                 taken_lo = more ? b1 : 0; taken_hi = more ? nb1 : 0;
             } else {
                 // (the batch before counted this batch's suffixes per tile while it filled its own)
@@ -991,7 +992,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
             const double for_reps = std::max(avail - (double)win_cap * per_out, 0.0);
             const double stage_bytes = 0.4 * for_reps;
             const uint64_t fit2 = (uint64_t)((for_reps - stage_bytes) / per_rep);
-            stage_cap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)(stage_bytes / 8.0), share_rep), 0xfff00000ull);   // (32-bit offsets per tile)
+            stage_cap = std::min<uint64_t>(std::min<uint64_t>((uint64_t)(stage_bytes / 4.0), share_rep), 0xfff00000ull);   // (32-bit offsets per tile)
             if (fit2 < (1u << 20) || fit2 < largest_rep || stage_cap < 2 * std::max<uint64_t>(largest_rep, 1)) staged = false;
             else rep_cap = std::min<uint64_t>(rep_cap, fit2);
         }
@@ -1121,9 +1122,9 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     carry.ensure(2);
     DevBuf<uint32_t> tile_cnt, tile_off;
     tile_cnt.ensure((size_t)n_tiles + 1); tile_off.ensure((size_t)n_tiles + 1);
-    DevBuf<uint64_t> stage;
+    DevBuf<uint32_t> stage, blk_tile;
     DevBuf<uint32_t> blk_cnt, blk_off;
-    if (staged) { stage.ensure(stage_cap + 16); blk_cnt.ensure(stage_cap / 4096 + 2); blk_off.ensure(stage_cap / 4096 + 2); }
+    if (staged) { stage.ensure(stage_cap + 16); blk_cnt.ensure(stage_cap / 4096 + 2); blk_off.ensure(stage_cap / 4096 + 2); blk_tile.ensure(stage_cap / 4096 + 3); }
     const uint64_t anchor = std::min<uint64_t>(doc_len_[0], n);
     const RmqView rmq = S.plcp.view();
     S.emit_ready = true;
@@ -1178,6 +1179,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
                 const bool more = next_total > 0;
                 real_range(pass_end, next_end, nlo, nhi, none);
                 gk::stage_fill(ctx, prefix_chars, lo, hi, tile_off.get(), stage.get(), nlo, more ? nhi : nlo, more ? tile_cnt.get() : nullptr, st);
+                gk::stage_block_tiles(tile_off.get(), n_tiles, n_staged, blk_tile.get(), st);
                 counted_lo = more ? pass_end + 1 : 0; counted_hi = more ? next_end + 1 : 0;
                 passes++;
             }
@@ -1204,7 +1206,7 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
             real_range(b1, nb1, nr_lo, nr_hi, nrs);
             const bool more = ntr > 0;
             gk::stage_take(ctx, stage.get(), n_staged, r_lo, r_hi, blk_off.get(), X.key_a.get(), X.pos_a.get(), nr_lo, more ? nr_hi : nr_lo,
-                           more ? blk_cnt.get() : nullptr, st);
+                           more ? blk_cnt.get() : nullptr, tile_off.get(), blk_tile.get(), st);
             taken_lo = more ? b1 + 1 : 0; taken_hi = more ? nb1 + 1 : 0;
         } else {
             // (the batch before counted this batch's representatives per tile while it collected its own)

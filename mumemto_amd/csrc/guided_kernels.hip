@@ -838,7 +838,7 @@ void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi
 // pass over a few G entries instead of hundreds of G characters) and only there looks up keys and records.
 // (the same pass also counts, per tile, the suffixes of the NEXT pass's bins [next_lo, next_hi): its k_batch_count is then not run)
 __device__ __forceinline__ void stage_fill_tile(const Ctx& c, uint64_t tile, int pc, uint32_t bin_lo, uint32_t bin_hi,
-                                                const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ staged,
+                                                const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ staged,
                                                 uint32_t next_lo, uint32_t next_hi, uint32_t* __restrict__ next_count) {
     __shared__ __align__(16) uint8_t s_sym[TILE + 64];
     __shared__ uint32_t s_wave[4], s_next[4];
@@ -895,11 +895,11 @@ __device__ __forceinline__ void stage_fill_tile(const Ctx& c, uint64_t tile, int
             for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | ((c.acgt_lut >> (8 * (uint32_t)((x >> (2 * ch)) & 3u))) & 0xffu);
         } else
         for (int ch = 0; ch < pc; ch++) bin = (bin << c.bits) | s_sym[o + ch];
-        staged[first + i] = (base + o + 1) | ((uint64_t)bin << 40);
+        staged[first + i] = o | (bin << 12);             // (the tile is where the entry lies in the list: tile_off)
     }
 }
 __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_lo, uint32_t bin_hi,
-                                                    const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ staged,
+                                                    const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ staged,
                                                     uint32_t next_lo, uint32_t next_hi, uint32_t* __restrict__ next_count,
                                                     uint32_t slice_tiles) {
     MMT_PASS_LOOP(c, slice_tiles, tile) {
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void k_stage_fill(Ctx c, int pc, uint32_t bin_
         __syncthreads();
     }
 }
-void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,
+void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint32_t* staged,
                 uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s) {
     for_tile_slices(c, [&](const Ctx& cs, unsigned blocks) {
         hipLaunchKernelGGL(k_stage_fill, dim3((blocks + PASS_TILES - 1) / PASS_TILES), dim3(256), 0, s, cs, prefix_chars, bin_lo, bin_hi,
@@ -915,8 +915,27 @@ void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi
     });
     MMT_HIP(hipGetLastError());
 }
+// the last tile t of [lo, hi] with tile_off[t] <= idx: the tile whose entries hold entry idx of the list (empty tiles share their
+// offset with the tile behind them: the last one owns the entries)
+__device__ __forceinline__ uint32_t tile_of_entry(const uint32_t* __restrict__ tile_off, uint32_t lo, uint32_t hi, uint32_t idx) {
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if (tile_off[mid] <= idx) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+// blk_tile[B] = the tile of entry 4096 B (B < blocks), blk_tile[blocks] = the last tile: a block of the list knows its tiles' range
+__global__ void k_stage_block_tiles(const uint32_t* __restrict__ tile_off, uint32_t n_tiles, uint64_t n, uint32_t blocks,
+                                    uint32_t* __restrict__ blk_tile) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > blocks) return;
+    blk_tile[b] = b == blocks || (uint64_t)b * 4096 >= n ? n_tiles - 1 : tile_of_entry(tile_off, 0, n_tiles - 1, b * 4096u);
+}
+void stage_block_tiles(const uint32_t* tile_off, uint32_t n_tiles, uint64_t n, uint32_t* blk_tile, hipStream_t s) {
+    if (!n) return;
+    const uint32_t blocks = (uint32_t)((n + 4095) / 4096);
+    hipLaunchKernelGGL(k_stage_block_tiles, dim3(grid_for((uint64_t)blocks + 1, 256)), dim3(256), 0, s, tile_off, n_tiles, n, blocks, blk_tile);
+    MMT_HIP(hipGetLastError());
+}
 // blocks of 4096 staged entries, 16 consecutive ones per work-item
-__global__ __launch_bounds__(256) void k_stage_count(const uint64_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
+__global__ __launch_bounds__(256) void k_stage_count(const uint32_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
                                                      uint32_t* __restrict__ block_count) {
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
@@ -925,7 +944,7 @@ __global__ __launch_bounds__(256) void k_stage_count(const uint64_t* __restrict_
     uint32_t mine = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++)
-        if (from + q < n) { const uint32_t b = (uint32_t)(staged[from + q] >> 40); mine += (b >= b0 && b < b1) ? 1u : 0u; }
+        if (from + q < n) { const uint32_t b = staged[from + q] >> 12; mine += (b >= b0 && b < b1) ? 1u : 0u; }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -933,21 +952,32 @@ __global__ __launch_bounds__(256) void k_stage_count(const uint64_t* __restrict_
     if (threadIdx.x == 0) block_count[blockIdx.x] = s_cnt;
 }
 // (next_count, optional: the same pass counts, per block, the entries of the NEXT batch's bins [nb0, nb1))
-__global__ __launch_bounds__(256) void k_stage_take(Ctx c, const uint64_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
+// An entry is four bytes -- its offset inside its tile and its bin -- since round 6 (eight before: V index and bin): the same
+// memory lists twice the suffixes, a share of 573 G characters takes ten passes over the text instead of nineteen.  The tile of an
+// entry is where the entry lies in the list (tile_off, the prefix sums the pass filled it by); a block of the list knows the range
+// of its tiles (blk_tile) and only the entries a batch TAKES look theirs up, in the block's staged offsets.
+constexpr uint32_t TAKE_SPAN = 2048;
+__global__ __launch_bounds__(256) void k_stage_take(Ctx c, const uint32_t* __restrict__ staged, uint64_t n, uint32_t b0, uint32_t b1,
                                                     const uint32_t* __restrict__ block_off, uint64_t* __restrict__ keys,
                                                     uint64_t* __restrict__ pos, uint32_t nb0, uint32_t nb1,
-                                                    uint32_t* __restrict__ next_count) {
+                                                    uint32_t* __restrict__ next_count, const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ blk_tile) {
     __shared__ uint8_t s_code[256];
     __shared__ uint32_t s_wave[4], s_next[4];
-    __shared__ uint64_t s_sel[4096];
+    __shared__ uint32_t s_sel[4096];
+    __shared__ uint16_t s_idx[4096];
+    __shared__ uint32_t s_off[TAKE_SPAN];
     for (int i = threadIdx.x; i < 256; i += 256) s_code[i] = c.code[i];
+    const uint32_t t_lo = blk_tile[blockIdx.x], t_hi = blk_tile[blockIdx.x + 1];
+    const bool in_lds = t_hi - t_lo < TAKE_SPAN;
+    if (in_lds) for (uint32_t j = threadIdx.x; j <= t_hi - t_lo; j += 256) s_off[j] = tile_off[t_lo + j];
     const uint64_t from = (uint64_t)blockIdx.x * 4096 + threadIdx.x * 16;
-    uint64_t mine[16];
+    uint32_t mine[16];
     uint32_t sel = 0, nxt = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        mine[q] = from + q < n ? staged[from + q] : ~0ull;
-        const uint32_t b = (uint32_t)(mine[q] >> 40);
+        mine[q] = from + q < n ? staged[from + q] : ~0u;
+        const uint32_t b = mine[q] >> 12;
         if (from + q < n && b >= b0 && b < b1) sel |= 1u << q;
         if (from + q < n && b >= nb0 && b < nb1) nxt++;
     }
@@ -965,26 +995,34 @@ __global__ __launch_bounds__(256) void k_stage_take(Ctx c, const uint64_t* __res
     for (uint32_t wv = 0; wv < 4; wv++) { if (wv < wave) at += s_wave[wv]; total += s_wave[wv]; }
 #pragma unroll
     for (int q = 0; q < 16; q++)
-        if (sel & (1u << q)) s_sel[at++] = mine[q] & ((1ull << 40) - 1ull);
+        if (sel & (1u << q)) { s_sel[at] = mine[q]; s_idx[at] = (uint16_t)(threadIdx.x * 16 + q); at++; }
     __syncthreads();
     const uint64_t first = block_off[blockIdx.x];
     if (next_count && threadIdx.x == 0) next_count[blockIdx.x] = s_next[0] + s_next[1] + s_next[2] + s_next[3];
     for (uint32_t i = threadIdx.x; i < total; i += 256) {
-        const uint64_t q = s_sel[i];
+        const uint32_t idx = blockIdx.x * 4096u + s_idx[i];
+        uint32_t tile;
+        if (in_lds) {
+            uint32_t lo = 0, hi = t_hi - t_lo;
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo + 1) / 2; if (s_off[mid] <= idx) lo = mid; else hi = mid - 1; }
+            tile = t_lo + lo;
+        } else tile = tile_of_entry(tile_off, t_lo, t_hi, idx);
+        const uint64_t q = (uint64_t)tile * TILE + (s_sel[i] & 4095u) + 1;
         keys[first + i] = pack_chars(c, s_code, q);
         pos[first + i] = make_rec(c, q);
     }
 }
-void stage_count(const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s) {
+void stage_count(const uint32_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_stage_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, staged, n, b0, b1, block_count);
     MMT_HIP(hipGetLastError());
 }
-void stage_take(const Ctx& c, const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
-                uint64_t* pos, uint32_t nb0, uint32_t nb1, uint32_t* next_count, hipStream_t s) {
+void stage_take(const Ctx& c, const uint32_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
+                uint64_t* pos, uint32_t nb0, uint32_t nb1, uint32_t* next_count, const uint32_t* tile_off, const uint32_t* blk_tile,
+                hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_stage_take, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, s, c, staged, n, b0, b1, block_off, keys, pos, nb0,
-                       nb1, next_count);
+                       nb1, next_count, tile_off, blk_tile);
     MMT_HIP(hipGetLastError());
 }
 

@@ -95,15 +95,19 @@ void batch_count(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_h
 // (next_count, optional: per-tile counts of the next batch's bins [next_lo, next_hi), taken along)
 void batch_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* keys,
                 uint64_t* pos, uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s, const RunSlice& rs = RunSlice());
-// several batches per pass over the text: the suffixes of bins [bin_lo, bin_hi) in text order as (V index | bin << 40) ...
+// several batches per pass over the text: the suffixes of bins [bin_lo, bin_hi) in text order as (offset in the tile | bin << 12):
+// four bytes an entry; its tile is where it lies in the list (tile_off, the prefix sums of the pass's per-tile counts)
 // (next_count, optional: the per-tile counts of the next pass's bins [next_lo, next_hi), taken along)
-void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint64_t* staged,
+void stage_fill(const Ctx& c, int prefix_chars, uint32_t bin_lo, uint32_t bin_hi, const uint32_t* tile_off, uint32_t* staged,
                 uint32_t next_lo, uint32_t next_hi, uint32_t* next_count, hipStream_t s);
+// blk_tile[B] = the tile of the list's entry 4096 B (one more entry behind the last block: the last tile)
+void stage_block_tiles(const uint32_t* tile_off, uint32_t n_tiles, uint64_t n, uint32_t* blk_tile, hipStream_t s);
 // ... and what a batch -- bins [b0, b1) -- takes from that list: counts per block of 4096 entries, then keys and records
-void stage_count(const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s);
+void stage_count(const uint32_t* staged, uint64_t n, uint32_t b0, uint32_t b1, uint32_t* block_count, hipStream_t s);
 // (next_count, optional: per-block counts of the next batch's bins [nb0, nb1), taken along)
-void stage_take(const Ctx& c, const uint64_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
-                uint64_t* pos, uint32_t nb0, uint32_t nb1, uint32_t* next_count, hipStream_t s);
+void stage_take(const Ctx& c, const uint32_t* staged, uint64_t n, uint32_t b0, uint32_t b1, const uint32_t* block_off, uint64_t* keys,
+                uint64_t* pos, uint32_t nb0, uint32_t nb1, uint32_t* next_count, const uint32_t* tile_off, const uint32_t* blk_tile,
+                hipStream_t s);
 // one element per distinct phrase (c.skip = 1)
 void phrase_items(const Ctx& c, const void* pstart, bool wide, const uint32_t* rep, uint32_t D, uint64_t* keys,
                   uint64_t* pos, hipStream_t s);

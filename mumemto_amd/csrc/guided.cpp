@@ -129,6 +129,8 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
         }
     }
     const bool no_early_giant = std::getenv("MMT_GUIDED_NO_EARLY_GIANT") != nullptr;
+    const bool no_tail = std::getenv("MMT_GUIDED_NO_TAIL") != nullptr;
+    bool tail_done = false;
     while (m) {
         if (++rs.rounds > (1 << 22)) throw std::runtime_error("parse-guided suffix sort did not converge");
         rs.active_sum += m;
@@ -190,6 +192,24 @@ RoundStats sort_batch(Batch& X, uint32_t B, const gk::Ctx& ctx, DevBuf<uint8_t>&
         m = m2;
         // (after the round that took its keys from the giant dictionary every alpha that is still tied is spent)
         offset = ctx.g_n && offset >= ctx.g_depth ? (1ull << 40) : offset + (uint64_t)ctx.chars;
+        // The tail: a few thousand elements -- the rests of giant phrases the group kernels left undecided -- used to walk on 21
+        // characters a round, a dozen launches and three round trips to the host each: 148 rounds a batch on a rank's share of
+        // configs[4], ~6 of its 61 s for 0.003 element-rounds per representative.  Their groups are small: once, when the active
+        // set has shrunk to that, every group of up to 1024 is finished by comparison (the giant dictionary answers what is long).
+        if (m && m <= 32768 && !tail_done && offset < (1ull << 40) && !no_tail) {
+            tail_done = true;
+            gk::resolve_small(ctx, X.pos_a.get(), X.ghead.get(), X.slot_a.get(), m, offset, X.pos_b.get(), X.flags.get(), err, st,
+                              std::getenv("MMT_GUIDED_NO_SMALL_LCP") ? nullptr : lcp_out, 1024);
+            prims::select_indices(temp, X.flags.get(), X.idx.get(), X.count.get(), m, st);
+            const uint32_t m3 = read_u32(X.count.get(), st);
+            if (m3 && m3 < m) {
+                gk::round_compact(X.idx.get(), m3, X.slot_a.get(), X.pos_a.get(), X.ghead.get(), X.slot_b.get(), X.pos_c.get(),
+                                  X.hv.get(), st);
+                prims::inclusive_max_u32(temp, X.hv.get(), X.ghead.get(), m3, st);
+                X.slot_a.swap(X.slot_b); X.pos_a.swap(X.pos_c);
+            }
+            m = m3;
+        }
     }
     return rs;
 }

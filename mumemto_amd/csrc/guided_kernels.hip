@@ -1151,13 +1151,13 @@ constexpr uint32_t SMALL = 8;
 __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const uint32_t* __restrict__ ghead,
                                 const uint32_t* __restrict__ slot, uint32_t m, uint64_t offset,
                                 uint64_t* __restrict__ out, uint8_t* __restrict__ flags, uint32_t* __restrict__ err,
-                                uint32_t* __restrict__ lcp_out) {
+                                uint32_t* __restrict__ lcp_out, uint32_t limit) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m) return;
     const uint32_t g0 = ghead[e];
     uint32_t end = e + 1;
-    while (end < m && end - g0 <= SMALL && ghead[end] == g0) end++;
-    if (end - g0 > SMALL) { flags[e] = 1; return; }
+    while (end < m && end - g0 <= limit && ghead[end] == g0) end++;
+    if (end - g0 > limit) { flags[e] = 1; return; }
     const uint64_t rec = pos[e], q = rec_pos(c, rec);
     if (end - g0 == 2 && c.rec_rank) {
         // a pair (two haplotypes): every load of the common case is issued before anything depends on one -- both
@@ -1233,8 +1233,9 @@ __global__ void k_resolve_small(Ctx c, const uint64_t* __restrict__ pos, const u
     flags[e] = 0;
 }
 void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
-                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s, uint32_t* lcp_out) {
-    hipLaunchKernelGGL(k_resolve_small, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, slot, m, offset, out, flags, err, lcp_out);
+                   uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s, uint32_t* lcp_out, uint32_t limit) {
+    hipLaunchKernelGGL(k_resolve_small, dim3(grid_for(m, 256)), dim3(256), 0, s, c, pos, ghead, slot, m, offset, out, flags, err, lcp_out,
+                       limit ? limit : SMALL);
     MMT_HIP(hipGetLastError());
 }
 

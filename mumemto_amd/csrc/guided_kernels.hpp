@@ -126,7 +126,8 @@ void giant_probe(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, uint3
 // groups of at most 8 elements, finished by direct comparison (their sorted records go to `out` at the group's slots)
 void resolve_small(const Ctx& c, const uint64_t* pos, const uint32_t* ghead, const uint32_t* slot, uint32_t m, uint64_t offset,
                    uint64_t* out, uint8_t* flags, uint32_t* err, hipStream_t s,
-                   uint32_t* lcp_out = nullptr);   // (lcp_out, optional, by output slot: the LCP of a member with the member before it)
+                   uint32_t* lcp_out = nullptr, uint32_t limit = 0);   // (lcp_out, optional, by output slot: the LCP of a member with the
+                   // member before it; limit: the largest group finished here, 0 = the eight of the first step)
 // groups of 9 .. 128 elements, in four size classes (<= 16, 32, 64, 128): list = 4 regions of `cap` (first element, size)
 // pairs (uint2), count4 = 4 counters; then 4 / 2 / 1 / 1 groups per wave; flags must be preset to 1 (elements of larger
 // groups keep it); lcp_out (optional, indexed by slot): the LCP of every member but the first with the member before it

@@ -48,6 +48,43 @@ def test_realistic_content_equals_the_oracle(producer):
         eng.close()
 
 
+@pytest.mark.parametrize("env", [dict(), dict(MMT_GIANT_PROMOTE="0"), dict(MMT_GUIDED_NO_EARLY_GIANT="1"),
+                                 dict(MMT_GUIDED_NO_TAIL="1", MMT_GUIDED_NO_SMALL_LCP="1", MMT_GUIDED_NO_ROUND_LCP="1"),
+                                 dict(MMT_GUIDED_NO_DENSE="1", MMT_PACKED_TEXT="1"), dict(MMT_PACKED_TEXT="1")])
+def test_giant_phrases_through_expansion_equal_the_oracle(env):
+    """Round 6's routes through the giant dictionary, at a size the oracle sorts: with the giant depth at two key lengths (42
+    characters) every microsatellite, satellite stretch and gap of the realistic haplotypes lies in giant phrases, so that groups take
+    their order from the giant dictionary EARLY (k_giant_probe: all members in its phrases), the dictionary holds the NEIGHBOURS of giant
+    occurrences (build_giant, MMT_GIANT_PROMOTE), the keys of a giant round are entries whose LCPs k_round_heads reads off the
+    dictionary's LCP array, k_resolve_small leaves LCPs, the tail of the rounds is finished by comparison -- each with its old path
+    beside it (the variables), on bytes and on packed text (plain tiles read as 2-bit words).  Stream, rows and thresholds."""
+    import mumemto_amd
+    docs = _docs(7, 300_000, 0.002, 33, indel_rate=2e-4, inversion_every=3)
+    eng = mumemto_amd.Engine(0)
+    os.environ.update(MMT_GUIDED_BATCH="120000", MMT_GIANT_DEPTH="2", **env)
+    try:
+        eng.set_producer("expand", 10, 30)
+        text, _ = O.build_text(docs, True)
+        sa, lcp, bwt = O.build_stream(text)
+        for kw in (dict(merge_metadata=True), dict(num_distinct=6, max_doc_freq=3, max_total_freq=21)):
+            eng.set_docs(docs)
+            eng.run(**kw)
+            assert eng.producer_used() == "guided" and eng.producer_expanded()
+            okw = dict(kw)
+            merge = okw.pop("merge_metadata", False)
+            want = O.run(docs, merge=merge, **okw)
+            assert eng.output_text() == want.text(), (env, kw)
+            if merge:
+                assert np.array_equal(eng.thresholds(), want.thresh())
+        assert np.array_equal(eng.sa().astype(np.int64), sa[1:])
+        assert np.array_equal(eng.lcp().astype(np.int64), lcp[1:])
+        assert np.array_equal(eng.bwt(), bwt[1:])
+    finally:
+        for k in ["MMT_GUIDED_BATCH", "MMT_GIANT_DEPTH"] + list(env):
+            os.environ.pop(k, None)
+        eng.close()
+
+
 @pytest.mark.parametrize("haps,length", [(12, 30_000), (40, 9_000), (130, 3_000)])
 def test_bucket_wise_producer_on_many_copies_equals_the_oracle(haps, length):
     """Groups of 9 .. 128 copies of a position are finished by one wave per group (guided_kernels.hip k_resolve_medium),

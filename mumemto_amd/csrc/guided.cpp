@@ -1002,7 +1002,9 @@ void Engine::guided_stream_expand(ScanState& SS, const mmt_params& p) {
     // Several batches per pass over the text (gk::stage_fill, as in the plain producer): a batch of representatives is a pass over
     // the WHOLE text, and a rank's share of configs[4] -- 573 G characters, 64 batches -- spent 64 of its 88 s of batches there.
     // Part of the memory becomes a list of the representatives of the next batches' bins (8 bytes each), filled by one pass.
-    staged = share_rep > 2 * rep_cap && (double)n * ((double)share_rep / (double)std::max<uint64_t>(rep_cap, 1)) >= 2e13;
+    // (1e12 since the entries are four bytes, 2e13 before: a rank's share of configs[3] -- 79 G characters, 15 - 30 batches -- gains a
+    // second of its 14, and three of 29 with realistic content: 4 and 14 passes over the text instead of 15 and 36)
+    staged = share_rep > 2 * rep_cap && (double)n * ((double)share_rep / (double)std::max<uint64_t>(rep_cap, 1)) >= 1e12;
     if (const char* c = std::getenv("MMT_GUIDED_STAGE")) staged = std::atoi(c) != 0;
     else if (std::getenv("MMT_GUIDED_BATCH")) staged = share_rep > 2 * rep_cap;      // (tests: every run of several batches)
     stage_cap = 0;

@@ -589,6 +589,15 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     occ_flag.release();
     S.gi_bits.ensure(((size_t)m + 31) / 32 + 1);
     gk::giant_bits(flags.get(), m, S.gi_bits.get(), st);
+    {
+        // rank directory over those bits: giant occurrences before phrase 32 j (gk::giant_entry)
+        const uint32_t nw = (uint32_t)(((size_t)m + 31) / 32);
+        DevBuf<uint32_t> pc;
+        pc.ensure(nw + 1); S.gi_rank.ensure(nw + 1);
+        gk::popcount_words(S.gi_bits.get(), nw, pc.get(), st);
+        prims::exclusive_sum_u32(d_temp_, pc.get(), S.gi_rank.get(), nw, st);
+        MMT_HIP(hipStreamSynchronize(st));
+    }
     DevBuf<uint32_t> occ_idx;
     occ_idx.ensure(m);
     prims::select_indices_u32flags(d_temp_, flags.get(), occ_idx.get(), count.get(), m, st);
@@ -601,7 +610,7 @@ void Engine::build_giant(const std::vector<uint64_t>& hist) {
     MMT_HIP(hipStreamSynchronize(st));
     S.gi_occ = nO; S.gi_distinct = nG; S.gi_chars = nd;
     ctx.g_k = S.gi_k.get(); ctx.g_ps = S.gi_ps.get(); ctx.g_base = S.gi_base.get(); ctx.g_n = nO;
-    ctx.g_isa = S.gi_isa.get(); ctx.g_grp = S.gi_grp.get(); ctx.g_bits = S.gi_bits.get();
+    ctx.g_isa = S.gi_isa.get(); ctx.g_grp = S.gi_grp.get(); ctx.g_bits = S.gi_bits.get(); ctx.g_rank = S.gi_rank.get();
     ctx.g_rmq.sl = S.gi_lcp.get(); ctx.g_rmq.bmin = S.gi_bmin.get(); ctx.g_rmq.m = nd; ctx.g_rmq.nb = S.gi_nb;
     if (std::getenv("MMT_GUIDED_STATS"))
         std::fprintf(stderr, "[guided] %u giant distinct phrases (%u characters, sorted in %d rounds), %u occurrences in the parse\n",

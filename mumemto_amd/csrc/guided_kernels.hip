@@ -192,10 +192,12 @@ __device__ __forceinline__ uint64_t make_rec(const Ctx& c, uint64_t q) {
 __device__ __forceinline__ bool giant_entry(const Ctx& c, uint64_t q, uint64_t off, uint32_t& r) {
     if (!c.g_n) return false;
     const uint32_t k = rank1(c, query_point(c, q));
-    if (!((c.g_bits[k >> 5] >> (k & 31)) & 1u)) return false;
-    uint32_t lo = 0, hi = c.g_n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (c.g_k[mid] < k) lo = mid + 1; else hi = mid; }
-    if (lo >= c.g_n || c.g_k[lo] != k) return false;
+    const uint32_t word = c.g_bits[k >> 5];
+    if (!((word >> (k & 31)) & 1u)) return false;
+    // (its place among the giant occurrences: a rank on the bits -- the binary search over the list of occurrences was twenty
+    // dependent loads per lookup, and a comparison of two suffixes inside giant phrases asks twice)
+    const uint32_t lo = c.g_rank[k >> 5] + (uint32_t)__popc(word & ((1u << (k & 31)) - 1u));
+    if (lo >= c.g_n) return false;
     r = c.g_isa[(uint64_t)c.g_base[lo] + (q + off - c.g_ps[lo])];
     return true;
 }
@@ -1964,6 +1966,14 @@ __global__ void k_giant_bits(const uint32_t* __restrict__ flags, uint32_t m, uin
     uint32_t word = 0;
     for (uint32_t t = 0; t < 32 && (uint64_t)i * 32 + t < m; t++) word |= (flags[(uint64_t)i * 32 + t] ? 1u : 0u) << t;
     bits[i] = word;
+}
+__global__ void k_popcount_words(const uint32_t* __restrict__ bits, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)__popc(bits[i]);
+}
+void popcount_words(const uint32_t* bits, uint32_t n, uint32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_popcount_words, dim3(grid_for(n, 256)), dim3(256), 0, s, bits, n, out);
+    MMT_HIP(hipGetLastError());
 }
 void giant_bits(const uint32_t* flags, uint32_t m, uint32_t* bits, hipStream_t s) {
     hipLaunchKernelGGL(k_giant_bits, dim3(grid_for(((uint64_t)m + 31) / 32, 256)), dim3(256), 0, s, flags, m, bits);

@@ -54,6 +54,7 @@ struct Ctx {
     const uint32_t* g_k = nullptr; const uint64_t* g_ps = nullptr; const uint32_t* g_base = nullptr; uint32_t g_n = 0;
     const uint32_t* g_isa = nullptr; const uint32_t* g_grp = nullptr; RmqView g_rmq; uint32_t g_depth = 0;
     const uint32_t* g_bits = nullptr;                        // bit k: phrase k of the parse is a giant occurrence
+    const uint32_t* g_rank = nullptr;                        // giant occurrences before phrase 32 j (one entry per word of g_bits)
     // Expansion (guided.cpp): bit k <=> phrase k is the representative occurrence of its distinct phrase; the text-order
     // kernels (bin_hist, batch_count, batch_fill) then see only the suffixes that start in such an occurrence.  nullptr: all.
     const uint32_t* repbits = nullptr;
@@ -163,6 +164,7 @@ void giant_distinct(const uint32_t* gids, uint32_t n, const uint32_t* rep, const
                     hipStream_t s);
 // bits[k / 32] bit k % 32 = flags[k] != 0
 void giant_bits(const uint32_t* flags, uint32_t m, uint32_t* bits, hipStream_t s);
+void popcount_words(const uint32_t* bits, uint32_t n, uint32_t* out, hipStream_t s);                        // out[i] = popcount(bits[i])
 void giant_map(const uint32_t* gids, const uint32_t* gstart, uint32_t n, uint32_t* dmap, hipStream_t s);
 void giant_occurrences(const uint32_t* gk, uint32_t n, const uint32_t* pid, const void* pstart, bool wide, const uint32_t* dmap,
                        uint64_t* gps, uint32_t* gbase, hipStream_t s);

@@ -71,7 +71,7 @@ struct PfpState {
     uint8_t g_code[256] = {0};
     bool g_share_valid = false;
     // giant phrases of the bucket-wise producer (guided.cpp::build_giant; gk::Ctx::g_*)
-    DevBuf<uint32_t> gi_k, gi_base, gi_isa, gi_grp, gi_lcp, gi_bmin, gi_bits;
+    DevBuf<uint32_t> gi_k, gi_base, gi_isa, gi_grp, gi_lcp, gi_bmin, gi_bits, gi_rank;
     DevBuf<uint64_t> gi_ps;
     uint32_t gi_occ = 0, gi_distinct = 0, gi_chars = 0, gi_nb = 0, gi_levels = 0;
 };
